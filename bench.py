@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the KDE hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): ProductKDE.slogl, fp64, N_train = 1e6, N_test = 1e5, d = 8,
+diagonal ("product") bandwidth from the normal reference rule, synthetic correlated Gaussian table
+(SURVEY.md §8d).  A *step* is one full slogl(test) on an already fitted model with train and test tables
+resident in HBM: pack the queries -> fused pairwise/logsumexp sweep -> finish/reduce -> one scalar.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Multi-GPU (weak scaling): the fitted training set is replicated on every GPU, each rank owns its own
+N_test test rows (independent units = test rows); there is no data-path collective — the
+only exchange is one all-reduce of the K per-step partial sums at the end of the timed region.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = kde_sweep,
+timed with HIP events on the library's own stream) and `cpu_baseline` (the oracle's restatement of the
+reference algorithm on the host cores, bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D = 8
+FLOPS_PER_PAIR = 3 * D + 2          # d sub + d fma(2) + exp(1) + add(1)
+FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector == matrix peak (AMD CDNA4 spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_tables(torch, device, n_train, n_test, seed_train, seed_test, dtype):
+    """Column-major (d x n contiguous) correlated Gaussian tables, generated on the GPU."""
+    mix = torch.tril(torch.full((D, D), 0.3, dtype=torch.float64, device=device), -1) + torch.eye(D, dtype=torch.float64, device=device)
+
+    def gen(n, seed):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        z = torch.randn((D, n), generator=g, device=device, dtype=torch.float64)
+        return (mix @ z).to(dtype).contiguous()  # row c = column c of the table
+
+    return gen(n_train, seed_train), gen(n_test, seed_test)
+
+
+def cpu_baseline(train_np, test_np, h, budget_s=12.0):
+    """Oracle (port of the reference algorithm, kde/ProductKDE.hpp:240-293) on all host cores, bounded sample."""
+    from oracle import oracle
+
+    cores = oracle.num_threads()
+    probe = max(cores, 8)
+    t0 = time.perf_counter()
+    oracle.product_kde_logl(train_np, h, test_np[:probe])
+    dt = time.perf_counter() - t0
+    rows = int(min(test_np.shape[0], max(probe, probe * budget_s / max(dt, 1e-3))))
+    rows = max(cores, rows // cores * cores)
+    t0 = time.perf_counter()
+    oracle.product_kde_logl(train_np, h, test_np[:rows])
+    dt = time.perf_counter() - t0
+    return {
+        "value": rows / dt / 1e6,
+        "unit": "M-samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{rows} test rows x {train_np.shape[0]} training rows, d={D}, fp64, {dt:.1f}s wall, OpenMP over test rows",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-train", type=int, default=1_000_000)
+    ap.add_argument("--n-test", type=int, default=100_000)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--kde", default="product", choices=["product", "full"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import pybnesian_amd as pbn
+    from pybnesian_amd import _lib
+
+    ctx = pbn.Context(local_rank)
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+    pdtype = _lib.PBN_F64 if args.dtype == "f64" else _lib.PBN_F32
+    names = [f"v{i}" for i in range(D)]
+    # same training set on every rank (seed 0); rank-specific test rows (seed 1 + rank)
+    train_t, test_t = make_tables(torch, device, args.n_train, args.n_test, 0, 1 + rank, tdtype)
+    torch.cuda.synchronize()
+    train = pbn.DeviceTable.from_device_pointer(ctx, train_t.data_ptr(), args.n_train, names, args.n_train, pdtype, keepalive=train_t)
+    test = pbn.DeviceTable.from_device_pointer(ctx, test_t.data_ptr(), args.n_test, names, args.n_test, pdtype, keepalive=test_t)
+
+    kde = (pbn.ProductKDE if args.kde == "product" else pbn.KDE)(names)
+    kde.fit_table(train)  # bandwidth (device Gram) + whitening/packing: not part of a slogl step
+    partial = torch.zeros(args.steps + args.warmup, dtype=torch.float64, device=device)
+
+    def step(i):
+        kde.slogl_table_async(test, partial.data_ptr() + 8 * i)
+
+    def sync_all():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ctx.sync()
+    if dist is not None:
+        dist.all_reduce(partial)  # the only exchange: K scalars
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    sweep_ms, sweep_n = ctx.kernel_time(_lib.PBN_K_SWEEP)
+    pack_ms, _ = ctx.kernel_time(_lib.PBN_K_PACK)
+    fin_ms, _ = ctx.kernel_time(_lib.PBN_K_FINISH)
+    ctx.set_profiling(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_samples = args.n_test * world * args.steps
+    value = total_samples / elapsed / 1e6
+    slogl = float(partial[args.warmup].item())
+
+    if rank == 0:
+        es = 8 if args.dtype == "f64" else 4
+        pairs = float(args.n_train) * float(args.n_test)
+        sweep_s = sweep_ms / max(sweep_n, 1) * 1e-3
+        alg_bytes = (args.n_train * D + args.n_test * D + args.n_test) * es
+        achieved_tf = pairs * FLOPS_PER_PAIR / sweep_s / 1e12
+        out = {
+            "metric": "KDE slogl M-samples/s",
+            "value": value,
+            "unit": "M-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {'ProductKDE' if args.kde == 'product' else 'KDE'}.slogl {args.dtype}, N_train={args.n_train}, "
+                            f"N_test={args.n_test} per GPU, d={D}, normal-reference {'diagonal' if args.kde == 'product' else 'full'} bandwidth",
+                "parallelism": f"test rows sharded over {world} GPU(s), training set replicated",
+                "pairs_per_step_per_gpu": pairs,
+                "slogl_step0_rank_sum": slogl,
+            },
+            "roofline": {
+                "kernel": "kde_sweep_kernel",
+                "bound": "mfma",
+                "achieved": achieved_tf,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                "traffic": None,
+                "note": "compute-bound sweep (SURVEY.md §8d): algorithmic flops = (3d+2) per train/test pair (exp counted as 1) "
+                        "against the FP64 vector==matrix peak; sweep launch duration from HIP events on the library stream",
+                "avg_launch_ms": sweep_s * 1e3,
+                "gpairs_per_s": pairs / sweep_s / 1e9,
+                "hbm_algorithmic_bytes": alg_bytes,
+                "hbm_achieved_GBs": alg_bytes / sweep_s / 1e9,
+                "hbm_frac_of_8TBs": alg_bytes / sweep_s / 1e9 / HBM_PEAK_GBS,
+                "pack_ms": pack_ms / max(sweep_n, 1),
+                "finish_ms": fin_ms / max(sweep_n, 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            h = np.asarray(kde.bandwidth, dtype=np.float64)
+            sample_rows = min(args.n_test, 4096)
+            train_np = train_t.T.cpu().numpy().astype(np.float64)
+            test_np = test_t[:, :sample_rows].T.cpu().numpy().astype(np.float64)
+            out["cpu_baseline"] = cpu_baseline(train_np, test_np, h)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

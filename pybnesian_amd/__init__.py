@@ -1,0 +1,14 @@
+"""pybnesian_amd — MI355X (gfx950) implementation of PyBNesian's KDE/CKDE log-likelihood and
+LinearGaussian/BIC/BGe/CV-likelihood scoring hot path, behind the reference's own class names.
+
+Only the hot path of SURVEY.md §8 lives here.  Everything numerical runs in libpbn_hip.so (hand-written
+HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
+"""
+from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
+from .dataset import Context, DeviceTable, default_context  # noqa: F401
+from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
+
+__all__ = [
+    "KDE", "ProductKDE", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
+    "SingularCovarianceData", "Context", "DeviceTable", "default_context", "load_library",
+]

@@ -1,0 +1,99 @@
+"""ctypes binding of libpbn_hip.so (the C ABI in include/pbn_hip.h).
+
+There is deliberately no CPU fallback: if the shared library is missing, or no MI355X is visible when a
+device context is requested, the call raises.  Error codes map onto the exception classes the reference
+raises for this path: ValueError, SingularCovarianceData(ValueError), RuntimeError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbn_hip.so")
+
+PBN_OK, PBN_ERR_INVALID, PBN_ERR_SINGULAR, PBN_ERR_DEVICE = 0, 1, 2, 3
+PBN_F64, PBN_F32 = 0, 1
+PBN_BW_FULL, PBN_BW_DIAG = 0, 1
+PBN_SEL_NORMAL_REFERENCE, PBN_SEL_SCOTT = 0, 1
+
+
+class SingularCovarianceData(ValueError):
+    """pybnesian.SingularCovarianceData (pybindings_kde.cpp:114): a ValueError subclass."""
+
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol declared in include/pbn_hip.h
+SIGNATURES = {
+    "pbn_last_error": (C.c_char_p, []),
+    "pbn_version": (C.c_char_p, []),
+    "pbn_ctx_create": (_int, [_int, C.POINTER(_vp)]),
+    "pbn_ctx_destroy": (None, [_vp]),
+    "pbn_ctx_sync": (_int, [_vp]),
+    "pbn_ctx_stream": (_vp, [_vp]),
+    "pbn_ctx_set_profiling": (_int, [_vp, _int]),
+    "pbn_ctx_kernel_time": (_int, [_vp, _int, _dp, C.POINTER(_i64)]),
+    "pbn_table_create": (_int, [_vp, C.POINTER(_vp), _int, _i64, _int, _vp, _i64, C.POINTER(_vp)]),
+    "pbn_table_from_device": (_int, [_vp, _vp, _i64, _int, _i64, _int, C.POINTER(_vp)]),
+    "pbn_table_destroy": (None, [_vp]),
+    "pbn_table_rows": (_i64, [_vp]),
+    "pbn_table_cols": (_int, [_vp]),
+    "pbn_table_take": (_int, [_vp, _vp, _i64, C.POINTER(_vp)]),
+    "pbn_table_read": (_int, [_vp, _ip, _int, _vp]),
+    "pbn_table_sse": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
+    "pbn_bandwidth": (_int, [_int, _int, _dp, _int, _i64, _int, _dp]),
+    "pbn_kde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _int, C.POINTER(_vp)]),
+    "pbn_ckde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, C.POINTER(_vp)]),
+    "pbn_kde_destroy": (None, [_vp]),
+    "pbn_kde_num_instances": (_i64, [_vp]),
+    "pbn_kde_lognorm": (C.c_double, [_vp, _int]),
+    "pbn_kde_logl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
+    "pbn_kde_logl_dev": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
+    "pbn_kde_slogl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
+    "pbn_kde_slogl_async": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpbn_hip.so and declare the prototypes.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  pybnesian_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == PBN_OK:
+        return
+    msg = load().pbn_last_error().decode("utf-8", "replace")
+    if status == PBN_ERR_SINGULAR:
+        raise SingularCovarianceData(msg)
+    if status == PBN_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def int_array(values):
+    arr = (C.c_int * len(values))(*[int(v) for v in values])
+    return arr
+
+
+def dptr(a):
+    """double* view of a C-contiguous float64 numpy array."""
+    return a.ctypes.data_as(_dp)

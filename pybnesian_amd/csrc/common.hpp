@@ -1,0 +1,153 @@
+// Shared host-side plumbing for libpbn_hip (MI355X / gfx950 only).
+//
+// Error convention (mirrors the reference's exception classes, see
+// SURVEY.md §8b "Error conventions"):
+//   PBN_OK                 success
+//   PBN_ERR_INVALID        std::invalid_argument  -> Python ValueError
+//   PBN_ERR_SINGULAR       util::singular_covariance_data -> SingularCovarianceData
+//   PBN_ERR_DEVICE         HIP failure            -> RuntimeError
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pbn_hip.h"
+
+namespace pbn {
+
+struct invalid_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct singular_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct device_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string& s);
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+        throw device_error(buf);
+    }
+}
+#define HIP_CHECK(x) ::pbn::hip_check((x), #x, __FILE__, __LINE__)
+
+// Translate C++ exceptions into status codes at the C-ABI boundary.
+template <typename F>
+int guarded(F&& f) noexcept {
+    try {
+        f();
+        return PBN_OK;
+    } catch (const invalid_error& e) {
+        set_last_error(e.what());
+        return PBN_ERR_INVALID;
+    } catch (const singular_error& e) {
+        set_last_error(e.what());
+        return PBN_ERR_SINGULAR;
+    } catch (const device_error& e) {
+        set_last_error(e.what());
+        return PBN_ERR_DEVICE;
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory");
+        return PBN_ERR_DEVICE;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return PBN_ERR_INVALID;
+    }
+}
+
+// RAII device buffer bound to a device; freed with hipFree.
+template <typename T>
+struct dev_buf {
+    T* p = nullptr;
+    size_t n = 0;
+    dev_buf() = default;
+    explicit dev_buf(size_t count) { alloc(count); }
+    dev_buf(const dev_buf&) = delete;
+    dev_buf& operator=(const dev_buf&) = delete;
+    dev_buf(dev_buf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    dev_buf& operator=(dev_buf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p; n = o.n; o.p = nullptr; o.n = 0;
+        }
+        return *this;
+    }
+    ~dev_buf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    // grow-only scratch
+    void reserve(size_t count) {
+        if (count > n) alloc(count);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+};
+
+inline size_t dtype_size(int dtype) { return dtype == PBN_F32 ? 4 : 8; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace pbn
+
+// ---- handle definitions (opaque in the C header) ---------------------------------------------
+
+struct pbn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // scratch reused across calls (grow-only)
+    pbn::dev_buf<char> scratch_part;
+    pbn::dev_buf<char> scratch_q;
+    pbn::dev_buf<char> scratch_misc;
+    pbn::dev_buf<double> scratch_red;
+    // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
+    bool profiling = false;
+    struct Timed { hipEvent_t e0, e1; int which; };
+    std::vector<Timed> pending;
+    double kernel_ms[PBN_NUM_KERNEL_CLASSES] = {0};
+    int64_t kernel_launches[PBN_NUM_KERNEL_CLASSES] = {0};
+};
+
+namespace pbn {
+// RAII: brackets the launches issued during its lifetime with two events when profiling is on.
+struct KernelTimer {
+    pbn_ctx* ctx; int which; hipEvent_t e0 = nullptr;
+    KernelTimer(pbn_ctx* c, int w) : ctx(c), which(w) {
+        if (ctx->profiling) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
+    }
+    ~KernelTimer() {
+        if (e0) {
+            hipEvent_t e1;
+            if (hipEventCreate(&e1) == hipSuccess && hipEventRecord(e1, ctx->stream) == hipSuccess)
+                ctx->pending.push_back({e0, e1, which});
+        }
+    }
+};
+}  // namespace pbn
+
+// Column-major device table: column c lives at base + c*ld elements.
+struct pbn_table {
+    pbn_ctx* ctx = nullptr;
+    int dtype = PBN_F64;
+    int n_cols = 0;
+    int64_t n_rows = 0;
+    int64_t ld = 0;          // elements between consecutive columns
+    void* data = nullptr;    // device
+    bool owns = false;
+    const void* col(int c) const { return (const char*)data + (size_t)c * ld * pbn::dtype_size(dtype); }
+};

@@ -1,0 +1,439 @@
+// KDE / ProductKDE / CKDE log-likelihood sweep for gfx950 (MI355X).
+//
+// Replaces the reference's tile-of-64 OpenCL pipeline
+//   substract -> solve -> square -> logl_values_mat_* -> max_mat_cols -> logsumexp_coeffs ->
+//   sum_mat_cols -> finish_lse_offset -> sum1d
+// (/root/reference/pybnesian/kde/KDE.hpp:592-640, kde/opencl_kernels/KDE.cl.src:115-233,
+//  opencl/opencl_config.hpp:517-536) with three kernels:
+//
+//   pack_rows     z = sqrt(log2 e) * L^-1 (x - mu)  (whiten + centre + scale to base-2 units), written
+//                 in MFMA 16x16x4 operand-fragment order together with -1/2 |z|^2.  After this
+//                 s2(t,q) = log2(e) * (-1/2 |L^-1 (x_t - y_q)|^2) = z_t . z_q - 1/2|z_t|^2 - 1/2|z_q|^2,
+//                 so the per-pair triangular solve of KDE.cl.src:123-135 disappears.
+//   kde_sweep     each wave owns QG groups of 16 query rows (B fragments live in registers) and
+//                 streams 16-row training tiles (A fragments, coalesced 512 B loads).  The
+//                 dot products run on the matrix pipe (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32)
+//                 with the accumulator pre-loaded with  -1/2|z_t|^2 - 1/2|z_q|^2 - m_q ; the VALU only
+//                 evaluates 2^x and the running sum.  Online logsumexp: m_q is a per-query offset
+//                 that is raised (rarely, wave-uniform slow path) when a term would overflow.
+//                 No N x 64 tile is ever materialised.
+//                 CKDE (COND=true): evidence-first Cholesky makes the marginal's whitened coordinates a
+//                 prefix of the joint's, so ONE sweep yields both logsumexps: the joint accumulator is
+//                 the marginal accumulator plus one extra augmented MFMA k-step.
+//   kde_finish    merge the per-split (m, sum) partials in fixed order, add the log-normalisation,
+//                 write logl and/or a deterministic tree-reduced slogl.
+#include "common.hpp"
+#include "kde_kernels.hpp"
+
+namespace pbn {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// 2^r on [-1/2, 1/2], degree-9 interpolant at Chebyshev nodes (max rel. error 1.85e-14, fitted with
+// mpmath at 50 digits; see DESIGN.md "exp2").
+#define PBN_C0 0x1.000000000003dp+0
+#define PBN_C1 0x1.62e42fefa39f7p-1
+#define PBN_C2 0x1.ebfbdff8149f2p-3
+#define PBN_C3 0x1.c6b08d7044119p-5
+#define PBN_C4 0x1.3b2ab72b175eep-7
+#define PBN_C5 0x1.5d87fe908f88ap-10
+#define PBN_C6 0x1.43088e257f341p-13
+#define PBN_C7 0x1.ffcb76789860fp-17
+#define PBN_C8 0x1.63ef969a64d3cp-20
+#define PBN_C9 0x1.b6571de2f2351p-24
+
+__device__ __forceinline__ double exp2_f64(double x) {
+    // x <= ~1000 (larger values are caught by the overflow check of the caller), any negative value.
+    double nf = __builtin_rint(x);  // v_rndne_f64
+    double r = x - nf;              // exact
+    double p = PBN_C9;
+    p = __builtin_fma(p, r, PBN_C8);
+    p = __builtin_fma(p, r, PBN_C7);
+    p = __builtin_fma(p, r, PBN_C6);
+    p = __builtin_fma(p, r, PBN_C5);
+    p = __builtin_fma(p, r, PBN_C4);
+    p = __builtin_fma(p, r, PBN_C3);
+    p = __builtin_fma(p, r, PBN_C2);
+    p = __builtin_fma(p, r, PBN_C1);
+    p = __builtin_fma(p, r, PBN_C0);
+    int n;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(nf));  // saturating: -1e30 -> INT_MIN -> ldexp gives 0
+    return __builtin_ldexp(p, n);                      // v_ldexp_f64
+}
+
+template <typename T>
+struct Tr;
+template <>
+struct Tr<double> {
+    using vec4 = d4;
+    static __device__ __forceinline__ vec4 mfma(double a, double b, vec4 c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ double ex2(double x) { return exp2_f64(x); }
+    static __device__ __forceinline__ double big() { return 0x1p900; }
+    // C/D row held by (lane group lg, register i): cdna_hip_programming.md §3 "f64 MFMA"
+    static __host__ __device__ __forceinline__ int crow(int lg, int i) { return lg + 4 * i; }
+};
+template <>
+struct Tr<float> {
+    using vec4 = f4;
+    static __device__ __forceinline__ vec4 mfma(float a, float b, vec4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+    static __device__ __forceinline__ float big() { return 0x1p100f; }
+    static __host__ __device__ __forceinline__ int crow(int lg, int i) { return 4 * lg + i; }
+};
+
+#define PBN_PAD_NORM (-1e30)
+
+// ------------------------------------------------------------------------------------------------
+// pack_rows: one thread per (padded) row.
+//   main components c < dm   -> pack[(tile*KS + c/4)*64 + (c%4)*16 + idx]   (A and B fragment order
+//                               coincide: element [idx = lane&15][k = lane>>4])
+//   norm  -1/2 sum_{c<dm} z^2 -> npack: training side in C-row order [tile][lg][i], query side [tile][idx]
+//   extra component (CKDE)   -> xpack[tile*64 + k*16 + idx]:
+//        training: k0 z_e, k1 -1/2 z_e^2, k2 1, k3 0      query: k0 z_e, k1 1, k2 -1/2 z_e^2, k3 0
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t npad = a.ntiles * 16;
+    if (r >= npad) return;
+    const int64_t tile = r >> 4;
+    const int idx = (int)(r & 15);
+    const int d = a.d, dm = a.dm, KS = a.KS;
+    T* pack = (T*)a.pack;
+    T* npack = (T*)a.npack;
+    T* xpack = (T*)a.xpack;
+    const bool valid = r < a.n;
+
+    double xc[PBN_MAX_D];
+    if (valid) {
+        const int64_t src = a.rows ? (int64_t)a.rows[r] : a.row0 + r;
+        for (int j = 0; j < d; ++j) {
+            const T* col = (const T*)a.base + (int64_t)a.cols[j] * a.ld;
+            xc[j] = (double)col[src] - a.mu[j];
+        }
+    }
+    double nrm = 0.0;
+    for (int i = 0; i < KS * 4; ++i) {
+        double z = 0.0;
+        if (valid && i < dm) {
+            const double* w = a.W + (size_t)i * d;
+            for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
+        }
+        const T zt = (T)z;
+        // the norm is taken from the ROUNDED coordinate so that s2(t,t) == 0 up to one rounding
+        nrm = __builtin_fma((double)zt, (double)zt, nrm);
+        pack[(tile * KS + (i >> 2)) * 64 + (i & 3) * 16 + idx] = zt;
+    }
+    double nv = -0.5 * nrm;
+    if (!valid) nv = a.is_query ? 0.0 : PBN_PAD_NORM;
+    if (a.is_query) {
+        npack[tile * 16 + idx] = (T)nv;
+    } else {
+        // idx -> (lg, i) with crow(lg, i) == idx
+        int lg, i;
+        if (sizeof(T) == 8) { lg = idx & 3; i = idx >> 2; } else { lg = idx >> 2; i = idx & 3; }
+        npack[tile * 16 + lg * 4 + i] = (T)nv;
+    }
+    if (xpack) {
+        double z = 0.0;
+        if (valid) {
+            const double* w = a.W + (size_t)dm * d;
+            for (int j = 0; j <= dm; ++j) z = __builtin_fma(w[j], xc[j], z);
+        }
+        const T zt = (T)z;
+        const T hn = (T)(-0.5 * (double)zt * (double)zt);
+        T* xp = xpack + tile * 64 + idx;
+        xp[0] = zt;
+        if (a.is_query) { xp[16] = (T)1; xp[32] = hn; } else { xp[16] = hn; xp[32] = (T)1; }
+        xp[48] = (T)0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kde_sweep
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T max4(typename Tr<T>::vec4 v) {
+    T a = v[0] > v[1] ? v[0] : v[1];
+    T b = v[2] > v[3] ? v[2] : v[3];
+    return a > b ? a : b;
+}
+template <typename T>
+__device__ __forceinline__ T colmax(T v) {  // max over the 4 lanes (lane>>4 = 0..3) that share a query column
+    T o = __shfl_xor(v, 16);
+    v = v > o ? v : o;
+    o = __shfl_xor(v, 32);
+    return v > o ? v : o;
+}
+
+template <typename T, int KS, bool COND, int QG>
+__global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
+    using V = typename Tr<T>::vec4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lg = lane >> 4;
+    const int64_t qt0 = ((int64_t)blockIdx.x * 4 + wave) * QG;
+    if (qt0 >= a.nqtiles) return;  // no barriers in this kernel: idle waves just leave
+    const int split = blockIdx.y;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+
+    const T* __restrict__ Ap = (const T*)a.Apack;
+    const T* __restrict__ Np = (const T*)a.nxpack;
+    const T* __restrict__ Xp = (const T*)a.Axpack;
+    const T* __restrict__ Bp = (const T*)a.Bpack;
+    const T* __restrict__ NYp = (const T*)a.nypack;
+    const T* __restrict__ BXp = (const T*)a.Bxpack;
+
+    // ---- query-side fragments and per-query state -------------------------------------------
+    T b[QG][KS];
+    T ny[QG], cm[QG], m[QG];
+    double sum[QG];
+    T bxb[QG], bx[QG], mj[QG];  // CKDE: extra-step B fragment (base / current), joint offset
+    double sumj[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bp[(qt * KS + ks) * 64 + lane];
+        ny[g] = NYp[qt * 16 + (lane & 15)];
+        sum[g] = 0.0;
+        if (COND) { bxb[g] = BXp[qt * 64 + lane]; sumj[g] = 0.0; }
+    }
+
+    // ---- prologue: offsets from the first tile (max of s2 over its 16 rows) ---------------------
+    {
+        T af[KS];
+        V nx;
+        T ax = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t0 * KS + ks) * 64 + lane];
+        nx = *(const V*)(Np + t0 * 16 + lg * 4);
+        if (COND) ax = Xp[t0 * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            V acc = nx + ny[g];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+            T mx = colmax<T>(max4<T>(acc));
+            m[g] = mx;
+            cm[g] = ny[g] - mx;
+            if (COND) {
+                V accj = Tr<T>::mfma(ax, bxb[g], acc);
+                T mxj = colmax<T>(max4<T>(accj));
+                mj[g] = mxj;
+                bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
+            }
+        }
+    }
+
+    // ---- main loop over training tiles --------------------------------------------------------
+    T af[KS];
+    V nx;
+    T ax = 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t0 * KS + ks) * 64 + lane];
+    nx = *(const V*)(Np + t0 * 16 + lg * 4);
+    if (COND) ax = Xp[t0 * 64 + lane];
+
+    for (int64_t t = t0; t < t1; ++t) {
+        // prefetch the next tile's fragments (clamped: the last iteration re-reads its own tile)
+        const int64_t tn = t + 1 < t1 ? t + 1 : t;
+        T afn[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afn[ks] = Ap[(tn * KS + ks) * 64 + lane];
+        V nxn = *(const V*)(Np + tn * 16 + lg * 4);
+        T axn = 0;
+        if (COND) axn = Xp[tn * 64 + lane];
+
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            V acc = nx + cm[g];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+            V accj;
+            if (COND) accj = Tr<T>::mfma(ax, bx[g], acc);
+
+            T e0 = Tr<T>::ex2(acc[0]), e1 = Tr<T>::ex2(acc[1]), e2 = Tr<T>::ex2(acc[2]), e3 = Tr<T>::ex2(acc[3]);
+            T ts = (e0 + e1) + (e2 + e3);
+            T tsj = 0;
+            bool bad = !(ts < Tr<T>::big());
+            if (COND) {
+                T j0 = Tr<T>::ex2(accj[0]), j1 = Tr<T>::ex2(accj[1]), j2 = Tr<T>::ex2(accj[2]), j3 = Tr<T>::ex2(accj[3]);
+                tsj = (j0 + j1) + (j2 + j3);
+                bad = bad || !(tsj < Tr<T>::big());
+            }
+            if (__builtin_expect(__any(bad), 0)) {
+                // Rare wave-uniform slow path: raise the offsets to the tile maximum and redo the tile.
+                T mx = colmax<T>(max4<T>(acc));
+                if (mx > (T)0) {
+                    m[g] += mx;
+                    cm[g] = ny[g] - m[g];
+                    sum[g] *= exp2(-(double)mx);
+                    acc -= mx;
+                }
+                e0 = Tr<T>::ex2(acc[0]); e1 = Tr<T>::ex2(acc[1]); e2 = Tr<T>::ex2(acc[2]); e3 = Tr<T>::ex2(acc[3]);
+                ts = (e0 + e1) + (e2 + e3);
+                if (COND) {
+                    T mxj = colmax<T>(max4<T>(accj));
+                    if (mxj > (T)0) {
+                        mj[g] += mxj;
+                        sumj[g] *= exp2(-(double)mxj);
+                        accj -= mxj;
+                    }
+                    bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
+                    T j0 = Tr<T>::ex2(accj[0]), j1 = Tr<T>::ex2(accj[1]), j2 = Tr<T>::ex2(accj[2]), j3 = Tr<T>::ex2(accj[3]);
+                    tsj = (j0 + j1) + (j2 + j3);
+                }
+            }
+            sum[g] += (double)ts;
+            if (COND) sumj[g] += (double)tsj;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = afn[ks];
+        nx = nxn;
+        ax = axn;
+    }
+
+    // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
+    double* part = a.part;
+    constexpr int P = COND ? 4 : 2;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        double s = sum[g];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        double sj = 0.0;
+        if (COND) {
+            sj = sumj[g];
+            sj += __shfl_xor(sj, 16);
+            sj += __shfl_xor(sj, 32);
+        }
+        if (lg == 0 && qt0 + g < a.nqtiles) {
+            double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
+            o[0] = (double)m[g];
+            o[1] = s;
+            if (COND) { o[2] = (double)mj[g]; o[3] = sj; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kde_finish: per query merge the split partials (fixed order), logl = lognorm + ln2*(m + log2 sum)
+// [CKDE: joint - marginal], optional logl store, deterministic block tree sum.
+// ------------------------------------------------------------------------------------------------
+template <bool COND>
+__global__ __launch_bounds__(256) void kde_finish_kernel(FinishArgs a) {
+    constexpr int P = COND ? 4 : 2;
+    constexpr double LN2 = 0.693147180559945309417232121458;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double val = 0.0;
+    if (q < a.nq) {
+        const double* p = a.part + q * P;
+        const int64_t stride = a.nqtiles * 16 * P;
+        double m = p[0], s = p[1];
+        double mjj = 0, sj = 0;
+        if (COND) { mjj = p[2]; sj = p[3]; }
+        for (int sp = 1; sp < a.nsplit; ++sp) {
+            const double* pp = p + sp * stride;
+            double m2 = pp[0], s2 = pp[1];
+            double M = m > m2 ? m : m2;
+            s = s * exp2(m - M) + s2 * exp2(m2 - M);
+            m = M;
+            if (COND) {
+                double m3 = pp[2], s3 = pp[3];
+                double MJ = mjj > m3 ? mjj : m3;
+                sj = sj * exp2(mjj - MJ) + s3 * exp2(m3 - MJ);
+                mjj = MJ;
+            }
+        }
+        double l = a.lognorm + LN2 * (m + log2(s));
+        if (COND) l = (a.lognorm + LN2 * (mjj + log2(sj))) - (a.lognorm_marg + LN2 * (m + log2(s)));
+        if (a.logl) a.logl[q] = l;
+        val = l;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = val;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.block_sums) a.block_sums[blockIdx.x] = red[0];
+}
+
+// Final fixed-order reduction of the per-block sums (replaces the multi-pass sum1d of
+// opencl_config.hpp:344-397 with one launch).
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ in, int64_t n, double* out) {
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) v += in[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
+    const int64_t npad = a.ntiles * 16;
+    if (npad == 0) return;
+    dim3 grid((unsigned)ceil_div(npad, 256)), block(256);
+    if (dtype == PBN_F64)
+        hipLaunchKernelGGL(pack_rows_kernel<double>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <typename T, bool COND>
+static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
+    constexpr int QG = PBN_SWEEP_QG;
+    dim3 block(256);
+    switch (KS) {
+        case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG>), grid, block, 0, st, a); break;
+        default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * PBN_SWEEP_QG), (unsigned)nsplit);
+    if (dtype == PBN_F64) {
+        if (cond) launch_sweep_t<double, true>(a, KS, grid, st); else launch_sweep_t<double, false>(a, KS, grid, st);
+    } else {
+        if (cond) launch_sweep_t<float, true>(a, KS, grid, st); else launch_sweep_t<float, false>(a, KS, grid, st);
+    }
+}
+
+void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st) {
+    const int64_t nblocks = ceil_div(a.nq, 256);
+    if (nblocks == 0) return;
+    dim3 grid((unsigned)nblocks), block(256);
+    if (cond)
+        hipLaunchKernelGGL(kde_finish_kernel<true>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(kde_finish_kernel<false>, grid, block, 0, st, a);
+    HIP_CHECK(hipGetLastError());
+    if (dev_sum_out) {
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const double*)a.block_sums, nblocks, dev_sum_out);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+}  // namespace pbn

@@ -1,0 +1,216 @@
+// Column statistics on gfx950: pilot-shifted centred Gram (sum of cross products) + column sums in ONE
+// pass over the rows, on the f64 matrix pipe (v_mfma_f64_16x16x4_f64).
+//
+// Replaces DataFrame::means / cov / sse of the reference (/root/reference/pybnesian/dataset/
+// dataset.hpp:208-234, 340-512), which centre a copy of every column and then run d(d+1)/2
+// length-N dot products on one CPU thread.  Consumers: bandwidth selectors
+// (kde/NormalReferenceRule.hpp:72-134), MLE<LinearGaussianCPD> (learning/parameters/
+// mle_LinearGaussianCPD.hpp:11-193, via the normal equations), BGe's cached SSE (learning/scores/
+// bge.hpp:52-72).
+//
+// Layout: the table is column-major (Arrow columns).  For a 16-row chunk a lane (c = lane&15,
+// kq = lane>>4) reads rows 4kq..4kq+3 of column 16*I + c; k-step j of the chunk multiplies, for every
+// column-tile pair I <= J, A[i][k] = x[row 4k+j][col 16I+i] with B[k][jj] = x[row 4k+j][col 16J+jj].
+// Row order inside the contraction is irrelevant, so no transpose through LDS is needed.
+// Numerics: values are shifted by a per-column pilot mean (mean of the first <=1024 rows) before the
+// products, so  SSE = G_shift - S S^T / N  has no catastrophic cancellation (S = shifted column sums).
+#include "common.hpp"
+#include "stats_kernels.hpp"
+
+namespace pbn {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(256) void pilot_mean_kernel(const void* base, int64_t ld, GramCols gc, int n_cols,
+                                                          int64_t row0, const int32_t* rows, int64_t n,
+                                                          double* shift) {
+    const int c = blockIdx.x;
+    if (c >= n_cols) return;
+    const T* col = (const T*)base + (int64_t)gc.cols[c] * ld;
+    const int64_t m = n < 1024 ? n : 1024;
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 256) v += (double)col[rows ? (int64_t)rows[i] : row0 + i];
+    __shared__ double red[256];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) shift[c] = m > 0 ? red[0] / (double)m : 0.0;
+}
+
+template <int NCT>
+struct NPairs {
+    static constexpr int value = NCT * (NCT + 1) / 2;
+};
+
+// partial layout per block: [NP][256] tile accumulators (lane-major: element lane*4 + reg), then [NCT*16] sums
+template <typename T, int NCT, bool GATHER>
+__global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
+    constexpr int NP = NPairs<NCT>::value;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+
+    const int64_t rb0 = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t rb1 = rb0 + a.rows_per_block;
+    if (rb1 > a.n) rb1 = a.n;
+
+    const T* colp[NCT];
+    double sh[NCT];
+    bool cvalid[NCT];
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) {
+        const int ci = I * 16 + c;
+        cvalid[I] = ci < a.n_cols;
+        const int src = cvalid[I] ? a.gc.cols[ci] : a.gc.cols[0];
+        colp[I] = (const T*)a.base + (int64_t)src * a.ld + (GATHER ? 0 : a.row0);
+        sh[I] = cvalid[I] ? a.shift[ci] : 0.0;
+    }
+
+    d4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0, 0, 0, 0};
+    double csum[NCT];
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) csum[I] = 0.0;
+
+    for (int64_t r = rb0 + wave * 16; r < rb1; r += 64) {
+        double x[NCT][4];
+        const int64_t rl = r + 4 * kq;
+        int64_t src[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool rv = rl + j < rb1;
+            src[j] = rv ? (GATHER ? (int64_t)a.rows[rl + j] : rl + j) : -1;
+        }
+#pragma unroll
+        for (int I = 0; I < NCT; ++I) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = src[j] >= 0 && cvalid[I];
+                x[I][j] = ok ? (double)colp[I][src[j]] - sh[I] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NCT; ++I) csum[I] += (x[I][0] + x[I][1]) + (x[I][2] + x[I][3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int p = 0;
+#pragma unroll
+            for (int I = 0; I < NCT; ++I)
+#pragma unroll
+                for (int J = I; J < NCT; ++J) {
+                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[I][j], x[J][j], acc[p], 0, 0, 0);
+                    ++p;
+                }
+        }
+    }
+
+    // ---- block combine (fixed wave order) -------------------------------------------------------
+    // one LDS image, waves add into it in wave order 0,1,2,3 (deterministic)
+    __shared__ double lds[NP * 256 + NCT * 16];
+    constexpr int WS = NP * 256 + NCT * 16;
+    double cs[NCT];
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) {
+        double s = csum[I];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[I] = s;
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = p * 256 + i * 64 + lane;
+                    lds[e] = (w == 0) ? acc[p][i] : lds[e] + acc[p][i];
+                }
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int I = 0; I < NCT; ++I) {
+                    const int e = NP * 256 + I * 16 + c;
+                    lds[e] = (w == 0) ? cs[I] : lds[e] + cs[I];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    for (int e = threadIdx.x; e < WS; e += 256) out[e] = lds[e];
+}
+
+// Sum the block partials in block order (deterministic); one thread per element.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial, int nblocks, int WS,
+                                                           double* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= WS) return;
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += partial[(int64_t)b * WS + e];
+    out[e] = v;
+}
+
+template <typename T, bool GATHER>
+static void launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st) {
+    dim3 grid(nblocks), block(256);
+    switch (nct) {
+        case 1: hipLaunchKernelGGL((gram_kernel<T, 1, GATHER>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((gram_kernel<T, 2, GATHER>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gram_kernel<T, 3, GATHER>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((gram_kernel<T, 4, GATHER>), grid, block, 0, st, a); break;
+        default: throw invalid_error("gram: at most 64 columns per launch");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+int gram_ws(int nct) { return nct * (nct + 1) / 2 * 256 + nct * 16; }
+
+void launch_pilot(const void* base, int64_t ld, const GramCols& gc, int n_cols, int64_t row0, const int32_t* rows,
+                  int64_t n, int dtype, double* shift, hipStream_t st) {
+    if (dtype == PBN_F64)
+        hipLaunchKernelGGL(pilot_mean_kernel<double>, dim3(n_cols), dim3(256), 0, st, base, ld, gc, n_cols, row0, rows, n, shift);
+    else
+        hipLaunchKernelGGL(pilot_mean_kernel<float>, dim3(n_cols), dim3(256), 0, st, base, ld, gc, n_cols, row0, rows, n, shift);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_gram(const GramArgs& a, int dtype, int nblocks, double* out, hipStream_t st) {
+    const int nct = (a.n_cols + 15) / 16;
+    const int WS = gram_ws(nct);
+    const bool gather = a.rows != nullptr;
+    if (dtype == PBN_F64) {
+        if (gather) launch_gram_t<double, true>(a, nct, nblocks, st); else launch_gram_t<double, false>(a, nct, nblocks, st);
+    } else {
+        if (gather) launch_gram_t<float, true>(a, nct, nblocks, st); else launch_gram_t<float, false>(a, nct, nblocks, st);
+    }
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((WS + 255) / 256), dim3(256), 0, st, (const double*)a.partial, nblocks, WS, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---- row gather (arrow::compute::Take, dataset.hpp:2072-2075) -------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void take_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,
+                                                   int64_t ld_dst, const int32_t* __restrict__ rows, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c = blockIdx.y;
+    dst[c * ld_dst + i] = src[c * ld_src + rows[i]];
+}
+
+void launch_take(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* rows, int64_t n,
+                 int n_cols, int dtype, hipStream_t st) {
+    if (n == 0 || n_cols == 0) return;
+    dim3 grid((unsigned)ceil_div(n, 256), (unsigned)n_cols), block(256);
+    if (dtype == PBN_F64)
+        hipLaunchKernelGGL(take_kernel<double>, grid, block, 0, st, (const double*)src, ld_src, (double*)dst, ld_dst, rows, n);
+    else
+        hipLaunchKernelGGL(take_kernel<float>, grid, block, 0, st, (const float*)src, ld_src, (float*)dst, ld_dst, rows, n);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace pbn

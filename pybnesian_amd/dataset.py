@@ -1,0 +1,219 @@
+"""Host-side DataFrame handling + device tables.
+
+Mirrors the part of the reference's `dataset::DataFrame` that the hot path needs
+(/root/reference/pybnesian/dataset/dataset.hpp:1953-2085, dataset.cpp:53-56,208-271): inputs are
+`pyarrow.RecordBatch` or `pandas.DataFrame`; continuous columns must all be float64 or all float32;
+nulls are Arrow validity bits and rows with a null in any requested column are compacted away before
+upload (dataset.hpp:92-106).  The Arrow column buffers are handed to the C ABI as plain pointers.
+"""
+import ctypes as C
+
+import numpy as np
+import pyarrow as pa
+
+from . import _lib
+
+try:  # pandas is optional at import time
+    import pandas as pd
+except Exception:  # pragma: no cover
+    pd = None
+
+
+def as_record_batch(df):
+    if isinstance(df, pa.RecordBatch):
+        return df
+    if isinstance(df, pa.Table):
+        batches = df.combine_chunks().to_batches()
+        if len(batches) != 1:
+            raise ValueError("Expected a single-chunk table.")
+        return batches[0]
+    if pd is not None and isinstance(df, pd.DataFrame):
+        # dataset.cpp:53-56: RecordBatch.from_pandas(df, None, False)
+        return pa.RecordBatch.from_pandas(df, preserve_index=False)
+    if isinstance(df, dict):
+        return pa.RecordBatch.from_pydict({k: pa.array(v) for k, v in df.items()})
+    raise TypeError("Expected a pandas.DataFrame or pyarrow.RecordBatch.")
+
+
+def _column(rb, name):
+    idx = rb.schema.get_field_index(name)
+    if idx < 0:
+        raise KeyError(f"Column {name} not present in DataFrame.")
+    return rb.column(idx)
+
+
+def column_values(arr):
+    """Zero-copy numpy view of a primitive Arrow array's data buffer (nulls hold arbitrary values)."""
+    if pa.types.is_float64(arr.type):
+        dt = np.float64
+    elif pa.types.is_float32(arr.type):
+        dt = np.float32
+    else:
+        raise ValueError("Wrong data type. [double] or [float] data is expected.")
+    buf = arr.buffers()[1]
+    n = len(arr)
+    if n == 0 or buf is None:
+        return np.empty(0, dtype=dt)
+    v = np.frombuffer(buf, dtype=dt, count=arr.offset + n)
+    return v[arr.offset:]
+
+
+def validity_mask(arr):
+    """Boolean numpy mask (True = valid) or None when the array has no nulls."""
+    if arr.null_count == 0:
+        return None
+    buf = arr.buffers()[0]
+    bits = np.unpackbits(np.frombuffer(buf, dtype=np.uint8), bitorder="little")
+    return bits[arr.offset: arr.offset + len(arr)].astype(bool)
+
+
+def same_type(rb, variables):
+    """DataFrame::same_type (dataset.cpp:253-271)."""
+    types = {_column(rb, v).type for v in variables}
+    if len(types) != 1:
+        raise ValueError("All the variables must have the same data type.")
+    t = types.pop()
+    if pa.types.is_float64(t):
+        return _lib.PBN_F64
+    if pa.types.is_float32(t):
+        return _lib.PBN_F32
+    raise ValueError("Wrong data type. [double] or [float] data is expected.")
+
+
+def combined_mask(rb, variables):
+    """AND of the validity bitmaps of `variables` (dataset.cpp:208-235); None if no nulls."""
+    mask = None
+    for v in variables:
+        m = validity_mask(_column(rb, v))
+        if m is not None:
+            mask = m if mask is None else (mask & m)
+    return mask
+
+
+class Context:
+    """One device + one stream; the analogue of the reference's OpenCLConfig singleton
+    (opencl/opencl_config.cpp:149-220), but explicit so that several GPUs can be driven."""
+
+    def __init__(self, device=0):
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.pbn_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def sync(self):
+        _lib.check(_lib.load().pbn_ctx_sync(self.handle))
+
+    @property
+    def stream(self):
+        return _lib.load().pbn_ctx_stream(self.handle)
+
+    def set_profiling(self, on=True):
+        _lib.check(_lib.load().pbn_ctx_set_profiling(self.handle, int(bool(on))))
+
+    def kernel_time(self, kernel_class):
+        """(total_ms, launches) of a kernel class (0 pack, 1 sweep, 2 finish, 3 gram) since profiling was enabled."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        _lib.check(_lib.load().pbn_ctx_kernel_time(self.handle, int(kernel_class), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().pbn_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    import os
+
+    if device is None:
+        device = int(os.environ.get("PBN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class DeviceTable:
+    """Column-major table resident in HBM (pbn_table)."""
+
+    def __init__(self, ctx, handle, names, dtype, keepalive=None):
+        self.ctx = ctx
+        self.handle = handle
+        self.names = list(names)
+        self.dtype = dtype
+        self._keepalive = keepalive
+
+    @classmethod
+    def from_dataframe(cls, ctx, df, variables, drop_null=True):
+        """Upload `variables` of df.  Returns (table, mask) where mask is the boolean validity mask
+        used for compaction (None when there were no nulls)."""
+        rb = as_record_batch(df)
+        variables = list(variables)
+        dtype = same_type(rb, variables)
+        mask = combined_mask(rb, variables) if drop_null else None
+        arrays = [column_values(_column(rb, v)) for v in variables]
+        n = rb.num_rows
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data if a.size else None for a in arrays])
+        bitmap = None
+        bm_ptr = None
+        if mask is not None:
+            bitmap = np.packbits(mask, bitorder="little")
+            bm_ptr = bitmap.ctypes.data
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_table_create(ctx.handle, ptrs, len(arrays), n, dtype, bm_ptr, 0, C.byref(h)))
+        return cls(ctx, h, variables, dtype), mask
+
+    @classmethod
+    def from_device_pointer(cls, ctx, ptr, ld, names, n_rows, dtype, keepalive=None):
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_table_from_device(ctx.handle, C.c_void_p(ptr), ld, len(names), n_rows, dtype, C.byref(h)))
+        return cls(ctx, h, names, dtype, keepalive)
+
+    @property
+    def num_rows(self):
+        return int(_lib.load().pbn_table_rows(self.handle))
+
+    def index(self, names):
+        return [self.names.index(n) for n in names]
+
+    def take(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_table_take(self.handle, rows.ctypes.data, rows.size, C.byref(h)))
+        return DeviceTable(self.ctx, h, self.names, self.dtype)
+
+    def read(self, names=None):
+        names = self.names if names is None else list(names)
+        n = self.num_rows
+        out = np.empty((len(names), n), dtype=np.float64 if self.dtype == _lib.PBN_F64 else np.float32)
+        _lib.check(_lib.load().pbn_table_read(self.handle, _lib.int_array(self.index(names)), len(names), out.ctypes.data))
+        return out.T  # (n, len(names)) column-major view
+
+    def sse(self, names, row0=0, n=None):
+        """(means, sse) over rows [row0, row0+n) of the named columns: DataFrame::means / ::sse."""
+        idx = self.index(names)
+        n = self.num_rows - row0 if n is None else n
+        d = len(idx)
+        means = np.zeros(d)
+        sse = np.zeros((d, d), order="F")
+        _lib.check(_lib.load().pbn_table_sse(self.handle, _lib.int_array(idx), d, row0, n, _lib.dptr(means), _lib.dptr(sse)))
+        return means, sse
+
+    def cov(self, names, row0=0, n=None):
+        n_ = self.num_rows - row0 if n is None else n
+        means, sse = self.sse(names, row0, n)
+        return sse / (n_ - 1)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().pbn_table_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

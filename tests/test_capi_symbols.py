@@ -1,0 +1,46 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/pbn_hip.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "pbn_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(ensure_built):
+    import pybnesian_amd._lib as L
+
+    lib = ctypes.CDLL(L.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in pbn_hip.h but not exported"
+    # and the Python binding table covers exactly the header
+    assert sorted(L.SIGNATURES) == names
+
+
+def test_no_cpu_fallback_without_gpu(ensure_built):
+    """Without a GPU, asking for a context must raise (no silent CPU path)."""
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pybnesian_amd as pbn
+
+    with pytest.raises(RuntimeError):
+        pbn.Context(0)
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "pybnesian_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower().replace("oracle/", ""), f"{f} mentions the oracle"

@@ -1,0 +1,276 @@
+"""GPU tier: KDE / ProductKDE through the Python mirror -> C ABI -> HIP kernels, against
+(1) the golden scipy recipes of the reference tests, (2) the CPU oracle on seeded inputs,
+(3) size-independent properties at larger sizes.  Tolerances: BASELINE.json north_star —
+1e-6 relative for fp64, 1e-3 for fp32 (the reference tests themselves use atol 5e-4 per value for fp32)."""
+import numpy as np
+import pandas as pd
+import pyarrow as pa
+import pytest
+
+from helpers import COLS, RTOL_F32, RTOL_F64, VARSETS, frame, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_kde_bandwidth_golden(pbn, golden, variables):
+    key = "".join(variables)
+    df = frame(golden["train500"])
+    for n in (50, 500):
+        k = pbn.KDE(variables)
+        k.fit(df.iloc[:n])
+        assert np.allclose(k.bandwidth, golden[f"kde_bw_nr_{key}_{n}"], rtol=1e-8)
+        k = pbn.KDE(variables, pbn.ScottsBandwidth())
+        k.fit(df.iloc[:n])
+        assert np.allclose(k.bandwidth, golden[f"kde_bw_scott_{key}_{n}"], rtol=1e-8)
+        k.fit(df.iloc[:n].astype("float32"))
+        assert np.allclose(k.bandwidth, golden[f"kde_bw_scott_{key}_{n}"], rtol=1e-4)
+    for n in (50, 150, 500):
+        k = pbn.ProductKDE(variables)
+        k.fit(df.iloc[:n])
+        assert np.allclose(k.bandwidth, golden[f"pkde_bw_nr_{key}_{n}"], rtol=1e-8)
+        k = pbn.ProductKDE(variables, pbn.ScottsBandwidth())
+        k.fit(df.iloc[:n])
+        assert np.allclose(k.bandwidth, golden[f"pkde_bw_scott_{key}_{n}"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_kde_logl_slogl_golden_f64(pbn, golden, variables):
+    key = "".join(variables)
+    k = pbn.KDE(variables)
+    k.fit(frame(golden["train500"]))
+    test = frame(golden["test50"])
+    want = golden[f"kde_logl_{key}_f64"]
+    got = k.logl(test)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < RTOL_F64
+    assert abs(k.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())
+    assert k.num_instances() == 500 and k.num_variables() == len(variables) and k.fitted()
+    assert k.data_type() == pa.float64()
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_kde_logl_golden_f32(pbn, golden, variables):
+    key = "".join(variables)
+    k = pbn.KDE(variables)
+    k.fit(frame(golden["train500"], "float32"))
+    test = frame(golden["test50"], "float32")
+    want = golden[f"kde_logl_{key}_f32"]
+    got = k.logl(test)
+    assert np.allclose(got, want, atol=5e-4)  # KDE_test.py:181-182
+    assert abs(k.slogl(test) - want.sum()) <= RTOL_F32 * abs(want.sum())
+    assert k.data_type() == pa.float32()
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_product_kde_golden(pbn, golden, variables):
+    key = "".join(variables)
+    k = pbn.ProductKDE(variables)
+    k.fit(frame(golden["train500"]))
+    test = frame(golden["test50"])
+    want = golden[f"pkde_logl_{key}_f64"]
+    assert rel_err(k.logl(test), want) < RTOL_F64
+    assert abs(k.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())
+    k.fit(frame(golden["train500"], "float32"))
+    got32 = k.logl(frame(golden["test50"], "float32"))
+    assert np.allclose(got32, want, atol=5e-3)  # ProductKDE_test.py:222-223
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_kde_logl_null_rows(pbn, golden, variables):
+    key = "".join(variables)
+    k = pbn.KDE(variables)
+    k.fit(frame(golden["train500"]))
+    test = frame(golden["test50_null"])
+    want = golden[f"kde_logl_null_{key}_f64"]
+    got = k.logl(test)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert rel_err(got[ok], want[ok]) < RTOL_F64
+    assert abs(k.slogl(test) - np.nansum(want)) <= RTOL_F64 * abs(np.nansum(want))
+
+
+def test_fit_with_null_rows(pbn, golden, oracle):
+    df = frame(golden["train500"]).copy()
+    rng = np.random.RandomState(0)
+    for c in COLS:
+        df.loc[df.index[rng.randint(0, 500, size=30)], c] = np.nan
+    variables = ["c", "a", "b"]
+    k = pbn.KDE(variables)
+    k.fit(df)
+    clean = df[variables].dropna()
+    assert k.num_instances() == clean.shape[0]
+    cov, _ = oracle.cov(clean.to_numpy())
+    H = oracle.bandwidth(0, 0, cov, clean.shape[0])
+    assert np.allclose(k.bandwidth, H, rtol=1e-9)
+    test = frame(golden["test50"])
+    want = oracle.kde_logl(clean.to_numpy(), H, test[variables].to_numpy())
+    assert rel_err(k.logl(test), want) < RTOL_F64
+
+
+def test_dtype_mismatch_and_unfitted(pbn, golden):
+    df, dff = frame(golden["train500"]), frame(golden["train500"], "float32")
+    k = pbn.KDE(["a"])
+    with pytest.raises(ValueError, match="not fitted"):
+        k.slogl(df)
+    k.fit(df)
+    for fn in (k.logl, k.slogl):
+        with pytest.raises(ValueError, match="Data type of training and test datasets is different."):
+            fn(dff)
+    k.fit(dff)
+    for fn in (k.logl, k.slogl):
+        with pytest.raises(ValueError, match="Data type of training and test datasets is different."):
+            fn(df)
+    with pytest.raises(ValueError):
+        pbn.KDE([])
+
+
+def test_singular_covariance(pbn, golden):
+    df = frame(golden["train500"])
+    with pytest.raises(pbn.SingularCovarianceData):
+        pbn.KDE(["a", "b", "c"]).fit(df.iloc[:3])  # N <= d
+    dup = df.copy()
+    dup["b"] = 2.0 * dup["a"]
+    with pytest.raises(pbn.SingularCovarianceData):
+        pbn.KDE(["a", "b"]).fit(dup)  # not positive definite
+    assert issubclass(pbn.SingularCovarianceData, ValueError)
+
+
+def test_variable_order_invariance(pbn, golden):
+    df, test = frame(golden["train500"]), frame(golden["test50"])
+    k1, k2 = pbn.KDE(["d", "a", "b", "c"]), pbn.KDE(["a", "c", "d", "b"])
+    k1.fit(df)
+    k2.fit(df)
+    assert np.allclose(k1.logl(test), k2.logl(test), rtol=1e-7)
+
+
+def test_set_bandwidth_refits(pbn, golden, oracle):
+    df, test = frame(golden["train500"]), frame(golden["test50"])
+    k = pbn.KDE(["a", "b"])
+    k.fit(df)
+    H = np.array([[0.5, 0.1], [0.1, 2.0]])
+    k.bandwidth = H
+    want = oracle.kde_logl(df[["a", "b"]].to_numpy(), H, test[["a", "b"]].to_numpy())
+    assert rel_err(k.logl(test), want) < RTOL_F64
+    with pytest.raises(ValueError):
+        k.bandwidth = np.eye(3)
+
+
+def test_custom_selector(pbn, golden, oracle):
+    class Fixed(pbn.BandwidthSelector):
+        def bandwidth(self, df, variables):
+            return np.eye(len(variables)) * 0.3
+
+        def diag_bandwidth(self, df, variables):
+            return np.full(len(variables), 0.3)
+
+    df, test = frame(golden["train500"]), frame(golden["test50"])
+    v = ["a", "c"]
+    k = pbn.KDE(v, Fixed())
+    k.fit(df)
+    want = oracle.kde_logl(df[v].to_numpy(), np.eye(2) * 0.3, test[v].to_numpy())
+    assert rel_err(k.logl(test), want) < RTOL_F64
+    p = pbn.ProductKDE(v, Fixed())
+    p.fit(df)
+    assert rel_err(p.logl(test), want) < RTOL_F64
+
+
+@pytest.mark.parametrize("dtype,rtol", [("float64", RTOL_F64), ("float32", RTOL_F32)])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 9, 13])
+def test_oracle_parity_random(pbn, oracle, d, dtype, rtol):
+    """Seeded correlated Gaussian tables; ragged sizes (not multiples of 16) on both sides."""
+    rng = np.random.default_rng(100 + d)
+    n, m = 3001, 257
+    mix = np.tril(rng.uniform(-0.5, 0.5, size=(d, d)), -1) + np.eye(d)
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame((rng.normal(size=(n, d)) @ mix.T) * 3.0 + 10.0, columns=names).astype(dtype)
+    test = pd.DataFrame((rng.normal(size=(m, d)) @ mix.T) * 3.0 + 10.0, columns=names).astype(dtype)
+    for cls, fn in ((pbn.KDE, oracle.kde_logl), (pbn.ProductKDE, oracle.product_kde_logl)):
+        k = cls(names)
+        k.fit(train)
+        # the oracle works in the data dtype like the reference; its f32 path is itself only ~1e-4 accurate,
+        # so the f32 comparison uses the f64 oracle on the f32-rounded data as the truth
+        want = fn(train.to_numpy().astype(np.float64), k.bandwidth, test.to_numpy().astype(np.float64))
+        got = k.logl(test)
+        if dtype == "float64":
+            assert rel_err(got, want) < rtol
+        else:
+            assert np.allclose(got, want, atol=5e-4, rtol=1e-4)
+        assert abs(k.slogl(test) - want.sum()) <= rtol * abs(want.sum())
+
+
+def test_far_queries_trigger_rescale(pbn, oracle):
+    """Queries tens of bandwidths away from every training point, and a training set whose first tile is
+    far from the queries' neighbourhood: exercises the offset (m) raise path and the no-underflow logic."""
+    rng = np.random.default_rng(7)
+    far = rng.normal(loc=500.0, scale=0.01, size=(16, 2))     # first tile: very far cluster
+    near = rng.normal(loc=0.0, scale=1.0, size=(5000, 2))
+    train = pd.DataFrame(np.vstack([far, near]), columns=["x", "y"])
+    q = np.vstack([rng.normal(size=(40, 2)), rng.normal(loc=60.0, size=(10, 2)), rng.normal(loc=-300.0, size=(7, 2))])
+    test = pd.DataFrame(q, columns=["x", "y"])
+    H = np.array([[0.05, 0.01], [0.01, 0.08]])
+    k = pbn.KDE(["x", "y"])
+    k.fit(train)
+    k.bandwidth = H
+    want = oracle.kde_logl(train.to_numpy(), H, test.to_numpy())
+    got = k.logl(test)
+    assert np.all(np.isfinite(got))
+    assert rel_err(got, want) < RTOL_F64
+
+
+def test_tiny_sizes(pbn, oracle):
+    rng = np.random.default_rng(3)
+    train = pd.DataFrame(rng.normal(size=(3, 1)), columns=["x"])
+    test = pd.DataFrame(rng.normal(size=(1, 1)), columns=["x"])
+    k = pbn.KDE(["x"])
+    k.fit(train)
+    want = oracle.kde_logl(train.to_numpy(), k.bandwidth, test.to_numpy())
+    assert rel_err(k.logl(test), want) < RTOL_F64
+    empty = test.iloc[:0]
+    assert k.logl(empty).shape == (0,)
+    assert k.slogl(empty) == 0.0
+
+
+def test_large_properties(pbn):
+    """Size-independent properties at a size the oracle cannot finish quickly (2e5 x 2e4, d=8):
+    slogl == sum(logl); splitting the test rows is additive; duplicating the training set leaves logl
+    unchanged when the bandwidth is held fixed; permuting training rows changes nothing beyond rounding."""
+    rng = np.random.default_rng(11)
+    d, n, m = 8, 200_000, 20_000
+    names = [f"v{i}" for i in range(d)]
+    mix = np.tril(np.full((d, d), 0.3), -1) + np.eye(d)
+    train = pd.DataFrame(rng.normal(size=(n, d)) @ mix.T, columns=names)
+    test = pd.DataFrame(rng.normal(size=(m, d)) @ mix.T, columns=names)
+    k = pbn.ProductKDE(names)
+    k.fit(train)
+    h = k.bandwidth.copy()
+    ll = k.logl(test)
+    s = k.slogl(test)
+    assert np.all(np.isfinite(ll))
+    assert abs(s - ll.sum()) <= 1e-9 * abs(s)
+    s1, s2 = k.slogl(test.iloc[:7777]), k.slogl(test.iloc[7777:])
+    assert abs((s1 + s2) - s) <= 1e-9 * abs(s)
+    perm = rng.permutation(n)
+    k2 = pbn.ProductKDE(names)
+    k2.fit(train.iloc[perm])
+    k2.bandwidth = h
+    assert np.allclose(k2.logl(test.iloc[:2000]), ll[:2000], rtol=1e-9, atol=1e-9)
+    k3 = pbn.ProductKDE(names)
+    k3.fit(pd.concat([train, train], ignore_index=True))
+    k3.bandwidth = h
+    assert np.allclose(k3.logl(test.iloc[:2000]), ll[:2000], rtol=1e-9, atol=1e-9)

@@ -1,0 +1,80 @@
+"""CPU tier: pin the oracle (oracle/pbn_oracle.cpp) against the reference tests' own scipy/numpy recipes
+(tests/golden/reference_recipes.npz, see gen_golden.py for the cited recipes)."""
+import numpy as np
+import pytest
+
+from helpers import CKDE_SETS, COLS, VARSETS, frame
+from oracle import oracle
+
+
+def _sel(arr, variables):
+    return np.asarray(arr)[:, [COLS.index(v) for v in variables]]
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_bandwidths(golden, variables):
+    key = "".join(variables)
+    for n in (50, 500):
+        data = _sel(golden["train500"], variables)[:n]
+        cov, _ = oracle.cov(data)
+        assert np.allclose(oracle.bandwidth(0, 0, cov, n), golden[f"kde_bw_nr_{key}_{n}"], rtol=1e-9)
+        assert np.allclose(oracle.bandwidth(1, 0, cov, n), golden[f"kde_bw_scott_{key}_{n}"], rtol=1e-9)
+    for n in (50, 150, 500):
+        data = _sel(golden["train500"], variables)[:n]
+        cov, _ = oracle.cov(data)
+        assert np.allclose(oracle.bandwidth(0, 1, cov, n), golden[f"pkde_bw_nr_{key}_{n}"], rtol=1e-9)
+        assert np.allclose(oracle.bandwidth(1, 1, cov, n), golden[f"pkde_bw_scott_{key}_{n}"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_kde_logl_f64(golden, variables):
+    key = "".join(variables)
+    tr, te = _sel(golden["train500"], variables), _sel(golden["test50"], variables)
+    H = golden[f"kde_bw_nr_{key}_500"]
+    got = oracle.kde_logl(tr, H, te)
+    assert np.allclose(got, golden[f"kde_logl_{key}_f64"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_kde_logl_f32(golden, variables):
+    # tolerance of the reference test for float32: atol 5e-4 per value (KDE_test.py:181-182)
+    key = "".join(variables)
+    tr = _sel(golden["train500"], variables).astype(np.float32)
+    te = _sel(golden["test50"], variables).astype(np.float32)
+    cov, _ = oracle.cov(tr)
+    H = oracle.bandwidth(0, 0, cov, tr.shape[0])
+    got = oracle.kde_logl(tr, H, te)
+    assert np.allclose(got, golden[f"kde_logl_{key}_f32"], atol=5e-4)
+
+
+@pytest.mark.parametrize("variables", VARSETS)
+def test_product_kde_logl(golden, variables):
+    key = "".join(variables)
+    tr, te = _sel(golden["train500"], variables), _sel(golden["test50"], variables)
+    h = golden[f"pkde_bw_nr_{key}_500"]
+    assert np.allclose(oracle.product_kde_logl(tr, h, te), golden[f"pkde_logl_{key}_f64"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+@pytest.mark.parametrize("tag", ["10k", "10"])
+def test_ckde_logl(golden, variable, evidence, tag):
+    key = variable + "_" + "".join(evidence)
+    tr = _sel(golden["train10k" if tag == "10k" else "train10"], [variable] + evidence)
+    te = _sel(golden["test50"], [variable] + evidence)
+    H = golden[f"ckde_bw_{key}_{tag}"]
+    got = oracle.ckde_logl(tr, H, te)
+    assert np.allclose(got, golden[f"ckde_logl_{key}_{tag}"], rtol=1e-8, atol=1e-9)
+
+
+def test_shuffle_known_answer(golden):
+    assert np.array_equal(oracle.shuffled_indices(12, 0), golden["shuffle12_seed0"])
+
+
+def test_cv_limits():
+    assert list(oracle.cv_limits(103, 10)) == [0, 11, 22, 33, 43, 53, 63, 73, 83, 93, 103]
+    with pytest.raises(ValueError):
+        oracle.cv_limits(5, 1)
+    with pytest.raises(ValueError):
+        oracle.cv_limits(5, 6)
+    assert oracle.holdout_test_rows(10000, 0.2) == 2000
+    assert oracle.holdout_test_rows(13, 0.5) == 7  # std::round half away from zero
