@@ -90,14 +90,16 @@ int pbn_bandwidth(int selector, int kind, const double* cov, int d, int64_t n, i
 
 /* ---- KDE / ProductKDE: replaces KDE::_fit / ProductKDE::_fit (kde/KDE.hpp:451-478,
  * kde/ProductKDE.hpp:153-190).  `bandwidth` is H (d*d col-major) or h (d variances), as chosen by
- * `kind`; the training rows are whitened, centred and packed into MFMA fragment order on device. */
+ * `kind`; the training rows are whitened, centred and packed into MFMA fragment order on device.
+ * `center` (d doubles, nullable) is any offset near the column means (the distances do not depend on
+ * it; it only keeps the whitened coordinates small); NULL lets the library take pilot means. */
 int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
-                const double* bandwidth, int kind, pbn_kde** out);
+                const double* bandwidth, int kind, const double* center, pbn_kde** out);
 /* CKDE: replaces CKDE::_fit (factors/continuous/CKDE.hpp:182-200).  cols[0] is the variable,
  * cols[1..d) the evidence; H is the joint bandwidth in that order (d*d col-major).  d==1 degrades
  * to a plain KDE exactly as CKDE.hpp:232-241 does. */
 int pbn_ckde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
-                 const double* H, pbn_kde** out);
+                 const double* H, const double* center, pbn_kde** out);
 void pbn_kde_destroy(pbn_kde* k);
 int64_t pbn_kde_num_instances(const pbn_kde* k);
 double pbn_kde_lognorm(const pbn_kde* k, int which); /* 0 joint / plain, 1 marginal (CKDE only)      */

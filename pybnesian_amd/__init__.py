@@ -6,9 +6,10 @@ HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
 """
 from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
 from .dataset import Context, DeviceTable, default_context  # noqa: F401
+from .factors import CKDE, Factor  # noqa: F401
 from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
 __all__ = [
-    "KDE", "ProductKDE", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
+    "KDE", "ProductKDE", "CKDE", "Factor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
     "SingularCovarianceData", "Context", "DeviceTable", "default_context", "load_library",
 ]

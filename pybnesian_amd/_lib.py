@@ -14,6 +14,7 @@ PBN_OK, PBN_ERR_INVALID, PBN_ERR_SINGULAR, PBN_ERR_DEVICE = 0, 1, 2, 3
 PBN_F64, PBN_F32 = 0, 1
 PBN_BW_FULL, PBN_BW_DIAG = 0, 1
 PBN_SEL_NORMAL_REFERENCE, PBN_SEL_SCOTT = 0, 1
+PBN_K_PACK, PBN_K_SWEEP, PBN_K_FINISH, PBN_K_GRAM = 0, 1, 2, 3
 
 
 class SingularCovarianceData(ValueError):
@@ -45,8 +46,8 @@ SIGNATURES = {
     "pbn_table_read": (_int, [_vp, _ip, _int, _vp]),
     "pbn_table_sse": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
     "pbn_bandwidth": (_int, [_int, _int, _dp, _int, _i64, _int, _dp]),
-    "pbn_kde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _int, C.POINTER(_vp)]),
-    "pbn_ckde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, C.POINTER(_vp)]),
+    "pbn_kde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _int, _dp, C.POINTER(_vp)]),
+    "pbn_ckde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _dp, C.POINTER(_vp)]),
     "pbn_kde_destroy": (None, [_vp]),
     "pbn_kde_num_instances": (_i64, [_vp]),
     "pbn_kde_lognorm": (C.c_double, [_vp, _int]),

@@ -31,7 +31,7 @@ struct pbn_kde {
     double lognorm = 0.0, lognorm_marg = 0.0;
     std::vector<int> perm;  // position in the caller's column list -> whitening order
     dev_buf<char> Apack, nxpack, Axpack;
-    dev_buf<double> W, mu;
+    std::vector<double> W, mu;  // whitening matrix (d x d row-major lower) and centring offsets, whitening order
 };
 
 extern "C" {
@@ -341,12 +341,13 @@ static void fill_pack_common(PackArgs& pa, const pbn_table* t, const int* cols, 
                              int dm, int KS, int64_t row0, int64_t n, const pbn_kde* k) {
     pa.base = t->data; pa.ld = t->ld; pa.d = d; pa.dm = dm; pa.KS = KS;
     for (int i = 0; i < d; ++i) pa.cols[i] = cols[perm[i]];
-    pa.row0 = row0; pa.rows = nullptr; pa.n = n; pa.ntiles = ceil_div(n, 16);
-    pa.W = k->W.p; pa.mu = k->mu.p;
+    pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.rows = nullptr; pa.n = n; pa.ntiles = ceil_div(n, 16);
+    for (int i = 0; i < d * d; ++i) pa.W[i] = k->W[i];
+    for (int i = 0; i < d; ++i) pa.mu[i] = k->mu[i];
 }
 
 static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
-                         const double* bw, int kind, bool cond, pbn_kde** out) {
+                         const double* bw, int kind, bool cond, const double* center, pbn_kde** out) {
     if (!ctx || !out || !bw) throw invalid_error("pbn_kde_fit: null argument");
     check_cols(train, cols, d, "pbn_kde_fit");
     check_range(train, row0, n, "pbn_kde_fit");
@@ -396,13 +397,19 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     k->lognorm = -logdet_half - 0.5 * d * LOG_2PI - std::log((double)n);
     k->lognorm_marg = -logdet_half_marg - 0.5 * dm * LOG_2PI - std::log((double)n);
 
-    k->W.alloc((size_t)d * d);
-    k->mu.alloc((size_t)d);
-    HIP_CHECK(hipMemcpyAsync(k->W.p, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    // centring offsets = pilot means (any offset is exact in the distances; it only keeps |z| small)
-    GramCols gc{};
-    for (int i = 0; i < d; ++i) gc.cols[i] = cols[k->perm[i]];
-    launch_pilot(train->data, train->ld, gc, d, row0, nullptr, n, train->dtype, k->mu.p, ctx->stream);
+    k->W = W;
+    k->mu.assign(d, 0.0);
+    if (center) {
+        for (int i = 0; i < d; ++i) k->mu[i] = center[k->perm[i]];
+    } else {
+        // centring offsets = pilot means (any offset is exact in the distances; it only keeps |z| small)
+        GramCols gc{};
+        for (int i = 0; i < d; ++i) gc.cols[i] = cols[k->perm[i]];
+        ctx->scratch_red.reserve(64);
+        launch_pilot(train->data, train->ld, gc, d, row0, nullptr, n, train->dtype, ctx->scratch_red.p, ctx->stream);
+        HIP_CHECK(hipMemcpyAsync(k->mu.data(), ctx->scratch_red.p, d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
 
     const size_t es = dtype_size(train->dtype);
     k->Apack.alloc((size_t)k->ntiles * k->KS * 64 * es);
@@ -412,22 +419,21 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     fill_pack_common(pa, train, cols, k->perm, d, dm, k->KS, row0, n, k.get());
     pa.is_query = 0;
     pa.pack = k->Apack.p; pa.npack = k->nxpack.p; pa.xpack = cond ? k->Axpack.p : nullptr;
-    launch_pack(pa, train->dtype, ctx->stream);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // W (host vector) must outlive the async copy
+    { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, train->dtype, ctx->stream); }
     *out = k.release();
 }
 
 int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
-                const double* bandwidth, int kind, pbn_kde** out) {
+                const double* bandwidth, int kind, const double* center, pbn_kde** out) {
     return guarded([&] {
         if (kind != PBN_BW_FULL && kind != PBN_BW_DIAG) throw invalid_error("pbn_kde_fit: unknown bandwidth kind");
-        kde_fit_impl(ctx, train, cols, d, row0, n, bandwidth, kind, false, out);
+        kde_fit_impl(ctx, train, cols, d, row0, n, bandwidth, kind, false, center, out);
     });
 }
 
 int pbn_ckde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
-                 const double* H, pbn_kde** out) {
-    return guarded([&] { kde_fit_impl(ctx, train, cols, d, row0, n, H, PBN_BW_FULL, true, out); });
+                 const double* H, const double* center, pbn_kde** out) {
+    return guarded([&] { kde_fit_impl(ctx, train, cols, d, row0, n, H, PBN_BW_FULL, true, center, out); });
 }
 
 void pbn_kde_destroy(pbn_kde* k) {
@@ -473,7 +479,7 @@ static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols,
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, k->dtype, ctx->stream); }
 
     // split the training tiles so that the grid is a few waves deep on every CU
-    const int64_t qblocks = ceil_div(nqtiles, 4 * PBN_SWEEP_QG);
+    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(k->dtype, k->cond));
     const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
     int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, k->ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));

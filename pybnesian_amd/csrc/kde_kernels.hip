@@ -25,30 +25,31 @@
 #include "common.hpp"
 #include "kde_kernels.hpp"
 
+#include <cstdlib>
+
 namespace pbn {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// 2^r on [-1/2, 1/2], degree-9 interpolant at Chebyshev nodes (max rel. error 1.85e-14, fitted with
-// mpmath at 50 digits; see DESIGN.md "exp2").
-#define PBN_C0 0x1.000000000003dp+0
-#define PBN_C1 0x1.62e42fefa39f7p-1
-#define PBN_C2 0x1.ebfbdff8149f2p-3
-#define PBN_C3 0x1.c6b08d7044119p-5
-#define PBN_C4 0x1.3b2ab72b175eep-7
-#define PBN_C5 0x1.5d87fe908f88ap-10
-#define PBN_C6 0x1.43088e257f341p-13
-#define PBN_C7 0x1.ffcb76789860fp-17
-#define PBN_C8 0x1.63ef969a64d3cp-20
-#define PBN_C9 0x1.b6571de2f2351p-24
+// 2^r on [-1/2, 1/2]: degree-8 interpolant at Chebyshev nodes, max relative error 1.07e-12 (fitted with
+// mpmath at 50 digits).  The DP units are the binding resource of the fp64 sweep (DESIGN.md "roofline"),
+// every polynomial degree costs 4.4 % of the kernel; 1e-12 per term is six orders below the 1e-6 parity bar.
+#define PBN_C0 0x1.0000000000000p+0
+#define PBN_C1 0x1.62e42fef84cf0p-1
+#define PBN_C2 0x1.ebfbdff823cedp-3
+#define PBN_C3 0x1.c6b08dd6fd234p-5
+#define PBN_C4 0x1.3b2ab7181b755p-7
+#define PBN_C5 0x1.5d8745a728441p-10
+#define PBN_C6 0x1.4308ac85aa947p-13
+#define PBN_C7 0x1.00dc4a532fb8ep-16
+#define PBN_C8 0x1.63d136366db24p-20
 
 __device__ __forceinline__ double exp2_f64(double x) {
     // x <= ~1000 (larger values are caught by the overflow check of the caller), any negative value.
     double nf = __builtin_rint(x);  // v_rndne_f64
     double r = x - nf;              // exact
-    double p = PBN_C9;
-    p = __builtin_fma(p, r, PBN_C8);
+    double p = PBN_C8;
     p = __builtin_fma(p, r, PBN_C7);
     p = __builtin_fma(p, r, PBN_C6);
     p = __builtin_fma(p, r, PBN_C5);
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 
     double xc[PBN_MAX_D];
     if (valid) {
-        const int64_t src = a.rows ? (int64_t)a.rows[r] : a.row0 + r;
+        const int64_t src = a.rows ? (int64_t)a.rows[r] : (r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0));
         for (int j = 0; j < d; ++j) {
             const T* col = (const T*)a.base + (int64_t)a.cols[j] * a.ld;
             xc[j] = (double)col[src] - a.mu[j];
@@ -400,7 +401,7 @@ void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
 
 template <typename T, bool COND>
 static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
-    constexpr int QG = PBN_SWEEP_QG;
+    constexpr int QG = SweepQG<sizeof(T) == 8, COND>::value;
     dim3 block(256);
     switch (KS) {
         case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG>), grid, block, 0, st, a); break;
@@ -412,8 +413,13 @@ static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st
     HIP_CHECK(hipGetLastError());
 }
 
+int sweep_qg(int dtype, bool cond) {
+    if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
+    return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
+}
+
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
-    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * PBN_SWEEP_QG), (unsigned)nsplit);
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond)), (unsigned)nsplit);
     if (dtype == PBN_F64) {
         if (cond) launch_sweep_t<double, true>(a, KS, grid, st); else launch_sweep_t<double, false>(a, KS, grid, st);
     } else {

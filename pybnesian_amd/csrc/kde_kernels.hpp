@@ -5,7 +5,6 @@
 #include <cstdint>
 
 #define PBN_MAX_D 17       // up to 16 whitened "main" dimensions (KS <= 4) + 1 CKDE extra coordinate
-#define PBN_SWEEP_QG 4     // query groups (of 16 rows) per wave
 
 namespace pbn {
 
@@ -17,12 +16,14 @@ struct PackArgs {
     int dm;               // main (marginal) dimensions written to `pack`; d == dm or dm + 1
     int KS;               // ceil(dm / 4)
     int is_query;
-    int64_t row0;         // contiguous source range ... or
-    const int32_t* rows;  // ... device gather list (nullable)
+    // source rows: logical row r maps to  r < n0 ? row0 + r : row1 + (r - n0)   (two contiguous ranges:
+    // a CV training set is "everything before the fold" ++ "everything after it"), or rows[r] if non-null
+    int64_t row0, n0, row1;
+    const int32_t* rows;  // device gather list (nullable)
     int64_t n;            // valid rows
     int64_t ntiles;       // ceil(n / 16)
-    const double* W;      // device, d x d row-major lower-triangular whitening matrix
-    const double* mu;     // device, d centring offsets
+    double W[PBN_MAX_D * PBN_MAX_D];  // d x d row-major lower-triangular whitening matrix (kernel argument)
+    double mu[PBN_MAX_D];             // d centring offsets
     void* pack;           // [ntiles][KS][64]
     void* npack;          // [ntiles][16]
     void* xpack;          // [ntiles][64] or null
@@ -51,6 +52,14 @@ struct FinishArgs {
     double* logl;        // nullable
     double* block_sums;  // nullable
 };
+
+// query groups (of 16 rows) per wave: 4, except the fp64 CKDE sweep (two accumulator + exp sets per group)
+// which keeps 2 to hold 3 waves/SIMD
+template <bool F64, bool COND>
+struct SweepQG {
+    static constexpr int value = (F64 && COND) ? 2 : 4;
+};
+int sweep_qg(int dtype, bool cond);
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);

@@ -1,0 +1,155 @@
+"""Continuous factors of the hot path: CKDE and LinearGaussianCPD — the reference's Python surface
+(/root/reference/pybnesian/pybindings/pybindings_factors.cpp:378-640) on top of the HIP C ABI.
+
+CKDE (factors/continuous/CKDE.hpp:182-287): ratio of KDEs.  The reference runs two sweeps (joint, then
+marginal) and subtracts; here one fused sweep yields both logsumexps (csrc/kde_kernels.hip, COND=true).
+"""
+import ctypes as C
+
+import numpy as np
+import pyarrow as pa
+
+from . import _lib
+from .dataset import DeviceTable, as_record_batch, default_context, same_type
+from .kde import NormalReferenceRule, _LibrarySelector
+
+
+class Factor:
+    """The subset of factors::Factor (factors/factors.hpp:113-189) that the hot path exposes."""
+
+    def __init__(self, variable, evidence):
+        self._variable = variable
+        self._evidence = list(evidence)
+        self._fitted = False
+
+    def variable(self):
+        return self._variable
+
+    def evidence(self):
+        return list(self._evidence)
+
+    def fitted(self):
+        return self._fitted
+
+    def _check_fitted(self, name):
+        if not self._fitted:
+            raise ValueError(f"{name} factor not fitted.")
+
+
+class CKDE(Factor):
+    """Conditional KDE: logl = logl_joint([variable] + evidence) - logl_marg(evidence)."""
+
+    def __init__(self, variable, evidence, bandwidth_selector=None):
+        super().__init__(variable, evidence)
+        self._variables = [variable] + list(evidence)
+        self._selector = bandwidth_selector if bandwidth_selector is not None else NormalReferenceRule()
+        self._handle = None
+        self._train = None
+        self._dtype = None
+        self._bandwidth = None
+        self._N = 0
+
+    def type(self):
+        return "CKDEFactor"
+
+    def data_type(self):
+        self._check_fitted("CKDE")
+        return pa.float64() if self._dtype == _lib.PBN_F64 else pa.float32()
+
+    def num_instances(self):
+        self._check_fitted("CKDE")
+        return self._N
+
+    @property
+    def bandwidth(self):
+        """Joint bandwidth matrix in [variable, evidence...] order (kde_joint().bandwidth)."""
+        return self._bandwidth
+
+    def fit(self, df):
+        rb = as_record_batch(df)
+        dtype = same_type(rb, self._variables)
+        ctx = default_context()
+        table, _ = DeviceTable.from_dataframe(ctx, rb, self._variables)
+        self._fit_table(table, list(range(len(self._variables))), rb)
+
+    def fit_table(self, table):
+        self._fit_table(table, table.index(self._variables), None)
+
+    def _fit_table(self, table, idx, rb):
+        d = len(self._variables)
+        n = table.num_rows
+        names = [table.names[i] for i in idx]
+        sel = self._selector
+        means = None
+        if isinstance(sel, _LibrarySelector):
+            if n <= d:
+                cov = np.eye(d)
+            else:
+                means, sse = table.sse(names)
+                cov = sse / (n - 1)
+            H = sel._from_cov(_lib.PBN_BW_FULL, cov, n, table.dtype)
+        else:
+            if rb is None:
+                raise ValueError("fit_table needs a library bandwidth selector")
+            H = np.asarray(sel.bandwidth(rb, self._variables), dtype=np.float64)
+        H = np.asfortranarray(H, dtype=np.float64)
+        lib = _lib.load()
+        if self._handle is not None:
+            lib.pbn_kde_destroy(self._handle)
+            self._handle = None
+        h = C.c_void_p()
+        cptr = _lib.dptr(np.ascontiguousarray(means)) if means is not None else None
+        _lib.check(lib.pbn_ckde_fit(table.ctx.handle, table.handle, _lib.int_array(idx), d, 0, n, _lib.dptr(H), cptr, C.byref(h)))
+        self._handle, self._train, self._dtype, self._bandwidth, self._N = h, table, table.dtype, H, n
+        self._fitted = True
+
+    def _upload_test(self, df):
+        self._check_fitted("CKDE")
+        rb = as_record_batch(df)
+        dtype = same_type(rb, self._variables)
+        if dtype != self._dtype:
+            raise ValueError("Data type of training and test datasets is different.")
+        table, mask = DeviceTable.from_dataframe(self._train.ctx, rb, self._variables)
+        return rb, table, mask
+
+    def logl(self, df):
+        rb, table, mask = self._upload_test(df)
+        m = table.num_rows
+        vals = np.empty(m, dtype=np.float64)
+        d = len(self._variables)
+        _lib.check(_lib.load().pbn_kde_logl(self._handle, table.handle, _lib.int_array(range(d)), 0, m, _lib.dptr(vals)))
+        if mask is None:
+            return vals
+        out = np.full(rb.num_rows, np.nan)
+        out[mask] = vals
+        return out
+
+    def slogl(self, df):
+        _, table, _ = self._upload_test(df)
+        res = C.c_double(0.0)
+        d = len(self._variables)
+        _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(range(d)), 0, table.num_rows, C.byref(res)))
+        return res.value
+
+    def slogl_table(self, table, row0=0, n=None):
+        self._check_fitted("CKDE")
+        if table.dtype != self._dtype:
+            raise ValueError("Data type of training and test datasets is different.")
+        idx = table.index(self._variables)
+        n = table.num_rows - row0 if n is None else n
+        res = C.c_double(0.0)
+        _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(idx), row0, n, C.byref(res)))
+        return res.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().pbn_kde_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def __str__(self):
+        if self._evidence:
+            return f"[CKDE] P({self._variable} | {', '.join(self._evidence)})"
+        return f"[CKDE] P({self._variable})"

@@ -194,7 +194,7 @@ class _KDEBase:
         d = len(self._variables)
         bw = np.asfortranarray(self._bandwidth, dtype=np.float64)
         _lib.check(lib.pbn_kde_fit(self._train.ctx.handle, self._train.handle, _lib.int_array(self._train_idx), d, 0, self._N,
-                                   _lib.dptr(bw), self._kind, C.byref(h)))
+                                   _lib.dptr(bw), self._kind, None, C.byref(h)))
         self._handle = h
 
     # -- evaluation ------------------------------------------------------------------------------------

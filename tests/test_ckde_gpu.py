@@ -1,0 +1,97 @@
+"""GPU tier: CKDE (fused joint+marginal sweep) against the golden scipy recipes of
+/root/reference/tests/factors/continuous/CKDE_test.py and against the CPU oracle."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import CKDE_SETS, COLS, RTOL_F32, RTOL_F64, frame, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+@pytest.mark.parametrize("tag", ["10k", "10"])
+def test_ckde_golden_f64(pbn, golden, variable, evidence, tag):
+    key = variable + "_" + "".join(evidence)
+    train = frame(golden["train10k" if tag == "10k" else "train10"])
+    test = frame(golden["test50"])
+    cpd = pbn.CKDE(variable, evidence)
+    cpd.fit(train)
+    assert np.allclose(cpd.bandwidth, golden[f"ckde_bw_{key}_{tag}"], rtol=1e-8)
+    want = golden[f"ckde_logl_{key}_{tag}"]
+    got = cpd.logl(test)
+    assert np.allclose(got, want, rtol=RTOL_F64, atol=1e-9)
+    assert abs(cpd.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())
+    assert cpd.num_instances() == train.shape[0]
+    assert cpd.variable() == variable and cpd.evidence() == evidence
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+def test_ckde_golden_f32(pbn, golden, variable, evidence):
+    key = variable + "_" + "".join(evidence)
+    cpd = pbn.CKDE(variable, evidence)
+    cpd.fit(frame(golden["train10k"], "float32"))
+    test = frame(golden["test50"], "float32")
+    want = golden[f"ckde_logl_{key}_10k"]
+    got = cpd.logl(test)
+    assert np.allclose(got, want, atol=5e-4)  # CKDE_test.py:231-232
+    assert abs(cpd.slogl(test) - want.sum()) <= 0.0005 * 10000  # CKDE_test.py:325-327
+
+
+def test_ckde_evidence_order_and_nulls(pbn, golden):
+    train, test = frame(golden["train10k"]), frame(golden["test50"])
+    c1, c2 = pbn.CKDE("d", ["a", "b", "c"]), pbn.CKDE("d", ["c", "b", "a"])
+    c1.fit(train)
+    c2.fit(train)
+    assert np.allclose(c1.logl(test), c2.logl(test), rtol=1e-7)
+    tn = frame(golden["test50_null"])
+    l1, l2 = c1.logl(tn), c2.logl(tn)
+    nulls = np.any(np.isnan(golden["test50_null"]), axis=1)
+    assert np.array_equal(np.isnan(l1), nulls) and np.array_equal(np.isnan(l2), nulls)
+    assert np.allclose(l1[~nulls], l2[~nulls], rtol=1e-7)
+    assert abs(c1.slogl(tn) - np.nansum(l1)) <= 1e-9 * abs(np.nansum(l1))
+
+
+def test_ckde_dtype_mismatch(pbn, golden):
+    cpd = pbn.CKDE("a", ["b"])
+    with pytest.raises(ValueError, match="not fitted"):
+        cpd.slogl(frame(golden["test50"]))
+    cpd.fit(frame(golden["train500"]))
+    with pytest.raises(ValueError, match="Data type of training and test datasets is different."):
+        cpd.logl(frame(golden["test50"], "float32"))
+
+
+@pytest.mark.parametrize("p", [1, 2, 4, 5, 8])
+def test_ckde_oracle_parity_random(pbn, oracle, p):
+    """Seeded non-linear tables, ragged sizes; includes conditional outliers (joint far, marginal near)."""
+    rng = np.random.default_rng(40 + p)
+    n, m = 4099, 301
+    ev = rng.normal(size=(n + m, p)) @ (np.tril(rng.uniform(-0.4, 0.4, size=(p, p)), -1) + np.eye(p)).T
+    y = np.tanh(ev[:, 0]) * 2.0 + 0.3 * ev.sum(axis=1) + rng.normal(scale=0.4, size=n + m)
+    data = np.column_stack([y, ev])
+    names = ["y"] + [f"e{i}" for i in range(p)]
+    train = pd.DataFrame(data[:n], columns=names)
+    test = pd.DataFrame(data[n:], columns=names)
+    test.iloc[:5, 0] += 40.0  # conditional outliers: evidence typical, variable far away
+    cpd = pbn.CKDE("y", names[1:])
+    cpd.fit(train)
+    want = oracle.ckde_logl(train.to_numpy(), cpd.bandwidth, test.to_numpy())
+    got = cpd.logl(test)
+    assert np.all(np.isfinite(got))
+    assert np.allclose(got, want, rtol=RTOL_F64, atol=1e-9)
+    assert abs(cpd.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())

@@ -9,7 +9,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-constexpr int ITER = 4096;
+constexpr int ITER = 32768;
 
 struct OpFma { static __device__ void run(double (&v)[8], double c) {
 #pragma unroll
@@ -112,7 +112,7 @@ int main() {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount; const double clk = 2.4e9;
   printf("device %s, %d CUs, clock %d kHz\n", p.name, cus, p.clockRate);
-  for (int wps = 1; wps <= 2; ++wps) {
+  for (int wps = 1; wps <= 8; wps *= 2) {
     dim3 grid(cus * wps), block(256);
     const double waves_per_simd = wps;  // 4 waves per block, 4 SIMDs per CU
     auto report = [&](const char* name, double ms, double instr_per_wave) {
