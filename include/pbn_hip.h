@@ -116,6 +116,84 @@ int pbn_kde_slogl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t ro
 int pbn_kde_slogl_async(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
                         double* dev_out);
 
+/* ---- score engine ---------------------------------------------------------------------------------
+ * pbn_scoredata replaces the DataFrame held by a Score plus its CrossValidation / HoldOut adaptors
+ * (learning/scores/cv_likelihood.hpp, holdout_likelihood.hpp, validated_likelihood.hpp:14-22;
+ * dataset/crossvalidation_adaptator.hpp:15-58, dataset/holdout_adaptator.hpp:17-61): the table (all
+ * columns continuous, no nulls) is permuted on device into split order with libstdc++
+ * std::shuffle(std::mt19937{seed}) - the reference's exact fold membership - and per-fold moments are
+ * cached.  `table` must outlive the handle. */
+typedef struct pbn_scoredata pbn_scoredata;
+typedef enum {
+    PBN_SPLIT_NONE = 0,     /* BIC, BGe                                   */
+    PBN_SPLIT_CV = 1,       /* CVLikelihood(df, k, seed)                  */
+    PBN_SPLIT_HOLDOUT = 2,  /* HoldoutLikelihood(df, test_ratio, seed)    */
+    PBN_SPLIT_VALIDATED = 3 /* ValidatedLikelihood(df, test_ratio, k, seed) */
+} pbn_split_kind;
+typedef enum {
+    PBN_SCORE_BIC = 0,    /* learning/scores/bic.cpp:12-27                                      */
+    PBN_SCORE_BGE = 1,    /* learning/scores/bge.hpp:154-234; params = iss_mu, iss_w, total_nodes[, nu x n] */
+    PBN_SCORE_CVLIK = 2,  /* learning/scores/cv_likelihood.cpp:11-25                            */
+    PBN_SCORE_HOLDOUT = 3 /* learning/scores/holdout_likelihood.cpp:14-23 (ValidatedScore::vlocal_score) */
+} pbn_score_kind;
+typedef enum { PBN_NODE_LG = 0, PBN_NODE_CKDE = 1 } pbn_node_type; /* LinearGaussianCPDType / CKDEType */
+
+int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
+                         pbn_scoredata** out);
+void pbn_scoredata_destroy(pbn_scoredata* sd);
+/* perm: n_rows ints (source row of every permuted row); limits: k+1 fold limits; all nullable. */
+int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold);
+/* MLE<LinearGaussianCPD>::estimate (learning/parameters/mle_LinearGaussianCPD.hpp:195-221) from the cached
+ * moments of the training region: beta has p+1 entries (intercept first). */
+int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, double* beta, double* variance);
+/* Score::local_score for a batch of candidates (replaces the serial double loop of
+ * learning/operators/operators.cpp:100-132,296-347): candidate c scores column var[c] given
+ * parents[par_off[c] .. par_off[c+1]) with node type node_type[c] (NULL = all LinearGaussian). */
+int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
+                    const int* parents, const double* params, int n_params, double* out);
+
+/* ---- greedy hill-climbing (host logic; replaces learning/algorithms/hillclimbing.hpp:62-199 driving
+ * learning/operators/operators.{hpp,cpp}).  Nodes are 0..n_nodes-1 in model.nodes() order.  Every step's
+ * Score::local_score requests are handed to `score` as ONE batch (same layout as pbn_score_batch);
+ * validated != 0 asks for ValidatedScore::vlocal_score.  The callback returns 0 on success. */
+typedef enum { PBN_BN_GAUSSIAN = 0, PBN_BN_SEMIPARAMETRIC = 1, PBN_BN_KDE = 2 } pbn_bn_type;
+typedef int (*pbn_hc_score_fn)(void* user, int validated, int n_cand, const int* var, const int* node_type,
+                               const int* par_off, const int* parents, double* out);
+typedef struct {
+    int n_nodes;
+    int bn_type;             /* pbn_bn_type                                                              */
+    const int* node_types;   /* n_nodes pbn_node_type of the start model (NULL: LG, or CKDE for PBN_BN_KDE) */
+    int n_arcs;
+    const int* arcs;         /* start model arcs, (source, target) pairs                                 */
+    int n_arc_blacklist;
+    const int* arc_blacklist;
+    int n_arc_whitelist;
+    const int* arc_whitelist;
+    int n_type_blacklist;
+    const int* type_blacklist; /* (node, node_type) pairs                                                */
+    int n_type_whitelist;
+    const int* type_whitelist;
+    int op_arcs;             /* ArcOperatorSet in the pool                                               */
+    int op_node_type;        /* ChangeNodeTypeSet in the pool                                            */
+    int arcs_first;          /* pool order: 1 = [arcs, node_type] (validate_options.cpp default)         */
+    int max_indegree;        /* 0 = unlimited                                                            */
+    int max_iters;
+    double epsilon;
+    int patience;
+    int validated;           /* score is a ValidatedScore                                                */
+} pbn_hc_config;
+typedef struct {
+    int iterations;
+    int64_t cells_scored;      /* delta cells written by cache_scores + update_scores                    */
+    int64_t local_score_evals; /* local_score / vlocal_score evaluations requested                       */
+    int trace_capacity;        /* in: capacity of trace (ops) ; trace = 4 ints per applied operator:     */
+    int* trace;                /*   kind (0 add, 1 remove, 2 flip, 3 change type), source|node, target|type, 0 */
+    double* trace_delta;       /* delta of every applied operator (nullable)                             */
+    int trace_len;
+} pbn_hc_stats;
+int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn score, void* user, int* out_arcs, int* out_n_arcs,
+                    int* out_node_types, pbn_hc_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

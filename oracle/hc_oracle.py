@@ -1,0 +1,319 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Pure-Python, strictly serial restatement of the reference's greedy
+hill-climbing: ArcOperatorSet / ChangeNodeTypeSet / OperatorPool (learning/operators/operators.{hpp,cpp}),
+estimate_hc (learning/algorithms/hillclimbing.hpp:46-199) and the DAG predicates
+(graph/generic_graph.hpp:2711-2745).  One local_score call per cell, exactly where the reference makes it.
+
+`score(var, node_type, parents)` and `vscore(...)` are callables over node indices (node_type: 0 LG, 1 CKDE).
+Returns (arcs, node_types, trace) with trace = [(kind, a, b, delta)], kind 0 add, 1 remove, 2 flip, 3 type.
+"""
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import oracle
+
+MACHINE_TOL = 1.4901161193847656e-08
+LOWEST = -sys.float_info.max
+
+
+class Model:
+    def __init__(self, n, bn_type, node_types=None, arcs=()):
+        self.n, self.bn_type = n, bn_type  # 0 gaussian, 1 semiparametric, 2 kde
+        self.parents = [[] for _ in range(n)]
+        self.children = [[] for _ in range(n)]
+        self.node_type = list(node_types) if node_types is not None else [1 if bn_type == 2 else 0] * n
+        for s, t in arcs:
+            self.add_arc(s, t)
+
+    def clone(self):
+        m = Model(self.n, self.bn_type, self.node_type)
+        m.parents = [list(p) for p in self.parents]
+        m.children = [list(c) for c in self.children]
+        return m
+
+    def has_arc(self, s, t):
+        return s in self.parents[t]
+
+    @staticmethod
+    def swap_remove(v, x):
+        if x in v:
+            i = v.index(x)
+            v[i] = v[-1]
+            v.pop()
+
+    def add_arc(self, s, t):
+        if not self.has_arc(s, t):
+            self.parents[t].append(s)
+            self.children[s].append(t)
+
+    def remove_arc(self, s, t):
+        if self.has_arc(s, t):
+            self.swap_remove(self.parents[t], s)
+            self.swap_remove(self.children[s], t)
+
+    def has_path(self, a, b, skip=None):
+        seen, stack = {a}, [a]
+        while stack:
+            u = stack.pop()
+            for c in self.children[u]:
+                if skip is not None and (u, c) == skip:
+                    continue
+                if c == b:
+                    return True
+                if c not in seen:
+                    seen.add(c)
+                    stack.append(c)
+        return False
+
+    def can_add_arc(self, s, t):
+        return s != t and (not self.parents[s] or not self.children[t] or not self.has_path(t, s))
+
+    def can_flip_arc(self, s, t):
+        if s == t:
+            return False
+        if self.has_arc(s, t):
+            if len(self.parents[t]) == 1 or len(self.children[s]) == 1:
+                return True
+            return not self.has_path(s, t, skip=(s, t))
+        if not self.parents[t] or not self.children[s]:
+            return True
+        return not self.has_path(s, t)
+
+    def alt_type(self, v):
+        return -1 if self.bn_type != 1 else (1 if self.node_type[v] == 0 else 0)
+
+    def apply(self, op):
+        k, a, b, _ = op
+        if k == 0:
+            self.add_arc(a, b)
+        elif k == 1:
+            self.remove_arc(a, b)
+        elif k == 2:
+            self.remove_arc(a, b)
+            self.add_arc(b, a)
+        else:
+            self.node_type[a] = b
+
+
+def _opposite(op):
+    k, a, b, d = op
+    if k == 0:
+        return (1, a, b, -d)
+    if k == 1:
+        return (0, a, b, -d)
+    if k == 2:
+        return (2, b, a, -d)
+    return (3, a, 1 - b, -d)
+
+
+def _same(o1, o2):
+    return o1[:3] == o2[:3]
+
+
+def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_blacklist=(), arc_whitelist=(), type_blacklist=(),
+             type_whitelist=(), op_arcs=True, op_types=False, arcs_first=True, max_indegree=0, max_iters=2 ** 31 - 1,
+             epsilon=0.0, patience=0):
+    m = Model(n, bn_type, node_types, arcs)
+    for v, t in type_whitelist:
+        m.node_type[v] = t
+    for s, t in arc_whitelist:
+        if not m.has_arc(s, t):
+            m.remove_arc(t, s)
+            m.add_arc(s, t)
+    validated = vscore is not None
+    zero_patience = patience == 0
+    type_wl = {v for v, _ in type_whitelist}
+    type_bl = set(type_blacklist)
+
+    def local_of(mod, v):
+        return score(v, mod.node_type[v], list(mod.parents[v]))
+
+    # ---- op-set state -------------------------------------------------------------------------------------
+    delta = np.full(n * n, LOWEST)
+    valid = np.ones(n * n, dtype=bool)
+    for s, t in arc_whitelist:
+        valid[s + t * n] = False
+        valid[t + s * n] = False
+    for s, t in arc_blacklist:
+        valid[s + t * n] = False
+    for i in range(n):
+        valid[i + i * n] = False
+    sorted_idx = np.array([i + j * n for i in range(n) for j in range(n) if valid[i + j * n]], dtype=np.int32)
+    tdelta = [LOWEST] * n
+    thas = [False] * n
+    cells = [0]
+
+    local = [local_of(m, v) for v in range(n)]
+
+    def cache_arcs():
+        for t in range(n):
+            pt = list(m.parents[t])
+            for s in range(n):
+                if not valid[s + t * n]:
+                    continue
+                if m.has_arc(s, t):
+                    Model.swap_remove(pt, s)
+                    d = score(t, m.node_type[t], list(pt)) - local[t]
+                    pt.append(s)
+                elif m.has_arc(t, s):
+                    ps = list(m.parents[s])
+                    Model.swap_remove(ps, t)
+                    pt.append(s)
+                    d = score(s, m.node_type[s], ps) + score(t, m.node_type[t], list(pt)) - local[s] - local[t]
+                    pt.pop()
+                else:
+                    pt.append(s)
+                    d = score(t, m.node_type[t], list(pt)) - local[t]
+                    pt.pop()
+                delta[s + t * n] = d
+                cells[0] += 1
+
+    def update_types(nodes):
+        for v in nodes:
+            if v in type_wl:
+                continue
+            alt = m.alt_type(v)
+            if alt < 0:
+                thas[v] = False
+                continue
+            thas[v] = True
+            if (v, alt) in type_bl:
+                tdelta[v] = LOWEST
+            else:
+                tdelta[v] = score(v, alt, list(m.parents[v])) - local[v]
+                cells[0] += 1
+
+    def update_arcs(t):
+        parents = list(m.parents[t])
+        for s in range(n):
+            if not valid[s + t * n]:
+                continue
+            if m.has_arc(s, t):
+                Model.swap_remove(parents, s)
+                d = score(t, m.node_type[t], list(parents)) - local[t]
+                parents.append(s)
+                delta[s + t * n] = d
+                cells[0] += 1
+                if valid[t + s * n]:
+                    ps = list(m.parents[s]) + [t]
+                    delta[t + s * n] = d + score(s, m.node_type[s], ps) - local[s]
+                    cells[0] += 1
+            elif m.has_arc(t, s):
+                ps = list(m.parents[s])
+                Model.swap_remove(ps, t)
+                parents.append(s)
+                d = score(s, m.node_type[s], ps) + score(t, m.node_type[t], list(parents)) - local[s] - local[t]
+                parents.pop()
+                delta[s + t * n] = d
+                cells[0] += 1
+            else:
+                parents.append(s)
+                d = score(t, m.node_type[t], list(parents)) - local[t]
+                parents.pop()
+                delta[s + t * n] = d
+                cells[0] += 1
+
+    def arcs_find_max(tabu):
+        oracle.lib().oracle_sort_idx_by_delta_desc(sorted_idx.ctypes.data_as(C.c_void_p), C.c_int64(sorted_idx.size),
+                                                   delta.ctypes.data_as(C.c_void_p))
+        for idx in sorted_idx:
+            s, t = int(idx) % n, int(idx) // n
+            d = float(delta[idx])
+            if m.has_arc(s, t):
+                op = (1, s, t, d)
+            elif m.has_arc(t, s) and m.can_flip_arc(t, s):
+                if max_indegree > 0 and len(m.parents[t]) >= max_indegree:
+                    continue
+                op = (2, t, s, d)
+            elif m.can_add_arc(s, t):
+                if max_indegree > 0 and len(m.parents[t]) >= max_indegree:
+                    continue
+                op = (0, s, t, d)
+            else:
+                continue
+            if tabu and any(_same(op, x) for x in tabu):
+                continue
+            return op
+        return None
+
+    def types_find_max(tabu):
+        best, node = LOWEST, -1
+        for i in range(n):
+            if i in type_wl or not thas[i]:
+                continue
+            if tdelta[i] > best:
+                if tabu and any(_same((3, i, m.alt_type(i), 0.0), x) for x in tabu):
+                    continue
+                best, node = tdelta[i], i
+        return (3, node, m.alt_type(node), best) if best > LOWEST else None
+
+    def find_max(tabu):
+        best, bd = None, LOWEST
+        order = [arcs_find_max, types_find_max] if arcs_first else [types_find_max, arcs_find_max]
+        for fn in order:
+            if (fn is arcs_find_max and not op_arcs) or (fn is types_find_max and not op_types):
+                continue
+            op = fn(tabu)
+            if op is not None and op[3] > bd:
+                best, bd = op, op[3]
+        return best
+
+    # ---- estimate_hc ------------------------------------------------------------------------------------------
+    prev = m.clone()
+    best_model, best_is_current = None, True
+    vlocal = [vscore(v, m.node_type[v], list(m.parents[v])) for v in range(n)] if validated else None
+    if arcs_first:
+        if op_arcs:
+            cache_arcs()
+        if op_types:
+            update_types(range(n))
+    else:
+        if op_types:
+            update_types(range(n))
+        if op_arcs:
+            cache_arcs()
+    p, offset, tabu, trace, it = 0, 0.0, [], [], 0
+    while it < max_iters:
+        it += 1
+        op = find_max(None if (zero_patience or not tabu) else tabu)
+        if op is None or (op[3] - epsilon) < MACHINE_TOL:
+            break
+        m.apply(op)
+        changed = [op[1], op[2]] if op[0] == 2 else ([op[1]] if op[0] == 3 else [op[2]])
+        vdelta = op[3]
+        if validated:
+            pv = nv = 0.0
+            for v in changed:
+                pv += vlocal[v]
+                vlocal[v] = vscore(v, m.node_type[v], list(m.parents[v]))
+                nv += vlocal[v]
+            vdelta = nv - pv
+        if vdelta + offset > MACHINE_TOL:
+            if not zero_patience:
+                if p > 0:
+                    best_is_current, p, offset = True, 0, 0.0
+                tabu = []
+        else:
+            if zero_patience:
+                best_model, best_is_current = prev, False
+                break
+            if p == 0:
+                best_model, best_is_current = prev.clone(), False
+            p += 1
+            if p > patience:
+                break
+            offset += vdelta
+            tabu.append(_opposite(op))
+        prev.apply(op)
+        trace.append(op)
+        for v in changed:
+            local[v] = local_of(m, v)
+        if op_arcs:
+            for v in changed:
+                update_arcs(v)
+        if op_types:
+            update_types(changed)
+    res = m if best_is_current else best_model
+    arcs_out = [(s, t) for t in range(n) for s in res.parents[t]]
+    return arcs_out, list(res.node_type), trace, {"iterations": it, "cells_scored": cells[0]}

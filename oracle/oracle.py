@@ -25,6 +25,8 @@ def lib():
             build()
         _lib = C.CDLL(_PATH)
         _lib.oracle_holdout_test_rows.restype = C.c_int64
+        for f in ("oracle_lg_fit_f64", "oracle_lg_fit_f32", "oracle_bic_lg", "oracle_bge_f64"):
+            getattr(_lib, f).restype = C.c_double
     return _lib
 
 
@@ -119,3 +121,98 @@ def cv_limits(n, k):
 
 def holdout_test_rows(n, ratio):
     return int(lib().oracle_holdout_test_rows(C.c_int64(n), C.c_double(ratio)))
+
+
+def _colptrs(data):
+    """(keepalive, void*[d], n, d, is_f32) for an n x d array (column 0 first)."""
+    data = np.asarray(data)
+    f32 = data.dtype == np.float32
+    a = _colmajor(data, np.float32 if f32 else np.float64)
+    n, d = a.shape
+    ptrs = (C.c_void_p * d)(*[a[:, j].ctypes.data for j in range(d)])
+    return a, ptrs, n, d, f32
+
+
+def lg_fit(data):
+    """MLE<LinearGaussianCPD>::estimate; data = [y, x1..xp] columns.  Returns (beta, variance)."""
+    a, ptrs, n, d, f32 = _colptrs(data)
+    beta = np.zeros(d)
+    fn = lib().oracle_lg_fit_f32 if f32 else lib().oracle_lg_fit_f64
+    var = fn(ptrs, C.c_int64(n), d - 1, _dp(beta))
+    return beta, var
+
+
+def lg_logl(data, beta, variance):
+    a, ptrs, n, d, f32 = _colptrs(data)
+    out = np.zeros(n)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    fn = lib().oracle_lg_logl_f32 if f32 else lib().oracle_lg_logl_f64
+    fn(ptrs, C.c_int64(n), d - 1, _dp(beta), C.c_double(variance), _dp(out))
+    return out
+
+
+def bic_lg(data):
+    beta, var = lg_fit(data)
+    n, d = np.asarray(data).shape if np.asarray(data).ndim == 2 else (len(data), 1)
+    return lib().oracle_bic_lg(C.c_int64(n), d - 1, C.c_double(var))
+
+
+def bge(data, total_nodes, iss_mu=1.0, iss_w=None, nu=None):
+    """BGe local score; data = [variable, parents...] fp64 columns; nu defaults to the sample means."""
+    a, ptrs, n, d, f32 = _colptrs(np.asarray(data, dtype=np.float64))
+    if iss_w is None:
+        iss_w = total_nodes + 2
+    nu = a.mean(axis=0) if nu is None else np.asarray(nu, dtype=np.float64)
+    _, means = cov(a)
+    if nu is None:
+        nu = means
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    return lib().oracle_bge_f64(ptrs, C.c_int64(n), d - 1, int(total_nodes), C.c_double(iss_mu), C.c_double(iss_w), _dp(nu))
+
+
+def cv_folds(n, k, seed):
+    """[(train_idx, test_idx)] exactly as CrossValidation::generate_cv_pair (crossvalidation_adaptator.cpp:5-31)."""
+    idx = shuffled_indices(n, seed)
+    lim = cv_limits(n, k)
+    return [(np.concatenate([idx[: lim[f]], idx[lim[f + 1]:]]), idx[lim[f]: lim[f + 1]]) for f in range(k)]
+
+
+def holdout_split(n, ratio, seed):
+    idx = shuffled_indices(n, seed)
+    test_rows = holdout_test_rows(n, ratio)
+    return idx[: n - test_rows], idx[n - test_rows:]
+
+
+def nr_bandwidth(data):
+    c, _ = cov(data)
+    return bandwidth(0, 0, c, np.asarray(data).shape[0])
+
+
+def cv_likelihood(data, node_type, k, seed):
+    """CVLikelihood::local_score (cv_likelihood.cpp:11-25) for columns [variable, parents...]."""
+    data = np.asarray(data)
+    total = 0.0
+    for tr, te in cv_folds(data.shape[0], k, seed):
+        total += _fit_slogl(data[tr], data[te], node_type)
+    return total
+
+
+def holdout_likelihood(data, node_type, ratio, seed):
+    data = np.asarray(data)
+    tr, te = holdout_split(data.shape[0], ratio, seed)
+    return _fit_slogl(data[tr], data[te], node_type)
+
+
+def validated_cv_likelihood(data, node_type, ratio, k, seed):
+    """ValidatedLikelihood::local_score: CV(k, seed) over the hold-out training part (validated_likelihood.hpp:14-60)."""
+    data = np.asarray(data)
+    tr, _ = holdout_split(data.shape[0], ratio, seed)
+    return cv_likelihood(data[tr], node_type, k, seed)
+
+
+def _fit_slogl(train, test, node_type):
+    if node_type == "lg":
+        beta, var = lg_fit(train)
+        return float(lg_logl(test, beta, var).sum())
+    H = nr_bandwidth(train)
+    return float(ckde_logl(train, H, test).sum())

@@ -9,7 +9,17 @@ from .dataset import Context, DeviceTable, default_context  # noqa: F401
 from .factors import CKDE, Factor  # noqa: F401
 from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
+from .learning import (AddArc, ArcOperatorSet, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
+                       OperatorPool, RemoveArc, hc)
+from .models import (BayesianNetwork, CKDEType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
+                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType)
+from .scores import BGe, BIC, CVLikelihood, HoldoutLikelihood, ValidatedLikelihood  # noqa: F401
+
 __all__ = [
+    "BIC", "BGe", "CVLikelihood", "HoldoutLikelihood", "ValidatedLikelihood", "GreedyHillClimbing", "hc",
+    "ArcOperatorSet", "ChangeNodeTypeSet", "OperatorPool", "AddArc", "RemoveArc", "FlipArc", "ChangeNodeType",
+    "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
+    "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType",
     "KDE", "ProductKDE", "CKDE", "Factor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
     "SingularCovarianceData", "Context", "DeviceTable", "default_context", "load_library",
 ]

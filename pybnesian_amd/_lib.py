@@ -15,6 +15,10 @@ PBN_F64, PBN_F32 = 0, 1
 PBN_BW_FULL, PBN_BW_DIAG = 0, 1
 PBN_SEL_NORMAL_REFERENCE, PBN_SEL_SCOTT = 0, 1
 PBN_K_PACK, PBN_K_SWEEP, PBN_K_FINISH, PBN_K_GRAM = 0, 1, 2, 3
+PBN_SPLIT_NONE, PBN_SPLIT_CV, PBN_SPLIT_HOLDOUT, PBN_SPLIT_VALIDATED = 0, 1, 2, 3
+PBN_SCORE_BIC, PBN_SCORE_BGE, PBN_SCORE_CVLIK, PBN_SCORE_HOLDOUT = 0, 1, 2, 3
+PBN_NODE_LG, PBN_NODE_CKDE = 0, 1
+PBN_BN_GAUSSIAN, PBN_BN_SEMIPARAMETRIC, PBN_BN_KDE = 0, 1, 2
 
 
 class SingularCovarianceData(ValueError):
@@ -55,7 +59,33 @@ SIGNATURES = {
     "pbn_kde_logl_dev": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
     "pbn_kde_slogl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_slogl_async": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
+    "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),
+    "pbn_scoredata_destroy": (None, [_vp]),
+    "pbn_scoredata_layout": (_int, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "pbn_lg_fit": (_int, [_vp, _int, _ip, _int, _dp, _dp]),
+    "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
+    "pbn_hc_estimate": (_int, [_vp, _vp, _vp, _ip, _ip, _ip, _vp]),
 }
+
+HC_SCORE_FN = C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)
+
+
+class HCConfig(C.Structure):
+    _fields_ = [
+        ("n_nodes", _int), ("bn_type", _int), ("node_types", _ip), ("n_arcs", _int), ("arcs", _ip),
+        ("n_arc_blacklist", _int), ("arc_blacklist", _ip), ("n_arc_whitelist", _int), ("arc_whitelist", _ip),
+        ("n_type_blacklist", _int), ("type_blacklist", _ip), ("n_type_whitelist", _int), ("type_whitelist", _ip),
+        ("op_arcs", _int), ("op_node_type", _int), ("arcs_first", _int), ("max_indegree", _int), ("max_iters", _int),
+        ("epsilon", C.c_double), ("patience", _int), ("validated", _int),
+    ]
+
+
+class HCStats(C.Structure):
+    _fields_ = [
+        ("iterations", _int), ("cells_scored", _i64), ("local_score_evals", _i64), ("trace_capacity", _int),
+        ("trace", _ip), ("trace_delta", _dp), ("trace_len", _int),
+    ]
+
 
 _lib = None
 

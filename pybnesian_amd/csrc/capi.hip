@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "hostmath.hpp"
 #include "kde_kernels.hpp"
+#include "kde_model.hpp"
 #include "stats_kernels.hpp"
 
 namespace pbn {
@@ -21,17 +22,8 @@ using namespace pbn;
 
 struct pbn_kde {
     pbn_ctx* ctx = nullptr;
-    int dtype = PBN_F64;
-    int d = 0;        // number of variables
-    int dm = 0;       // dimensions in the main MFMA contraction (d, or d-1 for CKDE)
-    int KS = 0;       // ceil(dm / 4)
-    bool cond = false;
-    int64_t N = 0;
-    int64_t ntiles = 0;
-    double lognorm = 0.0, lognorm_marg = 0.0;
-    std::vector<int> perm;  // position in the caller's column list -> whitening order
+    KdeModel m;
     dev_buf<char> Apack, nxpack, Axpack;
-    std::vector<double> W, mu;  // whitening matrix (d x d row-major lower) and centring offsets, whitening order
 };
 
 extern "C" {
@@ -220,15 +212,6 @@ int pbn_table_read(const pbn_table* t, const int* cols, int n_sel, void* outp) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-static void check_cols(const pbn_table* t, const int* cols, int d, const char* who) {
-    if (!t || !cols) throw invalid_error(std::string(who) + ": null argument");
-    for (int i = 0; i < d; ++i)
-        if (cols[i] < 0 || cols[i] >= t->n_cols) throw invalid_error(std::string(who) + ": column index out of range");
-}
-static void check_range(const pbn_table* t, int64_t row0, int64_t n, const char* who) {
-    if (row0 < 0 || n < 0 || row0 + n > t->n_rows) throw invalid_error(std::string(who) + ": row range out of bounds");
-}
-
 // Shifted Gram of up to 64 columns -> host means (d) and centred SSE (d x d, col-major).
 static void sse_block(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, double* means, double* sse) {
     pbn_ctx* ctx = t->ctx;
@@ -238,7 +221,8 @@ static void sse_block(const pbn_table* t, const int* cols, int d, int64_t row0, 
     int64_t rpb = ceil_div(std::max<int64_t>(n, 1), nblocks);
     rpb = (rpb + 63) / 64 * 64;
     nblocks = (int)std::max<int64_t>(1, ceil_div(n, rpb));
-    ctx->scratch_red.reserve((size_t)nblocks * WS + WS + 64);
+    const size_t nsh = (size_t)t->n_cols;
+    ctx->scratch_red.reserve((size_t)nblocks * WS + WS + nsh);
     double* partial = ctx->scratch_red.p;
     double* total = partial + (size_t)nblocks * WS;
     double* shift = total + WS;
@@ -248,13 +232,13 @@ static void sse_block(const pbn_table* t, const int* cols, int d, int64_t row0, 
     a.rows_per_block = rpb; a.shift = shift; a.partial = partial;
     launch_pilot(t->data, t->ld, a.gc, d, row0, nullptr, n, t->dtype, shift, ctx->stream);
     { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram(a, t->dtype, nblocks, total, ctx->stream); }
-    std::vector<double> h((size_t)WS + 64);
-    HIP_CHECK(hipMemcpyAsync(h.data(), total, ((size_t)WS + 64) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> h((size_t)WS + nsh);
+    HIP_CHECK(hipMemcpyAsync(h.data(), total, ((size_t)WS + nsh) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const double* hs = h.data() + WS;            // pilot shifts
+    const double* hs = h.data() + WS;            // pilot shifts, indexed by table column
     const double* S = h.data() + (WS - nct * 16);  // shifted column sums
     const double N = (double)n;
-    for (int i = 0; i < d; ++i) means[i] = hs[i] + (n > 0 ? S[i] / N : 0.0);
+    for (int i = 0; i < d; ++i) means[i] = hs[cols[i]] + (n > 0 ? S[i] / N : 0.0);
     int p = 0;
     for (int I = 0; I < nct; ++I)
         for (int J = I; J < nct; ++J, ++p) {
@@ -287,139 +271,39 @@ int pbn_table_sse(const pbn_table* t, const int* cols, int d, int64_t row0, int6
 
 // ---------------------------------------------------------------------------------------------------
 int pbn_bandwidth(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out) {
-    return guarded([&] {
-        if (!cov || !out || d <= 0) throw invalid_error("pbn_bandwidth: bad argument");
-        const bool f32 = dtype == PBN_F32;
-        const double N = (double)n, D = (double)d;
-        auto not_enough = [&](const char* what) {
-            throw singular_error(std::string(what) + " of " + std::to_string(d) + " variables cannot be estimated with " +
-                                 std::to_string(n) + " instances");
-        };
-        if (selector == PBN_SEL_SCOTT) {
-            // kde/ScottsBandwidth.hpp:66-117
-            if (kind == PBN_BW_DIAG) {
-                if (n <= 1) not_enough("Diagonal bandwidth matrix");
-                const double k = std::pow(N, -2.0 / (D + 4.0));
-                for (int i = 0; i < d; ++i) out[i] = k * cov[i + (size_t)i * d];
-            } else {
-                if (n <= d) not_enough("Bandwidth matrix");
-                if (!hm::is_psd(cov, d, f32)) throw singular_error("Covariance matrix is not positive-definite.");
-                const double k = std::pow(N, -2.0 / (D + 4.0));
-                for (int i = 0; i < d * d; ++i) out[i] = k * cov[i];
-            }
-            return;
-        }
-        if (selector != PBN_SEL_NORMAL_REFERENCE) throw invalid_error("pbn_bandwidth: unknown selector");
-        // kde/NormalReferenceRule.hpp:12-59 (pre-checks), :72-106 (diag), :109-134 (full)
-        if (n <= d) not_enough(kind == PBN_BW_DIAG ? "Diagonal bandwidth matrix" : "Bandwidth matrix");
-        if (!hm::is_psd(cov, d, f32)) throw singular_error("Covariance matrix is not positive-definite.");
-        if (kind == PBN_BW_FULL) {
-            const double k = std::pow(4.0 / (N * (D + 2.0)), 2.0 / (D + 4.0));
-            for (int i = 0; i < d * d; ++i) out[i] = k * cov[i];
-            return;
-        }
-        // Chacon & Duong (2018) eq. 3.4: delta = diag(cov)^-1 cov
-        std::vector<double> delta((size_t)d * d), dinv((size_t)d * d), dd((size_t)d * d);
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i < d; ++i) delta[i + (size_t)j * d] = cov[i + (size_t)j * d] / cov[i + (size_t)i * d];
-        if (!hm::inverse(delta.data(), d, dinv.data())) throw singular_error("Covariance matrix is not positive-definite.");
-        double tr = 0.0, tr2 = 0.0;
-        for (int i = 0; i < d; ++i) tr += dinv[i + (size_t)i * d];
-        for (int i = 0; i < d; ++i)
-            for (int k2 = 0; k2 < d; ++k2) tr2 += dinv[i + (size_t)k2 * d] * dinv[k2 + (size_t)i * d];
-        const double k = 4.0 * D * std::sqrt(hm::determinant(delta.data(), d)) / (2.0 * tr2 + tr * tr);
-        const double f = std::pow(k / N, 2.0 / (D + 4.0));
-        for (int i = 0; i < d; ++i) out[i] = f * cov[i + (size_t)i * d];
-    });
+    return guarded([&] { bandwidth_from_cov(selector, kind, cov, d, n, dtype, out); });
 }
 
 // ---------------------------------------------------------------------------------------------------
-static const double LOG2E = 1.4426950408889634073599246810019;
-static const double LOG_2PI = 1.8378770664093454835606594728112;
-
-static void fill_pack_common(PackArgs& pa, const pbn_table* t, const int* cols, const std::vector<int>& perm, int d,
-                             int dm, int KS, int64_t row0, int64_t n, const pbn_kde* k) {
-    pa.base = t->data; pa.ld = t->ld; pa.d = d; pa.dm = dm; pa.KS = KS;
-    for (int i = 0; i < d; ++i) pa.cols[i] = cols[perm[i]];
-    pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.rows = nullptr; pa.n = n; pa.ntiles = ceil_div(n, 16);
-    for (int i = 0; i < d * d; ++i) pa.W[i] = k->W[i];
-    for (int i = 0; i < d; ++i) pa.mu[i] = k->mu[i];
-}
-
 static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                          const double* bw, int kind, bool cond, const double* center, pbn_kde** out) {
-    if (!ctx || !out || !bw) throw invalid_error("pbn_kde_fit: null argument");
+    if (!ctx || !out) throw invalid_error("pbn_kde_fit: null argument");
     check_cols(train, cols, d, "pbn_kde_fit");
     check_range(train, row0, n, "pbn_kde_fit");
-    if (d <= 0) throw invalid_error("pbn_kde_fit: no variables");
-    if (n <= 0) throw invalid_error("pbn_kde_fit: no training instances");
-    if (cond && d < 2) cond = false;  // CKDE without evidence is a plain KDE (CKDE.hpp:232-241)
-    const int dm = cond ? d - 1 : d;
-    if (dm > 16) throw invalid_error("KDE with more than 16 (+1 conditional) variables is not supported");
     HIP_CHECK(hipSetDevice(ctx->device));
-
     auto k = std::make_unique<pbn_kde>();
-    k->ctx = ctx; k->dtype = train->dtype; k->d = d; k->dm = dm; k->KS = (dm + 3) / 4; k->cond = cond;
-    k->N = n; k->ntiles = ceil_div(n, 16);
-    k->perm.resize(d);
-    if (cond) {  // evidence first, variable last
-        for (int i = 0; i < d - 1; ++i) k->perm[i] = i + 1;
-        k->perm[d - 1] = 0;
-    } else {
-        std::iota(k->perm.begin(), k->perm.end(), 0);
-    }
-
-    // whitening matrix W (row-major lower) = sqrt(log2 e) * L^-1, with L = chol(P H P^T)
-    std::vector<double> W((size_t)d * d, 0.0);
-    const double sc = std::sqrt(LOG2E);
-    double logdet_half = 0.0, logdet_half_marg = 0.0;  // sum log L_ii
-    if (kind == PBN_BW_DIAG) {
-        for (int i = 0; i < d; ++i) {
-            const double h = bw[k->perm[i]];
-            if (!(h > 0.0) || !std::isfinite(h)) throw singular_error("ProductKDE: bandwidth must be positive");
-            W[(size_t)i * d + i] = sc / std::sqrt(h);
-            logdet_half += 0.5 * std::log(h);
-            if (i < dm) logdet_half_marg += 0.5 * std::log(h);
-        }
-    } else {
-        std::vector<double> H((size_t)d * d), L((size_t)d * d), Li((size_t)d * d);
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i < d; ++i) H[i + (size_t)j * d] = bw[k->perm[i] + (size_t)k->perm[j] * d];
-        if (!hm::cholesky(H.data(), d, L.data())) throw singular_error("KDE: bandwidth matrix is not positive-definite");
-        hm::lower_inverse(L.data(), d, Li.data());
-        for (int i = 0; i < d; ++i) {
-            for (int j = 0; j <= i; ++j) W[(size_t)i * d + j] = sc * Li[i + (size_t)j * d];
-            logdet_half += std::log(L[i + (size_t)i * d]);
-            if (i < dm) logdet_half_marg += std::log(L[i + (size_t)i * d]);
-        }
-    }
-    // KDE.hpp:476-477 / ProductKDE.hpp:188-189
-    k->lognorm = -logdet_half - 0.5 * d * LOG_2PI - std::log((double)n);
-    k->lognorm_marg = -logdet_half_marg - 0.5 * dm * LOG_2PI - std::log((double)n);
-
-    k->W = W;
-    k->mu.assign(d, 0.0);
-    if (center) {
-        for (int i = 0; i < d; ++i) k->mu[i] = center[k->perm[i]];
-    } else {
+    k->ctx = ctx;
+    std::vector<double> pilot;
+    if (!center && d > 0 && d <= 64 && n > 0) {
         // centring offsets = pilot means (any offset is exact in the distances; it only keeps |z| small)
-        GramCols gc{};
-        for (int i = 0; i < d; ++i) gc.cols[i] = cols[k->perm[i]];
-        ctx->scratch_red.reserve(64);
-        launch_pilot(train->data, train->ld, gc, d, row0, nullptr, n, train->dtype, ctx->scratch_red.p, ctx->stream);
-        HIP_CHECK(hipMemcpyAsync(k->mu.data(), ctx->scratch_red.p, d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        GramCols sel{};
+        for (int i = 0; i < d; ++i) sel.cols[i] = cols[i];
+        ctx->scratch_red.reserve((size_t)train->n_cols + 8);
+        launch_pilot(train->data, train->ld, sel, d, row0, nullptr, n, train->dtype, ctx->scratch_red.p, ctx->stream);
+        std::vector<double> all((size_t)train->n_cols);
+        HIP_CHECK(hipMemcpyAsync(all.data(), ctx->scratch_red.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        pilot.resize(d);
+        for (int i = 0; i < d; ++i) pilot[i] = all[cols[i]];
+        center = pilot.data();
     }
-
-    const size_t es = dtype_size(train->dtype);
-    k->Apack.alloc((size_t)k->ntiles * k->KS * 64 * es);
-    k->nxpack.alloc((size_t)k->ntiles * 16 * es);
-    if (cond) k->Axpack.alloc((size_t)k->ntiles * 64 * es);
-    PackArgs pa{};
-    fill_pack_common(pa, train, cols, k->perm, d, dm, k->KS, row0, n, k.get());
-    pa.is_query = 0;
-    pa.pack = k->Apack.p; pa.npack = k->nxpack.p; pa.xpack = cond ? k->Axpack.p : nullptr;
-    { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, train->dtype, ctx->stream); }
+    kde_prepare(k->m, train->dtype, d, n, bw, kind, cond, center);
+    const KdePackBytes pb = kde_pack_bytes(train->dtype, k->m.dm, k->m.cond, n);
+    k->Apack.alloc(pb.apack);
+    k->nxpack.alloc(pb.nxpack);
+    if (k->m.cond) k->Axpack.alloc(pb.axpack);
+    k->m.Apack = k->Apack.p; k->m.nxpack = k->nxpack.p; k->m.Axpack = k->Axpack.p;
+    kde_pack_train(ctx, k->m, train, cols, row0, n, 0);
     *out = k.release();
 }
 
@@ -443,65 +327,13 @@ void pbn_kde_destroy(pbn_kde* k) {
     delete k;
 }
 
-int64_t pbn_kde_num_instances(const pbn_kde* k) { return k ? k->N : 0; }
-double pbn_kde_lognorm(const pbn_kde* k, int which) { return which ? k->lognorm_marg : k->lognorm; }
+int64_t pbn_kde_num_instances(const pbn_kde* k) { return k ? k->m.N : 0; }
+double pbn_kde_lognorm(const pbn_kde* k, int which) { return which ? k->m.lognorm_marg : k->m.lognorm; }
 
-static int env_int(const char* name, int dflt) {
-    const char* s = std::getenv(name);
-    return s && *s ? std::atoi(s) : dflt;
-}
-
-// Enqueue pack(queries) -> sweep -> finish on the context stream.  dev_logl / dev_sum are nullable.
 static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
                              double* dev_logl, double* dev_sum) {
     if (!k) throw invalid_error("KDE factor not fitted.");
-    check_cols(test, cols, k->d, "pbn_kde_logl");
-    check_range(test, row0, n, "pbn_kde_logl");
-    if (test->dtype != k->dtype) throw invalid_error("Data type of training and test datasets is different.");
-    pbn_ctx* ctx = k->ctx;
-    if (test->ctx->device != ctx->device) throw invalid_error("pbn_kde_logl: test table lives on another device");
-    HIP_CHECK(hipSetDevice(ctx->device));
-    if (n == 0) {
-        if (dev_sum) HIP_CHECK(hipMemsetAsync(dev_sum, 0, sizeof(double), ctx->stream));
-        return;
-    }
-    const size_t es = dtype_size(k->dtype);
-    const int64_t nqtiles = ceil_div(n, 16);
-    // query fragments in scratch: Bpack | nypack | Bxpack
-    const size_t bpack_b = (size_t)nqtiles * k->KS * 64 * es, ny_b = (size_t)nqtiles * 16 * es,
-                 bx_b = k->cond ? (size_t)nqtiles * 64 * es : 0;
-    ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + 256);
-    char* q = ctx->scratch_q.p;
-    PackArgs pa{};
-    fill_pack_common(pa, test, cols, k->perm, k->d, k->dm, k->KS, row0, n, k);
-    pa.is_query = 1;
-    pa.pack = q; pa.npack = q + bpack_b; pa.xpack = k->cond ? q + bpack_b + ny_b : nullptr;
-    { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, k->dtype, ctx->stream); }
-
-    // split the training tiles so that the grid is a few waves deep on every CU
-    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(k->dtype, k->cond));
-    const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
-    int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
-    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, k->ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));
-    nsplit = std::min<int64_t>(nsplit, 4096);
-    const int64_t tps = ceil_div(k->ntiles, nsplit);
-    nsplit = ceil_div(k->ntiles, tps);
-    const int P = k->cond ? 4 : 2;
-    ctx->scratch_part.reserve((size_t)nsplit * nqtiles * 16 * P * sizeof(double));
-    SweepArgs sa{};
-    sa.Apack = k->Apack.p; sa.nxpack = k->nxpack.p; sa.Axpack = k->Axpack.p;
-    sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack;
-    sa.ntiles = k->ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
-    sa.part = (double*)ctx->scratch_part.p;
-    { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, k->dtype, k->KS, k->cond, (int)nsplit, ctx->stream); }
-
-    const int64_t nblocks = ceil_div(n, 256);
-    ctx->scratch_misc.reserve((size_t)nblocks * sizeof(double));
-    FinishArgs fa{};
-    fa.part = sa.part; fa.nsplit = (int)nsplit; fa.nqtiles = nqtiles; fa.nq = n;
-    fa.lognorm = k->lognorm; fa.lognorm_marg = k->lognorm_marg;
-    fa.logl = dev_logl; fa.block_sums = dev_sum ? (double*)ctx->scratch_misc.p : nullptr;
-    { KernelTimer kt(ctx, PBN_K_FINISH); launch_finish(fa, k->cond, dev_sum, ctx->stream); }
+    pbn::kde_eval_enqueue(k->ctx, k->m, test, cols, row0, n, dev_logl, dev_sum);
 }
 
 int pbn_kde_logl_dev(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* dev_out) {

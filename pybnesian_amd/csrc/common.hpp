@@ -18,6 +18,8 @@
 
 #include "../../include/pbn_hip.h"
 
+#define PBN_MAX_D_HOST 17  // == PBN_MAX_D of kde_kernels.hpp (16 whitened dims + 1 CKDE coordinate)
+
 namespace pbn {
 
 struct invalid_error : std::runtime_error {
@@ -115,6 +117,7 @@ struct pbn_ctx {
     pbn::dev_buf<char> scratch_q;
     pbn::dev_buf<char> scratch_misc;
     pbn::dev_buf<double> scratch_red;
+    pbn::dev_buf<char> scratch_train;  // packed training fragments of the score engine
     // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
     bool profiling = false;
     struct Timed { hipEvent_t e0, e1; int which; };

@@ -1,0 +1,560 @@
+// Greedy hill-climbing with the delta-score cache — host logic of libpbn_hip.
+//
+// Mirrors, decision for decision, /root/reference/pybnesian/learning/operators/operators.{hpp,cpp}
+// (ArcOperatorSet :19-132,296-363 / operators.hpp:489-525,580-623; ChangeNodeTypeSet operators.cpp:439-599;
+// OperatorPool operators.hpp:836-904; Operators :89-244; OperatorTabuSet :258-293; LocalScoreCache :295-338),
+// learning/algorithms/hillclimbing.hpp:46-199 (estimate_hc) and the DAG legality predicates of
+// graph/generic_graph.hpp:2711-2745.  What changes is WHEN scores are computed: every place where the
+// reference calls Score::local_score inside a loop (cache_scores' n(n-1) cells, update_scores' <= 2(n-1)
+// cells per changed node, the local caches) first collects all (variable, node type, parent list) requests
+// of that step and submits them as ONE batch to the score callback - the unit that is spread over the CUs of
+// a GPU and over the GPUs of a node.  Cell arithmetic, candidate parent orderings (swap_remove / push_back
+// exactly as the reference manipulates them), the std::sort-based find_max with its persistent index
+// vector, the stop rule, patience and tabu handling are the reference's.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace pbn;
+
+namespace {
+
+constexpr double MACHINE_TOL = 1.4901161193847656e-08;  // util/math_constants.hpp:30
+const double LOWEST = std::numeric_limits<double>::lowest();
+
+enum OpKind { OP_ADD = 0, OP_REMOVE = 1, OP_FLIP = 2, OP_TYPE = 3 };
+
+struct Op {
+    int kind = -1;
+    int source = -1, target = -1;  // arcs; OP_TYPE: source = node
+    int new_type = -1;             // OP_TYPE
+    double delta = 0;
+    bool valid() const { return kind >= 0; }
+    bool same(const Op& o) const {  // hash/eq of operators.hpp:108-119: type + source + target (+ node type)
+        return kind == o.kind && source == o.source && target == o.target && new_type == o.new_type;
+    }
+};
+
+struct Model {
+    int n = 0;
+    int bn_type = PBN_BN_GAUSSIAN;
+    std::vector<std::vector<int>> parents, children;
+    std::vector<char> adj;  // adj[s + t*n] = arc s -> t
+    std::vector<int> node_type;
+    bool has_arc(int s, int t) const { return adj[s + (size_t)t * n] != 0; }
+    void add_arc(int s, int t) {
+        if (has_arc(s, t)) return;
+        adj[s + (size_t)t * n] = 1;
+        parents[t].push_back(s);
+        children[s].push_back(t);
+    }
+    static void swap_remove(std::vector<int>& v, int x) {  // util::swap_remove_v
+        auto it = std::find(v.begin(), v.end(), x);
+        if (it != v.end()) { *it = v.back(); v.pop_back(); }
+    }
+    void remove_arc(int s, int t) {
+        if (!has_arc(s, t)) return;
+        adj[s + (size_t)t * n] = 0;
+        swap_remove(parents[t], s);
+        swap_remove(children[s], t);
+    }
+    bool has_path(int from, int to, int skip_s = -1, int skip_t = -1) const {  // follows children
+        std::vector<char> seen(n, 0);
+        std::vector<int> stack{from};
+        seen[from] = 1;
+        while (!stack.empty()) {
+            int u = stack.back();
+            stack.pop_back();
+            for (int c : children[u]) {
+                if (u == skip_s && c == skip_t) continue;
+                if (c == to) return true;
+                if (!seen[c]) { seen[c] = 1; stack.push_back(c); }
+            }
+        }
+        return false;
+    }
+    // continuous-only networks: BayesianNetworkType::can_have_arc is always true (SemiparametricBN.hpp:93-98)
+    bool can_add_arc(int s, int t) const {  // generic_graph.hpp:2711-2718
+        return s != t && (parents[s].empty() || children[t].empty() || !has_path(t, s));
+    }
+    bool can_flip_arc(int s, int t) const {  // generic_graph.hpp:2721-2745
+        if (s == t) return false;
+        if (has_arc(s, t)) {
+            if (parents[t].size() == 1 || children[s].size() == 1) return true;
+            return !has_path(s, t, s, t);
+        }
+        if (parents[t].empty() || children[s].empty()) return true;
+        return !has_path(s, t);
+    }
+    int alternative_type(int node) const {  // SemiparametricBN.hpp:106-119
+        if (bn_type != PBN_BN_SEMIPARAMETRIC) return -1;
+        return node_type[node] == PBN_NODE_LG ? PBN_NODE_CKDE : PBN_NODE_LG;
+    }
+    void apply(const Op& op) {
+        switch (op.kind) {
+            case OP_ADD: add_arc(op.source, op.target); break;
+            case OP_REMOVE: remove_arc(op.source, op.target); break;
+            case OP_FLIP: remove_arc(op.source, op.target); add_arc(op.target, op.source); break;
+            case OP_TYPE: node_type[op.source] = op.new_type; break;
+        }
+    }
+    Op opposite(const Op& op) const {  // operators.hpp:89-244, evaluated AFTER apply (as estimate_hc does)
+        Op o = op;
+        switch (op.kind) {
+            case OP_ADD: o.kind = OP_REMOVE; o.delta = -op.delta; break;
+            case OP_REMOVE: o.kind = OP_ADD; o.delta = -op.delta; break;
+            case OP_FLIP: o.source = op.target; o.target = op.source; o.delta = -op.delta; break;
+            case OP_TYPE: o.new_type = (op.new_type == PBN_NODE_LG) ? PBN_NODE_CKDE : PBN_NODE_LG; o.delta = -op.delta; break;
+        }
+        return o;
+    }
+    std::vector<int> nodes_changed(const Op& op) const {
+        if (op.kind == OP_FLIP) return {op.source, op.target};
+        if (op.kind == OP_TYPE) return {op.source};
+        return {op.target};
+    }
+};
+
+// One batch of Score::local_score requests.
+struct Batch {
+    std::vector<int> var, ntype, off{0}, par;
+    int add(int v, int t, const std::vector<int>& p) {
+        var.push_back(v);
+        ntype.push_back(t);
+        par.insert(par.end(), p.begin(), p.end());
+        off.push_back((int)par.size());
+        return (int)var.size() - 1;
+    }
+    int size() const { return (int)var.size(); }
+};
+
+struct Scorer {
+    pbn_hc_score_fn fn;
+    void* user;
+    int64_t evals = 0;
+    std::vector<double> run(const Batch& b, int validated) {
+        std::vector<double> out(b.size());
+        if (b.size() == 0) return out;
+        evals += b.size();
+        int rc = fn(user, validated, b.size(), b.var.data(), b.ntype.data(), b.off.data(), b.par.data(), out.data());
+        if (rc != 0) throw invalid_error(std::string("score callback failed: ") + pbn_last_error());
+        return out;
+    }
+};
+
+struct ArcSet {
+    int n = 0;
+    std::vector<double> delta;   // col-major: delta[s + t*n]
+    std::vector<char> valid_op;
+    mutable std::vector<int> sorted_idx;
+    int max_indegree = 0;
+    std::vector<std::pair<int, int>> blacklist, whitelist;
+
+    void update_valid_ops(const Model& m) {  // operators.cpp:19-69 (cells the reference leaves uninitialised start at lowest())
+        n = m.n;
+        delta.assign((size_t)n * n, LOWEST);
+        valid_op.assign((size_t)n * n, 1);
+        for (auto& a : whitelist) {
+            valid_op[a.first + (size_t)a.second * n] = 0;
+            valid_op[a.second + (size_t)a.first * n] = 0;
+        }
+        for (auto& a : blacklist) valid_op[a.first + (size_t)a.second * n] = 0;
+        for (int i = 0; i < n; ++i) valid_op[i + (size_t)i * n] = 0;
+        sorted_idx.clear();
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (valid_op[i + (size_t)j * n]) sorted_idx.push_back(i + j * n);
+    }
+};
+
+struct TypeSet {
+    std::vector<double> delta;  // one alternative type per node (SPBN); LOWEST when unavailable
+    std::vector<char> has;      // delta[i] has an entry (alt type exists)
+    std::vector<char> whitelisted;
+    std::set<std::pair<int, int>> type_blacklist;
+};
+
+struct Engine {
+    Model cur;
+    Scorer scorer;
+    bool use_arcs = false, use_types = false;
+    int order_arcs_first = 1;
+    ArcSet arcs;
+    TypeSet types;
+    std::vector<double> local;  // LocalScoreCache of the pool / op set
+    int64_t cells_scored = 0;
+
+    // ---- local cache ------------------------------------------------------------------------------
+    void cache_local_scores() {
+        Batch b;
+        for (int v = 0; v < cur.n; ++v) b.add(v, cur.node_type[v], cur.parents[v]);
+        local = scorer.run(b, 0);
+    }
+
+    // ---- ArcOperatorSet::cache_scores (operators.cpp:100-132 + cache_score_operation :71-98) ---------
+    void arcs_cache_scores() {
+        arcs.update_valid_ops(cur);
+        const int n = cur.n;
+        struct Cell { int s, t; int a, b; int kind; };  // kind 0: d = S[a]-local[t]; 1: S[a]+S[b]-local[s]-local[t]
+        std::vector<Cell> cells;
+        Batch bt;
+        for (int t = 0; t < n; ++t) {
+            std::vector<int> pt = cur.parents[t];
+            for (int s = 0; s < n; ++s) {
+                if (!arcs.valid_op[s + (size_t)t * n]) continue;
+                if (cur.has_arc(s, t)) {
+                    Model::swap_remove(pt, s);
+                    int a = bt.add(t, cur.node_type[t], pt);
+                    pt.push_back(s);
+                    cells.push_back({s, t, a, -1, 0});
+                } else if (cur.has_arc(t, s)) {
+                    std::vector<int> ps = cur.parents[s];
+                    Model::swap_remove(ps, t);
+                    pt.push_back(s);
+                    int a = bt.add(s, cur.node_type[s], ps);
+                    int b = bt.add(t, cur.node_type[t], pt);
+                    pt.pop_back();
+                    cells.push_back({s, t, a, b, 1});
+                } else {
+                    pt.push_back(s);
+                    int a = bt.add(t, cur.node_type[t], pt);
+                    pt.pop_back();
+                    cells.push_back({s, t, a, -1, 0});
+                }
+            }
+        }
+        std::vector<double> S = scorer.run(bt, 0);
+        for (const Cell& c : cells) {
+            double d;
+            if (c.kind == 0) d = S[c.a] - local[c.t];
+            else d = S[c.a] + S[c.b] - local[c.s] - local[c.t];
+            arcs.delta[c.s + (size_t)c.t * n] = d;
+        }
+        cells_scored += (int64_t)cells.size();
+    }
+
+    // ---- ArcOperatorSet::update_incoming_arcs_scores (operators.cpp:296-347), requests only -------------
+    struct UCell { int s, t; int a, b; int kind; };  // kind 0 remove/add: S[a]-local[t]; 1 flip-of-existing: cell(t,s) = d_remove + S[b]-local[s]; 2 flip: S[a]+S[b]-local[s]-local[t]
+    void arcs_collect_updates(int t, Batch& bt, std::vector<UCell>& cells) {
+        const int n = cur.n;
+        std::vector<int> parents = cur.parents[t];
+        for (int s = 0; s < n; ++s) {
+            if (!arcs.valid_op[s + (size_t)t * n]) continue;
+            if (cur.has_arc(s, t)) {
+                Model::swap_remove(parents, s);
+                int a = bt.add(t, cur.node_type[t], parents);
+                parents.push_back(s);
+                int b = -1;
+                if (arcs.valid_op[t + (size_t)s * n]) {
+                    std::vector<int> ps = cur.parents[s];
+                    ps.push_back(t);
+                    b = bt.add(s, cur.node_type[s], ps);
+                }
+                cells.push_back({s, t, a, b, 1});
+            } else if (cur.has_arc(t, s)) {
+                std::vector<int> ps = cur.parents[s];
+                Model::swap_remove(ps, t);
+                parents.push_back(s);
+                int a = bt.add(s, cur.node_type[s], ps);
+                int b = bt.add(t, cur.node_type[t], parents);
+                parents.pop_back();
+                cells.push_back({s, t, a, b, 2});
+            } else {
+                parents.push_back(s);
+                int a = bt.add(t, cur.node_type[t], parents);
+                parents.pop_back();
+                cells.push_back({s, t, a, -1, 0});
+            }
+        }
+    }
+    void arcs_apply_updates(const std::vector<UCell>& cells, const std::vector<double>& S) {
+        const int n = cur.n;
+        for (const UCell& c : cells) {
+            if (c.kind == 0) {
+                arcs.delta[c.s + (size_t)c.t * n] = S[c.a] - local[c.t];
+                ++cells_scored;
+            } else if (c.kind == 1) {
+                const double d = S[c.a] - local[c.t];
+                arcs.delta[c.s + (size_t)c.t * n] = d;
+                ++cells_scored;
+                if (c.b >= 0) {
+                    arcs.delta[c.t + (size_t)c.s * n] = d + S[c.b] - local[c.s];
+                    ++cells_scored;
+                }
+            } else {
+                arcs.delta[c.s + (size_t)c.t * n] = S[c.a] + S[c.b] - local[c.s] - local[c.t];
+                ++cells_scored;
+            }
+        }
+    }
+
+    // ---- ArcOperatorSet::find_max_indegree (operators.hpp:489-525, tabu :580-623) --------------------------
+    Op arcs_find_max(const std::vector<Op>* tabu) const {
+        const int n = cur.n;
+        const double* dp = arcs.delta.data();
+        std::sort(arcs.sorted_idx.begin(), arcs.sorted_idx.end(), [dp](int i1, int i2) { return dp[i1] > dp[i2]; });
+        auto in_tabu = [&](const Op& o) {
+            if (!tabu) return false;
+            for (const Op& x : *tabu)
+                if (x.same(o)) return true;
+            return false;
+        };
+        const bool limited = arcs.max_indegree > 0;
+        for (int idx : arcs.sorted_idx) {
+            const int s = idx % n, t = idx / n;
+            Op o;
+            if (cur.has_arc(s, t)) {
+                o.kind = OP_REMOVE; o.source = s; o.target = t; o.delta = dp[idx];
+                if (!in_tabu(o)) return o;
+            } else if (cur.has_arc(t, s) && cur.can_flip_arc(t, s)) {
+                if (limited && (int)cur.parents[t].size() >= arcs.max_indegree) continue;
+                o.kind = OP_FLIP; o.source = t; o.target = s; o.delta = dp[idx];
+                if (!in_tabu(o)) return o;
+            } else if (cur.can_add_arc(s, t)) {
+                if (limited && (int)cur.parents[t].size() >= arcs.max_indegree) continue;
+                o.kind = OP_ADD; o.source = s; o.target = t; o.delta = dp[idx];
+                if (!in_tabu(o)) return o;
+            }
+        }
+        return Op{};
+    }
+
+    // ---- ChangeNodeTypeSet (operators.cpp:439-599) ---------------------------------------------------------
+    void types_collect(const std::vector<int>& nodes, Batch& bt, std::vector<std::pair<int, int>>& req) {
+        for (int v : nodes) {
+            if (types.whitelisted[v]) continue;
+            const int alt = cur.alternative_type(v);
+            if (alt < 0) { types.has[v] = 0; continue; }
+            types.has[v] = 1;
+            if (types.type_blacklist.count({v, alt})) {
+                types.delta[v] = LOWEST;
+                continue;
+            }
+            req.push_back({v, bt.add(v, alt, cur.parents[v])});
+        }
+    }
+    void types_apply(const std::vector<std::pair<int, int>>& req, const std::vector<double>& S) {
+        for (auto& r : req) {
+            types.delta[r.first] = S[r.second] - local[r.first];
+            ++cells_scored;
+        }
+    }
+    Op types_find_max(const std::vector<Op>* tabu) const {
+        double max_score = LOWEST;
+        int max_node = -1;
+        for (int i = 0; i < cur.n; ++i) {
+            if (types.whitelisted[i] || !types.has[i]) continue;
+            if (types.delta[i] > max_score) {
+                if (tabu) {
+                    Op o; o.kind = OP_TYPE; o.source = i; o.new_type = cur.alternative_type(i);
+                    bool hit = false;
+                    for (const Op& x : *tabu) if (x.same(o)) { hit = true; break; }
+                    if (hit) continue;
+                }
+                max_score = types.delta[i];
+                max_node = i;
+            }
+        }
+        if (max_score > LOWEST) {
+            Op o; o.kind = OP_TYPE; o.source = max_node; o.new_type = cur.alternative_type(max_node); o.delta = max_score;
+            return o;
+        }
+        return Op{};
+    }
+
+    // ---- pool-level operations (OperatorPool, operators.hpp:836-904) ----------------------------------------
+    void cache_scores() {
+        cache_local_scores();
+        auto do_arcs = [&] { if (use_arcs) arcs_cache_scores(); };
+        auto do_types = [&] {
+            if (!use_types) return;
+            types.delta.assign(cur.n, LOWEST);
+            types.has.assign(cur.n, 0);
+            std::vector<int> all(cur.n);
+            for (int i = 0; i < cur.n; ++i) all[i] = i;
+            Batch bt;
+            std::vector<std::pair<int, int>> req;
+            types_collect(all, bt, req);
+            types_apply(req, scorer.run(bt, 0));
+        };
+        if (order_arcs_first) { do_arcs(); do_types(); } else { do_types(); do_arcs(); }
+    }
+
+    Op find_max(const std::vector<Op>* tabu) const {
+        if (tabu && tabu->empty()) tabu = nullptr;
+        double max_delta = LOWEST;
+        Op best;
+        auto consider = [&](const Op& o) {
+            if (o.valid() && o.delta > max_delta) { best = o; max_delta = o.delta; }
+        };
+        if (order_arcs_first) {
+            if (use_arcs) consider(arcs_find_max(tabu));
+            if (use_types) consider(types_find_max(tabu));
+        } else {
+            if (use_types) consider(types_find_max(tabu));
+            if (use_arcs) consider(arcs_find_max(tabu));
+        }
+        return best;
+    }
+
+    void update_scores(const std::vector<int>& changed) {
+        // 1) local cache of the changed nodes (one batch), 2) all dependent cells (one batch)
+        {
+            Batch b;
+            for (int v : changed) b.add(v, cur.node_type[v], cur.parents[v]);
+            std::vector<double> S = scorer.run(b, 0);
+            for (size_t i = 0; i < changed.size(); ++i) local[changed[i]] = S[i];
+        }
+        Batch bt;
+        std::vector<UCell> cells;
+        std::vector<std::pair<int, int>> treq;
+        if (use_arcs)
+            for (int t : changed) arcs_collect_updates(t, bt, cells);
+        if (use_types) types_collect(changed, bt, treq);
+        std::vector<double> S = scorer.run(bt, 0);
+        if (use_arcs) arcs_apply_updates(cells, S);
+        if (use_types) types_apply(treq, S);
+    }
+};
+
+}  // namespace
+
+extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user, int* out_arcs, int* out_n_arcs,
+                               int* out_node_types, pbn_hc_stats* stats) {
+    return guarded([&] {
+        if (!cfg || !fn || !out_arcs || !out_n_arcs || !out_node_types) throw invalid_error("pbn_hc_estimate: null argument");
+        const int n = cfg->n_nodes;
+        if (n <= 0) throw invalid_error("pbn_hc_estimate: empty model");
+        Engine e;
+        e.scorer = Scorer{fn, user};
+        Model& m = e.cur;
+        m.n = n; m.bn_type = cfg->bn_type;
+        m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
+        m.node_type.assign(n, cfg->bn_type == PBN_BN_KDE ? PBN_NODE_CKDE : PBN_NODE_LG);
+        if (cfg->node_types)
+            for (int i = 0; i < n; ++i) m.node_type[i] = cfg->node_types[i];
+        auto check_node = [&](int v) { if (v < 0 || v >= n) throw invalid_error("pbn_hc_estimate: node index out of range"); };
+        // force type whitelist (hillclimbing.hpp:77)
+        for (int i = 0; i < cfg->n_type_whitelist; ++i) {
+            check_node(cfg->type_whitelist[2 * i]);
+            m.node_type[cfg->type_whitelist[2 * i]] = cfg->type_whitelist[2 * i + 1];
+        }
+        for (int i = 0; i < cfg->n_arcs; ++i) {
+            check_node(cfg->arcs[2 * i]); check_node(cfg->arcs[2 * i + 1]);
+            m.add_arc(cfg->arcs[2 * i], cfg->arcs[2 * i + 1]);
+        }
+        // check_blacklist / force_whitelist (hillclimbing.hpp:95-96)
+        for (int i = 0; i < cfg->n_arc_blacklist; ++i) {
+            const int s = cfg->arc_blacklist[2 * i], t = cfg->arc_blacklist[2 * i + 1];
+            check_node(s); check_node(t);
+            if (m.has_arc(s, t)) throw invalid_error("Arc in the blacklist is present in the starting Bayesian network.");
+            e.arcs.blacklist.push_back({s, t});
+        }
+        for (int i = 0; i < cfg->n_arc_whitelist; ++i) {
+            const int s = cfg->arc_whitelist[2 * i], t = cfg->arc_whitelist[2 * i + 1];
+            check_node(s); check_node(t);
+            if (!m.has_arc(s, t)) {
+                if (m.has_arc(t, s)) m.remove_arc(t, s);
+                if (!m.can_add_arc(s, t)) throw invalid_error("Arc whitelist creates a cycle in the starting Bayesian network.");
+                m.add_arc(s, t);
+            }
+            e.arcs.whitelist.push_back({s, t});
+        }
+        e.use_arcs = cfg->op_arcs != 0;
+        e.use_types = cfg->op_node_type != 0;
+        e.order_arcs_first = cfg->arcs_first;
+        if (!e.use_arcs && !e.use_types) throw invalid_error("pbn_hc_estimate: no operator set");
+        if (e.use_types && cfg->bn_type != PBN_BN_SEMIPARAMETRIC)
+            throw invalid_error("ChangeNodeTypeSet can only be used with non-homogeneous Bayesian networks.");
+        e.arcs.max_indegree = cfg->max_indegree;
+        e.types.whitelisted.assign(n, 0);
+        for (int i = 0; i < cfg->n_type_whitelist; ++i) e.types.whitelisted[cfg->type_whitelist[2 * i]] = 1;
+        for (int i = 0; i < cfg->n_type_blacklist; ++i)
+            e.types.type_blacklist.insert({cfg->type_blacklist[2 * i], cfg->type_blacklist[2 * i + 1]});
+
+        // ---- estimate_hc (hillclimbing.hpp:62-199) ------------------------------------------------------------
+        const bool validated = cfg->validated != 0;
+        const bool zero_patience = cfg->patience == 0;
+        Model prev = m;   // prev_current_model
+        Model best = m;   // value copy; `best_is_current` models the reference's pointer aliasing
+        bool best_is_current = true;
+        std::vector<double> vlocal;
+        if (validated) {
+            Batch b;
+            for (int v = 0; v < n; ++v) b.add(v, m.node_type[v], m.parents[v]);
+            vlocal = e.scorer.run(b, 1);
+        }
+        e.cache_scores();
+        int p = 0;
+        double accumulated_offset = 0;
+        std::vector<Op> tabu;
+        int iter = 0;
+        std::vector<int> trace;
+        while (iter < cfg->max_iters) {
+            ++iter;
+            Op best_op = zero_patience ? e.find_max(nullptr) : e.find_max(&tabu);
+            if (!best_op.valid() || (best_op.delta - cfg->epsilon) < MACHINE_TOL) break;
+            m.apply(best_op);
+            std::vector<int> changed = m.nodes_changed(best_op);
+            double validation_delta = best_op.delta;
+            if (validated) {  // validation_delta_score (hillclimbing.hpp:46-60)
+                Batch b;
+                for (int v : changed) b.add(v, m.node_type[v], m.parents[v]);
+                std::vector<double> S = e.scorer.run(b, 1);
+                double prev_s = 0, new_s = 0;
+                for (size_t i = 0; i < changed.size(); ++i) {
+                    prev_s += vlocal[changed[i]];
+                    vlocal[changed[i]] = S[i];
+                    new_s += vlocal[changed[i]];
+                }
+                validation_delta = new_s - prev_s;
+            }
+            if ((validation_delta + accumulated_offset) > MACHINE_TOL) {
+                if (!zero_patience) {
+                    if (p > 0) { best_is_current = true; p = 0; accumulated_offset = 0; }
+                    tabu.clear();
+                }
+            } else {
+                if (zero_patience) {
+                    best = prev; best_is_current = false;
+                    break;
+                } else {
+                    if (p == 0) { best = prev; best_is_current = false; }
+                    if (++p > cfg->patience) break;
+                    accumulated_offset += validation_delta;
+                    tabu.push_back(m.opposite(best_op));
+                }
+            }
+            prev.apply(best_op);
+            if (stats && stats->trace && (int)trace.size() / 4 < stats->trace_capacity) {
+                trace.push_back(best_op.kind);
+                trace.push_back(best_op.source);
+                trace.push_back(best_op.kind == OP_TYPE ? best_op.new_type : best_op.target);
+                trace.push_back(0);
+                if (stats->trace_delta) stats->trace_delta[trace.size() / 4 - 1] = best_op.delta;
+            }
+            e.update_scores(changed);
+        }
+        const Model& res = best_is_current ? m : best;
+        int na = 0;
+        for (int t = 0; t < n; ++t)
+            for (int s : res.parents[t]) { out_arcs[2 * na] = s; out_arcs[2 * na + 1] = t; ++na; }
+        *out_n_arcs = na;
+        for (int i = 0; i < n; ++i) out_node_types[i] = res.node_type[i];
+        if (stats) {
+            stats->iterations = iter;
+            stats->cells_scored = e.cells_scored;
+            stats->local_score_evals = e.scorer.evals;
+            stats->trace_len = (int)trace.size() / 4;
+            if (stats->trace) std::memcpy(stats->trace, trace.data(), trace.size() * sizeof(int));
+        }
+    });
+}

@@ -1,0 +1,201 @@
+// Host side of KDE / ProductKDE / CKDE fitting and evaluation, shared by the public handles and the score
+// engine.  See kde_kernels.hip for the device side.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <numeric>
+
+#include "hostmath.hpp"
+#include "kde_kernels.hpp"
+#include "kde_model.hpp"
+#include "stats_kernels.hpp"
+
+namespace pbn {
+
+static const double LOG2E = 1.4426950408889634073599246810019;
+static const double LOG_2PI = 1.8378770664093454835606594728112;
+
+void check_cols(const pbn_table* t, const int* cols, int d, const char* who) {
+    if (!t || !cols) throw invalid_error(std::string(who) + ": null argument");
+    for (int i = 0; i < d; ++i)
+        if (cols[i] < 0 || cols[i] >= t->n_cols) throw invalid_error(std::string(who) + ": column index out of range");
+}
+void check_range(const pbn_table* t, int64_t row0, int64_t n, const char* who) {
+    if (row0 < 0 || n < 0 || row0 + n > t->n_rows) throw invalid_error(std::string(who) + ": row range out of bounds");
+}
+
+void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out) {
+    if (!cov || !out || d <= 0) throw invalid_error("pbn_bandwidth: bad argument");
+    const bool f32 = dtype == PBN_F32;
+    const double N = (double)n, D = (double)d;
+    auto not_enough = [&](const char* what) {
+        throw singular_error(std::string(what) + " of " + std::to_string(d) + " variables cannot be estimated with " +
+                             std::to_string(n) + " instances");
+    };
+    if (selector == PBN_SEL_SCOTT) {
+        // kde/ScottsBandwidth.hpp:66-117
+        if (kind == PBN_BW_DIAG) {
+            if (n <= 1) not_enough("Diagonal bandwidth matrix");
+            const double k = std::pow(N, -2.0 / (D + 4.0));
+            for (int i = 0; i < d; ++i) out[i] = k * cov[i + (size_t)i * d];
+        } else {
+            if (n <= d) not_enough("Bandwidth matrix");
+            if (!hm::is_psd(cov, d, f32)) throw singular_error("Covariance matrix is not positive-definite.");
+            const double k = std::pow(N, -2.0 / (D + 4.0));
+            for (int i = 0; i < d * d; ++i) out[i] = k * cov[i];
+        }
+        return;
+    }
+    if (selector != PBN_SEL_NORMAL_REFERENCE) throw invalid_error("pbn_bandwidth: unknown selector");
+    // kde/NormalReferenceRule.hpp:12-59 (pre-checks), :72-106 (diag), :109-134 (full)
+    if (n <= d) not_enough(kind == PBN_BW_DIAG ? "Diagonal bandwidth matrix" : "Bandwidth matrix");
+    if (!hm::is_psd(cov, d, f32)) throw singular_error("Covariance matrix is not positive-definite.");
+    if (kind == PBN_BW_FULL) {
+        const double k = std::pow(4.0 / (N * (D + 2.0)), 2.0 / (D + 4.0));
+        for (int i = 0; i < d * d; ++i) out[i] = k * cov[i];
+        return;
+    }
+    // Chacon & Duong (2018) eq. 3.4: delta = diag(cov)^-1 cov
+    std::vector<double> delta((size_t)d * d), dinv((size_t)d * d);
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i) delta[i + (size_t)j * d] = cov[i + (size_t)j * d] / cov[i + (size_t)i * d];
+    if (!hm::inverse(delta.data(), d, dinv.data())) throw singular_error("Covariance matrix is not positive-definite.");
+    double tr = 0.0, tr2 = 0.0;
+    for (int i = 0; i < d; ++i) tr += dinv[i + (size_t)i * d];
+    for (int i = 0; i < d; ++i)
+        for (int k2 = 0; k2 < d; ++k2) tr2 += dinv[i + (size_t)k2 * d] * dinv[k2 + (size_t)i * d];
+    const double k = 4.0 * D * std::sqrt(hm::determinant(delta.data(), d)) / (2.0 * tr2 + tr * tr);
+    const double f = std::pow(k / N, 2.0 / (D + 4.0));
+    for (int i = 0; i < d; ++i) out[i] = f * cov[i + (size_t)i * d];
+}
+
+KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n) {
+    const size_t es = dtype_size(dtype);
+    const int64_t ntiles = ceil_div(n, 16);
+    const int KS = (dm + 3) / 4;
+    return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es, cond ? (size_t)ntiles * 64 * es : 0};
+}
+
+void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int kind, bool cond, const double* center) {
+    if (!bw) throw invalid_error("pbn_kde_fit: null bandwidth");
+    if (d <= 0) throw invalid_error("pbn_kde_fit: no variables");
+    if (n <= 0) throw invalid_error("pbn_kde_fit: no training instances");
+    if (cond && d < 2) cond = false;  // CKDE without evidence is a plain KDE (CKDE.hpp:232-241)
+    const int dm = cond ? d - 1 : d;
+    if (dm > 16) throw invalid_error("KDE with more than 16 (+1 conditional) variables is not supported");
+    m.dtype = dtype; m.d = d; m.dm = dm; m.KS = (dm + 3) / 4; m.cond = cond;
+    m.N = n; m.ntiles = ceil_div(n, 16);
+    if (cond) {  // evidence first, variable last
+        for (int i = 0; i < d - 1; ++i) m.perm[i] = i + 1;
+        m.perm[d - 1] = 0;
+    } else {
+        for (int i = 0; i < d; ++i) m.perm[i] = i;
+    }
+    // whitening matrix W (row-major lower) = sqrt(log2 e) * L^-1, with L = chol(P H P^T)
+    m.W.assign((size_t)d * d, 0.0);
+    const double sc = std::sqrt(LOG2E);
+    double logdet_half = 0.0, logdet_half_marg = 0.0;  // sum log L_ii
+    if (kind == PBN_BW_DIAG) {
+        for (int i = 0; i < d; ++i) {
+            const double h = bw[m.perm[i]];
+            if (!(h > 0.0) || !std::isfinite(h)) throw singular_error("ProductKDE: bandwidth must be positive");
+            m.W[(size_t)i * d + i] = sc / std::sqrt(h);
+            logdet_half += 0.5 * std::log(h);
+            if (i < dm) logdet_half_marg += 0.5 * std::log(h);
+        }
+    } else {
+        std::vector<double> H((size_t)d * d), L((size_t)d * d), Li((size_t)d * d);
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i < d; ++i) H[i + (size_t)j * d] = bw[m.perm[i] + (size_t)m.perm[j] * d];
+        if (!hm::cholesky(H.data(), d, L.data())) throw singular_error("KDE: bandwidth matrix is not positive-definite");
+        hm::lower_inverse(L.data(), d, Li.data());
+        for (int i = 0; i < d; ++i) {
+            for (int j = 0; j <= i; ++j) m.W[(size_t)i * d + j] = sc * Li[i + (size_t)j * d];
+            logdet_half += std::log(L[i + (size_t)i * d]);
+            if (i < dm) logdet_half_marg += std::log(L[i + (size_t)i * d]);
+        }
+    }
+    // KDE.hpp:476-477 / ProductKDE.hpp:188-189
+    m.lognorm = -logdet_half - 0.5 * d * LOG_2PI - std::log((double)n);
+    m.lognorm_marg = -logdet_half_marg - 0.5 * dm * LOG_2PI - std::log((double)n);
+    m.mu.assign(d, 0.0);
+    if (center)
+        for (int i = 0; i < d; ++i) m.mu[i] = center[m.perm[i]];
+}
+
+static void fill_pack_common(PackArgs& pa, const pbn_table* t, const int* cols, const KdeModel& m) {
+    pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.dm; pa.KS = m.KS;
+    for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
+    pa.rows = nullptr;
+    for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];
+    for (int i = 0; i < m.d; ++i) pa.mu[i] = m.mu[i];
+}
+
+void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
+                    int64_t row1) {
+    PackArgs pa{};
+    fill_pack_common(pa, t, cols, m);
+    pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
+    pa.is_query = 0;
+    pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
+    KernelTimer kt(ctx, PBN_K_PACK);
+    launch_pack(pa, m.dtype, ctx->stream);
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* s = std::getenv(name);
+    return s && *s ? std::atoi(s) : dflt;
+}
+
+void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
+                      double* dev_logl, double* dev_sum) {
+    check_cols(test, cols, m.d, "pbn_kde_logl");
+    check_range(test, row0, n, "pbn_kde_logl");
+    if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
+    if (test->ctx->device != ctx->device) throw invalid_error("pbn_kde_logl: test table lives on another device");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) {
+        if (dev_sum) HIP_CHECK(hipMemsetAsync(dev_sum, 0, sizeof(double), ctx->stream));
+        return;
+    }
+    const size_t es = dtype_size(m.dtype);
+    const int64_t nqtiles = ceil_div(n, 16);
+    // query fragments in scratch: Bpack | nypack | Bxpack
+    const size_t bpack_b = (size_t)nqtiles * m.KS * 64 * es, ny_b = (size_t)nqtiles * 16 * es,
+                 bx_b = m.cond ? (size_t)nqtiles * 64 * es : 0;
+    ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + 256);
+    char* q = ctx->scratch_q.p;
+    PackArgs pa{};
+    fill_pack_common(pa, test, cols, m);
+    pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles;
+    pa.is_query = 1;
+    pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
+    { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
+
+    // split the training tiles so that the grid is a few waves deep on every CU
+    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond));
+    const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
+    int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));
+    nsplit = std::min<int64_t>(nsplit, 4096);
+    const int64_t tps = ceil_div(m.ntiles, nsplit);
+    nsplit = ceil_div(m.ntiles, tps);
+    const int P = m.cond ? 4 : 2;
+    ctx->scratch_part.reserve((size_t)nsplit * nqtiles * 16 * P * sizeof(double));
+    SweepArgs sa{};
+    sa.Apack = m.Apack; sa.nxpack = m.nxpack; sa.Axpack = m.Axpack;
+    sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack;
+    sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
+    sa.part = (double*)ctx->scratch_part.p;
+    { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, m.dtype, m.KS, m.cond, (int)nsplit, ctx->stream); }
+
+    const int64_t nblocks = ceil_div(n, 256);
+    ctx->scratch_misc.reserve((size_t)nblocks * sizeof(double));
+    FinishArgs fa{};
+    fa.part = sa.part; fa.nsplit = (int)nsplit; fa.nqtiles = nqtiles; fa.nq = n;
+    fa.lognorm = m.lognorm; fa.lognorm_marg = m.lognorm_marg;
+    fa.logl = dev_logl; fa.block_sums = dev_sum ? (double*)ctx->scratch_misc.p : nullptr;
+    { KernelTimer kt(ctx, PBN_K_FINISH); launch_finish(fa, m.cond, dev_sum, ctx->stream); }
+}
+
+}  // namespace pbn

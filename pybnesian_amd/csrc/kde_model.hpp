@@ -1,0 +1,49 @@
+// Non-owning fitted-KDE description shared by the public KDE handles (capi.hip) and the score engine
+// (scoring.hip): host-side whitening/normalisation data + pointers to packed training fragments.
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+
+namespace pbn {
+
+struct KdeModel {
+    int dtype = PBN_F64;
+    int d = 0;         // number of variables
+    int dm = 0;        // dimensions in the main MFMA contraction (d, or d-1 for CKDE)
+    int KS = 0;        // ceil(dm / 4)
+    bool cond = false;
+    int64_t N = 0;
+    int64_t ntiles = 0;
+    double lognorm = 0.0, lognorm_marg = 0.0;
+    int perm[PBN_MAX_D_HOST];  // whitening order -> position in the caller's column list
+    std::vector<double> W, mu; // d x d row-major lower whitening matrix; d centring offsets (whitening order)
+    void* Apack = nullptr;     // device [ntiles][KS][64]
+    void* nxpack = nullptr;    // device [ntiles][16]
+    void* Axpack = nullptr;    // device [ntiles][64] (CKDE only)
+};
+
+// Bytes needed for the three training-side fragment arrays.
+struct KdePackBytes { size_t apack, nxpack, axpack; };
+KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n);
+
+// Host math of KDE::_fit / ProductKDE::_fit / CKDE::_fit: permutation (evidence first for CKDE), Cholesky,
+// whitening matrix, log-normalisation constants.  bw: H (d*d col-major, caller's order) or h (d).
+// center: d offsets in the caller's order.  Throws singular_error when H is not PD.
+void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int kind, bool cond, const double* center);
+
+// Whiten + pack training rows (two contiguous ranges: [row0, row0+n0) ++ [row1, row1 + n - n0)).
+void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
+                    int64_t row1);
+
+// pack(queries) -> sweep -> finish on the context stream; dev_logl / dev_sum nullable (device pointers).
+void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
+                      double* dev_logl, double* dev_sum);
+
+// Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
+void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);
+
+void check_cols(const pbn_table* t, const int* cols, int d, const char* who);
+void check_range(const pbn_table* t, int64_t row0, int64_t n, const char* who);
+
+}  // namespace pbn

@@ -1,0 +1,555 @@
+// Score engine: BIC / BGe / CV-likelihood / hold-out likelihood local scores, batched.
+//
+// Reference (paths under /root/reference/pybnesian/): learning/scores/bic.cpp:12-27, bge.hpp:154-234,
+// bge.cpp:106-144, cv_likelihood.cpp:11-25, holdout_likelihood.cpp:14-23, validated_likelihood.hpp:14-60,
+// learning/parameters/mle_LinearGaussianCPD.hpp:11-221, factors/continuous/LinearGaussianCPD.cpp:92-149,
+// dataset/crossvalidation_adaptator.hpp:15-58, dataset/holdout_adaptator.hpp:17-61.
+//
+// MI355X design (DESIGN.md "score engine"):
+//  * The table is permuted ONCE on device into split order (libstdc++ std::shuffle of std::mt19937{seed},
+//    exactly the reference's fold membership): CV fold f is the contiguous row range [limits[f],
+//    limits[f+1]) and its training set the two ranges around it, so no per-call arrow::Take is needed.
+//  * One f64-MFMA Gram pass per fold gives pilot-shifted moments (N, S, G) of every fold; moments are
+//    additive, so the statistics of "all rows but fold f" are a subtraction.  Every LinearGaussian quantity
+//    (MLE, BIC, BGe, and the Gaussian test log-likelihood of a fold, which is a quadratic form in the test
+//    fold's moments) is then O(p^3) host arithmetic on <= (p+1)^2 numbers: the reference's O(N p^2) QR per
+//    candidate disappears.  (Normal equations instead of column-pivoted QR: see DESIGN.md "numerics".)
+//  * CKDE candidates: bandwidth from the training-fold moments (no extra pass), then per fold
+//    pack(train) -> pack(test) -> fused joint+marginal sweep -> finish, all enqueued on the stream from
+//    scratch arenas; one synchronisation and one D2H of all fold sums per batch.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <random>
+
+#include "common.hpp"
+#include "hostmath.hpp"
+#include "kde_model.hpp"
+#include "stats_kernels.hpp"
+
+using namespace pbn;
+
+namespace {
+
+constexpr double MACHINE_TOL = 1.4901161193847656e-08;  // util/math_constants.hpp:30, sqrt(eps(double))
+constexpr double LOG_2PI = 1.8378770664093454835606594728112;
+constexpr double LOG_PI = 1.1447298858494001741434273513531;
+const double INF = std::numeric_limits<double>::infinity();
+
+struct Stats {  // pilot-shifted moments of a row range over all n columns
+    int64_t N = 0;
+    std::vector<double> S;  // n   : sum_r (x_rc - shift_c)
+    std::vector<double> G;  // n*n : sum_r (x_ri - shift_i)(x_rj - shift_j), col-major symmetric
+    void zero(int n) { N = 0; S.assign(n, 0.0); G.assign((size_t)n * n, 0.0); }
+    void add(const Stats& o) {
+        N += o.N;
+        for (size_t i = 0; i < S.size(); ++i) S[i] += o.S[i];
+        for (size_t i = 0; i < G.size(); ++i) G[i] += o.G[i];
+    }
+};
+
+}  // namespace
+
+struct pbn_scoredata {
+    pbn_ctx* ctx = nullptr;
+    int dtype = PBN_F64;
+    int n = 0;  // columns
+    int split = PBN_SPLIT_NONE;
+    int k = 0;
+    const pbn_table* src = nullptr;  // caller's table (borrowed)
+    pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)
+    const pbn_table* table() const { return perm_table ? perm_table : src; }
+    std::vector<int32_t> perm;    // permuted row -> source row
+    std::vector<int32_t> limits;  // k+1 fold limits inside the CV region
+    int64_t n_cv = 0;             // rows of the CV / training region [0, n_cv)
+    int64_t n_hold = 0;           // hold-out test rows [n_cv, n_cv + n_hold)
+    std::vector<double> shift;    // n pilot shifts
+    dev_buf<double> shift_dev;
+    Stats all;                    // CV / training region
+    std::vector<Stats> fold;      // k
+    Stats hold;                   // hold-out test region
+};
+
+namespace {
+
+// Shifted Gram of up to 64 columns over a contiguous row range -> raw S (d) and G (d*d col-major).
+void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* shift_dev, double* S,
+              double* G) {
+    pbn_ctx* ctx = t->ctx;
+    const int nct = (d + 15) / 16;
+    const int WS = gram_ws(nct);
+    int nblocks = (int)std::min<int64_t>(2 * ctx->num_cus, std::max<int64_t>(1, ceil_div(n, 256)));
+    int64_t rpb = ceil_div(std::max<int64_t>(n, 1), nblocks);
+    rpb = (rpb + 63) / 64 * 64;
+    nblocks = (int)std::max<int64_t>(1, ceil_div(n, rpb));
+    ctx->scratch_red.reserve((size_t)nblocks * WS + WS);
+    double* partial = ctx->scratch_red.p;
+    double* total = partial + (size_t)nblocks * WS;
+    GramArgs a{};
+    a.base = t->data; a.ld = t->ld; a.n_cols = d; a.row0 = row0; a.rows = nullptr; a.n = n;
+    for (int i = 0; i < d; ++i) a.gc.cols[i] = cols[i];
+    a.rows_per_block = rpb; a.shift = shift_dev; a.partial = partial;
+    { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram(a, t->dtype, nblocks, total, ctx->stream); }
+    std::vector<double> h((size_t)WS);
+    HIP_CHECK(hipMemcpyAsync(h.data(), total, (size_t)WS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const double* Sx = h.data() + (WS - nct * 16);
+    for (int i = 0; i < d; ++i) S[i] = Sx[i];
+    int p = 0;
+    for (int I = 0; I < nct; ++I)
+        for (int J = I; J < nct; ++J, ++p) {
+            const double* tile = h.data() + (size_t)p * 256;
+            for (int e = 0; e < 256; ++e) {
+                const int reg = e >> 6, lane = e & 63;
+                const int r = I * 16 + (lane >> 4) + 4 * reg, c = J * 16 + (lane & 15);
+                if (r >= d || c >= d) continue;
+                if (I == J && r > c) continue;  // keep the upper triangle of diagonal tiles
+                G[r + (size_t)c * d] = tile[e];
+                G[c + (size_t)r * d] = tile[e];
+            }
+        }
+}
+
+// Moments of all n columns over [row0, row0 + nrows): blocks of 32 columns, pairs of blocks per launch.
+void compute_stats(const pbn_scoredata* sd, int64_t row0, int64_t nrows, Stats& out) {
+    const int n = sd->n;
+    out.zero(n);
+    out.N = nrows;
+    if (nrows == 0) return;
+    const pbn_table* t = sd->table();
+    if (n <= 64) {
+        std::vector<int> cols(n);
+        std::iota(cols.begin(), cols.end(), 0);
+        gram_raw(t, cols.data(), n, row0, nrows, sd->shift_dev.p, out.S.data(), out.G.data());
+        return;
+    }
+    const int nb = (n + 31) / 32;
+    std::vector<double> S(64), G(64 * 64);
+    for (int bi = 0; bi < nb; ++bi)
+        for (int bj = bi + (nb > 1 ? 1 : 0); bj < nb; ++bj) {
+            std::vector<int> cols;
+            for (int c = bi * 32; c < std::min(n, bi * 32 + 32); ++c) cols.push_back(c);
+            if (bj != bi)
+                for (int c = bj * 32; c < std::min(n, bj * 32 + 32); ++c) cols.push_back(c);
+            const int d = (int)cols.size();
+            gram_raw(t, cols.data(), d, row0, nrows, sd->shift_dev.p, S.data(), G.data());
+            for (int i = 0; i < d; ++i) {
+                out.S[cols[i]] = S[i];
+                for (int j = 0; j < d; ++j) out.G[cols[i] + (size_t)cols[j] * n] = G[i + (size_t)j * d];
+            }
+        }
+}
+
+// means / centred SSE of a column subset from moments.
+void subset_moments(const pbn_scoredata* sd, const Stats& st, const int* cols, int d, double* mu, double* sse) {
+    const int n = sd->n;
+    const double N = (double)st.N;
+    for (int i = 0; i < d; ++i) mu[i] = sd->shift[cols[i]] + (st.N > 0 ? st.S[cols[i]] / N : 0.0);
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i)
+            sse[i + (size_t)j * d] =
+                st.G[cols[i] + (size_t)cols[j] * n] - (st.N > 0 ? st.S[cols[i]] * st.S[cols[j]] / N : 0.0);
+}
+
+void stats_minus(const Stats& a, const Stats& b, Stats& out) {
+    out.N = a.N - b.N;
+    out.S.resize(a.S.size());
+    out.G.resize(a.G.size());
+    for (size_t i = 0; i < a.S.size(); ++i) out.S[i] = a.S[i] - b.S[i];
+    for (size_t i = 0; i < a.G.size(); ++i) out.G[i] = a.G[i] - b.G[i];
+}
+
+// ---- MLE<LinearGaussianCPD> from (N, means, SSE) of [y, x1..xp] (mle_LinearGaussianCPD.hpp:11-221) -----
+// beta: p+1 (intercept first); returns the unbiased variance (inf when N <= p+1).
+double lg_fit(int64_t N, int p, const double* mu, const double* S /* (p+1)^2 col-major */, double* beta) {
+    const int d = p + 1;
+    auto s = [&](int i, int j) { return S[i + (size_t)j * d]; };
+    const double rows = (double)N;
+    if (p == 0) {
+        beta[0] = mu[0];
+        if (N == 1) return INF;
+        return s(0, 0) / (rows - 1);
+    }
+    if (p == 1) {
+        const double var_x = s(1, 1) / (rows - 1);
+        if (var_x < MACHINE_TOL) {
+            beta[0] = mu[0]; beta[1] = 0;
+            return N <= 2 ? INF : s(0, 0) / (rows - 2);
+        }
+        const double b = s(0, 1) / s(1, 1);
+        beta[0] = mu[0] - b * mu[1]; beta[1] = b;
+        if (N <= 2) return INF;
+        const double rss = s(0, 0) - 2 * b * s(0, 1) + b * b * s(1, 1);
+        return std::max(rss, 0.0) / (rows - 2);
+    }
+    if (p == 2) {
+        const double v1 = s(1, 1) / (rows - 1), v2 = s(2, 2) / (rows - 1), c12 = s(1, 2) / (rows - 1);
+        const bool singular1 = v1 < MACHINE_TOL;
+        const bool singular2 = v2 < MACHINE_TOL || std::fabs(c12 / std::sqrt(v1 * v2)) > (1 - MACHINE_TOL);
+        double b1 = 0, b2 = 0;
+        if (singular1) {
+            if (!singular2) b2 = s(0, 2) / s(2, 2);
+        } else if (singular2) {
+            b1 = s(0, 1) / s(1, 1);
+        } else {
+            const double cy1 = s(0, 1) / (rows - 1), cy2 = s(0, 2) / (rows - 1);
+            const double den = v1 * v2 - c12 * c12;
+            b1 = (v2 * cy1 - c12 * cy2) / den;
+            b2 = (cy2 - b1 * c12) / v2;
+        }
+        beta[0] = mu[0] - b1 * mu[1] - b2 * mu[2]; beta[1] = b1; beta[2] = b2;
+        if (N <= 3) return INF;
+        const double rss = s(0, 0) - 2 * b1 * s(0, 1) - 2 * b2 * s(0, 2) + b1 * b1 * s(1, 1) + 2 * b1 * b2 * s(1, 2) +
+                           b2 * b2 * s(2, 2);
+        return std::max(rss, 0.0) / (rows - 3);
+    }
+    // p >= 3: normal equations on the centred moments, diagonally-pivoted Cholesky; a pivot that is not
+    // positive relative to its column's scale marks a dependent column (coefficient 0), the analogue of
+    // the rank decision of ColPivHouseholderQR (mle_LinearGaussianCPD.hpp:171)
+    std::vector<double> A((size_t)p * p), L((size_t)p * p, 0.0), b(p), y(p, 0.0);
+    std::vector<int> piv(p);
+    std::vector<char> dead(p, 0);
+    for (int j = 0; j < p; ++j) {
+        b[j] = s(0, j + 1);
+        for (int i = 0; i < p; ++i) A[i + (size_t)j * p] = s(i + 1, j + 1);
+    }
+    std::iota(piv.begin(), piv.end(), 0);
+    std::vector<double> diag(p);
+    for (int i = 0; i < p; ++i) diag[i] = A[i + (size_t)i * p];
+    // plain (unpivoted order) Cholesky with dependent-column detection
+    for (int j = 0; j < p; ++j) {
+        double sjj = A[j + (size_t)j * p];
+        for (int k2 = 0; k2 < j; ++k2) sjj -= L[j + (size_t)k2 * p] * L[j + (size_t)k2 * p];
+        if (!(sjj > diag[j] * p * 2.220446049250313e-16) || !std::isfinite(sjj)) {
+            dead[j] = 1;
+            L[j + (size_t)j * p] = 1.0;
+            for (int i = j + 1; i < p; ++i) L[i + (size_t)j * p] = 0.0;
+            continue;
+        }
+        const double ljj = std::sqrt(sjj);
+        L[j + (size_t)j * p] = ljj;
+        for (int i = j + 1; i < p; ++i) {
+            double t = A[i + (size_t)j * p];
+            for (int k2 = 0; k2 < j; ++k2) t -= L[i + (size_t)k2 * p] * L[j + (size_t)k2 * p];
+            L[i + (size_t)j * p] = t / ljj;
+        }
+    }
+    for (int i = 0; i < p; ++i) {  // forward
+        if (dead[i]) { y[i] = 0; continue; }
+        double t = b[i];
+        for (int k2 = 0; k2 < i; ++k2) t -= L[i + (size_t)k2 * p] * y[k2];
+        y[i] = t / L[i + (size_t)i * p];
+    }
+    for (int i = p - 1; i >= 0; --i) {  // backward
+        if (dead[i]) { beta[i + 1] = 0; continue; }
+        double t = y[i];
+        for (int k2 = i + 1; k2 < p; ++k2) t -= L[k2 + (size_t)i * p] * beta[k2 + 1];
+        beta[i + 1] = t / L[i + (size_t)i * p];
+    }
+    double b0 = mu[0];
+    for (int j = 0; j < p; ++j) b0 -= beta[j + 1] * mu[j + 1];
+    beta[0] = b0;
+    if (N <= p + 1) return INF;
+    double rss = s(0, 0);
+    for (int j = 0; j < p; ++j) rss -= 2 * beta[j + 1] * s(0, j + 1);
+    for (int j = 0; j < p; ++j)
+        for (int i = 0; i < p; ++i) rss += beta[i + 1] * beta[j + 1] * s(i + 1, j + 1);
+    return std::max(rss, 0.0) / (rows - p - 1);
+}
+
+// BIC of a LinearGaussianCPD (bic.cpp:12-27)
+double bic_lg(int64_t N, int p, double variance) {
+    if (variance < MACHINE_TOL || std::isinf(variance)) return -INF;
+    const double rows = (double)N;
+    const double loglik = 0.5 * (1 + (double)p - rows) - 0.5 * rows * LOG_2PI - rows * 0.5 * std::log(variance);
+    return loglik - std::log(rows) * 0.5 * (p + 2);
+}
+
+// Gaussian log-likelihood of the rows behind `test` moments under (beta, variance)
+// (LinearGaussianCPD.cpp:92-149 summed): -1/2 n log(2 pi var) - RSS / (2 var), RSS as a quadratic form.
+double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const int* cols, int p, const double* beta,
+                             double variance) {
+    const int n = sd->n;
+    const double Nt = (double)test.N;
+    // residual r = (y - s_y) - sum_j beta_j (x_j - s_j) - c,  c = beta0 - s_y + sum_j beta_j s_j
+    double c = beta[0] - sd->shift[cols[0]];
+    for (int j = 1; j <= p; ++j) c += beta[j] * sd->shift[cols[j]];
+    auto G = [&](int i, int j) { return test.G[cols[i] + (size_t)cols[j] * n]; };
+    double rss = G(0, 0);
+    double lin = test.S[cols[0]];
+    for (int j = 1; j <= p; ++j) {
+        rss -= 2 * beta[j] * G(0, j);
+        lin -= beta[j] * test.S[cols[j]];
+    }
+    for (int i = 1; i <= p; ++i)
+        for (int j = 1; j <= p; ++j) rss += beta[i] * beta[j] * G(i, j);
+    rss += -2 * c * lin + Nt * c * c;
+    rss = std::max(rss, 0.0);
+    return -0.5 * Nt * (std::log(variance) + LOG_2PI) - 0.5 * rss / variance;
+}
+
+// BGe (bge.hpp:154-234).  params: iss_mu, iss_w, total_nodes, then optionally nu[n] (per table column).
+double bge_score(const pbn_scoredata* sd, const Stats& st, const int* cols, int p, double iss_mu, double iss_w,
+                 int total_nodes, const double* nu_all) {
+    const int d = p + 1;
+    std::vector<double> mu(d), sse((size_t)d * d);
+    subset_moments(sd, st, cols, d, mu.data(), sse.data());
+    const double N = (double)st.N;
+    const double t = iss_mu * (iss_w - total_nodes - 1) / (iss_mu + 1);
+    double logprob = 0.5 * (std::log(iss_mu) - std::log(N + iss_mu));
+    logprob += std::lgamma(0.5 * (N + iss_w - total_nodes + p + 1)) - std::lgamma(0.5 * (iss_w - total_nodes + p + 1));
+    logprob -= 0.5 * N * LOG_PI;
+    std::vector<double> diff(d);
+    for (int i = 0; i < d; ++i) diff[i] = nu_all ? mu[i] - nu_all[cols[i]] : 0.0;
+    const double cte_r = (N * iss_mu) / (N + iss_mu);
+    if (p == 0) {
+        logprob += 0.5 * (iss_w - total_nodes + 1) * std::log(t);
+        const double r = t + sse[0] + cte_r * diff[0] * diff[0];
+        logprob -= 0.5 * (N + iss_w - total_nodes + 1) * std::log(r);
+        return logprob;
+    }
+    logprob += 0.5 * (iss_w - total_nodes + 2 * p + 1) * std::log(t);
+    std::vector<double> R((size_t)d * d), Rp((size_t)p * p);
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i) R[i + (size_t)j * d] = sse[i + (size_t)j * d] + (i == j ? t : 0.0) + cte_r * diff[i] * diff[j];
+    for (int j = 0; j < p; ++j)
+        for (int i = 0; i < p; ++i) Rp[i + (size_t)j * p] = R[(i + 1) + (size_t)(j + 1) * d];
+    logprob -= 0.5 * (N + iss_w - total_nodes + p + 1) * std::log(hm::determinant(R.data(), d));
+    logprob += 0.5 * (N + iss_w - total_nodes + p) * std::log(hm::determinant(Rp.data(), p));
+    return logprob;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
+                         pbn_scoredata** out) {
+    return guarded([&] {
+        if (!ctx || !table || !out) throw invalid_error("pbn_scoredata_create: null argument");
+        if (table->n_cols <= 0) throw invalid_error("pbn_scoredata_create: table has no columns");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        auto sd = std::make_unique<pbn_scoredata>();
+        sd->ctx = ctx; sd->dtype = table->dtype; sd->n = table->n_cols; sd->split = split; sd->src = table;
+        const int64_t rows = table->n_rows;
+        std::vector<int32_t> idx((size_t)rows);
+        std::iota(idx.begin(), idx.end(), 0);
+        sd->n_cv = rows;
+        if (split == PBN_SPLIT_HOLDOUT || split == PBN_SPLIT_VALIDATED) {
+            // holdout_adaptator.hpp:24-61
+            if (test_ratio <= 0 || test_ratio >= 1.0) throw invalid_error("test_ratio must be a number between 0 and 1.");
+            std::mt19937 rng{seed};
+            std::shuffle(idx.begin(), idx.end(), rng);
+            const int64_t test_rows = (int64_t)std::round((double)rows * test_ratio);
+            const int64_t train_rows = rows - test_rows;
+            if (test_rows == 0 || train_rows == 0)
+                throw invalid_error("Wrong test_ratio (" + std::to_string(test_ratio) + "selected for HoldOut.\nGenerated train instances: " +
+                                    std::to_string(train_rows) + "\nGenerated test instances: " + std::to_string(test_rows));
+            sd->n_cv = train_rows;
+            sd->n_hold = test_rows;
+        }
+        if (split == PBN_SPLIT_CV || split == PBN_SPLIT_VALIDATED) {
+            // crossvalidation_adaptator.hpp:17-57 on the (hold-out) training part; for VALIDATED the CV object is
+            // built on training_data() with the same seed (validated_likelihood.hpp:19-20)
+            const int64_t n = sd->n_cv;
+            if (k <= 1 || k > n)
+                throw invalid_error("Cannot split " + std::to_string(n) + " instances into " + std::to_string(k) + " folds.");
+            std::vector<int32_t> local((size_t)n);
+            std::iota(local.begin(), local.end(), 0);
+            std::mt19937 rng{seed};
+            std::shuffle(local.begin(), local.end(), rng);
+            std::vector<int32_t> tmp(idx.begin(), idx.begin() + n);
+            for (int64_t i = 0; i < n; ++i) idx[i] = tmp[local[i]];
+            const int fold_size = (int)(n / k), extra = (int)(n % k);
+            sd->k = k;
+            sd->limits.assign(1, 0);
+            int cur = 0;
+            for (int i = 0; i < extra; ++i) { cur += fold_size + 1; sd->limits.push_back(cur); }
+            for (int i = extra; i < k; ++i) { cur += fold_size; sd->limits.push_back(cur); }
+        }
+        sd->perm = idx;
+        if (split != PBN_SPLIT_NONE) {
+            pbn_table* pt = nullptr;
+            int rc = pbn_table_take(table, idx.data(), rows, &pt);
+            if (rc != PBN_OK) throw device_error(pbn_last_error());
+            sd->perm_table = pt;
+        }
+        // pilot shifts over the CV region of the (permuted) table
+        const pbn_table* t = sd->table();
+        sd->shift_dev.alloc((size_t)sd->n);
+        for (int c0 = 0; c0 < sd->n; c0 += 64) {
+            GramCols gc{};
+            const int d = std::min(64, sd->n - c0);
+            for (int i = 0; i < d; ++i) gc.cols[i] = c0 + i;
+            launch_pilot(t->data, t->ld, gc, d, 0, nullptr, sd->n_cv, t->dtype, sd->shift_dev.p, ctx->stream);
+        }
+        sd->shift.resize(sd->n);
+        HIP_CHECK(hipMemcpyAsync(sd->shift.data(), sd->shift_dev.p, sd->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // moments
+        if (sd->k > 0) {
+            sd->fold.resize(sd->k);
+            sd->all.zero(sd->n);
+            for (int f = 0; f < sd->k; ++f) {
+                compute_stats(sd.get(), sd->limits[f], sd->limits[f + 1] - sd->limits[f], sd->fold[f]);
+                sd->all.add(sd->fold[f]);
+            }
+        } else {
+            compute_stats(sd.get(), 0, sd->n_cv, sd->all);
+        }
+        if (sd->n_hold > 0) compute_stats(sd.get(), sd->n_cv, sd->n_hold, sd->hold);
+        *out = sd.release();
+    });
+}
+
+void pbn_scoredata_destroy(pbn_scoredata* sd) {
+    if (!sd) return;
+    if (sd->perm_table) pbn_table_destroy(sd->perm_table);
+    delete sd;
+}
+
+int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold) {
+    return guarded([&] {
+        if (!sd) throw invalid_error("pbn_scoredata_layout: null argument");
+        if (perm) std::memcpy(perm, sd->perm.data(), sd->perm.size() * sizeof(int32_t));
+        if (limits && sd->k > 0) std::memcpy(limits, sd->limits.data(), sd->limits.size() * sizeof(int32_t));
+        if (n_cv) *n_cv = sd->n_cv;
+        if (n_hold) *n_hold = sd->n_hold;
+    });
+}
+
+// MLE<LinearGaussianCPD>::estimate over the CV/training region (all rows for PBN_SPLIT_NONE).
+int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, double* beta, double* variance) {
+    return guarded([&] {
+        if (!sd || !beta || !variance) throw invalid_error("pbn_lg_fit: null argument");
+        std::vector<int> cols(p + 1);
+        cols[0] = var;
+        for (int i = 0; i < p; ++i) cols[i + 1] = parents[i];
+        for (int c : cols)
+            if (c < 0 || c >= sd->n) throw invalid_error("pbn_lg_fit: column out of range");
+        std::vector<double> mu(p + 1), sse((size_t)(p + 1) * (p + 1));
+        subset_moments(sd, sd->all, cols.data(), p + 1, mu.data(), sse.data());
+        *variance = lg_fit(sd->all.N, p, mu.data(), sse.data(), beta);
+    });
+}
+
+int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
+                    const int* parents, const double* params, int n_params, double* out) {
+    return guarded([&] {
+        if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
+        pbn_ctx* ctx = sd->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if ((kind == PBN_SCORE_CVLIK) && sd->k <= 0) throw invalid_error("pbn_score_batch: score data has no CV folds");
+        if ((kind == PBN_SCORE_HOLDOUT) && sd->n_hold <= 0) throw invalid_error("pbn_score_batch: score data has no hold-out split");
+        const pbn_table* t = sd->table();
+        // BGe parameters
+        double iss_mu = 1, iss_w = sd->n + 2;
+        int total_nodes = sd->n;
+        const double* nu = nullptr;
+        if (kind == PBN_SCORE_BGE) {
+            if (n_params >= 1) iss_mu = params[0];
+            if (n_params >= 2) iss_w = params[1];
+            if (n_params >= 3) total_nodes = (int)params[2];
+            if (n_params >= 3 + sd->n) nu = params + 3;
+        }
+        struct Pending { int cand; int unit0; int units; };
+        std::vector<Pending> pending;
+        int n_units = 0;
+        Stats train;
+        std::vector<int> cols;
+        std::vector<double> mu, sse, beta, H;
+        for (int c = 0; c < n_cand; ++c) {
+            const int p = par_off[c + 1] - par_off[c];
+            const int d = p + 1;
+            cols.resize(d);
+            cols[0] = var[c];
+            for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
+            for (int cc : cols)
+                if (cc < 0 || cc >= sd->n) throw invalid_error("pbn_score_batch: column out of range");
+            const int nt = node_type ? node_type[c] : PBN_NODE_LG;
+            mu.resize(d); sse.resize((size_t)d * d); beta.resize(d);
+            if (kind == PBN_SCORE_BIC) {
+                if (nt != PBN_NODE_LG) throw invalid_error("BIC: only LinearGaussianCPD node types are implemented on device");
+                subset_moments(sd, sd->all, cols.data(), d, mu.data(), sse.data());
+                const double v = lg_fit(sd->all.N, p, mu.data(), sse.data(), beta.data());
+                out[c] = bic_lg(sd->all.N, p, v);
+                continue;
+            }
+            if (kind == PBN_SCORE_BGE) {
+                out[c] = bge_score(sd, sd->all, cols.data(), p, iss_mu, iss_w, total_nodes, nu);
+                continue;
+            }
+            const bool cv = kind == PBN_SCORE_CVLIK;
+            const int units = cv ? sd->k : 1;
+            if (nt == PBN_NODE_LG) {
+                double acc = 0.0;
+                for (int f = 0; f < units; ++f) {
+                    const Stats* tr = &sd->all;
+                    const Stats* te = &sd->hold;
+                    if (cv) { stats_minus(sd->all, sd->fold[f], train); tr = &train; te = &sd->fold[f]; }
+                    subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
+                    const double v = lg_fit(tr->N, p, mu.data(), sse.data(), beta.data());
+                    acc += lg_slogl_from_moments(sd, *te, cols.data(), p, beta.data(), v);
+                }
+                out[c] = acc;
+                continue;
+            }
+            if (nt != PBN_NODE_CKDE) throw invalid_error("pbn_score_batch: unknown node type");
+            // CKDE: enqueue fit + slogl per unit from scratch arenas
+            ctx->scratch_misc.reserve(1);  // touched by kde_eval_enqueue
+            pending.push_back({c, n_units, units});
+            n_units += units;
+        }
+        if (!pending.empty()) {
+            dev_buf<double> dsums((size_t)n_units);
+            HIP_CHECK(hipMemsetAsync(dsums.p, 0, (size_t)n_units * sizeof(double), ctx->stream));
+            for (const Pending& pd : pending) {
+                const int c = pd.cand;
+                const int p = par_off[c + 1] - par_off[c];
+                const int d = p + 1;
+                cols.resize(d);
+                cols[0] = var[c];
+                for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
+                mu.resize(d); sse.resize((size_t)d * d); H.resize((size_t)d * d);
+                for (int f = 0; f < pd.units; ++f) {
+                    const bool cv = kind == PBN_SCORE_CVLIK;
+                    const Stats* tr = &sd->all;
+                    int64_t row0 = 0, n0 = sd->n_cv, row1 = 0, te0 = sd->n_cv, te_n = sd->n_hold;
+                    if (cv) {
+                        stats_minus(sd->all, sd->fold[f], train);
+                        tr = &train;
+                        n0 = sd->limits[f]; row1 = sd->limits[f + 1];
+                        te0 = sd->limits[f]; te_n = sd->limits[f + 1] - sd->limits[f];
+                    }
+                    subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
+                    const double inv = 1.0 / (double)(tr->N - 1);
+                    for (auto& x : sse) x *= inv;  // covariance
+                    bandwidth_from_cov(PBN_SEL_NORMAL_REFERENCE, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
+                    KdeModel m;
+                    kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
+                    const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
+                    ctx->scratch_train.reserve(pb.apack + pb.nxpack + pb.axpack + 768);
+                    char* base = ctx->scratch_train.p;
+                    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+                    m.Apack = base;
+                    m.nxpack = base + align(pb.apack);
+                    m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
+                    kde_pack_train(ctx, m, t, cols.data(), row0, n0, row1);
+                    kde_eval_enqueue(ctx, m, t, cols.data(), te0, te_n, nullptr, dsums.p + pd.unit0 + f);
+                }
+            }
+            std::vector<double> hs((size_t)n_units);
+            HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, (size_t)n_units * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (const Pending& pd : pending) {
+                double acc = 0.0;
+                for (int f = 0; f < pd.units; ++f) acc += hs[pd.unit0 + f];
+                out[pd.cand] = acc;
+            }
+        }
+    });
+}
+
+}  // extern "C"

@@ -12,7 +12,8 @@
 // kq = lane>>4) reads rows 4kq..4kq+3 of column 16*I + c; k-step j of the chunk multiplies, for every
 // column-tile pair I <= J, A[i][k] = x[row 4k+j][col 16I+i] with B[k][jj] = x[row 4k+j][col 16J+jj].
 // Row order inside the contraction is irrelevant, so no transpose through LDS is needed.
-// Numerics: values are shifted by a per-column pilot mean (mean of the first <=1024 rows) before the
+// Numerics: values are shifted by a per-column pilot mean (mean of the first <=1024 rows; the shift array
+// is indexed by TABLE column so that Grams of different row ranges / column subsets are additive) before the
 // products, so  SSE = G_shift - S S^T / N  has no catastrophic cancellation (S = shifted column sums).
 #include "common.hpp"
 #include "stats_kernels.hpp"
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void pilot_mean_kernel(const void* base, int64
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) shift[c] = m > 0 ? red[0] / (double)m : 0.0;
+    if (threadIdx.x == 0) shift[gc.cols[c]] = m > 0 ? red[0] / (double)m : 0.0;  // indexed by TABLE column
 }
 
 template <int NCT>
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
         cvalid[I] = ci < a.n_cols;
         const int src = cvalid[I] ? a.gc.cols[ci] : a.gc.cols[0];
         colp[I] = (const T*)a.base + (int64_t)src * a.ld + (GATHER ? 0 : a.row0);
-        sh[I] = cvalid[I] ? a.shift[ci] : 0.0;
+        sh[I] = cvalid[I] ? a.shift[src] : 0.0;
     }
 
     d4 acc[NP];

@@ -19,7 +19,7 @@ struct GramArgs {
     const int32_t* rows;  // device gather list or null
     int64_t n;            // number of rows
     int64_t rows_per_block;
-    const double* shift;  // device, n_cols pilot means
+    const double* shift;  // device, pilot means indexed by TABLE column id
     double* partial;      // device, [nblocks][gram_ws(nct)]
 };
 

@@ -1,0 +1,202 @@
+"""Minimal Bayesian-network model surface needed by the score / hill-climbing path.
+
+Only what `Score.local_score`, the operator sets and `GreedyHillClimbing` touch in the reference
+(/root/reference/pybnesian/models/BayesianNetwork.hpp:29-145,571-577,662-681, SemiparametricBN.hpp:93-119,
+graph/generic_graph.hpp:2711-2745): an ordered node list, a DAG with the reference's add / flip legality
+predicates, and a node-type table (LinearGaussianCPD / CKDE).  Everything else of `models/` is out of scope.
+"""
+
+
+class FactorType:
+    _name = "FactorType"
+
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __hash__(self):
+        return hash(type(self).__name__)
+
+    def __str__(self):
+        return self._name
+
+    __repr__ = __str__
+
+
+class LinearGaussianCPDType(FactorType):
+    _name = "LinearGaussianFactor"
+
+
+class CKDEType(FactorType):
+    _name = "CKDEFactor"
+
+
+class BayesianNetworkType:
+    _name = "BayesianNetworkType"
+    homogeneous = True
+    default_type = LinearGaussianCPDType()
+
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __str__(self):
+        return self._name
+
+
+class GaussianNetworkType(BayesianNetworkType):
+    _name = "GaussianNetworkType"
+
+
+class KDENetworkType(BayesianNetworkType):
+    _name = "KDENetworkType"
+    default_type = CKDEType()
+
+
+class SemiparametricBNType(BayesianNetworkType):
+    _name = "SemiparametricBNType"
+    homogeneous = False
+
+
+class BayesianNetwork:
+    def __init__(self, bn_type, nodes, arcs=(), node_types=()):
+        if nodes and isinstance(nodes[0], (tuple, list)) and not arcs:
+            # constructed from arcs only: nodes in order of first appearance
+            arcs = nodes
+            seen = []
+            for s, t in arcs:
+                for x in (s, t):
+                    if x not in seen:
+                        seen.append(x)
+            nodes = seen
+        self._type = bn_type
+        self._nodes = list(nodes)
+        if len(set(self._nodes)) != len(self._nodes):
+            raise ValueError("Nodes must be unique.")
+        self._index = {n: i for i, n in enumerate(self._nodes)}
+        self._parents = {n: [] for n in self._nodes}
+        self._children = {n: [] for n in self._nodes}
+        self._types = {n: bn_type.default_type for n in self._nodes}
+        for n, t in node_types:
+            self.set_node_type(n, t)
+        for s, t in arcs:
+            self.add_arc(s, t)
+
+    # -- structure -----------------------------------------------------------------------------------
+    def type(self):
+        return self._type
+
+    def nodes(self):
+        return list(self._nodes)
+
+    def num_nodes(self):
+        return len(self._nodes)
+
+    def index(self, node):
+        return self._index[node]
+
+    def name(self, idx):
+        return self._nodes[idx]
+
+    def contains_node(self, node):
+        return node in self._index
+
+    def arcs(self):
+        return [(p, n) for n in self._nodes for p in self._parents[n]]
+
+    def num_arcs(self):
+        return sum(len(v) for v in self._parents.values())
+
+    def parents(self, node):
+        return list(self._parents[node])
+
+    def num_parents(self, node):
+        return len(self._parents[node])
+
+    def children(self, node):
+        return list(self._children[node])
+
+    def has_arc(self, source, target):
+        return source in self._parents[target]
+
+    def has_path(self, source, target):
+        seen, stack = {source}, [source]
+        while stack:
+            u = stack.pop()
+            for c in self._children[u]:
+                if c == target:
+                    return True
+                if c not in seen:
+                    seen.add(c)
+                    stack.append(c)
+        return False
+
+    def can_add_arc(self, source, target):
+        return source != target and (
+            not self._parents[source] or not self._children[target] or not self.has_path(target, source)
+        )
+
+    def can_flip_arc(self, source, target):
+        if source == target:
+            return False
+        if self.has_arc(source, target):
+            if len(self._parents[target]) == 1 or len(self._children[source]) == 1:
+                return True
+            self._children[source].remove(target)
+            try:
+                return not self.has_path(source, target)
+            finally:
+                self._children[source].append(target)
+        if not self._parents[target] or not self._children[source]:
+            return True
+        return not self.has_path(source, target)
+
+    def add_arc(self, source, target):
+        if source not in self._index or target not in self._index:
+            raise ValueError("Node not present in the Bayesian network.")
+        if self.has_arc(source, target):
+            return
+        if not self.can_add_arc(source, target):
+            raise ValueError(f"Cannot add arc {source} -> {target}: it would create a cycle.")
+        self._parents[target].append(source)
+        self._children[source].append(target)
+
+    def remove_arc(self, source, target):
+        if self.has_arc(source, target):
+            self._parents[target].remove(source)
+            self._children[source].remove(target)
+
+    def flip_arc(self, source, target):
+        if self.has_arc(source, target):
+            self.remove_arc(source, target)
+            self.add_arc(target, source)
+
+    # -- node types -----------------------------------------------------------------------------------
+    def node_type(self, node):
+        return self._types[node]
+
+    def node_types(self):
+        return dict(self._types)
+
+    def set_node_type(self, node, node_type):
+        if self._type.homogeneous and node_type != self._type.default_type:
+            raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
+        self._types[node] = node_type
+
+    def clone(self):
+        return BayesianNetwork(self._type, self._nodes, self.arcs(), list(self._types.items()))
+
+    def __str__(self):
+        return f"{self._type} with {self.num_nodes()} nodes and {self.num_arcs()} arcs"
+
+
+def GaussianNetwork(nodes, arcs=()):
+    return BayesianNetwork(GaussianNetworkType(), nodes, arcs)
+
+
+def KDENetwork(nodes, arcs=()):
+    return BayesianNetwork(KDENetworkType(), nodes, arcs)
+
+
+def SemiparametricBN(nodes, arcs=(), node_types=()):
+    if arcs and isinstance(arcs[0], (tuple, list)) and len(arcs[0]) == 2 and isinstance(arcs[0][1], FactorType):
+        node_types, arcs = arcs, ()
+    return BayesianNetwork(SemiparametricBNType(), nodes, arcs, node_types)

@@ -1,0 +1,219 @@
+"""Scores of the hot path — BIC, BGe, CVLikelihood, HoldoutLikelihood, ValidatedLikelihood — with the
+reference's Python surface (/root/reference/pybnesian/pybindings/pybindings_learning/
+pybindings_scores.cpp:20-180,460-660) on top of the batched HIP score engine (pbn_score_batch).
+
+The table is uploaded once; splits are generated on the library side with libstdc++'s std::shuffle so that
+fold membership equals the reference's CrossValidation / HoldOut (dataset/crossvalidation_adaptator.hpp,
+holdout_adaptator.hpp).  Tables with nulls are not accepted by the device engine yet.
+"""
+import ctypes as C
+import random
+
+import numpy as np
+
+from . import _lib
+from .dataset import DeviceTable, as_record_batch, default_context
+from .models import CKDEType, GaussianNetworkType, KDENetworkType, LinearGaussianCPDType, SemiparametricBNType
+
+_TYPE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE}
+
+
+def _random_seed():
+    return random.SystemRandom().randrange(0, 2 ** 32)  # std::random_device{}()
+
+
+class Score:
+    _kind = None
+    _split = _lib.PBN_SPLIT_NONE
+    _allowed_types = (LinearGaussianCPDType(),)
+
+    def __init__(self, df, split_args=(0, 0, 0.0), ctx=None, table=None):
+        self._ctx = ctx or (table.ctx if table is not None else default_context())
+        if table is None:
+            rb = as_record_batch(df)
+            names = [f.name for f in rb.schema]
+            if any(rb.column(i).null_count for i in range(rb.num_columns)):
+                raise ValueError("The device score engine does not accept tables with nulls yet.")
+            table, _ = DeviceTable.from_dataframe(self._ctx, rb, names, drop_null=False)
+            self._df = rb
+        else:
+            self._df = None
+        self._table = table
+        self._names = list(table.names)
+        self._col = {n: i for i, n in enumerate(self._names)}
+        k, seed, ratio = split_args
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
+                                                    float(ratio), C.byref(h)))
+        self._handle = h
+        self._params = np.zeros(0)
+
+    # -- reference surface -------------------------------------------------------------------------------
+    def data(self):
+        return self._df
+
+    def has_variables(self, variables):
+        if isinstance(variables, str):
+            variables = [variables]
+        return all(v in self._col for v in variables)
+
+    def compatible_bn(self, model):
+        return self.has_variables(model.nodes())
+
+    def local_score(self, model, variable, evidence=None):
+        evidence = model.parents(variable) if evidence is None else list(evidence)
+        return self._batch(model, [(variable, model.node_type(variable), evidence)], self._kind)[0]
+
+    def local_score_node_type(self, model, variable_type, variable, evidence):
+        return self._batch(model, [(variable, variable_type, list(evidence))], self._kind)[0]
+
+    def score(self, model):
+        """Score::score (scores.hpp:17-24): sum of the local scores."""
+        cands = [(n, model.node_type(n), model.parents(n)) for n in model.nodes()]
+        return float(np.sum(self._batch(model, cands, self._kind)))
+
+    # -- batched engine entry ---------------------------------------------------------------------------------
+    def _encode(self, cands):
+        var, ntype, off, par = [], [], [0], []
+        for v, t, ev in cands:
+            if t not in self._allowed_types:
+                raise ValueError(f"Node type \"{t}\" not valid for score {type(self).__name__}")
+            var.append(self._col[v])
+            ntype.append(_TYPE_CODE[t])
+            par.extend(self._col[e] for e in ev)
+            off.append(len(par))
+        return var, ntype, off, par
+
+    def _batch(self, model, cands, kind):
+        var, ntype, off, par = self._encode(cands)
+        return self._batch_raw(model, var, ntype, off, par, kind)
+
+    def _batch_raw(self, model, var, ntype, off, par, kind):
+        n = len(var)
+        out = np.zeros(n)
+        if n == 0:
+            return out
+        params = self._batch_params(model)
+        _lib.check(_lib.load().pbn_score_batch(self._handle, kind, n, _lib.int_array(var), _lib.int_array(ntype),
+                                               _lib.int_array(off), _lib.int_array(par if par else [0]),
+                                               _lib.dptr(params) if params.size else None, int(params.size), _lib.dptr(out)))
+        return out
+
+    def _batch_params(self, model):
+        return self._params
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                _lib.load().pbn_scoredata_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+class BIC(Score):
+    """learning/scores/bic.cpp:12-27,108-142 (LinearGaussianCPD nodes)."""
+
+    _kind = _lib.PBN_SCORE_BIC
+
+    def __init__(self, df, ctx=None, table=None):
+        super().__init__(df, ctx=ctx, table=table)
+
+    def mle_lg(self, variable, evidence):
+        """MLE<LinearGaussianCPD>::estimate on this score's table: (beta, variance)."""
+        beta = np.zeros(len(evidence) + 1)
+        var = C.c_double(0.0)
+        _lib.check(_lib.load().pbn_lg_fit(self._handle, self._col[variable], _lib.int_array([self._col[e] for e in evidence] or [0]),
+                                          len(evidence), _lib.dptr(beta), C.byref(var)))
+        return beta, var.value
+
+
+class BGe(Score):
+    """learning/scores/bge.hpp:14-234.  BGe(df, iss_mu=1, iss_w=None, nu=None)."""
+
+    _kind = _lib.PBN_SCORE_BGE
+
+    def __init__(self, df, iss_mu=1.0, iss_w=None, nu=None, ctx=None, table=None):
+        super().__init__(df, ctx=ctx, table=table)
+        ncols = len(self._names)
+        if iss_w is not None and iss_w <= ncols - 1:
+            raise ValueError(f"Imaginary sample size for Wishart prior must be greater than  num_columns - 1 ({ncols - 1}).")
+        if nu is not None and len(nu) != ncols:
+            raise ValueError(f"\"nu\" argument contains {len(nu)} elements, but DataFrame \"df\" contains {ncols} columns.")
+        self._iss_mu = float(iss_mu)
+        self._iss_w = float(ncols + 2 if iss_w is None else iss_w)
+        self._nu = None if nu is None else np.asarray(nu, dtype=np.float64)
+
+    def _batch_params(self, model):
+        head = [self._iss_mu, self._iss_w, float(model.num_nodes())]
+        if self._nu is None:
+            return np.asarray(head)
+        return np.concatenate([head, self._nu])
+
+
+class _LikelihoodScore(Score):
+    _allowed_types = (LinearGaussianCPDType(), CKDEType())
+
+
+class CVLikelihood(_LikelihoodScore):
+    """learning/scores/cv_likelihood.cpp:5-25.  CVLikelihood(df, k=10, seed=None)."""
+
+    _kind = _lib.PBN_SCORE_CVLIK
+    _split = _lib.PBN_SPLIT_CV
+
+    def __init__(self, df, k=10, seed=None, ctx=None, table=None):
+        self._k = int(k)
+        self._seed = _random_seed() if seed is None else int(seed)
+        super().__init__(df, (self._k, self._seed, 0.0), ctx=ctx, table=table)
+
+    def fold_layout(self):
+        """(perm, limits): source row of every permuted row and the k+1 fold limits."""
+        n = self._table.num_rows
+        perm = np.zeros(n, dtype=np.int32)
+        limits = np.zeros(self._k + 1, dtype=np.int32)
+        _lib.check(_lib.load().pbn_scoredata_layout(self._handle, perm.ctypes.data, limits.ctypes.data, None, None))
+        return perm, limits
+
+
+class HoldoutLikelihood(_LikelihoodScore):
+    """learning/scores/holdout_likelihood.cpp:8-23.  HoldoutLikelihood(df, test_ratio=0.2, seed=None)."""
+
+    _kind = _lib.PBN_SCORE_HOLDOUT
+    _split = _lib.PBN_SPLIT_HOLDOUT
+
+    def __init__(self, df, test_ratio=0.2, seed=None, ctx=None, table=None):
+        self._seed = _random_seed() if seed is None else int(seed)
+        super().__init__(df, (0, self._seed, float(test_ratio)), ctx=ctx, table=table)
+
+
+class ValidatedLikelihood(_LikelihoodScore):
+    """learning/scores/validated_likelihood.hpp:12-75: local_score = CV over the hold-out training part,
+    vlocal_score = hold-out likelihood; the same seed drives both splits."""
+
+    _kind = _lib.PBN_SCORE_CVLIK
+    _split = _lib.PBN_SPLIT_VALIDATED
+    validated = True
+
+    def __init__(self, df, test_ratio=0.2, k=10, seed=None, ctx=None, table=None):
+        self._seed = _random_seed() if seed is None else int(seed)
+        super().__init__(df, (int(k), self._seed, float(test_ratio)), ctx=ctx, table=table)
+
+    def vlocal_score(self, model, variable, evidence=None):
+        evidence = model.parents(variable) if evidence is None else list(evidence)
+        return self._batch(model, [(variable, model.node_type(variable), evidence)], _lib.PBN_SCORE_HOLDOUT)[0]
+
+    def vlocal_score_node_type(self, model, variable_type, variable, evidence):
+        return self._batch(model, [(variable, variable_type, list(evidence))], _lib.PBN_SCORE_HOLDOUT)[0]
+
+    def vscore(self, model):
+        cands = [(n, model.node_type(n), model.parents(n)) for n in model.nodes()]
+        return float(np.sum(self._batch(model, cands, _lib.PBN_SCORE_HOLDOUT)))
+
+
+def default_score(bn_type, df, seed=None, num_folds=10, test_holdout_ratio=0.2):
+    """util/validate_options.cpp:16-58: Gaussian -> BIC; semiparametric / KDE networks -> ValidatedLikelihood."""
+    if isinstance(bn_type, GaussianNetworkType):
+        return BIC(df)
+    if isinstance(bn_type, (SemiparametricBNType, KDENetworkType)):
+        return ValidatedLikelihood(df, test_holdout_ratio, num_folds, seed)
+    raise ValueError("Default score not defined for this Bayesian network type.")
