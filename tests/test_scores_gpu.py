@@ -1,0 +1,201 @@
+"""GPU tier: BIC / BGe / CVLikelihood / HoldoutLikelihood / ValidatedLikelihood local scores and the
+MLE<LinearGaussianCPD> fit from device Gram moments, against the golden numpy recipes of the reference tests
+(bic_test.py, mle_test.py), the CPU oracle (QR-based, data-level restatement) and - for BGe, which has no
+reference test - an independent numpy transcription of bge.hpp:154-234 written here."""
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy.special import gammaln
+
+from helpers import CKDE_SETS, COLS, RTOL_F64, frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+FULL_ARCS = [("a", "b"), ("a", "c"), ("a", "d"), ("b", "c"), ("b", "d"), ("c", "d")]
+
+
+def numpy_bge(data, total_nodes, iss_mu=1.0, iss_w=None, nu=None):
+    """Independent transcription of BGe::bge_no_parents / bge_parents (bge.hpp:154-234)."""
+    data = np.asarray(data, dtype=np.float64)
+    N, d = data.shape
+    p = d - 1
+    iss_w = total_nodes + 2 if iss_w is None else iss_w
+    mean = data.mean(axis=0)
+    nu = mean if nu is None else np.asarray(nu)
+    c = data - mean
+    sse = c.T @ c
+    t = iss_mu * (iss_w - total_nodes - 1) / (iss_mu + 1)
+    lp = 0.5 * (math.log(iss_mu) - math.log(N + iss_mu))
+    lp += gammaln(0.5 * (N + iss_w - total_nodes + p + 1)) - gammaln(0.5 * (iss_w - total_nodes + p + 1))
+    lp -= 0.5 * N * math.log(math.pi)
+    cte = N * iss_mu / (N + iss_mu)
+    diff = (mean - nu)[:, None]
+    R = sse + t * np.eye(d) + cte * (diff @ diff.T)
+    if p == 0:
+        lp += 0.5 * (iss_w - total_nodes + 1) * math.log(t)
+        return lp - 0.5 * (N + iss_w - total_nodes + 1) * math.log(R[0, 0])
+    lp += 0.5 * (iss_w - total_nodes + 2 * p + 1) * math.log(t)
+    lp -= 0.5 * (N + iss_w - total_nodes + p + 1) * np.linalg.slogdet(R)[1]
+    lp += 0.5 * (N + iss_w - total_nodes + p) * np.linalg.slogdet(R[1:, 1:])[1]
+    return lp
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+def test_mle_and_bic_golden(pbn, golden, variable, evidence):
+    key = variable + "_" + "".join(evidence)
+    df = frame(golden["train10k"])
+    bic = pbn.BIC(df)
+    beta, var = bic.mle_lg(variable, evidence)
+    assert np.allclose(beta, golden[f"lg_beta_{key}"], rtol=1e-7)  # mle_test.py: np.isclose defaults are looser
+    assert np.isclose(var, golden[f"lg_var_{key}"], rtol=1e-8)
+    gbn = pbn.GaussianNetwork(COLS, FULL_ARCS)
+    got = bic.local_score(gbn, variable, evidence)
+    assert abs(got - golden[f"bic_{key}"]) <= RTOL_F64 * abs(golden[f"bic_{key}"])
+    assert bic.local_score(gbn, variable) == bic.local_score(gbn, variable, gbn.parents(variable))
+    if len(evidence) == 3:
+        perm = bic.local_score(gbn, variable, ["b", "c", "a"])
+        assert abs(perm - got) <= 1e-9 * abs(got)
+
+
+def test_bic_score_is_sum_of_local(pbn, golden):
+    df = frame(golden["train10k"])
+    bic = pbn.BIC(df)
+    gbn = pbn.GaussianNetwork(COLS, [("a", "b"), ("b", "c")])
+    assert np.isclose(bic.score(gbn), sum(bic.local_score(gbn, n) for n in COLS), rtol=1e-12)
+
+
+def test_bge_vs_oracle_and_numpy(pbn, golden, oracle):
+    data = golden["train10k"]
+    df = frame(data)
+    gbn = pbn.GaussianNetwork(COLS)
+    bge = pbn.BGe(df)
+    for variable, evidence in CKDE_SETS + [("a", ["d", "c"]), ("c", ["d"])]:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        got = bge.local_score(gbn, variable, evidence)
+        want_np = numpy_bge(data[:, idx], 4)
+        want_or = oracle.bge(data[:, idx], 4)
+        assert abs(got - want_np) <= 1e-9 * abs(want_np)
+        assert abs(got - want_or) <= 1e-9 * abs(want_or)
+    nu = np.array([2.5, 7.0, 15.0, 46.0])
+    bge2 = pbn.BGe(df, iss_mu=2.5, iss_w=9.0, nu=nu)
+    for variable, evidence in CKDE_SETS:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        got = bge2.local_score(gbn, variable, evidence)
+        want = numpy_bge(data[:, idx], 4, 2.5, 9.0, nu[idx])
+        assert abs(got - want) <= 1e-9 * abs(want)
+        assert abs(oracle.bge(data[:, idx], 4, 2.5, 9.0, nu[idx]) - want) <= 1e-9 * abs(want)
+    with pytest.raises(ValueError):
+        pbn.BGe(df, iss_w=2.0)
+
+
+def test_fold_membership_is_the_references(pbn, golden, oracle):
+    """Fold layout generated in the library (libstdc++ shuffle) == the oracle's restatement of
+    CrossValidationProperties, and the known-answer shuffle vector pins both to the reference."""
+    df = frame(golden["train500"])
+    cv = pbn.CVLikelihood(df, 7, 123)
+    perm, limits = cv.fold_layout()
+    assert np.array_equal(perm, oracle.shuffled_indices(500, 123))
+    assert np.array_equal(limits, oracle.cv_limits(500, 7))
+    with pytest.raises(ValueError, match="Cannot split"):
+        pbn.CVLikelihood(df, 1, 0)
+    with pytest.raises(ValueError, match="Cannot split"):
+        pbn.CVLikelihood(df, 501, 0)
+    with pytest.raises(ValueError, match="test_ratio"):
+        pbn.HoldoutLikelihood(df, 1.5, 0)
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+def test_cv_and_holdout_likelihood_lg(pbn, golden, oracle, variable, evidence):
+    data = golden["train10k"][:2000]
+    df = frame(data)
+    idx = [COLS.index(v) for v in [variable] + evidence]
+    gbn = pbn.GaussianNetwork(COLS)
+    cv = pbn.CVLikelihood(df, 10, 0)
+    got = cv.local_score(gbn, variable, evidence)
+    want = oracle.cv_likelihood(data[:, idx], "lg", 10, 0)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+    ho = pbn.HoldoutLikelihood(df, 0.2, 5)
+    got = ho.local_score(gbn, variable, evidence)
+    want = oracle.holdout_likelihood(data[:, idx], "lg", 0.2, 5)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+def test_cv_and_holdout_likelihood_ckde(pbn, golden, oracle, variable, evidence):
+    data = golden["train10k"][:1500]
+    df = frame(data)
+    idx = [COLS.index(v) for v in [variable] + evidence]
+    spbn = pbn.SemiparametricBN(COLS)
+    cv = pbn.CVLikelihood(df, 5, 3)
+    got = cv.local_score_node_type(spbn, pbn.CKDEType(), variable, evidence)
+    want = oracle.cv_likelihood(data[:, idx], "ckde", 5, 3)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+    ho = pbn.HoldoutLikelihood(df, 0.3, 9)
+    got = ho.local_score_node_type(spbn, pbn.CKDEType(), variable, evidence)
+    want = oracle.holdout_likelihood(data[:, idx], "ckde", 0.3, 9)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+
+
+def test_validated_likelihood(pbn, golden, oracle):
+    data = golden["train10k"][:1200]
+    df = frame(data)
+    spbn = pbn.SemiparametricBN(COLS, [], [("c", pbn.CKDEType())])
+    vl = pbn.ValidatedLikelihood(df, 0.2, 5, 11)
+    for variable, evidence in [("c", ["a", "b"]), ("b", ["a"]), ("d", [])]:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        kind = "ckde" if variable == "c" else "lg"
+        got = vl.local_score(spbn, variable, evidence)
+        want = oracle.validated_cv_likelihood(data[:, idx], kind, 0.2, 5, 11)
+        assert abs(got - want) <= RTOL_F64 * abs(want)
+        gotv = vl.vlocal_score(spbn, variable, evidence)
+        wantv = oracle.holdout_likelihood(data[:, idx], kind, 0.2, 11)
+        assert abs(gotv - wantv) <= RTOL_F64 * abs(wantv)
+
+
+def test_wide_table_blocked_gram(pbn, oracle):
+    """More than 64 columns: the Gram is assembled from 32-column block pairs."""
+    rng = np.random.default_rng(5)
+    n, cols = 3000, 70
+    data = rng.normal(size=(n, cols)) @ (np.eye(cols) + 0.2 * np.tril(rng.normal(size=(cols, cols)), -1)).T
+    names = [f"x{i}" for i in range(cols)]
+    df = pd.DataFrame(data, columns=names)
+    bic = pbn.BIC(df)
+    gbn = pbn.GaussianNetwork(names)
+    for var, ev in [(3, [65, 40, 1]), (69, [0, 33, 66, 12, 50]), (10, [])]:
+        got = bic.local_score(gbn, names[var], [names[e] for e in ev])
+        want = oracle.bic_lg(data[:, [var] + ev])
+        assert abs(got - want) <= RTOL_F64 * abs(want)
+
+
+def test_degenerate_branches(pbn, oracle):
+    """Singular parents (mle_LinearGaussianCPD.hpp:37-49,94-120) and BIC = -inf on degenerate variance."""
+    rng = np.random.default_rng(0)
+    n = 500
+    x = rng.normal(size=n)
+    df = pd.DataFrame({"y": 2 * x + rng.normal(scale=0.1, size=n), "x": x, "k": np.full(n, 3.0), "x2": 2 * x, "z": 1.5 * x})
+    bic = pbn.BIC(df)
+    gbn = pbn.GaussianNetwork(list(df.columns))
+    for ev in (["k"], ["x", "k"], ["k", "x"], ["x", "x2"]):
+        got = bic.local_score(gbn, "y", ev)
+        want = oracle.bic_lg(df[["y"] + ev].to_numpy())
+        assert abs(got - want) <= RTOL_F64 * abs(want), ev
+    assert bic.local_score(gbn, "z", ["x"]) == -np.inf  # exact linear function: variance < machine_tol
+    assert bic.local_score(gbn, "k", []) == -np.inf
