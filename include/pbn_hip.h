@@ -146,6 +146,12 @@ int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits
 /* MLE<LinearGaussianCPD>::estimate (learning/parameters/mle_LinearGaussianCPD.hpp:195-221) from the cached
  * moments of the training region: beta has p+1 entries (intercept first). */
 int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, double* beta, double* variance);
+/* The same fit on any row range of a table (one Gram pass): cols[0] is the variable, cols[1..d) the evidence. */
+int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, double* beta, double* variance);
+/* LinearGaussianCPD::logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149,251-292): one streaming
+ * pass; out_logl (n host doubles) and out_slogl are nullable. */
+int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
+                double* out_logl, double* out_slogl);
 /* Score::local_score for a batch of candidates (replaces the serial double loop of
  * learning/operators/operators.cpp:100-132,296-347): candidate c scores column var[c] given
  * parents[par_off[c] .. par_off[c+1]) with node type node_type[c] (NULL = all LinearGaussian). */

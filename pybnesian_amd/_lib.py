@@ -63,6 +63,8 @@ SIGNATURES = {
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_layout": (_int, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_lg_fit": (_int, [_vp, _int, _ip, _int, _dp, _dp]),
+    "pbn_lg_fit_table": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
+    "pbn_lg_logl": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp, _dp]),
     "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
     "pbn_hc_estimate": (_int, [_vp, _vp, _vp, _ip, _ip, _ip, _vp]),
 }

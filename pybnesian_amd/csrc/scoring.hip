@@ -435,6 +435,56 @@ int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, doub
     });
 }
 
+// MLE<LinearGaussianCPD>::estimate on a table row range (one Gram pass + host solve).
+int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, double* beta, double* variance) {
+    return guarded([&] {
+        if (!beta || !variance) throw invalid_error("pbn_lg_fit_table: null output");
+        check_cols(t, cols, d, "pbn_lg_fit_table");
+        check_range(t, row0, n, "pbn_lg_fit_table");
+        if (d < 1 || d > 64) throw invalid_error("pbn_lg_fit_table: between 1 and 64 columns (variable + evidence) are supported");
+        HIP_CHECK(hipSetDevice(t->ctx->device));
+        std::vector<double> mu(d), sse((size_t)d * d);
+        int rc = pbn_table_sse(t, cols, d, row0, n, mu.data(), sse.data());
+        if (rc != PBN_OK) throw device_error(pbn_last_error());
+        *variance = lg_fit(n, d - 1, mu.data(), sse.data(), beta);
+    });
+}
+
+// LinearGaussianCPD::logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149,251-292).
+int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
+                double* out_logl, double* out_slogl) {
+    return guarded([&] {
+        check_cols(t, cols, d, "pbn_lg_logl");
+        check_range(t, row0, n, "pbn_lg_logl");
+        if (!beta) throw invalid_error("pbn_lg_logl: null beta");
+        if (d < 1 || d > 64) throw invalid_error("pbn_lg_logl: between 1 and 64 columns are supported");
+        pbn_ctx* ctx = t->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (n == 0) { if (out_slogl) *out_slogl = 0.0; return; }
+        const int64_t nblocks = ceil_div(n, 256);
+        dev_buf<double> dlogl;
+        if (out_logl) dlogl.alloc((size_t)n);
+        ctx->scratch_misc.reserve((size_t)(nblocks + 1) * sizeof(double));
+        double* bs = (double*)ctx->scratch_misc.p;
+        LgArgs a{};
+        a.base = t->data; a.ld = t->ld; a.p = d - 1; a.row0 = row0; a.n = n;
+        for (int i = 0; i < d; ++i) { a.gc.cols[i] = cols[i]; a.beta[i] = beta[i]; }
+        a.inv_std = 1.0 / std::sqrt(variance);
+        a.cte = -0.5 * std::log(variance) - 0.5 * LOG_2PI;
+        a.logl = dlogl.p; a.block_sums = bs;
+        launch_lg_logl(a, t->dtype, ctx->stream);
+        if (out_logl) HIP_CHECK(hipMemcpyAsync(out_logl, dlogl.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<double> hb((size_t)nblocks);
+        HIP_CHECK(hipMemcpyAsync(hb.data(), bs, (size_t)nblocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (out_slogl) {
+            double s = 0.0;
+            for (double v : hb) s += v;  // fixed order
+            *out_slogl = s;
+        }
+    });
+}
+
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                     const int* parents, const double* params, int n_params, double* out) {
     return guarded([&] {

@@ -193,6 +193,44 @@ void launch_gram(const GramArgs& a, int dtype, int nblocks, double* out, hipStre
     HIP_CHECK(hipGetLastError());
 }
 
+// ---- LinearGaussianCPD logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149), one streaming pass:
+// N*(p+1)*sizeof(T) bytes, 2p+5 flops per row -> HBM-bound.  Arithmetic in double (the reference uses the
+// data dtype); deterministic block tree sum for slogl.
+template <typename T>
+__global__ __launch_bounds__(256) void lg_logl_kernel(LgArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double val = 0.0;
+    if (r < a.n) {
+        const T* base = (const T*)a.base;
+        const int64_t src = a.row0 + r;
+        double mean = a.beta[0];
+        for (int j = 1; j <= a.p; ++j) mean += a.beta[j] * (double)base[(int64_t)a.gc.cols[j] * a.ld + src];
+        const double y = (double)base[(int64_t)a.gc.cols[0] * a.ld + src];
+        const double z = a.inv_std * (y - mean);
+        val = -0.5 * z * z + a.cte;
+        if (a.logl) a.logl[r] = val;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = val;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.block_sums) a.block_sums[blockIdx.x] = red[0];
+}
+
+void launch_lg_logl(const LgArgs& a, int dtype, hipStream_t st) {
+    if (a.n == 0) return;
+    dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
+    if (dtype == PBN_F64)
+        hipLaunchKernelGGL(lg_logl_kernel<double>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(lg_logl_kernel<float>, grid, block, 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ---- row gather (arrow::compute::Take, dataset.hpp:2072-2075) -------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void take_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,

@@ -23,6 +23,20 @@ struct GramArgs {
     double* partial;      // device, [nblocks][gram_ws(nct)]
 };
 
+struct LgArgs {
+    const void* base;
+    int64_t ld;
+    GramCols gc;      // cols[0] = variable, cols[1..p] = evidence
+    int p;
+    int64_t row0, n;
+    double beta[64];  // p+1 coefficients (intercept first)
+    double inv_std;   // 1 / sqrt(variance)
+    double cte;       // -0.5 log(variance) - 0.5 log(2 pi)
+    double* logl;        // device, nullable
+    double* block_sums;  // device, nullable: ceil(n/256) partial sums
+};
+void launch_lg_logl(const LgArgs& a, int dtype, hipStream_t st);
+
 int gram_ws(int nct);  // doubles per partial: nct(nct+1)/2 tiles of 256 + nct*16 column sums
 void launch_pilot(const void* base, int64_t ld, const GramCols& gc, int n_cols, int64_t row0, const int32_t* rows,
                   int64_t n, int dtype, double* shift, hipStream_t st);

@@ -153,3 +153,89 @@ class CKDE(Factor):
         if self._evidence:
             return f"[CKDE] P({self._variable} | {', '.join(self._evidence)})"
         return f"[CKDE] P({self._variable})"
+
+
+class LinearGaussianCPD(Factor):
+    """factors/continuous/LinearGaussianCPD.{hpp,cpp}: y ~ N(beta0 + sum_i beta_i x_i, variance).
+    fit = MLE (learning/parameters/mle_LinearGaussianCPD.hpp) from one device Gram pass; logl / slogl = one
+    streaming device pass."""
+
+    def __init__(self, variable, evidence, beta=None, variance=None):
+        super().__init__(variable, evidence)
+        self._variables = [variable] + list(evidence)
+        if (beta is None) != (variance is None):
+            raise ValueError("beta and variance must be given together.")
+        if beta is not None:
+            beta = np.asarray(beta, dtype=np.float64)
+            if beta.size != len(evidence) + 1:
+                raise ValueError("Wrong number of beta parameters. Beta vector length: %d, Evidence length: %d" % (beta.size, len(evidence)))
+            if variance <= 0:
+                raise ValueError("Variance must be a positive value.")
+            self.beta, self.variance, self._fitted = beta, float(variance), True
+        else:
+            self.beta, self.variance = None, None
+
+    def type(self):
+        return "LinearGaussianFactor"
+
+    def fit(self, df):
+        rb = as_record_batch(df)
+        same_type(rb, self._variables)
+        table, _ = DeviceTable.from_dataframe(default_context(), rb, self._variables)
+        self.fit_table(table)
+
+    def fit_table(self, table, row0=0, n=None):
+        idx = table.index(self._variables)
+        n = table.num_rows - row0 if n is None else n
+        beta = np.zeros(len(idx))
+        var = C.c_double(0.0)
+        _lib.check(_lib.load().pbn_lg_fit_table(table.handle, _lib.int_array(idx), len(idx), row0, n, _lib.dptr(beta), C.byref(var)))
+        self.beta, self.variance, self._fitted = beta, var.value, True
+
+    def _eval(self, df, want_logl):
+        self._check_fitted("LinearGaussianCPD")
+        rb = as_record_batch(df)
+        same_type(rb, self._variables)
+        table, mask = DeviceTable.from_dataframe(default_context(), rb, self._variables)
+        m = table.num_rows
+        vals = np.empty(m) if want_logl else None
+        s = C.c_double(0.0)
+        d = len(self._variables)
+        _lib.check(_lib.load().pbn_lg_logl(table.handle, _lib.int_array(range(d)), d, 0, m, _lib.dptr(np.ascontiguousarray(self.beta)),
+                                           float(self.variance), _lib.dptr(vals) if want_logl else None, C.byref(s)))
+        return rb, mask, vals, s.value
+
+    def logl(self, df):
+        rb, mask, vals, _ = self._eval(df, True)
+        if mask is None:
+            return vals
+        out = np.full(rb.num_rows, np.nan)
+        out[mask] = vals
+        return out
+
+    def slogl(self, df):
+        return self._eval(df, False)[3]
+
+    def __str__(self):
+        return f"[LinearGaussianCPD] P({self._variable} | {', '.join(self._evidence)})"
+
+
+class LinearGaussianParams:
+    def __init__(self, beta, variance):
+        self.beta, self.variance = beta, variance
+
+
+class MLE:
+    """pbn.MLE(pbn.LinearGaussianCPDType()).estimate(df, variable, evidence) -> .beta, .variance
+    (pybindings_learning/pybindings_parameters.cpp:76-78)."""
+
+    def __init__(self, factor_type):
+        from .models import LinearGaussianCPDType
+
+        if factor_type != LinearGaussianCPDType():
+            raise ValueError(f"MLE not available for NodeType {factor_type}.")
+
+    def estimate(self, df, variable, evidence):
+        cpd = LinearGaussianCPD(variable, list(evidence))
+        cpd.fit(df)
+        return LinearGaussianParams(cpd.beta, cpd.variance)

@@ -1,0 +1,66 @@
+"""CPU tier, world_size 2 over gloo: the N>1 path of the delta-score cache.  Every rank scores its share of
+each batch (candidate i belongs to rank i % world), one all_gather per batch rebuilds the full result in
+rank order, and both ranks must take exactly the decisions of a single-process run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from test_hc_cpu import TableScore, run_product
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, seed, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ts = TableScore(n, seed, validated=True)
+        arcs, types, trace, last = run_product(ts, "spbn", n, [0] * n, op_types=True, patience=1)
+        queue.put((rank, arcs, types, trace, last.cells_scored, ts.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_sharded_delta_cache_world2(ensure_built, seed):
+    n, world = 9, 2
+    ts = TableScore(n, seed, validated=True)
+    ref = run_product(ts, "spbn", n, [0] * n, op_types=True, patience=1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    calls = []
+    for rank, arcs, types, trace, cells, ncalls in results:
+        assert trace == ref[2] and sorted(arcs) == sorted(ref[0]) and types == ref[1]
+        assert cells == ref[3].cells_scored
+        calls.append(ncalls)
+    # the work is really split: each rank evaluated roughly half of the single-process calls
+    assert max(calls) < 0.7 * ts.calls and sum(calls) >= ts.calls * 0.95
+
+
+def test_shard_indices_partition():
+    from pybnesian_amd.distributed import shard_indices
+
+    for n in (0, 1, 7, 64):
+        for world in (1, 2, 8):
+            parts = [shard_indices(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))

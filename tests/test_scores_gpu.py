@@ -199,3 +199,29 @@ def test_degenerate_branches(pbn, oracle):
         assert abs(got - want) <= RTOL_F64 * abs(want), ev
     assert bic.local_score(gbn, "z", ["x"]) == -np.inf  # exact linear function: variance < machine_tol
     assert bic.local_score(gbn, "k", []) == -np.inf
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+def test_linear_gaussian_cpd_fit_logl(pbn, golden, variable, evidence):
+    """LinearGaussianCPD_test.py:26-120 / mle_test.py: lstsq beta, residual variance, norm.logpdf."""
+    key = variable + "_" + "".join(evidence)
+    cpd = pbn.LinearGaussianCPD(variable, evidence)
+    cpd.fit(frame(golden["train10k"]))
+    assert np.allclose(cpd.beta, golden[f"lg_beta_{key}"], rtol=1e-7)
+    assert np.isclose(cpd.variance, golden[f"lg_var_{key}"], rtol=1e-8)
+    test = frame(golden["test50"])
+    want = golden[f"lg_logl_{key}"]
+    assert np.allclose(cpd.logl(test), want, rtol=1e-7, atol=1e-9)
+    assert abs(cpd.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())
+    tn = frame(golden["test50_null"])
+    ll = cpd.logl(tn)
+    nulls = np.any(np.isnan(tn[[variable] + evidence].to_numpy()), axis=1)
+    assert np.array_equal(np.isnan(ll), nulls)
+    assert np.isclose(cpd.slogl(tn), np.nansum(ll))
+    p = pbn.MLE(pbn.LinearGaussianCPDType()).estimate(frame(golden["train10k"]), variable, evidence)
+    assert np.allclose(p.beta, cpd.beta) and p.variance == cpd.variance
+    with pytest.raises(ValueError, match="MLE not available"):
+        pbn.MLE(pbn.CKDEType())
+    cpd32 = pbn.LinearGaussianCPD(variable, evidence)
+    cpd32.fit(frame(golden["train10k"], "float32"))
+    assert np.allclose(cpd32.beta, golden[f"lg_beta_{key}"], rtol=2e-3, atol=2e-3)
