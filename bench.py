@@ -47,6 +47,75 @@ def make_tables(torch, device, n_train, n_test, seed_train, seed_test, dtype):
     return gen(n_train, seed_train), gen(n_test, seed_test)
 
 
+def make_dag_table(torch, device, n_rows, n_cols, seed, dtype, nonlinear=False):
+    """SURVEY.md §8d generator: random linear-Gaussian DAG (max indegree 3, coefficients U(-1.5, 1.5), noise
+    sigma U(0.5, 1.5)), optionally tanh on half of the nodes.  Returns a (n_cols, n_rows) tensor (column-major table)."""
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n_cols, n_rows), dtype=torch.float64, device=device)
+    for j in range(n_cols):
+        k = int(rng.integers(0, min(3, j) + 1))
+        parents = rng.choice(j, size=k, replace=False) if k else []
+        sigma = float(rng.uniform(0.5, 1.5))
+        col = torch.randn(n_rows, generator=g, device=device, dtype=torch.float64) * sigma
+        for p in parents:
+            col += float(rng.uniform(-1.5, 1.5)) * out[int(p)]
+        if nonlinear and j % 2 == 1:
+            col = torch.tanh(col) * 2.0 + 0.1 * col
+        out[j] = col
+    return out.to(dtype).contiguous()
+
+
+def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
+    """Secondary metric: candidate-arcs (delta cells) scored per second during GreedyHillClimbing.estimate."""
+    if which == "c4":
+        n_cols = 64
+        n_rows = n_rows or 2_000_000
+        t = make_dag_table(torch, device, n_rows, n_cols, 2, torch.float64)
+        names = [f"x{i}" for i in range(n_cols)]
+        torch.cuda.synchronize()
+        table = pbn.DeviceTable.from_device_pointer(ctx, t.data_ptr(), n_rows, names, n_rows, _lib.PBN_F64, keepalive=t)
+        t0 = time.perf_counter()
+        score = pbn.BGe(None, table=table)
+        t_ctor = time.perf_counter() - t0
+        start, ops = pbn.GaussianNetwork(names), pbn.ArcOperatorSet()
+        label = f"C4: 64-node GaussianNetwork, BGe, ArcOperatorSet, {n_rows} rows fp64"
+        kw = {}
+    else:
+        n_cols = 32
+        n_rows = n_rows or 500_000
+        t = make_dag_table(torch, device, n_rows, n_cols, 2, torch.float64, nonlinear=True)
+        names = [f"x{i}" for i in range(n_cols)]
+        torch.cuda.synchronize()
+        table = pbn.DeviceTable.from_device_pointer(ctx, t.data_ptr(), n_rows, names, n_rows, _lib.PBN_F64, keepalive=t)
+        t0 = time.perf_counter()
+        score = pbn.CVLikelihood(None, 10, 0, table=table)
+        t_ctor = time.perf_counter() - t0
+        start = pbn.SemiparametricBN(names, [], [(n, pbn.CKDEType()) for n in names])
+        ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
+        label = f"C3: 32-node SemiparametricBN (all CKDE start), 10-fold CVLikelihood, arcs+node_type, max_indegree=3, {n_rows} rows fp64"
+        kw = {"max_indegree": 3}
+    hc = pbn.GreedyHillClimbing()
+    if max_iters:
+        kw["max_iters"] = max_iters
+    t0 = time.perf_counter()
+    res = hc.estimate(ops, score, start, **kw)
+    dt = time.perf_counter() - t0
+    return {
+        "metric": "hill-climb candidate-arcs scored/s",
+        "value": hc.last.cells_scored / dt,
+        "unit": "arcs/s",
+        "config": label + (f", max_iters={max_iters}" if max_iters else ""),
+        "cells_scored": hc.last.cells_scored,
+        "local_score_evals": hc.last.local_score_evals,
+        "iterations": hc.last.iterations,
+        "arcs_found": res.num_arcs(),
+        "estimate_s": dt,
+        "score_ctor_s": t_ctor,
+    }
+
+
 def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     """Oracle (port of the reference algorithm, kde/ProductKDE.hpp:240-293) on all host cores, bounded sample."""
     from oracle import oracle
@@ -80,6 +149,9 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kde", default="product", choices=["product", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3"], help="secondary hill-climb metric (rank-sharded when N>1)")
+    ap.add_argument("--hc-rows", type=int, default=0)
+    ap.add_argument("--hc-max-iters", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -145,6 +217,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    hc_out = None
+    if args.hc != "none":
+        hc_out = bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, args.hc_max_iters)
+
     total_samples = args.n_test * world * args.steps
     value = total_samples / elapsed / 1e6
     slogl = float(partial[args.warmup].item())
@@ -194,6 +270,8 @@ def main():
                 "finish_ms": fin_ms / max(sweep_n, 1),
             },
         }
+        if hc_out is not None:
+            out["secondary"] = hc_out
         if world == 1 and not args.no_cpu_baseline:
             h = np.asarray(kde.bandwidth, dtype=np.float64)
             sample_rows = min(args.n_test, 4096)

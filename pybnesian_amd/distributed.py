@@ -21,24 +21,41 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
-def sharded_batch(score, model, var, ntype, off, par, kind, min_per_rank=1):
-    """Score a batch; with torch.distributed initialised the candidates are sharded over the ranks."""
+def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
+    """Score a batch; with torch.distributed initialised the device-heavy candidates (CKDE node type under a
+    likelihood score: k sweeps each) are sharded over the ranks, while LinearGaussian candidates - O(p^3) host
+    arithmetic on replicated moments - are computed redundantly by every rank (sharding
+    them buys nothing and costs a collective)."""
+    from . import _lib
+
     dist = _dist()
     n = len(var)
-    if dist is None or n < 2 * min_per_rank:
+    if dist is None or n == 0:
         return score._batch_raw(model, var, ntype, off, par, kind)
+    heavy = [i for i in range(n) if shard_all or ntype[i] == _lib.PBN_NODE_CKDE]
+    light = [i for i in range(n) if not (shard_all or ntype[i] == _lib.PBN_NODE_CKDE)]
+    out = np.zeros(n)
+
+    def sub(idx):
+        o, p = [0], []
+        for i in idx:
+            p.extend(par[off[i]: off[i + 1]])
+            o.append(len(p))
+        return score._batch_raw(model, [var[i] for i in idx], [ntype[i] for i in idx], o, p, kind)
+
+    if light:
+        out[light] = sub(light)
+    if len(heavy) < 2:
+        if heavy:
+            out[heavy] = sub(heavy)
+        return out
     import torch
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    mine = shard_indices(n, rank, world)
-    v = [var[i] for i in mine]
-    t = [ntype[i] for i in mine]
-    o, p = [0], []
-    for i in mine:
-        p.extend(par[off[i]: off[i + 1]])
-        o.append(len(p))
-    local = score._batch_raw(model, v, t, o, p, kind)
-    per = (n + world - 1) // world
+    m = len(heavy)
+    mine = [heavy[j] for j in shard_indices(m, rank, world)]
+    local = sub(mine) if mine else np.zeros(0)
+    per = (m + world - 1) // world
     buf = np.zeros(per)
     buf[: len(mine)] = local
     backend = dist.get_backend()
@@ -47,8 +64,7 @@ def sharded_batch(score, model, var, ntype, off, par, kind, min_per_rank=1):
     recv = torch.empty(world * per, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(recv, send)
     allv = recv.cpu().numpy().reshape(world, per)
-    out = np.zeros(n)
     for r in range(world):
-        idx = shard_indices(n, r, world)
-        out[idx] = allv[r, : len(idx)]
+        idx = shard_indices(m, r, world)
+        out[[heavy[j] for j in idx]] = allv[r, : len(idx)]
     return out

