@@ -136,11 +136,16 @@ typedef enum {
     PBN_SCORE_CVLIK = 2,  /* learning/scores/cv_likelihood.cpp:11-25                            */
     PBN_SCORE_HOLDOUT = 3 /* learning/scores/holdout_likelihood.cpp:14-23 (ValidatedScore::vlocal_score) */
 } pbn_score_kind;
-typedef enum { PBN_NODE_LG = 0, PBN_NODE_CKDE = 1 } pbn_node_type; /* LinearGaussianCPDType / CKDEType */
+typedef enum { PBN_NODE_LG = 0, PBN_NODE_CKDE = 1, PBN_NODE_DISCRETE = 2 } pbn_node_type; /* LinearGaussianCPDType / CKDEType / DiscreteFactorType */
 
 int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
                          pbn_scoredata** out);
 void pbn_scoredata_destroy(pbn_scoredata* sd);
+/* Dictionary-encoded columns (arrow::DictionaryArray indices, factors/discrete/discrete_indices.cpp): n_disc int32
+ * arrays in SOURCE row order + cardinalities.  They get column ids n_cols .. n_cols+n_disc-1 in pbn_score_batch;
+ * a continuous column with discrete parents is scored as CLinearGaussianCPD / HCKDE (DiscreteAdaptator.hpp:201-348),
+ * a discrete column (node type PBN_NODE_DISCRETE, discrete parents only) as DiscreteFactor. */
+int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* const* codes, const int* cardinality);
 /* perm: n_rows ints (source row of every permuted row); limits: k+1 fold limits; all nullable. */
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold);
 /* MLE<LinearGaussianCPD>::estimate (learning/parameters/mle_LinearGaussianCPD.hpp:195-221) from the cached
@@ -162,7 +167,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
  * learning/operators/operators.{hpp,cpp}).  Nodes are 0..n_nodes-1 in model.nodes() order.  Every step's
  * Score::local_score requests are handed to `score` as ONE batch (same layout as pbn_score_batch);
  * validated != 0 asks for ValidatedScore::vlocal_score.  The callback returns 0 on success. */
-typedef enum { PBN_BN_GAUSSIAN = 0, PBN_BN_SEMIPARAMETRIC = 1, PBN_BN_KDE = 2 } pbn_bn_type;
+typedef enum { PBN_BN_GAUSSIAN = 0, PBN_BN_SEMIPARAMETRIC = 1, PBN_BN_KDE = 2, PBN_BN_CLG = 3 } pbn_bn_type;
 typedef int (*pbn_hc_score_fn)(void* user, int validated, int n_cand, const int* var, const int* node_type,
                                const int* par_off, const int* parents, double* out);
 typedef struct {

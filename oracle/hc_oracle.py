@@ -3,7 +3,7 @@ hill-climbing: ArcOperatorSet / ChangeNodeTypeSet / OperatorPool (learning/opera
 estimate_hc (learning/algorithms/hillclimbing.hpp:46-199) and the DAG predicates
 (graph/generic_graph.hpp:2711-2745).  One local_score call per cell, exactly where the reference makes it.
 
-`score(var, node_type, parents)` and `vscore(...)` are callables over node indices (node_type: 0 LG, 1 CKDE).
+`score(var, node_type, parents)` and `vscore(...)` are callables over node indices (node_type: 0 LG, 1 CKDE, 2 discrete; bn_type 0 gaussian, 1 semiparametric, 2 kde, 3 clg).
 Returns (arcs, node_types, trace) with trace = [(kind, a, b, delta)], kind 0 add, 1 remove, 2 flip, 3 type.
 """
 import ctypes as C
@@ -66,11 +66,14 @@ class Model:
                     stack.append(c)
         return False
 
+    def can_have_arc(self, s, t):
+        return not (self.node_type[t] == 2 and self.node_type[s] != 2)
+
     def can_add_arc(self, s, t):
-        return s != t and (not self.parents[s] or not self.children[t] or not self.has_path(t, s))
+        return s != t and self.can_have_arc(s, t) and (not self.parents[s] or not self.children[t] or not self.has_path(t, s))
 
     def can_flip_arc(self, s, t):
-        if s == t:
+        if s == t or not self.can_have_arc(t, s):
             return False
         if self.has_arc(s, t):
             if len(self.parents[t]) == 1 or len(self.children[s]) == 1:
@@ -81,7 +84,7 @@ class Model:
         return not self.has_path(s, t)
 
     def alt_type(self, v):
-        return -1 if self.bn_type != 1 else (1 if self.node_type[v] == 0 else 0)
+        return -1 if (self.bn_type != 1 or self.node_type[v] == 2) else (1 if self.node_type[v] == 0 else 0)
 
     def apply(self, op):
         k, a, b, _ = op
@@ -150,7 +153,7 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
         for t in range(n):
             pt = list(m.parents[t])
             for s in range(n):
-                if not valid[s + t * n]:
+                if not valid[s + t * n] or not m.can_have_arc(s, t):
                     continue
                 if m.has_arc(s, t):
                     Model.swap_remove(pt, s)
@@ -195,11 +198,11 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
                 parents.append(s)
                 delta[s + t * n] = d
                 cells[0] += 1
-                if valid[t + s * n]:
+                if valid[t + s * n] and m.can_have_arc(t, s):
                     ps = list(m.parents[s]) + [t]
                     delta[t + s * n] = d + score(s, m.node_type[s], ps) - local[s]
                     cells[0] += 1
-            elif m.has_arc(t, s):
+            elif m.has_arc(t, s) and m.can_have_arc(s, t):
                 ps = list(m.parents[s])
                 Model.swap_remove(ps, t)
                 parents.append(s)
@@ -207,7 +210,7 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
                 parents.pop()
                 delta[s + t * n] = d
                 cells[0] += 1
-            else:
+            elif m.can_have_arc(s, t):
                 parents.append(s)
                 d = score(t, m.node_type[t], list(parents)) - local[t]
                 parents.pop()

@@ -216,3 +216,111 @@ def _fit_slogl(train, test, node_type):
         return float(lg_logl(test, beta, var).sum())
     H = nr_bandwidth(train)
     return float(ckde_logl(train, H, test).sum())
+
+
+# ---- hybrid (discrete parents / discrete variables) ----------------------------------------------------------------
+# Restates factors/discrete/discrete_indices.cpp:93-204, DiscreteAdaptator.hpp:201-348, bic.cpp:29-96,
+# mle_DiscreteFactor.cpp:5-41 and DiscreteFactor.cpp:133-171 with per-slice calls into the C routines above.
+MACHINE_TOL = 1.4901161193847656e-08
+
+
+def config_index(codes, cards):
+    """codes: list of int arrays (evidence order); stride_0 = 1, stride_i = stride_{i-1} * card_{i-1}."""
+    idx = np.zeros(len(codes[0]) if codes else 0, dtype=np.int64)
+    stride, n = 1, 1
+    for c, k in zip(codes, cards):
+        idx += np.asarray(c, dtype=np.int64) * stride
+        stride *= k
+        n *= k
+    return idx, n
+
+
+def bic_clg(cont, dcodes, dcards):
+    """BIC::bic_clg (bic.cpp:29-64); cont = [variable, continuous parents...] (N x d)."""
+    cont = np.asarray(cont)
+    cfg, ncfg = config_index(dcodes, dcards)
+    p = cont.shape[1] - 1
+    loglik = 0.0
+    for c in range(ncfg):
+        rows = np.nonzero(cfg == c)[0]
+        if rows.size == 0:
+            continue
+        beta, var = lg_fit(cont[rows])
+        if var < MACHINE_TOL or np.isinf(var):
+            return -np.inf
+        n = rows.size
+        loglik += 0.5 * (1 + p - n) - 0.5 * n * np.log(2 * np.pi) - n * 0.5 * np.log(var)
+    return loglik - np.log(cont.shape[0]) * 0.5 * ncfg * (p + 2)
+
+
+def _joint_counts(vcodes, card0, pcodes, pcards, rows=None):
+    idx, n = config_index([vcodes] + list(pcodes), [card0] + list(pcards))
+    if rows is not None:
+        idx = idx[rows]
+    return np.bincount(idx, minlength=n).astype(np.int64)
+
+
+def bic_discrete(vcodes, card0, pcodes, pcards):
+    """BIC::bic_discrete (bic.cpp:66-96)."""
+    jc = _joint_counts(vcodes, card0, pcodes, pcards).reshape(-1, card0)
+    ll = 0.0
+    for row in jc:
+        s = row.sum()
+        if s > 0:
+            nz = row[row > 0].astype(np.float64)
+            ll += float(np.sum(nz * np.log(nz * (1.0 / s))))
+    return ll - np.log(float(jc.sum())) * 0.5 * (card0 - 1) * jc.shape[0]
+
+
+def discrete_fit_slogl(vcodes, card0, pcodes, pcards, train, test):
+    """MLE<DiscreteFactor> on train rows (uniform for unseen configurations) + DiscreteFactor::slogl on test rows."""
+    tr = _joint_counts(vcodes, card0, pcodes, pcards, train).reshape(-1, card0)
+    te = _joint_counts(vcodes, card0, pcodes, pcards, test).reshape(-1, card0)
+    res = 0.0
+    with np.errstate(divide="ignore"):
+        for k in range(tr.shape[0]):
+            s = tr[k].sum()
+            lp = np.full(card0, np.log(1.0 / card0)) if s == 0 else np.log(tr[k].astype(np.float64)) - np.log(float(s))
+            for i in range(card0):
+                if te[k, i]:
+                    res += te[k, i] * lp[i]
+    return float(res)
+
+
+def adaptator_fit_slogl(cont, dcodes, dcards, train, test, node_type):
+    """DiscreteAdaptator<LinearGaussianCPD | CKDE>::fit on train rows + slogl on test rows."""
+    cont = np.asarray(cont)
+    cfg, ncfg = config_index(dcodes, dcards)
+    total = 0.0
+    for c in range(ncfg):
+        tr = train[cfg[train] == c]
+        te = test[cfg[test] == c]
+        if tr.size == 0:
+            continue
+        if node_type == "lg":
+            beta, var = lg_fit(cont[tr])
+            if var < MACHINE_TOL or np.isinf(var):
+                continue  # LinearGaussianFitter -> no factor
+            if te.size:
+                total += float(lg_logl(cont[te], beta, var).sum())
+        else:
+            d = cont.shape[1]
+            if tr.size <= d:
+                continue  # SingularCovarianceData swallowed by CKDEFitter
+            c_, _ = cov(cont[tr])
+            ev = np.linalg.eigvalsh(c_)
+            if ev.min() < ev.max() * d * np.finfo(np.float64).eps:
+                continue  # is_psd fails -> SingularCovarianceData
+            H = bandwidth(0, 0, c_, tr.size)
+            if te.size:
+                total += float(ckde_logl(cont[tr], H, cont[te]).sum())
+    return total
+
+
+def hybrid_cv(fn, n, k, seed):
+    return sum(fn(tr, te) for tr, te in cv_folds(n, k, seed))
+
+
+def hybrid_holdout(fn, n, ratio, seed):
+    tr, te = holdout_split(n, ratio, seed)
+    return fn(tr, te)

@@ -11,7 +11,7 @@ from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, Scotts
 
 from .learning import (AddArc, ArcOperatorSet, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        OperatorPool, RemoveArc, hc)
-from .models import (BayesianNetwork, CKDEType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
+from .models import (BayesianNetwork, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType)
 from .scores import BGe, BIC, CVLikelihood, HoldoutLikelihood, ValidatedLikelihood  # noqa: F401
 
@@ -19,7 +19,7 @@ __all__ = [
     "BIC", "BGe", "CVLikelihood", "HoldoutLikelihood", "ValidatedLikelihood", "GreedyHillClimbing", "hc",
     "ArcOperatorSet", "ChangeNodeTypeSet", "OperatorPool", "AddArc", "RemoveArc", "FlipArc", "ChangeNodeType",
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
-    "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType",
+    "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
     "SingularCovarianceData", "Context", "DeviceTable", "default_context", "load_library",
 ]

@@ -17,8 +17,8 @@ PBN_SEL_NORMAL_REFERENCE, PBN_SEL_SCOTT = 0, 1
 PBN_K_PACK, PBN_K_SWEEP, PBN_K_FINISH, PBN_K_GRAM = 0, 1, 2, 3
 PBN_SPLIT_NONE, PBN_SPLIT_CV, PBN_SPLIT_HOLDOUT, PBN_SPLIT_VALIDATED = 0, 1, 2, 3
 PBN_SCORE_BIC, PBN_SCORE_BGE, PBN_SCORE_CVLIK, PBN_SCORE_HOLDOUT = 0, 1, 2, 3
-PBN_NODE_LG, PBN_NODE_CKDE = 0, 1
-PBN_BN_GAUSSIAN, PBN_BN_SEMIPARAMETRIC, PBN_BN_KDE = 0, 1, 2
+PBN_NODE_LG, PBN_NODE_CKDE, PBN_NODE_DISCRETE = 0, 1, 2
+PBN_BN_GAUSSIAN, PBN_BN_SEMIPARAMETRIC, PBN_BN_KDE, PBN_BN_CLG = 0, 1, 2, 3
 
 
 class SingularCovarianceData(ValueError):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "pbn_kde_slogl_async": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
     "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),
     "pbn_scoredata_destroy": (None, [_vp]),
+    "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
     "pbn_scoredata_layout": (_int, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_lg_fit": (_int, [_vp, _int, _ip, _int, _dp, _dp]),
     "pbn_lg_fit_table": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),

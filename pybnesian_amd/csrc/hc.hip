@@ -81,12 +81,13 @@ struct Model {
         }
         return false;
     }
-    // continuous-only networks: BayesianNetworkType::can_have_arc is always true (SemiparametricBN.hpp:93-98)
-    bool can_add_arc(int s, int t) const {  // generic_graph.hpp:2711-2718
-        return s != t && (parents[s].empty() || children[t].empty() || !has_path(t, s));
+    // BayesianNetworkType::can_have_arc (SemiparametricBN.hpp:93-98, CLGNetwork.hpp:84-89): no continuous -> discrete arcs
+    bool can_have_arc(int s, int t) const { return !(node_type[t] == PBN_NODE_DISCRETE && node_type[s] != PBN_NODE_DISCRETE); }
+    bool can_add_arc(int s, int t) const {  // generic_graph.hpp:2711-2718 && BayesianNetwork.hpp:571-577
+        return s != t && can_have_arc(s, t) && (parents[s].empty() || children[t].empty() || !has_path(t, s));
     }
-    bool can_flip_arc(int s, int t) const {  // generic_graph.hpp:2721-2745
-        if (s == t) return false;
+    bool can_flip_arc(int s, int t) const {  // generic_graph.hpp:2721-2745; the flipped arc is t -> s
+        if (s == t || !can_have_arc(t, s)) return false;
         if (has_arc(s, t)) {
             if (parents[t].size() == 1 || children[s].size() == 1) return true;
             return !has_path(s, t, s, t);
@@ -95,7 +96,7 @@ struct Model {
         return !has_path(s, t);
     }
     int alternative_type(int node) const {  // SemiparametricBN.hpp:106-119
-        if (bn_type != PBN_BN_SEMIPARAMETRIC) return -1;
+        if (bn_type != PBN_BN_SEMIPARAMETRIC || node_type[node] == PBN_NODE_DISCRETE) return -1;
         return node_type[node] == PBN_NODE_LG ? PBN_NODE_CKDE : PBN_NODE_LG;
     }
     void apply(const Op& op) {
@@ -112,7 +113,7 @@ struct Model {
             case OP_ADD: o.kind = OP_REMOVE; o.delta = -op.delta; break;
             case OP_REMOVE: o.kind = OP_ADD; o.delta = -op.delta; break;
             case OP_FLIP: o.source = op.target; o.target = op.source; o.delta = -op.delta; break;
-            case OP_TYPE: o.new_type = (op.new_type == PBN_NODE_LG) ? PBN_NODE_CKDE : PBN_NODE_LG; o.delta = -op.delta; break;
+            case OP_TYPE: o.new_type = (op.new_type == PBN_NODE_LG) ? PBN_NODE_CKDE : PBN_NODE_LG; o.delta = -op.delta; break;  // continuous nodes only
         }
         return o;
     }
@@ -209,7 +210,7 @@ struct Engine {
         for (int t = 0; t < n; ++t) {
             std::vector<int> pt = cur.parents[t];
             for (int s = 0; s < n; ++s) {
-                if (!arcs.valid_op[s + (size_t)t * n]) continue;
+                if (!arcs.valid_op[s + (size_t)t * n] || !cur.can_have_arc(s, t)) continue;
                 if (cur.has_arc(s, t)) {
                     Model::swap_remove(pt, s);
                     int a = bt.add(t, cur.node_type[t], pt);
@@ -253,13 +254,13 @@ struct Engine {
                 int a = bt.add(t, cur.node_type[t], parents);
                 parents.push_back(s);
                 int b = -1;
-                if (arcs.valid_op[t + (size_t)s * n]) {
+                if (arcs.valid_op[t + (size_t)s * n] && cur.can_have_arc(t, s)) {
                     std::vector<int> ps = cur.parents[s];
                     ps.push_back(t);
                     b = bt.add(s, cur.node_type[s], ps);
                 }
                 cells.push_back({s, t, a, b, 1});
-            } else if (cur.has_arc(t, s)) {
+            } else if (cur.has_arc(t, s) && cur.can_have_arc(s, t)) {
                 std::vector<int> ps = cur.parents[s];
                 Model::swap_remove(ps, t);
                 parents.push_back(s);
@@ -267,7 +268,7 @@ struct Engine {
                 int b = bt.add(t, cur.node_type[t], parents);
                 parents.pop_back();
                 cells.push_back({s, t, a, b, 2});
-            } else {
+            } else if (cur.can_have_arc(s, t)) {
                 parents.push_back(s);
                 int a = bt.add(t, cur.node_type[t], parents);
                 parents.pop_back();
@@ -439,6 +440,7 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
         m.n = n; m.bn_type = cfg->bn_type;
         m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
         m.node_type.assign(n, cfg->bn_type == PBN_BN_KDE ? PBN_NODE_CKDE : PBN_NODE_LG);
+        if (cfg->bn_type < PBN_BN_GAUSSIAN || cfg->bn_type > PBN_BN_CLG) throw invalid_error("pbn_hc_estimate: unknown network type");
         if (cfg->node_types)
             for (int i = 0; i < n; ++i) m.node_type[i] = cfg->node_types[i];
         auto check_node = [&](int v) { if (v < 0 || v >= n) throw invalid_error("pbn_hc_estimate: node index out of range"); };

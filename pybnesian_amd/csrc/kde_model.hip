@@ -132,9 +132,10 @@ static void fill_pack_common(PackArgs& pa, const pbn_table* t, const int* cols, 
 }
 
 void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
-                    int64_t row1) {
+                    int64_t row1, const int32_t* dev_rows) {
     PackArgs pa{};
     fill_pack_common(pa, t, cols, m);
+    pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
@@ -148,9 +149,9 @@ static int env_int(const char* name, int dflt) {
 }
 
 void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                      double* dev_logl, double* dev_sum) {
+                      double* dev_logl, double* dev_sum, const int32_t* dev_rows) {
     check_cols(test, cols, m.d, "pbn_kde_logl");
-    check_range(test, row0, n, "pbn_kde_logl");
+    if (!dev_rows) check_range(test, row0, n, "pbn_kde_logl");
     if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
     if (test->ctx->device != ctx->device) throw invalid_error("pbn_kde_logl: test table lives on another device");
     HIP_CHECK(hipSetDevice(ctx->device));
@@ -167,6 +168,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     char* q = ctx->scratch_q.p;
     PackArgs pa{};
     fill_pack_common(pa, test, cols, m);
+    pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles;
     pa.is_query = 1;
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;

@@ -33,12 +33,13 @@ KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n);
 void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int kind, bool cond, const double* center);
 
 // Whiten + pack training rows (two contiguous ranges: [row0, row0+n0) ++ [row1, row1 + n - n0)).
+// dev_rows (nullable): device gather list of m.N row ids, used instead of the ranges.
 void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
-                    int64_t row1);
+                    int64_t row1, const int32_t* dev_rows = nullptr);
 
 // pack(queries) -> sweep -> finish on the context stream; dev_logl / dev_sum nullable (device pointers).
 void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                      double* dev_logl, double* dev_sum);
+                      double* dev_logl, double* dev_sum, const int32_t* dev_rows = nullptr);
 
 // Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
 void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);

@@ -27,56 +27,18 @@
 #include "common.hpp"
 #include "hostmath.hpp"
 #include "kde_model.hpp"
+#include "scoring_internal.hpp"
 #include "stats_kernels.hpp"
 
 using namespace pbn;
+using namespace pbn::score;
 
-namespace {
-
-constexpr double MACHINE_TOL = 1.4901161193847656e-08;  // util/math_constants.hpp:30, sqrt(eps(double))
-constexpr double LOG_2PI = 1.8378770664093454835606594728112;
-constexpr double LOG_PI = 1.1447298858494001741434273513531;
-const double INF = std::numeric_limits<double>::infinity();
-
-struct Stats {  // pilot-shifted moments of a row range over all n columns
-    int64_t N = 0;
-    std::vector<double> S;  // n   : sum_r (x_rc - shift_c)
-    std::vector<double> G;  // n*n : sum_r (x_ri - shift_i)(x_rj - shift_j), col-major symmetric
-    void zero(int n) { N = 0; S.assign(n, 0.0); G.assign((size_t)n * n, 0.0); }
-    void add(const Stats& o) {
-        N += o.N;
-        for (size_t i = 0; i < S.size(); ++i) S[i] += o.S[i];
-        for (size_t i = 0; i < G.size(); ++i) G[i] += o.G[i];
-    }
-};
-
-}  // namespace
-
-struct pbn_scoredata {
-    pbn_ctx* ctx = nullptr;
-    int dtype = PBN_F64;
-    int n = 0;  // columns
-    int split = PBN_SPLIT_NONE;
-    int k = 0;
-    const pbn_table* src = nullptr;  // caller's table (borrowed)
-    pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)
-    const pbn_table* table() const { return perm_table ? perm_table : src; }
-    std::vector<int32_t> perm;    // permuted row -> source row
-    std::vector<int32_t> limits;  // k+1 fold limits inside the CV region
-    int64_t n_cv = 0;             // rows of the CV / training region [0, n_cv)
-    int64_t n_hold = 0;           // hold-out test rows [n_cv, n_cv + n_hold)
-    std::vector<double> shift;    // n pilot shifts
-    dev_buf<double> shift_dev;
-    Stats all;                    // CV / training region
-    std::vector<Stats> fold;      // k
-    Stats hold;                   // hold-out test region
-};
-
-namespace {
+namespace pbn {
+namespace score {
 
 // Shifted Gram of up to 64 columns over a contiguous row range -> raw S (d) and G (d*d col-major).
-void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* shift_dev, double* S,
-              double* G) {
+void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const int32_t* dev_rows,
+              const double* shift_dev, double* S, double* G) {
     pbn_ctx* ctx = t->ctx;
     const int nct = (d + 15) / 16;
     const int WS = gram_ws(nct);
@@ -88,7 +50,7 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
     double* partial = ctx->scratch_red.p;
     double* total = partial + (size_t)nblocks * WS;
     GramArgs a{};
-    a.base = t->data; a.ld = t->ld; a.n_cols = d; a.row0 = row0; a.rows = nullptr; a.n = n;
+    a.base = t->data; a.ld = t->ld; a.n_cols = d; a.row0 = row0; a.rows = dev_rows; a.n = n;
     for (int i = 0; i < d; ++i) a.gc.cols[i] = cols[i];
     a.rows_per_block = rpb; a.shift = shift_dev; a.partial = partial;
     { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram(a, t->dtype, nblocks, total, ctx->stream); }
@@ -122,7 +84,7 @@ void compute_stats(const pbn_scoredata* sd, int64_t row0, int64_t nrows, Stats& 
     if (n <= 64) {
         std::vector<int> cols(n);
         std::iota(cols.begin(), cols.end(), 0);
-        gram_raw(t, cols.data(), n, row0, nrows, sd->shift_dev.p, out.S.data(), out.G.data());
+        gram_raw(t, cols.data(), n, row0, nrows, nullptr, sd->shift_dev.p, out.S.data(), out.G.data());
         return;
     }
     const int nb = (n + 31) / 32;
@@ -134,7 +96,7 @@ void compute_stats(const pbn_scoredata* sd, int64_t row0, int64_t nrows, Stats& 
             if (bj != bi)
                 for (int c = bj * 32; c < std::min(n, bj * 32 + 32); ++c) cols.push_back(c);
             const int d = (int)cols.size();
-            gram_raw(t, cols.data(), d, row0, nrows, sd->shift_dev.p, S.data(), G.data());
+            gram_raw(t, cols.data(), d, row0, nrows, nullptr, sd->shift_dev.p, S.data(), G.data());
             for (int i = 0; i < d; ++i) {
                 out.S[cols[i]] = S[i];
                 for (int j = 0; j < d; ++j) out.G[cols[i] + (size_t)cols[j] * n] = G[i + (size_t)j * d];
@@ -321,7 +283,8 @@ double bge_score(const pbn_scoredata* sd, const Stats& st, const int* cols, int 
     return logprob;
 }
 
-}  // namespace
+}  // namespace score
+}  // namespace pbn
 
 extern "C" {
 
@@ -408,6 +371,23 @@ void pbn_scoredata_destroy(pbn_scoredata* sd) {
     if (!sd) return;
     if (sd->perm_table) pbn_table_destroy(sd->perm_table);
     delete sd;
+}
+
+// Attach the dictionary-encoded (discrete) columns: codes[j][r] = dictionary index of SOURCE row r.
+int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* const* codes, const int* cardinality) {
+    return guarded([&] {
+        if (!sd || (n_disc > 0 && (!codes || !cardinality))) throw invalid_error("pbn_scoredata_set_discrete: null argument");
+        const int64_t rows = (int64_t)sd->perm.size();
+        sd->n_disc = n_disc;
+        sd->codes.assign(n_disc, std::vector<int32_t>((size_t)rows));
+        sd->card.assign(cardinality, cardinality + n_disc);
+        for (int j = 0; j < n_disc; ++j)
+            for (int64_t r = 0; r < rows; ++r) {
+                const int32_t v = codes[j][sd->perm[r]];
+                if (v < 0 || v >= cardinality[j]) throw invalid_error("pbn_scoredata_set_discrete: code out of range");
+                sd->codes[j][r] = v;
+            }
+    });
 }
 
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold) {
@@ -516,9 +496,16 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             cols.resize(d);
             cols[0] = var[c];
             for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
-            for (int cc : cols)
-                if (cc < 0 || cc >= sd->n) throw invalid_error("pbn_score_batch: column out of range");
+            bool hybrid = false;
+            for (int cc : cols) {
+                if (cc < 0 || cc >= sd->n + sd->n_disc) throw invalid_error("pbn_score_batch: column out of range");
+                if (cc >= sd->n) hybrid = true;
+            }
             const int nt = node_type ? node_type[c] : PBN_NODE_LG;
+            if (hybrid) {
+                out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p);
+                continue;
+            }
             mu.resize(d); sse.resize((size_t)d * d); beta.resize(d);
             if (kind == PBN_SCORE_BIC) {
                 if (nt != PBN_NODE_LG) throw invalid_error("BIC: only LinearGaussianCPD node types are implemented on device");

@@ -1,0 +1,73 @@
+// Internal declarations shared by scoring.hip and hybrid.hip (score engine).
+#pragma once
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "common.hpp"
+
+namespace pbn {
+namespace score {
+
+constexpr double MACHINE_TOL = 1.4901161193847656e-08;  // util/math_constants.hpp:30, sqrt(eps(double))
+constexpr double LOG_2PI = 1.8378770664093454835606594728112;
+constexpr double LOG_PI = 1.1447298858494001741434273513531;
+const double INF = std::numeric_limits<double>::infinity();
+
+struct Stats {  // pilot-shifted moments of a row set over all n columns (or a column subset, see users)
+    int64_t N = 0;
+    std::vector<double> S;  // n   : sum_r (x_rc - shift_c)
+    std::vector<double> G;  // n*n : sum_r (x_ri - shift_i)(x_rj - shift_j), col-major symmetric
+    void zero(int n) { N = 0; S.assign(n, 0.0); G.assign((size_t)n * n, 0.0); }
+    void add(const Stats& o) {
+        N += o.N;
+        for (size_t i = 0; i < S.size(); ++i) S[i] += o.S[i];
+        for (size_t i = 0; i < G.size(); ++i) G[i] += o.G[i];
+    }
+};
+
+}  // namespace score
+}  // namespace pbn
+
+struct pbn_scoredata {
+    pbn_ctx* ctx = nullptr;
+    int dtype = PBN_F64;
+    int n = 0;  // continuous columns
+    int split = PBN_SPLIT_NONE;
+    int k = 0;
+    const pbn_table* src = nullptr;  // caller's table (borrowed)
+    pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)
+    const pbn_table* table() const { return perm_table ? perm_table : src; }
+    std::vector<int32_t> perm;    // permuted row -> source row
+    std::vector<int32_t> limits;  // k+1 fold limits inside the CV region
+    int64_t n_cv = 0;             // rows of the CV / training region [0, n_cv)
+    int64_t n_hold = 0;           // hold-out test rows [n_cv, n_cv + n_hold)
+    std::vector<double> shift;    // n pilot shifts
+    pbn::dev_buf<double> shift_dev;
+    pbn::score::Stats all;               // CV / training region
+    std::vector<pbn::score::Stats> fold; // k
+    pbn::score::Stats hold;              // hold-out test region
+    // discrete (dictionary) columns, addressed as column ids n .. n + n_disc - 1, in permuted row order
+    int n_disc = 0;
+    std::vector<std::vector<int32_t>> codes;
+    std::vector<int> card;
+    pbn::dev_buf<int32_t> rows_dev;  // gather lists of the hybrid path
+};
+
+namespace pbn {
+namespace score {
+
+// Shifted Gram of up to 64 columns over a contiguous row range or a device gather list -> raw S (d), G (d*d).
+void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const int32_t* dev_rows,
+              const double* shift_dev, double* S, double* G);
+void subset_moments(const pbn_scoredata* sd, const Stats& st, const int* cols, int d, double* mu, double* sse);
+void stats_minus(const Stats& a, const Stats& b, Stats& out);
+double lg_fit(int64_t N, int p, const double* mu, const double* S, double* beta);
+double bic_lg(int64_t N, int p, double variance);
+double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const int* cols, int p, const double* beta,
+                             double variance);
+// hybrid.hip: candidates with a discrete variable or discrete parents (synchronous)
+double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p);
+
+}  // namespace score
+}  // namespace pbn

@@ -13,14 +13,15 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .models import (BayesianNetwork, CKDEType, GaussianNetwork, GaussianNetworkType, KDENetworkType,
-                     LinearGaussianCPDType, SemiparametricBNType)
+from .models import (BayesianNetwork, CKDEType, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType,
+                     KDENetworkType, LinearGaussianCPDType, SemiparametricBNType)
 from .scores import Score, default_score
 
 _BN_CODE = {GaussianNetworkType: _lib.PBN_BN_GAUSSIAN, SemiparametricBNType: _lib.PBN_BN_SEMIPARAMETRIC,
-            KDENetworkType: _lib.PBN_BN_KDE}
-_NODE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE}
-_NODE_FROM_CODE = {_lib.PBN_NODE_LG: LinearGaussianCPDType(), _lib.PBN_NODE_CKDE: CKDEType()}
+            KDENetworkType: _lib.PBN_BN_KDE, CLGNetworkType: _lib.PBN_BN_CLG}
+_NODE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE,
+              DiscreteFactorType(): _lib.PBN_NODE_DISCRETE}
+_NODE_FROM_CODE = {v: k for k, v in _NODE_CODE.items()}
 
 
 class Operator:
@@ -149,7 +150,9 @@ class GreedyHillClimbing:
         for s in sets:
             if isinstance(s, ArcOperatorSet):
                 max_indegree = max_indegree or s.max_indegree
-        node_types = [_NODE_CODE[start.node_type(v)] for v in nodes]
+        # set_unknown_node_types (hillclimbing.hpp:81-93): dictionary columns are DiscreteFactor nodes
+        is_disc = getattr(score, "is_discrete", lambda v: False)
+        node_types = [_lib.PBN_NODE_DISCRETE if is_disc(v) else _NODE_CODE[start.node_type(v)] for v in nodes]
         arcs = pairs(start.arcs())
         cfg = _lib.HCConfig()
         keep = []

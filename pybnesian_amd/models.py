@@ -30,6 +30,10 @@ class CKDEType(FactorType):
     _name = "CKDEFactor"
 
 
+class DiscreteFactorType(FactorType):
+    _name = "DiscreteFactor"
+
+
 class BayesianNetworkType:
     _name = "BayesianNetworkType"
     homogeneous = True
@@ -53,6 +57,14 @@ class KDENetworkType(BayesianNetworkType):
 
 class SemiparametricBNType(BayesianNetworkType):
     _name = "SemiparametricBNType"
+    homogeneous = False
+
+
+class CLGNetworkType(BayesianNetworkType):
+    """models/CLGNetwork.hpp: discrete nodes are DiscreteFactor, continuous nodes LinearGaussianCPD (conditional
+    on their discrete parents); no continuous -> discrete arcs (CLGNetwork.hpp:84-89)."""
+
+    _name = "CLGNetworkType"
     homogeneous = False
 
 
@@ -129,13 +141,17 @@ class BayesianNetwork:
                     stack.append(c)
         return False
 
+    def can_have_arc(self, source, target):
+        """BayesianNetworkType::can_have_arc (SemiparametricBN.hpp:93-98, CLGNetwork.hpp:84-89)."""
+        return not (self._types[target] == DiscreteFactorType() and self._types[source] != DiscreteFactorType())
+
     def can_add_arc(self, source, target):
-        return source != target and (
+        return source != target and self.can_have_arc(source, target) and (
             not self._parents[source] or not self._children[target] or not self.has_path(target, source)
         )
 
     def can_flip_arc(self, source, target):
-        if source == target:
+        if source == target or not self.can_have_arc(target, source):
             return False
         if self.has_arc(source, target):
             if len(self._parents[target]) == 1 or len(self._children[source]) == 1:
@@ -177,6 +193,8 @@ class BayesianNetwork:
         return dict(self._types)
 
     def set_node_type(self, node, node_type):
+        if isinstance(self._type, CLGNetworkType) and node_type == CKDEType():
+            raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
         if self._type.homogeneous and node_type != self._type.default_type:
             raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
         self._types[node] = node_type
@@ -200,3 +218,7 @@ def SemiparametricBN(nodes, arcs=(), node_types=()):
     if arcs and isinstance(arcs[0], (tuple, list)) and len(arcs[0]) == 2 and isinstance(arcs[0][1], FactorType):
         node_types, arcs = arcs, ()
     return BayesianNetwork(SemiparametricBNType(), nodes, arcs, node_types)
+
+
+def CLGNetwork(nodes, arcs=(), node_types=()):
+    return BayesianNetwork(CLGNetworkType(), nodes, arcs, node_types)

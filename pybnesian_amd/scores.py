@@ -13,9 +13,10 @@ import numpy as np
 
 from . import _lib
 from .dataset import DeviceTable, as_record_batch, default_context
-from .models import CKDEType, GaussianNetworkType, KDENetworkType, LinearGaussianCPDType, SemiparametricBNType
+from .models import (CKDEType, CLGNetworkType, DiscreteFactorType, GaussianNetworkType, KDENetworkType, LinearGaussianCPDType,
+                     SemiparametricBNType)
 
-_TYPE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE}
+_TYPE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE, DiscreteFactorType(): _lib.PBN_NODE_DISCRETE}
 
 
 def _random_seed():
@@ -25,32 +26,52 @@ def _random_seed():
 class Score:
     _kind = None
     _split = _lib.PBN_SPLIT_NONE
-    _allowed_types = (LinearGaussianCPDType(),)
+    _allowed_types = (LinearGaussianCPDType(), DiscreteFactorType())
 
     def __init__(self, df, split_args=(0, 0, 0.0), ctx=None, table=None):
         self._ctx = ctx or (table.ctx if table is not None else default_context())
+        self._disc_names, self._disc_codes, self._disc_card, self._categories = [], [], [], {}
         if table is None:
+            import pyarrow as pa
+
             rb = as_record_batch(df)
-            names = [f.name for f in rb.schema]
             if any(rb.column(i).null_count for i in range(rb.num_columns)):
                 raise ValueError("The device score engine does not accept tables with nulls yet.")
-            table, _ = DeviceTable.from_dataframe(self._ctx, rb, names, drop_null=False)
+            cont = []
+            for f in rb.schema:
+                if pa.types.is_dictionary(f.type):
+                    arr = rb.column(rb.schema.get_field_index(f.name))
+                    self._disc_names.append(f.name)
+                    self._disc_codes.append(np.ascontiguousarray(arr.indices.to_numpy(zero_copy_only=False), dtype=np.int32))
+                    self._disc_card.append(len(arr.dictionary))
+                    self._categories[f.name] = arr.dictionary.to_pylist()
+                else:
+                    cont.append(f.name)
+            if not cont:
+                raise ValueError("The device score engine needs at least one continuous column.")
+            table, _ = DeviceTable.from_dataframe(self._ctx, rb, cont, drop_null=False)
             self._df = rb
         else:
             self._df = None
         self._table = table
-        self._names = list(table.names)
+        self._names = list(table.names) + self._disc_names
         self._col = {n: i for i, n in enumerate(self._names)}
         k, seed, ratio = split_args
         h = C.c_void_p()
         _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
                                                     float(ratio), C.byref(h)))
         self._handle = h
+        if self._disc_names:
+            ptrs = (C.c_void_p * len(self._disc_codes))(*[c.ctypes.data for c in self._disc_codes])
+            _lib.check(_lib.load().pbn_scoredata_set_discrete(h, len(self._disc_codes), ptrs, _lib.int_array(self._disc_card)))
         self._params = np.zeros(0)
 
     # -- reference surface -------------------------------------------------------------------------------
     def data(self):
         return self._df
+
+    def is_discrete(self, variable):
+        return variable in self._categories
 
     def has_variables(self, variables):
         if isinstance(variables, str):
@@ -152,7 +173,7 @@ class BGe(Score):
 
 
 class _LikelihoodScore(Score):
-    _allowed_types = (LinearGaussianCPDType(), CKDEType())
+    _allowed_types = (LinearGaussianCPDType(), CKDEType(), DiscreteFactorType())
 
 
 class CVLikelihood(_LikelihoodScore):
@@ -212,7 +233,7 @@ class ValidatedLikelihood(_LikelihoodScore):
 
 def default_score(bn_type, df, seed=None, num_folds=10, test_holdout_ratio=0.2):
     """util/validate_options.cpp:16-58: Gaussian -> BIC; semiparametric / KDE networks -> ValidatedLikelihood."""
-    if isinstance(bn_type, GaussianNetworkType):
+    if isinstance(bn_type, (GaussianNetworkType, CLGNetworkType)):
         return BIC(df)
     if isinstance(bn_type, (SemiparametricBNType, KDENetworkType)):
         return ValidatedLikelihood(df, test_holdout_ratio, num_folds, seed)

@@ -22,10 +22,10 @@ class TableScore:
     def __init__(self, n, seed, validated=False, decimals=2):
         rng = np.random.default_rng(seed)
         self.n = n
-        self.base = rng.normal(size=(n, 2)) * 3
-        self.w = rng.normal(size=(n, n, 2)) * 2
+        self.base = rng.normal(size=(n, 3)) * 3
+        self.w = rng.normal(size=(n, n, 3)) * 2
         self.pair = rng.normal(size=(n, n, n)) * 0.7
-        self.vnoise = rng.normal(size=(n, n, 2)) * 0.8
+        self.vnoise = rng.normal(size=(n, n, 3)) * 0.8
         self.decimals = decimals
         self.validated = validated
         self._col = {f"n{i}": i for i in range(n)}
@@ -155,3 +155,31 @@ def test_hc_errors(ensure_built):
     # epsilon above every delta returns the start model (hillclimbing_test.py:30-36)
     res = pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), ts, start, epsilon=1e9)
     assert res.num_arcs() == 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hc_with_discrete_nodes_type_rule(ensure_built, seed):
+    """No continuous -> discrete arcs (SemiparametricBN.hpp:93-98); discrete nodes have no alternative type."""
+    n = 8
+    types = [2, 2, 0, 1, 0, 2, 1, 0]
+
+    class Disc(TableScore):
+        def is_discrete(self, v):
+            return types[int(v[1:])] == 2
+
+    ts = Disc(n, seed)
+    import pybnesian_amd as pbn
+
+    names = [f"n{i}" for i in range(n)]
+    tcode = {0: pbn.LinearGaussianCPDType(), 1: pbn.CKDEType(), 2: pbn.DiscreteFactorType()}
+    start = pbn.SemiparametricBN(names, [], [(names[i], tcode[t]) for i, t in enumerate(types)])
+    hc = pbn.GreedyHillClimbing()
+    res = hc.estimate(pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]), ts, start)
+    o_arcs, o_types, o_trace, info = hc_oracle.estimate(n, 1, lambda v, t, ps: ts.raw(v, t, ps), node_types=types, op_types=True)
+    idx = {nm: i for i, nm in enumerate(names)}
+    assert sorted((idx[s], idx[t]) for s, t in res.arcs()) == sorted(o_arcs)
+    assert [{pbn.LinearGaussianCPDType(): 0, pbn.CKDEType(): 1, pbn.DiscreteFactorType(): 2}[res.node_type(nm)] for nm in names] == o_types
+    assert hc.last.cells_scored == info["cells_scored"] and hc.last.iterations == info["iterations"]
+    for s, t in res.arcs():
+        assert not (types[idx[t]] == 2 and types[idx[s]] != 2)
+    assert [o_types[i] for i in range(n) if types[i] == 2] == [2] * types.count(2)

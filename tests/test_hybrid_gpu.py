@@ -1,0 +1,156 @@
+"""GPU tier: hybrid scoring — CLinearGaussianCPD / HCKDE through
+DiscreteAdaptator semantics, bic_clg, bic_discrete, DiscreteFactor likelihoods — against the oracle's
+per-slice restatement, plus a small CLG / semiparametric hill-climb with discrete nodes."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import RTOL_F64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def make_hybrid(n, seed=0):
+    """In the spirit of tests/helpers/util_test.py:103-141 (generate_hybrid_data): discrete A (2), B (3),
+    continuous x | A, y | x, B, z | x, y with configuration-dependent means."""
+    rng = np.random.default_rng(seed)
+    A = rng.integers(0, 2, size=n)
+    B = (rng.random(n) < np.where(A == 0, 0.3, 0.6)).astype(int) + (rng.random(n) < 0.2)
+    x = rng.normal(loc=np.where(A == 0, -1.0, 2.0), scale=1.0)
+    y = 0.7 * x + np.array([0.0, 3.0, -2.0])[B] + rng.normal(scale=0.5, size=n)
+    z = np.tanh(x) - 0.4 * y + rng.normal(scale=0.3, size=n)
+    df = pd.DataFrame({
+        "A": pd.Categorical.from_codes(A, ["a0", "a1"]),
+        "B": pd.Categorical.from_codes(B, ["b0", "b1", "b2"]),
+        "x": x, "y": y, "z": z,
+    })
+    return df, {"A": A.astype(np.int32), "B": B.astype(np.int32)}, {"A": 2, "B": 3}
+
+
+def close(a, b, rtol=RTOL_F64):
+    if np.isinf(a) or np.isinf(b):
+        return a == b
+    return abs(a - b) <= rtol * max(abs(b), 1e-12)
+
+
+def test_bic_clg_and_discrete(pbn, oracle):
+    df, codes, cards = make_hybrid(3000)
+    bic = pbn.BIC(df)
+    net = pbn.CLGNetwork(list(df.columns), [], [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType())])
+    for var, dpar, cpar in [("x", ["A"], []), ("y", ["B"], ["x"]), ("z", ["A", "B"], ["x", "y"]), ("y", ["B", "A"], [])]:
+        got = bic.local_score(net, var, dpar + cpar)
+        want = oracle.bic_clg(df[[var] + cpar].to_numpy(), [codes[d] for d in dpar], [cards[d] for d in dpar])
+        assert close(got, want), (var, dpar, cpar, got, want)
+        # parent order between discrete and continuous evidence does not matter
+        assert close(bic.local_score(net, var, cpar + dpar), want)
+    for var, par in [("A", []), ("B", ["A"]), ("A", ["B"])]:
+        got = bic.local_score(net, var, par)
+        want = oracle.bic_discrete(codes[var], cards[var], [codes[p] for p in par], [cards[p] for p in par])
+        assert close(got, want), (var, par)
+    with pytest.raises(ValueError, match="non-discrete"):
+        bic.local_score(net, "A", ["x"])
+
+
+@pytest.mark.parametrize("node_type", ["lg", "ckde"])
+def test_hybrid_cv_and_holdout_likelihood(pbn, oracle, node_type):
+    n = 1200
+    df, codes, cards = make_hybrid(n, seed=3)
+    net = pbn.SemiparametricBN(list(df.columns), [], [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType())])
+    nt = pbn.LinearGaussianCPDType() if node_type == "lg" else pbn.CKDEType()
+    cv = pbn.CVLikelihood(df, 4, 7)
+    ho = pbn.HoldoutLikelihood(df, 0.25, 2)
+    for var, dpar, cpar in [("x", ["A"], []), ("y", ["B"], ["x"]), ("z", ["B", "A"], ["x", "y"])]:
+        cont = df[[var] + cpar].to_numpy()
+        dc, dk = [codes[d] for d in dpar], [cards[d] for d in dpar]
+        fn = lambda tr, te: oracle.adaptator_fit_slogl(cont, dc, dk, tr, te, node_type)
+        got = cv.local_score_node_type(net, nt, var, dpar + cpar)
+        want = oracle.hybrid_cv(fn, n, 4, 7)
+        assert close(got, want), (var, got, want)
+        got = ho.local_score_node_type(net, nt, var, cpar + dpar)
+        want = oracle.hybrid_holdout(fn, n, 0.25, 2)
+        assert close(got, want), (var, got, want)
+
+
+def test_discrete_factor_likelihoods(pbn, oracle):
+    n = 900
+    df, codes, cards = make_hybrid(n, seed=5)
+    net = pbn.SemiparametricBN(list(df.columns), [], [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType())])
+    cv = pbn.CVLikelihood(df, 5, 1)
+    vl = pbn.ValidatedLikelihood(df, 0.2, 3, 4)
+    for var, par in [("A", []), ("B", ["A"]), ("A", ["B"])]:
+        pc, pk = [codes[p] for p in par], [cards[p] for p in par]
+        fn = lambda tr, te: oracle.discrete_fit_slogl(codes[var], cards[var], pc, pk, tr, te)
+        assert close(cv.local_score(net, var, par), oracle.hybrid_cv(fn, n, 5, 1))
+        assert close(vl.vlocal_score(net, var, par), oracle.hybrid_holdout(fn, n, 0.2, 4))
+        tr, _ = oracle.holdout_split(n, 0.2, 4)
+        want = sum(fn(tr[a], tr[b]) for a, b in oracle.cv_folds(tr.size, 3, 4))
+        assert close(vl.local_score(net, var, par), want)
+
+
+def test_sparse_configurations_drop_factors(pbn, oracle):
+    """Slices too small for a CKDE (SingularCovarianceData swallowed) or with constant data (variance < tol)
+    contribute nothing (DiscreteAdaptator.hpp:339-344)."""
+    n = 400
+    rng = np.random.default_rng(0)
+    A = np.zeros(n, dtype=np.int32)
+    A[:3] = 1                      # configuration a1 has 3 rows only
+    A[3:40] = 2                    # configuration a2: constant target
+    x = rng.normal(size=n)
+    y = 0.5 * x + rng.normal(scale=0.2, size=n)
+    y[3:40] = 1.25
+    df = pd.DataFrame({"A": pd.Categorical.from_codes(A, ["a0", "a1", "a2"]), "x": x, "y": y})
+    net = pbn.SemiparametricBN(["A", "x", "y"], [], [("A", pbn.DiscreteFactorType())])
+    ho = pbn.HoldoutLikelihood(df, 0.3, 0)
+    cont = df[["y", "x"]].to_numpy()
+    for node_type, nt in (("lg", pbn.LinearGaussianCPDType()), ("ckde", pbn.CKDEType())):
+        fn = lambda tr, te: oracle.adaptator_fit_slogl(cont, [A], [3], tr, te, node_type)
+        got = ho.local_score_node_type(net, nt, "y", ["x", "A"])
+        assert close(got, oracle.hybrid_holdout(fn, n, 0.3, 0)), node_type
+
+
+def test_hc_with_discrete_nodes_vs_oracle(pbn, oracle):
+    from oracle import hc_oracle
+
+    n = 1500
+    df, codes, cards = make_hybrid(n, seed=9)
+    names = list(df.columns)
+    col = {c: i for i, c in enumerate(names)}
+    disc = {"A", "B"}
+
+    def score(v, t, ps):
+        var = names[v]
+        par = [names[p] for p in ps]
+        if var in disc:
+            return oracle.bic_discrete(codes[var], cards[var], [codes[p] for p in par], [cards[p] for p in par])
+        dpar = [p for p in par if p in disc]
+        cpar = [p for p in par if p not in disc]
+        if not dpar:
+            return oracle.bic_lg(df[[var] + cpar].to_numpy())
+        return oracle.bic_clg(df[[var] + cpar].to_numpy(), [codes[d] for d in dpar], [cards[d] for d in dpar])
+
+    types = [2 if c in disc else 0 for c in names]
+    bl = [(j, i) for i in range(5) for j in range(5) if j > i]
+    hc = pbn.GreedyHillClimbing()
+    res = hc.estimate(pbn.ArcOperatorSet(), pbn.BIC(df), pbn.CLGNetwork(names), arc_blacklist=[(names[a], names[b]) for a, b in bl])
+    o_arcs, o_types, o_trace, info = hc_oracle.estimate(5, 3, score, node_types=types, arc_blacklist=bl)
+    got_trace = [({pbn.AddArc: 0, pbn.RemoveArc: 1, pbn.FlipArc: 2}[type(op)], col[op.source()], col[op.target()]) for op in hc.last.trace]
+    assert got_trace == [t[:3] for t in o_trace]
+    assert sorted((col[s], col[t]) for s, t in res.arcs()) == sorted(o_arcs)
+    assert all(res.node_type(c) == pbn.DiscreteFactorType() for c in disc)
+    assert not any(s not in disc and t in disc for s, t in res.arcs())
+    assert hc.last.cells_scored == info["cells_scored"]
