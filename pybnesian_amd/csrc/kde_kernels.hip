@@ -325,6 +325,146 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// kde_sweep_sparse (fp64, unconditional): the DP units are the binding resource of the fp64 sweep and the
+// 2^x polynomial is more than half of their work, while for realistic bandwidths most (train, query) pairs
+// are negligible: a term with s2 - m_q <= -60 is below 2^-60 of its query's running sum (>= 1), i.e. below
+// the rounding of the sum even when a million of them are dropped (< 1e-12 relative).  So the exponential is
+// evaluated ONLY for "alive" values: after the MFMAs each lane pushes its alive accumulator values onto a
+// private LDS stack (conflict-free: slot-major, lane-minor), and when a stack gets full the wave pops in
+// lock-step and runs the polynomial densely on the popped values.  One query group per wave and TB
+// training tiles per iteration, so that all 16 values a lane produces per iteration belong to the same query
+// (no tags, one running sum per lane).  The offset m_q (uniform over the 4 lanes of a query column) starts as the
+// maximum over a max-only scan of the first `prologue_tiles` tiles and is raised whenever a popped value exceeds
+// `soft`, which keeps it within 2^soft of the running maximum - the alive test stays sharp and nothing can
+// overflow; queued values are re-based in that (rare, wave-uniform) path.
+// ------------------------------------------------------------------------------------------------
+#define PBN_SPARSE_TB 4
+#define PBN_SPARSE_CAP 24
+#define PBN_SPARSE_DEAD (-60.0)
+
+template <int KS>
+__global__ __launch_bounds__(256, 3) void kde_sweep_sparse_kernel(SweepArgs a) {
+    constexpr int TB = PBN_SPARSE_TB;
+    constexpr int CAP = PBN_SPARSE_CAP;
+    __shared__ double queue[4][CAP][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lg = lane >> 4;
+    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    if (qt >= a.nqtiles) return;  // no workgroup barriers in this kernel
+    const int split = blockIdx.y;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+
+    const double* __restrict__ Ap = (const double*)a.Apack;
+    const double* __restrict__ Np = (const double*)a.nxpack;
+    const double* __restrict__ Bp = (const double*)a.Bpack;
+    const double* __restrict__ NYp = (const double*)a.nypack;
+
+    double b[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) b[ks] = Bp[(qt * KS + ks) * 64 + lane];
+    const double ny = NYp[qt * 16 + (lane & 15)];
+
+    // ---- prologue: offset from the first TB tiles -----------------------------------------------
+    double m;
+    {
+        double mx = -INFINITY;
+        for (int j = 0; j < a.prologue_tiles; ++j) {
+            const int64_t t = t0 + j;
+            if (t >= t1) break;
+            d4 acc = *(const d4*)(Np + t * 16 + lg * 4) + ny;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = Tr<double>::mfma(Ap[(t * KS + ks) * 64 + lane], b[ks], acc);
+            const double v = max4<double>(acc);
+            mx = v > mx ? v : mx;
+        }
+        m = colmax<double>(mx);
+    }
+    double cm = ny - m;
+    double sum = 0.0;
+    double* const qbase = &queue[wave][0][lane];
+    double* qtop = qbase;                                   // next free slot (slot stride = 64 doubles)
+    double* const qhigh = qbase + (CAP - 4 * TB) * 64;      // above this a further iteration could overflow
+
+    // pop one value per non-empty lane, raise the offset if needed, accumulate 2^v
+    auto pop_round = [&]() {
+        const bool has = qtop > qbase;
+        double v = -1e30;
+        if (has) { qtop -= 64; v = *qtop; }
+        if (__builtin_expect(__any(v > a.soft), 0)) {
+            double mx = colmax<double>(v > 0.0 ? v : 0.0);  // uniform over the 4 lanes of the query column
+            if (mx > 0.0) {
+                m += mx;
+                cm = ny - m;
+                sum *= exp2(-mx);
+                v -= mx;
+                for (double* q = qbase; q < qtop; q += 64) *q -= mx;
+            }
+        }
+        if (has) sum += exp2_f64(v);
+    };
+
+    // fragments of the first TB tiles (clamped; tiles past t1 are masked out below)
+    double af[TB][KS];
+    d4 nx[TB];
+    auto load_tiles = [&](int64_t t, double (&f)[TB][KS], d4 (&n)[TB]) {
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int64_t tj = t + j < t1 ? t + j : t1 - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) f[j][ks] = Ap[(tj * KS + ks) * 64 + lane];
+            n[j] = *(const d4*)(Np + tj * 16 + lg * 4);
+        }
+    };
+    load_tiles(t0, af, nx);
+
+    for (int64_t t = t0; t < t1; t += TB) {
+        double afn[TB][KS];
+        d4 nxn[TB];
+        load_tiles(t + TB < t1 ? t + TB : t, afn, nxn);  // prefetch the next iteration
+
+        d4 acc[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            acc[j] = nx[j] + cm;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc[j] = Tr<double>::mfma(af[j][ks], b[ks], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const bool live = t + j < t1;  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double v = acc[j][i];
+                if (live && v > PBN_SPARSE_DEAD) { *qtop = v; qtop += 64; }
+            }
+        }
+        if (__any(qtop > qhigh)) {
+            // lock-step pops while most lanes have work, then whatever is needed to make room
+            while (__popcll(__ballot(qtop > qbase)) >= 48) pop_round();
+            while (__any(qtop > qhigh)) pop_round();
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[j][ks] = afn[j][ks];
+            nx[j] = nxn[j];
+        }
+    }
+    while (__any(qtop > qbase)) pop_round();
+
+    double s = sum;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lg == 0) {
+        double* o = a.part + ((int64_t)split * a.nqtiles * 16 + qt * 16 + lane) * 2;
+        o[0] = m;
+        o[1] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kde_finish: per query merge the split partials (fixed order), logl = lognorm + ln2*(m + log2 sum)
 // [CKDE: joint - marginal], optional logl store, deterministic block tree sum.
 // ------------------------------------------------------------------------------------------------
@@ -413,13 +553,30 @@ static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st
     HIP_CHECK(hipGetLastError());
 }
 
-int sweep_qg(int dtype, bool cond) {
+bool use_sparse(int dtype, bool cond, int KS) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PBN_SWEEP_SPARSE");
+        v = (e && *e) ? atoi(e) : 0;  // opt-in experiment, see DESIGN.md §3.1 "sparse exp"
+    }
+    return v != 0 && dtype == PBN_F64 && !cond && KS <= 2;
+}
+
+int sweep_qg(int dtype, bool cond, int KS) {
+    if (use_sparse(dtype, cond, KS)) return 1;
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }
 
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
-    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond)), (unsigned)nsplit);
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond, KS)), (unsigned)nsplit);
+    if (use_sparse(dtype, cond, KS)) {
+        dim3 block(256);
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_sparse_kernel<1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((kde_sweep_sparse_kernel<2>), grid, block, 0, st, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (dtype == PBN_F64) {
         if (cond) launch_sweep_t<double, true>(a, KS, grid, st); else launch_sweep_t<double, false>(a, KS, grid, st);
     } else {

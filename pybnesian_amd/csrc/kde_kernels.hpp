@@ -40,6 +40,8 @@ struct SweepArgs {
     int64_t nqtiles;
     int64_t tiles_per_split;
     double* part;  // [nsplit][nqtiles*16][P]
+    double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
+    int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
 };
 
 struct FinishArgs {
@@ -59,7 +61,7 @@ template <bool F64, bool COND>
 struct SweepQG {
     static constexpr int value = (F64 && COND) ? 2 : 4;
 };
-int sweep_qg(int dtype, bool cond);
+int sweep_qg(int dtype, bool cond, int KS);
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);

@@ -175,7 +175,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
 
     // split the training tiles so that the grid is a few waves deep on every CU
-    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond));
+    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond, m.KS));
     const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
     int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));
@@ -189,6 +189,8 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack;
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.part = (double*)ctx->scratch_part.p;
+    sa.soft = env_int("PBN_SPARSE_SOFT", 8);
+    sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, m.dtype, m.KS, m.cond, (int)nsplit, ctx->stream); }
 
     const int64_t nblocks = ceil_div(n, 256);
