@@ -146,6 +146,9 @@ void pbn_scoredata_destroy(pbn_scoredata* sd);
  * a continuous column with discrete parents is scored as CLinearGaussianCPD / HCKDE (DiscreteAdaptator.hpp:201-348),
  * a discrete column (node type PBN_NODE_DISCRETE, discrete parents only) as DiscreteFactor. */
 int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* const* codes, const int* cardinality);
+/* BIC / BGe on tables with nulls: masks[c] = byte array (1 = valid) of continuous column c in source row order, or
+ * NULL when the column has no nulls (valid_rows / combined_bitmap semantics of bic.cpp:12-27, bge.hpp:184-234). */
+int pbn_scoredata_set_validity(pbn_scoredata* sd, const uint8_t* const* masks);
 /* perm: n_rows ints (source row of every permuted row); limits: k+1 fold limits; all nullable. */
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold);
 /* MLE<LinearGaussianCPD>::estimate (learning/parameters/mle_LinearGaussianCPD.hpp:195-221) from the cached

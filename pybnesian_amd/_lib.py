@@ -62,6 +62,7 @@ SIGNATURES = {
     "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
+    "pbn_scoredata_set_validity": (_int, [_vp, C.POINTER(_vp)]),
     "pbn_scoredata_layout": (_int, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_lg_fit": (_int, [_vp, _int, _ip, _int, _dp, _dp]),
     "pbn_lg_fit_table": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),

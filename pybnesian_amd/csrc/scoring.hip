@@ -390,6 +390,25 @@ int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* con
     });
 }
 
+// Validity of the continuous columns for BIC / BGe on tables with nulls (bic.cpp:12-27 uses
+// valid_rows(variable, parents); bge.hpp:52-72 drops its cache when any column has nulls): masks[c] is a byte
+// array (1 = valid) in source row order, or NULL when column c has no nulls.  Likelihood scores never see nulls:
+// CrossValidation / HoldOut keep only rows valid in every column (crossvalidation_adaptator.hpp:24-37).
+int pbn_scoredata_set_validity(pbn_scoredata* sd, const uint8_t* const* masks) {
+    return guarded([&] {
+        if (!sd || !masks) throw invalid_error("pbn_scoredata_set_validity: null argument");
+        if (sd->split != PBN_SPLIT_NONE) throw invalid_error("pbn_scoredata_set_validity: only for BIC / BGe score data");
+        const int64_t rows = (int64_t)sd->perm.size();
+        sd->valid.assign(sd->n, {});
+        sd->has_nulls = false;
+        for (int c = 0; c < sd->n; ++c)
+            if (masks[c]) {
+                sd->valid[c].assign(masks[c], masks[c] + rows);
+                sd->has_nulls = true;
+            }
+    });
+}
+
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold) {
     return guarded([&] {
         if (!sd) throw invalid_error("pbn_scoredata_layout: null argument");
@@ -507,15 +526,46 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                 continue;
             }
             mu.resize(d); sse.resize((size_t)d * d); beta.resize(d);
+            const Stats* full = &sd->all;
+            Stats gathered;
+            if (sd->has_nulls && (kind == PBN_SCORE_BIC || kind == PBN_SCORE_BGE)) {
+                bool involved = false;
+                for (int cc : cols) involved = involved || !sd->valid[cc].empty();
+                if (involved) {
+                    // rows valid in every involved column (DataFrame::combined_bitmap, dataset.cpp:208-235)
+                    const int64_t rows = (int64_t)sd->perm.size();
+                    std::vector<int32_t> keep;
+                    keep.reserve(rows);
+                    for (int64_t r = 0; r < rows; ++r) {
+                        bool ok = true;
+                        for (int cc : cols) ok = ok && (sd->valid[cc].empty() || sd->valid[cc][r]);
+                        if (ok) keep.push_back((int32_t)r);
+                    }
+                    if (d > 64) throw invalid_error("pbn_score_batch: more than 64 columns in one candidate");
+                    sd->rows_dev.reserve(keep.size() + 16);
+                    if (!keep.empty())
+                        HIP_CHECK(hipMemcpyAsync(sd->rows_dev.p, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+                    std::vector<double> S(d), G((size_t)d * d);
+                    if (!keep.empty())
+                        gram_raw(t, cols.data(), d, 0, (int64_t)keep.size(), sd->rows_dev.p, sd->shift_dev.p, S.data(), G.data());
+                    gathered.zero(sd->n);
+                    gathered.N = (int64_t)keep.size();
+                    for (int i = 0; i < d; ++i) {
+                        gathered.S[cols[i]] = S[i];
+                        for (int j = 0; j < d; ++j) gathered.G[cols[i] + (size_t)cols[j] * sd->n] = G[i + (size_t)j * d];
+                    }
+                    full = &gathered;
+                }
+            }
             if (kind == PBN_SCORE_BIC) {
                 if (nt != PBN_NODE_LG) throw invalid_error("BIC: only LinearGaussianCPD node types are implemented on device");
-                subset_moments(sd, sd->all, cols.data(), d, mu.data(), sse.data());
-                const double v = lg_fit(sd->all.N, p, mu.data(), sse.data(), beta.data());
-                out[c] = bic_lg(sd->all.N, p, v);
+                subset_moments(sd, *full, cols.data(), d, mu.data(), sse.data());
+                const double v = lg_fit(full->N, p, mu.data(), sse.data(), beta.data());
+                out[c] = bic_lg(full->N, p, v);
                 continue;
             }
             if (kind == PBN_SCORE_BGE) {
-                out[c] = bge_score(sd, sd->all, cols.data(), p, iss_mu, iss_w, total_nodes, nu);
+                out[c] = bge_score(sd, *full, cols.data(), p, iss_mu, iss_w, total_nodes, nu);
                 continue;
             }
             const bool cv = kind == PBN_SCORE_CVLIK;

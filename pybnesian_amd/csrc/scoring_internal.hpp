@@ -52,6 +52,9 @@ struct pbn_scoredata {
     std::vector<std::vector<int32_t>> codes;
     std::vector<int> card;
     pbn::dev_buf<int32_t> rows_dev;  // gather lists of the hybrid path
+    // validity of the continuous columns (BIC / BGe on tables with nulls): byte masks, empty = no nulls
+    std::vector<std::vector<uint8_t>> valid;
+    bool has_nulls = false;
 };
 
 namespace pbn {

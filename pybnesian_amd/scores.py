@@ -35,8 +35,9 @@ class Score:
             import pyarrow as pa
 
             rb = as_record_batch(df)
+            self._masks = None
             if any(rb.column(i).null_count for i in range(rb.num_columns)):
-                raise ValueError("The device score engine does not accept tables with nulls yet.")
+                rb = self._handle_nulls(rb)
             cont = []
             for f in rb.schema:
                 if pa.types.is_dictionary(f.type):
@@ -51,6 +52,7 @@ class Score:
                 raise ValueError("The device score engine needs at least one continuous column.")
             table, _ = DeviceTable.from_dataframe(self._ctx, rb, cont, drop_null=False)
             self._df = rb
+            self._cont_names = cont
         else:
             self._df = None
         self._table = table
@@ -61,10 +63,43 @@ class Score:
         _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
                                                     float(ratio), C.byref(h)))
         self._handle = h
+        if getattr(self, "_masks", None):
+            keep = [np.ascontiguousarray(self._masks[c].astype(np.uint8)) if c in self._masks else None for c in self._cont_names]
+            ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data if k is not None else None for k in keep])
+            _lib.check(_lib.load().pbn_scoredata_set_validity(h, ptrs))
         if self._disc_names:
             ptrs = (C.c_void_p * len(self._disc_codes))(*[c.ctypes.data for c in self._disc_codes])
             _lib.check(_lib.load().pbn_scoredata_set_discrete(h, len(self._disc_codes), ptrs, _lib.int_array(self._disc_card)))
         self._params = np.zeros(0)
+
+    def _handle_nulls(self, rb):
+        """Likelihood scores: CrossValidation / HoldOut keep only the rows that are valid in EVERY column
+        (crossvalidation_adaptator.hpp:24-37).  BIC / BGe: per-candidate valid rows (bic.cpp:12-27) - the values
+        under null slots are zeroed for the upload and the validity masks go to the engine."""
+        import pyarrow as pa
+        import pyarrow.compute as pc
+
+        from .dataset import validity_mask
+
+        if self._split != _lib.PBN_SPLIT_NONE:
+            mask = None
+            for i in range(rb.num_columns):
+                m = validity_mask(rb.column(i))
+                if m is not None:
+                    mask = m if mask is None else (mask & m)
+            return rb.filter(pa.array(mask))
+        self._masks = {}
+        arrays = []
+        for i, f in enumerate(rb.schema):
+            col = rb.column(i)
+            m = validity_mask(col)
+            if m is not None:
+                if pa.types.is_dictionary(f.type):
+                    raise ValueError("Discrete columns with nulls are not supported by the device score engine.")
+                self._masks[f.name] = m
+                col = pc.fill_null(col, 0.0)
+            arrays.append(col)
+        return pa.RecordBatch.from_arrays(arrays, schema=rb.schema)
 
     # -- reference surface -------------------------------------------------------------------------------
     def data(self):

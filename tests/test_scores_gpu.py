@@ -225,3 +225,31 @@ def test_linear_gaussian_cpd_fit_logl(pbn, golden, variable, evidence):
     cpd32 = pbn.LinearGaussianCPD(variable, evidence)
     cpd32.fit(frame(golden["train10k"], "float32"))
     assert np.allclose(cpd32.beta, golden[f"lg_beta_{key}"], rtol=2e-3, atol=2e-3)
+
+
+def test_scores_with_nulls(pbn, golden, oracle):
+    """bic_test.py:45-85 (test_bic_local_score_null): BIC over the rows valid in [variable]+parents; BGe likewise;
+    CV/holdout scores drop rows with a null in any column before splitting (crossvalidation_adaptator.hpp:24-37)."""
+    data = golden["train10k"][:3000].copy()
+    np.random.seed(0)
+    for j in range(4):
+        data[np.random.randint(0, data.shape[0], size=100), j] = np.nan
+    df = frame(data)
+    gbn = pbn.GaussianNetwork(COLS, FULL_ARCS)
+    bic, bge = pbn.BIC(df), pbn.BGe(df)
+    for variable, evidence in CKDE_SETS:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        sub = data[:, idx]
+        sub = sub[~np.isnan(sub).any(axis=1)]
+        want = oracle.bic_lg(sub)
+        got = bic.local_score(gbn, variable, evidence)
+        assert abs(got - want) <= RTOL_F64 * abs(want)
+        wantb = numpy_bge(sub, 4)
+        assert abs(bge.local_score(gbn, variable, evidence) - wantb) <= 1e-9 * abs(wantb)
+    clean = data[~np.isnan(data).any(axis=1)]
+    cv = pbn.CVLikelihood(df, 5, 2)
+    for variable, evidence, kind, nt in [("c", ["a", "b"], "lg", pbn.LinearGaussianCPDType()), ("b", ["a"], "ckde", pbn.CKDEType())]:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        want = oracle.cv_likelihood(clean[:, idx], kind, 5, 2)
+        got = cv.local_score_node_type(pbn.SemiparametricBN(COLS), nt, variable, evidence)
+        assert abs(got - want) <= RTOL_F64 * abs(want)
