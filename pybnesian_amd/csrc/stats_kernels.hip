@@ -78,23 +78,31 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
 #pragma unroll
     for (int I = 0; I < NCT; ++I) csum[I] = 0.0;
 
-    for (int64_t r = rb0 + wave * 16; r < rb1; r += 64) {
-        double x[NCT][4];
+    // software-pipelined over 16-row chunks: the loads of chunk i+1 are in flight under the MFMAs of chunk i
+    auto load_chunk = [&](int64_t r, T (&raw)[NCT][4], bool (&ok)[4]) {
         const int64_t rl = r + 4 * kq;
         int64_t src[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool rv = rl + j < rb1;
-            src[j] = rv ? (GATHER ? (int64_t)a.rows[rl + j] : rl + j) : -1;
+            ok[j] = rl + j < rb1;
+            src[j] = ok[j] ? (GATHER ? (int64_t)a.rows[rl + j] : rl + j) : (GATHER ? (int64_t)a.rows[rb0] : rb0);
         }
 #pragma unroll
-        for (int I = 0; I < NCT; ++I) {
+        for (int I = 0; I < NCT; ++I)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = src[j] >= 0 && cvalid[I];
-                x[I][j] = ok ? (double)colp[I][src[j]] - sh[I] : 0.0;
-            }
-        }
+            for (int j = 0; j < 4; ++j) raw[I][j] = colp[I][src[j]];
+    };
+    T raw[NCT][4];
+    bool ok[4];
+    int64_t r = rb0 + wave * 16;
+    if (r < rb1) load_chunk(r, raw, ok);
+    for (; r < rb1; r += 64) {
+        double x[NCT][4];
+#pragma unroll
+        for (int I = 0; I < NCT; ++I)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[I][j] = (ok[j] && cvalid[I]) ? (double)raw[I][j] - sh[I] : 0.0;
+        if (r + 64 < rb1) load_chunk(r + 64, raw, ok);
 #pragma unroll
         for (int I = 0; I < NCT; ++I) csum[I] += (x[I][0] + x[I][1]) + (x[I][2] + x[I][3]);
 #pragma unroll
@@ -146,14 +154,19 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
     for (int e = threadIdx.x; e < WS; e += 256) out[e] = lds[e];
 }
 
-// Sum the block partials in block order (deterministic); one thread per element.
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial, int nblocks, int WS,
+// Sum the block partials (deterministic): stage 1 sums groups of 16 consecutive blocks in place into the first
+// block of each group (grid.y = groups), stage 2 sums the group leaders in group order.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ partial, int nblocks, int WS, int stride,
                                                            double* __restrict__ out) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= WS) return;
+    const int b0 = blockIdx.y * stride * 16;
     double v = 0.0;
-    for (int b = 0; b < nblocks; ++b) v += partial[(int64_t)b * WS + e];
-    out[e] = v;
+    for (int i = 0; i < 16; ++i) {
+        const int b = b0 + i * stride;
+        if (b < nblocks) v += partial[(int64_t)b * WS + e];
+    }
+    if (out) out[e] = v; else partial[(int64_t)b0 * WS + e] = v;
 }
 
 template <typename T, bool GATHER>
@@ -189,7 +202,14 @@ void launch_gram(const GramArgs& a, int dtype, int nblocks, double* out, hipStre
     } else {
         if (gather) launch_gram_t<float, true>(a, nct, nblocks, st); else launch_gram_t<float, false>(a, nct, nblocks, st);
     }
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((WS + 255) / 256), dim3(256), 0, st, (const double*)a.partial, nblocks, WS, out);
+    // tree of arity 16 over the blocks, fixed order
+    int stride = 1;
+    while ((nblocks + stride - 1) / stride > 16) {
+        const int groups = (nblocks + stride * 16 - 1) / (stride * 16);
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((WS + 255) / 256, groups), dim3(256), 0, st, a.partial, nblocks, WS, stride, (double*)nullptr);
+        stride *= 16;
+    }
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((WS + 255) / 256, 1), dim3(256), 0, st, a.partial, nblocks, WS, stride, out);
     HIP_CHECK(hipGetLastError());
 }
 
