@@ -116,6 +116,22 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
     }
 
 
+def pmc_traffic(args):
+    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/r1/pmc_per_dispatch.json:
+    FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc runs of this same command; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload; null otherwise."""
+    if (args.n_train, args.n_test, args.dtype, args.kde) != (1_000_000, 100_000, "f64", "product"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4>" in name)
+        return 2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     """Oracle (port of the reference algorithm, kde/ProductKDE.hpp:240-293) on all host cores, bounded sample."""
     from oracle import oracle
@@ -258,7 +274,7 @@ def main():
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args),
                 "note": "compute-bound sweep (SURVEY.md §8d): algorithmic flops = (3d+2) per train/test pair (exp counted as 1) "
                         "against the FP64 vector==matrix peak; sweep launch duration from HIP events on the library stream",
                 "avg_launch_ms": sweep_s * 1e3,

@@ -253,3 +253,24 @@ def test_scores_with_nulls(pbn, golden, oracle):
         want = oracle.cv_likelihood(clean[:, idx], kind, 5, 2)
         got = cv.local_score_node_type(pbn.SemiparametricBN(COLS), nt, variable, evidence)
         assert abs(got - want) <= RTOL_F64 * abs(want)
+
+
+def test_fp32_scores(pbn, golden, oracle):
+    """fp32 tables (config C5 dtype): statistics are accumulated in double from the float data; sweeps run on
+    v_mfma_f32 + v_exp_f32.  Tolerance: 1e-3 relative (north star) against the fp64 oracle on the same rounded data."""
+    data32 = golden["train10k"][:1500].astype(np.float32)
+    df = frame(data32, "float32")
+    data = data32.astype(np.float64)
+    spbn = pbn.SemiparametricBN(COLS)
+    cv = pbn.CVLikelihood(df, 4, 1)
+    for variable, evidence in [("b", ["a"]), ("c", ["a", "b"])]:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        for kind, nt in (("lg", pbn.LinearGaussianCPDType()), ("ckde", pbn.CKDEType())):
+            got = cv.local_score_node_type(spbn, nt, variable, evidence)
+            want = oracle.cv_likelihood(data[:, idx], kind, 4, 1)
+            assert abs(got - want) <= 1e-3 * abs(want), (variable, kind, got, want)
+    bic = pbn.BIC(df)
+    for variable, evidence in CKDE_SETS:
+        idx = [COLS.index(v) for v in [variable] + evidence]
+        want = oracle.bic_lg(data[:, idx])
+        assert abs(bic.local_score(pbn.GaussianNetwork(COLS), variable, evidence) - want) <= 1e-3 * abs(want)
