@@ -82,6 +82,23 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         start, ops = pbn.GaussianNetwork(names), pbn.ArcOperatorSet()
         label = f"C4: 64-node GaussianNetwork, BGe, ArcOperatorSet, {n_rows} rows fp64"
         kw = {}
+    elif which == "cv64":
+        # north star: "CV-likelihood hill-climbing on 64-node synthetic data" - CKDE candidates are sharded over the
+        # ranks (fixed total work: strong scaling of the delta cache); bounded to cache_scores + max_iters iterations
+        n_cols = 64
+        n_rows = n_rows or 100_000
+        max_iters = max_iters or 1
+        t = make_dag_table(torch, device, n_rows, n_cols, 2, torch.float64, nonlinear=True)
+        names = [f"x{i}" for i in range(n_cols)]
+        torch.cuda.synchronize()
+        table = pbn.DeviceTable.from_device_pointer(ctx, t.data_ptr(), n_rows, names, n_rows, _lib.PBN_F64, keepalive=t)
+        t0 = time.perf_counter()
+        score = pbn.CVLikelihood(None, 10, 0, table=table)
+        t_ctor = time.perf_counter() - t0
+        start = pbn.SemiparametricBN(names, [], [(n, pbn.CKDEType()) for n in names])
+        ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
+        label = f"64-node SemiparametricBN (all CKDE start), 10-fold CVLikelihood, arcs+node_type, max_indegree=3, {n_rows} rows fp64"
+        kw = {"max_indegree": 3}
     else:
         n_cols = 32
         n_rows = n_rows or 500_000
@@ -165,7 +182,9 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kde", default="product", choices=["product", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3"], help="secondary hill-climb metric (rank-sharded when N>1)")
+    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64"],
+                    help="secondary hill-climb metric: c4 = BASELINE config 4 (BGe, replicated moments), c3 = config 3 at full "
+                         "size (slow), cv64 = 64-node CV-likelihood CKDE hill-climb whose candidates are sharded over the ranks")
     ap.add_argument("--hc-rows", type=int, default=0)
     ap.add_argument("--hc-max-iters", type=int, default=0)
     args = ap.parse_args()
