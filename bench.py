@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64"],
                     help="secondary hill-climb metric: c4 = BASELINE config 4 (BGe, replicated moments), c3 = config 3 at full "
                          "size (slow), cv64 = 64-node CV-likelihood CKDE hill-climb whose candidates are sharded over the ranks")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--hc-rows", type=int, default=0)
     ap.add_argument("--hc-max-iters", type=int, default=0)
     args = ap.parse_args()
@@ -196,6 +198,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if "PBN_BENCH_DEVICE" in os.environ:  # testing aid: put every rank on one device (with --backend gloo)
+        local_rank = int(os.environ["PBN_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -203,7 +207,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     import pybnesian_amd as pbn
     from pybnesian_amd import _lib
