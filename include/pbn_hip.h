@@ -208,6 +208,20 @@ typedef struct {
 int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn score, void* user, int* out_arcs, int* out_n_arcs,
                     int* out_node_types, pbn_hc_stats* stats);
 
+/* Stateful form for callers that drive their own loop: OperatorSet::{cache_scores, find_max, find_max_tabu,
+ * update_scores} and LocalScoreCache (learning/operators/operators.hpp:295-355).  The handle owns a copy of the
+ * model; pbn_hc_set_model re-synchronises it after the caller applied an operator.  find_max: op = {kind, source|node,
+ * target|node_type}, kind -1 when no operator is available; tabu = 4 ints per forbidden operator (same encoding). */
+typedef struct pbn_hc pbn_hc;
+int pbn_hc_create(const pbn_hc_config* cfg, pbn_hc_score_fn score, void* user, pbn_hc** out);
+void pbn_hc_destroy(pbn_hc* h);
+int pbn_hc_set_model(pbn_hc* h, int n_arcs, const int* arcs, const int* node_types);
+int pbn_hc_cache_scores(pbn_hc* h);
+int pbn_hc_find_max(pbn_hc* h, int n_tabu, const int* tabu, int* op, double* delta);
+int pbn_hc_update_scores(pbn_hc* h, int n, const int* nodes);
+/* local: n cached local scores; delta_arcs: n*n col-major (row = source, column = target); delta_types: n. Nullable. */
+int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types);
+
 #ifdef __cplusplus
 }
 #endif

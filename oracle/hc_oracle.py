@@ -99,7 +99,9 @@ class Model:
             self.node_type[a] = b
 
 
-def _opposite(op):
+def _opposite(op, model):
+    """Operator::opposite(model) evaluated AFTER apply, as estimate_hc does (hillclimbing.hpp:175).  For
+    ChangeNodeType it reads model.node_type(node), i.e. the NEW type (operators.hpp:214-216)."""
     k, a, b, d = op
     if k == 0:
         return (1, a, b, -d)
@@ -107,7 +109,7 @@ def _opposite(op):
         return (0, a, b, -d)
     if k == 2:
         return (2, b, a, -d)
-    return (3, a, 1 - b, -d)
+    return (3, a, model.node_type[a], -d)
 
 
 def _same(o1, o2):
@@ -307,7 +309,7 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
             if p > patience:
                 break
             offset += vdelta
-            tabu.append(_opposite(op))
+            tabu.append(_opposite(op, m))
         prev.apply(op)
         trace.append(op)
         for v in changed:

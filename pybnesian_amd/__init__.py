@@ -10,14 +10,14 @@ from .factors import CKDE, MLE, Factor, LinearGaussianCPD  # noqa: F401
 from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
 from .learning import (AddArc, ArcOperatorSet, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
-                       OperatorPool, RemoveArc, hc)
+                       LocalScoreCache, OperatorPool, OperatorTabuSet, RemoveArc, hc)
 from .models import (BayesianNetwork, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType)
 from .scores import BGe, BIC, CVLikelihood, HoldoutLikelihood, ValidatedLikelihood  # noqa: F401
 
 __all__ = [
     "BIC", "BGe", "CVLikelihood", "HoldoutLikelihood", "ValidatedLikelihood", "GreedyHillClimbing", "hc",
-    "ArcOperatorSet", "ChangeNodeTypeSet", "OperatorPool", "AddArc", "RemoveArc", "FlipArc", "ChangeNodeType",
+    "ArcOperatorSet", "ChangeNodeTypeSet", "OperatorPool", "OperatorTabuSet", "LocalScoreCache", "AddArc", "RemoveArc", "FlipArc", "ChangeNodeType",
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",

@@ -69,6 +69,13 @@ SIGNATURES = {
     "pbn_lg_logl": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp, _dp]),
     "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
     "pbn_hc_estimate": (_int, [_vp, _vp, _vp, _ip, _ip, _ip, _vp]),
+    "pbn_hc_create": (_int, [_vp, _vp, _vp, C.POINTER(_vp)]),
+    "pbn_hc_destroy": (None, [_vp]),
+    "pbn_hc_set_model": (_int, [_vp, _int, _ip, _ip]),
+    "pbn_hc_cache_scores": (_int, [_vp]),
+    "pbn_hc_find_max": (_int, [_vp, _int, _ip, _ip, _dp]),
+    "pbn_hc_update_scores": (_int, [_vp, _int, _ip]),
+    "pbn_hc_get": (_int, [_vp, _dp, _dp, _dp]),
 }
 
 HC_SCORE_FN = C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)

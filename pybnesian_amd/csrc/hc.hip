@@ -113,7 +113,9 @@ struct Model {
             case OP_ADD: o.kind = OP_REMOVE; o.delta = -op.delta; break;
             case OP_REMOVE: o.kind = OP_ADD; o.delta = -op.delta; break;
             case OP_FLIP: o.source = op.target; o.target = op.source; o.delta = -op.delta; break;
-            case OP_TYPE: o.new_type = (op.new_type == PBN_NODE_LG) ? PBN_NODE_CKDE : PBN_NODE_LG; o.delta = -op.delta; break;  // continuous nodes only
+            // ChangeNodeType::opposite(m) = ChangeNodeType(node, m.node_type(node), -delta) (operators.hpp:214-216); estimate_hc
+            // calls it AFTER apply, so the tabu entry names the NEW type (a reference quirk that is reproduced, not fixed)
+            case OP_TYPE: o.new_type = node_type[op.source]; o.delta = -op.delta; break;
         }
         return o;
     }
@@ -428,59 +430,150 @@ struct Engine {
 
 }  // namespace
 
+static void init_engine(Engine& e, const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user) {
+    const int n = cfg->n_nodes;
+    if (n <= 0) throw invalid_error("pbn_hc_estimate: empty model");
+    e.scorer = Scorer{fn, user};
+    Model& m = e.cur;
+    m.n = n; m.bn_type = cfg->bn_type;
+    m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
+    m.node_type.assign(n, cfg->bn_type == PBN_BN_KDE ? PBN_NODE_CKDE : PBN_NODE_LG);
+    if (cfg->bn_type < PBN_BN_GAUSSIAN || cfg->bn_type > PBN_BN_CLG) throw invalid_error("pbn_hc_estimate: unknown network type");
+    if (cfg->node_types)
+        for (int i = 0; i < n; ++i) m.node_type[i] = cfg->node_types[i];
+    auto check_node = [&](int v) { if (v < 0 || v >= n) throw invalid_error("pbn_hc_estimate: node index out of range"); };
+    // force type whitelist (hillclimbing.hpp:77)
+    for (int i = 0; i < cfg->n_type_whitelist; ++i) {
+        check_node(cfg->type_whitelist[2 * i]);
+        m.node_type[cfg->type_whitelist[2 * i]] = cfg->type_whitelist[2 * i + 1];
+    }
+    for (int i = 0; i < cfg->n_arcs; ++i) {
+        check_node(cfg->arcs[2 * i]); check_node(cfg->arcs[2 * i + 1]);
+        m.add_arc(cfg->arcs[2 * i], cfg->arcs[2 * i + 1]);
+    }
+    // check_blacklist / force_whitelist (hillclimbing.hpp:95-96)
+    for (int i = 0; i < cfg->n_arc_blacklist; ++i) {
+        const int s = cfg->arc_blacklist[2 * i], t = cfg->arc_blacklist[2 * i + 1];
+        check_node(s); check_node(t);
+        if (m.has_arc(s, t)) throw invalid_error("Arc in the blacklist is present in the starting Bayesian network.");
+        e.arcs.blacklist.push_back({s, t});
+    }
+    for (int i = 0; i < cfg->n_arc_whitelist; ++i) {
+        const int s = cfg->arc_whitelist[2 * i], t = cfg->arc_whitelist[2 * i + 1];
+        check_node(s); check_node(t);
+        if (!m.has_arc(s, t)) {
+            if (m.has_arc(t, s)) m.remove_arc(t, s);
+            if (!m.can_add_arc(s, t)) throw invalid_error("Arc whitelist creates a cycle in the starting Bayesian network.");
+            m.add_arc(s, t);
+        }
+        e.arcs.whitelist.push_back({s, t});
+    }
+    e.use_arcs = cfg->op_arcs != 0;
+    e.use_types = cfg->op_node_type != 0;
+    e.order_arcs_first = cfg->arcs_first;
+    if (!e.use_arcs && !e.use_types) throw invalid_error("pbn_hc_estimate: no operator set");
+    if (e.use_types && cfg->bn_type != PBN_BN_SEMIPARAMETRIC)
+        throw invalid_error("ChangeNodeTypeSet can only be used with non-homogeneous Bayesian networks.");
+    e.arcs.max_indegree = cfg->max_indegree;
+    e.types.whitelisted.assign(n, 0);
+    for (int i = 0; i < cfg->n_type_whitelist; ++i) e.types.whitelisted[cfg->type_whitelist[2 * i]] = 1;
+    for (int i = 0; i < cfg->n_type_blacklist; ++i)
+        e.types.type_blacklist.insert({cfg->type_blacklist[2 * i], cfg->type_blacklist[2 * i + 1]});
+}
+
+struct pbn_hc {
+    Engine e;
+    bool cached = false;
+};
+
+extern "C" {
+
+// ---- stateful operator-set interface: OperatorSet::{cache_scores,find_max,find_max_tabu,update_scores} and
+// LocalScoreCache of learning/operators/operators.hpp:295-355 for callers that drive their own search loop ----
+int pbn_hc_create(const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user, pbn_hc** out) {
+    return guarded([&] {
+        if (!cfg || !fn || !out) throw invalid_error("pbn_hc_create: null argument");
+        auto h = std::make_unique<pbn_hc>();
+        init_engine(h->e, cfg, fn, user);
+        *out = h.release();
+    });
+}
+
+void pbn_hc_destroy(pbn_hc* h) { delete h; }
+
+int pbn_hc_set_model(pbn_hc* h, int n_arcs, const int* arcs, const int* node_types) {
+    return guarded([&] {
+        if (!h || (n_arcs > 0 && !arcs)) throw invalid_error("pbn_hc_set_model: null argument");
+        Model& m = h->e.cur;
+        const int n = m.n;
+        m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
+        if (node_types)
+            for (int i = 0; i < n; ++i) m.node_type[i] = node_types[i];
+        for (int i = 0; i < n_arcs; ++i) {
+            const int s = arcs[2 * i], t = arcs[2 * i + 1];
+            if (s < 0 || s >= n || t < 0 || t >= n) throw invalid_error("pbn_hc_set_model: node index out of range");
+            m.add_arc(s, t);
+        }
+    });
+}
+
+int pbn_hc_cache_scores(pbn_hc* h) {
+    return guarded([&] {
+        if (!h) throw invalid_error("pbn_hc_cache_scores: null handle");
+        h->e.cache_scores();
+        h->cached = true;
+    });
+}
+
+int pbn_hc_find_max(pbn_hc* h, int n_tabu, const int* tabu, int* op, double* delta) {
+    return guarded([&] {
+        if (!h || !op || !delta) throw invalid_error("pbn_hc_find_max: null argument");
+        if (!h->cached) throw invalid_error("Local cache not initialized. Call cache_scores() before find_max()");
+        std::vector<Op> tb((size_t)n_tabu);
+        for (int i = 0; i < n_tabu; ++i) {
+            tb[i].kind = tabu[4 * i];
+            tb[i].source = tabu[4 * i + 1];
+            if (tb[i].kind == OP_TYPE) tb[i].new_type = tabu[4 * i + 2]; else tb[i].target = tabu[4 * i + 2];
+        }
+        Op o = h->e.find_max(n_tabu > 0 ? &tb : nullptr);
+        op[0] = o.kind;
+        op[1] = o.source;
+        op[2] = o.kind == OP_TYPE ? o.new_type : o.target;
+        *delta = o.delta;
+    });
+}
+
+int pbn_hc_update_scores(pbn_hc* h, int n, const int* nodes) {
+    return guarded([&] {
+        if (!h || (n > 0 && !nodes)) throw invalid_error("pbn_hc_update_scores: null argument");
+        if (!h->cached) throw invalid_error("Local cache not initialized. Call cache_scores() before update_scores()");
+        std::vector<int> changed(nodes, nodes + n);
+        for (int v : changed)
+            if (v < 0 || v >= h->e.cur.n) throw invalid_error("pbn_hc_update_scores: node index out of range");
+        h->e.update_scores(changed);
+    });
+}
+
+int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types) {
+    return guarded([&] {
+        if (!h) throw invalid_error("pbn_hc_get: null handle");
+        const int n = h->e.cur.n;
+        if (local && (int)h->e.local.size() == n) std::memcpy(local, h->e.local.data(), n * sizeof(double));
+        if (delta_arcs && h->e.arcs.delta.size() == (size_t)n * n) std::memcpy(delta_arcs, h->e.arcs.delta.data(), (size_t)n * n * sizeof(double));
+        if (delta_types && (int)h->e.types.delta.size() == n) std::memcpy(delta_types, h->e.types.delta.data(), n * sizeof(double));
+    });
+}
+
+}  // extern "C"
+
 extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user, int* out_arcs, int* out_n_arcs,
                                int* out_node_types, pbn_hc_stats* stats) {
     return guarded([&] {
         if (!cfg || !fn || !out_arcs || !out_n_arcs || !out_node_types) throw invalid_error("pbn_hc_estimate: null argument");
-        const int n = cfg->n_nodes;
-        if (n <= 0) throw invalid_error("pbn_hc_estimate: empty model");
         Engine e;
-        e.scorer = Scorer{fn, user};
+        init_engine(e, cfg, fn, user);
         Model& m = e.cur;
-        m.n = n; m.bn_type = cfg->bn_type;
-        m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
-        m.node_type.assign(n, cfg->bn_type == PBN_BN_KDE ? PBN_NODE_CKDE : PBN_NODE_LG);
-        if (cfg->bn_type < PBN_BN_GAUSSIAN || cfg->bn_type > PBN_BN_CLG) throw invalid_error("pbn_hc_estimate: unknown network type");
-        if (cfg->node_types)
-            for (int i = 0; i < n; ++i) m.node_type[i] = cfg->node_types[i];
-        auto check_node = [&](int v) { if (v < 0 || v >= n) throw invalid_error("pbn_hc_estimate: node index out of range"); };
-        // force type whitelist (hillclimbing.hpp:77)
-        for (int i = 0; i < cfg->n_type_whitelist; ++i) {
-            check_node(cfg->type_whitelist[2 * i]);
-            m.node_type[cfg->type_whitelist[2 * i]] = cfg->type_whitelist[2 * i + 1];
-        }
-        for (int i = 0; i < cfg->n_arcs; ++i) {
-            check_node(cfg->arcs[2 * i]); check_node(cfg->arcs[2 * i + 1]);
-            m.add_arc(cfg->arcs[2 * i], cfg->arcs[2 * i + 1]);
-        }
-        // check_blacklist / force_whitelist (hillclimbing.hpp:95-96)
-        for (int i = 0; i < cfg->n_arc_blacklist; ++i) {
-            const int s = cfg->arc_blacklist[2 * i], t = cfg->arc_blacklist[2 * i + 1];
-            check_node(s); check_node(t);
-            if (m.has_arc(s, t)) throw invalid_error("Arc in the blacklist is present in the starting Bayesian network.");
-            e.arcs.blacklist.push_back({s, t});
-        }
-        for (int i = 0; i < cfg->n_arc_whitelist; ++i) {
-            const int s = cfg->arc_whitelist[2 * i], t = cfg->arc_whitelist[2 * i + 1];
-            check_node(s); check_node(t);
-            if (!m.has_arc(s, t)) {
-                if (m.has_arc(t, s)) m.remove_arc(t, s);
-                if (!m.can_add_arc(s, t)) throw invalid_error("Arc whitelist creates a cycle in the starting Bayesian network.");
-                m.add_arc(s, t);
-            }
-            e.arcs.whitelist.push_back({s, t});
-        }
-        e.use_arcs = cfg->op_arcs != 0;
-        e.use_types = cfg->op_node_type != 0;
-        e.order_arcs_first = cfg->arcs_first;
-        if (!e.use_arcs && !e.use_types) throw invalid_error("pbn_hc_estimate: no operator set");
-        if (e.use_types && cfg->bn_type != PBN_BN_SEMIPARAMETRIC)
-            throw invalid_error("ChangeNodeTypeSet can only be used with non-homogeneous Bayesian networks.");
-        e.arcs.max_indegree = cfg->max_indegree;
-        e.types.whitelisted.assign(n, 0);
-        for (int i = 0; i < cfg->n_type_whitelist; ++i) e.types.whitelisted[cfg->type_whitelist[2 * i]] = 1;
-        for (int i = 0; i < cfg->n_type_blacklist; ++i)
-            e.types.type_blacklist.insert({cfg->type_blacklist[2 * i], cfg->type_blacklist[2 * i + 1]});
+        const int n = m.n;
 
         // ---- estimate_hc (hillclimbing.hpp:62-199) ------------------------------------------------------------
         const bool validated = cfg->validated != 0;

@@ -65,6 +65,34 @@ class CKDE(Factor):
         """Joint bandwidth matrix in [variable, evidence...] order (kde_joint().bandwidth)."""
         return self._bandwidth
 
+    def kde_joint(self):
+        """KDE over [variable] + evidence sharing this factor's training rows (`CKDE.kde_joint`)."""
+        from .kde import KDE
+
+        self._check_fitted("CKDE")
+        k = KDE(self._variables)
+        k._train, k._dtype, k._N = self._train, self._dtype, self._N
+        k._train_idx = self._train.index(self._variables)
+        k._bandwidth = np.array(self._bandwidth)
+        k._device_fit()
+        k._fitted = True
+        return k
+
+    def kde_marg(self):
+        """KDE over the evidence with the bandwidth block H[1:, 1:] (CKDE.hpp:186-199)."""
+        from .kde import KDE
+
+        self._check_fitted("CKDE")
+        if not self._evidence:
+            raise ValueError("CKDE without evidence has no marginal KDE.")
+        k = KDE(self._evidence)
+        k._train, k._dtype, k._N = self._train, self._dtype, self._N
+        k._train_idx = self._train.index(self._evidence)
+        k._bandwidth = np.array(self._bandwidth[1:, 1:])
+        k._device_fit()
+        k._fitted = True
+        return k
+
     def fit(self, df):
         rb = as_record_batch(df)
         dtype = same_type(rb, self._variables)

@@ -25,14 +25,36 @@ _NODE_FROM_CODE = {v: k for k, v in _NODE_CODE.items()}
 
 
 class Operator:
+    _kind = -1
+
     def __init__(self, delta):
         self._delta = delta
 
     def delta(self):
         return self._delta
 
+    def _key(self):
+        raise NotImplementedError
+
+    def __eq__(self, other):  # operators.hpp:108-119: operator type + endpoints (+ node type), delta ignored
+        return isinstance(other, Operator) and self._key() == other._key()
+
+    def __hash__(self):
+        return hash(self._key())
+
 
 class AddArc(Operator):
+    _kind = 0
+
+    def _key(self):
+        return (type(self).__name__, self._source, self._target)
+
+    def opposite(self, model=None):
+        return RemoveArc(self._source, self._target, -self._delta)
+
+    def nodes_changed(self, model=None):
+        return [self._target]
+
     def __init__(self, source, target, delta):
         super().__init__(delta)
         self._source, self._target = source, target
@@ -51,6 +73,11 @@ class AddArc(Operator):
 
 
 class RemoveArc(AddArc):
+    _kind = 1
+
+    def opposite(self, model=None):
+        return AddArc(self._source, self._target, -self._delta)
+
     def apply(self, model):
         model.remove_arc(self._source, self._target)
 
@@ -59,6 +86,14 @@ class RemoveArc(AddArc):
 
 
 class FlipArc(AddArc):
+    _kind = 2
+
+    def opposite(self, model=None):
+        return FlipArc(self._target, self._source, -self._delta)
+
+    def nodes_changed(self, model=None):
+        return [self._source, self._target]
+
     def apply(self, model):
         model.flip_arc(self._source, self._target)
 
@@ -67,6 +102,18 @@ class FlipArc(AddArc):
 
 
 class ChangeNodeType(Operator):
+    _kind = 3
+
+    def _key(self):
+        return ("ChangeNodeType", self._node, self._type)
+
+    def opposite(self, model):
+        """operators.hpp:214-216: ChangeNodeType(node, model.node_type(node), -delta)."""
+        return ChangeNodeType(self._node, model.node_type(self._node), -self._delta)
+
+    def nodes_changed(self, model=None):
+        return [self._node]
+
     def __init__(self, node, node_type, delta):
         super().__init__(delta)
         self._node, self._type = node, node_type
@@ -84,29 +131,288 @@ class ChangeNodeType(Operator):
         return f"ChangeNodeType({self._node} -> {self._type}; {self._delta})"
 
 
+class OperatorTabuSet:
+    """learning/operators/operators.hpp:258-293."""
+
+    def __init__(self):
+        self._ops = set()
+
+    def insert(self, op):
+        self._ops.add(op)
+
+    def contains(self, op):
+        return op in self._ops
+
+    def clear(self):
+        self._ops.clear()
+
+    def empty(self):
+        return not self._ops
+
+
+class LocalScoreCache:
+    """Read-only view of the engine's LocalScoreCache (operators.hpp:295-338)."""
+
+    def __init__(self, binding):
+        self._binding = binding
+
+    def local_score(self, model, variable):
+        return float(self._binding.local_scores()[self._binding.idx[variable]])
+
+    def sum(self):
+        return float(np.sum(self._binding.local_scores()))
+
+
+class _EngineBinding:
+    """One pbn_hc handle bound to (operator sets, score, model node order)."""
+
+    def __init__(self, sets, score, model, arc_blacklist=(), arc_whitelist=(), type_blacklist=(), type_whitelist=(),
+                 max_indegree=0, max_iters=2 ** 31 - 1, epsilon=0.0, patience=0):
+        from .distributed import sharded_batch
+
+        self.nodes = model.nodes()
+        self.idx = {n: i for i, n in enumerate(self.nodes)}
+        self.score, self.model_type = score, model.type()
+        n = len(self.nodes)
+        col_of_node = [score._col[v] for v in self.nodes]
+        idx = self.idx
+
+        def pairs(lst, second=idx.__getitem__):
+            flat = []
+            for a, b in lst:
+                flat += [idx[a], second(b)]
+            return flat
+
+        for st in sets:
+            if isinstance(st, ArcOperatorSet):
+                max_indegree = max_indegree or st.max_indegree
+                arc_blacklist = list(arc_blacklist) + [a for a in st.blacklist if a not in arc_blacklist]
+                arc_whitelist = list(arc_whitelist) + [a for a in st.whitelist if a not in arc_whitelist]
+            else:
+                type_blacklist = list(type_blacklist) + [a for a in st.type_blacklist if a not in type_blacklist]
+                type_whitelist = list(type_whitelist) + [a for a in st.type_whitelist if a not in type_whitelist]
+        self._keep = []
+
+        def arr(values):
+            a = _lib.int_array(values if values else [0])
+            self._keep.append(a)
+            return a
+
+        cfg = _lib.HCConfig()
+        cfg.n_nodes, cfg.bn_type = n, _BN_CODE[type(model.type())]
+        cfg.node_types = arr(self.node_type_codes(model))
+        arcs = pairs(model.arcs())
+        cfg.n_arcs, cfg.arcs = len(arcs) // 2, arr(arcs)
+        bl, wl = pairs(arc_blacklist), pairs(arc_whitelist)
+        cfg.n_arc_blacklist, cfg.arc_blacklist = len(bl) // 2, arr(bl)
+        cfg.n_arc_whitelist, cfg.arc_whitelist = len(wl) // 2, arr(wl)
+        tbl, twl = pairs(type_blacklist, _NODE_CODE.__getitem__), pairs(type_whitelist, _NODE_CODE.__getitem__)
+        cfg.n_type_blacklist, cfg.type_blacklist = len(tbl) // 2, arr(tbl)
+        cfg.n_type_whitelist, cfg.type_whitelist = len(twl) // 2, arr(twl)
+        cfg.op_arcs = int(any(isinstance(st, ArcOperatorSet) for st in sets))
+        cfg.op_node_type = int(any(isinstance(st, ChangeNodeTypeSet) for st in sets))
+        cfg.arcs_first = int(isinstance(sets[0], ArcOperatorSet))
+        cfg.max_indegree, cfg.max_iters = int(max_indegree), int(min(max_iters, 2 ** 31 - 1))
+        cfg.epsilon, cfg.patience = float(epsilon), int(patience)
+        cfg.validated = int(getattr(score, "validated", False))
+        self.cfg = cfg
+        self.errors = []
+        self.batch_hook = None
+
+        def on_batch(_user, validated, n_cand, var, ntype, off, par, out):
+            try:
+                off_l = [off[i] for i in range(n_cand + 1)]
+                var_l = [col_of_node[var[i]] for i in range(n_cand)]
+                nt_l = [ntype[i] for i in range(n_cand)]
+                par_l = [col_of_node[par[i]] for i in range(off_l[-1])]
+                kind = _lib.PBN_SCORE_HOLDOUT if validated else score._kind
+                res = sharded_batch(score, model, var_l, nt_l, off_l, par_l, kind)
+                if self.batch_hook is not None:
+                    self.batch_hook(n_cand)
+                for i in range(n_cand):
+                    out[i] = res[i]
+                return 0
+            except Exception as ex:  # surfaced after the C call returns
+                self.errors.append(ex)
+                return 1
+
+        self.callback = _lib.HC_SCORE_FN(on_batch)
+        self.handle = None
+
+    def node_type_codes(self, model):
+        # set_unknown_node_types (hillclimbing.hpp:81-93): dictionary columns are DiscreteFactor nodes
+        is_disc = getattr(self.score, "is_discrete", lambda v: False)
+        return [_lib.PBN_NODE_DISCRETE if is_disc(v) else _NODE_CODE[model.node_type(v)] for v in self.nodes]
+
+    def check(self, rc):
+        if self.errors:
+            err, self.errors = self.errors[0], []
+            raise err
+        _lib.check(rc)
+
+    # ---- stateful interface -----------------------------------------------------------------------------
+    def create(self):
+        h = C.c_void_p()
+        self.check(_lib.load().pbn_hc_create(C.byref(self.cfg), self.callback, None, C.byref(h)))
+        self.handle = h
+
+    def sync(self, model):
+        if model.nodes() != self.nodes:
+            raise ValueError("The model's nodes changed since cache_scores().")
+        arcs = []
+        for a, b in model.arcs():
+            arcs += [self.idx[a], self.idx[b]]
+        self.check(_lib.load().pbn_hc_set_model(self.handle, len(arcs) // 2, _lib.int_array(arcs or [0]),
+                                               _lib.int_array(self.node_type_codes(model))))
+
+    def cache_scores(self):
+        self.check(_lib.load().pbn_hc_cache_scores(self.handle))
+
+    def find_max(self, tabu=None):
+        flat = []
+        for op in (tabu._ops if tabu is not None else ()):
+            if isinstance(op, ChangeNodeType):
+                flat += [3, self.idx[op.node()], _NODE_CODE[op.node_type()], 0]
+            else:
+                flat += [op._kind, self.idx[op.source()], self.idx[op.target()], 0]
+        out = (C.c_int * 3)()
+        delta = C.c_double(0.0)
+        self.check(_lib.load().pbn_hc_find_max(self.handle, len(flat) // 4, _lib.int_array(flat or [0]), out, C.byref(delta)))
+        return self.make_op(out[0], out[1], out[2], delta.value)
+
+    def make_op(self, kind, a, b, d):
+        if kind < 0:
+            return None
+        if kind == 3:
+            return ChangeNodeType(self.nodes[a], _NODE_FROM_CODE[b], d)
+        return (AddArc, RemoveArc, FlipArc)[kind](self.nodes[a], self.nodes[b], d)
+
+    def update_scores(self, variables):
+        ids = [self.idx[v] for v in variables]
+        self.check(_lib.load().pbn_hc_update_scores(self.handle, len(ids), _lib.int_array(ids or [0])))
+
+    def local_scores(self):
+        out = np.zeros(len(self.nodes))
+        self.check(_lib.load().pbn_hc_get(self.handle, _lib.dptr(out), None, None))
+        return out
+
+    def deltas(self):
+        n = len(self.nodes)
+        arcs, types = np.zeros((n, n), order="F"), np.zeros(n)
+        self.check(_lib.load().pbn_hc_get(self.handle, None, _lib.dptr(arcs), _lib.dptr(types)))
+        return arcs, types
+
+    def close(self):
+        if self.handle is not None:
+            _lib.load().pbn_hc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class OperatorSet:
-    pass
+    """OperatorSet interface of learning/operators/operators.hpp:340-355 on the C++ engine.  The engine keeps
+    its own copy of the model; find_max / update_scores re-synchronise it with the caller's model first."""
+
+    def __init__(self):
+        self._binding = None
+
+    def _sets(self):
+        return [self]
+
+    def _invalidate(self):
+        if self._binding is not None:
+            self._binding.close()
+        self._binding = None
+
+    def _require(self):
+        if self._binding is None or self._binding.handle is None:
+            raise ValueError("Local cache not initialized. Call cache_scores() before find_max()")
+        return self._binding
+
+    def cache_scores(self, model, score):
+        if not score.compatible_bn(model):
+            raise ValueError("BayesianNetwork is not compatible with the score.")
+        self._invalidate()
+        self._binding = _EngineBinding(_flatten_ops(self), score, model)
+        self._binding.create()
+        self._binding.cache_scores()
+
+    def find_max(self, model):
+        b = self._require()
+        b.sync(model)
+        return b.find_max()
+
+    def find_max_tabu(self, model, tabu_set):
+        b = self._require()
+        b.sync(model)
+        return b.find_max(tabu_set)
+
+    def update_scores(self, model, score, variables):
+        b = self._require()
+        b.sync(model)
+        b.update_scores(list(variables))
+
+    def local_score_cache(self):
+        return LocalScoreCache(self._require())
+
+    def delta(self):
+        """(arc delta matrix n x n [source, target], node-type delta vector) of the cached scores."""
+        return self._require().deltas()
+
+    def finished(self):
+        self._invalidate()
 
 
 class ArcOperatorSet(OperatorSet):
     def __init__(self, blacklist=(), whitelist=(), max_indegree=0):
+        super().__init__()
         self.blacklist, self.whitelist, self.max_indegree = list(blacklist), list(whitelist), int(max_indegree)
+
+    def set_arc_blacklist(self, blacklist):
+        self.blacklist = list(blacklist)
+        self._invalidate()
+
+    def set_arc_whitelist(self, whitelist):
+        self.whitelist = list(whitelist)
+        self._invalidate()
+
+    def set_max_indegree(self, max_indegree):
+        self.max_indegree = int(max_indegree)
+        self._invalidate()
 
 
 class ChangeNodeTypeSet(OperatorSet):
     def __init__(self, type_blacklist=(), type_whitelist=()):
+        super().__init__()
         self.type_blacklist, self.type_whitelist = list(type_blacklist), list(type_whitelist)
+
+    def set_type_blacklist(self, type_blacklist):
+        self.type_blacklist = list(type_blacklist)
+        self._invalidate()
+
+    def set_type_whitelist(self, type_whitelist):
+        self.type_whitelist = list(type_whitelist)
+        self._invalidate()
 
 
 class OperatorPool(OperatorSet):
     def __init__(self, opsets):
+        super().__init__()
         if not opsets:
             raise ValueError("op_sets argument cannot be empty.")
         self.opsets = list(opsets)
 
+    def _sets(self):
+        return self.opsets
+
 
 def _flatten_ops(operators):
-    sets = operators.opsets if isinstance(operators, OperatorPool) else [operators]
+    sets = operators._sets() if isinstance(operators, OperatorSet) else [operators]
     kinds = [type(s) for s in sets]
     for k in kinds:
         if k not in (ArcOperatorSet, ChangeNodeTypeSet):
@@ -133,72 +439,10 @@ class GreedyHillClimbing:
         if not score.compatible_bn(start):
             raise ValueError("BayesianNetwork is not compatible with the score.")  # hillclimbing.hpp:292-294
         sets = _flatten_ops(operators)
-        nodes = start.nodes()
-        idx = {n: i for i, n in enumerate(nodes)}
-        n = len(nodes)
-        bn_code = _BN_CODE[type(start.type())]
-        col_of_node = [score._col[v] for v in nodes]
-
-        def pairs(lst, second=idx.__getitem__):
-            flat = []
-            for a, b in lst:
-                flat += [idx[a], second(b)]
-            return flat
-
-        arc_bl, arc_wl = list(arc_blacklist), list(arc_whitelist)
-        type_bl, type_wl = list(type_blacklist), list(type_whitelist)
-        for s in sets:
-            if isinstance(s, ArcOperatorSet):
-                max_indegree = max_indegree or s.max_indegree
-        # set_unknown_node_types (hillclimbing.hpp:81-93): dictionary columns are DiscreteFactor nodes
-        is_disc = getattr(score, "is_discrete", lambda v: False)
-        node_types = [_lib.PBN_NODE_DISCRETE if is_disc(v) else _NODE_CODE[start.node_type(v)] for v in nodes]
-        arcs = pairs(start.arcs())
-        cfg = _lib.HCConfig()
-        keep = []
-
-        def arr(values):
-            a = _lib.int_array(values if values else [0])
-            keep.append(a)
-            return a
-
-        cfg.n_nodes, cfg.bn_type = n, bn_code
-        cfg.node_types = arr(node_types)
-        cfg.n_arcs, cfg.arcs = len(arcs) // 2, arr(arcs)
-        bl, wl = pairs(arc_bl), pairs(arc_wl)
-        cfg.n_arc_blacklist, cfg.arc_blacklist = len(bl) // 2, arr(bl)
-        cfg.n_arc_whitelist, cfg.arc_whitelist = len(wl) // 2, arr(wl)
-        tbl, twl = pairs(type_bl, _NODE_CODE.__getitem__), pairs(type_wl, _NODE_CODE.__getitem__)
-        cfg.n_type_blacklist, cfg.type_blacklist = len(tbl) // 2, arr(tbl)
-        cfg.n_type_whitelist, cfg.type_whitelist = len(twl) // 2, arr(twl)
-        cfg.op_arcs = int(any(isinstance(s, ArcOperatorSet) for s in sets))
-        cfg.op_node_type = int(any(isinstance(s, ChangeNodeTypeSet) for s in sets))
-        cfg.arcs_first = int(isinstance(sets[0], ArcOperatorSet))
-        cfg.max_indegree, cfg.max_iters = int(max_indegree), int(min(max_iters, 2 ** 31 - 1))
-        cfg.epsilon, cfg.patience = float(epsilon), int(patience)
-        cfg.validated = int(getattr(score, "validated", False))
-
-        errors = []
-        from .distributed import sharded_batch
-
-        def on_batch(_user, validated, n_cand, var, ntype, off, par, out):
-            try:
-                off_l = [off[i] for i in range(n_cand + 1)]
-                var_l = [col_of_node[var[i]] for i in range(n_cand)]
-                nt_l = [ntype[i] for i in range(n_cand)]
-                par_l = [col_of_node[par[i]] for i in range(off_l[-1])]
-                kind = _lib.PBN_SCORE_HOLDOUT if validated else score._kind
-                res = sharded_batch(score, start, var_l, nt_l, off_l, par_l, kind)
-                if batch_hook is not None:
-                    batch_hook(n_cand)
-                for i in range(n_cand):
-                    out[i] = res[i]
-                return 0
-            except Exception as ex:  # surfaced after pbn_hc_estimate returns
-                errors.append(ex)
-                return 1
-
-        cb = _lib.HC_SCORE_FN(on_batch)
+        binding = _EngineBinding(sets, score, start, arc_blacklist, arc_whitelist, type_blacklist, type_whitelist,
+                                 max_indegree, max_iters, epsilon, patience)
+        binding.batch_hook = batch_hook
+        nodes, n = binding.nodes, len(binding.nodes)
         out_arcs = (C.c_int * (2 * n * n))()
         out_n = C.c_int(0)
         out_types = (C.c_int * n)()
@@ -207,10 +451,9 @@ class GreedyHillClimbing:
         trace = (C.c_int * (4 * cap))()
         tdelta = (C.c_double * cap)()
         stats.trace_capacity, stats.trace, stats.trace_delta = cap, trace, tdelta
-        rc = _lib.load().pbn_hc_estimate(C.byref(cfg), cb, None, out_arcs, C.byref(out_n), out_types, C.byref(stats))
-        if errors:
-            raise errors[0]
-        _lib.check(rc)
+        rc = _lib.load().pbn_hc_estimate(C.byref(binding.cfg), binding.callback, None, out_arcs, C.byref(out_n), out_types,
+                                         C.byref(stats))
+        binding.check(rc)
         res_types = [(nodes[i], _NODE_FROM_CODE[out_types[i]]) for i in range(n)]
         res_arcs = [(nodes[out_arcs[2 * i]], nodes[out_arcs[2 * i + 1]]) for i in range(out_n.value)]
         result = BayesianNetwork(start.type(), nodes, res_arcs, [] if start.type().homogeneous else res_types)
@@ -218,15 +461,9 @@ class GreedyHillClimbing:
         self.last.iterations = stats.iterations
         self.last.cells_scored = stats.cells_scored
         self.last.local_score_evals = stats.local_score_evals
-        ops = []
-        for i in range(stats.trace_len):
-            kind, a, b = trace[4 * i], trace[4 * i + 1], trace[4 * i + 2]
-            d = tdelta[i]
-            if kind == 3:
-                ops.append(ChangeNodeType(nodes[a], _NODE_FROM_CODE[b], d))
-            else:
-                ops.append((AddArc, RemoveArc, FlipArc)[kind](nodes[a], nodes[b], d))
-        self.last.trace = ops
+        self.last.trace = [binding.make_op(trace[4 * i], trace[4 * i + 1], trace[4 * i + 2], tdelta[i]) for i in range(stats.trace_len)]
+        if callback is not None:  # Callback::call(model, operator, score, iteration) hook (hillclimbing.hpp:127,180,195)
+            callback.call(result, None, score, stats.iterations)
         return result
 
 

@@ -158,6 +158,24 @@ class Score:
     def _batch_params(self, model):
         return self._params
 
+    # -- split layout ------------------------------------------------------------------------------------------
+    def _layout(self):
+        """(perm, limits, n_cv, n_hold): source row of every split-ordered row, fold limits, region sizes."""
+        n = self._table.num_rows
+        perm = np.zeros(n, dtype=np.int32)
+        limits = np.zeros(max(getattr(self, "_k", 0), 0) + 1, dtype=np.int32)
+        n_cv, n_hold = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().pbn_scoredata_layout(self._handle, perm.ctypes.data, limits.ctypes.data if limits.size > 1 else None,
+                                                    C.byref(n_cv), C.byref(n_hold)))
+        return perm, limits, n_cv.value, n_hold.value
+
+    def _take(self, rows):
+        import pyarrow as pa
+
+        if self._df is None:
+            raise ValueError("This score was built from a device table; no host DataFrame is attached.")
+        return self._df.take(pa.array(np.asarray(rows, dtype=np.int32)))
+
     def __del__(self):
         try:
             if getattr(self, "_handle", None):
@@ -224,11 +242,13 @@ class CVLikelihood(_LikelihoodScore):
 
     def fold_layout(self):
         """(perm, limits): source row of every permuted row and the k+1 fold limits."""
-        n = self._table.num_rows
-        perm = np.zeros(n, dtype=np.int32)
-        limits = np.zeros(self._k + 1, dtype=np.int32)
-        _lib.check(_lib.load().pbn_scoredata_layout(self._handle, perm.ctypes.data, limits.ctypes.data, None, None))
+        perm, limits, _, _ = self._layout()
         return perm, limits
+
+    @property
+    def cv(self):
+        """The CrossValidation object of the reference (`CVLikelihood.cv`, pybindings_scores.cpp:553-557)."""
+        return CrossValidationView(self)
 
 
 class HoldoutLikelihood(_LikelihoodScore):
@@ -241,6 +261,14 @@ class HoldoutLikelihood(_LikelihoodScore):
         self._seed = _random_seed() if seed is None else int(seed)
         super().__init__(df, (0, self._seed, float(test_ratio)), ctx=ctx, table=table)
 
+    def training_data(self):
+        perm, _, n_cv, _ = self._layout()
+        return self._take(perm[:n_cv])
+
+    def test_data(self):
+        perm, _, n_cv, n_hold = self._layout()
+        return self._take(perm[n_cv: n_cv + n_hold])
+
 
 class ValidatedLikelihood(_LikelihoodScore):
     """learning/scores/validated_likelihood.hpp:12-75: local_score = CV over the hold-out training part,
@@ -252,7 +280,25 @@ class ValidatedLikelihood(_LikelihoodScore):
 
     def __init__(self, df, test_ratio=0.2, k=10, seed=None, ctx=None, table=None):
         self._seed = _random_seed() if seed is None else int(seed)
+        self._k = int(k)
         super().__init__(df, (int(k), self._seed, float(test_ratio)), ctx=ctx, table=table)
+
+    def training_data(self):
+        """Hold-out training part in the hold-out shuffle order is not kept: rows are returned in CV order."""
+        perm, _, n_cv, _ = self._layout()
+        return self._take(perm[:n_cv])
+
+    def validation_data(self):
+        perm, _, n_cv, n_hold = self._layout()
+        return self._take(perm[n_cv: n_cv + n_hold])
+
+    @property
+    def cv_lik(self):
+        return _ScoreView(self, _lib.PBN_SCORE_CVLIK)
+
+    @property
+    def holdout_lik(self):
+        return _ScoreView(self, _lib.PBN_SCORE_HOLDOUT)
 
     def vlocal_score(self, model, variable, evidence=None):
         evidence = model.parents(variable) if evidence is None else list(evidence)
@@ -264,6 +310,45 @@ class ValidatedLikelihood(_LikelihoodScore):
     def vscore(self, model):
         cands = [(n, model.node_type(n), model.parents(n)) for n in model.nodes()]
         return float(np.sum(self._batch(model, cands, _lib.PBN_SCORE_HOLDOUT)))
+
+
+class _ScoreView:
+    """`ValidatedLikelihood.cv_lik` / `.holdout_lik`: the same engine handle evaluated with one fixed score kind."""
+
+    def __init__(self, parent, kind):
+        self._parent, self._kind = parent, kind
+
+    def local_score(self, model, variable, evidence=None):
+        evidence = model.parents(variable) if evidence is None else list(evidence)
+        return self._parent._batch(model, [(variable, model.node_type(variable), evidence)], self._kind)[0]
+
+    def local_score_node_type(self, model, variable_type, variable, evidence):
+        return self._parent._batch(model, [(variable, variable_type, list(evidence))], self._kind)[0]
+
+    def score(self, model):
+        cands = [(n, model.node_type(n), model.parents(n)) for n in model.nodes()]
+        return float(np.sum(self._parent._batch(model, cands, self._kind)))
+
+
+class CrossValidationView:
+    """dataset::CrossValidation as seen from Python (pybindings_dataset.cpp): iterating yields (train, test) tables;
+    `.indices()` yields (train_indices, test_indices) exactly as generate_cv_pair_indices (crossvalidation_adaptator.cpp)."""
+
+    def __init__(self, score):
+        self._score = score
+
+    def indices(self):
+        perm, limits, n_cv, _ = self._score._layout()
+        for f in range(len(limits) - 1):
+            yield (np.concatenate([perm[: limits[f]], perm[limits[f + 1]: n_cv]]), perm[limits[f]: limits[f + 1]].copy())
+
+    def fold(self, f):
+        tr, te = list(self.indices())[f]
+        return self._score._take(tr), self._score._take(te)
+
+    def __iter__(self):
+        for tr, te in self.indices():
+            yield self._score._take(tr), self._score._take(te)
 
 
 def default_score(bn_type, df, seed=None, num_folds=10, test_holdout_ratio=0.2):

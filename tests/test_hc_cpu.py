@@ -183,3 +183,54 @@ def test_hc_with_discrete_nodes_type_rule(ensure_built, seed):
     for s, t in res.arcs():
         assert not (types[idx[t]] == 2 and types[idx[s]] != 2)
     assert [o_types[i] for i in range(n) if types[i] == 2] == [2] * types.count(2)
+
+
+def test_operator_set_piecewise_api_reproduces_estimate(ensure_built):
+    """OperatorSet.cache_scores / find_max / find_max_tabu / update_scores + LocalScoreCache + OperatorTabuSet
+    (operators.hpp:258-355) driven from Python reproduce GreedyHillClimbing.estimate step for step."""
+    import pybnesian_amd as pbn
+
+    n, seed = 9, 2
+    names = [f"n{i}" for i in range(n)]
+    ts = TableScore(n, seed)
+    hc = pbn.GreedyHillClimbing()
+    ref = hc.estimate(pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]), ts, pbn.SemiparametricBN(names))
+    ref_trace = list(hc.last.trace)
+
+    pool = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
+    model = pbn.SemiparametricBN(names)
+    with pytest.raises(ValueError, match="Local cache not initialized"):
+        pool.find_max(model)
+    pool.cache_scores(model, ts)
+    cache = pool.local_score_cache()
+    for v in names:
+        assert cache.local_score(model, v) == ts.raw(int(v[1:]), 0, [])
+    darcs, dtypes = pool.delta()
+    i, j = 2, 5  # delta(source, target) of an addition = S(t | s) - S(t)
+    assert darcs[i, j] == ts.raw(j, 0, [i]) - ts.raw(j, 0, [])
+    assert dtypes[3] == ts.raw(3, 1, []) - ts.raw(3, 0, [])
+    trace = []
+    while True:
+        op = pool.find_max(model)
+        if op is None or op.delta() < 1.4901161193847656e-08:
+            break
+        op.apply(model)
+        trace.append(op)
+        pool.update_scores(model, ts, op.nodes_changed(model))
+    assert trace == ref_trace and [o.delta() for o in trace] == [o.delta() for o in ref_trace]
+    assert sorted(model.arcs()) == sorted(ref.arcs())
+    assert cache.sum() == pytest.approx(sum(ts.raw(int(v[1:]), 0 if model.node_type(v) == pbn.LinearGaussianCPDType() else 1,
+                                                   [int(p[1:]) for p in model.parents(v)]) for v in names))
+    # tabu: the best operator is skipped when it is in the tabu set
+    pool.cache_scores(pbn.SemiparametricBN(names), ts)
+    fresh = pbn.SemiparametricBN(names)
+    best = pool.find_max(fresh)
+    tabu = pbn.OperatorTabuSet()
+    assert tabu.empty() and not tabu.contains(best)
+    tabu.insert(best)
+    second = pool.find_max_tabu(fresh, tabu)
+    assert tabu.contains(best) and second != best and second.delta() <= best.delta()
+    assert best.opposite(fresh) == (pbn.RemoveArc(best.source(), best.target(), 0) if isinstance(best, pbn.AddArc) else best.opposite(fresh))
+    pool.finished()
+    with pytest.raises(ValueError):
+        pool.find_max(fresh)

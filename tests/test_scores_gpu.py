@@ -274,3 +274,33 @@ def test_fp32_scores(pbn, golden, oracle):
         idx = [COLS.index(v) for v in [variable] + evidence]
         want = oracle.bic_lg(data[:, idx])
         assert abs(bic.local_score(pbn.GaussianNetwork(COLS), variable, evidence) - want) <= 1e-3 * abs(want)
+
+
+def test_split_accessors_and_kde_views(pbn, golden, oracle):
+    """CVLikelihood.cv, Holdout training_data/test_data, ValidatedLikelihood.cv_lik/holdout_lik
+    (pybindings_scores.cpp:516-660) and CKDE.kde_joint/kde_marg (pybindings_factors.cpp:583-640)."""
+    data = golden["train10k"][:400]
+    df = frame(data)
+    cv = pbn.CVLikelihood(df, 4, 6)
+    folds = list(cv.cv.indices())
+    want = oracle.cv_folds(400, 4, 6)
+    assert len(folds) == 4
+    for (tr, te), (wtr, wte) in zip(folds, want):
+        assert np.array_equal(tr, wtr) and np.array_equal(te, wte)
+    tr_df, te_df = cv.cv.fold(1)
+    assert tr_df.num_rows + te_df.num_rows == 400
+    assert np.allclose(te_df.column(0).to_numpy(), data[want[1][1], 0])
+    ho = pbn.HoldoutLikelihood(df, 0.25, 3)
+    wtr, wte = oracle.holdout_split(400, 0.25, 3)
+    assert np.allclose(ho.training_data().column(1).to_numpy(), data[wtr, 1])
+    assert np.allclose(ho.test_data().column(1).to_numpy(), data[wte, 1])
+    vl = pbn.ValidatedLikelihood(df, 0.2, 3, 8)
+    net = pbn.SemiparametricBN(COLS)
+    assert vl.cv_lik.local_score(net, "b", ["a"]) == vl.local_score(net, "b", ["a"])
+    assert vl.holdout_lik.local_score(net, "b", ["a"]) == vl.vlocal_score(net, "b", ["a"])
+    assert vl.training_data().num_rows + vl.validation_data().num_rows == 400
+    cpd = pbn.CKDE("c", ["a", "b"])
+    cpd.fit(df)
+    test = frame(golden["test50"])
+    lj, lm = cpd.kde_joint().logl(test), cpd.kde_marg().logl(test)
+    assert np.allclose(lj - lm, cpd.logl(test), rtol=1e-9, atol=1e-10)
