@@ -233,25 +233,15 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         }
     }
 
-    // ---- main loop over training tiles --------------------------------------------------------
-    T af[KS];
-    V nx;
-    T ax = 0;
+    // ---- main loop over training tiles: two tiles per iteration with ping-pong fragment buffers (no
+    // register copies); the fragments of tile t+1 / t+2 are in flight while tile t is processed -------------
+    auto load_tile = [&](int64_t t, T (&f)[KS], V& n, T& x) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t0 * KS + ks) * 64 + lane];
-    nx = *(const V*)(Np + t0 * 16 + lg * 4);
-    if (COND) ax = Xp[t0 * 64 + lane];
-
-    for (int64_t t = t0; t < t1; ++t) {
-        // prefetch the next tile's fragments (clamped: the last iteration re-reads its own tile)
-        const int64_t tn = t + 1 < t1 ? t + 1 : t;
-        T afn[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) afn[ks] = Ap[(tn * KS + ks) * 64 + lane];
-        V nxn = *(const V*)(Np + tn * 16 + lg * 4);
-        T axn = 0;
-        if (COND) axn = Xp[tn * 64 + lane];
-
+        for (int ks = 0; ks < KS; ++ks) f[ks] = Ap[(t * KS + ks) * 64 + lane];
+        n = *(const V*)(Np + t * 16 + lg * 4);
+        if (COND) x = Xp[t * 64 + lane];
+    };
+    auto process_tile = [&](const T (&af)[KS], const V& nx, const T ax) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             V acc = nx + cm[g];
@@ -295,10 +285,18 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             sum[g] += (double)ts;
             if (COND) sumj[g] += (double)tsj;
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = afn[ks];
-        nx = nxn;
-        ax = axn;
+    };
+
+    T afA[KS], afB[KS];
+    V nxA, nxB;
+    T axA = 0, axB = 0;
+    load_tile(t0, afA, nxA, axA);
+    for (int64_t t = t0; t < t1; t += 2) {
+        const bool second = t + 1 < t1;                       // wave-uniform
+        load_tile(second ? t + 1 : t, afB, nxB, axB);
+        process_tile(afA, nxA, axA);
+        load_tile(t + 2 < t1 ? t + 2 : t, afA, nxA, axA);
+        if (second) process_tile(afB, nxB, axB);
     }
 
     // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
