@@ -224,9 +224,9 @@ def _fit_slogl(train, test, node_type):
 MACHINE_TOL = 1.4901161193847656e-08
 
 
-def config_index(codes, cards):
+def config_index(codes, cards, n=None):
     """codes: list of int arrays (evidence order); stride_0 = 1, stride_i = stride_{i-1} * card_{i-1}."""
-    idx = np.zeros(len(codes[0]) if codes else 0, dtype=np.int64)
+    idx = np.zeros(len(codes[0]) if codes else (n or 0), dtype=np.int64)
     stride, n = 1, 1
     for c, k in zip(codes, cards):
         idx += np.asarray(c, dtype=np.int64) * stride
@@ -238,7 +238,7 @@ def config_index(codes, cards):
 def bic_clg(cont, dcodes, dcards):
     """BIC::bic_clg (bic.cpp:29-64); cont = [variable, continuous parents...] (N x d)."""
     cont = np.asarray(cont)
-    cfg, ncfg = config_index(dcodes, dcards)
+    cfg, ncfg = config_index(dcodes, dcards, cont.shape[0])
     p = cont.shape[1] - 1
     loglik = 0.0
     for c in range(ncfg):
@@ -290,7 +290,7 @@ def discrete_fit_slogl(vcodes, card0, pcodes, pcards, train, test):
 def adaptator_fit_slogl(cont, dcodes, dcards, train, test, node_type):
     """DiscreteAdaptator<LinearGaussianCPD | CKDE>::fit on train rows + slogl on test rows."""
     cont = np.asarray(cont)
-    cfg, ncfg = config_index(dcodes, dcards)
+    cfg, ncfg = config_index(dcodes, dcards, cont.shape[0])
     total = 0.0
     for c in range(ncfg):
         tr = train[cfg[train] == c]

@@ -6,7 +6,7 @@ HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
 """
 from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
 from .dataset import Context, DeviceTable, default_context  # noqa: F401
-from .factors import CKDE, MLE, Factor, LinearGaussianCPD  # noqa: F401
+from .factors import CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, Factor, LinearGaussianCPD  # noqa: F401
 from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
 from .learning import (AddArc, ArcOperatorSet, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
@@ -20,6 +20,6 @@ __all__ = [
     "ArcOperatorSet", "ChangeNodeTypeSet", "OperatorPool", "OperatorTabuSet", "LocalScoreCache", "AddArc", "RemoveArc", "FlipArc", "ChangeNodeType",
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
-    "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
+    "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
     "SingularCovarianceData", "Context", "DeviceTable", "default_context", "load_library",
 ]

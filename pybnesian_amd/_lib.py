@@ -99,6 +99,22 @@ class HCStats(C.Structure):
 
 
 _lib = None
+_alive = True
+
+
+def _shutdown():
+    # after this point (interpreter exit) destructors must not call into the HIP runtime any more
+    global _alive
+    _alive = False
+
+
+import atexit  # noqa: E402
+
+atexit.register(_shutdown)
+
+
+def alive():
+    return _alive
 
 
 def load():

@@ -119,6 +119,8 @@ class Context:
 
     def __del__(self):
         try:
+            if not _lib.alive():
+                return
             if getattr(self, "handle", None):
                 _lib.load().pbn_ctx_destroy(self.handle)
                 self.handle = None
@@ -212,6 +214,8 @@ class DeviceTable:
 
     def __del__(self):
         try:
+            if not _lib.alive():
+                return
             if getattr(self, "handle", None):
                 _lib.load().pbn_table_destroy(self.handle)
                 self.handle = None

@@ -171,6 +171,8 @@ class CKDE(Factor):
 
     def __del__(self):
         try:
+            if not _lib.alive():
+                return
             if getattr(self, "_handle", None) is not None:
                 _lib.load().pbn_kde_destroy(self._handle)
                 self._handle = None
@@ -267,3 +269,210 @@ class MLE:
         cpd = LinearGaussianCPD(variable, list(evidence))
         cpd.fit(df)
         return LinearGaussianParams(cpd.beta, cpd.variance)
+
+
+# ---- hybrid factors (factors/discrete/) --------------------------------------------------------------------------
+def _dictionary_column(rb, name):
+    import pyarrow as pa
+
+    idx = rb.schema.get_field_index(name)
+    if idx < 0:
+        raise KeyError(f"Column {name} not present in DataFrame.")
+    col = rb.column(idx)
+    if not pa.types.is_dictionary(col.type):
+        raise ValueError(f"Variable {name} is not categorical.")
+    return col
+
+
+class DiscreteFactor(Factor):
+    """Multinomial CPT (factors/discrete/DiscreteFactor.cpp:34-171, learning/parameters/mle_DiscreteFactor.cpp:5-41).
+    Integer counting on the host: logP = log(count) - log(sum over the parent
+    configuration), uniform for unseen configurations."""
+
+    def __init__(self, variable, evidence):
+        super().__init__(variable, evidence)
+        self._logprob = None
+
+    def type(self):
+        return "DiscreteFactor"
+
+    def _indices(self, rb):
+        cols = [_dictionary_column(rb, v) for v in [self._variable] + self._evidence]
+        if self._fitted:
+            for c, cats, name in zip(cols, self._categories, [self._variable] + self._evidence):
+                if c.dictionary.to_pylist() != cats:
+                    raise ValueError(f"Variable {name} does not contain the same categories.")  # discrete_indices.cpp:206-227
+        valid = np.ones(rb.num_rows, dtype=bool)
+        idx = np.zeros(rb.num_rows, dtype=np.int64)
+        stride = 1
+        cards = []
+        for c in cols:
+            codes = c.indices.to_numpy(zero_copy_only=False)
+            if c.null_count:
+                m = np.asarray(c.is_valid().to_numpy(zero_copy_only=False), dtype=bool)
+                valid &= m
+                codes = np.where(m, codes, 0)
+            idx += codes.astype(np.int64) * stride
+            cards.append(len(c.dictionary))
+            stride *= cards[-1]
+        return cols, idx, valid, cards
+
+    def fit(self, df):
+        rb = as_record_batch(df)
+        self._fitted = False
+        cols, idx, valid, cards = self._indices(rb)
+        self._categories = [c.dictionary.to_pylist() for c in cols]
+        self._cards = cards
+        counts = np.bincount(idx[valid], minlength=int(np.prod(cards))).astype(np.float64).reshape(-1, cards[0])
+        sums = counts.sum(axis=1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lp = np.where(sums > 0, np.log(counts) - np.log(np.where(sums > 0, sums, 1.0)), np.log(1.0 / cards[0]))
+        self._logprob = lp.reshape(-1)
+        self._fitted = True
+
+    def logl(self, df):
+        self._check_fitted("DiscreteFactor")
+        _, idx, valid, _ = self._indices(as_record_batch(df))
+        out = np.full(idx.shape[0], np.nan)
+        out[valid] = self._logprob[idx[valid]]
+        return out
+
+    def slogl(self, df):
+        return float(np.nansum(self.logl(df)))
+
+
+class _DiscreteAdaptator(Factor):
+    """DiscreteAdaptator<Base, Fitter> (factors/discrete/DiscreteAdaptator.hpp:201-348): one base factor per
+    configuration of the discrete evidence; the per-slice work runs on the device through the base factor."""
+
+    _name = "DiscreteAdaptator"
+
+    def __init__(self, variable, evidence):
+        super().__init__(variable, evidence)
+        self._factors = []
+
+    def _base(self, continuous_evidence):
+        raise NotImplementedError
+
+    def _fit_base(self, factor, df):
+        raise NotImplementedError
+
+    def _split(self, rb):
+        import pyarrow as pa
+
+        disc, cont = [], []
+        for e in self._evidence:
+            t = rb.schema.field(e).type
+            if pa.types.is_dictionary(t):
+                disc.append(e)
+            elif pa.types.is_floating(t):
+                cont.append(e)
+            else:
+                raise ValueError(f"Non valid data type for variable {e}. Only \"dictionary\", \"double\" and \"float\" data types are allowed.")
+        return disc, cont
+
+    def _config(self, rb):
+        idx = np.zeros(rb.num_rows, dtype=np.int64)
+        valid = np.ones(rb.num_rows, dtype=bool)
+        stride = 1
+        for name, cats in zip(self._disc, self._categories):
+            c = _dictionary_column(rb, name)
+            if c.dictionary.to_pylist() != cats:
+                raise ValueError(f"Variable {name} does not contain the same categories.")
+            codes = c.indices.to_numpy(zero_copy_only=False)
+            if c.null_count:
+                m = np.asarray(c.is_valid().to_numpy(zero_copy_only=False), dtype=bool)
+                valid &= m
+                codes = np.where(m, codes, 0)
+            idx += codes.astype(np.int64) * stride
+            stride *= len(cats)
+        return idx, valid
+
+    def fit(self, df):
+        import pyarrow as pa
+
+        rb = as_record_batch(df)
+        self._disc, self._cont = self._split(rb)
+        self._categories = [_dictionary_column(rb, d).dictionary.to_pylist() for d in self._disc]
+        self._factors = []
+        if not self._disc:
+            f = self._base(self._cont)
+            f.fit(rb)
+            self._factors = [f]
+        else:
+            ncfg = int(np.prod([len(c) for c in self._categories]))
+            idx, valid = self._config(rb)
+            for c in range(ncfg):
+                rows = np.nonzero(valid & (idx == c))[0]
+                if rows.size == 0:
+                    self._factors.append(None)
+                    continue
+                f = self._base(self._cont)
+                ok = self._fit_base(f, rb.take(pa.array(rows.astype(np.int32))))
+                self._factors.append(f if ok else None)
+        self._fitted = True
+
+    def logl(self, df):
+        import pyarrow as pa
+
+        self._check_fitted(self._name)
+        rb = as_record_batch(df)
+        if not self._disc:
+            return self._factors[0].logl(rb)
+        idx, valid = self._config(rb)
+        out = np.full(rb.num_rows, np.nan)
+        for c, f in enumerate(self._factors):
+            rows = np.nonzero(valid & (idx == c))[0]
+            if rows.size and f is not None:
+                out[rows] = f.logl(rb.take(pa.array(rows.astype(np.int32))))
+        return out
+
+    def slogl(self, df):
+        import pyarrow as pa
+
+        self._check_fitted(self._name)
+        rb = as_record_batch(df)
+        if not self._disc:
+            return self._factors[0].slogl(rb)
+        idx, valid = self._config(rb)
+        total = 0.0
+        for c, f in enumerate(self._factors):
+            rows = np.nonzero(valid & (idx == c))[0]
+            if rows.size and f is not None:
+                total += f.slogl(rb.take(pa.array(rows.astype(np.int32))))
+        return total
+
+
+class CLinearGaussianCPD(_DiscreteAdaptator):
+    """CLinearGaussianCPD = DiscreteAdaptator<LinearGaussianCPD, LinearGaussianFitter> (LinearGaussianCPD.hpp:120-140)."""
+
+    _name = "CLinearGaussianCPD"
+
+    def type(self):
+        return "LinearGaussianFactor"
+
+    def _base(self, continuous_evidence):
+        return LinearGaussianCPD(self._variable, continuous_evidence)
+
+    def _fit_base(self, factor, df):
+        factor.fit(df)
+        return not (factor.variance < 1.4901161193847656e-08 or np.isinf(factor.variance))
+
+
+class HCKDE(_DiscreteAdaptator):
+    """HCKDE = DiscreteAdaptator<CKDE, CKDEFitter> (CKDE.hpp:745-770): SingularCovarianceData drops the slice's factor."""
+
+    _name = "HCKDE"
+
+    def type(self):
+        return "CKDEFactor"
+
+    def _base(self, continuous_evidence):
+        return CKDE(self._variable, continuous_evidence)
+
+    def _fit_base(self, factor, df):
+        try:
+            factor.fit(df)
+            return True
+        except _lib.SingularCovarianceData:
+            return False

@@ -248,6 +248,8 @@ class _KDEBase:
 
     def __del__(self):
         try:
+            if not _lib.alive():
+                return
             if getattr(self, "_handle", None) is not None:
                 _lib.load().pbn_kde_destroy(self._handle)
                 self._handle = None

@@ -309,6 +309,8 @@ class _EngineBinding:
 
     def __del__(self):
         try:
+            if not _lib.alive():
+                return
             self.close()
         except Exception:
             pass

@@ -202,6 +202,57 @@ class BayesianNetwork:
     def clone(self):
         return BayesianNetwork(self._type, self._nodes, self.arcs(), list(self._types.items()))
 
+    # -- parameters: BayesianNetwork::fit / logl / slogl (models/BayesianNetwork.hpp:960-994) -------------------
+    def _new_factor(self, df, node):
+        """FactorType::new_factor (CKDE.cpp:15-41, LinearGaussianCPD.cpp:20-46): discrete evidence selects the
+        DiscreteAdaptator variant."""
+        import pyarrow as pa
+
+        from .dataset import as_record_batch
+        from .factors import CKDE, HCKDE, CLinearGaussianCPD, DiscreteFactor, LinearGaussianCPD
+
+        rb = as_record_batch(df)
+        parents = self.parents(node)
+        is_disc = lambda v: pa.types.is_dictionary(rb.schema.field(v).type)
+        nt = DiscreteFactorType() if is_disc(node) else self._types[node]
+        if nt == DiscreteFactorType():
+            return DiscreteFactor(node, parents)
+        hybrid = any(is_disc(p) for p in parents)
+        if nt == CKDEType():
+            return HCKDE(node, parents) if hybrid else CKDE(node, parents)
+        return CLinearGaussianCPD(node, parents) if hybrid else LinearGaussianCPD(node, parents)
+
+    def fit(self, df):
+        self._cpds = {}
+        for n in self._nodes:
+            f = self._new_factor(df, n)
+            f.fit(df)
+            self._cpds[n] = f
+
+    def fitted(self):
+        return getattr(self, "_cpds", None) is not None and all(n in self._cpds for n in self._nodes)
+
+    def cpd(self, node):
+        if not self.fitted():
+            raise ValueError("Model not fitted.")
+        return self._cpds[node]
+
+    def logl(self, df):
+        if not self.fitted():
+            raise ValueError("Model not fitted.")
+        import numpy as np
+
+        out = None
+        for n in self._nodes:
+            ll = self._cpds[n].logl(df)
+            out = ll if out is None else out + ll
+        return out if out is not None else np.zeros(0)
+
+    def slogl(self, df):
+        if not self.fitted():
+            raise ValueError("Model not fitted.")
+        return float(sum(self._cpds[n].slogl(df) for n in self._nodes))
+
     def __str__(self):
         return f"{self._type} with {self.num_nodes()} nodes and {self.num_arcs()} arcs"
 

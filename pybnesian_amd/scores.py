@@ -178,6 +178,8 @@ class Score:
 
     def __del__(self):
         try:
+            if not _lib.alive():
+                return
             if getattr(self, "_handle", None):
                 _lib.load().pbn_scoredata_destroy(self._handle)
                 self._handle = None

@@ -154,3 +154,35 @@ def test_hc_with_discrete_nodes_vs_oracle(pbn, oracle):
     assert all(res.node_type(c) == pbn.DiscreteFactorType() for c in disc)
     assert not any(s not in disc and t in disc for s, t in res.arcs())
     assert hc.last.cells_scored == info["cells_scored"]
+
+
+def test_hybrid_factor_classes_and_model_fit(pbn, oracle):
+    """HCKDE / CLinearGaussianCPD / DiscreteFactor as stand-alone factors and BayesianNetwork.fit / logl / slogl
+    (models/BayesianNetwork.hpp:960-994) on a hybrid table."""
+    n = 1000
+    df, codes, cards = make_hybrid(n, seed=11)
+    train, test = df.iloc[:800], df.iloc[800:]
+    tr, te = np.arange(800), np.arange(800, n)
+    cont = df[["y", "x"]].to_numpy()
+    for cls, node_type in ((pbn.CLinearGaussianCPD, "lg"), (pbn.HCKDE, "ckde")):
+        f = cls("y", ["x", "B"])
+        f.fit(train)
+        want = oracle.adaptator_fit_slogl(cont, [codes["B"]], [3], tr, te, node_type)
+        assert close(f.slogl(test), want)
+        assert close(float(np.nansum(f.logl(test))), want)
+    d = pbn.DiscreteFactor("B", ["A"])
+    d.fit(train)
+    want = oracle.discrete_fit_slogl(codes["B"], 3, [codes["A"]], [2], tr, te)
+    assert close(d.slogl(test), want)
+    net = pbn.SemiparametricBN(list(df.columns), [("A", "B"), ("A", "x"), ("x", "y"), ("B", "y"), ("y", "z")],
+                               [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType()), ("z", pbn.CKDEType())])
+    net.fit(train)
+    total = net.slogl(test)
+    parts = (oracle.discrete_fit_slogl(codes["A"], 2, [], [], tr, te)
+             + oracle.discrete_fit_slogl(codes["B"], 3, [codes["A"]], [2], tr, te)
+             + oracle.adaptator_fit_slogl(df[["x"]].to_numpy(), [codes["A"]], [2], tr, te, "lg")
+             + oracle.adaptator_fit_slogl(df[["y", "x"]].to_numpy(), [codes["B"]], [3], tr, te, "lg")
+             + oracle.adaptator_fit_slogl(df[["z", "y"]].to_numpy(), [], [], tr, te, "ckde"))
+    assert close(total, parts)
+    assert close(float(net.logl(test).sum()), total, rtol=1e-9)
+    assert isinstance(net.cpd("y"), pbn.CLinearGaussianCPD) and isinstance(net.cpd("z"), pbn.CKDE)
