@@ -131,6 +131,27 @@ class CKDE(Factor):
         self._handle, self._train, self._dtype, self._bandwidth, self._N = h, table, table.dtype, H, n
         self._fitted = True
 
+    def __getstate__(self):
+        state = {"variable": self._variable, "evidence": self._evidence, "selector": self._selector, "fitted": self._fitted}
+        if self._fitted:
+            vals = self._train.read(self._variables)
+            state.update(bandwidth=np.array(self._bandwidth), training=np.asfortranarray(vals).reshape(-1, order="F"),
+                         N=self._N, dtype=self._dtype)
+        return state
+
+    def __setstate__(self, state):
+        self.__init__(state["variable"], state["evidence"], state["selector"])
+        if state["fitted"]:
+            d, n = len(self._variables), state["N"]
+            vals = np.asarray(state["training"]).reshape(n, d, order="F")
+            rb = pa.RecordBatch.from_pydict({v: pa.array(np.ascontiguousarray(vals[:, i])) for i, v in enumerate(self._variables)})
+            table, _ = DeviceTable.from_dataframe(default_context(), rb, self._variables, drop_null=False)
+            H = np.asfortranarray(state["bandwidth"], dtype=np.float64)
+            h = C.c_void_p()
+            _lib.check(_lib.load().pbn_ckde_fit(table.ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, n, _lib.dptr(H), None, C.byref(h)))
+            self._handle, self._train, self._dtype, self._bandwidth, self._N = h, table, table.dtype, H, n
+            self._fitted = True
+
     def _upload_test(self, df):
         self._check_fitted("CKDE")
         rb = as_record_batch(df)

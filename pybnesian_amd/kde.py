@@ -246,6 +246,31 @@ class _KDEBase:
         n = table.num_rows - row0 if n is None else n
         _lib.check(_lib.load().pbn_kde_slogl_async(self._handle, table.handle, _lib.int_array(idx), row0, n, C.c_void_p(dev_out_ptr)))
 
+    # -- pickle: (variables, fitted, selector, bandwidth, flat column-major training values, lognorm, N, dtype),
+    # the tuple layout of KDE::__getstate__ (kde/KDE.hpp:642-666); the training matrix is read back from HBM ------
+    def __getstate__(self):
+        state = {"variables": self._variables, "fitted": self._fitted, "selector": self._selector}
+        if self._fitted:
+            vals = self._train.read([self._train.names[i] for i in self._train_idx])
+            state.update(bandwidth=np.array(self._bandwidth), training=np.asfortranarray(vals).reshape(-1, order="F"),
+                         N=self._N, dtype=self._dtype,
+                         lognorm=_lib.load().pbn_kde_lognorm(self._handle, 0))
+        return state
+
+    def __setstate__(self, state):
+        self.__init__(state["variables"], state["selector"])
+        if state["fitted"]:
+            d, n = len(self._variables), state["N"]
+            vals = np.asarray(state["training"]).reshape(n, d, order="F")
+            cols = {v: pa.array(np.ascontiguousarray(vals[:, i])) for i, v in enumerate(self._variables)}
+            rb = pa.RecordBatch.from_pydict(cols)
+            table, _ = DeviceTable.from_dataframe(default_context(), rb, self._variables, drop_null=False)
+            self._train, self._dtype, self._N = table, state["dtype"], n
+            self._train_idx = list(range(d))
+            self._bandwidth = np.array(state["bandwidth"])
+            self._device_fit()
+            self._fitted = True
+
     def __del__(self):
         try:
             if not _lib.alive():

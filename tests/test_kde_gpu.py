@@ -274,3 +274,23 @@ def test_large_properties(pbn):
     k3.fit(pd.concat([train, train], ignore_index=True))
     k3.bandwidth = h
     assert np.allclose(k3.logl(test.iloc[:2000]), ll[:2000], rtol=1e-9, atol=1e-9)
+
+
+def test_pickle_roundtrip(pbn, golden):
+    """tests/serialization/serialize_factor_test.py: a pickled fitted KDE / ProductKDE / CKDE scores identically."""
+    import pickle
+
+    df, test = frame(golden["train500"]), frame(golden["test50"])
+    for obj in (pbn.KDE(["a", "c"]), pbn.ProductKDE(["b", "d", "a"]), pbn.CKDE("d", ["a", "b"]), pbn.KDE(["a"], pbn.ScottsBandwidth())):
+        unfitted = pickle.loads(pickle.dumps(obj))
+        assert not unfitted.fitted()
+        obj.fit(df)
+        clone = pickle.loads(pickle.dumps(obj))
+        assert clone.fitted() and clone.num_instances() == 500
+        assert np.array_equal(clone.bandwidth, obj.bandwidth)
+        assert np.allclose(clone.logl(test), obj.logl(test), rtol=1e-12, atol=1e-12)
+    f32 = pbn.KDE(["a", "b"])
+    f32.fit(frame(golden["train500"], "float32"))
+    c32 = pickle.loads(pickle.dumps(f32))
+    assert c32.data_type() == pa.float32()
+    assert np.allclose(c32.logl(frame(golden["test50"], "float32")), f32.logl(frame(golden["test50"], "float32")), rtol=1e-6)
