@@ -82,6 +82,43 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         start, ops = pbn.GaussianNetwork(names), pbn.ArcOperatorSet()
         label = f"C4: 64-node GaussianNetwork, BGe, ArcOperatorSet, {n_rows} rows fp64"
         kw = {}
+    elif which == "c5":
+        # BASELINE config 5 (HC phase only; the MMPC restriction phase of MMHC is replaced by a supplied arc blacklist,
+        # SURVEY.md §8d): 32 continuous + 16 dictionary columns, fp32, ValidatedLikelihood(0.2, 10, seed 0)
+        import pandas as pd
+
+        n_rows = n_rows or 1_000_000
+        max_iters = max_iters or 1
+        rng = np.random.default_rng(3)
+        n_disc, n_cont = 16, 32
+        cards = rng.integers(2, 5, size=n_disc)
+        disc = {}
+        for j in range(n_disc):
+            base = rng.integers(0, cards[j], size=n_rows)
+            if j > 0:  # dependence on the previous discrete column
+                prev = disc[f"D{j - 1}"]
+                flip = rng.random(n_rows) < 0.3
+                base = np.where(flip, prev % cards[j], base)
+            disc[f"D{j}"] = base.astype(np.int32)
+        t = make_dag_table(torch, device, n_rows, n_cont, 3, torch.float32, nonlinear=True).cpu().numpy()
+        cols = {}
+        for j in range(n_cont):
+            shift = 1.5 * disc[f"D{j % n_disc}"].astype(np.float32)  # means shifted per discrete parent
+            cols[f"x{j}"] = t[j] + shift
+        df = pd.DataFrame(cols)
+        for j in range(n_disc):
+            df[f"D{j}"] = pd.Categorical.from_codes(disc[f"D{j}"], [f"c{v}" for v in range(cards[j])])
+        names = list(df.columns)
+        t0 = time.perf_counter()
+        score = pbn.ValidatedLikelihood(df, 0.2, 10, 0)
+        t_ctor = time.perf_counter() - t0
+        start = pbn.SemiparametricBN(names, [], [(f"D{j}", pbn.DiscreteFactorType()) for j in range(n_disc)])
+        ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
+        pairs = [(a, b) for a in names for b in names if a != b]
+        keep = rng.random(len(pairs)) < 0.15  # stand-in for the MMPC skeleton: 85 % of the arcs are blacklisted
+        kw = {"max_indegree": 3, "arc_blacklist": [p for p, k_ in zip(pairs, keep) if not k_]}
+        label = (f"C5 (HC phase): 48-node hybrid SemiparametricBN (16 discrete), ValidatedLikelihood(0.2, 10), arcs+node_type, "
+                 f"85% arc blacklist, max_indegree=3, {n_rows} rows fp32")
     elif which == "cv64":
         # north star: "CV-likelihood hill-climbing on 64-node synthetic data" - CKDE candidates are sharded over the
         # ranks (fixed total work: strong scaling of the delta cache); bounded to cache_scores + max_iters iterations
@@ -182,7 +219,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kde", default="product", choices=["product", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64"],
+    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64", "c5"],
                     help="secondary hill-climb metric: c4 = BASELINE config 4 (BGe, replicated moments), c3 = config 3 at full "
                          "size (slow), cv64 = 64-node CV-likelihood CKDE hill-climb whose candidates are sharded over the ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
