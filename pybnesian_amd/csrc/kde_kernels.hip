@@ -463,6 +463,264 @@ __global__ __launch_bounds__(256, 3) void kde_sweep_sparse_kernel(SweepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 path on the bf16 matrix cores ("bf16x3"): v_mfma_f32_16x16x4_f32 runs on the same FMA units as the
+// VALU (measured: no overlap, tools/microbench.hip), v_mfma_f32_16x16x32_bf16 does not (a 16-cycle MFMA costs the
+// VALU ~8 issue cycles).  Every f32 coordinate is split into three bf16 pieces z = a1 + a2 + a3 (24 mantissa
+// bits); the six products with combined weight >= 2^-24 (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2) are exact in the
+// f32 accumulator, so z_t.z_q is obtained to f32 accuracy from K = 6 d slots.  The training norm -1/2|z_t|^2 rides
+// along as three more slots against ones, the query side -1/2|z_q|^2 - m_q is the MFMA's C operand (a persistent
+// register quad), so the VALU does nothing but v_exp_f32 and the sums.
+// Slot s of a row: s = 6 k + r (dimension k, role r) for s < 6 dm, then the three norm pieces; slot s lives in MFMA
+// s / 32, lane group (s % 32) / 8, element s % 8.   Fragment arrays: [tile][NB][64 lanes][8 bf16].
+// CKDE: one extra MFMA whose 12 slots are the extra coordinate (6), its training norm against ones (3) and ones
+// against the query norm + (m_marg - m_joint) (3, rewritten by the lanes of group 1 when an offset is raised).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)x;
+    const float r1 = x - (float)p1;
+    p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    p3 = (__bf16)r2;
+}
+
+__global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t npad = a.ntiles * 16;
+    if (r >= npad) return;
+    const int64_t tile = r >> 4;
+    const int idx = (int)(r & 15);
+    const int d = a.d, dm = a.dm;
+    const int NB = a.KS;  // number of bf16 MFMAs of the main contraction
+    const bool valid = r < a.n;
+
+    double xc[PBN_MAX_D];
+    if (valid) {
+        const int64_t src = a.rows ? (int64_t)a.rows[r] : (r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0));
+        for (int j = 0; j < d; ++j) {
+            const float* col = (const float*)a.base + (int64_t)a.cols[j] * a.ld;
+            xc[j] = (double)col[src] - a.mu[j];
+        }
+    }
+    __bf16 p1[PBN_MAX_D], p2[PBN_MAX_D], p3[PBN_MAX_D];
+    double nrm = 0.0;
+    for (int i = 0; i < dm; ++i) {
+        double z = 0.0;
+        if (valid) {
+            const double* w = a.W + (size_t)i * d;
+            for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
+        }
+        const float zf = (float)z;
+        nrm = __builtin_fma((double)zf, (double)zf, nrm);
+        split3(zf, p1[i], p2[i], p3[i]);
+    }
+    float nv = (float)(-0.5 * nrm);
+    if (!valid) nv = a.is_query ? 0.0f : (float)PBN_PAD_NORM;
+    __bf16 n1, n2, n3;
+    split3(nv, n1, n2, n3);
+    const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+    auto slot = [&](int s) -> __bf16 {
+        if (s < 6 * dm) {
+            const int k = s / 6, role = s % 6;
+            if (!a.is_query) {  // a1 a1 a2 a1 a3 a2
+                return role == 2 || role == 5 ? p2[k] : (role == 4 ? p3[k] : p1[k]);
+            }                   // b1 b2 b1 b3 b1 b2
+            return role == 1 || role == 5 ? p2[k] : (role == 3 ? p3[k] : p1[k]);
+        }
+        const int t = s - 6 * dm;
+        if (t < 3) return a.is_query ? one : (t == 0 ? n1 : (t == 1 ? n2 : n3));
+        return zero;
+    };
+    bf8* pack = (bf8*)a.pack;
+    for (int mb = 0; mb < NB; ++mb)
+        for (int g = 0; g < 4; ++g) {
+            bf8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = slot(mb * 32 + g * 8 + j);
+            pack[(tile * NB + mb) * 64 + g * 16 + idx] = v;
+        }
+    if (a.is_query) ((float*)a.npack)[tile * 16 + idx] = nv;
+    if (a.xpack) {
+        double z = 0.0;
+        if (valid) {
+            const double* w = a.W + (size_t)dm * d;
+            for (int j = 0; j <= dm; ++j) z = __builtin_fma(w[j], xc[j], z);
+        }
+        const float zf = (float)z;
+        const float hn = (float)(-0.5 * (double)zf * (double)zf);
+        __bf16 e1, e2, e3, h1, h2, h3;
+        split3(zf, e1, e2, e3);
+        split3(hn, h1, h2, h3);
+        bf8* xp = (bf8*)a.xpack;
+        bf8 g0, g1, gz;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gz[j] = zero;
+        g1 = gz;
+        if (!a.is_query) {
+            g0[0] = e1; g0[1] = e1; g0[2] = e2; g0[3] = e1; g0[4] = e3; g0[5] = e2; g0[6] = h1; g0[7] = h2;
+            g1[0] = h3; g1[1] = one; g1[2] = one; g1[3] = one;
+        } else {
+            g0[0] = e1; g0[1] = e2; g0[2] = e1; g0[3] = e3; g0[4] = e1; g0[5] = e2; g0[6] = one; g0[7] = one;
+            g1[0] = one; g1[1] = h1; g1[2] = h2; g1[3] = h3;
+            ((float*)a.xnorm)[tile * 16 + idx] = hn;  // base of the rewritable slots 9..11
+        }
+        xp[tile * 64 + 0 * 16 + idx] = g0;
+        xp[tile * 64 + 1 * 16 + idx] = g1;
+        xp[tile * 64 + 2 * 16 + idx] = gz;
+        xp[tile * 64 + 3 * 16 + idx] = gz;
+    }
+}
+
+template <int NB, bool COND, int QG>
+__global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
+    using V = f4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lg = lane >> 4;
+    const int64_t qt0 = ((int64_t)blockIdx.x * 4 + wave) * QG;
+    if (qt0 >= a.nqtiles) return;
+    const int split = blockIdx.y;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+
+    const bf8* __restrict__ Ap = (const bf8*)a.Apack;
+    const bf8* __restrict__ Xp = (const bf8*)a.Axpack;
+    const bf8* __restrict__ Bp = (const bf8*)a.Bpack;
+    const float* __restrict__ NYp = (const float*)a.nypack;
+    const bf8* __restrict__ BXp = (const bf8*)a.Bxpack;
+    const float* __restrict__ XNp = (const float*)a.Bxnorm;
+
+    bf8 b[QG][NB];
+    float ny[QG], m[QG];
+    V cmv[QG];
+    double sum[QG];
+    bf8 bx[QG];
+    float xn[QG], mj[QG];
+    double sumj[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) b[g][mb] = Bp[(qt * NB + mb) * 64 + lane];
+        ny[g] = NYp[qt * 16 + (lane & 15)];
+        sum[g] = 0.0;
+        if (COND) { bx[g] = BXp[qt * 64 + lane]; xn[g] = XNp[qt * 16 + (lane & 15)]; sumj[g] = 0.0; }
+    }
+    auto set_bx = [&](int g) {  // slots 9..11 (lane group 1, elements 1..3) <- split3(xn + m - mj)
+        if (lg == 1) {
+            __bf16 q1, q2, q3;
+            split3(xn[g] + (m[g] - mj[g]), q1, q2, q3);
+            bx[g][1] = q1; bx[g][2] = q2; bx[g][3] = q3;
+        }
+    };
+    auto load_tile = [&](int64_t t, bf8 (&f)[NB], bf8& x) {
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) f[mb] = Ap[(t * NB + mb) * 64 + lane];
+        if (COND) x = Xp[t * 64 + lane];
+    };
+    auto mfma_main = [&](const bf8 (&f)[NB], int g, V c) {
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[mb], b[g][mb], c, 0, 0, 0);
+        return c;
+    };
+
+    // ---- prologue: offsets from the first tile ------------------------------------------------------------
+    {
+        bf8 f[NB], x;
+        load_tile(t0, f, x);
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const V c0 = {ny[g], ny[g], ny[g], ny[g]};
+            V acc = mfma_main(f, g, c0);
+            const float mx = colmax<float>(max4<float>(acc));
+            m[g] = mx;
+            const float cm = ny[g] - mx;
+            cmv[g] = V{cm, cm, cm, cm};
+            if (COND) {
+                V accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);  // slots 9..11 hold xn (m = mj = 0)
+                mj[g] = colmax<float>(max4<float>(accj));
+                set_bx(g);
+            }
+        }
+    }
+
+    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x) {
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            V acc = mfma_main(f, g, cmv[g]);
+            V accj;
+            if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);
+            float e0 = Tr<float>::ex2(acc[0]), e1 = Tr<float>::ex2(acc[1]), e2 = Tr<float>::ex2(acc[2]), e3 = Tr<float>::ex2(acc[3]);
+            float ts = (e0 + e1) + (e2 + e3);
+            float tsj = 0;
+            bool bad = !(ts < Tr<float>::big());
+            if (COND) {
+                float j0 = Tr<float>::ex2(accj[0]), j1 = Tr<float>::ex2(accj[1]), j2 = Tr<float>::ex2(accj[2]), j3 = Tr<float>::ex2(accj[3]);
+                tsj = (j0 + j1) + (j2 + j3);
+                bad = bad || !(tsj < Tr<float>::big());
+            }
+            if (__builtin_expect(__any(bad), 0)) {
+                float mx = colmax<float>(max4<float>(acc));
+                if (mx > 0.f) {
+                    m[g] += mx;
+                    const float cm = ny[g] - m[g];
+                    cmv[g] = V{cm, cm, cm, cm};
+                    sum[g] *= exp2(-(double)mx);
+                    acc -= mx;
+                }
+                e0 = Tr<float>::ex2(acc[0]); e1 = Tr<float>::ex2(acc[1]); e2 = Tr<float>::ex2(acc[2]); e3 = Tr<float>::ex2(acc[3]);
+                ts = (e0 + e1) + (e2 + e3);
+                if (COND) {
+                    float mxj = colmax<float>(max4<float>(accj));
+                    if (mxj > 0.f) {
+                        mj[g] += mxj;
+                        sumj[g] *= exp2(-(double)mxj);
+                        accj -= mxj;
+                    }
+                    set_bx(g);
+                    float j0 = Tr<float>::ex2(accj[0]), j1 = Tr<float>::ex2(accj[1]), j2 = Tr<float>::ex2(accj[2]), j3 = Tr<float>::ex2(accj[3]);
+                    tsj = (j0 + j1) + (j2 + j3);
+                }
+            }
+            sum[g] += (double)ts;
+            if (COND) sumj[g] += (double)tsj;
+        }
+    };
+
+    bf8 fA[NB], fB[NB], xA, xB;
+    load_tile(t0, fA, xA);
+    for (int64_t t = t0; t < t1; t += 2) {
+        const bool second = t + 1 < t1;
+        load_tile(second ? t + 1 : t, fB, xB);
+        process_tile(fA, xA);
+        load_tile(t + 2 < t1 ? t + 2 : t, fA, xA);
+        if (second) process_tile(fB, xB);
+    }
+
+    double* part = a.part;
+    constexpr int P = COND ? 4 : 2;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        double s = sum[g];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        double sj = 0.0;
+        if (COND) {
+            sj = sumj[g];
+            sj += __shfl_xor(sj, 16);
+            sj += __shfl_xor(sj, 32);
+        }
+        if (lg == 0 && qt0 + g < a.nqtiles) {
+            double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
+            o[0] = (double)m[g];
+            o[1] = s;
+            if (COND) { o[2] = (double)mj[g]; o[3] = sj; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kde_finish: per query merge the split partials (fixed order), logl = lognorm + ln2*(m + log2 sum)
 // [CKDE: joint - marginal], optional logl store, deterministic block tree sum.
 // ------------------------------------------------------------------------------------------------
@@ -526,10 +784,22 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+bool use_bf16x3(int dtype) {
+    static const int v = [] { const char* e = getenv("PBN_F32_BF16X3"); return (e && *e) ? atoi(e) : 1; }();
+    return v != 0 && dtype == PBN_F32;
+}
+
+int bf16x3_mfmas(int dm) { return (6 * dm + 3 + 31) / 32; }
+
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
     const int64_t npad = a.ntiles * 16;
     if (npad == 0) return;
     dim3 grid((unsigned)ceil_div(npad, 256)), block(256);
+    if (use_bf16x3(dtype)) {
+        hipLaunchKernelGGL(pack_rows_bf16_kernel, grid, block, 0, st, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (dtype == PBN_F64)
         hipLaunchKernelGGL(pack_rows_kernel<double>, grid, block, 0, st, a);
     else
@@ -566,8 +836,25 @@ int sweep_qg(int dtype, bool cond, int KS) {
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }
 
+template <bool COND>
+static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
+    dim3 block(256);
+    switch (NB) {
+        case 1: hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_sweep_bf16_kernel<3, COND, 4>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_sweep_bf16_kernel<4, COND, 4>), grid, block, 0, st, a); break;
+        default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond, KS)), (unsigned)nsplit);
+    if (use_bf16x3(dtype)) {  // KS carries the number of bf16 MFMAs
+        if (cond) launch_sweep_bf16<true>(a, KS, grid, st); else launch_sweep_bf16<false>(a, KS, grid, st);
+        return;
+    }
     if (use_sparse(dtype, cond, KS)) {
         dim3 block(256);
         if (KS == 1) hipLaunchKernelGGL((kde_sweep_sparse_kernel<1>), grid, block, 0, st, a);

@@ -27,6 +27,7 @@ struct PackArgs {
     void* pack;           // [ntiles][KS][64]
     void* npack;          // [ntiles][16]
     void* xpack;          // [ntiles][64] or null
+    void* xnorm;          // bf16x3 query side only: [ntiles][16] f32 base of the rewritable CKDE slots
 };
 
 struct SweepArgs {
@@ -36,6 +37,7 @@ struct SweepArgs {
     const void* Bpack;
     const void* nypack;
     const void* Bxpack;
+    const void* Bxnorm;  // bf16x3 CKDE: f32 [nqtiles][16]
     int64_t ntiles;
     int64_t nqtiles;
     int64_t tiles_per_split;
@@ -62,6 +64,8 @@ struct SweepQG {
     static constexpr int value = (F64 && COND) ? 2 : 4;
 };
 int sweep_qg(int dtype, bool cond, int KS);
+bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
+int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);

@@ -72,6 +72,8 @@ void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_
 KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n) {
     const size_t es = dtype_size(dtype);
     const int64_t ntiles = ceil_div(n, 16);
+    if (use_bf16x3(dtype))  // [ntiles][NB][64][8 bf16]; the training norm lives inside the fragments
+        return {(size_t)ntiles * bf16x3_mfmas(dm) * 64 * 16, 64, cond ? (size_t)ntiles * 64 * 16 : 0};
     const int KS = (dm + 3) / 4;
     return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es, cond ? (size_t)ntiles * 64 * es : 0};
 }
@@ -83,7 +85,7 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
     if (cond && d < 2) cond = false;  // CKDE without evidence is a plain KDE (CKDE.hpp:232-241)
     const int dm = cond ? d - 1 : d;
     if (dm > 16) throw invalid_error("KDE with more than 16 (+1 conditional) variables is not supported");
-    m.dtype = dtype; m.d = d; m.dm = dm; m.KS = (dm + 3) / 4; m.cond = cond;
+    m.dtype = dtype; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
     m.N = n; m.ntiles = ceil_div(n, 16);
     if (cond) {  // evidence first, variable last
         for (int i = 0; i < d - 1; ++i) m.perm[i] = i + 1;
@@ -162,9 +164,12 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     const size_t es = dtype_size(m.dtype);
     const int64_t nqtiles = ceil_div(n, 16);
     // query fragments in scratch: Bpack | nypack | Bxpack
-    const size_t bpack_b = (size_t)nqtiles * m.KS * 64 * es, ny_b = (size_t)nqtiles * 16 * es,
-                 bx_b = m.cond ? (size_t)nqtiles * 64 * es : 0;
-    ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + 256);
+    const bool b3 = use_bf16x3(m.dtype);
+    const size_t bpack_b = b3 ? (size_t)nqtiles * m.KS * 64 * 16 : (size_t)nqtiles * m.KS * 64 * es,
+                 ny_b = (size_t)nqtiles * 16 * es,
+                 bx_b = m.cond ? (b3 ? (size_t)nqtiles * 64 * 16 : (size_t)nqtiles * 64 * es) : 0,
+                 xn_b = (m.cond && b3) ? (size_t)nqtiles * 16 * 4 : 0;
+    ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + xn_b + 256);
     char* q = ctx->scratch_q.p;
     PackArgs pa{};
     fill_pack_common(pa, test, cols, m);
@@ -172,6 +177,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles;
     pa.is_query = 1;
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
+    pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
 
     // split the training tiles so that the grid is a few waves deep on every CU
@@ -186,7 +192,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     ctx->scratch_part.reserve((size_t)nsplit * nqtiles * 16 * P * sizeof(double));
     SweepArgs sa{};
     sa.Apack = m.Apack; sa.nxpack = m.nxpack; sa.Axpack = m.Axpack;
-    sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack;
+    sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack; sa.Bxnorm = pa.xnorm;
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);

@@ -99,6 +99,36 @@ __global__ __launch_bounds__(256) void k_mix(double* out, double c) {
   if (s == 12345.678) out[0] = s;
 }
 
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+// matrix-pipe / VALU overlap for the fp32 sweep: MODE 0 = 2 x v_mfma_f32_16x16x32_bf16, MODE 1 = 2 x v_mfma_f32_16x16x4_f32,
+// each with NV f32 VALU instructions (half v_exp_f32, half v_add_f32) per iteration
+template <int MODE, int NV>
+__global__ __launch_bounds__(256) void k_mix32(double* out, double c) {
+  f4 acc[2] = {{0,0,0,0},{0,0,0,0}};
+  bf8 a8, b8;
+  for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)(1.0f + threadIdx.x * 1e-3f); b8[i] = (__bf16)(float)c; }
+  float a = 1.0f + threadIdx.x * 1e-6f, b = (float)c;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.5f + i;
+  for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (MODE == 0) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[h], 0, 0, 0);
+      else if (MODE == 1) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[h], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NV / 4; ++j) {
+        asm volatile("v_exp_f32 %0, %0" : "+v"(v[(2 * j) % 8]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(2 * j + 1) % 8]) : "v"(b));
+      }
+    }
+  }
+  float s = acc[0][0] + acc[1][1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  if (s == 12345.678f) out[0] = s;
+}
+
 template <typename F>
 double time_ms(F launch) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -112,7 +142,7 @@ int main() {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount; const double clk = 2.4e9;
   printf("device %s, %d CUs, clock %d kHz\n", p.name, cus, p.clockRate);
-  for (int wps = 1; wps <= 8; wps *= 2) {
+  for (int wps = 2; wps <= 4; wps *= 2) {
     dim3 grid(cus * wps), block(256);
     const double waves_per_simd = wps;  // 4 waves per block, 4 SIMDs per CU
     auto report = [&](const char* name, double ms, double instr_per_wave) {
@@ -134,6 +164,13 @@ int main() {
     mix("2 mfma64 + 16 fma64", time_ms([&] { hipLaunchKernelGGL(k_mix<16>, grid, block, 0, 0, out, 1.0000001); }));
     mix("2 mfma64 + 32 fma64", time_ms([&] { hipLaunchKernelGGL(k_mix<32>, grid, block, 0, 0, out, 1.0000001); }));
     mix("2 mfma64 + 64 fma64", time_ms([&] { hipLaunchKernelGGL(k_mix<64>, grid, block, 0, 0, out, 1.0000001); }));
+    mix("2 mfma_bf16_16x16x32 + 0 valu32", time_ms([&] { hipLaunchKernelGGL((k_mix32<0, 0>), grid, block, 0, 0, out, 1.0000001); }));
+    mix("2 mfma_bf16_16x16x32 + 16 valu32", time_ms([&] { hipLaunchKernelGGL((k_mix32<0, 16>), grid, block, 0, 0, out, 1.0000001); }));
+    mix("2 mfma_bf16_16x16x32 + 32 valu32", time_ms([&] { hipLaunchKernelGGL((k_mix32<0, 32>), grid, block, 0, 0, out, 1.0000001); }));
+    mix("2 mfma_f32_16x16x4 + 0 valu32", time_ms([&] { hipLaunchKernelGGL((k_mix32<1, 0>), grid, block, 0, 0, out, 1.0000001); }));
+    mix("2 mfma_f32_16x16x4 + 16 valu32", time_ms([&] { hipLaunchKernelGGL((k_mix32<1, 16>), grid, block, 0, 0, out, 1.0000001); }));
+    mix("2 mfma_f32_16x16x4 + 32 valu32", time_ms([&] { hipLaunchKernelGGL((k_mix32<1, 32>), grid, block, 0, 0, out, 1.0000001); }));
+    mix("0 mfma + 32 valu32 (ref)", time_ms([&] { hipLaunchKernelGGL((k_mix32<2, 32>), grid, block, 0, 0, out, 1.0000001); }));
   }
   return 0;
 }
