@@ -195,20 +195,11 @@ struct Engine {
     std::vector<double> local;  // LocalScoreCache of the pool / op set
     int64_t cells_scored = 0;
 
-    // ---- local cache ------------------------------------------------------------------------------
-    void cache_local_scores() {
-        Batch b;
-        for (int v = 0; v < cur.n; ++v) b.add(v, cur.node_type[v], cur.parents[v]);
-        local = scorer.run(b, 0);
-    }
-
     // ---- ArcOperatorSet::cache_scores (operators.cpp:100-132 + cache_score_operation :71-98) ---------
-    void arcs_cache_scores() {
+    struct CCell { int s, t; int a, b; int kind; };  // kind 0: d = S[a]-local[t]; 1: S[a]+S[b]-local[s]-local[t]
+    void arcs_collect_cache(Batch& bt, std::vector<CCell>& cells) {
         arcs.update_valid_ops(cur);
         const int n = cur.n;
-        struct Cell { int s, t; int a, b; int kind; };  // kind 0: d = S[a]-local[t]; 1: S[a]+S[b]-local[s]-local[t]
-        std::vector<Cell> cells;
-        Batch bt;
         for (int t = 0; t < n; ++t) {
             std::vector<int> pt = cur.parents[t];
             for (int s = 0; s < n; ++s) {
@@ -234,8 +225,10 @@ struct Engine {
                 }
             }
         }
-        std::vector<double> S = scorer.run(bt, 0);
-        for (const Cell& c : cells) {
+    }
+    void arcs_apply_cache(const std::vector<CCell>& cells, const std::vector<double>& S) {
+        const int n = cur.n;
+        for (const CCell& c : cells) {
             double d;
             if (c.kind == 0) d = S[c.a] - local[c.t];
             else d = S[c.a] + S[c.b] - local[c.s] - local[c.t];
@@ -374,21 +367,25 @@ struct Engine {
     }
 
     // ---- pool-level operations (OperatorPool, operators.hpp:836-904) ----------------------------------------
+    // All local_score requests of a step travel in ONE batch (local cache + every delta cell): the values
+    // are the ones the reference computes call by call, only their evaluation is batched.
     void cache_scores() {
-        cache_local_scores();
-        auto do_arcs = [&] { if (use_arcs) arcs_cache_scores(); };
-        auto do_types = [&] {
-            if (!use_types) return;
+        Batch bt;
+        for (int v = 0; v < cur.n; ++v) bt.add(v, cur.node_type[v], cur.parents[v]);
+        std::vector<CCell> cells;
+        std::vector<std::pair<int, int>> treq;
+        if (use_arcs) arcs_collect_cache(bt, cells);
+        if (use_types) {
             types.delta.assign(cur.n, LOWEST);
             types.has.assign(cur.n, 0);
             std::vector<int> all(cur.n);
             for (int i = 0; i < cur.n; ++i) all[i] = i;
-            Batch bt;
-            std::vector<std::pair<int, int>> req;
-            types_collect(all, bt, req);
-            types_apply(req, scorer.run(bt, 0));
-        };
-        if (order_arcs_first) { do_arcs(); do_types(); } else { do_types(); do_arcs(); }
+            types_collect(all, bt, treq);
+        }
+        std::vector<double> S = scorer.run(bt, 0);
+        local.assign(S.begin(), S.begin() + cur.n);
+        if (use_arcs) arcs_apply_cache(cells, S);
+        if (use_types) types_apply(treq, S);
     }
 
     Op find_max(const std::vector<Op>* tabu) const {
@@ -409,20 +406,15 @@ struct Engine {
     }
 
     void update_scores(const std::vector<int>& changed) {
-        // 1) local cache of the changed nodes (one batch), 2) all dependent cells (one batch)
-        {
-            Batch b;
-            for (int v : changed) b.add(v, cur.node_type[v], cur.parents[v]);
-            std::vector<double> S = scorer.run(b, 0);
-            for (size_t i = 0; i < changed.size(); ++i) local[changed[i]] = S[i];
-        }
         Batch bt;
+        for (int v : changed) bt.add(v, cur.node_type[v], cur.parents[v]);  // refreshed local scores first
         std::vector<UCell> cells;
         std::vector<std::pair<int, int>> treq;
         if (use_arcs)
             for (int t : changed) arcs_collect_updates(t, bt, cells);
         if (use_types) types_collect(changed, bt, treq);
         std::vector<double> S = scorer.run(bt, 0);
+        for (size_t i = 0; i < changed.size(); ++i) local[changed[i]] = S[i];
         if (use_arcs) arcs_apply_updates(cells, S);
         if (use_types) types_apply(treq, S);
     }
