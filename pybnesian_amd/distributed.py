@@ -68,3 +68,31 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
         idx = shard_indices(m, r, world)
         out[[heavy[j] for j in idx]] = allv[r, : len(idx)]
     return out
+
+
+def sharded_slogl(factor, df):
+    """KDE / ProductKDE / CKDE `slogl(df)` with the test rows split over the ranks (independent units =
+    test rows, fitted model replicated).  Every rank passes the same `df`; rank r evaluates the contiguous slice
+    [r*m/W, (r+1)*m/W), the W partial sums are all-gathered and added in rank order (deterministic), and every rank
+    returns the same total.  Without torch.distributed it is `factor.slogl(df)`."""
+    dist = _dist()
+    if dist is None:
+        return factor.slogl(df)
+    import torch
+
+    from .dataset import as_record_batch
+
+    rb = as_record_batch(df)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    m = rb.num_rows
+    lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+    part = factor.slogl(rb.slice(lo, hi - lo)) if hi > lo else 0.0
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    send = torch.tensor([part], dtype=torch.float64, device=dev)
+    recv = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    total = 0.0
+    for v in recv.cpu().tolist():
+        total += v
+    return total
