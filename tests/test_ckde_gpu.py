@@ -76,7 +76,7 @@ def test_ckde_dtype_mismatch(pbn, golden):
         cpd.logl(frame(golden["test50"], "float32"))
 
 
-@pytest.mark.parametrize("p", [1, 2, 4, 5, 8])
+@pytest.mark.parametrize("p", [1, 2, 4, 5, 8, 10, 14])
 def test_ckde_oracle_parity_random(pbn, oracle, p):
     """Seeded non-linear tables, ragged sizes; includes conditional outliers (joint far, marginal near)."""
     rng = np.random.default_rng(40 + p)
@@ -95,3 +95,23 @@ def test_ckde_oracle_parity_random(pbn, oracle, p):
     assert np.all(np.isfinite(got))
     assert np.allclose(got, want, rtol=RTOL_F64, atol=1e-9)
     assert abs(cpd.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())
+
+
+@pytest.mark.parametrize("p", [2, 6, 11])
+def test_ckde_oracle_parity_random_f32(pbn, oracle, p):
+    """fp32 CKDE on the bf16 matrix cores (bf16x3 split), incl. NB = 1..3 MFMAs per tile: reference tolerances for
+    float data (atol 5e-4 per value, CKDE_test.py:231-232) against the fp64 oracle on the same rounded data."""
+    rng = np.random.default_rng(70 + p)
+    n, m = 3001, 203
+    ev = rng.normal(size=(n + m, p)) @ (np.tril(rng.uniform(-0.3, 0.3, size=(p, p)), -1) + np.eye(p)).T
+    y = np.tanh(ev[:, 0]) + 0.2 * ev.sum(axis=1) + rng.normal(scale=0.5, size=n + m)
+    data = np.column_stack([y, ev]).astype(np.float32)
+    names = ["y"] + [f"e{i}" for i in range(p)]
+    train = pd.DataFrame(data[:n], columns=names)
+    test = pd.DataFrame(data[n:], columns=names)
+    cpd = pbn.CKDE("y", names[1:])
+    cpd.fit(train)
+    want = oracle.ckde_logl(data[:n].astype(np.float64), cpd.bandwidth, data[n:].astype(np.float64))
+    got = cpd.logl(test)
+    assert np.allclose(got, want, atol=5e-4, rtol=1e-4)
+    assert abs(cpd.slogl(test) - want.sum()) <= RTOL_F32 * abs(want.sum())
