@@ -109,6 +109,11 @@ double pbn_kde_lognorm(const pbn_kde* k, int which); /* 0 joint / plain, 1 margi
 int pbn_kde_logl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out);
 int pbn_kde_logl_dev(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
                      double* dev_out);
+/* cdf: replaces CKDE::_cdf / _cdf_univariate / _cdf_multivariate (factors/continuous/CKDE.hpp:509-735 and the
+ * conditional_means / normal_cdf kernels, kde/opencl_kernels/KDE.cl.src:376-468): P(X <= x | evidence) of each
+ * test row, n doubles to HOST `out`.  Only for handles made by pbn_ckde_fit; one fused sweep instead of the
+ * reference's W / mu / cdf / product N x m matrices. */
+int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out);
 /* slogl: replaces KDE::_slogl / ProductKDE::_slogl / CKDE::_slogl (KDE.hpp:549-562,
  * ProductKDE.hpp:295-308, CKDE.hpp:256-287): sum of logl over the rows, one scalar read-back. */
 int pbn_kde_slogl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out);

@@ -100,6 +100,45 @@ def ckde_logl(train, H, test):
     return _logl(lib().oracle_ckde_logl_f32, lib().oracle_ckde_logl_f64, train, H, test)
 
 
+def ckde_cdf(train, H, test):
+    """CKDE::cdf restated step by step in the table's dtype (column 0 = variable, columns 1.. = evidence).
+
+    factors/continuous/CKDE.hpp:561-594 (_cdf_univariate) and :596-735 (_cdf_multivariate): the N x m weight
+    matrix W = exp(logl_mat) of the evidence KDE, the conditional means mu[t, q] = x_t + b.(e_q - e_t) with
+    b = H12 H22^-1 (kde/opencl_kernels/KDE.cl.src:376-430), 0.5 erfc((mu - x_q) / (sigma_c sqrt 2)) (:447-456),
+    the element-wise product, column sums and the final division."""
+    from scipy.special import erfc
+    dt = np.float32 if train.dtype == np.float32 else np.float64
+    train = np.asarray(train, dtype=dt)
+    test = np.asarray(test, dtype=dt)
+    H = np.atleast_2d(np.asarray(H, dtype=np.float64))
+    N, d = train.shape
+    sqrt1_2 = dt(np.sqrt(0.5))
+    if d == 1:
+        inv_std = dt(1.0 / np.sqrt(H[0, 0]))
+        inv_n = dt(1.0 / N)
+        mat = inv_n * (dt(0.5) * erfc(sqrt1_2 * inv_std * -(test[None, :, 0] - train[:, 0, None])))
+        return mat.astype(dt).sum(axis=0, dtype=dt).astype(np.float64)
+    p = d - 1
+    L = np.linalg.cholesky(H[1:, 1:])
+    Linv = np.linalg.solve(L, np.eye(p))
+    R = Linv @ H[1:, 0]
+    cond_var = H[0, 0] - R @ R
+    transform = (R @ Linv).astype(dt)
+    inv_std = dt(1.0 / np.sqrt(cond_var))
+    # logl_mat of the evidence KDE without the 1/N term (CKDE.hpp:653 new_lognorm_marg)
+    lognorm = dt(-np.log(np.diag(L)).sum() - 0.5 * p * np.log(2 * np.pi))
+    Ld = L.astype(dt)
+    diff = (test[None, :, 1:] - train[:, None, 1:]).reshape(-1, p).T       # p x (N m)
+    import scipy.linalg as sla
+    z = sla.solve_triangular(Ld, diff, lower=True, check_finite=False).astype(dt)
+    W = np.exp((dt(-0.5) * (z * z).sum(axis=0, dtype=dt) + lognorm).astype(dt)).reshape(N, -1)
+    mu = train[:, 0, None] + ((test[None, :, 1:] - train[:, None, 1:]) * transform).sum(axis=2, dtype=dt)
+    cdf = (dt(0.5) * erfc(sqrt1_2 * inv_std * (mu - test[None, :, 0]))).astype(dt)
+    num = (cdf * W).sum(axis=0, dtype=dt)
+    return (num / W.sum(axis=0, dtype=dt)).astype(np.float64)
+
+
 def shuffled_indices(n, seed):
     idx = np.arange(n, dtype=np.int32)
     lib().oracle_shuffle(_dp(idx), C.c_int64(n), C.c_uint32(seed))

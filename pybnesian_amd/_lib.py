@@ -57,6 +57,7 @@ SIGNATURES = {
     "pbn_kde_lognorm": (C.c_double, [_vp, _int]),
     "pbn_kde_logl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_logl_dev": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
+    "pbn_ckde_cdf": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_slogl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_slogl_async": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
     "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),

@@ -24,7 +24,22 @@ struct pbn_kde {
     pbn_ctx* ctx = nullptr;
     KdeModel m;
     dev_buf<char> Apack, nxpack, Axpack;
+    // CKDE::cdf state (pbn_ckde_fit only): classic fragments of the evidence dimensions + u = (x - b.e)/(sigma_c sqrt 2)
+    bool ckde = false;
+    int cdf_KS = 0;
+    std::vector<int> cols_fit;
+    double wu[PBN_MAX_D_HOST];
+    dev_buf<char> cA, cN, cU;
 };
+
+// PackArgs for the cdf fragments: whitening order (evidence first, variable last), contraction over the evidence only.
+static void fill_cdf_pack(PackArgs& pa, const pbn_kde& k, const pbn_table* t, const int* cols) {
+    const KdeModel& m = k.m;
+    pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.d - 1; pa.KS = k.cdf_KS;
+    for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
+    for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];
+    for (int i = 0; i < m.d; ++i) { pa.mu[i] = m.mu[i]; pa.wu[i] = k.wu[i]; }
+}
 
 extern "C" {
 
@@ -276,7 +291,7 @@ int pbn_bandwidth(int selector, int kind, const double* cov, int d, int64_t n, i
 
 // ---------------------------------------------------------------------------------------------------
 static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
-                         const double* bw, int kind, bool cond, const double* center, pbn_kde** out) {
+                         const double* bw, int kind, bool cond, const double* center, pbn_kde** out, bool ckde = false) {
     if (!ctx || !out) throw invalid_error("pbn_kde_fit: null argument");
     check_cols(train, cols, d, "pbn_kde_fit");
     check_range(train, row0, n, "pbn_kde_fit");
@@ -304,6 +319,25 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     if (k->m.cond) k->Axpack.alloc(pb.axpack);
     k->m.Apack = k->Apack.p; k->m.nxpack = k->nxpack.p; k->m.Axpack = k->Axpack.p;
     kde_pack_train(ctx, k->m, train, cols, row0, n, 0);
+    if (ckde) {
+        // The joint Cholesky factor with the variable last has the Schur complement on its corner: the last
+        // whitening row IS (x - H12 H22^-1 e) / sigma_c (CKDE.hpp:538-555 "transform" and "cond_var").
+        const KdeModel& m = k->m;
+        k->ckde = true;
+        k->cdf_KS = std::max(1, (m.d - 1 + 3) / 4);
+        const double sc = std::sqrt(2.0 * 1.4426950408889634073599246810019);
+        for (int j = 0; j < m.d; ++j) k->wu[j] = m.W[(size_t)(m.d - 1) * m.d + j] / sc;
+        const size_t es = dtype_size(m.dtype);
+        k->cA.alloc((size_t)m.ntiles * k->cdf_KS * 64 * es);
+        k->cN.alloc((size_t)m.ntiles * 16 * es);
+        k->cU.alloc((size_t)m.ntiles * 16 * es);
+        PackArgs pa{};
+        fill_cdf_pack(pa, *k, train, cols);
+        pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = m.ntiles; pa.is_query = 0;
+        pa.pack = k->cA.p; pa.npack = k->cN.p; pa.upack = k->cU.p;
+        KernelTimer kt(ctx, PBN_K_PACK);
+        launch_pack_classic(pa, m.dtype, ctx->stream);
+    }
     *out = k.release();
 }
 
@@ -317,7 +351,7 @@ int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, in
 
 int pbn_ckde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                  const double* H, const double* center, pbn_kde** out) {
-    return guarded([&] { kde_fit_impl(ctx, train, cols, d, row0, n, H, PBN_BW_FULL, true, center, out); });
+    return guarded([&] { kde_fit_impl(ctx, train, cols, d, row0, n, H, PBN_BW_FULL, true, center, out, true); });
 }
 
 void pbn_kde_destroy(pbn_kde* k) {
@@ -351,6 +385,48 @@ int pbn_kde_logl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
         kde_eval_enqueue(k, test, cols, row0, n, tmp.p, nullptr);
         if (n > 0) HIP_CHECK(hipMemcpyAsync(out, tmp.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, k->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
+    });
+}
+
+int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out) {
+    return guarded([&] {
+        if (!k) throw invalid_error("CKDE factor not fitted.");
+        if (!k->ckde) throw invalid_error("pbn_ckde_cdf: the handle was not created by pbn_ckde_fit");
+        if (!out && n > 0) throw invalid_error("pbn_ckde_cdf: null output");
+        pbn_ctx* ctx = k->ctx;
+        const KdeModel& m = k->m;
+        check_cols(test, cols, m.d, "pbn_ckde_cdf");
+        check_range(test, row0, n, "pbn_ckde_cdf");
+        if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
+        if (test->ctx->device != ctx->device) throw invalid_error("pbn_ckde_cdf: test table lives on another device");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (n == 0) return;
+        const size_t es = dtype_size(m.dtype);
+        const int64_t nqtiles = ceil_div(n, 16);
+        const size_t b_b = (size_t)nqtiles * k->cdf_KS * 64 * es, n_b = (size_t)nqtiles * 16 * es;
+        ctx->scratch_q.reserve(b_b + 2 * n_b + 256);
+        char* q = ctx->scratch_q.p;
+        PackArgs pa{};
+        fill_cdf_pack(pa, *k, test, cols);
+        pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles; pa.is_query = 1;
+        pa.pack = q; pa.npack = q + b_b; pa.upack = q + b_b + n_b;
+        { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pa, m.dtype, ctx->stream); }
+        const int64_t qblocks = ceil_div(nqtiles, 8);
+        int64_t nsplit = std::max<int64_t>(1, ceil_div((int64_t)ctx->num_cus * 16, qblocks));
+        nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / 16));
+        const int64_t tps = ceil_div(m.ntiles, nsplit);
+        nsplit = ceil_div(m.ntiles, tps);
+        ctx->scratch_part.reserve((size_t)nsplit * nqtiles * 16 * 4 * sizeof(double));
+        CdfArgs ca{};
+        ca.Apack = k->cA.p; ca.nxpack = k->cN.p; ca.utrain = k->cU.p;
+        ca.Bpack = pa.pack; ca.nypack = pa.npack; ca.uquery = pa.upack;
+        ca.ntiles = m.ntiles; ca.nqtiles = nqtiles; ca.tiles_per_split = tps;
+        ca.part = (double*)ctx->scratch_part.p;
+        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_cdf(ca, m.dtype, k->cdf_KS, (int)nsplit, ctx->stream); }
+        dev_buf<double> tmp((size_t)n);
+        { KernelTimer kt(ctx, PBN_K_FINISH); launch_cdf_finish(ca.part, (int)nsplit, nqtiles, n, tmp.p, ctx->stream); }
+        HIP_CHECK(hipMemcpyAsync(out, tmp.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
 }
 

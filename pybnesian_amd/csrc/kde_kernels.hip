@@ -140,6 +140,19 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
         if (sizeof(T) == 8) { lg = idx & 3; i = idx >> 2; } else { lg = idx >> 2; i = idx & 3; }
         npack[tile * 16 + lg * 4 + i] = (T)nv;
     }
+    if (a.upack) {  // CKDE::cdf: standardised "x - b.e" of the row, in the norm's layout
+        double u = 0.0;
+        if (valid)
+            for (int j = 0; j < d; ++j) u = __builtin_fma(a.wu[j], xc[j], u);
+        T* up = (T*)a.upack;
+        if (a.is_query) {
+            up[tile * 16 + idx] = (T)u;
+        } else {
+            int lg, i;
+            if (sizeof(T) == 8) { lg = idx & 3; i = idx >> 2; } else { lg = idx >> 2; i = idx & 3; }
+            up[tile * 16 + lg * 4 + i] = (T)u;
+        }
+    }
     if (xpack) {
         double z = 0.0;
         if (valid) {
@@ -721,6 +734,122 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// kde_cdf: CKDE::cdf.  The reference (CKDE.hpp:560-735 + KDE.cl.src:376-468) materialises, per tile of 64 test rows,
+// the N x 64 weight matrix W (marginal KDE terms), the N x 64 conditional means, their normal cdf, the element-wise
+// product and two column sums.  Here: the weights are the marginal sweep's 2^(s2 - m) (same MFMA + offset machinery),
+// the conditional mean is linear, (x_q - mu_t(e_q)) / sigma_c = u_q - u_t with u = (x - b.e) / sigma_c precomputed per
+// row, so a pair costs one erfc; cdf_q = sum_t w_t Phi(u_q - u_t) / sum_t w_t.  No evidence: w_t = 1.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T half_erfc(T x);
+template <>
+__device__ __forceinline__ double half_erfc<double>(double x) { return 0.5 * erfc(x); }
+template <>
+__device__ __forceinline__ float half_erfc<float>(float x) { return 0.5f * erfcf(x); }
+
+template <typename T, int KS, int QG>
+__global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
+    using V = typename Tr<T>::vec4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lg = lane >> 4;
+    const int64_t qt0 = ((int64_t)blockIdx.x * 4 + wave) * QG;
+    if (qt0 >= a.nqtiles) return;
+    const int split = blockIdx.y;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+    const T* __restrict__ Ap = (const T*)a.Apack;
+    const T* __restrict__ Np = (const T*)a.nxpack;
+    const T* __restrict__ Up = (const T*)a.utrain;
+    const T* __restrict__ Bp = (const T*)a.Bpack;
+    const T* __restrict__ NYp = (const T*)a.nypack;
+    const T* __restrict__ UQp = (const T*)a.uquery;
+
+    T b[QG][KS], ny[QG], cm[QG], m[QG], uq[QG];
+    double sw[QG], sc[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bp[(qt * KS + ks) * 64 + lane];
+        ny[g] = NYp[qt * 16 + (lane & 15)];
+        uq[g] = UQp[qt * 16 + (lane & 15)];
+        sw[g] = 0.0; sc[g] = 0.0;
+    }
+    {   // offsets from the first tile
+        const V nx = *(const V*)(Np + t0 * 16 + lg * 4);
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            V acc = nx + ny[g];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(Ap[(t0 * KS + ks) * 64 + lane], b[g][ks], acc);
+            m[g] = colmax<T>(max4<T>(acc));
+            cm[g] = ny[g] - m[g];
+        }
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+        T af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t * KS + ks) * 64 + lane];
+        const V nx = *(const V*)(Np + t * 16 + lg * 4);
+        const V ut = *(const V*)(Up + t * 16 + lg * 4);
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            V acc = nx + cm[g];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+            T w0 = Tr<T>::ex2(acc[0]), w1 = Tr<T>::ex2(acc[1]), w2 = Tr<T>::ex2(acc[2]), w3 = Tr<T>::ex2(acc[3]);
+            T ts = (w0 + w1) + (w2 + w3);
+            if (__builtin_expect(__any(!(ts < Tr<T>::big())), 0)) {
+                const T mx = colmax<T>(max4<T>(acc));
+                if (mx > (T)0) {
+                    m[g] += mx;
+                    cm[g] = ny[g] - m[g];
+                    const double f = exp2(-(double)mx);
+                    sw[g] *= f; sc[g] *= f;
+                    acc -= mx;
+                }
+                w0 = Tr<T>::ex2(acc[0]); w1 = Tr<T>::ex2(acc[1]); w2 = Tr<T>::ex2(acc[2]); w3 = Tr<T>::ex2(acc[3]);
+                ts = (w0 + w1) + (w2 + w3);
+            }
+            // Phi((x_q - mu_t)/sigma_c) = 1/2 erfc((u_t - u_q)), u pre-divided by sqrt 2 (KDE.cl.src:448-456)
+            const T c = (w0 * half_erfc<T>(ut[0] - uq[g]) + w1 * half_erfc<T>(ut[1] - uq[g])) +
+                        (w2 * half_erfc<T>(ut[2] - uq[g]) + w3 * half_erfc<T>(ut[3] - uq[g]));
+            sw[g] += (double)ts;
+            sc[g] += (double)c;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        double s = sw[g], c = sc[g];
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        c += __shfl_xor(c, 16); c += __shfl_xor(c, 32);
+        if (lg == 0 && qt0 + g < a.nqtiles) {
+            double* o = a.part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * 4;
+            o[0] = (double)m[g]; o[1] = s; o[2] = c; o[3] = 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kde_cdf_finish_kernel(const double* __restrict__ part, int nsplit, int64_t nqtiles, int64_t nq,
+                                                              double* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const double* p = part + q * 4;
+    const int64_t stride = nqtiles * 16 * 4;
+    double m = p[0], sw = p[1], sc = p[2];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const double* pp = p + sp * stride;
+        const double M = m > pp[0] ? m : pp[0];
+        const double f1 = exp2(m - M), f2 = exp2(pp[0] - M);
+        sw = sw * f1 + pp[1] * f2;
+        sc = sc * f1 + pp[2] * f2;
+        m = M;
+    }
+    out[q] = sc / sw;
+}
+
+// ------------------------------------------------------------------------------------------------
 // kde_finish: per query merge the split partials (fixed order), logl = lognorm + ln2*(m + log2 sum)
 // [CKDE: joint - marginal], optional logl store, deterministic block tree sum.
 // ------------------------------------------------------------------------------------------------
@@ -784,6 +913,39 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st) {
+    const int64_t npad = a.ntiles * 16;
+    if (npad == 0) return;
+    dim3 grid((unsigned)ceil_div(npad, 256)), block(256);
+    if (dtype == PBN_F64) hipLaunchKernelGGL(pack_rows_kernel<double>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+static void launch_cdf_t(const CdfArgs& a, int KS, dim3 grid, hipStream_t st) {
+    dim3 block(256);
+    switch (KS) {
+        case 1: hipLaunchKernelGGL((kde_cdf_kernel<T, 1, 2>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_cdf_kernel<T, 2, 2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_cdf_kernel<T, 3, 2>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_cdf_kernel<T, 4, 2>), grid, block, 0, st, a); break;
+        default: throw invalid_error("CKDE::cdf: more than 16 evidence variables are not supported");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * 2), (unsigned)nsplit);
+    if (dtype == PBN_F64) launch_cdf_t<double>(a, KS, grid, st); else launch_cdf_t<float>(a, KS, grid, st);
+}
+
+void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t nq, double* dev_out, hipStream_t st) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(kde_cdf_finish_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, part, nsplit, nqtiles, nq, dev_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 bool use_bf16x3(int dtype) {
     static const int v = [] { const char* e = getenv("PBN_F32_BF16X3"); return (e && *e) ? atoi(e) : 1; }();
     return v != 0 && dtype == PBN_F32;

@@ -28,6 +28,9 @@ struct PackArgs {
     void* npack;          // [ntiles][16]
     void* xpack;          // [ntiles][64] or null
     void* xnorm;          // bf16x3 query side only: [ntiles][16] f32 base of the rewritable CKDE slots
+    // CKDE::cdf: u = sum_j wu[j] * (x_j - mu_j) over the d selected columns -> upack (npack layout); classic pack only
+    double wu[PBN_MAX_D];
+    void* upack;          // nullable
 };
 
 struct SweepArgs {
@@ -70,5 +73,20 @@ int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, g
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);
 void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st);
+
+// CKDE::cdf (factors/continuous/CKDE.hpp:509-735): weights from the marginal sweep, normal cdf of the conditional mean.
+struct CdfArgs {
+    const void* Apack;   // classic fragments of the evidence dimensions
+    const void* nxpack;
+    const void* utrain;  // [ntiles][16] in C-row order: (x_t - b.e_t) / (sigma_c sqrt 2)
+    const void* Bpack;
+    const void* nypack;
+    const void* uquery;  // [nqtiles][16]
+    int64_t ntiles, nqtiles, tiles_per_split;
+    double* part;        // [nsplit][nqtiles*16][4] : m, sum w, sum w*cdf, 0
+};
+void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st);
+void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st);
+void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t nq, double* dev_out, hipStream_t st);
 
 }  // namespace pbn

@@ -173,6 +173,19 @@ class CKDE(Factor):
         out[mask] = vals
         return out
 
+    def cdf(self, df):
+        """CKDE.cdf (factors/continuous/CKDE.hpp:126, 509-558): P(X <= x | evidence) per row, NaN at null rows."""
+        rb, table, mask = self._upload_test(df)
+        m = table.num_rows
+        vals = np.empty(m, dtype=np.float64)
+        d = len(self._variables)
+        _lib.check(_lib.load().pbn_ckde_cdf(self._handle, table.handle, _lib.int_array(range(d)), 0, m, _lib.dptr(vals)))
+        if mask is None:
+            return vals
+        out = np.full(rb.num_rows, np.nan)
+        out[mask] = vals
+        return out
+
     def slogl(self, df):
         _, table, _ = self._upload_test(df)
         res = C.c_double(0.0)

@@ -89,6 +89,23 @@ def null_test_df(test_df):  # KDE_test.py:236-248 (same seeds and draw order)
     return out
 
 
+def ckde_cdf_recipe(joint, train, test):  # CKDE_test.py:181-222 (column 0 = variable, 1.. = evidence)
+    """P(X <= x | e) of a Gaussian-kernel CKDE: mixture of normal cdfs at the per-instance conditional means,
+    weighted by the evidence kernel."""
+    from scipy.stats import multivariate_normal as mvn
+    H = np.atleast_2d(joint.covariance)
+    if train.shape[1] == 1:
+        return norm.cdf(test[:, [0]], train[:, 0][None, :], np.sqrt(H[0, 0])).mean(axis=1)
+    Hee_inv = np.linalg.inv(H[1:, 1:])
+    cond_sd = np.sqrt(H[0, 0] - H[0, 1:] @ Hee_inv @ H[1:, 0])
+    out = np.empty(test.shape[0])
+    for i in range(test.shape[0]):
+        w = np.exp(mvn.logpdf(train[:, 1:], mean=test[i, 1:], cov=H[1:, 1:]))
+        cmean = train[:, 0] + (test[i, 1:] - train[:, 1:]) @ (Hee_inv @ H[1:, 0])
+        out[i] = w @ norm.cdf(test[i, 0], cmean, cond_sd) / w.sum()
+    return out
+
+
 def main():
     g = {}
     train500 = util_test.generate_normal_data(500, seed=0)    # KDE_test.py:10-11
@@ -141,6 +158,8 @@ def main():
                 lj = lj - marg.logpdf(test50.loc[:, evidence].to_numpy().T)
             g[f"ckde_logl_{key}_{tag}"] = lj
             g[f"ckde_bw_{key}_{tag}"] = joint.covariance
+            # CKDE.cdf (CKDE_test.py:256-314)
+            g[f"ckde_cdf_{key}_{tag}"] = ckde_cdf_recipe(joint, tr.loc[:, variables].to_numpy(), test50.loc[:, variables].to_numpy())
 
     # LinearGaussianCPD MLE + BIC (mle_test.py:10-56, bic_test.py:10-43) on the 10k table
     for variable, evidence in CKDE_SETS:

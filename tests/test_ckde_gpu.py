@@ -115,3 +115,87 @@ def test_ckde_oracle_parity_random_f32(pbn, oracle, p):
     got = cpd.logl(test)
     assert np.allclose(got, want, atol=5e-4, rtol=1e-4)
     assert abs(cpd.slogl(test) - want.sum()) <= RTOL_F32 * abs(want.sum())
+
+
+# ---- CKDE.cdf (CKDE_test.py:256-314) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+@pytest.mark.parametrize("tag", ["10k", "10"])
+def test_ckde_cdf_golden(pbn, golden, variable, evidence, tag):
+    key = variable + "_" + "".join(evidence)
+    want = golden[f"ckde_cdf_{key}_{tag}"]
+    base = golden["train10k" if tag == "10k" else "train10"]
+    cpd = pbn.CKDE(variable, evidence)
+    cpd.fit(frame(base))
+    got = cpd.cdf(frame(golden["test50"]))
+    assert np.allclose(got, want, rtol=1e-8, atol=1e-12)           # reference: np.isclose defaults
+    cpd32 = pbn.CKDE(variable, evidence)
+    cpd32.fit(frame(base, "float32"))
+    assert np.allclose(cpd32.cdf(frame(golden["test50"], "float32")), want, atol=5e-4)  # CKDE_test.py:268-271
+
+
+def test_ckde_cdf_nulls_and_order(pbn, golden):
+    train = frame(golden["train10k"])
+    c1, c2 = pbn.CKDE("d", ["a", "b", "c"]), pbn.CKDE("d", ["c", "b", "a"])
+    c1.fit(train)
+    c2.fit(train)
+    tn = frame(golden["test50_null"])
+    r1, r2 = c1.cdf(tn), c2.cdf(tn)
+    nulls = np.any(np.isnan(golden["test50_null"]), axis=1)
+    assert np.array_equal(np.isnan(r1), nulls)
+    assert np.allclose(r1[~nulls], r2[~nulls], rtol=1e-9)
+    full = c1.cdf(frame(golden["test50"]))
+    assert np.allclose(r1[~nulls], full[~nulls], rtol=1e-12)
+    kde = pbn.KDE(["a", "b"])
+    kde.fit(train)
+    assert not hasattr(kde, "cdf")
+
+
+@pytest.mark.parametrize("p", [0, 1, 3, 4, 5, 9, 13])
+def test_ckde_cdf_oracle_parity_random(pbn, oracle, p):
+    """Ragged sizes, KS = 1..4, evidence outliers (weights underflow in the reference's exp(logl) form only when ALL
+    of them do; here the offset keeps the ratio defined) and variable outliers (cdf -> 0 / 1)."""
+    rng = np.random.default_rng(90 + p)
+    n, m = 1237, 77
+    ev = rng.normal(size=(n + m, p)) @ (np.tril(rng.uniform(-0.4, 0.4, size=(p, p)), -1) + np.eye(p)).T
+    y = 0.5 * ev.sum(axis=1) + rng.normal(scale=0.7, size=n + m) + (np.sin(ev[:, 0]) if p else 0.0)
+    data = np.column_stack([y, ev])
+    names = ["y"] + [f"e{i}" for i in range(p)]
+    train = pd.DataFrame(data[:n], columns=names)
+    test = pd.DataFrame(data[n:], columns=names)
+    test.iloc[:3, 0] += 25.0
+    test.iloc[3:6, 0] -= 25.0
+    cpd = pbn.CKDE("y", names[1:])
+    cpd.fit(train)
+    want = oracle.ckde_cdf(train.to_numpy(), cpd.bandwidth, test.to_numpy())
+    got = cpd.cdf(test)
+    assert np.all((got >= 0) & (got <= 1))
+    assert np.allclose(got, want, rtol=1e-8, atol=1e-13)
+    assert np.all(got[:3] > 1 - 1e-9) and np.all(got[3:6] < 1e-9)
+    # monotone in the variable for fixed evidence
+    t2 = test.copy()
+    t2["y"] = t2["y"] + 0.25
+    assert np.all(cpd.cdf(t2) >= got - 1e-14)
+
+
+def test_ckde_cdf_far_evidence(pbn):
+    """Evidence 60 bandwidths away: every weight underflows exp(); the reference returns 0/0 = NaN there, the
+    offset form returns the cdf of the nearest kernels.  Check it is finite and equals the log-domain answer."""
+    rng = np.random.default_rng(5)
+    n = 500
+    e = rng.normal(size=n)
+    y = e + rng.normal(scale=0.5, size=n)
+    train = pd.DataFrame({"y": y, "e": e})
+    cpd = pbn.CKDE("y", ["e"])
+    cpd.fit(train)
+    test = pd.DataFrame({"y": [30.0, 29.0, 31.5], "e": [30.0, 30.0, 30.0]})
+    got = cpd.cdf(test)
+    H = cpd.bandwidth
+    b = H[0, 1] / H[1, 1]
+    sd = np.sqrt(H[0, 0] - H[0, 1] ** 2 / H[1, 1])
+    from scipy.special import logsumexp
+    from scipy.stats import norm
+
+    lw = -0.5 * (30.0 - e) ** 2 / H[1, 1]
+    want = [np.exp(logsumexp(lw + norm.logcdf(v, y + b * (30.0 - e), sd)) - logsumexp(lw)) for v in test["y"]]
+    assert np.all(np.isfinite(got))
+    assert np.allclose(got, want, rtol=1e-8)

@@ -66,6 +66,22 @@ def test_ckde_logl(golden, variable, evidence, tag):
     assert np.allclose(got, golden[f"ckde_logl_{key}_{tag}"], rtol=1e-8, atol=1e-9)
 
 
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+@pytest.mark.parametrize("tag", ["10k", "10"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ckde_cdf(golden, variable, evidence, tag, dtype):
+    """CKDE_test.py:256-314: isclose (fp64) / atol 5e-4 (fp32) against the scipy recipe."""
+    key = variable + "_" + "".join(evidence)
+    tr = _sel(golden["train10k" if tag == "10k" else "train10"], [variable] + evidence).astype(dtype)
+    te = _sel(golden["test50"], [variable] + evidence).astype(dtype)
+    H = golden[f"ckde_bw_{key}_{tag}"]
+    got = oracle.ckde_cdf(tr, H, te)
+    if dtype == np.float64:
+        assert np.allclose(got, golden[f"ckde_cdf_{key}_{tag}"], rtol=1e-8, atol=1e-10)
+    else:
+        assert np.allclose(got, golden[f"ckde_cdf_{key}_{tag}"], atol=5e-4)
+
+
 def test_shuffle_known_answer(golden):
     assert np.array_equal(oracle.shuffled_indices(12, 0), golden["shuffle12_seed0"])
 
