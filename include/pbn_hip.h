@@ -145,6 +145,14 @@ typedef enum { PBN_NODE_LG = 0, PBN_NODE_CKDE = 1, PBN_NODE_DISCRETE = 2 } pbn_n
 
 int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
                          pbn_scoredata** out);
+/* Row-sharded construction for one-process-per-GPU jobs (BGe / BIC / LG-CV row): every rank holds
+ * the same table and takes the Gram moments of its contiguous share of each region; the host adds the ranks'
+ * pbn_scoredata_moments buffers in rank order and installs the totals with set != 0 on every rank.  Until then
+ * pbn_score_batch refuses the handle.  The reference has no counterpart (single process, CPU Eigen). */
+int pbn_scoredata_create_sharded(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed,
+                                 double test_ratio, int rank, int world, pbn_scoredata** out);
+/* buf: per region (k folds or the single CV/training region, then hold-out) S[n] then G[n*n]; *len = doubles. */
+int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set);
 void pbn_scoredata_destroy(pbn_scoredata* sd);
 /* Dictionary-encoded columns (arrow::DictionaryArray indices, factors/discrete/discrete_indices.cpp): n_disc int32
  * arrays in SOURCE row order + cardinalities.  They get column ids n_cols .. n_cols+n_disc-1 in pbn_score_batch;

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pbn_kde_slogl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_slogl_async": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
     "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),
+    "pbn_scoredata_create_sharded": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, _int, _int, C.POINTER(_vp)]),
+    "pbn_scoredata_moments": (_int, [_vp, _dp, C.POINTER(_i64), _int]),
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
     "pbn_scoredata_set_validity": (_int, [_vp, C.POINTER(_vp)]),

@@ -288,10 +288,11 @@ double bge_score(const pbn_scoredata* sd, const Stats& st, const int* cols, int 
 
 extern "C" {
 
-int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
-                         pbn_scoredata** out) {
+static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
+                                 int rank, int world, pbn_scoredata** out) {
     return guarded([&] {
         if (!ctx || !table || !out) throw invalid_error("pbn_scoredata_create: null argument");
+        if (world < 1 || rank < 0 || rank >= world) throw invalid_error("pbn_scoredata_create_sharded: rank / world out of range");
         if (table->n_cols <= 0) throw invalid_error("pbn_scoredata_create: table has no columns");
         HIP_CHECK(hipSetDevice(ctx->device));
         auto sd = std::make_unique<pbn_scoredata>();
@@ -351,19 +352,72 @@ int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k,
         sd->shift.resize(sd->n);
         HIP_CHECK(hipMemcpyAsync(sd->shift.data(), sd->shift_dev.p, sd->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        // moments
+        // moments: of whole regions, or (world > 1) of this rank's contiguous share of every region; the caller
+        // then adds the ranks' shares in rank order and hands the totals back (pbn_scoredata_moments).
+        auto share = [&](int64_t r0, int64_t len, Stats& st) {
+            const int64_t lo = (len * rank) / world, hi = (len * (rank + 1)) / world;
+            compute_stats(sd.get(), r0 + lo, hi - lo, st);
+        };
         if (sd->k > 0) {
             sd->fold.resize(sd->k);
             sd->all.zero(sd->n);
             for (int f = 0; f < sd->k; ++f) {
-                compute_stats(sd.get(), sd->limits[f], sd->limits[f + 1] - sd->limits[f], sd->fold[f]);
+                share(sd->limits[f], sd->limits[f + 1] - sd->limits[f], sd->fold[f]);
                 sd->all.add(sd->fold[f]);
             }
         } else {
-            compute_stats(sd.get(), 0, sd->n_cv, sd->all);
+            share(0, sd->n_cv, sd->all);
         }
-        if (sd->n_hold > 0) compute_stats(sd.get(), sd->n_cv, sd->n_hold, sd->hold);
+        if (sd->n_hold > 0) share(sd->n_cv, sd->n_hold, sd->hold);
+        sd->partial = world > 1;
         *out = sd.release();
+    });
+}
+
+int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
+                         pbn_scoredata** out) {
+    return scoredata_create_impl(ctx, table, split, k, seed, test_ratio, 0, 1, out);
+}
+
+int pbn_scoredata_create_sharded(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
+                                 int rank, int world, pbn_scoredata** out) {
+    return scoredata_create_impl(ctx, table, split, k, seed, test_ratio, rank, world, out);
+}
+
+// Serialised moments: for each region (the k folds, or the single CV/training region when k == 0, then the hold-out
+// region if any): S[n] then G[n*n].  set == 0 copies them out, set != 0 installs totals and clears the partial flag.
+int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set) {
+    return guarded([&] {
+        if (!sd) throw invalid_error("pbn_scoredata_moments: null argument");
+        const size_t per = (size_t)sd->n + (size_t)sd->n * sd->n;
+        std::vector<Stats*> regions;
+        if (sd->k > 0) for (auto& f : sd->fold) regions.push_back(&f); else regions.push_back(&sd->all);
+        if (sd->n_hold > 0) regions.push_back(&sd->hold);
+        if (len) *len = (int64_t)(per * regions.size());
+        if (!buf) return;
+        double* p = buf;
+        for (Stats* st : regions) {
+            if (set) {
+                std::memcpy(st->S.data(), p, sd->n * sizeof(double));
+                std::memcpy(st->G.data(), p + sd->n, (size_t)sd->n * sd->n * sizeof(double));
+            } else {
+                std::memcpy(p, st->S.data(), sd->n * sizeof(double));
+                std::memcpy(p + sd->n, st->G.data(), (size_t)sd->n * sd->n * sizeof(double));
+            }
+            p += per;
+        }
+        if (!set) return;
+        if (sd->k > 0) {
+            sd->all.zero(sd->n);
+            for (int f = 0; f < sd->k; ++f) {
+                sd->fold[f].N = sd->limits[f + 1] - sd->limits[f];
+                sd->all.add(sd->fold[f]);
+            }
+        } else {
+            sd->all.N = sd->n_cv;
+        }
+        if (sd->n_hold > 0) sd->hold.N = sd->n_hold;
+        sd->partial = false;
     });
 }
 
@@ -423,6 +477,7 @@ int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits
 int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, double* beta, double* variance) {
     return guarded([&] {
         if (!sd || !beta || !variance) throw invalid_error("pbn_lg_fit: null argument");
+        if (sd->partial) throw invalid_error("pbn_lg_fit: row-sharded score data needs pbn_scoredata_moments(set) first");
         std::vector<int> cols(p + 1);
         cols[0] = var;
         for (int i = 0; i < p; ++i) cols[i + 1] = parents[i];
@@ -489,6 +544,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
     return guarded([&] {
         if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
         pbn_ctx* ctx = sd->ctx;
+        if (sd->partial) throw invalid_error("pbn_score_batch: row-sharded score data needs pbn_scoredata_moments(set) first");
         HIP_CHECK(hipSetDevice(ctx->device));
         if ((kind == PBN_SCORE_CVLIK) && sd->k <= 0) throw invalid_error("pbn_score_batch: score data has no CV folds");
         if ((kind == PBN_SCORE_HOLDOUT) && sd->n_hold <= 0) throw invalid_error("pbn_score_batch: score data has no hold-out split");

@@ -96,3 +96,32 @@ def sharded_slogl(factor, df):
     for v in recv.cpu().tolist():
         total += v
     return total
+
+
+def reduce_moments(handle):
+    """Row-sharded Gram (BGe / BIC / LG-CV row): every rank computed the moments of its share of
+    each region (pbn_scoredata_create_sharded); all-gather the (k+1) * (n + n^2) doubles, add them in rank order on
+    the host (deterministic, identical on every rank) and install the totals."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    dist = _dist()
+    lib = _lib.load()
+    ln = C.c_int64(0)
+    _lib.check(lib.pbn_scoredata_moments(handle, None, C.byref(ln), 0))
+    buf = np.zeros(ln.value)
+    _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 0))
+    if dist is not None:
+        world = dist.get_world_size()
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        send = torch.from_numpy(buf).to(dev)
+        recv = torch.empty(world * buf.size, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send)
+        parts = recv.cpu().numpy().reshape(world, buf.size)
+        buf = parts[0].copy()
+        for r in range(1, world):
+            buf += parts[r]
+    _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 1))

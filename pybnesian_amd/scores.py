@@ -60,8 +60,18 @@ class Score:
         self._col = {n: i for i, n in enumerate(self._names)}
         k, seed, ratio = split_args
         h = C.c_void_p()
-        _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
-                                                    float(ratio), C.byref(h)))
+        from .distributed import reduce_moments, _dist
+
+        dist = _dist()
+        if dist is None:
+            _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
+                                                        float(ratio), C.byref(h)))
+        else:
+            # one process per GPU: each rank takes the Gram of its share of the rows, one exchange of the moments
+            _lib.check(_lib.load().pbn_scoredata_create_sharded(self._ctx.handle, table.handle, self._split, int(k),
+                                                                C.c_uint32(int(seed)), float(ratio), dist.get_rank(),
+                                                                dist.get_world_size(), C.byref(h)))
+            reduce_moments(h)
         self._handle = h
         if getattr(self, "_masks", None):
             keep = [np.ascontiguousarray(self._masks[c].astype(np.uint8)) if c in self._masks else None for c in self._cont_names]

@@ -304,3 +304,56 @@ def test_split_accessors_and_kde_views(pbn, golden, oracle):
     test = frame(golden["test50"])
     lj, lm = cpd.kde_joint().logl(test), cpd.kde_marg().logl(test)
     assert np.allclose(lj - lm, cpd.logl(test), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_row_sharded_moments(pbn, world):
+    """SURVEY.md §8e (BGe / BIC / LG-CV): each rank's Gram over its share of every region, added in rank order, gives
+    the scores of the unsharded handle (to rounding of the different summation partition); a handle whose totals have
+    not been installed is refused."""
+    import ctypes as C
+
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(11)
+    n, rows = 6, 10007
+    data = rng.normal(size=(rows, n)) @ (np.eye(n) + np.triu(rng.uniform(-0.5, 0.5, (n, n)), 1)) + 3.0
+    df = pd.DataFrame(data, columns=[f"v{i}" for i in range(n)])
+    lib = _lib.load()
+    for make, kind, split, args in (
+        (lambda: pbn.BGe(df), _lib.PBN_SCORE_BGE, _lib.PBN_SPLIT_NONE, (0, 0, 0.0)),
+        (lambda: pbn.BIC(df), _lib.PBN_SCORE_BIC, _lib.PBN_SPLIT_NONE, (0, 0, 0.0)),
+        (lambda: pbn.CVLikelihood(df, k=7, seed=5), _lib.PBN_SCORE_CVLIK, _lib.PBN_SPLIT_CV, (7, 5, 0.0)),
+        (lambda: pbn.ValidatedLikelihood(df, test_ratio=0.3, k=4, seed=2), _lib.PBN_SCORE_HOLDOUT, _lib.PBN_SPLIT_VALIDATED, (4, 2, 0.3)),
+    ):
+        score = make()
+        model = pbn.GaussianNetwork(list(df.columns))
+        var, ntype, off, par = [0, 1, 5, 3], [0, 0, 0, 0], [0, 0, 1, 3, 8], [0, 0, 1, 0, 1, 2, 4, 5]
+        want = score._batch_raw(model, var, ntype, off, par, kind)
+        handles, bufs = [], []
+        for r in range(world):
+            h = C.c_void_p()
+            _lib.check(lib.pbn_scoredata_create_sharded(score._ctx.handle, score._table.handle, split, args[0],
+                                                        C.c_uint32(args[1]), args[2], r, world, C.byref(h)))
+            ln = C.c_int64(0)
+            _lib.check(lib.pbn_scoredata_moments(h, None, C.byref(ln), 0))
+            b = np.zeros(ln.value)
+            _lib.check(lib.pbn_scoredata_moments(h, _lib.dptr(b), C.byref(ln), 0))
+            handles.append(h)
+            bufs.append(b)
+        out = np.zeros(len(var))
+        params = score._batch_params(model)
+        call = lambda h: lib.pbn_score_batch(h, kind, len(var), _lib.int_array(var), _lib.int_array(ntype), _lib.int_array(off),
+                                             _lib.int_array(par), _lib.dptr(params) if params.size else None, int(params.size),
+                                             _lib.dptr(out))
+        with pytest.raises(ValueError, match="row-sharded"):
+            _lib.check(call(handles[0]))
+        total = bufs[0].copy()
+        for b in bufs[1:]:
+            total += b
+        for h in handles:
+            ln = C.c_int64(total.size)
+            _lib.check(lib.pbn_scoredata_moments(h, _lib.dptr(total), C.byref(ln), 1))
+            _lib.check(call(h))
+            assert np.allclose(out, want, rtol=1e-11, atol=0)
+            lib.pbn_scoredata_destroy(h)

@@ -11,8 +11,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pybnesian_amd as pbn  # noqa: E402
 from pybnesian_amd.distributed import sharded_slogl  # noqa: E402
 
-dist.init_process_group("gloo")
 rng = np.random.default_rng(0)
+# row-sharded Gram moments of the scores: reference values from unsharded handles, built BEFORE the process group exists
+sdf = pd.DataFrame(rng.normal(size=(50001, 5)) @ (np.eye(5) + np.triu(np.full((5, 5), 0.3), 1)), columns=list("vwxyz"))
+cands = [("v", []), ("w", ["v"]), ("z", ["v", "w", "x", "y"])]
+single = {}
+for name, mk in (("bge", lambda: pbn.BGe(sdf)), ("bic", lambda: pbn.BIC(sdf)), ("cv", lambda: pbn.CVLikelihood(sdf, k=5, seed=1))):
+    sc = mk()
+    single[name] = [sc.local_score(pbn.GaussianNetwork(list("vwxyz")), v, e) for v, e in cands]
+dist.init_process_group("gloo")
+for name, mk in (("bge", lambda: pbn.BGe(sdf)), ("bic", lambda: pbn.BIC(sdf)), ("cv", lambda: pbn.CVLikelihood(sdf, k=5, seed=1))):
+    sc = mk()   # now sharded: each rank takes the Gram of half of every region, one all_gather of the moments
+    got = [sc.local_score(pbn.GaussianNetwork(list("vwxyz")), v, e) for v, e in cands]
+    assert np.allclose(got, single[name], rtol=1e-11, atol=0), (name, got, single[name])
 train = pd.DataFrame(rng.normal(size=(20000, 3)), columns=list("abc"))
 test = pd.DataFrame(rng.normal(size=(3001, 3)), columns=list("abc"))
 for f in (pbn.KDE(list("abc")), pbn.CKDE("a", ["b", "c"])):
@@ -21,5 +32,5 @@ for f in (pbn.KDE(list("abc")), pbn.CKDE("a", ["b", "c"])):
     got = sharded_slogl(f, test)
     assert abs(got - whole) <= 1e-12 * abs(whole), (got, whole)
 if dist.get_rank() == 0:
-    print("sharded_slogl ok on", dist.get_world_size(), "ranks")
+    print("row-sharded moments + sharded_slogl ok on", dist.get_world_size(), "ranks")
 dist.destroy_process_group()
