@@ -153,6 +153,9 @@ int pbn_scoredata_create_sharded(pbn_ctx* ctx, const pbn_table* table, int split
                                  double test_ratio, int rank, int world, pbn_scoredata** out);
 /* buf: per region (k folds or the single CV/training region, then hold-out) S[n] then G[n*n]; *len = doubles. */
 int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set);
+/* Bandwidth selector (PBN_SEL_*) of the CKDEs fitted while scoring: the reference passes it through the scores'
+ * construction_args to CKDEType::new_factor (learning/scores/cv_likelihood.hpp:19-27). Default normal reference. */
+int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector);
 void pbn_scoredata_destroy(pbn_scoredata* sd);
 /* Dictionary-encoded columns (arrow::DictionaryArray indices, factors/discrete/discrete_indices.cpp): n_disc int32
  * arrays in SOURCE row order + cardinalities.  They get column ids n_cols .. n_cols+n_disc-1 in pbn_score_batch;
@@ -208,6 +211,13 @@ typedef struct {
     double epsilon;
     int patience;
     int validated;           /* score is a ValidatedScore                                                */
+    /* Callback::call(model, operator, score, iteration) (learning/algorithms/callbacks/callback.hpp; call sites
+     * hillclimbing.hpp:127,180,195): iteration 0 with the start model, every iteration after the operator was applied,
+     * and once more with the returned model.  op = {kind, source|node, target|type}, kind -1 = no operator.
+     * arcs = 2*n_arcs node indices (source, target).  Non-zero return aborts the search.  Nullable. */
+    int (*on_iter)(void* user, int iteration, const int* op, double delta, int n_arcs, const int* arcs,
+                   const int* node_types);
+    void* on_iter_user;
 } pbn_hc_config;
 typedef struct {
     int iterations;

@@ -9,11 +9,12 @@ from .dataset import Context, DeviceTable, default_context  # noqa: F401
 from .factors import CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, Factor, LinearGaussianCPD  # noqa: F401
 from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
-from .learning import (AddArc, ArcOperatorSet, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
+from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, OperatorPool, OperatorTabuSet, RemoveArc, hc)
 from .models import (BayesianNetwork, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType)
-from .scores import BGe, BIC, CVLikelihood, HoldoutLikelihood, ValidatedLikelihood  # noqa: F401
+from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
+                     ValidatedScore)
 
 __all__ = [
     "BIC", "BGe", "CVLikelihood", "HoldoutLikelihood", "ValidatedLikelihood", "GreedyHillClimbing", "hc",
@@ -21,5 +22,5 @@ __all__ = [
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
-    "SingularCovarianceData", "Context", "DeviceTable", "default_context", "load_library",
+    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "Callback", "Context", "DeviceTable", "default_context", "load_library",
 ]

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),
     "pbn_scoredata_create_sharded": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, _int, _int, C.POINTER(_vp)]),
     "pbn_scoredata_moments": (_int, [_vp, _dp, C.POINTER(_i64), _int]),
+    "pbn_scoredata_set_selector": (_int, [_vp, _int]),
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
     "pbn_scoredata_set_validity": (_int, [_vp, C.POINTER(_vp)]),
@@ -82,6 +83,7 @@ SIGNATURES = {
 }
 
 HC_SCORE_FN = C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)
+HC_ITER_FN = C.CFUNCTYPE(_int, _vp, _int, _ip, C.c_double, _int, _ip, _ip)
 
 
 class HCConfig(C.Structure):
@@ -91,6 +93,7 @@ class HCConfig(C.Structure):
         ("n_type_blacklist", _int), ("type_blacklist", _ip), ("n_type_whitelist", _int), ("type_whitelist", _ip),
         ("op_arcs", _int), ("op_node_type", _int), ("arcs_first", _int), ("max_indegree", _int), ("max_iters", _int),
         ("epsilon", C.c_double), ("patience", _int), ("validated", _int),
+        ("on_iter", HC_ITER_FN), ("on_iter_user", _vp),
     ]
 
 

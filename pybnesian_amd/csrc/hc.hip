@@ -585,6 +585,18 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
         std::vector<Op> tabu;
         int iter = 0;
         std::vector<int> trace;
+        auto notify = [&](const Model& mod, const Op* op, int iteration) {  // Callback::call
+            if (!cfg->on_iter) return;
+            std::vector<int> arcs;
+            for (int t = 0; t < n; ++t)
+                for (int s : mod.parents[t]) { arcs.push_back(s); arcs.push_back(t); }
+            int o[3] = {-1, 0, 0};
+            if (op) { o[0] = op->kind; o[1] = op->source; o[2] = op->kind == OP_TYPE ? op->new_type : op->target; }
+            if (cfg->on_iter(cfg->on_iter_user, iteration, o, op ? op->delta : 0.0, (int)arcs.size() / 2, arcs.data(),
+                             mod.node_type.data()) != 0)
+                throw device_error("pbn_hc_estimate: the iteration callback failed");
+        };
+        notify(m, nullptr, 0);
         while (iter < cfg->max_iters) {
             ++iter;
             Op best_op = zero_patience ? e.find_max(nullptr) : e.find_max(&tabu);
@@ -628,9 +640,11 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
                 trace.push_back(0);
                 if (stats->trace_delta) stats->trace_delta[trace.size() / 4 - 1] = best_op.delta;
             }
+            notify(m, &best_op, iter);
             e.update_scores(changed);
         }
         const Model& res = best_is_current ? m : best;
+        notify(res, nullptr, iter);
         int na = 0;
         for (int t = 0; t < n; ++t)
             for (int s : res.parents[t]) { out_arcs[2 * na] = s; out_arcs[2 * na + 1] = t; ++na; }

@@ -270,7 +270,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             const double inv = 1.0 / (double)(tr->N - 1);
             for (auto& x : sse) x *= inv;
             try {
-                bandwidth_from_cov(PBN_SEL_NORMAL_REFERENCE, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
+                bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
             } catch (const singular_error&) {
                 continue;
             }

@@ -463,6 +463,16 @@ int pbn_scoredata_set_validity(pbn_scoredata* sd, const uint8_t* const* masks) {
     });
 }
 
+// Bandwidth selector used for every CKDE the engine fits while scoring (CKDEType::new_factor with construction
+// arguments, cv_likelihood.hpp:19-27; selectors kde/NormalReferenceRule.hpp, kde/ScottsBandwidth.hpp).
+int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
+    return guarded([&] {
+        if (!sd) throw invalid_error("pbn_scoredata_set_selector: null argument");
+        if (selector != PBN_SEL_NORMAL_REFERENCE && selector != PBN_SEL_SCOTT) throw invalid_error("pbn_scoredata_set_selector: unknown selector");
+        sd->selector = selector;
+    });
+}
+
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold) {
     return guarded([&] {
         if (!sd) throw invalid_error("pbn_scoredata_layout: null argument");
@@ -669,7 +679,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                     subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
                     const double inv = 1.0 / (double)(tr->N - 1);
                     for (auto& x : sse) x *= inv;  // covariance
-                    bandwidth_from_cov(PBN_SEL_NORMAL_REFERENCE, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
+                    bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
                     KdeModel m;
                     kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
                     const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);

@@ -35,6 +35,7 @@ struct pbn_scoredata {
     int n = 0;  // continuous columns
     int split = PBN_SPLIT_NONE;
     int k = 0;
+    int selector = PBN_SEL_NORMAL_REFERENCE;  // bandwidth selector of the CKDEs fitted while scoring
     bool partial = false;  // moments hold only this rank's row share (pbn_scoredata_create_sharded)
     const pbn_table* src = nullptr;  // caller's table (borrowed)
     pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)

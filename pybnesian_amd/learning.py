@@ -151,16 +151,75 @@ class OperatorTabuSet:
 
 
 class LocalScoreCache:
-    """Read-only view of the engine's LocalScoreCache (operators.hpp:295-338)."""
+    """LocalScoreCache (learning/operators/operators.hpp:295-338): one local score per node.  `LocalScoreCache()` /
+    `LocalScoreCache(model)` own their values and fill them through the score (one batch for device scores); the
+    object returned by `OperatorSet.local_score_cache()` is a view of the engine's cache."""
 
-    def __init__(self, binding):
-        self._binding = binding
+    def __init__(self, model=None):
+        self._binding = None
+        self._values, self._idx = None, {}
+        if isinstance(model, _EngineBinding):
+            self._binding = model
+        elif model is not None:
+            self._reset(model)
+
+    def _reset(self, model):
+        self._idx = {n: i for i, n in enumerate(model.nodes())}
+        self._values = np.zeros(len(self._idx))
+
+    def _fill(self, model, score, validated):
+        from .scores import _DeviceScore
+
+        if self._binding is not None:
+            raise ValueError("This LocalScoreCache is a view of an operator set's cache.")
+        if self._values is None or len(self._idx) != model.num_nodes():
+            self._reset(model)
+        nodes = model.nodes()
+        if isinstance(score, _DeviceScore):
+            cands = [(n, model.node_type(n), model.parents(n)) for n in nodes]
+            vals = score._batch(model, cands, _lib.PBN_SCORE_HOLDOUT if validated else score._kind)
+        else:
+            fn = score.vlocal_score if validated else score.local_score
+            vals = [fn(model, n, model.parents(n)) for n in nodes]
+        for n, v in zip(nodes, vals):
+            self._values[self._idx[n]] = v
+
+    def cache_local_scores(self, model, score):
+        self._fill(model, score, False)
+
+    def cache_vlocal_scores(self, model, score):
+        self._fill(model, score, True)
+
+    def _update(self, model, score, variable, validated):
+        if self._binding is not None:
+            raise ValueError("This LocalScoreCache is a view of an operator set's cache.")
+        fn = score.vlocal_score if validated else score.local_score
+        self._values[self._idx[variable]] = fn(model, variable, model.parents(variable))
+
+    def update_local_score(self, model, score, variable):
+        self._update(model, score, variable, False)
+
+    def update_vlocal_score(self, model, score, variable):
+        self._update(model, score, variable, True)
 
     def local_score(self, model, variable):
-        return float(self._binding.local_scores()[self._binding.idx[variable]])
+        if self._binding is not None:
+            return float(self._binding.local_scores()[self._binding.idx[variable]])
+        return float(self._values[self._idx[variable]])
 
     def sum(self):
-        return float(np.sum(self._binding.local_scores()))
+        if self._binding is not None:
+            return float(np.sum(self._binding.local_scores()))
+        return float(np.sum(self._values)) if self._values is not None else 0.0
+
+
+class Callback:
+    """learning/algorithms/callbacks/callback.hpp: subclass and implement call(model, operator, score, iteration).
+    Called with iteration 0 and operator None before the search, after every applied operator, and once more with
+    operator None on the returned model (hillclimbing.hpp:127,180,195)."""
+
+    def call(self, model, operator, score, iteration):
+        raise NotImplementedError("Tried to call pure virtual function \"Callback::call\"")
 
 
 class _EngineBinding:
@@ -169,12 +228,14 @@ class _EngineBinding:
     def __init__(self, sets, score, model, arc_blacklist=(), arc_whitelist=(), type_blacklist=(), type_whitelist=(),
                  max_indegree=0, max_iters=2 ** 31 - 1, epsilon=0.0, patience=0):
         from .distributed import sharded_batch
+        from .scores import ValidatedScore, _DeviceScore
 
+        device_score = isinstance(score, _DeviceScore) or hasattr(score, "_batch_raw")  # batched engine protocol
         self.nodes = model.nodes()
         self.idx = {n: i for i, n in enumerate(self.nodes)}
         self.score, self.model_type = score, model.type()
         n = len(self.nodes)
-        col_of_node = [score._col[v] for v in self.nodes]
+        col_of_node = [score._col[v] for v in self.nodes] if device_score else list(range(len(self.nodes)))
         idx = self.idx
 
         def pairs(lst, second=idx.__getitem__):
@@ -214,7 +275,7 @@ class _EngineBinding:
         cfg.arcs_first = int(isinstance(sets[0], ArcOperatorSet))
         cfg.max_indegree, cfg.max_iters = int(max_indegree), int(min(max_iters, 2 ** 31 - 1))
         cfg.epsilon, cfg.patience = float(epsilon), int(patience)
-        cfg.validated = int(getattr(score, "validated", False))
+        cfg.validated = int(isinstance(score, ValidatedScore) or bool(getattr(score, "validated", False)))
         self.cfg = cfg
         self.errors = []
         self.batch_hook = None
@@ -225,8 +286,19 @@ class _EngineBinding:
                 var_l = [col_of_node[var[i]] for i in range(n_cand)]
                 nt_l = [ntype[i] for i in range(n_cand)]
                 par_l = [col_of_node[par[i]] for i in range(off_l[-1])]
-                kind = _lib.PBN_SCORE_HOLDOUT if validated else score._kind
-                res = sharded_batch(score, model, var_l, nt_l, off_l, par_l, kind)
+                if device_score:
+                    kind = _lib.PBN_SCORE_HOLDOUT if validated else score._kind
+                    res = sharded_batch(score, model, var_l, nt_l, off_l, par_l, kind)
+                else:  # Python-derived Score: one trampoline call per candidate, as the reference does
+                    fn = score.vlocal_score_node_type if validated else score.local_score_node_type
+                    plain = score.vlocal_score if validated else score.local_score
+                    res = []
+                    for i in range(n_cand):
+                        v, ev = self.nodes[var_l[i]], [self.nodes[j] for j in par_l[off_l[i]: off_l[i + 1]]]
+                        if model.type().homogeneous:
+                            res.append(float(plain(model, v, ev)))
+                        else:
+                            res.append(float(fn(model, _NODE_FROM_CODE[nt_l[i]], v, ev)))
                 if self.batch_hook is not None:
                     self.batch_hook(n_cand)
                 for i in range(n_cand):
@@ -369,6 +441,32 @@ class OperatorSet:
     def finished(self):
         self._invalidate()
 
+    # OperatorSet setters (operators.hpp:346-353): every set accepts all of them, each keeps what concerns it
+    def set_arc_blacklist(self, blacklist):
+        for st in self._sets():
+            if st is not self:
+                st.set_arc_blacklist(blacklist)
+
+    def set_arc_whitelist(self, whitelist):
+        for st in self._sets():
+            if st is not self:
+                st.set_arc_whitelist(whitelist)
+
+    def set_max_indegree(self, max_indegree):
+        for st in self._sets():
+            if st is not self:
+                st.set_max_indegree(max_indegree)
+
+    def set_type_blacklist(self, type_blacklist):
+        for st in self._sets():
+            if st is not self:
+                st.set_type_blacklist(type_blacklist)
+
+    def set_type_whitelist(self, type_whitelist):
+        for st in self._sets():
+            if st is not self:
+                st.set_type_whitelist(type_whitelist)
+
 
 class ArcOperatorSet(OperatorSet):
     def __init__(self, blacklist=(), whitelist=(), max_indegree=0):
@@ -412,6 +510,9 @@ class OperatorPool(OperatorSet):
     def _sets(self):
         return self.opsets
 
+    def _invalidate(self):
+        super()._invalidate()
+
 
 def _flatten_ops(operators):
     sets = operators._sets() if isinstance(operators, OperatorSet) else [operators]
@@ -453,6 +554,20 @@ class GreedyHillClimbing:
         trace = (C.c_int * (4 * cap))()
         tdelta = (C.c_double * cap)()
         stats.trace_capacity, stats.trace, stats.trace_delta = cap, trace, tdelta
+        if callback is not None:
+            def on_iter(_user, iteration, op, delta, n_arcs, arcs, ntypes):
+                try:
+                    cur_arcs = [(nodes[arcs[2 * i]], nodes[arcs[2 * i + 1]]) for i in range(n_arcs)]
+                    cur_types = [(nodes[i], _NODE_FROM_CODE[ntypes[i]]) for i in range(n)]
+                    cur = BayesianNetwork(start.type(), nodes, cur_arcs, [] if start.type().homogeneous else cur_types)
+                    callback.call(cur, binding.make_op(op[0], op[1], op[2], delta), score, iteration)
+                    return 0
+                except Exception as ex:
+                    binding.errors.append(ex)
+                    return 1
+
+            binding.iter_callback = _lib.HC_ITER_FN(on_iter)
+            binding.cfg.on_iter = binding.iter_callback
         rc = _lib.load().pbn_hc_estimate(C.byref(binding.cfg), binding.callback, None, out_arcs, C.byref(out_n), out_types,
                                          C.byref(stats))
         binding.check(rc)
@@ -464,8 +579,6 @@ class GreedyHillClimbing:
         self.last.cells_scored = stats.cells_scored
         self.last.local_score_evals = stats.local_score_evals
         self.last.trace = [binding.make_op(trace[4 * i], trace[4 * i + 1], trace[4 * i + 2], tdelta[i]) for i in range(stats.trace_len)]
-        if callback is not None:  # Callback::call(model, operator, score, iteration) hook (hillclimbing.hpp:127,180,195)
-            callback.call(result, None, score, stats.iterations)
         return result
 
 

@@ -24,6 +24,128 @@ def _random_seed():
 
 
 class Score:
+    """Abstract score, subclassable from Python exactly as the reference's trampoline allows
+    (pybindings_scores.cpp:281-392, docs/source/extending.rst): a subclass implements
+    `local_score(model, variable, evidence)`, `has_variables(vars)`, `compatible_bn(model)` and optionally
+    `local_score_node_type(model, variable_type, variable, evidence)`, `data()`, `score(model)`.  The hill-climbing
+    engine calls such a score candidate by candidate through its batch callback (no device work involved)."""
+
+    def local_score(self, model, variable, evidence=None):
+        raise NotImplementedError("Tried to call pure virtual function \"Score::local_score\"")
+
+    def local_score_node_type(self, model, variable_type, variable, evidence):
+        raise NotImplementedError("Tried to call pure virtual function \"Score::local_score_node_type\"")
+
+    def has_variables(self, variables):
+        raise NotImplementedError("Tried to call pure virtual function \"Score::has_variables\"")
+
+    def compatible_bn(self, model):
+        raise NotImplementedError("Tried to call pure virtual function \"Score::compatible_bn\"")
+
+    def score(self, model):
+        """Score::score (scores.hpp:17-24): sum of the local scores."""
+        return float(sum(self.local_score(model, n, model.parents(n)) for n in model.nodes()))
+
+    def data(self):
+        return None
+
+
+class ValidatedScore(Score):
+    """Score with a validation counterpart (scores.hpp:103-141, trampoline pybindings_scores.cpp:394-440)."""
+
+    validated = True
+
+    def vlocal_score(self, model, variable, evidence=None):
+        raise NotImplementedError("Tried to call pure virtual function \"ValidatedScore::vlocal_score\"")
+
+    def vlocal_score_node_type(self, model, variable_type, variable, evidence):
+        raise NotImplementedError("Tried to call pure virtual function \"ValidatedScore::vlocal_score_node_type\"")
+
+    def vscore(self, model):
+        return float(sum(self.vlocal_score(model, n, model.parents(n)) for n in model.nodes()))
+
+
+class Args:
+    """factors/arguments.hpp:16-24: wrapper that marks a tuple as *args."""
+
+    def __init__(self, *args):
+        self.args = tuple(args)
+
+
+class Kwargs:
+    """factors/arguments.hpp:26-34: wrapper that marks a dict as **kwargs."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = dict(kwargs)
+
+
+class Arguments:
+    """factors/arguments.hpp:36-140: construction arguments per (name, factor type) / name / factor type, most
+    specific first."""
+
+    def __init__(self, dict_arguments=None):
+        from .models import FactorType
+
+        self._name_type, self._name, self._type = {}, {}, {}
+        for key, value in (dict_arguments or {}).items():
+            av = self._process(value)
+            if isinstance(key, str):
+                self._name[key] = av
+            elif isinstance(key, FactorType):
+                self._type[key] = av
+            elif isinstance(key, tuple) and len(key) == 2 and isinstance(key[0], str) and isinstance(key[1], FactorType):
+                self._name_type[key] = av
+            else:
+                raise ValueError("Key value is not of type str, FactorType or 2-tuple (str, FactorType).")
+
+    @staticmethod
+    def _process(value):
+        if isinstance(value, Args):
+            return value.args, {}
+        if isinstance(value, Kwargs):
+            return (), value.kwargs
+        if isinstance(value, dict):
+            return (), dict(value)
+        if isinstance(value, tuple):
+            if len(value) == 2 and isinstance(value[0], Args) and isinstance(value[1], Kwargs):
+                return value[0].args, value[1].kwargs
+            return tuple(value), {}
+        raise ValueError("The provided arguments must be a 2-tuple (Args, Kwargs), an Args/tuple or a Kwargs/dict.")
+
+    def args(self, node, node_type):
+        for table, key in ((self._name_type, (node, node_type)), (self._name, node), (self._type, node_type)):
+            if key in table:
+                return table[key]
+        return (), {}
+
+    def empty(self):
+        return not (self._name_type or self._name or self._type)
+
+    def __repr__(self):
+        return "Arguments"
+
+
+def _engine_selector(construction_args):
+    """What the device engine can honour of an `Arguments`: one bandwidth selector for every CKDE it fits while
+    scoring (NormalReferenceRule, the default, or ScottsBandwidth), given for CKDEType()."""
+    from .kde import NormalReferenceRule, ScottsBandwidth
+
+    if construction_args is None or construction_args.empty():
+        return _lib.PBN_SEL_NORMAL_REFERENCE
+    if construction_args._name or construction_args._name_type or list(construction_args._type) != [CKDEType()]:
+        raise ValueError("The device score engine only accepts construction arguments keyed by CKDEType().")
+    args, kwargs = construction_args._type[CKDEType()]
+    sel = args[0] if len(args) == 1 and not kwargs else kwargs.get("bandwidth_selector") if (not args and list(kwargs) == ["bandwidth_selector"]) else None
+    if type(sel) is NormalReferenceRule:
+        return _lib.PBN_SEL_NORMAL_REFERENCE
+    if type(sel) is ScottsBandwidth:
+        return _lib.PBN_SEL_SCOTT
+    raise ValueError("The device score engine only accepts NormalReferenceRule() or ScottsBandwidth() as the CKDE bandwidth selector.")
+
+
+class _DeviceScore(Score):
+    """Score evaluated by the batched HIP engine (pbn_score_batch)."""
+
     _kind = None
     _split = _lib.PBN_SPLIT_NONE
     _allowed_types = (LinearGaussianCPDType(), DiscreteFactorType())
@@ -197,7 +319,7 @@ class Score:
             pass
 
 
-class BIC(Score):
+class BIC(_DeviceScore):
     """learning/scores/bic.cpp:12-27,108-142 (LinearGaussianCPD nodes)."""
 
     _kind = _lib.PBN_SCORE_BIC
@@ -214,7 +336,7 @@ class BIC(Score):
         return beta, var.value
 
 
-class BGe(Score):
+class BGe(_DeviceScore):
     """learning/scores/bge.hpp:14-234.  BGe(df, iss_mu=1, iss_w=None, nu=None)."""
 
     _kind = _lib.PBN_SCORE_BGE
@@ -237,8 +359,13 @@ class BGe(Score):
         return np.concatenate([head, self._nu])
 
 
-class _LikelihoodScore(Score):
+class _LikelihoodScore(_DeviceScore):
     _allowed_types = (LinearGaussianCPDType(), CKDEType(), DiscreteFactorType())
+
+    def _set_selector(self, construction_args):
+        """`construction_args` (cv_likelihood.hpp:19-27 -> FactorType::new_factor args): see _engine_selector."""
+        self._construction_args = construction_args if construction_args is not None else Arguments()
+        _lib.check(_lib.load().pbn_scoredata_set_selector(self._handle, _engine_selector(construction_args)))
 
 
 class CVLikelihood(_LikelihoodScore):
@@ -247,10 +374,11 @@ class CVLikelihood(_LikelihoodScore):
     _kind = _lib.PBN_SCORE_CVLIK
     _split = _lib.PBN_SPLIT_CV
 
-    def __init__(self, df, k=10, seed=None, ctx=None, table=None):
+    def __init__(self, df, k=10, seed=None, construction_args=None, ctx=None, table=None):
         self._k = int(k)
         self._seed = _random_seed() if seed is None else int(seed)
         super().__init__(df, (self._k, self._seed, 0.0), ctx=ctx, table=table)
+        self._set_selector(construction_args)
 
     def fold_layout(self):
         """(perm, limits): source row of every permuted row and the k+1 fold limits."""
@@ -269,9 +397,10 @@ class HoldoutLikelihood(_LikelihoodScore):
     _kind = _lib.PBN_SCORE_HOLDOUT
     _split = _lib.PBN_SPLIT_HOLDOUT
 
-    def __init__(self, df, test_ratio=0.2, seed=None, ctx=None, table=None):
+    def __init__(self, df, test_ratio=0.2, seed=None, construction_args=None, ctx=None, table=None):
         self._seed = _random_seed() if seed is None else int(seed)
         super().__init__(df, (0, self._seed, float(test_ratio)), ctx=ctx, table=table)
+        self._set_selector(construction_args)
 
     def training_data(self):
         perm, _, n_cv, _ = self._layout()
@@ -282,7 +411,7 @@ class HoldoutLikelihood(_LikelihoodScore):
         return self._take(perm[n_cv: n_cv + n_hold])
 
 
-class ValidatedLikelihood(_LikelihoodScore):
+class ValidatedLikelihood(_LikelihoodScore, ValidatedScore):
     """learning/scores/validated_likelihood.hpp:12-75: local_score = CV over the hold-out training part,
     vlocal_score = hold-out likelihood; the same seed drives both splits."""
 
@@ -290,10 +419,11 @@ class ValidatedLikelihood(_LikelihoodScore):
     _split = _lib.PBN_SPLIT_VALIDATED
     validated = True
 
-    def __init__(self, df, test_ratio=0.2, k=10, seed=None, ctx=None, table=None):
+    def __init__(self, df, test_ratio=0.2, k=10, seed=None, construction_args=None, ctx=None, table=None):
         self._seed = _random_seed() if seed is None else int(seed)
         self._k = int(k)
         super().__init__(df, (int(k), self._seed, float(test_ratio)), ctx=ctx, table=table)
+        self._set_selector(construction_args)
 
     def training_data(self):
         """Hold-out training part in the hold-out shuffle order is not kept: rows are returned in CV order."""

@@ -357,3 +357,35 @@ def test_row_sharded_moments(pbn, world):
             _lib.check(call(h))
             assert np.allclose(out, want, rtol=1e-11, atol=0)
             lib.pbn_scoredata_destroy(h)
+
+
+def test_construction_args_bandwidth_selector(pbn):
+    """CVLikelihood(df, k, seed, Arguments({CKDEType(): (ScottsBandwidth(),)})): every CKDE fitted while scoring uses
+    that selector (cv_likelihood.hpp:19-27); checked against explicit per-fold CKDE fits."""
+    rng = np.random.default_rng(21)
+    n = 3000
+    a = rng.normal(size=n)
+    b = np.sin(a) + rng.normal(scale=0.3, size=n)
+    c = 0.5 * a - b + rng.normal(scale=0.5, size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c})
+    model = pbn.SemiparametricBN(["a", "b", "c"], [], [("c", pbn.CKDEType())])
+    for sel in (pbn.ScottsBandwidth(), pbn.NormalReferenceRule()):
+        for args in (pbn.Arguments({pbn.CKDEType(): (sel,)}), pbn.Arguments({pbn.CKDEType(): pbn.Kwargs(bandwidth_selector=sel)})):
+            score = pbn.CVLikelihood(df, k=4, seed=9, construction_args=args)
+            want = 0.0
+            for tr, te in score.cv.indices():
+                cpd = pbn.CKDE("c", ["a", "b"], sel)
+                cpd.fit(df.iloc[tr])
+                want += cpd.slogl(df.iloc[te])
+            got = score.local_score(model, "c", ["a", "b"])
+            assert abs(got - want) <= 1e-9 * abs(want)
+    plain = pbn.CVLikelihood(df, k=4, seed=9).local_score(model, "c", ["a", "b"])
+    scott = pbn.CVLikelihood(df, k=4, seed=9, construction_args=pbn.Arguments({pbn.CKDEType(): (pbn.ScottsBandwidth(),)}))
+    assert abs(scott.local_score(model, "c", ["a", "b"]) - plain) > 1e-3
+    with pytest.raises(ValueError, match="construction arguments"):
+        pbn.CVLikelihood(df, k=4, seed=9, construction_args=pbn.Arguments({"c": (1,)}))
+    hold = pbn.HoldoutLikelihood(df, 0.25, 3, pbn.Arguments({pbn.CKDEType(): (pbn.ScottsBandwidth(),)}))
+    cpd = pbn.CKDE("c", ["a"], pbn.ScottsBandwidth())
+    cpd.fit(hold.training_data())
+    want = cpd.slogl(hold.test_data())
+    assert abs(hold.local_score(model, "c", ["a"]) - want) <= 1e-9 * abs(want)
