@@ -114,6 +114,25 @@ int pbn_kde_logl_dev(pbn_kde* k, const pbn_table* test, const int* cols, int64_t
  * test row, n doubles to HOST `out`.  Only for handles made by pbn_ckde_fit; one fused sweep instead of the
  * reference's W / mu / cdf / product N x m matrices. */
 int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out);
+/* sample: replaces CKDE::_sample / _sample_multivariate / _sample_indices_from_weights (CKDE.hpp:289-508) and the
+ * normalize_accum_sum_mat_cols / find_random_indices kernels (KDE.cl.src:351-374).  Random numbers come from
+ * std::mt19937{seed} through libstdc++'s distributions in the reference's call order; the instance selection (weights
+ * of the evidence KDE, prefix sums, bracket search) runs on the device without the N x n matrix.  evidence: n rows of
+ * the evidence columns (ev_cols in the factor's evidence order), NULL for a factor without evidence.  stream_n >= n:
+ * how many samples the reference call would have been asked for (DiscreteAdaptator hands the whole batch size to every
+ * slice factor, DiscreteAdaptator.hpp:442) - 0 means n.  out: n values of the factor's dtype on the HOST.  The
+ * training table given to pbn_ckde_fit must still be alive. */
+int pbn_ckde_sample(pbn_kde* k, int64_t n, int64_t stream_n, const pbn_table* evidence, const int* ev_cols,
+                    uint32_t seed, void* out);
+/* LinearGaussianCPD::sample (factors/continuous/LinearGaussianCPD.cpp:317-380), host only: n normal draws around
+ * beta[0] plus beta[j+1] * evidence[j][i]; evidence[j] = n HOST values of ev_dtype. */
+int pbn_lg_sample(int64_t n, const double* beta, int p, double variance, uint32_t seed, const void* const* evidence,
+                  int ev_dtype, double* out);
+/* DiscreteFactor::sample_indices (factors/discrete/DiscreteFactor.hpp:144-205), host only: logprob = CPT with the
+ * variable fastest (card values per parent configuration, n_entries in total); parent_offset[i] = first entry of row
+ * i's configuration (NULL without evidence); out: n category indices. */
+int pbn_discrete_sample(int64_t n, const double* logprob, int card, int64_t n_entries, const int32_t* parent_offset,
+                        uint32_t seed, int32_t* out);
 /* slogl: replaces KDE::_slogl / ProductKDE::_slogl / CKDE::_slogl (KDE.hpp:549-562,
  * ProductKDE.hpp:295-308, CKDE.hpp:256-287): sum of logl over the rows, one scalar read-back. */
 int pbn_kde_slogl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out);

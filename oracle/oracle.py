@@ -139,6 +139,45 @@ def ckde_cdf(train, H, test):
     return (num / W.sum(axis=0, dtype=dt)).astype(np.float64)
 
 
+def ckde_sample(train, H, ev, n, seed, stream_n=0):
+    """(values, instance indices) of CKDE::sample; train column 0 = variable; ev: n x p evidence rows (or None)."""
+    f32 = train.dtype == np.float32
+    dt = np.float32 if f32 else np.float64
+    ct = C.c_float if f32 else C.c_double
+    tr = _colmajor(train, dt)
+    N, d = train.shape
+    e = _colmajor(ev, dt) if ev is not None and d > 1 else np.zeros(1, dtype=dt)
+    Hm = np.asfortranarray(np.atleast_2d(H), dtype=np.float64)
+    out = np.zeros(n, dtype=dt)
+    idx = np.zeros(n, dtype=np.int32)
+    fn = lib().oracle_ckde_sample_f32 if f32 else lib().oracle_ckde_sample_f64
+    fn.restype = C.c_int
+    rc = fn(tr.ctypes.data_as(C.POINTER(ct)), C.c_int64(N), C.c_int(d), _dp(Hm), e.ctypes.data_as(C.POINTER(ct)), C.c_int64(n),
+            C.c_int64(max(n, stream_n)), C.c_uint32(seed), out.ctypes.data_as(C.POINTER(ct)), idx.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise ValueError("singular bandwidth")
+    return out, idx
+
+
+def lg_sample(n, beta, variance, seed, ev=None):
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    p = beta.size - 1
+    e = np.asfortranarray(ev, dtype=np.float64) if p else np.zeros(1)
+    out = np.zeros(n)
+    lib().oracle_lg_sample(C.c_int64(n), _dp(beta), C.c_int(p), C.c_double(variance), C.c_uint32(seed), _dp(e), _dp(out))
+    return out
+
+
+def discrete_sample(n, logprob, card, seed, parent_offset=None):
+    lp = np.ascontiguousarray(logprob, dtype=np.float64)
+    out = np.zeros(n, dtype=np.int32)
+    po = None if parent_offset is None else np.ascontiguousarray(parent_offset, dtype=np.int32)
+    lib().oracle_discrete_sample(C.c_int64(n), _dp(lp), C.c_int(card), C.c_int64(lp.size),
+                                 po.ctypes.data_as(C.POINTER(C.c_int32)) if po is not None else None, C.c_uint32(seed),
+                                 out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
 def shuffled_indices(n, seed):
     idx = np.arange(n, dtype=np.int32)
     lib().oracle_shuffle(_dp(idx), C.c_int64(n), C.c_uint32(seed))

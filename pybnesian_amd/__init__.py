@@ -12,7 +12,7 @@ from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, Scotts
 from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, OperatorPool, OperatorTabuSet, RemoveArc, hc)
 from .models import (BayesianNetwork, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
-                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType)
+                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, load)
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
 
@@ -22,5 +22,5 @@ __all__ = [
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
-    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "Callback", "Context", "DeviceTable", "default_context", "load_library",
+    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "Callback", "load", "Context", "DeviceTable", "default_context", "load_library",
 ]

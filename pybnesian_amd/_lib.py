@@ -58,6 +58,9 @@ SIGNATURES = {
     "pbn_kde_logl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_logl_dev": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
     "pbn_ckde_cdf": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
+    "pbn_ckde_sample": (_int, [_vp, _i64, _i64, _vp, _ip, C.c_uint32, _vp]),
+    "pbn_lg_sample": (_int, [_i64, _dp, _int, C.c_double, C.c_uint32, C.POINTER(_vp), _int, _dp]),
+    "pbn_discrete_sample": (_int, [_i64, _dp, _int, _i64, _ip, C.c_uint32, _ip]),
     "pbn_kde_slogl": (_int, [_vp, _vp, _ip, _i64, _i64, _dp]),
     "pbn_kde_slogl_async": (_int, [_vp, _vp, _ip, _i64, _i64, _vp]),
     "pbn_scoredata_create": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, C.POINTER(_vp)]),

@@ -11,6 +11,7 @@
 #include "hostmath.hpp"
 #include "kde_kernels.hpp"
 #include "kde_model.hpp"
+#include "kde_handle.hpp"
 #include "stats_kernels.hpp"
 
 namespace pbn {
@@ -19,27 +20,6 @@ void set_last_error(const std::string& s) { g_last_error = s; }
 }  // namespace pbn
 
 using namespace pbn;
-
-struct pbn_kde {
-    pbn_ctx* ctx = nullptr;
-    KdeModel m;
-    dev_buf<char> Apack, nxpack, Axpack;
-    // CKDE::cdf state (pbn_ckde_fit only): classic fragments of the evidence dimensions + u = (x - b.e)/(sigma_c sqrt 2)
-    bool ckde = false;
-    int cdf_KS = 0;
-    std::vector<int> cols_fit;
-    double wu[PBN_MAX_D_HOST];
-    dev_buf<char> cA, cN, cU;
-};
-
-// PackArgs for the cdf fragments: whitening order (evidence first, variable last), contraction over the evidence only.
-static void fill_cdf_pack(PackArgs& pa, const pbn_kde& k, const pbn_table* t, const int* cols) {
-    const KdeModel& m = k.m;
-    pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.d - 1; pa.KS = k.cdf_KS;
-    for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
-    for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];
-    for (int i = 0; i < m.d; ++i) { pa.mu[i] = m.mu[i]; pa.wu[i] = k.wu[i]; }
-}
 
 extern "C" {
 
@@ -324,6 +304,9 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         // whitening row IS (x - H12 H22^-1 e) / sigma_c (CKDE.hpp:538-555 "transform" and "cond_var").
         const KdeModel& m = k->m;
         k->ckde = true;
+        k->cols_fit.assign(cols, cols + d);
+        k->train = train;
+        k->train_row0 = row0;
         k->cdf_KS = std::max(1, (m.d - 1 + 3) / 4);
         const double sc = std::sqrt(2.0 * 1.4426950408889634073599246810019);
         for (int j = 0; j < m.d; ++j) k->wu[j] = m.W[(size_t)(m.d - 1) * m.d + j] / sc;

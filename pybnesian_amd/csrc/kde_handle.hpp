@@ -1,0 +1,32 @@
+// The public fitted-KDE handle (opaque `pbn_kde` of include/pbn_hip.h), shared by capi.hip and sampling.hip.
+#pragma once
+#include "kde_kernels.hpp"
+#include "kde_model.hpp"
+
+using pbn::KdeModel;
+using pbn::PackArgs;
+using pbn::dev_buf;
+
+struct pbn_kde {
+    pbn_ctx* ctx = nullptr;
+    KdeModel m;
+    dev_buf<char> Apack, nxpack, Axpack;
+    // CKDE::cdf state (pbn_ckde_fit only): classic fragments of the evidence dimensions + u = (x - b.e)/(sigma_c sqrt 2)
+    bool ckde = false;
+    int cdf_KS = 0;
+    std::vector<int> cols_fit;          // caller's column order (variable first)
+    const pbn_table* train = nullptr;   // borrowed: CKDE::sample reads the sampled training rows from it
+    int64_t train_row0 = 0;
+    double wu[PBN_MAX_D_HOST];
+    dev_buf<char> cA, cN, cU;
+};
+
+// PackArgs for the cdf fragments: whitening order (evidence first, variable last), contraction over the evidence only.
+inline void fill_cdf_pack(PackArgs& pa, const pbn_kde& k, const pbn_table* t, const int* cols) {
+    const KdeModel& m = k.m;
+    pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.d - 1; pa.KS = k.cdf_KS;
+    for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
+    for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];
+    for (int i = 0; i < m.d; ++i) { pa.mu[i] = m.mu[i]; pa.wu[i] = k.wu[i]; }
+}
+

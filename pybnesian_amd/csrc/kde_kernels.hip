@@ -747,7 +747,7 @@ __device__ __forceinline__ double half_erfc<double>(double x) { return 0.5 * erf
 template <>
 __device__ __forceinline__ float half_erfc<float>(float x) { return 0.5f * erfcf(x); }
 
-template <typename T, int KS, int QG>
+template <typename T, int KS, int QG, bool CDF>
 __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bp[(qt * KS + ks) * 64 + lane];
         ny[g] = NYp[qt * 16 + (lane & 15)];
-        uq[g] = UQp[qt * 16 + (lane & 15)];
+        uq[g] = CDF ? UQp[qt * 16 + (lane & 15)] : (T)0;
         sw[g] = 0.0; sc[g] = 0.0;
     }
     {   // offsets from the first tile
@@ -792,7 +792,8 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t * KS + ks) * 64 + lane];
         const V nx = *(const V*)(Np + t * 16 + lg * 4);
-        const V ut = *(const V*)(Up + t * 16 + lg * 4);
+        V ut = {0, 0, 0, 0};
+        if (CDF) ut = *(const V*)(Up + t * 16 + lg * 4);
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             V acc = nx + cm[g];
@@ -813,10 +814,12 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
                 ts = (w0 + w1) + (w2 + w3);
             }
             // Phi((x_q - mu_t)/sigma_c) = 1/2 erfc((u_t - u_q)), u pre-divided by sqrt 2 (KDE.cl.src:448-456)
-            const T c = (w0 * half_erfc<T>(ut[0] - uq[g]) + w1 * half_erfc<T>(ut[1] - uq[g])) +
-                        (w2 * half_erfc<T>(ut[2] - uq[g]) + w3 * half_erfc<T>(ut[3] - uq[g]));
             sw[g] += (double)ts;
-            sc[g] += (double)c;
+            if (CDF) {
+                const T c = (w0 * half_erfc<T>(ut[0] - uq[g]) + w1 * half_erfc<T>(ut[1] - uq[g])) +
+                            (w2 * half_erfc<T>(ut[2] - uq[g]) + w3 * half_erfc<T>(ut[3] - uq[g]));
+                sc[g] += (double)c;
+            }
         }
     }
 #pragma unroll
@@ -922,22 +925,25 @@ void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
-template <typename T>
+template <typename T, bool CDF>
 static void launch_cdf_t(const CdfArgs& a, int KS, dim3 grid, hipStream_t st) {
     dim3 block(256);
     switch (KS) {
-        case 1: hipLaunchKernelGGL((kde_cdf_kernel<T, 1, 2>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((kde_cdf_kernel<T, 2, 2>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((kde_cdf_kernel<T, 3, 2>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((kde_cdf_kernel<T, 4, 2>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((kde_cdf_kernel<T, 1, 2, CDF>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_cdf_kernel<T, 2, 2, CDF>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_cdf_kernel<T, 3, 2, CDF>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_cdf_kernel<T, 4, 2, CDF>), grid, block, 0, st, a); break;
         default: throw invalid_error("CKDE::cdf: more than 16 evidence variables are not supported");
     }
     HIP_CHECK(hipGetLastError());
 }
 
+// utrain == nullptr: weights only (sum w per split; used by CKDE::sample to locate the sampled instance).
 void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * 2), (unsigned)nsplit);
-    if (dtype == PBN_F64) launch_cdf_t<double>(a, KS, grid, st); else launch_cdf_t<float>(a, KS, grid, st);
+    const bool cdf = a.utrain != nullptr;
+    if (dtype == PBN_F64) { if (cdf) launch_cdf_t<double, true>(a, KS, grid, st); else launch_cdf_t<double, false>(a, KS, grid, st); }
+    else                  { if (cdf) launch_cdf_t<float, true>(a, KS, grid, st); else launch_cdf_t<float, false>(a, KS, grid, st); }
 }
 
 void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t nq, double* dev_out, hipStream_t st) {

@@ -36,6 +36,25 @@ class Factor:
             raise ValueError(f"{name} factor not fitted.")
 
 
+def _random_seed():
+    import random
+
+    return random.SystemRandom().randrange(0, 2 ** 32)  # std::random_device{}()
+
+
+def _check_sample_args(n, evidence, evidence_values):
+    if n < 0:
+        raise ValueError("n should be a non-negative number")
+    if not evidence:
+        return None
+    if evidence_values is None:
+        raise ValueError("Evidence values not present for sampling.")
+    rb = as_record_batch(evidence_values)
+    if any(rb.schema.get_field_index(e) < 0 for e in evidence):
+        raise ValueError("Evidence values not present for sampling.")
+    return rb
+
+
 class CKDE(Factor):
     """Conditional KDE: logl = logl_joint([variable] + evidence) - logl_marg(evidence)."""
 
@@ -186,6 +205,28 @@ class CKDE(Factor):
         out[mask] = vals
         return out
 
+    def sample(self, n, evidence_values=None, seed=None, _stream_n=0):
+        """CKDE.sample(n, evidence_values, seed) (factors/continuous/CKDE.hpp:289-385): pyarrow array of the factor's
+        data type.  Instance selection on the device, random numbers as the reference draws them (pbn_ckde_sample)."""
+        self._check_fitted("CKDE")
+        rb = _check_sample_args(n, self._evidence, evidence_values)
+        seed = _random_seed() if seed is None else int(seed)
+        npdt = np.float64 if self._dtype == _lib.PBN_F64 else np.float32
+        out = np.empty(n, dtype=npdt)
+        table, cols = None, None
+        if rb is not None:
+            if rb.num_rows < n:
+                raise ValueError(f"Evidence values do not have {n} rows to sample.")
+            if same_type(rb, self._evidence) != self._dtype:
+                raise ValueError("Data type of training and test datasets is different.")
+            table, mask = DeviceTable.from_dataframe(self._train.ctx, rb, self._evidence)
+            if mask is not None:
+                raise ValueError("Evidence values contain null rows in the evidence variables.")
+            cols = _lib.int_array(range(len(self._evidence)))
+        _lib.check(_lib.load().pbn_ckde_sample(self._handle, n, int(_stream_n), table.handle if table is not None else None, cols,
+                                               C.c_uint32(seed), out.ctypes.data_as(C.c_void_p)))
+        return pa.array(out)
+
     def slogl(self, df):
         _, table, _ = self._upload_test(df)
         res = C.c_double(0.0)
@@ -280,6 +321,29 @@ class LinearGaussianCPD(Factor):
     def slogl(self, df):
         return self._eval(df, False)[3]
 
+    def data_type(self):
+        return pa.float64()  # LinearGaussianCPD.hpp: always double
+
+    def sample(self, n, evidence_values=None, seed=None, _stream_n=0):
+        """LinearGaussianCPD.sample (LinearGaussianCPD.cpp:317-380): float64 pyarrow array (pbn_lg_sample)."""
+        self._check_fitted("LinearGaussianCPD")
+        rb = _check_sample_args(n, self._evidence, evidence_values)
+        seed = _random_seed() if seed is None else int(seed)
+        out = np.empty(n)
+        keep, ptrs, ev_dtype = [], None, _lib.PBN_F64
+        if rb is not None:
+            if rb.num_rows < n:
+                raise ValueError(f"Evidence values do not have {n} rows to sample.")
+            ev_dtype = same_type(rb, self._evidence)
+            npdt = np.float64 if ev_dtype == _lib.PBN_F64 else np.float32
+            for e in self._evidence:
+                col = rb.column(rb.schema.get_field_index(e))
+                keep.append(np.ascontiguousarray(col.to_numpy(zero_copy_only=False), dtype=npdt))
+            ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        _lib.check(_lib.load().pbn_lg_sample(n, _lib.dptr(np.ascontiguousarray(self.beta, dtype=np.float64)), len(self._evidence),
+                                             float(self.variance), C.c_uint32(seed), ptrs, ev_dtype, _lib.dptr(out)))
+        return pa.array(out)
+
     def __str__(self):
         return f"[LinearGaussianCPD] P({self._variable} | {', '.join(self._evidence)})"
 
@@ -373,6 +437,38 @@ class DiscreteFactor(Factor):
 
     def slogl(self, df):
         return float(np.nansum(self.logl(df)))
+
+    def data_type(self):
+        self._check_fitted("DiscreteFactor")
+        return pa.dictionary(pa.int8(), pa.string())
+
+    def sample(self, n, evidence_values=None, seed=None, _stream_n=0):
+        """DiscreteFactor.sample (DiscreteFactor.cpp:173-208, .hpp:144-205): dictionary array (pbn_discrete_sample)."""
+        self._check_fitted("DiscreteFactor")
+        rb = _check_sample_args(n, self._evidence, evidence_values)
+        seed = _random_seed() if seed is None else int(seed)
+        card = self._cards[0]
+        offs = None
+        if rb is not None:
+            if rb.num_rows != n:
+                raise ValueError(f"Evidence values do not have {n} rows to sample.")
+            off = np.zeros(n, dtype=np.int64)
+            stride = card
+            for e, cats in zip(self._evidence, self._categories[1:]):
+                c = _dictionary_column(rb, e)
+                if c.null_count:
+                    raise ValueError("Evidence values contain null rows in the evidence variables.")
+                if c.dictionary.to_pylist() != cats:
+                    raise ValueError(f"Variable {e} does not contain the same categories.")
+                off += c.indices.to_numpy(zero_copy_only=False).astype(np.int64) * stride
+                stride *= len(cats)
+            offs = np.ascontiguousarray(off, dtype=np.int32)
+        out = np.zeros(n, dtype=np.int32)
+        lp = np.ascontiguousarray(self._logprob, dtype=np.float64)
+        _lib.check(_lib.load().pbn_discrete_sample(n, _lib.dptr(lp), card, lp.size,
+                                                   offs.ctypes.data_as(C.POINTER(C.c_int)) if offs is not None else None,
+                                                   C.c_uint32(seed), out.ctypes.data_as(C.POINTER(C.c_int))))
+        return pa.DictionaryArray.from_arrays(pa.array(out.astype(np.int8) if card <= 127 else out), pa.array(self._categories[0]))
 
 
 class _DiscreteAdaptator(Factor):
@@ -475,6 +571,31 @@ class _DiscreteAdaptator(Factor):
             if rows.size and f is not None:
                 total += f.slogl(rb.take(pa.array(rows.astype(np.int32))))
         return total
+
+
+    def sample(self, n, evidence_values=None, seed=None, _stream_n=0):
+        """DiscreteAdaptator::sample (DiscreteAdaptator.hpp:427-520): slice i is sampled by its factor with seed + i;
+        every slice factor is asked for the whole batch size, so its random stream is the one of an n-sample call."""
+        self._check_fitted(self._name)
+        rb = _check_sample_args(n, self._evidence, evidence_values)
+        seed = _random_seed() if seed is None else int(seed)
+        if not self._disc:
+            return self._factors[0].sample(n, rb, seed)
+        if rb.num_rows != n:
+            raise ValueError(f"Evidence values do not have {n} rows to sample.")
+        idx, valid = self._config(rb)
+        if not valid.all():
+            raise ValueError("Evidence values contain null rows in the evidence variables.")
+        first = next((f for f in self._factors if f is not None), None)
+        npdt = np.float32 if (first is not None and first.data_type() == pa.float32()) else np.float64
+        out = np.full(n, np.nan, dtype=npdt)
+        for c, f in enumerate(self._factors):
+            rows = np.nonzero(idx == c)[0]
+            if rows.size == 0 or f is None:
+                continue
+            sub = rb.take(pa.array(rows.astype(np.int32)))
+            out[rows] = f.sample(int(rows.size), sub, (seed + c) & 0xFFFFFFFF, _stream_n=n).to_numpy(zero_copy_only=False)
+        return pa.array(out)
 
 
 class CLinearGaussianCPD(_DiscreteAdaptator):

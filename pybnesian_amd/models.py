@@ -253,6 +253,113 @@ class BayesianNetwork:
             raise ValueError("Model not fitted.")
         return float(sum(self._cpds[n].slogl(df) for n in self._nodes))
 
+    # -- graph queries of models/BayesianNetwork.hpp / graph/generic_graph.hpp the callers of the hot path use -------
+    def num_children(self, node):
+        return len(self._children[node])
+
+    def roots(self):
+        return {n for n in self._nodes if not self._parents[n]}
+
+    def leaves(self):
+        return {n for n in self._nodes if not self._children[n]}
+
+    def indices(self):
+        return dict(self._index)
+
+    collapsed_indices = indices
+
+    def collapsed_index(self, node):
+        return self._index[node]
+
+    def collapsed_name(self, idx):
+        return self._nodes[idx]
+
+    def is_valid(self, idx):
+        return 0 <= idx < len(self._nodes)
+
+    def topological_sort(self):
+        """DagImpl::topological_sort (graph/generic_graph.hpp:2659-2710): stack-driven Kahn order.  The reference
+        walks libstdc++ unordered_sets (roots, children), whose iteration order depends on the graph's edit history;
+        here roots and children are visited in node-index order, so the result is a valid, deterministic order that
+        need not be the reference's."""
+        incoming = {n: len(self._parents[n]) for n in self._nodes}
+        stack = [n for n in self._nodes if incoming[n] == 0]
+        order = []
+        while stack:
+            u = stack.pop()
+            order.append(u)
+            for c in sorted(self._children[u], key=self._index.__getitem__):
+                incoming[c] -= 1
+                if incoming[c] == 0:
+                    stack.append(c)
+        if len(order) != len(self._nodes):
+            raise ValueError("Graph must be a DAG to obtain a topological sort.")
+        return order
+
+    def add_cpds(self, cpds):
+        """BayesianNetwork::add_cpds (BayesianNetwork.hpp:845-905): fitted factors whose evidence equals the parents."""
+        for f in cpds:
+            v = f.variable()
+            if v not in self._index:
+                raise ValueError(f"CPD defined on variable which is not present in the model:\n{f}")
+            if sorted(f.evidence()) != sorted(self._parents[v]):
+                raise ValueError(f"CPD do not have the model's parent set as evidence:\n{f}")
+        if getattr(self, "_cpds", None) is None:
+            self._cpds = {}
+        for f in cpds:
+            self._cpds[f.variable()] = f
+
+    def sample(self, n, seed=None, ordered=False):
+        """BNGeneric::sample (BayesianNetwork.hpp:1023-1062): ancestral sampling in topological order, node i of that
+        order with seed + i; returns a pyarrow.RecordBatch (columns in topological order, or in nodes() order when
+        `ordered`)."""
+        import pyarrow as pa
+
+        if n < 0:
+            raise ValueError("n should be a non-negative number")
+        if not self.fitted():
+            raise ValueError("Model not fitted.")
+        from .factors import _random_seed
+
+        seed = _random_seed() if seed is None else int(seed)
+        names, arrays = [], []
+        for i, node in enumerate(self.topological_sort()):
+            parents = pa.RecordBatch.from_arrays(arrays, names=names) if arrays else None
+            arrays.append(self._cpds[node].sample(n, parents, (seed + i) & 0xFFFFFFFF))
+            names.append(node)
+        if ordered:
+            pos = {nm: i for i, nm in enumerate(names)}
+            arrays, names = [arrays[pos[nm]] for nm in self._nodes], list(self._nodes)
+        return pa.RecordBatch.from_arrays(arrays, names=names)
+
+    def save(self, name, include_cpd=False):
+        """BayesianNetwork::save (BayesianNetwork.hpp:643, util/pickle.hpp): pickle to `name`.pickle."""
+        import pickle
+
+        self._include_cpd = bool(include_cpd)
+        with open(name if name.endswith(".pickle") else name + ".pickle", "wb") as f:
+            pickle.dump(self, f, protocol=2)
+
+    def __getstate__(self):
+        state = {"type": self._type, "nodes": self._nodes, "arcs": self.arcs(), "types": list(self._types.items())}
+        if getattr(self, "_include_cpd", False) and self.fitted():
+            state["cpds"] = [self._cpds[n] for n in self._nodes]
+        return state
+
+    def __setstate__(self, state):
+        self.__init__(state["type"], state["nodes"], state["arcs"], state["types"])
+        if "cpds" in state:
+            self._cpds = {f.variable(): f for f in state["cpds"]}
+            self._include_cpd = True
+
+    @property
+    def include_cpd(self):
+        return getattr(self, "_include_cpd", False)
+
+    @include_cpd.setter
+    def include_cpd(self, value):
+        self._include_cpd = bool(value)
+
     def __str__(self):
         return f"{self._type} with {self.num_nodes()} nodes and {self.num_arcs()} arcs"
 
@@ -273,3 +380,11 @@ def SemiparametricBN(nodes, arcs=(), node_types=()):
 
 def CLGNetwork(nodes, arcs=(), node_types=()):
     return BayesianNetwork(CLGNetworkType(), nodes, arcs, node_types)
+
+
+def load(name):
+    """pybnesian.load (pybindings/lib.cpp, util/pickle.hpp): un-pickle a saved model / factor."""
+    import pickle
+
+    with open(name, "rb") as f:
+        return pickle.load(f)

@@ -1,0 +1,144 @@
+"""GPU tier: CKDE.sample (factors/continuous/CKDE.hpp:289-508).  The reference's own test only checks type and length
+(CKDE_test.py:499-560); here the device instance selection is compared with the oracle's full-matrix restatement
+(same libstdc++ random streams), plus distributional checks, hybrid factors and BayesianNetwork.sample."""
+import numpy as np
+import pandas as pd
+import pyarrow as pa
+import pytest
+
+from helpers import frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def test_ckde_sample_reference_cases(pbn, golden):
+    """CKDE_test.py:499-560: types and lengths for float64 / float32, 0-2 evidence variables."""
+    n = 1000
+    for dtype, pat in (("float64", pa.float64()), ("float32", pa.float32())):
+        df = frame(golden["train10k"], dtype)
+        for variable, evidence, values in (("a", [], None), ("b", ["a"], {"a": 3.0}), ("c", ["a", "b"], {"a": 3.0, "b": 7.45})):
+            cpd = pbn.CKDE(variable, evidence)
+            cpd.fit(df)
+            ev = None if values is None else pd.DataFrame({k: np.full(n, v, dtype=dtype) for k, v in values.items()})
+            s = cpd.sample(n, ev, 0)
+            assert s.type == pat and len(s) == n and np.all(np.isfinite(s.to_numpy()))
+            assert np.array_equal(s.to_numpy(), cpd.sample(n, ev, 0).to_numpy())       # same seed, same sample
+            assert not np.array_equal(s.to_numpy(), cpd.sample(n, ev, 1).to_numpy())
+
+
+@pytest.mark.parametrize("p", [0, 1, 2, 5])
+def test_ckde_sample_matches_oracle_f64(pbn, oracle, p):
+    rng = np.random.default_rng(30 + p)
+    N, n = 1500, 700
+    ev = rng.normal(size=(N + n, p)) @ (np.eye(p) + np.tril(rng.uniform(-0.4, 0.4, (p, p)), -1)).T
+    y = 0.6 * ev.sum(axis=1) + rng.normal(scale=0.5, size=N + n) + (np.cos(ev[:, 0]) if p else 0.0)
+    names = ["y"] + [f"e{i}" for i in range(p)]
+    train = pd.DataFrame(np.column_stack([y, ev])[:N], columns=names)
+    cpd = pbn.CKDE("y", names[1:])
+    cpd.fit(train)
+    evq = pd.DataFrame(ev[N:], columns=names[1:]) if p else None
+    if p:
+        evq.iloc[:4] = 6.0          # far evidence: a handful of training rows carry all the weight
+    for seed in (0, 123):
+        got = cpd.sample(n, evq, seed).to_numpy()
+        want, idx = oracle.ckde_sample(train.to_numpy(), cpd.bandwidth, evq.to_numpy() if p else None, n, seed)
+        assert np.allclose(got, want, rtol=1e-10, atol=1e-12)
+    # fewer rows requested than evidence rows: the first n are used
+    if p:
+        assert np.allclose(cpd.sample(10, evq, 5).to_numpy(), oracle.ckde_sample(train.to_numpy(), cpd.bandwidth, evq.to_numpy()[:10], 10, 5)[0])
+
+
+def test_ckde_sample_f32_and_large_training_set(pbn, oracle):
+    """float32: the oracle's float prefix sums and the device's double ones may pick neighbouring instances for a few
+    samples; the rest must agree to float rounding.  Also > 64 training tiles per split boundary (N = 40k)."""
+    rng = np.random.default_rng(77)
+    N, n = 3000, 400
+    e = rng.normal(size=N + n)
+    y = np.sin(2 * e) + rng.normal(scale=0.3, size=N + n)
+    data = np.column_stack([y, e]).astype(np.float32)
+    cpd = pbn.CKDE("y", ["e"])
+    cpd.fit(pd.DataFrame(data[:N], columns=["y", "e"]))
+    evq = pd.DataFrame(data[N:, 1:], columns=["e"])
+    got = cpd.sample(n, evq, 9)
+    assert got.type == pa.float32()
+    want, _ = oracle.ckde_sample(data[:N], cpd.bandwidth, data[N:, 1:], n, 9)
+    same = np.isclose(got.to_numpy(), want, rtol=1e-4, atol=1e-5)
+    assert same.mean() > 0.9
+    # large N: several splits of 64 tiles, double precision, exact agreement expected
+    N2 = 40000
+    e2 = rng.normal(size=N2)
+    y2 = np.sin(2 * e2) + rng.normal(scale=0.3, size=N2)
+    tr = pd.DataFrame({"y": y2, "e": e2})
+    cpd2 = pbn.CKDE("y", ["e"])
+    cpd2.fit(tr)
+    q = pd.DataFrame({"e": rng.normal(size=64)})
+    got2 = cpd2.sample(64, q, 3).to_numpy()
+    want2, _ = oracle.ckde_sample(tr.to_numpy(), cpd2.bandwidth, q.to_numpy(), 64, 3)
+    assert np.allclose(got2, want2, rtol=1e-9, atol=1e-11)
+
+
+def test_ckde_sample_distribution(pbn):
+    """At fixed evidence the samples follow the conditional mixture: mean = sum_t w_t mu_t / sum_t w_t and the
+    empirical cdf matches CKDE.cdf (Kolmogorov distance)."""
+    rng = np.random.default_rng(3)
+    N, n = 4000, 20000
+    e = rng.normal(size=N)
+    y = 1.5 * e + rng.normal(scale=0.7, size=N)
+    cpd = pbn.CKDE("y", ["e"])
+    cpd.fit(pd.DataFrame({"y": y, "e": e}))
+    s = cpd.sample(n, pd.DataFrame({"e": np.full(n, 0.8)}), 17).to_numpy()
+    H = cpd.bandwidth
+    w = np.exp(-0.5 * (0.8 - e) ** 2 / H[1, 1])
+    mu = y + H[0, 1] / H[1, 1] * (0.8 - e)
+    assert abs(s.mean() - (w @ mu) / w.sum()) < 0.03
+    grid = np.quantile(s, [0.1, 0.3, 0.5, 0.7, 0.9])
+    model_cdf = cpd.cdf(pd.DataFrame({"y": grid, "e": np.full(5, 0.8)}))
+    assert np.all(np.abs(model_cdf - [0.1, 0.3, 0.5, 0.7, 0.9]) < 0.02)
+    with pytest.raises(ValueError, match="Evidence values not present"):
+        cpd.sample(5, None, 0)
+    with pytest.raises(ValueError, match="do not have"):
+        cpd.sample(50, pd.DataFrame({"e": np.zeros(5)}), 0)
+
+
+def test_hybrid_and_network_sample(pbn):
+    rng = np.random.default_rng(8)
+    n = 4000
+    d = rng.choice(["lo", "hi"], size=n)
+    a = rng.normal(size=n) + np.where(d == "hi", 3.0, 0.0)
+    b = np.where(d == "hi", -1.0, 1.0) * a + rng.normal(scale=0.4, size=n)
+    df = pd.DataFrame({"d": pd.Categorical(d, categories=["lo", "hi"]), "a": a, "b": b})
+    model = pbn.CLGNetwork(["d", "a", "b"], [("d", "a"), ("d", "b"), ("a", "b")])
+    model.fit(df)
+    s = model.sample(6000, 21, ordered=True)
+    assert s.schema.names == ["d", "a", "b"] and pa.types.is_dictionary(s.column(0).type)
+    sd = np.asarray(s.column(0).to_pylist())
+    sa, sb = s.column(1).to_numpy(), s.column(2).to_numpy()
+    assert abs((sd == "hi").mean() - (d == "hi").mean()) < 0.03
+    assert abs(sa[sd == "hi"].mean() - a[d == "hi"].mean()) < 0.08
+    slope_hi = np.polyfit(sa[sd == "hi"], sb[sd == "hi"], 1)[0]
+    slope_lo = np.polyfit(sa[sd == "lo"], sb[sd == "lo"], 1)[0]
+    assert abs(slope_hi + 1.0) < 0.05 and abs(slope_lo - 1.0) < 0.05
+    # semiparametric network with a CKDE node conditioned on a discrete parent (HCKDE)
+    sp = pbn.SemiparametricBN(["d", "a", "b"], [("d", "a"), ("d", "b"), ("a", "b")], [("b", pbn.CKDEType())])
+    sp.fit(df.iloc[:1500])
+    s2 = sp.sample(3000, 5, ordered=True)
+    sd2 = np.asarray(s2.column(0).to_pylist())
+    sa2, sb2 = s2.column(1).to_numpy(), s2.column(2).to_numpy()
+    assert np.all(np.isfinite(sb2))
+    assert abs(np.polyfit(sa2[sd2 == "hi"], sb2[sd2 == "hi"], 1)[0] + 1.0) < 0.15
+    assert np.array_equal(sp.sample(3000, 5, ordered=True).column(2).to_numpy(), sb2)
