@@ -264,6 +264,27 @@ int pbn_hc_update_scores(pbn_hc* h, int n, const int* nodes);
 /* local: n cached local scores; delta_arcs: n*n col-major (row = source, column = target); delta_types: n. Nullable. */
 int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types);
 
+/* ---- restriction phase of MMHC ---------------------------------------------------------
+ * Conditional-independence test callback: p-value of v1 _||_ v2 | cond (indices into the test's variables);
+ * IndependenceTest::pvalue (learning/independences/independence.hpp:17-40).  NaN aborts the search. */
+typedef double (*pbn_ci_pvalue_fn)(void* user, int v1, int v2, int n_cond, const int* cond);
+/* LinearCorrelation (learning/independences/continuous/linearcorrelation.hpp:62-88, .cpp:9-100): covariance of all
+ * columns of `table` taken once on the device (Gram kernel), partial correlations from the eigen-decomposition of the
+ * (k+2)-variable block, two-sided Student-t p-value.  pbn_lincor_pvalue has the pbn_ci_pvalue_fn signature with
+ * user = the handle. */
+typedef struct pbn_lincor pbn_lincor;
+int pbn_lincor_create(pbn_ctx* ctx, const pbn_table* table, pbn_lincor** out);
+int pbn_lincor_from_cov(int n, int64_t rows, const double* cov /* n*n col-major */, pbn_lincor** out); /* host only */
+void pbn_lincor_destroy(pbn_lincor* h);
+int pbn_lincor_cov(const pbn_lincor* h, double* cov /* n*n */);
+double pbn_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
+/* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
+ * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies
+ * remove_asymmetries (learning/algorithms/mmhc.cpp:12-22).  cpc_off: n+1 offsets into cpc (capacity n*(n-1)). */
+int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist, const int* arc_whitelist,
+                  int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist, const int* edge_whitelist,
+                  int symmetric, int* cpc_off, int* cpc, int64_t* n_tests);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,12 @@ SIGNATURES = {
     "pbn_lg_fit_table": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
     "pbn_lg_logl": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp, _dp]),
     "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
+    "pbn_lincor_create": (_int, [_vp, _vp, C.POINTER(_vp)]),
+    "pbn_lincor_from_cov": (_int, [_int, _i64, _dp, C.POINTER(_vp)]),
+    "pbn_lincor_destroy": (None, [_vp]),
+    "pbn_lincor_cov": (_int, [_vp, _dp]),
+    "pbn_lincor_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
+    "pbn_mmpc_cpcs": (_int, [_int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_hc_estimate": (_int, [_vp, _vp, _vp, _ip, _ip, _ip, _vp]),
     "pbn_hc_create": (_int, [_vp, _vp, _vp, C.POINTER(_vp)]),
     "pbn_hc_destroy": (None, [_vp]),
@@ -86,6 +92,7 @@ SIGNATURES = {
 }
 
 HC_SCORE_FN = C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)
+CI_PVALUE_FN = C.CFUNCTYPE(C.c_double, _vp, _int, _int, _int, _ip)
 HC_ITER_FN = C.CFUNCTYPE(_int, _vp, _int, _ip, C.c_double, _int, _ip, _ip)
 
 

@@ -1,0 +1,182 @@
+"""Conditional-independence tests and the MMPC restriction phase.
+
+`IndependenceTest` is the reference's abstract test (learning/independences/independence.hpp:17-77), subclassable
+from Python; `LinearCorrelation` (learning/independences/continuous/linearcorrelation.hpp) keeps the covariance of all
+continuous columns, taken once on the device, and answers every p-value from it on the host.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .dataset import DeviceTable, as_record_batch, default_context
+
+
+class IndependenceTest:
+    """Subclass and implement pvalue(x, y, z=None), num_variables(), variable_names(), name(i), has_variables(v)."""
+
+    def pvalue(self, x, y, z=None):
+        raise NotImplementedError("Tried to call pure virtual function \"IndependenceTest::pvalue\"")
+
+    def variable_names(self):
+        raise NotImplementedError("Tried to call pure virtual function \"IndependenceTest::variable_names\"")
+
+    def num_variables(self):
+        return len(self.variable_names())
+
+    def name(self, index):
+        return self.variable_names()[index]
+
+    def has_variables(self, variables):
+        names = set(self.variable_names())
+        variables = [variables] if isinstance(variables, str) else variables
+        return all(v in names for v in variables)
+
+    # -- engine hook: (callback, user pointer, keep-alive) for pbn_mmpc_cpcs over the node order `nodes` ------------------
+    def _ci_callback(self, nodes):
+        errors = []
+
+        def fn(_user, v1, v2, n_cond, cond):
+            try:
+                z = [nodes[cond[i]] for i in range(n_cond)]
+                if not z:
+                    return float(self.pvalue(nodes[v1], nodes[v2]))
+                return float(self.pvalue(nodes[v1], nodes[v2], z[0] if len(z) == 1 else z))
+            except Exception as ex:  # surfaced by the caller after the C call returns
+                errors.append(ex)
+                return float("nan")
+
+        cb = _lib.CI_PVALUE_FN(fn)
+        return cb, None, (cb, errors), errors
+
+
+class LinearCorrelation(IndependenceTest):
+    """pbn.LinearCorrelation(df): partial-correlation t-test on the continuous columns."""
+
+    def __init__(self, df, ctx=None):
+        import pyarrow as pa
+
+        rb = as_record_batch(df)
+        cont = [f.name for f in rb.schema if pa.types.is_floating(f.type)]
+        if len(cont) < 2:
+            raise ValueError("DataFrame does not contain enough continuous columns.")
+        if any(rb.column(rb.schema.get_field_index(c)).null_count for c in cont):
+            raise ValueError("LinearCorrelation on the device needs columns without nulls.")
+        self._all_names = [f.name for f in rb.schema]
+        self._names = cont
+        self._index = {n: i for i, n in enumerate(cont)}
+        ctx = ctx or default_context()
+        table, _ = DeviceTable.from_dataframe(ctx, rb, cont, drop_null=False)
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_lincor_create(ctx.handle, table.handle, C.byref(h)))
+        self._handle = h
+
+    @classmethod
+    def from_covariance(cls, names, cov, num_rows):
+        """A test over a covariance matrix already at hand (host only, no device work)."""
+        self = cls.__new__(cls)
+        self._all_names = self._names = list(names)
+        self._index = {n: i for i, n in enumerate(self._names)}
+        cov = np.asfortranarray(cov, dtype=np.float64)
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_lincor_from_cov(len(self._names), int(num_rows), _lib.dptr(cov), C.byref(h)))
+        self._handle = h
+        return self
+
+    def _idx(self, name):
+        if name not in self._index:
+            raise ValueError(f"Continuous variable {name} not present in LinearCorrelation.")
+        return self._index[name]
+
+    def pvalue(self, x, y, z=None):
+        cond = [] if z is None else ([z] if isinstance(z, str) else list(z))
+        arr = _lib.int_array([self._idx(c) for c in cond] or [0])
+        p = _lib.load().pbn_lincor_pvalue(self._handle, self._idx(x), self._idx(y), len(cond), arr)
+        if np.isnan(p):
+            raise ValueError("LinearCorrelation: bad variable index")
+        return p
+
+    def covariance(self):
+        n = len(self._names)
+        cov = np.zeros((n, n), order="F")
+        _lib.check(_lib.load().pbn_lincor_cov(self._handle, _lib.dptr(cov)))
+        return cov
+
+    def variable_names(self):
+        return list(self._all_names)
+
+    def _ci_callback(self, nodes):
+        # native fast path: the C function itself is the callback, no Python frame per test
+        if all(n in self._index for n in nodes) and [self._index[n] for n in nodes] == list(range(len(nodes))) and len(nodes) == len(self._names):
+            lib = _lib.load()
+            return C.cast(lib.pbn_lincor_pvalue, C.c_void_p), self._handle, self, []
+        return super()._ci_callback(nodes)
+
+    def __del__(self):
+        try:
+            if _lib.alive() and getattr(self, "_handle", None):
+                _lib.load().pbn_lincor_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def validate_restrictions(nodes, arc_blacklist=(), arc_whitelist=(), edge_blacklist=(), edge_whitelist=()):
+    """util::validate_restrictions (util/validate_whitelists.hpp:72-146) over node indices: returns
+    (arc_blacklist, arc_whitelist, edge_blacklist, edge_whitelist) as ordered lists of index pairs."""
+    idx = {n: i for i, n in enumerate(nodes)}
+    for lst in (arc_blacklist, arc_whitelist, edge_blacklist, edge_whitelist):
+        for a, b in lst:
+            for v in (a, b):
+                if v not in idx:
+                    raise ValueError(f"Node {v} not present in the graph.")
+    und = lambda a, b: (min(a, b), max(a, b))
+    e_bl = {und(idx[a], idx[b]): None for a, b in edge_blacklist}
+    e_wl = {}
+    for a, b in edge_whitelist:
+        if und(idx[a], idx[b]) in e_bl:
+            raise ValueError(f"Edge {a} -- {b} in blacklist and whitelist")
+        e_wl[und(idx[a], idx[b])] = None
+    a_wl = {}
+    for a, b in arc_whitelist:
+        s, t = idx[a], idx[b]
+        if und(s, t) in e_bl:
+            raise ValueError(f"Edge blacklist {a} -- {b} is incompatible with arc whitelist{a} -> {b}")
+        e_wl.pop(und(s, t), None)
+        a_wl[(s, t)] = None
+    a_bl = {}
+    for a, b in arc_blacklist:
+        s, t = idx[a], idx[b]
+        if (s, t) in a_wl:
+            raise ValueError(f"Arc {a} -> {b} in blacklist and whitelist")
+        if und(s, t) in e_wl:
+            a_wl[(t, s)] = None
+            del e_wl[und(s, t)]
+        if und(s, t) not in e_bl:
+            a_bl[(s, t)] = None
+    for (s, t) in list(a_bl):
+        if (s, t) in a_bl and (t, s) in a_bl:
+            e_bl[und(s, t)] = None
+            del a_bl[(s, t)]
+            del a_bl[(t, s)]
+    return list(a_bl), list(a_wl), list(e_bl), list(e_wl)
+
+
+def mmpc_cpcs(test, nodes, alpha=0.05, arc_whitelist=(), edge_blacklist=(), edge_whitelist=(), symmetric=True):
+    """mmpc_all_variables (+ remove_asymmetries when `symmetric`): list of candidate parents-and-children (node names)
+    per node, and the number of independence tests evaluated.  Index-pair restriction lists as validate_restrictions
+    returns them."""
+    n = len(nodes)
+    fn, user, keep, errors = test._ci_callback(list(nodes))
+    flat = lambda prs: _lib.int_array([v for p in prs for v in p] or [0])
+    off = (C.c_int * (n + 1))()
+    out = (C.c_int * max(1, n * (n - 1)))()
+    ntests = C.c_int64(0)
+    rc = _lib.load().pbn_mmpc_cpcs(n, fn, user, float(alpha), len(arc_whitelist), flat(arc_whitelist), len(edge_blacklist),
+                                   flat(edge_blacklist), len(edge_whitelist), flat(edge_whitelist), int(bool(symmetric)), off, out,
+                                   C.byref(ntests))
+    if errors:
+        raise errors[0]
+    _lib.check(rc)
+    del keep
+    return [[nodes[out[j]] for j in range(off[i], off[i + 1])] for i in range(n)], ntests.value

@@ -582,6 +582,46 @@ class GreedyHillClimbing:
         return result
 
 
+class MMHC:
+    """Max-Min Hill-Climbing (learning/algorithms/mmhc.cpp:77-160): MMPC over all variables with the given independence
+    test, symmetric correction, every arc outside the candidate parents-and-children blacklisted, then the greedy
+    hill-climb of this package.  `MMHC().estimate(hypot_test, operators, score, nodes=[], bn_type=GaussianNetworkType(),
+    arc_blacklist=[], arc_whitelist=[], edge_blacklist=[], edge_whitelist=[], type_blacklist=[], type_whitelist=[],
+    callback=None, max_indegree=0, max_iters=2**31-1, epsilon=0, patience=0, alpha=0.05, verbose=0)`."""
+
+    def __init__(self):
+        self.last_cpcs, self.last_tests, self.hc = None, 0, GreedyHillClimbing()
+
+    def estimate(self, hypot_test, operators, score, nodes=(), bn_type=None, arc_blacklist=(), arc_whitelist=(), edge_blacklist=(),
+                 edge_whitelist=(), type_blacklist=(), type_whitelist=(), callback=None, max_indegree=0, max_iters=2 ** 31 - 1,
+                 epsilon=0.0, patience=0, alpha=0.05, verbose=0):
+        from .independences import mmpc_cpcs, validate_restrictions
+        from .models import GaussianNetworkType
+
+        bn_type = bn_type if bn_type is not None else GaussianNetworkType()
+        nodes = list(nodes) if nodes else list(hypot_test.variable_names())
+        if not hypot_test.has_variables(nodes):
+            raise ValueError("IndependenceTest do not contain all the variables in nodes list.")
+        bn = BayesianNetwork(bn_type, nodes)
+        if not score.compatible_bn(bn):
+            raise ValueError("BayesianNetwork is not compatible with the score.")
+        if not score.has_variables(nodes):
+            raise ValueError("Score do not contain all the variables in nodes list.")
+        _, a_wl, e_bl, e_wl = validate_restrictions(nodes, arc_blacklist, arc_whitelist, edge_blacklist, edge_whitelist)
+        cpcs, self.last_tests = mmpc_cpcs(hypot_test, nodes, alpha, a_wl, e_bl, e_wl, symmetric=True)
+        self.last_cpcs = cpcs
+        allowed = [set(c) for c in cpcs]
+        hc_blacklist = []
+        for i in range(len(nodes) - 1):               # create_hc_blacklist (mmhc.cpp:24-42)
+            for j in range(i + 1, len(nodes)):
+                if nodes[j] not in allowed[i]:
+                    hc_blacklist += [(nodes[i], nodes[j]), (nodes[j], nodes[i])]
+        hc_blacklist += [tuple(a) for a in arc_blacklist]
+        hc_whitelist = [(nodes[s], nodes[t]) for s, t in a_wl]
+        return self.hc.estimate(operators, score, bn, hc_blacklist, hc_whitelist, type_blacklist, type_whitelist, callback,
+                                max_indegree, max_iters, epsilon, patience, verbose)
+
+
 def hc(df, bn_type=None, start=None, score=None, operators=None, arc_blacklist=(), arc_whitelist=(), type_blacklist=(),
        type_whitelist=(), callback=None, max_indegree=0, max_iters=2 ** 31 - 1, epsilon=0.0, patience=0, seed=None,
        num_folds=10, test_holdout_ratio=0.2, verbose=0):
