@@ -82,7 +82,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         start, ops = pbn.GaussianNetwork(names), pbn.ArcOperatorSet()
         label = f"C4: 64-node GaussianNetwork, BGe, ArcOperatorSet, {n_rows} rows fp64"
         kw = {}
-    elif which == "c5":
+    elif which in ("c5", "c5mmhc"):
         # BASELINE config 5 (HC phase only; the MMPC restriction phase of MMHC is replaced by a supplied arc blacklist,
         # SURVEY.md §8d): 32 continuous + 16 dictionary columns, fp32, ValidatedLikelihood(0.2, 10, seed 0)
         import pandas as pd
@@ -115,10 +115,29 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         start = pbn.SemiparametricBN(names, [], [(f"D{j}", pbn.DiscreteFactorType()) for j in range(n_disc)])
         ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
         pairs = [(a, b) for a in names for b in names if a != b]
-        keep = rng.random(len(pairs)) < 0.15  # stand-in for the MMPC skeleton: 85 % of the arcs are blacklisted
-        kw = {"max_indegree": 3, "arc_blacklist": [p for p, k_ in zip(pairs, keep) if not k_]}
-        label = (f"C5 (HC phase): 48-node hybrid SemiparametricBN (16 discrete), ValidatedLikelihood(0.2, 10), arcs+node_type, "
-                 f"85% arc blacklist, max_indegree=3, {n_rows} rows fp32")
+        extra = {}
+        if which == "c5mmhc":
+            # the real restriction phase: MMPC over all 48 variables with the hybrid MutualInformation test
+            from pybnesian_amd.independences import mmpc_cpcs
+
+            t0 = time.perf_counter()
+            citest = pbn.MutualInformation(df)
+            t_test = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            cpcs, ntests = mmpc_cpcs(citest, names, 0.05)
+            t_mmpc = time.perf_counter() - t0
+            allowed = {n: set(c) for n, c in zip(names, cpcs)}
+            blacklist = [(a, b) for a, b in pairs if b not in allowed[a]]
+            extra = {"mmpc_s": t_mmpc, "ci_tests": ntests, "ci_tests_per_s": ntests / t_mmpc, "ci_test_ctor_s": t_test,
+                     "cpc_edges": sum(len(c) for c in cpcs) // 2, "device_passes": citest.passes()[0], "host_passes": citest.passes()[1]}
+            kw = {"max_indegree": 3, "arc_blacklist": blacklist}
+            label = (f"C5 (MMHC): 48-node hybrid SemiparametricBN (16 discrete), MMPC with MutualInformation (alpha 0.05) then "
+                     f"ValidatedLikelihood(0.2, 10) hill-climb, arcs+node_type, max_indegree=3, {n_rows} rows fp32")
+        else:
+            keep = rng.random(len(pairs)) < 0.15  # stand-in for the MMPC skeleton: 85 % of the arcs are blacklisted
+            kw = {"max_indegree": 3, "arc_blacklist": [p for p, k_ in zip(pairs, keep) if not k_]}
+            label = (f"C5 (HC phase): 48-node hybrid SemiparametricBN (16 discrete), ValidatedLikelihood(0.2, 10), arcs+node_type, "
+                     f"85% arc blacklist, max_indegree=3, {n_rows} rows fp32")
     elif which == "cv64":
         # north star: "CV-likelihood hill-climbing on 64-node synthetic data" - CKDE candidates are sharded over the
         # ranks (fixed total work: strong scaling of the delta cache); bounded to cache_scores + max_iters iterations
@@ -156,7 +175,9 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
     t0 = time.perf_counter()
     res = hc.estimate(ops, score, start, **kw)
     dt = time.perf_counter() - t0
+    more = extra if which == "c5mmhc" else {}
     return {
+        **more,
         "metric": "hill-climb candidate-arcs scored/s",
         "value": hc.last.cells_scored / dt,
         "unit": "arcs/s",
@@ -219,7 +240,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kde", default="product", choices=["product", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64", "c5"],
+    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64", "c5", "c5mmhc"],
                     help="secondary hill-climb metric: c4 = BASELINE config 4 (BGe, replicated moments), c3 = config 3 at full "
                          "size (slow), cv64 = 64-node CV-likelihood CKDE hill-climb whose candidates are sharded over the ranks")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -278,6 +278,20 @@ int pbn_lincor_from_cov(int n, int64_t rows, const double* cov /* n*n col-major 
 void pbn_lincor_destroy(pbn_lincor* h);
 int pbn_lincor_cov(const pbn_lincor* h, double* cov /* n*n */);
 double pbn_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
+/* Hybrid MutualInformation (learning/independences/hybrid/mutual_information.{hpp,cpp}): conditional-Gaussian MI of
+ * mixed discrete / continuous variables and its chi-square p-value.  table = the continuous columns (device, may be
+ * NULL), codes[j] = n_rows int32 category indices of discrete column j (HOST), cardinality[j] its categories.
+ * Variable ids: continuous columns first (table order), then the discrete ones.  One device pass per test gathers the
+ * per-configuration counts and moments; pbn_mi_pvalue has the pbn_ci_pvalue_fn signature (user = the handle, indices
+ * mapped through pbn_mi_set_order when set). */
+typedef struct pbn_mi pbn_mi;
+int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_disc, const int32_t* const* codes,
+                  const int* cardinality, int asymptotic_df, pbn_mi** out);
+void pbn_mi_destroy(pbn_mi* h);
+int pbn_mi_value(pbn_mi* h, int v1, int v2, int n_cond, const int* cond, double* mi, double* df);
+double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
+int pbn_mi_set_order(pbn_mi* h, int n, const int* ids);
+int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes);
 /* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
  * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies
  * remove_asymmetries (learning/algorithms/mmhc.cpp:12-22).  cpc_off: n+1 offsets into cpc (capacity n*(n-1)). */

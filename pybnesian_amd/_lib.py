@@ -80,6 +80,12 @@ SIGNATURES = {
     "pbn_lincor_destroy": (None, [_vp]),
     "pbn_lincor_cov": (_int, [_vp, _dp]),
     "pbn_lincor_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
+    "pbn_mi_create": (_int, [_vp, _vp, _i64, _int, C.POINTER(_vp), _ip, _int, C.POINTER(_vp)]),
+    "pbn_mi_destroy": (None, [_vp]),
+    "pbn_mi_value": (_int, [_vp, _int, _int, _int, _ip, _dp, _dp]),
+    "pbn_mi_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
+    "pbn_mi_set_order": (_int, [_vp, _int, _ip]),
+    "pbn_mi_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_mmpc_cpcs": (_int, [_int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_hc_estimate": (_int, [_vp, _vp, _vp, _ip, _ip, _ip, _vp]),
     "pbn_hc_create": (_int, [_vp, _vp, _vp, C.POINTER(_vp)]),

@@ -1,0 +1,511 @@
+// Hybrid mutual-information independence test (learning/independences/hybrid/mutual_information.{hpp,cpp}): the CI test
+// of the MMHC restriction phase on mixed discrete / continuous tables (BASELINE config 5).
+//
+// Under the conditional-Gaussian assumption every MI(X; Y | Z) of the reference is a combination of (a) counts of the
+// discrete configurations and (b) log-determinants of covariances of the continuous variables inside configurations
+// and inside configurations pooled over X and / or Y.  The reference makes 2 passes over the rows per quantity
+// (conditional_means_impl, conditional_covariance_impl).  Here one device pass per test gathers, per configuration of
+// the discrete variables involved, the count and the pilot-shifted first and second moments of the continuous ones;
+// moments are additive, so every pooled covariance is a sum of per-configuration moments on the host.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+#include "common.hpp"
+#include "hostmath.hpp"
+#include "stats_kernels.hpp"
+
+using namespace pbn;
+
+#define MI_MAX_CONT 24
+#define MI_MAX_DISC 16
+
+struct pbn_mi {
+    pbn_ctx* ctx = nullptr;
+    const pbn_table* table = nullptr;  // continuous columns (borrowed), null when there are none
+    int n_cont = 0, n_disc = 0;
+    int64_t N = 0;
+    bool asymptotic = true;
+    std::vector<int> card;
+    std::vector<std::vector<int32_t>> codes;  // host copies (fallback path)
+    dev_buf<int32_t> codes_dev;               // [n_disc][N]
+    std::vector<double> shift;                // pilot mean of every continuous column
+    std::vector<std::vector<double>> host_cols;  // lazily read back for the host fallback
+    int64_t device_passes = 0, host_passes = 0;
+    std::vector<int> order;  // external index -> variable id for the callback form (empty = identity)
+};
+
+namespace {
+
+struct GroupArgs {
+    const void* base;
+    int64_t ld;
+    int cols[MI_MAX_CONT];
+    double shift[MI_MAX_CONT];
+    int c;
+    const int32_t* codes;
+    int64_t codes_ld;
+    int dvar[MI_MAX_DISC];
+    int dstride[MI_MAX_DISC];
+    int m;
+    int64_t n;
+    int G, stats;
+    double* partial;
+    int64_t chunks_per_block;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+
+// One wave per block.  A chunk of 64 rows is staged in LDS (shifted values, a trailing 1, the configuration id); then
+// lane s owns statistic s of every configuration - statistic s is the product of two staged entries (i_s, j_s), the
+// trailing 1 turning products into sums and the count - and walks the 64 rows in order adding into its own LDS
+// cells: no two lanes share a cell, no atomics, fixed order, run-to-run identical, cost independent of how many
+// configurations a chunk touches.  stats per configuration: count, c sums, c(c+1)/2 products (upper triangle).
+template <typename T>
+__global__ __launch_bounds__(64) void group_moments_kernel(GroupArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int total = a.G * a.stats, c1 = a.c + 1;
+    double* acc = lds;                         // [G][stats]
+    double* stage = lds + total;               // [64][c + 1]
+    int* gid = (int*)(stage + 64 * c1);        // [64]
+    unsigned char* pi = (unsigned char*)(gid + 64);   // [stats] first factor
+    unsigned char* pj = pi + a.stats;                 // [stats] second factor
+    for (int i = lane; i < total; i += 64) acc[i] = 0.0;
+    for (int s0 = lane; s0 < a.stats; s0 += 64) {
+        int fi, fj;
+        if (s0 == 0) { fi = a.c; fj = a.c; }
+        else if (s0 <= a.c) { fi = s0 - 1; fj = a.c; }
+        else {
+            int rem = s0 - 1 - a.c, i = 0;
+            while (rem >= a.c - i) { rem -= a.c - i; ++i; }
+            fi = i; fj = i + rem;
+        }
+        pi[s0] = (unsigned char)fi; pj[s0] = (unsigned char)fj;
+    }
+    __syncthreads();
+    const int64_t chunk0 = (int64_t)blockIdx.x * a.chunks_per_block;
+    for (int64_t ch = chunk0; ch < chunk0 + a.chunks_per_block; ++ch) {
+        if (ch * 64 >= a.n) break;
+        const int64_t r = ch * 64 + lane;
+        const int rows = (int)((a.n - ch * 64 < 64) ? a.n - ch * 64 : 64);
+        if (r < a.n) {
+            for (int i = 0; i < a.c; ++i) stage[lane * c1 + i] = (double)((const T*)a.base)[(int64_t)a.cols[i] * a.ld + r] - a.shift[i];
+            stage[lane * c1 + a.c] = 1.0;
+            int g = 0;
+            for (int j = 0; j < a.m; ++j) g += a.codes[(int64_t)a.dvar[j] * a.codes_ld + r] * a.dstride[j];
+            gid[lane] = g;
+        }
+        __syncthreads();
+        for (int s0 = lane; s0 < a.stats; s0 += 64) {
+            const int fi = pi[s0], fj = pj[s0];
+            for (int rr = 0; rr < rows; ++rr) {
+                double* cell = acc + (size_t)gid[rr] * a.stats + s0;
+                *cell += stage[rr * c1 + fi] * stage[rr * c1 + fj];
+            }
+        }
+        __syncthreads();
+    }
+    double* out = a.partial + (size_t)blockIdx.x * total;
+    for (int i = lane; i < total; i += 64) out[i] = acc[i];
+}
+
+// one wave per statistic: lane l adds the partials of blocks l, l + 64, ... in order, then a fixed butterfly
+__global__ __launch_bounds__(64) void group_reduce_kernel(const double* __restrict__ partial, int nblocks, int total,
+                                                          double* __restrict__ out) {
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * total + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[i] = s;
+}
+
+// ---- regularised upper incomplete gamma Q(a, x): chi-square survival function (boost chi_squared complement) --------
+double gamma_q(double a, double x) {
+    if (std::isnan(x) || std::isnan(a)) return std::numeric_limits<double>::quiet_NaN();
+    if (x <= 0) return 1.0;
+    if (std::isinf(x)) return 0.0;
+    const double lg = std::lgamma(a);
+    if (x < a + 1.0) {  // series for P, Q = 1 - P
+        double ap = a, sum = 1.0 / a, del = sum;
+        for (int n = 0; n < 100000; ++n) {
+            ap += 1.0;
+            del *= x / ap;
+            sum += del;
+            if (std::fabs(del) < std::fabs(sum) * 1e-17) break;
+        }
+        return 1.0 - sum * std::exp(-x + a * std::log(x) - lg);
+    }
+    // Lentz continued fraction for Q
+    const double tiny = 1e-300;
+    double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+    for (int i = 1; i < 100000; ++i) {
+        const double an = -i * (i - a);
+        b += 2.0;
+        d = an * d + b; if (std::fabs(d) < tiny) d = tiny;
+        c = b + an / c; if (std::fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (std::fabs(del - 1.0) < 1e-16) break;
+    }
+    const double q = std::exp(-x + a * std::log(x) - lg) * h;
+    return q < std::numeric_limits<double>::min() ? 0.0 : q;
+}
+
+const double PI_ = 3.14159265358979323846264338327950288;
+
+double entropy_mvn(int d, double det) {  // mutual_information.cpp:921-924
+    return 0.5 * d + 0.5 * d * std::log(2 * PI_) + 0.5 * std::log(det);
+}
+
+// pooled moments of a set of configurations over the continuous variables
+struct Mom {
+    double n = 0;
+    int c = 0;
+    std::vector<double> S, P;  // sums, products (full c x c)
+    explicit Mom(int c_ = 0) : c(c_), S(c_, 0.0), P((size_t)c_ * c_, 0.0) {}
+    void add(const double* st) {  // one configuration's [count, sums, upper-triangle products]
+        n += st[0];
+        int pos = 1;
+        for (int i = 0; i < c; ++i) S[i] += st[pos++];
+        for (int i = 0; i < c; ++i)
+            for (int j = i; j < c; ++j) {
+                P[i + (size_t)j * c] += st[pos];
+                if (i != j) P[j + (size_t)i * c] += st[pos];
+                ++pos;
+            }
+    }
+    // determinant of the unbiased covariance of the selected variables (cov = centred SSE / (n - 1))
+    double det(const std::vector<int>& sel) const {
+        const int k = (int)sel.size();
+        if (k == 0) return 1.0;
+        std::vector<double> cov((size_t)k * k);
+        for (int b = 0; b < k; ++b)
+            for (int a2 = 0; a2 < k; ++a2)
+                cov[a2 + (size_t)b * k] = (P[sel[a2] + (size_t)sel[b] * c] - S[sel[a2]] * S[sel[b]] / n) / (n - 1.0);
+        return hm::determinant(cov.data(), k);
+    }
+};
+
+struct Query {
+    bool xd, yd;
+    int x, y;                   // variable ids
+    std::vector<int> zD, zC;    // variable ids
+};
+
+struct Engine {
+    pbn_mi* h;
+
+    bool is_disc(int v) const { return v >= h->n_cont; }
+    int card(int v) const { return h->card[v - h->n_cont]; }
+
+    // per-configuration statistics of the continuous variables `cont` over the discrete variables `disc` (first fastest)
+    void group_stats(const std::vector<int>& cont, const std::vector<int>& disc, int G, std::vector<double>& out) {
+        const int c = (int)cont.size(), m = (int)disc.size();
+        const int stats = 1 + c + c * (c + 1) / 2;
+        out.assign((size_t)G * stats, 0.0);
+        if (c > MI_MAX_CONT || m > MI_MAX_DISC) throw invalid_error("MutualInformation: conditioning set too large");
+        const int64_t N = h->N;
+        const size_t lds = ((size_t)G * stats + 64 * (size_t)(c + 1)) * sizeof(double) + 64 * sizeof(int) + 2 * (size_t)stats + 16;
+        if (lds <= 60 * 1024 && N > 0 && (h->table || c == 0)) {
+            pbn_ctx* ctx = h->ctx;
+            HIP_CHECK(hipSetDevice(ctx->device));
+            GroupArgs a{};
+            a.base = h->table ? h->table->data : nullptr;
+            a.ld = h->table ? h->table->ld : 0;
+            a.c = c; a.m = m; a.n = N; a.G = G; a.stats = stats;
+            for (int i = 0; i < c; ++i) { a.cols[i] = cont[i]; a.shift[i] = h->shift[cont[i]]; }
+            int stride = 1;
+            for (int j = 0; j < m; ++j) { a.dvar[j] = disc[j] - h->n_cont; a.dstride[j] = stride; stride *= card(disc[j]); }
+            a.codes = h->codes_dev.p; a.codes_ld = N;
+            const int64_t chunks = ceil_div(N, 64);
+            const int nblocks = (int)std::min<int64_t>(chunks, 4096);
+            a.chunks_per_block = ceil_div(chunks, nblocks);
+            const int total = G * stats;
+            ctx->scratch_part.reserve((size_t)(nblocks + 1) * total * sizeof(double));
+            a.partial = (double*)ctx->scratch_part.p;
+            double* dout = a.partial + (size_t)nblocks * total;
+            const bool f64 = !h->table || h->table->dtype == PBN_F64;
+            if (f64) hipLaunchKernelGGL(group_moments_kernel<double>, dim3(nblocks), dim3(64), lds, ctx->stream, a);
+            else hipLaunchKernelGGL(group_moments_kernel<float>, dim3(nblocks), dim3(64), lds, ctx->stream, a);
+            hipLaunchKernelGGL(group_reduce_kernel, dim3(total), dim3(64), 0, ctx->stream, a.partial, nblocks, total, dout);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(out.data(), dout, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ++h->device_passes;
+            return;
+        }
+        // host fallback: more configurations than fit the LDS accumulators
+        if (c > 0 && h->host_cols.empty()) {
+            h->host_cols.resize(h->n_cont);
+            const size_t es = dtype_size(h->table->dtype);
+            std::vector<char> tmp((size_t)N * es);
+            for (int j = 0; j < h->n_cont; ++j) {
+                HIP_CHECK(hipMemcpy(tmp.data(), h->table->col(j), (size_t)N * es, hipMemcpyDeviceToHost));
+                h->host_cols[j].resize(N);
+                if (es == 8) std::memcpy(h->host_cols[j].data(), tmp.data(), (size_t)N * 8);
+                else for (int64_t r = 0; r < N; ++r) h->host_cols[j][r] = ((const float*)tmp.data())[r];
+            }
+        }
+        std::vector<int> strides(m);
+        int stride = 1;
+        for (int j = 0; j < m; ++j) { strides[j] = stride; stride *= card(disc[j]); }
+        double v[MI_MAX_CONT];
+        for (int64_t r = 0; r < N; ++r) {
+            int64_t g = 0;
+            for (int j = 0; j < m; ++j) g += (int64_t)h->codes[disc[j] - h->n_cont][r] * strides[j];
+            double* dst = out.data() + (size_t)g * stats;
+            dst[0] += 1.0;
+            for (int i = 0; i < c; ++i) v[i] = h->host_cols[cont[i]][r] - h->shift[cont[i]];
+            int pos = 1;
+            for (int i = 0; i < c; ++i) dst[pos++] += v[i];
+            for (int i = 0; i < c; ++i)
+                for (int j = i; j < c; ++j) dst[pos++] += v[i] * v[j];
+        }
+        ++h->host_passes;
+    }
+
+    // MI(X; Y | Z) (mutual_information.cpp:926-1055 no conditioning, :1139-1312 one variable, :1391-1658 general);
+    // every overload of the reference is the general formula with the matching emptiness of zD / zC.
+    double mi(const Query& q) {
+        std::vector<int> disc, cont;
+        if (q.xd) disc.push_back(q.x);
+        if (q.yd) disc.push_back(q.y);
+        disc.insert(disc.end(), q.zD.begin(), q.zD.end());
+        if (!q.xd) cont.push_back(q.x);
+        if (!q.yd) cont.push_back(q.y);
+        cont.insert(cont.end(), q.zC.begin(), q.zC.end());
+        int64_t G64 = 1;
+        for (int v : disc) { G64 *= card(v); if (G64 > (1 << 24)) throw invalid_error("MutualInformation: too many discrete configurations"); }
+        const int G = (int)G64, c = (int)cont.size(), zc = (int)q.zC.size();
+        const int stats = 1 + c + c * (c + 1) / 2;
+        std::vector<double> st;
+        group_stats(cont, disc, G, st);
+        const double N = (double)h->N;
+        auto S = [&](int g) { return st.data() + (size_t)g * stats; };
+        std::vector<int> selz(zc);
+        double mi = 0.0;
+        if (q.xd && q.yd) {
+            const int cx = card(q.x), cy = card(q.y), vars = cx * cy, zcat = G / vars;
+            for (int i = 0; i < zc; ++i) selz[i] = i;
+            for (int k = 0; k < zcat; ++k) {
+                const int off = k * vars;
+                double Nz = 0;
+                std::vector<double> Nxz(cx, 0.0), Nyz(cy, 0.0);
+                for (int i = 0; i < cx; ++i)
+                    for (int j = 0; j < cy; ++j) {
+                        const double nn = S(off + i + j * cx)[0];
+                        Nxz[i] += nn; Nyz[j] += nn; Nz += nn;
+                    }
+                if (Nz == 0) continue;
+                const double pz = Nz / N;
+                for (int i = 0; i < cx; ++i) {
+                    const double pxz = Nxz[i] / N;
+                    for (int j = 0; j < cy; ++j) {
+                        const double nn = S(off + i + j * cx)[0];
+                        if (nn == 0) continue;
+                        const double pyz = Nyz[j] / N, pxyz = nn / N;
+                        double term = std::log((pz * pxyz) / (pxz * pyz));
+                        if (zc > 0) { Mom mo(c); mo.add(S(off + i + j * cx)); term -= entropy_mvn(zc, mo.det(selz)); }
+                        mi += pxyz * term;
+                    }
+                }
+                if (zc == 0) continue;
+                for (int i = 0; i < cx; ++i) {
+                    if (Nxz[i] == 0) continue;
+                    Mom mo(c);
+                    for (int j = 0; j < cy; ++j) mo.add(S(off + i + j * cx));
+                    mi += (Nxz[i] / N) * entropy_mvn(zc, mo.det(selz));
+                }
+                for (int j = 0; j < cy; ++j) {
+                    if (Nyz[j] == 0) continue;
+                    Mom mo(c);
+                    for (int i = 0; i < cx; ++i) mo.add(S(off + i + j * cx));
+                    mi += (Nyz[j] / N) * entropy_mvn(zc, mo.det(selz));
+                }
+                Mom mo(c);
+                for (int i = 0; i < vars; ++i) mo.add(S(off + i));
+                mi -= pz * entropy_mvn(zc, mo.det(selz));
+            }
+            // the purely discrete overloads return the sum as it is (mutual_information.cpp:955,1445); the
+            // conditional-Gaussian ones clamp at zero (:1530)
+            return zc == 0 ? mi : std::max(mi, 0.0);
+        }
+        if (q.xd != q.yd) {  // one discrete (leading in disc), one continuous (leading in cont)
+            const int cx = card(disc[0]), zcat = G / cx;
+            std::vector<int> sely(zc + 1);
+            for (int i = 0; i <= zc; ++i) sely[i] = i;
+            for (int i = 0; i < zc; ++i) selz[i] = i + 1;
+            for (int k = 0; k < zcat; ++k) {
+                const int off = k * cx;
+                double Nz = 0;
+                for (int i = 0; i < cx; ++i) Nz += S(off + i)[0];
+                if (Nz == 0) continue;
+                const double pz = Nz / N;
+                Mom pool(c);
+                for (int i = 0; i < cx; ++i) {
+                    const double nn = S(off + i)[0];
+                    pool.add(S(off + i));
+                    if (nn == 0) continue;
+                    Mom mo(c);
+                    mo.add(S(off + i));
+                    const double pxz = nn / N;
+                    mi -= pxz * entropy_mvn(zc + 1, mo.det(sely));
+                    if (zc > 0) mi += pxz * entropy_mvn(zc, mo.det(selz));
+                }
+                mi += pz * entropy_mvn(zc + 1, pool.det(sely));
+                if (zc > 0) mi -= pz * entropy_mvn(zc, pool.det(selz));
+            }
+            return std::max(mi, 0.0);
+        }
+        // both continuous: cont = [x, y, zC...]
+        std::vector<int> selxyz(zc + 2), selxz(zc + 1), selyz(zc + 1);
+        for (int i = 0; i < zc + 2; ++i) selxyz[i] = i;
+        selxz[0] = 0; selyz[0] = 1;
+        for (int i = 0; i < zc; ++i) { selxz[i + 1] = i + 2; selyz[i + 1] = i + 2; selz[i] = i + 2; }
+        for (int k = 0; k < G; ++k) {
+            const double Nz = S(k)[0];
+            if (Nz == 0) continue;
+            const double pz = Nz / N;
+            Mom mo(c);
+            mo.add(S(k));
+            mi += pz * (entropy_mvn(zc + 1, mo.det(selxz)) + entropy_mvn(zc + 1, mo.det(selyz)) - entropy_mvn(zc + 2, mo.det(selxyz)));
+            if (zc > 0) mi -= pz * entropy_mvn(zc, mo.det(selz));
+        }
+        // without any conditioning the reference uses -1/2 log(1 - cor^2) unclamped (:1055-1062); same value
+        return (q.zD.empty() && zc == 0) ? mi : std::max(mi, 0.0);
+    }
+
+    // degrees of freedom of 2 N MI (mutual_information.cpp:1093-1123, 1314-1375, 1660-1731)
+    double df(const Query& q) const {
+        double llz = 1;
+        for (int v : q.zD) llz *= card(v);
+        const double zc = (double)q.zC.size();
+        if (q.xd && q.yd) {
+            const double base = (card(q.x) - 1.0) * (card(q.y) - 1.0) * llz;
+            return h->asymptotic ? base * (1 + 0.5 * (zc * (zc + 3))) : base * (1 + 0.5 * (zc * (zc + 1)));
+        }
+        if (q.xd != q.yd) {
+            const double llx = card(q.xd ? q.x : q.y);
+            return h->asymptotic ? (llx - 1) * llz * (zc + 2) : (llx - 1) * llz * (zc + 1);
+        }
+        return llz;
+    }
+
+    Query make(int v1, int v2, int k, const int* cond) const {
+        const int nv = h->n_cont + h->n_disc;
+        auto chk = [&](int v) { if (v < 0 || v >= nv) throw invalid_error("MutualInformation: variable index out of range"); };
+        chk(v1); chk(v2);
+        Query q;
+        q.xd = is_disc(v1); q.yd = is_disc(v2); q.x = v1; q.y = v2;
+        if (!q.xd && q.yd) { std::swap(q.x, q.y); std::swap(q.xd, q.yd); }  // mi(): the discrete one is passed first
+        for (int i = 0; i < k; ++i) { chk(cond[i]); (is_disc(cond[i]) ? q.zD : q.zC).push_back(cond[i]); }
+        return q;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// table: the continuous columns (device, may be NULL when n_cont == 0); codes[j]: N int32 category indices of the
+// j-th discrete column (HOST), cardinality[j] its number of categories.  Variable ids: continuous columns first
+// (table order), then the discrete ones.
+int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_disc, const int32_t* const* codes,
+                  const int* cardinality, int asymptotic_df, pbn_mi** out) {
+    return guarded([&] {
+        if (!ctx || !out || (n_disc > 0 && (!codes || !cardinality))) throw invalid_error("pbn_mi_create: null argument");
+        if (table && table->n_rows != n_rows) throw invalid_error("pbn_mi_create: row counts differ");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        auto h = std::make_unique<pbn_mi>();
+        h->ctx = ctx; h->table = table; h->n_cont = table ? table->n_cols : 0; h->n_disc = n_disc; h->N = n_rows;
+        h->asymptotic = asymptotic_df != 0;
+        h->card.assign(cardinality, cardinality + n_disc);
+        h->codes.resize(n_disc);
+        h->codes_dev.alloc((size_t)std::max<int64_t>(1, (int64_t)n_disc * n_rows));
+        for (int j = 0; j < n_disc; ++j) {
+            h->codes[j].assign(codes[j], codes[j] + n_rows);
+            for (int64_t r = 0; r < n_rows; ++r)
+                if (codes[j][r] < 0 || codes[j][r] >= cardinality[j]) throw invalid_error("pbn_mi_create: category index out of range");
+            HIP_CHECK(hipMemcpyAsync(h->codes_dev.p + (size_t)j * n_rows, codes[j], (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        }
+        h->shift.assign(h->n_cont, 0.0);
+        if (table && n_rows > 0) {
+            dev_buf<double> dshift((size_t)h->n_cont);
+            for (int c0 = 0; c0 < h->n_cont; c0 += 64) {
+                GramCols gc{};
+                const int d = std::min(64, h->n_cont - c0);
+                for (int i = 0; i < d; ++i) gc.cols[i] = c0 + i;
+                launch_pilot(table->data, table->ld, gc, d, 0, nullptr, n_rows, table->dtype, dshift.p, ctx->stream);
+            }
+            HIP_CHECK(hipMemcpyAsync(h->shift.data(), dshift.p, h->n_cont * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *out = h.release();
+    });
+}
+
+void pbn_mi_destroy(pbn_mi* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+}
+
+// MI(v1; v2 | cond) and the degrees of freedom of its chi-square statistic; either output may be NULL.
+int pbn_mi_value(pbn_mi* h, int v1, int v2, int n_cond, const int* cond, double* mi, double* df) {
+    return guarded([&] {
+        if (!h || (n_cond > 0 && !cond)) throw invalid_error("pbn_mi_value: null argument");
+        Engine e{h};
+        const Query q = e.make(v1, v2, n_cond, cond);
+        if (mi) *mi = e.mi(q);
+        if (df) *df = e.df(q);
+    });
+}
+
+// pbn_ci_pvalue_fn over a pbn_mi handle: P(chi2_df > 2 N MI) (mutual_information.cpp:1125-1137,1377-1389,1733-1750)
+double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
+    pbn_mi* h = (pbn_mi*)user;
+    double mi = 0, df = 0;
+    std::vector<int> mapped;
+    if (h && !h->order.empty()) {
+        const int no = (int)h->order.size();
+        if (v1 < 0 || v2 < 0 || v1 >= no || v2 >= no) return std::nan("");
+        v1 = h->order[v1]; v2 = h->order[v2];
+        mapped.resize(n_cond);
+        for (int i = 0; i < n_cond; ++i) {
+            if (cond[i] < 0 || cond[i] >= no) return std::nan("");
+            mapped[i] = h->order[cond[i]];
+        }
+        cond = mapped.data();
+    }
+    if (pbn_mi_value(h, v1, v2, n_cond, cond, &mi, &df) != PBN_OK) return std::nan("");
+    return gamma_q(0.5 * df, 0.5 * (mi * 2.0 * (double)h->N));
+}
+
+// Index space of pbn_mi_pvalue: external index i stands for variable ids[i] (n == 0 restores the identity).
+int pbn_mi_set_order(pbn_mi* h, int n, const int* ids) {
+    return guarded([&] {
+        if (!h || (n > 0 && !ids)) throw invalid_error("pbn_mi_set_order: null argument");
+        for (int i = 0; i < n; ++i)
+            if (ids[i] < 0 || ids[i] >= h->n_cont + h->n_disc) throw invalid_error("pbn_mi_set_order: variable id out of range");
+        h->order.assign(ids, ids + n);
+    });
+}
+
+int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes) {
+    return guarded([&] {
+        if (!h) throw invalid_error("pbn_mi_stats: null argument");
+        if (device_passes) *device_passes = h->device_passes;
+        if (host_passes) *host_passes = h->host_passes;
+    });
+}
+
+}  // extern "C"

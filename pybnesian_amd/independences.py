@@ -121,6 +121,91 @@ class LinearCorrelation(IndependenceTest):
             pass
 
 
+class MutualInformation(IndependenceTest):
+    """pbn.MutualInformation(df, asymptotic_df=True): conditional-Gaussian mutual information for tables that mix
+    float and dictionary columns (learning/independences/hybrid/mutual_information.hpp)."""
+
+    def __init__(self, df, asymptotic_df=True, ctx=None):
+        import pyarrow as pa
+
+        rb = as_record_batch(df)
+        self._all_names = [f.name for f in rb.schema]
+        cont, disc = [], []
+        for f in rb.schema:
+            if pa.types.is_floating(f.type):
+                cont.append(f.name)
+            elif pa.types.is_dictionary(f.type):
+                disc.append(f.name)
+            else:
+                raise ValueError(f"Wrong data type ({f.type}) for column {f.name}.")
+        if any(rb.column(i).null_count for i in range(rb.num_columns)):
+            raise ValueError("MutualInformation on the device needs columns without nulls.")
+        ctx = ctx or default_context()
+        self._table = DeviceTable.from_dataframe(ctx, rb, cont, drop_null=False)[0] if cont else None
+        self._codes, card = [], []
+        for d in disc:
+            col = rb.column(rb.schema.get_field_index(d))
+            self._codes.append(np.ascontiguousarray(col.indices.to_numpy(zero_copy_only=False), dtype=np.int32))
+            card.append(len(col.dictionary))
+        self._id = {n: i for i, n in enumerate(cont + disc)}
+        ptrs = (C.c_void_p * max(1, len(disc)))(*[c.ctypes.data for c in self._codes])
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_mi_create(ctx.handle, self._table.handle if self._table is not None else None, rb.num_rows,
+                                             len(disc), ptrs, _lib.int_array(card or [0]), int(bool(asymptotic_df)), C.byref(h)))
+        self._handle = h
+
+    def _var(self, name):
+        if name not in self._id:
+            raise ValueError(f"Variable {name} not present in MutualInformation.")
+        return self._id[name]
+
+    def _args(self, x, y, z):
+        cond = [] if z is None else ([z] if isinstance(z, str) else list(z))
+        return self._var(x), self._var(y), len(cond), _lib.int_array([self._var(c) for c in cond] or [0])
+
+    def mi(self, x, y, z=None):
+        v = C.c_double(0.0)
+        a = self._args(x, y, z)
+        _lib.check(_lib.load().pbn_mi_value(self._handle, a[0], a[1], a[2], a[3], C.byref(v), None))
+        return v.value
+
+    def degrees_of_freedom(self, x, y, z=None):
+        v = C.c_double(0.0)
+        a = self._args(x, y, z)
+        _lib.check(_lib.load().pbn_mi_value(self._handle, a[0], a[1], a[2], a[3], None, C.byref(v)))
+        return v.value
+
+    def pvalue(self, x, y, z=None):
+        lib = _lib.load()
+        _lib.check(lib.pbn_mi_set_order(self._handle, 0, None))
+        a = self._args(x, y, z)
+        p = lib.pbn_mi_pvalue(self._handle, a[0], a[1], a[2], a[3])
+        if np.isnan(p):
+            raise ValueError("MutualInformation: the test is not defined for these variables (" + lib.pbn_last_error().decode() + ")")
+        return p
+
+    def passes(self):
+        d, h = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().pbn_mi_stats(self._handle, C.byref(d), C.byref(h)))
+        return d.value, h.value
+
+    def variable_names(self):
+        return list(self._all_names)
+
+    def _ci_callback(self, nodes):
+        lib = _lib.load()
+        _lib.check(lib.pbn_mi_set_order(self._handle, len(nodes), _lib.int_array([self._var(n) for n in nodes])))
+        return C.cast(lib.pbn_mi_pvalue, C.c_void_p), self._handle, self, []
+
+    def __del__(self):
+        try:
+            if _lib.alive() and getattr(self, "_handle", None):
+                _lib.load().pbn_mi_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
 def validate_restrictions(nodes, arc_blacklist=(), arc_whitelist=(), edge_blacklist=(), edge_whitelist=()):
     """util::validate_restrictions (util/validate_whitelists.hpp:72-146) over node indices: returns
     (arc_blacklist, arc_whitelist, edge_blacklist, edge_whitelist) as ordered lists of index pairs."""

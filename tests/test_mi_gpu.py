@@ -1,0 +1,106 @@
+"""GPU tier: hybrid MutualInformation (device per-configuration moments + host formulas) against the numpy restatement
+of learning/independences/hybrid/mutual_information.cpp, every overload: discrete/discrete, mixed, continuous, with
+discrete, continuous and mixed conditioning sets; degrees of freedom; chi-square tails; MMHC on a hybrid table."""
+import itertools
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+def hybrid_table(n, seed, dtype="float64"):
+    rng = np.random.default_rng(seed)
+    d1 = rng.integers(0, 3, size=n)
+    d2 = (d1 + rng.integers(0, 2, size=n) * (rng.random(n) < 0.6)) % 2
+    d3 = rng.integers(0, 4, size=n)
+    c1 = rng.normal(size=n) + 0.8 * d1
+    c2 = 0.7 * c1 + rng.normal(scale=0.6, size=n) - 0.5 * d2
+    c3 = rng.normal(size=n) * (1 + 0.3 * d3)
+    c4 = 0.4 * c2 - 0.6 * c3 + rng.normal(scale=0.8, size=n)
+    df = pd.DataFrame({"c1": c1, "c2": c2, "c3": c3, "c4": c4}).astype(dtype)
+    for name, codes, k in (("d1", d1, 3), ("d2", d2, 2), ("d3", d3, 4)):
+        df[name] = pd.Categorical.from_codes(codes, [f"{name}_{i}" for i in range(k)])
+    return df
+
+
+def make_oracle(df, asymptotic=True):
+    from oracle.mi_oracle import MIOracle
+
+    cols = {}
+    for c in df.columns:
+        if isinstance(df[c].dtype, pd.CategoricalDtype):
+            cols[c] = (df[c].cat.codes.to_numpy().astype(np.int64), len(df[c].cat.categories))
+        else:
+            cols[c] = df[c].to_numpy().astype(np.float64)
+    return MIOracle(cols, asymptotic)
+
+
+@pytest.mark.parametrize("n,dtype", [(600, "float64"), (50000, "float64"), (20000, "float32")])
+def test_mi_all_overloads(pbn, n, dtype):
+    df = hybrid_table(n, 5, dtype)
+    test = pbn.MutualInformation(df)
+    orc = make_oracle(df)
+    names = list(df.columns)
+    rng = np.random.default_rng(1)
+    rel = 1e-9 if dtype == "float64" else 2e-4
+    cases = [(x, y, ()) for x, y in itertools.combinations(names, 2)]
+    for _ in range(120):
+        k = int(rng.integers(1, 5))
+        sel = [names[i] for i in rng.choice(len(names), size=k + 2, replace=False)]
+        cases.append((sel[0], sel[1], tuple(sel[2:])))
+    for x, y, z in cases:
+        zz = None if not z else (z[0] if len(z) == 1 else list(z))
+        got_mi, want_mi = test.mi(x, y, zz), orc.mi(x, y, z)
+        assert got_mi == pytest.approx(want_mi, rel=rel, abs=(1e-11 if dtype == "float64" else 1e-6)), (x, y, z)
+        assert test.degrees_of_freedom(x, y, zz) == orc.df(x, y, z)
+        if dtype == "float64":
+            assert test.pvalue(x, y, zz) == pytest.approx(orc.pvalue(x, y, z), rel=1e-6, abs=1e-300), (x, y, z)
+    dev, host = test.passes()
+    assert dev > 0 and host == 0
+    assert pbn.MutualInformation(df, asymptotic_df=False).degrees_of_freedom("d1", "c1", ["c2", "d3"]) == make_oracle(df, False).df("d1", "c1", ["c2", "d3"])
+    with pytest.raises(ValueError, match="not present"):
+        test.pvalue("c1", "zz")
+
+
+def test_mi_many_configurations_host_fallback(pbn):
+    """More discrete configurations x statistics than the LDS accumulators hold: the host pass gives the same numbers."""
+    rng = np.random.default_rng(3)
+    n = 30000
+    df = pd.DataFrame({f"c{i}": rng.normal(size=n) for i in range(5)})
+    for j in range(6):
+        df[f"d{j}"] = pd.Categorical.from_codes(rng.integers(0, 4, size=n), [f"k{i}" for i in range(4)])
+    df["c1"] = df["c1"] + 0.5 * df["c0"] + 0.3 * df["d0"].cat.codes
+    test, orc = pbn.MutualInformation(df), make_oracle(df)
+    z = ["d1", "d2", "d3", "d4", "c2", "c3", "c4"]           # 4^5 configurations with d0 -> 1024 x 21 statistics
+    assert test.mi("d0", "c1", z) == pytest.approx(orc.mi("d0", "c1", z), rel=1e-8)
+    assert test.passes()[1] == 1
+
+
+def test_mmhc_hybrid(pbn):
+    from oracle import mmpc_oracle
+    from pybnesian_amd.independences import mmpc_cpcs
+
+    df = hybrid_table(20000, 9)
+    names = list(df.columns)
+    test, orc = pbn.MutualInformation(df), make_oracle(df)
+    got, ntests = mmpc_cpcs(test, names, 0.05)
+    want, calls = mmpc_oracle.mmpc_all_variables(lambda a, b, c: orc.pvalue(names[a], names[b], [names[i] for i in c]), len(names), 0.05)
+    assert [[names.index(v) for v in c] for c in got] == want and ntests == calls
+    assert any(want)
+    score = pbn.BIC(df)
+    model = pbn.MMHC().estimate(test, pbn.ArcOperatorSet(), score, bn_type=pbn.CLGNetworkType(), alpha=0.05)
+    allowed = [set(c) for c in want]
+    for a, b in model.arcs():
+        assert names.index(b) in allowed[names.index(a)]
+        assert not (isinstance(df[b].dtype, pd.CategoricalDtype) and not isinstance(df[a].dtype, pd.CategoricalDtype))
+    assert model.num_arcs() >= 3
