@@ -237,6 +237,11 @@ typedef struct {
     int (*on_iter)(void* user, int iteration, const int* op, double delta, int n_arcs, const int* arcs,
                    const int* node_types);
     void* on_iter_user;
+    /* Conditional networks (ConditionalBayesianNetwork; operators.cpp:134-256,365-437, operators.hpp:526-578): the
+     * last n_interface ids n_nodes .. n_nodes+n_interface-1 are interface nodes - parents only, never scored, never
+     * flipped.  node_types then holds n_nodes+n_interface entries, arc sources may be interface ids, the delta
+     * matrix of pbn_hc_get is (n_nodes+n_interface) x n_nodes. */
+    int n_interface;
 } pbn_hc_config;
 typedef struct {
     int iterations;

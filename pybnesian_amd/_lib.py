@@ -109,7 +109,7 @@ class HCConfig(C.Structure):
         ("n_type_blacklist", _int), ("type_blacklist", _ip), ("n_type_whitelist", _int), ("type_whitelist", _ip),
         ("op_arcs", _int), ("op_node_type", _int), ("arcs_first", _int), ("max_indegree", _int), ("max_iters", _int),
         ("epsilon", C.c_double), ("patience", _int), ("validated", _int),
-        ("on_iter", HC_ITER_FN), ("on_iter_user", _vp),
+        ("on_iter", HC_ITER_FN), ("on_iter_user", _vp), ("n_interface", _int),
     ]
 
 

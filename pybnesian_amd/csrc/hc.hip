@@ -44,15 +44,21 @@ struct Op {
 };
 
 struct Model {
-    int n = 0;
+    int n = 0;   // nodes
+    int ni = 0;  // interface nodes of a conditional network: ids n .. n+ni-1, sources only (ConditionalBayesianNetwork)
     int bn_type = PBN_BN_GAUSSIAN;
     std::vector<std::vector<int>> parents, children;
-    std::vector<char> adj;  // adj[s + t*n] = arc s -> t
+    std::vector<char> adj;  // adj[s + t*J] = arc s -> t, J = n + ni
     std::vector<int> node_type;
-    bool has_arc(int s, int t) const { return adj[s + (size_t)t * n] != 0; }
+    int J() const { return n + ni; }
+    bool is_interface(int v) const { return v >= n; }
+    void reset_graph() {
+        parents.assign(J(), {}); children.assign(J(), {}); adj.assign((size_t)J() * J(), 0);
+    }
+    bool has_arc(int s, int t) const { return adj[s + (size_t)t * J()] != 0; }
     void add_arc(int s, int t) {
         if (has_arc(s, t)) return;
-        adj[s + (size_t)t * n] = 1;
+        adj[s + (size_t)t * J()] = 1;
         parents[t].push_back(s);
         children[s].push_back(t);
     }
@@ -62,12 +68,12 @@ struct Model {
     }
     void remove_arc(int s, int t) {
         if (!has_arc(s, t)) return;
-        adj[s + (size_t)t * n] = 0;
+        adj[s + (size_t)t * J()] = 0;
         swap_remove(parents[t], s);
         swap_remove(children[s], t);
     }
     bool has_path(int from, int to, int skip_s = -1, int skip_t = -1) const {  // follows children
-        std::vector<char> seen(n, 0);
+        std::vector<char> seen(J(), 0);
         std::vector<int> stack{from};
         seen[from] = 1;
         while (!stack.empty()) {
@@ -84,10 +90,10 @@ struct Model {
     // BayesianNetworkType::can_have_arc (SemiparametricBN.hpp:93-98, CLGNetwork.hpp:84-89): no continuous -> discrete arcs
     bool can_have_arc(int s, int t) const { return !(node_type[t] == PBN_NODE_DISCRETE && node_type[s] != PBN_NODE_DISCRETE); }
     bool can_add_arc(int s, int t) const {  // generic_graph.hpp:2711-2718 && BayesianNetwork.hpp:571-577
-        return s != t && can_have_arc(s, t) && (parents[s].empty() || children[t].empty() || !has_path(t, s));
+        return s != t && !is_interface(t) && can_have_arc(s, t) && (parents[s].empty() || children[t].empty() || !has_path(t, s));
     }
     bool can_flip_arc(int s, int t) const {  // generic_graph.hpp:2721-2745; the flipped arc is t -> s
-        if (s == t || !can_have_arc(t, s)) return false;
+        if (s == t || is_interface(s) || is_interface(t) || !can_have_arc(t, s)) return false;
         if (has_arc(s, t)) {
             if (parents[t].size() == 1 || children[s].size() == 1) return true;
             return !has_path(s, t, s, t);
@@ -154,27 +160,29 @@ struct Scorer {
 };
 
 struct ArcSet {
-    int n = 0;
-    std::vector<double> delta;   // col-major: delta[s + t*n]
+    int n = 0, J = 0;
+    std::vector<double> delta;   // col-major: delta[s + t*J], s over the joint nodes, t over the nodes
     std::vector<char> valid_op;
     mutable std::vector<int> sorted_idx;
     int max_indegree = 0;
     std::vector<std::pair<int, int>> blacklist, whitelist;
 
     void update_valid_ops(const Model& m) {  // operators.cpp:19-69 (cells the reference leaves uninitialised start at lowest())
-        n = m.n;
-        delta.assign((size_t)n * n, LOWEST);
-        valid_op.assign((size_t)n * n, 1);
+        // conditional networks (operators.cpp:153-210): rows run over the joint nodes; an interface source has no
+        // reverse cell
+        n = m.n; J = m.J();
+        delta.assign((size_t)J * n, LOWEST);
+        valid_op.assign((size_t)J * n, 1);
         for (auto& a : whitelist) {
-            valid_op[a.first + (size_t)a.second * n] = 0;
-            valid_op[a.second + (size_t)a.first * n] = 0;
+            valid_op[a.first + (size_t)a.second * J] = 0;
+            if (!m.is_interface(a.first)) valid_op[a.second + (size_t)a.first * J] = 0;
         }
-        for (auto& a : blacklist) valid_op[a.first + (size_t)a.second * n] = 0;
-        for (int i = 0; i < n; ++i) valid_op[i + (size_t)i * n] = 0;
+        for (auto& a : blacklist) valid_op[a.first + (size_t)a.second * J] = 0;
+        for (int i = 0; i < n; ++i) valid_op[i + (size_t)i * J] = 0;
         sorted_idx.clear();
-        for (int i = 0; i < n; ++i)
+        for (int i = 0; i < J; ++i)
             for (int j = 0; j < n; ++j)
-                if (valid_op[i + (size_t)j * n]) sorted_idx.push_back(i + j * n);
+                if (valid_op[i + (size_t)j * J]) sorted_idx.push_back(i + j * J);
     }
 };
 
@@ -199,12 +207,12 @@ struct Engine {
     struct CCell { int s, t; int a, b; int kind; };  // kind 0: d = S[a]-local[t]; 1: S[a]+S[b]-local[s]-local[t]
     void arcs_collect_cache(Batch& bt, std::vector<CCell>& cells) {
         arcs.update_valid_ops(cur);
-        const int n = cur.n;
+        const int n = cur.n, J = cur.J();
         for (int t = 0; t < n; ++t) {
             std::vector<int> pt = cur.parents[t];
-            for (int s = 0; s < n; ++s) {
-                if (!arcs.valid_op[s + (size_t)t * n] || !cur.can_have_arc(s, t)) continue;
-                if (cur.has_arc(s, t)) {
+            for (int s = 0; s < J; ++s) {
+                if (!arcs.valid_op[s + (size_t)t * J] || !cur.can_have_arc(s, t)) continue;
+                if (cur.has_arc(s, t)) {   // also cache_score_interface (operators.cpp:134-151) for an interface source
                     Model::swap_remove(pt, s);
                     int a = bt.add(t, cur.node_type[t], pt);
                     pt.push_back(s);
@@ -227,7 +235,7 @@ struct Engine {
         }
     }
     void arcs_apply_cache(const std::vector<CCell>& cells, const std::vector<double>& S) {
-        const int n = cur.n;
+        const int n = cur.J();
         for (const CCell& c : cells) {
             double d;
             if (c.kind == 0) d = S[c.a] - local[c.t];
@@ -240,7 +248,7 @@ struct Engine {
     // ---- ArcOperatorSet::update_incoming_arcs_scores (operators.cpp:296-347), requests only -------------
     struct UCell { int s, t; int a, b; int kind; };  // kind 0 remove/add: S[a]-local[t]; 1 flip-of-existing: cell(t,s) = d_remove + S[b]-local[s]; 2 flip: S[a]+S[b]-local[s]-local[t]
     void arcs_collect_updates(int t, Batch& bt, std::vector<UCell>& cells) {
-        const int n = cur.n;
+        const int n = cur.J();   // stride of the delta matrix; interface sources (operators.cpp:365-418) never flip
         std::vector<int> parents = cur.parents[t];
         for (int s = 0; s < n; ++s) {
             if (!arcs.valid_op[s + (size_t)t * n]) continue;
@@ -249,13 +257,13 @@ struct Engine {
                 int a = bt.add(t, cur.node_type[t], parents);
                 parents.push_back(s);
                 int b = -1;
-                if (arcs.valid_op[t + (size_t)s * n] && cur.can_have_arc(t, s)) {
+                if (!cur.is_interface(s) && cur.can_have_arc(t, s) && arcs.valid_op[t + (size_t)s * n]) {
                     std::vector<int> ps = cur.parents[s];
                     ps.push_back(t);
                     b = bt.add(s, cur.node_type[s], ps);
                 }
                 cells.push_back({s, t, a, b, 1});
-            } else if (cur.has_arc(t, s) && cur.can_have_arc(s, t)) {
+            } else if (!cur.is_interface(s) && cur.has_arc(t, s) && cur.can_have_arc(s, t)) {
                 std::vector<int> ps = cur.parents[s];
                 Model::swap_remove(ps, t);
                 parents.push_back(s);
@@ -272,7 +280,7 @@ struct Engine {
         }
     }
     void arcs_apply_updates(const std::vector<UCell>& cells, const std::vector<double>& S) {
-        const int n = cur.n;
+        const int n = cur.J();
         for (const UCell& c : cells) {
             if (c.kind == 0) {
                 arcs.delta[c.s + (size_t)c.t * n] = S[c.a] - local[c.t];
@@ -294,7 +302,7 @@ struct Engine {
 
     // ---- ArcOperatorSet::find_max_indegree (operators.hpp:489-525, tabu :580-623) --------------------------
     Op arcs_find_max(const std::vector<Op>* tabu) const {
-        const int n = cur.n;
+        const int n = cur.J();
         const double* dp = arcs.delta.data();
         std::sort(arcs.sorted_idx.begin(), arcs.sorted_idx.end(), [dp](int i1, int i2) { return dp[i1] > dp[i2]; });
         auto in_tabu = [&](const Op& o) {
@@ -310,6 +318,13 @@ struct Engine {
             if (cur.has_arc(s, t)) {
                 o.kind = OP_REMOVE; o.source = s; o.target = t; o.delta = dp[idx];
                 if (!in_tabu(o)) return o;
+            } else if (cur.is_interface(s)) {
+                // operators.hpp:547-556: one direction only, no cycle possible
+                if (limited && (int)cur.parents[t].size() >= arcs.max_indegree) continue;
+                if (cur.can_have_arc(s, t)) {
+                    o.kind = OP_ADD; o.source = s; o.target = t; o.delta = dp[idx];
+                    if (!in_tabu(o)) return o;
+                }
             } else if (cur.has_arc(t, s) && cur.can_flip_arc(t, s)) {
                 if (limited && (int)cur.parents[t].size() >= arcs.max_indegree) continue;
                 o.kind = OP_FLIP; o.source = t; o.target = s; o.delta = dp[idx];
@@ -427,34 +442,36 @@ static void init_engine(Engine& e, const pbn_hc_config* cfg, pbn_hc_score_fn fn,
     if (n <= 0) throw invalid_error("pbn_hc_estimate: empty model");
     e.scorer = Scorer{fn, user};
     Model& m = e.cur;
-    m.n = n; m.bn_type = cfg->bn_type;
-    m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
-    m.node_type.assign(n, cfg->bn_type == PBN_BN_KDE ? PBN_NODE_CKDE : PBN_NODE_LG);
+    if (cfg->n_interface < 0) throw invalid_error("pbn_hc_estimate: negative number of interface nodes");
+    m.n = n; m.ni = cfg->n_interface; m.bn_type = cfg->bn_type;
+    m.reset_graph();
+    m.node_type.assign(m.J(), cfg->bn_type == PBN_BN_KDE ? PBN_NODE_CKDE : PBN_NODE_LG);
     if (cfg->bn_type < PBN_BN_GAUSSIAN || cfg->bn_type > PBN_BN_CLG) throw invalid_error("pbn_hc_estimate: unknown network type");
     if (cfg->node_types)
-        for (int i = 0; i < n; ++i) m.node_type[i] = cfg->node_types[i];
+        for (int i = 0; i < m.J(); ++i) m.node_type[i] = cfg->node_types[i];
     auto check_node = [&](int v) { if (v < 0 || v >= n) throw invalid_error("pbn_hc_estimate: node index out of range"); };
+    auto check_source = [&](int v) { if (v < 0 || v >= m.J()) throw invalid_error("pbn_hc_estimate: node index out of range"); };
     // force type whitelist (hillclimbing.hpp:77)
     for (int i = 0; i < cfg->n_type_whitelist; ++i) {
         check_node(cfg->type_whitelist[2 * i]);
         m.node_type[cfg->type_whitelist[2 * i]] = cfg->type_whitelist[2 * i + 1];
     }
     for (int i = 0; i < cfg->n_arcs; ++i) {
-        check_node(cfg->arcs[2 * i]); check_node(cfg->arcs[2 * i + 1]);
+        check_source(cfg->arcs[2 * i]); check_node(cfg->arcs[2 * i + 1]);
         m.add_arc(cfg->arcs[2 * i], cfg->arcs[2 * i + 1]);
     }
     // check_blacklist / force_whitelist (hillclimbing.hpp:95-96)
     for (int i = 0; i < cfg->n_arc_blacklist; ++i) {
         const int s = cfg->arc_blacklist[2 * i], t = cfg->arc_blacklist[2 * i + 1];
-        check_node(s); check_node(t);
+        check_source(s); check_node(t);
         if (m.has_arc(s, t)) throw invalid_error("Arc in the blacklist is present in the starting Bayesian network.");
         e.arcs.blacklist.push_back({s, t});
     }
     for (int i = 0; i < cfg->n_arc_whitelist; ++i) {
         const int s = cfg->arc_whitelist[2 * i], t = cfg->arc_whitelist[2 * i + 1];
-        check_node(s); check_node(t);
+        check_source(s); check_node(t);
         if (!m.has_arc(s, t)) {
-            if (m.has_arc(t, s)) m.remove_arc(t, s);
+            if (!m.is_interface(s) && m.has_arc(t, s)) m.remove_arc(t, s);
             if (!m.can_add_arc(s, t)) throw invalid_error("Arc whitelist creates a cycle in the starting Bayesian network.");
             m.add_arc(s, t);
         }
@@ -498,12 +515,12 @@ int pbn_hc_set_model(pbn_hc* h, int n_arcs, const int* arcs, const int* node_typ
         if (!h || (n_arcs > 0 && !arcs)) throw invalid_error("pbn_hc_set_model: null argument");
         Model& m = h->e.cur;
         const int n = m.n;
-        m.parents.assign(n, {}); m.children.assign(n, {}); m.adj.assign((size_t)n * n, 0);
+        m.reset_graph();
         if (node_types)
-            for (int i = 0; i < n; ++i) m.node_type[i] = node_types[i];
+            for (int i = 0; i < m.J(); ++i) m.node_type[i] = node_types[i];
         for (int i = 0; i < n_arcs; ++i) {
             const int s = arcs[2 * i], t = arcs[2 * i + 1];
-            if (s < 0 || s >= n || t < 0 || t >= n) throw invalid_error("pbn_hc_set_model: node index out of range");
+            if (s < 0 || s >= m.J() || t < 0 || t >= n) throw invalid_error("pbn_hc_set_model: node index out of range");
             m.add_arc(s, t);
         }
     });
@@ -551,7 +568,8 @@ int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types
         if (!h) throw invalid_error("pbn_hc_get: null handle");
         const int n = h->e.cur.n;
         if (local && (int)h->e.local.size() == n) std::memcpy(local, h->e.local.data(), n * sizeof(double));
-        if (delta_arcs && h->e.arcs.delta.size() == (size_t)n * n) std::memcpy(delta_arcs, h->e.arcs.delta.data(), (size_t)n * n * sizeof(double));
+        const size_t cells = (size_t)h->e.cur.J() * n;
+        if (delta_arcs && h->e.arcs.delta.size() == cells) std::memcpy(delta_arcs, h->e.arcs.delta.data(), cells * sizeof(double));
         if (delta_types && (int)h->e.types.delta.size() == n) std::memcpy(delta_types, h->e.types.delta.data(), n * sizeof(double));
     });
 }
