@@ -18,16 +18,19 @@ LOWEST = -sys.float_info.max
 
 
 class Model:
-    def __init__(self, n, bn_type, node_types=None, arcs=()):
-        self.n, self.bn_type = n, bn_type  # 0 gaussian, 1 semiparametric, 2 kde
-        self.parents = [[] for _ in range(n)]
-        self.children = [[] for _ in range(n)]
-        self.node_type = list(node_types) if node_types is not None else [1 if bn_type == 2 else 0] * n
+    def __init__(self, n, bn_type, node_types=None, arcs=(), ni=0):
+        self.n, self.bn_type, self.ni = n, bn_type, ni  # 0 gaussian, 1 semiparametric, 2 kde; ni interface nodes n..n+ni-1
+        self.parents = [[] for _ in range(n + ni)]
+        self.children = [[] for _ in range(n + ni)]
+        self.node_type = list(node_types) if node_types is not None else [1 if bn_type == 2 else 0] * (n + ni)
         for s, t in arcs:
             self.add_arc(s, t)
 
+    def is_interface(self, v):
+        return v >= self.n
+
     def clone(self):
-        m = Model(self.n, self.bn_type, self.node_type)
+        m = Model(self.n, self.bn_type, self.node_type, ni=self.ni)
         m.parents = [list(p) for p in self.parents]
         m.children = [list(c) for c in self.children]
         return m
@@ -70,7 +73,7 @@ class Model:
         return not (self.node_type[t] == 2 and self.node_type[s] != 2)
 
     def can_add_arc(self, s, t):
-        return s != t and self.can_have_arc(s, t) and (not self.parents[s] or not self.children[t] or not self.has_path(t, s))
+        return s != t and t < self.n and self.can_have_arc(s, t) and (not self.parents[s] or not self.children[t] or not self.has_path(t, s))
 
     def can_flip_arc(self, s, t):
         if s == t or not self.can_have_arc(t, s):
@@ -118,13 +121,18 @@ def _same(o1, o2):
 
 def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_blacklist=(), arc_whitelist=(), type_blacklist=(),
              type_whitelist=(), op_arcs=True, op_types=False, arcs_first=True, max_indegree=0, max_iters=2 ** 31 - 1,
-             epsilon=0.0, patience=0):
-    m = Model(n, bn_type, node_types, arcs)
+             epsilon=0.0, patience=0, n_interface=0):
+    """n_interface > 0: conditional network (operators.cpp:134-256,365-437; operators.hpp:526-578) - ids n .. n+ni-1 are
+    interface nodes; the delta matrix is (n + ni) x n."""
+    ni = n_interface
+    J = n + ni
+    m = Model(n, bn_type, node_types, arcs, ni)
     for v, t in type_whitelist:
         m.node_type[v] = t
     for s, t in arc_whitelist:
         if not m.has_arc(s, t):
-            m.remove_arc(t, s)
+            if s < n:
+                m.remove_arc(t, s)
             m.add_arc(s, t)
     validated = vscore is not None
     zero_patience = patience == 0
@@ -135,16 +143,17 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
         return score(v, mod.node_type[v], list(mod.parents[v]))
 
     # ---- op-set state -------------------------------------------------------------------------------------
-    delta = np.full(n * n, LOWEST)
-    valid = np.ones(n * n, dtype=bool)
+    delta = np.full(J * n, LOWEST)
+    valid = np.ones(J * n, dtype=bool)
     for s, t in arc_whitelist:
-        valid[s + t * n] = False
-        valid[t + s * n] = False
+        valid[s + t * J] = False
+        if s < n:
+            valid[t + s * J] = False
     for s, t in arc_blacklist:
-        valid[s + t * n] = False
+        valid[s + t * J] = False
     for i in range(n):
-        valid[i + i * n] = False
-    sorted_idx = np.array([i + j * n for i in range(n) for j in range(n) if valid[i + j * n]], dtype=np.int32)
+        valid[i + i * J] = False
+    sorted_idx = np.array([i + j * J for i in range(J) for j in range(n) if valid[i + j * J]], dtype=np.int32)
     tdelta = [LOWEST] * n
     thas = [False] * n
     cells = [0]
@@ -154,8 +163,8 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
     def cache_arcs():
         for t in range(n):
             pt = list(m.parents[t])
-            for s in range(n):
-                if not valid[s + t * n] or not m.can_have_arc(s, t):
+            for s in range(J):
+                if not valid[s + t * J] or not m.can_have_arc(s, t):
                     continue
                 if m.has_arc(s, t):
                     Model.swap_remove(pt, s)
@@ -171,7 +180,7 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
                     pt.append(s)
                     d = score(t, m.node_type[t], list(pt)) - local[t]
                     pt.pop()
-                delta[s + t * n] = d
+                delta[s + t * J] = d
                 cells[0] += 1
 
     def update_types(nodes):
@@ -191,42 +200,48 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
 
     def update_arcs(t):
         parents = list(m.parents[t])
-        for s in range(n):
-            if not valid[s + t * n]:
+        for s in range(J):
+            if not valid[s + t * J]:
                 continue
             if m.has_arc(s, t):
                 Model.swap_remove(parents, s)
                 d = score(t, m.node_type[t], list(parents)) - local[t]
                 parents.append(s)
-                delta[s + t * n] = d
+                delta[s + t * J] = d
                 cells[0] += 1
-                if valid[t + s * n] and m.can_have_arc(t, s):
+                if s < n and m.can_have_arc(t, s) and valid[t + s * J]:
                     ps = list(m.parents[s]) + [t]
-                    delta[t + s * n] = d + score(s, m.node_type[s], ps) - local[s]
+                    delta[t + s * J] = d + score(s, m.node_type[s], ps) - local[s]
                     cells[0] += 1
-            elif m.has_arc(t, s) and m.can_have_arc(s, t):
+            elif s < n and m.has_arc(t, s) and m.can_have_arc(s, t):
                 ps = list(m.parents[s])
                 Model.swap_remove(ps, t)
                 parents.append(s)
                 d = score(s, m.node_type[s], ps) + score(t, m.node_type[t], list(parents)) - local[s] - local[t]
                 parents.pop()
-                delta[s + t * n] = d
+                delta[s + t * J] = d
                 cells[0] += 1
             elif m.can_have_arc(s, t):
                 parents.append(s)
                 d = score(t, m.node_type[t], list(parents)) - local[t]
                 parents.pop()
-                delta[s + t * n] = d
+                delta[s + t * J] = d
                 cells[0] += 1
 
     def arcs_find_max(tabu):
         oracle.lib().oracle_sort_idx_by_delta_desc(sorted_idx.ctypes.data_as(C.c_void_p), C.c_int64(sorted_idx.size),
                                                    delta.ctypes.data_as(C.c_void_p))
         for idx in sorted_idx:
-            s, t = int(idx) % n, int(idx) // n
+            s, t = int(idx) % J, int(idx) // J
             d = float(delta[idx])
             if m.has_arc(s, t):
                 op = (1, s, t, d)
+            elif s >= n:   # interface source: one direction, no cycle (operators.hpp:547-556)
+                if max_indegree > 0 and len(m.parents[t]) >= max_indegree:
+                    continue
+                if not m.can_have_arc(s, t):
+                    continue
+                op = (0, s, t, d)
             elif m.has_arc(t, s) and m.can_flip_arc(t, s):
                 if max_indegree > 0 and len(m.parents[t]) >= max_indegree:
                     continue

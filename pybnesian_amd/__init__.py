@@ -12,7 +12,8 @@ from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, Scotts
 from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, MMHC, OperatorPool, OperatorTabuSet, RemoveArc, hc)
 from .independences import IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
-from .models import (BayesianNetwork, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
+from .models import (BayesianNetwork, ConditionalBayesianNetwork, ConditionalCLGNetwork, ConditionalGaussianNetwork,  # noqa: F401
+                     ConditionalKDENetwork, ConditionalSemiparametricBN, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, load)
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
@@ -23,5 +24,5 @@ __all__ = [
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
-    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "load", "Context", "DeviceTable", "default_context", "load_library",
+    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "load", "Context", "DeviceTable", "default_context", "load_library",
 ]

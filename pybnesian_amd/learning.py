@@ -231,10 +231,12 @@ class _EngineBinding:
         from .scores import ValidatedScore, _DeviceScore
 
         device_score = isinstance(score, _DeviceScore) or hasattr(score, "_batch_raw")  # batched engine protocol
-        self.nodes = model.nodes()
+        # joint index space of the engine: the nodes, then the interface nodes of a conditional network
+        self.n_nodes = len(model.nodes())
+        self.nodes = model.nodes() + (model.interface_nodes() if hasattr(model, "interface_nodes") else [])
         self.idx = {n: i for i, n in enumerate(self.nodes)}
         self.score, self.model_type = score, model.type()
-        n = len(self.nodes)
+        n = self.n_nodes
         col_of_node = [score._col[v] for v in self.nodes] if device_score else list(range(len(self.nodes)))
         idx = self.idx
 
@@ -275,6 +277,7 @@ class _EngineBinding:
         cfg.arcs_first = int(isinstance(sets[0], ArcOperatorSet))
         cfg.max_indegree, cfg.max_iters = int(max_indegree), int(min(max_iters, 2 ** 31 - 1))
         cfg.epsilon, cfg.patience = float(epsilon), int(patience)
+        cfg.n_interface = len(self.nodes) - self.n_nodes
         cfg.validated = int(isinstance(score, ValidatedScore) or bool(getattr(score, "validated", False)))
         self.cfg = cfg
         self.errors = []
@@ -329,7 +332,7 @@ class _EngineBinding:
         self.handle = h
 
     def sync(self, model):
-        if model.nodes() != self.nodes:
+        if model.nodes() + (model.interface_nodes() if hasattr(model, "interface_nodes") else []) != self.nodes:
             raise ValueError("The model's nodes changed since cache_scores().")
         arcs = []
         for a, b in model.arcs():
@@ -364,13 +367,13 @@ class _EngineBinding:
         self.check(_lib.load().pbn_hc_update_scores(self.handle, len(ids), _lib.int_array(ids or [0])))
 
     def local_scores(self):
-        out = np.zeros(len(self.nodes))
+        out = np.zeros(self.n_nodes)
         self.check(_lib.load().pbn_hc_get(self.handle, _lib.dptr(out), None, None))
         return out
 
     def deltas(self):
-        n = len(self.nodes)
-        arcs, types = np.zeros((n, n), order="F"), np.zeros(n)
+        n = self.n_nodes
+        arcs, types = np.zeros((len(self.nodes), n), order="F"), np.zeros(n)
         self.check(_lib.load().pbn_hc_get(self.handle, None, _lib.dptr(arcs), _lib.dptr(types)))
         return arcs, types
 
@@ -545,8 +548,9 @@ class GreedyHillClimbing:
         binding = _EngineBinding(sets, score, start, arc_blacklist, arc_whitelist, type_blacklist, type_whitelist,
                                  max_indegree, max_iters, epsilon, patience)
         binding.batch_hook = batch_hook
-        nodes, n = binding.nodes, len(binding.nodes)
-        out_arcs = (C.c_int * (2 * n * n))()
+        nodes, n = binding.nodes, binding.n_nodes
+        interface = nodes[n:]
+        out_arcs = (C.c_int * (2 * len(nodes) * n))()
         out_n = C.c_int(0)
         out_types = (C.c_int * n)()
         stats = _lib.HCStats()
@@ -558,8 +562,8 @@ class GreedyHillClimbing:
             def on_iter(_user, iteration, op, delta, n_arcs, arcs, ntypes):
                 try:
                     cur_arcs = [(nodes[arcs[2 * i]], nodes[arcs[2 * i + 1]]) for i in range(n_arcs)]
-                    cur_types = [(nodes[i], _NODE_FROM_CODE[ntypes[i]]) for i in range(n)]
-                    cur = BayesianNetwork(start.type(), nodes, cur_arcs, [] if start.type().homogeneous else cur_types)
+                    cur_types = [(nodes[i], _NODE_FROM_CODE[ntypes[i]]) for i in range(n)] + [(v, start.node_type(v)) for v in interface]
+                    cur = BayesianNetwork(start.type(), nodes[:n], cur_arcs, [] if start.type().homogeneous else cur_types, interface)
                     callback.call(cur, binding.make_op(op[0], op[1], op[2], delta), score, iteration)
                     return 0
                 except Exception as ex:
@@ -571,9 +575,9 @@ class GreedyHillClimbing:
         rc = _lib.load().pbn_hc_estimate(C.byref(binding.cfg), binding.callback, None, out_arcs, C.byref(out_n), out_types,
                                          C.byref(stats))
         binding.check(rc)
-        res_types = [(nodes[i], _NODE_FROM_CODE[out_types[i]]) for i in range(n)]
+        res_types = [(nodes[i], _NODE_FROM_CODE[out_types[i]]) for i in range(n)] + [(v, start.node_type(v)) for v in interface]
         res_arcs = [(nodes[out_arcs[2 * i]], nodes[out_arcs[2 * i + 1]]) for i in range(out_n.value)]
-        result = BayesianNetwork(start.type(), nodes, res_arcs, [] if start.type().homogeneous else res_types)
+        result = BayesianNetwork(start.type(), nodes[:n], res_arcs, [] if start.type().homogeneous else res_types, interface)
         self.last = HCResult()
         self.last.iterations = stats.iterations
         self.last.cells_scored = stats.cells_scored

@@ -69,7 +69,10 @@ class CLGNetworkType(BayesianNetworkType):
 
 
 class BayesianNetwork:
-    def __init__(self, bn_type, nodes, arcs=(), node_types=()):
+    """BayesianNetwork / ConditionalBayesianNetwork (models/BayesianNetwork.hpp): with `interface_nodes` the network is
+    conditional - interface nodes can be parents of the nodes but have no parents, factors or scores of their own."""
+
+    def __init__(self, bn_type, nodes, arcs=(), node_types=(), interface_nodes=()):
         if nodes and isinstance(nodes[0], (tuple, list)) and not arcs:
             # constructed from arcs only: nodes in order of first appearance
             arcs = nodes
@@ -81,12 +84,14 @@ class BayesianNetwork:
             nodes = seen
         self._type = bn_type
         self._nodes = list(nodes)
-        if len(set(self._nodes)) != len(self._nodes):
+        self._interface = list(interface_nodes)
+        joint = self._nodes + self._interface
+        if len(set(joint)) != len(joint):
             raise ValueError("Nodes must be unique.")
-        self._index = {n: i for i, n in enumerate(self._nodes)}
-        self._parents = {n: [] for n in self._nodes}
-        self._children = {n: [] for n in self._nodes}
-        self._types = {n: bn_type.default_type for n in self._nodes}
+        self._index = {n: i for i, n in enumerate(joint)}
+        self._parents = {n: [] for n in joint}
+        self._children = {n: [] for n in joint}
+        self._types = {n: bn_type.default_type for n in joint}
         for n, t in node_types:
             self.set_node_type(n, t)
         for s, t in arcs:
@@ -109,7 +114,44 @@ class BayesianNetwork:
         return self._nodes[idx]
 
     def contains_node(self, node):
+        return node in self._index and node not in self._interface
+
+    # -- conditional networks (ConditionalBayesianNetworkBase, BayesianNetwork.hpp:140-222) ---------------------
+    def interface_nodes(self):
+        return list(self._interface)
+
+    def joint_nodes(self):
+        return self._nodes + self._interface
+
+    def num_interface_nodes(self):
+        return len(self._interface)
+
+    def num_joint_nodes(self):
+        return len(self._nodes) + len(self._interface)
+
+    def is_interface(self, node):
+        return node in self._interface
+
+    def contains_interface_node(self, node):
+        return node in self._interface
+
+    def contains_joint_node(self, node):
         return node in self._index
+
+    def conditional_bn(self, nodes=None, interface_nodes=None):
+        """BNGeneric::conditional_bn (BayesianNetwork.hpp:1064-1100): the same arcs and node types over a new split of
+        the variables into nodes and interface nodes (arcs into interface nodes are dropped)."""
+        if nodes is None:
+            nodes, interface_nodes = self._nodes, self._interface
+        interface_nodes = list(interface_nodes or [])
+        keep = set(nodes) | set(interface_nodes)
+        arcs = [(s, t) for s, t in self.arcs() if s in keep and t in set(nodes)]
+        types = [(n, t) for n, t in self._types.items() if n in keep]
+        return BayesianNetwork(self._type, list(nodes), arcs, [] if self._type.homogeneous else types, interface_nodes)
+
+    def unconditional_bn(self):
+        types = list(self._types.items())
+        return BayesianNetwork(self._type, self.joint_nodes(), self.arcs(), [] if self._type.homogeneous else types)
 
     def arcs(self):
         return [(p, n) for n in self._nodes for p in self._parents[n]]
@@ -146,12 +188,12 @@ class BayesianNetwork:
         return not (self._types[target] == DiscreteFactorType() and self._types[source] != DiscreteFactorType())
 
     def can_add_arc(self, source, target):
-        return source != target and self.can_have_arc(source, target) and (
+        return source != target and target not in self._interface and self.can_have_arc(source, target) and (
             not self._parents[source] or not self._children[target] or not self.has_path(target, source)
         )
 
     def can_flip_arc(self, source, target):
-        if source == target or not self.can_have_arc(target, source):
+        if source == target or source in self._interface or target in self._interface or not self.can_have_arc(target, source):
             return False
         if self.has_arc(source, target):
             if len(self._parents[target]) == 1 or len(self._children[source]) == 1:
@@ -168,6 +210,8 @@ class BayesianNetwork:
     def add_arc(self, source, target):
         if source not in self._index or target not in self._index:
             raise ValueError("Node not present in the Bayesian network.")
+        if target in self._interface:
+            raise ValueError(f"Interface node {target} cannot have parents.")
         if self.has_arc(source, target):
             return
         if not self.can_add_arc(source, target):
@@ -200,7 +244,7 @@ class BayesianNetwork:
         self._types[node] = node_type
 
     def clone(self):
-        return BayesianNetwork(self._type, self._nodes, self.arcs(), list(self._types.items()))
+        return BayesianNetwork(self._type, self._nodes, self.arcs(), list(self._types.items()), self._interface)
 
     # -- parameters: BayesianNetwork::fit / logl / slogl (models/BayesianNetwork.hpp:960-994) -------------------
     def _new_factor(self, df, node):
@@ -282,13 +326,15 @@ class BayesianNetwork:
         walks libstdc++ unordered_sets (roots, children), whose iteration order depends on the graph's edit history;
         here roots and children are visited in node-index order, so the result is a valid, deterministic order that
         need not be the reference's."""
-        incoming = {n: len(self._parents[n]) for n in self._nodes}
+        incoming = {n: sum(1 for p in self._parents[n] if p not in self._interface) for n in self._nodes}
         stack = [n for n in self._nodes if incoming[n] == 0]
         order = []
         while stack:
             u = stack.pop()
             order.append(u)
             for c in sorted(self._children[u], key=self._index.__getitem__):
+                if c not in incoming:
+                    continue
                 incoming[c] -= 1
                 if incoming[c] == 0:
                     stack.append(c)
@@ -309,28 +355,41 @@ class BayesianNetwork:
         for f in cpds:
             self._cpds[f.variable()] = f
 
-    def sample(self, n, seed=None, ordered=False):
+    def sample(self, n, seed=None, ordered=False, concat_evidence=False):
         """BNGeneric::sample (BayesianNetwork.hpp:1023-1062): ancestral sampling in topological order, node i of that
         order with seed + i; returns a pyarrow.RecordBatch (columns in topological order, or in nodes() order when
-        `ordered`)."""
+        `ordered`).  Conditional networks take the evidence table of the interface nodes instead of `n`
+        (ConditionalBayesianNetwork::sample(evidence, seed, concat_evidence, ordered), :1165-1215)."""
         import pyarrow as pa
 
+        from .factors import _random_seed
+
+        names, arrays = [], []
+        if self._interface:
+            from .dataset import as_record_batch
+
+            ev = as_record_batch(n)
+            if any(ev.schema.get_field_index(v) < 0 for v in self._interface):
+                raise ValueError("Evidence DataFrame does not contain all the interface nodes.")
+            n = ev.num_rows
+            names = list(self._interface)
+            arrays = [ev.column(ev.schema.get_field_index(v)) for v in names]
+        elif not isinstance(n, int):
+            raise ValueError("n should be an integer number of samples")
         if n < 0:
             raise ValueError("n should be a non-negative number")
         if not self.fitted():
             raise ValueError("Model not fitted.")
-        from .factors import _random_seed
-
         seed = _random_seed() if seed is None else int(seed)
-        names, arrays = [], []
         for i, node in enumerate(self.topological_sort()):
             parents = pa.RecordBatch.from_arrays(arrays, names=names) if arrays else None
             arrays.append(self._cpds[node].sample(n, parents, (seed + i) & 0xFFFFFFFF))
             names.append(node)
-        if ordered:
-            pos = {nm: i for i, nm in enumerate(names)}
-            arrays, names = [arrays[pos[nm]] for nm in self._nodes], list(self._nodes)
-        return pa.RecordBatch.from_arrays(arrays, names=names)
+        pos = {nm: i for i, nm in enumerate(names)}
+        out = list(self._nodes) if ordered else [nm for nm in names if nm not in self._interface]
+        if self._interface and concat_evidence:
+            out = out + list(self._interface)
+        return pa.RecordBatch.from_arrays([arrays[pos[nm]] for nm in out], names=out)
 
     def save(self, name, include_cpd=False):
         """BayesianNetwork::save (BayesianNetwork.hpp:643, util/pickle.hpp): pickle to `name`.pickle."""
@@ -341,13 +400,14 @@ class BayesianNetwork:
             pickle.dump(self, f, protocol=2)
 
     def __getstate__(self):
-        state = {"type": self._type, "nodes": self._nodes, "arcs": self.arcs(), "types": list(self._types.items())}
+        state = {"type": self._type, "nodes": self._nodes, "arcs": self.arcs(), "types": list(self._types.items()),
+                 "interface": self._interface}
         if getattr(self, "_include_cpd", False) and self.fitted():
             state["cpds"] = [self._cpds[n] for n in self._nodes]
         return state
 
     def __setstate__(self, state):
-        self.__init__(state["type"], state["nodes"], state["arcs"], state["types"])
+        self.__init__(state["type"], state["nodes"], state["arcs"], state["types"], state.get("interface", ()))
         if "cpds" in state:
             self._cpds = {f.variable(): f for f in state["cpds"]}
             self._include_cpd = True
@@ -380,6 +440,28 @@ def SemiparametricBN(nodes, arcs=(), node_types=()):
 
 def CLGNetwork(nodes, arcs=(), node_types=()):
     return BayesianNetwork(CLGNetworkType(), nodes, arcs, node_types)
+
+
+def ConditionalBayesianNetwork(bn_type, nodes, interface_nodes, arcs=(), node_types=()):
+    return BayesianNetwork(bn_type, list(nodes), arcs, node_types, list(interface_nodes))
+
+
+def ConditionalGaussianNetwork(nodes, interface_nodes, arcs=()):
+    return BayesianNetwork(GaussianNetworkType(), list(nodes), arcs, (), list(interface_nodes))
+
+
+def ConditionalKDENetwork(nodes, interface_nodes, arcs=()):
+    return BayesianNetwork(KDENetworkType(), list(nodes), arcs, (), list(interface_nodes))
+
+
+def ConditionalSemiparametricBN(nodes, interface_nodes, arcs=(), node_types=()):
+    if arcs and isinstance(arcs[0], (tuple, list)) and len(arcs[0]) == 2 and isinstance(arcs[0][1], FactorType):
+        node_types, arcs = arcs, ()
+    return BayesianNetwork(SemiparametricBNType(), list(nodes), arcs, node_types, list(interface_nodes))
+
+
+def ConditionalCLGNetwork(nodes, interface_nodes, arcs=(), node_types=()):
+    return BayesianNetwork(CLGNetworkType(), list(nodes), arcs, node_types, list(interface_nodes))
 
 
 def load(name):

@@ -246,7 +246,7 @@ class _DeviceScore(Score):
         return all(v in self._col for v in variables)
 
     def compatible_bn(self, model):
-        return self.has_variables(model.nodes())
+        return self.has_variables(model.joint_nodes() if hasattr(model, "joint_nodes") else model.nodes())
 
     def local_score(self, model, variable, evidence=None):
         evidence = model.parents(variable) if evidence is None else list(evidence)

@@ -234,3 +234,75 @@ def test_operator_set_piecewise_api_reproduces_estimate(ensure_built):
     pool.finished()
     with pytest.raises(ValueError):
         pool.find_max(fresh)
+
+
+# ---- conditional networks: interface nodes (operators.cpp:134-256,365-437; operators.hpp:526-578) ---------------------------
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("n,ni", [(5, 2), (8, 4), (6, 1)])
+def test_conditional_hc_matches_reference_restatement(ensure_built, n, ni, seed):
+    import pybnesian_amd as pbn
+
+    J = n + ni
+    names = [f"n{i}" for i in range(J)]
+    tcode = {LG: pbn.LinearGaussianCPDType(), CKDE: pbn.CKDEType()}
+    rng = np.random.default_rng(100 + seed)
+    for bn, validated, op_types, patience in (("gaussian", False, False, 0), ("spbn", True, True, 2)):
+        ts = TableScore(J, seed, validated=validated)
+        types = [int(t) for t in rng.integers(0, 2, size=J)] if bn == "spbn" else None
+        bl = [(int(a), int(b)) for a, b in zip(rng.integers(0, J, size=4), rng.integers(0, n, size=4)) if a != b]
+        wl = [(n, 0)] if seed % 2 == 0 else []          # whitelisted interface -> node arc
+        bl = [p for p in bl if p not in wl]
+        if bn == "gaussian":
+            start = pbn.ConditionalGaussianNetwork(names[:n], names[n:])
+        else:
+            start = pbn.ConditionalSemiparametricBN(names[:n], names[n:], [], [(names[i], tcode[t]) for i, t in enumerate(types)])
+        ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]) if op_types else pbn.ArcOperatorSet()
+        hc = pbn.GreedyHillClimbing()
+        res = hc.estimate(ops, ts, start, arc_blacklist=[(names[a], names[b]) for a, b in bl],
+                          arc_whitelist=[(names[a], names[b]) for a, b in wl], max_indegree=3, patience=patience)
+        score = lambda v, t, ps: ts.raw(v, t, ps, False)
+        vscore = (lambda v, t, ps: ts.raw(v, t, ps, True)) if validated else None
+        o_arcs, o_types, o_trace, info = hc_oracle.estimate(n, BN_CODE[bn], score, vscore, node_types=types, arc_blacklist=bl,
+                                                            arc_whitelist=wl, op_types=op_types, max_indegree=3, patience=patience,
+                                                            n_interface=ni)
+        idx = {nm: i for i, nm in enumerate(names)}
+        trace = []
+        for op in hc.last.trace:
+            if isinstance(op, pbn.ChangeNodeType):
+                trace.append((3, idx[op.node()], LG if op.node_type() == pbn.LinearGaussianCPDType() else CKDE, op.delta()))
+            else:
+                trace.append(({pbn.AddArc: 0, pbn.RemoveArc: 1, pbn.FlipArc: 2}[type(op)], idx[op.source()], idx[op.target()], op.delta()))
+        assert trace == o_trace
+        assert sorted((idx[s], idx[t]) for s, t in res.arcs()) == sorted(o_arcs)
+        assert hc.last.cells_scored == info["cells_scored"] and hc.last.iterations == info["iterations"]
+        assert res.interface_nodes() == names[n:] and res.nodes() == names[:n]
+        assert all(idx[t] < n for _, t in res.arcs())                       # nothing points into an interface node
+        if bn == "spbn":
+            assert [LG if res.node_type(nm) == pbn.LinearGaussianCPDType() else CKDE for nm in names[:n]] == o_types[:n]
+
+
+def test_conditional_network_surface(ensure_built):
+    import pybnesian_amd as pbn
+
+    m = pbn.ConditionalGaussianNetwork(["a", "b"], ["x", "y"], [("x", "a"), ("a", "b")])
+    assert m.nodes() == ["a", "b"] and m.interface_nodes() == ["x", "y"] and m.joint_nodes() == ["a", "b", "x", "y"]
+    assert m.num_nodes() == 2 and m.num_interface_nodes() == 2 and m.num_joint_nodes() == 4
+    assert m.is_interface("x") and not m.is_interface("a") and m.contains_joint_node("y") and not m.contains_node("y")
+    assert m.can_add_arc("y", "b") and not m.can_add_arc("a", "x") and not m.can_flip_arc("x", "a")
+    with pytest.raises(ValueError, match="cannot have parents"):
+        m.add_arc("a", "x")
+    u = m.unconditional_bn()
+    assert u.nodes() == ["a", "b", "x", "y"] and sorted(u.arcs()) == [("a", "b"), ("x", "a")] and not u.interface_nodes()
+    c = u.conditional_bn(["a", "b", "y"], ["x"])
+    assert c.interface_nodes() == ["x"] and sorted(c.arcs()) == [("a", "b"), ("x", "a")]
+    assert m.topological_sort() == ["a", "b"]
+    c2 = m.clone()
+    assert c2.interface_nodes() == ["x", "y"] and c2.arcs() == m.arcs()
+    m.add_cpds([pbn.LinearGaussianCPD("a", ["x"], [1.0, 2.0], 0.01), pbn.LinearGaussianCPD("b", ["a"], [0.0, -1.0], 0.01)])
+    import pandas as pd
+
+    ev = pd.DataFrame({"x": np.linspace(-1, 1, 50), "y": np.zeros(50)})
+    s = m.sample(ev, 3, concat_evidence=True, ordered=True)
+    assert s.schema.names == ["a", "b", "x", "y"]
+    a, b = s.column(0).to_numpy(), s.column(1).to_numpy()
+    assert np.allclose(a, 1.0 + 2.0 * ev["x"], atol=0.5) and np.allclose(b, -a, atol=0.5)

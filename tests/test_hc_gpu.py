@@ -2,6 +2,7 @@
 CPU oracle scores, on the reference's 4-variable test table, plus the behavioural assertions of
 /root/reference/tests/learning/algorithms/hillclimbing_test.py:8-58."""
 import numpy as np
+import pandas as pd
 import pytest
 
 from helpers import COLS, frame
@@ -134,3 +135,28 @@ def test_hc_convenience_wrapper(pbn, golden):
     assert res.num_arcs() == 2
     with pytest.raises(ValueError):
         pbn.hc(df, bn_type=pbn.GaussianNetworkType(), score="nope")
+
+
+def test_conditional_gaussian_network_hc_gpu(pbn):
+    """A conditional network on device scores: interface columns are parents only; learned arcs never enter them, and
+    fit / slogl of the result use factors of the nodes only (ConditionalBayesianNetwork, BayesianNetwork.hpp:140-222)."""
+    rng = np.random.default_rng(12)
+    n = 6000
+    x = rng.normal(size=n)
+    y = rng.normal(size=n)
+    a = 1.5 * x + rng.normal(scale=0.5, size=n)
+    b = -a + 0.8 * y + rng.normal(scale=0.5, size=n)
+    c = rng.normal(size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c, "x": x, "y": y})
+    score = pbn.BIC(df)
+    start = pbn.ConditionalGaussianNetwork(["a", "b", "c"], ["x", "y"])
+    res = pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), score, start)
+    arcs = set(res.arcs())
+    assert ("x", "a") in arcs and ("y", "b") in arcs and (("a", "b") in arcs or ("b", "a") in arcs)
+    assert all(t in ("a", "b", "c") for _, t in arcs) and res.interface_nodes() == ["x", "y"]
+    assert score.score(res) > score.score(start)
+    res.fit(df)
+    want = sum(res.cpd(v).slogl(df) for v in ("a", "b", "c"))
+    assert abs(res.slogl(df) - want) <= 1e-9 * abs(want)
+    with pytest.raises(ValueError, match="not compatible"):
+        pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), pbn.BIC(df[["a", "b", "c"]]), start)
