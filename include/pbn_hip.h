@@ -175,6 +175,9 @@ int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set)
 /* Bandwidth selector (PBN_SEL_*) of the CKDEs fitted while scoring: the reference passes it through the scores'
  * construction_args to CKDEType::new_factor (learning/scores/cv_likelihood.hpp:19-27). Default normal reference. */
 int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector);
+/* CKDE likelihood scores are assembled from A(S, m) = sum over a test region of log KDE(S) under the m-dimensional
+ * bandwidth rule; the engine remembers every A it has swept.  entries / sweeps so far. */
+int pbn_scoredata_cache_stats(const pbn_scoredata* sd, int64_t* entries, int64_t* sweeps);
 void pbn_scoredata_destroy(pbn_scoredata* sd);
 /* Dictionary-encoded columns (arrow::DictionaryArray indices, factors/discrete/discrete_indices.cpp): n_disc int32
  * arrays in SOURCE row order + cardinalities.  They get column ids n_cols .. n_cols+n_disc-1 in pbn_score_batch;

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pbn_scoredata_create_sharded": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, _int, _int, C.POINTER(_vp)]),
     "pbn_scoredata_moments": (_int, [_vp, _dp, C.POINTER(_i64), _int]),
     "pbn_scoredata_set_selector": (_int, [_vp, _int]),
+    "pbn_scoredata_cache_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
     "pbn_scoredata_set_validity": (_int, [_vp, C.POINTER(_vp)]),

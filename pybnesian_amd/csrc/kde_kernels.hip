@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void kde_finish_kernel(FinishArgs a) {
     constexpr int P = COND ? 4 : 2;
     constexpr double LN2 = 0.693147180559945309417232121458;
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double val = 0.0;
+    double val = 0.0, val_marg = 0.0;
     if (q < a.nq) {
         const double* p = a.part + q * P;
         const int64_t stride = a.nqtiles * 16 * P;
@@ -882,7 +882,11 @@ __global__ __launch_bounds__(256) void kde_finish_kernel(FinishArgs a) {
             }
         }
         double l = a.lognorm + LN2 * (m + log2(s));
-        if (COND) l = (a.lognorm + LN2 * (mjj + log2(sj))) - (a.lognorm_marg + LN2 * (m + log2(s)));
+        if (COND) {
+            const double lj = a.lognorm + LN2 * (mjj + log2(sj)), lm = a.lognorm_marg + LN2 * (m + log2(s));
+            l = lj - lm;
+            if (a.block_sums_marg) { l = lj; val_marg = lm; }   // the two sums separately (score engine's set cache)
+        }
         if (a.logl) a.logl[q] = l;
         val = l;
     }
@@ -895,6 +899,17 @@ __global__ __launch_bounds__(256) void kde_finish_kernel(FinishArgs a) {
         __syncthreads();
     }
     if (threadIdx.x == 0 && a.block_sums) a.block_sums[blockIdx.x] = red[0];
+    if (COND && a.block_sums_marg) {
+        __syncthreads();
+        red[threadIdx.x] = val_marg;
+        __syncthreads();
+#pragma unroll
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.block_sums_marg[blockIdx.x] = red[0];
+    }
 }
 
 // Final fixed-order reduction of the per-block sums (replaces the multi-pass sum1d of
@@ -1037,7 +1052,7 @@ void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, 
     }
 }
 
-void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st) {
+void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st, double* dev_sum_marg_out) {
     const int64_t nblocks = ceil_div(a.nq, 256);
     if (nblocks == 0) return;
     dim3 grid((unsigned)nblocks), block(256);
@@ -1048,6 +1063,10 @@ void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStrea
     HIP_CHECK(hipGetLastError());
     if (dev_sum_out) {
         hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const double*)a.block_sums, nblocks, dev_sum_out);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (dev_sum_marg_out && a.block_sums_marg) {
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const double*)a.block_sums_marg, nblocks, dev_sum_marg_out);
         HIP_CHECK(hipGetLastError());
     }
 }

@@ -58,6 +58,7 @@ struct FinishArgs {
     double lognorm_marg;
     double* logl;        // nullable
     double* block_sums;  // nullable
+    double* block_sums_marg;  // nullable, COND only: block_sums then holds the joint logl, this one the marginal logl
 };
 
 // query groups (of 16 rows) per wave: 4, except the fp64 CKDE sweep (two accumulator + exp sets per group)
@@ -72,7 +73,7 @@ int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, g
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);
-void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st);
+void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st, double* dev_sum_marg_out = nullptr);
 
 // CKDE::cdf (factors/continuous/CKDE.hpp:509-735): weights from the marginal sweep, normal cdf of the conditional mean.
 struct CdfArgs {

@@ -151,7 +151,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                      double* dev_logl, double* dev_sum, const int32_t* dev_rows) {
+                      double* dev_logl, double* dev_sum, const int32_t* dev_rows, double* dev_sum_marg) {
     check_cols(test, cols, m.d, "pbn_kde_logl");
     if (!dev_rows) check_range(test, row0, n, "pbn_kde_logl");
     if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
@@ -159,6 +159,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     HIP_CHECK(hipSetDevice(ctx->device));
     if (n == 0) {
         if (dev_sum) HIP_CHECK(hipMemsetAsync(dev_sum, 0, sizeof(double), ctx->stream));
+        if (dev_sum_marg) HIP_CHECK(hipMemsetAsync(dev_sum_marg, 0, sizeof(double), ctx->stream));
         return;
     }
     const size_t es = dtype_size(m.dtype);
@@ -200,12 +201,13 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, m.dtype, m.KS, m.cond, (int)nsplit, ctx->stream); }
 
     const int64_t nblocks = ceil_div(n, 256);
-    ctx->scratch_misc.reserve((size_t)nblocks * sizeof(double));
+    ctx->scratch_misc.reserve((size_t)nblocks * 2 * sizeof(double));
     FinishArgs fa{};
     fa.part = sa.part; fa.nsplit = (int)nsplit; fa.nqtiles = nqtiles; fa.nq = n;
     fa.lognorm = m.lognorm; fa.lognorm_marg = m.lognorm_marg;
     fa.logl = dev_logl; fa.block_sums = dev_sum ? (double*)ctx->scratch_misc.p : nullptr;
-    { KernelTimer kt(ctx, PBN_K_FINISH); launch_finish(fa, m.cond, dev_sum, ctx->stream); }
+    fa.block_sums_marg = (m.cond && dev_sum && dev_sum_marg) ? (double*)ctx->scratch_misc.p + nblocks : nullptr;
+    { KernelTimer kt(ctx, PBN_K_FINISH); launch_finish(fa, m.cond, dev_sum, ctx->stream, dev_sum_marg); }
 }
 
 }  // namespace pbn

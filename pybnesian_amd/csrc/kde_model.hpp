@@ -38,8 +38,10 @@ void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const i
                     int64_t row1, const int32_t* dev_rows = nullptr);
 
 // pack(queries) -> sweep -> finish on the context stream; dev_logl / dev_sum nullable (device pointers).
+// dev_sum_marg (CKDE only, nullable): dev_sum then receives the sum of the JOINT log-densities and dev_sum_marg the sum
+// of the marginal ones, instead of their difference.
 void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                      double* dev_logl, double* dev_sum, const int32_t* dev_rows = nullptr);
+                      double* dev_logl, double* dev_sum, const int32_t* dev_rows = nullptr, double* dev_sum_marg = nullptr);
 
 // Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
 void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);

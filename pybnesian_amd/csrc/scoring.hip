@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <numeric>
 #include <random>
 
@@ -418,6 +419,7 @@ int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set)
         }
         if (sd->n_hold > 0) sd->hold.N = sd->n_hold;
         sd->partial = false;
+        sd->kde_cache.clear();
     });
 }
 
@@ -470,6 +472,16 @@ int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
         if (!sd) throw invalid_error("pbn_scoredata_set_selector: null argument");
         if (selector != PBN_SEL_NORMAL_REFERENCE && selector != PBN_SEL_SCOTT) throw invalid_error("pbn_scoredata_set_selector: unknown selector");
         sd->selector = selector;
+        sd->kde_cache.clear();
+    });
+}
+
+// Set-function cache of the CKDE likelihood scores: entries held, sweeps launched so far.
+int pbn_scoredata_cache_stats(const pbn_scoredata* sd, int64_t* entries, int64_t* sweeps) {
+    return guarded([&] {
+        if (!sd) throw invalid_error("pbn_scoredata_cache_stats: null argument");
+        if (entries) *entries = (int64_t)sd->kde_cache.size();
+        if (sweeps) *sweeps = sd->kde_sweeps;
     });
 }
 
@@ -656,50 +668,123 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             n_units += units;
         }
         if (!pending.empty()) {
-            dev_buf<double> dsums((size_t)n_units);
-            HIP_CHECK(hipMemsetAsync(dsums.p, 0, (size_t)n_units * sizeof(double), ctx->stream));
+            // ---- CKDE likelihood units through the set-function cache ------------------------------------------------
+            // slogl of a CKDE on a test region = A(vars, d) - A(parents, d), with A(S, m) = sum_q log KDE(S) under the
+            // bandwidth rule evaluated for m dimensions on the region's training rows: the marginal of the reference
+            // (CKDE.hpp:186-199) is the KDE of the parents with H[1:,1:], and H = k(N, d) cov, so both terms are
+            // functions of a variable SET (and m, and the region) only.  A({s,t}, 2) serves s -> t and t -> s,
+            // A({s}, 2) serves every child of s: each is swept once and remembered for the life of the score data.
+            // Neither term known: one fused sweep yields both; one known: a plain sweep of the other.
+            struct Term { double value = 0; int slot = -1; };           // cached value, or slot in the device sums
+            std::map<std::vector<int>, int> scheduled;                    // key -> slot (this batch)
+            std::vector<std::vector<int>> slot_key;
+            auto key_of = [&](int region, int m, const int* v, int nv) {
+                std::vector<int> k(v, v + nv);
+                std::sort(k.begin(), k.end());
+                k.insert(k.begin(), {region, m});
+                return k;
+            };
+            auto lookup = [&](const std::vector<int>& key, Term& t) {
+                auto it = sd->kde_cache.find(key);
+                if (it != sd->kde_cache.end()) { t.value = it->second; return true; }
+                auto is = scheduled.find(key);
+                if (is != scheduled.end()) { t.slot = is->second; return true; }
+                return false;
+            };
+            auto new_slot = [&](const std::vector<int>& key) {
+                const int slot = (int)slot_key.size();
+                slot_key.push_back(key);
+                scheduled[key] = slot;
+                return slot;
+            };
+            struct Unit { int cand; Term joint, marg; bool has_marg; };
+            std::vector<Unit> units_v;
+            struct Work { int cand, f, mode, slot_j, slot_m; };          // mode 0 fused, 1 joint only, 2 marginal only
+            std::vector<Work> work;
+            const bool cv = kind == PBN_SCORE_CVLIK;
             for (const Pending& pd : pending) {
                 const int c = pd.cand;
-                const int p = par_off[c + 1] - par_off[c];
-                const int d = p + 1;
+                const int p = par_off[c + 1] - par_off[c], d = p + 1;
+                cols.resize(d);
+                cols[0] = var[c];
+                for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
+                for (int f = 0; f < pd.units; ++f) {
+                    const int region = cv ? f : sd->k;                    // fold index, or the hold-out region
+                    Unit u{c, {}, {}, p > 0};
+                    const std::vector<int> kj = key_of(region, d, cols.data(), d);
+                    const bool have_j = lookup(kj, u.joint);
+                    bool have_m = true;
+                    std::vector<int> km;
+                    if (p > 0) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup(km, u.marg); }
+                    if (!have_j && !have_m) {
+                        u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
+                        work.push_back({c, f, 0, u.joint.slot, u.marg.slot});
+                    } else if (!have_j) {
+                        u.joint.slot = new_slot(kj);
+                        work.push_back({c, f, 1, u.joint.slot, -1});
+                    } else if (!have_m) {
+                        u.marg.slot = new_slot(km);
+                        work.push_back({c, f, 2, -1, u.marg.slot});
+                    }
+                    units_v.push_back(u);
+                }
+            }
+            const size_t nslots = slot_key.size();
+            dev_buf<double> dsums(std::max<size_t>(1, nslots));
+            HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, nslots) * sizeof(double), ctx->stream));
+            auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+            for (const Work& w : work) {
+                const int c = w.cand;
+                const int p = par_off[c + 1] - par_off[c], d = p + 1;
                 cols.resize(d);
                 cols[0] = var[c];
                 for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
                 mu.resize(d); sse.resize((size_t)d * d); H.resize((size_t)d * d);
-                for (int f = 0; f < pd.units; ++f) {
-                    const bool cv = kind == PBN_SCORE_CVLIK;
-                    const Stats* tr = &sd->all;
-                    int64_t row0 = 0, n0 = sd->n_cv, row1 = 0, te0 = sd->n_cv, te_n = sd->n_hold;
-                    if (cv) {
-                        stats_minus(sd->all, sd->fold[f], train);
-                        tr = &train;
-                        n0 = sd->limits[f]; row1 = sd->limits[f + 1];
-                        te0 = sd->limits[f]; te_n = sd->limits[f + 1] - sd->limits[f];
-                    }
-                    subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
-                    const double inv = 1.0 / (double)(tr->N - 1);
-                    for (auto& x : sse) x *= inv;  // covariance
-                    bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
-                    KdeModel m;
-                    kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
-                    const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
-                    ctx->scratch_train.reserve(pb.apack + pb.nxpack + pb.axpack + 768);
-                    char* base = ctx->scratch_train.p;
-                    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
-                    m.Apack = base;
-                    m.nxpack = base + align(pb.apack);
-                    m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
-                    kde_pack_train(ctx, m, t, cols.data(), row0, n0, row1);
-                    kde_eval_enqueue(ctx, m, t, cols.data(), te0, te_n, nullptr, dsums.p + pd.unit0 + f);
+                const Stats* tr = &sd->all;
+                int64_t row0 = 0, n0 = sd->n_cv, row1 = 0, te0 = sd->n_cv, te_n = sd->n_hold;
+                if (cv) {
+                    stats_minus(sd->all, sd->fold[w.f], train);
+                    tr = &train;
+                    n0 = sd->limits[w.f]; row1 = sd->limits[w.f + 1];
+                    te0 = sd->limits[w.f]; te_n = sd->limits[w.f + 1] - sd->limits[w.f];
                 }
+                subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
+                const double inv = 1.0 / (double)(tr->N - 1);
+                for (auto& x : sse) x *= inv;  // covariance
+                bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
+                KdeModel m;
+                const int* use_cols = cols.data();
+                if (w.mode == 2) {            // KDE of the parents with the bandwidth block H[1:, 1:]
+                    std::vector<double> Hm((size_t)p * p);
+                    for (int j = 0; j < p; ++j)
+                        for (int i = 0; i < p; ++i) Hm[i + (size_t)j * p] = H[(i + 1) + (size_t)(j + 1) * d];
+                    kde_prepare(m, sd->dtype, p, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
+                    use_cols = cols.data() + 1;
+                } else {
+                    kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, w.mode == 0, mu.data());
+                }
+                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
+                ctx->scratch_train.reserve(pb.apack + pb.nxpack + pb.axpack + 768);
+                char* base = ctx->scratch_train.p;
+                m.Apack = base;
+                m.nxpack = base + align(pb.apack);
+                m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
+                kde_pack_train(ctx, m, t, use_cols, row0, n0, row1);
+                if (w.mode == 0 && m.cond)
+                    kde_eval_enqueue(ctx, m, t, use_cols, te0, te_n, nullptr, dsums.p + w.slot_j, nullptr, dsums.p + w.slot_m);
+                else
+                    kde_eval_enqueue(ctx, m, t, use_cols, te0, te_n, nullptr, dsums.p + (w.mode == 2 ? w.slot_m : w.slot_j));
             }
-            std::vector<double> hs((size_t)n_units);
-            HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, (size_t)n_units * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            std::vector<double> hs(std::max<size_t>(1, nslots));
+            if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            for (const Pending& pd : pending) {
-                double acc = 0.0;
-                for (int f = 0; f < pd.units; ++f) acc += hs[pd.unit0 + f];
-                out[pd.cand] = acc;
+            for (size_t i = 0; i < nslots; ++i) sd->kde_cache[slot_key[i]] = hs[i];
+            sd->kde_sweeps += (int64_t)work.size();
+            for (const Pending& pd : pending) out[pd.cand] = 0.0;
+            for (const Unit& u : units_v) {
+                const double j = u.joint.slot >= 0 ? hs[u.joint.slot] : u.joint.value;
+                const double mg = !u.has_marg ? 0.0 : (u.marg.slot >= 0 ? hs[u.marg.slot] : u.marg.value);
+                out[u.cand] += j - mg;
             }
         }
     });

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <limits>
+#include <map>
 #include <vector>
 
 #include "common.hpp"
@@ -36,6 +37,9 @@ struct pbn_scoredata {
     int split = PBN_SPLIT_NONE;
     int k = 0;
     int selector = PBN_SEL_NORMAL_REFERENCE;  // bandwidth selector of the CKDEs fitted while scoring
+    // A(S, m) of the CKDE likelihood scores, keyed by [region, m, sorted columns...] (see pbn_score_batch)
+    std::map<std::vector<int>, double> kde_cache;
+    int64_t kde_sweeps = 0;
     bool partial = false;  // moments hold only this rank's row share (pbn_scoredata_create_sharded)
     const pbn_table* src = nullptr;  // caller's table (borrowed)
     pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)

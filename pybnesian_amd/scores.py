@@ -290,6 +290,12 @@ class _DeviceScore(Score):
     def _batch_params(self, model):
         return self._params
 
+    def kde_cache_stats(self):
+        """(entries, sweeps) of the engine's set-function cache for CKDE likelihood scores."""
+        e, w = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().pbn_scoredata_cache_stats(self._handle, C.byref(e), C.byref(w)))
+        return e.value, w.value
+
     # -- split layout ------------------------------------------------------------------------------------------
     def _layout(self):
         """(perm, limits, n_cv, n_hold): source row of every split-ordered row, fold limits, region sizes."""
