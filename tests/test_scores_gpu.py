@@ -389,3 +389,52 @@ def test_construction_args_bandwidth_selector(pbn):
     cpd.fit(hold.training_data())
     want = cpd.slogl(hold.test_data())
     assert abs(hold.local_score(model, "c", ["a"]) - want) <= 1e-9 * abs(want)
+
+
+def test_ckde_set_function_cache_paths(pbn):
+    """CKDE likelihood scores through the engine's set-function cache: whichever of the fused / joint-only /
+    marginal-only / fully-cached paths a candidate takes (it depends on what was scored before), the value equals the
+    explicit per-fold CKDE fit + slogl; all ordered pairs cost one joint sweep per unordered pair."""
+    rng = np.random.default_rng(31)
+    n, k = 2500, 3
+    a = rng.normal(size=n)
+    b = np.tanh(a) + rng.normal(scale=0.4, size=n)
+    c = a * b + rng.normal(scale=0.5, size=n)
+    d = rng.normal(size=n) - 0.5 * c
+    df = pd.DataFrame({"a": a, "b": b, "c": c, "d": d})
+    names = list(df.columns)
+    model = pbn.SemiparametricBN(names, [], [(v, pbn.CKDEType()) for v in names])
+
+    def explicit(score, var, ev):
+        tot = 0.0
+        for tr, te in score.cv.indices():
+            cpd = pbn.CKDE(var, ev)
+            cpd.fit(df.iloc[tr])
+            tot += cpd.slogl(df.iloc[te])
+        return tot
+
+    cands = [(v, [e]) for v in names for e in names if e != v] + [("a", []), ("c", ["a", "b"]), ("d", ["c", "a", "b"]), ("b", ["a", "c"])]
+    orders = [list(range(len(cands))), list(reversed(range(len(cands)))), list(rng.permutation(len(cands)))]
+    results = []
+    for order in orders:
+        score = pbn.CVLikelihood(df, k=k, seed=4)
+        got = {}
+        for i in order:                                   # one candidate per call: every cache state is exercised
+            v, ev = cands[i]
+            got[i] = score.local_score(model, v, ev)
+        results.append(got)
+        if order is orders[0]:
+            want = {i: explicit(score, *cands[i]) for i in range(len(cands))}
+        for i in range(len(cands)):
+            assert abs(got[i] - want[i]) <= 1e-9 * abs(want[i]), (cands[i], got[i], want[i])
+    for got in results[1:]:
+        assert all(abs(got[i] - results[0][i]) <= 1e-11 * abs(results[0][i]) for i in got)
+    # batched: the 12 ordered pairs need 6 joint sets + 4 marginal sets per fold, however they are evaluated
+    score = pbn.CVLikelihood(df, k=k, seed=4)
+    pairs = [(v, pbn.CKDEType(), [e]) for v in names for e in names if e != v]
+    vals = score._batch(model, pairs, score._kind)
+    entries, sweeps = score.kde_cache_stats()
+    assert entries == (6 + 4) * k and sweeps <= (6 + 1) * k + 4 * k
+    assert np.allclose(vals, [results[0][i] for i in range(12)], rtol=1e-11)
+    again = score._batch(model, pairs, score._kind)      # everything cached now: no new sweeps, identical values
+    assert score.kde_cache_stats() == (entries, sweeps) and np.array_equal(vals, again)
