@@ -104,6 +104,16 @@ void pbn_kde_destroy(pbn_kde* k);
 int64_t pbn_kde_num_instances(const pbn_kde* k);
 double pbn_kde_lognorm(const pbn_kde* k, int which); /* 0 joint / plain, 1 marginal (CKDE only)      */
 
+/* UCV bandwidth selection (kde/UCV.{hpp,cpp}; sum_ucv_* / ucv_diag kernels, kde/opencl_kernels/KDE.cl.src:470-574).
+ * pbn_ucv_score: N * UCV(bandwidth) = UCVScorer::score_unconstrained / score_diagonal (UCV.cpp:226-360); the two
+ * pair sums come from one self-sweep of the training rows.  pbn_ucv_bandwidth: UCV::bandwidth / diag_bandwidth
+ * (:452-526) - a Nelder-Mead search (the reference uses NLopt's LN_NELDERMEAD, ftol_rel = xtol_rel = 1e-4) from
+ * `start`, the normal reference bandwidth; kind = PBN_BW_FULL (d*d col-major) or PBN_BW_DIAG (d variances). */
+int pbn_ucv_score(pbn_ctx* ctx, const pbn_table* table, const int* cols, int d, int64_t row0, int64_t n,
+                  const double* bandwidth, int kind, double* out);
+int pbn_ucv_bandwidth(pbn_ctx* ctx, const pbn_table* table, const int* cols, int d, int64_t row0, int64_t n, int kind,
+                      const double* start, double* out, int64_t* n_evals);
+
 /* logl: replaces KDE::_logl / ProductKDE::_logl / CKDE::_logl (KDE.hpp:513-547,
  * ProductKDE.hpp:192-238, CKDE.hpp:202-254).  Writes n doubles to HOST `out` (dev_out: DEVICE). */
 int pbn_kde_logl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out);

@@ -178,6 +178,32 @@ def discrete_sample(n, logprob, card, seed, parent_offset=None):
     return out
 
 
+def ucv_score(data, bandwidth):
+    """N * UCV(H) (kde/UCV.cpp:226-360 with the pair terms of kde/opencl_kernels/KDE.cl.src:470-574): all i < j pairs,
+    in the table's dtype for the kernel terms.  bandwidth: d x d matrix or vector of d variances."""
+    dt = np.float32 if data.dtype == np.float32 else np.float64
+    X = np.asarray(data, dtype=dt)
+    N, d = X.shape
+    bw = np.asarray(bandwidth, dtype=np.float64)
+    if bw.ndim == 1:
+        L = np.diag(np.sqrt(bw))
+    else:
+        L = np.linalg.cholesky(bw)
+    lognorm_H = dt(-np.log(np.diag(L)).sum() - 0.5 * d * np.log(2 * np.pi))
+    lognorm_2H = dt(lognorm_H - 0.5 * d * np.log(2.0))
+    Ld = L.astype(dt)
+    import scipy.linalg as sla
+
+    s2h = sh = 0.0
+    for i in range(1, N):
+        diff = (X[i][None, :] - X[:i]).T                                   # pairs (i, j < i)
+        z = sla.solve_triangular(Ld, diff, lower=True, check_finite=False).astype(dt)
+        dist = (z * z).sum(axis=0, dtype=dt)
+        s2h += float(np.exp((dt(-0.25) * dist + lognorm_2H).astype(dt)).sum(dtype=np.float64))
+        sh += float(np.exp((dt(-0.5) * dist + lognorm_H).astype(dt)).sum(dtype=np.float64))
+    return float(np.exp(np.float64(lognorm_2H)) + 2 * s2h / N - 4 * sh / (N - 1))
+
+
 def shuffled_indices(n, seed):
     idx = np.arange(n, dtype=np.int32)
     lib().oracle_shuffle(_dp(idx), C.c_int64(n), C.c_uint32(seed))

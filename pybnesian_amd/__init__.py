@@ -7,7 +7,7 @@ HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
 from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
 from .dataset import Context, DeviceTable, default_context  # noqa: F401
 from .factors import CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, Factor, LinearGaussianCPD  # noqa: F401
-from .kde import KDE, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
+from .kde import KDE, UCV, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
 from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, MMHC, OperatorPool, OperatorTabuSet, RemoveArc, hc)
@@ -23,6 +23,6 @@ __all__ = [
     "ArcOperatorSet", "ChangeNodeTypeSet", "OperatorPool", "OperatorTabuSet", "LocalScoreCache", "AddArc", "RemoveArc", "FlipArc", "ChangeNodeType",
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
-    "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth",
+    "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth", "UCV",
     "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "load", "Context", "DeviceTable", "default_context", "load_library",
 ]

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pbn_table_read": (_int, [_vp, _ip, _int, _vp]),
     "pbn_table_sse": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
     "pbn_bandwidth": (_int, [_int, _int, _dp, _int, _i64, _int, _dp]),
+    "pbn_ucv_score": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _int, _dp]),
+    "pbn_ucv_bandwidth": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _int, _dp, _dp, C.POINTER(_i64)]),
     "pbn_kde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _int, _dp, C.POINTER(_vp)]),
     "pbn_ckde_fit": (_int, [_vp, _vp, _ip, _int, _i64, _i64, _dp, _dp, C.POINTER(_vp)]),
     "pbn_kde_destroy": (None, [_vp]),

@@ -747,8 +747,11 @@ __device__ __forceinline__ double half_erfc<double>(double x) { return 0.5 * erf
 template <>
 __device__ __forceinline__ float half_erfc<float>(float x) { return 0.5f * erfcf(x); }
 
-template <typename T, int KS, int QG, bool CDF>
+// MODE 0: weights only (CKDE::sample), 1: weights x normal cdf (CKDE::cdf), 2: sum w and sum sqrt(w) with the offset
+// pinned at 0 (UCV: K_2H = sqrt of the un-normalised K_H; self pairs keep every exponent <= 0)
+template <typename T, int KS, int QG, int MODE>
 __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
+    constexpr bool CDF = MODE == 1;
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
             V acc = nx + ny[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(Ap[(t0 * KS + ks) * 64 + lane], b[g][ks], acc);
-            m[g] = colmax<T>(max4<T>(acc));
+            m[g] = MODE == 2 ? (T)0 : colmax<T>(max4<T>(acc));
             cm[g] = ny[g] - m[g];
         }
     }
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
             T w0 = Tr<T>::ex2(acc[0]), w1 = Tr<T>::ex2(acc[1]), w2 = Tr<T>::ex2(acc[2]), w3 = Tr<T>::ex2(acc[3]);
             T ts = (w0 + w1) + (w2 + w3);
-            if (__builtin_expect(__any(!(ts < Tr<T>::big())), 0)) {
+            if (MODE != 2 && __builtin_expect(__any(!(ts < Tr<T>::big())), 0)) {
                 const T mx = colmax<T>(max4<T>(acc));
                 if (mx > (T)0) {
                     m[g] += mx;
@@ -815,6 +818,7 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
             }
             // Phi((x_q - mu_t)/sigma_c) = 1/2 erfc((u_t - u_q)), u pre-divided by sqrt 2 (KDE.cl.src:448-456)
             sw[g] += (double)ts;
+            if (MODE == 2) sc[g] += (double)((sqrt(w0) + sqrt(w1)) + (sqrt(w2) + sqrt(w3)));
             if (CDF) {
                 const T c = (w0 * half_erfc<T>(ut[0] - uq[g]) + w1 * half_erfc<T>(ut[1] - uq[g])) +
                             (w2 * half_erfc<T>(ut[2] - uq[g]) + w3 * half_erfc<T>(ut[3] - uq[g]));
@@ -940,7 +944,7 @@ void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
-template <typename T, bool CDF>
+template <typename T, int CDF>
 static void launch_cdf_t(const CdfArgs& a, int KS, dim3 grid, hipStream_t st) {
     dim3 block(256);
     switch (KS) {
@@ -957,8 +961,46 @@ static void launch_cdf_t(const CdfArgs& a, int KS, dim3 grid, hipStream_t st) {
 void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st) {
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * 2), (unsigned)nsplit);
     const bool cdf = a.utrain != nullptr;
-    if (dtype == PBN_F64) { if (cdf) launch_cdf_t<double, true>(a, KS, grid, st); else launch_cdf_t<double, false>(a, KS, grid, st); }
-    else                  { if (cdf) launch_cdf_t<float, true>(a, KS, grid, st); else launch_cdf_t<float, false>(a, KS, grid, st); }
+    if (dtype == PBN_F64) { if (cdf) launch_cdf_t<double, 1>(a, KS, grid, st); else launch_cdf_t<double, 0>(a, KS, grid, st); }
+    else                  { if (cdf) launch_cdf_t<float, 1>(a, KS, grid, st); else launch_cdf_t<float, 0>(a, KS, grid, st); }
+}
+
+// UCV pair sums: part[split][query] = (0, sum_t w, sum_t sqrt w, 0) with w = 2^(s2(t, q)); then the two totals over the
+// first nq queries and all splits, fixed order.
+__global__ __launch_bounds__(256) void ucv_block_sums_kernel(const double* __restrict__ part, int nsplit, int64_t nqtiles, int64_t nq,
+                                                              double* __restrict__ block_w, double* __restrict__ block_r) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double w = 0.0, r = 0.0;
+    if (q < nq) {
+        const int64_t stride = nqtiles * 16 * 4;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            w += part[sp * stride + q * 4 + 1];
+            r += part[sp * stride + q * 4 + 2];
+        }
+    }
+    __shared__ double red[256];
+    for (int pass = 0; pass < 2; ++pass) {
+        red[threadIdx.x] = pass ? r : w;
+        __syncthreads();
+#pragma unroll
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) (pass ? block_r : block_w)[blockIdx.x] = red[0];
+        __syncthreads();
+    }
+}
+
+void launch_ucv(const CdfArgs& a, int dtype, int KS, int nsplit, int64_t nq, double* block_scratch, double* dev_out2, hipStream_t st) {
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * 2), (unsigned)nsplit);
+    if (dtype == PBN_F64) launch_cdf_t<double, 2>(a, KS, grid, st); else launch_cdf_t<float, 2>(a, KS, grid, st);
+    const int64_t nblocks = ceil_div(nq, 256);
+    hipLaunchKernelGGL(ucv_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, a.part, nsplit, a.nqtiles, nq, block_scratch,
+                       block_scratch + nblocks);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const double*)block_scratch, nblocks, dev_out2);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const double*)(block_scratch + nblocks), nblocks, dev_out2 + 1);
+    HIP_CHECK(hipGetLastError());
 }
 
 void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t nq, double* dev_out, hipStream_t st) {

@@ -88,6 +88,8 @@ struct CdfArgs {
 };
 void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st);
 void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st);
+// UCV (kde/UCV.cpp:300-360): dev_out2[0] = sum over all ordered pairs (t, q < nq) of w, dev_out2[1] = of sqrt(w).
+void launch_ucv(const CdfArgs& a, int dtype, int KS, int nsplit, int64_t nq, double* block_scratch, double* dev_out2, hipStream_t st);
 void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t nq, double* dev_out, hipStream_t st);
 
 }  // namespace pbn

@@ -1,9 +1,9 @@
 """Sharding of a score batch over the GPUs of one node (one process per GPU, torch.distributed with the
 "nccl" backend = RCCL over xGMI; "gloo" on CPU for tests).
 
-Independent units = candidates: every rank holds the whole table, scores the candidates
-i with i % world == rank on its own GPU, and one all_gather of <= n^2 doubles per batch gives every rank
-the full result in fixed rank order, so that all ranks take the same deterministic find_max decision.
+Independent units = candidates: every rank holds the whole table, scores its share of the candidates
+(dealt by variable set, see sharded_batch) on its own GPU, and one all_gather of <= n^2 doubles per batch gives every
+rank the full result in fixed rank order, so that all ranks take the same deterministic find_max decision.
 No other collective is on the data path.
 """
 import numpy as np
@@ -53,9 +53,18 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
 
     rank, world = dist.get_rank(), dist.get_world_size()
     m = len(heavy)
-    mine = [heavy[j] for j in shard_indices(m, rank, world)]
+    # candidates over the same variable set (s -> t and t -> s share their joint KDE sum in the engine's set-function
+    # cache) go to the same rank: sets are dealt round-robin in order of first appearance, identically on every rank
+    set_of, owner = {}, []
+    for i in heavy:
+        key = tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))
+        if key not in set_of:
+            set_of[key] = len(set_of) % world
+        owner.append(set_of[key])
+    lists = [[heavy[j] for j in range(m) if owner[j] == r] for r in range(world)]
+    mine = lists[rank]
     local = sub(mine) if mine else np.zeros(0)
-    per = (m + world - 1) // world
+    per = max(1, max(len(l) for l in lists))
     buf = np.zeros(per)
     buf[: len(mine)] = local
     backend = dist.get_backend()
@@ -65,8 +74,7 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
     dist.all_gather_into_tensor(recv, send)
     allv = recv.cpu().numpy().reshape(world, per)
     for r in range(world):
-        idx = shard_indices(m, r, world)
-        out[[heavy[j] for j in idx]] = allv[r, : len(idx)]
+        out[lists[r]] = allv[r, : len(lists[r])]
     return out
 
 

@@ -86,6 +86,60 @@ class ScottsBandwidth(_LibrarySelector):
         return "ScottsBandwidth"
 
 
+class UCV(BandwidthSelector):
+    """Unbiased cross-validation selector (kde/UCV.hpp:47-56, UCV.cpp:452-526): minimises N * UCV(H) from the normal
+    reference bandwidth.  The pair sums of the objective are one self-sweep on the device per evaluation; the simplex
+    search restates NLopt's LN_NELDERMEAD (the optimiser's trajectory is not pinned against a reference build)."""
+
+    def __init__(self):
+        self.last_evaluations = 0
+
+    def _run(self, df, variables, kind):
+        import ctypes as C
+
+        variables = list(variables)
+        if not variables:
+            return np.zeros((0, 0)) if kind == _lib.PBN_BW_FULL else np.zeros(0)
+        rb = as_record_batch(df)
+        ctx = default_context()
+        table, _, n, cov = _covariance(ctx, rb, variables)
+        start = NormalReferenceRule()._from_cov(kind, cov, n, table.dtype)
+        d = len(variables)
+        out = np.zeros((d, d), order="F") if kind == _lib.PBN_BW_FULL else np.zeros(d)
+        ev = C.c_int64(0)
+        _lib.check(_lib.load().pbn_ucv_bandwidth(ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, n, kind,
+                                                 _lib.dptr(np.asfortranarray(start)), _lib.dptr(out), C.byref(ev)))
+        self.last_evaluations = ev.value
+        return out
+
+    def bandwidth(self, df, variables):
+        return self._run(df, variables, _lib.PBN_BW_FULL)
+
+    def diag_bandwidth(self, df, variables):
+        return self._run(df, variables, _lib.PBN_BW_DIAG)
+
+    def score(self, df, variables, bandwidth):
+        """UCVScorer: N * UCV(bandwidth); a d x d matrix or a vector of d variances."""
+        import ctypes as C
+
+        variables = list(variables)
+        rb = as_record_batch(df)
+        ctx = default_context()
+        table, _ = DeviceTable.from_dataframe(ctx, rb, variables)
+        bw = np.asarray(bandwidth, dtype=np.float64)
+        kind = _lib.PBN_BW_FULL if bw.ndim == 2 else _lib.PBN_BW_DIAG
+        d = len(variables)
+        if bw.shape != ((d, d) if bw.ndim == 2 else (d,)):
+            raise ValueError(f"Wrong dimension for bandwidth. it should be a {d}x{d} matrix or a {d} vector.")
+        out = C.c_double(0.0)
+        _lib.check(_lib.load().pbn_ucv_score(ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, table.num_rows,
+                                             _lib.dptr(np.asfortranarray(bw)), kind, C.byref(out)))
+        return out.value
+
+    def __str__(self):
+        return "UCV"
+
+
 class _KDEBase:
     _kind = _lib.PBN_BW_FULL
     _name = "KDE"
