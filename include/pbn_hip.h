@@ -198,6 +198,11 @@ int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* con
  * NULL when the column has no nulls (valid_rows / combined_bitmap semantics of bic.cpp:12-27, bge.hpp:184-234). */
 int pbn_scoredata_set_validity(pbn_scoredata* sd, const uint8_t* const* masks);
 /* perm: n_rows ints (source row of every permuted row); limits: k+1 fold limits; all nullable. */
+/* The split layout alone, host only (dataset::CrossValidation / HoldOut as stand-alone objects,
+ * dataset/crossvalidation_adaptator.hpp:15-58, holdout_adaptator.hpp:17-61): perm[n_rows] = source row of every
+ * split-ordered row, limits[k+1] fold limits (nullable), sizes of the CV/training and hold-out regions. */
+int pbn_split_layout(int64_t n_rows, int split, int k, uint32_t seed, double test_ratio, int32_t* perm, int32_t* limits,
+                     int64_t* n_cv, int64_t* n_hold);
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold);
 /* MLE<LinearGaussianCPD>::estimate (learning/parameters/mle_LinearGaussianCPD.hpp:195-221) from the cached
  * moments of the training region: beta has p+1 entries (intercept first). */
@@ -309,6 +314,9 @@ void pbn_mi_destroy(pbn_mi* h);
 int pbn_mi_value(pbn_mi* h, int v1, int v2, int n_cond, const int* cond, double* mi, double* df);
 double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
 int pbn_mi_set_order(pbn_mi* h, int n, const int* ids);
+/* ChiSquare::pvalue (learning/independences/discrete/chi_square.cpp:8-139) over the discrete columns of the same
+ * handle (pbn_ci_pvalue_fn signature). */
+double pbn_chisq_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes);
 /* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
  * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies

@@ -5,14 +5,14 @@ Only the hot path of SURVEY.md §8 lives here.  Everything numerical runs in lib
 HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
 """
 from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
-from .dataset import Context, DeviceTable, default_context  # noqa: F401
+from .dataset import Context, CrossValidation, DeviceTable, HoldOut, default_context  # noqa: F401
 from .factors import CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, Factor, LinearGaussianCPD  # noqa: F401
 from .kde import KDE, UCV, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
 from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, MMHC, OperatorPool, OperatorTabuSet, RemoveArc, hc)
-from .independences import IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
-from .models import (BayesianNetwork, ConditionalBayesianNetwork, ConditionalCLGNetwork, ConditionalGaussianNetwork,  # noqa: F401
+from .independences import ChiSquare, IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
+from .models import (BayesianNetwork, BayesianNetworkType, FactorType, ConditionalBayesianNetwork, ConditionalCLGNetwork, ConditionalGaussianNetwork,  # noqa: F401
                      ConditionalKDENetwork, ConditionalSemiparametricBN, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, load)
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
@@ -24,5 +24,5 @@ __all__ = [
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth", "UCV",
-    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "load", "Context", "DeviceTable", "default_context", "load_library",
+    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
 ]

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
     "pbn_scoredata_set_validity": (_int, [_vp, C.POINTER(_vp)]),
+    "pbn_split_layout": (_int, [_i64, _int, _int, C.c_uint32, C.c_double, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_scoredata_layout": (_int, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_lg_fit": (_int, [_vp, _int, _ip, _int, _dp, _dp]),
     "pbn_lg_fit_table": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "pbn_mi_destroy": (None, [_vp]),
     "pbn_mi_value": (_int, [_vp, _int, _int, _int, _ip, _dp, _dp]),
     "pbn_mi_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
+    "pbn_chisq_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
     "pbn_mi_set_order": (_int, [_vp, _int, _ip]),
     "pbn_mi_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_mmpc_cpcs": (_int, [_int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),

@@ -500,6 +500,55 @@ int pbn_mi_set_order(pbn_mi* h, int n, const int* ids) {
     });
 }
 
+// ChiSquare::pvalue (learning/independences/discrete/chi_square.cpp:8-139) over the discrete columns of a pbn_mi handle:
+// Pearson's statistic summed over the configurations of the conditioning set, df = (|X|-1)(|Y|-1) prod |Z|.  Counts come
+// from the same device pass as the mutual information (no continuous statistics).  Expected counts are formed in
+// double; the reference multiplies two int marginals (chi_square.cpp:21,62,116), which overflows beyond ~46 000 rows
+// per cell pair.  pbn_ci_pvalue_fn signature, indices mapped through pbn_mi_set_order when set.
+double pbn_chisq_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
+    pbn_mi* h = (pbn_mi*)user;
+    double result = std::nan("");
+    const int rc = guarded([&] {
+        if (!h || (n_cond > 0 && !cond)) throw invalid_error("pbn_chisq_pvalue: null argument");
+        std::vector<int> vars{v1, v2};
+        vars.insert(vars.end(), cond, cond + n_cond);
+        if (!h->order.empty())
+            for (int& v : vars) {
+                if (v < 0 || v >= (int)h->order.size()) throw invalid_error("ChiSquare: variable index out of range");
+                v = h->order[v];
+            }
+        Engine e{h};
+        int64_t G = 1;
+        for (int v : vars) {
+            if (v < h->n_cont || v >= h->n_cont + h->n_disc) throw invalid_error("ChiSquare: variable is not categorical");
+            G *= e.card(v);
+            if (G > (1 << 24)) throw invalid_error("ChiSquare: too many discrete configurations");
+        }
+        std::vector<double> st;
+        e.group_stats({}, vars, (int)G, st);
+        const int cx = e.card(vars[0]), cy = e.card(vars[1]), vc = cx * cy, zc = (int)(G / vc);
+        double statistic = 0;
+        for (int k = 0; k < zc; ++k) {
+            const double* c = st.data() + (size_t)k * vc;
+            std::vector<double> mx(cx, 0.0), my(cy, 0.0);
+            double tot = 0;
+            for (int i = 0; i < cx; ++i)
+                for (int j = 0; j < cy; ++j) { mx[i] += c[i + j * cx]; my[j] += c[i + j * cx]; tot += c[i + j * cx]; }
+            if (tot == 0) continue;
+            const double inv = 1.0 / tot;
+            for (int i = 0; i < cx; ++i)
+                for (int j = 0; j < cy; ++j) {
+                    const double expected = mx[i] * my[j] * inv;
+                    if (expected != 0) { const double dd = c[i + j * cx] - expected; statistic += dd * dd / expected; }
+                }
+        }
+        if (n_cond > 1 && statistic < 1.4901161193847656e-08) { result = 1.0; return; }   // chi_square.cpp:130-134
+        const double df = (cx - 1.0) * (cy - 1.0) * zc;
+        result = gamma_q(0.5 * df, 0.5 * statistic);
+    });
+    return rc == PBN_OK ? result : std::nan("");
+}
+
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes) {
     return guarded([&] {
         if (!h) throw invalid_error("pbn_mi_stats: null argument");

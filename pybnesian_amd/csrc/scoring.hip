@@ -289,6 +289,56 @@ double bge_score(const pbn_scoredata* sd, const Stats& st, const int* cols, int 
 
 extern "C" {
 
+// Row layout of the splits: HoldOut (dataset/holdout_adaptator.hpp:24-61), CrossValidation
+// (dataset/crossvalidation_adaptator.hpp:17-57) and, for PBN_SPLIT_VALIDATED, the CV of the hold-out training part
+// with the same seed (validated_likelihood.hpp:19-20).  Host only.
+struct SplitLayout {
+    std::vector<int32_t> idx, limits;
+    int64_t n_cv = 0, n_hold = 0;
+    int k = 0;
+};
+static SplitLayout split_layout(int64_t rows, int split, int k, uint32_t seed, double test_ratio) {
+    SplitLayout L;
+    SplitLayout* sd = &L;
+    std::vector<int32_t> idx((size_t)rows);
+    std::iota(idx.begin(), idx.end(), 0);
+    sd->n_cv = rows;
+    if (split == PBN_SPLIT_HOLDOUT || split == PBN_SPLIT_VALIDATED) {
+        // holdout_adaptator.hpp:24-61
+        if (test_ratio <= 0 || test_ratio >= 1.0) throw invalid_error("test_ratio must be a number between 0 and 1.");
+        std::mt19937 rng{seed};
+        std::shuffle(idx.begin(), idx.end(), rng);
+        const int64_t test_rows = (int64_t)std::round((double)rows * test_ratio);
+        const int64_t train_rows = rows - test_rows;
+        if (test_rows == 0 || train_rows == 0)
+            throw invalid_error("Wrong test_ratio (" + std::to_string(test_ratio) + "selected for HoldOut.\nGenerated train instances: " +
+                                std::to_string(train_rows) + "\nGenerated test instances: " + std::to_string(test_rows));
+        sd->n_cv = train_rows;
+        sd->n_hold = test_rows;
+    }
+    if (split == PBN_SPLIT_CV || split == PBN_SPLIT_VALIDATED) {
+        // crossvalidation_adaptator.hpp:17-57 on the (hold-out) training part; for VALIDATED the CV object is
+        // built on training_data() with the same seed (validated_likelihood.hpp:19-20)
+        const int64_t n = sd->n_cv;
+        if (k <= 1 || k > n)
+            throw invalid_error("Cannot split " + std::to_string(n) + " instances into " + std::to_string(k) + " folds.");
+        std::vector<int32_t> local((size_t)n);
+        std::iota(local.begin(), local.end(), 0);
+        std::mt19937 rng{seed};
+        std::shuffle(local.begin(), local.end(), rng);
+        std::vector<int32_t> tmp(idx.begin(), idx.begin() + n);
+        for (int64_t i = 0; i < n; ++i) idx[i] = tmp[local[i]];
+        const int fold_size = (int)(n / k), extra = (int)(n % k);
+        sd->k = k;
+        sd->limits.assign(1, 0);
+        int cur = 0;
+        for (int i = 0; i < extra; ++i) { cur += fold_size + 1; sd->limits.push_back(cur); }
+        for (int i = extra; i < k; ++i) { cur += fold_size; sd->limits.push_back(cur); }
+    }
+    L.idx = idx;
+    return L;
+}
+
 static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
                                  int rank, int world, pbn_scoredata** out) {
     return guarded([&] {
@@ -299,41 +349,9 @@ static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split
         auto sd = std::make_unique<pbn_scoredata>();
         sd->ctx = ctx; sd->dtype = table->dtype; sd->n = table->n_cols; sd->split = split; sd->src = table;
         const int64_t rows = table->n_rows;
-        std::vector<int32_t> idx((size_t)rows);
-        std::iota(idx.begin(), idx.end(), 0);
-        sd->n_cv = rows;
-        if (split == PBN_SPLIT_HOLDOUT || split == PBN_SPLIT_VALIDATED) {
-            // holdout_adaptator.hpp:24-61
-            if (test_ratio <= 0 || test_ratio >= 1.0) throw invalid_error("test_ratio must be a number between 0 and 1.");
-            std::mt19937 rng{seed};
-            std::shuffle(idx.begin(), idx.end(), rng);
-            const int64_t test_rows = (int64_t)std::round((double)rows * test_ratio);
-            const int64_t train_rows = rows - test_rows;
-            if (test_rows == 0 || train_rows == 0)
-                throw invalid_error("Wrong test_ratio (" + std::to_string(test_ratio) + "selected for HoldOut.\nGenerated train instances: " +
-                                    std::to_string(train_rows) + "\nGenerated test instances: " + std::to_string(test_rows));
-            sd->n_cv = train_rows;
-            sd->n_hold = test_rows;
-        }
-        if (split == PBN_SPLIT_CV || split == PBN_SPLIT_VALIDATED) {
-            // crossvalidation_adaptator.hpp:17-57 on the (hold-out) training part; for VALIDATED the CV object is
-            // built on training_data() with the same seed (validated_likelihood.hpp:19-20)
-            const int64_t n = sd->n_cv;
-            if (k <= 1 || k > n)
-                throw invalid_error("Cannot split " + std::to_string(n) + " instances into " + std::to_string(k) + " folds.");
-            std::vector<int32_t> local((size_t)n);
-            std::iota(local.begin(), local.end(), 0);
-            std::mt19937 rng{seed};
-            std::shuffle(local.begin(), local.end(), rng);
-            std::vector<int32_t> tmp(idx.begin(), idx.begin() + n);
-            for (int64_t i = 0; i < n; ++i) idx[i] = tmp[local[i]];
-            const int fold_size = (int)(n / k), extra = (int)(n % k);
-            sd->k = k;
-            sd->limits.assign(1, 0);
-            int cur = 0;
-            for (int i = 0; i < extra; ++i) { cur += fold_size + 1; sd->limits.push_back(cur); }
-            for (int i = extra; i < k; ++i) { cur += fold_size; sd->limits.push_back(cur); }
-        }
+        SplitLayout lay = split_layout(rows, split, k, seed, test_ratio);
+        const std::vector<int32_t>& idx = lay.idx;
+        sd->n_cv = lay.n_cv; sd->n_hold = lay.n_hold; sd->k = lay.k; sd->limits = lay.limits;
         sd->perm = idx;
         if (split != PBN_SPLIT_NONE) {
             pbn_table* pt = nullptr;
@@ -482,6 +500,20 @@ int pbn_scoredata_cache_stats(const pbn_scoredata* sd, int64_t* entries, int64_t
         if (!sd) throw invalid_error("pbn_scoredata_cache_stats: null argument");
         if (entries) *entries = (int64_t)sd->kde_cache.size();
         if (sweeps) *sweeps = sd->kde_sweeps;
+    });
+}
+
+// The same layout without a table or a device (CrossValidation / HoldOut as stand-alone objects): perm has n_rows
+// entries, limits k + 1 (nullable when k <= 1).
+int pbn_split_layout(int64_t n_rows, int split, int k, uint32_t seed, double test_ratio, int32_t* perm, int32_t* limits,
+                     int64_t* n_cv, int64_t* n_hold) {
+    return guarded([&] {
+        if (n_rows < 0 || !perm) throw invalid_error("pbn_split_layout: bad argument");
+        SplitLayout lay = split_layout(n_rows, split, k, seed, test_ratio);
+        std::memcpy(perm, lay.idx.data(), lay.idx.size() * sizeof(int32_t));
+        if (limits && !lay.limits.empty()) std::memcpy(limits, lay.limits.data(), lay.limits.size() * sizeof(int32_t));
+        if (n_cv) *n_cv = lay.n_cv;
+        if (n_hold) *n_hold = lay.n_hold;
     });
 }
 

@@ -221,3 +221,106 @@ class DeviceTable:
                 self.handle = None
         except Exception:
             pass
+
+
+# ---- dataset::CrossValidation / HoldOut (dataset/crossvalidation_adaptator.hpp, holdout_adaptator.hpp) -----------------
+def _valid_rows(rb, include_null):
+    """Row ids the reference splits: all rows, or (default) the rows without a null in any column."""
+    import numpy as np
+
+    n = rb.num_rows
+    if include_null:
+        return np.arange(n, dtype=np.int64)
+    mask = None
+    for i in range(rb.num_columns):
+        m = validity_mask(rb.column(i))
+        if m is not None:
+            mask = m if mask is None else (mask & m)
+    return np.arange(n, dtype=np.int64) if mask is None else np.nonzero(mask)[0].astype(np.int64)
+
+
+def _layout(n, split, k, seed, ratio):
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+
+    perm = np.zeros(max(n, 1), dtype=np.int32)
+    limits = np.zeros(max(k, 0) + 1, dtype=np.int32)
+    n_cv, n_hold = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.load().pbn_split_layout(n, split, int(k), C.c_uint32(int(seed)), float(ratio), perm.ctypes.data,
+                                            limits.ctypes.data if k > 1 else None, C.byref(n_cv), C.byref(n_hold)))
+    return perm[:n], limits, n_cv.value, n_hold.value
+
+
+class CrossValidation:
+    """pbn.CrossValidation(df, k=10, seed=None, include_null=False): iterating yields (train, test) tables; `.indices()`
+    yields the (train_indices, test_indices) of generate_cv_pair_indices; `.fold(i)`, `.loc(columns)`."""
+
+    def __init__(self, df, k=10, seed=None, include_null=False):
+        import random
+
+        from . import _lib
+
+        self._rb = as_record_batch(df)
+        self._k = int(k)
+        self._seed = random.SystemRandom().randrange(0, 2 ** 32) if seed is None else int(seed)
+        self._include_null = bool(include_null)
+        self._rows = _valid_rows(self._rb, include_null)
+        self._perm, self._limits, _, _ = _layout(len(self._rows), _lib.PBN_SPLIT_CV, self._k, self._seed, 0.0)
+
+    def indices(self):
+        src = self._rows[self._perm]
+        for f in range(self._k):
+            lo, hi = int(self._limits[f]), int(self._limits[f + 1])
+            yield (__import__("numpy").concatenate([src[:lo], src[hi:]]), src[lo:hi].copy())
+
+    def _take(self, idx):
+        import pyarrow as pa
+
+        return self._rb.take(pa.array(idx))
+
+    def fold(self, i):
+        if not 0 <= i < self._k:
+            raise IndexError("fold index out of range")
+        tr, te = list(self.indices())[i]
+        return self._take(tr), self._take(te)
+
+    def loc(self, columns):
+        columns = [columns] if isinstance(columns, (str, int)) else list(columns)
+        names = [c if isinstance(c, str) else self._rb.schema.names[c] for c in columns]
+        out = CrossValidation.__new__(CrossValidation)
+        out.__dict__.update(self.__dict__)
+        out._rb = self._rb.select(names)
+        return out
+
+    def __iter__(self):
+        for tr, te in self.indices():
+            yield self._take(tr), self._take(te)
+
+
+class HoldOut:
+    """pbn.HoldOut(df, test_ratio=0.2, seed=None, include_null=False) with training_data() / test_data()."""
+
+    def __init__(self, df, test_ratio=0.2, seed=None, include_null=False):
+        import random
+
+        from . import _lib
+
+        self._rb = as_record_batch(df)
+        self._seed = random.SystemRandom().randrange(0, 2 ** 32) if seed is None else int(seed)
+        rows = _valid_rows(self._rb, include_null)
+        perm, _, n_train, n_test = _layout(len(rows), _lib.PBN_SPLIT_HOLDOUT, 0, self._seed, test_ratio)
+        src = rows[perm]
+        self._train, self._test = src[:n_train], src[n_train: n_train + n_test]
+
+    def training_data(self):
+        import pyarrow as pa
+
+        return self._rb.take(pa.array(self._train))
+
+    def test_data(self):
+        import pyarrow as pa
+
+        return self._rb.take(pa.array(self._test))

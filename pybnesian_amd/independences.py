@@ -206,6 +206,38 @@ class MutualInformation(IndependenceTest):
             pass
 
 
+class ChiSquare(MutualInformation):
+    """pbn.ChiSquare(df): Pearson's chi-square test on the categorical columns (learning/independences/discrete/
+    chi_square.hpp); shares the device counting pass of MutualInformation."""
+
+    def __init__(self, df, ctx=None):
+        import pyarrow as pa
+
+        rb = as_record_batch(df)
+        disc = [f.name for f in rb.schema if pa.types.is_dictionary(f.type)]
+        if len(disc) < 2:
+            raise ValueError("DataFrame does not contain enough categorical columns.")
+        super().__init__(rb.select(disc), True, ctx)
+        self._all_names = [f.name for f in rb.schema]
+
+    def pvalue(self, x, y, z=None):
+        lib = _lib.load()
+        _lib.check(lib.pbn_mi_set_order(self._handle, 0, None))
+        a = self._args(x, y, z)
+        p = lib.pbn_chisq_pvalue(self._handle, a[0], a[1], a[2], a[3])
+        if np.isnan(p):
+            raise ValueError("ChiSquare: " + lib.pbn_last_error().decode())
+        return p
+
+    def mi(self, x, y, z=None):
+        raise AttributeError("ChiSquare has no mi()")
+
+    def _ci_callback(self, nodes):
+        lib = _lib.load()
+        _lib.check(lib.pbn_mi_set_order(self._handle, len(nodes), _lib.int_array([self._var(n) for n in nodes])))
+        return C.cast(lib.pbn_chisq_pvalue, C.c_void_p), self._handle, self, []
+
+
 def validate_restrictions(nodes, arc_blacklist=(), arc_whitelist=(), edge_blacklist=(), edge_whitelist=()):
     """util::validate_restrictions (util/validate_whitelists.hpp:72-146) over node indices: returns
     (arc_blacklist, arc_whitelist, edge_blacklist, edge_whitelist) as ordered lists of index pairs."""

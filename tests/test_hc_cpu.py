@@ -306,3 +306,41 @@ def test_conditional_network_surface(ensure_built):
     assert s.schema.names == ["a", "b", "x", "y"]
     a, b = s.column(0).to_numpy(), s.column(1).to_numpy()
     assert np.allclose(a, 1.0 + 2.0 * ev["x"], atol=0.5) and np.allclose(b, -a, atol=0.5)
+
+
+def test_cross_validation_and_holdout_objects(ensure_built):
+    """dataset::CrossValidation / HoldOut (tests/dataset/crossvalidation_test.py, holdout_test.py of the reference):
+    fold sizes, disjointness, determinism in the seed, null handling, and the libstdc++ shuffle known answer."""
+    import pandas as pd
+
+    import pybnesian_amd as pbn
+    from oracle import oracle
+
+    n = 103
+    df = pd.DataFrame({"a": np.arange(n, dtype=float), "b": np.arange(n, dtype=float) * 2})
+    cv = pbn.CrossValidation(df, 10, 0)
+    folds = list(cv.indices())
+    assert [len(te) for _, te in folds] == [11, 11, 11] + [10] * 7               # first n % k folds one longer
+    assert sorted(np.concatenate([te for _, te in folds]).tolist()) == list(range(n))
+    perm = oracle.shuffled_indices(n, 0)
+    assert np.array_equal(np.concatenate([te for _, te in folds]), perm)         # folds are slices of the shuffled order
+    for tr, te in folds:
+        assert len(tr) + len(te) == n and not set(tr) & set(te)
+    tr0, te0 = cv.fold(0)
+    assert te0.num_rows == 11 and np.array_equal(te0.column(0).to_numpy(), perm[:11].astype(float))
+    assert [te.num_rows for _, te in pbn.CrossValidation(df, 10, 0)] == [len(te) for _, te in folds]
+    assert not np.array_equal(list(pbn.CrossValidation(df, 10, 1).indices())[0][1], folds[0][1])
+    assert cv.loc(["b"]).fold(1)[1].schema.names == ["b"]
+    with pytest.raises(ValueError, match="Cannot split"):
+        pbn.CrossValidation(df, 200, 0)
+    dn = df.copy()
+    dn.loc[[3, 50], "a"] = np.nan
+    cvn = pbn.CrossValidation(dn, 5, 0)
+    assert sorted(np.concatenate([te for _, te in cvn.indices()]).tolist()) == [i for i in range(n) if i not in (3, 50)]
+    assert sum(te.num_rows for _, te in pbn.CrossValidation(dn, 5, 0, include_null=True)) == n
+    ho = pbn.HoldOut(df, 0.2, 0)
+    assert ho.test_data().num_rows == round(n * 0.2) and ho.training_data().num_rows == n - round(n * 0.2)
+    both = np.concatenate([ho.training_data().column(0).to_numpy(), ho.test_data().column(0).to_numpy()])
+    assert np.array_equal(both, perm.astype(float))                              # train = first n - test of the shuffle
+    with pytest.raises(ValueError, match="test_ratio"):
+        pbn.HoldOut(df, 1.5, 0)

@@ -104,3 +104,41 @@ def test_mmhc_hybrid(pbn):
         assert names.index(b) in allowed[names.index(a)]
         assert not (isinstance(df[b].dtype, pd.CategoricalDtype) and not isinstance(df[a].dtype, pd.CategoricalDtype))
     assert model.num_arcs() >= 3
+
+
+def test_chi_square(pbn):
+    """ChiSquare (chi_square.cpp:8-139) against scipy's contingency test, marginal and conditional."""
+    from scipy.stats import chi2, chi2_contingency
+
+    rng = np.random.default_rng(2)
+    n = 20000
+    a = rng.integers(0, 3, size=n)
+    b = (a + rng.integers(0, 3, size=n) * (rng.random(n) < 0.5)) % 3
+    c = rng.integers(0, 2, size=n)
+    d = (c + (rng.random(n) < 0.2)) % 2
+    df = pd.DataFrame({"x": rng.normal(size=n)})
+    for name, codes, k in (("a", a, 3), ("b", b, 3), ("c", c, 2), ("d", d, 2)):
+        df[name] = pd.Categorical.from_codes(codes, [f"{name}{i}" for i in range(k)])
+    test = pbn.ChiSquare(df)
+    tab = pd.crosstab(df["a"], df["b"]).to_numpy()
+    stat, p, dof, _ = chi2_contingency(tab, correction=False)
+    assert test.pvalue("a", "b") == pytest.approx(p, rel=1e-8, abs=1e-300)
+    assert test.pvalue("a", "c") == pytest.approx(chi2_contingency(pd.crosstab(df["a"], df["c"]).to_numpy(), correction=False)[1], rel=1e-8)
+    # conditional: sum of the per-configuration statistics, df multiplied by the configurations
+    for z in (["c"], ["c", "d"]):
+        stat, cfgs = 0.0, 0
+        for _, sub in df.groupby(z, observed=False):
+            cfgs += 1
+            if len(sub) == 0:
+                continue
+            t = pd.crosstab(sub["a"], sub["b"], dropna=False).reindex(index=df["a"].cat.categories, columns=df["b"].cat.categories, fill_value=0).to_numpy().astype(float)
+            e = np.outer(t.sum(1), t.sum(0)) / t.sum()
+            stat += np.where(e != 0, (t - e) ** 2 / np.where(e != 0, e, 1), 0).sum()
+        want = chi2.sf(stat, (3 - 1) * (3 - 1) * cfgs)
+        assert test.pvalue("a", "b", z if len(z) > 1 else z[0]) == pytest.approx(want, rel=1e-8, abs=1e-300)
+    with pytest.raises(ValueError, match="not present"):
+        test.pvalue("a", "x")
+    from pybnesian_amd.independences import mmpc_cpcs
+
+    cpcs, _ = mmpc_cpcs(test, ["a", "b", "c", "d"], 0.01)
+    assert "b" in cpcs[0] and "d" in cpcs[2] and "c" not in cpcs[0]
