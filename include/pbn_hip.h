@@ -325,6 +325,13 @@ int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_ar
                   int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist, const int* edge_whitelist,
                   int symmetric, int* cpc_off, int* cpc, int64_t* n_tests);
 
+/* The same over a conditional graph (mmpc.cpp:875-908, 740-784, 984-993): the last n_interface of the n variables are
+ * interface nodes - candidates of the nodes, never of each other. */
+int pbn_mmpc_cpcs_conditional(int n, int n_interface, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist,
+                              const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist,
+                              int n_edge_whitelist, const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc,
+                              int64_t* n_tests);
+
 #ifdef __cplusplus
 }
 #endif

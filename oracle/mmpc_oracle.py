@@ -224,8 +224,11 @@ def mmpc_backward_phase(test, variable, alpha, cpc, whitelisted):   # mmpc.cpp:5
             subset_variables.append(x)
 
 
-def mmpc_all_variables(pvalue, n, alpha, arc_whitelist=(), edge_blacklist=(), edge_whitelist=(), symmetric=True):
-    """mmpc.cpp:833-966 (+ mmhc.cpp:12-22 remove_asymmetries).  Returns (list of CPC lists in set iteration order, #tests)."""
+def mmpc_all_variables(pvalue, n, alpha, arc_whitelist=(), edge_blacklist=(), edge_whitelist=(), symmetric=True, n_interface=0):
+    """mmpc.cpp:833-966 (+ mmhc.cpp:12-22 remove_asymmetries).  Returns (list of CPC lists in set iteration order, #tests).
+    n_interface > 0: the conditional-graph overloads (generate_cpcs :875-908, marginal pass :740-784) - the last
+    n_interface of the n variables are interface nodes."""
+    nn = n - n_interface
     test = Counter(pvalue)
     ebl = {(min(a, b), max(a, b)) for a, b in edge_blacklist}
     ewl = {(min(a, b), max(a, b)) for a, b in edge_whitelist}
@@ -239,26 +242,42 @@ def mmpc_all_variables(pvalue, n, alpha, arc_whitelist=(), edge_blacklist=(), ed
     for a, b in arc_whitelist:
         cpcs[a].insert(b)
         cpcs[b].insert(a)
-    for i in range(n - 1):
-        for j in range(i + 1, n):
-            if (i, j) not in ebl:
-                if j not in cpcs[i]:
-                    tbc[i].insert(j)
-                if i not in cpcs[j]:
-                    tbc[j].insert(i)
+    if n_interface == 0:
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                if (i, j) not in ebl:
+                    if j not in cpcs[i]:
+                        tbc[i].insert(j)
+                    if i not in cpcs[j]:
+                        tbc[j].insert(i)
+    else:
+        for i in range(nn):
+            for j in range(n):
+                if i != j and (min(i, j), max(i, j)) not in ebl:
+                    if j not in cpcs[i]:
+                        tbc[i].insert(j)
+                    if i not in cpcs[j]:
+                        tbc[j].insert(i)
     assoc = Assoc(n, alpha)
-    for i in range(n - 1):   # marginal_cpcs_all_variables
-        for j in range(i + 1, n):
-            if (len(cpcs[i]) == 0 or len(cpcs[j]) == 0) and (i, j) not in ebl:
-                p = test(i, j)
-                if p < alpha:
-                    if len(cpcs[i]) == 0:
-                        assoc.initialize_assoc(j, i, p)
-                    if len(cpcs[j]) == 0:
-                        assoc.initialize_assoc(i, j, p)
-                else:
-                    tbc[i].erase(j)
-                    tbc[j].erase(i)
+
+    def marginal_pair(i, j):
+        if (len(cpcs[i]) == 0 or len(cpcs[j]) == 0) and (min(i, j), max(i, j)) not in ebl:
+            p = test(i, j)
+            if p < alpha:
+                if len(cpcs[i]) == 0:
+                    assoc.initialize_assoc(j, i, p)
+                if len(cpcs[j]) == 0:
+                    assoc.initialize_assoc(i, j, p)
+            else:
+                tbc[i].erase(j)
+                tbc[j].erase(i)
+
+    for i in range(nn - 1):   # marginal_cpcs_all_variables, nodes against nodes
+        for j in range(i + 1, nn):
+            marginal_pair(i, j)
+    for i in range(nn):       # nodes against interface nodes
+        for j in range(nn, n):
+            marginal_pair(i, j)
     all_finished = True
     for i in range(n):
         if assoc.maxmin_index[i] != STOP:

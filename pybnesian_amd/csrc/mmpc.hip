@@ -208,7 +208,7 @@ struct Lex {
 };
 
 struct Mmpc {
-    int n;
+    int n;        // all variables: nodes first, then ni interface nodes (ConditionalPartiallyDirectedGraph)
     double alpha;
     pbn_ci_pvalue_fn fn;
     void* user;
@@ -218,6 +218,7 @@ struct Mmpc {
     std::vector<int> maxmin_idx;
     PairSet arc_wl, edge_bl, edge_wl;
     std::vector<std::pair<int, int>> arc_wl_list, edge_wl_list;
+    int ni = 0;   // interface nodes: candidates of the nodes only, never of each other (mmpc.cpp:875-908)
 
     double pvalue(int a, int b, const std::vector<int>& cond) {
         ++tests;
@@ -317,28 +318,42 @@ struct Mmpc {
         std::vector<IntSet> cpcs(n), tbc(n);
         for (auto& e : edge_wl_list) { cpcs[e.first].insert(e.second); cpcs[e.second].insert(e.first); }
         for (auto& a : arc_wl_list) { cpcs[a.first].insert(a.second); cpcs[a.second].insert(a.first); }
-        for (int i = 0; i + 1 < n; ++i)
-            for (int j = i + 1; j < n; ++j)
-                if (!edge_bl.has(i, j)) {
-                    if (!cpcs[i].count(j)) tbc[i].insert(j);
-                    if (!cpcs[j].count(i)) tbc[j].insert(i);
-                }
+        const int nn = n - ni;   // nodes
+        if (ni == 0) {
+            for (int i = 0; i + 1 < n; ++i)
+                for (int j = i + 1; j < n; ++j)
+                    if (!edge_bl.has(i, j)) {
+                        if (!cpcs[i].count(j)) tbc[i].insert(j);
+                        if (!cpcs[j].count(i)) tbc[j].insert(i);
+                    }
+        } else {   // generate_cpcs of the conditional graph: every node against every other joint node
+            for (int i = 0; i < nn; ++i)
+                for (int j = 0; j < n; ++j)
+                    if (i != j && !edge_bl.has(i, j)) {
+                        if (!cpcs[i].count(j)) tbc[i].insert(j);
+                        if (!cpcs[j].count(i)) tbc[j].insert(i);
+                    }
+        }
         min_assoc.assign((size_t)n * n, 0.0);
         maxmin.assign(n, alpha);
         maxmin_idx.assign(n, STOP);
-        // marginal associations of all pairs at once (mmpc.cpp:698-738)
-        for (int i = 0; i + 1 < n; ++i)
-            for (int j = i + 1; j < n; ++j)
-                if ((cpcs[i].empty() || cpcs[j].empty()) && !edge_bl.has(i, j)) {
-                    const double p = pvalue(i, j);
-                    if (p < alpha) {
-                        if (cpcs[i].empty()) init_assoc(j, i, p);
-                        if (cpcs[j].empty()) init_assoc(i, j, p);
-                    } else {
-                        tbc[i].erase(j);
-                        tbc[j].erase(i);
-                    }
+        // marginal associations of all pairs at once (mmpc.cpp:698-738; node x interface pairs :740-784)
+        auto marginal_pair = [&](int i, int j) {
+            if ((cpcs[i].empty() || cpcs[j].empty()) && !edge_bl.has(i, j)) {
+                const double p = pvalue(i, j);
+                if (p < alpha) {
+                    if (cpcs[i].empty()) init_assoc(j, i, p);
+                    if (cpcs[j].empty()) init_assoc(i, j, p);
+                } else {
+                    tbc[i].erase(j);
+                    tbc[j].erase(i);
                 }
+            }
+        };
+        for (int i = 0; i + 1 < nn; ++i)
+            for (int j = i + 1; j < nn; ++j) marginal_pair(i, j);
+        for (int i = 0; i < nn; ++i)
+            for (int j = nn; j < n; ++j) marginal_pair(i, j);
         bool all_finished = true;
         for (int i = 0; i < n; ++i) {
             if (maxmin_idx[i] != STOP) {
@@ -450,13 +465,14 @@ double pbn_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond
     return lincor_pvalue(h, v1, v2, n_cond, cond);
 }
 
-int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist, const int* arc_whitelist,
-                  int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist, const int* edge_whitelist,
-                  int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
+static int mmpc_cpcs_impl(int n, int n_interface, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist,
+                          const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist,
+                          const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
     return guarded([&] {
-        if (n <= 0 || !fn || !cpc_off || !cpc) throw invalid_error("pbn_mmpc_cpcs: bad argument");
+        if (n <= 0 || n_interface < 0 || n_interface >= n || !fn || !cpc_off || !cpc) throw invalid_error("pbn_mmpc_cpcs: bad argument");
         if (!(alpha > 0 && alpha < 1)) throw invalid_error("alpha must be a number between 0 and 1.");
         Mmpc m{n, alpha, fn, user};
+        m.ni = n_interface;
         m.arc_wl.n = m.edge_bl.n = m.edge_wl.n = n;
         m.edge_bl.symmetric = m.edge_wl.symmetric = true;
         auto chk = [&](int v) { if (v < 0 || v >= n) throw invalid_error("pbn_mmpc_cpcs: node index out of range"); };
@@ -491,6 +507,22 @@ int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_ar
         cpc_off[n] = pos;
         if (n_tests) *n_tests = m.tests;
     });
+}
+
+int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist, const int* arc_whitelist,
+                  int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist, const int* edge_whitelist,
+                  int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
+    return mmpc_cpcs_impl(n, 0, fn, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist, n_edge_whitelist,
+                          edge_whitelist, symmetric, cpc_off, cpc, n_tests);
+}
+
+// mmpc_all_variables over a ConditionalPartiallyDirectedGraph (mmpc.cpp:875-908, 740-784, 984-993): the last
+// n_interface of the n variables are interface nodes.
+int pbn_mmpc_cpcs_conditional(int n, int n_interface, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist,
+                              const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist,
+                              const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
+    return mmpc_cpcs_impl(n, n_interface, fn, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist,
+                          n_edge_whitelist, edge_whitelist, symmetric, cpc_off, cpc, n_tests);
 }
 
 }  // extern "C"

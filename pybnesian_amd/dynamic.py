@@ -1,0 +1,287 @@
+"""Dynamic Bayesian networks on top of the same kernels: DynamicDataFrame (dataset/dynamic_dataset.{hpp,
+cpp}), the Dynamic* adaptators of scores and independence tests (learning/scores/scores.hpp:74-101,
+learning/independences/independence.hpp:42-77), DynamicBayesianNetwork (models/DynamicBayesianNetwork.{hpp,cpp}) and DMMHC
+(learning/algorithms/dmmhc.cpp).  Everything here is index bookkeeping: the static network is learned on the lagged
+"static" table, the transition network - a conditional network whose interface nodes are the lagged variables - on the
+"transition" table, with the scores, tests, MMPC and hill-climb of this package."""
+import numpy as np
+
+from .dataset import as_record_batch
+from .models import BayesianNetwork, GaussianNetworkType
+
+
+def temporal_name(name, slice_index):   # util/temporal.cpp:5-7
+    return f"{name}_t_{slice_index}"
+
+
+def temporal_names(variables, offset_slice, markovian_order):   # util/temporal.cpp:9-23
+    return [temporal_name(v, i) for v in variables for i in range(offset_slice, markovian_order + 1)]
+
+
+def _temporal_slice(rb, slice_index, slice_offset, markovian_order):   # dynamic_dataset.cpp:16-33
+    import pyarrow as pa
+
+    new_length = rb.num_rows - markovian_order
+    offset = markovian_order - slice_index
+    sl = rb.slice(offset, new_length)
+    return pa.RecordBatch.from_arrays(sl.columns, names=[temporal_name(n, slice_index + slice_offset) for n in rb.schema.names])
+
+
+def _concat_columns(batches):
+    import pyarrow as pa
+
+    cols, names = [], []
+    for b in batches:
+        cols += b.columns
+        names += b.schema.names
+    return pa.RecordBatch.from_arrays(cols, names=names)
+
+
+def static_table(df, markovian_order):   # create_static_df, dynamic_dataset.cpp:45-71
+    import pyarrow as pa
+
+    rb = as_record_batch(df)
+    if markovian_order == 1:
+        return pa.RecordBatch.from_arrays(rb.columns, names=[temporal_name(n, 1) for n in rb.schema.names])
+    return _concat_columns([_temporal_slice(rb, i, 1, markovian_order - 1) for i in range(markovian_order)])
+
+
+def transition_table(df, markovian_order):   # create_temporal_slices + create_transition_df, :35-43, :73-85
+    rb = as_record_batch(df)
+    return _concat_columns([_temporal_slice(rb, i, 0, markovian_order) for i in range(markovian_order + 1)])
+
+
+class DynamicDataFrame:
+    def __init__(self, df, markovian_order):
+        if markovian_order < 1:
+            raise ValueError("Markovian order must be at least 1.")
+        self._origin = as_record_batch(df)
+        if self._origin.num_rows <= markovian_order:
+            raise ValueError("Not enough rows for this markovian order.")
+        self._order = int(markovian_order)
+        self._static = static_table(self._origin, self._order)
+        self._transition = transition_table(self._origin, self._order)
+
+    def markovian_order(self):
+        return self._order
+
+    def num_variables(self):
+        return self._origin.num_columns
+
+    def num_rows(self):
+        return self._transition.num_rows
+
+    def num_columns(self):
+        return self._transition.num_columns
+
+    def origin_df(self):
+        return self._origin
+
+    def static_df(self):
+        return self._static
+
+    def transition_df(self):
+        return self._transition
+
+    def temporal_slice(self, index):
+        if not 0 <= index <= self._order:
+            raise ValueError(f"slice_index must be an index between 0 and {self._order}")
+        return _temporal_slice(self._origin, index, 0, self._order)
+
+    def variable_names(self):
+        return list(self._origin.schema.names)
+
+
+class _DynamicAdaptator:
+    """DynamicAdaptator<Base> (dataset/dynamic_dataset.hpp): one Base on the static table, one on the transition table."""
+
+    def __init__(self, base, ddf, *args, **kwargs):
+        if not isinstance(ddf, DynamicDataFrame):
+            raise ValueError("A DynamicDataFrame is needed.")
+        self._ddf = ddf
+        self._static = base(ddf.static_df(), *args, **kwargs)
+        self._transition = base(ddf.transition_df(), *args, **kwargs)
+
+    def variable_names(self):
+        return self._ddf.variable_names()
+
+    def has_variables(self, variables):
+        names = set(self._ddf.variable_names())
+        variables = [variables] if isinstance(variables, str) else variables
+        return all(v in names for v in variables)
+
+    def markovian_order(self):
+        return self._ddf.markovian_order()
+
+
+class DynamicScoreAdaptator(_DynamicAdaptator):
+    def static_score(self):
+        return self._static
+
+    def transition_score(self):
+        return self._transition
+
+
+class DynamicIndependenceTestAdaptator(_DynamicAdaptator):
+    def static_tests(self):
+        return self._static
+
+    def transition_tests(self):
+        return self._transition
+
+
+def _adaptator(kind, base_name):
+    def make(ddf, *args, **kwargs):
+        import pybnesian_amd as pbn
+
+        return kind(getattr(pbn, base_name), ddf, *args, **kwargs)
+
+    make.__name__ = "Dynamic" + base_name
+    make.__doc__ = f"Dynamic{base_name}(ddf, ...): {base_name} on the static and on the transition table of a DynamicDataFrame."
+    return make
+
+
+DynamicBIC = _adaptator(DynamicScoreAdaptator, "BIC")
+DynamicBGe = _adaptator(DynamicScoreAdaptator, "BGe")
+DynamicCVLikelihood = _adaptator(DynamicScoreAdaptator, "CVLikelihood")
+DynamicHoldoutLikelihood = _adaptator(DynamicScoreAdaptator, "HoldoutLikelihood")
+DynamicValidatedLikelihood = _adaptator(DynamicScoreAdaptator, "ValidatedLikelihood")
+DynamicLinearCorrelation = _adaptator(DynamicIndependenceTestAdaptator, "LinearCorrelation")
+DynamicMutualInformation = _adaptator(DynamicIndependenceTestAdaptator, "MutualInformation")
+DynamicChiSquare = _adaptator(DynamicIndependenceTestAdaptator, "ChiSquare")
+
+
+class DynamicBayesianNetwork:
+    """models/DynamicBayesianNetwork.hpp: a static network over the lagged variables v_t_1 .. v_t_order and a conditional
+    transition network over v_t_0 with the lagged variables as interface nodes."""
+
+    def __init__(self, variables, markovian_order, static_bn=None, transition_bn=None, bn_type=None):
+        self._variables = list(variables)
+        self._order = int(markovian_order)
+        if self._order < 1:
+            raise ValueError("Markovian order must be at least 1.")
+        bn_type = bn_type if bn_type is not None else (static_bn.type() if static_bn is not None else GaussianNetworkType())
+        static_nodes = temporal_names(self._variables, 1, self._order)
+        transition_nodes = temporal_names(self._variables, 0, 0)
+        if static_bn is None:
+            static_bn = BayesianNetwork(bn_type, static_nodes)
+        if transition_bn is None:
+            transition_bn = BayesianNetwork(bn_type, transition_nodes, (), (), static_nodes)
+        if set(static_bn.nodes()) != set(static_nodes):
+            raise ValueError("Static Bayesian network must contain the nodes: " + ", ".join(static_nodes))
+        if set(transition_bn.nodes()) != set(transition_nodes) or set(transition_bn.interface_nodes()) != set(static_nodes):
+            raise ValueError("Transition Bayesian network has the wrong nodes / interface nodes.")
+        self._static, self._transition = static_bn, transition_bn
+
+    def variables(self):
+        return list(self._variables)
+
+    def num_variables(self):
+        return len(self._variables)
+
+    def markovian_order(self):
+        return self._order
+
+    def static_bn(self):
+        return self._static
+
+    def transition_bn(self):
+        return self._transition
+
+    def type(self):
+        return self._transition.type()
+
+    def fit(self, df):
+        ddf = df if isinstance(df, DynamicDataFrame) else DynamicDataFrame(df, self._order)
+        self._static.fit(ddf.static_df())
+        self._transition.fit(ddf.transition_df())
+
+    def fitted(self):
+        return self._static.fitted() and self._transition.fitted()
+
+    def _check(self, rb):
+        if not self.fitted():
+            raise ValueError("Model not fitted.")
+        if rb.num_rows < self._order:
+            raise ValueError(f"Not enough information. There are less rows in test DataFrame ({rb.num_rows}) than the markovian "
+                             f"order of the DynamicBayesianNetwork ({self._order})")
+
+    def logl(self, df):
+        """DynamicBayesianNetwork::logl (DynamicBayesianNetwork.cpp:71-113): the first `order` rows from the static
+        network (row i scored by the factors of slice order - i), the rest from the transition network."""
+        rb = as_record_batch(df)
+        self._check(rb)
+        ll = np.zeros(rb.num_rows)
+        dstatic = static_table(rb.slice(0, self._order), self._order)
+        for i in range(self._order):
+            for v in self._variables:
+                ll[i] += self._static.cpd(temporal_name(v, self._order - i)).slogl(dstatic)
+        if rb.num_rows > self._order:
+            dtrans = transition_table(rb, self._order)
+            for v in self._variables:
+                ll[self._order:] += self._transition.cpd(temporal_name(v, 0)).logl(dtrans)
+        return ll
+
+    def slogl(self, df):
+        rb = as_record_batch(df)
+        self._check(rb)
+        total = 0.0
+        dstatic = static_table(rb.slice(0, self._order), self._order)
+        for i in range(self._order):
+            for v in self._variables:
+                total += self._static.cpd(temporal_name(v, self._order - i)).slogl(dstatic)
+        if rb.num_rows > self._order:
+            dtrans = transition_table(rb, self._order)
+            for v in self._variables:
+                total += self._transition.cpd(temporal_name(v, 0)).slogl(dtrans)
+        return total
+
+    def save(self, name, include_cpd=False):
+        import pickle
+
+        self._static.include_cpd = self._transition.include_cpd = bool(include_cpd)
+        with open(name if name.endswith(".pickle") else name + ".pickle", "wb") as f:
+            pickle.dump(self, f, protocol=2)
+
+    def __str__(self):
+        return f"Dynamic{self.type()} of order {self._order} over {len(self._variables)} variables"
+
+
+def static_blacklist(variables, markovian_order):
+    """dmmhc.cpp:12-32: in the static network no arc may run from a more recent slice to an older one."""
+    if markovian_order == 1:
+        return []
+    slices = [[temporal_name(v, i) for v in variables] for i in range(1, markovian_order + 1)]
+    out = []
+    for i in range(markovian_order - 1):
+        for source in slices[i]:
+            for j in range(i + 1, markovian_order):
+                out += [(source, dest) for dest in slices[j]]
+    return out
+
+
+class DMMHC:
+    """learning/algorithms/dmmhc.cpp:34-118: MMHC on the static table, conditional MMHC on the transition table."""
+
+    def estimate(self, hypot_test, operators, score, variables=(), bn_type=None, markovian_order=1, static_callback=None,
+                 transition_callback=None, max_indegree=0, max_iters=2 ** 31 - 1, epsilon=0.0, patience=0, alpha=0.05, verbose=0):
+        from .learning import MMHC
+
+        bn_type = bn_type if bn_type is not None else GaussianNetworkType()
+        variables = list(variables) if variables else list(hypot_test.variable_names())
+        if not hypot_test.has_variables(variables):
+            raise ValueError("DynamicIndependenceTest do not contain all the variables in nodes lists.")
+        if not score.has_variables(variables):
+            raise ValueError("Score do not contain all the variables in nodes list.")
+        mmhc = MMHC()
+        static_nodes = temporal_names(variables, 1, markovian_order)
+        g0 = mmhc.estimate(hypot_test.static_tests(), operators, score.static_score(), static_nodes, bn_type,
+                           arc_blacklist=static_blacklist(variables, markovian_order), callback=static_callback,
+                           max_indegree=max_indegree, max_iters=max_iters, epsilon=epsilon, patience=patience, alpha=alpha)
+        self.static_tests = mmhc.last_tests
+        transition_nodes = temporal_names(variables, 0, 0)
+        gt = mmhc.estimate_conditional(hypot_test.transition_tests(), operators, score.transition_score(), transition_nodes,
+                                       static_nodes, bn_type, callback=transition_callback, max_indegree=max_indegree,
+                                       max_iters=max_iters, epsilon=epsilon, patience=patience, alpha=alpha)
+        self.transition_tests = mmhc.last_tests
+        return DynamicBayesianNetwork(variables, markovian_order, g0, gt)

@@ -279,19 +279,20 @@ def validate_restrictions(nodes, arc_blacklist=(), arc_whitelist=(), edge_blackl
     return list(a_bl), list(a_wl), list(e_bl), list(e_wl)
 
 
-def mmpc_cpcs(test, nodes, alpha=0.05, arc_whitelist=(), edge_blacklist=(), edge_whitelist=(), symmetric=True):
+def mmpc_cpcs(test, nodes, alpha=0.05, arc_whitelist=(), edge_blacklist=(), edge_whitelist=(), symmetric=True, interface_nodes=()):
     """mmpc_all_variables (+ remove_asymmetries when `symmetric`): list of candidate parents-and-children (node names)
     per node, and the number of independence tests evaluated.  Index-pair restriction lists as validate_restrictions
-    returns them."""
+    returns them.  With `interface_nodes` (conditional graph) the result covers nodes + interface_nodes, in that order."""
+    nodes = list(nodes) + list(interface_nodes)
     n = len(nodes)
     fn, user, keep, errors = test._ci_callback(list(nodes))
     flat = lambda prs: _lib.int_array([v for p in prs for v in p] or [0])
     off = (C.c_int * (n + 1))()
     out = (C.c_int * max(1, n * (n - 1)))()
     ntests = C.c_int64(0)
-    rc = _lib.load().pbn_mmpc_cpcs(n, fn, user, float(alpha), len(arc_whitelist), flat(arc_whitelist), len(edge_blacklist),
-                                   flat(edge_blacklist), len(edge_whitelist), flat(edge_whitelist), int(bool(symmetric)), off, out,
-                                   C.byref(ntests))
+    rc = _lib.load().pbn_mmpc_cpcs_conditional(n, len(interface_nodes), fn, user, float(alpha), len(arc_whitelist),
+                                               flat(arc_whitelist), len(edge_blacklist), flat(edge_blacklist), len(edge_whitelist),
+                                               flat(edge_whitelist), int(bool(symmetric)), off, out, C.byref(ntests))
     if errors:
         raise errors[0]
     _lib.check(rc)

@@ -626,6 +626,48 @@ class MMHC:
                                 max_indegree, max_iters, epsilon, patience, verbose)
 
 
+    def estimate_conditional(self, hypot_test, operators, score, nodes, interface_nodes=(), bn_type=None, arc_blacklist=(),
+                             arc_whitelist=(), edge_blacklist=(), edge_whitelist=(), type_blacklist=(), type_whitelist=(),
+                             callback=None, max_indegree=0, max_iters=2 ** 31 - 1, epsilon=0.0, patience=0, alpha=0.05, verbose=0):
+        """MMHC::estimate_conditional (mmhc.cpp:162-244): MMPC over the conditional graph, then the hill-climb of a
+        conditional network; arcs between nodes outside each other's CPC and interface -> node arcs outside the node's
+        CPC are blacklisted (create_conditional_hc_blacklist, :44-75)."""
+        from .independences import mmpc_cpcs, validate_restrictions
+        from .models import GaussianNetworkType
+
+        nodes, interface_nodes = list(nodes), list(interface_nodes)
+        if not nodes:
+            raise ValueError("Node list cannot be empty to train a Conditional Bayesian network.")
+        bn_type = bn_type if bn_type is not None else GaussianNetworkType()
+        if not interface_nodes:
+            return self.estimate(hypot_test, operators, score, nodes, bn_type, arc_blacklist, arc_whitelist, edge_blacklist,
+                                 edge_whitelist, type_blacklist, type_whitelist, callback, max_indegree, max_iters, epsilon,
+                                 patience, alpha, verbose).conditional_bn()
+        if not hypot_test.has_variables(nodes) or not hypot_test.has_variables(interface_nodes):
+            raise ValueError("IndependenceTest do not contain all the variables in nodes/interface_nodes lists.")
+        if not score.has_variables(nodes) or not score.has_variables(interface_nodes):
+            raise ValueError("Score do not contain all the variables in nodes list.")
+        bn = BayesianNetwork(bn_type, nodes, (), (), interface_nodes)
+        if not score.compatible_bn(bn):
+            raise ValueError("BayesianNetwork is not compatible with the score.")
+        joint = nodes + interface_nodes
+        _, a_wl, e_bl, e_wl = validate_restrictions(joint, arc_blacklist, arc_whitelist, edge_blacklist, edge_whitelist)
+        cpcs, self.last_tests = mmpc_cpcs(hypot_test, nodes, alpha, a_wl, e_bl, e_wl, symmetric=True, interface_nodes=interface_nodes)
+        self.last_cpcs = cpcs
+        allowed = [set(c) for c in cpcs]
+        hc_blacklist = []
+        for i in range(len(nodes) - 1):
+            for j in range(i + 1, len(nodes)):
+                if nodes[j] not in allowed[i]:
+                    hc_blacklist += [(nodes[i], nodes[j]), (nodes[j], nodes[i])]
+        for i, node in enumerate(nodes):
+            hc_blacklist += [(inode, node) for inode in interface_nodes if inode not in allowed[i]]
+        hc_blacklist += [tuple(a) for a in arc_blacklist]
+        hc_whitelist = [(joint[s], joint[t]) for s, t in a_wl]
+        return self.hc.estimate(operators, score, bn, hc_blacklist, hc_whitelist, type_blacklist, type_whitelist, callback,
+                                max_indegree, max_iters, epsilon, patience, verbose)
+
+
 def hc(df, bn_type=None, start=None, score=None, operators=None, arc_blacklist=(), arc_whitelist=(), type_blacklist=(),
        type_whitelist=(), callback=None, max_indegree=0, max_iters=2 ** 31 - 1, epsilon=0.0, patience=0, seed=None,
        num_folds=10, test_holdout_ratio=0.2, verbose=0):

@@ -108,3 +108,17 @@ def test_linear_correlation_from_covariance(ensure_built, rows):
     got, ntests = mmpc_cpcs(test, names, 0.01)
     want, calls = mmpc_oracle.mmpc_all_variables(lambda a, b, c: mmpc_oracle.lincor_pvalue(cov, rows, a, b, c), n, 0.01)
     assert [[names.index(v) for v in c] for c in got] == want and ntests == calls
+
+
+@pytest.mark.parametrize("n,ni,seed", [(6, 2, 0), (8, 4, 3), (9, 1, 5)])
+def test_conditional_mmpc_matches_restatement(ensure_built, n, ni, seed):
+    """mmpc_all_variables over a conditional graph (mmpc.cpp:875-908, 740-784): interface nodes are candidates of the
+    nodes only."""
+    t1, t2 = TableTest(n + ni, seed, 400), TableTest(n + ni, seed, 400)
+    names = t1.names
+    got, ntests = mmpc_cpcs(t1, names[:n], 0.05, interface_nodes=names[n:])
+    want, calls = mmpc_oracle.mmpc_all_variables(t2.by_index, n + ni, 0.05, n_interface=ni)
+    assert [[t1.idx[v] for v in c] for c in got] == want and ntests == calls
+    for i in range(n, n + ni):
+        assert all(v < n for v in want[i])           # no interface - interface candidates
+    assert any(any(v >= n for v in want[i]) for i in range(n))

@@ -99,3 +99,34 @@ def test_network_pickle_roundtrip(ensure_built, tmp_path):
     back = pbn.load(str(tmp_path / "g.pickle"))
     assert back.fitted() and np.array_equal(back.cpd("b").beta, [1.0, 2.0]) and back.cpd("b").variance == 0.5
     assert np.array_equal(back.sample(50, 1).column(1).to_numpy(), g.sample(50, 1).column(1).to_numpy())
+
+
+def test_dynamic_dataframe_layout(ensure_built):
+    """DynamicDataFrame (dataset/dynamic_dataset.cpp:16-85): slice i of order m holds rows [m - i, m - i + N - m) under the
+    name v_t_i; the static table of order m has N - m + 1 rows and the slices 1..m."""
+    n = 12
+    df = pd.DataFrame({"a": np.arange(n, dtype=float), "b": np.arange(n, dtype=float) * 10})
+    d1 = pbn.DynamicDataFrame(df, 1)
+    assert d1.static_df().schema.names == ["a_t_1", "b_t_1"] and d1.static_df().num_rows == n
+    t1 = d1.transition_df()
+    assert t1.schema.names == ["a_t_0", "b_t_0", "a_t_1", "b_t_1"] and t1.num_rows == n - 1
+    assert np.array_equal(t1.column(0).to_numpy(), np.arange(1, n)) and np.array_equal(t1.column(2).to_numpy(), np.arange(0, n - 1))
+    d3 = pbn.DynamicDataFrame(df, 3)
+    t3 = d3.transition_df()
+    assert t3.schema.names == [f"{v}_t_{i}" for i in range(4) for v in ("a", "b")] and t3.num_rows == n - 3
+    for i in range(4):
+        assert np.array_equal(t3.column(2 * i).to_numpy(), np.arange(3 - i, n - i))
+    s3 = d3.static_df()
+    assert s3.schema.names == [f"{v}_t_{i}" for i in (1, 2, 3) for v in ("a", "b")] and s3.num_rows == n - 2
+    assert np.array_equal(s3.column(0).to_numpy(), np.arange(2, n)) and np.array_equal(s3.column(4).to_numpy(), np.arange(0, n - 2))
+    assert d3.temporal_slice(2).schema.names == ["a_t_2", "b_t_2"] and d3.num_rows() == n - 3 and d3.num_variables() == 2
+    with pytest.raises(ValueError, match="at least 1"):
+        pbn.DynamicDataFrame(df, 0)
+    from pybnesian_amd.dynamic import static_blacklist, temporal_names
+
+    assert temporal_names(["a", "b"], 1, 2) == ["a_t_1", "a_t_2", "b_t_1", "b_t_2"]
+    assert static_blacklist(["a", "b"], 1) == []
+    assert static_blacklist(["a", "b"], 2) == [("a_t_1", "a_t_2"), ("a_t_1", "b_t_2"), ("b_t_1", "a_t_2"), ("b_t_1", "b_t_2")]
+    dbn = pbn.DynamicBayesianNetwork(["a", "b"], 2)
+    assert dbn.static_bn().nodes() == ["a_t_1", "a_t_2", "b_t_1", "b_t_2"]
+    assert dbn.transition_bn().nodes() == ["a_t_0", "b_t_0"] and dbn.transition_bn().interface_nodes() == dbn.static_bn().nodes()
