@@ -66,7 +66,8 @@ double ibeta_cf(double a, double b, double x) {
 
 // 2 * P(T_df > |t|) = I_{df/(df+t^2)}(df/2, 1/2)   (linearcorrelation.cpp:9-13 with boost's students_t)
 double two_sided_t_pvalue(double t, double df) {
-    if (std::isnan(t)) return std::numeric_limits<double>::quiet_NaN();
+    // Boost's students_t rejects df <= 0 (domain_error): fewer rows than variables + 2
+    if (std::isnan(t) || !(df > 0)) return std::numeric_limits<double>::quiet_NaN();
     if (std::isinf(t)) return 0.0;
     const double t2 = t * t;
     if (t2 == 0.0) return 1.0;

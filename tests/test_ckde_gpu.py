@@ -199,3 +199,27 @@ def test_ckde_cdf_far_evidence(pbn):
     want = [np.exp(logsumexp(lw + norm.logcdf(v, y + b * (30.0 - e), sd)) - logsumexp(lw)) for v in test["y"]]
     assert np.all(np.isfinite(got))
     assert np.allclose(got, want, rtol=1e-8)
+
+
+def test_new_entry_points_edge_cases(pbn, golden):
+    """Empty and tiny inputs through cdf / sample / UCV / independence tests."""
+    train = frame(golden["train500"])
+    cpd = pbn.CKDE("a", ["b"])
+    cpd.fit(train)
+    empty = train.iloc[:0]
+    assert cpd.cdf(empty).shape == (0,) and cpd.logl(empty).shape == (0,) and cpd.slogl(empty) == 0.0
+    assert len(cpd.sample(0, empty[["b"]], 0)) == 0
+    one = cpd.cdf(train.iloc[:1])
+    assert one.shape == (1,) and 0 <= one[0] <= 1
+    tiny = train.iloc[:3]
+    c2 = pbn.CKDE("a", [])
+    c2.fit(tiny)
+    s = c2.sample(7, None, 1).to_numpy()
+    assert s.shape == (7,) and np.all(np.isfinite(s))
+    assert np.isfinite(pbn.UCV().score(tiny, ["a"], np.array([[0.5]])))
+    with pytest.raises(ValueError):
+        pbn.UCV().score(train.iloc[:1], ["a"], np.array([[0.5]]))
+    lc = pbn.LinearCorrelation(train.iloc[:4])
+    assert 0 <= lc.pvalue("a", "b") <= 1
+    with pytest.raises(ValueError):                        # 4 rows, 2 conditioning variables: no degrees of freedom left
+        lc.pvalue("a", "b", ["c", "d"])
