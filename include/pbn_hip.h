@@ -291,6 +291,9 @@ int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types
  * Conditional-independence test callback: p-value of v1 _||_ v2 | cond (indices into the test's variables);
  * IndependenceTest::pvalue (learning/independences/independence.hpp:17-40).  NaN aborts the search. */
 typedef double (*pbn_ci_pvalue_fn)(void* user, int v1, int v2, int n_cond, const int* cond);
+/* n_tests independent tests at once: cond_off has n_tests + 1 offsets into cond; NaN in out[i] aborts the search. */
+typedef void (*pbn_ci_pvalue_batch_fn)(void* user, int n_tests, const int* v1, const int* v2, const int* cond_off,
+                                       const int* cond, double* out);
 /* LinearCorrelation (learning/independences/continuous/linearcorrelation.hpp:62-88, .cpp:9-100): covariance of all
  * columns of `table` taken once on the device (Gram kernel), partial correlations from the eigen-decomposition of the
  * (k+2)-variable block, two-sided Student-t p-value.  pbn_lincor_pvalue has the pbn_ci_pvalue_fn signature with
@@ -313,6 +316,8 @@ int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_di
 void pbn_mi_destroy(pbn_mi* h);
 int pbn_mi_value(pbn_mi* h, int v1, int v2, int n_cond, const int* cond, double* mi, double* df);
 double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
+void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, const int* cond_off, const int* cond,
+                         double* out); /* pbn_ci_pvalue_batch_fn: one launch for many tests */
 int pbn_mi_set_order(pbn_mi* h, int n, const int* ids);
 /* ChiSquare::pvalue (learning/independences/discrete/chi_square.cpp:8-139) over the discrete columns of the same
  * handle (pbn_ci_pvalue_fn signature). */
@@ -331,6 +336,13 @@ int pbn_mmpc_cpcs_conditional(int n, int n_interface, pbn_ci_pvalue_fn fn, void*
                               const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist,
                               int n_edge_whitelist, const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc,
                               int64_t* n_tests);
+
+/* With a batched callback for the steps whose tests are mutually independent (marginal pass, forward extensions);
+ * results are identical to the unbatched search.  batch_fn may be NULL. */
+int pbn_mmpc_cpcs_batched(int n, int n_interface, pbn_ci_pvalue_fn fn, pbn_ci_pvalue_batch_fn batch_fn, void* user,
+                          double alpha, int n_arc_whitelist, const int* arc_whitelist, int n_edge_blacklist,
+                          const int* edge_blacklist, int n_edge_whitelist, const int* edge_whitelist, int symmetric,
+                          int* cpc_off, int* cpc, int64_t* n_tests);
 
 #ifdef __cplusplus
 }

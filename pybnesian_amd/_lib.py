@@ -93,6 +93,8 @@ SIGNATURES = {
     "pbn_mi_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_mmpc_cpcs": (_int, [_int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_mmpc_cpcs_conditional": (_int, [_int, _int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
+    "pbn_mmpc_cpcs_batched": (_int, [_int, _int, _vp, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
+    "pbn_mi_pvalue_batch": (None, [_vp, _int, _ip, _ip, _ip, _ip, _dp]),
     "pbn_hc_estimate": (_int, [_vp, _vp, _vp, _ip, _ip, _ip, _vp]),
     "pbn_hc_create": (_int, [_vp, _vp, _vp, C.POINTER(_vp)]),
     "pbn_hc_destroy": (None, [_vp]),

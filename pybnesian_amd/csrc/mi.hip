@@ -33,7 +33,7 @@ struct pbn_mi {
     dev_buf<int32_t> codes_dev;               // [n_disc][N]
     std::vector<double> shift;                // pilot mean of every continuous column
     std::vector<std::vector<double>> host_cols;  // lazily read back for the host fallback
-    int64_t device_passes = 0, host_passes = 0;
+    int64_t device_passes = 0, host_passes = 0, device_launches = 0;
     std::vector<int> order;  // external index -> variable id for the callback form (empty = identity)
 };
 
@@ -52,7 +52,8 @@ struct GroupArgs {
     int m;
     int64_t n;
     int G, stats;
-    double* partial;
+    double* partial;   // [nblocks][G * stats]
+    double* out;       // [G * stats]
     int64_t chunks_per_block;
 };
 
@@ -68,8 +69,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // cells: no two lanes share a cell, no atomics, fixed order, run-to-run identical, cost independent of how many
 // configurations a chunk touches.  stats per configuration: count, c sums, c(c+1)/2 products (upper triangle).
 template <typename T>
-__global__ __launch_bounds__(64) void group_moments_kernel(GroupArgs a) {
+__global__ __launch_bounds__(64) void group_moments_kernel(const GroupArgs* __restrict__ descs) {
     extern __shared__ double lds[];
+    const GroupArgs& a = descs[blockIdx.y];   // one independence test per grid row
     const int lane = threadIdx.x;
     const int total = a.G * a.stats, c1 = a.c + 1;
     double* acc = lds;                         // [G][stats]
@@ -117,13 +119,15 @@ __global__ __launch_bounds__(64) void group_moments_kernel(GroupArgs a) {
 }
 
 // one wave per statistic: lane l adds the partials of blocks l, l + 64, ... in order, then a fixed butterfly
-__global__ __launch_bounds__(64) void group_reduce_kernel(const double* __restrict__ partial, int nblocks, int total,
-                                                          double* __restrict__ out) {
+__global__ __launch_bounds__(64) void group_reduce_kernel(const GroupArgs* __restrict__ descs, int nblocks) {
+    const GroupArgs& a = descs[blockIdx.y];
+    const int total = a.G * a.stats;
     const int i = blockIdx.x;
+    if (i >= total) return;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * total + i];
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += a.partial[(size_t)b * total + i];
     s = wave_sum(s);
-    if (threadIdx.x == 0) out[i] = s;
+    if (threadIdx.x == 0) a.out[i] = s;
 }
 
 // ---- regularised upper incomplete gamma Q(a, x): chi-square survival function (boost chi_squared complement) --------
@@ -206,43 +210,95 @@ struct Engine {
     bool is_disc(int v) const { return v >= h->n_cont; }
     int card(int v) const { return h->card[v - h->n_cont]; }
 
-    // per-configuration statistics of the continuous variables `cont` over the discrete variables `disc` (first fastest)
-    void group_stats(const std::vector<int>& cont, const std::vector<int>& disc, int G, std::vector<double>& out) {
-        const int c = (int)cont.size(), m = (int)disc.size();
-        const int stats = 1 + c + c * (c + 1) / 2;
-        out.assign((size_t)G * stats, 0.0);
-        if (c > MI_MAX_CONT || m > MI_MAX_DISC) throw invalid_error("MutualInformation: conditioning set too large");
-        const int64_t N = h->N;
-        const size_t lds = ((size_t)G * stats + 64 * (size_t)(c + 1)) * sizeof(double) + 64 * sizeof(int) + 2 * (size_t)stats + 16;
-        if (lds <= 60 * 1024 && N > 0 && (h->table || c == 0)) {
-            pbn_ctx* ctx = h->ctx;
-            HIP_CHECK(hipSetDevice(ctx->device));
-            GroupArgs a{};
+    struct Plan {
+        std::vector<int> cont, disc;
+        int G = 1, c = 0, stats = 1;
+        size_t lds() const { return ((size_t)G * stats + 64 * (size_t)(c + 1)) * sizeof(double) + 64 * sizeof(int) + 2 * (size_t)stats + 16; }
+    };
+    Plan plan(const std::vector<int>& cont, const std::vector<int>& disc) const {
+        Plan p;
+        p.cont = cont; p.disc = disc;
+        if (cont.size() > MI_MAX_CONT || disc.size() > MI_MAX_DISC) throw invalid_error("MutualInformation: conditioning set too large");
+        int64_t G64 = 1;
+        for (int v : disc) { G64 *= card(v); if (G64 > (1 << 24)) throw invalid_error("MutualInformation: too many discrete configurations"); }
+        p.G = (int)G64; p.c = (int)cont.size(); p.stats = 1 + p.c + p.c * (p.c + 1) / 2;
+        return p;
+    }
+    Plan plan(const Query& q) const {
+        std::vector<int> disc, cont;
+        if (q.xd) disc.push_back(q.x);
+        if (q.yd) disc.push_back(q.y);
+        disc.insert(disc.end(), q.zD.begin(), q.zD.end());
+        if (!q.xd) cont.push_back(q.x);
+        if (!q.yd) cont.push_back(q.y);
+        cont.insert(cont.end(), q.zC.begin(), q.zC.end());
+        return plan(cont, disc);
+    }
+    bool on_device(const Plan& p) const { return p.lds() <= 60 * 1024 && h->N > 0 && (h->table || p.c == 0); }
+
+    // per-configuration statistics (count, sums, upper-triangle products of the pilot-shifted continuous variables) of
+    // several tests in ONE launch: grid row = test, so launch / sync latency is paid once per batch
+    void group_stats_device(const std::vector<const Plan*>& plans, std::vector<std::vector<double>>& outs) {
+        pbn_ctx* ctx = h->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const int64_t N = h->N, chunks = ceil_div(N, 64);
+        const int B = (int)plans.size();
+        const int nblocks = (int)std::min<int64_t>(chunks, B >= 8 ? 512 : (B >= 2 ? 2048 : 4096));
+        std::vector<GroupArgs> descs(B);
+        size_t part_doubles = 0, out_doubles = 0, lds = 0;
+        int max_total = 0;
+        for (int t = 0; t < B; ++t) {
+            const Plan& p = *plans[t];
+            const size_t total = (size_t)p.G * p.stats;
+            part_doubles += (size_t)nblocks * total;
+            out_doubles += total;
+            lds = std::max(lds, p.lds());
+            max_total = std::max(max_total, (int)total);
+        }
+        const size_t desc_bytes = ((size_t)B * sizeof(GroupArgs) + 255) / 256 * 256;
+        ctx->scratch_part.reserve(desc_bytes + (part_doubles + out_doubles) * sizeof(double));
+        char* base = ctx->scratch_part.p;
+        double* dpart = (double*)(base + desc_bytes);
+        double* dout = dpart + part_doubles;
+        size_t po = 0, oo = 0;
+        for (int t = 0; t < B; ++t) {
+            const Plan& p = *plans[t];
+            GroupArgs& a = descs[t];
+            a = GroupArgs{};
             a.base = h->table ? h->table->data : nullptr;
             a.ld = h->table ? h->table->ld : 0;
-            a.c = c; a.m = m; a.n = N; a.G = G; a.stats = stats;
-            for (int i = 0; i < c; ++i) { a.cols[i] = cont[i]; a.shift[i] = h->shift[cont[i]]; }
+            a.c = p.c; a.m = (int)p.disc.size(); a.n = N; a.G = p.G; a.stats = p.stats;
+            for (int i = 0; i < p.c; ++i) { a.cols[i] = p.cont[i]; a.shift[i] = h->shift[p.cont[i]]; }
             int stride = 1;
-            for (int j = 0; j < m; ++j) { a.dvar[j] = disc[j] - h->n_cont; a.dstride[j] = stride; stride *= card(disc[j]); }
+            for (int j = 0; j < a.m; ++j) { a.dvar[j] = p.disc[j] - h->n_cont; a.dstride[j] = stride; stride *= card(p.disc[j]); }
             a.codes = h->codes_dev.p; a.codes_ld = N;
-            const int64_t chunks = ceil_div(N, 64);
-            const int nblocks = (int)std::min<int64_t>(chunks, 4096);
             a.chunks_per_block = ceil_div(chunks, nblocks);
-            const int total = G * stats;
-            ctx->scratch_part.reserve((size_t)(nblocks + 1) * total * sizeof(double));
-            a.partial = (double*)ctx->scratch_part.p;
-            double* dout = a.partial + (size_t)nblocks * total;
-            const bool f64 = !h->table || h->table->dtype == PBN_F64;
-            if (f64) hipLaunchKernelGGL(group_moments_kernel<double>, dim3(nblocks), dim3(64), lds, ctx->stream, a);
-            else hipLaunchKernelGGL(group_moments_kernel<float>, dim3(nblocks), dim3(64), lds, ctx->stream, a);
-            hipLaunchKernelGGL(group_reduce_kernel, dim3(total), dim3(64), 0, ctx->stream, a.partial, nblocks, total, dout);
-            HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(out.data(), dout, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            ++h->device_passes;
-            return;
+            a.partial = dpart + po; a.out = dout + oo;
+            po += (size_t)nblocks * p.G * p.stats; oo += (size_t)p.G * p.stats;
         }
-        // host fallback: more configurations than fit the LDS accumulators
+        HIP_CHECK(hipMemcpyAsync(base, descs.data(), (size_t)B * sizeof(GroupArgs), hipMemcpyHostToDevice, ctx->stream));
+        const bool f64 = !h->table || h->table->dtype == PBN_F64;
+        if (f64) hipLaunchKernelGGL(group_moments_kernel<double>, dim3(nblocks, B), dim3(64), lds, ctx->stream, (const GroupArgs*)base);
+        else hipLaunchKernelGGL(group_moments_kernel<float>, dim3(nblocks, B), dim3(64), lds, ctx->stream, (const GroupArgs*)base);
+        hipLaunchKernelGGL(group_reduce_kernel, dim3(max_total, B), dim3(64), 0, ctx->stream, (const GroupArgs*)base, nblocks);
+        HIP_CHECK(hipGetLastError());
+        std::vector<double> all(out_doubles);
+        HIP_CHECK(hipMemcpyAsync(all.data(), dout, out_doubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        oo = 0;
+        for (int t = 0; t < B; ++t) {
+            const size_t total = (size_t)plans[t]->G * plans[t]->stats;
+            outs[t].assign(all.begin() + oo, all.begin() + oo + total);
+            oo += total;
+        }
+        h->device_passes += B;
+        ++h->device_launches;
+    }
+
+    void group_stats_host(const Plan& p, std::vector<double>& out) {   // more configurations than fit the LDS accumulators
+        const int c = p.c, m = (int)p.disc.size(), stats = p.stats;
+        const int64_t N = h->N;
+        out.assign((size_t)p.G * stats, 0.0);
         if (c > 0 && h->host_cols.empty()) {
             h->host_cols.resize(h->n_cont);
             const size_t es = dtype_size(h->table->dtype);
@@ -256,14 +312,14 @@ struct Engine {
         }
         std::vector<int> strides(m);
         int stride = 1;
-        for (int j = 0; j < m; ++j) { strides[j] = stride; stride *= card(disc[j]); }
+        for (int j = 0; j < m; ++j) { strides[j] = stride; stride *= card(p.disc[j]); }
         double v[MI_MAX_CONT];
         for (int64_t r = 0; r < N; ++r) {
             int64_t g = 0;
-            for (int j = 0; j < m; ++j) g += (int64_t)h->codes[disc[j] - h->n_cont][r] * strides[j];
+            for (int j = 0; j < m; ++j) g += (int64_t)h->codes[p.disc[j] - h->n_cont][r] * strides[j];
             double* dst = out.data() + (size_t)g * stats;
             dst[0] += 1.0;
-            for (int i = 0; i < c; ++i) v[i] = h->host_cols[cont[i]][r] - h->shift[cont[i]];
+            for (int i = 0; i < c; ++i) v[i] = h->host_cols[p.cont[i]][r] - h->shift[p.cont[i]];
             int pos = 1;
             for (int i = 0; i < c; ++i) dst[pos++] += v[i];
             for (int i = 0; i < c; ++i)
@@ -272,22 +328,50 @@ struct Engine {
         ++h->host_passes;
     }
 
+    // statistics of a list of plans: device batches bounded by scratch memory, host fallback one by one
+    void group_stats_many(const std::vector<Plan>& plans, std::vector<std::vector<double>>& outs) {
+        outs.assign(plans.size(), {});
+        const int64_t chunks = ceil_div(h->N, 64);
+        std::vector<const Plan*> cur;
+        std::vector<size_t> cur_idx;
+        size_t cur_doubles = 0;
+        auto flush = [&] {
+            if (cur.empty()) return;
+            std::vector<std::vector<double>> o(cur.size());
+            group_stats_device(cur, o);
+            for (size_t i = 0; i < cur.size(); ++i) outs[cur_idx[i]].swap(o[i]);
+            cur.clear(); cur_idx.clear(); cur_doubles = 0;
+        };
+        for (size_t t = 0; t < plans.size(); ++t) {
+            if (!on_device(plans[t])) { group_stats_host(plans[t], outs[t]); continue; }
+            const size_t need = (size_t)std::min<int64_t>(chunks, 512) * plans[t].G * plans[t].stats;
+            if (!cur.empty() && (cur.size() >= 256 || cur_doubles + need > ((size_t)1 << 25))) flush();   // <= 256 MB of partials
+            cur.push_back(&plans[t]); cur_idx.push_back(t); cur_doubles += need;
+        }
+        flush();
+    }
+
+    void group_stats(const std::vector<int>& cont, const std::vector<int>& disc, int G, std::vector<double>& out) {
+        std::vector<Plan> one{plan(cont, disc)};
+        (void)G;
+        std::vector<std::vector<double>> o;
+        group_stats_many(one, o);
+        out.swap(o[0]);
+    }
+
     // MI(X; Y | Z) (mutual_information.cpp:926-1055 no conditioning, :1139-1312 one variable, :1391-1658 general);
     // every overload of the reference is the general formula with the matching emptiness of zD / zC.
     double mi(const Query& q) {
-        std::vector<int> disc, cont;
-        if (q.xd) disc.push_back(q.x);
-        if (q.yd) disc.push_back(q.y);
-        disc.insert(disc.end(), q.zD.begin(), q.zD.end());
-        if (!q.xd) cont.push_back(q.x);
-        if (!q.yd) cont.push_back(q.y);
-        cont.insert(cont.end(), q.zC.begin(), q.zC.end());
-        int64_t G64 = 1;
-        for (int v : disc) { G64 *= card(v); if (G64 > (1 << 24)) throw invalid_error("MutualInformation: too many discrete configurations"); }
-        const int G = (int)G64, c = (int)cont.size(), zc = (int)q.zC.size();
-        const int stats = 1 + c + c * (c + 1) / 2;
-        std::vector<double> st;
-        group_stats(cont, disc, G, st);
+        std::vector<Plan> one{plan(q)};
+        std::vector<std::vector<double>> o;
+        group_stats_many(one, o);
+        return mi_from_stats(q, one[0], o[0]);
+    }
+
+    double mi_from_stats(const Query& q, const Plan& pl, const std::vector<double>& st) {
+        const std::vector<int>& disc = pl.disc;
+        const int G = pl.G, c = pl.c, zc = (int)q.zC.size();
+        const int stats = pl.stats;
         const double N = (double)h->N;
         auto S = [&](int g) { return st.data() + (size_t)g * stats; };
         std::vector<int> selz(zc);
@@ -488,6 +572,37 @@ double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
     }
     if (pbn_mi_value(h, v1, v2, n_cond, cond, &mi, &df) != PBN_OK) return std::nan("");
     return gamma_q(0.5 * df, 0.5 * (mi * 2.0 * (double)h->N));
+}
+
+// Batched form: n_tests independence tests in as few launches as scratch memory allows (pbn_ci_pvalue_batch_fn).
+// cond_off has n_tests + 1 entries into cond.  NaN in out[i] marks a failed test (pbn_last_error has the last reason).
+void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, const int* cond_off, const int* cond, double* out) {
+    pbn_mi* h = (pbn_mi*)user;
+    for (int i = 0; i < n_tests; ++i) out[i] = std::nan("");
+    (void)guarded([&] {
+        if (!h || !v1 || !v2 || !cond_off || !out) throw invalid_error("pbn_mi_pvalue_batch: null argument");
+        Engine e{h};
+        auto map = [&](int v) {
+            if (h->order.empty()) return v;
+            if (v < 0 || v >= (int)h->order.size()) throw invalid_error("MutualInformation: variable index out of range");
+            return h->order[v];
+        };
+        std::vector<Query> qs(n_tests);
+        std::vector<Engine::Plan> plans(n_tests);
+        std::vector<int> cm;
+        for (int i = 0; i < n_tests; ++i) {
+            cm.clear();
+            for (int j = cond_off[i]; j < cond_off[i + 1]; ++j) cm.push_back(map(cond[j]));
+            qs[i] = e.make(map(v1[i]), map(v2[i]), (int)cm.size(), cm.data());
+            plans[i] = e.plan(qs[i]);
+        }
+        std::vector<std::vector<double>> st;
+        e.group_stats_many(plans, st);
+        for (int i = 0; i < n_tests; ++i) {
+            const double mi = e.mi_from_stats(qs[i], plans[i], st[i]);
+            out[i] = gamma_q(0.5 * e.df(qs[i]), 0.5 * (mi * 2.0 * (double)h->N));
+        }
+    });
 }
 
 // Index space of pbn_mi_pvalue: external index i stands for variable ids[i] (n == 0 restores the identity).

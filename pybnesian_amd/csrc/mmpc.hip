@@ -213,6 +213,7 @@ struct Mmpc {
     double alpha;
     pbn_ci_pvalue_fn fn;
     void* user;
+    pbn_ci_pvalue_batch_fn batch_fn = nullptr;   // optional: many independent tests per call (one device launch)
     int64_t tests = 0;
     std::vector<double> min_assoc;   // n x n, column = variable whose CPC is built
     std::vector<double> maxmin;
@@ -226,6 +227,27 @@ struct Mmpc {
         const double p = fn(user, a, b, (int)cond.size(), cond.data());
         if (std::isnan(p)) throw invalid_error("MMPC: the independence test failed");
         return p;
+    }
+    struct Req { int a, b; std::vector<int> cond; };
+    // p-values of independent requests, in request order; one call of the batched callback when there is one
+    std::vector<double> pvalues(const std::vector<Req>& reqs) {
+        std::vector<double> out(reqs.size());
+        if (!batch_fn || reqs.size() < 2) {
+            for (size_t i = 0; i < reqs.size(); ++i) out[i] = pvalue(reqs[i].a, reqs[i].b, reqs[i].cond);
+            return out;
+        }
+        std::vector<int> v1, v2, off{0}, cond;
+        for (const Req& r : reqs) {
+            v1.push_back(r.a); v2.push_back(r.b);
+            cond.insert(cond.end(), r.cond.begin(), r.cond.end());
+            off.push_back((int)cond.size());
+        }
+        if (cond.empty()) cond.push_back(0);
+        batch_fn(user, (int)reqs.size(), v1.data(), v2.data(), off.data(), cond.data(), out.data());
+        tests += (int64_t)reqs.size();
+        for (double p : out)
+            if (std::isnan(p)) throw invalid_error("MMPC: the independence test failed");
+        return out;
     }
     double pvalue(int a, int b) { static const std::vector<int> none; return pvalue(a, b, none); }
     double pvalue(int a, int b, int c) { return pvalue(a, b, std::vector<int>{c}); }
@@ -249,8 +271,13 @@ struct Mmpc {
     // association of every remaining candidate given every subset of the CPC that contains the variable added last
     void extend_assoc(int var, const IntSet& tbc, const IntSet& cpc, int last) {
         reset(var);
+        // the tests of one extension step are independent of each other: requested together, applied in the
+        // reference's order
+        std::vector<Req> reqs;
         if (cpc.empty()) {
-            for (int v : tbc) init_assoc(v, var, pvalue(var, v));
+            for (int v : tbc) reqs.push_back({var, v, {}});
+            const std::vector<double> p = pvalues(reqs);
+            for (size_t i = 0; i < reqs.size(); ++i) init_assoc(reqs[i].b, var, p[i]);
             return;
         }
         std::vector<int> old;
@@ -262,8 +289,10 @@ struct Mmpc {
                     cond.clear();
                     for (int i : c.idx) cond.push_back(old[i]);
                     cond.push_back(last);
-                    update_assoc(v, var, pvalue(var, v, cond));
+                    reqs.push_back({var, v, cond});
                 }
+        const std::vector<double> p = pvalues(reqs);
+        for (size_t i = 0; i < reqs.size(); ++i) update_assoc(reqs[i].b, var, p[i]);
     }
 
     void forward(int var, IntSet& cpc, IntSet& tbc, int last) {
@@ -339,9 +368,20 @@ struct Mmpc {
         maxmin.assign(n, alpha);
         maxmin_idx.assign(n, STOP);
         // marginal associations of all pairs at once (mmpc.cpp:698-738; node x interface pairs :740-784)
+        // (the CPCs do not change during this pass, so the pairs can be requested together)
+        std::vector<Req> mreq;
         auto marginal_pair = [&](int i, int j) {
-            if ((cpcs[i].empty() || cpcs[j].empty()) && !edge_bl.has(i, j)) {
-                const double p = pvalue(i, j);
+            if ((cpcs[i].empty() || cpcs[j].empty()) && !edge_bl.has(i, j)) mreq.push_back({i, j, {}});
+        };
+        for (int i = 0; i + 1 < nn; ++i)
+            for (int j = i + 1; j < nn; ++j) marginal_pair(i, j);
+        for (int i = 0; i < nn; ++i)
+            for (int j = nn; j < n; ++j) marginal_pair(i, j);
+        {
+            const std::vector<double> mp = pvalues(mreq);
+            for (size_t q = 0; q < mreq.size(); ++q) {
+                const int i = mreq[q].a, j = mreq[q].b;
+                const double p = mp[q];
                 if (p < alpha) {
                     if (cpcs[i].empty()) init_assoc(j, i, p);
                     if (cpcs[j].empty()) init_assoc(i, j, p);
@@ -350,11 +390,7 @@ struct Mmpc {
                     tbc[j].erase(i);
                 }
             }
-        };
-        for (int i = 0; i + 1 < nn; ++i)
-            for (int j = i + 1; j < nn; ++j) marginal_pair(i, j);
-        for (int i = 0; i < nn; ++i)
-            for (int j = nn; j < n; ++j) marginal_pair(i, j);
+        }
         bool all_finished = true;
         for (int i = 0; i < n; ++i) {
             if (maxmin_idx[i] != STOP) {
@@ -466,13 +502,14 @@ double pbn_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond
     return lincor_pvalue(h, v1, v2, n_cond, cond);
 }
 
-static int mmpc_cpcs_impl(int n, int n_interface, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist,
+static int mmpc_cpcs_impl(int n, int n_interface, pbn_ci_pvalue_fn fn, pbn_ci_pvalue_batch_fn batch_fn, void* user, double alpha, int n_arc_whitelist,
                           const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist,
                           const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
     return guarded([&] {
         if (n <= 0 || n_interface < 0 || n_interface >= n || !fn || !cpc_off || !cpc) throw invalid_error("pbn_mmpc_cpcs: bad argument");
         if (!(alpha > 0 && alpha < 1)) throw invalid_error("alpha must be a number between 0 and 1.");
         Mmpc m{n, alpha, fn, user};
+        m.batch_fn = batch_fn;
         m.ni = n_interface;
         m.arc_wl.n = m.edge_bl.n = m.edge_wl.n = n;
         m.edge_bl.symmetric = m.edge_wl.symmetric = true;
@@ -513,7 +550,7 @@ static int mmpc_cpcs_impl(int n, int n_interface, pbn_ci_pvalue_fn fn, void* use
 int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist, const int* arc_whitelist,
                   int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist, const int* edge_whitelist,
                   int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
-    return mmpc_cpcs_impl(n, 0, fn, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist, n_edge_whitelist,
+    return mmpc_cpcs_impl(n, 0, fn, nullptr, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist, n_edge_whitelist,
                           edge_whitelist, symmetric, cpc_off, cpc, n_tests);
 }
 
@@ -522,7 +559,16 @@ int pbn_mmpc_cpcs(int n, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_ar
 int pbn_mmpc_cpcs_conditional(int n, int n_interface, pbn_ci_pvalue_fn fn, void* user, double alpha, int n_arc_whitelist,
                               const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist,
                               const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
-    return mmpc_cpcs_impl(n, n_interface, fn, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist,
+    return mmpc_cpcs_impl(n, n_interface, fn, nullptr, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist,
+                          n_edge_whitelist, edge_whitelist, symmetric, cpc_off, cpc, n_tests);
+}
+
+// The same with a batched test callback for the steps whose tests are independent of each other (the marginal pass and
+// every extension of the forward phase); fn still serves the sequential steps.  batch_fn may be NULL.
+int pbn_mmpc_cpcs_batched(int n, int n_interface, pbn_ci_pvalue_fn fn, pbn_ci_pvalue_batch_fn batch_fn, void* user, double alpha,
+                          int n_arc_whitelist, const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist,
+                          int n_edge_whitelist, const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
+    return mmpc_cpcs_impl(n, n_interface, fn, batch_fn, user, alpha, n_arc_whitelist, arc_whitelist, n_edge_blacklist, edge_blacklist,
                           n_edge_whitelist, edge_whitelist, symmetric, cpc_off, cpc, n_tests);
 }
 

@@ -197,6 +197,14 @@ class MutualInformation(IndependenceTest):
         _lib.check(lib.pbn_mi_set_order(self._handle, len(nodes), _lib.int_array([self._var(n) for n in nodes])))
         return C.cast(lib.pbn_mi_pvalue, C.c_void_p), self._handle, self, []
 
+    def _ci_batch_callback(self):
+        """Batched native callback (same handle / index order as _ci_callback): independent tests share a launch."""
+        import os
+
+        if os.environ.get("PBN_MI_BATCH", "1") == "0":
+            return None
+        return C.cast(_lib.load().pbn_mi_pvalue_batch, C.c_void_p)
+
     def __del__(self):
         try:
             if _lib.alive() and getattr(self, "_handle", None):
@@ -231,6 +239,9 @@ class ChiSquare(MutualInformation):
 
     def mi(self, x, y, z=None):
         raise AttributeError("ChiSquare has no mi()")
+
+    def _ci_batch_callback(self):
+        return None
 
     def _ci_callback(self, nodes):
         lib = _lib.load()
@@ -290,9 +301,10 @@ def mmpc_cpcs(test, nodes, alpha=0.05, arc_whitelist=(), edge_blacklist=(), edge
     off = (C.c_int * (n + 1))()
     out = (C.c_int * max(1, n * (n - 1)))()
     ntests = C.c_int64(0)
-    rc = _lib.load().pbn_mmpc_cpcs_conditional(n, len(interface_nodes), fn, user, float(alpha), len(arc_whitelist),
-                                               flat(arc_whitelist), len(edge_blacklist), flat(edge_blacklist), len(edge_whitelist),
-                                               flat(edge_whitelist), int(bool(symmetric)), off, out, C.byref(ntests))
+    batch = getattr(test, "_ci_batch_callback", lambda: None)()
+    rc = _lib.load().pbn_mmpc_cpcs_batched(n, len(interface_nodes), fn, batch, user, float(alpha), len(arc_whitelist),
+                                           flat(arc_whitelist), len(edge_blacklist), flat(edge_blacklist), len(edge_whitelist),
+                                           flat(edge_whitelist), int(bool(symmetric)), off, out, C.byref(ntests))
     if errors:
         raise errors[0]
     _lib.check(rc)
