@@ -107,6 +107,7 @@ SIGNATURES = {
 
 HC_SCORE_FN = C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)
 CI_PVALUE_FN = C.CFUNCTYPE(C.c_double, _vp, _int, _int, _int, _ip)
+CI_BATCH_FN = C.CFUNCTYPE(None, _vp, _int, _ip, _ip, _ip, _ip, _dp)
 HC_ITER_FN = C.CFUNCTYPE(_int, _vp, _int, _ip, C.c_double, _int, _ip, _ip)
 
 

@@ -133,3 +133,60 @@ def reduce_moments(handle):
         for r in range(1, world):
             buf += parts[r]
     _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 1))
+
+
+def sharded_ci_batch(fn, native_batch, user, errors):
+    """Independence tests of one MMPC step spread over the ranks (same idea as the delta cache: independent units, one
+    all_gather per batch).  Every rank runs the same search; test i of a batch is evaluated by rank i % world - through
+    the native batched callback when the test has one, else one by one - and the p-values are gathered, so every rank
+    sees bit-identical numbers and takes identical decisions.  Returns (batch callback or None, keep-alive)."""
+    import ctypes as C
+
+    from . import _lib
+
+    dist = _dist()
+    if dist is None:
+        return native_batch, None
+    import torch
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    single = fn if callable(fn) else _lib.CI_PVALUE_FN(fn.value)
+    native = _lib.CI_BATCH_FN(native_batch.value) if native_batch is not None else None
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    def batch(_user, n, v1, v2, off, cond, out):
+        try:
+            mine = list(range(rank, n, world))
+            local = np.full(len(mine), np.nan)
+            if mine:
+                a = _lib.int_array([v1[i] for i in mine])
+                b = _lib.int_array([v2[i] for i in mine])
+                o, c = [0], []
+                for i in mine:
+                    c.extend(cond[j] for j in range(off[i], off[i + 1]))
+                    o.append(len(c))
+                if native is not None:
+                    native(user, len(mine), a, b, _lib.int_array(o), _lib.int_array(c or [0]), _lib.dptr(local))
+                else:
+                    for q, i in enumerate(mine):
+                        ci = _lib.int_array(c[o[q]: o[q + 1]] or [0])
+                        local[q] = single(user, v1[i], v2[i], o[q + 1] - o[q], ci)
+            per = (n + world - 1) // world
+            buf = np.full(per, np.nan)
+            buf[: len(mine)] = local
+            send = torch.from_numpy(buf).to(dev)
+            recv = torch.empty(world * per, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(recv, send)
+            allv = recv.cpu().numpy().reshape(world, per)
+            for r in range(world):
+                idx = range(r, n, world)
+                for q, i in enumerate(idx):
+                    out[i] = allv[r, q]
+        except Exception as ex:  # surfaced after the C call returns
+            errors.append(ex)
+            for i in range(n):
+                out[i] = float("nan")
+
+    cb = _lib.CI_BATCH_FN(batch)
+    return C.cast(cb, C.c_void_p), (cb, single, native)

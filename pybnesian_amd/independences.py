@@ -302,11 +302,14 @@ def mmpc_cpcs(test, nodes, alpha=0.05, arc_whitelist=(), edge_blacklist=(), edge
     out = (C.c_int * max(1, n * (n - 1)))()
     ntests = C.c_int64(0)
     batch = getattr(test, "_ci_batch_callback", lambda: None)()
+    from .distributed import sharded_ci_batch
+
+    batch, keep_batch = sharded_ci_batch(fn, batch, user, errors)
     rc = _lib.load().pbn_mmpc_cpcs_batched(n, len(interface_nodes), fn, batch, user, float(alpha), len(arc_whitelist),
                                            flat(arc_whitelist), len(edge_blacklist), flat(edge_blacklist), len(edge_whitelist),
                                            flat(edge_whitelist), int(bool(symmetric)), off, out, C.byref(ntests))
     if errors:
         raise errors[0]
     _lib.check(rc)
-    del keep
+    del keep, keep_batch
     return [[nodes[out[j]] for j in range(off[i], off[i + 1])] for i in range(n)], ntests.value

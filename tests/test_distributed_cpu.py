@@ -64,3 +64,43 @@ def test_shard_indices_partition():
         for world in (1, 2, 8):
             parts = [shard_indices(n, r, world) for r in range(world)]
             assert sorted(i for p in parts for i in p) == list(range(n))
+
+
+def _mmpc_worker(rank, world, port, n, seed, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pybnesian_amd.independences import mmpc_cpcs
+        from test_mmpc_cpu import TableTest
+
+        t = TableTest(n, seed, 500)
+        cpcs, ntests = mmpc_cpcs(t, t.names, 0.05)
+        queue.put((rank, cpcs, ntests, t.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_mmpc_world2(ensure_built):
+    """The independence tests of every batched MMPC step are dealt over the ranks and gathered: both ranks end with the
+    single-process CPCs (same members, same libstdc++ set order, same number of tests) while evaluating fewer tests."""
+    from pybnesian_amd.independences import mmpc_cpcs
+    from test_mmpc_cpu import TableTest
+
+    n, seed, world = 10, 4, 2
+    ref_t = TableTest(n, seed, 500)
+    ref, ref_tests = mmpc_cpcs(ref_t, ref_t.names, 0.05)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mmpc_worker, args=(r, world, port, n, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, cpcs, ntests, calls in results:
+        assert cpcs == ref and ntests == ref_tests
+        assert calls < ref_t.calls
+    assert sum(r[3] for r in results) >= ref_t.calls

@@ -19,7 +19,21 @@ single = {}
 for name, mk in (("bge", lambda: pbn.BGe(sdf)), ("bic", lambda: pbn.BIC(sdf)), ("cv", lambda: pbn.CVLikelihood(sdf, k=5, seed=1))):
     sc = mk()
     single[name] = [sc.local_score(pbn.GaussianNetwork(list("vwxyz")), v, e) for v, e in cands]
+# MMPC with the hybrid MutualInformation test: single-process CPCs first
+from pybnesian_amd.independences import mmpc_cpcs  # noqa: E402
+
+hn = 30000
+hd = rng.integers(0, 3, size=hn)
+hdf = pd.DataFrame({"h0": rng.normal(size=hn) + hd, "h1": rng.normal(size=hn), "h2": rng.normal(size=hn)})
+hdf["h1"] += 0.8 * hdf["h0"]
+hdf["h2"] -= 0.6 * hdf["h1"]
+hdf["hd"] = pd.Categorical.from_codes(hd, ["a", "b", "c"])
+single_cpcs = mmpc_cpcs(pbn.MutualInformation(hdf), list(hdf.columns), 0.05)
 dist.init_process_group("gloo")
+mi_test = pbn.MutualInformation(hdf)
+sharded_cpcs = mmpc_cpcs(mi_test, list(hdf.columns), 0.05)      # test batches dealt over the ranks, one all_gather each
+assert sharded_cpcs == single_cpcs, (sharded_cpcs, single_cpcs)
+assert mi_test.passes()[0] < single_cpcs[1]
 for name, mk in (("bge", lambda: pbn.BGe(sdf)), ("bic", lambda: pbn.BIC(sdf)), ("cv", lambda: pbn.CVLikelihood(sdf, k=5, seed=1))):
     sc = mk()   # now sharded: each rank takes the Gram of half of every region, one all_gather of the moments
     got = [sc.local_score(pbn.GaussianNetwork(list("vwxyz")), v, e) for v, e in cands]
@@ -32,5 +46,5 @@ for f in (pbn.KDE(list("abc")), pbn.CKDE("a", ["b", "c"])):
     got = sharded_slogl(f, test)
     assert abs(got - whole) <= 1e-12 * abs(whole), (got, whole)
 if dist.get_rank() == 0:
-    print("row-sharded moments + sharded_slogl ok on", dist.get_world_size(), "ranks")
+    print("row-sharded moments + sharded MMPC + sharded_slogl ok on", dist.get_world_size(), "ranks")
 dist.destroy_process_group()
