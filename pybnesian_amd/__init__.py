@@ -17,7 +17,7 @@ from .dynamic import (DMMHC, DynamicBayesianNetwork, DynamicBGe, DynamicBIC, Dyn
 from .independences import ChiSquare, IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
 from .models import (BayesianNetwork, BayesianNetworkType, FactorType, ConditionalBayesianNetwork, ConditionalCLGNetwork, ConditionalGaussianNetwork,  # noqa: F401
                      ConditionalKDENetwork, ConditionalSemiparametricBN, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
-                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, load)
+                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load)
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
 
@@ -27,5 +27,5 @@ __all__ = [
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth", "UCV",
-    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "DynamicDataFrame", "DynamicBayesianNetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
+    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "UnknownFactorType", "DynamicDataFrame", "DynamicBayesianNetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
 ]

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .models import (BayesianNetwork, CKDEType, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType,
+from .models import (UnknownFactorType, BayesianNetwork, CKDEType, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType,
                      KDENetworkType, LinearGaussianCPDType, SemiparametricBNType)
 from .scores import Score, default_score
 
@@ -22,6 +22,7 @@ _BN_CODE = {GaussianNetworkType: _lib.PBN_BN_GAUSSIAN, SemiparametricBNType: _li
 _NODE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE,
               DiscreteFactorType(): _lib.PBN_NODE_DISCRETE}
 _NODE_FROM_CODE = {v: k for k, v in _NODE_CODE.items()}
+_NODE_CODE[UnknownFactorType()] = _lib.PBN_NODE_LG   # set_unknown_node_types: a continuous column defaults to LinearGaussianCPD
 
 
 class Operator:
@@ -240,10 +241,15 @@ class _EngineBinding:
         col_of_node = [score._col[v] for v in self.nodes] if device_score else list(range(len(self.nodes)))
         idx = self.idx
 
-        def pairs(lst, second=idx.__getitem__):
+        def node_index(v):
+            if v not in idx:
+                raise ValueError(f"Node {v} not present in the graph.")   # util::check_arc_list (validate_whitelists.hpp:24-33)
+            return idx[v]
+
+        def pairs(lst, second=node_index):
             flat = []
             for a, b in lst:
-                flat += [idx[a], second(b)]
+                flat += [node_index(a), second(b)]
             return flat
 
         for st in sets:

@@ -34,6 +34,13 @@ class DiscreteFactorType(FactorType):
     _name = "DiscreteFactor"
 
 
+class UnknownFactorType(FactorType):
+    """Node type of a heterogeneous network before it has seen data (factors/factors.hpp:60-90): resolved from the
+    column's data type by set_unknown_node_types / fit / the hill-climb (hillclimbing.hpp:81-93)."""
+
+    _name = "UnknownFactor"
+
+
 class BayesianNetworkType:
     _name = "BayesianNetworkType"
     homogeneous = True
@@ -58,6 +65,7 @@ class KDENetworkType(BayesianNetworkType):
 class SemiparametricBNType(BayesianNetworkType):
     _name = "SemiparametricBNType"
     homogeneous = False
+    default_type = UnknownFactorType()
 
 
 class CLGNetworkType(BayesianNetworkType):
@@ -66,6 +74,7 @@ class CLGNetworkType(BayesianNetworkType):
 
     _name = "CLGNetworkType"
     homogeneous = False
+    default_type = UnknownFactorType()
 
 
 class BayesianNetwork:
@@ -236,6 +245,51 @@ class BayesianNetwork:
     def node_types(self):
         return dict(self._types)
 
+    def has_unknown_node_types(self):
+        return any(t == UnknownFactorType() for t in self._types.values())
+
+    def underlying_node_type(self, df, node):
+        """BNGeneric::underlying_node_type (BayesianNetwork.hpp:662-681): the node's type, or for an unknown one the
+        first default of the network type for the column's data type (SemiparametricBN.hpp:60-75, CLGNetwork.hpp:55-68:
+        float -> LinearGaussianCPD, dictionary -> DiscreteFactor)."""
+        import pyarrow as pa
+
+        from .dataset import as_record_batch
+
+        t = self._types[node]
+        if t != UnknownFactorType():
+            return t
+        rb = as_record_batch(df)
+        f = rb.schema.field(node)
+        if pa.types.is_dictionary(f.type):
+            return DiscreteFactorType()
+        if pa.types.is_floating(f.type):
+            return LinearGaussianCPDType()
+        raise ValueError(f"There is no underlying FactorType for node {node} as there is no valid FactorType for DataType {f.type}")
+
+    def set_unknown_node_types(self, df, type_blacklist=()):
+        """BNGeneric::set_unknown_node_types (BayesianNetwork.hpp:700-745)."""
+        import pyarrow as pa
+
+        from .dataset import as_record_batch
+
+        rb = as_record_batch(df)
+        black = {(n, t) for n, t in type_blacklist}
+        for node, t in list(self._types.items()):
+            if t != UnknownFactorType():
+                continue
+            f = rb.schema.field(node)
+            if pa.types.is_dictionary(f.type):
+                options = [DiscreteFactorType()]
+            elif isinstance(self._type, CLGNetworkType):
+                options = [LinearGaussianCPDType()]
+            else:
+                options = [LinearGaussianCPDType(), CKDEType()]
+            options = [o for o in options if (node, o) not in black]
+            if not options:
+                raise ValueError(f"There is no valid FactorType for node {node} (all the defaults are blacklisted).")
+            self._types[node] = options[0]
+
     def set_node_type(self, node, node_type):
         if isinstance(self._type, CLGNetworkType) and node_type == CKDEType():
             raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
@@ -259,6 +313,8 @@ class BayesianNetwork:
         parents = self.parents(node)
         is_disc = lambda v: pa.types.is_dictionary(rb.schema.field(v).type)
         nt = DiscreteFactorType() if is_disc(node) else self._types[node]
+        if nt == UnknownFactorType():
+            nt = LinearGaussianCPDType()
         if nt == DiscreteFactorType():
             return DiscreteFactor(node, parents)
         hybrid = any(is_disc(p) for p in parents)

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from .dataset import DeviceTable, as_record_batch, default_context
 from .models import (CKDEType, CLGNetworkType, DiscreteFactorType, GaussianNetworkType, KDENetworkType, LinearGaussianCPDType,
-                     SemiparametricBNType)
+                     SemiparametricBNType, UnknownFactorType)
 
 _TYPE_CODE = {LinearGaussianCPDType(): _lib.PBN_NODE_LG, CKDEType(): _lib.PBN_NODE_CKDE, DiscreteFactorType(): _lib.PBN_NODE_DISCRETE}
 
@@ -264,6 +264,8 @@ class _DeviceScore(Score):
     def _encode(self, cands):
         var, ntype, off, par = [], [], [0], []
         for v, t, ev in cands:
+            if t == UnknownFactorType():   # Score::local_score on an unknown node type: underlying_node_type(data, node)
+                t = DiscreteFactorType() if self.is_discrete(v) else LinearGaussianCPDType()
             if t not in self._allowed_types:
                 raise ValueError(f"Node type \"{t}\" not valid for score {type(self).__name__}")
             var.append(self._col[v])

@@ -219,7 +219,7 @@ def test_operator_set_piecewise_api_reproduces_estimate(ensure_built):
         pool.update_scores(model, ts, op.nodes_changed(model))
     assert trace == ref_trace and [o.delta() for o in trace] == [o.delta() for o in ref_trace]
     assert sorted(model.arcs()) == sorted(ref.arcs())
-    assert cache.sum() == pytest.approx(sum(ts.raw(int(v[1:]), 0 if model.node_type(v) == pbn.LinearGaussianCPDType() else 1,
+    assert cache.sum() == pytest.approx(sum(ts.raw(int(v[1:]), 1 if model.node_type(v) == pbn.CKDEType() else 0,   # unknown -> LinearGaussian
                                                    [int(p[1:]) for p in model.parents(v)]) for v in names))
     # tabu: the best operator is skipped when it is in the tabu set
     pool.cache_scores(pbn.SemiparametricBN(names), ts)
