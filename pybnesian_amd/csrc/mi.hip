@@ -29,10 +29,8 @@ struct pbn_mi {
     int64_t N = 0;
     bool asymptotic = true;
     std::vector<int> card;
-    std::vector<std::vector<int32_t>> codes;  // host copies (fallback path)
     dev_buf<int32_t> codes_dev;               // [n_disc][N]
     std::vector<double> shift;                // pilot mean of every continuous column
-    std::vector<std::vector<double>> host_cols;  // lazily read back for the host fallback
     int64_t device_passes = 0, host_passes = 0, device_launches = 0;
     std::vector<int> order;  // external index -> variable id for the callback form (empty = identity)
 };
@@ -51,7 +49,8 @@ struct GroupArgs {
     int dstride[MI_MAX_DISC];
     int m;
     int64_t n;
-    int G, stats;
+    int G, stats;      // configurations handled by this launch row (a window of the test's configurations) and statistics each
+    int g0;            // first configuration of the window
     double* partial;   // [nblocks][G * stats]
     double* out;       // [G * stats]
     int64_t chunks_per_block;
@@ -102,13 +101,16 @@ __global__ __launch_bounds__(64) void group_moments_kernel(const GroupArgs* __re
             stage[lane * c1 + a.c] = 1.0;
             int g = 0;
             for (int j = 0; j < a.m; ++j) g += a.codes[(int64_t)a.dvar[j] * a.codes_ld + r] * a.dstride[j];
-            gid[lane] = g;
+            g -= a.g0;
+            gid[lane] = (g >= 0 && g < a.G) ? g : -1;   // rows of other windows are skipped
         }
         __syncthreads();
         for (int s0 = lane; s0 < a.stats; s0 += 64) {
             const int fi = pi[s0], fj = pj[s0];
             for (int rr = 0; rr < rows; ++rr) {
-                double* cell = acc + (size_t)gid[rr] * a.stats + s0;
+                const int g = gid[rr];
+                if (g < 0) continue;
+                double* cell = acc + (size_t)g * a.stats + s0;
                 *cell += stage[rr * c1 + fi] * stage[rr * c1 + fj];
             }
         }
@@ -213,7 +215,14 @@ struct Engine {
     struct Plan {
         std::vector<int> cont, disc;
         int G = 1, c = 0, stats = 1;
-        size_t lds() const { return ((size_t)G * stats + 64 * (size_t)(c + 1)) * sizeof(double) + 64 * sizeof(int) + 2 * (size_t)stats + 16; }
+        int g0 = 0, Gw = 0;   // window of configurations one launch row accumulates in LDS (Gw == 0: all of them)
+        int window() const { return Gw ? Gw : G; }
+        size_t lds() const { return ((size_t)window() * stats + 64 * (size_t)(c + 1)) * sizeof(double) + 64 * sizeof(int) + 2 * (size_t)stats + 16; }
+        // configurations whose accumulators fit 60 KB of LDS next to the staging area
+        int max_window() const {
+            const size_t fixed = 64 * (size_t)(c + 1) * sizeof(double) + 64 * sizeof(int) + 2 * (size_t)stats + 16;
+            return (int)((60 * 1024 - fixed) / (stats * sizeof(double)));
+        }
     };
     Plan plan(const std::vector<int>& cont, const std::vector<int>& disc) const {
         Plan p;
@@ -234,7 +243,6 @@ struct Engine {
         cont.insert(cont.end(), q.zC.begin(), q.zC.end());
         return plan(cont, disc);
     }
-    bool on_device(const Plan& p) const { return p.lds() <= 60 * 1024 && h->N > 0 && (h->table || p.c == 0); }
 
     // per-configuration statistics (count, sums, upper-triangle products of the pilot-shifted continuous variables) of
     // several tests in ONE launch: grid row = test, so launch / sync latency is paid once per batch
@@ -249,7 +257,7 @@ struct Engine {
         int max_total = 0;
         for (int t = 0; t < B; ++t) {
             const Plan& p = *plans[t];
-            const size_t total = (size_t)p.G * p.stats;
+            const size_t total = (size_t)p.window() * p.stats;
             part_doubles += (size_t)nblocks * total;
             out_doubles += total;
             lds = std::max(lds, p.lds());
@@ -267,14 +275,14 @@ struct Engine {
             a = GroupArgs{};
             a.base = h->table ? h->table->data : nullptr;
             a.ld = h->table ? h->table->ld : 0;
-            a.c = p.c; a.m = (int)p.disc.size(); a.n = N; a.G = p.G; a.stats = p.stats;
+            a.c = p.c; a.m = (int)p.disc.size(); a.n = N; a.G = p.window(); a.g0 = p.g0; a.stats = p.stats;
             for (int i = 0; i < p.c; ++i) { a.cols[i] = p.cont[i]; a.shift[i] = h->shift[p.cont[i]]; }
             int stride = 1;
             for (int j = 0; j < a.m; ++j) { a.dvar[j] = p.disc[j] - h->n_cont; a.dstride[j] = stride; stride *= card(p.disc[j]); }
             a.codes = h->codes_dev.p; a.codes_ld = N;
             a.chunks_per_block = ceil_div(chunks, nblocks);
             a.partial = dpart + po; a.out = dout + oo;
-            po += (size_t)nblocks * p.G * p.stats; oo += (size_t)p.G * p.stats;
+            po += (size_t)nblocks * p.window() * p.stats; oo += (size_t)p.window() * p.stats;
         }
         HIP_CHECK(hipMemcpyAsync(base, descs.data(), (size_t)B * sizeof(GroupArgs), hipMemcpyHostToDevice, ctx->stream));
         const bool f64 = !h->table || h->table->dtype == PBN_F64;
@@ -287,7 +295,7 @@ struct Engine {
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         oo = 0;
         for (int t = 0; t < B; ++t) {
-            const size_t total = (size_t)plans[t]->G * plans[t]->stats;
+            const size_t total = (size_t)plans[t]->window() * plans[t]->stats;
             outs[t].assign(all.begin() + oo, all.begin() + oo + total);
             oo += total;
         }
@@ -295,43 +303,27 @@ struct Engine {
         ++h->device_launches;
     }
 
-    void group_stats_host(const Plan& p, std::vector<double>& out) {   // more configurations than fit the LDS accumulators
-        const int c = p.c, m = (int)p.disc.size(), stats = p.stats;
-        const int64_t N = h->N;
-        out.assign((size_t)p.G * stats, 0.0);
-        if (c > 0 && h->host_cols.empty()) {
-            h->host_cols.resize(h->n_cont);
-            const size_t es = dtype_size(h->table->dtype);
-            std::vector<char> tmp((size_t)N * es);
-            for (int j = 0; j < h->n_cont; ++j) {
-                HIP_CHECK(hipMemcpy(tmp.data(), h->table->col(j), (size_t)N * es, hipMemcpyDeviceToHost));
-                h->host_cols[j].resize(N);
-                if (es == 8) std::memcpy(h->host_cols[j].data(), tmp.data(), (size_t)N * 8);
-                else for (int64_t r = 0; r < N; ++r) h->host_cols[j][r] = ((const float*)tmp.data())[r];
-            }
-        }
-        std::vector<int> strides(m);
-        int stride = 1;
-        for (int j = 0; j < m; ++j) { strides[j] = stride; stride *= card(p.disc[j]); }
-        double v[MI_MAX_CONT];
-        for (int64_t r = 0; r < N; ++r) {
-            int64_t g = 0;
-            for (int j = 0; j < m; ++j) g += (int64_t)h->codes[p.disc[j] - h->n_cont][r] * strides[j];
-            double* dst = out.data() + (size_t)g * stats;
-            dst[0] += 1.0;
-            for (int i = 0; i < c; ++i) v[i] = h->host_cols[p.cont[i]][r] - h->shift[p.cont[i]];
-            int pos = 1;
-            for (int i = 0; i < c; ++i) dst[pos++] += v[i];
-            for (int i = 0; i < c; ++i)
-                for (int j = i; j < c; ++j) dst[pos++] += v[i] * v[j];
-        }
-        ++h->host_passes;
-    }
-
-    // statistics of a list of plans: device batches bounded by scratch memory, host fallback one by one
+    // statistics of a list of plans: launch rows bounded by scratch memory.  A test with more configurations than fit
+    // the LDS accumulators is covered by several rows, each accumulating one window of configurations (rows of other
+    // windows are skipped), stitched back together here - still device only.
     void group_stats_many(const std::vector<Plan>& plans, std::vector<std::vector<double>>& outs) {
         outs.assign(plans.size(), {});
+        if (h->N <= 0) { for (size_t t = 0; t < plans.size(); ++t) outs[t].assign((size_t)plans[t].G * plans[t].stats, 0.0); return; }
         const int64_t chunks = ceil_div(h->N, 64);
+        std::vector<Plan> rows;                 // launch rows (windows)
+        std::vector<std::pair<size_t, int>> row_of;   // (plan index, first configuration)
+        for (size_t t = 0; t < plans.size(); ++t) {
+            const Plan& p = plans[t];
+            outs[t].assign((size_t)p.G * p.stats, 0.0);
+            const int w = std::max(1, p.max_window());
+            if (ceil_div(p.G, w) > 4096) throw invalid_error("MutualInformation: too many discrete configurations");
+            for (int g0 = 0; g0 < p.G; g0 += w) {
+                Plan r = p;
+                r.g0 = g0; r.Gw = std::min(w, p.G - g0);
+                rows.push_back(std::move(r));
+                row_of.push_back({t, g0});
+            }
+        }
         std::vector<const Plan*> cur;
         std::vector<size_t> cur_idx;
         size_t cur_doubles = 0;
@@ -339,14 +331,16 @@ struct Engine {
             if (cur.empty()) return;
             std::vector<std::vector<double>> o(cur.size());
             group_stats_device(cur, o);
-            for (size_t i = 0; i < cur.size(); ++i) outs[cur_idx[i]].swap(o[i]);
+            for (size_t i = 0; i < cur.size(); ++i) {
+                const auto [t, g0] = row_of[cur_idx[i]];
+                std::copy(o[i].begin(), o[i].end(), outs[t].begin() + (size_t)g0 * plans[t].stats);
+            }
             cur.clear(); cur_idx.clear(); cur_doubles = 0;
         };
-        for (size_t t = 0; t < plans.size(); ++t) {
-            if (!on_device(plans[t])) { group_stats_host(plans[t], outs[t]); continue; }
-            const size_t need = (size_t)std::min<int64_t>(chunks, 512) * plans[t].G * plans[t].stats;
+        for (size_t r = 0; r < rows.size(); ++r) {
+            const size_t need = (size_t)std::min<int64_t>(chunks, 512) * rows[r].window() * rows[r].stats;
             if (!cur.empty() && (cur.size() >= 256 || cur_doubles + need > ((size_t)1 << 25))) flush();   // <= 256 MB of partials
-            cur.push_back(&plans[t]); cur_idx.push_back(t); cur_doubles += need;
+            cur.push_back(&rows[r]); cur_idx.push_back(r); cur_doubles += need;
         }
         flush();
     }
@@ -512,10 +506,8 @@ int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_di
         h->ctx = ctx; h->table = table; h->n_cont = table ? table->n_cols : 0; h->n_disc = n_disc; h->N = n_rows;
         h->asymptotic = asymptotic_df != 0;
         h->card.assign(cardinality, cardinality + n_disc);
-        h->codes.resize(n_disc);
         h->codes_dev.alloc((size_t)std::max<int64_t>(1, (int64_t)n_disc * n_rows));
         for (int j = 0; j < n_disc; ++j) {
-            h->codes[j].assign(codes[j], codes[j] + n_rows);
             for (int64_t r = 0; r < n_rows; ++r)
                 if (codes[j][r] < 0 || codes[j][r] >= cardinality[j]) throw invalid_error("pbn_mi_create: category index out of range");
             HIP_CHECK(hipMemcpyAsync(h->codes_dev.p + (size_t)j * n_rows, codes[j], (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));

@@ -72,8 +72,9 @@ def test_mi_all_overloads(pbn, n, dtype):
         test.pvalue("c1", "zz")
 
 
-def test_mi_many_configurations_host_fallback(pbn):
-    """More discrete configurations x statistics than the LDS accumulators hold: the host pass gives the same numbers."""
+def test_mi_many_configurations_windows(pbn):
+    """More discrete configurations x statistics than the LDS accumulators hold: the test is covered by several launch
+    rows, each accumulating one window of configurations - still on the device, same numbers."""
     rng = np.random.default_rng(3)
     n = 30000
     df = pd.DataFrame({f"c{i}": rng.normal(size=n) for i in range(5)})
@@ -83,7 +84,8 @@ def test_mi_many_configurations_host_fallback(pbn):
     test, orc = pbn.MutualInformation(df), make_oracle(df)
     z = ["d1", "d2", "d3", "d4", "c2", "c3", "c4"]           # 4^5 configurations with d0 -> 1024 x 21 statistics
     assert test.mi("d0", "c1", z) == pytest.approx(orc.mi("d0", "c1", z), rel=1e-8)
-    assert test.passes()[1] == 1
+    dev, host = test.passes()
+    assert host == 0 and dev >= 3
 
 
 def test_mmhc_hybrid(pbn):
