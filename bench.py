@@ -319,7 +319,10 @@ def main():
 
     hc_out = None
     if args.hc != "none":
-        hc_out = bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, args.hc_max_iters)
+        try:
+            hc_out = bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, args.hc_max_iters)
+        except Exception as ex:  # the secondary metric must never cost the headline line
+            hc_out = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
 
     total_samples = args.n_test * world * args.steps
     value = total_samples / elapsed / 1e6
@@ -377,7 +380,10 @@ def main():
             sample_rows = min(args.n_test, 4096)
             train_np = train_t.T.cpu().numpy().astype(np.float64)
             test_np = test_t[:, :sample_rows].T.cpu().numpy().astype(np.float64)
-            out["cpu_baseline"] = cpu_baseline(train_np, test_np, h)
+            try:
+                out["cpu_baseline"] = cpu_baseline(train_np, test_np, h)
+            except Exception as ex:  # never lose the headline line to the baseline leg
+                out["cpu_baseline"] = {"value": None, "unit": "M-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
