@@ -11,7 +11,7 @@ from .kde import KDE, UCV, BandwidthSelector, NormalReferenceRule, ProductKDE, S
 
 from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, MMHC, OperatorPool, OperatorTabuSet, RemoveArc, hc)
-from .dynamic import (DMMHC, DynamicBayesianNetwork, DynamicBGe, DynamicBIC, DynamicChiSquare, DynamicCVLikelihood,  # noqa: F401
+from .dynamic import (DMMHC, DynamicBayesianNetwork, DynamicGaussianNetwork, DynamicKDENetwork, DynamicSemiparametricBN, DynamicBGe, DynamicBIC, DynamicChiSquare, DynamicCVLikelihood,  # noqa: F401
                       DynamicDataFrame, DynamicHoldoutLikelihood, DynamicIndependenceTestAdaptator, DynamicLinearCorrelation,
                       DynamicMutualInformation, DynamicScoreAdaptator, DynamicValidatedLikelihood)
 from .independences import ChiSquare, IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
@@ -27,5 +27,5 @@ __all__ = [
     "GaussianNetwork", "SemiparametricBN", "KDENetwork", "BayesianNetwork", "LinearGaussianCPDType", "CKDEType",
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth", "UCV",
-    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "UnknownFactorType", "DynamicDataFrame", "DynamicBayesianNetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
+    "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "UnknownFactorType", "DynamicDataFrame", "DynamicBayesianNetwork", "DynamicGaussianNetwork", "DynamicSemiparametricBN", "DynamicKDENetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
 ]

@@ -167,6 +167,8 @@ class DynamicBayesianNetwork:
             static_bn = BayesianNetwork(bn_type, static_nodes)
         if transition_bn is None:
             transition_bn = BayesianNetwork(bn_type, transition_nodes, (), (), static_nodes)
+        if static_bn.type() != transition_bn.type():
+            raise ValueError("Static and transition Bayesian networks do not have the same type.")
         if set(static_bn.nodes()) != set(static_nodes):
             raise ValueError("Static Bayesian network must contain the nodes: " + ", ".join(static_nodes))
         if set(transition_bn.nodes()) != set(transition_nodes) or set(transition_bn.interface_nodes()) != set(static_nodes):
@@ -178,6 +180,29 @@ class DynamicBayesianNetwork:
 
     def num_variables(self):
         return len(self._variables)
+
+    def contains_variable(self, name):
+        return name in self._variables
+
+    def add_variable(self, name):
+        """DynamicBayesianNetwork::add_variable (DynamicBayesianNetwork.hpp:100-120): its lagged copies join the static
+        network and the transition network's interface, name_t_0 the transition network's nodes."""
+        if name in self._variables:
+            raise ValueError(f"Cannot add variable {name} because a variable with the same name already exists.")
+        self._variables.append(name)
+        for i in range(1, self._order + 1):
+            self._static.add_node(temporal_name(name, i))
+            self._transition.add_interface_node(temporal_name(name, i))
+        self._transition.add_node(temporal_name(name, 0))
+
+    def remove_variable(self, name):
+        if name not in self._variables:
+            raise ValueError(f"Variable {name} not present in the dynamic Bayesian network.")
+        self._variables.remove(name)
+        for i in range(1, self._order + 1):
+            self._static.remove_node(temporal_name(name, i))
+            self._transition.remove_interface_node(temporal_name(name, i))
+        self._transition.remove_node(temporal_name(name, 0))
 
     def markovian_order(self):
         return self._order
@@ -245,6 +270,37 @@ class DynamicBayesianNetwork:
 
     def __str__(self):
         return f"Dynamic{self.type()} of order {self._order} over {len(self._variables)} variables"
+
+
+def _typed_dbn(bn_type_cls, message):
+    def make(variables, markovian_order, static_bn=None, transition_bn=None):
+        for bn in (static_bn, transition_bn):
+            if bn is not None and static_bn is not None and transition_bn is not None and static_bn.type() != transition_bn.type():
+                raise ValueError("Static and transition Bayesian networks do not have the same type.")
+        for bn in (static_bn, transition_bn):
+            if bn is not None and not isinstance(bn.type(), bn_type_cls):
+                raise ValueError(message)
+        return DynamicBayesianNetwork(variables, markovian_order, static_bn, transition_bn, bn_type_cls())
+
+    return make
+
+
+def DynamicGaussianNetwork(variables, markovian_order, static_bn=None, transition_bn=None):
+    from .models import GaussianNetworkType as T
+
+    return _typed_dbn(T, "Bayesian networks are not Gaussian.")(variables, markovian_order, static_bn, transition_bn)
+
+
+def DynamicSemiparametricBN(variables, markovian_order, static_bn=None, transition_bn=None):
+    from .models import SemiparametricBNType as T
+
+    return _typed_dbn(T, "Bayesian networks are not semiparametric.")(variables, markovian_order, static_bn, transition_bn)
+
+
+def DynamicKDENetwork(variables, markovian_order, static_bn=None, transition_bn=None):
+    from .models import KDENetworkType as T
+
+    return _typed_dbn(T, "Bayesian networks are not KDE networks.")(variables, markovian_order, static_bn, transition_bn)
 
 
 def static_blacklist(variables, markovian_order):

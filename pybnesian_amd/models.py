@@ -125,6 +125,58 @@ class BayesianNetwork:
     def contains_node(self, node):
         return node in self._index and node not in self._interface
 
+    def _reindex(self):
+        self._index = {n: i for i, n in enumerate(self._nodes + self._interface)}
+
+    def add_node(self, node):
+        """BNGeneric::add_node (BayesianNetwork.hpp:330-345): a new isolated node with the network's default type."""
+        if node in self._index:
+            raise ValueError(f"Cannot add node {node} because a node with the same name already exists.")
+        self._nodes.append(node)
+        self._parents[node], self._children[node] = [], []
+        self._types[node] = self._type.default_type
+        self._reindex()
+        if getattr(self, "_cpds", None):
+            self._cpds.pop(node, None)
+        return self._index[node]
+
+    def remove_node(self, node):
+        """BNGeneric::remove_node: the node, its arcs and the factors that conditioned on it go."""
+        if node not in self._index or node in self._interface:
+            raise ValueError(f"Node {node} not present in the Bayesian network.")
+        for c in list(self._children[node]):
+            self._parents[c].remove(node)
+            if getattr(self, "_cpds", None):
+                self._cpds.pop(c, None)
+        for p in list(self._parents[node]):
+            self._children[p].remove(node)
+        self._nodes.remove(node)
+        for d in (self._parents, self._children, self._types):
+            d.pop(node)
+        if getattr(self, "_cpds", None):
+            self._cpds.pop(node, None)
+        self._reindex()
+
+    def add_interface_node(self, node):
+        if node in self._index:
+            raise ValueError(f"Cannot add node {node} because a node with the same name already exists.")
+        self._interface.append(node)
+        self._parents[node], self._children[node] = [], []
+        self._types[node] = self._type.default_type
+        self._reindex()
+
+    def remove_interface_node(self, node):
+        if node not in self._interface:
+            raise ValueError(f"Interface node {node} not present in the Bayesian network.")
+        for c in list(self._children[node]):
+            self._parents[c].remove(node)
+            if getattr(self, "_cpds", None):
+                self._cpds.pop(c, None)
+        self._interface.remove(node)
+        for d in (self._parents, self._children, self._types):
+            d.pop(node)
+        self._reindex()
+
     # -- conditional networks (ConditionalBayesianNetworkBase, BayesianNetwork.hpp:140-222) ---------------------
     def interface_nodes(self):
         return list(self._interface)

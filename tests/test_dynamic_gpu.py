@@ -69,3 +69,58 @@ def test_dmmhc_order2_semiparametric(pbn):
     for s, t in st.arcs():                                                  # static blacklist: no recent -> older arcs
         assert not (s.endswith("_t_1") and t.endswith("_t_2"))
     assert tr.num_arcs() <= 4 and all(t.endswith("_t_0") for _, t in tr.arcs())
+
+
+def test_dbn_fit_logl_reference_recipe(pbn, golden):
+    """/root/reference/tests/models/DynamicBayesianNetwork_test.py:78-230 re-typed: fit bookkeeping and logl / slogl
+    against the row-by-row normal-density recipe (static part: row i scored by the factors of slice order - i)."""
+    import re
+
+    from scipy.stats import norm
+
+    from helpers import frame
+
+    df = frame(golden["train10k"]).iloc[:1000].reset_index(drop=True)
+    test_df = frame(golden["train500"]).iloc[:100].reset_index(drop=True)
+    variables = ["a", "b", "c", "d"]
+    gbn = pbn.DynamicGaussianNetwork(variables, 2)
+    assert not gbn.fitted() and not gbn.static_bn().fitted() and not gbn.transition_bn().fitted()
+    ddf = pbn.DynamicDataFrame(df, 2)
+    gbn2 = pbn.DynamicGaussianNetwork(variables, 2)
+    gbn2.static_bn().fit(ddf.static_df())
+    assert not gbn2.fitted() and gbn2.static_bn().fitted() and not gbn2.transition_bn().fitted()
+    gbn2.transition_bn().fit(ddf.transition_df())
+    assert gbn2.fitted()
+    st, tr = gbn.static_bn(), gbn.transition_bn()
+    for t in (2, 1):
+        st.add_arc(f"a_t_{t}", f"c_t_{t}")
+        st.add_arc(f"b_t_{t}", f"c_t_{t}")
+        st.add_arc(f"c_t_{t}", f"d_t_{t}")
+        for v in variables:
+            tr.add_arc(f"{v}_t_{t}", f"{v}_t_0")
+    gbn.fit(df)
+    assert gbn.fitted()
+
+    def lg(cpd, value, evidence_values):
+        m = cpd.beta[0] + np.dot(cpd.beta[1:], evidence_values)
+        return norm(m, np.sqrt(cpd.variance)).logpdf(value)
+
+    def lookup(e, base_row):
+        m = re.search(r"(.*)_t_(\d+)", e)
+        return m[1], int(m[2])
+
+    want = np.zeros(test_df.shape[0])
+    order = gbn.markovian_order()
+    for i in range(order):
+        for v in variables:
+            cpd = st.cpd(f"{v}_t_{order - i}")
+            ev = [test_df.loc[order - lookup(e, i)[1], lookup(e, i)[0]] for e in cpd.evidence()]
+            want[i] += lg(cpd, test_df.loc[i, v], ev)
+    for i in range(order, test_df.shape[0]):
+        for v in variables:
+            cpd = tr.cpd(f"{v}_t_0")
+            ev = [test_df.loc[i - lookup(e, i)[1], lookup(e, i)[0]] for e in cpd.evidence()]
+            want[i] += lg(cpd, test_df.loc[i, v], ev)
+    ll = gbn.logl(test_df)
+    assert np.all(np.isclose(want, ll))
+    assert np.isclose(gbn.slogl(test_df), want.sum())

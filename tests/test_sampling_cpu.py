@@ -130,3 +130,36 @@ def test_dynamic_dataframe_layout(ensure_built):
     dbn = pbn.DynamicBayesianNetwork(["a", "b"], 2)
     assert dbn.static_bn().nodes() == ["a_t_1", "a_t_2", "b_t_1", "b_t_2"]
     assert dbn.transition_bn().nodes() == ["a_t_0", "b_t_0"] and dbn.transition_bn().interface_nodes() == dbn.static_bn().nodes()
+
+
+def test_dynamic_network_create_and_variables(ensure_built):
+    """/root/reference/tests/models/DynamicBayesianNetwork_test.py:12-76 re-typed (creation, type checks, add / remove
+    variable)."""
+    variables = ["a", "b", "c", "d"]
+    gbn = pbn.DynamicGaussianNetwork(variables, 2)
+    assert gbn.markovian_order() == 2 and gbn.variables() == variables and gbn.num_variables() == 4
+    assert gbn.type() == pbn.GaussianNetworkType()
+    transition_nodes = [v + "_t_0" for v in variables]
+    static_nodes = [v + "_t_" + str(m) for v in variables for m in range(1, 3)]
+    assert set(gbn.static_bn().nodes()) == set(static_nodes)
+    assert set(gbn.transition_bn().interface_nodes()) == set(static_nodes)
+    assert set(gbn.transition_bn().nodes()) == set(transition_nodes)
+    static_bn = pbn.GaussianNetwork(static_nodes)
+    transition_bn = pbn.ConditionalGaussianNetwork(transition_nodes, static_nodes)
+    pbn.DynamicGaussianNetwork(variables, 2, static_bn, transition_bn)
+    wrong_transition = pbn.ConditionalKDENetwork(transition_nodes, static_nodes)
+    with pytest.raises(ValueError, match="Static and transition Bayesian networks do not have the same type"):
+        pbn.DynamicGaussianNetwork(variables, 2, static_bn, wrong_transition)
+    with pytest.raises(ValueError, match="Bayesian networks are not Gaussian."):
+        pbn.DynamicGaussianNetwork(variables, 2, pbn.KDENetwork(static_nodes), wrong_transition)
+    assert all(gbn.contains_variable(v) for v in variables)
+    gbn.add_variable("e")
+    assert set(gbn.variables()) == set(variables + ["e"]) and gbn.num_variables() == 5
+    assert set(gbn.static_bn().nodes()) == set(v + "_t_" + str(m) for v in variables + ["e"] for m in range(1, 3))
+    assert set(gbn.transition_bn().nodes()) == set(v + "_t_0" for v in variables + ["e"])
+    gbn.remove_variable("b")
+    left = ["a", "c", "d", "e"]
+    assert set(gbn.variables()) == set(left) and gbn.num_variables() == 4
+    assert set(gbn.static_bn().nodes()) == set(v + "_t_" + str(m) for v in left for m in range(1, 3))
+    assert set(gbn.transition_bn().nodes()) == set(v + "_t_0" for v in left)
+    assert set(gbn.transition_bn().interface_nodes()) == set(gbn.static_bn().nodes())
