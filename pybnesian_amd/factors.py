@@ -69,7 +69,9 @@ class CKDE(Factor):
         self._N = 0
 
     def type(self):
-        return "CKDEFactor"
+        from .models import CKDEType
+
+        return CKDEType()
 
     def data_type(self):
         self._check_fitted("CKDE")
@@ -281,7 +283,9 @@ class LinearGaussianCPD(Factor):
             self.beta, self.variance = None, None
 
     def type(self):
-        return "LinearGaussianFactor"
+        from .models import LinearGaussianCPDType
+
+        return LinearGaussianCPDType()
 
     def fit(self, df):
         rb = as_record_batch(df)
@@ -392,7 +396,9 @@ class DiscreteFactor(Factor):
         self._logprob = None
 
     def type(self):
-        return "DiscreteFactor"
+        from .models import DiscreteFactorType
+
+        return DiscreteFactorType()
 
     def _indices(self, rb):
         cols = [_dictionary_column(rb, v) for v in [self._variable] + self._evidence]
@@ -604,7 +610,9 @@ class CLinearGaussianCPD(_DiscreteAdaptator):
     _name = "CLinearGaussianCPD"
 
     def type(self):
-        return "LinearGaussianFactor"
+        from .models import LinearGaussianCPDType
+
+        return LinearGaussianCPDType()
 
     def _base(self, continuous_evidence):
         return LinearGaussianCPD(self._variable, continuous_evidence)
@@ -620,7 +628,9 @@ class HCKDE(_DiscreteAdaptator):
     _name = "HCKDE"
 
     def type(self):
-        return "CKDEFactor"
+        from .models import CKDEType
+
+        return CKDEType()
 
     def _base(self, continuous_evidence):
         return CKDE(self._variable, continuous_evidence)

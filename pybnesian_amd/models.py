@@ -347,6 +347,8 @@ class BayesianNetwork:
             raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
         if self._type.homogeneous and node_type != self._type.default_type:
             raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
+        if self._types.get(node) != node_type and getattr(self, "_cpds", None):
+            self._cpds.pop(node, None)   # a factor of the old type no longer belongs to the node (BayesianNetwork.hpp:770-790)
         self._types[node] = node_type
 
     def clone(self):
@@ -374,24 +376,44 @@ class BayesianNetwork:
             return HCKDE(node, parents) if hybrid else CKDE(node, parents)
         return CLinearGaussianCPD(node, parents) if hybrid else LinearGaussianCPD(node, parents)
 
+    def _cpd_valid(self, node):
+        """must_construct_cpd (BayesianNetwork.hpp:905-935): a factor is kept when its type and evidence still match."""
+        f = getattr(self, "_cpds", {}).get(node)
+        if f is None:
+            return False
+        t = self._types[node]
+        if t != UnknownFactorType() and f.type() != t and not (t == DiscreteFactorType()):
+            return False
+        return sorted(f.evidence()) == sorted(self._parents[node])
+
     def fit(self, df):
-        self._cpds = {}
+        """BNGeneric::fit (BayesianNetwork.hpp:960-994): unknown node types are resolved from the data, factors that are
+        missing, of the wrong type, with stale evidence or unfitted are (re)built and fitted; the others are kept."""
+        if getattr(self, "_cpds", None) is None:
+            self._cpds = {}
+        if self.has_unknown_node_types():
+            self.set_unknown_node_types(df)
         for n in self._nodes:
-            f = self._new_factor(df, n)
-            f.fit(df)
-            self._cpds[n] = f
+            if not self._cpd_valid(n):
+                self._cpds[n] = self._new_factor(df, n)
+            if not self._cpds[n].fitted():
+                self._cpds[n].fit(df)
 
     def fitted(self):
-        return getattr(self, "_cpds", None) is not None and all(n in self._cpds for n in self._nodes)
+        cp = getattr(self, "_cpds", None)
+        return cp is not None and all(n in cp and self._cpd_valid(n) and cp[n].fitted() for n in self._nodes)
 
     def cpd(self, node):
-        if not self.fitted():
-            raise ValueError("Model not fitted.")
-        return self._cpds[node]
+        if node not in self._index or node in self._interface:
+            raise ValueError(f"Node {node} not present in the Bayesian network.")
+        cp = getattr(self, "_cpds", None)
+        if not cp or node not in cp:
+            raise ValueError(f"CPD of variable \"{node}\" not added. Call add_cpds() or fit() to add the CPD.")
+        return cp[node]
 
     def logl(self, df):
         if not self.fitted():
-            raise ValueError("Model not fitted.")
+            raise ValueError("Model not fitted.")  # BayesianNetwork.hpp check_fitted
         import numpy as np
 
         out = None
@@ -458,9 +480,14 @@ class BayesianNetwork:
                 raise ValueError(f"CPD defined on variable which is not present in the model:\n{f}")
             if sorted(f.evidence()) != sorted(self._parents[v]):
                 raise ValueError(f"CPD do not have the model's parent set as evidence:\n{f}")
+            t = self._types[v]
+            if t != UnknownFactorType() and f.type() != t:
+                raise ValueError(f"Bayesian network expects type {t} for node {v}, but {f.type()} was provided.")
         if getattr(self, "_cpds", None) is None:
             self._cpds = {}
         for f in cpds:
+            if self._types[f.variable()] == UnknownFactorType():
+                self._types[f.variable()] = f.type()
             self._cpds[f.variable()] = f
 
     def sample(self, n, seed=None, ordered=False, concat_evidence=False):

@@ -1,0 +1,102 @@
+"""GPU tier: the fit / cpd / add_cpds / logl assertions of the reference's model tests
+(/root/reference/tests/models/SemiparametricBN_test.py:99-240, BayesianNetwork_test.py:221-330) re-typed."""
+import numpy as np
+import pytest
+
+from helpers import frame
+
+pytestmark = pytest.mark.gpu
+FULL = [("a", "b"), ("a", "c"), ("a", "d"), ("b", "c"), ("b", "d"), ("c", "d")]
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def df(golden):
+    return frame(golden["train10k"])
+
+
+def test_spbn_node_type_and_fit(pbn, df):   # SemiparametricBN_test.py:99-153
+    spbn = pbn.SemiparametricBN(["a", "b", "c", "d"])
+    assert all(spbn.node_type(n) == pbn.UnknownFactorType() for n in spbn.nodes())
+    spbn.set_node_type("b", pbn.CKDEType())
+    assert spbn.node_type("b") == pbn.CKDEType()
+    spbn.set_node_type("b", pbn.LinearGaussianCPDType())
+    assert spbn.node_type("b") == pbn.LinearGaussianCPDType()
+
+    spbn = pbn.SemiparametricBN(FULL)
+    with pytest.raises(ValueError, match="not added"):
+        spbn.cpd("a")
+    spbn.fit(df)
+    for n in spbn.nodes():
+        cpd = spbn.cpd(n)
+        assert cpd.type() == pbn.LinearGaussianCPDType() and type(cpd) == pbn.LinearGaussianCPD
+        assert cpd.variable() == n and set(cpd.evidence()) == set(spbn.parents(n))
+    spbn.fit(df)
+    spbn.remove_arc("a", "b")
+    cpd_b = spbn.cpd("b")
+    assert type(cpd_b) == pbn.LinearGaussianCPD and cpd_b.evidence() != spbn.parents("b")
+    spbn.fit(df)
+    cpd_b = spbn.cpd("b")
+    assert type(cpd_b) == pbn.LinearGaussianCPD and cpd_b.evidence() == spbn.parents("b")
+    spbn.set_node_type("c", pbn.CKDEType())
+    with pytest.raises(ValueError, match="not added"):
+        spbn.cpd("c")
+    spbn.fit(df)
+    assert spbn.cpd("c").type() == spbn.node_type("c") == pbn.CKDEType()
+
+
+def test_spbn_cpd_and_add_cpds(pbn, df):   # SemiparametricBN_test.py:155-203
+    spbn = pbn.SemiparametricBN(FULL, [("d", pbn.CKDEType())])
+    with pytest.raises(ValueError, match="not added"):
+        spbn.cpd("a")
+    spbn.fit(df)
+    assert [spbn.cpd(v).type() for v in "abcd"] == [pbn.LinearGaussianCPDType()] * 3 + [pbn.CKDEType()]
+    assert all(spbn.cpd(v).fitted() for v in "abcd")
+
+    spbn = pbn.SemiparametricBN(FULL, [("d", pbn.CKDEType())])
+    assert spbn.node_type("a") == pbn.UnknownFactorType()
+    spbn.add_cpds([pbn.CKDE("a", [])])
+    assert spbn.node_type("a") == pbn.CKDEType()
+    with pytest.raises(ValueError, match="Bayesian network expects type"):
+        spbn.add_cpds([pbn.LinearGaussianCPD("d", ["a", "b", "c"])])
+    lg = pbn.LinearGaussianCPD("b", ["a"], [2.5, 1.65], 4)
+    ckde = pbn.CKDE("d", ["a", "b", "c"])
+    assert lg.fitted() and not ckde.fitted()
+    spbn.add_cpds([lg, ckde])
+    spbn.set_node_type("a", pbn.UnknownFactorType())
+    with pytest.raises(ValueError, match='CPD of variable "a" not added. Call add_cpds\\(\\) or fit\\(\\) to add the CPD.'):
+        spbn.cpd("a")
+    assert spbn.cpd("b").fitted()
+    with pytest.raises(ValueError, match='CPD of variable "c" not added'):
+        spbn.cpd("c")
+    assert not spbn.cpd("d").fitted()
+
+
+@pytest.mark.parametrize("kind", ["spbn", "gbn", "mixed"])
+def test_network_logl_is_sum_of_factors(pbn, df, golden, kind):   # SemiparametricBN_test.py:205-230, BayesianNetwork_test.py:300-322
+    if kind == "gbn":
+        net = pbn.GaussianNetwork(FULL)
+    elif kind == "spbn":
+        net = pbn.SemiparametricBN(FULL)
+    else:
+        net = pbn.SemiparametricBN(FULL, [("a", pbn.CKDEType()), ("c", pbn.CKDEType())])
+    net.fit(df)
+    test_df = frame(golden["train500"])
+    ll, sll = net.logl(test_df), net.slogl(test_df)
+    sum_ll, sum_sll = np.zeros(test_df.shape[0]), 0.0
+    for n in net.nodes():
+        cpd = net.cpd(n)
+        l, s = cpd.logl(test_df), cpd.slogl(test_df)
+        assert np.isclose(s, l.sum())
+        sum_ll += l
+        sum_sll += s
+    assert np.all(np.isclose(ll, sum_ll)) and np.isclose(sll, ll.sum()) and sll == pytest.approx(sum_sll, rel=1e-12)
+    s = net.sample(100, 0, ordered=True)   # BayesianNetwork_test.py:324-340: shape and column order
+    assert s.num_rows == 100 and s.schema.names == net.nodes()
