@@ -221,13 +221,38 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     t0 = time.perf_counter()
     oracle.product_kde_logl(train_np, h, test_np[:rows])
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": rows / dt / 1e6,
         "unit": "M-samples/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{rows} test rows x {train_np.shape[0]} training rows, d={D}, fp64, {dt:.1f}s wall, OpenMP over test rows",
     }
+    # SURVEY.md §8d also asks for the single-thread port (the reference itself is single-threaded) and for scipy's
+    # gaussian_kde, the oracle of the reference's own tests (full covariance, so not the same kernel as C2's diagonal one)
+    try:
+        one = max(8, min(64, rows // max(cores, 1)))
+        oracle.set_num_threads(1)
+        t0 = time.perf_counter()
+        oracle.product_kde_logl(train_np, h, test_np[:one])
+        d1 = time.perf_counter() - t0
+        oracle.set_num_threads(cores)
+        out["single_thread"] = {"value": one / d1 / 1e6, "unit": "M-samples/s", "sample": f"{one} test rows, {d1:.1f}s wall"}
+        from scipy.stats import gaussian_kde
+
+        sub = train_np[:: max(1, train_np.shape[0] // 100_000)]          # scipy needs N x m memory: 1e5 training rows
+        k = gaussian_kde(sub.T)
+        m = min(200, test_np.shape[0])
+        t0 = time.perf_counter()
+        k.logpdf(test_np[:m].T)
+        d2 = time.perf_counter() - t0
+        scale = train_np.shape[0] / sub.shape[0]
+        out["scipy_gaussian_kde"] = {"value": m / (d2 * scale) / 1e6, "unit": "M-samples/s",
+                                     "sample": f"full-covariance gaussian_kde.logpdf, {m} test rows x {sub.shape[0]} training rows in {d2:.1f}s, "
+                                               f"scaled linearly to {train_np.shape[0]} training rows"}
+    except Exception as ex:
+        out["extra_error"] = f"{type(ex).__name__}: {ex}"
+    return out
 
 
 def main():
@@ -377,7 +402,7 @@ def main():
             out["secondary"] = hc_out
         if world == 1 and not args.no_cpu_baseline:
             h = np.asarray(kde.bandwidth, dtype=np.float64)
-            sample_rows = min(args.n_test, 4096)
+            sample_rows = min(args.n_test, 16384)
             train_np = train_t.T.cpu().numpy().astype(np.float64)
             test_np = test_t[:, :sample_rows].T.cpu().numpy().astype(np.float64)
             try:
