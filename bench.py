@@ -175,7 +175,23 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
     t0 = time.perf_counter()
     res = hc.estimate(ops, score, start, **kw)
     dt = time.perf_counter() - t0
-    more = extra if which == "c5mmhc" else {}
+    more = dict(extra) if which == "c5mmhc" else {}
+    if which == "c4" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PBN_BENCH_NO_CPU"):
+        # the CPU side of BGe is the constructor (means + covariance of all columns, one thread in the
+        # reference); timed with the restatement on a row sample and scaled linearly
+        try:
+            from oracle import oracle
+
+            rows = min(n_rows, 200_000)
+            host = t[:, :rows].T.cpu().numpy()
+            t0 = time.perf_counter()
+            oracle.cov(host)
+            dcpu = (time.perf_counter() - t0) * (n_rows / rows)
+            more["cpu_baseline"] = {"score_ctor_s": dcpu, "kind": "port", "cores": 1,
+                                    "sample": f"covariance of {rows} x {n_cols} rows on one thread, scaled to {n_rows} rows; "
+                                              f"per-candidate work is O(p^3) on both sides"}
+        except Exception as ex:
+            more["cpu_baseline"] = {"score_ctor_s": None, "sample": f"failed: {ex}"}
     return {
         **more,
         "metric": "hill-climb candidate-arcs scored/s",
@@ -344,6 +360,8 @@ def main():
 
     hc_out = None
     if args.hc != "none":
+        if args.no_cpu_baseline:
+            os.environ["PBN_BENCH_NO_CPU"] = "1"
         try:
             hc_out = bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, args.hc_max_iters)
         except Exception as ex:  # the secondary metric must never cost the headline line
