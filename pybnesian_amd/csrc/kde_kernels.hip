@@ -67,6 +67,29 @@ __device__ __forceinline__ double exp2_poly<7>(double r) {
     return __builtin_fma(p, r, 0x1.ffffffffa7138p-1);
 }
 
+// the leading coefficient of the degree-7 polynomial as a register operand: v_fma_f64 reads one scalar/literal only, so
+// the first step C7 r + C6 needs one of the two in a VGPR; a caller that pins it once (pin_top) saves the v_mov the
+// compiler otherwise re-materialises per 4 values
+__device__ __forceinline__ double pin_top() {
+    double c;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(0x1.00c0e56000f6ep-16));
+    return c;
+}
+__device__ __forceinline__ double exp2_f64_top(double x, double top) {
+    double nf = __builtin_rint(x);
+    double r = x - nf;
+    double p = __builtin_fma(top, r, 0x1.446c79f27429dp-13);
+    p = __builtin_fma(p, r, 0x1.5d8775970d4b9p-10);
+    p = __builtin_fma(p, r, 0x1.3b29d8bb04b01p-7);
+    p = __builtin_fma(p, r, 0x1.c6b08da70e83cp-5);
+    p = __builtin_fma(p, r, 0x1.ebfbe0aa03e9fp-3);
+    p = __builtin_fma(p, r, 0x1.62e42fef9cc4fp-1);
+    p = __builtin_fma(p, r, 0x1.ffffffffa7138p-1);
+    int n;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(nf));
+    return __builtin_ldexp(p, n);
+}
+
 template <int DEG>
 __device__ __forceinline__ double exp2_f64(double x) {
     // x <= ~1000 (larger values are caught by the overflow check of the caller), any negative value.
@@ -87,6 +110,10 @@ struct Tr<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ double ex2(double x) { return exp2_f64<PBN_EXP2_DEGREE>(x); }
+    static __device__ __forceinline__ double top() { return PBN_EXP2_DEGREE == 7 ? pin_top() : 0.0; }
+    static __device__ __forceinline__ double ex2p(double x, double top) {
+        return PBN_EXP2_DEGREE == 7 ? exp2_f64_top(x, top) : exp2_f64<PBN_EXP2_DEGREE>(x);
+    }
     static __device__ __forceinline__ double ex2_hi(double x) { return exp2_f64<8>(x); }
     static __device__ __forceinline__ double big() { return 0x1p900; }
     // C/D row held by (lane group lg, register i): cdna_hip_programming.md §3 "f64 MFMA"
@@ -100,6 +127,8 @@ struct Tr<float> {
     }
     static __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
     static __device__ __forceinline__ float ex2_hi(float x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ float top() { return 0.0f; }
+    static __device__ __forceinline__ float ex2p(float x, float) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float big() { return 0x1p100f; }
     static __host__ __device__ __forceinline__ int crow(int lg, int i) { return 4 * lg + i; }
 };
@@ -237,6 +266,8 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         if (COND) { bxb[g] = BXp[qt * 64 + lane]; sumj[g] = 0.0; }
     }
 
+    const T ctop = Tr<T>::top();   // leading exp2 coefficient pinned in a VGPR for the whole kernel
+
     // ---- prologue: offsets from the first tile (max of s2 over its 16 rows) ---------------------
     {
         T af[KS];
@@ -280,12 +311,12 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             V accj;
             if (COND) accj = Tr<T>::mfma(ax, bx[g], acc);
 
-            T e0 = Tr<T>::ex2(acc[0]), e1 = Tr<T>::ex2(acc[1]), e2 = Tr<T>::ex2(acc[2]), e3 = Tr<T>::ex2(acc[3]);
+            T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
             T ts = (e0 + e1) + (e2 + e3);
             T tsj = 0;
             bool bad = !(ts < Tr<T>::big());
             if (COND) {
-                T j0 = Tr<T>::ex2(accj[0]), j1 = Tr<T>::ex2(accj[1]), j2 = Tr<T>::ex2(accj[2]), j3 = Tr<T>::ex2(accj[3]);
+                T j0 = Tr<T>::ex2p(accj[0], ctop), j1 = Tr<T>::ex2p(accj[1], ctop), j2 = Tr<T>::ex2p(accj[2], ctop), j3 = Tr<T>::ex2p(accj[3], ctop);
                 tsj = (j0 + j1) + (j2 + j3);
                 bad = bad || !(tsj < Tr<T>::big());
             }
