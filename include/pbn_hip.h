@@ -213,6 +213,9 @@ int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, i
  * pass; out_logl (n host doubles) and out_slogl are nullable. */
 int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
                 double* out_logl, double* out_slogl);
+/* LinearGaussianCPD::cdf (factors/continuous/LinearGaussianCPD.cpp:171-249): Phi((y - beta.x) / sigma), n doubles to HOST. */
+int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
+               double* out);
 /* Score::local_score for a batch of candidates (replaces the serial double loop of
  * learning/operators/operators.cpp:100-132,296-347): candidate c scores column var[c] given
  * parents[par_off[c] .. par_off[c+1]) with node type node_type[c] (NULL = all LinearGaussian). */

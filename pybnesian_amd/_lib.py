@@ -78,6 +78,7 @@ SIGNATURES = {
     "pbn_lg_fit": (_int, [_vp, _int, _ip, _int, _dp, _dp]),
     "pbn_lg_fit_table": (_int, [_vp, _ip, _int, _i64, _i64, _dp, _dp]),
     "pbn_lg_logl": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp, _dp]),
+    "pbn_lg_cdf": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp]),
     "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
     "pbn_lincor_create": (_int, [_vp, _vp, C.POINTER(_vp)]),
     "pbn_lincor_from_cov": (_int, [_int, _i64, _dp, C.POINTER(_vp)]),

@@ -559,8 +559,8 @@ int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, i
 }
 
 // LinearGaussianCPD::logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149,251-292).
-int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
-                double* out_logl, double* out_slogl) {
+static int lg_eval(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
+                   double* out_logl, double* out_slogl, int want_cdf) {
     return guarded([&] {
         check_cols(t, cols, d, "pbn_lg_logl");
         check_range(t, row0, n, "pbn_lg_logl");
@@ -579,7 +579,7 @@ int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_
         for (int i = 0; i < d; ++i) { a.gc.cols[i] = cols[i]; a.beta[i] = beta[i]; }
         a.inv_std = 1.0 / std::sqrt(variance);
         a.cte = -0.5 * std::log(variance) - 0.5 * LOG_2PI;
-        a.logl = dlogl.p; a.block_sums = bs;
+        a.logl = dlogl.p; a.block_sums = bs; a.want_cdf = want_cdf;
         launch_lg_logl(a, t->dtype, ctx->stream);
         if (out_logl) HIP_CHECK(hipMemcpyAsync(out_logl, dlogl.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         std::vector<double> hb((size_t)nblocks);
@@ -591,6 +591,18 @@ int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_
             *out_slogl = s;
         }
     });
+}
+
+int pbn_lg_logl(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
+                double* out_logl, double* out_slogl) {
+    return lg_eval(t, cols, d, row0, n, beta, variance, out_logl, out_slogl, 0);
+}
+
+// LinearGaussianCPD::cdf (factors/continuous/LinearGaussianCPD.cpp:171-249): Phi((y - beta.x) / sigma) per row.
+int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
+               double* out) {
+    if (!out && n > 0) { set_last_error("pbn_lg_cdf: null output"); return PBN_ERR_INVALID; }
+    return lg_eval(t, cols, d, row0, n, beta, variance, out, nullptr, 1);
 }
 
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,

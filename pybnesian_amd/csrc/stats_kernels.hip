@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void lg_logl_kernel(LgArgs a) {
         const double y = (double)base[(int64_t)a.gc.cols[0] * a.ld + src];
         const double z = a.inv_std * (y - mean);
         val = -0.5 * z * z + a.cte;
-        if (a.logl) a.logl[r] = val;
+        if (a.logl) a.logl[r] = a.want_cdf ? 0.5 * erfc(-z * 0.70710678118654752440) : val;
     }
     __shared__ double red[256];
     red[threadIdx.x] = val;

@@ -32,6 +32,7 @@ struct LgArgs {
     double beta[64];  // p+1 coefficients (intercept first)
     double inv_std;   // 1 / sqrt(variance)
     double cte;       // -0.5 log(variance) - 0.5 log(2 pi)
+    int want_cdf;        // logl[] receives Phi((y - mean) / sigma) instead (LinearGaussianCPD::cdf)
     double* logl;        // device, nullable
     double* block_sums;  // device, nullable: ceil(n/256) partial sums
 };

@@ -328,6 +328,23 @@ class LinearGaussianCPD(Factor):
     def data_type(self):
         return pa.float64()  # LinearGaussianCPD.hpp: always double
 
+    def cdf(self, df):
+        """LinearGaussianCPD.cdf (LinearGaussianCPD.cpp:171-249): Phi((y - beta.x) / sigma) per row, NaN at null rows."""
+        self._check_fitted("LinearGaussianCPD")
+        rb = as_record_batch(df)
+        same_type(rb, self._variables)
+        table, mask = DeviceTable.from_dataframe(default_context(), rb, self._variables)
+        m = table.num_rows
+        vals = np.empty(m)
+        d = len(self._variables)
+        _lib.check(_lib.load().pbn_lg_cdf(table.handle, _lib.int_array(range(d)), d, 0, m, _lib.dptr(np.ascontiguousarray(self.beta)),
+                                          float(self.variance), _lib.dptr(vals)))
+        if mask is None:
+            return vals
+        out = np.full(rb.num_rows, np.nan)
+        out[mask] = vals
+        return out
+
     def sample(self, n, evidence_values=None, seed=None, _stream_n=0):
         """LinearGaussianCPD.sample (LinearGaussianCPD.cpp:317-380): float64 pyarrow array (pbn_lg_sample)."""
         self._check_fitted("LinearGaussianCPD")

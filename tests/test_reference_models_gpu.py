@@ -100,3 +100,27 @@ def test_network_logl_is_sum_of_factors(pbn, df, golden, kind):   # Semiparametr
     assert np.all(np.isclose(ll, sum_ll)) and np.isclose(sll, ll.sum()) and sll == pytest.approx(sum_sll, rel=1e-12)
     s = net.sample(100, 0, ordered=True)   # BayesianNetwork_test.py:324-340: shape and column order
     assert s.num_rows == 100 and s.schema.names == net.nodes()
+
+
+def test_lg_cdf_and_sample(pbn, df, golden):   # LinearGaussianCPD_test.py:211-290
+    from scipy.stats import norm
+
+    test_df = frame(golden["train500"])
+    np.random.seed(0)
+    tn = test_df.copy()
+    for c in "abcd":
+        tn.loc[tn.index[np.random.randint(0, tn.shape[0], size=20)], c] = np.nan
+    for variable, evidence in [("a", []), ("b", ["a"]), ("c", ["a", "b"]), ("d", ["a", "b", "c"])]:
+        cpd = pbn.LinearGaussianCPD(variable, evidence)
+        cpd.fit(df)
+        want = lambda t: norm.cdf(t[variable], cpd.beta[0] + (t[evidence].to_numpy() @ cpd.beta[1:] if evidence else 0.0), np.sqrt(cpd.variance))
+        assert np.all(np.isclose(cpd.cdf(test_df), want(test_df)))
+        got = cpd.cdf(tn)
+        nulls = tn[[variable] + evidence].isna().any(axis=1).to_numpy()
+        assert np.array_equal(np.isnan(got), nulls) and np.all(np.isclose(got[~nulls], want(tn)[~nulls]))
+        s = cpd.sample(1000, test_df.iloc[np.arange(1000) % test_df.shape[0]][evidence] if evidence else None, 0)
+        assert len(s) == 1000 and str(s.type) == "double"
+    a, b = pbn.LinearGaussianCPD("d", ["a", "b", "c"]), pbn.LinearGaussianCPD("d", ["c", "a", "b"])
+    a.fit(df)
+    b.fit(df)
+    assert np.all(np.isclose(a.cdf(test_df), b.cdf(test_df)))
