@@ -67,6 +67,9 @@ class CKDE(Factor):
         self._dtype = None
         self._bandwidth = None
         self._N = 0
+        self._kde_joint_obj = None
+        self._kde_marg_obj = None
+        self._split = False
 
     def type(self):
         from .models import CKDEType
@@ -86,33 +89,53 @@ class CKDE(Factor):
         """Joint bandwidth matrix in [variable, evidence...] order (kde_joint().bandwidth)."""
         return self._bandwidth
 
-    def kde_joint(self):
-        """KDE over [variable] + evidence sharing this factor's training rows (`CKDE.kde_joint`)."""
+    def _member_kde(self, variables, H):
         from .kde import KDE
 
-        self._check_fitted("CKDE")
-        k = KDE(self._variables)
+        k = KDE(variables)
         k._train, k._dtype, k._N = self._train, self._dtype, self._N
-        k._train_idx = self._train.index(self._variables)
-        k._bandwidth = np.array(self._bandwidth)
+        k._train_idx = self._train.index(variables)
+        k._bandwidth = np.array(H)
         k._device_fit()
         k._fitted = True
+        k._on_bandwidth = self._member_bandwidth_changed
         return k
 
-    def kde_marg(self):
-        """KDE over the evidence with the bandwidth block H[1:, 1:] (CKDE.hpp:186-199)."""
-        from .kde import KDE
+    def _member_bandwidth_changed(self):
+        """The reference's CKDE owns two independent KDE members (CKDE.hpp:262-263) and hands out references to them,
+        so assigning `cpd.kde_joint().bandwidth` changes what the factor evaluates.  From then on logl / slogl are the
+        difference of the two members' device sweeps (the fused sweep needs marg H = joint H[1:,1:]); cdf and sample
+        keep reading the joint bandwidth as the reference does (CKDE.hpp:289-385, 509-558)."""
+        self._split = True
+        if self._kde_joint_obj is not None and not np.array_equal(self._kde_joint_obj.bandwidth, self._bandwidth):
+            self._refit_handle(np.asfortranarray(self._kde_joint_obj.bandwidth, dtype=np.float64))
 
+    def _refit_handle(self, H):
+        lib = _lib.load()
+        d = len(self._variables)
+        h = C.c_void_p()
+        _lib.check(lib.pbn_ckde_fit(self._train.ctx.handle, self._train.handle, _lib.int_array(self._train.index(self._variables)), d, 0,
+                                    self._N, _lib.dptr(H), None, C.byref(h)))
+        if self._handle is not None:
+            lib.pbn_kde_destroy(self._handle)
+        self._handle, self._bandwidth = h, H
+
+    def kde_joint(self):
+        """KDE over [variable] + evidence sharing this factor's training rows (`CKDE.kde_joint`); the same object on
+        every call, as the reference returns a reference to its member."""
+        self._check_fitted("CKDE")
+        if self._kde_joint_obj is None:
+            self._kde_joint_obj = self._member_kde(self._variables, self._bandwidth)
+        return self._kde_joint_obj
+
+    def kde_marg(self):
+        """KDE over the evidence with the bandwidth block H[1:, 1:] (CKDE.hpp:186-199); same object on every call."""
         self._check_fitted("CKDE")
         if not self._evidence:
             raise ValueError("CKDE without evidence has no marginal KDE.")
-        k = KDE(self._evidence)
-        k._train, k._dtype, k._N = self._train, self._dtype, self._N
-        k._train_idx = self._train.index(self._evidence)
-        k._bandwidth = np.array(self._bandwidth[1:, 1:])
-        k._device_fit()
-        k._fitted = True
-        return k
+        if self._kde_marg_obj is None:
+            self._kde_marg_obj = self._member_kde(self._evidence, self._bandwidth[1:, 1:])
+        return self._kde_marg_obj
 
     def fit(self, df):
         rb = as_record_batch(df)
@@ -150,6 +173,7 @@ class CKDE(Factor):
         cptr = _lib.dptr(np.ascontiguousarray(means)) if means is not None else None
         _lib.check(lib.pbn_ckde_fit(table.ctx.handle, table.handle, _lib.int_array(idx), d, 0, n, _lib.dptr(H), cptr, C.byref(h)))
         self._handle, self._train, self._dtype, self._bandwidth, self._N = h, table, table.dtype, H, n
+        self._kde_joint_obj, self._kde_marg_obj, self._split = None, None, False
         self._fitted = True
 
     def __getstate__(self):
@@ -158,6 +182,8 @@ class CKDE(Factor):
             vals = self._train.read(self._variables)
             state.update(bandwidth=np.array(self._bandwidth), training=np.asfortranarray(vals).reshape(-1, order="F"),
                          N=self._N, dtype=self._dtype)
+            if self._split and self._evidence:
+                state["marg_bandwidth"] = np.array(self.kde_marg().bandwidth)
         return state
 
     def __setstate__(self, state):
@@ -172,6 +198,8 @@ class CKDE(Factor):
             _lib.check(_lib.load().pbn_ckde_fit(table.ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, n, _lib.dptr(H), None, C.byref(h)))
             self._handle, self._train, self._dtype, self._bandwidth, self._N = h, table, table.dtype, H, n
             self._fitted = True
+            if "marg_bandwidth" in state:
+                self.kde_marg().bandwidth = state["marg_bandwidth"]
 
     def _upload_test(self, df):
         self._check_fitted("CKDE")
@@ -183,6 +211,10 @@ class CKDE(Factor):
         return rb, table, mask
 
     def logl(self, df):
+        if self._split:
+            self._upload_test(df)  # same argument checks as the fused path
+            lj = self.kde_joint().logl(df)
+            return lj - self.kde_marg().logl(df) if self._evidence else lj
         rb, table, mask = self._upload_test(df)
         m = table.num_rows
         vals = np.empty(m, dtype=np.float64)
@@ -230,6 +262,8 @@ class CKDE(Factor):
         return pa.array(out)
 
     def slogl(self, df):
+        if self._split:
+            return float(np.nansum(self.logl(df)))
         _, table, _ = self._upload_test(df)
         res = C.c_double(0.0)
         d = len(self._variables)
@@ -240,6 +274,9 @@ class CKDE(Factor):
         self._check_fitted("CKDE")
         if table.dtype != self._dtype:
             raise ValueError("Data type of training and test datasets is different.")
+        if self._split:
+            lj = self.kde_joint().slogl_table(table, None, row0, n)
+            return lj - self.kde_marg().slogl_table(table, None, row0, n) if self._evidence else lj
         idx = table.index(self._variables)
         n = table.num_rows - row0 if n is None else n
         res = C.c_double(0.0)

@@ -156,6 +156,7 @@ class _KDEBase:
         self._dtype = None
         self._bandwidth = None
         self._N = 0
+        self._on_bandwidth = None  # set by a CKDE that owns this KDE as its joint / marginal member
 
     # -- reference accessors ---------------------------------------------------------------------
     def variables(self):
@@ -196,6 +197,8 @@ class _KDEBase:
         self._bandwidth = value.copy()
         if self._fitted:
             self._device_fit()
+            if self._on_bandwidth is not None:
+                self._on_bandwidth()
 
     def _check_fitted(self):
         if not self._fitted:
