@@ -17,7 +17,10 @@ from .dynamic import (DMMHC, DynamicBayesianNetwork, DynamicGaussianNetwork, Dyn
 from .independences import ChiSquare, IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
 from .models import (BayesianNetwork, BayesianNetworkType, FactorType, ConditionalBayesianNetwork, ConditionalCLGNetwork, ConditionalGaussianNetwork,  # noqa: F401
                      ConditionalKDENetwork, ConditionalSemiparametricBN, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
-                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load)
+                     LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load,
+                     ConditionalDiscreteBN, ConditionalHeterogeneousBN, ConditionalHomogeneousBN, DiscreteBN, DiscreteBNType,
+                     HeterogeneousBN, HeterogeneousBNType, HomogeneousBN, HomogeneousBNType)
+from .dynamic import DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN  # noqa: F401
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
 
@@ -28,4 +31,7 @@ __all__ = [
     "GaussianNetworkType", "SemiparametricBNType", "KDENetworkType", "CLGNetwork", "CLGNetworkType", "DiscreteFactorType",
     "KDE", "ProductKDE", "CKDE", "Factor", "LinearGaussianCPD", "MLE", "HCKDE", "CLinearGaussianCPD", "DiscreteFactor", "BandwidthSelector", "NormalReferenceRule", "ScottsBandwidth", "UCV",
     "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "UnknownFactorType", "DynamicDataFrame", "DynamicBayesianNetwork", "DynamicGaussianNetwork", "DynamicSemiparametricBN", "DynamicKDENetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
+    "DiscreteBN", "DiscreteBNType", "HomogeneousBN", "HomogeneousBNType", "HeterogeneousBN", "HeterogeneousBNType", "ConditionalDiscreteBN",
+    "ConditionalHomogeneousBN", "ConditionalHeterogeneousBN", "DynamicDiscreteBN", "DynamicCLGNetwork", "DynamicHomogeneousBN",
+    "DynamicHeterogeneousBN",
 ]

@@ -155,18 +155,33 @@ class DynamicBayesianNetwork:
     """models/DynamicBayesianNetwork.hpp: a static network over the lagged variables v_t_1 .. v_t_order and a conditional
     transition network over v_t_0 with the lagged variables as interface nodes."""
 
-    def __init__(self, variables, markovian_order, static_bn=None, transition_bn=None, bn_type=None):
+    def __init__(self, *args, **kwargs):
+        """The reference's overloads (pybindings_models.cpp:2590-2665): (type, variables, markovian_order) and
+        (variables, markovian_order, static_bn, transition_bn); `bn_type=` as keyword also accepted."""
+        from .models import BayesianNetworkType
+
+        args = list(args)
+        bn_type = kwargs.pop("bn_type", None)
+        if args and isinstance(args[0], BayesianNetworkType):
+            bn_type = args.pop(0)
+        names = ["variables", "markovian_order", "static_bn", "transition_bn", "bn_type"]
+        for k, v in zip(names, args):
+            kwargs[k] = v
+        variables, markovian_order = kwargs["variables"], kwargs["markovian_order"]
+        static_bn, transition_bn = kwargs.get("static_bn"), kwargs.get("transition_bn")
+        bn_type = kwargs.get("bn_type", bn_type)
         self._variables = list(variables)
         self._order = int(markovian_order)
         if self._order < 1:
             raise ValueError("Markovian order must be at least 1.")
+        if (static_bn is None) != (transition_bn is None):
+            raise ValueError("Static and transition Bayesian networks must be given together.")
         bn_type = bn_type if bn_type is not None else (static_bn.type() if static_bn is not None else GaussianNetworkType())
         static_nodes = temporal_names(self._variables, 1, self._order)
         transition_nodes = temporal_names(self._variables, 0, 0)
         if static_bn is None:
-            static_bn = BayesianNetwork(bn_type, static_nodes)
-        if transition_bn is None:
-            transition_bn = BayesianNetwork(bn_type, transition_nodes, (), (), static_nodes)
+            static_bn = bn_type.new_bn(static_nodes)
+            transition_bn = bn_type.new_cbn(transition_nodes, static_nodes)
         if static_bn.type() != transition_bn.type():
             raise ValueError("Static and transition Bayesian networks do not have the same type.")
         if set(static_bn.nodes()) != set(static_nodes):
@@ -261,46 +276,78 @@ class DynamicBayesianNetwork:
                 total += self._transition.cpd(temporal_name(v, 0)).slogl(dtrans)
         return total
 
+    @property
+    def include_cpd(self):
+        return bool(self._static.include_cpd and self._transition.include_cpd)
+
+    @include_cpd.setter
+    def include_cpd(self, value):
+        self._static.include_cpd = self._transition.include_cpd = bool(value)
+
     def save(self, name, include_cpd=False):
         import pickle
 
-        self._static.include_cpd = self._transition.include_cpd = bool(include_cpd)
+        self.include_cpd = include_cpd
         with open(name if name.endswith(".pickle") else name + ".pickle", "wb") as f:
             pickle.dump(self, f, protocol=2)
+
+    def __getstate__(self):
+        """DynamicBayesianNetwork::__getstate__ (DynamicBayesianNetwork.hpp:160-190): variables, order and the two
+        networks (which carry their factors when include_cpd is set); a Python-derived class adds __getstate_extra__()."""
+        state = {"variables": self._variables, "order": self._order, "static": self._static, "transition": self._transition}
+        extra = getattr(self, "__getstate_extra__", None)
+        if extra is not None:
+            state["extra"] = extra()
+        return state
+
+    def __setstate__(self, state):
+        self._variables, self._order = list(state["variables"]), state["order"]
+        self._static, self._transition = state["static"], state["transition"]
+        if "extra" in state:
+            self.__setstate_extra__(state["extra"])
 
     def __str__(self):
         return f"Dynamic{self.type()} of order {self._order} over {len(self._variables)} variables"
 
+    __repr__ = __str__
 
-def _typed_dbn(bn_type_cls, message):
-    def make(variables, markovian_order, static_bn=None, transition_bn=None):
+
+def _typed_dbn(name, type_name, message, doc):
+    def __init__(self, variables, markovian_order, static_bn=None, transition_bn=None):
+        from . import models
+
+        bn_type = getattr(models, type_name)()
+        if static_bn is not None and transition_bn is not None and static_bn.type() != transition_bn.type():
+            raise ValueError("Static and transition Bayesian networks do not have the same type.")
         for bn in (static_bn, transition_bn):
-            if bn is not None and static_bn is not None and transition_bn is not None and static_bn.type() != transition_bn.type():
-                raise ValueError("Static and transition Bayesian networks do not have the same type.")
-        for bn in (static_bn, transition_bn):
-            if bn is not None and not isinstance(bn.type(), bn_type_cls):
+            if bn is not None and bn.type() != bn_type:
                 raise ValueError(message)
-        return DynamicBayesianNetwork(variables, markovian_order, static_bn, transition_bn, bn_type_cls())
+        DynamicBayesianNetwork.__init__(self, variables, markovian_order, static_bn, transition_bn, bn_type=bn_type)
 
-    return make
-
-
-def DynamicGaussianNetwork(variables, markovian_order, static_bn=None, transition_bn=None):
-    from .models import GaussianNetworkType as T
-
-    return _typed_dbn(T, "Bayesian networks are not Gaussian.")(variables, markovian_order, static_bn, transition_bn)
+    return type(name, (DynamicBayesianNetwork,), {"__init__": __init__, "__doc__": doc, "__module__": __name__})
 
 
-def DynamicSemiparametricBN(variables, markovian_order, static_bn=None, transition_bn=None):
-    from .models import SemiparametricBNType as T
+DynamicGaussianNetwork = _typed_dbn("DynamicGaussianNetwork", "GaussianNetworkType", "Bayesian networks are not Gaussian.",
+                                    "models/DynamicBayesianNetwork.hpp: dynamic GaussianNetwork.")
+DynamicSemiparametricBN = _typed_dbn("DynamicSemiparametricBN", "SemiparametricBNType", "Bayesian networks are not semiparametric.",
+                                     "Dynamic SemiparametricBN.")
+DynamicKDENetwork = _typed_dbn("DynamicKDENetwork", "KDENetworkType", "Bayesian networks are not KDE networks.", "Dynamic KDENetwork.")
+DynamicDiscreteBN = _typed_dbn("DynamicDiscreteBN", "DiscreteBNType", "Bayesian networks are not discrete.", "Dynamic DiscreteBN.")
+DynamicCLGNetwork = _typed_dbn("DynamicCLGNetwork", "CLGNetworkType", "Bayesian networks are not CLG networks.", "Dynamic CLGNetwork.")
 
-    return _typed_dbn(T, "Bayesian networks are not semiparametric.")(variables, markovian_order, static_bn, transition_bn)
+
+class DynamicHomogeneousBN(DynamicBayesianNetwork):
+    def __init__(self, factor_type, variables, markovian_order):
+        from .models import HomogeneousBNType
+
+        DynamicBayesianNetwork.__init__(self, HomogeneousBNType(factor_type), variables, markovian_order)
 
 
-def DynamicKDENetwork(variables, markovian_order, static_bn=None, transition_bn=None):
-    from .models import KDENetworkType as T
+class DynamicHeterogeneousBN(DynamicBayesianNetwork):
+    def __init__(self, factor_types, variables, markovian_order):
+        from .models import HeterogeneousBNType
 
-    return _typed_dbn(T, "Bayesian networks are not KDE networks.")(variables, markovian_order, static_bn, transition_bn)
+        DynamicBayesianNetwork.__init__(self, HeterogeneousBNType(factor_types), variables, markovian_order)
 
 
 def static_blacklist(variables, markovian_order):

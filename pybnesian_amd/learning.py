@@ -25,6 +25,32 @@ _NODE_FROM_CODE = {v: k for k, v in _NODE_CODE.items()}
 _NODE_CODE[UnknownFactorType()] = _lib.PBN_NODE_LG   # set_unknown_node_types: a continuous column defaults to LinearGaussianCPD
 
 
+def _bn_code(bn_type):
+    """Engine family of a network type.  The reference's own types map one to one; a user-defined BayesianNetworkType is
+    run as the built-in family with the same homogeneity / default factor, its can_have_arc() answers entering the
+    engine as extra blacklist entries (see _type_blacklist)."""
+    code = _BN_CODE.get(type(bn_type))
+    if code is not None:
+        return code
+    if bn_type.is_homogeneous():
+        d = bn_type.default_node_type()
+        if d == LinearGaussianCPDType():
+            return _lib.PBN_BN_GAUSSIAN
+        if d == CKDEType():
+            return _lib.PBN_BN_KDE
+        raise ValueError(f"The hill-climbing engine has no factor family for the default node type {d} of {bn_type}.")
+    return _lib.PBN_BN_SEMIPARAMETRIC
+
+
+def _type_blacklist(model):
+    """Arcs a user-defined network type rejects through can_have_arc(model, source, target) (BayesianNetwork.hpp:273):
+    asked once per ordered pair on the start model.  The built-in types' rules live in the engine itself."""
+    if type(model.type()) in _BN_CODE:
+        return []
+    joint = model.nodes() + (model.interface_nodes() if hasattr(model, "interface_nodes") else [])
+    return [(s, t) for s in joint for t in model.nodes() if s != t and not model.type().can_have_arc(model, s, t)]
+
+
 class Operator:
     _kind = -1
 
@@ -268,7 +294,8 @@ class _EngineBinding:
             return a
 
         cfg = _lib.HCConfig()
-        cfg.n_nodes, cfg.bn_type = n, _BN_CODE[type(model.type())]
+        cfg.n_nodes, cfg.bn_type = n, _bn_code(model.type())
+        arc_blacklist = list(arc_blacklist) + [a for a in _type_blacklist(model) if a not in set(map(tuple, arc_blacklist))]
         cfg.node_types = arr(self.node_type_codes(model))
         arcs = pairs(model.arcs())
         cfg.n_arcs, cfg.arcs = len(arcs) // 2, arr(arcs)
@@ -569,7 +596,7 @@ class GreedyHillClimbing:
                 try:
                     cur_arcs = [(nodes[arcs[2 * i]], nodes[arcs[2 * i + 1]]) for i in range(n_arcs)]
                     cur_types = [(nodes[i], _NODE_FROM_CODE[ntypes[i]]) for i in range(n)] + [(v, start.node_type(v)) for v in interface]
-                    cur = BayesianNetwork(start.type(), nodes[:n], cur_arcs, [] if start.type().homogeneous else cur_types, interface)
+                    cur = start.clone()._set_structure(cur_arcs, cur_types)
                     callback.call(cur, binding.make_op(op[0], op[1], op[2], delta), score, iteration)
                     return 0
                 except Exception as ex:
@@ -583,7 +610,7 @@ class GreedyHillClimbing:
         binding.check(rc)
         res_types = [(nodes[i], _NODE_FROM_CODE[out_types[i]]) for i in range(n)] + [(v, start.node_type(v)) for v in interface]
         res_arcs = [(nodes[out_arcs[2 * i]], nodes[out_arcs[2 * i + 1]]) for i in range(out_n.value)]
-        result = BayesianNetwork(start.type(), nodes[:n], res_arcs, [] if start.type().homogeneous else res_types, interface)
+        result = start.clone()._set_structure(res_arcs, res_types)   # hillclimbing.hpp:296: the result is a clone of start
         self.last = HCResult()
         self.last.iterations = stats.iterations
         self.last.cells_scored = stats.cells_scored
@@ -612,7 +639,7 @@ class MMHC:
         nodes = list(nodes) if nodes else list(hypot_test.variable_names())
         if not hypot_test.has_variables(nodes):
             raise ValueError("IndependenceTest do not contain all the variables in nodes list.")
-        bn = BayesianNetwork(bn_type, nodes)
+        bn = bn_type.new_bn(nodes)
         if not score.compatible_bn(bn):
             raise ValueError("BayesianNetwork is not compatible with the score.")
         if not score.has_variables(nodes):
@@ -653,7 +680,7 @@ class MMHC:
             raise ValueError("IndependenceTest do not contain all the variables in nodes/interface_nodes lists.")
         if not score.has_variables(nodes) or not score.has_variables(interface_nodes):
             raise ValueError("Score do not contain all the variables in nodes list.")
-        bn = BayesianNetwork(bn_type, nodes, (), (), interface_nodes)
+        bn = bn_type.new_cbn(nodes, interface_nodes)
         if not score.compatible_bn(bn):
             raise ValueError("BayesianNetwork is not compatible with the score.")
         joint = nodes + interface_nodes
@@ -684,7 +711,7 @@ def hc(df, bn_type=None, start=None, score=None, operators=None, arc_blacklist=(
     if start is None:
         if bn_type is None:
             raise ValueError("\"bn_type\" or \"start\" parameter must be specified.")
-        start = BayesianNetwork(bn_type, [f.name for f in rb.schema])
+        start = bn_type.new_bn([f.name for f in rb.schema])
     bn_type = start.type()
     if isinstance(score, str) or score is None:
         from . import scores as S

@@ -1,14 +1,24 @@
-"""Minimal Bayesian-network model surface needed by the score / hill-climbing path.
+"""The Bayesian-network model surface around the score / hill-climbing path.
 
-Only what `Score.local_score`, the operator sets and `GreedyHillClimbing` touch in the reference
-(/root/reference/pybnesian/models/BayesianNetwork.hpp:29-145,571-577,662-681, SemiparametricBN.hpp:93-119,
-graph/generic_graph.hpp:2711-2745): an ordered node list, a DAG with the reference's add / flip legality
-predicates, and a node-type table (LinearGaussianCPD / CKDE).  Everything else of `models/` is out of scope.
+What `Score.local_score`, the operator sets, `GreedyHillClimbing` / `MMHC` and the model-level fit / logl / sample /
+pickle calls touch in the reference (/root/reference/pybnesian/models/BayesianNetwork.hpp:29-300,571-1260,
+SemiparametricBN.hpp, CLGNetwork.hpp, HomogeneousBN.hpp, HeterogeneousBN.hpp, graph/generic_graph.hpp:2659-2745): an
+ordered node list, a DAG with the reference's add / flip legality predicates, a node-type table, and the
+BayesianNetworkType protocol (subclassable, as through the reference's trampolines) that decides node types and arc
+legality.  The numbers all come from the factors (pybnesian_amd.factors), i.e. from the device.
 """
 
 
 class FactorType:
-    _name = "FactorType"
+    """factors/factors.hpp:20-58.  Subclassable; two factor types are equal when they are of the same class."""
+
+    _name = None
+
+    def __init__(self):
+        pass
+
+    def new_factor(self, model, variable, evidence, *args, **kwargs):
+        raise RuntimeError('Tried to call pure virtual function "FactorType::new_factor"')
 
     def __eq__(self, other):
         return type(self) is type(other)
@@ -17,21 +27,47 @@ class FactorType:
         return hash(type(self).__name__)
 
     def __str__(self):
-        return self._name
+        return self._name if self._name is not None else type(self).__name__
 
-    __repr__ = __str__
+    def __repr__(self):
+        return self.__str__()
+
+
+def _has_discrete_evidence(model, evidence):
+    return model is not None and any(model.node_type(e) == DiscreteFactorType() for e in evidence)
 
 
 class LinearGaussianCPDType(FactorType):
     _name = "LinearGaussianFactor"
 
+    def new_factor(self, model, variable, evidence, *args, **kwargs):
+        """LinearGaussianCPDType::new_factor (LinearGaussianCPD.cpp:20-46)."""
+        from .factors import CLinearGaussianCPD, LinearGaussianCPD
+
+        if _has_discrete_evidence(model, evidence):
+            return CLinearGaussianCPD(variable, list(evidence))
+        return LinearGaussianCPD(variable, list(evidence), *args, **kwargs)
+
 
 class CKDEType(FactorType):
     _name = "CKDEFactor"
 
+    def new_factor(self, model, variable, evidence, *args, **kwargs):
+        """CKDEType::new_factor (CKDE.cpp:15-41)."""
+        from .factors import CKDE, HCKDE
+
+        if _has_discrete_evidence(model, evidence):
+            return HCKDE(variable, list(evidence))
+        return CKDE(variable, list(evidence), *args, **kwargs)
+
 
 class DiscreteFactorType(FactorType):
     _name = "DiscreteFactor"
+
+    def new_factor(self, model, variable, evidence, *args, **kwargs):
+        from .factors import DiscreteFactor
+
+        return DiscreteFactor(variable, list(evidence))
 
 
 class UnknownFactorType(FactorType):
@@ -42,39 +78,303 @@ class UnknownFactorType(FactorType):
 
 
 class BayesianNetworkType:
-    _name = "BayesianNetworkType"
-    homogeneous = True
-    default_type = LinearGaussianCPDType()
+    """models/BayesianNetwork.hpp:224-300.  Subclass it to define a new family of networks: `is_homogeneous`,
+    `default_node_type` (homogeneous) or `data_default_node_type(dt)` (heterogeneous), and optionally
+    `compatible_node_type(model, node, type)`, `can_have_arc(model, source, target)`, `alternative_node_type(model,
+    node)`, `new_bn(nodes)`, `new_cbn(nodes, interface_nodes)`.  Two types are equal when they are of the same class
+    (the reference hashes the Python type object)."""
+
+    def __init__(self):
+        pass
+
+    def is_homogeneous(self):
+        raise NotImplementedError(f"{type(self).__name__}.is_homogeneous() is not implemented.")
+
+    def default_node_type(self):
+        raise RuntimeError(f"default_node_type() for {self} is not defined.")
+
+    def data_default_node_type(self, dt):
+        raise RuntimeError(f"data_default_node_type() for {self} is not defined.")
+
+    def compatible_node_type(self, model, node, node_type):
+        return True
+
+    def can_have_arc(self, model, source, target):
+        return True
+
+    def alternative_node_type(self, model, node):
+        return []
+
+    def new_bn(self, nodes):
+        return BayesianNetwork(self, list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalBayesianNetwork(self, list(nodes), list(interface_nodes))
+
+    def _key(self):
+        return (type(self),)
 
     def __eq__(self, other):
-        return type(self) is type(other)
+        return isinstance(other, BayesianNetworkType) and self._key() == other._key()
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self._key())
 
     def __str__(self):
-        return self._name
+        return type(self).__name__
+
+    def __repr__(self):
+        return self.__str__()
+
+    # the attribute spelling the engine binding reads
+    @property
+    def homogeneous(self):
+        return bool(self.is_homogeneous())
+
+
+def _is_float(dt):
+    import pyarrow as pa
+
+    return pa.types.is_floating(dt)
+
+
+def _is_dict(dt):
+    import pyarrow as pa
+
+    return pa.types.is_dictionary(dt)
 
 
 class GaussianNetworkType(BayesianNetworkType):
-    _name = "GaussianNetworkType"
+    def is_homogeneous(self):
+        return True
+
+    def default_node_type(self):
+        return LinearGaussianCPDType()
+
+    def new_bn(self, nodes):
+        return GaussianNetwork(list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalGaussianNetwork(list(nodes), list(interface_nodes))
 
 
 class KDENetworkType(BayesianNetworkType):
-    _name = "KDENetworkType"
-    default_type = CKDEType()
+    def is_homogeneous(self):
+        return True
+
+    def default_node_type(self):
+        return CKDEType()
+
+    def new_bn(self, nodes):
+        return KDENetwork(list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalKDENetwork(list(nodes), list(interface_nodes))
+
+
+class DiscreteBNType(BayesianNetworkType):
+    def is_homogeneous(self):
+        return True
+
+    def default_node_type(self):
+        return DiscreteFactorType()
+
+    def new_bn(self, nodes):
+        return DiscreteBN(list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalDiscreteBN(list(nodes), list(interface_nodes))
+
+
+def _discrete_parents_ok(model, node, node_type):
+    if node_type == DiscreteFactorType():
+        return all(model.is_interface(p) or model.node_type(p) == DiscreteFactorType() for p in model.parents(node))
+    return True
 
 
 class SemiparametricBNType(BayesianNetworkType):
-    _name = "SemiparametricBNType"
-    homogeneous = False
-    default_type = UnknownFactorType()
+    """models/SemiparametricBN.hpp:30-125."""
+
+    def is_homogeneous(self):
+        return False
+
+    def default_node_type(self):
+        raise RuntimeError("default_node_type() for SemiparametricBN is not defined.")
+
+    def data_default_node_type(self, dt):
+        if _is_float(dt):
+            return [LinearGaussianCPDType(), CKDEType()]
+        if _is_dict(dt):
+            return [DiscreteFactorType()]
+        raise ValueError(f"Data type [{dt}] not compatible with SemiparametricBNType")
+
+    def compatible_node_type(self, model, node, node_type):
+        if node_type not in (LinearGaussianCPDType(), CKDEType(), DiscreteFactorType()):
+            return False
+        return _discrete_parents_ok(model, node, node_type)
+
+    def can_have_arc(self, model, source, target):
+        return model.node_type(target) != DiscreteFactorType() or model.node_type(source) == DiscreteFactorType()
+
+    def alternative_node_type(self, model, node):
+        t = model.node_type(node)
+        if t == LinearGaussianCPDType():
+            return [CKDEType()]
+        if t == CKDEType():
+            return [LinearGaussianCPDType()]
+        return []
+
+    def new_bn(self, nodes):
+        return SemiparametricBN(list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalSemiparametricBN(list(nodes), list(interface_nodes))
+
+    def __str__(self):
+        return "SemiparametricNetworkType"
 
 
 class CLGNetworkType(BayesianNetworkType):
     """models/CLGNetwork.hpp: discrete nodes are DiscreteFactor, continuous nodes LinearGaussianCPD (conditional
     on their discrete parents); no continuous -> discrete arcs (CLGNetwork.hpp:84-89)."""
 
-    _name = "CLGNetworkType"
-    homogeneous = False
-    default_type = UnknownFactorType()
+    def is_homogeneous(self):
+        return False
+
+    def default_node_type(self):
+        raise RuntimeError("default_node_type() for CLGNetwork is not defined.")
+
+    def data_default_node_type(self, dt):
+        if _is_float(dt):
+            return [LinearGaussianCPDType()]
+        if _is_dict(dt):
+            return [DiscreteFactorType()]
+        raise ValueError(f"Data type [{dt}] not compatible with CLGNetworkType")
+
+    def compatible_node_type(self, model, node, node_type):
+        if node_type not in (LinearGaussianCPDType(), DiscreteFactorType()):
+            return False
+        return _discrete_parents_ok(model, node, node_type)
+
+    def can_have_arc(self, model, source, target):
+        return model.node_type(target) == LinearGaussianCPDType() or model.node_type(source) != LinearGaussianCPDType()
+
+    def new_bn(self, nodes):
+        return CLGNetwork(list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalCLGNetwork(list(nodes), list(interface_nodes))
+
+
+class HomogeneousBNType(BayesianNetworkType):
+    """models/HomogeneousBN.hpp: every node has the one factor type given at construction."""
+
+    def __init__(self, default_factor_type):
+        if default_factor_type is None:
+            raise ValueError("Default factor_type cannot be null.")
+        self._ft = default_factor_type
+
+    def is_homogeneous(self):
+        return True
+
+    def default_node_type(self):
+        return self._ft
+
+    def new_bn(self, nodes):
+        return HomogeneousBN(self._ft, list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalHomogeneousBN(self._ft, list(nodes), list(interface_nodes))
+
+    def _key(self):
+        return (type(self), self._ft)
+
+    def __str__(self):
+        return f"HomogeneousType({self._ft})"
+
+
+class HeterogeneousBNType(BayesianNetworkType):
+    """models/HeterogeneousBN.hpp:28-150: default factor types either as one list for every column or as a map
+    pyarrow data type -> list (order of the lists matters for equality, order of the map does not)."""
+
+    def __init__(self, default_factor_types):
+        if isinstance(default_factor_types, dict):
+            self._map = {k: list(v) for k, v in default_factor_types.items() if len(v)}
+            self._single = None
+            if not self._map:
+                raise ValueError("Default factor_type cannot be empty.")
+            if any(f is None for v in self._map.values() for f in v):
+                raise ValueError("Default factor_type cannot contain null FactorType.")
+        else:
+            self._single = list(default_factor_types)
+            self._map = None
+            if not self._single:
+                raise ValueError("Default factor_type cannot be empty.")
+            if any(f is None for f in self._single):
+                raise ValueError("Default factor_type cannot contain null FactorType.")
+
+    def is_homogeneous(self):
+        return False
+
+    def default_node_type(self):
+        raise RuntimeError("default_node_type() for HeterogeneousBN is not defined.")
+
+    def data_default_node_type(self, dt):
+        if self._single is not None:
+            return list(self._single)
+        for k, v in self._map.items():
+            if k.equals(dt):
+                return list(v)
+        raise ValueError(f"Not valid FactorType for DataType {dt}")
+
+    def single_default(self):
+        return self._single is not None
+
+    def default_node_types(self):
+        return {None: list(self._single)} if self._single is not None else {k: list(v) for k, v in self._map.items()}
+
+    def new_bn(self, nodes):
+        return HeterogeneousBN(self._single if self._single is not None else self._map, list(nodes))
+
+    def new_cbn(self, nodes, interface_nodes):
+        return ConditionalHeterogeneousBN(self._single if self._single is not None else self._map, list(nodes), list(interface_nodes))
+
+    def _key(self):
+        if self._single is not None:
+            return (type(self), tuple(self._single))
+        return (type(self), frozenset((str(k), tuple(v)) for k, v in self._map.items()))
+
+    def __str__(self):
+        return "HeterogeneousBNType"
+
+
+def _is_arc_list(x):
+    return len(x) > 0 and all(isinstance(a, (tuple, list)) and len(a) == 2 and isinstance(a[0], str) and isinstance(a[1], str) for a in x)
+
+
+def _is_type_list(x):
+    return len(x) > 0 and all(isinstance(a, (tuple, list)) and len(a) == 2 and isinstance(a[1], FactorType) for a in x)
+
+
+def _split_ctor_args(nodes, arcs, node_types):
+    """Disentangle the reference's constructor overloads: the first list holds node names or arcs, the second arcs or
+    (node, FactorType) pairs."""
+    nodes = list(nodes) if nodes is not None else []
+    arcs = list(arcs) if arcs is not None else []
+    node_types = list(node_types) if node_types is not None else []
+    if _is_type_list(arcs) and not node_types:
+        arcs, node_types = [], arcs
+    if _is_arc_list(nodes) and not arcs:
+        arcs, seen = nodes, []
+        for s, t in arcs:
+            for x in (s, t):
+                if x not in seen:
+                    seen.append(x)
+        nodes = seen
+    return nodes, arcs, node_types
 
 
 class BayesianNetwork:
@@ -82,15 +382,11 @@ class BayesianNetwork:
     conditional - interface nodes can be parents of the nodes but have no parents, factors or scores of their own."""
 
     def __init__(self, bn_type, nodes, arcs=(), node_types=(), interface_nodes=()):
-        if nodes and isinstance(nodes[0], (tuple, list)) and not arcs:
-            # constructed from arcs only: nodes in order of first appearance
-            arcs = nodes
-            seen = []
-            for s, t in arcs:
-                for x in (s, t):
-                    if x not in seen:
-                        seen.append(x)
-            nodes = seen
+        """The reference's overloads (pybindings_models.cpp:2211-2390): (type, nodes), (type, nodes, node_types),
+        (type, arcs), (type, arcs, node_types), (type, nodes, arcs), (type, nodes, arcs, node_types)."""
+        if bn_type is None:
+            raise ValueError("Type of Bayesian network must be non-null.")
+        nodes, arcs, node_types = _split_ctor_args(nodes, arcs, node_types)
         self._type = bn_type
         self._nodes = list(nodes)
         self._interface = list(interface_nodes)
@@ -100,8 +396,11 @@ class BayesianNetwork:
         self._index = {n: i for i, n in enumerate(joint)}
         self._parents = {n: [] for n in joint}
         self._children = {n: [] for n in joint}
-        self._types = {n: bn_type.default_type for n in joint}
+        default = bn_type.default_node_type() if bn_type.is_homogeneous() else UnknownFactorType()
+        self._types = {n: default for n in joint}
         for n, t in node_types:
+            if n not in self._index:
+                raise ValueError(f"Node {n} not present in the Bayesian network.")
             self.set_node_type(n, t)
         for s, t in arcs:
             self.add_arc(s, t)
@@ -125,6 +424,9 @@ class BayesianNetwork:
     def contains_node(self, node):
         return node in self._index and node not in self._interface
 
+    def _default_type(self):
+        return self._type.default_node_type() if self._type.is_homogeneous() else UnknownFactorType()
+
     def _reindex(self):
         self._index = {n: i for i, n in enumerate(self._nodes + self._interface)}
 
@@ -134,7 +436,7 @@ class BayesianNetwork:
             raise ValueError(f"Cannot add node {node} because a node with the same name already exists.")
         self._nodes.append(node)
         self._parents[node], self._children[node] = [], []
-        self._types[node] = self._type.default_type
+        self._types[node] = self._default_type()
         self._reindex()
         if getattr(self, "_cpds", None):
             self._cpds.pop(node, None)
@@ -162,7 +464,7 @@ class BayesianNetwork:
             raise ValueError(f"Cannot add node {node} because a node with the same name already exists.")
         self._interface.append(node)
         self._parents[node], self._children[node] = [], []
-        self._types[node] = self._type.default_type
+        self._types[node] = self._default_type()
         self._reindex()
 
     def remove_interface_node(self, node):
@@ -199,20 +501,29 @@ class BayesianNetwork:
     def contains_joint_node(self, node):
         return node in self._index
 
+    def _filled(self, net, arcs, types):
+        """Copy node types and arcs onto a network just made by the type's new_bn / new_cbn."""
+        if not self._type.is_homogeneous():
+            for n, t in types:
+                if net.contains_joint_node(n):
+                    net._types[n] = t
+        for s, t in arcs:
+            net.add_arc(s, t)
+        return net
+
     def conditional_bn(self, nodes=None, interface_nodes=None):
         """BNGeneric::conditional_bn (BayesianNetwork.hpp:1064-1100): the same arcs and node types over a new split of
-        the variables into nodes and interface nodes (arcs into interface nodes are dropped)."""
+        the variables into nodes and interface nodes (arcs into interface nodes are dropped); the network object comes
+        from the type's new_cbn."""
         if nodes is None:
             nodes, interface_nodes = self._nodes, self._interface
         interface_nodes = list(interface_nodes or [])
         keep = set(nodes) | set(interface_nodes)
         arcs = [(s, t) for s, t in self.arcs() if s in keep and t in set(nodes)]
-        types = [(n, t) for n, t in self._types.items() if n in keep]
-        return BayesianNetwork(self._type, list(nodes), arcs, [] if self._type.homogeneous else types, interface_nodes)
+        return self._filled(self._type.new_cbn(list(nodes), interface_nodes), arcs, list(self._types.items()))
 
     def unconditional_bn(self):
-        types = list(self._types.items())
-        return BayesianNetwork(self._type, self.joint_nodes(), self.arcs(), [] if self._type.homogeneous else types)
+        return self._filled(self._type.new_bn(self.joint_nodes()), self.arcs(), list(self._types.items()))
 
     def arcs(self):
         return [(p, n) for n in self._nodes for p in self._parents[n]]
@@ -245,8 +556,8 @@ class BayesianNetwork:
         return False
 
     def can_have_arc(self, source, target):
-        """BayesianNetworkType::can_have_arc (SemiparametricBN.hpp:93-98, CLGNetwork.hpp:84-89)."""
-        return not (self._types[target] == DiscreteFactorType() and self._types[source] != DiscreteFactorType())
+        """BayesianNetworkType::can_have_arc (SemiparametricBN.hpp:93-98, CLGNetwork.hpp:84-89, user types)."""
+        return bool(self._type.can_have_arc(self, source, target))
 
     def can_add_arc(self, source, target):
         return source != target and target not in self._interface and self.can_have_arc(source, target) and (
@@ -275,6 +586,8 @@ class BayesianNetwork:
             raise ValueError(f"Interface node {target} cannot have parents.")
         if self.has_arc(source, target):
             return
+        if not self.can_have_arc(source, target):
+            raise ValueError(f"Cannot add arc {source} -> {target}: the Bayesian network type \"{self._type}\" does not allow it.")
         if not self.can_add_arc(source, target):
             raise ValueError(f"Cannot add arc {source} -> {target}: it would create a cycle.")
         self._parents[target].append(source)
@@ -298,14 +611,14 @@ class BayesianNetwork:
         return dict(self._types)
 
     def has_unknown_node_types(self):
-        return any(t == UnknownFactorType() for t in self._types.values())
+        if self._type.is_homogeneous():
+            return False
+        return any(self._types[n] == UnknownFactorType() for n in self._nodes)
 
     def underlying_node_type(self, df, node):
         """BNGeneric::underlying_node_type (BayesianNetwork.hpp:662-681): the node's type, or for an unknown one the
-        first default of the network type for the column's data type (SemiparametricBN.hpp:60-75, CLGNetwork.hpp:55-68:
+        first default of the network type for the column's data type (SemiparametricBN.hpp:43-55, CLGNetwork.hpp:40-50:
         float -> LinearGaussianCPD, dictionary -> DiscreteFactor)."""
-        import pyarrow as pa
-
         from .dataset import as_record_batch
 
         t = self._types[node]
@@ -313,46 +626,112 @@ class BayesianNetwork:
             return t
         rb = as_record_batch(df)
         f = rb.schema.field(node)
-        if pa.types.is_dictionary(f.type):
-            return DiscreteFactorType()
-        if pa.types.is_floating(f.type):
-            return LinearGaussianCPDType()
-        raise ValueError(f"There is no underlying FactorType for node {node} as there is no valid FactorType for DataType {f.type}")
+        options = self._type.data_default_node_type(f.type)
+        if not options:
+            raise ValueError(f"There is no underlying FactorType for node {node} as there is no valid FactorType for DataType {f.type}")
+        return options[0]
 
     def set_unknown_node_types(self, df, type_blacklist=()):
-        """BNGeneric::set_unknown_node_types (BayesianNetwork.hpp:700-745)."""
-        import pyarrow as pa
-
+        """BNGeneric::set_unknown_node_types (BayesianNetwork.hpp:720-748): the first default of the column's data
+        type that is not blacklisted."""
         from .dataset import as_record_batch
 
+        if self._type.is_homogeneous():
+            return
         rb = as_record_batch(df)
         black = {(n, t) for n, t in type_blacklist}
-        for node, t in list(self._types.items()):
-            if t != UnknownFactorType():
+        new_types = []
+        for node in self._nodes:
+            if self._types[node] != UnknownFactorType():
                 continue
-            f = rb.schema.field(node)
-            if pa.types.is_dictionary(f.type):
-                options = [DiscreteFactorType()]
-            elif isinstance(self._type, CLGNetworkType):
-                options = [LinearGaussianCPDType()]
-            else:
-                options = [LinearGaussianCPDType(), CKDEType()]
-            options = [o for o in options if (node, o) not in black]
+            if rb.schema.get_field_index(node) < 0:
+                raise ValueError(f"Column {node} not present in the DataFrame.")
+            options = [o for o in self._type.data_default_node_type(rb.schema.field(node).type) if (node, o) not in black]
             if not options:
-                raise ValueError(f"There is no valid FactorType for node {node} (all the defaults are blacklisted).")
-            self._types[node] = options[0]
+                raise ValueError(f"A valid FactorType for node {node} could not be inferred.")
+            new_types.append((node, options[0]))
+        self.force_type_whitelist(new_types)
+
+    def force_type_whitelist(self, type_whitelist):
+        """BNGeneric::force_type_whitelist (BayesianNetwork.hpp:761-790)."""
+        for n, t in type_whitelist:
+            self.set_node_type(n, t)
+
+    def force_whitelist(self, arc_whitelist):
+        """BNGeneric::force_whitelist: every whitelisted arc present, flipping the opposite arc when needed."""
+        for s, t in arc_whitelist:
+            if self.has_arc(s, t):
+                continue
+            if self.has_arc(t, s):
+                raise ValueError(f"Arc {t} -> {s} in whitelist, but the opposite arc is present in the Bayesian network.")
+            if not self.can_add_arc(s, t):
+                raise ValueError(f"Arc {s} -> {t} in whitelist can not be added to the Bayesian network.")
+            self.add_arc(s, t)
+
+    def check_blacklist(self, arc_blacklist):
+        for s, t in arc_blacklist:
+            if self.has_arc(s, t):
+                raise ValueError(f"Arc {s} -> {t} in blacklist, but it is present in the Bayesian Network.")
 
     def set_node_type(self, node, node_type):
-        if isinstance(self._type, CLGNetworkType) and node_type == CKDEType():
-            raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
-        if self._type.homogeneous and node_type != self._type.default_type:
-            raise ValueError(f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\".")
+        """BNGeneric::set_node_type (BayesianNetwork.hpp:701-718)."""
+        wrong = f"Wrong factor type \"{node_type}\" for node \"{node}\" in Bayesian network type \"{self._type}\"."
+        if self._type.is_homogeneous():
+            if node_type != self._type.default_node_type():
+                raise ValueError(wrong)
+            return
+        if node not in self._index:
+            raise ValueError(f"Node {node} not present in the Bayesian network.")
+        if node_type != UnknownFactorType() and not self._type.compatible_node_type(self, node, node_type):
+            raise ValueError(wrong)
         if self._types.get(node) != node_type and getattr(self, "_cpds", None):
-            self._cpds.pop(node, None)   # a factor of the old type no longer belongs to the node (BayesianNetwork.hpp:770-790)
+            self._cpds.pop(node, None)   # a factor of the old type no longer belongs to the node
         self._types[node] = node_type
 
+    def can_have_cpd(self, node):
+        return self.contains_node(node)
+
+    def check_compatible_cpd(self, cpd):
+        v = cpd.variable()
+        if not self.contains_node(v):
+            raise ValueError(f"CPD defined on variable which is not present in the model:\n{cpd}")
+        if sorted(cpd.evidence()) != sorted(self._parents[v]):
+            raise ValueError(f"CPD do not have the model's parent set as evidence:\n{cpd}")
+        t = self._types[v]
+        if t != UnknownFactorType() and cpd.type() != t:
+            raise ValueError(f"Bayesian network expects type {t} for node {v}, but {cpd.type()} was provided.")
+
     def clone(self):
-        return BayesianNetwork(self._type, self._nodes, self.arcs(), list(self._types.items()), self._interface)
+        """BayesianNetworkBase::clone (BayesianNetwork.hpp:105-119): same class (also a Python-derived one, with its
+        extra attributes), structure, node types and factors; the containers are the clone's own."""
+        import copy
+
+        new = copy.copy(self)
+        new._nodes, new._interface = list(self._nodes), list(self._interface)
+        new._index, new._types = dict(self._index), dict(self._types)
+        new._parents = {k: list(v) for k, v in self._parents.items()}
+        new._children = {k: list(v) for k, v in self._children.items()}
+        if getattr(self, "_cpds", None) is not None:
+            new._cpds = dict(self._cpds)
+        return new
+
+    def _set_structure(self, arcs, node_types=()):
+        """Replace arcs (and, for heterogeneous networks, node types) in place: how the learning algorithms write their
+        result onto a clone of the start model."""
+        for n in self._parents:
+            self._parents[n], self._children[n] = [], []
+        if not self._type.is_homogeneous():
+            for n, t in node_types:
+                if self._types.get(n) != t:
+                    self._types[n] = t
+        for s, t in arcs:
+            self._parents[t].append(s)
+            self._children[s].append(t)
+        if getattr(self, "_cpds", None):
+            for n in list(self._cpds):
+                if not self._cpd_valid(n):
+                    self._cpds.pop(n)
+        return self
 
     # -- parameters: BayesianNetwork::fit / logl / slogl (models/BayesianNetwork.hpp:960-994) -------------------
     def _new_factor(self, df, node):
@@ -366,9 +745,13 @@ class BayesianNetwork:
         rb = as_record_batch(df)
         parents = self.parents(node)
         is_disc = lambda v: pa.types.is_dictionary(rb.schema.field(v).type)
-        nt = DiscreteFactorType() if is_disc(node) else self._types[node]
+        nt = self._types[node]
         if nt == UnknownFactorType():
-            nt = LinearGaussianCPDType()
+            nt = self.underlying_node_type(rb, node)
+        if is_disc(node) and nt in (LinearGaussianCPDType(), CKDEType()):
+            nt = DiscreteFactorType()
+        if hasattr(nt, "new_factor") and type(nt) not in (LinearGaussianCPDType, CKDEType, DiscreteFactorType):
+            return nt.new_factor(self, node, parents)   # FactorType::new_factor of a user-defined type
         if nt == DiscreteFactorType():
             return DiscreteFactor(node, parents)
         hybrid = any(is_disc(p) for p in parents)
@@ -475,14 +858,7 @@ class BayesianNetwork:
     def add_cpds(self, cpds):
         """BayesianNetwork::add_cpds (BayesianNetwork.hpp:845-905): fitted factors whose evidence equals the parents."""
         for f in cpds:
-            v = f.variable()
-            if v not in self._index:
-                raise ValueError(f"CPD defined on variable which is not present in the model:\n{f}")
-            if sorted(f.evidence()) != sorted(self._parents[v]):
-                raise ValueError(f"CPD do not have the model's parent set as evidence:\n{f}")
-            t = self._types[v]
-            if t != UnknownFactorType() and f.type() != t:
-                raise ValueError(f"Bayesian network expects type {t} for node {v}, but {f.type()} was provided.")
+            self.check_compatible_cpd(f)
         if getattr(self, "_cpds", None) is None:
             self._cpds = {}
         for f in cpds:
@@ -535,17 +911,30 @@ class BayesianNetwork:
             pickle.dump(self, f, protocol=2)
 
     def __getstate__(self):
+        """BNGeneric::__getstate__ (BayesianNetwork.hpp:1217-1260): structure, type, node types, and - with include_cpd -
+        the factors added so far; a Python-derived class adds `__getstate_extra__()`."""
         state = {"type": self._type, "nodes": self._nodes, "arcs": self.arcs(), "types": list(self._types.items()),
-                 "interface": self._interface}
-        if getattr(self, "_include_cpd", False) and self.fitted():
-            state["cpds"] = [self._cpds[n] for n in self._nodes]
+                 "interface": self._interface, "include_cpd": bool(getattr(self, "_include_cpd", False))}
+        if state["include_cpd"] and getattr(self, "_cpds", None):
+            state["cpds"] = [self._cpds[n] for n in self._nodes if n in self._cpds]
+        extra = getattr(self, "__getstate_extra__", None)
+        if extra is not None:
+            state["extra"] = extra()
         return state
 
     def __setstate__(self, state):
-        self.__init__(state["type"], state["nodes"], state["arcs"], state["types"], state.get("interface", ()))
+        BayesianNetwork.__init__(self, state["type"], state["nodes"], (), (), state.get("interface", ()))
+        if not self._type.is_homogeneous():
+            self._types.update(dict(state["types"]))
+        for s, t in state["arcs"]:
+            self._parents[t].append(s)
+            self._children[s].append(t)
+        self._include_cpd = bool(state.get("include_cpd", False))
         if "cpds" in state:
             self._cpds = {f.variable(): f for f in state["cpds"]}
             self._include_cpd = True
+        if "extra" in state:
+            self.__setstate_extra__(state["extra"])
 
     @property
     def include_cpd(self):
@@ -558,45 +947,66 @@ class BayesianNetwork:
     def __str__(self):
         return f"{self._type} with {self.num_nodes()} nodes and {self.num_arcs()} arcs"
 
-
-def GaussianNetwork(nodes, arcs=()):
-    return BayesianNetwork(GaussianNetworkType(), nodes, arcs)
+    __repr__ = __str__
 
 
-def KDENetwork(nodes, arcs=()):
-    return BayesianNetwork(KDENetworkType(), nodes, arcs)
+
+class ConditionalBayesianNetwork(BayesianNetwork):
+    """models/BayesianNetwork.hpp ConditionalBayesianNetwork: (type, nodes, interface_nodes[, arcs][, node_types])."""
+
+    def __init__(self, bn_type, nodes, interface_nodes, arcs=(), node_types=()):
+        BayesianNetwork.__init__(self, bn_type, list(nodes), arcs, node_types, list(interface_nodes))
 
 
-def SemiparametricBN(nodes, arcs=(), node_types=()):
-    if arcs and isinstance(arcs[0], (tuple, list)) and len(arcs[0]) == 2 and isinstance(arcs[0][1], FactorType):
-        node_types, arcs = arcs, ()
-    return BayesianNetwork(SemiparametricBNType(), nodes, arcs, node_types)
+def _typed(name, bn_type_cls, conditional, takes_types, doc):
+    base = ConditionalBayesianNetwork if conditional else BayesianNetwork
+    if conditional:
+        def __init__(self, nodes, interface_nodes, arcs=(), node_types=()):
+            if not takes_types and node_types:
+                raise TypeError(f"{name} does not take node types")
+            ConditionalBayesianNetwork.__init__(self, bn_type_cls(), nodes, interface_nodes, arcs, node_types)
+    else:
+        def __init__(self, nodes, arcs=(), node_types=()):
+            if not takes_types and (node_types or _is_type_list(list(arcs))):
+                raise TypeError(f"{name} does not take node types")
+            BayesianNetwork.__init__(self, bn_type_cls(), nodes, arcs, node_types)
+    return type(name, (base,), {"__init__": __init__, "__doc__": doc, "__module__": __name__})
 
 
-def CLGNetwork(nodes, arcs=(), node_types=()):
-    return BayesianNetwork(CLGNetworkType(), nodes, arcs, node_types)
+GaussianNetwork = _typed("GaussianNetwork", GaussianNetworkType, False, False, "models/GaussianNetwork.hpp: every node a LinearGaussianCPD.")
+KDENetwork = _typed("KDENetwork", KDENetworkType, False, False, "models/KDENetwork.hpp: every node a CKDE.")
+DiscreteBN = _typed("DiscreteBN", DiscreteBNType, False, False, "models/DiscreteBN.hpp: every node a DiscreteFactor.")
+SemiparametricBN = _typed("SemiparametricBN", SemiparametricBNType, False, True, "models/SemiparametricBN.hpp: LinearGaussianCPD / CKDE (/ DiscreteFactor) per node.")
+CLGNetwork = _typed("CLGNetwork", CLGNetworkType, False, True, "models/CLGNetwork.hpp: DiscreteFactor and (conditional) LinearGaussianCPD nodes.")
+ConditionalGaussianNetwork = _typed("ConditionalGaussianNetwork", GaussianNetworkType, True, False, "Conditional GaussianNetwork.")
+ConditionalKDENetwork = _typed("ConditionalKDENetwork", KDENetworkType, True, False, "Conditional KDENetwork.")
+ConditionalDiscreteBN = _typed("ConditionalDiscreteBN", DiscreteBNType, True, False, "Conditional DiscreteBN.")
+ConditionalSemiparametricBN = _typed("ConditionalSemiparametricBN", SemiparametricBNType, True, True, "Conditional SemiparametricBN.")
+ConditionalCLGNetwork = _typed("ConditionalCLGNetwork", CLGNetworkType, True, True, "Conditional CLGNetwork.")
 
 
-def ConditionalBayesianNetwork(bn_type, nodes, interface_nodes, arcs=(), node_types=()):
-    return BayesianNetwork(bn_type, list(nodes), arcs, node_types, list(interface_nodes))
+class HomogeneousBN(BayesianNetwork):
+    """models/HomogeneousBN.hpp: HomogeneousBN(factor_type, nodes | arcs[, arcs])."""
+
+    def __init__(self, factor_type, nodes, arcs=()):
+        BayesianNetwork.__init__(self, HomogeneousBNType(factor_type), nodes, arcs)
 
 
-def ConditionalGaussianNetwork(nodes, interface_nodes, arcs=()):
-    return BayesianNetwork(GaussianNetworkType(), list(nodes), arcs, (), list(interface_nodes))
+class ConditionalHomogeneousBN(ConditionalBayesianNetwork):
+    def __init__(self, factor_type, nodes, interface_nodes, arcs=()):
+        ConditionalBayesianNetwork.__init__(self, HomogeneousBNType(factor_type), nodes, interface_nodes, arcs)
 
 
-def ConditionalKDENetwork(nodes, interface_nodes, arcs=()):
-    return BayesianNetwork(KDENetworkType(), list(nodes), arcs, (), list(interface_nodes))
+class HeterogeneousBN(BayesianNetwork):
+    """models/HeterogeneousBN.hpp: HeterogeneousBN(factor_types (list | {DataType: list}), nodes | arcs[, arcs][, node_types])."""
+
+    def __init__(self, factor_types, nodes, arcs=(), node_types=()):
+        BayesianNetwork.__init__(self, HeterogeneousBNType(factor_types), nodes, arcs, node_types)
 
 
-def ConditionalSemiparametricBN(nodes, interface_nodes, arcs=(), node_types=()):
-    if arcs and isinstance(arcs[0], (tuple, list)) and len(arcs[0]) == 2 and isinstance(arcs[0][1], FactorType):
-        node_types, arcs = arcs, ()
-    return BayesianNetwork(SemiparametricBNType(), list(nodes), arcs, node_types, list(interface_nodes))
-
-
-def ConditionalCLGNetwork(nodes, interface_nodes, arcs=(), node_types=()):
-    return BayesianNetwork(CLGNetworkType(), list(nodes), arcs, node_types, list(interface_nodes))
+class ConditionalHeterogeneousBN(ConditionalBayesianNetwork):
+    def __init__(self, factor_types, nodes, interface_nodes, arcs=(), node_types=()):
+        ConditionalBayesianNetwork.__init__(self, HeterogeneousBNType(factor_types), nodes, interface_nodes, arcs, node_types)
 
 
 def load(name):
