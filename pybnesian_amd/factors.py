@@ -500,7 +500,13 @@ class DiscreteFactor(Factor):
 
     def data_type(self):
         self._check_fitted("DiscreteFactor")
-        return pa.dictionary(pa.int8(), pa.string())
+        return pa.dictionary(self._index_type(), pa.string())
+
+    def _index_type(self):
+        """Smallest signed index type that holds the variable's categories, as pyarrow / pandas encode them
+        (DiscreteFactor_test.py:11-35: 128 categories -> int8, 129 -> int16)."""
+        card = self._cards[0]
+        return pa.int8() if card <= 128 else pa.int16() if card <= 32768 else pa.int32()
 
     def sample(self, n, evidence_values=None, seed=None, _stream_n=0):
         """DiscreteFactor.sample (DiscreteFactor.cpp:173-208, .hpp:144-205): dictionary array (pbn_discrete_sample)."""
@@ -528,7 +534,7 @@ class DiscreteFactor(Factor):
         _lib.check(_lib.load().pbn_discrete_sample(n, _lib.dptr(lp), card, lp.size,
                                                    offs.ctypes.data_as(C.POINTER(C.c_int)) if offs is not None else None,
                                                    C.c_uint32(seed), out.ctypes.data_as(C.POINTER(C.c_int))))
-        return pa.DictionaryArray.from_arrays(pa.array(out.astype(np.int8) if card <= 127 else out), pa.array(self._categories[0]))
+        return pa.DictionaryArray.from_arrays(pa.array(out, type=pa.int32()).cast(self._index_type()), pa.array(self._categories[0]))
 
 
 class _DiscreteAdaptator(Factor):

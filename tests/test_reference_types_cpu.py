@@ -538,3 +538,17 @@ def test_serialization_partially_fitted_dbn():
     assert l.static_bn().node_type("b_t_1") == pbn.DiscreteFactorType() and l.static_bn().node_type("c_t_1") == pbn.CKDEType()
     assert l.transition_bn().node_type("b_t_0") == pbn.DiscreteFactorType() and l.transition_bn().node_type("d_t_0") == pbn.LinearGaussianCPDType()
     assert list(l.static_bn().cpd("d_t_1").beta) == [1, 2] and l.transition_bn().cpd("d_t_0").variance == 1.5
+
+
+def test_discrete_factor_data_type():   # factors/discrete/DiscreteFactor_test.py:11-35
+    import numpy as np
+    import pandas as pd
+
+    a = pbn.DiscreteFactor("A", [])
+    with pytest.raises(ValueError, match="DiscreteFactor factor not fitted."):
+        a.data_type()
+    for ncat, index_type in ((2, pa.int8()), (128, pa.int8()), (129, pa.int16())):
+        categories = np.asarray(["a" + str(i) for i in range(1, ncat + 1)])
+        values = pd.Categorical(categories[np.random.RandomState(ncat).randint(len(categories), size=100)], categories=categories, ordered=False)
+        a.fit(pd.DataFrame({"A": values}))
+        assert a.data_type() == pa.dictionary(index_type, pa.string())

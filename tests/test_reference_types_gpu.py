@@ -164,3 +164,87 @@ def test_homogeneous_and_heterogeneous_networks_fit(pbn):
     learned = pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), pbn.BIC(df), pbn.HomogeneousBN(pbn.LinearGaussianCPDType(), ABCD))
     ref = pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), pbn.BIC(df), pbn.GaussianNetwork(ABCD))
     assert type(learned) is pbn.HomogeneousBN and sorted(learned.arcs()) == sorted(ref.arcs())
+
+
+class ExtraNewBN(NewBN):
+    """hillclimbing_test.py:180-195: a Python-derived network with extra pickled state."""
+
+    def __init__(self, variables, arcs=None):
+        NewBN.__init__(self, variables, arcs)
+        self.extra_data = "extra"
+
+    def __getstate_extra__(self):
+        return self.extra_data
+
+    def __setstate_extra__(self, extra):
+        self.extra_data = extra
+
+
+def test_hc_conditional_and_removed_nodes(pbn, golden):   # hillclimbing_test.py:60-101
+    from helpers import frame
+
+    df = frame(golden["train10k"])
+    bic = pbn.BIC(df)
+    names = list(df.columns)
+    start = pbn.ConditionalGaussianNetwork(names[2:], names[:2])
+    nodes, interface = names[2:], names[:2]
+    nodes.insert(1, "e")
+    interface.insert(1, "f")
+    start_removed = pbn.ConditionalGaussianNetwork(nodes, interface)
+    start_removed.remove_node("e")
+    start_removed.remove_interface_node("f")
+    arc_set, hc = pbn.ArcOperatorSet(), pbn.GreedyHillClimbing()
+    res = hc.estimate(arc_set, bic, start, max_iters=1)
+    assert res.num_arcs() == 1 and type(res) is pbn.ConditionalGaussianNetwork
+    added = res.arcs()[0]
+    op_delta = bic.score(res) - bic.score(start)
+    res_removed = hc.estimate(arc_set, bic, start_removed, max_iters=1)
+    assert res_removed.num_arcs() == 1
+    added_removed = res_removed.arcs()[0]
+    assert added == added_removed or added == added_removed[::-1]
+    assert np.isclose(op_delta, bic.score(res_removed) - bic.score(start_removed))
+    assert np.isclose(op_delta, bic.local_score(res, added[1], [added[0]]) - bic.local_score(res, added[1], []))
+    assert hc.estimate(arc_set, bic, start, epsilon=op_delta + 0.01).num_arcs() == start.num_arcs()
+    assert hc.estimate(arc_set, bic, start_removed, epsilon=op_delta + 0.01).num_arcs() == 0
+    full = hc.estimate(arc_set, bic, start)
+    assert full.num_arcs() > 1 and all(not full.is_interface(t) for _, t in full.arcs())
+    full_removed = hc.estimate(arc_set, bic, start_removed)
+    assert sorted(full_removed.arcs()) == sorted(full.arcs())
+
+
+def test_hc_validated_and_shortcut(pbn, golden):   # hillclimbing_test.py:103-205
+    from helpers import frame
+
+    df = frame(golden["train10k"])
+    names = list(df.columns)
+    start = pbn.GaussianNetwork(names)
+    names.insert(1, "e")
+    names.insert(4, "f")
+    start_removed = pbn.GaussianNetwork(names)
+    start_removed.remove_node("e")
+    start_removed.remove_node("f")
+    vl = pbn.ValidatedLikelihood(df, seed=0)
+    arc_set, hc = pbn.ArcOperatorSet(), pbn.GreedyHillClimbing()
+    res = hc.estimate(arc_set, vl, start, max_iters=1)
+    assert res.num_arcs() == 1
+    added = res.arcs()[0]
+    op_delta = vl.cv_lik.score(res) - vl.cv_lik.score(start)
+    res_removed = hc.estimate(arc_set, vl, start_removed, max_iters=1)
+    added_removed = res_removed.arcs()[0]
+    assert added == added_removed or added == added_removed[::-1]
+    assert np.isclose(op_delta, vl.cv_lik.score(res_removed) - vl.cv_lik.score(start_removed))
+    assert np.isclose(op_delta, vl.cv_lik.local_score(res, added[1], [added[0]]) - vl.cv_lik.local_score(res, added[1], []))
+    # CV is score equivalent for Gaussian networks: blacklisting the added arc adds its reverse
+    res = hc.estimate(arc_set, vl, start, max_iters=1, arc_blacklist=[added])
+    assert res.num_arcs() == 1 and res.arcs()[0][::-1] == added
+    assert hc.estimate(arc_set, vl, start, epsilon=op_delta + 0.01).num_arcs() == 0
+    hc.estimate(arc_set, vl, start)
+    hc.estimate(arc_set, vl, start_removed)
+
+    model = pbn.hc(df, bn_type=pbn.GaussianNetworkType())
+    assert type(model) == pbn.GaussianNetwork
+    model = pbn.hc(df, bn_type=MyRestrictedGaussianNetworkType(), score="bic", operators=["arcs"])
+    assert type(model) == NewBN and all("a" in s for s, _ in model.arcs())
+
+    estimated = hc.estimate(arc_set, pbn.BIC(df), ExtraNewBN(ABCD))
+    assert type(estimated) is ExtraNewBN and estimated.extra_data == "extra"
