@@ -34,9 +34,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 // 2^r on [-1/2, 1/2]: interpolants at Chebyshev nodes.  The DP units are the binding resource of the fp64 sweep
 // (DESIGN.md "roofline"); every polynomial degree costs 4.4 % of that kernel.  The log-likelihood sweeps use degree 7:
-// max relative error 5.5e-11 per term, four orders below the 1e-6 parity bar and below every tolerance of the parity
-// tests (-DPBN_EXP2_DEGREE=8 restores 1.07e-12 there).  The weight kernels (CKDE::cdf / sample, UCV) always use
-// degree 8: the UCV objective is a difference of two pair sums and amplifies per-term errors.
+// max relative error 5.5e-11 per term (4.0e-11 for the [0, 1) form below), four orders below the 1e-6 parity bar and
+// below every tolerance of the parity tests (-DPBN_EXP2_DEGREE=8 restores 1.07e-12 there).  The weight kernels
+// (CKDE::cdf / sample, UCV) always use degree 8: the UCV objective is a difference of two pair sums and amplifies
+// per-term errors.
 #ifndef PBN_EXP2_DEGREE
 #define PBN_EXP2_DEGREE 7
 #endif
@@ -90,6 +91,32 @@ __device__ __forceinline__ double exp2_f64_top(double x, double top) {
     return __builtin_ldexp(p, n);
 }
 
+// 2^x for the sweep's main loop, 10 instructions instead of 11: the caller keeps its exponents biased by
+// PBN_EXP2_BIAS (folded into the per-query constant, so free), which makes every value that matters non-negative; then
+// v_fract_f64 is the whole range reduction (f = x - floor(x), exact) and the truncating v_cvt_i32_f64 of x itself is
+// floor(x) - no v_rndne / subtract pair.  Degree-7 minimax (relative, Remez: tools/exp2_coeffs.py 7 0 1) on [0, 1):
+// 4.02e-11.  A negative x (a term below 2^-128 of its query's sum, which holds a term >= 2^0) comes out at most 2x too
+// large: invisible (N * 2^-128 relative); x <= -2^31 saturates to INT_MIN and gives 0 like the general form.
+#define PBN_EXP2_BIAS 128.0
+__device__ __forceinline__ double pin_top_fract() {
+    double c;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(0x1.68b07e4ac7b5bp-16));
+    return c;
+}
+__device__ __forceinline__ double exp2_f64_fract(double x, double top) {
+    const double f = __builtin_amdgcn_fract(x);      // v_fract_f64
+    int n;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));  // truncation = floor for x >= 0; saturating
+    double p = __builtin_fma(top, f, 0x1.2cfd657b74f58p-13);
+    p = __builtin_fma(p, f, 0x1.5fddc72ac74dep-10);
+    p = __builtin_fma(p, f, 0x1.3b0838502e0f5p-7);
+    p = __builtin_fma(p, f, 0x1.c6b2b0142cedbp-5);
+    p = __builtin_fma(p, f, 0x1.ebfbcf8c8da34p-3);
+    p = __builtin_fma(p, f, 0x1.62e4301f16f2dp-1);
+    p = __builtin_fma(p, f, 0x1.ffffffffa7934p-1);
+    return __builtin_ldexp(p, n);
+}
+
 template <int DEG>
 __device__ __forceinline__ double exp2_f64(double x) {
     // x <= ~1000 (larger values are caught by the overflow check of the caller), any negative value.
@@ -110,10 +137,12 @@ struct Tr<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ double ex2(double x) { return exp2_f64<PBN_EXP2_DEGREE>(x); }
-    static __device__ __forceinline__ double top() { return PBN_EXP2_DEGREE == 7 ? pin_top() : 0.0; }
+    static __device__ __forceinline__ double top() { return PBN_EXP2_DEGREE == 7 ? pin_top_fract() : 0.0; }
+    // main-loop form: x carries bias() (see exp2_f64_fract)
     static __device__ __forceinline__ double ex2p(double x, double top) {
-        return PBN_EXP2_DEGREE == 7 ? exp2_f64_top(x, top) : exp2_f64<PBN_EXP2_DEGREE>(x);
+        return PBN_EXP2_DEGREE == 7 ? exp2_f64_fract(x, top) : exp2_f64<PBN_EXP2_DEGREE>(x);
     }
+    static __device__ __forceinline__ double bias() { return PBN_EXP2_BIAS; }
     static __device__ __forceinline__ double ex2_hi(double x) { return exp2_f64<8>(x); }
     static __device__ __forceinline__ double big() { return 0x1p900; }
     // C/D row held by (lane group lg, register i): cdna_hip_programming.md §3 "f64 MFMA"
@@ -129,6 +158,7 @@ struct Tr<float> {
     static __device__ __forceinline__ float ex2_hi(float x) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float top() { return 0.0f; }
     static __device__ __forceinline__ float ex2p(float x, float) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ float bias() { return 0.0f; }
     static __device__ __forceinline__ float big() { return 0x1p100f; }
     static __host__ __device__ __forceinline__ int crow(int lg, int i) { return 4 * lg + i; }
 };
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
             T mx = colmax<T>(max4<T>(acc));
             m[g] = mx;
-            cm[g] = ny[g] - mx;
+            cm[g] = ny[g] - mx + Tr<T>::bias();   // main-loop exponents are kept biased (Tr<T>::ex2p)
             if (COND) {
                 V accj = Tr<T>::mfma(ax, bxb[g], acc);
                 T mxj = colmax<T>(max4<T>(accj));
@@ -322,17 +352,17 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             }
             if (__builtin_expect(__any(bad), 0)) {
                 // Rare wave-uniform slow path: raise the offsets to the tile maximum and redo the tile.
-                T mx = colmax<T>(max4<T>(acc));
+                T mx = colmax<T>(max4<T>(acc)) - Tr<T>::bias();
                 if (mx > (T)0) {
                     m[g] += mx;
-                    cm[g] = ny[g] - m[g];
+                    cm[g] = ny[g] - m[g] + Tr<T>::bias();
                     sum[g] *= exp2(-(double)mx);
                     acc -= mx;
                 }
                 e0 = Tr<T>::ex2(acc[0]); e1 = Tr<T>::ex2(acc[1]); e2 = Tr<T>::ex2(acc[2]); e3 = Tr<T>::ex2(acc[3]);
                 ts = (e0 + e1) + (e2 + e3);
                 if (COND) {
-                    T mxj = colmax<T>(max4<T>(accj));
+                    T mxj = colmax<T>(max4<T>(accj)) - Tr<T>::bias();
                     if (mxj > (T)0) {
                         mj[g] += mxj;
                         sumj[g] *= exp2(-(double)mxj);
@@ -376,9 +406,9 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         }
         if (lg == 0 && qt0 + g < a.nqtiles) {
             double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
-            o[0] = (double)m[g];
+            o[0] = (double)m[g] - (double)Tr<T>::bias();   // the sums carry 2^bias
             o[1] = s;
-            if (COND) { o[2] = (double)mj[g]; o[3] = sj; }
+            if (COND) { o[2] = (double)mj[g] - (double)Tr<T>::bias(); o[3] = sj; }
         }
     }
 }

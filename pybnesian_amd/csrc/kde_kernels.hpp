@@ -63,9 +63,12 @@ struct FinishArgs {
 
 // query groups (of 16 rows) per wave: 4, except the fp64 CKDE sweep (two accumulator + exp sets per group)
 // which keeps 2 to hold 3 waves/SIMD
+#ifndef PBN_QG_F64
+#define PBN_QG_F64 4
+#endif
 template <bool F64, bool COND>
 struct SweepQG {
-    static constexpr int value = (F64 && COND) ? 2 : 4;
+    static constexpr int value = (F64 && COND) ? 2 : (F64 ? PBN_QG_F64 : 4);
 };
 int sweep_qg(int dtype, bool cond, int KS);
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)

@@ -45,6 +45,28 @@ struct OpLshlAdd { static __device__ void run(double (&v)[8], double c) { int* f
 #pragma unroll
   for (int i = 0; i < 8; ++i) asm volatile("v_lshl_add_u32 %0, %0, %1, %0" : "+v"(f[i]) : "v"(s)); } };
 
+struct OpFract { static __device__ void run(double (&v)[8], double c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("v_fract_f64 %0, %0" : "+v"(v[i])); } };
+// the two range reductions of the sweep's 2^x, each followed by the same 7 FMAs and the ldexp (11 vs 10 instructions)
+struct OpExp2Rndne { static __device__ void run(double (&v)[8], double c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { double nf, r, p; int n;
+    asm volatile("v_rndne_f64 %0, %1" : "=v"(nf) : "v"(v[i]));
+    asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(v[i]), "v"(nf));
+    asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(p) : "v"(c), "v"(r));
+    for (int k = 0; k < 6; ++k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(p) : "v"(r), "v"(c));
+    asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(nf));
+    asm volatile("v_ldexp_f64 %0, %1, %2" : "=v"(v[i]) : "v"(p), "v"(n)); } } };
+struct OpExp2Fract { static __device__ void run(double (&v)[8], double c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { double r, p; int n;
+    asm volatile("v_fract_f64 %0, %1" : "=v"(r) : "v"(v[i]));
+    asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(v[i]));
+    asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(p) : "v"(c), "v"(r));
+    for (int k = 0; k < 6; ++k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(p) : "v"(r), "v"(c));
+    asm volatile("v_ldexp_f64 %0, %1, %2" : "=v"(v[i]) : "v"(p), "v"(n)); } } };
+
 template <typename Op>
 __global__ __launch_bounds__(256) void k_valu(double* out, double c) {
   double v[8];
@@ -153,7 +175,8 @@ int main() {
 #define V(Op, name) report(name, time_ms([&] { hipLaunchKernelGGL(k_valu<Op>, grid, block, 0, 0, out, 1.0000001); }), (double)ITER * 8)
     V(OpFma, "v_fma_f64"); V(OpAdd, "v_add_f64"); V(OpMul, "v_mul_f64"); V(OpLdexp, "v_ldexp_f64"); V(OpRndne, "v_rndne_f64");
     V(OpCvt, "v_cvt_i32_f64"); V(OpMax, "v_max_f64"); V(OpCmp, "v_cmp_lt_f64"); V(OpFma32, "v_fma_f32"); V(OpExp32, "v_exp_f32");
-    V(OpLshlAdd, "v_lshl_add_u32");
+    V(OpLshlAdd, "v_lshl_add_u32"); V(OpFract, "v_fract_f64");
+    V(OpExp2Rndne, "2^x rndne form: cyc per 2^x"); V(OpExp2Fract, "2^x fract form: cyc per 2^x");
     report("v_mfma_f64_16x16x4", time_ms([&] { hipLaunchKernelGGL(k_mfma64, grid, block, 0, 0, out, 1.0000001); }), (double)ITER * 4);
     report("v_mfma_f32_16x16x4", time_ms([&] { hipLaunchKernelGGL(k_mfma32, grid, block, 0, 0, out, 1.0000001); }), (double)ITER * 4);
     // mixes: cycles per iteration (2 MFMA + NV FMA)
