@@ -402,8 +402,20 @@ class BayesianNetwork:
             if n not in self._index:
                 raise ValueError(f"Node {n} not present in the Bayesian network.")
             self.set_node_type(n, t)
-        for s, t in arcs:
-            self.add_arc(s, t)
+        # the graph constructor (generic_graph.hpp:120-160, 2659-2710): arcs by name, then one acyclicity check
+        for arc in arcs:
+            if not (isinstance(arc, (tuple, list)) and len(arc) == 2 and all(isinstance(x, str) for x in arc)):
+                raise TypeError("BayesianNetwork(): incompatible constructor arguments: arcs must be (source, target) pairs of node names.")
+            for x in arc:
+                if x not in self._index:
+                    raise IndexError(f"Node {x} not present in the graph.")
+            if arc[1] in self._interface:
+                raise ValueError("Interface node cannot have parents.")
+            if arc[0] not in self._parents[arc[1]]:
+                self._parents[arc[1]].append(arc[0])
+                self._children[arc[0]].append(arc[1])
+        if arcs:
+            self.topological_sort()   # raises "Graph must be a DAG to obtain a topological sort."
 
     # -- structure -----------------------------------------------------------------------------------
     def type(self):
@@ -579,29 +591,41 @@ class BayesianNetwork:
             return True
         return not self.has_path(source, target)
 
+    def _check_node(self, node):
+        if node not in self._index:
+            raise ValueError(f"Node {node} not present in the graph.")   # generic_graph.hpp:488-495
+
     def add_arc(self, source, target):
-        if source not in self._index or target not in self._index:
-            raise ValueError("Node not present in the Bayesian network.")
+        """BNGeneric::add_arc (BayesianNetwork.hpp:549-555): allowed when the graph stays acyclic and the network type
+        accepts the arc; adding an arc that is already there changes nothing."""
+        self._check_node(source)
+        self._check_node(target)
         if target in self._interface:
-            raise ValueError(f"Interface node {target} cannot have parents.")
-        if self.has_arc(source, target):
-            return
-        if not self.can_have_arc(source, target):
-            raise ValueError(f"Cannot add arc {source} -> {target}: the Bayesian network type \"{self._type}\" does not allow it.")
+            raise ValueError("Interface node cannot have parents.")       # generic_graph.hpp:952-956
         if not self.can_add_arc(source, target):
-            raise ValueError(f"Cannot add arc {source} -> {target}: it would create a cycle.")
-        self._parents[target].append(source)
-        self._children[source].append(target)
+            raise ValueError(f"Cannot add arc {source} -> {target}.")
+        if not self.has_arc(source, target):
+            self._parents[target].append(source)
+            self._children[source].append(target)
 
     def remove_arc(self, source, target):
+        self._check_node(source)
+        self._check_node(target)
         if self.has_arc(source, target):
             self._parents[target].remove(source)
             self._children[source].remove(target)
 
     def flip_arc(self, source, target):
+        """BNGeneric::flip_arc (BayesianNetwork.hpp:561-567)."""
+        self._check_node(source)
+        self._check_node(target)
+        if not self.can_flip_arc(source, target):
+            raise ValueError(f"Cannot flip arc {source} -> {target}.")
         if self.has_arc(source, target):
-            self.remove_arc(source, target)
-            self.add_arc(target, source)
+            self._parents[target].remove(source)
+            self._children[source].remove(target)
+            self._parents[source].append(target)
+            self._children[target].append(source)
 
     # -- node types -----------------------------------------------------------------------------------
     def node_type(self, node):
