@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     }
     double nv = -0.5 * nrm;
     if (!valid) nv = a.is_query ? 0.0 : PBN_PAD_NORM;
+    if (a.fold_norm && dm < KS * 4) pack[(tile * KS + (dm >> 2)) * 64 + (dm & 3) * 16 + idx] = a.is_query ? (T)1 : (T)nv;
     if (a.is_query) {
         npack[tile * 16 + idx] = (T)nv;
     } else {
@@ -261,7 +262,7 @@ __device__ __forceinline__ T colmax(T v) {  // max over the 4 lanes (lane>>4 = 0
     return v > o ? v : o;
 }
 
-template <typename T, int KS, bool COND, int QG>
+template <typename T, int KS, bool COND, int QG, bool FOLD>
 __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     // ---- query-side fragments and per-query state -------------------------------------------
     T b[QG][KS];
     T ny[QG], cm[QG], m[QG];
+    V cmv[QG];  // FOLD: the accumulator's start value, cm in all four rows (the training norms ride in a K slot)
     double sum[QG];
     T bxb[QG], bx[QG], mj[QG];  // CKDE: extra-step B fragment (base / current), joint offset
     double sumj[QG];
@@ -305,16 +307,17 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         T ax = 0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t0 * KS + ks) * 64 + lane];
-        nx = *(const V*)(Np + t0 * 16 + lg * 4);
+        if (!FOLD) nx = *(const V*)(Np + t0 * 16 + lg * 4);
         if (COND) ax = Xp[t0 * 64 + lane];
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-            V acc = nx + ny[g];
+            V acc = FOLD ? V{ny[g], ny[g], ny[g], ny[g]} : nx + ny[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
             T mx = colmax<T>(max4<T>(acc));
             m[g] = mx;
             cm[g] = ny[g] - mx + Tr<T>::bias();   // main-loop exponents are kept biased (Tr<T>::ex2p)
+            if (FOLD) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
             if (COND) {
                 V accj = Tr<T>::mfma(ax, bxb[g], acc);
                 T mxj = colmax<T>(max4<T>(accj));
@@ -329,13 +332,14 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     auto load_tile = [&](int64_t t, T (&f)[KS], V& n, T& x) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) f[ks] = Ap[(t * KS + ks) * 64 + lane];
-        n = *(const V*)(Np + t * 16 + lg * 4);
+        if (!FOLD) n = *(const V*)(Np + t * 16 + lg * 4);
         if (COND) x = Xp[t * 64 + lane];
     };
     auto process_tile = [&](const T (&af)[KS], const V& nx, const T ax) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-            V acc = nx + cm[g];
+            V acc;
+            if (FOLD) acc = cmv[g]; else acc = nx + cm[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
             V accj;
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
                 if (mx > (T)0) {
                     m[g] += mx;
                     cm[g] = ny[g] - m[g] + Tr<T>::bias();
+                    if (FOLD) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
                     sum[g] *= exp2(-(double)mx);
                     acc -= mx;
                 }
@@ -1110,18 +1115,31 @@ void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
-template <typename T, bool COND>
-static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
+template <typename T, bool COND, bool FOLD>
+static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
     constexpr int QG = SweepQG<sizeof(T) == 8, COND>::value;
     dim3 block(256);
     switch (KS) {
-        case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG, FOLD>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG, FOLD>), grid, block, 0, st, a); break;
         default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
     }
     HIP_CHECK(hipGetLastError());
+}
+template <typename T, bool COND>
+static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
+    if (a.fold) launch_sweep_tf<T, COND, true>(a, KS, grid, st); else launch_sweep_tf<T, COND, false>(a, KS, grid, st);
+}
+
+bool sweep_folds_norm(int dtype, bool cond, int KS, int dm) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PBN_SWEEP_FOLD");
+        v = (e && *e) ? atoi(e) : 1;
+    }
+    return v != 0 && !use_bf16x3(dtype) && !use_sparse(dtype, cond, KS) && dm % 4 != 0;
 }
 
 bool use_sparse(int dtype, bool cond, int KS) {

@@ -16,6 +16,10 @@ struct PackArgs {
     int dm;               // main (marginal) dimensions written to `pack`; d == dm or dm + 1
     int KS;               // ceil(dm / 4)
     int is_query;
+    // classic (non-bf16) pack, dm % 4 != 0: the first unused K slot of the last MFMA carries the norm - training side
+    // -1/2|z|^2, query side 1 - so the sweep's accumulator starts from a per-query constant (no add per value).  A
+    // query pack that leaves the slot 0 (CKDE::cdf, UCV) makes the training side's entry inert.
+    int fold_norm;
     // source rows: logical row r maps to  r < n0 ? row0 + r : row1 + (r - n0)   (two contiguous ranges:
     // a CV training set is "everything before the fold" ++ "everything after it"), or rows[r] if non-null
     int64_t row0, n0, row1;
@@ -44,6 +48,7 @@ struct SweepArgs {
     int64_t ntiles;
     int64_t nqtiles;
     int64_t tiles_per_split;
+    int fold;      // the packs carry the training norms in a free K slot (PackArgs::fold_norm)
     double* part;  // [nsplit][nqtiles*16][P]
     double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
     int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
@@ -71,6 +76,8 @@ struct SweepQG {
     static constexpr int value = (F64 && COND) ? 2 : (F64 ? PBN_QG_F64 : 4);
 };
 int sweep_qg(int dtype, bool cond, int KS);
+bool use_sparse(int dtype, bool cond, int KS);
+bool sweep_folds_norm(int dtype, bool cond, int KS, int dm);   // see PackArgs::fold_norm
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 

@@ -140,6 +140,7 @@ void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const i
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
+    pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
     launch_pack(pa, m.dtype, ctx->stream);
@@ -177,6 +178,8 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles;
     pa.is_query = 1;
+    const bool fold = sweep_folds_norm(m.dtype, m.cond, m.KS, m.dm);
+    pa.fold_norm = fold ? 1 : 0;
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
     pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
@@ -195,6 +198,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.Apack = m.Apack; sa.nxpack = m.nxpack; sa.Axpack = m.Axpack;
     sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack; sa.Bxnorm = pa.xnorm;
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
+    sa.fold = fold ? 1 : 0;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
