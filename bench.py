@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 D = 8
 FLOPS_PER_PAIR = 3 * D + 2          # d sub + d fma(2) + exp(1) + add(1)
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector == matrix peak (AMD CDNA4 spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+FP32_PEAK_TFLOPS = 157.3            # MI355X FP32 vector == f32-matrix peak (MI355X_MICROARCH.md); the --dtype f32 run is priced against it
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -377,6 +378,7 @@ def main():
         sweep_s = sweep_ms / max(sweep_n, 1) * 1e-3
         alg_bytes = (args.n_train * D + args.n_test * D + args.n_test) * es
         achieved_tf = pairs * FLOPS_PER_PAIR / sweep_s / 1e12
+        peak_tf = FP64_PEAK_TFLOPS if args.dtype == "f64" else FP32_PEAK_TFLOPS
         out = {
             "metric": "KDE slogl M-samples/s",
             "value": value,
@@ -398,15 +400,18 @@ def main():
                 "slogl_step0_rank_sum": slogl,
             },
             "roofline": {
-                "kernel": "kde_sweep_kernel",
+                "kernel": "kde_sweep_kernel" if args.dtype == "f64" else "kde_sweep_bf16_kernel",
                 "bound": "mfma",
                 "achieved": achieved_tf,
-                "peak": FP64_PEAK_TFLOPS,
+                "peak": peak_tf,
                 "unit": "TFLOP/s",
-                "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                "frac": achieved_tf / peak_tf,
                 "traffic": pmc_traffic(args),
                 "note": "compute-bound sweep (SURVEY.md §8d): algorithmic flops = (3d+2) per train/test pair (exp counted as 1) "
-                        "against the FP64 vector==matrix peak; sweep launch duration from HIP events on the library stream",
+                        + ("against the FP64 vector==matrix peak" if args.dtype == "f64" else
+                           "against the FP32 vector peak (the fp32 sweep's distances run as bf16x3 on the bf16 matrix cores, its "
+                           "2^x and sums on the f32 VALU, which is the binding unit)")
+                        + "; sweep launch duration from HIP events on the library stream",
                 "avg_launch_ms": sweep_s * 1e3,
                 "gpairs_per_s": pairs / sweep_s / 1e9,
                 "hbm_algorithmic_bytes": alg_bytes,
