@@ -11,7 +11,10 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.hpp"
 #include "hostmath.hpp"
@@ -21,6 +24,24 @@ using namespace pbn;
 
 #define MI_MAX_CONT 24
 #define MI_MAX_DISC 16
+#define MI_SORTED_MAX_CONT 6      // continuous variables the register-accumulator kernel is instantiated for
+#define MI_SORTED_ROWS 4096       // rows of one configuration a 256-thread block sums
+#define MI_GROUP_CACHE 1024       // cached row groupings (one per set of discrete variables), least recently used out
+
+// Rows grouped by the configuration of one set of discrete variables (sorted ids, first id fastest): `perm` lists the
+// rows configuration by configuration, ascending inside a configuration (stable radix sort), `off` are the segment
+// bounds = the counts, `blk` cuts every segment into pieces of at most MI_SORTED_ROWS rows.  Built once per set and
+// reused by every test over it; the set of no variables is the identity (perm empty).
+struct DiscGroup {
+    std::vector<int> vars;
+    int G = 1;
+    dev_buf<int32_t> perm;          // [N]
+    std::vector<int64_t> off;       // [G + 1]
+    dev_buf<int32_t> blk;           // [nblk][4]: configuration, first position, end position, unused
+    std::vector<int> blk_off;       // [G + 1] first block of every configuration
+    int nblk = 0;
+    uint64_t stamp = 0;
+};
 
 struct pbn_mi {
     pbn_ctx* ctx = nullptr;
@@ -33,6 +54,13 @@ struct pbn_mi {
     std::vector<double> shift;                // pilot mean of every continuous column
     int64_t device_passes = 0, host_passes = 0, device_launches = 0;
     std::vector<int> order;  // external index -> variable id for the callback form (empty = identity)
+    std::map<std::vector<int>, std::unique_ptr<DiscGroup>> groups;
+    uint64_t clock = 0;
+    int64_t groups_built = 0, count_only = 0;
+    dev_buf<int32_t> iota;       // [N] 0..N-1, the values the radix sort permutes
+    dev_buf<uint32_t> keys[2];   // [N] configuration ids, unsorted / sorted
+    dev_buf<int32_t> first;      // [G] first sorted position of every configuration
+    dev_buf<char> sort_tmp;
 };
 
 namespace {
@@ -130,6 +158,96 @@ __global__ __launch_bounds__(64) void group_reduce_kernel(const GroupArgs* __res
     for (int b = threadIdx.x; b < nblocks; b += 64) s += a.partial[(size_t)b * total + i];
     s = wave_sum(s);
     if (threadIdx.x == 0) a.out[i] = s;
+}
+
+
+// ---- sorted-segment path ------------------------------------------------------------------------------------------
+// With the rows grouped by configuration (DiscGroup) a block only ever sees ONE configuration: every lane adds its rows
+// into registers (no LDS cells, no atomics, all 256 lanes busy), a fixed butterfly + wave order gives the block's
+// partial, and a second kernel adds a configuration's partials in block order.  Deterministic, and the work per test no
+// longer depends on the number of configurations.
+struct SortedArgs {
+    const void* base;
+    int64_t ld;
+    int cols[MI_SORTED_MAX_CONT];
+    double shift[MI_SORTED_MAX_CONT];
+    const int32_t* perm;     // null: identity
+    const int32_t* blk;      // [nblk][4]
+    const int32_t* blk_off;  // device copy, [G + 1]
+    int nblk, G;
+    double* partial;         // [nblk][S]
+    double* out;             // [G][S]
+};
+
+struct KeyArgs {
+    int m;
+    int dvar[MI_MAX_DISC], stride[MI_MAX_DISC];
+};
+__global__ __launch_bounds__(256) void config_keys_kernel(const int32_t* __restrict__ codes, int64_t n, KeyArgs k, uint32_t* __restrict__ keys) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    uint32_t g = 0;
+    for (int j = 0; j < k.m; ++j) g += (uint32_t)codes[(int64_t)k.dvar[j] * n + r] * (uint32_t)k.stride[j];
+    keys[r] = g;
+}
+__global__ __launch_bounds__(256) void iota_kernel(int32_t* v, int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < n) v[r] = (int32_t)r;
+}
+__global__ __launch_bounds__(256) void segment_first_kernel(const uint32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ first) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t k = keys[r];
+    if (r == 0 || keys[r - 1] != k) first[k] = (int32_t)r;
+}
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void moments_sorted_kernel(const SortedArgs* __restrict__ descs) {
+    constexpr int S = C + C * (C + 1) / 2;   // sums, upper-triangle products (the count is the segment length)
+    __shared__ double red[4][S];
+    const SortedArgs& a = descs[blockIdx.y];
+    if ((int)blockIdx.x >= a.nblk) return;
+    const int r0 = a.blk[4 * blockIdx.x + 1], r1 = a.blk[4 * blockIdx.x + 2];
+    double acc[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) acc[i] = 0.0;
+    const T* col[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) col[i] = (const T*)a.base + (int64_t)a.cols[i] * a.ld;
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
+        const int64_t row = a.perm ? a.perm[r] : r;
+        double x[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) x[i] = (double)col[i][row] - a.shift[i];
+        int pos = C;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            acc[i] += x[i];
+#pragma unroll
+            for (int j = i; j < C; ++j) { acc[pos] = __builtin_fma(x[i], x[j], acc[pos]); ++pos; }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const double v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < S) a.partial[(size_t)blockIdx.x * S + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// one wave per (configuration, statistic): lanes stride over the configuration's blocks, fixed butterfly
+__global__ __launch_bounds__(64) void sorted_reduce_kernel(const SortedArgs* __restrict__ descs, int S) {
+    const SortedArgs& a = descs[blockIdx.y];
+    const int cell = blockIdx.x;
+    if (cell >= a.G * S) return;
+    const int g = cell / S, st = cell - g * S;
+    const int b0 = a.blk_off[g], b1 = a.blk_off[g + 1];
+    double v = 0.0;
+    for (int b = b0 + (int)threadIdx.x; b < b1; b += 64) v += a.partial[(size_t)b * S + st];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) a.out[cell] = v;
 }
 
 // ---- regularised upper incomplete gamma Q(a, x): chi-square survival function (boost chi_squared complement) --------
@@ -306,7 +424,7 @@ struct Engine {
     // statistics of a list of plans: launch rows bounded by scratch memory.  A test with more configurations than fit
     // the LDS accumulators is covered by several rows, each accumulating one window of configurations (rows of other
     // windows are skipped), stitched back together here - still device only.
-    void group_stats_many(const std::vector<Plan>& plans, std::vector<std::vector<double>>& outs) {
+    void group_stats_legacy(const std::vector<Plan>& plans, std::vector<std::vector<double>>& outs) {
         outs.assign(plans.size(), {});
         if (h->N <= 0) { for (size_t t = 0; t < plans.size(); ++t) outs[t].assign((size_t)plans[t].G * plans[t].stats, 0.0); return; }
         const int64_t chunks = ceil_div(h->N, 64);
@@ -343,6 +461,193 @@ struct Engine {
             cur.push_back(&rows[r]); cur_idx.push_back(r); cur_doubles += need;
         }
         flush();
+    }
+
+    // ---- sorted-segment path (DiscGroup) ---------------------------------------------------------------------------
+    DiscGroup& group_for(const std::vector<int>& vars) {   // vars: sorted discrete variable ids
+        auto it = h->groups.find(vars);
+        if (it != h->groups.end()) { it->second->stamp = ++h->clock; return *it->second; }
+        pbn_ctx* ctx = h->ctx;
+        const int64_t N = h->N;
+        auto g = std::make_unique<DiscGroup>();
+        g->vars = vars;
+        int64_t G64 = 1;
+        for (int v : vars) G64 *= card(v);
+        g->G = (int)G64;
+        g->off.assign((size_t)g->G + 1, 0);
+        g->off[g->G] = N;
+        if (!vars.empty()) {
+            KeyArgs ka{};
+            ka.m = (int)vars.size();
+            int stride = 1;
+            for (int j = 0; j < ka.m; ++j) { ka.dvar[j] = vars[j] - h->n_cont; ka.stride[j] = stride; stride *= card(vars[j]); }
+            const unsigned nb = (unsigned)ceil_div(N, 256);
+            if (h->iota.n < (size_t)N) {
+                h->iota.alloc((size_t)N);
+                hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->iota.p, N);
+                h->keys[0].alloc((size_t)N); h->keys[1].alloc((size_t)N);
+            }
+            hipLaunchKernelGGL(config_keys_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)h->codes_dev.p, N, ka, h->keys[0].p);
+            g->perm.alloc((size_t)N);
+            int bits = 1;
+            while ((1ll << bits) < G64) ++bits;
+            size_t tmp = 0;
+            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, h->keys[0].p, h->keys[1].p, h->iota.p, g->perm.p, (size_t)N, 0, bits, ctx->stream));
+            h->sort_tmp.reserve(tmp);
+            HIP_CHECK(rocprim::radix_sort_pairs((void*)h->sort_tmp.p, tmp, h->keys[0].p, h->keys[1].p, h->iota.p, g->perm.p, (size_t)N, 0, bits, ctx->stream));
+            h->first.reserve((size_t)g->G);
+            HIP_CHECK(hipMemsetAsync(h->first.p, 0xFF, (size_t)g->G * sizeof(int32_t), ctx->stream));
+            hipLaunchKernelGGL(segment_first_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t*)h->keys[1].p, N, h->first.p);
+            HIP_CHECK(hipGetLastError());
+            std::vector<int32_t> first((size_t)g->G);
+            HIP_CHECK(hipMemcpyAsync(first.data(), h->first.p, first.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (int c = g->G - 1; c >= 0; --c) g->off[c] = first[c] >= 0 ? first[c] : g->off[c + 1];
+        }
+        std::vector<int32_t> blk;
+        g->blk_off.assign((size_t)g->G + 1, 0);
+        for (int c = 0; c < g->G; ++c) {
+            g->blk_off[c] = (int)(blk.size() / 4);
+            for (int64_t r = g->off[c]; r < g->off[c + 1]; r += MI_SORTED_ROWS) {
+                blk.push_back(c); blk.push_back((int32_t)r); blk.push_back((int32_t)std::min<int64_t>(r + MI_SORTED_ROWS, g->off[c + 1])); blk.push_back(0);
+            }
+        }
+        g->nblk = (int)(blk.size() / 4);
+        g->blk_off[g->G] = g->nblk;
+        blk.insert(blk.end(), g->blk_off.begin(), g->blk_off.end());   // device copy of blk_off behind the block table
+        g->blk.alloc(blk.size());
+        HIP_CHECK(hipMemcpyAsync(g->blk.p, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        g->stamp = ++h->clock;
+        ++h->groups_built;
+        DiscGroup& ref = *g;
+        h->groups.emplace(vars, std::move(g));
+        return ref;
+    }
+
+    template <int C>
+    void launch_sorted(bool f64, int max_nblk, int B, const SortedArgs* d) {
+        if (f64) hipLaunchKernelGGL((moments_sorted_kernel<double, C>), dim3(max_nblk, B), dim3(256), 0, h->ctx->stream, d);
+        else hipLaunchKernelGGL((moments_sorted_kernel<float, C>), dim3(max_nblk, B), dim3(256), 0, h->ctx->stream, d);
+    }
+
+    // one launch pair for tests with the same number of continuous variables; `items` = (plan index, its group)
+    void sorted_batch(int c, const std::vector<Plan>& plans, const std::vector<std::pair<size_t, DiscGroup*>>& items,
+                      const std::vector<std::vector<int>>& cmap, std::vector<std::vector<double>>& outs) {
+        pbn_ctx* ctx = h->ctx;
+        const int S = c + c * (c + 1) / 2, B = (int)items.size();
+        std::vector<SortedArgs> descs(B);
+        size_t part = 0, outd = 0;
+        int max_nblk = 1, max_cells = 1;
+        for (int i = 0; i < B; ++i) {
+            const DiscGroup& g = *items[i].second;
+            part += (size_t)g.nblk * S; outd += (size_t)g.G * S;
+            max_nblk = std::max(max_nblk, g.nblk); max_cells = std::max(max_cells, g.G * S);
+        }
+        const size_t desc_bytes = ((size_t)B * sizeof(SortedArgs) + 255) / 256 * 256;
+        ctx->scratch_part.reserve(desc_bytes + (part + outd) * sizeof(double));
+        char* base = ctx->scratch_part.p;
+        double* dpart = (double*)(base + desc_bytes);
+        double* dout = dpart + part;
+        size_t po = 0, oo = 0;
+        for (int i = 0; i < B; ++i) {
+            const Plan& p = plans[items[i].first];
+            const DiscGroup& g = *items[i].second;
+            SortedArgs& a = descs[i];
+            a = SortedArgs{};
+            a.base = h->table->data; a.ld = h->table->ld;
+            for (int k = 0; k < c; ++k) { a.cols[k] = p.cont[k]; a.shift[k] = h->shift[p.cont[k]]; }
+            a.perm = g.vars.empty() ? nullptr : g.perm.p;
+            a.blk = g.blk.p; a.blk_off = g.blk.p + 4 * (size_t)g.nblk;
+            a.nblk = g.nblk; a.G = g.G;
+            a.partial = dpart + po; a.out = dout + oo;
+            po += (size_t)g.nblk * S; oo += (size_t)g.G * S;
+        }
+        HIP_CHECK(hipMemcpyAsync(base, descs.data(), (size_t)B * sizeof(SortedArgs), hipMemcpyHostToDevice, ctx->stream));
+        const bool f64 = h->table->dtype == PBN_F64;
+        const SortedArgs* d = (const SortedArgs*)base;
+        switch (c) {
+            case 1: launch_sorted<1>(f64, max_nblk, B, d); break;
+            case 2: launch_sorted<2>(f64, max_nblk, B, d); break;
+            case 3: launch_sorted<3>(f64, max_nblk, B, d); break;
+            case 4: launch_sorted<4>(f64, max_nblk, B, d); break;
+            case 5: launch_sorted<5>(f64, max_nblk, B, d); break;
+            default: launch_sorted<6>(f64, max_nblk, B, d); break;
+        }
+        hipLaunchKernelGGL(sorted_reduce_kernel, dim3(max_cells, B), dim3(64), 0, ctx->stream, d, S);
+        HIP_CHECK(hipGetLastError());
+        std::vector<double> all(outd);
+        HIP_CHECK(hipMemcpyAsync(all.data(), dout, outd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        oo = 0;
+        for (int i = 0; i < B; ++i) {
+            const size_t t = items[i].first;
+            const DiscGroup& g = *items[i].second;
+            const int stats = plans[t].stats;
+            for (int cg = 0; cg < g.G; ++cg) {
+                double* dst = outs[t].data() + (size_t)cmap[t][cg] * stats + 1;
+                const double* src = all.data() + oo + (size_t)cg * S;
+                for (int k = 0; k < S; ++k) dst[k] = src[k];
+            }
+            oo += (size_t)g.G * S;
+        }
+        ++h->device_launches;
+    }
+
+    // Per-configuration statistics of a list of tests.  The counts are the segment lengths of the test's DiscGroup (no
+    // data pass at all for a purely discrete test); the continuous moments come from the sorted-segment kernels, batched
+    // by the number of continuous variables.  More than MI_SORTED_MAX_CONT continuous variables: the LDS-cell kernel.
+    void group_stats_many(const std::vector<Plan>& plans, std::vector<std::vector<double>>& outs) {
+        outs.assign(plans.size(), {});
+        if (h->N <= 0) { for (size_t t = 0; t < plans.size(); ++t) outs[t].assign((size_t)plans[t].G * plans[t].stats, 0.0); return; }
+        while (h->groups.size() > MI_GROUP_CACHE) {   // least recently used out (never during a batch: groups are referenced below)
+            auto lru = h->groups.begin();
+            for (auto it = h->groups.begin(); it != h->groups.end(); ++it)
+                if (it->second->stamp < lru->second->stamp) lru = it;
+            h->groups.erase(lru);
+        }
+        std::vector<Plan> legacy;
+        std::vector<size_t> legacy_idx;
+        std::vector<std::vector<int>> cmap(plans.size());
+        std::vector<std::vector<std::pair<size_t, DiscGroup*>>> by_c(MI_SORTED_MAX_CONT + 1);
+        for (size_t t = 0; t < plans.size(); ++t) {
+            const Plan& p = plans[t];
+            if (p.c > MI_SORTED_MAX_CONT || p.G > (1 << 22)) { legacy.push_back(p); legacy_idx.push_back(t); continue; }
+            std::vector<int> vars = p.disc;
+            std::sort(vars.begin(), vars.end());
+            DiscGroup& g = group_for(vars);
+            outs[t].assign((size_t)p.G * p.stats, 0.0);
+            // canonical configuration id (sorted variables, first fastest) -> the test's own (x, y, z order)
+            std::vector<int>& map = cmap[t];
+            map.resize((size_t)g.G);
+            const int m = (int)vars.size();
+            std::vector<int> tstride(m), cards(m);
+            for (int j = 0; j < m; ++j) {
+                cards[j] = card(vars[j]);
+                int stride = 1;
+                for (int v : p.disc) { if (v == vars[j]) break; stride *= card(v); }
+                tstride[j] = stride;
+            }
+            for (int cg = 0; cg < g.G; ++cg) {
+                int rem = cg, gt = 0;
+                for (int j = 0; j < m; ++j) { gt += (rem % cards[j]) * tstride[j]; rem /= cards[j]; }
+                map[cg] = gt;
+                outs[t][(size_t)gt * p.stats] = (double)(g.off[cg + 1] - g.off[cg]);
+            }
+            if (p.c == 0) { ++h->count_only; continue; }
+            by_c[p.c].push_back({t, &g});
+        }
+        for (int c = 1; c <= MI_SORTED_MAX_CONT; ++c)
+            for (size_t i = 0; i < by_c[c].size(); i += 256) {
+                std::vector<std::pair<size_t, DiscGroup*>> items(by_c[c].begin() + i, by_c[c].begin() + std::min(by_c[c].size(), i + 256));
+                sorted_batch(c, plans, items, cmap, outs);
+            }
+        h->device_passes += (int64_t)(plans.size() - legacy.size());
+        if (!legacy.empty()) {
+            std::vector<std::vector<double>> lo;
+            group_stats_legacy(legacy, lo);
+            for (size_t i = 0; i < legacy.size(); ++i) outs[legacy_idx[i]].swap(lo[i]);
+        }
     }
 
     void group_stats(const std::vector<int>& cont, const std::vector<int>& disc, int G, std::vector<double>& out) {

@@ -72,20 +72,42 @@ def test_mi_all_overloads(pbn, n, dtype):
         test.pvalue("c1", "zz")
 
 
-def test_mi_many_configurations_windows(pbn):
-    """More discrete configurations x statistics than the LDS accumulators hold: the test is covered by several launch
-    rows, each accumulating one window of configurations - still on the device, same numbers."""
+def test_mi_many_configurations(pbn):
+    """1024 configurations x 21 statistics.  With up to six continuous variables the rows are grouped by configuration
+    once and every block sums one configuration in registers (one device pass); with more, the LDS-cell kernel covers
+    the configurations in several windows - both on the device, same numbers as the restatement."""
     rng = np.random.default_rng(3)
     n = 30000
-    df = pd.DataFrame({f"c{i}": rng.normal(size=n) for i in range(5)})
+    df = pd.DataFrame({f"c{i}": rng.normal(size=n) for i in range(9)})
     for j in range(6):
         df[f"d{j}"] = pd.Categorical.from_codes(rng.integers(0, 4, size=n), [f"k{i}" for i in range(4)])
     df["c1"] = df["c1"] + 0.5 * df["c0"] + 0.3 * df["d0"].cat.codes
     test, orc = pbn.MutualInformation(df), make_oracle(df)
-    z = ["d1", "d2", "d3", "d4", "c2", "c3", "c4"]           # 4^5 configurations with d0 -> 1024 x 21 statistics
+    z = ["d1", "d2", "d3", "d4", "c2", "c3", "c4"]
     assert test.mi("d0", "c1", z) == pytest.approx(orc.mi("d0", "c1", z), rel=1e-8)
+    assert test.mi("c1", "d0", z[::-1]) == pytest.approx(orc.mi("c1", "d0", z[::-1]), rel=1e-8)   # another variable order, same grouping
     dev, host = test.passes()
-    assert host == 0 and dev >= 3
+    assert host == 0 and dev == 2
+    z = ["d1", "d2", "d3", "c2", "c3", "c4", "c5", "c6", "c7"]   # 8 continuous variables: 256 x 45 statistics, windowed
+    assert test.mi("d0", "c1", z) == pytest.approx(orc.mi("d0", "c1", z), rel=1e-8)
+    dev2, host = test.passes()
+    assert host == 0 and dev2 >= dev + 2
+
+
+def test_mi_grouping_cache_and_count_only_tests(pbn):
+    """Tests over the same set of discrete variables share one row grouping; a purely discrete test reads its counts off
+    the grouping (ChiSquare and discrete-discrete MutualInformation make no data pass of their own)."""
+    df = hybrid_table(20000, 5)
+    test, orc = pbn.MutualInformation(df), make_oracle(df)
+    chi = pbn.ChiSquare(df)
+    for x, y, z in (("d1", "d2", ["d3"]), ("d2", "d1", ["d3"]), ("d3", "d1", ["d2"]), ("d1", "d2", [])):
+        assert test.mi(x, y, z) == pytest.approx(orc.mi(x, y, z), rel=1e-9, abs=1e-12)
+    from scipy.stats import chi2_contingency
+
+    tab = pd.crosstab(df["d1"], df["d2"]).to_numpy()
+    assert chi.pvalue("d1", "d2") == pytest.approx(chi2_contingency(tab, correction=False)[1], rel=1e-9, abs=1e-300)
+    for x, y, z in (("c1", "d2", ["d1"]), ("c2", "c1", ["d1", "d2"]), ("d1", "c2", ["d2", "c1"]), ("c3", "c4", ["c1"])):
+        assert test.mi(x, y, z) == pytest.approx(orc.mi(x, y, z), rel=1e-9, abs=1e-12)
 
 
 def test_mmhc_hybrid(pbn):
