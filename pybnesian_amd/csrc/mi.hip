@@ -11,6 +11,9 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 
@@ -24,7 +27,7 @@ using namespace pbn;
 
 #define MI_MAX_CONT 24
 #define MI_MAX_DISC 16
-#define MI_SORTED_MAX_CONT 6      // continuous variables the register-accumulator kernel is instantiated for
+#define MI_SORTED_MAX_CONT 16     // continuous variables the register-accumulator kernel is instantiated for (152 accumulators)
 #define MI_SORTED_ROWS 4096       // rows of one configuration a 256-thread block sums
 #define MI_GROUP_CACHE 1024       // cached row groupings (one per set of discrete variables), least recently used out
 
@@ -41,6 +44,8 @@ struct DiscGroup {
     std::vector<int> blk_off;       // [G + 1] first block of every configuration
     int nblk = 0;
     uint64_t stamp = 0;
+    // configuration id in this grouping's order -> id in a test's own (x, y, z...) order, per variable order seen
+    std::map<std::vector<int>, std::vector<int>> order_maps;
 };
 
 struct pbn_mi {
@@ -61,7 +66,12 @@ struct pbn_mi {
     dev_buf<uint32_t> keys[2];   // [N] configuration ids, unsorted / sorted
     dev_buf<int32_t> first;      // [G] first sorted position of every configuration
     dev_buf<char> sort_tmp;
+    // PBN_MI_TIMING=1: wall seconds per phase, printed when the handle is destroyed
+    double t_group = 0, t_device = 0, t_host = 0, t_prep = 0;
+    int64_t batches = 0;
 };
+
+static inline double mi_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 namespace {
 
@@ -469,6 +479,7 @@ struct Engine {
         if (it != h->groups.end()) { it->second->stamp = ++h->clock; return *it->second; }
         pbn_ctx* ctx = h->ctx;
         const int64_t N = h->N;
+        const double tg0 = mi_now();
         auto g = std::make_unique<DiscGroup>();
         g->vars = vars;
         int64_t G64 = 1;
@@ -520,6 +531,7 @@ struct Engine {
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         g->stamp = ++h->clock;
         ++h->groups_built;
+        h->t_group += mi_now() - tg0;
         DiscGroup& ref = *g;
         h->groups.emplace(vars, std::move(g));
         return ref;
@@ -533,8 +545,9 @@ struct Engine {
 
     // one launch pair for tests with the same number of continuous variables; `items` = (plan index, its group)
     void sorted_batch(int c, const std::vector<Plan>& plans, const std::vector<std::pair<size_t, DiscGroup*>>& items,
-                      const std::vector<std::vector<int>>& cmap, std::vector<std::vector<double>>& outs) {
+                      const std::vector<const std::vector<int>*>& cmap, std::vector<std::vector<double>>& outs) {
         pbn_ctx* ctx = h->ctx;
+        const double td0 = mi_now();
         const int S = c + c * (c + 1) / 2, B = (int)items.size();
         std::vector<SortedArgs> descs(B);
         size_t part = 0, outd = 0;
@@ -567,12 +580,11 @@ struct Engine {
         const bool f64 = h->table->dtype == PBN_F64;
         const SortedArgs* d = (const SortedArgs*)base;
         switch (c) {
-            case 1: launch_sorted<1>(f64, max_nblk, B, d); break;
-            case 2: launch_sorted<2>(f64, max_nblk, B, d); break;
-            case 3: launch_sorted<3>(f64, max_nblk, B, d); break;
-            case 4: launch_sorted<4>(f64, max_nblk, B, d); break;
-            case 5: launch_sorted<5>(f64, max_nblk, B, d); break;
-            default: launch_sorted<6>(f64, max_nblk, B, d); break;
+#define PBN_MI_CASE(C) case C: launch_sorted<C>(f64, max_nblk, B, d); break;
+            PBN_MI_CASE(1) PBN_MI_CASE(2) PBN_MI_CASE(3) PBN_MI_CASE(4) PBN_MI_CASE(5) PBN_MI_CASE(6) PBN_MI_CASE(7) PBN_MI_CASE(8)
+            PBN_MI_CASE(9) PBN_MI_CASE(10) PBN_MI_CASE(11) PBN_MI_CASE(12) PBN_MI_CASE(13) PBN_MI_CASE(14) PBN_MI_CASE(15)
+            default: launch_sorted<16>(f64, max_nblk, B, d); break;
+#undef PBN_MI_CASE
         }
         hipLaunchKernelGGL(sorted_reduce_kernel, dim3(max_cells, B), dim3(64), 0, ctx->stream, d, S);
         HIP_CHECK(hipGetLastError());
@@ -585,13 +597,14 @@ struct Engine {
             const DiscGroup& g = *items[i].second;
             const int stats = plans[t].stats;
             for (int cg = 0; cg < g.G; ++cg) {
-                double* dst = outs[t].data() + (size_t)cmap[t][cg] * stats + 1;
+                double* dst = outs[t].data() + (size_t)(*cmap[t])[cg] * stats + 1;
                 const double* src = all.data() + oo + (size_t)cg * S;
                 for (int k = 0; k < S; ++k) dst[k] = src[k];
             }
             oo += (size_t)g.G * S;
         }
         ++h->device_launches;
+        h->t_device += mi_now() - td0;
     }
 
     // Per-configuration statistics of a list of tests.  The counts are the segment lengths of the test's DiscGroup (no
@@ -608,7 +621,7 @@ struct Engine {
         }
         std::vector<Plan> legacy;
         std::vector<size_t> legacy_idx;
-        std::vector<std::vector<int>> cmap(plans.size());
+        std::vector<const std::vector<int>*> cmap(plans.size(), nullptr);
         std::vector<std::vector<std::pair<size_t, DiscGroup*>>> by_c(MI_SORTED_MAX_CONT + 1);
         for (size_t t = 0; t < plans.size(); ++t) {
             const Plan& p = plans[t];
@@ -618,22 +631,27 @@ struct Engine {
             DiscGroup& g = group_for(vars);
             outs[t].assign((size_t)p.G * p.stats, 0.0);
             // canonical configuration id (sorted variables, first fastest) -> the test's own (x, y, z order)
-            std::vector<int>& map = cmap[t];
-            map.resize((size_t)g.G);
-            const int m = (int)vars.size();
-            std::vector<int> tstride(m), cards(m);
-            for (int j = 0; j < m; ++j) {
-                cards[j] = card(vars[j]);
-                int stride = 1;
-                for (int v : p.disc) { if (v == vars[j]) break; stride *= card(v); }
-                tstride[j] = stride;
+            auto om = g.order_maps.find(p.disc);
+            if (om == g.order_maps.end()) {
+                std::vector<int> map((size_t)g.G);
+                const int m = (int)vars.size();
+                std::vector<int> tstride(m), cards(m);
+                for (int j = 0; j < m; ++j) {
+                    cards[j] = card(vars[j]);
+                    int stride = 1;
+                    for (int v : p.disc) { if (v == vars[j]) break; stride *= card(v); }
+                    tstride[j] = stride;
+                }
+                for (int cg = 0; cg < g.G; ++cg) {
+                    int rem = cg, gt = 0;
+                    for (int j = 0; j < m; ++j) { gt += (rem % cards[j]) * tstride[j]; rem /= cards[j]; }
+                    map[cg] = gt;
+                }
+                om = g.order_maps.emplace(p.disc, std::move(map)).first;
             }
-            for (int cg = 0; cg < g.G; ++cg) {
-                int rem = cg, gt = 0;
-                for (int j = 0; j < m; ++j) { gt += (rem % cards[j]) * tstride[j]; rem /= cards[j]; }
-                map[cg] = gt;
-                outs[t][(size_t)gt * p.stats] = (double)(g.off[cg + 1] - g.off[cg]);
-            }
+            cmap[t] = &om->second;
+            const std::vector<int>& map = om->second;
+            for (int cg = 0; cg < g.G; ++cg) outs[t][(size_t)map[cg] * p.stats] = (double)(g.off[cg + 1] - g.off[cg]);
             if (p.c == 0) { ++h->count_only; continue; }
             by_c[p.c].push_back({t, &g});
         }
@@ -645,7 +663,9 @@ struct Engine {
         h->device_passes += (int64_t)(plans.size() - legacy.size());
         if (!legacy.empty()) {
             std::vector<std::vector<double>> lo;
+            const double tl = mi_now();
             group_stats_legacy(legacy, lo);
+            h->t_device += mi_now() - tl;
             for (size_t i = 0; i < legacy.size(); ++i) outs[legacy_idx[i]].swap(lo[i]);
         }
     }
@@ -837,6 +857,11 @@ void pbn_mi_destroy(pbn_mi* h) {
     if (!h) return;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
+    const char* tm = std::getenv("PBN_MI_TIMING");
+    if (tm && *tm == '1')
+        std::fprintf(stderr, "[pbn_mi] tests %lld (count-only %lld), batches %lld, launches %lld, groupings built %lld: build %.2f s, "
+                     "plan/map %.2f s, device %.2f s, host statistics %.2f s\n", (long long)h->device_passes, (long long)h->count_only,
+                     (long long)h->batches, (long long)h->device_launches, (long long)h->groups_built, h->t_group, h->t_prep, h->t_device, h->t_host);
     delete h;
 }
 
@@ -894,11 +919,16 @@ void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, 
             plans[i] = e.plan(qs[i]);
         }
         std::vector<std::vector<double>> st;
+        const double t0 = mi_now(), g0 = h->t_group, d0 = h->t_device;
         e.group_stats_many(plans, st);
+        const double t1 = mi_now();
+        h->t_prep += (t1 - t0) - (h->t_group - g0) - (h->t_device - d0);
         for (int i = 0; i < n_tests; ++i) {
             const double mi = e.mi_from_stats(qs[i], plans[i], st[i]);
             out[i] = gamma_q(0.5 * e.df(qs[i]), 0.5 * (mi * 2.0 * (double)h->N));
         }
+        h->t_host += mi_now() - t1;
+        ++h->batches;
     });
 }
 

@@ -230,10 +230,11 @@ struct Mmpc {
     }
     struct Req { int a, b; std::vector<int> cond; };
     // p-values of independent requests, in request order; one call of the batched callback when there is one
-    std::vector<double> pvalues(const std::vector<Req>& reqs) {
+    std::vector<double> pvalues(const std::vector<Req>& reqs, bool count = true) {
         std::vector<double> out(reqs.size());
         if (!batch_fn || reqs.size() < 2) {
             for (size_t i = 0; i < reqs.size(); ++i) out[i] = pvalue(reqs[i].a, reqs[i].b, reqs[i].cond);
+            if (!count) tests -= (int64_t)reqs.size();
             return out;
         }
         std::vector<int> v1, v2, off{0}, cond;
@@ -244,7 +245,7 @@ struct Mmpc {
         }
         if (cond.empty()) cond.push_back(0);
         batch_fn(user, (int)reqs.size(), v1.data(), v2.data(), off.data(), cond.data(), out.data());
-        tests += (int64_t)reqs.size();
+        if (count) tests += (int64_t)reqs.size();
         for (double p : out)
             if (std::isnan(p)) throw invalid_error("MMPC: the independence test failed");
         return out;
@@ -329,7 +330,7 @@ struct Mmpc {
             *pos = rest.back();
             rest.pop_back();
             bool separated = pvalue(var, x) > alpha;
-            if (!separated) {
+            if (!separated && !batch_fn) {
                 std::vector<int> cond;
                 // subsets by increasing size, lexicographic inside a size, as the reference visits them
                 for (int sz = 1; sz <= (int)rest.size() && !separated; ++sz)
@@ -338,6 +339,25 @@ struct Mmpc {
                         for (int i : c.idx) cond.push_back(rest[i]);
                         separated = pvalue(var, x, cond) > alpha;
                     }
+            } else if (!separated) {
+                // batched callback: the subsets of one size are requested together and read in the reference's order up
+                // to the first separating one - same decisions, same number of tests counted; what lies behind the
+                // separating subset was evaluated for nothing, which costs less than one launch per subset
+                std::vector<Req> reqs;
+                std::vector<int> cond;
+                for (int sz = 1; sz <= (int)rest.size() && !separated; ++sz) {
+                    reqs.clear();
+                    for (Lex c((int)rest.size(), sz); c.live; c.next()) {
+                        cond.clear();
+                        for (int i : c.idx) cond.push_back(rest[i]);
+                        reqs.push_back({var, x, cond});
+                    }
+                    const std::vector<double> p = pvalues(reqs, false);
+                    size_t used = reqs.size();
+                    for (size_t i = 0; i < p.size(); ++i)
+                        if (p[i] > alpha) { separated = true; used = i + 1; break; }
+                    tests += (int64_t)used;
+                }
             }
             if (separated) it = cpc.erase(it);
             else { rest.push_back(x); ++it; }

@@ -24,6 +24,7 @@ for j in range(n_disc):
     df[f"D{j}"] = pd.Categorical.from_codes(disc[f"D{j}"], [f"c{v}" for v in range(cards[j])])
 names = list(df.columns)
 test = pbn.MutualInformation(df)
+t_all = time.perf_counter()
 t0 = time.perf_counter()
 try:
     cpcs, nt = mmpc_cpcs(test, names, 0.05)
@@ -31,3 +32,6 @@ try:
     print("ok tests", nt, "s", dt, "tests/s", nt / dt, "cpc sizes", [len(c) for c in cpcs], "passes", test.passes())
 except Exception as ex:
     print("error", repr(ex), time.perf_counter() - t0, test.passes())
+del test
+import gc; gc.collect()
+print("wall incl. handle teardown", time.perf_counter() - t_all)
