@@ -262,15 +262,29 @@ __device__ __forceinline__ T colmax(T v) {  // max over the 4 lanes (lane>>4 = 0
     return v > o ? v : o;
 }
 
+// XCD-aware block order (cdna_hip_programming.md T1, bijective form): workgroups are handed round-robin to the 8 XCDs, so
+// `linear id % 8` labels the blocks that share an L2.  The remap gives every XCD a CONTIGUOUS range of the logical
+// (split-major) grid: all blocks resident on an XCD sweep the same training split, which then lives in that XCD's 4 MB
+// L2 instead of being re-fetched through the fabric by every query block.  Pure placement - results do not depend on it.
+__device__ __forceinline__ void xcd_block(int& qx, int& split) {
+    const unsigned gx = gridDim.x, nwg = gx * gridDim.y;
+    const unsigned bid = blockIdx.x + gx * blockIdx.y;
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    qx = (int)(wg % gx);
+    split = (int)(wg / gx);
+}
+
 template <typename T, int KS, bool COND, int QG, bool FOLD>
 __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
-    const int64_t qt0 = ((int64_t)blockIdx.x * 4 + wave) * QG;
+    int qx, split;
+    xcd_block(qx, split);
+    const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
     if (qt0 >= a.nqtiles) return;  // no barriers in this kernel: idle waves just leave
-    const int split = blockIdx.y;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
 
@@ -674,9 +688,10 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
-    const int64_t qt0 = ((int64_t)blockIdx.x * 4 + wave) * QG;
+    int qx, split;
+    xcd_block(qx, split);
+    const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
     if (qt0 >= a.nqtiles) return;
-    const int split = blockIdx.y;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
 

@@ -188,6 +188,12 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond, m.KS));
     const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
     int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
+    // with the XCD-aware block order (xcd_block) the blocks resident on one XCD share a split: keep a split's training
+    // fragments within half of the 4 MB L2, and the number of splits a multiple of 8 so that the XCDs get equal shares
+    const int64_t tile_bytes = b3 ? (int64_t)m.KS * 64 * 16 + (m.cond ? 64 * 16 : 0)
+                                  : ((int64_t)m.KS * 64 + 16 + (m.cond ? 64 : 0)) * (int64_t)es;
+    nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles * tile_bytes, (int64_t)env_int("PBN_SWEEP_SPLIT_KB", 2048) * 1024));
+    if (nsplit > 1) nsplit = ceil_div(nsplit, 8) * 8;
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));
     nsplit = std::min<int64_t>(nsplit, 4096);
     const int64_t tps = ceil_div(m.ntiles, nsplit);
