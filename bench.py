@@ -218,7 +218,7 @@ def pmc_traffic(args):
     try:
         with open(path) as f:
             d = json.load(f)
-        k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4>" in name)
+        k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4" in name)
         return 2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0
     except Exception:
         return None
