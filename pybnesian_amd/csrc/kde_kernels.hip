@@ -854,9 +854,10 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
-    const int64_t qt0 = ((int64_t)blockIdx.x * 4 + wave) * QG;
+    int qx, split;
+    xcd_block(qx, split);
+    const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
     if (qt0 >= a.nqtiles) return;
-    const int split = blockIdx.y;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
     const T* __restrict__ Ap = (const T*)a.Apack;

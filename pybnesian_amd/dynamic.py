@@ -276,6 +276,77 @@ class DynamicBayesianNetwork:
                 total += self._transition.cpd(temporal_name(v, 0)).slogl(dtrans)
         return total
 
+    def sample(self, n, seed=None):
+        """DynamicBayesianNetwork::sample (DynamicBayesianNetwork.cpp:153-466): the first `markovian_order` rows are ONE
+        sample of the static network (row i is slice order - i), every later row i is drawn variable by variable in the
+        transition network's topological order, each factor sampling one value given the window of rows i-order .. i
+        with seed + i.  Returns a pyarrow.RecordBatch over variables()."""
+        import pyarrow as pa
+
+        from .factors import _random_seed
+
+        if not self.fitted():
+            raise ValueError("DynamicBayesianNetwork currently not fitted. Call fit() method, or add_cpds() for static_bn() and transition_bn()")
+        if n < 0:
+            raise ValueError("n should be a non-negative number")
+        seed = _random_seed() if seed is None else int(seed)
+        order = self._order
+        types, cats, cols = {}, {}, {}
+        for v in self._variables:   # check_same_datatypes + generate_empty_dataframe
+            cpd0 = self._transition.cpd(temporal_name(v, 0))
+            dt = cpd0.data_type()
+            for i in range(1, order + 1):
+                other = self._static.cpd(temporal_name(v, i)).data_type()
+                if pa.types.is_dictionary(dt) != pa.types.is_dictionary(other) or (not pa.types.is_dictionary(dt) and dt != other):
+                    raise ValueError(f"Data type for transition Bayesian network node {temporal_name(v, 0)} [{dt}] is different from data "
+                                     f"type of static Bayesian network node {temporal_name(v, i)}[{other}]")
+            types[v] = dt
+            if pa.types.is_dictionary(dt):
+                cats[v] = list(cpd0._categories[0])
+                for i in range(1, order):
+                    if list(self._static.cpd(temporal_name(v, i))._categories[0]) != cats[v]:
+                        raise ValueError(f"CPD of transition Bayesian network node {temporal_name(v, 0)} have different categories than "
+                                         f"static Bayesian network node {temporal_name(v, i)}.")
+                cols[v] = np.zeros(n, dtype=np.int64)
+            elif dt == pa.float64() or dt == pa.float32():
+                cols[v] = np.zeros(n, dtype=np.float64 if dt == pa.float64() else np.float32)
+            else:
+                raise ValueError("Data type not supported for sampling.")
+
+        def scalar(arr):
+            if isinstance(arr, pa.ChunkedArray):
+                arr = arr.combine_chunks()
+            if pa.types.is_dictionary(arr.type):
+                return int(arr.indices[0].as_py())
+            return arr[0].as_py()
+
+        static_sample = self._static.sample(1, seed & 0xFFFFFFFF)
+        for v in self._variables:
+            for i in range(min(order, n)):
+                cols[v][i] = scalar(static_sample.column(static_sample.schema.get_field_index(temporal_name(v, order - i))))
+
+        def window_value(name, i):   # column `name` = v_t_k of the one-row transition table of rows i-order .. i
+            v, k = name.rsplit("_t_", 1)
+            val = cols[v][i - int(k)]
+            if v in cats:
+                return pa.DictionaryArray.from_arrays(pa.array([int(val)], type=pa.int32()), pa.array(cats[v]))
+            return pa.array(np.asarray([val], dtype=cols[v].dtype))
+
+        top_sort = self._transition.topological_sort()
+        for i in range(order, n):
+            for full in top_sort:
+                cpd = self._transition.cpd(full)
+                ev = cpd.evidence()
+                evidence = pa.RecordBatch.from_arrays([window_value(e, i) for e in ev], names=list(ev)) if ev else None
+                cols[full[:-4]][i] = scalar(cpd.sample(1, evidence, (seed + i) & 0xFFFFFFFF))
+        arrays = []
+        for v in self._variables:
+            if v in cats:
+                arrays.append(pa.DictionaryArray.from_arrays(pa.array(cols[v], type=pa.int64()).cast(types[v].index_type), pa.array(cats[v])))
+            else:
+                arrays.append(pa.array(cols[v]))
+        return pa.RecordBatch.from_arrays(arrays, names=list(self._variables))
+
     @property
     def include_cpd(self):
         return bool(self._static.include_cpd and self._transition.include_cpd)

@@ -124,3 +124,41 @@ def test_dbn_fit_logl_reference_recipe(pbn, golden):
     ll = gbn.logl(test_df)
     assert np.all(np.isclose(want, ll))
     assert np.isclose(gbn.slogl(test_df), want.sum())
+
+
+def test_dbn_sample(pbn):
+    """DynamicBayesianNetwork.sample (DynamicBayesianNetwork.cpp:259-466): the first `order` rows are one sample of the
+    static network, every later row is drawn factor by factor from the window of the previous rows with seed + i."""
+    import pyarrow as pa
+
+    df = var_process(4000, 5)
+    dbn = pbn.DynamicGaussianNetwork(["a", "b", "c"], 2)
+    for s, t in (("a_t_1", "a_t_0"), ("b_t_1", "b_t_0"), ("a_t_0", "b_t_0"), ("b_t_1", "c_t_0")):
+        dbn.transition_bn().add_arc(s, t)
+    dbn.static_bn().add_arc("a_t_2", "a_t_1")
+    with pytest.raises(ValueError, match="not fitted"):
+        dbn.sample(10, 0)
+    dbn.fit(df)
+    s = dbn.sample(300, seed=7)
+    assert s.schema.names == ["a", "b", "c"] and s.num_rows == 300 and all(c.type == pa.float64() for c in s.columns)
+    again = dbn.sample(300, seed=7)
+    assert s.equals(again) and not s.equals(dbn.sample(300, seed=8))
+    sp = s.to_pandas()
+    st = dbn.static_bn().sample(1, 7).to_pandas()
+    for v in "abc":
+        assert sp[v][0] == st[f"{v}_t_2"][0] and sp[v][1] == st[f"{v}_t_1"][0]
+    # row i of a variable = its factor's one-value sample given the window, seed + i
+    tr = dbn.transition_bn()
+    for i in (2, 17, 299):
+        window = {f"{v}_t_{k}": [sp[v][i - k]] for v in "abc" for k in range(3)}
+        for v in "abc":
+            cpd = tr.cpd(f"{v}_t_0")
+            ev = pd.DataFrame({e: window[e] for e in cpd.evidence()}) if cpd.evidence() else None
+            assert sp[v][i] == cpd.sample(1, ev, 7 + i)[0].as_py()
+    # the process keeps its dynamics: strong positive lag-1 autocorrelation of a, b follows a
+    long = dbn.sample(3000, seed=1).to_pandas()
+    assert np.corrcoef(long["a"][1:], long["a"][:-1])[0, 1] > 0.6
+    assert np.corrcoef(long["a"], long["b"])[0, 1] > 0.5
+    assert dbn.sample(1, 3).num_rows == 1 and dbn.sample(0, 3).num_rows == 0
+    with pytest.raises(ValueError, match="non-negative"):
+        dbn.sample(-1, 0)
