@@ -19,7 +19,7 @@ from .models import (BayesianNetwork, BayesianNetworkType, FactorType, Condition
                      ConditionalKDENetwork, ConditionalSemiparametricBN, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load,
                      ConditionalDiscreteBN, ConditionalHeterogeneousBN, ConditionalHomogeneousBN, DiscreteBN, DiscreteBNType,
-                     HeterogeneousBN, HeterogeneousBNType, HomogeneousBN, HomogeneousBNType)
+                     HeterogeneousBN, HeterogeneousBNType, HomogeneousBN, HomogeneousBNType, Dag, ConditionalDag)
 from .dynamic import DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN  # noqa: F401
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
@@ -33,5 +33,5 @@ __all__ = [
     "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "UnknownFactorType", "DynamicDataFrame", "DynamicBayesianNetwork", "DynamicGaussianNetwork", "DynamicSemiparametricBN", "DynamicKDENetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
     "DiscreteBN", "DiscreteBNType", "HomogeneousBN", "HomogeneousBNType", "HeterogeneousBN", "HeterogeneousBNType", "ConditionalDiscreteBN",
     "ConditionalHomogeneousBN", "ConditionalHeterogeneousBN", "DynamicDiscreteBN", "DynamicCLGNetwork", "DynamicHomogeneousBN",
-    "DynamicHeterogeneousBN",
+    "DynamicHeterogeneousBN", "Dag", "ConditionalDag",
 ]

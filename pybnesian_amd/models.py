@@ -377,6 +377,44 @@ def _split_ctor_args(nodes, arcs, node_types):
     return nodes, arcs, node_types
 
 
+class Dag:
+    """The directed graph of a network as a value (graph/generic_graph.hpp Dag / ConditionalDag, the part the model
+    constructors and pickles use): `BayesianNetwork(type, bn.graph()[, node_types])` rebuilds the structure."""
+
+    def __init__(self, nodes, arcs=(), interface_nodes=()):
+        self._nodes, self._arcs, self._interface = list(nodes), [tuple(a) for a in arcs], list(interface_nodes)
+
+    def nodes(self):
+        return list(self._nodes)
+
+    def interface_nodes(self):
+        return list(self._interface)
+
+    def arcs(self):
+        return list(self._arcs)
+
+    def num_nodes(self):
+        return len(self._nodes)
+
+    def num_arcs(self):
+        return len(self._arcs)
+
+    def has_arc(self, source, target):
+        return (source, target) in self._arcs
+
+    def parents(self, node):
+        return [s for s, t in self._arcs if t == node]
+
+    def children(self, node):
+        return [t for s, t in self._arcs if s == node]
+
+    def __eq__(self, other):
+        return isinstance(other, Dag) and (self._nodes, self._interface, sorted(self._arcs)) == (other._nodes, other._interface, sorted(other._arcs))
+
+
+ConditionalDag = Dag
+
+
 class BayesianNetwork:
     """BayesianNetwork / ConditionalBayesianNetwork (models/BayesianNetwork.hpp): with `interface_nodes` the network is
     conditional - interface nodes can be parents of the nodes but have no parents, factors or scores of their own."""
@@ -386,6 +424,12 @@ class BayesianNetwork:
         (type, arcs), (type, arcs, node_types), (type, nodes, arcs), (type, nodes, arcs, node_types)."""
         if bn_type is None:
             raise ValueError("Type of Bayesian network must be non-null.")
+        if isinstance(nodes, Dag):   # (type, graph[, node_types])
+            if arcs and not node_types:
+                node_types = arcs
+            if nodes.interface_nodes() and not interface_nodes:
+                interface_nodes = nodes.interface_nodes()
+            nodes, arcs = nodes.nodes(), nodes.arcs()
         nodes, arcs, node_types = _split_ctor_args(nodes, arcs, node_types)
         self._type = bn_type
         self._nodes = list(nodes)
@@ -539,6 +583,9 @@ class BayesianNetwork:
 
     def arcs(self):
         return [(p, n) for n in self._nodes for p in self._parents[n]]
+
+    def graph(self):
+        return Dag(self._nodes, self.arcs(), self._interface)
 
     def num_arcs(self):
         return sum(len(v) for v in self._parents.values())
@@ -796,6 +843,9 @@ class BayesianNetwork:
     def fit(self, df):
         """BNGeneric::fit (BayesianNetwork.hpp:960-994): unknown node types are resolved from the data, factors that are
         missing, of the wrong type, with stale evidence or unfitted are (re)built and fitted; the others are kept."""
+        from .dataset import as_record_batch
+
+        df = as_record_batch(df)   # factors - also Python-derived ones - see a pyarrow.RecordBatch, as in the reference
         if getattr(self, "_cpds", None) is None:
             self._cpds = {}
         if self.has_unknown_node_types():
@@ -823,15 +873,21 @@ class BayesianNetwork:
             raise ValueError("Model not fitted.")  # BayesianNetwork.hpp check_fitted
         import numpy as np
 
+        from .dataset import as_record_batch
+
+        df = as_record_batch(df)
         out = None
         for n in self._nodes:
-            ll = self._cpds[n].logl(df)
+            ll = np.asarray(self._cpds[n].logl(df), dtype=np.float64)
             out = ll if out is None else out + ll
         return out if out is not None else np.zeros(0)
 
     def slogl(self, df):
         if not self.fitted():
             raise ValueError("Model not fitted.")
+        from .dataset import as_record_batch
+
+        df = as_record_batch(df)
         return float(sum(self._cpds[n].slogl(df) for n in self._nodes))
 
     # -- graph queries of models/BayesianNetwork.hpp / graph/generic_graph.hpp the callers of the hot path use -------
