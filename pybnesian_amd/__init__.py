@@ -6,10 +6,11 @@ HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
 """
 from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
 from .dataset import Context, CrossValidation, DeviceTable, HoldOut, default_context  # noqa: F401
-from .factors import CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, Factor, LinearGaussianCPD  # noqa: F401
+from .factors import (CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, DiscreteFactorParams, Factor, LinearGaussianCPD,  # noqa: F401
+                      LinearGaussianParams, MLEDiscreteFactor, MLELinearGaussianCPD)
 from .kde import KDE, UCV, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
-from .learning import (AddArc, ArcOperatorSet, Callback, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
+from .learning import (AddArc, ArcOperator, ArcOperatorSet, Callback, Operator, OperatorSet, SaveModel, ChangeNodeType, ChangeNodeTypeSet, FlipArc, GreedyHillClimbing,  # noqa: F401
                        LocalScoreCache, MMHC, OperatorPool, OperatorTabuSet, RemoveArc, hc)
 from .dynamic import (DMMHC, DynamicBayesianNetwork, DynamicGaussianNetwork, DynamicKDENetwork, DynamicSemiparametricBN, DynamicBGe, DynamicBIC, DynamicChiSquare, DynamicCVLikelihood,  # noqa: F401
                       DynamicDataFrame, DynamicHoldoutLikelihood, DynamicIndependenceTestAdaptator, DynamicLinearCorrelation,
@@ -20,7 +21,9 @@ from .models import (BayesianNetwork, BayesianNetworkType, FactorType, Condition
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load,
                      ConditionalDiscreteBN, ConditionalHeterogeneousBN, ConditionalHomogeneousBN, DiscreteBN, DiscreteBNType,
                      HeterogeneousBN, HeterogeneousBNType, HomogeneousBN, HomogeneousBNType, Dag, ConditionalDag)
-from .dynamic import DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN  # noqa: F401
+from .dynamic import (DynamicBayesianNetworkBase, DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN,  # noqa: F401
+                      DynamicIndependenceTest, DynamicScore)
+from .models import BayesianNetworkBase, ConditionalBayesianNetworkBase  # noqa: F401
 from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
 
@@ -33,5 +36,7 @@ __all__ = [
     "SingularCovarianceData", "Score", "ValidatedScore", "Arguments", "Args", "Kwargs", "ConditionalBayesianNetwork", "ConditionalGaussianNetwork", "ConditionalKDENetwork", "ConditionalSemiparametricBN", "ConditionalCLGNetwork", "CrossValidation", "HoldOut", "FactorType", "BayesianNetworkType", "UnknownFactorType", "DynamicDataFrame", "DynamicBayesianNetwork", "DynamicGaussianNetwork", "DynamicSemiparametricBN", "DynamicKDENetwork", "DMMHC", "DynamicBIC", "DynamicBGe", "DynamicCVLikelihood", "DynamicHoldoutLikelihood", "DynamicValidatedLikelihood", "DynamicLinearCorrelation", "DynamicMutualInformation", "DynamicChiSquare", "DynamicScoreAdaptator", "DynamicIndependenceTestAdaptator", "Callback", "MMHC", "IndependenceTest", "LinearCorrelation", "MutualInformation", "ChiSquare", "load", "Context", "DeviceTable", "default_context", "load_library",
     "DiscreteBN", "DiscreteBNType", "HomogeneousBN", "HomogeneousBNType", "HeterogeneousBN", "HeterogeneousBNType", "ConditionalDiscreteBN",
     "ConditionalHomogeneousBN", "ConditionalHeterogeneousBN", "DynamicDiscreteBN", "DynamicCLGNetwork", "DynamicHomogeneousBN",
-    "DynamicHeterogeneousBN", "Dag", "ConditionalDag",
+    "DynamicHeterogeneousBN", "Dag", "ConditionalDag", "Operator", "ArcOperator", "OperatorSet", "SaveModel", "LinearGaussianParams",
+    "DiscreteFactorParams", "MLELinearGaussianCPD", "MLEDiscreteFactor", "BayesianNetworkBase", "ConditionalBayesianNetworkBase",
+    "DynamicBayesianNetworkBase", "DynamicScore", "DynamicIndependenceTest",
 ]

@@ -114,7 +114,34 @@ class _DynamicAdaptator:
         return self._ddf.markovian_order()
 
 
-class DynamicScoreAdaptator(_DynamicAdaptator):
+def _pure(cls, name):
+    def fn(self, *args, **kwargs):
+        raise NotImplementedError(f'Tried to call pure virtual function "{cls}::{name}"')
+    return fn
+
+
+class DynamicScore:
+    """learning/scores/scores.hpp:74-101: subclass and implement has_variables, static_score, transition_score."""
+
+    has_variables = _pure("DynamicScore", "has_variables")
+    static_score = _pure("DynamicScore", "static_score")
+    transition_score = _pure("DynamicScore", "transition_score")
+
+
+class DynamicIndependenceTest:
+    """learning/independences/independence.hpp: subclass and implement num_variables, variable_names, name,
+    has_variables, markovian_order, static_tests, transition_tests."""
+
+    num_variables = _pure("DynamicIndependenceTest", "num_variables")
+    variable_names = _pure("DynamicIndependenceTest", "variable_names")
+    name = _pure("DynamicIndependenceTest", "name")
+    has_variables = _pure("DynamicIndependenceTest", "has_variables")
+    markovian_order = _pure("DynamicIndependenceTest", "markovian_order")
+    static_tests = _pure("DynamicIndependenceTest", "static_tests")
+    transition_tests = _pure("DynamicIndependenceTest", "transition_tests")
+
+
+class DynamicScoreAdaptator(_DynamicAdaptator, DynamicScore):
     def static_score(self):
         return self._static
 
@@ -122,7 +149,13 @@ class DynamicScoreAdaptator(_DynamicAdaptator):
         return self._transition
 
 
-class DynamicIndependenceTestAdaptator(_DynamicAdaptator):
+class DynamicIndependenceTestAdaptator(_DynamicAdaptator, DynamicIndependenceTest):
+    def num_variables(self):
+        return len(self._ddf.variable_names())
+
+    def name(self, index):
+        return self._ddf.variable_names()[index]
+
     def static_tests(self):
         return self._static
 
@@ -151,7 +184,11 @@ DynamicMutualInformation = _adaptator(DynamicIndependenceTestAdaptator, "MutualI
 DynamicChiSquare = _adaptator(DynamicIndependenceTestAdaptator, "ChiSquare")
 
 
-class DynamicBayesianNetwork:
+class DynamicBayesianNetworkBase:
+    """models/DynamicBayesianNetwork.hpp:20-60: the abstract interface DynamicBayesianNetwork implements."""
+
+
+class DynamicBayesianNetwork(DynamicBayesianNetworkBase):
     """models/DynamicBayesianNetwork.hpp: a static network over the lagged variables v_t_1 .. v_t_order and a conditional
     transition network over v_t_0 with the lagged variables as interface nodes."""
 

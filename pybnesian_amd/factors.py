@@ -407,24 +407,52 @@ class LinearGaussianCPD(Factor):
 
 
 class LinearGaussianParams:
+    """LinearGaussianCPD::ParamsClass (pybindings_parameters.cpp:43-62)."""
+
     def __init__(self, beta, variance):
-        self.beta, self.variance = beta, variance
+        self.beta, self.variance = np.asarray(beta, dtype=np.float64), float(variance)
 
 
-class MLE:
-    """pbn.MLE(pbn.LinearGaussianCPDType()).estimate(df, variable, evidence) -> .beta, .variance
-    (pybindings_learning/pybindings_parameters.cpp:76-78)."""
+class DiscreteFactorParams:
+    """DiscreteFactor::ParamsClass (pybindings_parameters.cpp:93-135): `logprob` with one axis per variable - the
+    factor's variable first, then its evidence - and `cardinality`."""
 
-    def __init__(self, factor_type):
-        from .models import LinearGaussianCPDType
+    def __init__(self, logprob):
+        self.logprob = np.asarray(logprob, dtype=np.float64)
 
-        if factor_type != LinearGaussianCPDType():
-            raise ValueError(f"MLE not available for NodeType {factor_type}.")
+    @property
+    def cardinality(self):
+        return np.asarray(self.logprob.shape, dtype=np.int32)
+
+
+class MLELinearGaussianCPD:
+    """MLE<LinearGaussianCPD> (learning/parameters/mle_LinearGaussianCPD.cpp:5-45): one device Gram pass + closed forms."""
 
     def estimate(self, df, variable, evidence):
         cpd = LinearGaussianCPD(variable, list(evidence))
         cpd.fit(df)
         return LinearGaussianParams(cpd.beta, cpd.variance)
+
+
+class MLEDiscreteFactor:
+    """MLE<DiscreteFactor> (learning/parameters/mle_DiscreteFactor.cpp:5-41)."""
+
+    def estimate(self, df, variable, evidence):
+        f = DiscreteFactor(variable, list(evidence))
+        f.fit(df)
+        return DiscreteFactorParams(f._logprob.reshape(f._cards, order="F"))
+
+
+def MLE(factor_type):
+    """pbn.MLE(factor_type) (pybindings_parameters.cpp:31-40, mle_base.cpp): the estimator of LinearGaussianCPDType or
+    DiscreteFactorType; any other type raises "MLE not available"."""
+    from .models import DiscreteFactorType, LinearGaussianCPDType
+
+    if factor_type == LinearGaussianCPDType():
+        return MLELinearGaussianCPD()
+    if factor_type == DiscreteFactorType():
+        return MLEDiscreteFactor()
+    raise ValueError(f"MLE not available for NodeType {factor_type}.")
 
 
 # ---- hybrid factors (factors/discrete/) --------------------------------------------------------------------------

@@ -70,27 +70,31 @@ class Operator:
         return hash(self._key())
 
 
-class AddArc(Operator):
-    _kind = 0
-
-    def _key(self):
-        return (type(self).__name__, self._source, self._target)
-
-    def opposite(self, model=None):
-        return RemoveArc(self._source, self._target, -self._delta)
-
-    def nodes_changed(self, model=None):
-        return [self._target]
+class ArcOperator(Operator):
+    """operators.hpp:122-140: an operator on one arc; AddArc, RemoveArc and FlipArc derive from it."""
 
     def __init__(self, source, target, delta):
         super().__init__(delta)
         self._source, self._target = source, target
+
+    def _key(self):
+        return (type(self).__name__, self._source, self._target)
 
     def source(self):
         return self._source
 
     def target(self):
         return self._target
+
+    def nodes_changed(self, model=None):
+        return [self._target]
+
+
+class AddArc(ArcOperator):
+    _kind = 0
+
+    def opposite(self, model=None):
+        return RemoveArc(self._source, self._target, -self._delta)
 
     def apply(self, model):
         model.add_arc(self._source, self._target)
@@ -99,7 +103,7 @@ class AddArc(Operator):
         return f"AddArc({self._source} -> {self._target}; {self._delta})"
 
 
-class RemoveArc(AddArc):
+class RemoveArc(ArcOperator):
     _kind = 1
 
     def opposite(self, model=None):
@@ -112,7 +116,7 @@ class RemoveArc(AddArc):
         return f"RemoveArc({self._source} -> {self._target}; {self._delta})"
 
 
-class FlipArc(AddArc):
+class FlipArc(ArcOperator):
     _kind = 2
 
     def opposite(self, model=None):
@@ -247,6 +251,18 @@ class Callback:
 
     def call(self, model, operator, score, iteration):
         raise NotImplementedError("Tried to call pure virtual function \"Callback::call\"")
+
+
+class SaveModel(Callback):
+    """learning/algorithms/callbacks/save_model.hpp: saves the model of every iteration as `folder/000123.pickle`."""
+
+    def __init__(self, folder_name):
+        self._folder = folder_name
+
+    def call(self, model, operator, score, iteration):
+        import os
+
+        model.save(os.path.join(self._folder, "%06d" % iteration), False)
 
 
 class _EngineBinding:

@@ -415,7 +415,15 @@ class Dag:
 ConditionalDag = Dag
 
 
-class BayesianNetwork:
+class BayesianNetworkBase:
+    """models/BayesianNetwork.hpp:29-145: the abstract interface of every network (isinstance checks of user code)."""
+
+
+class ConditionalBayesianNetworkBase(BayesianNetworkBase):
+    """models/BayesianNetwork.hpp:147-222."""
+
+
+class BayesianNetwork(BayesianNetworkBase):
     """BayesianNetwork / ConditionalBayesianNetwork (models/BayesianNetwork.hpp): with `interface_nodes` the network is
     conditional - interface nodes can be parents of the nodes but have no parents, factors or scores of their own."""
 
@@ -1031,7 +1039,7 @@ class BayesianNetwork:
 
 
 
-class ConditionalBayesianNetwork(BayesianNetwork):
+class ConditionalBayesianNetwork(BayesianNetwork, ConditionalBayesianNetworkBase):
     """models/BayesianNetwork.hpp ConditionalBayesianNetwork: (type, nodes, interface_nodes[, arcs][, node_types])."""
 
     def __init__(self, bn_type, nodes, interface_nodes, arcs=(), node_types=()):

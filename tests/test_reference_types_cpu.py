@@ -552,3 +552,33 @@ def test_discrete_factor_data_type():   # factors/discrete/DiscreteFactor_test.p
         values = pd.Categorical(categories[np.random.RandomState(ncat).randint(len(categories), size=100)], categories=categories, ordered=False)
         a.fit(pd.DataFrame({"A": values}))
         assert a.data_type() == pa.dictionary(index_type, pa.string())
+
+
+def test_documented_names_and_small_helpers(tmp_path):
+    """Names of the reference's API pages (docs/source/api) that user code reaches for around the hot path: operator and
+    network base classes, the MLE estimators and their parameter classes, the SaveModel callback."""
+    import numpy as np
+    import pandas as pd
+
+    assert isinstance(pbn.RemoveArc("a", "b", 0.0), pbn.ArcOperator) and isinstance(pbn.FlipArc("a", "b", 0.0), pbn.Operator)
+    assert not isinstance(pbn.RemoveArc("a", "b", 0.0), pbn.AddArc)
+    assert issubclass(pbn.ArcOperatorSet, pbn.OperatorSet)
+    assert isinstance(GaussianNetwork(ABCD), pbn.BayesianNetworkBase)
+    assert isinstance(pbn.ConditionalGaussianNetwork(["a"], ["b"]), pbn.ConditionalBayesianNetworkBase)
+    assert isinstance(pbn.DynamicGaussianNetwork(["a", "b"], 1), pbn.DynamicBayesianNetworkBase)
+    with pytest.raises(ValueError, match="MLE not available"):   # mle_test.py:26-31
+        pbn.MLE(pbn.CKDEType())
+    assert isinstance(pbn.MLE(pbn.LinearGaussianCPDType()), pbn.MLELinearGaussianCPD)
+    rng = np.random.RandomState(0)   # pybindings_parameters.cpp:151-165
+    df = pd.DataFrame({"variable": rng.choice(["a1", "a2", "a3"], size=50, p=[0.5, 0.3, 0.2]),
+                       "evidence": rng.choice(["b1", "b2"], size=50, p=[0.5, 0.5])}, dtype="category")
+    params = pbn.MLE(pbn.DiscreteFactorType()).estimate(df, "variable", ["evidence"])
+    assert isinstance(params, pbn.DiscreteFactorParams) and params.logprob.shape == (3, 2) and list(params.cardinality) == [3, 2]
+    assert np.allclose(np.exp(params.logprob).sum(axis=0), 1.0)
+    p = pbn.LinearGaussianParams([1, 2], 0.5)
+    assert list(p.beta) == [1, 2] and p.variance == 0.5
+    cb = pbn.SaveModel(str(tmp_path))
+    cb.call(GaussianNetwork(ABCD, [("a", "b")]), None, None, 7)
+    assert pbn.load(str(tmp_path / "000007.pickle")).arcs() == [("a", "b")]
+    with pytest.raises(NotImplementedError, match="DynamicScore::static_score"):
+        pbn.DynamicScore().static_score()
