@@ -325,6 +325,10 @@ int pbn_mi_set_order(pbn_mi* h, int n, const int* ids);
 /* ChiSquare::pvalue (learning/independences/discrete/chi_square.cpp:8-139) over the discrete columns of the same
  * handle (pbn_ci_pvalue_fn signature). */
 double pbn_chisq_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
+/* Tables with nulls (hybrid/mutual_information.cpp:152-215, the contains_null overloads): a discrete null is code -1 in
+ * pbn_mi_create; continuous nulls are NaN cells of the columns flagged here, with the pilot shift to use for them.  A
+ * test then counts only the rows valid in all of its variables. */
+int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const double* shift);
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes);
 /* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
  * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies

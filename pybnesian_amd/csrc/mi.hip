@@ -55,6 +55,8 @@ struct pbn_mi {
     int64_t N = 0;
     bool asymptotic = true;
     std::vector<int> card;
+    std::vector<char> disc_null, cont_null;   // columns holding nulls: code == card[j] / NaN; such rows drop out of a test
+    bool any_null = false;
     dev_buf<int32_t> codes_dev;               // [n_disc][N]
     std::vector<double> shift;                // pilot mean of every continuous column
     int64_t device_passes = 0, host_passes = 0, device_launches = 0;
@@ -211,9 +213,12 @@ __global__ __launch_bounds__(256) void segment_first_kernel(const uint32_t* __re
     if (r == 0 || keys[r - 1] != k) first[k] = (int32_t)r;
 }
 
-template <typename T, int C>
+// NULLS: some of the test's continuous columns hold NaN for null cells; a row with a NaN in any of the C columns drops
+// out (the reference filters the rows valid in all columns of the test, mutual_information.cpp:152-215) and one more
+// statistic, the number of rows kept, follows the products.
+template <typename T, int C, bool NULLS>
 __global__ __launch_bounds__(256) void moments_sorted_kernel(const SortedArgs* __restrict__ descs) {
-    constexpr int S = C + C * (C + 1) / 2;   // sums, upper-triangle products (the count is the segment length)
+    constexpr int S = C + C * (C + 1) / 2 + (NULLS ? 1 : 0);   // sums, upper-triangle products (the count is the segment length)
     __shared__ double red[4][S];
     const SortedArgs& a = descs[blockIdx.y];
     if ((int)blockIdx.x >= a.nblk) return;
@@ -227,8 +232,13 @@ __global__ __launch_bounds__(256) void moments_sorted_kernel(const SortedArgs* _
     for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
         const int64_t row = a.perm ? a.perm[r] : r;
         double x[C];
+        bool ok = true;
 #pragma unroll
-        for (int i = 0; i < C; ++i) x[i] = (double)col[i][row] - a.shift[i];
+        for (int i = 0; i < C; ++i) { x[i] = (double)col[i][row] - a.shift[i]; ok = ok && (x[i] == x[i]); }
+        if (NULLS) {
+            if (!ok) continue;
+            acc[S - 1] += 1.0;
+        }
         int pos = C;
 #pragma unroll
         for (int i = 0; i < C; ++i) {
@@ -339,6 +349,8 @@ struct Engine {
 
     bool is_disc(int v) const { return v >= h->n_cont; }
     int card(int v) const { return h->card[v - h->n_cont]; }
+    // categories as grouped on the device: a column with nulls has one more, the null bucket (code == card)
+    int card_eff(int v) const { return card(v) + (h->disc_null.empty() ? 0 : (int)h->disc_null[v - h->n_cont]); }
 
     struct Plan {
         std::vector<int> cont, disc;
@@ -483,7 +495,7 @@ struct Engine {
         auto g = std::make_unique<DiscGroup>();
         g->vars = vars;
         int64_t G64 = 1;
-        for (int v : vars) G64 *= card(v);
+        for (int v : vars) G64 *= card_eff(v);
         g->G = (int)G64;
         g->off.assign((size_t)g->G + 1, 0);
         g->off[g->G] = N;
@@ -491,7 +503,7 @@ struct Engine {
             KeyArgs ka{};
             ka.m = (int)vars.size();
             int stride = 1;
-            for (int j = 0; j < ka.m; ++j) { ka.dvar[j] = vars[j] - h->n_cont; ka.stride[j] = stride; stride *= card(vars[j]); }
+            for (int j = 0; j < ka.m; ++j) { ka.dvar[j] = vars[j] - h->n_cont; ka.stride[j] = stride; stride *= card_eff(vars[j]); }
             const unsigned nb = (unsigned)ceil_div(N, 256);
             if (h->iota.n < (size_t)N) {
                 h->iota.alloc((size_t)N);
@@ -538,17 +550,20 @@ struct Engine {
     }
 
     template <int C>
-    void launch_sorted(bool f64, int max_nblk, int B, const SortedArgs* d) {
-        if (f64) hipLaunchKernelGGL((moments_sorted_kernel<double, C>), dim3(max_nblk, B), dim3(256), 0, h->ctx->stream, d);
-        else hipLaunchKernelGGL((moments_sorted_kernel<float, C>), dim3(max_nblk, B), dim3(256), 0, h->ctx->stream, d);
+    void launch_sorted(bool f64, bool nulls, int max_nblk, int B, const SortedArgs* d) {
+        const dim3 grid(max_nblk, B), block(256);
+        if (f64 && !nulls) hipLaunchKernelGGL((moments_sorted_kernel<double, C, false>), grid, block, 0, h->ctx->stream, d);
+        else if (f64) hipLaunchKernelGGL((moments_sorted_kernel<double, C, true>), grid, block, 0, h->ctx->stream, d);
+        else if (!nulls) hipLaunchKernelGGL((moments_sorted_kernel<float, C, false>), grid, block, 0, h->ctx->stream, d);
+        else hipLaunchKernelGGL((moments_sorted_kernel<float, C, true>), grid, block, 0, h->ctx->stream, d);
     }
 
     // one launch pair for tests with the same number of continuous variables; `items` = (plan index, its group)
-    void sorted_batch(int c, const std::vector<Plan>& plans, const std::vector<std::pair<size_t, DiscGroup*>>& items,
+    void sorted_batch(int c, bool nulls, const std::vector<Plan>& plans, const std::vector<std::pair<size_t, DiscGroup*>>& items,
                       const std::vector<const std::vector<int>*>& cmap, std::vector<std::vector<double>>& outs) {
         pbn_ctx* ctx = h->ctx;
         const double td0 = mi_now();
-        const int S = c + c * (c + 1) / 2, B = (int)items.size();
+        const int S0 = c + c * (c + 1) / 2, S = S0 + (nulls ? 1 : 0), B = (int)items.size();
         std::vector<SortedArgs> descs(B);
         size_t part = 0, outd = 0;
         int max_nblk = 1, max_cells = 1;
@@ -580,10 +595,10 @@ struct Engine {
         const bool f64 = h->table->dtype == PBN_F64;
         const SortedArgs* d = (const SortedArgs*)base;
         switch (c) {
-#define PBN_MI_CASE(C) case C: launch_sorted<C>(f64, max_nblk, B, d); break;
+#define PBN_MI_CASE(C) case C: launch_sorted<C>(f64, nulls, max_nblk, B, d); break;
             PBN_MI_CASE(1) PBN_MI_CASE(2) PBN_MI_CASE(3) PBN_MI_CASE(4) PBN_MI_CASE(5) PBN_MI_CASE(6) PBN_MI_CASE(7) PBN_MI_CASE(8)
             PBN_MI_CASE(9) PBN_MI_CASE(10) PBN_MI_CASE(11) PBN_MI_CASE(12) PBN_MI_CASE(13) PBN_MI_CASE(14) PBN_MI_CASE(15)
-            default: launch_sorted<16>(f64, max_nblk, B, d); break;
+            default: launch_sorted<16>(f64, nulls, max_nblk, B, d); break;
 #undef PBN_MI_CASE
         }
         hipLaunchKernelGGL(sorted_reduce_kernel, dim3(max_cells, B), dim3(64), 0, ctx->stream, d, S);
@@ -597,9 +612,12 @@ struct Engine {
             const DiscGroup& g = *items[i].second;
             const int stats = plans[t].stats;
             for (int cg = 0; cg < g.G; ++cg) {
-                double* dst = outs[t].data() + (size_t)(*cmap[t])[cg] * stats + 1;
+                const int gt = (*cmap[t])[cg];
+                if (gt < 0) continue;   // a configuration with a null category
+                double* dst = outs[t].data() + (size_t)gt * stats + 1;
                 const double* src = all.data() + oo + (size_t)cg * S;
-                for (int k = 0; k < S; ++k) dst[k] = src[k];
+                for (int k = 0; k < S0; ++k) dst[k] = src[k];
+                if (nulls) dst[-1] = src[S0];   // rows of the configuration that are valid in all continuous columns
             }
             oo += (size_t)g.G * S;
         }
@@ -622,10 +640,13 @@ struct Engine {
         std::vector<Plan> legacy;
         std::vector<size_t> legacy_idx;
         std::vector<const std::vector<int>*> cmap(plans.size(), nullptr);
-        std::vector<std::vector<std::pair<size_t, DiscGroup*>>> by_c(MI_SORTED_MAX_CONT + 1);
+        std::vector<std::vector<std::pair<size_t, DiscGroup*>>> by_c(2 * MI_SORTED_MAX_CONT + 2);   // index 2 c + (continuous nulls ? 1 : 0)
         for (size_t t = 0; t < plans.size(); ++t) {
             const Plan& p = plans[t];
-            if (p.c > MI_SORTED_MAX_CONT || p.G > (1 << 22)) { legacy.push_back(p); legacy_idx.push_back(t); continue; }
+            if (p.c > MI_SORTED_MAX_CONT || p.G > (1 << 22)) {
+                if (h->any_null) throw invalid_error("MutualInformation: tables with nulls support at most 16 continuous variables per test");
+                legacy.push_back(p); legacy_idx.push_back(t); continue;
+            }
             std::vector<int> vars = p.disc;
             std::sort(vars.begin(), vars.end());
             DiscGroup& g = group_for(vars);
@@ -635,30 +656,38 @@ struct Engine {
             if (om == g.order_maps.end()) {
                 std::vector<int> map((size_t)g.G);
                 const int m = (int)vars.size();
-                std::vector<int> tstride(m), cards(m);
+                std::vector<int> tstride(m), cards(m), ecards(m);
                 for (int j = 0; j < m; ++j) {
-                    cards[j] = card(vars[j]);
+                    cards[j] = card(vars[j]); ecards[j] = card_eff(vars[j]);
                     int stride = 1;
                     for (int v : p.disc) { if (v == vars[j]) break; stride *= card(v); }
                     tstride[j] = stride;
                 }
                 for (int cg = 0; cg < g.G; ++cg) {
                     int rem = cg, gt = 0;
-                    for (int j = 0; j < m; ++j) { gt += (rem % cards[j]) * tstride[j]; rem /= cards[j]; }
+                    for (int j = 0; j < m; ++j) {
+                        const int digit = rem % ecards[j];
+                        rem /= ecards[j];
+                        if (digit >= cards[j]) { gt = -1; break; }   // the null bucket: these rows are not part of the test
+                        gt += digit * tstride[j];
+                    }
                     map[cg] = gt;
                 }
                 om = g.order_maps.emplace(p.disc, std::move(map)).first;
             }
             cmap[t] = &om->second;
             const std::vector<int>& map = om->second;
-            for (int cg = 0; cg < g.G; ++cg) outs[t][(size_t)map[cg] * p.stats] = (double)(g.off[cg + 1] - g.off[cg]);
+            for (int cg = 0; cg < g.G; ++cg)
+                if (map[cg] >= 0) outs[t][(size_t)map[cg] * p.stats] = (double)(g.off[cg + 1] - g.off[cg]);
             if (p.c == 0) { ++h->count_only; continue; }
-            by_c[p.c].push_back({t, &g});
+            bool nulls = false;
+            for (int v : p.cont) nulls = nulls || (!h->cont_null.empty() && h->cont_null[v]);
+            by_c[2 * p.c + (nulls ? 1 : 0)].push_back({t, &g});
         }
-        for (int c = 1; c <= MI_SORTED_MAX_CONT; ++c)
-            for (size_t i = 0; i < by_c[c].size(); i += 256) {
-                std::vector<std::pair<size_t, DiscGroup*>> items(by_c[c].begin() + i, by_c[c].begin() + std::min(by_c[c].size(), i + 256));
-                sorted_batch(c, plans, items, cmap, outs);
+        for (int key = 2; key <= 2 * MI_SORTED_MAX_CONT + 1; ++key)
+            for (size_t i = 0; i < by_c[key].size(); i += 256) {
+                std::vector<std::pair<size_t, DiscGroup*>> items(by_c[key].begin() + i, by_c[key].begin() + std::min(by_c[key].size(), i + 256));
+                sorted_batch(key / 2, (key & 1) != 0, plans, items, cmap, outs);
             }
         h->device_passes += (int64_t)(plans.size() - legacy.size());
         if (!legacy.empty()) {
@@ -680,18 +709,27 @@ struct Engine {
 
     // MI(X; Y | Z) (mutual_information.cpp:926-1055 no conditioning, :1139-1312 one variable, :1391-1658 general);
     // every overload of the reference is the general formula with the matching emptiness of zD / zC.
-    double mi(const Query& q) {
+    double mi(const Query& q, double* rows = nullptr) {
         std::vector<Plan> one{plan(q)};
         std::vector<std::vector<double>> o;
         group_stats_many(one, o);
+        if (rows) *rows = rows_of(one[0], o[0]);
         return mi_from_stats(q, one[0], o[0]);
+    }
+
+    // rows of the test: all of them, or - with nulls - those valid in every variable of the test (the counts add up to it)
+    double rows_of(const Plan& pl, const std::vector<double>& st) const {
+        if (!h->any_null) return (double)h->N;
+        double n = 0;
+        for (int g = 0; g < pl.G; ++g) n += st[(size_t)g * pl.stats];
+        return n;
     }
 
     double mi_from_stats(const Query& q, const Plan& pl, const std::vector<double>& st) {
         const std::vector<int>& disc = pl.disc;
         const int G = pl.G, c = pl.c, zc = (int)q.zC.size();
         const int stats = pl.stats;
-        const double N = (double)h->N;
+        const double N = rows_of(pl, st);
         auto S = [&](int g) { return st.data() + (size_t)g * stats; };
         std::vector<int> selz(zc);
         double mi = 0.0;
@@ -831,11 +869,25 @@ int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_di
         h->ctx = ctx; h->table = table; h->n_cont = table ? table->n_cols : 0; h->n_disc = n_disc; h->N = n_rows;
         h->asymptotic = asymptotic_df != 0;
         h->card.assign(cardinality, cardinality + n_disc);
+        h->disc_null.assign(n_disc, 0);
+        h->cont_null.assign(h->n_cont, 0);
         h->codes_dev.alloc((size_t)std::max<int64_t>(1, (int64_t)n_disc * n_rows));
+        std::vector<int32_t> bucketed;
         for (int j = 0; j < n_disc; ++j) {
-            for (int64_t r = 0; r < n_rows; ++r)
-                if (codes[j][r] < 0 || codes[j][r] >= cardinality[j]) throw invalid_error("pbn_mi_create: category index out of range");
-            HIP_CHECK(hipMemcpyAsync(h->codes_dev.p + (size_t)j * n_rows, codes[j], (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            bool has_null = false;
+            for (int64_t r = 0; r < n_rows; ++r) {
+                if (codes[j][r] < -1 || codes[j][r] >= cardinality[j]) throw invalid_error("pbn_mi_create: category index out of range");
+                has_null = has_null || codes[j][r] == -1;
+            }
+            const int32_t* src = codes[j];
+            if (has_null) {   // a null cell (code -1) goes to one more bucket, card[j], which no test ever reads
+                bucketed.assign(codes[j], codes[j] + n_rows);
+                for (int32_t& c : bucketed) if (c < 0) c = cardinality[j];
+                src = bucketed.data();
+                h->disc_null[j] = 1; h->any_null = true;
+            }
+            HIP_CHECK(hipMemcpyAsync(h->codes_dev.p + (size_t)j * n_rows, src, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            if (has_null) HIP_CHECK(hipStreamSynchronize(ctx->stream));   // `bucketed` is reused
         }
         h->shift.assign(h->n_cont, 0.0);
         if (table && n_rows > 0) {
@@ -850,6 +902,19 @@ int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_di
         }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *out = h.release();
+    });
+}
+
+// Continuous columns that hold NaN for null cells (flags[i] != 0) and the pilot shift to use for them (their own pilot
+// would be NaN).  A test then runs over the rows valid in all of its variables, as the reference's contains_null
+// overloads do (hybrid/mutual_information.cpp:152-215).
+int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const double* shift) {
+    return guarded([&] {
+        if (!h || !flags || !shift) throw invalid_error("pbn_mi_set_continuous_nulls: null argument");
+        for (int i = 0; i < h->n_cont; ++i) {
+            h->cont_null[i] = flags[i] ? 1 : 0;
+            if (flags[i]) { h->shift[i] = shift[i]; h->any_null = true; }
+        }
     });
 }
 
@@ -892,8 +957,16 @@ double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
         }
         cond = mapped.data();
     }
-    if (pbn_mi_value(h, v1, v2, n_cond, cond, &mi, &df) != PBN_OK) return std::nan("");
-    return gamma_q(0.5 * df, 0.5 * (mi * 2.0 * (double)h->N));
+    double rows = 0;
+    const int rc = guarded([&] {
+        if (!h || (n_cond > 0 && !cond)) throw invalid_error("pbn_mi_pvalue: null argument");
+        Engine e{h};
+        const Query q = e.make(v1, v2, n_cond, cond);
+        mi = e.mi(q, &rows);
+        df = e.df(q);
+    });
+    if (rc != PBN_OK) return std::nan("");
+    return gamma_q(0.5 * df, 0.5 * (mi * 2.0 * rows));
 }
 
 // Batched form: n_tests independence tests in as few launches as scratch memory allows (pbn_ci_pvalue_batch_fn).
@@ -925,7 +998,7 @@ void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, 
         h->t_prep += (t1 - t0) - (h->t_group - g0) - (h->t_device - d0);
         for (int i = 0; i < n_tests; ++i) {
             const double mi = e.mi_from_stats(qs[i], plans[i], st[i]);
-            out[i] = gamma_q(0.5 * e.df(qs[i]), 0.5 * (mi * 2.0 * (double)h->N));
+            out[i] = gamma_q(0.5 * e.df(qs[i]), 0.5 * (mi * 2.0 * e.rows_of(plans[i], st[i])));
         }
         h->t_host += mi_now() - t1;
         ++h->batches;

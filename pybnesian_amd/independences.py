@@ -138,14 +138,21 @@ class MutualInformation(IndependenceTest):
                 disc.append(f.name)
             else:
                 raise ValueError(f"Wrong data type ({f.type}) for column {f.name}.")
-        if any(rb.column(i).null_count for i in range(rb.num_columns)):
-            raise ValueError("MutualInformation on the device needs columns without nulls.")
         ctx = ctx or default_context()
+        # nulls stay in the tables (NaN cells, category code -1): every test runs over the rows valid in all of ITS
+        # variables, like the reference's contains_null overloads (hybrid/mutual_information.cpp:152-215)
         self._table = DeviceTable.from_dataframe(ctx, rb, cont, drop_null=False)[0] if cont else None
         self._codes, card = [], []
         for d in disc:
             col = rb.column(rb.schema.get_field_index(d))
-            self._codes.append(np.ascontiguousarray(col.indices.to_numpy(zero_copy_only=False), dtype=np.int32))
+            if isinstance(col, pa.ChunkedArray):
+                col = col.combine_chunks()
+            idx = col.indices
+            if col.null_count:
+                import pyarrow.compute as pc
+
+                idx = pc.if_else(col.is_valid(), idx, pa.scalar(-1, type=idx.type))
+            self._codes.append(np.ascontiguousarray(idx.to_numpy(zero_copy_only=False), dtype=np.int32))
             card.append(len(col.dictionary))
         self._id = {n: i for i, n in enumerate(cont + disc)}
         ptrs = (C.c_void_p * max(1, len(disc)))(*[c.ctypes.data for c in self._codes])
@@ -153,6 +160,14 @@ class MutualInformation(IndependenceTest):
         _lib.check(_lib.load().pbn_mi_create(ctx.handle, self._table.handle if self._table is not None else None, rb.num_rows,
                                              len(disc), ptrs, _lib.int_array(card or [0]), int(bool(asymptotic_df)), C.byref(h)))
         self._handle = h
+        flags = np.array([1 if rb.column(rb.schema.get_field_index(c)).null_count else 0 for c in cont], dtype=np.uint8)
+        if flags.any():
+            shift = np.zeros(len(cont))
+            for i, c in enumerate(cont):
+                if flags[i]:
+                    vals = rb.column(rb.schema.get_field_index(c)).to_numpy(zero_copy_only=False).astype(np.float64)
+                    shift[i] = np.nanmean(vals) if np.isfinite(vals).any() else 0.0
+            _lib.check(_lib.load().pbn_mi_set_continuous_nulls(h, flags.ctypes.data_as(C.POINTER(C.c_ubyte)), _lib.dptr(shift)))
 
     def _var(self, name):
         if name not in self._id:

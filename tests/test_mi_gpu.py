@@ -170,3 +170,33 @@ def test_chi_square(pbn):
 
     cpcs, _ = mmpc_cpcs(test, ["a", "b", "c", "d"], 0.01)
     assert "b" in cpcs[0] and "d" in cpcs[2] and "c" not in cpcs[0]
+
+
+def test_mi_and_chisquare_with_nulls(pbn):
+    """Null cells (hybrid/mutual_information.cpp:152-215, the contains_null overloads): every test runs over the rows that
+    are valid in all of ITS variables - here: the restatement on the table filtered per test."""
+    from scipy.stats import chi2_contingency
+
+    df = hybrid_table(20000, 11)
+    rng = np.random.default_rng(5)
+    for c, frac in (("c1", 0.03), ("c3", 0.05), ("d1", 0.04), ("d3", 0.02)):
+        df.loc[df.index[rng.random(len(df)) < frac], c] = np.nan
+    test = pbn.MutualInformation(df)
+    cases = [("c1", "c2", []), ("c1", "c2", ["c3"]), ("c2", "c4", ["d2"]), ("c1", "d2", ["d1"]), ("d1", "d2", ["d3"]),
+             ("c3", "d3", ["c1", "d1"]), ("d1", "c4", ["c3", "d3", "c2"]), ("c2", "c4", ["d1", "d3", "c1"])]
+    for x, y, z in cases:
+        sub = df.dropna(subset=[x, y] + z).reset_index(drop=True)
+        orc = make_oracle(sub[[x, y] + z])
+        assert test.mi(x, y, z or None) == pytest.approx(orc.mi(x, y, tuple(z)), rel=1e-8, abs=1e-11), (x, y, z)
+        assert test.pvalue(x, y, z or None) == pytest.approx(orc.pvalue(x, y, tuple(z)), rel=1e-6, abs=1e-300), (x, y, z)
+    chi = pbn.ChiSquare(df)
+    sub = df.dropna(subset=["d1", "d3"])
+    tab = pd.crosstab(sub["d1"], sub["d3"]).to_numpy()
+    assert chi.pvalue("d1", "d3") == pytest.approx(chi2_contingency(tab, correction=False)[1], rel=1e-9, abs=1e-300)
+    # batched form (what MMPC uses) gives the same p-values
+    from pybnesian_amd.independences import mmpc_cpcs
+
+    clean = hybrid_table(20000, 11)
+    cp_null, _ = mmpc_cpcs(test, list(df.columns), 0.05)
+    cp_clean, _ = mmpc_cpcs(pbn.MutualInformation(clean), list(clean.columns), 0.05)
+    assert [sorted(c) for c in cp_null] == [sorted(c) for c in cp_clean]   # 2-5 % missing cells do not change the skeleton here
