@@ -329,6 +329,10 @@ double pbn_chisq_pvalue(void* user, int v1, int v2, int n_cond, const int* cond)
  * pbn_mi_create; continuous nulls are NaN cells of the columns flagged here, with the pilot shift to use for them.  A
  * test then counts only the rows valid in all of its variables. */
 int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const double* shift);
+/* LinearCorrelation::pvalue on a table with nulls (continuous/linearcorrelation.cpp:20-122, pvalue_impl): covariance of
+ * [v1, v2, cond...] over the rows valid in all of them, then the partial-correlation t-test with valid_rows - 2 - n_cond
+ * degrees of freedom.  pbn_ci_pvalue_fn signature, user = a pbn_mi handle over continuous columns. */
+double pbn_mi_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes);
 /* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
  * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies

@@ -969,6 +969,47 @@ double pbn_mi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
     return gamma_q(0.5 * df, 0.5 * (mi * 2.0 * rows));
 }
 
+// LinearCorrelation::pvalue on a table with nulls (continuous/linearcorrelation.cpp:20-122, the pvalue_impl branch): the
+// covariance of [v1, v2, cond...] over the rows valid in all of them - one pass of the NaN-skipping moments kernel - then
+// the same partial-correlation t-test as the cached form, with `valid rows - 2 - |cond|` degrees of freedom.
+// pbn_ci_pvalue_fn signature over a pbn_mi handle whose variables are all continuous.
+double pbn_mi_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
+    pbn_mi* h = (pbn_mi*)user;
+    double result = std::nan("");
+    (void)guarded([&] {
+        if (!h || (n_cond > 0 && !cond)) throw invalid_error("pbn_mi_lincor_pvalue: null argument");
+        std::vector<int> vars{v1, v2};
+        vars.insert(vars.end(), cond, cond + n_cond);
+        if (!h->order.empty())
+            for (int& v : vars) {
+                if (v < 0 || v >= (int)h->order.size()) throw invalid_error("LinearCorrelation: variable index out of range");
+                v = h->order[v];
+            }
+        for (int v : vars)
+            if (v < 0 || v >= h->n_cont) throw invalid_error("LinearCorrelation: variable is not continuous");
+        Engine e{h};
+        std::vector<double> st;
+        e.group_stats(vars, {}, 1, st);
+        const int c = (int)vars.size();
+        const double n = st[0];
+        if (!(n > c)) throw invalid_error("LinearCorrelation: not enough valid rows");
+        std::vector<double> cov((size_t)c * c);
+        int pos = 1 + c;
+        for (int i = 0; i < c; ++i)
+            for (int j = i; j < c; ++j) {
+                const double v = (st[pos++] - st[1 + i] * st[1 + j] / n) / (n - 1.0);
+                cov[i + (size_t)j * c] = cov[j + (size_t)i * c] = v;
+            }
+        pbn_lincor* lc = nullptr;
+        if (pbn_lincor_from_cov(c, (int64_t)n, cov.data(), &lc) != PBN_OK) throw device_error(pbn_last_error());
+        std::vector<int> zc(std::max(1, n_cond));
+        for (int i = 0; i < n_cond; ++i) zc[i] = 2 + i;
+        result = pbn_lincor_pvalue(lc, 0, 1, n_cond, zc.data());
+        pbn_lincor_destroy(lc);
+    });
+    return result;
+}
+
 // Batched form: n_tests independence tests in as few launches as scratch memory allows (pbn_ci_pvalue_batch_fn).
 // cond_off has n_tests + 1 entries into cond.  NaN in out[i] marks a failed test (pbn_last_error has the last reason).
 void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, const int* cond_off, const int* cond, double* out) {

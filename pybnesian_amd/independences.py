@@ -60,12 +60,17 @@ class LinearCorrelation(IndependenceTest):
         cont = [f.name for f in rb.schema if pa.types.is_floating(f.type)]
         if len(cont) < 2:
             raise ValueError("DataFrame does not contain enough continuous columns.")
-        if any(rb.column(rb.schema.get_field_index(c)).null_count for c in cont):
-            raise ValueError("LinearCorrelation on the device needs columns without nulls.")
         self._all_names = [f.name for f in rb.schema]
         self._names = cont
         self._index = {n: i for i, n in enumerate(cont)}
         ctx = ctx or default_context()
+        self._handle = None
+        self._per_test = None
+        if any(rb.column(rb.schema.get_field_index(c)).null_count for c in cont):
+            # nulls: no cached covariance - every test takes the covariance of ITS variables over the rows valid in all
+            # of them (continuous/linearcorrelation.cpp:20-122, the pvalue_impl branch), one device pass per test
+            self._per_test = MutualInformation(rb.select(cont), True, ctx)
+            return
         table, _ = DeviceTable.from_dataframe(ctx, rb, cont, drop_null=False)
         h = C.c_void_p()
         _lib.check(_lib.load().pbn_lincor_create(ctx.handle, table.handle, C.byref(h)))
@@ -75,6 +80,7 @@ class LinearCorrelation(IndependenceTest):
     def from_covariance(cls, names, cov, num_rows):
         """A test over a covariance matrix already at hand (host only, no device work)."""
         self = cls.__new__(cls)
+        self._per_test = None
         self._all_names = self._names = list(names)
         self._index = {n: i for i, n in enumerate(self._names)}
         cov = np.asfortranarray(cov, dtype=np.float64)
@@ -91,12 +97,21 @@ class LinearCorrelation(IndependenceTest):
     def pvalue(self, x, y, z=None):
         cond = [] if z is None else ([z] if isinstance(z, str) else list(z))
         arr = _lib.int_array([self._idx(c) for c in cond] or [0])
-        p = _lib.load().pbn_lincor_pvalue(self._handle, self._idx(x), self._idx(y), len(cond), arr)
+        lib = _lib.load()
+        if self._per_test is not None:
+            _lib.check(lib.pbn_mi_set_order(self._per_test._handle, 0, None))
+            p = lib.pbn_mi_lincor_pvalue(self._per_test._handle, self._idx(x), self._idx(y), len(cond), arr)
+            if np.isnan(p):
+                raise ValueError("LinearCorrelation: " + lib.pbn_last_error().decode())
+            return p
+        p = lib.pbn_lincor_pvalue(self._handle, self._idx(x), self._idx(y), len(cond), arr)
         if np.isnan(p):
             raise ValueError("LinearCorrelation: bad variable index")
         return p
 
     def covariance(self):
+        if self._per_test is not None:
+            raise ValueError("LinearCorrelation over a table with nulls keeps no covariance: every test uses its own valid rows.")
         n = len(self._names)
         cov = np.zeros((n, n), order="F")
         _lib.check(_lib.load().pbn_lincor_cov(self._handle, _lib.dptr(cov)))
@@ -106,6 +121,10 @@ class LinearCorrelation(IndependenceTest):
         return list(self._all_names)
 
     def _ci_callback(self, nodes):
+        if self._per_test is not None:
+            lib = _lib.load()
+            _lib.check(lib.pbn_mi_set_order(self._per_test._handle, len(nodes), _lib.int_array([self._idx(n) for n in nodes])))
+            return C.cast(lib.pbn_mi_lincor_pvalue, C.c_void_p), self._per_test._handle, self, []
         # native fast path: the C function itself is the callback, no Python frame per test
         if all(n in self._index for n in nodes) and [self._index[n] for n in nodes] == list(range(len(nodes))) and len(nodes) == len(self._names):
             lib = _lib.load()

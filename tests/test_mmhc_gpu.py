@@ -82,3 +82,32 @@ def test_mmhc_gaussian_end_to_end(pbn):
     assert sp.num_arcs() <= 3
     with pytest.raises(ValueError, match="do not contain all the variables"):
         mm.estimate(test, pbn.ArcOperatorSet(), score, nodes=["x0", "zz"])
+
+
+def test_linear_correlation_with_nulls(pbn):
+    """continuous/linearcorrelation.cpp:20-122 (pvalue_impl): with nulls every test uses the covariance of ITS variables
+    over the rows valid in all of them and valid_rows - 2 - |cond| degrees of freedom."""
+    from oracle import mmpc_oracle
+
+    df = dag_data(6000, 7, 2)
+    rng = np.random.default_rng(4)
+    for c, frac in (("x1", 0.04), ("x3", 0.07), ("x6", 0.02)):
+        df.loc[df.index[rng.random(len(df)) < frac], c] = np.nan
+    test = pbn.LinearCorrelation(df)
+    names = list(df.columns)
+    for _ in range(60):
+        k = int(rng.integers(0, 4))
+        sel = [names[i] for i in rng.choice(7, size=k + 2, replace=False)]
+        sub = df[sel].dropna()
+        cov = np.atleast_2d(np.cov(sub.to_numpy(), rowvar=False))
+        want = mmpc_oracle.lincor_pvalue(cov, len(sub), 0, 1, list(range(2, k + 2)))
+        got = test.pvalue(sel[0], sel[1], sel[2:] if k != 1 else sel[2])
+        assert got == pytest.approx(want, rel=1e-8, abs=1e-300), (sel, got, want)
+    with pytest.raises(ValueError, match="keeps no covariance"):
+        test.covariance()
+    # the same test drives MMPC through the native callback
+    from pybnesian_amd.independences import mmpc_cpcs
+
+    cpcs, ntests = mmpc_cpcs(test, names, 0.01)
+    clean, _ = mmpc_cpcs(pbn.LinearCorrelation(dag_data(6000, 7, 2)), names, 0.01)
+    assert ntests > 0 and [sorted(c) for c in cpcs] == [sorted(c) for c in clean]
