@@ -333,6 +333,10 @@ int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const dou
  * [v1, v2, cond...] over the rows valid in all of them, then the partial-correlation t-test with valid_rows - 2 - n_cond
  * degrees of freedom.  pbn_ci_pvalue_fn signature, user = a pbn_mi handle over continuous columns. */
 double pbn_mi_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);
+/* joint_counts (factors/discrete/discrete_indices.cpp:134-150) of n_vars categorical variables of the handle: out has
+ * prod(cardinality) entries, index = sum code_i * stride_i with the first variable fastest.  Serves BDe (learning/scores/
+ * bde.cpp:5-50). */
+int pbn_mi_counts(pbn_mi* h, int n_vars, const int* vars, double* out);
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes);
 /* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
  * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies

@@ -21,10 +21,10 @@ from .models import (BayesianNetwork, BayesianNetworkType, FactorType, Condition
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load,
                      ConditionalDiscreteBN, ConditionalHeterogeneousBN, ConditionalHomogeneousBN, DiscreteBN, DiscreteBNType,
                      HeterogeneousBN, HeterogeneousBNType, HomogeneousBN, HomogeneousBNType, Dag, ConditionalDag)
-from .dynamic import (DynamicBayesianNetworkBase, DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN,  # noqa: F401
+from .dynamic import (DynamicBDe, DynamicBayesianNetworkBase, DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN,  # noqa: F401
                       DynamicIndependenceTest, DynamicScore)
 from .models import BayesianNetworkBase, ConditionalBayesianNetworkBase  # noqa: F401
-from .scores import (Args, Arguments, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
+from .scores import (Args, Arguments, BDe, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
                      ValidatedScore)
 
 __all__ = [
@@ -38,5 +38,5 @@ __all__ = [
     "ConditionalHomogeneousBN", "ConditionalHeterogeneousBN", "DynamicDiscreteBN", "DynamicCLGNetwork", "DynamicHomogeneousBN",
     "DynamicHeterogeneousBN", "Dag", "ConditionalDag", "Operator", "ArcOperator", "OperatorSet", "SaveModel", "LinearGaussianParams",
     "DiscreteFactorParams", "MLELinearGaussianCPD", "MLEDiscreteFactor", "BayesianNetworkBase", "ConditionalBayesianNetworkBase",
-    "DynamicBayesianNetworkBase", "DynamicScore", "DynamicIndependenceTest",
+    "DynamicBayesianNetworkBase", "DynamicScore", "DynamicIndependenceTest", "BDe", "DynamicBDe",
 ]

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pbn_mi_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_mi_set_continuous_nulls": (_int, [_vp, C.POINTER(C.c_ubyte), _dp]),
     "pbn_mi_lincor_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
+    "pbn_mi_counts": (_int, [_vp, _int, _ip, _dp]),
     "pbn_mmpc_cpcs": (_int, [_int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_mmpc_cpcs_conditional": (_int, [_int, _int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_mmpc_cpcs_batched": (_int, [_int, _int, _vp, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),

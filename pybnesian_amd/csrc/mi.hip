@@ -1105,6 +1105,27 @@ double pbn_chisq_pvalue(void* user, int v1, int v2, int n_cond, const int* cond)
     return rc == PBN_OK ? result : std::nan("");
 }
 
+// Joint counts of discrete variables (factors/discrete/discrete_indices.cpp:134-150 joint_counts): out[sum_i code_i *
+// stride_i], the first variable fastest, prod(cardinality) entries, rows with a null in any of the variables left out.
+// The counts are the segment lengths of the cached row grouping of that variable set.
+int pbn_mi_counts(pbn_mi* h, int n_vars, const int* vars, double* out) {
+    return guarded([&] {
+        if (!h || !vars || !out || n_vars < 1) throw invalid_error("pbn_mi_counts: null argument");
+        std::vector<int> v(vars, vars + n_vars);
+        if (!h->order.empty())
+            for (int& x : v) {
+                if (x < 0 || x >= (int)h->order.size()) throw invalid_error("pbn_mi_counts: variable index out of range");
+                x = h->order[x];
+            }
+        for (int x : v)
+            if (x < h->n_cont || x >= h->n_cont + h->n_disc) throw invalid_error("pbn_mi_counts: variable is not categorical");
+        Engine e{h};
+        std::vector<double> st;
+        e.group_stats({}, v, 1, st);
+        std::copy(st.begin(), st.end(), out);
+    });
+}
+
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes) {
     return guarded([&] {
         if (!h) throw invalid_error("pbn_mi_stats: null argument");

@@ -176,6 +176,7 @@ def _adaptator(kind, base_name):
 
 DynamicBIC = _adaptator(DynamicScoreAdaptator, "BIC")
 DynamicBGe = _adaptator(DynamicScoreAdaptator, "BGe")
+DynamicBDe = _adaptator(DynamicScoreAdaptator, "BDe")
 DynamicCVLikelihood = _adaptator(DynamicScoreAdaptator, "CVLikelihood")
 DynamicHoldoutLikelihood = _adaptator(DynamicScoreAdaptator, "HoldoutLikelihood")
 DynamicValidatedLikelihood = _adaptator(DynamicScoreAdaptator, "ValidatedLikelihood")

@@ -38,6 +38,8 @@ def _bn_code(bn_type):
             return _lib.PBN_BN_GAUSSIAN
         if d == CKDEType():
             return _lib.PBN_BN_KDE
+        if d == DiscreteFactorType():
+            return _lib.PBN_BN_GAUSSIAN   # every arc between discrete nodes is legal: the unrestricted family; the score decides
         raise ValueError(f"The hill-climbing engine has no factor family for the default node type {d} of {bn_type}.")
     return _lib.PBN_BN_SEMIPARAMETRIC
 

@@ -480,6 +480,83 @@ class _ScoreView:
         return float(np.sum(self._parent._batch(model, cands, self._kind)))
 
 
+class BDe(Score):
+    """learning/scores/bde.{hpp,cpp}: Bayesian Dirichlet equivalent score of discrete networks, BDe(df, iss=1).  The joint
+    counts come from the device (the cached row groupings of pbn_mi, `pbn_mi_counts`); the log-gamma sums over the counts
+    are host arithmetic on at most prod(cardinality) numbers."""
+
+    def __init__(self, df, iss=1.0, ctx=None):
+        import pyarrow as pa
+
+        from .dataset import as_record_batch
+        from .independences import MutualInformation
+
+        rb = as_record_batch(df)
+        self._rb = rb
+        self._iss = float(iss)
+        self._names = [f.name for f in rb.schema]
+        disc = [f.name for f in rb.schema if pa.types.is_dictionary(f.type)]
+        self._counts = MutualInformation(rb.select(disc), True, ctx) if disc else None
+        self._card = {d: len(rb.column(rb.schema.get_field_index(d)).dictionary) for d in disc}
+
+    def __str__(self):
+        return "BDe"
+
+    def has_variables(self, variables):
+        variables = [variables] if isinstance(variables, str) else list(variables)
+        return all(v in self._names for v in variables)
+
+    def compatible_bn(self, model):
+        from .models import DiscreteFactorType
+
+        t = model.type()
+        nodes = model.joint_nodes() if model.interface_nodes() else model.nodes()
+        return bool(t.is_homogeneous()) and t.default_node_type() == DiscreteFactorType() and self.has_variables(nodes)
+
+    def data(self):
+        return self._rb
+
+    def _joint_counts(self, variables):
+        for v in variables:
+            if v not in self._card:
+                raise ValueError(f"Variable {v} is not categorical.")
+        lib = _lib.load()
+        h = self._counts._handle
+        _lib.check(lib.pbn_mi_set_order(h, 0, None))
+        out = np.zeros(int(np.prod([self._card[v] for v in variables])))
+        _lib.check(lib.pbn_mi_counts(h, len(variables), _lib.int_array([self._counts._var(v) for v in variables]), _lib.dptr(out)))
+        return out
+
+    def _bde(self, variable, parents):
+        from math import lgamma
+
+        counts = self._joint_counts([variable] + list(parents))
+        card0 = self._card[variable]
+        total = counts.size
+        alpha = self._iss / total
+        res = -total * lgamma(alpha) + float(sum(lgamma(m + alpha) for m in counts))
+        if not parents:   # bde.cpp:5-21
+            return res + lgamma(self._iss) - lgamma(self._iss + float(counts.sum()))
+        sums = counts.reshape(-1, card0).sum(axis=1)   # bde.cpp:23-50: one term per parent configuration
+        sum_alpha = alpha * card0
+        return res + float(sum(lgamma(sum_alpha) - lgamma(sum_alpha + s) for s in sums))
+
+    def local_score(self, model, variable, evidence=None):
+        from .models import DiscreteFactorType
+
+        evidence = model.parents(variable) if evidence is None else list(evidence)
+        if model.node_type(variable) != DiscreteFactorType():
+            raise ValueError(f"Bayesian network type \"{model.type()}\" not valid for score BDe")
+        return self._bde(variable, evidence)
+
+    def local_score_node_type(self, model, variable_type, variable, evidence):
+        from .models import DiscreteFactorType
+
+        if variable_type != DiscreteFactorType():
+            raise ValueError(f"Node type \"{variable_type}\" not valid for score BDe")
+        return self._bde(variable, list(evidence))
+
+
 class CrossValidationView:
     """dataset::CrossValidation as seen from Python (pybindings_dataset.cpp): iterating yields (train, test) tables;
     `.indices()` yields (train_indices, test_indices) exactly as generate_cv_pair_indices (crossvalidation_adaptator.cpp)."""

@@ -248,3 +248,49 @@ def test_hc_validated_and_shortcut(pbn, golden):   # hillclimbing_test.py:103-20
 
     estimated = hc.estimate(arc_set, pbn.BIC(df), ExtraNewBN(ABCD))
     assert type(estimated) is ExtraNewBN and estimated.extra_data == "extra"
+
+
+def test_bde_score_and_discrete_hill_climb(pbn):
+    """learning/scores/bde.cpp:5-50 against a direct restatement on pandas counts; the hill-climb of a DiscreteBN driven
+    by it (counts from the device groupings, per-candidate Python score calls as for any derived Score)."""
+    from math import lgamma
+
+    df = discrete_dependent(5000, 3)
+    bde = pbn.BDe(df, iss=2.0)
+    model = pbn.DiscreteBN(ABCD)
+    assert bde.compatible_bn(model) and not bde.compatible_bn(pbn.GaussianNetwork(ABCD)) and bde.has_variables(["a", "d"])
+
+    def restated(variable, parents, iss=2.0):
+        cards = {c: len(df[c].cat.categories) for c in df.columns}
+        total = int(np.prod([cards[v] for v in [variable] + parents]))
+        alpha = iss / total
+        res = -total * lgamma(alpha)
+        if not parents:
+            counts = df[variable].value_counts().reindex(df[variable].cat.categories, fill_value=0)
+            return res + sum(lgamma(m + alpha) for m in counts) + lgamma(iss) - lgamma(iss + len(df))
+        import itertools
+
+        for config in itertools.product(*[df[p].cat.categories for p in parents]):   # every configuration, also unseen ones
+            rows = np.ones(len(df), dtype=bool)
+            for p, value in zip(parents, config):
+                rows &= (df[p] == value).to_numpy()
+            counts = df[variable][rows].value_counts().reindex(df[variable].cat.categories, fill_value=0)
+            res += sum(lgamma(m + alpha) for m in counts)
+            res += lgamma(alpha * cards[variable]) - lgamma(alpha * cards[variable] + counts.sum())
+        return res
+
+    for variable, parents in (("a", []), ("b", ["a"]), ("c", ["b"]), ("c", ["a", "b"]), ("d", ["c", "a", "b"])):
+        assert bde.local_score(model, variable, parents) == pytest.approx(restated(variable, parents), rel=1e-12)
+    model.add_arc("a", "b")
+    assert bde.local_score(model, "b") == bde.local_score(model, "b", ["a"])
+    assert bde.score(model) == pytest.approx(sum(bde.local_score(model, v) for v in ABCD), rel=1e-12)
+    with pytest.raises(ValueError, match="not valid for score BDe"):
+        bde.local_score(pbn.GaussianNetwork(ABCD), "a", [])
+
+    learned = pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), bde, pbn.DiscreteBN(ABCD))
+    assert type(learned) is pbn.DiscreteBN
+    skeleton = {frozenset(a) for a in learned.arcs()}
+    assert frozenset(("a", "b")) in skeleton and frozenset(("b", "c")) in skeleton
+    assert not any("d" in e for e in skeleton)            # d is independent of everything
+    learned.fit(df)
+    assert learned.fitted() and np.isfinite(learned.slogl(df))
