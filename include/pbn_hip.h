@@ -338,6 +338,18 @@ double pbn_mi_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* c
  * bde.cpp:5-50). */
 int pbn_mi_counts(pbn_mi* h, int n_vars, const int* vars, double* out);
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes);
+/* ---- k-nearest-neighbour mutual information (learning/independences/continuous/mutual_information.{hpp,cpp}:
+ * KMutualInformation).  cols: n_vars host columns of N values as double.  Ranks as rank_data (:17-52); MI by the KSG /
+ * Frenzel-Pompe estimator on the ranks (mi_pair :9-43, mi_triple :45-116, mi_general :118-145) with brute-force
+ * neighbour kernels instead of the kd-tree; p-values by `samples` permutations drawn exactly as the reference draws them
+ * (:157-190, hpp:128-206; seeded std::mt19937). */
+typedef struct pbn_kmi pbn_kmi;
+int pbn_kmi_create(pbn_ctx* ctx, const double* const* cols, int n_vars, int64_t N, int k, uint32_t seed, int shuffle_neighbors,
+                   int samples, pbn_kmi** out);
+void pbn_kmi_destroy(pbn_kmi* h);
+int pbn_kmi_value(pbn_kmi* h, int v1, int v2, int n_cond, const int* cond, double* mi);
+double pbn_kmi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond);   /* pbn_ci_pvalue_fn */
+
 /* mmpc_all_variables (learning/algorithms/mmpc.cpp:910-966; forward / backward phases :356-644): candidate
  * parents-and-children of every variable.  Lists are pairs of node indices.  symmetric != 0 applies
  * remove_asymmetries (learning/algorithms/mmhc.cpp:12-22).  cpc_off: n+1 offsets into cpc (capacity n*(n-1)). */

@@ -428,3 +428,14 @@ def hybrid_cv(fn, n, k, seed):
 def hybrid_holdout(fn, n, ratio, seed):
     tr, te = holdout_split(n, ratio, seed)
     return fn(tr, te)
+
+
+def kmi(data, k, seed=0, shuffle_neighbors=5, samples=0):
+    """KMutualInformation on the columns of `data` = [x, y, z...] (N x dims): (mi, pvalue); pvalue is None when samples == 0."""
+    a = np.asfortranarray(np.asarray(data, dtype=np.float64))
+    n, d = a.shape
+    cols = (C.c_void_p * d)(*[a[:, j].ctypes.data for j in range(d)])
+    mi, pv = C.c_double(0.0), C.c_double(0.0)
+    lib().oracle_kmi(cols, C.c_int(d), C.c_int64(n), C.c_int(k), C.c_uint32(seed), C.c_int(shuffle_neighbors), C.c_int(max(samples, 1)),
+                     C.byref(mi), C.byref(pv) if samples else None)
+    return mi.value, (pv.value if samples else None)

@@ -15,13 +15,13 @@ from .learning import (AddArc, ArcOperator, ArcOperatorSet, Callback, Operator, 
 from .dynamic import (DMMHC, DynamicBayesianNetwork, DynamicGaussianNetwork, DynamicKDENetwork, DynamicSemiparametricBN, DynamicBGe, DynamicBIC, DynamicChiSquare, DynamicCVLikelihood,  # noqa: F401
                       DynamicDataFrame, DynamicHoldoutLikelihood, DynamicIndependenceTestAdaptator, DynamicLinearCorrelation,
                       DynamicMutualInformation, DynamicScoreAdaptator, DynamicValidatedLikelihood)
-from .independences import ChiSquare, IndependenceTest, LinearCorrelation, MutualInformation  # noqa: F401
+from .independences import ChiSquare, IndependenceTest, KMutualInformation, LinearCorrelation, MutualInformation  # noqa: F401
 from .models import (BayesianNetwork, BayesianNetworkType, FactorType, ConditionalBayesianNetwork, ConditionalCLGNetwork, ConditionalGaussianNetwork,  # noqa: F401
                      ConditionalKDENetwork, ConditionalSemiparametricBN, CKDEType, CLGNetwork, CLGNetworkType, DiscreteFactorType, GaussianNetwork, GaussianNetworkType, KDENetwork, KDENetworkType,  # noqa: F401
                      LinearGaussianCPDType, SemiparametricBN, SemiparametricBNType, UnknownFactorType, load,
                      ConditionalDiscreteBN, ConditionalHeterogeneousBN, ConditionalHomogeneousBN, DiscreteBN, DiscreteBNType,
                      HeterogeneousBN, HeterogeneousBNType, HomogeneousBN, HomogeneousBNType, Dag, ConditionalDag)
-from .dynamic import (DynamicBDe, DynamicBayesianNetworkBase, DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN,  # noqa: F401
+from .dynamic import (DynamicBDe, DynamicBayesianNetworkBase, DynamicKMutualInformation, DynamicCLGNetwork, DynamicDiscreteBN, DynamicHeterogeneousBN, DynamicHomogeneousBN,  # noqa: F401
                       DynamicIndependenceTest, DynamicScore)
 from .models import BayesianNetworkBase, ConditionalBayesianNetworkBase  # noqa: F401
 from .scores import (Args, Arguments, BDe, BGe, BIC, CVLikelihood, HoldoutLikelihood, Kwargs, Score, ValidatedLikelihood,  # noqa: F401
@@ -38,5 +38,6 @@ __all__ = [
     "ConditionalHomogeneousBN", "ConditionalHeterogeneousBN", "DynamicDiscreteBN", "DynamicCLGNetwork", "DynamicHomogeneousBN",
     "DynamicHeterogeneousBN", "Dag", "ConditionalDag", "Operator", "ArcOperator", "OperatorSet", "SaveModel", "LinearGaussianParams",
     "DiscreteFactorParams", "MLELinearGaussianCPD", "MLEDiscreteFactor", "BayesianNetworkBase", "ConditionalBayesianNetworkBase",
-    "DynamicBayesianNetworkBase", "DynamicScore", "DynamicIndependenceTest", "BDe", "DynamicBDe",
+    "DynamicBayesianNetworkBase", "DynamicScore", "DynamicIndependenceTest", "BDe", "DynamicBDe", "KMutualInformation",
+    "DynamicKMutualInformation",
 ]

@@ -95,6 +95,10 @@ SIGNATURES = {
     "pbn_mi_set_continuous_nulls": (_int, [_vp, C.POINTER(C.c_ubyte), _dp]),
     "pbn_mi_lincor_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
     "pbn_mi_counts": (_int, [_vp, _int, _ip, _dp]),
+    "pbn_kmi_create": (_int, [_vp, C.POINTER(_vp), _int, _i64, _int, C.c_uint32, _int, _int, C.POINTER(_vp)]),
+    "pbn_kmi_destroy": (None, [_vp]),
+    "pbn_kmi_value": (_int, [_vp, _int, _int, _int, _ip, _dp]),
+    "pbn_kmi_pvalue": (C.c_double, [_vp, _int, _int, _int, _ip]),
     "pbn_mmpc_cpcs": (_int, [_int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_mmpc_cpcs_conditional": (_int, [_int, _int, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),
     "pbn_mmpc_cpcs_batched": (_int, [_int, _int, _vp, _vp, _vp, C.c_double, _int, _ip, _int, _ip, _int, _ip, _int, _ip, _ip, C.POINTER(_i64)]),

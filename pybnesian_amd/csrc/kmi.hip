@@ -1,0 +1,395 @@
+// k-nearest-neighbour conditional mutual information on rank-transformed data with permutation p-values
+// (learning/independences/continuous/mutual_information.{hpp,cpp}: KMutualInformation; kdtree/kdtree.hpp supplies the
+// neighbour queries there).  SURVEY.md §8 f1.
+//
+// The reference ranks every column (0 .. N-1), finds for every row i the Chebyshev distance eps_i to its k-th neighbour
+// in the joint (x, y, z) rank space with a kd-tree, counts the rows strictly inside eps_i in the (x, z), (y, z) and z
+// subspaces with another kd-tree walk, and averages digammas of the counts (Frenzel-Pompe / KSG estimator).  The trees
+// only accelerate exact set counts, so here both steps are brute-force kernels over all N^2 pairs on integer ranks - every
+// thread owns one row, the other rows stream through LDS tiles - which is the same pairwise-distance shape as the KDE
+// sweep and gives bit-identical counts.  The permutation p-values keep the reference's host procedure call for call
+// (std::mt19937, std::shuffle, std::uniform_real_distribution<float>, std::sort of libstdc++, which this library is
+// built against too); each permuted sample costs one upload of the permuted x ranks and the two kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <random>
+
+#include "common.hpp"
+
+using namespace pbn;
+
+#define KMI_MAX_DIM 16     // x, y and up to 14 conditioning variables
+#define KMI_MAX_K 64
+#define KMI_TILE 256
+
+struct pbn_kmi {
+    pbn_ctx* ctx = nullptr;
+    int64_t N = 0;
+    int n_vars = 0, k = 0, shuffle_neighbors = 5, samples = 1000;
+    uint32_t seed = 0;
+    std::vector<std::vector<float>> ranks;     // [n_vars][N] rank of every row in every column (rank_data, :17-52)
+    std::vector<std::vector<double>> values;   // [n_vars][N] original values (neighbours in z for the conditional shuffle)
+    dev_buf<float> d_ranks;                    // [n_vars][N]
+    dev_buf<double> d_values;                  // [n_vars][N]
+    dev_buf<float> d_x;                        // [N] permuted x ranks of the current sample
+    dev_buf<int32_t> d_eps, d_cnt;             // [N], [3][N]
+    dev_buf<int32_t> d_nbr;                    // [N][shuffle_neighbors]
+    std::vector<double> harmonic;              // digamma(n) = harmonic[n - 1] - gamma for integer n
+    int64_t evaluations = 0;
+};
+
+namespace {
+
+struct KmiArgs {
+    const float* col[KMI_MAX_DIM];   // col[0] = x (possibly the permuted copy), col[1] = y, col[2..] = z
+    int dims;
+    int64_t n;
+    int k;
+    int32_t* eps;
+    int32_t* cnt;   // [3][n]: n_xz, n_yz, n_z
+};
+
+// eps_i = Chebyshev distance from row i to its k-th neighbour (the row itself, at distance 0, is the 0-th): the (k+1)-th
+// smallest of the N distances.  Every thread keeps its k+1 smallest distances in a sorted array; once it is full only a
+// closer row costs an insertion.
+// D: number of columns when it is one of the instantiated small values (coordinates in registers, loops unrolled), 0 = any
+// (runtime a.dims); TILE: rows per block - small tables use 64 so that more compute units get a block.
+template <int D, int TILE>
+__global__ __launch_bounds__(TILE) void kmi_eps_kernel(KmiArgs a) {
+    constexpr int MAXD = D ? D : KMI_MAX_DIM;
+    __shared__ float tile[MAXD][TILE];
+    const int dims = D ? D : a.dims;
+    const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
+    float mine[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) mine[d] = (d < dims && i < a.n) ? a.col[d][i] : 0.f;
+    float best[KMI_MAX_K + 1];
+    const int keep = a.k + 1;
+    for (int q = 0; q < keep; ++q) best[q] = INFINITY;
+    float worst = INFINITY;   // best[keep - 1], kept in a register: the array itself lives in scratch (dynamic index)
+    for (int64_t j0 = 0; j0 < a.n; j0 += TILE) {
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+            if (d < dims) tile[d][threadIdx.x] = j < a.n ? a.col[d][j] : 0.f;
+        __syncthreads();
+        const int cnt = (int)((a.n - j0 < TILE) ? a.n - j0 : TILE);
+        for (int t = 0; t < cnt; ++t) {
+            float dist = 0.f;
+#pragma unroll
+            for (int d = 0; d < MAXD; ++d)
+                if (d < dims) dist = fmaxf(dist, fabsf(mine[d] - tile[d][t]));
+            if (dist < worst) {
+                int q = keep - 1;
+                while (q > 0 && best[q - 1] > dist) { best[q] = best[q - 1]; --q; }
+                best[q] = dist;
+                worst = best[keep - 1];
+            }
+        }
+        __syncthreads();
+    }
+    if (i < a.n) a.eps[i] = (int32_t)best[keep - 1];
+}
+
+// counts of rows strictly inside eps_i: in z (Chebyshev over the conditioning columns), and of those the ones whose x /
+// y rank is also strictly inside (kdtree.hpp:474-520; mutual_information.cpp:63-105 for one conditioning variable)
+template <int D, int TILE>
+__global__ __launch_bounds__(TILE) void kmi_count_kernel(KmiArgs a) {
+    constexpr int MAXD = D ? D : KMI_MAX_DIM;
+    __shared__ float tile[MAXD][TILE];
+    const int dims = D ? D : a.dims;
+    const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
+    float mine[MAXD];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) mine[d] = (d < dims && i < a.n) ? a.col[d][i] : 0.f;
+    const float eps = i < a.n ? (float)a.eps[i] : 0.f;
+    int nxz = 0, nyz = 0, nz = 0;
+    for (int64_t j0 = 0; j0 < a.n; j0 += TILE) {
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int d = 0; d < MAXD; ++d)
+            if (d < dims) tile[d][threadIdx.x] = j < a.n ? a.col[d][j] : 0.f;
+        __syncthreads();
+        const int cnt = (int)((a.n - j0 < TILE) ? a.n - j0 : TILE);
+        for (int t = 0; t < cnt; ++t) {
+            float dz = 0.f;
+#pragma unroll
+            for (int d = 2; d < MAXD; ++d)
+                if (d < dims) dz = fmaxf(dz, fabsf(mine[d] - tile[d][t]));
+            if (dz < eps) {
+                ++nz;
+                nxz += fabsf(mine[0] - tile[0][t]) < eps;
+                nyz += fabsf(mine[1] - tile[1][t]) < eps;
+            }
+        }
+        __syncthreads();
+    }
+    if (i < a.n) { a.cnt[i] = nxz; a.cnt[a.n + i] = nyz; a.cnt[2 * a.n + i] = nz; }
+}
+
+// the `m` nearest rows of every row in the space of the ORIGINAL conditioning values (Chebyshev), nearest first, the row
+// itself included (kdtree query of shuffled_pvalue, mutual_information.hpp:178-188)
+struct NbrArgs {
+    const double* col[KMI_MAX_DIM];
+    int dims;
+    int64_t n;
+    int m;
+    int32_t* out;   // [n][m]
+};
+__global__ __launch_bounds__(KMI_TILE) void kmi_neighbors_kernel(NbrArgs a) {
+    __shared__ double tile[KMI_MAX_DIM][KMI_TILE];
+    const int64_t i = (int64_t)blockIdx.x * KMI_TILE + threadIdx.x;
+    double mine[KMI_MAX_DIM];
+    for (int d = 0; d < a.dims; ++d) mine[d] = i < a.n ? a.col[d][i] : 0.0;
+    double best[KMI_MAX_K];
+    int32_t who[KMI_MAX_K];
+    for (int q = 0; q < a.m; ++q) { best[q] = INFINITY; who[q] = -1; }
+    double worst = INFINITY;
+    for (int64_t j0 = 0; j0 < a.n; j0 += KMI_TILE) {
+        const int64_t j = j0 + threadIdx.x;
+        for (int d = 0; d < a.dims; ++d) tile[d][threadIdx.x] = j < a.n ? a.col[d][j] : 0.0;
+        __syncthreads();
+        const int cnt = (int)((a.n - j0 < KMI_TILE) ? a.n - j0 : KMI_TILE);
+        for (int t = 0; t < cnt; ++t) {
+            double dist = 0.0;
+            for (int d = 0; d < a.dims; ++d) dist = fmax(dist, fabs(mine[d] - tile[d][t]));
+            if (dist < worst) {
+                int q = a.m - 1;
+                while (q > 0 && best[q - 1] > dist) { best[q] = best[q - 1]; who[q] = who[q - 1]; --q; }
+                best[q] = dist; who[q] = (int32_t)(j0 + t);
+                worst = best[a.m - 1];
+            }
+        }
+        __syncthreads();
+    }
+    if (i < a.n)
+        for (int q = 0; q < a.m; ++q) a.out[i * a.m + q] = who[q];
+}
+
+struct IndexLess {   // kdtree::IndexComparator
+    const float* v;
+    bool operator()(size_t a, size_t b) const { return v[a] < v[b]; }
+};
+
+struct Kmi {
+    pbn_kmi* h;
+
+    double digamma_int(int64_t n) const {   // psi(n) = H_{n-1} - gamma
+        static const double EULER = 0.57721566490153286060651209008240243;
+        if (n < 1) return -std::numeric_limits<double>::infinity();
+        return h->harmonic[(size_t)n - 1] - EULER;
+    }
+
+    template <bool EPS, int D, int TILE>
+    void launch_dt(const KmiArgs& a) {
+        const dim3 grid((unsigned)ceil_div(a.n, TILE)), block(TILE);
+        if (EPS) hipLaunchKernelGGL((kmi_eps_kernel<D, TILE>), grid, block, 0, h->ctx->stream, a);
+        else hipLaunchKernelGGL((kmi_count_kernel<D, TILE>), grid, block, 0, h->ctx->stream, a);
+    }
+    template <bool EPS, int D>
+    void launch_d(const KmiArgs& a) {
+        if (a.n < 64 * 1024) launch_dt<EPS, D, 64>(a); else launch_dt<EPS, D, 256>(a);
+    }
+    template <bool EPS>
+    void launch(const KmiArgs& a) {
+        switch (a.dims) {
+            case 2: launch_d<EPS, 2>(a); break;
+            case 3: launch_d<EPS, 3>(a); break;
+            case 4: launch_d<EPS, 4>(a); break;
+            case 5: launch_d<EPS, 5>(a); break;
+            case 6: launch_d<EPS, 6>(a); break;
+            default: launch_d<EPS, 0>(a); break;
+        }
+    }
+
+    // MI of columns vars = [x, y, z...]; a permuted sample passes its x ranks (device copy + the host original)
+    double evaluate(const std::vector<int>& vars, const float* x_override, const float* x_host = nullptr) {
+        pbn_ctx* ctx = h->ctx;
+        const int64_t N = h->N;
+        KmiArgs a{};
+        a.dims = (int)vars.size(); a.n = N; a.k = h->k;
+        for (int d = 0; d < a.dims; ++d) a.col[d] = h->d_ranks.p + (size_t)vars[d] * N;
+        if (x_override) a.col[0] = x_override;
+        a.eps = h->d_eps.p; a.cnt = h->d_cnt.p;
+        launch<true>(a);
+        ++h->evaluations;
+        std::vector<int32_t> eps((size_t)N), cnt;
+        double res = 0;
+        if (a.dims == 2) {   // mi_pair (mutual_information.cpp:9-43): marginal counts have a closed form on ranks
+            HIP_CHECK(hipMemcpyAsync(eps.data(), h->d_eps.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            const float* x = x_override ? x_host : h->ranks[vars[0]].data();
+            const float* y = h->ranks[vars[1]].data();
+            const int rows = (int)N;
+            for (int i = 0; i < rows; ++i) {
+                const int e = eps[i], v1 = (int)x[i], v2 = (int)y[i];
+                const int nv1 = std::min(1 + v1, e) + std::min(rows - v1, e) - 1;
+                const int nv2 = std::min(1 + v2, e) + std::min(rows - v2, e) - 1;
+                res -= digamma_int(nv1) + digamma_int(nv2);
+            }
+            res /= (double)N;
+            res += digamma_int(h->k) + digamma_int(N);
+            return res;
+        }
+        launch<false>(a);
+        HIP_CHECK(hipGetLastError());
+        cnt.resize((size_t)3 * N);
+        HIP_CHECK(hipMemcpyAsync(cnt.data(), h->d_cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < N; ++i)   // mi_triple / mi_general (mutual_information.cpp:107-114,136-143)
+            res += digamma_int(cnt[2 * N + i]) - digamma_int(cnt[i]) - digamma_int(cnt[N + i]);
+        res /= (double)N;
+        res += digamma_int(h->k);
+        return res;
+    }
+
+    void check(const std::vector<int>& vars) const {
+        if ((int)vars.size() > KMI_MAX_DIM) throw invalid_error("KMutualInformation: conditioning set too large");
+        for (size_t a = 0; a < vars.size(); ++a) {
+            if (vars[a] < 0 || vars[a] >= h->n_vars) throw invalid_error("KMutualInformation: variable index out of range");
+            for (size_t b = 0; b < a; ++b)
+                if (vars[a] == vars[b]) throw invalid_error("KMutualInformation: repeated variable");
+        }
+    }
+
+    // KMutualInformation::pvalue (mutual_information.cpp:157-190, hpp:128-206)
+    double pvalue(const std::vector<int>& vars) {
+        check(vars);
+        pbn_ctx* ctx = h->ctx;
+        const int64_t N = h->N;
+        const double original = evaluate(vars, nullptr);
+        std::mt19937 rng{h->seed};
+        std::vector<float> shuffled(h->ranks[vars[0]]);
+        int count_greater = 0;
+        if (vars.size() == 2) {
+            for (int s = 0; s < h->samples; ++s) {
+                std::shuffle(shuffled.begin(), shuffled.end(), rng);
+                HIP_CHECK(hipMemcpyAsync(h->d_x.p, shuffled.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                if (evaluate(vars, h->d_x.p, shuffled.data()) >= original) ++count_greater;
+            }
+            return (double)count_greater / h->samples;
+        }
+        // neighbours in the space of the original conditioning values
+        const int m = h->shuffle_neighbors;
+        NbrArgs na{};
+        na.dims = (int)vars.size() - 2; na.n = N; na.m = m; na.out = h->d_nbr.p;
+        for (int d = 0; d < na.dims; ++d) na.col[d] = h->d_values.p + (size_t)vars[d + 2] * N;
+        hipLaunchKernelGGL(kmi_neighbors_kernel, dim3((unsigned)ceil_div(N, KMI_TILE)), dim3(KMI_TILE), 0, ctx->stream, na);
+        HIP_CHECK(hipGetLastError());
+        std::vector<int32_t> neighbors((size_t)N * m);   // column i = the m neighbours of row i (MatrixXi(m, N), column-major)
+        HIP_CHECK(hipMemcpyAsync(neighbors.data(), h->d_nbr.p, neighbors.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const float* original_x = h->ranks[vars[0]].data();
+        std::vector<size_t> order((size_t)N), sorted_indices((size_t)N);
+        std::iota(order.begin(), order.end(), 0);
+        std::vector<bool> used((size_t)N);
+        for (int s = 0; s < h->samples; ++s) {
+            std::shuffle(order.begin(), order.end(), rng);
+            // shuffle_dataframe (mutual_information.hpp:128-167)
+            for (int64_t i = 0; i < N; ++i) std::shuffle(neighbors.begin() + i * m, neighbors.begin() + (i + 1) * m, rng);
+            std::uniform_real_distribution<float> tiebreaker(-0.5, 0.5);
+            for (int64_t i = 0; i < N; ++i) {
+                const size_t index = order[(size_t)i];
+                int neighbor_index = 0;
+                for (int j = 0; j < m; ++j) {
+                    neighbor_index = neighbors[index * m + j];
+                    if (!used[(size_t)neighbor_index]) break;
+                }
+                if (used[(size_t)neighbor_index]) {
+                    shuffled[index] = original_x[neighbor_index] + tiebreaker(rng);
+                } else {
+                    shuffled[index] = original_x[neighbor_index];
+                    used[(size_t)neighbor_index] = true;
+                }
+            }
+            std::iota(sorted_indices.begin(), sorted_indices.end(), 0);
+            std::sort(sorted_indices.begin(), sorted_indices.end(), IndexLess{shuffled.data()});
+            for (size_t i = 0; i < sorted_indices.size(); ++i) shuffled[sorted_indices[i]] = (float)i;
+            HIP_CHECK(hipMemcpyAsync(h->d_x.p, shuffled.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            if (evaluate(vars, h->d_x.p, shuffled.data()) >= original) ++count_greater;
+            std::fill(used.begin(), used.end(), false);
+        }
+        return (double)count_greater / h->samples;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// cols: n_vars host columns of N values (already converted to double; a float32 table converts exactly).  The ranks are
+// taken as rank_data does (mutual_information.hpp:17-52): ONE index vector, std::sort'ed column after column.
+int pbn_kmi_create(pbn_ctx* ctx, const double* const* cols, int n_vars, int64_t N, int k, uint32_t seed, int shuffle_neighbors,
+                   int samples, pbn_kmi** out) {
+    return guarded([&] {
+        if (!ctx || !cols || !out) throw invalid_error("pbn_kmi_create: null argument");
+        if (n_vars < 2) throw invalid_error("DataFrame does not contain enough continuous columns.");
+        if (k < 1 || k > KMI_MAX_K || k >= N) throw invalid_error("KMutualInformation: k must be between 1 and min(64, rows - 1)");
+        if (shuffle_neighbors < 1 || shuffle_neighbors > KMI_MAX_K || shuffle_neighbors > N)
+            throw invalid_error("KMutualInformation: shuffle_neighbors must be between 1 and min(64, rows)");
+        if (samples < 1) throw invalid_error("KMutualInformation: samples must be positive");
+        if (N >= (1 << 24)) throw invalid_error("KMutualInformation: ranks are kept in float32 like the reference's: at most 2^24 rows");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        auto h = std::make_unique<pbn_kmi>();
+        h->ctx = ctx; h->N = N; h->n_vars = n_vars; h->k = k; h->seed = seed; h->shuffle_neighbors = shuffle_neighbors; h->samples = samples;
+        h->ranks.assign(n_vars, std::vector<float>((size_t)N));
+        h->values.assign(n_vars, std::vector<double>((size_t)N));
+        std::vector<size_t> indices((size_t)N);
+        std::iota(indices.begin(), indices.end(), 0);
+        for (int j = 0; j < n_vars; ++j) {
+            std::copy(cols[j], cols[j] + N, h->values[j].begin());
+            const double* v = cols[j];
+            std::sort(indices.begin(), indices.end(), [v](size_t a, size_t b) { return v[a] < v[b]; });
+            for (int64_t i = 0; i < N; ++i) h->ranks[j][indices[(size_t)i]] = (float)i;
+        }
+        h->d_ranks.alloc((size_t)n_vars * N); h->d_values.alloc((size_t)n_vars * N);
+        h->d_x.alloc((size_t)N); h->d_eps.alloc((size_t)N); h->d_cnt.alloc((size_t)3 * N); h->d_nbr.alloc((size_t)N * shuffle_neighbors);
+        for (int j = 0; j < n_vars; ++j) {
+            HIP_CHECK(hipMemcpyAsync(h->d_ranks.p + (size_t)j * N, h->ranks[j].data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(h->d_values.p + (size_t)j * N, h->values[j].data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
+        h->harmonic.assign((size_t)N + 1, 0.0);
+        for (int64_t n = 1; n <= N; ++n) h->harmonic[(size_t)n] = h->harmonic[(size_t)n - 1] + 1.0 / (double)n;
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *out = h.release();
+    });
+}
+
+void pbn_kmi_destroy(pbn_kmi* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+}
+
+// KMutualInformation::mi (mutual_information.cpp:142-155)
+int pbn_kmi_value(pbn_kmi* h, int v1, int v2, int n_cond, const int* cond, double* mi) {
+    return guarded([&] {
+        if (!h || !mi || (n_cond > 0 && !cond)) throw invalid_error("pbn_kmi_value: null argument");
+        std::vector<int> vars{v1, v2};
+        vars.insert(vars.end(), cond, cond + n_cond);
+        Kmi e{h};
+        e.check(vars);
+        *mi = e.evaluate(vars, nullptr);
+    });
+}
+
+// pbn_ci_pvalue_fn over a pbn_kmi handle: the permutation p-value with the handle's seed and number of samples
+double pbn_kmi_pvalue(void* user, int v1, int v2, int n_cond, const int* cond) {
+    pbn_kmi* h = (pbn_kmi*)user;
+    double result = std::nan("");
+    (void)guarded([&] {
+        if (!h || (n_cond > 0 && !cond)) throw invalid_error("pbn_kmi_pvalue: null argument");
+        std::vector<int> vars{v1, v2};
+        vars.insert(vars.end(), cond, cond + n_cond);
+        Kmi e{h};
+        result = e.pvalue(vars);
+    });
+    return result;
+}
+
+}  // extern "C"

@@ -183,6 +183,7 @@ DynamicValidatedLikelihood = _adaptator(DynamicScoreAdaptator, "ValidatedLikelih
 DynamicLinearCorrelation = _adaptator(DynamicIndependenceTestAdaptator, "LinearCorrelation")
 DynamicMutualInformation = _adaptator(DynamicIndependenceTestAdaptator, "MutualInformation")
 DynamicChiSquare = _adaptator(DynamicIndependenceTestAdaptator, "ChiSquare")
+DynamicKMutualInformation = _adaptator(DynamicIndependenceTestAdaptator, "KMutualInformation")
 
 
 class DynamicBayesianNetworkBase:

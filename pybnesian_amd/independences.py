@@ -248,6 +248,70 @@ class MutualInformation(IndependenceTest):
             pass
 
 
+class KMutualInformation(IndependenceTest):
+    """pbn.KMutualInformation(df, k, seed=None, shuffle_neighbors=5, samples=1000): k-nearest-neighbour (conditional)
+    mutual information on the rank-transformed continuous columns with permutation p-values
+    (learning/independences/continuous/mutual_information.{hpp,cpp}).  Neighbour distances and ball counts are device
+    kernels over all pairs of rows; the permutations are drawn as the reference draws them."""
+
+    def __init__(self, df, k, seed=None, shuffle_neighbors=5, samples=1000, ctx=None):
+        import pyarrow as pa
+
+        from .factors import _random_seed
+
+        rb = as_record_batch(df)
+        types = {str(f.type) for f in rb.schema}
+        if not all(pa.types.is_floating(f.type) for f in rb.schema) or len(types) != 1:
+            raise ValueError("Wrong data type in KMutualInformation.")
+        if any(rb.column(i).null_count for i in range(rb.num_columns)):
+            raise ValueError("KMutualInformation needs columns without nulls.")
+        self._names = [f.name for f in rb.schema]
+        self._index = {n: i for i, n in enumerate(self._names)}
+        self._seed = _random_seed() if seed is None else int(seed)
+        ctx = ctx or default_context()
+        self._ctx = ctx
+        cols = [np.ascontiguousarray(rb.column(i).to_numpy(zero_copy_only=False), dtype=np.float64) for i in range(rb.num_columns)]
+        ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        h = C.c_void_p()
+        _lib.check(_lib.load().pbn_kmi_create(ctx.handle, ptrs, len(cols), rb.num_rows, int(k), C.c_uint32(self._seed & 0xFFFFFFFF),
+                                              int(shuffle_neighbors), int(samples), C.byref(h)))
+        self._handle = h
+
+    def _idx(self, name):
+        if name not in self._index:
+            raise ValueError(f"Variable {name} not present in KMutualInformation.")
+        return self._index[name]
+
+    def _args(self, x, y, z):
+        cond = [] if z is None else ([z] if isinstance(z, str) else list(z))
+        return self._idx(x), self._idx(y), len(cond), _lib.int_array([self._idx(c) for c in cond] or [0])
+
+    def mi(self, x, y, z=None):
+        v = C.c_double(0.0)
+        a = self._args(x, y, z)
+        _lib.check(_lib.load().pbn_kmi_value(self._handle, a[0], a[1], a[2], a[3], C.byref(v)))
+        return v.value
+
+    def pvalue(self, x, y, z=None):
+        lib = _lib.load()
+        a = self._args(x, y, z)
+        p = lib.pbn_kmi_pvalue(self._handle, a[0], a[1], a[2], a[3])
+        if np.isnan(p):
+            raise ValueError("KMutualInformation: " + lib.pbn_last_error().decode())
+        return p
+
+    def variable_names(self):
+        return list(self._names)
+
+    def __del__(self):
+        try:
+            if _lib.alive() and getattr(self, "_handle", None):
+                _lib.load().pbn_kmi_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
 class ChiSquare(MutualInformation):
     """pbn.ChiSquare(df): Pearson's chi-square test on the categorical columns (learning/independences/discrete/
     chi_square.hpp); shares the device counting pass of MutualInformation."""
