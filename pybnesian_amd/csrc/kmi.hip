@@ -38,6 +38,7 @@ struct pbn_kmi {
     dev_buf<float> d_x;                        // [N] permuted x ranks of the current sample
     dev_buf<int32_t> d_eps, d_cnt;             // [N], [3][N]
     dev_buf<int32_t> d_nbr;                    // [N][shuffle_neighbors]
+    dev_buf<float> d_cand;                     // [slices][k + 1][N]
     std::vector<double> harmonic;              // digamma(n) = harmonic[n - 1] - gamma for integer n
     int64_t evaluations = 0;
 };
@@ -51,48 +52,88 @@ struct KmiArgs {
     int k;
     int32_t* eps;
     int32_t* cnt;   // [3][n]: n_xz, n_yz, n_z
+    int slices;     // the other rows are cut into `slices` ranges (grid.y) so that small tables fill the device too
+    float* cand;    // slices > 1: [slices][k + 1][n] the k + 1 smallest distances every slice found
 };
 
 // eps_i = Chebyshev distance from row i to its k-th neighbour (the row itself, at distance 0, is the 0-th): the (k+1)-th
 // smallest of the N distances.  Every thread keeps its k+1 smallest distances in a sorted array; once it is full only a
 // closer row costs an insertion.
 // D: number of columns when it is one of the instantiated small values (coordinates in registers, loops unrolled), 0 = any
-// (runtime a.dims); TILE: rows per block - small tables use 64 so that more compute units get a block.
+// (runtime a.dims); TILE: rows per block - small tables use 64 so that more compute units get a block.  The sorted
+// candidate lists live in LDS ([slot][thread], conflict-free): a lane that inserts drags its whole wave through the
+// insertion, so the list has to be cheap to touch (in scratch memory this kernel was 6x slower).
 template <int D, int TILE>
 __global__ __launch_bounds__(TILE) void kmi_eps_kernel(KmiArgs a) {
     constexpr int MAXD = D ? D : KMI_MAX_DIM;
     __shared__ float tile[MAXD][TILE];
+    extern __shared__ float best[];   // [k + 1][TILE]
     const int dims = D ? D : a.dims;
-    const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * TILE + tid;
     float mine[MAXD];
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) mine[d] = (d < dims && i < a.n) ? a.col[d][i] : 0.f;
-    float best[KMI_MAX_K + 1];
     const int keep = a.k + 1;
-    for (int q = 0; q < keep; ++q) best[q] = INFINITY;
-    float worst = INFINITY;   // best[keep - 1], kept in a register: the array itself lives in scratch (dynamic index)
-    for (int64_t j0 = 0; j0 < a.n; j0 += TILE) {
-        const int64_t j = j0 + threadIdx.x;
+    for (int q = 0; q < keep; ++q) best[q * TILE + tid] = INFINITY;
+    float worst = INFINITY;   // best[keep - 1]
+    auto offer = [&](float dist) {
+        if (dist < worst) {
+            int q = keep - 1;
+            while (q > 0 && best[(q - 1) * TILE + tid] > dist) { best[q * TILE + tid] = best[(q - 1) * TILE + tid]; --q; }
+            best[q * TILE + tid] = dist;
+            worst = best[(keep - 1) * TILE + tid];
+        }
+    };
+    auto distance = [&](int t) {
+        float dist = 0.f;
 #pragma unroll
         for (int d = 0; d < MAXD; ++d)
-            if (d < dims) tile[d][threadIdx.x] = j < a.n ? a.col[d][j] : 0.f;
-        __syncthreads();
-        const int cnt = (int)((a.n - j0 < TILE) ? a.n - j0 : TILE);
-        for (int t = 0; t < cnt; ++t) {
-            float dist = 0.f;
+            if (d < dims) dist = fmaxf(dist, fabsf(mine[d] - tile[d][t]));
+        return dist;
+    };
+    const int64_t per = ((a.n + a.slices - 1) / a.slices + TILE - 1) / TILE * TILE;
+    const int64_t jbeg = (int64_t)blockIdx.y * per, jend = jbeg + per < a.n ? jbeg + per : a.n;
+    for (int64_t j0 = jbeg; j0 < jend; j0 += TILE) {
+        const int64_t j = j0 + tid;
 #pragma unroll
-            for (int d = 0; d < MAXD; ++d)
-                if (d < dims) dist = fmaxf(dist, fabsf(mine[d] - tile[d][t]));
-            if (dist < worst) {
-                int q = keep - 1;
-                while (q > 0 && best[q - 1] > dist) { best[q] = best[q - 1]; --q; }
-                best[q] = dist;
-                worst = best[keep - 1];
-            }
+        for (int d = 0; d < MAXD; ++d)
+            if (d < dims) tile[d][tid] = j < jend ? a.col[d][j] : 0.f;
+        __syncthreads();
+        const int cnt = (int)((jend - j0 < TILE) ? jend - j0 : TILE);
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {   // four distances in flight, then the (rarely taken) insertions
+            const float d0 = distance(t), d1 = distance(t + 1), d2 = distance(t + 2), d3 = distance(t + 3);
+            if (fminf(fminf(d0, d1), fminf(d2, d3)) < worst) { offer(d0); offer(d1); offer(d2); offer(d3); }
         }
+        for (; t < cnt; ++t) offer(distance(t));
         __syncthreads();
     }
-    if (i < a.n) a.eps[i] = (int32_t)best[keep - 1];
+    if (i >= a.n) return;
+    if (a.slices == 1) { a.eps[i] = (int32_t)worst; return; }
+    for (int q = 0; q < keep; ++q) a.cand[((size_t)blockIdx.y * keep + q) * a.n + i] = best[q * TILE + tid];
+}
+
+// slices > 1: the (k+1)-th smallest of the slices' candidates
+template <int TILE>
+__global__ __launch_bounds__(TILE) void kmi_eps_merge_kernel(KmiArgs a) {
+    extern __shared__ float best[];   // [k + 1][TILE]
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * TILE + tid;
+    if (i >= a.n) return;
+    const int keep = a.k + 1;
+    for (int q = 0; q < keep; ++q) best[q * TILE + tid] = INFINITY;
+    float worst = INFINITY;
+    for (int c = 0; c < a.slices * keep; ++c) {
+        const float dist = a.cand[(size_t)c * a.n + i];
+        if (dist < worst) {
+            int q = keep - 1;
+            while (q > 0 && best[(q - 1) * TILE + tid] > dist) { best[q * TILE + tid] = best[(q - 1) * TILE + tid]; --q; }
+            best[q * TILE + tid] = dist;
+            worst = best[(keep - 1) * TILE + tid];
+        }
+    }
+    a.eps[i] = (int32_t)worst;
 }
 
 // counts of rows strictly inside eps_i: in z (Chebyshev over the conditioning columns), and of those the ones whose x /
@@ -108,27 +149,31 @@ __global__ __launch_bounds__(TILE) void kmi_count_kernel(KmiArgs a) {
     for (int d = 0; d < MAXD; ++d) mine[d] = (d < dims && i < a.n) ? a.col[d][i] : 0.f;
     const float eps = i < a.n ? (float)a.eps[i] : 0.f;
     int nxz = 0, nyz = 0, nz = 0;
-    for (int64_t j0 = 0; j0 < a.n; j0 += TILE) {
+    const int64_t per = ((a.n + a.slices - 1) / a.slices + TILE - 1) / TILE * TILE;
+    const int64_t jbeg = (int64_t)blockIdx.y * per, jend = jbeg + per < a.n ? jbeg + per : a.n;
+    for (int64_t j0 = jbeg; j0 < jend; j0 += TILE) {
         const int64_t j = j0 + threadIdx.x;
 #pragma unroll
         for (int d = 0; d < MAXD; ++d)
-            if (d < dims) tile[d][threadIdx.x] = j < a.n ? a.col[d][j] : 0.f;
+            if (d < dims) tile[d][threadIdx.x] = j < jend ? a.col[d][j] : 0.f;
         __syncthreads();
-        const int cnt = (int)((a.n - j0 < TILE) ? a.n - j0 : TILE);
-        for (int t = 0; t < cnt; ++t) {
+        const int cnt = (int)((jend - j0 < TILE) ? jend - j0 : TILE);
+#pragma unroll 4
+        for (int t = 0; t < cnt; ++t) {   // branch-free: the compiler keeps several rows' LDS reads in flight
             float dz = 0.f;
 #pragma unroll
             for (int d = 2; d < MAXD; ++d)
                 if (d < dims) dz = fmaxf(dz, fabsf(mine[d] - tile[d][t]));
-            if (dz < eps) {
-                ++nz;
-                nxz += fabsf(mine[0] - tile[0][t]) < eps;
-                nyz += fabsf(mine[1] - tile[1][t]) < eps;
-            }
+            const int in = dz < eps;
+            nz += in;
+            nxz += in & (int)(fabsf(mine[0] - tile[0][t]) < eps);
+            nyz += in & (int)(fabsf(mine[1] - tile[1][t]) < eps);
         }
         __syncthreads();
     }
-    if (i < a.n) { a.cnt[i] = nxz; a.cnt[a.n + i] = nyz; a.cnt[2 * a.n + i] = nz; }
+    if (i >= a.n) return;
+    if (a.slices == 1) { a.cnt[i] = nxz; a.cnt[a.n + i] = nyz; a.cnt[2 * a.n + i] = nz; return; }
+    atomicAdd(&a.cnt[i], nxz); atomicAdd(&a.cnt[a.n + i], nyz); atomicAdd(&a.cnt[2 * a.n + i], nz);   // integer sums: order-free
 }
 
 // the `m` nearest rows of every row in the space of the ORIGINAL conditioning values (Chebyshev), nearest first, the row
@@ -186,9 +231,15 @@ struct Kmi {
 
     template <bool EPS, int D, int TILE>
     void launch_dt(const KmiArgs& a) {
-        const dim3 grid((unsigned)ceil_div(a.n, TILE)), block(TILE);
-        if (EPS) hipLaunchKernelGGL((kmi_eps_kernel<D, TILE>), grid, block, 0, h->ctx->stream, a);
-        else hipLaunchKernelGGL((kmi_count_kernel<D, TILE>), grid, block, 0, h->ctx->stream, a);
+        const dim3 grid((unsigned)ceil_div(a.n, TILE), (unsigned)a.slices), block(TILE);
+        const size_t lds = (size_t)(a.k + 1) * TILE * sizeof(float);
+        if (EPS) {
+            hipLaunchKernelGGL((kmi_eps_kernel<D, TILE>), grid, block, lds, h->ctx->stream, a);
+            if (a.slices > 1) hipLaunchKernelGGL((kmi_eps_merge_kernel<TILE>), dim3(grid.x), block, lds, h->ctx->stream, a);
+        } else {
+            if (a.slices > 1) HIP_CHECK(hipMemsetAsync(a.cnt, 0, (size_t)3 * a.n * sizeof(int32_t), h->ctx->stream));
+            hipLaunchKernelGGL((kmi_count_kernel<D, TILE>), grid, block, 0, h->ctx->stream, a);
+        }
     }
     template <bool EPS, int D>
     void launch_d(const KmiArgs& a) {
@@ -215,6 +266,11 @@ struct Kmi {
         for (int d = 0; d < a.dims; ++d) a.col[d] = h->d_ranks.p + (size_t)vars[d] * N;
         if (x_override) a.col[0] = x_override;
         a.eps = h->d_eps.p; a.cnt = h->d_cnt.p;
+        {   // enough blocks for ~4 per compute unit
+            const int64_t bx = ceil_div(N, N < 64 * 1024 ? 64 : 256);
+            a.slices = (int)std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)h->ctx->num_cus * 4 / bx));
+            if (a.slices > 1) { h->d_cand.reserve((size_t)a.slices * (h->k + 1) * N); a.cand = h->d_cand.p; }
+        }
         launch<true>(a);
         ++h->evaluations;
         std::vector<int32_t> eps((size_t)N), cnt;
