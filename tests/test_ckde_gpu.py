@@ -76,7 +76,7 @@ def test_ckde_dtype_mismatch(pbn, golden):
         cpd.logl(frame(golden["test50"], "float32"))
 
 
-@pytest.mark.parametrize("p", [1, 2, 4, 5, 8, 10, 14])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 8, 10, 12, 14, 16])
 def test_ckde_oracle_parity_random(pbn, oracle, p):
     """Seeded non-linear tables, ragged sizes; includes conditional outliers (joint far, marginal near)."""
     rng = np.random.default_rng(40 + p)

@@ -191,7 +191,7 @@ def test_custom_selector(pbn, golden, oracle):
 
 
 @pytest.mark.parametrize("dtype,rtol", [("float64", RTOL_F64), ("float32", RTOL_F32)])
-@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 9, 13])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16])   # every KS with and without a free K slot
 def test_oracle_parity_random(pbn, oracle, d, dtype, rtol):
     """Seeded correlated Gaussian tables; ragged sizes (not multiples of 16) on both sides."""
     rng = np.random.default_rng(100 + d)
