@@ -842,6 +842,35 @@ template <typename T>
 __device__ __forceinline__ T half_erfc(T x);
 template <>
 __device__ __forceinline__ double half_erfc<double>(double x) { return 0.5 * erfc(x); }
+
+// 1/2 erfc(x) for the fp64 CKDE::cdf kernel, branch-free: erfc(|x|) = erfcx(|x|) exp(-x^2) with erfcx from a table of
+// degree-7 polynomials on [i/8, (i+1)/8) (48 intervals up to 6, relative error 6.5e-14: tools/erfcx_table.py; beyond 6
+// the exponential alone is below 2^-52), the table staged in LDS, the exponential by the sweep's own 2^x.  About a third
+// of the instructions of the library erfc.
+#define PBN_ERFCX_INTERVALS 48
+__device__ const double ERFCX_TABLE[PBN_ERFCX_INTERVALS * 8] = {
+#include "erfcx_table.inc"
+};
+__device__ __forceinline__ double half_erfc_table(double x, const double* __restrict__ tab) {
+    const double a = __builtin_fabs(x);
+    const double ac = __builtin_fmin(a, 5.999999999);
+    int idx;
+    const double scaled = ac * 8.0;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(idx) : "v"(scaled));                 // truncation = floor: ac >= 0
+    const double r = __builtin_fma((double)idx, -0.125, ac) - 0.0625;     // centred in the interval
+    const double* c = tab + idx * 8;
+    double p = c[7];
+    p = __builtin_fma(p, r, c[6]);
+    p = __builtin_fma(p, r, c[5]);
+    p = __builtin_fma(p, r, c[4]);
+    p = __builtin_fma(p, r, c[3]);
+    p = __builtin_fma(p, r, c[2]);
+    p = __builtin_fma(p, r, c[1]);
+    p = __builtin_fma(p, r, c[0]);
+    const double e = exp2_f64<8>(-(a * a) * 0x1.71547652b82fep+0);        // exp(-a^2)
+    const double h = 0.5 * p * e;
+    return x >= 0.0 ? h : 1.0 - h;
+}
 template <>
 __device__ __forceinline__ float half_erfc<float>(float x) { return 0.5f * erfcf(x); }
 
@@ -856,6 +885,12 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
     const int lg = lane >> 4;
     int qx, split;
     xcd_block(qx, split);
+    constexpr bool TABLE = CDF && sizeof(T) == 8;
+    __shared__ double etab[TABLE ? PBN_ERFCX_INTERVALS * 8 : 1];
+    if (TABLE) {   // before any wave leaves: the barrier needs them all
+        for (int e = threadIdx.x; e < PBN_ERFCX_INTERVALS * 8; e += 256) etab[e] = ERFCX_TABLE[e];
+        __syncthreads();
+    }
     const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
     if (qt0 >= a.nqtiles) return;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
@@ -919,8 +954,11 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
             sw[g] += (double)ts;
             if (MODE == 2) sc[g] += (double)((sqrt(w0) + sqrt(w1)) + (sqrt(w2) + sqrt(w3)));
             if (CDF) {
-                const T c = (w0 * half_erfc<T>(ut[0] - uq[g]) + w1 * half_erfc<T>(ut[1] - uq[g])) +
-                            (w2 * half_erfc<T>(ut[2] - uq[g]) + w3 * half_erfc<T>(ut[3] - uq[g]));
+                auto phi = [&](T v) -> T {
+                    if constexpr (TABLE) return (T)half_erfc_table((double)v, etab);
+                    else return half_erfc<T>(v);
+                };
+                const T c = (w0 * phi(ut[0] - uq[g]) + w1 * phi(ut[1] - uq[g])) + (w2 * phi(ut[2] - uq[g]) + w3 * phi(ut[3] - uq[g]));
                 sc[g] += (double)c;
             }
         }
