@@ -6,7 +6,7 @@ HIP kernels behind the C ABI of include/pbn_hip.h); there is no CPU fallback.
 """
 from ._lib import SingularCovarianceData, load as load_library  # noqa: F401
 from .dataset import Context, CrossValidation, DeviceTable, HoldOut, default_context  # noqa: F401
-from .factors import (CKDE, HCKDE, MLE, CLinearGaussianCPD, DiscreteFactor, DiscreteFactorParams, Factor, LinearGaussianCPD,  # noqa: F401
+from .factors import (CKDE, HCKDE, MLE, Assignment, CLinearGaussianCPD, DiscreteFactor, DiscreteFactorParams, Factor, LinearGaussianCPD,  # noqa: F401
                       LinearGaussianParams, MLEDiscreteFactor, MLELinearGaussianCPD)
 from .kde import KDE, UCV, BandwidthSelector, NormalReferenceRule, ProductKDE, ScottsBandwidth  # noqa: F401
 
@@ -39,5 +39,5 @@ __all__ = [
     "DynamicHeterogeneousBN", "Dag", "ConditionalDag", "Operator", "ArcOperator", "OperatorSet", "SaveModel", "LinearGaussianParams",
     "DiscreteFactorParams", "MLELinearGaussianCPD", "MLEDiscreteFactor", "BayesianNetworkBase", "ConditionalBayesianNetworkBase",
     "DynamicBayesianNetworkBase", "DynamicScore", "DynamicIndependenceTest", "BDe", "DynamicBDe", "KMutualInformation",
-    "DynamicKMutualInformation",
+    "DynamicKMutualInformation", "Assignment",
 ]

@@ -565,6 +565,52 @@ class DiscreteFactor(Factor):
         return pa.DictionaryArray.from_arrays(pa.array(out, type=pa.int32()).cast(self._index_type()), pa.array(self._categories[0]))
 
 
+class Assignment:
+    """factors/assignment.hpp:154-260: values assigned to a set of variables (category names or numbers), the key of
+    `conditional_factor`.  `Assignment({"a": "a1", "b": 2.5})`."""
+
+    def __init__(self, assignments):
+        self._values = dict(assignments)
+        for k, v in self._values.items():
+            if not isinstance(v, (str, int, float)):
+                raise TypeError(f"Assignment value for {k} must be a string or a number.")
+
+    def value(self, variable):
+        if variable not in self._values:
+            raise IndexError(f"Variable {variable} not found in Assignment.")
+        return self._values[variable]
+
+    def has_variables(self, variables):
+        variables = [variables] if isinstance(variables, str) else list(variables)
+        return all(v in self._values for v in variables)
+
+    def empty(self):
+        return not self._values
+
+    def size(self):
+        return len(self._values)
+
+    def insert(self, variable, value):
+        self._values[variable] = value
+
+    def remove(self, variable):
+        self._values.pop(variable, None)
+
+    def __iter__(self):
+        return iter(self._values.items())
+
+    def __eq__(self, other):
+        return isinstance(other, Assignment) and self._values == other._values
+
+    def __hash__(self):
+        return hash(frozenset(self._values.items()))
+
+    def __str__(self):
+        return "[" + ", ".join(f"{k} = {v}" for k, v in self._values.items()) + "]"
+
+    __repr__ = __str__
+
+
 class _DiscreteAdaptator(Factor):
     """DiscreteAdaptator<Base, Fitter> (factors/discrete/DiscreteAdaptator.hpp:201-348): one base factor per
     configuration of the discrete evidence; the per-slice work runs on the device through the base factor."""
@@ -635,6 +681,23 @@ class _DiscreteAdaptator(Factor):
                 ok = self._fit_base(f, rb.take(pa.array(rows.astype(np.int32))))
                 self._factors.append(f if ok else None)
         self._fitted = True
+
+    def conditional_factor(self, assignment):
+        """DiscreteAdaptator::conditional_factor (DiscreteAdaptator.hpp:350-356): the base factor fitted on the rows of one
+        configuration of the discrete evidence (None when the configuration was not observed)."""
+        self._check_fitted(self._name)
+        if not self._disc:
+            return self._factors[0]
+        index, stride = 0, 1
+        for name, cats in zip(self._disc, self._categories):
+            if not assignment.has_variables(name):
+                raise ValueError(f"Discrete variable {name} not found in Assignment.")
+            value = assignment.value(name)
+            if value not in cats:
+                raise ValueError(f"Category {value} not found for variable {name}.")
+            index += cats.index(value) * stride
+            stride *= len(cats)
+        return self._factors[index]
 
     def logl(self, df):
         import pyarrow as pa

@@ -186,3 +186,30 @@ def test_hybrid_factor_classes_and_model_fit(pbn, oracle):
     assert close(total, parts)
     assert close(float(net.logl(test).sum()), total, rtol=1e-9)
     assert isinstance(net.cpd("y"), pbn.CLinearGaussianCPD) and isinstance(net.cpd("z"), pbn.CKDE)
+
+
+def test_conditional_factor_by_assignment(pbn):
+    """DiscreteAdaptator::conditional_factor (DiscreteAdaptator.hpp:350-356) keyed by an Assignment (factors/assignment.hpp)."""
+    df = make_hybrid(4000, 3)[0]
+    clg = pbn.CLinearGaussianCPD("y", ["x", "A", "B"])
+    clg.fit(df)
+    hck = pbn.HCKDE("z", ["x", "B"])
+    hck.fit(df)
+    for a, b in (("a0", "b0"), ("a1", "b2")):
+        rows = df[(df["A"] == a) & (df["B"] == b)]
+        f = clg.conditional_factor(pbn.Assignment({"A": a, "B": b}))
+        want = pbn.LinearGaussianCPD("y", ["x"])
+        want.fit(rows)
+        assert np.allclose(f.beta, want.beta, rtol=1e-10) and np.isclose(f.variance, want.variance, rtol=1e-10)
+    rows = df[df["B"] == "b1"]
+    k = hck.conditional_factor(pbn.Assignment({"B": "b1", "unused": 1.5}))
+    ref = pbn.CKDE("z", ["x"])
+    ref.fit(rows)
+    assert k.num_instances() == len(rows) and np.allclose(k.logl(rows.iloc[:50]), ref.logl(rows.iloc[:50]), rtol=1e-10)
+    with pytest.raises(ValueError, match="not found"):
+        clg.conditional_factor(pbn.Assignment({"A": "a0"}))
+    with pytest.raises(ValueError, match="Category"):
+        clg.conditional_factor(pbn.Assignment({"A": "zz", "B": "b0"}))
+    asg = pbn.Assignment({"A": "a0", "B": "b1"})
+    assert asg.size() == 2 and not asg.empty() and asg.value("B") == "b1" and asg == pbn.Assignment({"B": "b1", "A": "a0"})
+    assert dict(iter(asg)) == {"A": "a0", "B": "b1"} and hash(asg) == hash(pbn.Assignment({"B": "b1", "A": "a0"}))
