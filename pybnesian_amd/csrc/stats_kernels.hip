@@ -48,6 +48,22 @@ struct NPairs {
 };
 
 // partial layout per block: [NP][256] tile accumulators (lane-major: element lane*4 + reg), then [NCT*16] sums
+// 16 bytes of a column with only element alignment guaranteed (global_load_dwordx4 asks for no more): vector types with
+// their alignment lowered, so that the load stays one instruction
+typedef double d2_elem_aligned __attribute__((ext_vector_type(2), aligned(8)));
+typedef float f4_elem_aligned __attribute__((ext_vector_type(4), aligned(4)));
+template <typename T>
+__device__ __forceinline__ void load_rows4(const T* p, T (&out)[4]);
+template <>
+__device__ __forceinline__ void load_rows4<double>(const double* p, double (&out)[4]) {
+    const d2_elem_aligned lo = *(const d2_elem_aligned*)p, hi = *(const d2_elem_aligned*)(p + 2);
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = hi[0]; out[3] = hi[1];
+}
+template <>
+__device__ __forceinline__ void load_rows4<float>(const float* p, float (&out)[4]) {
+    const f4_elem_aligned v = *(const f4_elem_aligned*)p;
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
 template <typename T, int NCT, bool GATHER>
 __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
     constexpr int NP = NPairs<NCT>::value;
@@ -86,6 +102,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
         for (int j = 0; j < 4; ++j) {
             ok[j] = rl + j < rb1;
             src[j] = ok[j] ? (GATHER ? (int64_t)a.rows[rl + j] : rl + j) : (GATHER ? (int64_t)a.rows[rb0] : rb0);
+        }
+        if (!GATHER && ok[3]) {
+            // the lane's four rows are consecutive in memory: one 16- / two 16-byte loads per column instead of four
+            // 4- / 8-byte ones (element alignment is all the hardware asks for), half the sectors the L1 has to serve
+#pragma unroll
+            for (int I = 0; I < NCT; ++I) load_rows4<T>(colp[I] + rl, raw[I]);
+            return;
         }
 #pragma unroll
         for (int I = 0; I < NCT; ++I)
