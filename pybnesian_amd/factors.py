@@ -35,6 +35,29 @@ class Factor:
         if not self._fitted:
             raise ValueError(f"{name} factor not fitted.")
 
+    def save(self, filename):
+        """Factor::save (factors/factors.hpp:150-152, util/pickle.hpp): pickle to `filename`.pickle."""
+        import pickle
+
+        with open(filename if filename.endswith(".pickle") else filename + ".pickle", "wb") as f:
+            pickle.dump(self, f, protocol=2)
+
+    # A Python-derived factor is pickled as the reference pickles it (pybindings_factors.cpp:160-233): variable and
+    # evidence from the base class plus whatever __getstate_extra__() returns, handed back to __setstate_extra__().
+    # Without those two methods the instance dictionary travels as usual.
+    def __getstate__(self):
+        extra = getattr(self, "__getstate_extra__", None)
+        if extra is None:
+            return dict(self.__dict__)
+        return {"__factor_base__": (self._variable, list(self._evidence)), "__factor_extra__": extra()}
+
+    def __setstate__(self, state):
+        if "__factor_base__" in state:
+            Factor.__init__(self, *state["__factor_base__"])
+            self.__setstate_extra__(state["__factor_extra__"])
+        else:
+            self.__dict__.update(state)
+
 
 def _random_seed():
     import random

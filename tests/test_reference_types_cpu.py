@@ -582,3 +582,19 @@ def test_documented_names_and_small_helpers(tmp_path):
     assert pbn.load(str(tmp_path / "000007.pickle")).arcs() == [("a", "b")]
     with pytest.raises(NotImplementedError, match="DynamicScore::static_score"):
         pbn.DynamicScore().static_score()
+
+
+def test_factor_save_and_extra_state(tmp_path):
+    """Factor.save (factors.hpp:150-152) and the extra-state protocol (docs/source/extending.rst:196-255): only variable,
+    evidence and __getstate_extra__() travel; __setstate_extra__() restores."""
+    n = NewFactor("c", ["a", "b"])
+    n.fit(None)
+    n.scratch = "not part of the extra state"
+    n.save(str(tmp_path / "factor"))
+    loaded = pbn.load(str(tmp_path / "factor.pickle"))
+    assert type(loaded) is NewFactor and loaded.variable() == "c" and loaded.evidence() == ["a", "b"]
+    assert loaded.fitted() and loaded.some_fit_data == "fitted" and not hasattr(loaded, "scratch")
+    lg = LinearGaussianCPD("b", ["a"], [1.0, 2.0], 0.5)
+    lg.save(str(tmp_path / "lg.pickle"))
+    again = pbn.load(str(tmp_path / "lg.pickle"))
+    assert list(again.beta) == [1.0, 2.0] and again.variance == 0.5
