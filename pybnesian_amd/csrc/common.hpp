@@ -118,6 +118,9 @@ struct pbn_ctx {
     pbn::dev_buf<char> scratch_misc;
     pbn::dev_buf<double> scratch_red;
     pbn::dev_buf<char> scratch_train;  // packed training fragments of the score engine
+    pbn::dev_buf<char> scratch_prune;  // pruned sweeps: whitened rows, keys, permutation, tile boxes of the training side
+    pbn::dev_buf<char> scratch_pruneq; // ... of the query side
+    pbn::dev_buf<char> scratch_sort;   // radix sort temporaries
     // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
     bool profiling = false;
     struct Timed { hipEvent_t e0, e1; int which; };

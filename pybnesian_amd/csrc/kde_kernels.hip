@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 
     double xc[PBN_MAX_D];
     if (valid) {
-        const int64_t src = a.rows ? (int64_t)a.rows[r] : (r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0));
+        const int64_t rr = a.perm ? (int64_t)a.perm[r] : r;
+        const int64_t src = a.rows ? (int64_t)a.rows[rr] : (rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0));
         for (int j = 0; j < d; ++j) {
             const T* col = (const T*)a.base + (int64_t)a.cols[j] * a.ld;
             xc[j] = (double)col[src] - a.mu[j];
@@ -246,6 +247,100 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile pruning support (SweepArgs::prune): whitened coordinates + Morton keys of the logical rows, bounding boxes of the
+// sorted 16-row tiles, and per query tile a lower bound of its queries' largest exponents.
+// ------------------------------------------------------------------------------------------------
+#define PBN_PRUNE_CELL 2.0      // key cell edge in (base-2) whitened units; a term vanishes beyond ~11.3 of them
+#define PBN_PRUNE_WINDOW 32     // training rows scanned on either side of a query's Morton position
+#define PBN_PRUNE_MARGIN 64.0   // terms below 2^-64 of their query's largest known term are dropped
+
+template <typename T>
+__global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int kd, double* __restrict__ zrow, uint32_t* __restrict__ keys,
+                                                         int32_t* __restrict__ iota) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n) return;
+    const int d = a.d;
+    const int64_t src = a.rows ? (int64_t)a.rows[r] : (r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0));
+    double xc[PBN_MAX_D];
+    for (int j = 0; j < d; ++j) xc[j] = (double)((const T*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
+    uint32_t key = 0;
+    for (int i = 0; i < zd; ++i) {
+        double z = 0.0;
+        const double* w = a.W + (size_t)i * d;
+        for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
+        z = (double)(T)z;   // the rounding the pack applies
+        zrow[r * zd + i] = z;
+        if (i < kd) {
+            double c = __builtin_floor(z * (1.0 / PBN_PRUNE_CELL)) + 512.0;
+            c = c < 0.0 ? 0.0 : (c > 1023.0 ? 1023.0 : c);
+            const uint32_t cell = (uint32_t)c;
+            for (int b = 0; b < 10; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
+        }
+    }
+    keys[r] = key;
+    iota[r] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(256) void tile_box_kernel(const double* __restrict__ zrow, const int32_t* __restrict__ perm, int64_t n, int zd, int pd,
+                                                       double* __restrict__ box, double* __restrict__ zsorted) {
+    const int64_t tile = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tile * 16 >= n) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = tile * 16 + i;
+        if (r >= n) break;
+        const double* z = zrow + (int64_t)perm[r] * zd;
+        for (int k = 0; k < zd; ++k) zsorted[r * zd + k] = z[k];
+        for (int k = 0; k < pd; ++k) { lo[k] = z[k] < lo[k] ? z[k] : lo[k]; hi[k] = z[k] > hi[k] ? z[k] : hi[k]; }
+    }
+    for (int k = 0; k < pd; ++k) { box[tile * 2 * pd + k] = lo[k]; box[tile * 2 * pd + pd + k] = hi[k]; }
+}
+
+// one thread per (sorted) query: largest exponent against the training rows around its Morton position - a valid lower
+// bound of its largest term whatever those rows are - then per 16-query tile the smallest of those bounds and the box
+__global__ __launch_bounds__(256) void query_prepass_kernel(const double* __restrict__ zq_row, const int32_t* __restrict__ qperm, int64_t nq,
+                                                            const uint32_t* __restrict__ qkeys, const double* __restrict__ zt,
+                                                            const uint32_t* __restrict__ tkeys, int64_t n, int zd, int pd,
+                                                            double* __restrict__ qbox, double* __restrict__ qthr) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = q < nq;
+    double z[PBN_MAX_D];
+    double best = -INFINITY;
+    if (valid) {
+        const double* zp = zq_row + (int64_t)qperm[q] * zd;
+        for (int k = 0; k < zd; ++k) z[k] = zp[k];
+        const uint32_t key = qkeys[q];
+        int64_t lo = 0, hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tkeys[mid] < key) lo = mid + 1; else hi = mid; }
+        const int64_t b = lo - PBN_PRUNE_WINDOW > 0 ? lo - PBN_PRUNE_WINDOW : 0, e = lo + PBN_PRUNE_WINDOW < n ? lo + PBN_PRUNE_WINDOW : n;
+        for (int64_t t = b; t < e; ++t) {
+            double d2 = 0.0;
+            for (int k = 0; k < zd; ++k) { const double dd = zt[t * zd + k] - z[k]; d2 = __builtin_fma(dd, dd, d2); }
+            const double ex = -0.5 * d2;
+            best = ex > best ? ex : best;
+        }
+    }
+    // reduce over the 16 lanes of a query tile
+    double thr = valid ? best : INFINITY;
+    double lob[3], hib[3];
+    for (int k = 0; k < 3; ++k) { lob[k] = (valid && k < pd) ? z[k] : INFINITY; hib[k] = (valid && k < pd) ? z[k] : -INFINITY; }
+    for (int off = 1; off < 16; off <<= 1) {
+        const double o = __shfl_xor(thr, off);
+        thr = o < thr ? o : thr;
+        for (int k = 0; k < 3; ++k) {
+            const double l = __shfl_xor(lob[k], off), h = __shfl_xor(hib[k], off);
+            lob[k] = l < lob[k] ? l : lob[k];
+            hib[k] = h > hib[k] ? h : hib[k];
+        }
+    }
+    if (valid && (threadIdx.x & 15) == 0) {
+        const int64_t tile = q >> 4;
+        qthr[tile] = thr;
+        for (int k = 0; k < pd; ++k) { qbox[tile * 2 * pd + k] = lob[k]; qbox[tile * 2 * pd + pd + k] = hib[k]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kde_sweep
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -275,14 +370,15 @@ __device__ __forceinline__ void xcd_block(int& qx, int& split) {
     split = (int)(wg / gx);
 }
 
-template <typename T, int KS, bool COND, int QG, bool FOLD>
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE>
 __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    xcd_block(qx, split);
+    if (PRUNE) { qx = blockIdx.x; split = blockIdx.y; }   // pruned work per split is uneven: keep every XCD on every split
+    else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
     if (qt0 >= a.nqtiles) return;  // no barriers in this kernel: idle waves just leave
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
@@ -313,6 +409,43 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     }
 
     const T ctop = Tr<T>::top();   // leading exp2 coefficient pinned in a VGPR for the whole kernel
+
+    // ---- tile pruning: box of this wave's queries and the exponent below which a training tile cannot matter -------
+    double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0}, wthr = 0;
+    const int pd = PRUNE ? a.pdims : 0;
+    if (PRUNE) {
+        wthr = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+            const double th = a.qtile_thr[qt];
+            wthr = th < wthr ? th : wthr;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < pd) {
+                    const double l = a.qtile_box[qt * 2 * pd + k], h = a.qtile_box[qt * 2 * pd + pd + k];
+                    wlo[k] = l < wlo[k] ? l : wlo[k];
+                    whi[k] = h > whi[k] ? h : whi[k];
+                }
+        }
+        wthr -= PBN_PRUNE_MARGIN;
+    }
+    auto skip_tile = [&](int64_t t) -> bool {
+        if (!PRUNE) return false;
+        const double* bx = a.tile_box + t * 2 * pd;
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < pd) {
+                const double g1 = bx[k] - whi[k], g2 = wlo[k] - bx[pd + k];
+                double g = g1 > g2 ? g1 : g2;
+                g = g > 0.0 ? g : 0.0;
+                d2 = __builtin_fma(g, g, d2);
+            }
+        return -0.5 * d2 < wthr;   // every exponent of the tile lies below the bound of every query of the wave
+    };
 
     // ---- prologue: offsets from the first tile (max of s2 over its 16 rows) ---------------------
     {
@@ -403,10 +536,11 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     load_tile(t0, afA, nxA, axA);
     for (int64_t t = t0; t < t1; t += 2) {
         const bool second = t + 1 < t1;                       // wave-uniform
+        const bool doA = !skip_tile(t), doB = second && !skip_tile(t + 1);
         load_tile(second ? t + 1 : t, afB, nxB, axB);
-        process_tile(afA, nxA, axA);
+        if (doA) process_tile(afA, nxA, axA);
         load_tile(t + 2 < t1 ? t + 2 : t, afA, nxA, axA);
-        if (second) process_tile(afB, nxB, axB);
+        if (doB) process_tile(afB, nxB, axB);
     }
 
     // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
@@ -1173,11 +1307,22 @@ template <typename T, bool COND, bool FOLD>
 static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
     constexpr int QG = SweepQG<sizeof(T) == 8, COND>::value;
     dim3 block(256);
+    if (a.prune) {   // fp64, at most 5 marginal dimensions (KS <= 2)
+        if constexpr (sizeof(T) == 8) {
+            if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD, true>), grid, block, 0, st, a);
+            else if (KS == 2) hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD, true>), grid, block, 0, st, a);
+            else throw invalid_error("KDE: pruned sweeps cover at most 8 whitened dimensions");
+            HIP_CHECK(hipGetLastError());
+            return;
+        } else {
+            throw invalid_error("KDE: pruned sweeps are fp64 only");
+        }
+    }
     switch (KS) {
-        case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG, FOLD>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG, FOLD>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
         default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
     }
     HIP_CHECK(hipGetLastError());
@@ -1185,6 +1330,26 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
 template <typename T, bool COND>
 static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
     if (a.fold) launch_sweep_tf<T, COND, true>(a, KS, grid, st); else launch_sweep_tf<T, COND, false>(a, KS, grid, st);
+}
+
+void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st) {
+    if (a.n == 0) return;
+    const dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
+    if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
+    else hipLaunchKernelGGL(prune_keys_kernel<float>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ceil_div(ceil_div(n, 16), 256)), dim3(256), 0, st, zrow, perm, n, zd, pd, box, zsorted);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
+                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st) {
+    if (nq == 0) return;
+    hipLaunchKernelGGL(query_prepass_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, zq_row, qperm, nq, qkeys_sorted, ztrain_sorted,
+                       tkeys_sorted, n, zd, pd, qbox, qthr);
+    HIP_CHECK(hipGetLastError());
 }
 
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm) {

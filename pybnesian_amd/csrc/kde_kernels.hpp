@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "common.hpp"
+
 #define PBN_MAX_D 17       // up to 16 whitened "main" dimensions (KS <= 4) + 1 CKDE extra coordinate
 
 namespace pbn {
@@ -24,6 +26,7 @@ struct PackArgs {
     // a CV training set is "everything before the fold" ++ "everything after it"), or rows[r] if non-null
     int64_t row0, n0, row1;
     const int32_t* rows;  // device gather list (nullable)
+    const int32_t* perm;  // nullable: logical row r is taken from logical row perm[r] (spatially sorted packs, see SweepArgs::prune)
     int64_t n;            // valid rows
     int64_t ntiles;       // ceil(n / 16)
     double W[PBN_MAX_D * PBN_MAX_D];  // d x d row-major lower-triangular whitening matrix (kernel argument)
@@ -49,6 +52,16 @@ struct SweepArgs {
     int64_t nqtiles;
     int64_t tiles_per_split;
     int fold;      // the packs carry the training norms in a free K slot (PackArgs::fold_norm)
+    // Tile pruning (low-dimensional fp64 sweeps of the score engine): both sides are packed in Morton order of their
+    // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first
+    // `pdims` whitened dimensions, and qtile_thr holds, per query tile, a lower bound of its queries' largest exponents
+    // (from a scan of the training rows next to them in Morton order).  A wave skips a training tile whose box is so far
+    // from the box of its queries that every exponent is below that bound - 64: such terms are < 2^-64 of their sums.
+    int prune;
+    int pdims;
+    const double* tile_box;    // [ntiles][2 * pdims]: lo..., hi...
+    const double* qtile_box;   // [nqtiles][2 * pdims]
+    const double* qtile_thr;   // [nqtiles]
     double* part;  // [nsplit][nqtiles*16][P]
     double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
     int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
@@ -78,6 +91,13 @@ struct SweepQG {
 int sweep_qg(int dtype, bool cond, int KS);
 bool use_sparse(int dtype, bool cond, int KS);
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm);   // see PackArgs::fold_norm
+// spatial sort + bounding boxes + exponent bounds of the pruned sweeps (SweepArgs::prune)
+void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st);
+void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st);
+void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
+                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st);
+void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+               int bits, hipStream_t st);
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 

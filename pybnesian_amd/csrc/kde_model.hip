@@ -133,13 +133,55 @@ static void fill_pack_common(PackArgs& pa, const pbn_table* t, const int* cols, 
     for (int i = 0; i < m.d; ++i) pa.mu[i] = m.mu[i];
 }
 
-void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
-                    int64_t row1, const int32_t* dev_rows) {
+static int env_int(const char* name, int dflt);
+
+// Morton order of the logical rows described by `pa` (already filled): whitened rows -> keys -> stable sort.  Returns the
+// carved buffers inside `arena`.
+struct PruneSide {
+    double* zrow;        // [n][zd] in logical order
+    uint32_t* keys;      // [n] sorted
+    int32_t* perm;       // [n] sorted position -> logical row
+    char* rest;          // first free byte behind them (256-aligned)
+};
+static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackArgs& pa, int dtype, int zd, int kd, size_t extra_bytes) {
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t n = (size_t)pa.n;
+    const size_t zb = al(n * zd * sizeof(double)), kb = al(n * sizeof(uint32_t)), ib = al(n * sizeof(int32_t));
+    arena.reserve(zb + 2 * kb + 2 * ib + extra_bytes + 256);
+    char* p = arena.p;
+    PruneSide s{};
+    s.zrow = (double*)p; p += zb;
+    uint32_t* keys_unsorted = (uint32_t*)p; p += kb;
+    s.keys = (uint32_t*)p; p += kb;
+    int32_t* iota = (int32_t*)p; p += ib;
+    s.perm = (int32_t*)p; p += ib;
+    s.rest = p;
+    launch_prune_keys(pa, dtype, zd, kd, s.zrow, keys_unsorted, iota, ctx->stream);
+    sort_keys(ctx->scratch_sort, keys_unsorted, s.keys, iota, s.perm, pa.n, 10 * kd, ctx->stream);
+    return s;
+}
+
+void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
+                    int64_t row1, const int32_t* dev_rows, bool prune) {
     PackArgs pa{};
     fill_pack_common(pa, t, cols, m);
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
+    m.prune = false;
+    if (prune && env_int("PBN_SWEEP_PRUNE", 1) && m.dtype == PBN_F64 && m.dm <= 5 && m.N >= env_int("PBN_PRUNE_MIN_ROWS", 32768)) {
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        m.zdims = m.d;
+        m.pdims = std::min(m.dm, 3);
+        const size_t box_b = al((size_t)m.ntiles * 2 * m.pdims * sizeof(double)), zs_b = al((size_t)m.N * m.zdims * sizeof(double));
+        const PruneSide s = prune_sort_side(ctx, ctx->scratch_prune, pa, m.dtype, m.zdims, m.pdims, box_b + zs_b);
+        double* box = (double*)s.rest;
+        double* zsorted = (double*)(s.rest + box_b);
+        launch_tile_boxes(s.zrow, s.perm, m.N, m.zdims, m.pdims, box, zsorted, ctx->stream);
+        pa.perm = s.perm;
+        m.prune = true;
+        m.tile_box = box; m.zsorted = zsorted; m.keys_sorted = s.keys;
+    }
     pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
@@ -180,6 +222,19 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     pa.is_query = 1;
     const bool fold = sweep_folds_norm(m.dtype, m.cond, m.KS, m.dm);
     pa.fold_norm = fold ? 1 : 0;
+    const double* qbox = nullptr;
+    const double* qthr = nullptr;
+    if (m.prune) {
+        if (dev_logl) throw invalid_error("pruned KDE sweeps deliver sums only");
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t qbox_b = al((size_t)nqtiles * 2 * m.pdims * sizeof(double)), qthr_b = al((size_t)nqtiles * sizeof(double));
+        const PruneSide s = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b);
+        double* qb = (double*)s.rest;
+        double* qt = (double*)(s.rest + qbox_b);
+        launch_query_prepass(s.zrow, s.perm, n, s.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, qb, qt, ctx->stream);
+        pa.perm = s.perm;
+        qbox = qb; qthr = qt;
+    }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
     pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
@@ -205,6 +260,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack; sa.Bxnorm = pa.xnorm;
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
+    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);

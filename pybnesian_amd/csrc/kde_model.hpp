@@ -21,6 +21,13 @@ struct KdeModel {
     void* Apack = nullptr;     // device [ntiles][KS][64]
     void* nxpack = nullptr;    // device [ntiles][16]
     void* Axpack = nullptr;    // device [ntiles][64] (CKDE only)
+    // tile pruning (set by kde_pack_train when asked for and the shape qualifies; see SweepArgs::prune): the packs above
+    // hold the training rows in Morton order of their whitened coordinates
+    bool prune = false;
+    int pdims = 0, zdims = 0;
+    const double* tile_box = nullptr;      // [ntiles][2 * pdims]
+    const double* zsorted = nullptr;       // [N][zdims] whitened rows in packed order
+    const uint32_t* keys_sorted = nullptr; // [N]
 };
 
 // Bytes needed for the three training-side fragment arrays.
@@ -34,8 +41,11 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
 
 // Whiten + pack training rows (two contiguous ranges: [row0, row0+n0) ++ [row1, row1 + n - n0)).
 // dev_rows (nullable): device gather list of m.N row ids, used instead of the ranges.
-void kde_pack_train(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
-                    int64_t row1, const int32_t* dev_rows = nullptr);
+// prune: ask for the spatially sorted pack + tile boxes of the pruned sweep (fp64, <= 5 marginal dimensions, enough rows;
+// otherwise ignored).  The training order inside the pack is then NOT the table order: only for consumers that need
+// sums over the training rows (the score engine), not for CKDE::sample / cdf handles.
+void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
+                    int64_t row1, const int32_t* dev_rows = nullptr, bool prune = false);
 
 // pack(queries) -> sweep -> finish on the context stream; dev_logl / dev_sum nullable (device pointers).
 // dev_sum_marg (CKDE only, nullable): dev_sum then receives the sum of the JOINT log-densities and dev_sum_marg the sum

@@ -813,7 +813,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                 m.Apack = base;
                 m.nxpack = base + align(pb.apack);
                 m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
-                kde_pack_train(ctx, m, t, use_cols, row0, n0, row1);
+                kde_pack_train(ctx, m, t, use_cols, row0, n0, row1, nullptr, /*prune=*/true);
                 if (w.mode == 0 && m.cond)
                     kde_eval_enqueue(ctx, m, t, use_cols, te0, te_n, nullptr, dsums.p + w.slot_j, nullptr, dsums.p + w.slot_m);
                 else

@@ -438,3 +438,32 @@ def test_ckde_set_function_cache_paths(pbn):
     assert np.allclose(vals, [results[0][i] for i in range(12)], rtol=1e-11)
     again = score._batch(model, pairs, score._kind)      # everything cached now: no new sweeps, identical values
     assert score.kde_cache_stats() == (entries, sweeps) and np.array_equal(vals, again)
+
+
+def test_pruned_sweeps_match_unpruned(pbn):
+    """Low-dimensional CKDE candidates of the score engine run the Morton-sorted, tile-pruned sweep once the training folds
+    are large enough; dropping the tiles whose terms are below 2^-64 of their sums must not move the scores."""
+    import os
+
+    rng = np.random.default_rng(11)
+    n = 90000
+    a = rng.normal(size=n)
+    b = np.tanh(a) + 0.4 * rng.normal(size=n)
+    c = 0.5 * a - 0.7 * b + 0.5 * rng.standard_t(5, size=n)       # heavy tails: far-away queries
+    d = rng.normal(size=n) * (1.0 + 0.5 * (a > 1))
+    e = 0.3 * c + rng.normal(size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c, "d": d, "e": e})
+    model = pbn.SemiparametricBN(list(df.columns))
+    cands = [("a", []), ("b", ["a"]), ("c", ["a", "b"]), ("d", ["a", "b", "c"]), ("e", ["a", "b", "c", "d"])]
+    values = {}
+    for flag in ("0", "1"):
+        os.environ["PBN_SWEEP_PRUNE"] = flag
+        try:
+            score = pbn.CVLikelihood(df, k=3, seed=5)
+            values[flag] = [score.local_score_node_type(model, pbn.CKDEType(), v, ev) for v, ev in cands]
+            vl = pbn.ValidatedLikelihood(df, test_ratio=0.25, k=2, seed=1)
+            values[flag] += [vl.vlocal_score_node_type(model, pbn.CKDEType(), "c", ["a", "b"])]
+        finally:
+            os.environ.pop("PBN_SWEEP_PRUNE", None)
+    for off, on in zip(values["0"], values["1"]):
+        assert np.isfinite(off) and on == pytest.approx(off, rel=1e-11)
