@@ -304,7 +304,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             m.Apack = arena;
             m.nxpack = arena + align(pb.apack);
             m.Axpack = m.cond ? arena + align(pb.apack) + align(pb.nxpack) : nullptr;
-            kde_pack_train(ctx, m, t, cols.data(), 0, 0, 0, dev_train);
+            kde_pack_train(ctx, m, t, cols.data(), 0, 0, 0, dev_train, /*prune=*/true);
             kde_eval_enqueue(ctx, m, t, cols.data(), 0, te->N, nullptr, dsums.p + n_slots, dev_test);
             HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host-side gather list and the arenas are reused by the next slice
             ++n_slots;

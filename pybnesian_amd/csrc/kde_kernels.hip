@@ -741,7 +741,8 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 
     double xc[PBN_MAX_D];
     if (valid) {
-        const int64_t src = a.rows ? (int64_t)a.rows[r] : (r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0));
+        const int64_t rr = a.perm ? (int64_t)a.perm[r] : r;
+        const int64_t src = a.rows ? (int64_t)a.rows[rr] : (rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0));
         for (int j = 0; j < d; ++j) {
             const float* col = (const float*)a.base + (int64_t)a.cols[j] * a.ld;
             xc[j] = (double)col[src] - a.mu[j];
@@ -816,14 +817,14 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
     }
 }
 
-template <int NB, bool COND, int QG>
+template <int NB, bool COND, int QG, bool PRUNE>
 __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     using V = f4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    xcd_block(qx, split);
+    if (PRUNE) { qx = blockIdx.x; split = blockIdx.y; } else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
     if (qt0 >= a.nqtiles) return;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
@@ -852,6 +853,42 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
         sum[g] = 0.0;
         if (COND) { bx[g] = BXp[qt * 64 + lane]; xn[g] = XNp[qt * 16 + (lane & 15)]; sumj[g] = 0.0; }
     }
+    // tile pruning, as in kde_sweep_kernel
+    double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0}, wthr = 0;
+    const int pd = PRUNE ? a.pdims : 0;
+    if (PRUNE) {
+        wthr = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+            const double th = a.qtile_thr[qt];
+            wthr = th < wthr ? th : wthr;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < pd) {
+                    const double l = a.qtile_box[qt * 2 * pd + k], h = a.qtile_box[qt * 2 * pd + pd + k];
+                    wlo[k] = l < wlo[k] ? l : wlo[k];
+                    whi[k] = h > whi[k] ? h : whi[k];
+                }
+        }
+        wthr -= PBN_PRUNE_MARGIN;
+    }
+    auto skip_tile = [&](int64_t t) -> bool {
+        if (!PRUNE) return false;
+        const double* bx = a.tile_box + t * 2 * pd;
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < pd) {
+                const double g1 = bx[k] - whi[k], g2 = wlo[k] - bx[pd + k];
+                double g = g1 > g2 ? g1 : g2;
+                g = g > 0.0 ? g : 0.0;
+                d2 = __builtin_fma(g, g, d2);
+            }
+        return -0.5 * d2 < wthr;
+    };
     auto set_bx = [&](int g) {  // slots 9..11 (lane group 1, elements 1..3) <- split3(xn + m - mj)
         if (lg == 1) {
             __bf16 q1, q2, q3;
@@ -937,10 +974,11 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     load_tile(t0, fA, xA);
     for (int64_t t = t0; t < t1; t += 2) {
         const bool second = t + 1 < t1;
+        const bool doA = !skip_tile(t), doB = second && !skip_tile(t + 1);
         load_tile(second ? t + 1 : t, fB, xB);
-        process_tile(fA, xA);
+        if (doA) process_tile(fA, xA);
         load_tile(t + 2 < t1 ? t + 2 : t, fA, xA);
-        if (second) process_tile(fB, xB);
+        if (doB) process_tile(fB, xB);
     }
 
     double* part = a.part;
@@ -1379,11 +1417,18 @@ int sweep_qg(int dtype, bool cond, int KS) {
 template <bool COND>
 static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
     dim3 block(256);
+    if (a.prune) {   // at most 5 marginal dimensions: 33 bf16 slots, two MFMAs
+        if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, true>), grid, block, 0, st, a);
+        else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, true>), grid, block, 0, st, a);
+        else throw invalid_error("KDE: pruned sweeps cover at most 5 whitened dimensions");
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     switch (NB) {
-        case 1: hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((kde_sweep_bf16_kernel<3, COND, 4>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((kde_sweep_bf16_kernel<4, COND, 4>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, false>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, false>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_sweep_bf16_kernel<3, COND, 4, false>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_sweep_bf16_kernel<4, COND, 4, false>), grid, block, 0, st, a); break;
         default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
     }
     HIP_CHECK(hipGetLastError());

@@ -169,7 +169,8 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
     m.prune = false;
-    if (prune && env_int("PBN_SWEEP_PRUNE", 1) && m.dtype == PBN_F64 && m.dm <= 5 && m.N >= env_int("PBN_PRUNE_MIN_ROWS", 32768)) {
+    if (prune && env_int("PBN_SWEEP_PRUNE", 1) && (m.dtype == PBN_F64 || use_bf16x3(m.dtype)) && m.dm <= 5 &&
+        m.N >= env_int("PBN_PRUNE_MIN_ROWS", 32768)) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         m.zdims = m.d;
         m.pdims = std::min(m.dm, 3);
