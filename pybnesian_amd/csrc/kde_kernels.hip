@@ -1347,8 +1347,9 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
     dim3 block(256);
     if (a.prune) {   // fp64, at most 5 marginal dimensions (KS <= 2)
         if constexpr (sizeof(T) == 8) {
-            if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD, true>), grid, block, 0, st, a);
-            else if (KS == 2) hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD, true>), grid, block, 0, st, a);
+            constexpr int QGP = PBN_QG_PRUNE < QG ? PBN_QG_PRUNE : QG;   // fewer queries per wave: a tighter box to test against
+            if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QGP, FOLD, true>), grid, block, 0, st, a);
+            else if (KS == 2) hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QGP, FOLD, true>), grid, block, 0, st, a);
             else throw invalid_error("KDE: pruned sweeps cover at most 8 whitened dimensions");
             HIP_CHECK(hipGetLastError());
             return;
@@ -1408,8 +1409,9 @@ bool use_sparse(int dtype, bool cond, int KS) {
     return v != 0 && dtype == PBN_F64 && !cond && KS <= 2;
 }
 
-int sweep_qg(int dtype, bool cond, int KS) {
+int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     if (use_sparse(dtype, cond, KS)) return 1;
+    if (prune && dtype == PBN_F64) return std::min(PBN_QG_PRUNE, cond ? SweepQG<true, true>::value : SweepQG<true, false>::value);
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }
@@ -1435,7 +1437,7 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
 }
 
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
-    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond, KS)), (unsigned)nsplit);
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond, KS, a.prune != 0)), (unsigned)nsplit);
     if (use_bf16x3(dtype)) {  // KS carries the number of bf16 MFMAs
         if (cond) launch_sweep_bf16<true>(a, KS, grid, st); else launch_sweep_bf16<false>(a, KS, grid, st);
         return;

@@ -88,7 +88,10 @@ template <bool F64, bool COND>
 struct SweepQG {
     static constexpr int value = (F64 && COND) ? 2 : (F64 ? PBN_QG_F64 : 4);
 };
-int sweep_qg(int dtype, bool cond, int KS);
+#ifndef PBN_QG_PRUNE
+#define PBN_QG_PRUNE 4
+#endif
+int sweep_qg(int dtype, bool cond, int KS, bool prune = false);
 bool use_sparse(int dtype, bool cond, int KS);
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm);   // see PackArgs::fold_norm
 // spatial sort + bounding boxes + exponent bounds of the pruned sweeps (SweepArgs::prune)

@@ -241,7 +241,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
 
     // split the training tiles so that the grid is a few waves deep on every CU
-    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond, m.KS));
+    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond, m.KS, m.prune));
     const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
     int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
     // with the XCD-aware block order (xcd_block) the blocks resident on one XCD share a split: keep a split's training
