@@ -1347,7 +1347,7 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
     dim3 block(256);
     if (a.prune) {   // fp64, at most 5 marginal dimensions (KS <= 2)
         if constexpr (sizeof(T) == 8) {
-            constexpr int QGP = PBN_QG_PRUNE < QG ? PBN_QG_PRUNE : QG;   // fewer queries per wave: a tighter box to test against
+            constexpr int QGP = COND ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;   // query groups per wave of the pruned kernels
             if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QGP, FOLD, true>), grid, block, 0, st, a);
             else if (KS == 2) hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QGP, FOLD, true>), grid, block, 0, st, a);
             else throw invalid_error("KDE: pruned sweeps cover at most 8 whitened dimensions");
@@ -1411,7 +1411,7 @@ bool use_sparse(int dtype, bool cond, int KS) {
 
 int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     if (use_sparse(dtype, cond, KS)) return 1;
-    if (prune && dtype == PBN_F64) return std::min(PBN_QG_PRUNE, cond ? SweepQG<true, true>::value : SweepQG<true, false>::value);
+    if (prune && dtype == PBN_F64) return cond ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }

@@ -91,6 +91,9 @@ struct SweepQG {
 #ifndef PBN_QG_PRUNE
 #define PBN_QG_PRUNE 4
 #endif
+#ifndef PBN_QG_PRUNE_COND
+#define PBN_QG_PRUNE_COND 2
+#endif
 int sweep_qg(int dtype, bool cond, int KS, bool prune = false);
 bool use_sparse(int dtype, bool cond, int KS);
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm);   // see PackArgs::fold_norm
