@@ -11,6 +11,7 @@ struct pbn_kde {
     pbn_ctx* ctx = nullptr;
     KdeModel m;
     dev_buf<char> Apack, nxpack, Axpack;
+    dev_buf<char> prune_store;          // tile boxes | Morton-ordered whitened rows | keys (when m.prune)
     // CKDE::cdf state (pbn_ckde_fit only): classic fragments of the evidence dimensions + u = (x - b.e)/(sigma_c sqrt 2)
     bool ckde = false;
     int cdf_KS = 0;

@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(256) void kde_finish_kernel(FinishArgs a) {
             l = lj - lm;
             if (a.block_sums_marg) { l = lj; val_marg = lm; }   // the two sums separately (score engine's set cache)
         }
-        if (a.logl) a.logl[q] = l;
+        if (a.logl) a.logl[a.scatter ? (int64_t)a.scatter[q] : q] = l;
         val = l;
     }
     __shared__ double red[256];

@@ -77,6 +77,7 @@ struct FinishArgs {
     double* logl;        // nullable
     double* block_sums;  // nullable
     double* block_sums_marg;  // nullable, COND only: block_sums then holds the joint logl, this one the marginal logl
+    const int32_t* scatter;   // nullable: logl[scatter[q]] instead of logl[q] (queries evaluated in Morton order)
 };
 
 // query groups (of 16 rows) per wave: 4, except the fp64 CKDE sweep (two accumulator + exp sets per group)

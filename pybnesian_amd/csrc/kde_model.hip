@@ -189,6 +189,21 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     launch_pack(pa, m.dtype, ctx->stream);
 }
 
+// A fitted handle outlives the context's arenas: move the pruning tables of a freshly packed model into `store`.
+void kde_prune_persist(pbn_ctx* ctx, KdeModel& m, dev_buf<char>& store) {
+    if (!m.prune) return;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t box_b = al((size_t)m.ntiles * 2 * m.pdims * sizeof(double)), zs_b = al((size_t)m.N * m.zdims * sizeof(double)),
+                 key_b = al((size_t)m.N * sizeof(uint32_t));
+    store.alloc(box_b + zs_b + key_b);
+    HIP_CHECK(hipMemcpyAsync(store.p, m.tile_box, box_b, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(store.p + box_b, m.zsorted, (size_t)m.N * m.zdims * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(store.p + box_b + zs_b, m.keys_sorted, (size_t)m.N * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    m.tile_box = (const double*)store.p;
+    m.zsorted = (const double*)(store.p + box_b);
+    m.keys_sorted = (const uint32_t*)(store.p + box_b + zs_b);
+}
+
 static int env_int(const char* name, int dflt) {
     const char* s = std::getenv(name);
     return s && *s ? std::atoi(s) : dflt;
@@ -225,8 +240,8 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     pa.fold_norm = fold ? 1 : 0;
     const double* qbox = nullptr;
     const double* qthr = nullptr;
+    const int32_t* qperm = nullptr;
     if (m.prune) {
-        if (dev_logl) throw invalid_error("pruned KDE sweeps deliver sums only");
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         const size_t qbox_b = al((size_t)nqtiles * 2 * m.pdims * sizeof(double)), qthr_b = al((size_t)nqtiles * sizeof(double));
         const PruneSide s = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b);
@@ -234,6 +249,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
         double* qt = (double*)(s.rest + qbox_b);
         launch_query_prepass(s.zrow, s.perm, n, s.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, qb, qt, ctx->stream);
         pa.perm = s.perm;
+        qperm = s.perm;
         qbox = qb; qthr = qt;
     }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
@@ -272,7 +288,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     FinishArgs fa{};
     fa.part = sa.part; fa.nsplit = (int)nsplit; fa.nqtiles = nqtiles; fa.nq = n;
     fa.lognorm = m.lognorm; fa.lognorm_marg = m.lognorm_marg;
-    fa.logl = dev_logl; fa.block_sums = dev_sum ? (double*)ctx->scratch_misc.p : nullptr;
+    fa.logl = dev_logl; fa.scatter = qperm; fa.block_sums = dev_sum ? (double*)ctx->scratch_misc.p : nullptr;
     fa.block_sums_marg = (m.cond && dev_sum && dev_sum_marg) ? (double*)ctx->scratch_misc.p + nblocks : nullptr;
     { KernelTimer kt(ctx, PBN_K_FINISH); launch_finish(fa, m.cond, dev_sum, ctx->stream, dev_sum_marg); }
 }

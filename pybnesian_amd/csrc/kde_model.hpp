@@ -43,9 +43,12 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
 // dev_rows (nullable): device gather list of m.N row ids, used instead of the ranges.
 // prune: ask for the spatially sorted pack + tile boxes of the pruned sweep (fp64, <= 5 marginal dimensions, enough rows;
 // otherwise ignored).  The training order inside the pack is then NOT the table order: only for consumers that need
-// sums over the training rows (the score engine), not for CKDE::sample / cdf handles.
+// sums over the training rows (the score engine, logl / slogl of fitted handles); CKDE::sample / cdf keep their own
+// table-ordered fragments.  Queries are evaluated in Morton order too and scattered back by the finish kernel.
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
                     int64_t row1, const int32_t* dev_rows = nullptr, bool prune = false);
+// Copies the pruning tables of a pruned pack out of the context arena into `store` (handles that outlive the call).
+void kde_prune_persist(pbn_ctx* ctx, KdeModel& m, dev_buf<char>& store);
 
 // pack(queries) -> sweep -> finish on the context stream; dev_logl / dev_sum nullable (device pointers).
 // dev_sum_marg (CKDE only, nullable): dev_sum then receives the sum of the JOINT log-densities and dev_sum_marg the sum

@@ -294,3 +294,48 @@ def test_pickle_roundtrip(pbn, golden):
     c32 = pickle.loads(pickle.dumps(f32))
     assert c32.data_type() == pa.float32()
     assert np.allclose(c32.logl(frame(golden["test50"], "float32")), f32.logl(frame(golden["test50"], "float32")), rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("d", [1, 2, 3, 5])
+def test_pruned_handles_match_oracle(pbn, oracle, d, dtype, monkeypatch):
+    """Fitted KDE / ProductKDE / CKDE handles with <= 5 (marginal) dimensions and >= 32768 training rows pack their rows in
+    Morton order and skip the tile pairs that cannot contribute: logl comes back in the caller's row
+    order, equal to the oracle and to the unpruned sweep, on clustered data with far-away queries."""
+    rng = np.random.default_rng(900 + d)
+    n, m = 40_003, 1501
+    centres = rng.uniform(-30.0, 30.0, size=(4, d))
+    mix = np.tril(rng.uniform(-0.4, 0.4, size=(d, d)), -1) + np.eye(d)
+    def draw(k):
+        return centres[rng.integers(0, 4, size=k)] + rng.normal(size=(k, d)) @ mix.T
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame(draw(n), columns=names).astype(dtype)
+    q = draw(m)
+    q[:9] += 400.0                                   # queries far from every training row
+    q[9:20] = 0.5 * (centres[0] + centres[1])        # between clusters
+    test = pd.DataFrame(q, columns=names).astype(dtype)
+    t64, q64 = train.to_numpy().astype(np.float64), test.to_numpy().astype(np.float64)
+    cases = [(lambda: pbn.KDE(names), oracle.kde_logl), (lambda: pbn.ProductKDE(names), oracle.product_kde_logl)]
+    if d >= 2:
+        cases.append((lambda: pbn.CKDE(names[0], names[1:]), oracle.ckde_logl))
+    for make, fn in cases:
+        k = make()
+        k.fit(train)
+        got, s = k.logl(test), k.slogl(test)
+        want = fn(t64, k.bandwidth, q64)
+        assert np.all(np.isfinite(got))
+        if dtype == "float64":
+            assert rel_err(got, want) < RTOL_F64
+            assert abs(s - want.sum()) <= RTOL_F64 * abs(want.sum())
+        else:
+            assert np.allclose(got, want, atol=5e-4, rtol=1e-4)
+            assert abs(s - want.sum()) <= RTOL_F32 * abs(want.sum())
+        assert abs(s - got.sum()) <= 1e-9 * abs(s)
+        monkeypatch.setenv("PBN_SWEEP_PRUNE", "0")
+        plain = make()
+        plain.fit(train)
+        monkeypatch.delenv("PBN_SWEEP_PRUNE")
+        ref = plain.logl(test)
+        assert np.allclose(got, ref, rtol=1e-9 if dtype == "float64" else 1e-4, atol=1e-9 if dtype == "float64" else 5e-4)
+        assert np.allclose(k.logl(test.iloc[100:777]), got[100:777], rtol=1e-9 if dtype == "float64" else 1e-4,
+                           atol=1e-9 if dtype == "float64" else 5e-4)
