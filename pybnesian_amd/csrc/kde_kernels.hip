@@ -927,46 +927,107 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
         }
     }
 
+    // Plain unpruned sweeps (the else branch): all groups' MFMAs are issued before the first exponential so that the matrix pipe works under the
+    // VALU's exponentials, one overflow test per tile, the rare path redoes a group (C2 fp32: 15.2 -> 14.1 ms).  The
+    // fused CKDE sweep and the pruned sweeps keep the group-by-group form: with two accumulator sets per group in flight,
+    // or one wave per SIMD less, the other form loses (C5's sweeps 33 -> 40 s; pruned d = 1 plain sweep 8.3 -> 10.2 ms).
     auto process_tile = [&](const bf8 (&f)[NB], const bf8& x) {
+        if constexpr (COND || PRUNE) {
 #pragma unroll
-        for (int g = 0; g < QG; ++g) {
-            V acc = mfma_main(f, g, cmv[g]);
-            V accj;
-            if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);
-            float e0 = Tr<float>::ex2(acc[0]), e1 = Tr<float>::ex2(acc[1]), e2 = Tr<float>::ex2(acc[2]), e3 = Tr<float>::ex2(acc[3]);
-            float ts = (e0 + e1) + (e2 + e3);
-            float tsj = 0;
-            bool bad = !(ts < Tr<float>::big());
-            if (COND) {
-                float j0 = Tr<float>::ex2(accj[0]), j1 = Tr<float>::ex2(accj[1]), j2 = Tr<float>::ex2(accj[2]), j3 = Tr<float>::ex2(accj[3]);
-                tsj = (j0 + j1) + (j2 + j3);
-                bad = bad || !(tsj < Tr<float>::big());
-            }
-            if (__builtin_expect(__any(bad), 0)) {
-                float mx = colmax<float>(max4<float>(acc));
-                if (mx > 0.f) {
-                    m[g] += mx;
-                    const float cm = ny[g] - m[g];
-                    cmv[g] = V{cm, cm, cm, cm};
-                    sum[g] *= exp2(-(double)mx);
-                    acc -= mx;
-                }
-                e0 = Tr<float>::ex2(acc[0]); e1 = Tr<float>::ex2(acc[1]); e2 = Tr<float>::ex2(acc[2]); e3 = Tr<float>::ex2(acc[3]);
-                ts = (e0 + e1) + (e2 + e3);
+            for (int g = 0; g < QG; ++g) {
+                V acc = mfma_main(f, g, cmv[g]);
+                V accj;
+                if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);
+                float e0 = Tr<float>::ex2(acc[0]), e1 = Tr<float>::ex2(acc[1]), e2 = Tr<float>::ex2(acc[2]), e3 = Tr<float>::ex2(acc[3]);
+                float ts = (e0 + e1) + (e2 + e3);
+                float tsj = 0;
+                bool bad = !(ts < Tr<float>::big());
                 if (COND) {
-                    float mxj = colmax<float>(max4<float>(accj));
-                    if (mxj > 0.f) {
-                        mj[g] += mxj;
-                        sumj[g] *= exp2(-(double)mxj);
-                        accj -= mxj;
-                    }
-                    set_bx(g);
                     float j0 = Tr<float>::ex2(accj[0]), j1 = Tr<float>::ex2(accj[1]), j2 = Tr<float>::ex2(accj[2]), j3 = Tr<float>::ex2(accj[3]);
                     tsj = (j0 + j1) + (j2 + j3);
+                    bad = bad || !(tsj < Tr<float>::big());
+                }
+                if (__builtin_expect(__any(bad), 0)) {
+                    float mx = colmax<float>(max4<float>(acc));
+                    if (mx > 0.f) {
+                        m[g] += mx;
+                        const float cm = ny[g] - m[g];
+                        cmv[g] = V{cm, cm, cm, cm};
+                        sum[g] *= exp2(-(double)mx);
+                        acc -= mx;
+                    }
+                    e0 = Tr<float>::ex2(acc[0]); e1 = Tr<float>::ex2(acc[1]); e2 = Tr<float>::ex2(acc[2]); e3 = Tr<float>::ex2(acc[3]);
+                    ts = (e0 + e1) + (e2 + e3);
+                    if (COND) {
+                        float mxj = colmax<float>(max4<float>(accj));
+                        if (mxj > 0.f) {
+                            mj[g] += mxj;
+                            sumj[g] *= exp2(-(double)mxj);
+                            accj -= mxj;
+                        }
+                        set_bx(g);
+                        float j0 = Tr<float>::ex2(accj[0]), j1 = Tr<float>::ex2(accj[1]), j2 = Tr<float>::ex2(accj[2]), j3 = Tr<float>::ex2(accj[3]);
+                        tsj = (j0 + j1) + (j2 + j3);
+                    }
+                }
+                sum[g] += (double)ts;
+                if (COND) sumj[g] += (double)tsj;
+            }
+        } else {
+            V acc[QG], accj[QG];
+            float ts[QG], tsj[QG];
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                acc[g] = mfma_main(f, g, cmv[g]);
+                if (COND) accj[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc[g], 0, 0, 0);
+            }
+            bool bad = false;
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const float e0 = Tr<float>::ex2(acc[g][0]), e1 = Tr<float>::ex2(acc[g][1]), e2 = Tr<float>::ex2(acc[g][2]), e3 = Tr<float>::ex2(acc[g][3]);
+                ts[g] = (e0 + e1) + (e2 + e3);
+                tsj[g] = 0;
+                bad = bad || !(ts[g] < Tr<float>::big());
+                if (COND) {
+                    const float j0 = Tr<float>::ex2(accj[g][0]), j1 = Tr<float>::ex2(accj[g][1]), j2 = Tr<float>::ex2(accj[g][2]), j3 = Tr<float>::ex2(accj[g][3]);
+                    tsj[g] = (j0 + j1) + (j2 + j3);
+                    bad = bad || !(tsj[g] < Tr<float>::big());
                 }
             }
-            sum[g] += (double)ts;
-            if (COND) sumj[g] += (double)tsj;
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    bool badg = !(ts[g] < Tr<float>::big());
+                    if (COND) badg = badg || !(tsj[g] < Tr<float>::big());
+                    if (!__any(badg)) continue;
+                    float mx = colmax<float>(max4<float>(acc[g]));
+                    if (mx > 0.f) {
+                        m[g] += mx;
+                        const float cm = ny[g] - m[g];
+                        cmv[g] = V{cm, cm, cm, cm};
+                        sum[g] *= exp2(-(double)mx);
+                        acc[g] -= mx;
+                    }
+                    const float e0 = Tr<float>::ex2(acc[g][0]), e1 = Tr<float>::ex2(acc[g][1]), e2 = Tr<float>::ex2(acc[g][2]), e3 = Tr<float>::ex2(acc[g][3]);
+                    ts[g] = (e0 + e1) + (e2 + e3);
+                    if (COND) {
+                        float mxj = colmax<float>(max4<float>(accj[g]));
+                        if (mxj > 0.f) {
+                            mj[g] += mxj;
+                            sumj[g] *= exp2(-(double)mxj);
+                            accj[g] -= mxj;
+                        }
+                        set_bx(g);
+                        const float j0 = Tr<float>::ex2(accj[g][0]), j1 = Tr<float>::ex2(accj[g][1]), j2 = Tr<float>::ex2(accj[g][2]), j3 = Tr<float>::ex2(accj[g][3]);
+                        tsj[g] = (j0 + j1) + (j2 + j3);
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                sum[g] += (double)ts[g];
+                if (COND) sumj[g] += (double)tsj[g];
+            }
         }
     };
 
