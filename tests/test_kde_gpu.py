@@ -339,3 +339,5 @@ def test_pruned_handles_match_oracle(pbn, oracle, d, dtype, monkeypatch):
         assert np.allclose(got, ref, rtol=1e-9 if dtype == "float64" else 1e-4, atol=1e-9 if dtype == "float64" else 5e-4)
         assert np.allclose(k.logl(test.iloc[100:777]), got[100:777], rtol=1e-9 if dtype == "float64" else 1e-4,
                            atol=1e-9 if dtype == "float64" else 5e-4)
+        assert np.allclose(k.logl(test.iloc[5:6]), got[5:6], rtol=1e-9 if dtype == "float64" else 1e-4, atol=5e-4)   # one far query alone
+        assert k.logl(test.iloc[:0]).shape == (0,) and k.slogl(test.iloc[:0]) == 0.0
