@@ -341,3 +341,28 @@ def test_pruned_handles_match_oracle(pbn, oracle, d, dtype, monkeypatch):
                            atol=1e-9 if dtype == "float64" else 5e-4)
         assert np.allclose(k.logl(test.iloc[5:6]), got[5:6], rtol=1e-9 if dtype == "float64" else 1e-4, atol=5e-4)   # one far query alone
         assert k.logl(test.iloc[:0]).shape == (0,) and k.slogl(test.iloc[:0]) == 0.0
+
+
+def test_pruned_handles_full_size_properties(pbn, monkeypatch):
+    """BASELINE sizes (1e6 training x 1e5 test rows) at d = 2, where the fitted handle prunes: the sum equals the unpruned
+    sweep's and the sum of the per-row values, and splitting the test rows is additive (each slice is Morton-ordered on its
+    own, so this also checks that the scatter back to caller order does not depend on the slice)."""
+    rng = np.random.default_rng(5)
+    n, m, names = 1_000_000, 100_000, ["a", "b"]
+    mix = np.array([[1.0, 0.0], [0.3, 1.0]])
+    train = pa.RecordBatch.from_arrays([pa.array(c) for c in (rng.normal(size=(n, 2)) @ mix.T).T], names=names)
+    q = rng.normal(size=(m, 2)) @ mix.T
+    test = pd.DataFrame(q, columns=names)
+    k = pbn.KDE(names)
+    k.fit(train)
+    ll, s = k.logl(test), k.slogl(test)
+    assert np.all(np.isfinite(ll)) and abs(s - ll.sum()) <= 1e-10 * abs(s)
+    s1, s2 = k.slogl(test.iloc[:33_333]), k.slogl(test.iloc[33_333:])
+    assert abs((s1 + s2) - s) <= 1e-10 * abs(s)
+    assert np.allclose(k.logl(test.iloc[50_000:50_100]), ll[50_000:50_100], rtol=1e-11, atol=1e-11)
+    monkeypatch.setenv("PBN_SWEEP_PRUNE", "0")
+    plain = pbn.KDE(names)
+    plain.fit(train)
+    monkeypatch.delenv("PBN_SWEEP_PRUNE")
+    assert abs(plain.slogl(test) - s) <= 1e-10 * abs(s)
+    assert np.allclose(plain.logl(test.iloc[:4096]), ll[:4096], rtol=1e-10, atol=1e-10)
