@@ -223,3 +223,32 @@ def test_new_entry_points_edge_cases(pbn, golden):
     assert 0 <= lc.pvalue("a", "b") <= 1
     with pytest.raises(ValueError):                        # 4 rows, 2 conditioning variables: no degrees of freedom left
         lc.pvalue("a", "b", ["c", "d"])
+
+
+@pytest.mark.parametrize("n", [20_000, 120_000])   # below / above the row count from which fitted handles prune
+def test_far_queries_fp32_stay_finite(pbn, n):
+    """Queries ~10^6 bandwidths away from fp32 training data with a large offset: the exponents (~1e13) are far beyond
+    what fp32 resolves, the result must still be the finite, hugely negative value of the fp64 evaluation (relative 1e-5),
+    never -inf (tools/fuzz_pruned.py, seed 1 case 65)."""
+    rng = np.random.default_rng(65)
+    names = ["y", "e"]
+    train = pd.DataFrame(1e4 + rng.normal(size=(n, 2)) * np.array([1.0, 2.0]), columns=names).astype("float32")
+    near = 1e4 + rng.normal(size=(4097, 2)) * np.array([1.0, 2.0])
+    # (a near variable with far evidence is left out: lj - lm of two ~1e12 values is not resolvable in fp32 anywhere)
+    far = np.array([[5.01e5, 5.01e5], [5.0e5, 5.02e5], [-3e5, 1e4], [2e6, -2e6], [6e4, 6e4]])
+    test = pd.DataFrame(np.vstack([near, far]), columns=names).astype("float32")
+    cpd = pbn.CKDE("y", ["e"])
+    cpd.fit(train)
+    got = cpd.logl(test)
+    ref = pbn.CKDE("y", ["e"])
+    ref.fit(train.astype("float64"))
+    want = ref.logl(test.astype("float64"))
+    assert np.all(np.isfinite(got))
+    assert np.allclose(got[-5:], want[-5:], rtol=1e-5, atol=5e-3)
+    assert np.allclose(got[:-5], want[:-5], rtol=1e-4, atol=5e-4)
+    kde = pbn.KDE(names)
+    kde.fit(train)
+    ref = pbn.KDE(names)
+    ref.fit(train.astype("float64"))
+    got, want = kde.logl(test), ref.logl(test.astype("float64"))
+    assert np.all(np.isfinite(got)) and np.allclose(got[-5:], want[-5:], rtol=1e-5, atol=5e-3)

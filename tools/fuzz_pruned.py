@@ -1,0 +1,77 @@
+"""Randomised comparison of pruned against unpruned KDE / CKDE handles (logl per row) on awkward data: heavy tails,
+clusters, duplicated rows, lattice-valued columns, large offsets.  python tools/fuzz_pruned.py [n_cases] [seed]"""
+import os, sys
+import numpy as np
+import pandas as pd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pybnesian_amd as pbn
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = 0.0
+for case in range(n_cases):
+    d = int(rng.integers(1, 5))
+    dtype = "float64" if rng.random() < 0.6 else "float32"
+    n = int(rng.choice([32768, 33000, 50_001, 120_000]))
+    m = int(rng.choice([1, 17, 1000, 4097]))
+    kind = rng.choice(["cauchy", "clusters", "dups", "lattice", "offset", "line"])
+    def draw(k):
+        if kind == "cauchy":
+            return rng.standard_t(1.5, size=(k, d))
+        if kind == "clusters":
+            c = rng.uniform(-200, 200, size=(6, d))
+            return c[rng.integers(0, 6, size=k)] + rng.normal(scale=rng.uniform(0.01, 3.0), size=(k, d))
+        if kind == "dups":
+            base = rng.normal(size=(50, d))
+            return base[rng.integers(0, 50, size=k)] + rng.normal(scale=1e-3, size=(k, d))
+        if kind == "lattice":
+            return rng.integers(-5, 6, size=(k, d)).astype(float) + rng.normal(scale=0.05, size=(k, d))
+        if kind == "offset":
+            return 1e4 + rng.normal(size=(k, d)) * np.arange(1, d + 1)
+        t = rng.normal(size=(k, 1))          # nearly degenerate: points along a line
+        return t @ np.ones((1, d)) + rng.normal(scale=0.02, size=(k, d))
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame(draw(n), columns=names).astype(dtype)
+    test = pd.DataFrame(np.vstack([draw(m), draw(3) * 50.0 + 1e3]), columns=names).astype(dtype)
+    for what in ("KDE", "ProductKDE", "CKDE"):
+        if what == "CKDE" and d == 1:
+            continue
+        mk = (lambda: pbn.KDE(names)) if what == "KDE" else (lambda: pbn.ProductKDE(names)) if what == "ProductKDE" else (lambda: pbn.CKDE(names[0], names[1:]))
+        try:
+            os.environ["PBN_SWEEP_PRUNE"] = "1"; a = mk(); a.fit(train); la = a.logl(test); sa = a.slogl(test)
+            os.environ["PBN_SWEEP_PRUNE"] = "0"; b = mk(); b.fit(train); lb = b.logl(test); sb = b.slogl(test)
+        except ValueError as ex:
+            print(f"case {case} {kind} d={d} {dtype} {what}: {type(ex).__name__} {str(ex)[:60]}")
+            continue
+        tol = 1e-9
+        if dtype == "float32":
+            # the fp32 sweeps take -|z_t|^2/2 + z_t.z_q - |z_q|^2/2 in fp32: absolute error of an exponent ~ 2^-24 |z|^2 with z the
+            # whitened coordinate relative to the training mean - tiny bandwidths on spread-out data show up here
+            H = np.atleast_1d(np.asarray(b.bandwidth, dtype=np.float64))
+            X = np.vstack([train.to_numpy(), test.to_numpy()[:-3]]).astype(np.float64)
+            X = X - train.to_numpy().astype(np.float64).mean(axis=0)
+            Z = X / np.sqrt(H) if H.ndim == 1 else np.linalg.solve(np.linalg.cholesky(H), X.T).T
+            tol = 5e-4 + 8.0 * 2.0 ** -24 * float((Z * Z).sum(axis=1).max())
+        fin = np.isfinite(lb)
+        err = float(np.max(np.abs(la[fin] - lb[fin]) / np.maximum(1.0, np.abs(lb[fin])))) if fin.any() else 0.0
+        same_inf = np.array_equal(np.isfinite(la), fin) and np.array_equal(la[~fin], lb[~fin], equal_nan=True)
+        worst = max(worst, err if dtype == "float64" else 0.0)
+        ok = err <= tol and same_inf and (not np.isfinite(sb) or abs(sa - sb) <= tol * max(1.0, abs(sb)) * 10)
+        print(f"case {case} {kind:8s} d={d} {dtype} n={n} m={m} {what:10s} max rel diff {err:.2e} {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            os.environ["PBN_SWEEP_PRUNE"] = "0"
+            t = mk(); t.fit(train.astype("float64"))
+            try:
+                t.bandwidth = np.asarray(b.bandwidth, dtype=np.float64)
+            except AttributeError:
+                pass
+            lt = t.logl(test.astype("float64"))
+            with np.errstate(invalid="ignore"):
+                key = np.abs(la - lb) / np.maximum(1.0, np.abs(lb))
+            key[~np.isfinite(la) & np.isfinite(lb)] = np.inf
+            bad = np.argsort(-np.nan_to_num(key, nan=0.0, posinf=1e300))[:6]
+            for i in bad:
+                print(f"   row {i} of {len(la)}: pruned {la[i]:.9g} unpruned {lb[i]:.9g} fp64 on the same data {lt[i]:.9g}  x = {test.to_numpy()[i]}")
+            print("   bandwidth", np.asarray(b.bandwidth).ravel())
+            sys.exit(1)
+print("all ok; worst fp64 difference", worst)
