@@ -434,9 +434,6 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     }
     auto skip_tile = [&](int64_t t) -> bool {
         if (!PRUNE) return false;
-        // the split's first tile defined the offsets: it always stays in the sum, so that every split's partial holds the term
-        // its offset came from (otherwise rounding at huge exponents - far queries in fp32 - can leave only empty partials)
-        if (t == t0) return false;
         const double* bx = a.tile_box + t * 2 * pd;
         double d2 = 0.0;
 #pragma unroll
@@ -560,6 +557,9 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             sj += __shfl_xor(sj, 16);
             sj += __shfl_xor(sj, 32);
         }
+        // an empty sum still holds the term its offset came from (see kde_sweep_bf16_kernel; 2^bias is that term here)
+        if (s == 0.0) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        if (COND && sj == 0.0) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (lg == 0 && qt0 + g < a.nqtiles) {
             double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g] - (double)Tr<T>::bias();   // the sums carry 2^bias
@@ -880,9 +880,6 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     }
     auto skip_tile = [&](int64_t t) -> bool {
         if (!PRUNE) return false;
-        // the split's first tile defined the offsets: it always stays in the sum, so that every split's partial holds the term
-        // its offset came from (otherwise rounding at huge exponents - far queries in fp32 - can leave only empty partials)
-        if (t == t0) return false;
         const double* bx = a.tile_box + t * 2 * pd;
         double d2 = 0.0;
 #pragma unroll
@@ -1061,9 +1058,10 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
             sj += __shfl_xor(sj, 16);
             sj += __shfl_xor(sj, 32);
         }
-        // The offsets are exponents of pairs of this split's first tile, which is part of the sum; when the exponents are so
-        // large that their fp32 rounding (ulp(|e|) >> 1: queries ~10^6 bandwidths away) makes the second evaluation of that
-        // tile underflow, the sum can come out empty: it holds at least the offset's own term.
+        // The offsets are exponents of pairs of this split's first tile.  When the exponents are so large that their fp32
+        // rounding (ulp(|e|) >> 1: queries ~10^6 bandwidths away) makes the second evaluation of that tile underflow, the
+        // sum can come out empty although it holds at least the offset's own term: count that term.  (A split whose tiles
+        // were all pruned gets the same term: below 2^-64 of the query's sum by the pruning rule.)
         if (s == 0.0) s = 1.0;
         if (COND && sj == 0.0) sj = 1.0;
         if (lg == 0 && qt0 + g < a.nqtiles) {
