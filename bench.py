@@ -6,7 +6,7 @@ diagonal ("product") bandwidth from the normal reference rule, synthetic correla
 (SURVEY.md §8d).  A *step* is one full slogl(test) on an already fitted model with train and test tables
 resident in HBM: pack the queries -> fused pairwise/logsumexp sweep -> finish/reduce -> one scalar.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        # N > 1 without WORLD_SIZE: starts its own N ranks (see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Multi-GPU (weak scaling): the fitted training set is replicated on every GPU, each rank owns its own
@@ -33,6 +33,7 @@ FLOPS_PER_PAIR = 3 * D + 2          # d sub + d fma(2) + exp(1) 
 FP64_PEAK_TFLOPS = 78.6             # MI355X FP64 vector == matrix peak (AMD CDNA4 spec; 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 FP32_PEAK_TFLOPS = 157.3            # MI355X FP32 vector == f32-matrix peak (MI355X_MICROARCH.md); the --dtype f32 run is priced against it
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_VALU_CYCLES_PER_VALUE = 12.0    # fp32 sweep: v_exp_f32 (8 issue cycles per wave64) + v_add_f32 (4) per pair value
 
 
 def make_tables(torch, device, n_train, n_test, seed_train, seed_test, dtype):
@@ -213,15 +214,19 @@ def pmc_traffic(args):
     FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc runs of this same command; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload; null otherwise."""
     if (args.n_train, args.n_test, args.dtype, args.kde) != (1_000_000, 100_000, "f64", "product"):
-        return None
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4" in name)
-        return 2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0
-    except Exception:
-        return None
+        return None, None
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4" in name)
+            return (2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0,
+                    f"committed rocprofv3 --pmc passes of this command (profiles/{rnd}/pmc_per_dispatch.json: 2 x FETCH_SIZE + "
+                    f"WRITE_SIZE), not measured in this run")
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(train_np, test_np, h, budget_s=12.0):
@@ -272,6 +277,62 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves (one
+    process per GPU, `python -m torch.distributed.run` as a CHILD process) and exit with its code.  This parent never
+    imports torch and never touches HIP (a process that has initialised the GPU must not be replaced, and the children
+    own the devices); rank 0 of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def e2e_host(pbn, kde, names, test_np, repeats=3):
+    """the same slogl with the test table in HOST Arrow memory - upload (PCIe), query pack, sweep, finish,
+    scalar back - through the reference-shaped Python call `ProductKDE.slogl(record_batch)`.  Never the headline value."""
+    import pyarrow as pa
+
+    rb = pa.RecordBatch.from_arrays([pa.array(np.ascontiguousarray(test_np[:, i])) for i in range(test_np.shape[1])], names=names)
+    kde.slogl(rb.slice(0, 256))   # warm the path
+    best, val = None, None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        val = kde.slogl(rb)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": rb.num_rows / best / 1e6, "unit": "M-samples/s", "ms": best * 1e3, "slogl": val,
+            "what": f"{kde.__class__.__name__}.slogl(pyarrow.RecordBatch in host memory, {rb.num_rows} rows): H2D of the test "
+                    f"columns + query pack + sweep + finish + D2H of the scalar, best of {repeats}"}
+
+
+def dp_issue_util():
+    """Share of the FP64 issue slots the sweep kept busy, from the committed rocprofv3 PMC pass of this command:
+    (MFMA busy cycles + 4 cycles per VALU wave-instruction) / (cycles x 1024 SIMDs)."""
+    for rnd in ("r2", "r1"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")) as f:
+                d = json.load(f)
+            k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4" in name)
+            simd_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            return {"value": (k["SQ_VALU_MFMA_BUSY_CYCLES"] + 4.0 * k["SQ_INSTS_VALU"]) / simd_cycles,
+                    "mfma_busy_frac": k["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
+                    "valu_insts_per_pair_value": k["SQ_INSTS_VALU"] * 64.0 / 1e11,
+                    "source": f"profiles/{rnd}/pmc_per_dispatch.json (separate rocprofv3 --pmc pass, not this run)"}
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,20 +343,28 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--kde", default="product", choices=["product", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hc", default="c4", choices=["none", "c4", "c3", "cv64", "c5", "c5mmhc"],
+    ap.add_argument("--hc", default="auto", choices=["auto", "none", "c4", "c3", "cv64", "c5", "c5mmhc"],
                     help="secondary hill-climb metric: c4 = BASELINE config 4 (BGe, replicated moments), c3 = config 3 at full "
-                         "size (slow), cv64 = 64-node CV-likelihood CKDE hill-climb whose candidates are sharded over the ranks")
+                         "size (bounded by --hc-max-iters), cv64 = 64-node CV-likelihood CKDE hill-climb whose candidates are "
+                         "sharded over the ranks; auto = c4 on one GPU, cv64 on several")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to exercise the N>1 path on one GPU)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the bounded config-3 (CKDE, 10-fold CV) hill-climb leg of the default run")
     ap.add_argument("--hc-rows", type=int, default=0)
     ap.add_argument("--hc-max-iters", type=int, default=0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))   # before any torch / HIP call in this process
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    hc_auto = args.hc == "auto"
+    if hc_auto:
+        args.hc = "c4" if world == 1 else "cv64"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if "PBN_BENCH_DEVICE" in os.environ:  # testing aid: put every rank on one device (with --backend gloo)
@@ -365,8 +434,20 @@ def main():
             os.environ["PBN_BENCH_NO_CPU"] = "1"
         try:
             hc_out = bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, args.hc_max_iters)
+            if dist is not None:
+                hc_out["ranks"] = world
+                hc_out["sharding"] = ("CKDE candidates of every delta-cache batch dealt to the ranks by variable set, one all_gather of "
+                                      "the batch's scores per batch; fixed total work (strong scaling of the search)")
         except Exception as ex:  # the secondary metric must never cost the headline line
             hc_out = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
+    c3_out = None
+    if hc_auto and world == 1 and not args.no_c3:
+        # the CKDE path of the search, driver-timed: BASELINE config 3 at FULL size (32-node SPBN, 10-fold CV, 500 k rows),
+        # bounded to the initial delta cache + one iteration
+        try:
+            c3_out = bench_hill_climb(torch, pbn, _lib, ctx, device, "c3", 0, 1)
+        except Exception as ex:
+            c3_out = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
 
     total_samples = args.n_test * world * args.steps
     value = total_samples / elapsed / 1e6
@@ -378,7 +459,21 @@ def main():
         sweep_s = sweep_ms / max(sweep_n, 1) * 1e-3
         alg_bytes = (args.n_train * D + args.n_test * D + args.n_test) * es
         achieved_tf = pairs * FLOPS_PER_PAIR / sweep_s / 1e12
-        peak_tf = FP64_PEAK_TFLOPS if args.dtype == "f64" else FP32_PEAK_TFLOPS
+        if args.dtype == "f64":
+            peak_tf = FP64_PEAK_TFLOPS
+            peak_note = ("against the FP64 vector==matrix peak (v_mfma_f64 and the FP64 VALU share their issue slots on MI355X: "
+                         "DESIGN.md §3.1)")
+        else:
+            # fp32 sweep: the dot products run as bf16x3 on the bf16 matrix cores and overlap with the VALU, which is
+            # the binding unit: per pair value one v_exp_f32 (quarter rate: 8 issue cycles per wave64 on this part,
+            # profiles/r1/microbench_r1.txt) and one v_add_f32 (4) at least.  Peak pair rate by VALU issue =
+            # SIMDs x clock x 64 / 12 cycles, expressed in the same algorithmic flops (3d+2 per pair)
+            peak_pairs = 256 * 4 * 2.4e9 * 64.0 / F32_VALU_CYCLES_PER_VALUE
+            peak_tf = peak_pairs * FLOPS_PER_PAIR / 1e12
+            peak_note = (f"against the VALU-issue bound of the fp32 sweep: one v_exp_f32 (8 issue cycles per wave64) + one v_add_f32 (4) per "
+                         f"pair value -> {peak_pairs / 1e12:.2f}e12 pairs/s x (3d+2) flop; the distances run as bf16x3 on the bf16 matrix "
+                         f"cores under the VALU work (the FP32 vector peak, {FP32_PEAK_TFLOPS} TFLOP/s, is not the binding unit)")
+        traffic, traffic_source = pmc_traffic(args)
         out = {
             "metric": "KDE slogl M-samples/s",
             "value": value,
@@ -396,6 +491,8 @@ def main():
                 "workload": f"C2: {'ProductKDE' if args.kde == 'product' else 'KDE'}.slogl {args.dtype}, N_train={args.n_train}, "
                             f"N_test={args.n_test} per GPU, d={D}, normal-reference {'diagonal' if args.kde == 'product' else 'full'} bandwidth",
                 "parallelism": f"test rows sharded over {world} GPU(s), training set replicated",
+                "ranks": world,
+                "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
                 "pairs_per_step_per_gpu": pairs,
                 "slogl_step0_rank_sum": slogl,
             },
@@ -406,12 +503,10 @@ def main():
                 "peak": peak_tf,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / peak_tf,
-                "traffic": pmc_traffic(args),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "note": "compute-bound sweep (SURVEY.md §8d): algorithmic flops = (3d+2) per train/test pair (exp counted as 1) "
-                        + ("against the FP64 vector==matrix peak" if args.dtype == "f64" else
-                           "against the FP32 vector peak (the fp32 sweep's distances run as bf16x3 on the bf16 matrix cores, its "
-                           "2^x and sums on the f32 VALU, which is the binding unit)")
-                        + "; sweep launch duration from HIP events on the library stream",
+                        + peak_note + "; sweep launch duration from HIP events on the library stream",
                 "avg_launch_ms": sweep_s * 1e3,
                 "gpairs_per_s": pairs / sweep_s / 1e9,
                 "hbm_algorithmic_bytes": alg_bytes,
@@ -421,8 +516,17 @@ def main():
                 "finish_ms": fin_ms / max(sweep_n, 1),
             },
         }
+        if args.dtype == "f64" and traffic is not None:
+            out["roofline"]["dp_issue_util"] = dp_issue_util()
         if hc_out is not None:
             out["secondary"] = hc_out
+        if c3_out is not None:
+            out["secondary_c3"] = c3_out
+        if world == 1:
+            try:
+                out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy())
+            except Exception as ex:
+                out["e2e_host"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not args.no_cpu_baseline:
             h = np.asarray(kde.bandwidth, dtype=np.float64)
             sample_rows = min(args.n_test, 16384)

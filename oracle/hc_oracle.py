@@ -121,8 +121,14 @@ def _same(o1, o2):
 
 def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_blacklist=(), arc_whitelist=(), type_blacklist=(),
              type_whitelist=(), op_arcs=True, op_types=False, arcs_first=True, max_indegree=0, max_iters=2 ** 31 - 1,
-             epsilon=0.0, patience=0, n_interface=0):
-    """n_interface > 0: conditional network (operators.cpp:134-256,365-437; operators.hpp:526-578) - ids n .. n+ni-1 are
+             epsilon=0.0, patience=0, n_interface=0, follow=None, tie_tol=1e-9):
+    """follow: an operator sequence [(kind, a, b), ...] (e.g. the product's trace) to REPLAY - at every iteration the
+    restatement still takes its own greedy decision from its own deltas, but then applies follow[i]; whenever the two differ
+    it records (iteration, own op, followed op, |own delta - delta of the followed op|) in info["flips"], and raises
+    AssertionError if that gap exceeds tie_tol * max(1, |delta|): the followed sequence is then not a greedy sequence
+    under this restatement's scores.  This is the tie-flip accounting of SURVEY.md §7 hard part (a): score-equivalent
+    orientations (a -> b vs b -> a under BIC / BGe) tie mathematically, so which one wins is decided in the last ulps.
+    n_interface > 0: conditional network (operators.cpp:134-256,365-437; operators.hpp:526-578) - ids n .. n+ni-1 are
     interface nodes; the delta matrix is (n + ni) x n."""
     ni = n_interface
     J = n + ni
@@ -294,10 +300,35 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
         if op_arcs:
             cache_arcs()
     p, offset, tabu, trace, it = 0, 0.0, [], [], 0
+    flips = []
+
+    def delta_of(kind, a, b):
+        if kind == 3:
+            return tdelta[a]
+        if kind == 2:                      # FlipArc(a -> b) lives in the cell of the NEW arc b -> a
+            return float(delta[b + a * J])
+        return float(delta[a + b * J])
+
     while it < max_iters:
         it += 1
         op = find_max(None if (zero_patience or not tabu) else tabu)
-        if op is None or (op[3] - epsilon) < MACHINE_TOL:
+        if follow is not None:
+            stop = op is None or (op[3] - epsilon) < MACHINE_TOL
+            if it - 1 >= len(follow):
+                if not stop and op[3] > tie_tol * max(1.0, abs(op[3])) + MACHINE_TOL:
+                    raise AssertionError(f"followed trace stops at iteration {it} but the restatement still improves by {op[3]} with {op[:3]}")
+                break
+            f = tuple(follow[it - 1][:3])
+            fd = delta_of(*f)
+            if stop or tuple(op[:3]) != f:
+                own = None if op is None else op[3]
+                gap = abs((own if own is not None else 0.0) - fd)
+                flips.append({"iteration": it, "own": None if op is None else list(op[:3]), "followed": list(f), "own_delta": own,
+                              "followed_delta": fd, "gap": gap})
+                if gap > tie_tol * max(1.0, abs(fd)):
+                    raise AssertionError(f"iteration {it}: followed op {f} (delta {fd}) is not a tie of the restatement's {op}")
+            op = (f[0], f[1], f[2], fd)          # replay: always applied
+        elif op is None or (op[3] - epsilon) < MACHINE_TOL:
             break
         m.apply(op)
         changed = [op[1], op[2]] if op[0] == 2 else ([op[1]] if op[0] == 3 else [op[2]])
@@ -336,4 +367,4 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
             update_types(changed)
     res = m if best_is_current else best_model
     arcs_out = [(s, t) for t in range(n) for s in res.parents[t]]
-    return arcs_out, list(res.node_type), trace, {"iterations": it, "cells_scored": cells[0]}
+    return arcs_out, list(res.node_type), trace, {"iterations": it, "cells_scored": cells[0], "flips": flips}

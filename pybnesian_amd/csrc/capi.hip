@@ -17,6 +17,10 @@
 namespace pbn {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
+std::recursive_mutex& api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
 }  // namespace pbn
 
 using namespace pbn;
@@ -46,6 +50,7 @@ int pbn_ctx_create(int device, pbn_ctx** out) {
 
 void pbn_ctx_destroy(pbn_ctx* ctx) {
     if (!ctx) return;
+    PBN_API_LOCK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->scratch_part.release();
@@ -159,6 +164,7 @@ int pbn_table_from_device(pbn_ctx* ctx, void* dev_base, int64_t ld, int n_cols, 
 
 void pbn_table_destroy(pbn_table* t) {
     if (!t) return;
+    PBN_API_LOCK;
     if (t->owns && t->data) {
         (void)hipSetDevice(t->ctx->device);
         (void)hipStreamSynchronize(t->ctx->stream);
@@ -293,17 +299,36 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         center = pilot.data();
     }
     kde_prepare(k->m, train->dtype, d, n, bw, kind, cond, center);
-    const KdePackBytes pb = kde_pack_bytes(train->dtype, k->m.dm, k->m.cond, n);
-    k->Apack.alloc(pb.apack);
-    k->nxpack.alloc(pb.nxpack);
-    if (k->m.cond) k->Axpack.alloc(pb.axpack);
-    k->m.Apack = k->Apack.p; k->m.nxpack = k->nxpack.p; k->m.Axpack = k->Axpack.p;
-    // low-dimensional, large models: rows packed in Morton order with per-tile boxes, so that logl / slogl skip the
-    // tile pairs that cannot contribute (same rule as the score engine's sweeps)
-    // (measured at 1e6 x 1e5 rows, tools/prune_handles_timing.py: pays up to 4 marginal dimensions in fp64, 3 in fp32)
-    const bool prune = k->m.dm <= (train->dtype == PBN_F64 ? 4 : 3);
-    kde_pack_train(ctx, k->m, train, cols, row0, n, 0, nullptr, prune);
-    kde_prune_persist(ctx, k->m, k->prune_store);
+    // Low-dimensional CKDE on a large training set: two pruned plain sweeps (joint over [variable, evidence], marginal over
+    // the evidence with H[1:, 1:] - CKDE.hpp:186-199) beat the fused sweep, whose pruning can only use the marginal box
+    // (tools/prune_handles_timing.py; fp64 up to 3 variables, fp32 2).  PBN_CKDE_SPLIT=0 keeps the fused sweep, =1 splits
+    // whenever the marginal qualifies for pruning.
+    static const int split_mode = [] { const char* e = getenv("PBN_CKDE_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
+    const bool split = ckde && k->m.cond && split_mode != 0 && kde_prune_applies(train->dtype, d - 1, n) &&
+                       (split_mode > 0 || d <= (train->dtype == PBN_F64 ? 3 : 2));
+    if (split) {
+        std::vector<double> Hm((size_t)(d - 1) * (d - 1));
+        for (int j = 1; j < d; ++j)
+            for (int i = 1; i < d; ++i) Hm[(i - 1) + (size_t)(j - 1) * (d - 1)] = bw[i + (size_t)j * d];
+        pbn_kde* kj = nullptr;
+        pbn_kde* km = nullptr;
+        kde_fit_impl(ctx, train, cols, d, row0, n, bw, PBN_BW_FULL, false, center, &kj);
+        k->split_joint.reset(kj);
+        kde_fit_impl(ctx, train, cols + 1, d - 1, row0, n, Hm.data(), PBN_BW_FULL, false, center ? center + 1 : nullptr, &km);
+        k->split_marg.reset(km);
+    } else {
+        const KdePackBytes pb = kde_pack_bytes(train->dtype, k->m.dm, k->m.cond, n);
+        k->Apack.alloc(pb.apack);
+        k->nxpack.alloc(pb.nxpack);
+        if (k->m.cond) k->Axpack.alloc(pb.axpack);
+        k->m.Apack = k->Apack.p; k->m.nxpack = k->nxpack.p; k->m.Axpack = k->Axpack.p;
+        // low-dimensional, large models: rows packed in Morton order with per-tile boxes, so that logl / slogl skip the
+        // tile pairs that cannot contribute (same rule as the score engine's sweeps)
+        // (measured at 1e6 x 1e5 rows, tools/prune_handles_timing.py: pays up to 4 marginal dimensions in fp64, 3 in fp32)
+        const bool prune = k->m.dm <= (train->dtype == PBN_F64 ? 4 : 3);
+        kde_pack_train(ctx, k->m, train, cols, row0, n, 0, nullptr, prune);
+        kde_prune_persist(ctx, k->m, k->prune_store);
+    }
     if (ckde) {
         // The joint Cholesky factor with the variable last has the Schur complement on its corner: the last
         // whitening row IS (x - H12 H22^-1 e) / sigma_c (CKDE.hpp:538-555 "transform" and "cond_var").
@@ -344,6 +369,7 @@ int pbn_ckde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, i
 
 void pbn_kde_destroy(pbn_kde* k) {
     if (!k) return;
+    PBN_API_LOCK;
     (void)hipSetDevice(k->ctx->device);
     (void)hipStreamSynchronize(k->ctx->stream);
     delete k;
@@ -355,6 +381,21 @@ double pbn_kde_lognorm(const pbn_kde* k, int which) { return which ? k->m.lognor
 static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
                              double* dev_logl, double* dev_sum) {
     if (!k) throw invalid_error("KDE factor not fitted.");
+    if (k->split_joint) {   // CKDE as joint - marginal from two plain (pruned) sweeps
+        pbn_ctx* ctx = k->ctx;
+        check_cols(test, cols, k->m.d, "pbn_kde_logl");
+        const size_t per = dev_logl ? (size_t)std::max<int64_t>(n, 1) : 0;
+        ctx->scratch_split.reserve(2 * per + 2);
+        double* lj = dev_logl ? ctx->scratch_split.p : nullptr;
+        double* lm = dev_logl ? ctx->scratch_split.p + per : nullptr;
+        double* sj = dev_sum ? ctx->scratch_split.p + 2 * per : nullptr;
+        double* sm = dev_sum ? sj + 1 : nullptr;
+        pbn::kde_eval_enqueue(ctx, k->split_joint->m, test, cols, row0, n, lj, sj);
+        pbn::kde_eval_enqueue(ctx, k->split_marg->m, test, cols + 1, row0, n, lm, sm);
+        if (dev_logl) launch_diff(dev_logl, lj, lm, n, ctx->stream);
+        if (dev_sum) launch_diff(dev_sum, sj, sm, 1, ctx->stream);
+        return;
+    }
     pbn::kde_eval_enqueue(k->ctx, k->m, test, cols, row0, n, dev_logl, dev_sum);
 }
 

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -34,6 +35,14 @@ struct device_error : std::runtime_error {
 
 void set_last_error(const std::string& s);
 
+// One lock for the whole C ABI.  A context has ONE stream and grow-only scratch arenas that every call re-carves
+// (scratch_q, scratch_part, ...), and the Python layer loads the library with ctypes.CDLL, which drops the GIL around
+// calls - the reference holds the GIL through its pybind11 calls (SURVEY.md §8b "Threading"), so there two Python
+// threads can never be inside the library at once; here this mutex gives the same guarantee.  Recursive: entry points
+// call each other, and Python callbacks (user-defined scores / independence tests) re-enter on the same thread.
+std::recursive_mutex& api_mutex();
+#define PBN_API_LOCK std::lock_guard<std::recursive_mutex> pbn_api_lock_(::pbn::api_mutex())
+
 inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {
         char buf[512];
@@ -47,6 +56,7 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 template <typename F>
 int guarded(F&& f) noexcept {
     try {
+        PBN_API_LOCK;
         f();
         return PBN_OK;
     } catch (const invalid_error& e) {
@@ -121,6 +131,7 @@ struct pbn_ctx {
     pbn::dev_buf<char> scratch_prune;  // pruned sweeps: whitened rows, keys, permutation, tile boxes of the training side
     pbn::dev_buf<char> scratch_pruneq; // ... of the query side
     pbn::dev_buf<char> scratch_sort;   // radix sort temporaries
+    pbn::dev_buf<double> scratch_split; // CKDE handles evaluated as two plain sweeps: joint / marginal logl or sums
     // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
     bool profiling = false;
     struct Timed { hipEvent_t e0, e1; int which; };

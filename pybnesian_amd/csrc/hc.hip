@@ -508,7 +508,7 @@ int pbn_hc_create(const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user, pbn_
     });
 }
 
-void pbn_hc_destroy(pbn_hc* h) { delete h; }
+void pbn_hc_destroy(pbn_hc* h) { PBN_API_LOCK; delete h; }
 
 int pbn_hc_set_model(pbn_hc* h, int n_arcs, const int* arcs, const int* node_types) {
     return guarded([&] {

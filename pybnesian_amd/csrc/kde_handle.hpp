@@ -1,5 +1,7 @@
 // The public fitted-KDE handle (opaque `pbn_kde` of include/pbn_hip.h), shared by capi.hip and sampling.hip.
 #pragma once
+#include <memory>
+
 #include "kde_kernels.hpp"
 #include "kde_model.hpp"
 
@@ -20,6 +22,10 @@ struct pbn_kde {
     int64_t train_row0 = 0;
     double wu[PBN_MAX_D_HOST];
     dev_buf<char> cA, cN, cU;
+    // Low-dimensional CKDE handles (where tile pruning pays, see kde_fit_impl): logl = logl_joint - logl_marginal from two
+    // pruned PLAIN sweeps - the reference's own formulation (factors/continuous/CKDE.hpp:256-287) - instead of the fused
+    // sweep, which cannot prune on the joint box.  `m` then only carries the host-side whitening / normalisation data.
+    std::unique_ptr<pbn_kde> split_joint, split_marg;
 };
 
 // PackArgs for the cdf fragments: whitening order (evidence first, variable last), contraction over the evidence only.

@@ -32,14 +32,20 @@ namespace pbn {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// 2^r on [-1/2, 1/2]: interpolants at Chebyshev nodes.  The DP units are the binding resource of the fp64 sweep
-// (DESIGN.md "roofline"); every polynomial degree costs 4.4 % of that kernel.  The log-likelihood sweeps use degree 7:
-// max relative error 5.5e-11 per term (4.0e-11 for the [0, 1) form below), four orders below the 1e-6 parity bar and
-// below every tolerance of the parity tests (-DPBN_EXP2_DEGREE=8 restores 1.07e-12 there).  The weight kernels
-// (CKDE::cdf / sample, UCV) always use degree 8: the UCV objective is a difference of two pair sums and amplifies
-// per-term errors.
+// 2^r on [-1/2, 1/2]: interpolants at Chebyshev nodes (exp2_poly), and minimax polynomials on [0, 1) for the v_fract form
+// of the sweep's main loop (exp2_f64_fract).  The DP units are the binding resource of the fp64 sweep (DESIGN.md
+// "roofline"); every polynomial degree costs one of its ~42 DP instructions per (tile, group, 4 values).  The
+// log-likelihood sweeps use degree 6 on [0, 1) pinned to p(0) = 1, p(1) = 2 (Remez on the relative error among such
+// polynomials, tools/exp2_coeffs.py 6 pinned): max relative error 2.22e-9 per term, i.e. <= 2.3e-9 ABSOLUTE on a logl
+// whatever the number of terms (the error of a sum of positive terms is bounded by the per-term bound) - 400x inside the
+// 1e-6 parity bar.  The pinning keeps 2^x continuous across the integers, where v_fract wraps: the largest term of a KDE
+// sum sits at x = bias + 0 exactly, and the free minimax of even degree (1.86e-9) has errors of opposite sign at the two
+// ends - a jump of 3.7e-9 on that term under perturbations of the last ulp.  -DPBN_EXP2_DEGREE=7 restores 4.0e-11
+// (free minimax: same sign at both ends), =8 1.07e-12 (v_rndne form).
+// The weight kernels (CKDE::cdf / sample, UCV) always use degree 8: the UCV objective is a difference of two pair sums
+// and amplifies per-term errors.
 #ifndef PBN_EXP2_DEGREE
-#define PBN_EXP2_DEGREE 7
+#define PBN_EXP2_DEGREE 6
 #endif
 
 template <int DEG>
@@ -98,15 +104,28 @@ __device__ __forceinline__ double exp2_f64_top(double x, double top) {
 // 4.02e-11.  A negative x (a term below 2^-128 of its query's sum, which holds a term >= 2^0) comes out at most 2x too
 // large: invisible (N * 2^-128 relative); x <= -2^31 saturates to INT_MIN and gives 0 like the general form.
 #define PBN_EXP2_BIAS 128.0
+#if PBN_EXP2_DEGREE == 6
+#define PBN_FRACT_TOP 0x1.c765a82c535bdp-13
+#else
+#define PBN_FRACT_TOP 0x1.68b07e4ac7b5bp-16
+#endif
 __device__ __forceinline__ double pin_top_fract() {
     double c;
-    asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(0x1.68b07e4ac7b5bp-16));
+    asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(PBN_FRACT_TOP));
     return c;
 }
 __device__ __forceinline__ double exp2_f64_fract(double x, double top) {
     const double f = __builtin_amdgcn_fract(x);      // v_fract_f64
     int n;
     asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));  // truncation = floor for x >= 0; saturating
+#if PBN_EXP2_DEGREE == 6
+    double p = __builtin_fma(top, f, 0x1.46214fe0d40c9p-10);
+    p = __builtin_fma(p, f, 0x1.3d217bf137896p-7);
+    p = __builtin_fma(p, f, 0x1.c686b389d4c31p-5);
+    p = __builtin_fma(p, f, 0x1.ebfd7378d3f76p-3);
+    p = __builtin_fma(p, f, 0x1.62e42af6f5a89p-1);
+    p = __builtin_fma(p, f, 1.0);
+#else
     double p = __builtin_fma(top, f, 0x1.2cfd657b74f58p-13);
     p = __builtin_fma(p, f, 0x1.5fddc72ac74dep-10);
     p = __builtin_fma(p, f, 0x1.3b0838502e0f5p-7);
@@ -114,6 +133,7 @@ __device__ __forceinline__ double exp2_f64_fract(double x, double top) {
     p = __builtin_fma(p, f, 0x1.ebfbcf8c8da34p-3);
     p = __builtin_fma(p, f, 0x1.62e4301f16f2dp-1);
     p = __builtin_fma(p, f, 0x1.ffffffffa7934p-1);
+#endif
     return __builtin_ldexp(p, n);
 }
 
@@ -136,11 +156,12 @@ struct Tr<double> {
     static __device__ __forceinline__ vec4 mfma(double a, double b, vec4 c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ double ex2(double x) { return exp2_f64<PBN_EXP2_DEGREE>(x); }
-    static __device__ __forceinline__ double top() { return PBN_EXP2_DEGREE == 7 ? pin_top_fract() : 0.0; }
+    static constexpr int GEN_DEG = PBN_EXP2_DEGREE < 7 ? 7 : PBN_EXP2_DEGREE;   // rare paths: v_rndne form, degree >= 7
+    static __device__ __forceinline__ double ex2(double x) { return exp2_f64<GEN_DEG>(x); }
+    static __device__ __forceinline__ double top() { return PBN_EXP2_DEGREE <= 7 ? pin_top_fract() : 0.0; }
     // main-loop form: x carries bias() (see exp2_f64_fract)
     static __device__ __forceinline__ double ex2p(double x, double top) {
-        return PBN_EXP2_DEGREE == 7 ? exp2_f64_fract(x, top) : exp2_f64<PBN_EXP2_DEGREE>(x);
+        return PBN_EXP2_DEGREE <= 7 ? exp2_f64_fract(x, top) : exp2_f64<GEN_DEG>(x);
     }
     static __device__ __forceinline__ double bias() { return PBN_EXP2_BIAS; }
     static __device__ __forceinline__ double ex2_hi(double x) { return exp2_f64<8>(x); }
@@ -217,6 +238,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
         int lg, i;
         if (sizeof(T) == 8) { lg = idx & 3; i = idx >> 2; } else { lg = idx >> 2; i = idx & 3; }
         npack[tile * 16 + lg * 4 + i] = (T)nv;
+        // weights of the WMUL sweep behind the norms: 2^norm; NaN where it would lose bits (the sweep then takes its
+        // classic path for that tile), 0 for padding
+        if (a.write_w) npack[a.ntiles * 16 + tile * 16 + lg * 4 + i] = !valid ? (T)0 : (nv < -1000.0 ? (T)NAN : (T)exp2(nv));
     }
     if (a.upack) {  // CKDE::cdf: standardised "x - b.e" of the row, in the norm's layout
         double u = 0.0;
@@ -253,6 +277,12 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 #define PBN_PRUNE_CELL 2.0      // key cell edge in (base-2) whitened units; a term vanishes beyond ~11.3 of them
 #define PBN_PRUNE_WINDOW 32     // training rows scanned on either side of a query's Morton position
 #define PBN_PRUNE_MARGIN 64.0   // terms below 2^-64 of their query's largest known term are dropped
+// fp32 (bf16x3) sweeps: 2^-40.  What is dropped is at most N * 2^-40 of a sum (9e-7 at 10^6 rows, against the fp32 bar of
+// 1e-3 and fp32's own 6e-8 per term); the support shrinks from 9.4 to 7.4 bandwidths per axis (a third of the tiles at 2-3
+// dimensions).
+#ifndef PBN_PRUNE_MARGIN_F32
+#define PBN_PRUNE_MARGIN_F32 40.0
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int kd, double* __restrict__ zrow, uint32_t* __restrict__ keys,
@@ -370,8 +400,17 @@ __device__ __forceinline__ void xcd_block(int& qx, int& split) {
     split = (int)(wg / gx);
 }
 
-template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE>
+// WMUL (d mod 4 == 0, no free K slot for the norm): the training norms enter as WEIGHTS.  The accumulator starts from the
+// per-query constant alone (a persistent register quad as the MFMA's C operand, as with FOLD) and holds
+// x' = z_t.z_q - 1/2|z_q|^2 - m_q + bias; the term is 2^x' * w_t with w_t = 2^(-1/2|z_t|^2) precomputed by the pack kernel, and
+// the multiply rides in the running sum's FMA: no add per value for the norm.  x' >= 0 for every term that matters (x' >=
+// x' - 1/2|z_t|^2 >= 0), so the v_fract form still applies; x' can exceed the exponent range only when z_t.z_q is huge (a
+// far-out query next to a far-out training row): 2^x' = inf (times w = 0: NaN) fails the per-tile test `ts < big`, and the
+// rare path redoes the tile the classic way (norms added to the accumulator).  Rows with -1/2|z|^2 < -1000, whose weight
+// would lose bits or underflow, carry w = NaN and always take that path.
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
 __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
+    static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -386,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
 
     const T* __restrict__ Ap = (const T*)a.Apack;
     const T* __restrict__ Np = (const T*)a.nxpack;
+    const T* __restrict__ Wp = Np + a.ntiles * 16;   // WMUL: weights 2^norm behind the norms (PackArgs::write_w)
     const T* __restrict__ Xp = (const T*)a.Axpack;
     const T* __restrict__ Bp = (const T*)a.Bpack;
     const T* __restrict__ NYp = (const T*)a.nypack;
@@ -461,13 +501,17 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             V acc = FOLD ? V{ny[g], ny[g], ny[g], ny[g]} : nx + ny[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
-            T mx = colmax<T>(max4<T>(acc));
+            // The offsets are INTEGERS (base-2 units): then fract(s2 - m + bias) = fract(s2), so the argument of the 2^f
+            // polynomial - and with it its ~2e-9 approximation error - belongs to the (training row, query) pair and not to
+            // the offset, i.e. not to the split, the tile order or the pruning: sums taken in a different partition agree to
+            // rounding (1e-13), not to the polynomial's error bound.  Scaling by 2^integer is exact.
+            T mx = __builtin_ceil(colmax<T>(max4<T>(acc)));
             m[g] = mx;
             cm[g] = ny[g] - mx + Tr<T>::bias();   // main-loop exponents are kept biased (Tr<T>::ex2p)
-            if (FOLD) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
+            if (FOLD || WMUL) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
             if (COND) {
                 V accj = Tr<T>::mfma(ax, bxb[g], acc);
-                T mxj = colmax<T>(max4<T>(accj));
+                T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)));
                 mj[g] = mxj;
                 bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
             }
@@ -479,21 +523,23 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     auto load_tile = [&](int64_t t, T (&f)[KS], V& n, T& x) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) f[ks] = Ap[(t * KS + ks) * 64 + lane];
-        if (!FOLD) n = *(const V*)(Np + t * 16 + lg * 4);
+        if (!FOLD) n = *(const V*)((WMUL ? Wp : Np) + t * 16 + lg * 4);
         if (COND) x = Xp[t * 64 + lane];
     };
-    auto process_tile = [&](const T (&af)[KS], const V& nx, const T ax) {
+    auto process_tile = [&](const int64_t t, const T (&af)[KS], const V& nx, const T ax) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             V acc;
-            if (FOLD) acc = cmv[g]; else acc = nx + cm[g];
+            if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
             V accj;
             if (COND) accj = Tr<T>::mfma(ax, bx[g], acc);
 
             T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
-            T ts = (e0 + e1) + (e2 + e3);
+            T ts;
+            if (WMUL) ts = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], e0 * nx[0])));   // nx holds the weights
+            else ts = (e0 + e1) + (e2 + e3);
             T tsj = 0;
             bool bad = !(ts < Tr<T>::big());
             if (COND) {
@@ -503,18 +549,19 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             }
             if (__builtin_expect(__any(bad), 0)) {
                 // Rare wave-uniform slow path: raise the offsets to the tile maximum and redo the tile.
-                T mx = colmax<T>(max4<T>(acc)) - Tr<T>::bias();
+                if (WMUL) acc += *(const V*)(Np + t * 16 + lg * 4);   // the classic exponents: norms added
+                T mx = __builtin_ceil(colmax<T>(max4<T>(acc)) - Tr<T>::bias());
                 if (mx > (T)0) {
                     m[g] += mx;
                     cm[g] = ny[g] - m[g] + Tr<T>::bias();
-                    if (FOLD) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
+                    if (FOLD || WMUL) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
                     sum[g] *= exp2(-(double)mx);
                     acc -= mx;
                 }
                 e0 = Tr<T>::ex2(acc[0]); e1 = Tr<T>::ex2(acc[1]); e2 = Tr<T>::ex2(acc[2]); e3 = Tr<T>::ex2(acc[3]);
                 ts = (e0 + e1) + (e2 + e3);
                 if (COND) {
-                    T mxj = colmax<T>(max4<T>(accj)) - Tr<T>::bias();
+                    T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)) - Tr<T>::bias());
                     if (mxj > (T)0) {
                         mj[g] += mxj;
                         sumj[g] *= exp2(-(double)mxj);
@@ -538,9 +585,9 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         const bool second = t + 1 < t1;                       // wave-uniform
         const bool doA = !skip_tile(t), doB = second && !skip_tile(t + 1);
         load_tile(second ? t + 1 : t, afB, nxB, axB);
-        if (doA) process_tile(afA, nxA, axA);
+        if (doA) process_tile(t, afA, nxA, axA);
         load_tile(t + 2 < t1 ? t + 2 : t, afA, nxA, axA);
-        if (doB) process_tile(afB, nxB, axB);
+        if (doB) process_tile(t + 1, afB, nxB, axB);
     }
 
     // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
@@ -647,7 +694,7 @@ __global__ __launch_bounds__(256, 3) void kde_sweep_sparse_kernel(SweepArgs a) {
                 for (double* q = qbase; q < qtop; q += 64) *q -= mx;
             }
         }
-        if (has) sum += exp2_f64<PBN_EXP2_DEGREE>(v);
+        if (has) sum += Tr<double>::ex2(v);
     };
 
     // fragments of the first TB tiles (clamped; tiles past t1 are masked out below)
@@ -876,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
                     whi[k] = h > whi[k] ? h : whi[k];
                 }
         }
-        wthr -= PBN_PRUNE_MARGIN;
+        wthr -= PBN_PRUNE_MARGIN_F32;
     }
     auto skip_tile = [&](int64_t t) -> bool {
         if (!PRUNE) return false;
@@ -1311,9 +1358,20 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
     if (threadIdx.x == 0) *out = red[0];
 }
 
+__global__ __launch_bounds__(256) void diff_kernel(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] - b[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+void launch_diff(double* out, const double* a, const double* b, int64_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(diff_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, out, a, b, n);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st) {
     const int64_t npad = a.ntiles * 16;
     if (npad == 0) return;
@@ -1418,6 +1476,13 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
     if (a.prune) {   // fp64, at most 5 marginal dimensions (KS <= 2)
         if constexpr (sizeof(T) == 8) {
             constexpr int QGP = COND ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;   // query groups per wave of the pruned kernels
+            if constexpr (!COND && !FOLD) {
+                if (a.wmul && KS == 1) {   // 4 marginal dimensions: the only pruned shape without a free K slot
+                    hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QGP, false, true, true>), grid, block, 0, st, a);
+                    HIP_CHECK(hipGetLastError());
+                    return;
+                }
+            }
             if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QGP, FOLD, true>), grid, block, 0, st, a);
             else if (KS == 2) hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QGP, FOLD, true>), grid, block, 0, st, a);
             else throw invalid_error("KDE: pruned sweeps cover at most 8 whitened dimensions");
@@ -1425,6 +1490,17 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
             return;
         } else {
             throw invalid_error("KDE: pruned sweeps are fp64 only");
+        }
+    }
+    if constexpr (sizeof(T) == 8 && !COND && !FOLD) {
+        if (a.wmul) {
+            switch (KS) {
+                case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QG, false, false, true>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, false, QG, false, false, true>), grid, block, 0, st, a); break;
+                default: throw invalid_error("KDE: weighted-norm sweeps cover at most 8 whitened dimensions");
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
         }
     }
     switch (KS) {
@@ -1468,6 +1544,15 @@ bool sweep_folds_norm(int dtype, bool cond, int KS, int dm) {
         v = (e && *e) ? atoi(e) : 1;
     }
     return v != 0 && !use_bf16x3(dtype) && !use_sparse(dtype, cond, KS) && dm % 4 != 0;
+}
+
+bool sweep_weights_norm(int dtype, bool cond, int KS, int dm) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PBN_SWEEP_WMUL");
+        v = (e && *e) ? atoi(e) : 1;
+    }
+    return v != 0 && dtype == PBN_F64 && !cond && !use_sparse(dtype, cond, KS) && dm % 4 == 0 && KS <= 2;   // KS 3, 4: 169 / 181 VGPRs, a wave per SIMD lost
 }
 
 bool use_sparse(int dtype, bool cond, int KS) {

@@ -22,6 +22,7 @@ struct PackArgs {
     // -1/2|z|^2, query side 1 - so the sweep's accumulator starts from a per-query constant (no add per value).  A
     // query pack that leaves the slot 0 (CKDE::cdf, UCV) makes the training side's entry inert.
     int fold_norm;
+    int write_w;          // training side, classic pack: also write the weights 2^norm at npack + ntiles * 16 (WMUL sweeps)
     // source rows: logical row r maps to  r < n0 ? row0 + r : row1 + (r - n0)   (two contiguous ranges:
     // a CV training set is "everything before the fold" ++ "everything after it"), or rows[r] if non-null
     int64_t row0, n0, row1;
@@ -52,6 +53,7 @@ struct SweepArgs {
     int64_t nqtiles;
     int64_t tiles_per_split;
     int fold;      // the packs carry the training norms in a free K slot (PackArgs::fold_norm)
+    int wmul;      // fp64 plain sweeps with d mod 4 == 0: training norms as weights 2^norm behind the norms (PackArgs::write_w)
     // Tile pruning (low-dimensional fp64 sweeps of the score engine): both sides are packed in Morton order of their
     // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first
     // `pdims` whitened dimensions, and qtile_thr holds, per query tile, a lower bound of its queries' largest exponents
@@ -98,6 +100,7 @@ struct SweepQG {
 int sweep_qg(int dtype, bool cond, int KS, bool prune = false);
 bool use_sparse(int dtype, bool cond, int KS);
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm);   // see PackArgs::fold_norm
+bool sweep_weights_norm(int dtype, bool cond, int KS, int dm); // see SweepArgs::wmul
 // spatial sort + bounding boxes + exponent bounds of the pruned sweeps (SweepArgs::prune)
 void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st);
 void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st);
@@ -111,6 +114,8 @@ int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, g
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);
 void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st, double* dev_sum_marg_out = nullptr);
+// out[i] = a[i] - b[i] (CKDE as joint - marginal when the two come from separate sweeps)
+void launch_diff(double* out, const double* a, const double* b, int64_t n, hipStream_t st);
 
 // CKDE::cdf (factors/continuous/CKDE.hpp:509-735): weights from the marginal sweep, normal cdf of the conditional mean.
 struct CdfArgs {

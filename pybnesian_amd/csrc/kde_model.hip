@@ -75,7 +75,8 @@ KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n) {
     if (use_bf16x3(dtype))  // [ntiles][NB][64][8 bf16]; the training norm lives inside the fragments
         return {(size_t)ntiles * bf16x3_mfmas(dm) * 64 * 16, 64, cond ? (size_t)ntiles * 64 * 16 : 0};
     const int KS = (dm + 3) / 4;
-    return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es, cond ? (size_t)ntiles * 64 * es : 0};
+    // norms [ntiles][16], then the weights 2^norm [ntiles][16] of the WMUL sweep
+    return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es * 2, cond ? (size_t)ntiles * 64 * es : 0};
 }
 
 void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int kind, bool cond, const double* center) {
@@ -161,6 +162,10 @@ static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackA
     return s;
 }
 
+bool kde_prune_applies(int dtype, int dm, int64_t n) {
+    return env_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= 5 && n >= env_int("PBN_PRUNE_MIN_ROWS", 32768);
+}
+
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
                     int64_t row1, const int32_t* dev_rows, bool prune) {
     PackArgs pa{};
@@ -169,8 +174,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
     m.prune = false;
-    if (prune && env_int("PBN_SWEEP_PRUNE", 1) && (m.dtype == PBN_F64 || use_bf16x3(m.dtype)) && m.dm <= 5 &&
-        m.N >= env_int("PBN_PRUNE_MIN_ROWS", 32768)) {
+    if (prune && kde_prune_applies(m.dtype, m.dm, m.N)) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         m.zdims = m.d;
         m.pdims = std::min(m.dm, 3);
@@ -184,6 +188,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
         m.tile_box = box; m.zsorted = zsorted; m.keys_sorted = s.keys;
     }
     pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
+    pa.write_w = !use_bf16x3(m.dtype);
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
     launch_pack(pa, m.dtype, ctx->stream);
@@ -277,6 +282,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack; sa.Bxnorm = pa.xnorm;
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
+    sa.wmul = (!fold && sweep_weights_norm(m.dtype, m.cond, m.KS, m.dm)) ? 1 : 0;
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);

@@ -47,6 +47,8 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
 // table-ordered fragments.  Queries are evaluated in Morton order too and scattered back by the finish kernel.
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
                     int64_t row1, const int32_t* dev_rows = nullptr, bool prune = false);
+// Whether kde_pack_train(prune = true) would build the Morton-ordered pack for a model of `dm` main dimensions and n rows.
+bool kde_prune_applies(int dtype, int dm, int64_t n);
 // Copies the pruning tables of a pruned pack out of the context arena into `store` (handles that outlive the call).
 void kde_prune_persist(pbn_ctx* ctx, KdeModel& m, dev_buf<char>& store);
 

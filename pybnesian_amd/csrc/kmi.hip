@@ -417,6 +417,7 @@ int pbn_kmi_create(pbn_ctx* ctx, const double* const* cols, int n_vars, int64_t 
 
 void pbn_kmi_destroy(pbn_kmi* h) {
     if (!h) return;
+    PBN_API_LOCK;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     delete h;

@@ -920,6 +920,7 @@ int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const dou
 
 void pbn_mi_destroy(pbn_mi* h) {
     if (!h) return;
+    PBN_API_LOCK;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     const char* tm = std::getenv("PBN_MI_TIMING");

@@ -504,7 +504,7 @@ int pbn_lincor_from_cov(int n, int64_t rows, const double* cov, pbn_lincor** out
     });
 }
 
-void pbn_lincor_destroy(pbn_lincor* h) { delete h; }
+void pbn_lincor_destroy(pbn_lincor* h) { PBN_API_LOCK; delete h; }
 
 int pbn_lincor_cov(const pbn_lincor* h, double* cov) {
     return guarded([&] {

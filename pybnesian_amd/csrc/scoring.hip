@@ -19,6 +19,7 @@
 //    scratch arenas; one synchronisation and one D2H of all fold sums per batch.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <map>
@@ -126,7 +127,8 @@ void stats_minus(const Stats& a, const Stats& b, Stats& out) {
 
 // ---- MLE<LinearGaussianCPD> from (N, means, SSE) of [y, x1..xp] (mle_LinearGaussianCPD.hpp:11-221) -----
 // beta: p+1 (intercept first); returns the unbiased variance (inf when N <= p+1).
-double lg_fit(int64_t N, int p, const double* mu, const double* S /* (p+1)^2 col-major */, double* beta) {
+double lg_fit(int64_t N, int p, const double* mu, const double* S /* (p+1)^2 col-major */, double* beta, bool* suspect) {
+    if (suspect) *suspect = false;
     const int d = p + 1;
     auto s = [&](int i, int j) { return S[i + (size_t)j * d]; };
     const double rows = (double)N;
@@ -168,57 +170,60 @@ double lg_fit(int64_t N, int p, const double* mu, const double* S /* (p+1)^2 col
                            b2 * b2 * s(2, 2);
         return std::max(rss, 0.0) / (rows - 3);
     }
-    // p >= 3: normal equations on the centred moments, diagonally-pivoted Cholesky; a pivot that is not
-    // positive relative to its column's scale marks a dependent column (coefficient 0), the analogue of
-    // the rank decision of ColPivHouseholderQR (mle_LinearGaussianCPD.hpp:171)
-    std::vector<double> A((size_t)p * p), L((size_t)p * p, 0.0), b(p), y(p, 0.0);
+    // p >= 3: normal equations on the centred moments by a diagonally pivoted Cholesky - the pivot order of
+    // ColPivHouseholderQR (largest remaining column norm first, mle_LinearGaussianCPD.hpp:171) - a pivot that is not
+    // positive relative to its column's scale marks a dependent column (coefficient 0, like the rank-deficient QR solve).
+    // RSS is the Schur complement S_yy - |L^-1 b|^2 (error ~ eps S_yy, whatever the size of the coefficients), not the
+    // quadratic form in beta.  What this cannot deliver is reported through `suspect`: nearly collinear parents (smallest
+    // pivot ratio below 1e-6: coefficients good to ~1e-9 at best) or a nearly exact fit (RSS < 1e-8 S_yy): the callers
+    // then refit from the rows in double-double (lg_accurate.hip).
+    std::vector<double> A((size_t)p * p), L((size_t)p * p, 0.0), w(p, 0.0), z(p, 0.0), diag(p), scale(p);
     std::vector<int> piv(p);
-    std::vector<char> dead(p, 0);
-    for (int j = 0; j < p; ++j) {
-        b[j] = s(0, j + 1);
+    for (int j = 0; j < p; ++j)
         for (int i = 0; i < p; ++i) A[i + (size_t)j * p] = s(i + 1, j + 1);
-    }
     std::iota(piv.begin(), piv.end(), 0);
-    std::vector<double> diag(p);
-    for (int i = 0; i < p; ++i) diag[i] = A[i + (size_t)i * p];
-    // plain (unpivoted order) Cholesky with dependent-column detection
-    for (int j = 0; j < p; ++j) {
-        double sjj = A[j + (size_t)j * p];
-        for (int k2 = 0; k2 < j; ++k2) sjj -= L[j + (size_t)k2 * p] * L[j + (size_t)k2 * p];
-        if (!(sjj > diag[j] * p * 2.220446049250313e-16) || !std::isfinite(sjj)) {
-            dead[j] = 1;
-            L[j + (size_t)j * p] = 1.0;
-            for (int i = j + 1; i < p; ++i) L[i + (size_t)j * p] = 0.0;
-            continue;
+    for (int i = 0; i < p; ++i) diag[i] = scale[i] = A[i + (size_t)i * p];
+    int rank = 0;
+    double min_ratio = 1.0;
+    for (int k = 0; k < p; ++k) {
+        int best = k;
+        for (int j = k + 1; j < p; ++j)
+            if (diag[piv[j]] > diag[piv[best]]) best = j;
+        std::swap(piv[k], piv[best]);
+        for (int c2 = 0; c2 < k; ++c2) std::swap(L[k + (size_t)c2 * p], L[best + (size_t)c2 * p]);
+        const double pk = diag[piv[k]];
+        if (!(pk > scale[piv[k]] * p * 2.220446049250313e-16) || !std::isfinite(pk)) break;  // the rest depends on the columns taken
+        min_ratio = std::min(min_ratio, pk / scale[piv[k]]);
+        const double lkk = std::sqrt(pk);
+        L[k + (size_t)k * p] = lkk;
+        for (int i = k + 1; i < p; ++i) {
+            double t = A[piv[i] + (size_t)piv[k] * p];
+            for (int c2 = 0; c2 < k; ++c2) t -= L[i + (size_t)c2 * p] * L[k + (size_t)c2 * p];
+            t /= lkk;
+            L[i + (size_t)k * p] = t;
+            diag[piv[i]] -= t * t;
         }
-        const double ljj = std::sqrt(sjj);
-        L[j + (size_t)j * p] = ljj;
-        for (int i = j + 1; i < p; ++i) {
-            double t = A[i + (size_t)j * p];
-            for (int k2 = 0; k2 < j; ++k2) t -= L[i + (size_t)k2 * p] * L[j + (size_t)k2 * p];
-            L[i + (size_t)j * p] = t / ljj;
-        }
+        rank = k + 1;
     }
-    for (int i = 0; i < p; ++i) {  // forward
-        if (dead[i]) { y[i] = 0; continue; }
-        double t = b[i];
-        for (int k2 = 0; k2 < i; ++k2) t -= L[i + (size_t)k2 * p] * y[k2];
-        y[i] = t / L[i + (size_t)i * p];
+    double rss = s(0, 0);
+    for (int i = 0; i < rank; ++i) {  // forward: w = L^-1 b
+        double t = s(0, piv[i] + 1);
+        for (int c2 = 0; c2 < i; ++c2) t -= L[i + (size_t)c2 * p] * w[c2];
+        w[i] = t / L[i + (size_t)i * p];
+        rss -= w[i] * w[i];
     }
-    for (int i = p - 1; i >= 0; --i) {  // backward
-        if (dead[i]) { beta[i + 1] = 0; continue; }
-        double t = y[i];
-        for (int k2 = i + 1; k2 < p; ++k2) t -= L[k2 + (size_t)i * p] * beta[k2 + 1];
-        beta[i + 1] = t / L[i + (size_t)i * p];
+    for (int i = rank - 1; i >= 0; --i) {  // backward
+        double t = w[i];
+        for (int c2 = i + 1; c2 < rank; ++c2) t -= L[c2 + (size_t)i * p] * z[c2];
+        z[i] = t / L[i + (size_t)i * p];
     }
+    for (int j = 0; j < p; ++j) beta[j + 1] = 0.0;
+    for (int i = 0; i < rank; ++i) beta[piv[i] + 1] = z[i];
     double b0 = mu[0];
     for (int j = 0; j < p; ++j) b0 -= beta[j + 1] * mu[j + 1];
     beta[0] = b0;
+    if (suspect) *suspect = rank < p || min_ratio < 1e-6 || !(rss > 1e-8 * s(0, 0));
     if (N <= p + 1) return INF;
-    double rss = s(0, 0);
-    for (int j = 0; j < p; ++j) rss -= 2 * beta[j + 1] * s(0, j + 1);
-    for (int j = 0; j < p; ++j)
-        for (int i = 0; i < p; ++i) rss += beta[i + 1] * beta[j + 1] * s(i + 1, j + 1);
     return std::max(rss, 0.0) / (rows - p - 1);
 }
 
@@ -286,6 +291,18 @@ double bge_score(const pbn_scoredata* sd, const Stats& st, const int* cols, int 
 
 }  // namespace score
 }  // namespace pbn
+
+namespace pbn { namespace score {
+bool lg_guard_on() {
+    const char* e = getenv("PBN_LG_GUARD");   // read per call: the tests switch it
+    return !(e && *e) || atoi(e) != 0;
+}
+} }
+
+static bool score_memo_on() {
+    static const bool v = [] { const char* e = getenv("PBN_SCORE_MEMO"); return !(e && *e) || atoi(e) != 0; }();
+    return v;
+}
 
 extern "C" {
 
@@ -438,11 +455,13 @@ int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set)
         if (sd->n_hold > 0) sd->hold.N = sd->n_hold;
         sd->partial = false;
         sd->kde_cache.clear();
+        sd->score_memo.clear();
     });
 }
 
 void pbn_scoredata_destroy(pbn_scoredata* sd) {
     if (!sd) return;
+    PBN_API_LOCK;
     if (sd->perm_table) pbn_table_destroy(sd->perm_table);
     delete sd;
 }
@@ -491,6 +510,7 @@ int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
         if (selector != PBN_SEL_NORMAL_REFERENCE && selector != PBN_SEL_SCOTT) throw invalid_error("pbn_scoredata_set_selector: unknown selector");
         sd->selector = selector;
         sd->kde_cache.clear();
+        sd->score_memo.clear();
     });
 }
 
@@ -539,7 +559,10 @@ int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, doub
             if (c < 0 || c >= sd->n) throw invalid_error("pbn_lg_fit: column out of range");
         std::vector<double> mu(p + 1), sse((size_t)(p + 1) * (p + 1));
         subset_moments(sd, sd->all, cols.data(), p + 1, mu.data(), sse.data());
-        *variance = lg_fit(sd->all.N, p, mu.data(), sse.data(), beta);
+        bool suspect = false;
+        *variance = lg_fit(sd->all.N, p, mu.data(), sse.data(), beta, &suspect);
+        if (suspect && lg_guard_on() && p + 1 <= 16 && !sd->has_nulls)
+            *variance = lg_fit_accurate(sd->table(), cols.data(), p + 1, 0, sd->n_cv, 0, sd->n_cv, nullptr, beta);
     });
 }
 
@@ -554,7 +577,9 @@ int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, i
         std::vector<double> mu(d), sse((size_t)d * d);
         int rc = pbn_table_sse(t, cols, d, row0, n, mu.data(), sse.data());
         if (rc != PBN_OK) throw device_error(pbn_last_error());
-        *variance = lg_fit(n, d - 1, mu.data(), sse.data(), beta);
+        bool suspect = false;
+        *variance = lg_fit(n, d - 1, mu.data(), sse.data(), beta, &suspect);
+        if (suspect && lg_guard_on() && d <= 16) *variance = lg_fit_accurate(t, cols, d, row0, n, 0, n, nullptr, beta);
     });
 }
 
@@ -644,7 +669,22 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             }
             const int nt = node_type ? node_type[c] : PBN_NODE_LG;
             if (hybrid) {
+                // Likelihood scores of DiscreteAdaptator factors cost k x configurations sweeps / Gram passes each, and a
+                // hill-climb asks for the same (variable, type, parent SET) again and again: every RemoveArc cell is the
+                // local score the node had before that arc was added, every FlipArc cell's source side likewise.  They
+                // are remembered by parent set (the value depends on the parent ORDER only through rounding, ~1e-13,
+                // and these scores are not score-equivalent: no exact ties to flip).  BIC stays out: bic_clg ties.
+                const bool memo = score_memo_on() && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT) && nt != PBN_NODE_DISCRETE;
+                std::vector<int> key;
+                if (memo) {
+                    key.assign(cols.begin() + 1, cols.end());
+                    std::sort(key.begin(), key.end());
+                    key.insert(key.begin(), {kind, nt, cols[0]});
+                    auto it = sd->score_memo.find(key);
+                    if (it != sd->score_memo.end()) { out[c] = it->second; ++sd->memo_hits; continue; }
+                }
                 out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p);
+                if (memo) sd->score_memo[key] = out[c];
                 continue;
             }
             mu.resize(d); sse.resize((size_t)d * d); beta.resize(d);
@@ -682,7 +722,12 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             if (kind == PBN_SCORE_BIC) {
                 if (nt != PBN_NODE_LG) throw invalid_error("BIC: only LinearGaussianCPD node types are implemented on device");
                 subset_moments(sd, *full, cols.data(), d, mu.data(), sse.data());
-                const double v = lg_fit(full->N, p, mu.data(), sse.data(), beta.data());
+                bool suspect = false;
+                double v = lg_fit(full->N, p, mu.data(), sse.data(), beta.data(), &suspect);
+                if (suspect && lg_guard_on() && d <= 16) {   // nearly collinear parents / nearly exact fit: double-double refit
+                    if (full == &gathered) v = lg_fit_accurate(t, cols.data(), d, 0, full->N, 0, full->N, sd->rows_dev.p, beta.data());
+                    else v = lg_fit_accurate(t, cols.data(), d, 0, sd->n_cv, 0, sd->n_cv, nullptr, beta.data());
+                }
                 out[c] = bic_lg(full->N, p, v);
                 continue;
             }
@@ -699,7 +744,12 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                     const Stats* te = &sd->hold;
                     if (cv) { stats_minus(sd->all, sd->fold[f], train); tr = &train; te = &sd->fold[f]; }
                     subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
-                    const double v = lg_fit(tr->N, p, mu.data(), sse.data(), beta.data());
+                    bool suspect = false;
+                    double v = lg_fit(tr->N, p, mu.data(), sse.data(), beta.data(), &suspect);
+                    if (suspect && lg_guard_on() && d <= 16) {
+                        if (cv) v = lg_fit_accurate(t, cols.data(), d, 0, sd->limits[f], sd->limits[f + 1], tr->N, nullptr, beta.data());
+                        else v = lg_fit_accurate(t, cols.data(), d, 0, sd->n_cv, 0, sd->n_cv, nullptr, beta.data());
+                    }
                     acc += lg_slogl_from_moments(sd, *te, cols.data(), p, beta.data(), v);
                 }
                 out[c] = acc;
@@ -746,6 +796,11 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             struct Work { int cand, f, mode, slot_j, slot_m; };          // mode 0 fused, 1 joint only, 2 marginal only
             std::vector<Work> work;
             const bool cv = kind == PBN_SCORE_CVLIK;
+            // Neither term known: two plain sweeps (joint, marginal), each pruned on its own box.  The fused joint+marginal
+            // sweep costs exactly two sweeps' worth of exponentials anyway (they, not the MFMAs, are the cost) and under tile
+            // pruning it can only prune on the marginal box (C3: 16-21 ms fused against 2 x 7 ms plain per fold), so the
+            // engine no longer uses it; PBN_SCORE_FUSED=1 brings it back for comparison.
+            static const bool fused = [] { const char* e = getenv("PBN_SCORE_FUSED"); return e && *e && atoi(e) != 0; }();
             for (const Pending& pd : pending) {
                 const int c = pd.cand;
                 const int p = par_off[c + 1] - par_off[c], d = p + 1;
@@ -760,9 +815,13 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                     bool have_m = true;
                     std::vector<int> km;
                     if (p > 0) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup(km, u.marg); }
-                    if (!have_j && !have_m) {
+                    if (!have_j && !have_m && fused) {
                         u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
                         work.push_back({c, f, 0, u.joint.slot, u.marg.slot});
+                    } else if (!have_j && !have_m) {
+                        u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
+                        work.push_back({c, f, 1, u.joint.slot, -1});
+                        work.push_back({c, f, 2, -1, u.marg.slot});
                     } else if (!have_j) {
                         u.joint.slot = new_slot(kj);
                         work.push_back({c, f, 1, u.joint.slot, -1});

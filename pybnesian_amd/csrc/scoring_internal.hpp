@@ -40,6 +40,9 @@ struct pbn_scoredata {
     // A(S, m) of the CKDE likelihood scores, keyed by [region, m, sorted columns...] (see pbn_score_batch)
     std::map<std::vector<int>, double> kde_cache;
     int64_t kde_sweeps = 0;
+    // hybrid likelihood local scores by [kind, node type, variable, sorted parents...] (see pbn_score_batch)
+    std::map<std::vector<int>, double> score_memo;
+    int64_t memo_hits = 0;
     bool partial = false;  // moments hold only this rank's row share (pbn_scoredata_create_sharded)
     const pbn_table* src = nullptr;  // caller's table (borrowed)
     pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)
@@ -71,7 +74,13 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
               const double* shift_dev, double* S, double* G);
 void subset_moments(const pbn_scoredata* sd, const Stats& st, const int* cols, int d, double* mu, double* sse);
 void stats_minus(const Stats& a, const Stats& b, Stats& out);
-double lg_fit(int64_t N, int p, const double* mu, const double* S, double* beta);
+// suspect (nullable, p >= 3 only): set when the normal equations cannot be trusted (see lg_fit) - refit with lg_fit_accurate
+double lg_fit(int64_t N, int p, const double* mu, const double* S, double* beta, bool* suspect = nullptr);
+// lg_accurate.hip: least-squares fit of cols[0] on cols[1..d-1] from double-double moments of the rows
+// r < n0 ? row0 + r : row1 + (r - n0), r < n (through dev_rows when given).  d <= 16.
+double lg_fit_accurate(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n0, int64_t row1, int64_t n,
+                       const int32_t* dev_rows, double* beta);
+bool lg_guard_on();   // PBN_LG_GUARD (default 1)
 double bic_lg(int64_t N, int p, double variance);
 double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const int* cols, int p, const double* beta,
                              double variance);

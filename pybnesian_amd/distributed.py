@@ -17,6 +17,26 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
+def _all_gather(dist, buf):
+    """all_gather of one float64 vector per rank -> (world * len) numpy array, on the backend's device."""
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    send = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64)).to(dev)
+    recv = torch.empty(dist.get_world_size() * send.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    return recv.cpu().numpy()
+
+
+def _raise_if_failed(flags, failure, where):
+    """Every rank took part in the collective; if any of them failed while computing its share, all raise together."""
+    bad = [r for r, f in enumerate(flags) if f != 0.0]
+    if failure is not None:
+        raise failure
+    if bad:
+        raise RuntimeError(f"{where}: rank(s) {bad} failed while computing their share of the batch")
+
+
 def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
@@ -63,16 +83,18 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
         owner.append(set_of[key])
     lists = [[heavy[j] for j in range(m) if owner[j] == r] for r in range(world)]
     mine = lists[rank]
-    local = sub(mine) if mine else np.zeros(0)
     per = max(1, max(len(l) for l in lists))
-    buf = np.zeros(per)
-    buf[: len(mine)] = local
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    send = torch.from_numpy(buf).to(dev)
-    recv = torch.empty(world * per, dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(recv, send)
-    allv = recv.cpu().numpy().reshape(world, per)
+    buf = np.zeros(per + 1)                    # last slot: this rank's error flag
+    failure = None
+    try:
+        local = sub(mine) if mine else np.zeros(0)
+        buf[: len(mine)] = local
+    except Exception as ex:                    # never skip the collective: the other ranks are already on their way to it
+        failure = ex
+        buf[:] = np.nan
+        buf[per] = 1.0
+    allv = _all_gather(dist, buf).reshape(world, per + 1)
+    _raise_if_failed(allv[:, per], failure, "sharded_batch")
     for r in range(world):
         out[lists[r]] = allv[r, : len(lists[r])]
     return out
@@ -94,14 +116,17 @@ def sharded_slogl(factor, df):
     rank, world = dist.get_rank(), dist.get_world_size()
     m = rb.num_rows
     lo, hi = (m * rank) // world, (m * (rank + 1)) // world
-    part = factor.slogl(rb.slice(lo, hi - lo)) if hi > lo else 0.0
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    send = torch.tensor([part], dtype=torch.float64, device=dev)
-    recv = torch.empty(world, dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(recv, send)
+    buf = np.zeros(2)
+    failure = None
+    try:
+        buf[0] = factor.slogl(rb.slice(lo, hi - lo)) if hi > lo else 0.0
+    except Exception as ex:
+        failure = ex
+        buf[:] = (np.nan, 1.0)
+    allv = _all_gather(dist, buf).reshape(world, 2)
+    _raise_if_failed(allv[:, 1], failure, "sharded_slogl")
     total = 0.0
-    for v in recv.cpu().tolist():
+    for v in allv[:, 0].tolist():
         total += v
     return total
 
@@ -156,8 +181,11 @@ def sharded_ci_batch(fn, native_batch, user, errors):
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
     def batch(_user, n, v1, v2, off, cond, out):
+        mine = list(range(rank, n, world))
+        per = (n + world - 1) // world
+        buf = np.full(per + 1, np.nan)
+        buf[per] = 0.0                               # error flag
         try:
-            mine = list(range(rank, n, world))
             local = np.full(len(mine), np.nan)
             if mine:
                 a = _lib.int_array([v1[i] for i in mine])
@@ -172,18 +200,19 @@ def sharded_ci_batch(fn, native_batch, user, errors):
                     for q, i in enumerate(mine):
                         ci = _lib.int_array(c[o[q]: o[q + 1]] or [0])
                         local[q] = single(user, v1[i], v2[i], o[q + 1] - o[q], ci)
-            per = (n + world - 1) // world
-            buf = np.full(per, np.nan)
             buf[: len(mine)] = local
-            send = torch.from_numpy(buf).to(dev)
-            recv = torch.empty(world * per, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(recv, send)
-            allv = recv.cpu().numpy().reshape(world, per)
+        except Exception as ex:  # surfaced after the C call returns; the collective below still happens
+            errors.append(ex)
+            buf[per] = 1.0
+        try:
+            allv = _all_gather(dist, buf).reshape(world, per + 1)
+            if np.any(allv[:, per] != 0.0) and not errors:
+                errors.append(RuntimeError("sharded_ci_batch: another rank failed while computing its share of the tests"))
             for r in range(world):
                 idx = range(r, n, world)
                 for q, i in enumerate(idx):
-                    out[i] = allv[r, q]
-        except Exception as ex:  # surfaced after the C call returns
+                    out[i] = allv[r, q] if not errors else float("nan")
+        except Exception as ex:
             errors.append(ex)
             for i in range(n):
                 out[i] = float("nan")

@@ -1,0 +1,57 @@
+"""Worker of tests/test_distributed_gpu.py (not a test): one rank of a gloo world on ONE GPU.  Runs the CVLikelihood
+hill-climb of a small semiparametric network - its CKDE candidates are sharded over the ranks with real device scores - and a
+sharded KDE slogl; prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def table(n=1500, seed=4):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=n)
+    b = np.tanh(1.5 * a) + rng.normal(scale=0.3, size=n)
+    c = 0.8 * a - 0.5 * b + rng.normal(scale=0.5, size=n)
+    d = np.sin(c) + rng.normal(scale=0.4, size=n)
+    e = rng.normal(size=n)
+    return pd.DataFrame({"a": a, "b": b, "c": c, "d": d, "e": e})
+
+
+def run(fail_rank=-1):
+    import pybnesian_amd as pbn
+    from pybnesian_amd import distributed
+
+    df = table()
+    names = list(df.columns)
+    score = pbn.CVLikelihood(df, 3, 0)
+    hc = pbn.GreedyHillClimbing()
+    start = pbn.SemiparametricBN(names, [], [(n, pbn.CKDEType()) for n in names])
+    res = hc.estimate(pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]), score, start, max_indegree=2)
+    kinds = {pbn.AddArc: 0, pbn.RemoveArc: 1, pbn.FlipArc: 2}
+    trace = [[3, op.node(), str(op.node_type())] if isinstance(op, pbn.ChangeNodeType) else [kinds[type(op)], op.source(), op.target()]
+             for op in hc.last.trace]
+    entries, sweeps = score.kde_cache_stats()
+    kde = pbn.KDE(["a", "b", "c"])
+    kde.fit(df)
+    test = table(700, 9)
+    return {"trace": trace, "deltas": [op.delta() for op in hc.last.trace], "arcs": sorted(res.arcs()),
+            "types": [str(res.node_type(n)) for n in names], "cells": hc.last.cells_scored, "sweeps": sweeps,
+            "slogl": distributed.sharded_slogl(kde, test)}
+
+
+if __name__ == "__main__":
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    out = run()
+    out["rank"] = int(os.environ.get("RANK", "0"))
+    print("RESULT " + json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()

@@ -1,0 +1,57 @@
+"""GPU tier, world_size 2 over gloo on ONE GPU: the N > 1 path of the delta-score cache with REAL device scores
+(shards learning/operators/operators.cpp:100-132).  Two ranks run the CVLikelihood hill-climb of a
+semiparametric network: the CKDE candidates of every batch are dealt to the ranks by variable set, each rank sweeps only its
+share on the device, one all_gather per batch hands every rank the full delta table, and both ranks must take exactly the
+decisions of the single-process run.  The ranks are separate child processes (tests/dist_worker_gpu.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch(world):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker_gpu.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-2000:]
+        line = [l for l in o.splitlines() if l.startswith("RESULT ")][-1]
+        outs.append(json.loads(line[len("RESULT "):]))
+    return outs
+
+
+def test_sharded_delta_cache_with_device_ckde_scores_world2():
+    single = _launch(1)[0]
+    ranks = _launch(2)
+    assert len(single["trace"]) >= 3 and any(t[0] == 3 for t in single["trace"]) or len(single["arcs"]) >= 2
+    for r in ranks:
+        assert r["trace"] == single["trace"], (r["trace"], single["trace"])
+        assert r["arcs"] == single["arcs"] and r["types"] == single["types"]
+        assert r["cells"] == single["cells"]
+        assert np.allclose(r["deltas"], single["deltas"], rtol=1e-9, atol=1e-9)
+        assert abs(r["slogl"] - single["slogl"]) <= 1e-11 * abs(single["slogl"])
+    # the device work was split: every rank swept fewer (set, fold) units than the single process, together at least as many
+    assert max(r["sweeps"] for r in ranks) < single["sweeps"]
+    assert sum(r["sweeps"] for r in ranks) >= single["sweeps"]

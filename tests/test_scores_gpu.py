@@ -185,6 +185,44 @@ def test_wide_table_blocked_gram(pbn, oracle):
         assert abs(got - want) <= RTOL_F64 * abs(want)
 
 
+@pytest.mark.parametrize("p", [3, 4, 6])
+@pytest.mark.parametrize("kappa", [1e4, 1e6, 1e8])
+def test_near_collinear_parents_vs_pivoted_qr(pbn, oracle, p, kappa, monkeypatch):
+    """SURVEY.md §7 hard part (c): >= 3 parents, one of them a near copy of another (condition number ~ kappa).  The reference
+    solves by column-pivoted Householder QR (mle_LinearGaussianCPD.hpp:152-193, error ~ kappa eps); the engine's normal
+    equations on fp64 moments lose kappa^2 eps and hand such candidates to the double-double refit (lg_accurate.hip).
+    beta, variance and the BIC local score must match the oracle's QR; with the guard off the coefficients drift."""
+    rng = np.random.default_rng(int(p * 1000 + np.log10(kappa)))
+    n = 20000
+    X = rng.normal(size=(n, p)) @ (np.eye(p) + 0.3 * np.tril(rng.normal(size=(p, p)), -1)).T + 5.0
+    X[:, p - 1] = X[:, 0] + rng.normal(size=n) / kappa
+    y = X @ rng.uniform(0.5, 1.5, size=p) + rng.normal(scale=0.5, size=n)
+    names = ["y"] + [f"x{i}" for i in range(p)]
+    df = pd.DataFrame(np.column_stack([y, X]), columns=names)
+    want_beta, want_var = oracle.lg_fit(df.to_numpy())
+    cpd = pbn.LinearGaussianCPD("y", names[1:])
+    cpd.fit(df)
+    # the oracle's QR carries ~kappa eps itself on the two nearly collinear coefficients
+    tol = max(1e-8, 200 * kappa * 2.2e-16)
+    assert np.allclose(cpd.beta, want_beta, rtol=tol, atol=tol * np.abs(want_beta).max()), (cpd.beta, want_beta)
+    assert np.isclose(cpd.variance, want_var, rtol=1e-9)
+    bic = pbn.BIC(df)
+    got = bic.local_score(pbn.GaussianNetwork(names), "y", names[1:])
+    want = oracle.bic_lg(df.to_numpy())
+    assert abs(got - want) <= 1e-9 * abs(want)
+    cv = pbn.CVLikelihood(df, 4, 3)
+    got = cv.local_score(pbn.GaussianNetwork(names), "y", names[1:])
+    want = oracle.cv_likelihood(df.to_numpy(), "lg", 4, 3)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+    if kappa >= 1e6:
+        monkeypatch.setenv("PBN_LG_GUARD", "0")
+        raw = pbn.LinearGaussianCPD("y", names[1:])
+        raw.fit(df)
+        err_raw = np.abs(raw.beta - want_beta).max() / np.abs(want_beta).max()
+        err_guard = np.abs(cpd.beta - want_beta).max() / np.abs(want_beta).max()
+        assert err_guard <= err_raw and err_raw > 1e-9, (err_raw, err_guard)
+
+
 def test_degenerate_branches(pbn, oracle):
     """Singular parents (mle_LinearGaussianCPD.hpp:37-49,94-120) and BIC = -inf on degenerate variance."""
     rng = np.random.default_rng(0)

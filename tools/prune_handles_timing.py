@@ -23,8 +23,10 @@ for dtype in ("float64", "float32"):
                 os.environ["PBN_SWEEP_PRUNE"] = prune
                 k = pbn.KDE(names) if what == "KDE" else pbn.CKDE(names[0], names[1:])
                 t0 = time.perf_counter(); k.fit(trb); tf = time.perf_counter() - t0
-                k.slogl(teb)
-                t0 = time.perf_counter(); s = k.slogl(teb); ts = time.perf_counter() - t0
-                t0 = time.perf_counter(); l = k.logl(teb); tl = time.perf_counter() - t0
+                k.slogl(teb); k.logl(teb)   # warm-up: arenas, first launches of these kernel variants
+                ts = tl = 1e9
+                for _ in range(3):       # best of 3
+                    t0 = time.perf_counter(); s = k.slogl(teb); ts = min(ts, time.perf_counter() - t0)
+                    t0 = time.perf_counter(); l = k.logl(teb); tl = min(tl, time.perf_counter() - t0)
                 row.append(f"{what} prune={prune}: fit {tf*1e3:.1f} ms slogl {ts*1e3:.1f} ms logl {tl*1e3:.1f} ms (slogl {s:.6f})")
         print(" | ".join(row), flush=True)
