@@ -3,9 +3,11 @@
 numpy restatement of the reference's hybrid MutualInformation (learning/independences/hybrid/mutual_information.cpp),
 overload by overload, with the reference's own arithmetic: per-configuration means first, then centred sums, division
 by (count - 1), determinants, entropies, chi-square tail from scipy (Boost underneath, like the reference).  It shares
-no code path with the product (one-pass pilot-shifted moments, pooled by addition).  Parity unpinned by reference
-tests beyond tests/learning/independences/mutual_information_test.py, whose recipe (scipy entropies of fitted normals)
-this file's formulas reduce to."""
+no code path with the product (one-pass pilot-shifted moments, pooled by addition).
+
+PARITY UNPINNED: the reference ships no test for its independence tests (there is no tests/learning/independences/ in
+/root/reference), so nothing outside this restatement anchors these numbers; the restatement has to be read against
+mutual_information.cpp line by line (the cited line ranges)."""
 import numpy as np
 
 

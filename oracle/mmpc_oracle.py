@@ -5,7 +5,11 @@ LinearCorrelation test (learning/independences/continuous/linearcorrelation.{hpp
 are real libstdc++ std::unordered_set<int> objects (oracle_uset_*), because the reference's results depend on their
 iteration order whenever p-values tie (exact zeros at large N).  P-values come from numpy's eigh and scipy's Student t
 (Boost underneath, like the reference), i.e. from code that shares nothing with the product's Jacobi / continued
-fraction.  Parity unpinned by the reference's tests beyond tests/learning/algorithms (structure checks only)."""
+fraction.
+
+PARITY UNPINNED: the reference has no test for LinearCorrelation or for the CPC sets of MMPC
+(tests/learning/algorithms/constraint_test.py only checks that PC / MMPC run and respect white- / blacklists), so nothing
+outside this restatement anchors these numbers."""
 import ctypes as C
 import itertools
 

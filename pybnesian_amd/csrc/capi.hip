@@ -218,7 +218,7 @@ static void sse_block(const pbn_table* t, const int* cols, int d, int64_t row0, 
     pbn_ctx* ctx = t->ctx;
     const int nct = (d + 15) / 16;
     const int WS = gram_ws(nct);
-    int nblocks = (int)std::min<int64_t>(2 * ctx->num_cus, std::max<int64_t>(1, ceil_div(n, 256)));
+    int nblocks = (int)std::min<int64_t>(4 * ctx->num_cus, std::max<int64_t>(1, ceil_div(n, 256)));
     int64_t rpb = ceil_div(std::max<int64_t>(n, 1), nblocks);
     rpb = (rpb + 63) / 64 * 64;
     nblocks = (int)std::max<int64_t>(1, ceil_div(n, rpb));

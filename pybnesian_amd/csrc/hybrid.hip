@@ -17,9 +17,12 @@
 // and, for CKDE, pack(train slice) -> pack(test slice) -> fused sweep -> finish.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <memory>
 #include <numeric>
 
 #include "hostmath.hpp"
+#include "kde_kernels.hpp"
 #include "kde_model.hpp"
 #include "scoring_internal.hpp"
 #include "stats_kernels.hpp"
@@ -30,15 +33,6 @@ namespace score {
 namespace {
 
 struct Region { int64_t r0, r1; };
-
-// rows of every region grouped by configuration: list(region, config) = rows[off[region*nc + config] ...)
-struct Groups {
-    int nc = 1;
-    std::vector<int32_t> rows;
-    std::vector<int64_t> off;
-    int64_t count(int region, int c) const { return off[(size_t)region * nc + c + 1] - off[(size_t)region * nc + c]; }
-    int64_t begin(int region, int c) const { return off[(size_t)region * nc + c]; }
-};
 
 std::vector<Region> regions_of(const pbn_scoredata* sd, int kind) {
     std::vector<Region> r;
@@ -51,35 +45,6 @@ std::vector<Region> regions_of(const pbn_scoredata* sd, int kind) {
         r.push_back({0, sd->n_cv});
     }
     return r;
-}
-
-void build_groups(const pbn_scoredata* sd, const std::vector<int>& dpar, const std::vector<Region>& regions, Groups& g,
-                  std::vector<int>& strides) {
-    // discrete_indices.cpp:113-132: stride_0 = 1, stride_i = stride_{i-1} * card_{i-1}, evidence order
-    strides.assign(dpar.size(), 1);
-    int nc = 1;
-    for (size_t i = 0; i < dpar.size(); ++i) {
-        strides[i] = nc;
-        nc *= sd->card[dpar[i] - sd->n];
-    }
-    g.nc = nc;
-    const size_t cells = regions.size() * (size_t)nc;
-    g.off.assign(cells + 1, 0);
-    auto config = [&](int64_t r) {
-        int c = 0;
-        for (size_t i = 0; i < dpar.size(); ++i) c += sd->codes[dpar[i] - sd->n][r] * strides[i];
-        return c;
-    };
-    int64_t total = 0;
-    for (size_t ri = 0; ri < regions.size(); ++ri) {
-        for (int64_t r = regions[ri].r0; r < regions[ri].r1; ++r) ++g.off[ri * nc + config(r) + 1];
-        total += regions[ri].r1 - regions[ri].r0;
-    }
-    for (size_t i = 0; i < cells; ++i) g.off[i + 1] += g.off[i];
-    g.rows.resize((size_t)total);
-    std::vector<int64_t> cur(g.off.begin(), g.off.end() - 1);
-    for (size_t ri = 0; ri < regions.size(); ++ri)
-        for (int64_t r = regions[ri].r0; r < regions[ri].r1; ++r) g.rows[cur[ri * nc + config(r)]++] = (int32_t)r;
 }
 
 // ---- discrete variable: DiscreteFactor MLE + slogl, bic_discrete --------------------------------------------
@@ -150,18 +115,193 @@ double score_discrete(const pbn_scoredata* sd, int kind, int var, const int* par
     return acc;
 }
 
-// moments of columns `cols` (d) for every (region, configuration)
-void group_moments(pbn_scoredata* sd, const Groups& g, size_t nregions, const int* cols, int d, const int32_t* dev_rows,
-                   std::vector<Stats>& M) {
-    M.assign(nregions * (size_t)g.nc, Stats());
-    for (size_t ri = 0; ri < nregions; ++ri)
-        for (int c = 0; c < g.nc; ++c) {
-            Stats& st = M[ri * g.nc + c];
-            st.zero(d);
-            st.N = g.count((int)ri, c);
-            if (st.N > 0)
-                gram_raw(sd->table(), cols, d, 0, st.N, dev_rows + g.begin((int)ri, c), sd->shift_dev.p, st.S.data(), st.G.data());
+// ---- rows grouped by (configuration, region), cached per set of discrete parents -----------------------------------------
+// One counting sort per SET of discrete parents and score kind, kept on the score data (host offsets + device row list +
+// the piece table of the segmented moments kernel): C5's restricted hill-climb asks for ~50 distinct sets in 1 671 local
+// scores.  Layout: configuration-major, the regions (CV folds / hold-out train, test) of one configuration next to each
+// other in the list, so that "all folds but u" of a configuration is two contiguous ranges of it - the training gather list of
+// a slice needs no copy (PackArgs: two ranges, then through the list).  Configurations are numbered in CANONICAL order
+// (parents sorted by column id, stride_0 = 1); a candidate's own numbering (evidence order, discrete_indices.cpp:113-132) is
+// mapped onto it, which keeps the reference's summation order over configurations.
+constexpr int SEG_PIECE = 4096;
+
+const HybridGrouping& grouping_for(pbn_scoredata* sd, int kind, const std::vector<int>& dpar_sorted, const std::vector<Region>& regions) {
+    std::vector<int> key{kind};
+    key.insert(key.end(), dpar_sorted.begin(), dpar_sorted.end());
+    auto it = sd->groupings.find(key);
+    if (it != sd->groupings.end()) return *it->second;
+    auto gp = std::make_unique<HybridGrouping>();
+    HybridGrouping& g = *gp;
+    std::vector<int> strides(dpar_sorted.size(), 1);
+    int nc = 1;
+    for (size_t i = 0; i < dpar_sorted.size(); ++i) { strides[i] = nc; nc *= sd->card[dpar_sorted[i] - sd->n]; }
+    g.nc = nc;
+    g.nregions = (int)regions.size();
+    const size_t cells = (size_t)nc * regions.size();
+    g.off.assign(cells + 1, 0);
+    auto config = [&](int64_t r) {
+        int c = 0;
+        for (size_t i = 0; i < dpar_sorted.size(); ++i) c += sd->codes[dpar_sorted[i] - sd->n][r] * strides[i];
+        return c;
+    };
+    int64_t total = 0;
+    for (size_t ri = 0; ri < regions.size(); ++ri) {
+        for (int64_t r = regions[ri].r0; r < regions[ri].r1; ++r) ++g.off[(size_t)config(r) * regions.size() + ri + 1];
+        total += regions[ri].r1 - regions[ri].r0;
+    }
+    for (size_t i = 0; i < cells; ++i) g.off[i + 1] += g.off[i];
+    std::vector<int32_t> rows((size_t)total);
+    std::vector<int64_t> cur(g.off.begin(), g.off.end() - 1);
+    for (size_t ri = 0; ri < regions.size(); ++ri)
+        for (int64_t r = regions[ri].r0; r < regions[ri].r1; ++r) rows[cur[(size_t)config(r) * regions.size() + ri]++] = (int32_t)r;
+    // pieces of <= SEG_PIECE rows, cell by cell
+    std::vector<int32_t> piece, piece_off(cells + 1, 0);
+    for (size_t c = 0; c < cells; ++c) {
+        for (int64_t r = g.off[c]; r < g.off[c + 1]; r += SEG_PIECE) {
+            piece.push_back((int32_t)c);
+            piece.push_back((int32_t)r);
+            piece.push_back((int32_t)std::min<int64_t>(r + SEG_PIECE, g.off[c + 1]));
         }
+        piece_off[c + 1] = (int32_t)(piece.size() / 3);
+    }
+    g.npieces = (int)(piece.size() / 3);
+    pbn_ctx* ctx = sd->ctx;
+    g.rows.alloc(rows.size() + 16);
+    g.piece.alloc(piece.size() + 3);
+    g.piece_off.alloc(piece_off.size());
+    if (!rows.empty()) HIP_CHECK(hipMemcpyAsync(g.rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (!piece.empty()) HIP_CHECK(hipMemcpyAsync(g.piece.p, piece.data(), piece.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(g.piece_off.p, piece_off.data(), piece_off.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope
+    const HybridGrouping& ref = g;
+    sd->groupings[key] = std::move(gp);
+    return ref;
+}
+
+// ---- segmented Gram: pilot-shifted moments of D columns for EVERY (configuration, region) cell in one launch pair ---------
+// (the batched per-configuration fit of SURVEY.md §7: replaces one Gram launch + sync per cell).  A block takes one piece of
+// one cell: lanes stride over the piece, gather their rows through the grouped list and add sums and upper-triangle products
+// into registers; fixed butterfly + wave order -> the piece's partial; a second kernel adds a cell's pieces in order.
+// Deterministic, no atomics.  D <= 8 (variable + 7 continuous parents); wider candidates take the per-cell MFMA Gram.
+struct SegArgs {
+    const void* base;
+    int64_t ld;
+    int cols[8];
+    double shift[8];
+    const int32_t* rows;
+    const int32_t* piece;      // [npieces][3]
+    const int32_t* piece_off;  // [ncells + 1]
+    int npieces, ncells;
+    double* partial;           // [npieces][S]
+    double* out;               // [ncells][S]
+};
+
+__device__ __forceinline__ double seg_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void seg_moments_kernel(SegArgs a) {
+    constexpr int S = D + D * (D + 1) / 2;
+    __shared__ double red[4][S];
+    const int pc = blockIdx.x;
+    if (pc >= a.npieces) return;
+    const int r0 = a.piece[3 * pc + 1], r1 = a.piece[3 * pc + 2];
+    double acc[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) acc[i] = 0.0;
+    const T* col[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) col[i] = (const T*)a.base + (int64_t)a.cols[i] * a.ld;
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
+        const int64_t row = a.rows[r];
+        double x[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = (double)col[i][row] - a.shift[i];
+        int pos = D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            acc[i] += x[i];
+#pragma unroll
+            for (int j = i; j < D; ++j) { acc[pos] = __builtin_fma(x[i], x[j], acc[pos]); ++pos; }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const double v = seg_wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < S) a.partial[(size_t)pc * S + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void seg_reduce_kernel(SegArgs a, int S) {
+    const int cell = blockIdx.x / S, st = blockIdx.x - cell * S;
+    if (cell >= a.ncells) return;
+    const int b0 = a.piece_off[cell], b1 = a.piece_off[cell + 1];
+    double v = 0.0;
+    for (int b = b0 + (int)threadIdx.x; b < b1; b += 64) v += a.partial[(size_t)b * S + st];
+    v = seg_wave_sum(v);
+    if (threadIdx.x == 0) a.out[(size_t)cell * S + st] = v;
+}
+
+template <typename T>
+void launch_seg(const SegArgs& a, int d, hipStream_t st) {
+    const dim3 grid((unsigned)a.npieces), block(256);
+    switch (d) {
+        case 1: hipLaunchKernelGGL((seg_moments_kernel<T, 1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((seg_moments_kernel<T, 2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((seg_moments_kernel<T, 3>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((seg_moments_kernel<T, 4>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((seg_moments_kernel<T, 5>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((seg_moments_kernel<T, 6>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((seg_moments_kernel<T, 7>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((seg_moments_kernel<T, 8>), grid, block, 0, st, a); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// moments of columns `cols` (d) for every cell of the grouping: M[cell], cell = configuration * nregions + region
+void group_moments(pbn_scoredata* sd, const HybridGrouping& g, const int* cols, int d, std::vector<Stats>& M) {
+    const size_t cells = (size_t)g.nc * g.nregions;
+    M.assign(cells, Stats());
+    for (size_t c = 0; c < cells; ++c) { M[c].zero(d); M[c].N = g.off[c + 1] - g.off[c]; }
+    pbn_ctx* ctx = sd->ctx;
+    const pbn_table* t = sd->table();
+    static const bool batched = [] { const char* e = getenv("PBN_HYBRID_SEGMENTED"); return !(e && *e) || atoi(e) != 0; }();
+    if (d <= 8 && batched && g.npieces > 0) {
+        const int S = d + d * (d + 1) / 2;
+        ctx->scratch_red.reserve((size_t)(g.npieces + cells) * S);
+        SegArgs a{};
+        a.base = t->data; a.ld = t->ld;
+        for (int i = 0; i < d; ++i) { a.cols[i] = cols[i]; a.shift[i] = sd->shift[cols[i]]; }
+        a.rows = g.rows.p; a.piece = g.piece.p; a.piece_off = g.piece_off.p; a.npieces = g.npieces; a.ncells = (int)cells;
+        a.partial = ctx->scratch_red.p; a.out = ctx->scratch_red.p + (size_t)g.npieces * S;
+        {
+            KernelTimer kt(ctx, PBN_K_GRAM);
+            if (t->dtype == PBN_F64) launch_seg<double>(a, d, ctx->stream); else launch_seg<float>(a, d, ctx->stream);
+            hipLaunchKernelGGL(seg_reduce_kernel, dim3((unsigned)(cells * S)), dim3(64), 0, ctx->stream, a, S);
+            HIP_CHECK(hipGetLastError());
+        }
+        std::vector<double> h(cells * S);
+        HIP_CHECK(hipMemcpyAsync(h.data(), a.out, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (size_t c = 0; c < cells; ++c) {
+            const double* o = h.data() + c * S;
+            Stats& st = M[c];
+            int pos = d;
+            for (int i = 0; i < d; ++i) {
+                st.S[i] = o[i];
+                for (int j = i; j < d; ++j) { st.G[i + (size_t)j * d] = st.G[j + (size_t)i * d] = o[pos]; ++pos; }
+            }
+        }
+        return;
+    }
+    for (size_t c = 0; c < cells; ++c)
+        if (M[c].N > 0) gram_raw(t, cols, d, 0, M[c].N, g.rows.p + g.off[c], sd->shift_dev.p, M[c].S.data(), M[c].G.data());
 }
 
 // means / centred SSE from moments that were computed for exactly the columns `cols` (index i <-> cols[i])
@@ -204,26 +344,53 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     pbn_ctx* ctx = sd->ctx;
     const pbn_table* t = sd->table();
     std::vector<Region> regions = regions_of(sd, kind);
-    Groups g;
-    std::vector<int> strides;
-    build_groups(sd, dpar, regions, g, strides);
-    sd->rows_dev.reserve(g.rows.size() + 16);
-    if (!g.rows.empty())
-        HIP_CHECK(hipMemcpyAsync(sd->rows_dev.p, g.rows.data(), g.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const int R = (int)regions.size();
+    // canonical grouping (parents sorted) and the map from the candidate's configuration numbering onto it
+    std::vector<int> dsorted(dpar);
+    std::sort(dsorted.begin(), dsorted.end());
+    const HybridGrouping& g = grouping_for(sd, kind, dsorted, regions);
+    std::vector<int> canon(g.nc);
+    {
+        std::vector<int> cstride(dsorted.size(), 1);
+        int acc = 1;
+        for (size_t i = 0; i < dsorted.size(); ++i) { cstride[i] = acc; acc *= sd->card[dsorted[i] - n]; }
+        for (int c = 0; c < g.nc; ++c) {   // c in evidence order: stride_0 = 1, stride_i = stride_{i-1} * card_{i-1}
+            int rest = c, cc = 0;
+            for (size_t i = 0; i < dpar.size(); ++i) {
+                const int card = sd->card[dpar[i] - n], digit = rest % card;
+                rest /= card;
+                const size_t pos = std::lower_bound(dsorted.begin(), dsorted.end(), dpar[i]) - dsorted.begin();
+                cc += digit * cstride[pos];
+            }
+            canon[c] = cc;
+        }
+    }
+    auto cell = [&](int c, int r) { return (size_t)canon[c] * R + r; };
     std::vector<Stats> M;
-    group_moments(sd, g, regions.size(), cols.data(), d, sd->rows_dev.p, M);
+    group_moments(sd, g, cols.data(), d, M);
     std::vector<double> mu(d), sse((size_t)d * d), beta(d), H((size_t)d * d);
+    // double-double refit of an ill-conditioned slice from its rows (lg_accurate.hip): the rows of configuration c are one
+    // block of the grouped list, region u two ranges around its own rows
+    auto refit = [&](int c, int u, int64_t ntrain, double* b) {
+        const int64_t base = g.off[cell(c, 0)], end = g.off[cell(c, R - 1) + 1];
+        if (u < 0) return lg_fit_accurate(t, cols.data(), d, base, ntrain, 0, ntrain, g.rows.p, b);   // one region: [base, base + ntrain)
+        const int64_t f0 = g.off[cell(c, u)], f1 = g.off[cell(c, u) + 1];
+        (void)end;
+        return lg_fit_accurate(t, cols.data(), d, base, f0 - base, f1, ntrain, g.rows.p, b);
+    };
 
     if (kind == PBN_SCORE_BIC) {  // bic.cpp:29-64
         if (node_type != PBN_NODE_LG) throw invalid_error("BIC: only LinearGaussianCPD / DiscreteFactor node types are implemented");
         double loglik = 0;
         int64_t valid = 0;
         for (int c = 0; c < g.nc; ++c) {
-            const Stats& st = M[c];
+            const Stats& st = M[cell(c, 0)];
             valid += st.N;
             if (st.N == 0) continue;
             local_moments(sd, st, cols.data(), d, mu.data(), sse.data());
-            const double v = lg_fit(st.N, pc, mu.data(), sse.data(), beta.data());
+            bool suspect = false;
+            double v = lg_fit(st.N, pc, mu.data(), sse.data(), beta.data(), &suspect);
+            if (suspect && lg_guard_on() && d <= 16) v = refit(c, -1, st.N, beta.data());
             if (v < MACHINE_TOL || std::isinf(v)) return -INF;
             const double nv = (double)st.N;
             loglik += 0.5 * (1 + (double)pc - nv) - 0.5 * nv * LOG_2PI - nv * 0.5 * std::log(v);
@@ -233,36 +400,60 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
 
     // likelihood scores (cv_likelihood.cpp:11-25 / holdout_likelihood.cpp:14-23 over DiscreteAdaptator factors)
     const bool cv = kind == PBN_SCORE_CVLIK;
-    const int units = cv ? (int)regions.size() : 1;
+    const int units = cv ? R : 1;
     std::vector<Stats> allc(g.nc);
     if (cv)
         for (int c = 0; c < g.nc; ++c) {
             allc[c].zero(d);
-            for (size_t f = 0; f < regions.size(); ++f) allc[c].add(M[f * g.nc + c]);
+            for (int f = 0; f < R; ++f) allc[c].add(M[cell(c, f)]);
         }
     double acc = 0;
-    std::vector<int32_t> train_rows;
-    dev_buf<double> dsums;
-    int n_slots = 0;
-    if (node_type == PBN_NODE_CKDE) {
-        dsums.alloc((size_t)units * g.nc + 1);
-        HIP_CHECK(hipMemsetAsync(dsums.p, 0, ((size_t)units * g.nc + 1) * sizeof(double), ctx->stream));
-    }
-    dev_buf<int32_t> train_dev;  // concatenated training gather list of the current slice (CKDE, CV)
     Stats train;
+    // CKDE slices: slogl = A(joint set) - A(parent set), A = sum of log KDE over the slice's test rows (CKDE.hpp:256-287), each
+    // from a plain sweep pruned on its own box and remembered by [region, dimension of the bandwidth rule, variable set |
+    // kind, discrete parents, configuration]: the joint of x | {y} + D and of y | {x} + D is the same number, the marginal
+    // A({y}) serves every child of y under D.  All sweeps of the candidate are enqueued back to back - gather lists are
+    // device resident - with ONE synchronisation at the end.
+    struct Term { double value = 0; int slot = -1; };
+    struct Slice { Term joint, marg; bool has_marg; };
+    std::vector<Slice> slices;
+    std::vector<std::vector<int>> slot_key;
+    dev_buf<double> dsums;
+    if (node_type == PBN_NODE_CKDE) {
+        dsums.alloc((size_t)units * g.nc * 2 + 1);
+        HIP_CHECK(hipMemsetAsync(dsums.p, 0, ((size_t)units * g.nc * 2 + 1) * sizeof(double), ctx->stream));
+    }
+    auto key_of = [&](int region, int c, const int* v, int nv) {
+        std::vector<int> k(v, v + nv);
+        std::sort(k.begin(), k.end());
+        k.insert(k.begin(), {region, d});
+        k.push_back(-1);
+        k.push_back(kind);
+        k.insert(k.end(), dsorted.begin(), dsorted.end());
+        k.push_back(-2);
+        k.push_back(canon[c]);
+        return k;
+    };
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
     for (int u = 0; u < units; ++u) {
         for (int c = 0; c < g.nc; ++c) {
             const Stats* tr;
             const Stats* te;
-            if (cv) { stats_minus(allc[c], M[(size_t)u * g.nc + c], train); tr = &train; te = &M[(size_t)u * g.nc + c]; }
-            else { tr = &M[c]; te = &M[(size_t)g.nc + c]; }
+            if (cv) { stats_minus(allc[c], M[cell(c, u)], train); tr = &train; te = &M[cell(c, u)]; }
+            else { tr = &M[cell(c, 0)]; te = &M[cell(c, 1)]; }
             if (tr->N == 0) continue;  // empty training slice -> no factor (DiscreteAdaptator.hpp:266-268)
             local_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
             if (node_type == PBN_NODE_LG) {
-                const double v = lg_fit(tr->N, pc, mu.data(), sse.data(), beta.data());
+                bool suspect = false;
+                double v = lg_fit(tr->N, pc, mu.data(), sse.data(), beta.data(), &suspect);
+                const bool refitted = suspect && lg_guard_on() && d <= 16;
+                if (refitted) v = refit(c, cv ? u : -1, tr->N, beta.data());
                 if (v < MACHINE_TOL || std::isinf(v)) continue;  // LinearGaussianFitter -> nullptr
                 if (te->N == 0) continue;
-                acc += local_lg_slogl(sd, *te, cols.data(), pc, beta.data(), v);
+                if (refitted)   // huge coefficients: the test rows' log-likelihood from the rows, not from their moments
+                    acc += lg_slogl_from_rows(t, cols.data(), d, g.off[cell(c, cv ? u : 1)], te->N, g.rows.p, beta.data(), v);
+                else
+                    acc += local_lg_slogl(sd, *te, cols.data(), pc, beta.data(), v);
                 continue;
             }
             // CKDE slice: CKDEFitter turns SingularCovarianceData into "no factor"
@@ -275,46 +466,88 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 continue;
             }
             if (te->N == 0) continue;
-            KdeModel m;
-            try {
-                kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
-            } catch (const singular_error&) {
+            // rows: configuration block [base, ...) of the grouped list; training = everything of it but region u (CV) or
+            // region 0 (hold-out), test = region u / region 1
+            const int64_t base = g.off[cell(c, 0)];
+            int64_t tr_row0 = base, tr_n0 = tr->N, tr_row1 = 0, te0 = g.off[cell(c, 1)];
+            if (cv) { tr_n0 = g.off[cell(c, u)] - base; tr_row1 = g.off[cell(c, u) + 1]; te0 = g.off[cell(c, u)]; }
+            Slice sl{{}, {}, pc > 0};
+            // fp32 (bf16x3) slices with neither term known: the fused joint + marginal sweep - there the extra MFMA step hides
+            // under the exponentials and one pack / one launch serves both terms (C5: 22.3 s of sweeps fused against 24.2 s as
+            // two plain ones); fp64 slices and slices with one term cached take the plain sweeps
+            if (pc > 0 && use_bf16x3(sd->dtype) && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
+                sd->kde_cache.find(key_of(u, c, cols.data() + 1, pc)) == sd->kde_cache.end()) {
+                KdeModel m;
+                try {
+                    kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
+                } catch (const singular_error&) {
+                    continue;
+                }
+                sl.joint.slot = (int)slot_key.size();
+                slot_key.push_back(key_of(u, c, cols.data(), d));
+                sl.marg.slot = (int)slot_key.size();
+                slot_key.push_back(key_of(u, c, cols.data() + 1, pc));
+                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
+                ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + align(pb.axpack) + 256);
+                char* arena = ctx->scratch_train.p;
+                m.Apack = arena;
+                m.nxpack = arena + align(pb.apack);
+                m.Axpack = arena + align(pb.apack) + align(pb.nxpack);
+                kde_pack_train(ctx, m, t, cols.data(), tr_row0, tr_n0, tr_row1, g.rows.p, /*prune=*/true);
+                kde_eval_enqueue(ctx, m, t, cols.data(), te0, te->N, nullptr, dsums.p + sl.joint.slot, g.rows.p, dsums.p + sl.marg.slot);
+                ++sd->kde_sweeps;
+                slices.push_back(sl);
                 continue;
             }
-            // training gather list
-            const int32_t* dev_train;
-            if (cv) {
-                train_rows.clear();
-                for (size_t f = 0; f < regions.size(); ++f) {
-                    if ((int)f == u) continue;
-                    const int64_t b = g.begin((int)f, c), cnt = g.count((int)f, c);
-                    train_rows.insert(train_rows.end(), g.rows.begin() + b, g.rows.begin() + b + cnt);
+            for (int which = 0; which < (pc > 0 ? 2 : 1); ++which) {   // 0: joint over cols, 1: marginal over cols[1:]
+                Term& term = which ? sl.marg : sl.joint;
+                const int* v = cols.data() + which;
+                const int nv = d - which;
+                const std::vector<int> key = key_of(u, c, v, nv);
+                auto itc = sd->kde_cache.find(key);
+                if (itc != sd->kde_cache.end()) { term.value = itc->second; continue; }
+                KdeModel m;
+                try {
+                    if (which) {
+                        std::vector<double> Hm((size_t)pc * pc);
+                        for (int jj = 0; jj < pc; ++jj)
+                            for (int ii = 0; ii < pc; ++ii) Hm[ii + (size_t)jj * pc] = H[(ii + 1) + (size_t)(jj + 1) * d];
+                        kde_prepare(m, sd->dtype, pc, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
+                    } else {
+                        kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, false, mu.data());
+                    }
+                } catch (const singular_error&) {
+                    term.slot = -2;   // no factor for this slice
+                    break;
                 }
-                train_dev.reserve(train_rows.size());
-                HIP_CHECK(hipMemcpyAsync(train_dev.p, train_rows.data(), train_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-                dev_train = train_dev.p;
-            } else {
-                dev_train = sd->rows_dev.p + g.begin(0, c);
+                term.slot = (int)slot_key.size();
+                slot_key.push_back(key);
+                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, false, tr->N);
+                ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
+                char* arena = ctx->scratch_train.p;
+                m.Apack = arena;
+                m.nxpack = arena + align(pb.apack);
+                m.Axpack = nullptr;
+                kde_pack_train(ctx, m, t, v, tr_row0, tr_n0, tr_row1, g.rows.p, /*prune=*/true);
+                kde_eval_enqueue(ctx, m, t, v, te0, te->N, nullptr, dsums.p + term.slot, g.rows.p);
+                ++sd->kde_sweeps;
             }
-            const int32_t* dev_test = sd->rows_dev.p + (cv ? g.begin(u, c) : g.begin(1, c));
-            const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
-            auto align = [](size_t x) { return (x + 255) / 256 * 256; };
-            ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + align(pb.axpack) + 256);
-            char* arena = ctx->scratch_train.p;
-            m.Apack = arena;
-            m.nxpack = arena + align(pb.apack);
-            m.Axpack = m.cond ? arena + align(pb.apack) + align(pb.nxpack) : nullptr;
-            kde_pack_train(ctx, m, t, cols.data(), 0, 0, 0, dev_train, /*prune=*/true);
-            kde_eval_enqueue(ctx, m, t, cols.data(), 0, te->N, nullptr, dsums.p + n_slots, dev_test);
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host-side gather list and the arenas are reused by the next slice
-            ++n_slots;
+            if (sl.joint.slot == -2 || sl.marg.slot == -2) continue;
+            slices.push_back(sl);
         }
     }
-    if (node_type == PBN_NODE_CKDE && n_slots > 0) {
-        std::vector<double> hs((size_t)n_slots);
-        HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, (size_t)n_slots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (node_type == PBN_NODE_CKDE && !slices.empty()) {
+        std::vector<double> hs(std::max<size_t>(1, slot_key.size()));
+        if (!slot_key.empty()) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, slot_key.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (double v : hs) acc += v;
+        for (size_t i = 0; i < slot_key.size(); ++i) sd->kde_cache[slot_key[i]] = hs[i];
+        for (const Slice& sl : slices) {
+            const double jv = sl.joint.slot >= 0 ? hs[sl.joint.slot] : sl.joint.value;
+            const double mv = !sl.has_marg ? 0.0 : (sl.marg.slot >= 0 ? hs[sl.marg.slot] : sl.marg.value);
+            acc += jv - mv;
+        }
+    } else if (node_type == PBN_NODE_CKDE) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     return acc;
 }

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     double xc[PBN_MAX_D];
     if (valid) {
         const int64_t rr = a.perm ? (int64_t)a.perm[r] : r;
-        const int64_t src = a.rows ? (int64_t)a.rows[rr] : (rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0));
+        const int64_t lr = rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0);
+        const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
         for (int j = 0; j < d; ++j) {
             const T* col = (const T*)a.base + (int64_t)a.cols[j] * a.ld;
             xc[j] = (double)col[src] - a.mu[j];
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= a.n) return;
     const int d = a.d;
-    const int64_t src = a.rows ? (int64_t)a.rows[r] : (r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0));
+    const int64_t lr = r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0);
+    const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
     double xc[PBN_MAX_D];
     for (int j = 0; j < d; ++j) xc[j] = (double)((const T*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
     uint32_t key = 0;
@@ -400,6 +402,31 @@ __device__ __forceinline__ void xcd_block(int& qx, int& split) {
     split = (int)(wg / gx);
 }
 
+// Tile pruning, lane-parallel: lane l tests training tile tb + l against the box of the wave's queries (squared distance
+// between the boxes puts every exponent of the tile below the wave's bound -> skip), one ballot gives the visit mask of 64
+// tiles.  The sweeps then walk the set bits only: a skipped tile costs 1/64 of a test and no fragment load (the first
+// version tested tile by tile on wave-uniform values - 15 DP instructions and three loads per tile, skipped or not:
+// a fifth of a kept tile's cost in the fp32 sweep and ALL of a skipped tile's).
+__device__ __forceinline__ unsigned long long prune_visit_mask(const double* __restrict__ tile_box, int pd, int64_t tb, int64_t t1,
+                                                               const double (&wlo)[3], const double (&whi)[3], double wthr, int lane) {
+    const int64_t t = tb + lane;
+    bool keep = false;
+    if (t < t1) {
+        const double* bx = tile_box + t * 2 * pd;
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < pd) {
+                const double g1 = bx[k] - whi[k], g2 = wlo[k] - bx[pd + k];
+                double g = g1 > g2 ? g1 : g2;
+                g = g > 0.0 ? g : 0.0;
+                d2 = __builtin_fma(g, g, d2);
+            }
+        keep = !(-0.5 * d2 < wthr);
+    }
+    return __ballot(keep);
+}
+
 // WMUL (d mod 4 == 0, no free K slot for the norm): the training norms enter as WEIGHTS.  The accumulator starts from the
 // per-query constant alone (a persistent register quad as the MFMA's C operand, as with FOLD) and holds
 // x' = z_t.z_q - 1/2|z_q|^2 - m_q + bias; the term is 2^x' * w_t with w_t = 2^(-1/2|z_t|^2) precomputed by the pack kernel, and
@@ -472,21 +499,6 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         }
         wthr -= PBN_PRUNE_MARGIN;
     }
-    auto skip_tile = [&](int64_t t) -> bool {
-        if (!PRUNE) return false;
-        const double* bx = a.tile_box + t * 2 * pd;
-        double d2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < pd) {
-                const double g1 = bx[k] - whi[k], g2 = wlo[k] - bx[pd + k];
-                double g = g1 > g2 ? g1 : g2;
-                g = g > 0.0 ? g : 0.0;
-                d2 = __builtin_fma(g, g, d2);
-            }
-        return -0.5 * d2 < wthr;   // every exponent of the tile lies below the bound of every query of the wave
-    };
-
     // ---- prologue: offsets from the first tile (max of s2 over its 16 rows) ---------------------
     {
         T af[KS];
@@ -580,14 +592,35 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     T afA[KS], afB[KS];
     V nxA, nxB;
     T axA = 0, axB = 0;
-    load_tile(t0, afA, nxA, axA);
-    for (int64_t t = t0; t < t1; t += 2) {
-        const bool second = t + 1 < t1;                       // wave-uniform
-        const bool doA = !skip_tile(t), doB = second && !skip_tile(t + 1);
-        load_tile(second ? t + 1 : t, afB, nxB, axB);
-        if (doA) process_tile(t, afA, nxA, axA);
-        load_tile(t + 2 < t1 ? t + 2 : t, afA, nxA, axA);
-        if (doB) process_tile(t + 1, afB, nxB, axB);
+    if constexpr (PRUNE) {
+        // 64 tiles per visit mask; inside a batch the kept tiles are processed two at a time with ping-pong fragment buffers
+        for (int64_t tb = t0; tb < t1; tb += 64) {
+            unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            if (!mask) continue;
+            int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            load_tile(tb + b, afA, nxA, axA);
+            for (;;) {
+                int b2 = -1;
+                if (mask) { b2 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b2, afB, nxB, axB); }
+                process_tile(tb + b, afA, nxA, axA);
+                if (b2 < 0) break;
+                int b3 = -1;
+                if (mask) { b3 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b3, afA, nxA, axA); }
+                process_tile(tb + b2, afB, nxB, axB);
+                if (b3 < 0) break;
+                b = b3;
+            }
+        }
+    } else {
+        load_tile(t0, afA, nxA, axA);
+        for (int64_t t = t0; t < t1; t += 2) {
+            const bool second = t + 1 < t1;                       // wave-uniform
+            load_tile(second ? t + 1 : t, afB, nxB, axB);
+            process_tile(t, afA, nxA, axA);
+            load_tile(t + 2 < t1 ? t + 2 : t, afA, nxA, axA);
+            if (second) process_tile(t + 1, afB, nxB, axB);
+        }
     }
 
     // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
@@ -605,8 +638,10 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             sj += __shfl_xor(sj, 32);
         }
         // an empty sum still holds the term its offset came from (see kde_sweep_bf16_kernel; 2^bias is that term here)
-        if (s == 0.0) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
-        if (COND && sj == 0.0) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        // (only when the offset is a real exponent: a NaN / infinite offset - NaN queries, an all-padding split - keeps its sum)
+        const bool mfin = (m[g] - m[g]) == (T)0;
+        if (s == 0.0 && mfin) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        if (COND && sj == 0.0 && (mj[g] - mj[g]) == (T)0) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (lg == 0 && qt0 + g < a.nqtiles) {
             double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g] - (double)Tr<T>::bias();   // the sums carry 2^bias
@@ -792,7 +827,8 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
     double xc[PBN_MAX_D];
     if (valid) {
         const int64_t rr = a.perm ? (int64_t)a.perm[r] : r;
-        const int64_t src = a.rows ? (int64_t)a.rows[rr] : (rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0));
+        const int64_t lr = rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0);
+        const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
         for (int j = 0; j < d; ++j) {
             const float* col = (const float*)a.base + (int64_t)a.cols[j] * a.ld;
             xc[j] = (double)col[src] - a.mu[j];
@@ -925,20 +961,6 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
         }
         wthr -= PBN_PRUNE_MARGIN_F32;
     }
-    auto skip_tile = [&](int64_t t) -> bool {
-        if (!PRUNE) return false;
-        const double* bx = a.tile_box + t * 2 * pd;
-        double d2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < pd) {
-                const double g1 = bx[k] - whi[k], g2 = wlo[k] - bx[pd + k];
-                double g = g1 > g2 ? g1 : g2;
-                g = g > 0.0 ? g : 0.0;
-                d2 = __builtin_fma(g, g, d2);
-            }
-        return -0.5 * d2 < wthr;
-    };
     auto set_bx = [&](int g) {  // slots 9..11 (lane group 1, elements 1..3) <- split3(xn + m - mj)
         if (lg == 1) {
             __bf16 q1, q2, q3;
@@ -1082,14 +1104,34 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     };
 
     bf8 fA[NB], fB[NB], xA, xB;
-    load_tile(t0, fA, xA);
-    for (int64_t t = t0; t < t1; t += 2) {
-        const bool second = t + 1 < t1;
-        const bool doA = !skip_tile(t), doB = second && !skip_tile(t + 1);
-        load_tile(second ? t + 1 : t, fB, xB);
-        if (doA) process_tile(fA, xA);
-        load_tile(t + 2 < t1 ? t + 2 : t, fA, xA);
-        if (doB) process_tile(fB, xB);
+    if constexpr (PRUNE) {
+        for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
+            unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            if (!mask) continue;
+            int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            load_tile(tb + b, fA, xA);
+            for (;;) {
+                int b2 = -1;
+                if (mask) { b2 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b2, fB, xB); }
+                process_tile(fA, xA);
+                if (b2 < 0) break;
+                int b3 = -1;
+                if (mask) { b3 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b3, fA, xA); }
+                process_tile(fB, xB);
+                if (b3 < 0) break;
+                b = b3;
+            }
+        }
+    } else {
+        load_tile(t0, fA, xA);
+        for (int64_t t = t0; t < t1; t += 2) {
+            const bool second = t + 1 < t1;
+            load_tile(second ? t + 1 : t, fB, xB);
+            process_tile(fA, xA);
+            load_tile(t + 2 < t1 ? t + 2 : t, fA, xA);
+            if (second) process_tile(fB, xB);
+        }
     }
 
     double* part = a.part;
@@ -1109,8 +1151,8 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
         // rounding (ulp(|e|) >> 1: queries ~10^6 bandwidths away) makes the second evaluation of that tile underflow, the
         // sum can come out empty although it holds at least the offset's own term: count that term.  (A split whose tiles
         // were all pruned gets the same term: below 2^-64 of the query's sum by the pruning rule.)
-        if (s == 0.0) s = 1.0;
-        if (COND && sj == 0.0) sj = 1.0;
+        if (s == 0.0 && (m[g] - m[g]) == 0.f) s = 1.0;
+        if (COND && sj == 0.0 && (mj[g] - mj[g]) == 0.f) sj = 1.0;
         if (lg == 0 && qt0 + g < a.nqtiles) {
             double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g];

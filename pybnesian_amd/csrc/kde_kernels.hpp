@@ -23,8 +23,9 @@ struct PackArgs {
     // query pack that leaves the slot 0 (CKDE::cdf, UCV) makes the training side's entry inert.
     int fold_norm;
     int write_w;          // training side, classic pack: also write the weights 2^norm at npack + ntiles * 16 (WMUL sweeps)
-    // source rows: logical row r maps to  r < n0 ? row0 + r : row1 + (r - n0)   (two contiguous ranges:
-    // a CV training set is "everything before the fold" ++ "everything after it"), or rows[r] if non-null
+    // source rows: logical row r maps to  l = r < n0 ? row0 + r : row1 + (r - n0)   (two contiguous ranges: a CV training
+    // set is "everything before the fold" ++ "everything after it"), and then through the gather list, rows[l], when one is
+    // given (hybrid slices: the rows of one discrete configuration, grouped fold by fold - the same two-range trick inside it)
     int64_t row0, n0, row1;
     const int32_t* rows;  // device gather list (nullable)
     const int32_t* perm;  // nullable: logical row r is taken from logical row perm[r] (spatially sorted packs, see SweepArgs::prune)

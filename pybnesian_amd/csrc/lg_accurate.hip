@@ -21,6 +21,12 @@
 #include "common.hpp"
 #include "scoring_internal.hpp"
 
+// The error-free transformations below (TwoSum, TwoProd) are exact only if every operation is rounded exactly as
+// written: hipcc's default for device code, -ffp-contract=fast, would fuse the product of TwoProd into the first addition of
+// the following TwoSum (s = fma(x, y, acc) instead of acc + round(x y)) and silently turn the double-double accumulation
+// back into plain double.
+#pragma STDC FP_CONTRACT OFF
+
 namespace pbn {
 namespace score {
 

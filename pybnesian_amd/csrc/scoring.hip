@@ -44,7 +44,7 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
     pbn_ctx* ctx = t->ctx;
     const int nct = (d + 15) / 16;
     const int WS = gram_ws(nct);
-    int nblocks = (int)std::min<int64_t>(2 * ctx->num_cus, std::max<int64_t>(1, ceil_div(n, 256)));
+    int nblocks = (int)std::min<int64_t>(4 * ctx->num_cus, std::max<int64_t>(1, ceil_div(n, 256)));
     int64_t rpb = ceil_div(std::max<int64_t>(n, 1), nblocks);
     rpb = (rpb + 63) / 64 * 64;
     nblocks = (int)std::max<int64_t>(1, ceil_div(n, rpb));
@@ -256,6 +256,30 @@ double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const i
     rss += -2 * c * lin + Nt * c * c;
     rss = std::max(rss, 0.0);
     return -0.5 * Nt * (std::log(variance) + LOG_2PI) - 0.5 * rss / variance;
+}
+
+// The same sum from the ROWS (one streaming pass, lg_logl_kernel): for fits whose coefficients are huge (nearly collinear
+// parents) the quadratic form above cancels - eps beta^2 G against a residual sum of squares that is tiny beside it.
+double lg_slogl_from_rows(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const int32_t* dev_rows,
+                          const double* beta, double variance) {
+    if (n == 0) return 0.0;
+    pbn_ctx* ctx = t->ctx;
+    const int64_t nblocks = ceil_div(n, 256);
+    ctx->scratch_misc.reserve((size_t)(nblocks + 1) * sizeof(double));
+    double* bs = (double*)ctx->scratch_misc.p;
+    LgArgs a{};
+    a.base = t->data; a.ld = t->ld; a.p = d - 1; a.row0 = row0; a.n = n; a.rows = dev_rows;
+    for (int i = 0; i < d; ++i) { a.gc.cols[i] = cols[i]; a.beta[i] = beta[i]; }
+    a.inv_std = 1.0 / std::sqrt(variance);
+    a.cte = -0.5 * std::log(variance) - 0.5 * LOG_2PI;
+    a.logl = nullptr; a.block_sums = bs; a.want_cdf = 0;
+    launch_lg_logl(a, t->dtype, ctx->stream);
+    std::vector<double> hb((size_t)nblocks);
+    HIP_CHECK(hipMemcpyAsync(hb.data(), bs, (size_t)nblocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (double v : hb) s += v;  // fixed order
+    return s;
 }
 
 // BGe (bge.hpp:154-234).  params: iss_mu, iss_w, total_nodes, then optionally nu[n] (per table column).
@@ -749,6 +773,10 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                     if (suspect && lg_guard_on() && d <= 16) {
                         if (cv) v = lg_fit_accurate(t, cols.data(), d, 0, sd->limits[f], sd->limits[f + 1], tr->N, nullptr, beta.data());
                         else v = lg_fit_accurate(t, cols.data(), d, 0, sd->n_cv, 0, sd->n_cv, nullptr, beta.data());
+                        // and the test fold's log-likelihood from its rows, as the reference evaluates it
+                        const int64_t te0 = cv ? sd->limits[f] : sd->n_cv;
+                        acc += lg_slogl_from_rows(t, cols.data(), d, te0, te->N, nullptr, beta.data(), v);
+                        continue;
                     }
                     acc += lg_slogl_from_moments(sd, *te, cols.data(), p, beta.data(), v);
                 }

@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <limits>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "common.hpp"
@@ -29,6 +30,16 @@ struct Stats {  // pilot-shifted moments of a row set over all n columns (or a c
 
 }  // namespace score
 }  // namespace pbn
+
+// Rows of the score regions grouped by (configuration of a set of discrete parents, region): see hybrid.hip
+struct HybridGrouping {
+    int nc = 1, nregions = 1;
+    std::vector<int64_t> off;          // [nc * nregions + 1], cell = configuration * nregions + region
+    pbn::dev_buf<int32_t> rows;        // device: permuted-table row ids, cell by cell
+    pbn::dev_buf<int32_t> piece;       // device [npieces][3]: cell, first, last + 1 (pieces of <= 4096 rows)
+    pbn::dev_buf<int32_t> piece_off;   // device [cells + 1]
+    int npieces = 0;
+};
 
 struct pbn_scoredata {
     pbn_ctx* ctx = nullptr;
@@ -60,7 +71,8 @@ struct pbn_scoredata {
     int n_disc = 0;
     std::vector<std::vector<int32_t>> codes;
     std::vector<int> card;
-    pbn::dev_buf<int32_t> rows_dev;  // gather lists of the hybrid path
+    pbn::dev_buf<int32_t> rows_dev;  // gather lists (valid rows of BIC / BGe candidates on tables with nulls)
+    std::map<std::vector<int>, std::unique_ptr<HybridGrouping>> groupings;  // by [kind, sorted discrete parents...]
     // validity of the continuous columns (BIC / BGe on tables with nulls): byte masks, empty = no nulls
     std::vector<std::vector<uint8_t>> valid;
     bool has_nulls = false;
@@ -82,6 +94,8 @@ double lg_fit_accurate(const pbn_table* t, const int* cols, int d, int64_t row0,
                        const int32_t* dev_rows, double* beta);
 bool lg_guard_on();   // PBN_LG_GUARD (default 1)
 double bic_lg(int64_t N, int p, double variance);
+double lg_slogl_from_rows(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const int32_t* dev_rows,
+                          const double* beta, double variance);
 double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const int* cols, int p, const double* beta,
                              double variance);
 // hybrid.hip: candidates with a discrete variable or discrete parents (synchronous)

@@ -15,6 +15,9 @@
 // Numerics: values are shifted by a per-column pilot mean (mean of the first <=1024 rows; the shift array
 // is indexed by TABLE column so that Grams of different row ranges / column subsets are additive) before the
 // products, so  SSE = G_shift - S S^T / N  has no catastrophic cancellation (S = shifted column sums).
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.hpp"
 #include "stats_kernels.hpp"
 
@@ -177,6 +180,147 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
     for (int e = threadIdx.x; e < WS; e += 256) out[e] = lds[e];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gram_lds_kernel: the same statistics with the rows staged through LDS and the accumulator tiles SPLIT OVER THE WAVES.
+// gram_kernel above keeps all NCT(NCT+1)/2 accumulator tiles in every wave (NCT = 4: 10 tiles = 80 VGPRs + 64 of operands
+// and prefetch -> 196 VGPRs, 2 waves / SIMD, each alternating between its load phase and its MFMA phase: 0.52 of the HBM
+// peak at 64 columns).  Here a 256-thread block loads a chunk of 32 rows x all columns ONCE, coalesced (4 threads per
+// column, 64 contiguous bytes each), subtracts the pilot shift and writes doubles to LDS in [column][row] order; every
+// wave then owns a few (I, J) tile pairs (10 pairs over 4 waves: 3 + 3 + 2 + 2, rotated by block so that co-resident blocks
+// load the four SIMDs evenly) and reads its two operand fragments per k-step from LDS.  24 accumulator VGPRs per wave,
+// ~60 in all: 4 blocks = 16 waves per CU, and the global loads of chunk i+1 are in flight (registers) under the MFMAs of
+// chunk i (double-buffered LDS, one barrier per chunk).
+// LDS image: column stride CS = 32 rows * 8 B + 16 B padding: lane (c = lane & 15, k = lane >> 4) reads element
+// [16 I + c][4 s + k]; with the 16-byte pad the 32 lanes of a half wave touch 64 distinct banks (ds_read_b64: two banks per
+// lane) - conflict free.  Every pair has exactly one owner, so the block's partial is written straight from the
+// accumulators in the layout gram_raw / sse_block decode ([pair][reg * 64 + lane], then the column sums).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GL_ROWS = 32;                         // rows per chunk
+constexpr int GL_CS = GL_ROWS + 2;                  // doubles per column in LDS (32 + 16 B pad)
+
+template <typename T, int NCT, bool GATHER>
+__global__ __launch_bounds__(256, 3) void gram_lds_kernel(GramArgs a) {
+    constexpr int NP = NPairs<NCT>::value;
+    constexpr int NC = NCT * 16;
+    __shared__ double lds[2][NC * GL_CS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar
+    const int c = lane & 15, kq = lane >> 4;
+
+    const int64_t rb0 = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t rb1 = rb0 + a.rows_per_block;
+    if (rb1 > a.n) rb1 = a.n;
+
+    // loader role: thread t -> column t >> 2 (of the first NC columns), rows (t & 3) * 8 .. + 7 of the chunk
+    const int lcol = tid >> 2, lrg = tid & 3;
+    const bool lvalid = lcol < a.n_cols;
+    const bool lactive = lcol < NC;
+    const int lsrc = lvalid ? a.gc.cols[lcol] : a.gc.cols[0];
+    const T* lp = (const T*)a.base + (int64_t)lsrc * a.ld + (GATHER ? 0 : a.row0);
+    const double lsh = lvalid ? a.shift[lsrc] : 0.0;
+    double csum = 0.0;
+
+    // MFMA role: pairs owned by this wave
+    int pI[3], pJ[3], pidx[3], np = 0;
+    {
+        const int rot = blockIdx.x & 3;
+        int p = 0;
+#pragma unroll
+        for (int I = 0; I < NCT; ++I)
+#pragma unroll
+            for (int J = I; J < NCT; ++J) {
+                if (((p + rot) & 3) == wave && np < 3) { pI[np] = I; pJ[np] = J; pidx[np] = p; ++np; }
+                ++p;
+            }
+    }
+    d4 acc[3];
+    int offA[3], offB[3];   // LDS offsets (doubles) of this lane's operand elements at k-step 0
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        acc[q] = d4{0, 0, 0, 0};
+        offA[q] = q < np ? (pI[q] * 16 + c) * GL_CS + kq : 0;
+        offB[q] = q < np ? (pJ[q] * 16 + c) * GL_CS + kq : 0;
+    }
+
+    T raw[8];
+    auto load_chunk = [&](int64_t r) {   // rows r + lrg * 8 .. + 7 of this thread's column into registers
+        if (!lactive) return;
+        const int64_t rl = r + lrg * 8;
+        if (!GATHER && rl + 8 <= rb1) {
+            T q0[4], q1[4];
+            load_rows4<T>(lp + rl, q0);
+            load_rows4<T>(lp + rl + 4, q1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { raw[j] = q0[j]; raw[4 + j] = q1[j]; }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = rl + j < rb1;
+            const int64_t src = ok ? (GATHER ? (int64_t)a.rows[rl + j] : rl + j) : (GATHER ? (int64_t)a.rows[rb0] : rb0);
+            raw[j] = lp[src];
+        }
+    };
+    auto store_chunk = [&](int64_t r, int buf) {   // shift, widen, column sums, LDS image [column][row]
+        if (!lactive) return;
+        const int64_t rl = r + lrg * 8;
+        double x[8];
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = (lvalid && rl + j < rb1) ? (double)raw[j] - lsh : 0.0;
+            s += x[j];
+        }
+        csum += s;
+        double* dst = &lds[buf][lcol * GL_CS + lrg * 8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) *(d2_elem_aligned*)(dst + j) = d2_elem_aligned{x[j], x[j + 1]};
+    };
+
+    int64_t r = rb0;
+    int buf = 0;
+    if (r < rb1) { load_chunk(r); store_chunk(r, 0); }
+    __syncthreads();
+    // the chunk loop, specialised on the number of pairs this wave owns: no branch inside, so the LDS reads of the next k-steps
+    // are scheduled under the MFMAs of the current one (every wave executes the same number of barriers)
+    auto run = [&](auto npw_c) {
+        constexpr int NPW = decltype(npw_c)::value;
+        for (; r < rb1; r += GL_ROWS) {
+            const bool more = r + GL_ROWS < rb1;
+            if (more) load_chunk(r + GL_ROWS);             // in flight under the MFMAs below
+            const double* img = lds[buf];
+#pragma unroll
+            for (int s4 = 0; s4 < GL_ROWS / 4; ++s4) {
+                double xa[NPW > 0 ? NPW : 1], xb[NPW > 0 ? NPW : 1];
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) { xa[q] = img[offA[q] + s4 * 4]; xb[q] = img[offB[q] + s4 * 4]; }
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q], xb[q], acc[q], 0, 0, 0);
+            }
+            if (more) store_chunk(r + GL_ROWS, buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    if (np == 3) run(std::integral_constant<int, 3>{});
+    else if (np == 2) run(std::integral_constant<int, 2>{});
+    else if (np == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+
+    constexpr int WS = NP * 256 + NCT * 16;
+    double* out = a.partial + (int64_t)blockIdx.x * WS;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < np) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[pidx[q] * 256 + i * 64 + lane] = acc[q][i];
+        }
+    // column sums: the 4 loader threads of a column are adjacent lanes
+    double s = csum;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (lactive && lrg == 0) out[NP * 256 + lcol] = s;
+}
+
 // Sum the block partials (deterministic): stage 1 sums groups of 16 consecutive blocks in place into the first
 // block of each group (grid.y = groups), stage 2 sums the group leaders in group order.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ partial, int nblocks, int WS, int stride,
@@ -192,9 +336,25 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ p
     if (out) out[e] = v; else partial[(int64_t)b0 * WS + e] = v;
 }
 
+static bool gram_uses_lds() {
+    static const bool v = [] { const char* e = getenv("PBN_GRAM_LDS"); return !(e && *e) || atoi(e) != 0; }();
+    return v;
+}
+
 template <typename T, bool GATHER>
 static void launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st) {
     dim3 grid(nblocks), block(256);
+    if (gram_uses_lds()) {
+        switch (nct) {
+            case 1: hipLaunchKernelGGL((gram_lds_kernel<T, 1, GATHER>), grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((gram_lds_kernel<T, 2, GATHER>), grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((gram_lds_kernel<T, 3, GATHER>), grid, block, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((gram_lds_kernel<T, 4, GATHER>), grid, block, 0, st, a); break;
+            default: throw invalid_error("gram: at most 64 columns per launch");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     switch (nct) {
         case 1: hipLaunchKernelGGL((gram_kernel<T, 1, GATHER>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((gram_kernel<T, 2, GATHER>), grid, block, 0, st, a); break;
@@ -245,7 +405,7 @@ __global__ __launch_bounds__(256) void lg_logl_kernel(LgArgs a) {
     double val = 0.0;
     if (r < a.n) {
         const T* base = (const T*)a.base;
-        const int64_t src = a.row0 + r;
+        const int64_t src = a.rows ? (int64_t)a.rows[a.row0 + r] : a.row0 + r;
         double mean = a.beta[0];
         for (int j = 1; j <= a.p; ++j) mean += a.beta[j] * (double)base[(int64_t)a.gc.cols[j] * a.ld + src];
         const double y = (double)base[(int64_t)a.gc.cols[0] * a.ld + src];

@@ -29,6 +29,7 @@ struct LgArgs {
     GramCols gc;      // cols[0] = variable, cols[1..p] = evidence
     int p;
     int64_t row0, n;
+    const int32_t* rows;  // nullable device gather list: row r of the evaluation is rows[row0 + r] instead of row0 + r
     double beta[64];  // p+1 coefficients (intercept first)
     double inv_std;   // 1 / sqrt(variance)
     double cte;       // -0.5 log(variance) - 0.5 log(2 pi)

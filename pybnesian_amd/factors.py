@@ -199,30 +199,50 @@ class CKDE(Factor):
         self._kde_joint_obj, self._kde_marg_obj, self._split = None, None, False
         self._fitted = True
 
+    # pickle: CKDE::__getstate__ (factors/continuous/CKDE.hpp:737-745): (variable, evidence, fitted, joint KDE tuple) with the
+    # joint tuple in KDE::__getstate__'s layout (kde/KDE.hpp:642-666) and () when unfitted; the marginal is rebuilt from the
+    # bottom-right block of the joint bandwidth (CKDE.cpp:190-214).  A marginal bandwidth the user overrode through
+    # kde_marg().bandwidth - which the reference's pickle silently loses - rides as an optional fifth entry.
     def __getstate__(self):
-        state = {"variable": self._variable, "evidence": self._evidence, "selector": self._selector, "fitted": self._fitted}
-        if self._fitted:
-            vals = self._train.read(self._variables)
-            state.update(bandwidth=np.array(self._bandwidth), training=np.asfortranarray(vals).reshape(-1, order="F"),
-                         N=self._N, dtype=self._dtype)
-            if self._split and self._evidence:
-                state["marg_bandwidth"] = np.array(self.kde_marg().bandwidth)
+        if not self._fitted:
+            return (self._variable, list(self._evidence), False, ())
+        np_t = np.float64 if self._dtype == _lib.PBN_F64 else np.float32
+        vals = np.asarray(self._train.read(self._variables), dtype=np_t)
+        joint = (list(self._variables), True, self._selector, np.array(self._bandwidth), np.asfortranarray(vals).reshape(-1, order="F"),
+                 float(_lib.load().pbn_kde_lognorm(self._handle, 0)), int(self._N), 12 if self._dtype == _lib.PBN_F64 else 11)
+        state = (self._variable, list(self._evidence), True, joint)
+        if self._split and self._evidence:
+            state += (np.array(self.kde_marg().bandwidth),)
         return state
 
     def __setstate__(self, state):
-        self.__init__(state["variable"], state["evidence"], state["selector"])
-        if state["fitted"]:
-            d, n = len(self._variables), state["N"]
-            vals = np.asarray(state["training"]).reshape(n, d, order="F")
+        if isinstance(state, dict):      # states written before the reference layout was adopted
+            joint = ()
+            if state["fitted"]:
+                joint = ([state["variable"]] + list(state["evidence"]), True, state["selector"], state["bandwidth"], state["training"], -1.0,
+                         state["N"], 12 if state["dtype"] == _lib.PBN_F64 else 11)
+            extra = (state["marg_bandwidth"],) if "marg_bandwidth" in state else ()
+            state = (state["variable"], state["evidence"], state["fitted"], joint) + extra
+            selector = None if not joint else joint[2]
+        if len(state) not in (4, 5):
+            raise RuntimeError("Not valid CKDE.")                   # CKDE.cpp:177
+        variable, evidence, fitted, joint = state[:4]
+        self.__init__(variable, evidence, joint[2] if fitted else None)
+        if fitted:
+            if len(joint) != 8:
+                raise RuntimeError("Not valid KDE.")
+            d, n, type_id = len(self._variables), int(joint[6]), joint[7]
+            np_t = np.float64 if type_id == 12 else np.float32
+            vals = np.asarray(joint[4], dtype=np_t).reshape(n, d, order="F")
             rb = pa.RecordBatch.from_pydict({v: pa.array(np.ascontiguousarray(vals[:, i])) for i, v in enumerate(self._variables)})
             table, _ = DeviceTable.from_dataframe(default_context(), rb, self._variables, drop_null=False)
-            H = np.asfortranarray(state["bandwidth"], dtype=np.float64)
+            H = np.asfortranarray(joint[3], dtype=np.float64)
             h = C.c_void_p()
             _lib.check(_lib.load().pbn_ckde_fit(table.ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, n, _lib.dptr(H), None, C.byref(h)))
             self._handle, self._train, self._dtype, self._bandwidth, self._N = h, table, table.dtype, H, n
             self._fitted = True
-            if "marg_bandwidth" in state:
-                self.kde_marg().bandwidth = state["marg_bandwidth"]
+            if len(state) == 5:
+                self.kde_marg().bandwidth = state[4]
 
     def _upload_test(self, df):
         self._check_fitted("CKDE")

@@ -303,29 +303,54 @@ class _KDEBase:
         n = table.num_rows - row0 if n is None else n
         _lib.check(_lib.load().pbn_kde_slogl_async(self._handle, table.handle, _lib.int_array(idx), row0, n, C.c_void_p(dev_out_ptr)))
 
-    # -- pickle: (variables, fitted, selector, bandwidth, flat column-major training values, lognorm, N, dtype),
-    # the tuple layout of KDE::__getstate__ (kde/KDE.hpp:642-666); the training matrix is read back from HBM ------
+    # -- pickle: the tuple layout of KDE::__getstate__ / ProductKDE::__getstate__ (kde/KDE.hpp:642-666, ProductKDE.hpp:310-334),
+    #    (variables, fitted, bandwidth selector, bandwidth, training data, lognorm_const, N, arrow type id)
+    # with the reference's placeholders for an unfitted model (empty bandwidth / data, -1.0, -1, -1).  KDE: bandwidth is the
+    # d x d matrix, training data ONE flat column-major vector of N * d values in the data's dtype; ProductKDE: bandwidth the
+    # d vector, training data a list of d column vectors (the reference forgets to append its columns to that list - its
+    # pickled ProductKDE cannot be restored, ProductKDE.hpp:323-326 - here the list is filled).  The training matrix is
+    # read back from HBM.
+    _ARROW_TYPE_ID = {_lib.PBN_F64: 12, _lib.PBN_F32: 11}   # arrow::Type::DOUBLE / FLOAT, as static_cast<int>(type->id())
+
     def __getstate__(self):
-        state = {"variables": self._variables, "fitted": self._fitted, "selector": self._selector}
-        if self._fitted:
-            vals = self._train.read([self._train.names[i] for i in self._train_idx])
-            state.update(bandwidth=np.array(self._bandwidth), training=np.asfortranarray(vals).reshape(-1, order="F"),
-                         N=self._N, dtype=self._dtype,
-                         lognorm=_lib.load().pbn_kde_lognorm(self._handle, 0))
-        return state
+        d = len(self._variables)
+        if not self._fitted:
+            empty_bw = np.zeros((0, 0)) if self._kind == _lib.PBN_BW_FULL else np.zeros(0)
+            empty_data = np.zeros(0) if self._kind == _lib.PBN_BW_FULL else []
+            return (list(self._variables), False, self._selector, empty_bw, empty_data, -1.0, -1, -1)
+        np_t = np.float64 if self._dtype == _lib.PBN_F64 else np.float32
+        vals = np.asarray(self._train.read([self._train.names[i] for i in self._train_idx]), dtype=np_t)
+        if self._kind == _lib.PBN_BW_FULL:
+            training = np.asfortranarray(vals).reshape(-1, order="F")
+        else:
+            training = [np.ascontiguousarray(vals[:, i]) for i in range(d)]
+        return (list(self._variables), True, self._selector, np.array(self._bandwidth), training,
+                float(_lib.load().pbn_kde_lognorm(self._handle, 0)), int(self._N), self._ARROW_TYPE_ID[self._dtype])
 
     def __setstate__(self, state):
-        self.__init__(state["variables"], state["selector"])
-        if state["fitted"]:
-            d, n = len(self._variables), state["N"]
-            vals = np.asarray(state["training"]).reshape(n, d, order="F")
-            cols = {v: pa.array(np.ascontiguousarray(vals[:, i])) for i, v in enumerate(self._variables)}
+        if isinstance(state, dict):      # states written before the reference layout was adopted
+            state = (state["variables"], state["fitted"], state["selector"], state.get("bandwidth"),
+                     state.get("training"), -1.0, state.get("N", -1), self._ARROW_TYPE_ID.get(state.get("dtype"), -1))
+        if len(state) != 8:
+            raise RuntimeError(f"Not valid {self._name}.")          # KDE.cpp:121
+        variables, fitted, selector, bw, training, _lognorm, n, type_id = state
+        self.__init__(variables, selector)
+        if fitted:
+            d, n = len(self._variables), int(n)
+            if type_id not in (11, 12):
+                raise RuntimeError(f"Not valid data type in {self._name}.")
+            np_t = np.float64 if type_id == 12 else np.float32
+            if self._kind == _lib.PBN_BW_FULL:
+                vals = np.asarray(training, dtype=np_t).reshape(n, d, order="F")
+                cols = {v: pa.array(np.ascontiguousarray(vals[:, i])) for i, v in enumerate(self._variables)}
+            else:
+                cols = {v: pa.array(np.ascontiguousarray(np.asarray(training[i], dtype=np_t))) for i, v in enumerate(self._variables)}
             rb = pa.RecordBatch.from_pydict(cols)
             table, _ = DeviceTable.from_dataframe(default_context(), rb, self._variables, drop_null=False)
-            self._train, self._dtype, self._N = table, state["dtype"], n
+            self._train, self._dtype, self._N = table, (_lib.PBN_F64 if type_id == 12 else _lib.PBN_F32), n
             self._train_idx = list(range(d))
-            self._bandwidth = np.array(state["bandwidth"])
-            self._device_fit()
+            self._bandwidth = np.array(bw, dtype=np.float64)
+            self._device_fit()          # lognorm_const is recomputed from the bandwidth (the reference trusts the stored one)
             self._fitted = True
 
     def __del__(self):

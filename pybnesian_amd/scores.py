@@ -358,7 +358,16 @@ class BGe(_DeviceScore):
             raise ValueError(f"\"nu\" argument contains {len(nu)} elements, but DataFrame \"df\" contains {ncols} columns.")
         self._iss_mu = float(iss_mu)
         self._iss_w = float(ncols + 2 if iss_w is None else iss_w)
-        self._nu = None if nu is None else np.asarray(nu, dtype=np.float64)
+        # nu is given per DataFrame column, in DataFrame order (bge.hpp:36-49 indexes it by m_df.index(variable)); the engine
+        # numbers the continuous columns on their own (dictionary columns follow them): hand it the continuous entries
+        # in ITS order
+        if nu is None:
+            self._nu = None
+        else:
+            nu = np.asarray(nu, dtype=np.float64)
+            order = list(self._df.schema.names) if self._df is not None else list(self._names)
+            pos = {name: i for i, name in enumerate(order)}
+            self._nu = np.asarray([nu[pos[name]] for name in self._table.names], dtype=np.float64)
 
     def _batch_params(self, model):
         head = [self._iss_mu, self._iss_w, float(model.num_nodes())]

@@ -30,13 +30,14 @@ def _launch(world):
     for rank in range(world):
         env = dict(os.environ)
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   PBN_DEVICE="0",   # one GPU: every rank's context on device 0
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker_gpu.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=600)
-        assert p.returncode == 0, e[-2000:]
+    results = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(e[-1500:] for _, e in results)
+    for o, e in results:
         line = [l for l in o.splitlines() if l.startswith("RESULT ")][-1]
         outs.append(json.loads(line[len("RESULT "):]))
     return outs

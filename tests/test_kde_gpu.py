@@ -296,6 +296,47 @@ def test_pickle_roundtrip(pbn, golden):
     assert np.allclose(c32.logl(frame(golden["test50"], "float32")), f32.logl(frame(golden["test50"], "float32")), rtol=1e-6)
 
 
+def test_pickle_state_is_the_reference_tuple(pbn, golden):
+    """The on-disk format of this path (SURVEY.md §8 f3): KDE::__getstate__ (kde/KDE.hpp:642-666) =
+    (variables, fitted, selector, bandwidth, flat column-major training vector, lognorm_const, N, arrow type id);
+    ProductKDE the same with a bandwidth vector and a list of columns (ProductKDE.hpp:310-334); CKDE =
+    (variable, evidence, fitted, joint KDE tuple) (CKDE.hpp:737-745); unfitted models carry the reference's placeholders."""
+    df = frame(golden["train500"])
+    k = pbn.KDE(["a", "c"])
+    st = k.__getstate__()
+    assert len(st) == 8 and st[0] == ["a", "c"] and st[1] is False and st[3].shape == (0, 0) and len(st[4]) == 0
+    assert st[5:] == (-1.0, -1, -1)
+    k.fit(df)
+    st = k.__getstate__()
+    assert len(st) == 8 and st[1] is True and isinstance(st[2], pbn.NormalReferenceRule)
+    assert st[3].shape == (2, 2) and np.array_equal(st[3], k.bandwidth)
+    assert st[4].dtype == np.float64 and np.array_equal(st[4], df[["a", "c"]].to_numpy().reshape(-1, order="F"))
+    d, n = 2, 500
+    want_lognorm = -0.5 * np.linalg.slogdet(k.bandwidth)[1] - 0.5 * d * np.log(2 * np.pi) - np.log(n)   # KDE.hpp:476-477
+    assert abs(st[5] - want_lognorm) <= 1e-12 * abs(want_lognorm) and st[6] == 500 and st[7] == 12            # arrow::Type::DOUBLE
+    k32 = pbn.KDE(["a", "b"])
+    k32.fit(frame(golden["train500"], "float32"))
+    s32 = k32.__getstate__()
+    assert s32[7] == 11 and s32[4].dtype == np.float32
+    pk = pbn.ProductKDE(["b", "d", "a"])
+    assert pk.__getstate__()[3].shape == (0,) and pk.__getstate__()[4] == []
+    pk.fit(df)
+    sp = pk.__getstate__()
+    assert len(sp) == 8 and sp[3].shape == (3,) and isinstance(sp[4], list) and len(sp[4]) == 3
+    assert all(np.array_equal(c, df[v].to_numpy()) for c, v in zip(sp[4], ["b", "d", "a"]))
+    want = -0.5 * 3 * np.log(2 * np.pi) - 0.5 * np.log(pk.bandwidth).sum() - np.log(500)                     # ProductKDE.hpp:188-189
+    assert abs(sp[5] - want) <= 1e-12 * abs(want)
+    c = pbn.CKDE("d", ["a", "b"])
+    assert c.__getstate__() == ("d", ["a", "b"], False, ())
+    c.fit(df)
+    sc = c.__getstate__()
+    assert len(sc) == 4 and sc[:3] == ("d", ["a", "b"], True) and len(sc[3]) == 8
+    assert sc[3][0] == ["d", "a", "b"] and sc[3][3].shape == (3, 3) and sc[3][6] == 500
+    assert np.array_equal(sc[3][4], df[["d", "a", "b"]].to_numpy().reshape(-1, order="F"))
+    with pytest.raises(RuntimeError, match="Not valid KDE"):
+        pbn.KDE(["a"]).__setstate__((["a"], False))
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("d", [1, 2, 3, 5])
 def test_pruned_handles_match_oracle(pbn, oracle, d, dtype, monkeypatch):
@@ -341,6 +382,37 @@ def test_pruned_handles_match_oracle(pbn, oracle, d, dtype, monkeypatch):
                            atol=1e-9 if dtype == "float64" else 5e-4)
         assert np.allclose(k.logl(test.iloc[5:6]), got[5:6], rtol=1e-9 if dtype == "float64" else 1e-4, atol=5e-4)   # one far query alone
         assert k.logl(test.iloc[:0]).shape == (0,) and k.slogl(test.iloc[:0]) == 0.0
+
+
+@pytest.mark.parametrize("what,d", [("kde", 2), ("ckde", 3), ("ckde", 4)])
+def test_whole_splits_pruned_far_cluster(pbn, oracle, monkeypatch, what, d):
+    """Two clusters ~1000 bandwidths apart, queries next to one of them: every tile of the other cluster - whole training
+    splits of the sweep - is pruned, so their partial sums are the empty-sum rule's single term (kde_sweep_kernel epilogue).
+    fp64, plain pruned sweep (KDE d = 2; CKDE d = 3 as two plain sweeps) and the fused pruned CKDE sweep (d = 4): equal to
+    the unpruned sweep and to the oracle."""
+    rng = np.random.default_rng(17)
+    n = 48_000
+    mix = np.tril(np.full((d, d), 0.3), -1) + np.eye(d)
+    a = rng.normal(size=(n, d)) @ mix.T
+    b = rng.normal(size=(n, d)) @ mix.T + 300.0
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame(np.vstack([a, b]), columns=names)
+    test = pd.DataFrame(np.vstack([rng.normal(size=(700, d)) @ mix.T, rng.normal(size=(300, d)) @ mix.T + 300.0]), columns=names)
+    make = (lambda: pbn.KDE(names)) if what == "kde" else (lambda: pbn.CKDE(names[0], names[1:]))
+    k = make()
+    k.fit(train)
+    got = k.logl(test)
+    assert np.all(np.isfinite(got))
+    monkeypatch.setenv("PBN_SWEEP_PRUNE", "0")
+    plain = make()
+    plain.fit(train)
+    monkeypatch.delenv("PBN_SWEEP_PRUNE")
+    # (Gram-form distances around a centre between the clusters: eps |z|^2 ~ 1e-10 on every exponent, in both sweeps)
+    assert np.allclose(got, plain.logl(test), rtol=1e-8, atol=1e-8)
+    sub = test.iloc[np.r_[0:40, 700:740]]
+    fn = oracle.kde_logl if what == "kde" else oracle.ckde_logl
+    want = fn(train.to_numpy(), k.bandwidth, sub.to_numpy())
+    assert np.allclose(k.logl(sub), want, rtol=1e-7, atol=1e-7)
 
 
 def test_pruned_handles_full_size_properties(pbn, monkeypatch):

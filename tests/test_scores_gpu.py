@@ -102,6 +102,12 @@ def test_bge_vs_oracle_and_numpy(pbn, golden, oracle):
         want = numpy_bge(data[:, idx], 4, 2.5, 9.0, nu[idx])
         assert abs(got - want) <= 1e-9 * abs(want)
         assert abs(oracle.bge(data[:, idx], 4, 2.5, 9.0, nu[idx]) - want) <= 1e-9 * abs(want)
+    # nu is indexed by DataFrame column (bge.hpp:36-49): a dictionary column in front of the continuous ones must not shift it
+    df3 = df.copy()
+    df3.insert(0, "k", pd.Categorical.from_codes(np.arange(len(df)) % 3, ["k0", "k1", "k2"]))
+    bge3 = pbn.BGe(df3, iss_mu=2.5, iss_w=9.0, nu=np.concatenate([[99.0], nu]))
+    for variable, evidence in CKDE_SETS:
+        assert bge3.local_score(gbn, variable, evidence) == pytest.approx(bge2.local_score(gbn, variable, evidence), rel=1e-13)
     with pytest.raises(ValueError):
         pbn.BGe(df, iss_w=2.0)
 
