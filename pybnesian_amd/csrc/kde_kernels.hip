@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 
     double xc[PBN_MAX_D];
     if (valid) {
-        const int64_t rr = a.perm ? (int64_t)a.perm[r] : r;
+        const int64_t rr = a.perm ? (int64_t)a.perm[a.perm_stride > 1 ? r * a.perm_stride : r] : r;
         const int64_t lr = rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0);
         const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
         for (int j = 0; j < d; ++j) {
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256) void tile_box_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __restrict__ zq_row, const int32_t* __restrict__ qperm, int64_t nq,
                                                             const uint32_t* __restrict__ qkeys, const double* __restrict__ zt,
                                                             const uint32_t* __restrict__ tkeys, int64_t n, int zd, int pd,
-                                                            double* __restrict__ qbox, double* __restrict__ qthr) {
+                                                            double* __restrict__ qbox, double* __restrict__ qthr,
+                                                            const double* __restrict__ subpart, int P, int which, double log2_nsub) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = q < nq;
     double z[PBN_MAX_D];
@@ -350,6 +351,15 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
             for (int k = 0; k < zd; ++k) { const double dd = zt[t * zd + k] - z[k]; d2 = __builtin_fma(dd, dd, d2); }
             const double ex = -0.5 * d2;
             best = ex > best ? ex : best;
+        }
+        // Neighbours in Morton order are neighbours in the keyed (<= 3) dimensions only: with more dimensions than that the
+        // scan above finds rows that are close in 3 coordinates and anywhere in the others - a loose bound (d = 4: 6 % of the
+        // tiles pruned where 70 % could be).  The sweep over a stratified subsample of the training rows bounds the largest
+        // exponent whatever the dimension: max_t s2 >= log2(sum over the subsample of 2^s2) - log2(size of the subsample).
+        if (subpart) {
+            const double* sp = subpart + q * P + which;
+            const double lb = sp[0] + log2(sp[1]) - log2_nsub;
+            best = lb > best ? lb : best;
         }
     }
     // reduce over the 16 lanes of a query tile
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 
     double xc[PBN_MAX_D];
     if (valid) {
-        const int64_t rr = a.perm ? (int64_t)a.perm[r] : r;
+        const int64_t rr = a.perm ? (int64_t)a.perm[a.perm_stride > 1 ? r * a.perm_stride : r] : r;
         const int64_t lr = rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0);
         const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
         for (int j = 0; j < d; ++j) {
@@ -1519,8 +1529,9 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
         if constexpr (sizeof(T) == 8) {
             constexpr int QGP = COND ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;   // query groups per wave of the pruned kernels
             if constexpr (!COND && !FOLD) {
-                if (a.wmul && KS == 1) {   // 4 marginal dimensions: the only pruned shape without a free K slot
-                    hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QGP, false, true, true>), grid, block, 0, st, a);
+                if (a.wmul && KS <= 2) {   // 4 / 8 marginal dimensions: the pruned shapes without a free K slot
+                    if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QGP, false, true, true>), grid, block, 0, st, a);
+                    else hipLaunchKernelGGL((kde_sweep_kernel<T, 2, false, QGP, false, true, true>), grid, block, 0, st, a);
                     HIP_CHECK(hipGetLastError());
                     return;
                 }
@@ -1572,10 +1583,11 @@ void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int z
     HIP_CHECK(hipGetLastError());
 }
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
-                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st) {
+                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st,
+                          const double* subpart, int P, int which, double log2_nsub) {
     if (nq == 0) return;
     hipLaunchKernelGGL(query_prepass_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, zq_row, qperm, nq, qkeys_sorted, ztrain_sorted,
-                       tkeys_sorted, n, zd, pd, qbox, qthr);
+                       tkeys_sorted, n, zd, pd, qbox, qthr, subpart, P, which, log2_nsub);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1619,7 +1631,7 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
     if (a.prune) {   // at most 5 marginal dimensions: 33 bf16 slots, two MFMAs
         if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, true>), grid, block, 0, st, a);
         else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, true>), grid, block, 0, st, a);
-        else throw invalid_error("KDE: pruned sweeps cover at most 5 whitened dimensions");
+        else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;
     }

@@ -29,6 +29,7 @@ struct PackArgs {
     int64_t row0, n0, row1;
     const int32_t* rows;  // device gather list (nullable)
     const int32_t* perm;  // nullable: logical row r is taken from logical row perm[r] (spatially sorted packs, see SweepArgs::prune)
+    int64_t perm_stride;  // > 1: from logical row perm[r * perm_stride] (the stratified subsample of a sorted pack)
     int64_t n;            // valid rows
     int64_t ntiles;       // ceil(n / 16)
     double W[PBN_MAX_D * PBN_MAX_D];  // d x d row-major lower-triangular whitening matrix (kernel argument)
@@ -105,8 +106,12 @@ bool sweep_weights_norm(int dtype, bool cond, int KS, int dm); // see SweepArgs:
 // spatial sort + bounding boxes + exponent bounds of the pruned sweeps (SweepArgs::prune)
 void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st);
 void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st);
+// subpart (nullable): per query (in sorted order) the (offset, sum) partials of a sweep over a subsample of nsub training rows,
+// P doubles per query, the pair to use at [which]: offset + log2(sum) - log2(nsub) is a second lower bound of the query's
+// largest exponent
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
-                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st);
+                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st,
+                          const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)

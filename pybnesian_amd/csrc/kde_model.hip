@@ -163,7 +163,18 @@ static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackA
 }
 
 bool kde_prune_applies(int dtype, int dm, int64_t n) {
-    return env_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= 5 && n >= env_int("PBN_PRUNE_MIN_ROWS", 32768);
+    return env_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= env_int("PBN_PRUNE_MAX_DIMS", 5) &&
+           n >= env_int("PBN_PRUNE_MIN_ROWS", 32768);
+}
+
+// bytes of the subsample packs (kde_pack_bytes of nsub rows, each part 256-aligned)
+struct SubBytes { size_t a, n, x, total; };
+static SubBytes sub_bytes(const KdeModel& m, int64_t nsub) {
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const KdePackBytes pb = kde_pack_bytes(m.dtype, m.dm, m.cond, nsub);
+    SubBytes b{al(pb.apack), al(pb.nxpack), al(pb.axpack), 0};
+    b.total = b.a + b.n + b.x;
+    return b;
 }
 
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
@@ -179,19 +190,36 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
         m.zdims = m.d;
         m.pdims = std::min(m.dm, 3);
         const size_t box_b = al((size_t)m.ntiles * 2 * m.pdims * sizeof(double)), zs_b = al((size_t)m.N * m.zdims * sizeof(double));
-        const PruneSide s = prune_sort_side(ctx, ctx->scratch_prune, pa, m.dtype, m.zdims, m.pdims, box_b + zs_b);
+        // more dimensions than the keys cover: a stratified subsample (every N / nsub-th row of the sorted order, <= 4096
+        // rows, <= 1/64 of the set) is packed as well; the queries are swept against it first (kde_eval_enqueue)
+        m.nsub = 0;
+        if (m.d > m.pdims && env_int("PBN_PRUNE_SUBSAMPLE", 1)) m.nsub = std::min<int64_t>(4096, m.N / 64) / 16 * 16;
+        const SubBytes sb = sub_bytes(m, m.nsub);
+        const PruneSide s = prune_sort_side(ctx, ctx->scratch_prune, pa, m.dtype, m.zdims, m.pdims, box_b + zs_b + (m.nsub ? sb.total : 0));
         double* box = (double*)s.rest;
         double* zsorted = (double*)(s.rest + box_b);
         launch_tile_boxes(s.zrow, s.perm, m.N, m.zdims, m.pdims, box, zsorted, ctx->stream);
         pa.perm = s.perm;
         m.prune = true;
         m.tile_box = box; m.zsorted = zsorted; m.keys_sorted = s.keys;
+        if (m.nsub) {
+            char* sp = s.rest + box_b + zs_b;
+            m.ntiles_sub = m.nsub / 16;
+            m.Asub = sp; m.nxsub = sp + sb.a; m.Axsub = m.cond ? sp + sb.a + sb.n : nullptr;
+        }
     }
     pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
     pa.write_w = !use_bf16x3(m.dtype);
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
     launch_pack(pa, m.dtype, ctx->stream);
+    if (m.prune && m.nsub) {
+        PackArgs ps = pa;
+        ps.perm_stride = m.N / m.nsub;
+        ps.n = m.nsub; ps.ntiles = m.ntiles_sub;
+        ps.pack = m.Asub; ps.npack = m.nxsub; ps.xpack = m.Axsub;
+        launch_pack(ps, m.dtype, ctx->stream);
+    }
 }
 
 // A fitted handle outlives the context's arenas: move the pruning tables of a freshly packed model into `store`.
@@ -200,13 +228,19 @@ void kde_prune_persist(pbn_ctx* ctx, KdeModel& m, dev_buf<char>& store) {
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t box_b = al((size_t)m.ntiles * 2 * m.pdims * sizeof(double)), zs_b = al((size_t)m.N * m.zdims * sizeof(double)),
                  key_b = al((size_t)m.N * sizeof(uint32_t));
-    store.alloc(box_b + zs_b + key_b);
+    const SubBytes sb = sub_bytes(m, m.nsub);
+    store.alloc(box_b + zs_b + key_b + (m.nsub ? sb.total : 0));
     HIP_CHECK(hipMemcpyAsync(store.p, m.tile_box, box_b, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(store.p + box_b, m.zsorted, (size_t)m.N * m.zdims * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(store.p + box_b + zs_b, m.keys_sorted, (size_t)m.N * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     m.tile_box = (const double*)store.p;
     m.zsorted = (const double*)(store.p + box_b);
     m.keys_sorted = (const uint32_t*)(store.p + box_b + zs_b);
+    if (m.nsub) {   // the three subsample packs are contiguous in the arena (kde_pack_train)
+        char* sp = store.p + box_b + zs_b + key_b;
+        HIP_CHECK(hipMemcpyAsync(sp, m.Asub, sb.total, hipMemcpyDeviceToDevice, ctx->stream));
+        m.Asub = sp; m.nxsub = sp + sb.a; m.Axsub = m.cond ? sp + sb.a + sb.n : nullptr;
+    }
 }
 
 static int env_int(const char* name, int dflt) {
@@ -246,20 +280,39 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     const double* qbox = nullptr;
     const double* qthr = nullptr;
     const int32_t* qperm = nullptr;
+    PruneSide qs{};
     if (m.prune) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         const size_t qbox_b = al((size_t)nqtiles * 2 * m.pdims * sizeof(double)), qthr_b = al((size_t)nqtiles * sizeof(double));
-        const PruneSide s = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b);
-        double* qb = (double*)s.rest;
-        double* qt = (double*)(s.rest + qbox_b);
-        launch_query_prepass(s.zrow, s.perm, n, s.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, qb, qt, ctx->stream);
-        pa.perm = s.perm;
-        qperm = s.perm;
-        qbox = qb; qthr = qt;
+        qs = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b);
+        pa.perm = qs.perm;
+        qperm = qs.perm;
+        qbox = (double*)qs.rest; qthr = (double*)(qs.rest + qbox_b);
     }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
     pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
+    const int P = m.cond ? 4 : 2;
+    const bool wmul = !fold && sweep_weights_norm(m.dtype, m.cond, m.KS, m.dm);
+    if (m.prune) {
+        // bounds of the queries' largest exponents: neighbours in Morton order, and (more dimensions than keys) one sweep over
+        // the subsample of the training rows; then per query tile the smallest bound and the box
+        const double* subpart = nullptr;
+        if (m.nsub) {
+            ctx->scratch_part.reserve((size_t)nqtiles * 16 * P * sizeof(double));
+            SweepArgs ss{};
+            ss.Apack = m.Asub; ss.nxpack = m.nxsub; ss.Axpack = m.Axsub;
+            ss.Bpack = pa.pack; ss.nypack = pa.npack; ss.Bxpack = pa.xpack; ss.Bxnorm = pa.xnorm;
+            ss.ntiles = m.ntiles_sub; ss.nqtiles = nqtiles; ss.tiles_per_split = m.ntiles_sub;
+            ss.fold = fold ? 1 : 0; ss.wmul = wmul ? 1 : 0; ss.prune = 0;
+            ss.part = (double*)ctx->scratch_part.p;
+            ss.soft = env_int("PBN_SPARSE_SOFT", 8); ss.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
+            { KernelTimer kt(ctx, PBN_K_PACK); launch_sweep(ss, m.dtype, m.KS, m.cond, 1, ctx->stream); }
+            subpart = ss.part;
+        }
+        launch_query_prepass(qs.zrow, qs.perm, n, qs.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, (double*)qbox, (double*)qthr,
+                             ctx->stream, subpart, P, m.cond ? 2 : 0, subpart ? std::log2((double)m.nsub) : 0.0);
+    }
 
     // split the training tiles so that the grid is a few waves deep on every CU
     const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond, m.KS, m.prune));
@@ -275,14 +328,13 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     nsplit = std::min<int64_t>(nsplit, 4096);
     const int64_t tps = ceil_div(m.ntiles, nsplit);
     nsplit = ceil_div(m.ntiles, tps);
-    const int P = m.cond ? 4 : 2;
     ctx->scratch_part.reserve((size_t)nsplit * nqtiles * 16 * P * sizeof(double));
     SweepArgs sa{};
     sa.Apack = m.Apack; sa.nxpack = m.nxpack; sa.Axpack = m.Axpack;
     sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack; sa.Bxnorm = pa.xnorm;
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
-    sa.wmul = (!fold && sweep_weights_norm(m.dtype, m.cond, m.KS, m.dm)) ? 1 : 0;
+    sa.wmul = wmul ? 1 : 0;
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);

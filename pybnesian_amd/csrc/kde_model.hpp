@@ -28,6 +28,12 @@ struct KdeModel {
     const double* tile_box = nullptr;      // [ntiles][2 * pdims]
     const double* zsorted = nullptr;       // [N][zdims] whitened rows in packed order
     const uint32_t* keys_sorted = nullptr; // [N]
+    // stratified subsample of the sorted training rows (every N / nsub-th), packed like the full set; a sweep over it gives
+    // every query a lower bound of its largest exponent that holds in ALL dimensions (models with more than 3 of them)
+    int64_t nsub = 0, ntiles_sub = 0;
+    void* Asub = nullptr;
+    void* nxsub = nullptr;
+    void* Axsub = nullptr;
 };
 
 // Bytes needed for the three training-side fragment arrays.

@@ -181,28 +181,37 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// gram_lds_kernel: the same statistics with the rows staged through LDS and the accumulator tiles SPLIT OVER THE WAVES.
-// gram_kernel above keeps all NCT(NCT+1)/2 accumulator tiles in every wave (NCT = 4: 10 tiles = 80 VGPRs + 64 of operands
-// and prefetch -> 196 VGPRs, 2 waves / SIMD, each alternating between its load phase and its MFMA phase: 0.52 of the HBM
-// peak at 64 columns).  Here a 256-thread block loads a chunk of 32 rows x all columns ONCE, coalesced (4 threads per
-// column, 64 contiguous bytes each), subtracts the pilot shift and writes doubles to LDS in [column][row] order; every
-// wave then owns a few (I, J) tile pairs (10 pairs over 4 waves: 3 + 3 + 2 + 2, rotated by block so that co-resident blocks
-// load the four SIMDs evenly) and reads its two operand fragments per k-step from LDS.  24 accumulator VGPRs per wave,
-// ~60 in all: 4 blocks = 16 waves per CU, and the global loads of chunk i+1 are in flight (registers) under the MFMAs of
-// chunk i (double-buffered LDS, one barrier per chunk).
-// LDS image: column stride CS = 32 rows * 8 B + 16 B padding: lane (c = lane & 15, k = lane >> 4) reads element
-// [16 I + c][4 s + k]; with the 16-byte pad the 32 lanes of a half wave touch 64 distinct banks (ds_read_b64: two banks per
-// lane) - conflict free.  Every pair has exactly one owner, so the block's partial is written straight from the
-// accumulators in the layout gram_raw / sse_block decode ([pair][reg * 64 + lane], then the column sums).
+// gram_lds_kernel: the same statistics with the rows staged through LDS and the K-STEPS split over the waves.
+// gram_kernel above gives every wave its own rows: all NCT(NCT+1)/2 accumulator tiles AND four k-steps of operands and
+// their prefetch live in registers (NCT = 4: 196 VGPRs, 2 waves / SIMD, each alternating between its load phase and its
+// MFMA phase: 0.52 of the HBM peak at 64 columns).  Here a 256-thread block loads a chunk of 32 rows x all columns ONCE,
+// coalesced (4 threads per column, 64 contiguous bytes each), subtracts the pilot shift and writes doubles to LDS; wave w
+// then multiplies k-steps 2w and 2w + 1 of the chunk (rows 8w .. 8w + 7) into ALL tile pairs: per k-step NCT operand
+// fragments from LDS feed NCT(NCT+1)/2 MFMAs, every wave has the same work (20 MFMAs per chunk at NCT = 4), and the
+// registers hold the accumulators (80) plus one k-step of operands - ~120 VGPRs, 4 waves / SIMD, 4 blocks per CU.  The
+// global loads of chunk i + 1 are in flight (registers) under the MFMAs of chunk i (double-buffered LDS, one barrier per
+// chunk); the four waves' accumulators are added through LDS in wave order at the end (deterministic).
+// Two earlier splits were measured and dropped: tile PAIRS over the waves (10 pairs = 3 + 3 + 2 + 2: the barrier per chunk
+// waits for the 3-pair waves, and every wave reads two fragments per MFMA from LDS - 216 us for the MFMA side alone against
+// 130 us of MFMA work; with the compiler's ds_read2_b64 fusion the LDS reads alone took as long as the MFMAs), and a
+// prefetch distance of two chunks (158 VGPRs, a block per CU lost: 320 us).
+// LDS image: [k-step s (8)][column group I][half h = k >> 1][column c (16)][k & 1] - the 32 lanes of a half wave
+// (lane = 16 k + c, k in {0, 1} or {2, 3}) read 32 CONSECUTIVE doubles of k-step s, group I: one conflict-free
+// ds_read_b64 (2 LDS cycles, 256 B/clk; MI355X_MICROARCH.md "LDS").  The k-steps are 2064 B apart on purpose: at <= 2040 B
+// or at a multiple of 512 B the compiler fuses reads of neighbouring k-steps into ds_read2[st64]_b64, which run at half the
+// rate (8 cycles per KiB, 32-bank mapping).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int GL_ROWS = 32;                         // rows per chunk
-constexpr int GL_CS = GL_ROWS + 2;                  // doubles per column in LDS (32 + 16 B pad)
+constexpr int GL_KSTRIDE = 258;                     // doubles between k-steps in the LDS image: 4 groups x 64, + 16 B
 
 template <typename T, int NCT, bool GATHER>
-__global__ __launch_bounds__(256, 3) void gram_lds_kernel(GramArgs a) {
+__global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
     constexpr int NP = NPairs<NCT>::value;
     constexpr int NC = NCT * 16;
-    __shared__ double lds[2][NC * GL_CS];
+    constexpr int WS = NP * 256 + NCT * 16;
+    constexpr int IMG = (GL_ROWS / 4) * GL_KSTRIDE;
+    static_assert(2 * IMG >= WS, "the final combine reuses the LDS images");
+    __shared__ double lds[2 * IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar
     const int c = lane & 15, kq = lane >> 4;
 
@@ -219,31 +228,15 @@ __global__ __launch_bounds__(256, 3) void gram_lds_kernel(GramArgs a) {
     const double lsh = lvalid ? a.shift[lsrc] : 0.0;
     double csum = 0.0;
 
-    // MFMA role: pairs owned by this wave
-    int pI[3], pJ[3], pidx[3], np = 0;
-    {
-        const int rot = blockIdx.x & 3;
-        int p = 0;
+    d4 acc[NP];
 #pragma unroll
-        for (int I = 0; I < NCT; ++I)
-#pragma unroll
-            for (int J = I; J < NCT; ++J) {
-                if (((p + rot) & 3) == wave && np < 3) { pI[np] = I; pJ[np] = J; pidx[np] = p; ++np; }
-                ++p;
-            }
-    }
-    d4 acc[3];
-    int offA[3], offB[3];   // LDS offsets (doubles) of this lane's operand elements at k-step 0
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        acc[q] = d4{0, 0, 0, 0};
-        offA[q] = q < np ? (pI[q] * 16 + c) * GL_CS + kq : 0;
-        offB[q] = q < np ? (pJ[q] * 16 + c) * GL_CS + kq : 0;
-    }
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0, 0, 0, 0};
+    // this lane's operand element of k-step 2 * wave, column group 0 (doubles into an image)
+    const int off0 = (2 * wave) * GL_KSTRIDE + (kq >> 1) * 32 + c * 2 + (kq & 1);
 
-    T raw[8];
+    T raw[8] = {};
     auto load_chunk = [&](int64_t r) {   // rows r + lrg * 8 .. + 7 of this thread's column into registers
-        if (!lactive) return;
+        if (!lactive || a.debug_skip == 2) return;
         const int64_t rl = r + lrg * 8;
         if (!GATHER && rl + 8 <= rb1) {
             T q0[4], q1[4];
@@ -260,7 +253,7 @@ __global__ __launch_bounds__(256, 3) void gram_lds_kernel(GramArgs a) {
             raw[j] = lp[src];
         }
     };
-    auto store_chunk = [&](int64_t r, int buf) {   // shift, widen, column sums, LDS image [column][row]
+    auto store_chunk = [&](int64_t r, int buf) {   // shift, widen, column sums, LDS image
         if (!lactive) return;
         const int64_t rl = r + lrg * 8;
         double x[8];
@@ -271,49 +264,60 @@ __global__ __launch_bounds__(256, 3) void gram_lds_kernel(GramArgs a) {
             s += x[j];
         }
         csum += s;
-        double* dst = &lds[buf][lcol * GL_CS + lrg * 8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) *(d2_elem_aligned*)(dst + j) = d2_elem_aligned{x[j], x[j + 1]};
+        // rows lrg * 8 + j: k-steps 2 lrg (j < 4) and 2 lrg + 1, k = j & 3; (k = 0, 1) and (k = 2, 3) are 16-byte pairs
+        double* dst = &lds[buf * IMG + (2 * lrg) * GL_KSTRIDE + (lcol >> 4) * 64 + (lcol & 15) * 2];
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        *(d2v*)(dst) = d2v{x[0], x[1]};
+        *(d2v*)(dst + 32) = d2v{x[2], x[3]};
+        *(d2v*)(dst + GL_KSTRIDE) = d2v{x[4], x[5]};
+        *(d2v*)(dst + GL_KSTRIDE + 32) = d2v{x[6], x[7]};
     };
 
     int64_t r = rb0;
     int buf = 0;
     if (r < rb1) { load_chunk(r); store_chunk(r, 0); }
     __syncthreads();
-    // the chunk loop, specialised on the number of pairs this wave owns: no branch inside, so the LDS reads of the next k-steps
-    // are scheduled under the MFMAs of the current one (every wave executes the same number of barriers)
-    auto run = [&](auto npw_c) {
-        constexpr int NPW = decltype(npw_c)::value;
-        for (; r < rb1; r += GL_ROWS) {
-            const bool more = r + GL_ROWS < rb1;
-            if (more) load_chunk(r + GL_ROWS);             // in flight under the MFMAs below
-            const double* img = lds[buf];
+    for (; r < rb1; r += GL_ROWS) {
+        const bool more = r + GL_ROWS < rb1;
+        if (more) load_chunk(r + GL_ROWS);             // in flight under the MFMAs below
+        const double* img = lds + buf * IMG + off0;
+        if (a.debug_skip != 1) {
 #pragma unroll
-            for (int s4 = 0; s4 < GL_ROWS / 4; ++s4) {
-                double xa[NPW > 0 ? NPW : 1], xb[NPW > 0 ? NPW : 1];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                double x[NCT];
 #pragma unroll
-                for (int q = 0; q < NPW; ++q) { xa[q] = img[offA[q] + s4 * 4]; xb[q] = img[offB[q] + s4 * 4]; }
+                for (int I = 0; I < NCT; ++I) x[I] = img[s2 * GL_KSTRIDE + I * 64];
+                int p = 0;
 #pragma unroll
-                for (int q = 0; q < NPW; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q], xb[q], acc[q], 0, 0, 0);
+                for (int I = 0; I < NCT; ++I)
+#pragma unroll
+                    for (int J = I; J < NCT; ++J) {
+                        acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[I], x[J], acc[p], 0, 0, 0);
+                        ++p;
+                    }
             }
-            if (more) store_chunk(r + GL_ROWS, buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
         }
-    };
-    if (np == 3) run(std::integral_constant<int, 3>{});
-    else if (np == 2) run(std::integral_constant<int, 2>{});
-    else if (np == 1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 0>{});
+        if (more) store_chunk(r + GL_ROWS, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
 
-    constexpr int WS = NP * 256 + NCT * 16;
-    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    // ---- block combine: one LDS image, the waves add into it in wave order 0, 1, 2, 3 (deterministic) -----------------
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-        if (q < np) {
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[pidx[q] * 256 + i * 64 + lane] = acc[q][i];
+                for (int i = 0; i < 4; ++i) {
+                    const int e = p * 256 + i * 64 + lane;
+                    lds[e] = (w == 0) ? acc[p][i] : lds[e] + acc[p][i];
+                }
+            }
         }
+        __syncthreads();
+    }
+    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
     // column sums: the 4 loader threads of a column are adjacent lanes
     double s = csum;
     s += __shfl_xor(s, 1);
@@ -376,7 +380,10 @@ void launch_pilot(const void* base, int64_t ld, const GramCols& gc, int n_cols, 
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_gram(const GramArgs& a, int dtype, int nblocks, double* out, hipStream_t st) {
+void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipStream_t st) {
+    GramArgs a = a_in;
+    static const int dbg = [] { const char* e = getenv("PBN_GRAM_DEBUG"); return (e && *e) ? atoi(e) : 0; }();
+    a.debug_skip = dbg;
     const int nct = (a.n_cols + 15) / 16;
     const int WS = gram_ws(nct);
     const bool gather = a.rows != nullptr;

@@ -21,6 +21,7 @@ struct GramArgs {
     int64_t rows_per_block;
     const double* shift;  // device, pilot means indexed by TABLE column id
     double* partial;      // device, [nblocks][gram_ws(nct)]
+    int debug_skip;       // measurement aid (PBN_GRAM_DEBUG): 1 = no MFMAs (loads + LDS traffic only), 2 = no global loads
 };
 
 struct LgArgs {

@@ -160,3 +160,35 @@ def test_conditional_gaussian_network_hc_gpu(pbn):
     assert abs(res.slogl(df) - want) <= 1e-9 * abs(want)
     with pytest.raises(ValueError, match="not compatible"):
         pbn.GreedyHillClimbing().estimate(pbn.ArcOperatorSet(), pbn.BIC(df[["a", "b", "c"]]), start)
+
+
+def test_conditional_spbn_cv_hc_vs_oracle(pbn):
+    """SURVEY.md §8 f2 on the device: a conditional semiparametric network (two interface nodes) learnt with CVLikelihood
+    device scores over arcs and node types against hc_oracle's conditional restatement (operators.cpp:134-256,365-437;
+    operators.hpp:526-578) driven by oracle scores: same operator trace, arcs, node types and number of scored cells."""
+    from oracle import hc_oracle, oracle
+
+    rng = np.random.default_rng(7)
+    n = 700
+    x = rng.normal(size=n)
+    y = rng.normal(size=n)
+    a = np.tanh(1.5 * x) + rng.normal(scale=0.4, size=n)
+    b = -0.8 * a + 0.8 * y + rng.normal(scale=0.5, size=n)
+    c = 0.5 * b + rng.normal(scale=0.7, size=n)
+    names = ["a", "b", "c", "x", "y"]                 # nodes first, interface nodes behind them (the engine's id order)
+    df = pd.DataFrame({"a": a, "b": b, "c": c, "x": x, "y": y})
+    data = df.to_numpy()
+    score = pbn.CVLikelihood(df, 3, 2)
+    start = pbn.ConditionalSemiparametricBN(["a", "b", "c"], ["x", "y"])
+    hc = pbn.GreedyHillClimbing()
+    res = hc.estimate(pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]), score, start, max_indegree=2)
+
+    def sc(v, t, ps):
+        return oracle.cv_likelihood(data[:, [v] + list(ps)], "lg" if t == 0 else "ckde", 3, 2)
+
+    o_arcs, o_types, o_trace, info = hc_oracle.estimate(3, 1, sc, op_types=True, max_indegree=2, n_interface=2)
+    assert trace_of(pbn, hc, names) == [t[:3] for t in o_trace]
+    assert sorted((names.index(s), names.index(t)) for s, t in res.arcs()) == sorted(o_arcs)
+    assert [0 if res.node_type(v) == pbn.LinearGaussianCPDType() else 1 for v in ("a", "b", "c")] == list(o_types)[:3]
+    assert hc.last.cells_scored == info["cells_scored"] and len(o_trace) >= 3
+    assert np.allclose([op.delta() for op in hc.last.trace], [t[3] for t in o_trace], rtol=1e-5, atol=1e-7)
