@@ -349,6 +349,7 @@ def main():
                          "sharded over the ranks; auto = c4 on one GPU, cv64 on several")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to exercise the N>1 path on one GPU)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-Arrow end-to-end leg (profiling runs: keeps every sweep launch the full one)")
     ap.add_argument("--no-c3", action="store_true", help="skip the bounded config-3 (CKDE, 10-fold CV) hill-climb leg of the default run")
     ap.add_argument("--hc-rows", type=int, default=0)
     ap.add_argument("--hc-max-iters", type=int, default=0)
@@ -522,7 +523,7 @@ def main():
             out["secondary"] = hc_out
         if c3_out is not None:
             out["secondary_c3"] = c3_out
-        if world == 1:
+        if world == 1 and not args.no_e2e:
             try:
                 out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy())
             except Exception as ex:

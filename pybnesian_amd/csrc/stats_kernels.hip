@@ -238,12 +238,9 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
     auto load_chunk = [&](int64_t r) {   // rows r + lrg * 8 .. + 7 of this thread's column into registers
         if (!lactive || a.debug_skip == 2) return;
         const int64_t rl = r + lrg * 8;
-        if (!GATHER && rl + 8 <= rb1) {
-            T q0[4], q1[4];
-            load_rows4<T>(lp + rl, q0);
-            load_rows4<T>(lp + rl + 4, q1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { raw[j] = q0[j]; raw[4 + j] = q1[j]; }
+        if (!GATHER && rl + 8 <= rb1) {   // straight into the prefetch registers: a copy would make the compiler wait for the loads here
+            load_rows4<T>(lp + rl, reinterpret_cast<T(&)[4]>(raw[0]));
+            load_rows4<T>(lp + rl + 4, reinterpret_cast<T(&)[4]>(raw[4]));
             return;
         }
 #pragma unroll
