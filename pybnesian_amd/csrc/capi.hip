@@ -301,11 +301,11 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     kde_prepare(k->m, train->dtype, d, n, bw, kind, cond, center);
     // Low-dimensional CKDE on a large training set: two pruned plain sweeps (joint over [variable, evidence], marginal over
     // the evidence with H[1:, 1:] - CKDE.hpp:186-199) beat the fused sweep, whose pruning can only use the marginal box
-    // (tools/prune_handles_timing.py; fp64 up to 3 variables, fp32 2).  PBN_CKDE_SPLIT=0 keeps the fused sweep, =1 splits
+    // (tools/prune_handles_timing.py; fp64 up to 3 variables - 4 is a tie, 5 goes to the fused sweep -, fp32 up to 4).  PBN_CKDE_SPLIT=0 keeps the fused sweep, =1 splits
     // whenever the marginal qualifies for pruning.
     static const int split_mode = [] { const char* e = getenv("PBN_CKDE_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
     const bool split = ckde && k->m.cond && split_mode != 0 && kde_prune_applies(train->dtype, d - 1, n) &&
-                       (split_mode > 0 || d <= (train->dtype == PBN_F64 ? 3 : 2));
+                       (split_mode > 0 || d <= (train->dtype == PBN_F64 ? 3 : 4));
     if (split) {
         std::vector<double> Hm((size_t)(d - 1) * (d - 1));
         for (int j = 1; j < d; ++j)

@@ -124,6 +124,9 @@ double score_discrete(const pbn_scoredata* sd, int kind, int var, const int* par
 // (parents sorted by column id, stride_0 = 1); a candidate's own numbering (evidence order, discrete_indices.cpp:113-132) is
 // mapped onto it, which keeps the reference's summation order over configurations.
 constexpr int SEG_PIECE = 4096;
+#ifndef PBN_HYBRID_SPLIT_MAX_D
+#define PBN_HYBRID_SPLIT_MAX_D 1   // fp32 CKDE slices with more variables than this: the fused sweep (C5: 21.3 s fused, 22.1 s with slices up to 4 variables split - fewer exponentials, more launches)
+#endif
 
 const HybridGrouping& grouping_for(pbn_scoredata* sd, int kind, const std::vector<int>& dpar_sorted, const std::vector<Region>& regions) {
     std::vector<int> key{kind};
@@ -475,7 +478,9 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             // fp32 (bf16x3) slices with neither term known: the fused joint + marginal sweep - there the extra MFMA step hides
             // under the exponentials and one pack / one launch serves both terms (C5: 22.3 s of sweeps fused against 24.2 s as
             // two plain ones); fp64 slices and slices with one term cached take the plain sweeps
-            if (pc > 0 && use_bf16x3(sd->dtype) && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
+            static const int fused_mode = [] { const char* e = getenv("PBN_HYBRID_FUSED"); return (e && *e) ? atoi(e) : -1; }();
+            const bool want_fused = fused_mode < 0 ? (use_bf16x3(sd->dtype) && d > PBN_HYBRID_SPLIT_MAX_D) : fused_mode != 0;
+            if (pc > 0 && want_fused && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
                 sd->kde_cache.find(key_of(u, c, cols.data() + 1, pc)) == sd->kde_cache.end()) {
                 KdeModel m;
                 try {

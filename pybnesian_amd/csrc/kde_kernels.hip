@@ -185,6 +185,11 @@ struct Tr<float> {
 };
 
 #define PBN_PAD_NORM (-1e30)
+// measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
+__device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
+#ifndef PBN_SWEEP_UNCHECKED
+#define PBN_SWEEP_UNCHECKED 1   // fp64 plain unpruned sweeps: blind first pass, checked redo (kde_sweep_kernel)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // pack_rows: one thread per (padded) row.
@@ -580,7 +585,10 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
                     sum[g] *= exp2(-(double)mx);
                     acc -= mx;
                 }
-                e0 = Tr<T>::ex2(acc[0]); e1 = Tr<T>::ex2(acc[1]); e2 = Tr<T>::ex2(acc[2]); e3 = Tr<T>::ex2(acc[3]);
+                // the SAME 2^x as the main loop (the exponents are still biased, the offsets integers): a term must come out
+                // identical whichever path evaluates it, or sums taken in another tile order would differ by the polynomial's
+                // error (the Morton-ordered sweeps come through here often, table-ordered ones hardly ever)
+                e0 = Tr<T>::ex2p(acc[0], ctop); e1 = Tr<T>::ex2p(acc[1], ctop); e2 = Tr<T>::ex2p(acc[2], ctop); e3 = Tr<T>::ex2p(acc[3], ctop);
                 ts = (e0 + e1) + (e2 + e3);
                 if (COND) {
                     T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)) - Tr<T>::bias());
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
                         accj -= mxj;
                     }
                     bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
-                    T j0 = Tr<T>::ex2(accj[0]), j1 = Tr<T>::ex2(accj[1]), j2 = Tr<T>::ex2(accj[2]), j3 = Tr<T>::ex2(accj[3]);
+                    T j0 = Tr<T>::ex2p(accj[0], ctop), j1 = Tr<T>::ex2p(accj[1], ctop), j2 = Tr<T>::ex2p(accj[2], ctop), j3 = Tr<T>::ex2p(accj[3], ctop);
                     tsj = (j0 + j1) + (j2 + j3);
                 }
             }
@@ -623,13 +631,67 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
             }
         }
     } else {
-        load_tile(t0, afA, nxA, axA);
-        for (int64_t t = t0; t < t1; t += 2) {
-            const bool second = t + 1 < t1;                       // wave-uniform
-            load_tile(second ? t + 1 : t, afB, nxB, axB);
-            process_tile(t, afA, nxA, axA);
-            load_tile(t + 2 < t1 ? t + 2 : t, afA, nxA, axA);
-            if (second) process_tile(t + 1, afB, nxB, axB);
+        // Unchecked passes (fp64 plain sweeps): the per-(tile, group) overflow test and the separate add into the running sum are
+        // 2 of the 42 DP instructions.  2^x overflows only when an exponent lies 896 above the offsets (a query whose neighbours
+        // are ~25 bandwidths closer than the rows that set its offset) or, with the norms as weights, when z_t.z_q alone is
+        // that large (a far-out row next to a far-out query; rows beyond |z|^2 = 2000 carry a NaN weight on purpose).  So the
+        // sums are accumulated blind (weights riding in the FMA chain, or plain adds) and looked at once per chunk of 32 tiles:
+        // a wave that finds an infinite / NaN sum restores the sums it saved in LDS at the start of the chunk and redoes the
+        // chunk with the checked loop - 32 tiles, not the split: an outlier row costs its chunk, not every query block of its
+        // split (measured with whole-split redo on the C2 data, whose diagonal bandwidths leave 5 rows beyond |z|^2 = 1780: 12 % of
+        // the units redone, all on the XCDs that own those splits - 76 ms instead of 50).
+        // (only where the second loop body leaves the kernel at 3 waves / SIMD: <= 168 VGPRs)
+        constexpr bool FAST = PBN_SWEEP_UNCHECKED && !COND && sizeof(T) == 8 && (WMUL || (FOLD && KS <= 3) || (!FOLD && KS <= 2));
+        auto checked_range = [&](int64_t ta, int64_t tb) {
+            load_tile(ta, afA, nxA, axA);
+            for (int64_t t = ta; t < tb; t += 2) {
+                const bool second = t + 1 < tb;                       // wave-uniform
+                load_tile(second ? t + 1 : t, afB, nxB, axB);
+                process_tile(t, afA, nxA, axA);
+                load_tile(t + 2 < tb ? t + 2 : t, afA, nxA, axA);
+                if (second) process_tile(t + 1, afB, nxB, axB);
+            }
+        };
+        if constexpr (FAST) {
+            constexpr int CH = 32;
+            __shared__ double sumsave[QG][256];
+            auto process_fast = [&](const T (&af)[KS], const V& nx) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    V acc;
+                    if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+                    const T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
+                    if (WMUL) sum[g] = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], __builtin_fma(e0, nx[0], sum[g]))));
+                    else sum[g] += (e0 + e1) + (e2 + e3);
+                }
+            };
+            for (int64_t tc = t0; tc < t1; tc += CH) {
+                const int64_t te = tc + CH < t1 ? tc + CH : t1;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) sumsave[g][threadIdx.x] = sum[g];
+                load_tile(tc, afA, nxA, axA);
+                for (int64_t t = tc; t < te; t += 2) {
+                    const bool second = t + 1 < te;                   // wave-uniform
+                    load_tile(second ? t + 1 : t, afB, nxB, axB);
+                    process_fast(afA, nxA);
+                    load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
+                    if (second) process_fast(afB, nxB);
+                }
+                bool bad = false;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < INFINITY);
+                const bool redo = __any(bad);
+                if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo) atomicAdd(&g_sweep_redo, 1ull); }
+                if (redo) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) sum[g] = sumsave[g][threadIdx.x];
+                    checked_range(tc, te);
+                }
+            }
+        } else {
+            checked_range(t0, t1);
         }
     }
 
@@ -1685,3 +1747,10 @@ void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStrea
 }
 
 }  // namespace pbn
+
+extern "C" void pbn_debug_sweep_redo(unsigned long long* redo, unsigned long long* units, int reset) {
+    unsigned long long z = 0;
+    if (redo) (void)hipMemcpyFromSymbol(redo, HIP_SYMBOL(pbn::g_sweep_redo), sizeof z);
+    if (units) (void)hipMemcpyFromSymbol(units, HIP_SYMBOL(pbn::g_sweep_units), sizeof z);
+    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_redo), &z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_units), &z, sizeof z); }
+}

@@ -104,3 +104,57 @@ def test_sharded_mmpc_world2(ensure_built):
         assert cpcs == ref and ntests == ref_tests
         assert calls < ref_t.calls
     assert sum(r[3] for r in results) >= ref_t.calls
+
+
+class _FailingScore:
+    """Stands in for a device score: rank `bad` raises while computing its share."""
+
+    def __init__(self, bad):
+        self.bad = bad
+
+    def _batch_raw(self, model, var, ntype, off, par, kind):
+        if dist.get_rank() == self.bad:
+            raise ValueError("boom on purpose")
+        return np.asarray([float(v) for v in var])
+
+
+def _failing_worker(rank, world, port, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pybnesian_amd.distributed import sharded_batch
+
+        n = 8
+        try:
+            sharded_batch(_FailingScore(1), None, list(range(n)), [1] * n, list(range(n + 1)), [(i + 1) % n for i in range(n)], 0, shard_all=True)
+            queue.put((rank, "no error"))
+        except ValueError as ex:
+            queue.put((rank, "ValueError: " + str(ex)))
+        except RuntimeError as ex:
+            queue.put((rank, "RuntimeError: " + str(ex)))
+        # the group is still usable: nobody was left behind in the collective
+        ok = sharded_batch(_FailingScore(-1), None, list(range(n)), [1] * n, list(range(n + 1)), [(i + 1) % n for i in range(n)], 0, shard_all=True)
+        queue.put((rank, list(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_rank_does_not_hang_the_collective(ensure_built):
+    """A rank that raises while scoring its share still enters the all_gather (with an error flag); every rank raises
+    afterwards - the failing one its own exception, the others a RuntimeError naming it - and the next batch works."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    first = {r: v for r, v in got if isinstance(v, str)}
+    second = {r: v for r, v in got if not isinstance(v, str)}
+    assert first[1].startswith("ValueError: boom") and first[0].startswith("RuntimeError") and "[1]" in first[0]
+    assert second[0] == second[1] == [float(i) for i in range(8)]

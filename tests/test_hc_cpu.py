@@ -344,3 +344,33 @@ def test_cross_validation_and_holdout_objects(ensure_built):
     assert np.array_equal(both, perm.astype(float))                              # train = first n - test of the shuffle
     with pytest.raises(ValueError, match="test_ratio"):
         pbn.HoldOut(df, 1.5, 0)
+
+
+def test_oracle_follow_mode_accounts_for_ties():
+    """hc_oracle.estimate(follow=...) - the tie-flip accounting used by tests/test_tieflip_gpu.py: replaying the restatement's
+    own trace records no flips; a trace whose first operator is the reversed (exactly tied) arc is accepted and recorded with
+    gap 0; a trace that starts with a clearly worse operator is rejected."""
+    from oracle import hc_oracle
+
+    n = 5
+    rng = np.random.default_rng(3)
+    base = rng.normal(size=(n, n))
+    sym = base + base.T                      # score-equivalent toy score: s(v | {p}) - s(v | {}) symmetric in (v, p)
+
+    def score(v, t, ps):
+        return float(sum(sym[v, p] for p in ps)) - 0.3 * len(ps) ** 2
+
+    arcs, _, trace, info = hc_oracle.estimate(n, 0, score)
+    assert len(trace) >= 2 and info["flips"] == []
+    _, _, _, same = hc_oracle.estimate(n, 0, score, follow=[t[:3] for t in trace])
+    assert same["flips"] == []
+    k, a, b, d = trace[0]
+    flipped = [(k, b, a)] + [t[:3] for t in trace[1:]]
+    try:
+        r_arcs, _, _, rinfo = hc_oracle.estimate(n, 0, score, follow=flipped)
+        assert rinfo["flips"] and rinfo["flips"][0]["iteration"] == 1 and rinfo["flips"][0]["gap"] <= 1e-12
+    except AssertionError as ex:             # later operators of the original trace may not be greedy any more on the flipped graph
+        assert "iteration 1:" not in str(ex)
+    worst = min(((score(t, 0, [s]) - score(t, 0, []), s, t) for s in range(n) for t in range(n) if s != t))
+    with pytest.raises(AssertionError, match="not a tie"):
+        hc_oracle.estimate(n, 0, score, follow=[(0, worst[1], worst[2])])

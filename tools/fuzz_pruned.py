@@ -1,5 +1,7 @@
 """Randomised comparison of pruned against unpruned KDE / CKDE handles (logl per row) on awkward data: heavy tails,
-clusters, duplicated rows, lattice-valued columns, large offsets.  python tools/fuzz_pruned.py [n_cases] [seed]"""
+clusters, duplicated rows, lattice-valued columns, large offsets; d = 1...8 (pruned up to 5 marginal dimensions, the
+weighted-norm sweep at d = 4 and 8, the subsample bound from d = 4), and in fp64 a sample of rows against the oracle.
+python tools/fuzz_pruned.py [n_cases] [seed]"""
 import os, sys
 import numpy as np
 import pandas as pd
@@ -10,7 +12,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
 for case in range(n_cases):
-    d = int(rng.integers(1, 5))
+    d = int(rng.integers(1, 9))
     dtype = "float64" if rng.random() < 0.6 else "float32"
     n = int(rng.choice([32768, 33000, 50_001, 120_000]))
     m = int(rng.choice([1, 17, 1000, 4097]))
@@ -44,11 +46,18 @@ for case in range(n_cases):
             print(f"case {case} {kind} d={d} {dtype} {what}: {type(ex).__name__} {str(ex)[:60]}")
             continue
         tol = 1e-9
+        if dtype == "float64":
+            # Gram-form distances: absolute error of an exponent ~ 2^-52 |z|^2 (z = whitened coordinate relative to the centre):
+            # nearly singular bandwidths ("line") reach |z|^2 ~ 1e6, and pruned / unpruned sweeps round differently
+            Hq = np.atleast_1d(np.asarray(b.bandwidth, dtype=np.float64))
+            Xq = np.vstack([train.to_numpy(), test.to_numpy()[:-3]]) - train.to_numpy().mean(axis=0)
+            Zq = Xq / np.sqrt(Hq) if Hq.ndim == 1 else np.linalg.solve(np.linalg.cholesky(Hq), Xq.T).T
+            tol = 1e-9 + 8.0 * 2.0 ** -52 * float((Zq * Zq).sum(axis=1).max())
         if dtype == "float32":
             # the fp32 sweeps take -|z_t|^2/2 + z_t.z_q - |z_q|^2/2 in fp32: absolute error of an exponent ~ 2^-24 |z|^2 with z the
             # whitened coordinate relative to the training mean - tiny bandwidths on spread-out data show up here
             H = np.atleast_1d(np.asarray(b.bandwidth, dtype=np.float64))
-            X = np.vstack([train.to_numpy(), test.to_numpy()[:-3]]).astype(np.float64)
+            X = np.vstack([train.to_numpy(), test.to_numpy()]).astype(np.float64)   # incl. the three far queries: a CKDE evaluated as joint - marginal rounds the two sweeps independently
             X = X - train.to_numpy().astype(np.float64).mean(axis=0)
             Z = X / np.sqrt(H) if H.ndim == 1 else np.linalg.solve(np.linalg.cholesky(H), X.T).T
             tol = 5e-4 + 8.0 * 2.0 ** -24 * float((Z * Z).sum(axis=1).max())
@@ -57,7 +66,21 @@ for case in range(n_cases):
         same_inf = np.array_equal(np.isfinite(la), fin) and np.array_equal(la[~fin], lb[~fin], equal_nan=True)
         worst = max(worst, err if dtype == "float64" else 0.0)
         ok = err <= tol and same_inf and (not np.isfinite(sb) or abs(sa - sb) <= tol * max(1.0, abs(sb)) * 10)
-        print(f"case {case} {kind:8s} d={d} {dtype} n={n} m={m} {what:10s} max rel diff {err:.2e} {'ok' if ok else 'MISMATCH'}", flush=True)
+        oerr = 0.0
+        if ok and dtype == "float64" and what != "ProductKDE" and kind not in ("line",):
+            from oracle import oracle as orc
+            pick = np.unique(np.r_[0:min(m, 24), len(test) - 3:len(test)])
+            fn = orc.kde_logl if what == "KDE" else orc.ckde_logl
+            want = fn(train.to_numpy(), np.asarray(b.bandwidth), test.to_numpy()[pick])
+            got = la[pick]
+            fo = np.isfinite(want)
+            # Gram-form distances: eps |z|^2 on an exponent; bandwidth-relative spread is what matters
+            Hc = np.linalg.cholesky(np.asarray(b.bandwidth, dtype=np.float64))
+            Zc = np.linalg.solve(Hc, (np.vstack([train.to_numpy(), test.to_numpy()[pick]]) - train.to_numpy().mean(axis=0)).T).T
+            otol = 1e-8 + 4.0 * 2.0 ** -52 * float((Zc * Zc).sum(axis=1).max())
+            oerr = float(np.max(np.abs(got[fo] - want[fo]) / np.maximum(1.0, np.abs(want[fo])))) if fo.any() else 0.0
+            ok = ok and oerr <= otol and np.array_equal(np.isfinite(got), fo)
+        print(f"case {case} {kind:8s} d={d} {dtype} n={n} m={m} {what:10s} max rel diff {err:.2e} vs oracle {oerr:.2e} {'ok' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             os.environ["PBN_SWEEP_PRUNE"] = "0"
             t = mk(); t.fit(train.astype("float64"))
