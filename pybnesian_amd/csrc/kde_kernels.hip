@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
                 }
                 bool bad = false;
 #pragma unroll
-                for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < INFINITY);
+                for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);   // not merely finite: the epilogue adds 4 lanes' sums
                 const bool redo = __any(bad);
                 if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo) atomicAdd(&g_sweep_redo, 1ull); }
                 if (redo) {

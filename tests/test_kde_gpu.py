@@ -415,6 +415,64 @@ def test_whole_splits_pruned_far_cluster(pbn, oracle, monkeypatch, what, d):
     assert np.allclose(k.logl(sub), want, rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("d", [4, 8])
+@pytest.mark.parametrize("cls", ["KDE", "ProductKDE"])
+def test_weighted_norm_sweep_with_outliers(pbn, oracle, d, cls):
+    """d mod 4 = 0: the sweep takes the training norms as weights 2^(-|z|^2/2) and accumulates blind over chunks of 32 tiles
+    (kde_sweep_kernel WMUL / unchecked passes).  Heavy-tailed rows (|z|^2 far beyond 2000: NaN weights by design), queries next
+    to them (2^x overflows) and queries far from everything (offsets hundreds of bandwidths off) must all come through the
+    checked redo with the oracle's values."""
+    rng = np.random.default_rng(100 + d)
+    n, m = 6000, 400
+    names = [f"v{i}" for i in range(d)]
+    train = rng.standard_t(1.5, size=(n, d))
+    train[:40] *= 50.0                                   # a block of extreme rows in the first tiles
+    test = np.vstack([rng.standard_t(1.5, size=(m, d)), train[:8] + 0.01, train[-8:] * 1.001, rng.normal(size=(8, d)) * 1e4])
+    tdf, qdf = pd.DataFrame(train, columns=names), pd.DataFrame(test, columns=names)
+    k = getattr(pbn, cls)(names)
+    k.fit(tdf)
+    got = k.logl(qdf)
+    fn = oracle.kde_logl if cls == "KDE" else oracle.product_kde_logl
+    want = fn(train, k.bandwidth, test)
+    assert np.all(np.isfinite(got)) == np.all(np.isfinite(want))
+    fin = np.isfinite(want)
+    # Gram-form distances around the pilot centre: eps |z|^2 on an exponent, |z|^2 up to ~1e9 for the far queries here
+    H = np.asarray(k.bandwidth, dtype=np.float64)
+    X = np.vstack([train, test]) - train[:1024].mean(axis=0)
+    Z2 = ((X * X) / H).sum(axis=1) if H.ndim == 1 else (np.linalg.solve(np.linalg.cholesky(H), X.T) ** 2).sum(axis=0)
+    tol = 1e-8 + 16.0 * 2.0 ** -52 * Z2[n:]
+    assert np.all(np.abs(got[fin] - want[fin]) <= tol[fin] * np.maximum(1.0, np.abs(want[fin]))), np.max(np.abs(got[fin] - want[fin]))
+    assert abs(k.slogl(qdf.iloc[:m]) - want[:m].sum()) <= 1e-7 * abs(want[:m].sum())
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_unchecked_passes_with_stale_offsets(pbn, oracle, monkeypatch, d):
+    """Unpruned fp64 sweeps over a SORTED training table: the offsets a split takes from its first tile are thousands of
+    bandwidths off for most queries, so the blind passes overflow all the time - including the nasty case of a lane's
+    partial sum that is finite but so large that adding the four lanes of a query column overflows - and every such chunk
+    must come back through the checked redo: finite everywhere, equal to the pruned handle and to the oracle."""
+    rng = np.random.default_rng(40 + d)
+    n, m = 150_000, 3000
+    names = [f"v{i}" for i in range(d)]
+    x = rng.normal(size=(n, d))
+    x = x[np.argsort(x[:, 0])]
+    train = pd.DataFrame(x, columns=names)
+    test = pd.DataFrame(rng.normal(size=(m, d)) * 1.3, columns=names)
+    monkeypatch.setenv("PBN_SWEEP_PRUNE", "0")
+    plain = pbn.KDE(names)
+    plain.fit(train)
+    got = plain.logl(test)
+    s = plain.slogl(test)
+    monkeypatch.delenv("PBN_SWEEP_PRUNE")
+    assert np.all(np.isfinite(got)) and np.isfinite(s) and abs(s - got.sum()) <= 1e-10 * abs(s)
+    pruned = pbn.KDE(names)
+    pruned.fit(train)
+    assert np.allclose(pruned.logl(test), got, rtol=1e-10, atol=1e-10)
+    sub = np.r_[0:60, m - 60:m]
+    want = oracle.kde_logl(x, plain.bandwidth, test.to_numpy()[sub])
+    assert np.allclose(got[sub], want, rtol=1e-8, atol=1e-8)
+
+
 def test_pruned_handles_full_size_properties(pbn, monkeypatch):
     """BASELINE sizes (1e6 training x 1e5 test rows) at d = 2, where the fitted handle prunes: the sum equals the unpruned
     sweep's and the sum of the per-row values, and splitting the test rows is additive (each slice is Morton-ordered on its

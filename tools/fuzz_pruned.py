@@ -61,6 +61,9 @@ for case in range(n_cases):
             X = X - train.to_numpy().astype(np.float64).mean(axis=0)
             Z = X / np.sqrt(H) if H.ndim == 1 else np.linalg.solve(np.linalg.cholesky(H), X.T).T
             tol = 5e-4 + 8.0 * 2.0 ** -24 * float((Z * Z).sum(axis=1).max())
+        if not (np.isfinite(sa) and np.isfinite(sb)) and np.all(np.isfinite(train.to_numpy())) and np.all(np.isfinite(test.to_numpy())):
+            print(f"case {case} {kind} d={d} {dtype} {what}: non-finite slogl (pruned {sa}, unpruned {sb}) MISMATCH", flush=True)
+            sys.exit(1)
         fin = np.isfinite(lb)
         err = float(np.max(np.abs(la[fin] - lb[fin]) / np.maximum(1.0, np.abs(lb[fin])))) if fin.any() else 0.0
         same_inf = np.array_equal(np.isfinite(la), fin) and np.array_equal(la[~fin], lb[~fin], equal_nan=True)
