@@ -133,6 +133,11 @@ const HybridGrouping& grouping_for(pbn_scoredata* sd, int kind, const std::vecto
     key.insert(key.end(), dpar_sorted.begin(), dpar_sorted.end());
     auto it = sd->groupings.find(key);
     if (it != sd->groupings.end()) return *it->second;
+    // each grouping holds a 4 B / row device list: beyond 256 of them (a search over very many discrete parent sets) start over
+    if (sd->groupings.size() >= 256) {
+        HIP_CHECK(hipStreamSynchronize(sd->ctx->stream));
+        sd->groupings.clear();
+    }
     auto gp = std::make_unique<HybridGrouping>();
     HybridGrouping& g = *gp;
     std::vector<int> strides(dpar_sorted.size(), 1);

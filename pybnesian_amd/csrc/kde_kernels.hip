@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
                     whi[k] = h > whi[k] ? h : whi[k];
                 }
         }
-        wthr -= PBN_PRUNE_MARGIN;
+        wthr -= a.prune_margin;
     }
     // ---- prologue: offsets from the first tile (max of s2 over its 16 rows) ---------------------
     {
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
                     whi[k] = h > whi[k] ? h : whi[k];
                 }
         }
-        wthr -= PBN_PRUNE_MARGIN_F32;
+        wthr -= a.prune_margin;
     }
     auto set_bx = [&](int g) {  // slots 9..11 (lane group 1, elements 1..3) <- split3(xn + m - mj)
         if (lg == 1) {
@@ -1558,6 +1558,12 @@ void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t 
     if (nq == 0) return;
     hipLaunchKernelGGL(kde_cdf_finish_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, part, nsplit, nqtiles, nq, dev_out);
     HIP_CHECK(hipGetLastError());
+}
+
+double prune_margin(int dtype) {
+    static const double m64 = [] { const char* e = getenv("PBN_PRUNE_MARGIN"); return (e && *e) ? atof(e) : (double)PBN_PRUNE_MARGIN; }();
+    static const double m32 = [] { const char* e = getenv("PBN_PRUNE_MARGIN_F32"); return (e && *e) ? atof(e) : (double)PBN_PRUNE_MARGIN_F32; }();
+    return use_bf16x3(dtype) ? m32 : m64;
 }
 
 bool use_bf16x3(int dtype) {

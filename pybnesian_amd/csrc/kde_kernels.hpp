@@ -64,6 +64,7 @@ struct SweepArgs {
     // from the box of its queries that every exponent is below that bound - 64: such terms are < 2^-64 of their sums.
     int prune;
     int pdims;
+    double prune_margin;       // base-2 exponent distance below the queries' bound beyond which a tile is skipped (64 / 40)
     const double* tile_box;    // [ntiles][2 * pdims]: lo..., hi...
     const double* qtile_box;   // [nqtiles][2 * pdims]
     const double* qtile_thr;   // [nqtiles]
@@ -115,6 +116,7 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
                           const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);
+double prune_margin(int dtype);   // 64 (fp64) / 40 (fp32 on the bf16 cores); PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 
