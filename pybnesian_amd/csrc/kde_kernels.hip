@@ -282,7 +282,13 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 // ------------------------------------------------------------------------------------------------
 #define PBN_PRUNE_CELL 2.0      // key cell edge in (base-2) whitened units; a term vanishes beyond ~11.3 of them
 #define PBN_PRUNE_WINDOW 32     // training rows scanned on either side of a query's Morton position
-#define PBN_PRUNE_MARGIN 64.0   // terms below 2^-64 of their query's largest known term are dropped
+// terms below 2^-52 of their query's largest known term are dropped: at most N * 2^-52 of a sum (2.2e-10 at 10^6 rows), a
+// tenth of the error bound of the 2^x polynomial the kept terms go through.  (Round 1 and the first half of round 2 used
+// 2^-64: C3's first iteration 28.2 s instead of 26.4 s, a pruned d = 2 sweep at 10^6 x 10^5 rows 15.0 ms instead of 13.6;
+// 2^-44 would give 24.9 s / 12.5 ms at a worst case of 6e-8.)  PBN_PRUNE_MARGIN overrides at run time.
+#ifndef PBN_PRUNE_MARGIN
+#define PBN_PRUNE_MARGIN 52.0
+#endif
 // fp32 (bf16x3) sweeps: 2^-40.  What is dropped is at most N * 2^-40 of a sum (9e-7 at 10^6 rows, against the fp32 bar of
 // 1e-3 and fp32's own 6e-8 per term); the support shrinks from 9.4 to 7.4 bandwidths per axis (a third of the tiles at 2-3
 // dimensions).
