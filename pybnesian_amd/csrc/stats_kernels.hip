@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
 
     T raw[8] = {};
     auto load_chunk = [&](int64_t r) {   // rows r + lrg * 8 .. + 7 of this thread's column into registers
-        if (!lactive || a.debug_skip == 2) return;
+        if (!lactive || a.debug_skip >= 2) return;
         const int64_t rl = r + lrg * 8;
         if (!GATHER && rl + 8 <= rb1) {   // straight into the prefetch registers: a copy would make the compiler wait for the loads here
             load_rows4<T>(lp + rl, reinterpret_cast<T(&)[4]>(raw[0]));
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
         }
     };
     auto store_chunk = [&](int64_t r, int buf) {   // shift, widen, column sums, LDS image
-        if (!lactive) return;
+        if (!lactive || a.debug_skip == 3) return;
         const int64_t rl = r + lrg * 8;
         double x[8];
         double s = 0.0;
