@@ -230,7 +230,7 @@ static void sse_block(const pbn_table* t, const int* cols, int d, int64_t row0, 
     GramArgs a{};
     a.base = t->data; a.ld = t->ld; a.n_cols = d; a.row0 = row0; a.rows = nullptr; a.n = n;
     for (int i = 0; i < d; ++i) a.gc.cols[i] = cols[i];
-    a.rows_per_block = rpb; a.shift = shift; a.partial = partial;
+    a.rows_per_block = rpb; a.shift = shift; a.partial = partial; a.num_cus = ctx->num_cus;
     launch_pilot(t->data, t->ld, a.gc, d, row0, nullptr, n, t->dtype, shift, ctx->stream);
     { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram(a, t->dtype, nblocks, total, ctx->stream); }
     std::vector<double> h((size_t)WS + nsh);

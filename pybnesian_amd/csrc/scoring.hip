@@ -54,7 +54,7 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
     GramArgs a{};
     a.base = t->data; a.ld = t->ld; a.n_cols = d; a.row0 = row0; a.rows = dev_rows; a.n = n;
     for (int i = 0; i < d; ++i) a.gc.cols[i] = cols[i];
-    a.rows_per_block = rpb; a.shift = shift_dev; a.partial = partial;
+    a.rows_per_block = rpb; a.shift = shift_dev; a.partial = partial; a.num_cus = ctx->num_cus;
     { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram(a, t->dtype, nblocks, total, ctx->stream); }
     std::vector<double> h((size_t)WS);
     HIP_CHECK(hipMemcpyAsync(h.data(), total, (size_t)WS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

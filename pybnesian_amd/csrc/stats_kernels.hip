@@ -15,7 +15,10 @@
 // Numerics: values are shifted by a per-column pilot mean (mean of the first <=1024 rows; the shift array
 // is indexed by TABLE column so that Grams of different row ranges / column subsets are additive) before the
 // products, so  SSE = G_shift - S S^T / N  has no catastrophic cancellation (S = shifted column sums).
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hpp"
@@ -201,6 +204,25 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(GramArgs a) {
 // or at a multiple of 512 B the compiler fuses reads of neighbouring k-steps into ds_read2[st64]_b64, which run at half the
 // rate (8 cycles per KiB, 32-bank mapping).
 // ------------------------------------------------------------------------------------------------------------------
+// Wave priority for kernels that run ONE long-lived block per resident slot with the same work in each: a SIMD issues by
+// priority, then AGE, so at equal priority the oldest wave's MFMAs go nearly unimpeded and the youngest gets the leftovers -
+// measured with in-kernel time stamps on gram_lds_kernel (2M x 64, loads off): the four blocks of a CU finished after 88,
+// 121, 155 and 178 us, the last stretch with one or two waves per SIMD, which cannot keep the matrix pipe busy.  A wave's
+// priority therefore rotates with its OWN chunk count offset by its slot: whoever holds the highest runs ahead one chunk and
+// drops to 0; no block leads by more than a few chunks and the blocks of a CU finish together (172-200 us after the change).
+__device__ __forceinline__ int wave_slot() {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(id));   // wave id within the SIMD = dispatch order
+    return (int)id;
+}
+__device__ __forceinline__ void rotate_priority(int k) {
+    switch (k & 3) {   // s_setprio takes an immediate
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 constexpr int GL_ROWS = 32;                         // rows per chunk
 constexpr int GL_KSTRIDE = 258;                     // doubles between k-steps in the LDS image: 4 groups x 64, + 16 B
 
@@ -274,7 +296,9 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
     int buf = 0;
     if (r < rb1) { load_chunk(r); store_chunk(r, 0); }
     __syncthreads();
+    int turn = wave_slot();
     for (; r < rb1; r += GL_ROWS) {
+        rotate_priority(turn++);
         const bool more = r + GL_ROWS < rb1;
         if (more) load_chunk(r + GL_ROWS);             // in flight under the MFMAs below
         const double* img = lds + buf * IMG + off0;
@@ -299,6 +323,7 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
         buf ^= 1;
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- block combine: one LDS image, the waves add into it in wave order 0, 1, 2, 3 (deterministic) -----------------
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -322,6 +347,266 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
     if (lactive && lrg == 0) out[NP * 256 + lcol] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gram_glds_kernel (double tables, contiguous rows): every WAVE streams its own rows through its own ring of LDS stages
+// filled by the LDS-DMA (global_load_lds_dwordx4) - no barrier in the loop, no register spent on the prefetch.
+// What the measurements on gram_lds_kernel said (2M x 64 fp64, profiles/r2/gram_floors.txt): (1) the shift / convert /
+// ds_write_b128 phase costs a quarter of the MFMA side (206 -> 158 us without it; 16-byte LDS stores move their data at
+// ~79 B/clk per CU, MI355X_MICROARCH.md "LDS"); (2) with one chunk in flight per block the loads alone take 185-215 us - the
+// memory side is latency-bound, not bandwidth-bound; (3) the blocks of a CU finish one after the other (rotate_priority
+// above); (4) an in-order wave that meets its VALU / scalar / branch work in one block between two MFMA bursts leaves the
+// matrix pipe idle for it: 92 cycles per MFMA for a wave alone on its SIMD, 83 with a second wave, against 64.
+// Here wave w of a block owns rows 16w .. 16w + 15 of each of the block's 64-row chunks: one 128-byte line of every column.
+// A stage is 2 NCT DMA instructions of 64 lanes x 16 B (8 KiB at 64 columns); operand lane (c = lane & 15, kq = lane >> 4)
+// reads row pairs kq and kq + 4 of column 16 I + c back with two ds_read_b128 per group: four k-steps per chunk, k-step
+// 2h + e contracting rows 16w + 8h + 2kq + e - the contraction does not care which rows share a k-step as long as every
+// column group agrees.  LDS is a register file extension: a ring of two stages per wave, filled two chunks ahead (a stage
+// is refilled as soon as its chunk sits in registers, one chunk before it is multiplied), 16 KiB in flight per wave,
+// 128 KiB per CU at two blocks - against 64 KiB with gram_lds_kernel's block-wide double buffer.  Own counted vmcnt is all
+// the ordering a wave needs for its own DMA (MI355X_MICROARCH.md, "Two waves per SIMD", item 7).  The pilot shift is
+// subtracted and the column sums are taken where the operands are read (4 NCT + 4 NCT DP instructions beside
+// 2 NCT (NCT + 1) MFMAs per chunk); the steady state is one branch-free block with that work and the DMA instructions
+// pinned between groups of NCT + 1 MFMAs.
+// Chunk j of block b is chunk j gridDim.x + b of the range, so at any moment the resident blocks read one contiguous
+// window of every column; only the range's very last chunk can be cut short, and its rows come through registers.
+// Measured (tools/gram_bench.py, 2M x 64): 190-200 us per launch against 224-237 for gram_lds_kernel on the same boxes; MFMAs
+// alone (PBN_GRAM_DEBUG=2) 165-172, DMA alone (=1) 172-185 = 5.5-5.9 TB/s.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// One LDS-DMA instruction as inline asm (recipe: cdna_hip_programming.md section 5.7): hipcc does not count an asm memory
+// operation, which is the point - with the builtin it drains the VMEM counter (vmcnt(0)) before the first use of any ds_read
+// result while a DMA may be pending, and the ring would never have more than its own latency in flight.  The waits are counted
+// by hand below (wait_vmcnt).  lds_dst: wave-uniform LDS byte address, the lanes land at lds_dst + 16 lane.
+__device__ __forceinline__ void glds16(const double* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int GD_STAGES = 2;          // ring depth per wave
+constexpr int GD_BLOCKS_PER_CU = 2;   // 64 KiB of rings per block at 64 columns
+constexpr int GD_ROWS = 64;           // rows per block chunk: 16 per wave = one 128-byte line of every column
+
+template <int NCT>
+struct TilePairs {   // pair p -> (I, J), I <= J, in the order the accumulators are numbered
+    int I[NPairs<NCT>::value], J[NPairs<NCT>::value];
+    constexpr TilePairs() : I{}, J{} {
+        int p = 0;
+        for (int i = 0; i < NCT; ++i)
+            for (int j = i; j < NCT; ++j) { I[p] = i; J[p] = j; ++p; }
+    }
+};
+
+// DBG (PBN_GRAM_DEBUG, measurement only): 1 = no MFMAs, 2 = no DMA (the statistics are garbage then)
+template <int NCT, int DBG>
+__global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_kernel(GramArgs a) {
+    constexpr int NP = NPairs<NCT>::value;
+    constexpr int NC = NCT * 16;
+    constexpr int WS = NP * 256 + NCT * 16;
+    constexpr int NQ = 2 * NCT;                 // DMA instructions (= 16-byte reads per lane) per stage
+    constexpr int STAGE = NQ * 128;             // doubles per stage: NQ instructions x 64 lanes x 16 B
+    constexpr int RING = GD_STAGES * STAGE;     // doubles per wave
+    constexpr int COMBINE = NP * 256 + 4 * NCT * 64;
+    constexpr int LDS_DOUBLES = 4 * RING > COMBINE ? 4 * RING : COMBINE;   // the rings, then the block combine
+    constexpr TilePairs<NCT> PAIRS{};
+    __shared__ double lds[LDS_DOUBLES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+    const int slot = wave_slot();
+    const long long t_start = a.stamps ? wall_clock64() : 0;
+
+    const int64_t nchunks = (a.n + GD_ROWS - 1) / GD_ROWS, B = gridDim.x, b = blockIdx.x;
+    const int64_t mine = b < nchunks ? (nchunks - 1 - b) / B + 1 : 0;
+    const bool partial_last = mine > 0 && ((mine - 1) * B + b + 1) * GD_ROWS > a.n;   // the range's last chunk, cut short
+    const int64_t nfull = mine - (partial_last ? 1 : 0);   // whole chunks (LDS-DMA); the cut one goes through registers
+
+    // operand role: lane (c, kq) holds column 16 I + c; shift, column sums
+    double sh[NCT], cs[NCT];
+    bool cvalid[NCT];
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) {
+        cvalid[I] = 16 * I + c < a.n_cols;
+        sh[I] = a.shift[cvalid[I] ? a.gc.cols[16 * I + c] : a.gc.cols[0]];
+        cs[I] = 0.0;
+    }
+    // DMA role: instruction q moves whole 128-byte lines - 16 rows of columns 8q .. 8q + 7, eight ADJACENT lanes per line
+    // (the texture addresser merges neighbouring lanes; with the operand layout's lanes c, c + 16, c + 32, c + 48 on one
+    // segment every lane was a request of its own).  Lane l fetches row pair m = (l & 7) ^ r, r = (column & 15) >> 1, of
+    // column 8q + (l >> 3); operand lane (c, kq) finds row pair m of its column in slot 8 (c & 7) + (m ^ (c >> 1)) of
+    // instruction 2I + (c >> 3) - the XOR spreads the 16 lanes of every ds_read_b128 group over all 64 banks.
+    const double* dsrc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int cc = 8 * q + (lane >> 3);
+        const int col = cc < a.n_cols ? a.gc.cols[cc] : a.gc.cols[0];
+        const int m = (lane & 7) ^ ((cc & 15) >> 1);
+        dsrc[q] = (const double*)a.base + (int64_t)col * a.ld + a.row0 + b * GD_ROWS + 16 * wave + 2 * m;
+    }
+    // doubles from a stage's start to this lane's row pairs kq (rows 2kq, +1) and kq + 4 (rows 8 + 2kq, +1) of group 0
+    const int rd0 = (c >> 3) * 128 + ((c & 7) * 8 + (kq ^ (c >> 1))) * 2, rd1 = (c >> 3) * 128 + ((c & 7) * 8 + ((kq + 4) ^ (c >> 1))) * 2;
+    // the shifts must be IN before the first DMA: an empty asm that reads them makes hipcc place its own wait here - left to
+    // itself it waits at their first use inside the loop, on every trip, and its vmcnt(0) there drains the DMA ring
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) asm volatile("" : "+v"(sh[I]));
+    d4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0, 0, 0, 0};
+
+    double* ring = lds + wave * RING;
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_ptr)ring);   // LDS byte address
+    auto dma1 = [&](int64_t i, int st, int q) {   // instruction q of chunk i of the block into stage st
+        if (DBG >= 2) return;
+        glds16(dsrc[q] + i * B * GD_ROWS, ring_addr + (st * STAGE + q * 128) * 8);
+    };
+    auto read_stage = [&](int st, d2v (&x2)[NQ]) {   // x2[2I + h]: rows 8h + 2kq, + 1 of column 16 I + c
+#pragma unroll
+        for (int I = 0; I < NCT; ++I) {
+            x2[2 * I] = *(const d2v*)(ring + st * STAGE + I * 256 + rd0);
+            x2[2 * I + 1] = *(const d2v*)(ring + st * STAGE + I * 256 + rd1);
+        }
+    };
+    // operands of read q of a stage (k-steps 2 (q & 1), + 1 of group q >> 1): subtract the shift, zero the columns past n_cols
+    // (only the last group can hold any), column sums.  k-steps: rows 16w + {0,2,4,6}, {1,3,5,7}, {8,..,14}, {9,..,15}
+    auto prepare1 = [&](const d2v (&x2)[NQ], double (&x)[4][NCT], int q) {
+        const int I = q >> 1, h = q & 1;
+        double lo = x2[q][0] - sh[I], hi = x2[q][1] - sh[I];
+        if (I == NCT - 1) {
+            lo = cvalid[I] ? lo : 0.0;
+            hi = cvalid[I] ? hi : 0.0;
+        }
+        x[2 * h][I] = lo;
+        x[2 * h + 1][I] = hi;
+        cs[I] += lo + hi;
+    };
+    auto mfma1 = [&](const double (&x)[4][NCT], int m) {   // MFMA m of a stage's 4 NP: k-step m / NP, tile pair m % NP
+        if (DBG == 1) return;
+        const int k = m / NP, p = m % NP;
+        acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[k][PAIRS.I[p]], x[k][PAIRS.J[p]], acc[p], 0, 0, 0);
+    };
+    // One chunk of the steady state, branch-free: chunk i is multiplied out of registers (xc) while chunk i + 1 is read from its
+    // stage st, the stage is refilled with chunk i + 3 (chunk i + 2 is in flight in the other stage) and chunk i + 1's
+    // operands (xn) are prepared.  The 4 NP MFMAs are cut into NQ groups of NCT + 1, each followed by one DMA instruction and
+    // the preparation of one 16-byte read - pinned in that order (sched_barrier), so that everything but the DP
+    // additions issues while an MFMA runs: an in-order wave that meets its VALU / scalar / branch work in one block between two
+    // MFMA bursts leaves the matrix pipe idle for it (measured: 92 cycles per MFMA alone on a SIMD, 83 with a second wave).
+    auto steady = [&](int64_t i, int st, const double (&xc)[4][NCT], double (&xn)[4][NCT]) {
+        wait_vmcnt<NQ>();   // chunk i + 1 has landed; chunk i + 2 may stay in flight
+        d2v x2[NQ];
+        read_stage(st, x2);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int e = 0; e < NCT + 1; ++e) mfma1(xc, q * (NCT + 1) + e);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // chunk i + 1 is in registers: its stage can be refilled
+            dma1(i + 1 + GD_STAGES, st, q);
+            prepare1(x2, xn, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    double xa[4][NCT], xb[4][NCT];
+    for (int i = 0; i < GD_STAGES && i < nfull; ++i)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dma1(i, i, q);
+    if (nfull > 0) {
+        if (nfull > 1) wait_vmcnt<NQ>(); else wait_vmcnt<0>();
+        d2v x2[NQ];
+        read_stage(0, x2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (GD_STAGES < nfull)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dma1(GD_STAGES, 0, q);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) prepare1(x2, xa, q);
+    }
+    int64_t i = 0;
+    for (; i + 4 < nfull; i += 2) {   // both chunks of a trip have a chunk i + 3 to prefetch
+        rotate_priority((int)(i >> 1) + slot);
+        steady(i, 1, xa, xb);
+        steady(i + 1, 0, xb, xa);
+    }
+    for (; i < nfull; ++i) {   // the last chunks: the same steps with their conditions
+        const int st = (int)(i + 1) & 1;   // stage of chunk i + 1
+        const bool more = i + 1 < nfull;
+        d2v x2[NQ];
+        if (more) {
+            if (i + 2 < nfull) wait_vmcnt<NQ>(); else wait_vmcnt<0>();
+            read_stage(st, x2);
+        }
+#pragma unroll
+        for (int m = 0; m < 4 * NP; ++m) mfma1(xa, m);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i + 1 + GD_STAGES < nfull)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) dma1(i + 1 + GD_STAGES, st, q);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) prepare1(x2, xb, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int I = 0; I < NCT; ++I) xa[k][I] = xb[k][I];
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (partial_last) {   // rows past the range read as the shift: x - shift = 0 exactly
+        const int64_t r = (nfull * B + b) * GD_ROWS + 16 * wave + 2 * kq, left = a.n - r;   // this lane's first row; rows from it on
+        d2v x2[NQ];
+#pragma unroll
+        for (int I = 0; I < NCT; ++I) {
+            const double* p = (const double*)a.base + (int64_t)(cvalid[I] ? a.gc.cols[16 * I + c] : a.gc.cols[0]) * a.ld + a.row0 + r;
+            x2[2 * I][0] = left > 0 ? p[0] : sh[I];
+            x2[2 * I][1] = left > 1 ? p[1] : sh[I];
+            x2[2 * I + 1][0] = left > 8 ? p[8] : sh[I];
+            x2[2 * I + 1][1] = left > 9 ? p[9] : sh[I];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) prepare1(x2, xa, q);
+#pragma unroll
+        for (int m = 0; m < 4 * NP; ++m) mfma1(xa, m);
+    }
+    __syncthreads();   // every wave is done with its ring
+
+    // ---- block combine: the waves add their tiles in wave order; the column sums go through LDS per (wave, group, lane) -----
+    double* lcs = lds + NP * 256;
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) lcs[(wave * NCT + I) * 64 + lane] = cs[I];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = p * 256 + e4 * 64 + lane;
+                    lds[e] = (w == 0) ? acc[p][e4] : lds[e] + acc[p][e4];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
+    if (tid < NC) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < 4; ++k) s += lcs[(w * NCT + (tid >> 4)) * 64 + k * 16 + (tid & 15)];
+        out[NP * 256 + tid] = s;
+    }
+    if (a.stamps && tid == 0) {   // PBN_GRAM_STAMPS: start, end (10 ns ticks) and hardware slot of every block
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        a.stamps[blockIdx.x * 3] = t_start; a.stamps[blockIdx.x * 3 + 1] = wall_clock64(); a.stamps[blockIdx.x * 3 + 2] = hwid;
+    }
+}
+
 // Sum the block partials (deterministic): stage 1 sums groups of 16 consecutive blocks in place into the first
 // block of each group (grid.y = groups), stage 2 sums the group leaders in group order.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ partial, int nblocks, int WS, int stride,
@@ -337,15 +622,37 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ p
     if (out) out[e] = v; else partial[(int64_t)b0 * WS + e] = v;
 }
 
-static bool gram_uses_lds() {
-    static const bool v = [] { const char* e = getenv("PBN_GRAM_LDS"); return !(e && *e) || atoi(e) != 0; }();
+// PBN_GRAM_LDS: 0 = gram_kernel (rows in registers), 1 = gram_lds_kernel, 2 (default) = gram_glds_kernel where it applies
+// (double table, contiguous rows) and gram_lds_kernel elsewhere.
+static int gram_variant() {
+    static const int v = [] { const char* e = getenv("PBN_GRAM_LDS"); return (e && *e) ? atoi(e) : 2; }();
     return v;
 }
 
+// launches the partial-sum kernel; returns the number of blocks (= partials) it used (<= nblocks)
 template <typename T, bool GATHER>
-static void launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st) {
+static int launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st) {
     dim3 grid(nblocks), block(256);
-    if (gram_uses_lds()) {
+    if constexpr (sizeof(T) == 8 && !GATHER) {
+        if (gram_variant() >= 2) {
+            if (a.num_cus > 0 && nblocks > GD_BLOCKS_PER_CU * a.num_cus) grid.x = GD_BLOCKS_PER_CU * a.num_cus;   // one block per slot
+            const int dbg = a.debug_skip == 1 ? 1 : a.debug_skip >= 2 ? 2 : 0;
+#define PBN_GLDS(N)                                                                                     \
+    case N:                                                                                             \
+        if (dbg == 0) hipLaunchKernelGGL((gram_glds_kernel<N, 0>), grid, block, 0, st, a);             \
+        else if (dbg == 1) hipLaunchKernelGGL((gram_glds_kernel<N, 1>), grid, block, 0, st, a);        \
+        else hipLaunchKernelGGL((gram_glds_kernel<N, 2>), grid, block, 0, st, a);                       \
+        break;
+            switch (nct) {
+                PBN_GLDS(1) PBN_GLDS(2) PBN_GLDS(3) PBN_GLDS(4)
+                default: throw invalid_error("gram: at most 64 columns per launch");
+            }
+#undef PBN_GLDS
+            HIP_CHECK(hipGetLastError());
+            return (int)grid.x;
+        }
+    }
+    if (gram_variant() >= 1) {
         switch (nct) {
             case 1: hipLaunchKernelGGL((gram_lds_kernel<T, 1, GATHER>), grid, block, 0, st, a); break;
             case 2: hipLaunchKernelGGL((gram_lds_kernel<T, 2, GATHER>), grid, block, 0, st, a); break;
@@ -354,7 +661,7 @@ static void launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t s
             default: throw invalid_error("gram: at most 64 columns per launch");
         }
         HIP_CHECK(hipGetLastError());
-        return;
+        return nblocks;
     }
     switch (nct) {
         case 1: hipLaunchKernelGGL((gram_kernel<T, 1, GATHER>), grid, block, 0, st, a); break;
@@ -364,6 +671,7 @@ static void launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t s
         default: throw invalid_error("gram: at most 64 columns per launch");
     }
     HIP_CHECK(hipGetLastError());
+    return nblocks;
 }
 
 int gram_ws(int nct) { return nct * (nct + 1) / 2 * 256 + nct * 16; }
@@ -381,14 +689,18 @@ void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipS
     GramArgs a = a_in;
     static const int dbg = [] { const char* e = getenv("PBN_GRAM_DEBUG"); return (e && *e) ? atoi(e) : 0; }();
     a.debug_skip = dbg;
+    // PBN_GRAM_STAMPS=1: gram_glds_kernel's blocks record their start / end (10 ns ticks) and hardware slot; printed to stderr
+    static const bool want_stamps = [] { const char* e = getenv("PBN_GRAM_STAMPS"); return e && *e && atoi(e) != 0; }();
+    static long long* stamps_dev = nullptr;
+    if (want_stamps && !stamps_dev) HIP_CHECK(hipMalloc(&stamps_dev, 4096 * 3 * sizeof(long long)));
+    a.stamps = want_stamps && nblocks <= 4096 ? stamps_dev : nullptr;
     const int nct = (a.n_cols + 15) / 16;
     const int WS = gram_ws(nct);
     const bool gather = a.rows != nullptr;
-    if (dtype == PBN_F64) {
-        if (gather) launch_gram_t<double, true>(a, nct, nblocks, st); else launch_gram_t<double, false>(a, nct, nblocks, st);
-    } else {
-        if (gather) launch_gram_t<float, true>(a, nct, nblocks, st); else launch_gram_t<float, false>(a, nct, nblocks, st);
-    }
+    if (dtype == PBN_F64)
+        nblocks = gather ? launch_gram_t<double, true>(a, nct, nblocks, st) : launch_gram_t<double, false>(a, nct, nblocks, st);
+    else
+        nblocks = gather ? launch_gram_t<float, true>(a, nct, nblocks, st) : launch_gram_t<float, false>(a, nct, nblocks, st);
     // tree of arity 16 over the blocks, fixed order
     int stride = 1;
     while ((nblocks + stride - 1) / stride > 16) {
@@ -398,6 +710,16 @@ void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipS
     }
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((WS + 255) / 256, 1), dim3(256), 0, st, a.partial, nblocks, WS, stride, out);
     HIP_CHECK(hipGetLastError());
+    if (a.stamps && dtype == PBN_F64 && !gather && gram_variant() >= 2) {
+        std::vector<long long> h((size_t)nblocks * 3);
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpy(h.data(), stamps_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long long t0 = h[0];
+        for (int b = 0; b < nblocks; ++b) t0 = std::min(t0, h[(size_t)b * 3]);
+        fprintf(stderr, "GRAM_STAMPS %d blocks: block start end hw_id\n", nblocks);
+        for (int b = 0; b < nblocks; ++b)
+            fprintf(stderr, "S %d %lld %lld %llx\n", b, h[(size_t)b * 3] - t0, h[(size_t)b * 3 + 1] - t0, h[(size_t)b * 3 + 2]);
+    }
 }
 
 // ---- LinearGaussianCPD logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149), one streaming pass:

@@ -21,6 +21,8 @@ struct GramArgs {
     int64_t rows_per_block;
     const double* shift;  // device, pilot means indexed by TABLE column id
     double* partial;      // device, [nblocks][gram_ws(nct)]
+    int num_cus;          // of the device (0 = unknown): gram_glds_kernel runs one block per resident slot
+    long long* stamps;    // measurement aid (PBN_GRAM_STAMPS): per-block start / end / hardware slot, or null
     int debug_skip;       // measurement aid (PBN_GRAM_DEBUG): 1 = no MFMAs (loads + LDS traffic only), 2 = no global loads
 };
 

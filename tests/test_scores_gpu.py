@@ -512,3 +512,28 @@ def test_pruned_sweeps_match_unpruned(pbn, dtype, rel):
             os.environ.pop("PBN_SWEEP_PRUNE", None)
     for off, on in zip(values["0"], values["1"]):
         assert np.isfinite(off) and on == pytest.approx(off, rel=rel)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("d", [1, 7, 16, 17, 32, 40, 48, 49, 64])
+def test_device_table_sse_shapes_and_offsets(pbn, d, dtype):
+    """DataFrame::means / ::sse (dataset.hpp:208-234, 340-512) from the device Gram over row ranges that start at odd rows, end
+    inside a 32-row chunk, or hold fewer rows than one chunk - every column-tile count (1-4 tiles of 16) of the Gram kernels
+    (LDS-DMA for double tables, register staging for float ones), with a large mean so that the pilot shift matters."""
+    rng = np.random.default_rng(100 + d)
+    n = 70001
+    data = (rng.normal(size=(n, d)) @ (np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1)).T + 1000.0).astype(dtype)
+    names = [f"x{i}" for i in range(d)]
+    table, _ = pbn.DeviceTable.from_dataframe(pbn.default_context(), pd.DataFrame(data, columns=names), names)
+    cols = [names[i] for i in rng.permutation(d)]
+    idx = [names.index(c) for c in cols]
+    for row0, rows in [(0, n), (1, n - 1), (3, 65536), (4097, 31), (12345, 33), (7, 1), (100, 20000 + d)]:
+        x = data[row0:row0 + rows][:, idx].astype(np.float64)
+        want_mean = x.mean(axis=0)
+        c = x - want_mean
+        want = c.T @ c
+        means, sse = table.sse(cols, row0, rows)
+        tol = 1e-10 if dtype == "float64" else 1e-9
+        assert np.allclose(means, want_mean, rtol=tol, atol=0), (row0, rows)
+        scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1.0
+        assert np.max(np.abs(sse - want) / scale) <= 1e-9, (row0, rows, np.max(np.abs(sse - want) / scale))

@@ -2,6 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=${1:-gram_prof}
+rm -rf $R/gpurun_out/$OUT
 mkdir -p $R/gpurun_out/$OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$OUT -- python3 $R/tools/gram_bench.py > $R/gpurun_out/$OUT.log 2>&1
 cd $R
