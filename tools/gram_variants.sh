@@ -2,6 +2,6 @@
 # rings, gram_glds_kernel), 1 (register-staged block-wide LDS image, gram_lds_kernel), 0 (rows in registers, gram_kernel), the
 # default kernel's floors (PBN_GRAM_DEBUG 1 = no MFMAs, 2 = no DMA) and the float table (gram_lds_kernel<float>).
 # Usage (GPU box): bash tools/gram_variants.sh
-for v in 2 1 0; do echo "== PBN_GRAM_LDS=$v"; PBN_GRAM_LDS=$v bash tools/gram_timing.sh gram_v$v | grep "gram_[a-z]*_*kernel"; done
-for d in 1 2; do echo "== PBN_GRAM_LDS=2 PBN_GRAM_DEBUG=$d"; PBN_GRAM_DEBUG=$d bash tools/gram_timing.sh gram_v2d$d | grep "gram_glds"; done
-echo "== float table"; GRAM_DTYPE=f32 bash tools/gram_timing.sh gram_f32 | grep "gram_lds"
+for v in 2 1 0; do echo "== PBN_GRAM_LDS=$v"; PBN_GRAM_LDS=$v bash tools/gram_timing.sh gram_v$v | grep "gram_[a-z]*_*kernel\|per call"; done
+for d in 1 2; do echo "== PBN_GRAM_LDS=2 PBN_GRAM_DEBUG=$d"; PBN_GRAM_DEBUG=$d bash tools/gram_timing.sh gram_v2d$d | grep "gram_glds\|per call"; done
+echo "== float table"; GRAM_DTYPE=f32 bash tools/gram_timing.sh gram_f32 | grep "gram_lds\|per call"
