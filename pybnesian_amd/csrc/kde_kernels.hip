@@ -26,6 +26,7 @@
 #include "kde_kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace pbn {
 
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void tile_box_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __restrict__ zq_row, const int32_t* __restrict__ qperm, int64_t nq,
                                                             const uint32_t* __restrict__ qkeys, const double* __restrict__ zt,
                                                             const uint32_t* __restrict__ tkeys, int64_t n, int zd, int pd,
-                                                            double* __restrict__ qbox, double* __restrict__ qthr,
+                                                            double* __restrict__ qbox, double* __restrict__ qthr, double* __restrict__ qlb,
                                                             const double* __restrict__ subpart, int P, int which, double log2_nsub) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = q < nq;
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
             best = lb > best ? lb : best;
         }
     }
+    if (qlb && q < (nq + 15) / 16 * 16) qlb[q] = valid ? best : -INFINITY;   // per query: the sweep's starting offset
     // reduce over the 16 lanes of a query tile
     double thr = valid ? best : INFINITY;
     double lob[3], hib[3];
@@ -551,6 +553,40 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         }
     }
 
+    // Pruned plain sweeps: the prepass knows a lower bound of every query's largest exponent over ALL training rows (its
+    // Morton neighbours, the subsample sweep).  Where that bound lies above the first tile's maximum it becomes the offset: the
+    // first tile of a Morton-ordered split is typically thousands of exponent units away from the queries, so the first
+    // VISITED tile used to overflow 2^x and take the redo path once per (group, split); with the bound as the offset no term
+    // can exceed it by more than the bound's slack (log2 of the subsample size, or the distance to the best Morton
+    // neighbour), and the blind passes below never trip.  Such an offset has no term of this split behind it: an empty sum
+    // stays empty (the query's largest term is never pruned, so the split that holds it has a positive sum).
+    // (fused CKDE sweeps: the bound is the JOINT one, which also bounds the marginal maximum from below.)
+    bool lbm[QG], lbmj[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) lbm[g] = lbmj[g] = false;
+    if constexpr (PRUNE) {
+        if (a.qlb) {
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+                const T lb = __builtin_ceil((T)a.qlb[qt * 16 + (lane & 15)]);
+                // (a bound too large for T to hold to a fraction of a unit is not used: see kde_sweep_bf16_kernel)
+                const bool fin = (lb < (T)0 ? -lb : lb) < (sizeof(T) == 8 ? (T)0x1p50 : (T)0x1p22);
+                lbm[g] = fin && lb > m[g];
+                if (lbm[g]) {
+                    m[g] = lb;
+                    cm[g] = ny[g] - lb + Tr<T>::bias();
+                }
+                if (FOLD || WMUL) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
+                if (COND) {
+                    lbmj[g] = fin && lb > mj[g];
+                    if (lbmj[g]) mj[g] = lb;
+                    bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
+                }
+            }
+        }
+    }
+
     // ---- main loop over training tiles: two tiles per iteration with ping-pong fragment buffers (no
     // register copies); the fragments of tile t+1 / t+2 are in flight while tile t is processed -------------
     auto load_tile = [&](int64_t t, T (&f)[KS], V& n, T& x) {
@@ -616,24 +652,61 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
     T afA[KS], afB[KS];
     V nxA, nxB;
     T axA = 0, axB = 0;
+    // blind accumulation (see "Unchecked passes" below): no overflow test, no separate add
+    auto process_fast = [&](const T (&af)[KS], const V& nx) {
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            V acc;
+            if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+            const T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
+            if (WMUL) sum[g] = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], __builtin_fma(e0, nx[0], sum[g]))));
+            else sum[g] += (e0 + e1) + (e2 + e3);
+        }
+    };
     if constexpr (PRUNE) {
         // 64 tiles per visit mask; inside a batch the kept tiles are processed two at a time with ping-pong fragment buffers
-        for (int64_t tb = t0; tb < t1; tb += 64) {
-            unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
-            if (!mask) continue;
+        auto run_batch = [&](int64_t tb, unsigned long long mask, auto blind) {
+            constexpr bool BLIND = decltype(blind)::value;
             int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             load_tile(tb + b, afA, nxA, axA);
             for (;;) {
                 int b2 = -1;
                 if (mask) { b2 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b2, afB, nxB, axB); }
-                process_tile(tb + b, afA, nxA, axA);
+                if constexpr (BLIND) process_fast(afA, nxA); else process_tile(tb + b, afA, nxA, axA);
                 if (b2 < 0) break;
                 int b3 = -1;
                 if (mask) { b3 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b3, afA, nxA, axA); }
-                process_tile(tb + b2, afB, nxB, axB);
+                if constexpr (BLIND) process_fast(afB, nxB); else process_tile(tb + b2, afB, nxB, axB);
                 if (b3 < 0) break;
                 b = b3;
+            }
+        };
+        // fp64 plain sweeps take a batch blind first (the offsets start from the prepass bounds: an overflow needs a term 896
+        // exponent units above its query's bound) and redo it with the checked loop from the saved sums if a sum went bad
+        constexpr bool FASTP = PBN_SWEEP_UNCHECKED && !COND && sizeof(T) == 8 && (FOLD || KS == 1);   // the shapes that stay <= 168 VGPRs
+        for (int64_t tb = t0; tb < t1; tb += 64) {
+            const unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            if (!mask) continue;
+            if constexpr (FASTP) {
+                double saved[QG];
+#pragma unroll
+                for (int g = 0; g < QG; ++g) saved[g] = sum[g];
+                run_batch(tb, mask, std::true_type{});
+                bool bad = false;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
+                const bool redo = __any(bad);
+                if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo) atomicAdd(&g_sweep_redo, 1ull); }
+                if (redo) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) sum[g] = saved[g];
+                    run_batch(tb, mask, std::false_type{});
+                }
+            } else {
+                run_batch(tb, mask, std::false_type{});
             }
         }
     } else {
@@ -661,18 +734,6 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         if constexpr (FAST) {
             constexpr int CH = 32;
             __shared__ double sumsave[QG][256];
-            auto process_fast = [&](const T (&af)[KS], const V& nx) {
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    V acc;
-                    if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
-                    const T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
-                    if (WMUL) sum[g] = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], __builtin_fma(e0, nx[0], sum[g]))));
-                    else sum[g] += (e0 + e1) + (e2 + e3);
-                }
-            };
             for (int64_t tc = t0; tc < t1; tc += CH) {
                 const int64_t te = tc + CH < t1 ? tc + CH : t1;
 #pragma unroll
@@ -718,8 +779,8 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         // an empty sum still holds the term its offset came from (see kde_sweep_bf16_kernel; 2^bias is that term here)
         // (only when the offset is a real exponent: a NaN / infinite offset - NaN queries, an all-padding split - keeps its sum)
         const bool mfin = (m[g] - m[g]) == (T)0;
-        if (s == 0.0 && mfin) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
-        if (COND && sj == 0.0 && (mj[g] - mj[g]) == (T)0) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        if (s == 0.0 && mfin && !lbm[g]) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        if (COND && sj == 0.0 && (mj[g] - mj[g]) == (T)0 && !lbmj[g]) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (lg == 0 && qt0 + g < a.nqtiles) {
             double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g] - (double)Tr<T>::bias();   // the sums carry 2^bias
@@ -1077,6 +1138,34 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
         }
     }
 
+    // pruned sweeps: offsets from the prepass bounds where they lie above the first tile's maximum (see kde_sweep_kernel)
+    bool lbm[QG], lbmj[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) lbm[g] = lbmj[g] = false;
+    if constexpr (PRUNE) {
+        if (a.qlb) {
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+                const float lb = (float)a.qlb[qt * 16 + (lane & 15)];
+                // a bound so large that fp32 cannot hold it to a fraction of a unit (a query ~2000 bandwidths out) is not used:
+                // the first tile's offset comes with a term that is known to survive the rounding, the bound does not
+                const bool fin = __builtin_fabsf(lb) < 0x1p22f;
+                lbm[g] = fin && lb > m[g];
+                if (lbm[g]) {
+                    m[g] = lb;
+                    const float cm = ny[g] - lb;
+                    cmv[g] = V{cm, cm, cm, cm};
+                }
+                if (COND) {
+                    lbmj[g] = fin && lb > mj[g];
+                    if (lbmj[g]) mj[g] = lb;
+                    set_bx(g);
+                }
+            }
+        }
+    }
+
     // Plain unpruned sweeps (the else branch): all groups' MFMAs are issued before the first exponential so that the matrix pipe works under the
     // VALU's exponentials, one overflow test per tile, the rare path redoes a group (C2 fp32: 15.2 -> 14.1 ms).  The
     // fused CKDE sweep and the pruned sweeps keep the group-by-group form: with two accumulator sets per group in flight,
@@ -1229,8 +1318,9 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
         // rounding (ulp(|e|) >> 1: queries ~10^6 bandwidths away) makes the second evaluation of that tile underflow, the
         // sum can come out empty although it holds at least the offset's own term: count that term.  (A split whose tiles
         // were all pruned gets the same term: below 2^-64 of the query's sum by the pruning rule.)
-        if (s == 0.0 && (m[g] - m[g]) == 0.f) s = 1.0;
-        if (COND && sj == 0.0 && (mj[g] - mj[g]) == 0.f) sj = 1.0;
+        // (not when the offset is a prepass bound: no term of this split stands behind it, an empty sum is empty)
+        if (s == 0.0 && (m[g] - m[g]) == 0.f && !lbm[g]) s = 1.0;
+        if (COND && sj == 0.0 && (mj[g] - mj[g]) == 0.f && !lbmj[g]) sj = 1.0;
         if (lg == 0 && qt0 + g < a.nqtiles) {
             double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g];
@@ -1657,11 +1747,11 @@ void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int z
     HIP_CHECK(hipGetLastError());
 }
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
-                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st,
+                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
                           const double* subpart, int P, int which, double log2_nsub) {
     if (nq == 0) return;
     hipLaunchKernelGGL(query_prepass_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, zq_row, qperm, nq, qkeys_sorted, ztrain_sorted,
-                       tkeys_sorted, n, zd, pd, qbox, qthr, subpart, P, which, log2_nsub);
+                       tkeys_sorted, n, zd, pd, qbox, qthr, qlb, subpart, P, which, log2_nsub);
     HIP_CHECK(hipGetLastError());
 }
 

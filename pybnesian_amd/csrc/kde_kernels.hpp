@@ -68,6 +68,7 @@ struct SweepArgs {
     const double* tile_box;    // [ntiles][2 * pdims]: lo..., hi...
     const double* qtile_box;   // [nqtiles][2 * pdims]
     const double* qtile_thr;   // [nqtiles]
+    const double* qlb;         // [nqtiles * 16] per (sorted) query: lower bound of its largest exponent, -inf = none; nullable
     double* part;  // [nsplit][nqtiles*16][P]
     double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
     int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
@@ -112,7 +113,7 @@ void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int z
 // P doubles per query, the pair to use at [which]: offset + log2(sum) - log2(nsub) is a second lower bound of the query's
 // largest exponent
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
-                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, hipStream_t st,
+                          const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
                           const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);

@@ -279,15 +279,19 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     pa.fold_norm = fold ? 1 : 0;
     const double* qbox = nullptr;
     const double* qthr = nullptr;
+    const double* qlb = nullptr;
     const int32_t* qperm = nullptr;
     PruneSide qs{};
     if (m.prune) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         const size_t qbox_b = al((size_t)nqtiles * 2 * m.pdims * sizeof(double)), qthr_b = al((size_t)nqtiles * sizeof(double));
-        qs = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b);
+        const size_t qlb_b = al((size_t)nqtiles * 16 * sizeof(double));
+        qs = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b + qlb_b);
         pa.perm = qs.perm;
         qperm = qs.perm;
         qbox = (double*)qs.rest; qthr = (double*)(qs.rest + qbox_b);
+        static const bool use_qlb = env_int("PBN_SWEEP_QLB", 1) != 0;   // offsets of the pruned plain sweeps from the prepass bounds
+        if (use_qlb) qlb = (double*)(qs.rest + qbox_b + qthr_b);
     }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
     pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
@@ -310,7 +314,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
             { KernelTimer kt(ctx, PBN_K_PACK); launch_sweep(ss, m.dtype, m.KS, m.cond, 1, ctx->stream); }
             subpart = ss.part;
         }
-        launch_query_prepass(qs.zrow, qs.perm, n, qs.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, (double*)qbox, (double*)qthr,
+        launch_query_prepass(qs.zrow, qs.perm, n, qs.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, (double*)qbox, (double*)qthr, (double*)qlb,
                              ctx->stream, subpart, P, m.cond ? 2 : 0, subpart ? std::log2((double)m.nsub) : 0.0);
     }
 
@@ -336,7 +340,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.fold = fold ? 1 : 0;
     sa.wmul = wmul ? 1 : 0;
     sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(m.dtype); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr;
+    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(m.dtype); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
