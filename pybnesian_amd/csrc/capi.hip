@@ -58,6 +58,7 @@ void pbn_ctx_destroy(pbn_ctx* ctx) {
     ctx->scratch_misc.release();
     ctx->scratch_red.release();
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->alt.stream) { (void)hipStreamSynchronize(ctx->alt.stream); (void)hipStreamDestroy(ctx->alt.stream); (void)hipEventDestroy(ctx->alt.fence); }
     delete ctx;
 }
 

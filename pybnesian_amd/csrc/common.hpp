@@ -8,6 +8,7 @@
 //   PBN_ERR_DEVICE         HIP failure            -> RuntimeError
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 
 #include <cstdarg>
 #include <cstdint>
@@ -132,6 +133,33 @@ struct pbn_ctx {
     pbn::dev_buf<char> scratch_pruneq; // ... of the query side
     pbn::dev_buf<char> scratch_sort;   // radix sort temporaries
     pbn::dev_buf<double> scratch_split; // CKDE handles evaluated as two plain sweeps: joint / marginal logl or sums
+    // Second issue lane (score engine): independent evaluations are enqueued alternately on `stream` and on `alt.stream`, each
+    // with its own scratch, so that the tail of one sweep - the last workgroups of a pruned sweep run 2-3 ms with the slots
+    // emptying - overlaps the next evaluation's sorts, packs and the head of its sweep.  swap_lane() exchanges the active
+    // resources with the parked ones; every routine keeps using ctx->stream / ctx->scratch_*.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        pbn::dev_buf<char> part, q, misc, train, prune, pruneq, sort;
+        pbn::dev_buf<double> red, split;
+        hipEvent_t fence = nullptr;
+    } alt;
+    void ensure_alt() {
+        if (!alt.stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&alt.fence, hipEventDisableTiming));
+        }
+    }
+    void swap_lane() {
+        std::swap(stream, alt.stream);
+        std::swap(scratch_part, alt.part); std::swap(scratch_q, alt.q); std::swap(scratch_misc, alt.misc);
+        std::swap(scratch_train, alt.train); std::swap(scratch_prune, alt.prune); std::swap(scratch_pruneq, alt.pruneq);
+        std::swap(scratch_sort, alt.sort); std::swap(scratch_red, alt.red); std::swap(scratch_split, alt.split);
+    }
+    // the parked lane waits for everything enqueued so far on the active one (e.g. the zeroing of a result buffer)
+    void alt_waits_for_stream() {
+        HIP_CHECK(hipEventRecord(alt.fence, stream));
+        HIP_CHECK(hipStreamWaitEvent(alt.stream, alt.fence, 0));
+    }
     // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
     bool profiling = false;
     struct Timed { hipEvent_t e0, e1; int which; };

@@ -188,6 +188,9 @@ struct Tr<float> {
 #define PBN_PAD_NORM (-1e30)
 // measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
+__device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
+__device__ unsigned long long g_sweep_cyc[4] = {0, 0, 0, 0};
+__device__ unsigned long long g_sweep_hist[128];   // TEMP: wave-ticks (10 ns) active per 2^14-tick bin, modulo 128   // TEMP: wave cycles total / in mask building / in batches / prologue   // pruned fp64 sweeps: tiles visited / tiles in the split, per wave
 #ifndef PBN_SWEEP_UNCHECKED
 #define PBN_SWEEP_UNCHECKED 1   // fp64 plain unpruned sweeps: blind first pass, checked redo (kde_sweep_kernel)
 #endif
@@ -458,17 +461,25 @@ __device__ __forceinline__ unsigned long long prune_visit_mask(const double* __r
 // far-out query next to a far-out training row): 2^x' = inf (times w = 0: NaN) fails the per-tile test `ts < big`, and the
 // rare path redoes the tile the classic way (norms added to the accumulator).  Rows with -1/2|z|^2 < -1000, whose weight
 // would lose bits or underflow, carry w = NaN and always take that path.
+// Pruned sweeps run ONE wave per workgroup: the kept tiles differ from wave to wave (each has its own query box), and a
+// 4-wave workgroup holds its slots until its slowest wave is done - measured at 0.67-0.77 of the unpruned rate per visited
+// tile at d = 2, 3 whatever the number of splits (tools/prune_visits.py); nothing in the kernel is shared between waves.
+constexpr int sweep_block_threads(bool prune) { return prune ? 64 : 256; }
+
 template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
-__global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kernel(SweepArgs a) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
+    constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // waves per workgroup
+    const long long c_kernel0 = clock64();
+    const long long w_kernel0 = wall_clock64();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
     if (PRUNE) { qx = blockIdx.x; split = blockIdx.y; }   // pruned work per split is uneven: keep every XCD on every split
     else xcd_block(qx, split);
-    const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
+    const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;  // no barriers in this kernel: idle waves just leave
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
@@ -687,9 +698,16 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
         // fp64 plain sweeps take a batch blind first (the offsets start from the prepass bounds: an overflow needs a term 896
         // exponent units above its query's bound) and redo it with the checked loop from the saved sums if a sum went bad
         constexpr bool FASTP = PBN_SWEEP_UNCHECKED && !COND && sizeof(T) == 8 && (FOLD || KS == 1);   // the shapes that stay <= 168 VGPRs
+        if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
+        long long c_mask = 0, c_batch = 0;
+        const long long c_loop0 = clock64();
         for (int64_t tb = t0; tb < t1; tb += 64) {
+            const long long c0_ = clock64();
             const unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            const long long c1_ = clock64();
+            c_mask += c1_ - c0_;
             if (!mask) continue;
+            if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
             if constexpr (FASTP) {
                 double saved[QG];
 #pragma unroll
@@ -707,6 +725,18 @@ __global__ __launch_bounds__(256, 2) void kde_sweep_kernel(SweepArgs a) {
                 }
             } else {
                 run_batch(tb, mask, std::false_type{});
+            }
+            c_batch += clock64() - c1_;
+        }
+        if (a.count_redo && lane == 0) {
+            atomicAdd(&g_sweep_cyc[0], (unsigned long long)(clock64() - c_loop0));
+            atomicAdd(&g_sweep_cyc[1], (unsigned long long)c_mask);
+            atomicAdd(&g_sweep_cyc[2], (unsigned long long)c_batch);
+            atomicAdd(&g_sweep_cyc[3], (unsigned long long)(c_loop0 - c_kernel0));
+            const long long w1 = wall_clock64();
+            for (long long bn = w_kernel0 >> 14; bn <= (w1 >> 14); ++bn) {
+                const long long lo = bn << 14 > w_kernel0 ? bn << 14 : w_kernel0, hi = ((bn + 1) << 14) < w1 ? ((bn + 1) << 14) : w1;
+                if (hi > lo) atomicAdd(&g_sweep_hist[bn & 127], (unsigned long long)(hi - lo));
             }
         }
     } else {
@@ -1692,6 +1722,8 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
     if (a.prune) {   // fp64, at most 5 marginal dimensions (KS <= 2)
         if constexpr (sizeof(T) == 8) {
             constexpr int QGP = COND ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;   // query groups per wave of the pruned kernels
+            block = dim3(sweep_block_threads(true));
+            grid.x = (unsigned)ceil_div(a.nqtiles, QGP);   // one wave per workgroup
             if constexpr (!COND && !FOLD) {
                 if (a.wmul && KS <= 2) {   // 4 / 8 marginal dimensions: the pruned shapes without a free K slot
                     if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QGP, false, true, true>), grid, block, 0, st, a);
@@ -1855,4 +1887,21 @@ extern "C" void pbn_debug_sweep_redo(unsigned long long* redo, unsigned long lon
     if (redo) (void)hipMemcpyFromSymbol(redo, HIP_SYMBOL(pbn::g_sweep_redo), sizeof z);
     if (units) (void)hipMemcpyFromSymbol(units, HIP_SYMBOL(pbn::g_sweep_units), sizeof z);
     if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_redo), &z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_units), &z, sizeof z); }
+}
+// measurement aid like the above: tiles visited / tiles offered to the waves of the pruned fp64 sweeps since the last reset
+extern "C" void pbn_debug_sweep_hist(unsigned long long* out, int reset) {
+    unsigned long long z[128] = {};
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pbn::g_sweep_hist), sizeof z);
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_hist), z, sizeof z);
+}
+extern "C" void pbn_debug_sweep_cyc(unsigned long long* out, int reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pbn::g_sweep_cyc), sizeof z);
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_cyc), z, sizeof z);
+}
+extern "C" void pbn_debug_sweep_visits(unsigned long long* visited, unsigned long long* tiles, int reset) {
+    unsigned long long z = 0;
+    if (visited) (void)hipMemcpyFromSymbol(visited, HIP_SYMBOL(pbn::g_sweep_visit), sizeof z);
+    if (tiles) (void)hipMemcpyFromSymbol(tiles, HIP_SYMBOL(pbn::g_sweep_tiles), sizeof z);
+    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_visit), &z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_tiles), &z, sizeof z); }
 }
