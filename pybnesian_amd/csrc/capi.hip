@@ -58,7 +58,8 @@ void pbn_ctx_destroy(pbn_ctx* ctx) {
     ctx->scratch_misc.release();
     ctx->scratch_red.release();
     (void)hipStreamDestroy(ctx->stream);
-    if (ctx->alt.stream) { (void)hipStreamSynchronize(ctx->alt.stream); (void)hipStreamDestroy(ctx->alt.stream); (void)hipEventDestroy(ctx->alt.fence); }
+    for (auto& ln : ctx->parked)
+        if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); (void)hipEventDestroy(ln.fence); }
     delete ctx;
 }
 

@@ -8,6 +8,7 @@
 //   PBN_ERR_DEVICE         HIP failure            -> RuntimeError
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <utility>
 
 #include <cstdarg>
@@ -133,32 +134,42 @@ struct pbn_ctx {
     pbn::dev_buf<char> scratch_pruneq; // ... of the query side
     pbn::dev_buf<char> scratch_sort;   // radix sort temporaries
     pbn::dev_buf<double> scratch_split; // CKDE handles evaluated as two plain sweeps: joint / marginal logl or sums
-    // Second issue lane (score engine): independent evaluations are enqueued alternately on `stream` and on `alt.stream`, each
-    // with its own scratch, so that the tail of one sweep - the last workgroups of a pruned sweep run 2-3 ms with the slots
-    // emptying - overlaps the next evaluation's sorts, packs and the head of its sweep.  swap_lane() exchanges the active
-    // resources with the parked ones; every routine keeps using ctx->stream / ctx->scratch_*.
+    // Extra issue lanes (score engine): independent evaluations are enqueued round-robin on `stream` and on the parked lanes'
+    // streams, each with its own scratch, so that the tail of one sweep - the last workgroups of a pruned sweep run 2-3 ms
+    // with the slots emptying - overlaps the next evaluations' sorts, packs and sweeps.  swap_lane(k) exchanges the active
+    // resources with parked lane k; every routine keeps using ctx->stream / ctx->scratch_*.
     struct Lane {
         hipStream_t stream = nullptr;
         pbn::dev_buf<char> part, q, misc, train, prune, pruneq, sort;
         pbn::dev_buf<double> red, split;
         hipEvent_t fence = nullptr;
-    } alt;
-    void ensure_alt() {
-        if (!alt.stream) {
-            HIP_CHECK(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&alt.fence, hipEventDisableTiming));
-        }
+    };
+    static constexpr int MAX_PARKED = 3;
+    Lane parked[MAX_PARKED];
+    void ensure_lanes(int n_parked) {
+        for (int k = 0; k < n_parked && k < MAX_PARKED; ++k)
+            if (!parked[k].stream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&parked[k].stream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&parked[k].fence, hipEventDisableTiming));
+            }
     }
-    void swap_lane() {
+    void swap_lane(int k) {
+        Lane& alt = parked[k];
         std::swap(stream, alt.stream);
         std::swap(scratch_part, alt.part); std::swap(scratch_q, alt.q); std::swap(scratch_misc, alt.misc);
         std::swap(scratch_train, alt.train); std::swap(scratch_prune, alt.prune); std::swap(scratch_pruneq, alt.pruneq);
         std::swap(scratch_sort, alt.sort); std::swap(scratch_red, alt.red); std::swap(scratch_split, alt.split);
     }
-    // the parked lane waits for everything enqueued so far on the active one (e.g. the zeroing of a result buffer)
-    void alt_waits_for_stream() {
-        HIP_CHECK(hipEventRecord(alt.fence, stream));
-        HIP_CHECK(hipStreamWaitEvent(alt.stream, alt.fence, 0));
+    // the parked lanes wait for everything enqueued so far on the active one (e.g. the zeroing of a result buffer)
+    void lanes_wait_for_stream(int n_parked) {
+        for (int k = 0; k < n_parked && k < MAX_PARKED; ++k) {
+            HIP_CHECK(hipEventRecord(parked[k].fence, stream));
+            HIP_CHECK(hipStreamWaitEvent(parked[k].stream, parked[k].fence, 0));
+        }
+    }
+    void sync_lanes(int n_parked) {
+        for (int k = 0; k < n_parked && k < MAX_PARKED; ++k)
+            if (parked[k].stream) HIP_CHECK(hipStreamSynchronize(parked[k].stream));
     }
     // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
     bool profiling = false;
@@ -169,6 +180,25 @@ struct pbn_ctx {
 };
 
 namespace pbn {
+// PBN_SCORE_LANES (default 2, at most 4): issue lanes of the score engine's independent evaluations; 1 keeps everything on the
+// context's own stream
+inline int score_lanes() {
+    static const int v = [] {
+        const char* e = getenv("PBN_SCORE_LANES");
+        const int n = (e && *e) ? atoi(e) : 2;
+        return n < 1 ? 1 : (n > 1 + pbn_ctx::MAX_PARKED ? 1 + pbn_ctx::MAX_PARKED : n);
+    }();
+    return v;
+}
+// RAII: the enclosed enqueues go to lane `lane` (0 = the context's own, k > 0 = parked lane k - 1); the active lane is restored on
+// scope exit, also by a throw
+struct LaneSwitch {
+    pbn_ctx* ctx; int k;
+    LaneSwitch(pbn_ctx* c, int lane) : ctx(c), k(lane - 1) { if (k >= 0) ctx->swap_lane(k); }
+    ~LaneSwitch() { if (k >= 0) ctx->swap_lane(k); }
+    LaneSwitch(const LaneSwitch&) = delete;
+    LaneSwitch& operator=(const LaneSwitch&) = delete;
+};
 // RAII: brackets the launches issued during its lifetime with two events when profiling is on.
 struct KernelTimer {
     pbn_ctx* ctx; int which; hipEvent_t e0 = nullptr;

@@ -431,6 +431,10 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         dsums.alloc((size_t)units * g.nc * 2 + 1);
         HIP_CHECK(hipMemsetAsync(dsums.p, 0, ((size_t)units * g.nc * 2 + 1) * sizeof(double), ctx->stream));
     }
+    // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
+    const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes() : 1;
+    if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
+    size_t issued = 0;
     auto key_of = [&](int region, int c, const int* v, int nv) {
         std::vector<int> k(v, v + nv);
         std::sort(k.begin(), k.end());
@@ -498,6 +502,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 sl.marg.slot = (int)slot_key.size();
                 slot_key.push_back(key_of(u, c, cols.data() + 1, pc));
                 const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
+                LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + align(pb.axpack) + 256);
                 char* arena = ctx->scratch_train.p;
                 m.Apack = arena;
@@ -533,6 +538,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 term.slot = (int)slot_key.size();
                 slot_key.push_back(key);
                 const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, false, tr->N);
+                LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
                 char* arena = ctx->scratch_train.p;
                 m.Apack = arena;
@@ -548,6 +554,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     }
     if (node_type == PBN_NODE_CKDE && !slices.empty()) {
         std::vector<double> hs(std::max<size_t>(1, slot_key.size()));
+        if (lanes > 1) ctx->sync_lanes(lanes - 1);
         if (!slot_key.empty()) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, slot_key.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < slot_key.size(); ++i) sd->kde_cache[slot_key[i]] = hs[i];
@@ -557,6 +564,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             acc += jv - mv;
         }
     } else if (node_type == PBN_NODE_CKDE) {
+        if (lanes > 1) ctx->sync_lanes(lanes - 1);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     return acc;

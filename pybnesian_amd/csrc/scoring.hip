@@ -865,14 +865,11 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, nslots) * sizeof(double), ctx->stream));
             auto align = [](size_t x) { return (x + 255) / 256 * 256; };
             // independent evaluations alternate between the context's two issue lanes (common.hpp)
-            static const bool two_lanes_on = [] { const char* e = getenv("PBN_SCORE_LANES"); return !(e && *e) || atoi(e) >= 2; }();
-            const bool two_lanes = two_lanes_on && work.size() > 1 && !ctx->profiling;
-            if (two_lanes) { ctx->ensure_alt(); ctx->alt_waits_for_stream(); }
+            const int lanes = (work.size() > 1 && !ctx->profiling) ? score_lanes() : 1;
+            if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
             size_t wi = 0;
             for (const Work& w : work) {
-                const bool on_alt = two_lanes && (wi++ & 1);
-                if (on_alt) ctx->swap_lane();
-                struct Back { pbn_ctx* c; bool on; ~Back() { if (on) c->swap_lane(); } } back{ctx, on_alt};   // also when an evaluation throws
+                LaneSwitch lane(ctx, (int)(wi++ % (size_t)lanes));
                 const int c = w.cand;
                 const int p = par_off[c + 1] - par_off[c], d = p + 1;
                 cols.resize(d);
@@ -915,7 +912,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                     kde_eval_enqueue(ctx, m, t, use_cols, te0, te_n, nullptr, dsums.p + (w.mode == 2 ? w.slot_m : w.slot_j));
             }
             std::vector<double> hs(std::max<size_t>(1, nslots));
-            if (two_lanes) HIP_CHECK(hipStreamSynchronize(ctx->alt.stream));
+            if (lanes > 1) ctx->sync_lanes(lanes - 1);
             if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             for (size_t i = 0; i < nslots; ++i) sd->kde_cache[slot_key[i]] = hs[i];
