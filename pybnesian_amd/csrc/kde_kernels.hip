@@ -189,8 +189,7 @@ struct Tr<float> {
 // measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
 __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
-__device__ unsigned long long g_sweep_cyc[4] = {0, 0, 0, 0};
-__device__ unsigned long long g_sweep_hist[128];   // TEMP: wave-ticks (10 ns) active per 2^14-tick bin, modulo 128   // TEMP: wave cycles total / in mask building / in batches / prologue   // pruned fp64 sweeps: tiles visited / tiles in the split, per wave
+// (pruned fp64 sweeps: tiles visited / tiles offered, per wave)
 #ifndef PBN_SWEEP_UNCHECKED
 #define PBN_SWEEP_UNCHECKED 1   // fp64 plain unpruned sweeps: blind first pass, checked redo (kde_sweep_kernel)
 #endif
@@ -471,8 +470,6 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kerne
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // waves per workgroup
-    const long long c_kernel0 = clock64();
-    const long long w_kernel0 = wall_clock64();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
@@ -699,13 +696,8 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kerne
         // exponent units above its query's bound) and redo it with the checked loop from the saved sums if a sum went bad
         constexpr bool FASTP = PBN_SWEEP_UNCHECKED && !COND && sizeof(T) == 8 && (FOLD || KS == 1);   // the shapes that stay <= 168 VGPRs
         if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
-        long long c_mask = 0, c_batch = 0;
-        const long long c_loop0 = clock64();
         for (int64_t tb = t0; tb < t1; tb += 64) {
-            const long long c0_ = clock64();
             const unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
-            const long long c1_ = clock64();
-            c_mask += c1_ - c0_;
             if (!mask) continue;
             if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
             if constexpr (FASTP) {
@@ -725,18 +717,6 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kerne
                 }
             } else {
                 run_batch(tb, mask, std::false_type{});
-            }
-            c_batch += clock64() - c1_;
-        }
-        if (a.count_redo && lane == 0) {
-            atomicAdd(&g_sweep_cyc[0], (unsigned long long)(clock64() - c_loop0));
-            atomicAdd(&g_sweep_cyc[1], (unsigned long long)c_mask);
-            atomicAdd(&g_sweep_cyc[2], (unsigned long long)c_batch);
-            atomicAdd(&g_sweep_cyc[3], (unsigned long long)(c_loop0 - c_kernel0));
-            const long long w1 = wall_clock64();
-            for (long long bn = w_kernel0 >> 14; bn <= (w1 >> 14); ++bn) {
-                const long long lo = bn << 14 > w_kernel0 ? bn << 14 : w_kernel0, hi = ((bn + 1) << 14) < w1 ? ((bn + 1) << 14) : w1;
-                if (hi > lo) atomicAdd(&g_sweep_hist[bn & 127], (unsigned long long)(hi - lo));
             }
         }
     } else {
@@ -1889,16 +1869,7 @@ extern "C" void pbn_debug_sweep_redo(unsigned long long* redo, unsigned long lon
     if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_redo), &z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_units), &z, sizeof z); }
 }
 // measurement aid like the above: tiles visited / tiles offered to the waves of the pruned fp64 sweeps since the last reset
-extern "C" void pbn_debug_sweep_hist(unsigned long long* out, int reset) {
-    unsigned long long z[128] = {};
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pbn::g_sweep_hist), sizeof z);
-    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_hist), z, sizeof z);
-}
-extern "C" void pbn_debug_sweep_cyc(unsigned long long* out, int reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pbn::g_sweep_cyc), sizeof z);
-    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_sweep_cyc), z, sizeof z);
-}
+// measurement aid like the above: tiles visited / tiles offered to the waves of the pruned fp64 sweeps since the last reset
 extern "C" void pbn_debug_sweep_visits(unsigned long long* visited, unsigned long long* tiles, int reset) {
     unsigned long long z = 0;
     if (visited) (void)hipMemcpyFromSymbol(visited, HIP_SYMBOL(pbn::g_sweep_visit), sizeof z);

@@ -27,15 +27,7 @@ for d in (1, 2, 3, 4, 5):
         k.slogl(teb)
         lib.pbn_debug_sweep_visits(None, None, 1)
         lib.pbn_debug_sweep_redo(None, None, 1)
-        lib.pbn_debug_sweep_cyc(None, 1)
-        lib.pbn_debug_sweep_hist(None, 1)
         k.slogl(teb)
-        hist = (C.c_ulonglong * 128)()
-        lib.pbn_debug_sweep_hist(hist, 0)
-        if prune == "1": print("   active waves per 164 us bin:", " ".join(f"{h / 16384:.0f}" for h in hist if h))
-        cyc = (C.c_ulonglong * 4)()
-        lib.pbn_debug_sweep_cyc(cyc, 0)
-        if prune == "1": print("   wave cycles: loop", cyc[0], "mask", cyc[1], "batch", cyc[2], "prologue", cyc[3], " per visited tile:", cyc[2] / max(1, 1))
         v, t, r, u = (C.c_ulonglong(0) for _ in range(4))
         lib.pbn_debug_sweep_visits(C.byref(v), C.byref(t), 0)
         lib.pbn_debug_sweep_redo(C.byref(r), C.byref(u), 0)
