@@ -1053,14 +1053,15 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 }
 
 template <int NB, bool COND, int QG, bool PRUNE>
-__global__ __launch_bounds__(256, 2) void kde_sweep_bf16_kernel(SweepArgs a) {
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     using V = f4;
+    constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
     if (PRUNE) { qx = blockIdx.x; split = blockIdx.y; } else xcd_block(qx, split);
-    const int64_t qt0 = ((int64_t)qx * 4 + wave) * QG;
+    const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
@@ -1805,6 +1806,8 @@ template <bool COND>
 static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
     dim3 block(256);
     if (a.prune) {   // at most 5 marginal dimensions: 33 bf16 slots, two MFMAs
+        block = dim3(sweep_block_threads(true));
+        grid.x = (unsigned)ceil_div(a.nqtiles, 4);   // one wave (4 query groups) per workgroup
         if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, true>), grid, block, 0, st, a);
         else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, true>), grid, block, 0, st, a);
         else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
