@@ -396,8 +396,16 @@ static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols,
         double* lm = dev_logl ? ctx->scratch_split.p + per : nullptr;
         double* sj = dev_sum ? ctx->scratch_split.p + 2 * per : nullptr;
         double* sm = dev_sum ? sj + 1 : nullptr;
+        // the two sweeps are independent: the marginal one goes to the second issue lane, so that the joint sweep's tail (the
+        // last workgroups of a pruned sweep drain for 2-3 ms) runs under it; the difference waits for both on the device
+        const bool lanes = pbn::score_lanes() > 1 && !ctx->profiling;
+        if (lanes) { ctx->ensure_lanes(1); ctx->lanes_wait_for_stream(1); }
         pbn::kde_eval_enqueue(ctx, k->split_joint->m, test, cols, row0, n, lj, sj);
-        pbn::kde_eval_enqueue(ctx, k->split_marg->m, test, cols + 1, row0, n, lm, sm);
+        {
+            pbn::LaneSwitch lane(ctx, lanes ? 1 : 0);
+            pbn::kde_eval_enqueue(ctx, k->split_marg->m, test, cols + 1, row0, n, lm, sm);
+        }
+        if (lanes) ctx->stream_waits_for_lane(0);
         if (dev_logl) launch_diff(dev_logl, lj, lm, n, ctx->stream);
         if (dev_sum) launch_diff(dev_sum, sj, sm, 1, ctx->stream);
         return;

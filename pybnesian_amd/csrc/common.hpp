@@ -167,6 +167,11 @@ struct pbn_ctx {
             HIP_CHECK(hipStreamWaitEvent(parked[k].stream, parked[k].fence, 0));
         }
     }
+    // the active stream waits for everything enqueued so far on parked lane k (device-side join, no host wait)
+    void stream_waits_for_lane(int k) {
+        HIP_CHECK(hipEventRecord(parked[k].fence, parked[k].stream));
+        HIP_CHECK(hipStreamWaitEvent(stream, parked[k].fence, 0));
+    }
     void sync_lanes(int n_parked) {
         for (int k = 0; k < n_parked && k < MAX_PARKED; ++k)
             if (parked[k].stream) HIP_CHECK(hipStreamSynchronize(parked[k].stream));
