@@ -464,6 +464,16 @@ __device__ __forceinline__ unsigned long long prune_visit_mask(const double* __r
 // 4-wave workgroup holds its slots until its slowest wave is done - measured at 0.67-0.77 of the unpruned rate per visited
 // tile at d = 2, 3 whatever the number of splits (tools/prune_visits.py); nothing in the kernel is shared between waves.
 constexpr int sweep_block_threads(bool prune) { return prune ? 64 : 256; }
+// The grid of a pruned sweep is one-dimensional and split-major (the workgroups in flight share a split's fragments in L2),
+// with the splits taken from both ends of the Morton order inwards: the corner splits - sparse regions, where a query's
+// whole neighbourhood lies in its own split and the workgroup visits nearly all of its tiles - start first.  Pure placement.
+// (Measured and dropped: every query group's nearest splits first - all splits in flight at once, the L2 sharing is gone.)
+__device__ __forceinline__ void pruned_block(const SweepArgs& a, int groups_per_block, int& qx, int& split) {
+    const unsigned Gq = (unsigned)((a.nqtiles + groups_per_block - 1) / groups_per_block), Gs = (unsigned)a.nsplit_grid;
+    const unsigned b = blockIdx.x, k = b / Gq;
+    qx = (int)(b % Gq);
+    split = (k & 1u) ? (int)(Gs - 1 - (k >> 1)) : (int)(k >> 1);
+}
 
 template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
 __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kernel(SweepArgs a) {
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kerne
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    if (PRUNE) { qx = blockIdx.x; split = blockIdx.y; }   // pruned work per split is uneven: keep every XCD on every split
+    if (PRUNE) pruned_block(a, WPB * QG, qx, split);
     else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;  // no barriers in this kernel: idle waves just leave
@@ -1060,7 +1070,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_bf16_
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    if (PRUNE) { qx = blockIdx.x; split = blockIdx.y; } else xcd_block(qx, split);
+    if (PRUNE) pruned_block(a, WPB * QG, qx, split); else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
@@ -1704,7 +1714,7 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
         if constexpr (sizeof(T) == 8) {
             constexpr int QGP = COND ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;   // query groups per wave of the pruned kernels
             block = dim3(sweep_block_threads(true));
-            grid.x = (unsigned)ceil_div(a.nqtiles, QGP);   // one wave per workgroup
+            grid = dim3((unsigned)(ceil_div(a.nqtiles, QGP) * a.nsplit_grid));   // one wave per workgroup, placed by pruned_block
             if constexpr (!COND && !FOLD) {
                 if (a.wmul && KS <= 2) {   // 4 / 8 marginal dimensions: the pruned shapes without a free K slot
                     if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QGP, false, true, true>), grid, block, 0, st, a);
@@ -1807,7 +1817,7 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
     dim3 block(256);
     if (a.prune) {   // at most 5 marginal dimensions: 33 bf16 slots, two MFMAs
         block = dim3(sweep_block_threads(true));
-        grid.x = (unsigned)ceil_div(a.nqtiles, 4);   // one wave (4 query groups) per workgroup
+        grid = dim3((unsigned)(ceil_div(a.nqtiles, 4) * a.nsplit_grid));   // one wave (4 query groups) per workgroup, placed by pruned_block
         if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, true>), grid, block, 0, st, a);
         else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, true>), grid, block, 0, st, a);
         else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
@@ -1824,7 +1834,9 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
+void launch_sweep(const SweepArgs& a_in, int dtype, int KS, bool cond, int nsplit, hipStream_t st) {
+    SweepArgs a = a_in;
+    a.nsplit_grid = nsplit;
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond, KS, a.prune != 0)), (unsigned)nsplit);
     if (use_bf16x3(dtype)) {  // KS carries the number of bf16 MFMAs
         if (cond) launch_sweep_bf16<true>(a, KS, grid, st); else launch_sweep_bf16<false>(a, KS, grid, st);

@@ -69,6 +69,7 @@ struct SweepArgs {
     const double* qtile_box;   // [nqtiles][2 * pdims]
     const double* qtile_thr;   // [nqtiles]
     const double* qlb;         // [nqtiles * 16] per (sorted) query: lower bound of its largest exponent, -inf = none; nullable
+    int nsplit_grid;           // pruned sweeps: number of splits (their grid is one-dimensional; launch_sweep sets this)
     double* part;  // [nsplit][nqtiles*16][P]
     double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
     int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
