@@ -237,9 +237,10 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar
     const int c = lane & 15, kq = lane >> 4;
 
-    const int64_t rb0 = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t rb0 = (int64_t)blockIdx.x * a.rows_per_block;
     int64_t rb1 = rb0 + a.rows_per_block;
     if (rb1 > a.n) rb1 = a.n;
+    if (a.blk) { rb0 = a.blk[4 * blockIdx.x + 1]; rb1 = a.blk[4 * blockIdx.x + 2]; }   // a piece of one segment (launch_gram_segments)
 
     // loader role: thread t -> column t >> 2 (of the first NC columns), rows (t & 3) * 8 .. + 7 of the chunk
     const int lcol = tid >> 2, lrg = tid & 3;
@@ -622,6 +623,16 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ p
     if (out) out[e] = v; else partial[(int64_t)b0 * WS + e] = v;
 }
 
+// one thread per (segment, element): the segment's block partials in block order
+__global__ __launch_bounds__(256) void gram_seg_reduce_kernel(const double* __restrict__ partial, const int32_t* __restrict__ blk_off, int WS,
+                                                               double* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (e >= WS) return;
+    double v = 0.0;
+    for (int b = blk_off[g]; b < blk_off[g + 1]; ++b) v += partial[(size_t)b * WS + e];
+    out[(size_t)g * WS + e] = v;
+}
+
 // PBN_GRAM_LDS: 0 = gram_kernel (rows in registers), 1 = gram_lds_kernel, 2 (default) = gram_glds_kernel where it applies
 // (double table, contiguous rows) and gram_lds_kernel elsewhere.
 static int gram_variant() {
@@ -720,6 +731,33 @@ void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipS
         for (int b = 0; b < nblocks; ++b)
             fprintf(stderr, "S %d %lld %lld %llx\n", b, h[(size_t)b * 3] - t0, h[(size_t)b * 3 + 1] - t0, h[(size_t)b * 3 + 2]);
     }
+}
+
+void launch_gram_segments(const GramArgs& a_in, int dtype, int nblocks, const int32_t* blk_off, int n_seg, double* out, hipStream_t st) {
+    GramArgs a = a_in;
+    a.debug_skip = 0; a.stamps = nullptr;
+    if (!a.blk) throw invalid_error("gram: the segmented form needs a block table");
+    const int nct = (a.n_cols + 15) / 16;
+    const int WS = gram_ws(nct);
+    if (nblocks > 0) {
+        const bool gather = a.rows != nullptr;
+        const dim3 grid(nblocks), block(256);
+#define PBN_SEG(T, N, GA) hipLaunchKernelGGL((gram_lds_kernel<T, N, GA>), grid, block, 0, st, a)
+#define PBN_SEG_N(T, GA)                                                                        \
+    switch (nct) {                                                                              \
+        case 1: PBN_SEG(T, 1, GA); break;                                                       \
+        case 2: PBN_SEG(T, 2, GA); break;                                                       \
+        case 3: PBN_SEG(T, 3, GA); break;                                                       \
+        case 4: PBN_SEG(T, 4, GA); break;                                                       \
+        default: throw invalid_error("gram: at most 64 columns per launch");                    \
+    }
+        if (dtype == PBN_F64) { if (gather) { PBN_SEG_N(double, true) } else { PBN_SEG_N(double, false) } }
+        else { if (gather) { PBN_SEG_N(float, true) } else { PBN_SEG_N(float, false) } }
+#undef PBN_SEG_N
+#undef PBN_SEG
+    }
+    if (n_seg > 0) hipLaunchKernelGGL(gram_seg_reduce_kernel, dim3((WS + 255) / 256, n_seg), dim3(256), 0, st, a.partial, blk_off, WS, out);
+    HIP_CHECK(hipGetLastError());
 }
 
 // ---- LinearGaussianCPD logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149), one streaming pass:

@@ -19,6 +19,8 @@ struct GramArgs {
     const int32_t* rows;  // device gather list or null
     int64_t n;            // number of rows
     int64_t rows_per_block;
+    const int32_t* blk;   // nullable device block table [nblocks][4] = (segment, first position, end position, unused): block b
+                          // takes positions [blk[4b+1], blk[4b+2]) of the row list instead of its rows_per_block share (launch_gram_segments)
     const double* shift;  // device, pilot means indexed by TABLE column id
     double* partial;      // device, [nblocks][gram_ws(nct)]
     int num_cus;          // of the device (0 = unknown): gram_glds_kernel runs one block per resident slot
@@ -46,6 +48,10 @@ int gram_ws(int nct);  // doubles per partial: nct(nct+1)/2 tiles of 256 + nct*1
 void launch_pilot(const void* base, int64_t ld, const GramCols& gc, int n_cols, int64_t row0, const int32_t* rows,
                   int64_t n, int dtype, double* shift, hipStream_t st);
 void launch_gram(const GramArgs& a, int dtype, int nblocks, double* out, hipStream_t st);
+// Segmented form: the rows (a.rows: a gather list, or null = the table's own order) are cut into segments, the blocks of the
+// table a.blk each cover a piece of one segment, and out receives one partial layout (gram_ws doubles) PER SEGMENT: segment g
+// is the sum of blocks blk_off[g] .. blk_off[g + 1] - 1 (blk_off: device, [n_seg + 1]) in block order.  a.partial: [nblocks][gram_ws].
+void launch_gram_segments(const GramArgs& a, int dtype, int nblocks, const int32_t* blk_off, int n_seg, double* out, hipStream_t st);
 void launch_take(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* rows, int64_t n,
                  int n_cols, int dtype, hipStream_t st);
 
