@@ -1,0 +1,66 @@
+"""GPU tier: the run-time switches that select between implementations of the same quantity must not change it.  Each
+configuration runs tests/switch_worker_gpu.py in its own process (the switches are read once per process) and the outputs are
+compared with the default run:
+ * PBN_SCORE_LANES=1 (one issue lane) - the sums do not depend on the issue order: identical to the last bit;
+ * PBN_SWEEP_QLB=0 (offsets from the split's first tile instead of the prepass bounds) and PBN_SWEEP_PRUNE=0 (no tile
+   pruning) - other offsets / other partitions of the same sums: equal to rounding, the fp32 sweeps to their own precision;
+ * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_THREADS=1;
+ * PBN_GRAM_LDS=1 / 0 (the older Gram kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "switch_worker_gpu.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.fixture(scope="module")
+def default():
+    return run({})
+
+
+def close(a, b, rtol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.allclose(a, b, rtol=rtol, atol=rtol, equal_nan=True)
+
+
+def test_one_issue_lane_is_bit_identical(default):
+    got = run({"PBN_SCORE_LANES": "1"})
+    assert got == default
+
+
+@pytest.mark.parametrize("env", [{"PBN_SWEEP_QLB": "0"}, {"PBN_SWEEP_PRUNE": "0"}])
+def test_sweep_switches(default, env):
+    got = run(env)
+    assert close(got["cv_ckde_float64"], default["cv_ckde_float64"], 1e-10)
+    assert close(got["cv_ckde_float32"], default["cv_ckde_float32"], 1e-4)
+    assert got["hc_arcs_float64"] == default["hc_arcs_float64"]
+    assert got["hc_arcs_float32"] == default["hc_arcs_float32"]
+
+
+@pytest.mark.parametrize("env", [{"PBN_MI_FULLGRAM": "0"}, {"PBN_MI_THREADS": "1"}])
+def test_mi_switches(default, env):
+    got = run(env)
+    for key in ("mi_plain", "mi_nulls"):
+        assert close(got[key], default[key], 1e-9), key
+
+
+@pytest.mark.parametrize("variant", ["1", "0"])
+def test_gram_kernel_variants(default, variant):
+    got = run({"PBN_GRAM_LDS": variant})
+    assert close(got["bic"], default["bic"], 1e-11)
+    assert close(got["mi_plain"], default["mi_plain"], 1e-9)
