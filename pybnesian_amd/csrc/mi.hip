@@ -76,6 +76,7 @@ struct pbn_mi {
     dev_buf<char> sort_tmp;
     dev_buf<double> shift_dev;   // the pilot means on the device, indexed by table column (Engine::ensure_full)
     int64_t full_grams = 0;      // groupings whose full per-configuration moments were taken
+    size_t full_bytes_held = 0;  // host bytes of the cached full moments
     // PBN_MI_TIMING=1: wall seconds per phase, printed when the handle is destroyed
     double t_group = 0, t_device = 0, t_host = 0, t_prep = 0;
     int64_t batches = 0;
@@ -565,8 +566,14 @@ struct Engine {
         static const bool v = [] { const char* e = getenv("PBN_MI_FULLGRAM"); return !(e && *e) || atoi(e) != 0; }();
         return v;
     }
+    // host bytes of a grouping's full moments; all cached groupings together stay below PBN_MI_FULL_BUDGET_MB (default 1024) -
+    // beyond it (thousands of configurations x dozens of columns x hundreds of groupings) later groupings use the per-test kernels
+    size_t full_bytes(const DiscGroup& g) const { return (size_t)g.G * h->n_cont * (h->n_cont + 1) * sizeof(double); }
     bool full_applies(const DiscGroup& g) const {
-        return full_gram_on() && h->table && h->n_cont >= 1 && h->n_cont <= 64 && g.G <= 4096 && g.nblk > 0;
+        if (!(full_gram_on() && h->table && h->n_cont >= 1 && h->n_cont <= 64 && g.G <= 4096 && g.nblk > 0)) return false;
+        if (g.full_ready) return true;
+        static const size_t budget = [] { const char* e = getenv("PBN_MI_FULL_BUDGET_MB"); return (size_t)((e && *e) ? atoll(e) : 1024) << 20; }();
+        return h->full_bytes_held + full_bytes(g) <= budget;
     }
     void ensure_full(DiscGroup& g) {
         if (g.full_ready) return;
@@ -613,6 +620,7 @@ struct Engine {
                 }
         }
         g.full_ready = true;
+        h->full_bytes_held += full_bytes(g);
         ++h->full_grams;
         ++h->device_launches;
         h->t_device += mi_now() - td0;
@@ -704,6 +712,7 @@ struct Engine {
             auto lru = h->groups.begin();
             for (auto it = h->groups.begin(); it != h->groups.end(); ++it)
                 if (it->second->stamp < lru->second->stamp) lru = it;
+            if (lru->second->full_ready) h->full_bytes_held -= std::min(h->full_bytes_held, full_bytes(*lru->second));
             h->groups.erase(lru);
         }
         std::vector<Plan> legacy;

@@ -4,7 +4,8 @@ compared with the default run:
  * PBN_SCORE_LANES=1 (one issue lane) - the sums do not depend on the issue order: identical to the last bit;
  * PBN_SWEEP_QLB=0 (offsets from the split's first tile instead of the prepass bounds) and PBN_SWEEP_PRUNE=0 (no tile
    pruning) - other offsets / other partitions of the same sums: equal to rounding, the fp32 sweeps to their own precision;
- * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_THREADS=1;
+ * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_FULL_BUDGET_MB=0 (their cache
+   budget exhausted: the same fallback), PBN_MI_THREADS=1;
  * PBN_GRAM_LDS=1 / 0 (the older Gram kernels)."""
 import json
 import os
@@ -52,7 +53,7 @@ def test_sweep_switches(default, env):
     assert got["hc_arcs_float32"] == default["hc_arcs_float32"]
 
 
-@pytest.mark.parametrize("env", [{"PBN_MI_FULLGRAM": "0"}, {"PBN_MI_THREADS": "1"}])
+@pytest.mark.parametrize("env", [{"PBN_MI_FULLGRAM": "0"}, {"PBN_MI_THREADS": "1"}, {"PBN_MI_FULL_BUDGET_MB": "0"}])
 def test_mi_switches(default, env):
     got = run(env)
     for key in ("mi_plain", "mi_nulls"):
