@@ -327,10 +327,10 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     const int64_t tile_bytes = b3 ? (int64_t)m.KS * 64 * 16 + (m.cond ? 64 * 16 : 0)
                                   : ((int64_t)m.KS * 64 + 16 + (m.cond ? 64 : 0)) * (int64_t)es;
     nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles * tile_bytes, (int64_t)env_int("PBN_SWEEP_SPLIT_KB", 2048) * 1024));
-    // pruned fp32 sweeps: a workgroup of the queries' own neighbourhood visits most tiles of its split, and at the fp32 rate the
-    // sweep is so short that those long workgroups are its tail - at most 1024 tiles per split (1e6 x 1e5 handles: -7 %; the
-    // score engine's slices are below that anyway; the fp64 sweeps, 3.7x longer per tile, lose more to the extra splits than they gain)
-    if (m.prune && b3) nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles, (int64_t)env_int("PBN_PRUNE_F32_MAX_TILES", 1024)));
+    // pruned sweeps: a workgroup of the queries' own neighbourhood visits most tiles of its split, and those long workgroups are
+    // the sweep's tail - at most PBN_PRUNE_MAX_TILES tiles per split (1e6 x 1e5 handles: fp64 -5...9 %, fp32 -7 %; the score
+    // engine's slices are below that anyway - splitting THEM four times finer costs C5 12 %)
+    if (m.prune) nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles, (int64_t)env_int("PBN_PRUNE_MAX_TILES", 1024)));
     if (nsplit > 1) nsplit = ceil_div(nsplit, 8) * 8;
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));
     nsplit = std::min<int64_t>(nsplit, 4096);
