@@ -1,8 +1,8 @@
 """What the tile pruning of the fp64 sweeps leaves to do, and what the kernel makes of it: fraction of (wave, training tile)
-pairs visited (PBN_SWEEP_COUNT_REDO counters), time of the pruned slogl, and the time the unpruned sweep would need for
-the visited fraction alone (its rate x the fraction) - 1e6 x 1e5 rows, KDE d = 1..5.  python tools/prune_visits.py"""
+pairs visited (one call with the PBN_SWEEP_COUNT_REDO counters on), time of the pruned slogl WITH THE COUNTERS OFF (their
+per-batch atomics cost time that grows with the number of workgroups), and the time the unpruned sweep would need for the
+visited fraction alone (its rate x the fraction) - 1e6 x 1e5 rows, KDE d = 1..5.  python tools/prune_visits.py"""
 import ctypes as C, os, sys, time
-os.environ["PBN_SWEEP_COUNT_REDO"] = "1"
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pyarrow as pa
@@ -27,7 +27,9 @@ for d in (1, 2, 3, 4, 5):
         k.slogl(teb)
         lib.pbn_debug_sweep_visits(None, None, 1)
         lib.pbn_debug_sweep_redo(None, None, 1)
+        os.environ["PBN_SWEEP_COUNT_REDO"] = "1"   # read per call (kde_model.hip env_int)
         k.slogl(teb)
+        os.environ["PBN_SWEEP_COUNT_REDO"] = "0"
         v, t, r, u = (C.c_ulonglong(0) for _ in range(4))
         lib.pbn_debug_sweep_visits(C.byref(v), C.byref(t), 0)
         lib.pbn_debug_sweep_redo(C.byref(r), C.byref(u), 0)
