@@ -381,7 +381,7 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 // operation, which is the point - with the builtin it drains the VMEM counter (vmcnt(0)) before the first use of any ds_read
 // result while a DMA may be pending, and the ring would never have more than its own latency in flight.  The waits are counted
 // by hand below (wait_vmcnt).  lds_dst: wave-uniform LDS byte address, the lanes land at lds_dst + 16 lane.
-__device__ __forceinline__ void glds16(const double* gsrc, unsigned lds_dst) {
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -623,6 +623,195 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ p
     if (out) out[e] = v; else partial[(int64_t)b0 * WS + e] = v;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gram_glds_f32_kernel: the same ring for FLOAT tables.  16 bytes are four rows, so wave w owns rows 32w .. 32w + 31 of each
+// 128-row block chunk (again one 128-byte line of every column), a stage is 2 NCT DMA instructions = eight k-steps; operand lane
+// (c, kq) reads row quads kq and kq + 4 of column 16 I + c (k-step 4h + e contracts rows 32w + 16h + 4kq + e).  The floats stay
+// raw in registers - this chunk's and the next one's - and are widened and shifted k-step by k-step, right before the k-step's
+// MFMAs (NCT conversions, subtractions and column-sum additions beside NCT (NCT + 1) / 2 MFMAs), with one DMA instruction pinned
+// behind each of the first 2 NCT k-steps.  Half the bytes of the double table: the MFMA side is what bounds it.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int GF_ROWS = 128;   // rows per block chunk of the float ring: 32 per wave
+
+template <int NCT, int DBG>
+__global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(GramArgs a) {
+    constexpr int NP = NPairs<NCT>::value;
+    constexpr int NC = NCT * 16;
+    constexpr int WS = NP * 256 + NCT * 16;
+    constexpr int NQ = 2 * NCT;                 // DMA instructions (= 16-byte reads per lane) per stage
+    constexpr int STAGE = NQ * 256;             // floats per stage
+    constexpr int RING = GD_STAGES * STAGE;     // floats per wave
+    constexpr int COMBINE = NP * 256 + 4 * NCT * 64;   // doubles
+    constexpr int LDS_DOUBLES = 4 * RING / 2 > COMBINE ? 4 * RING / 2 : COMBINE;
+    constexpr TilePairs<NCT> PAIRS{};
+    __shared__ double lds[LDS_DOUBLES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+    const int slot = wave_slot();
+    const long long t_start = a.stamps ? wall_clock64() : 0;
+
+    const int64_t nchunks = (a.n + GF_ROWS - 1) / GF_ROWS, B = gridDim.x, b = blockIdx.x;
+    const int64_t mine = b < nchunks ? (nchunks - 1 - b) / B + 1 : 0;
+    const bool partial_last = mine > 0 && ((mine - 1) * B + b + 1) * GF_ROWS > a.n;
+    const int64_t nfull = mine - (partial_last ? 1 : 0);
+
+    double sh[NCT], cs[NCT];
+    bool cvalid[NCT];
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) {
+        cvalid[I] = 16 * I + c < a.n_cols;
+        sh[I] = a.shift[cvalid[I] ? a.gc.cols[16 * I + c] : a.gc.cols[0]];
+        cs[I] = 0.0;
+    }
+    // DMA role (see gram_glds_kernel): instruction q moves 32 rows of columns 8q .. 8q + 7, eight adjacent lanes per line; lane l
+    // fetches row quad m = (l & 7) ^ r, r = (column & 15) >> 1
+    const float* dsrc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int cc = 8 * q + (lane >> 3);
+        const int col = cc < a.n_cols ? a.gc.cols[cc] : a.gc.cols[0];
+        const int m = (lane & 7) ^ ((cc & 15) >> 1);
+        dsrc[q] = (const float*)a.base + (int64_t)col * a.ld + a.row0 + b * GF_ROWS + 32 * wave + 4 * m;
+    }
+    // floats from a stage's start to this lane's row quads kq and kq + 4 of group 0
+    const int rd0 = (c >> 3) * 256 + ((c & 7) * 8 + (kq ^ (c >> 1))) * 4, rd1 = (c >> 3) * 256 + ((c & 7) * 8 + ((kq + 4) ^ (c >> 1))) * 4;
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) asm volatile("" : "+v"(sh[I]));   // the shifts are in before the first DMA (see gram_glds_kernel)
+    d4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0, 0, 0, 0};
+
+    float* ring = (float*)lds + wave * RING;
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_ptr)ring);
+    auto dma1 = [&](int64_t i, int st, int q) {
+        if (DBG >= 2) return;
+        glds16(dsrc[q] + i * B * GF_ROWS, ring_addr + (st * STAGE + q * 256) * 4);
+    };
+    auto read_stage = [&](int st, f4v (&raw)[NQ]) {   // raw[2I + h][e]: row 16h + 4kq + e of column 16 I + c
+#pragma unroll
+        for (int I = 0; I < NCT; ++I) {
+            raw[2 * I] = *(const f4v*)(ring + st * STAGE + I * 512 + rd0);
+            raw[2 * I + 1] = *(const f4v*)(ring + st * STAGE + I * 512 + rd1);
+        }
+    };
+    // k-step k = 4h + e of a chunk: widen, shift, zero the columns past n_cols, column sums, the tile pairs' MFMAs
+    auto kstep = [&](const f4v (&raw)[NQ], int k) {
+        const int h = k >> 2, e = k & 3;
+        double x[NCT];
+#pragma unroll
+        for (int I = 0; I < NCT; ++I) {
+            x[I] = (double)raw[2 * I + h][e] - sh[I];
+            if (I == NCT - 1) x[I] = cvalid[I] ? x[I] : 0.0;
+            cs[I] += x[I];
+        }
+        if (DBG == 1) return;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[PAIRS.I[p]], x[PAIRS.J[p]], acc[p], 0, 0, 0);
+    };
+    auto steady = [&](int64_t i, int st, const f4v (&rc)[NQ], f4v (&rn)[NQ]) {
+        wait_vmcnt<NQ>();   // chunk i + 1 has landed; chunk i + 2 may stay in flight
+        read_stage(st, rn);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            kstep(rc, k);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // chunk i + 1 is in registers: its stage can be refilled
+            if (k < NQ) dma1(i + 1 + GD_STAGES, st, k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f4v ra[NQ], rb[NQ];
+    for (int i = 0; i < GD_STAGES && i < nfull; ++i)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dma1(i, i, q);
+    if (nfull > 0) {
+        if (nfull > 1) wait_vmcnt<NQ>(); else wait_vmcnt<0>();
+        read_stage(0, ra);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (GD_STAGES < nfull)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dma1(GD_STAGES, 0, q);
+    }
+    int64_t i = 0;
+    for (; i + 4 < nfull; i += 2) {
+        rotate_priority((int)(i >> 1) + slot);
+        steady(i, 1, ra, rb);
+        steady(i + 1, 0, rb, ra);
+    }
+    for (; i < nfull; ++i) {   // the last chunks: the same steps with their conditions
+        const int st = (int)(i + 1) & 1;
+        const bool more = i + 1 < nfull;
+        if (more) {
+            if (i + 2 < nfull) wait_vmcnt<NQ>(); else wait_vmcnt<0>();
+            read_stage(st, rb);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) kstep(ra, k);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i + 1 + GD_STAGES < nfull)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) dma1(i + 1 + GD_STAGES, st, q);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ra[q] = rb[q];
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (partial_last) {   // the cut chunk through registers: rows past the range contribute nothing
+        const int64_t r = (nfull * B + b) * GF_ROWS + 32 * wave + 4 * kq, left = a.n - r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int h = k >> 2, e = k & 3;
+            const bool in = left > 16 * h + e;
+            double x[NCT];
+#pragma unroll
+            for (int I = 0; I < NCT; ++I) {
+                const float* p = (const float*)a.base + (int64_t)(cvalid[I] ? a.gc.cols[16 * I + c] : a.gc.cols[0]) * a.ld + a.row0 + r;
+                x[I] = (in && cvalid[I]) ? (double)p[16 * h + e] - sh[I] : 0.0;
+                cs[I] += x[I];
+            }
+            if (DBG != 1) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[PAIRS.I[p]], x[PAIRS.J[p]], acc[p], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with its ring
+
+    // ---- block combine, as in gram_glds_kernel -----
+    double* lcs = lds + NP * 256;
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) lcs[(wave * NCT + I) * 64 + lane] = cs[I];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = p * 256 + e4 * 64 + lane;
+                    lds[e] = (w == 0) ? acc[p][e4] : lds[e] + acc[p][e4];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
+    if (tid < NC) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < 4; ++k) s += lcs[(w * NCT + (tid >> 4)) * 64 + k * 16 + (tid & 15)];
+        out[NP * 256 + tid] = s;
+    }
+    if (a.stamps && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        a.stamps[blockIdx.x * 3] = t_start; a.stamps[blockIdx.x * 3 + 1] = wall_clock64(); a.stamps[blockIdx.x * 3 + 2] = hwid;
+    }
+}
+
 // one thread per (segment, element): the segment's block partials in block order
 __global__ __launch_bounds__(256) void gram_seg_reduce_kernel(const double* __restrict__ partial, const int32_t* __restrict__ blk_off, int WS,
                                                                double* __restrict__ out) {
@@ -633,8 +822,8 @@ __global__ __launch_bounds__(256) void gram_seg_reduce_kernel(const double* __re
     out[(size_t)g * WS + e] = v;
 }
 
-// PBN_GRAM_LDS: 0 = gram_kernel (rows in registers), 1 = gram_lds_kernel, 2 (default) = gram_glds_kernel where it applies
-// (double table, contiguous rows) and gram_lds_kernel elsewhere.
+// PBN_GRAM_LDS: 0 = gram_kernel (rows in registers), 1 = gram_lds_kernel, 2 (default) = the LDS-DMA ring kernels where they apply
+// (contiguous rows: gram_glds_kernel for double tables, gram_glds_f32_kernel for float ones) and gram_lds_kernel elsewhere.
 static int gram_variant() {
     static const int v = [] { const char* e = getenv("PBN_GRAM_LDS"); return (e && *e) ? atoi(e) : 2; }();
     return v;
@@ -644,21 +833,24 @@ static int gram_variant() {
 template <typename T, bool GATHER>
 static int launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st) {
     dim3 grid(nblocks), block(256);
-    if constexpr (sizeof(T) == 8 && !GATHER) {
+    if constexpr (!GATHER) {
         if (gram_variant() >= 2) {
             if (a.num_cus > 0 && nblocks > GD_BLOCKS_PER_CU * a.num_cus) grid.x = GD_BLOCKS_PER_CU * a.num_cus;   // one block per slot
             const int dbg = a.debug_skip == 1 ? 1 : a.debug_skip >= 2 ? 2 : 0;
+#define PBN_GLDS_K(K, N)                                                                                \
+        if (dbg == 0) hipLaunchKernelGGL((K<N, 0>), grid, block, 0, st, a);                            \
+        else if (dbg == 1) hipLaunchKernelGGL((K<N, 1>), grid, block, 0, st, a);                       \
+        else hipLaunchKernelGGL((K<N, 2>), grid, block, 0, st, a);
 #define PBN_GLDS(N)                                                                                     \
     case N:                                                                                             \
-        if (dbg == 0) hipLaunchKernelGGL((gram_glds_kernel<N, 0>), grid, block, 0, st, a);             \
-        else if (dbg == 1) hipLaunchKernelGGL((gram_glds_kernel<N, 1>), grid, block, 0, st, a);        \
-        else hipLaunchKernelGGL((gram_glds_kernel<N, 2>), grid, block, 0, st, a);                       \
+        if constexpr (sizeof(T) == 8) { PBN_GLDS_K(gram_glds_kernel, N) } else { PBN_GLDS_K(gram_glds_f32_kernel, N) }   \
         break;
             switch (nct) {
                 PBN_GLDS(1) PBN_GLDS(2) PBN_GLDS(3) PBN_GLDS(4)
                 default: throw invalid_error("gram: at most 64 columns per launch");
             }
 #undef PBN_GLDS
+#undef PBN_GLDS_K
             HIP_CHECK(hipGetLastError());
             return (int)grid.x;
         }
