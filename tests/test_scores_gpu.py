@@ -537,3 +537,30 @@ def test_device_table_sse_shapes_and_offsets(pbn, d, dtype):
         assert np.allclose(means, want_mean, rtol=tol, atol=0), (row0, rows)
         scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1.0
         assert np.max(np.abs(sse - want) / scale) <= 1e-9, (row0, rows, np.max(np.abs(sse - want) / scale))
+
+
+def test_gram_random_shapes_and_ranges(pbn):
+    """Short form of tools/gram_fuzz.py: random (rows, columns, first row, dtype, column subset) against numpy - the LDS-DMA Gram
+    kernels count their DMA completions by hand, a miscount would show as a wrong tile for some shapes only."""
+    rng = np.random.default_rng(77)
+    ctx = pbn.default_context()
+    for case in range(24):
+        d = int(rng.integers(1, 65))
+        n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 20000)), int(rng.integers(20000, 150000))]))
+        dtype = "float64" if case % 2 == 0 else "float32"
+        data = (rng.normal(size=(n, d)) * rng.uniform(0.5, 3.0, size=d) + rng.uniform(-50, 50, size=d)).astype(dtype)
+        names = [f"x{i}" for i in range(d)]
+        table, _ = pbn.DeviceTable.from_dataframe(ctx, pd.DataFrame(data, columns=names), names)
+        for _ in range(3):
+            row0 = int(rng.integers(0, max(1, n // 3)))
+            rows = int(rng.integers(1, n - row0 + 1))
+            k = int(rng.integers(1, d + 1))
+            idx = [int(i) for i in rng.choice(d, size=k, replace=False)]
+            x = data[row0:row0 + rows][:, idx].astype(np.float64)
+            mean = x.mean(axis=0)
+            c = x - mean
+            want = c.T @ c
+            means, sse = table.sse([names[i] for i in idx], row0, rows)
+            scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1.0
+            assert np.max(np.abs(sse - want) / scale) < 1e-9, (case, n, d, dtype, row0, rows)
+            assert np.max(np.abs(means - mean) / (np.abs(mean) + 1.0)) < 1e-10, (case, n, d, dtype, row0, rows)
