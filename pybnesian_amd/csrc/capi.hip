@@ -326,10 +326,8 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         k->m.Apack = k->Apack.p; k->m.nxpack = k->nxpack.p; k->m.Axpack = k->Axpack.p;
         // low-dimensional, large models: rows packed in Morton order with per-tile boxes, so that logl / slogl skip the
         // tile pairs that cannot contribute (same rule as the score engine's sweeps)
-        // (measured at 1e6 x 1e5 rows, tools/prune_handles_timing.py: pays up to 4 marginal dimensions in fp64, 3 in fp32)
-        // (measured at 1e6 x 1e5 rows, tools/prune_handles_timing.py: with the subsample bound of the queries' largest exponents
-        // it pays up to 5 marginal dimensions in fp64 and fp32 - d = 5: 52 -> 43 ms / 13.9 -> 12.2 ms; at d = 8 the boxes over 3 of
-        // the 8 dimensions prune too little: 53.2 -> 55.3 ms - kde_prune_applies caps the dimension, PBN_PRUNE_MAX_DIMS)
+        // (which dimensions: kde_prune_applies - up to 7 marginal dimensions in fp64, 5 in fp32; at d = 8 the boxes over 3 of the
+        // 8 dimensions prune too little)
         static const int max_dm = [] { const char* e = getenv("PBN_HANDLE_PRUNE_DIMS"); return (e && *e) ? atoi(e) : 8; }();
         const bool prune = k->m.dm <= max_dm;
         kde_pack_train(ctx, k->m, train, cols, row0, n, 0, nullptr, prune);
