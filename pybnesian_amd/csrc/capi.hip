@@ -341,19 +341,23 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         k->cols_fit.assign(cols, cols + d);
         k->train = train;
         k->train_row0 = row0;
-        k->cdf_KS = std::max(1, (m.d - 1 + 3) / 4);
         const double sc = std::sqrt(2.0 * 1.4426950408889634073599246810019);
         for (int j = 0; j < m.d; ++j) k->wu[j] = m.W[(size_t)(m.d - 1) * m.d + j] / sc;
-        const size_t es = dtype_size(m.dtype);
-        k->cA.alloc((size_t)m.ntiles * k->cdf_KS * 64 * es);
-        k->cN.alloc((size_t)m.ntiles * 16 * es);
-        k->cU.alloc((size_t)m.ntiles * 16 * es);
-        PackArgs pa{};
-        fill_cdf_pack(pa, *k, train, cols);
-        pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = m.ntiles; pa.is_query = 0;
-        pa.pack = k->cA.p; pa.npack = k->cN.p; pa.upack = k->cU.p;
-        KernelTimer kt(ctx, PBN_K_PACK);
-        launch_pack_classic(pa, m.dtype, ctx->stream);
+        if (m.d <= PBN_W_INLINE_D) {   // cdf / sample fragments: up to 16 evidence variables (logl / slogl go to 32 in fp64)
+            k->cdf_KS = std::max(1, (m.d - 1 + 3) / 4);
+            const size_t es = dtype_size(m.dtype);
+            k->cA.alloc((size_t)m.ntiles * k->cdf_KS * 64 * es);
+            k->cN.alloc((size_t)m.ntiles * 16 * es);
+            k->cU.alloc((size_t)m.ntiles * 16 * es);
+            PackArgs pa{};
+            fill_cdf_pack(pa, *k, train, cols);
+            pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = m.ntiles; pa.is_query = 0;
+            pa.pack = k->cA.p; pa.npack = k->cN.p; pa.upack = k->cU.p;
+            KernelTimer kt(ctx, PBN_K_PACK);
+            launch_pack_classic(pa, m.dtype, ctx->stream);
+        } else {
+            k->cdf_KS = 0;   // pbn_ckde_cdf / pbn_ckde_sample refuse such a handle
+        }
     }
     *out = k.release();
 }
@@ -433,6 +437,7 @@ int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
     return guarded([&] {
         if (!k) throw invalid_error("CKDE factor not fitted.");
         if (!k->ckde) throw invalid_error("pbn_ckde_cdf: the handle was not created by pbn_ckde_fit");
+        if (k->cdf_KS == 0) throw invalid_error("CKDE.cdf: at most 16 evidence variables are supported");
         if (!out && n > 0) throw invalid_error("pbn_ckde_cdf: null output");
         pbn_ctx* ctx = k->ctx;
         const KdeModel& m = k->m;

@@ -31,6 +31,8 @@ struct pbn_kde {
 // PackArgs for the cdf fragments: whitening order (evidence first, variable last), contraction over the evidence only.
 inline void fill_cdf_pack(PackArgs& pa, const pbn_kde& k, const pbn_table* t, const int* cols) {
     const KdeModel& m = k.m;
+    if (m.d > PBN_W_INLINE_D) throw pbn::invalid_error("CKDE.cdf / sample: at most 16 evidence variables are supported");
+    pa.Wdev = nullptr;
     pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.d - 1; pa.KS = k.cdf_KS;
     for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
     for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];

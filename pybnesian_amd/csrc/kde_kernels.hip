@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     for (int i = 0; i < KS * 4; ++i) {
         double z = 0.0;
         if (valid && i < dm) {
-            const double* w = a.W + (size_t)i * d;
+            const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
             for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
         }
         const T zt = (T)z;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     if (xpack) {
         double z = 0.0;
         if (valid) {
-            const double* w = a.W + (size_t)dm * d;
+            const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)dm * d;
             for (int j = 0; j <= dm; ++j) z = __builtin_fma(w[j], xc[j], z);
         }
         const T zt = (T)z;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
     uint32_t key = 0;
     for (int i = 0; i < zd; ++i) {
         double z = 0.0;
-        const double* w = a.W + (size_t)i * d;
+        const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
         for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
         z = (double)(T)z;   // the rounding the pack applies
         zrow[r * zd + i] = z;
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
     for (int i = 0; i < dm; ++i) {
         double z = 0.0;
         if (valid) {
-            const double* w = a.W + (size_t)i * d;
+            const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
             for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
         }
         const float zf = (float)z;
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
     if (a.xpack) {
         double z = 0.0;
         if (valid) {
-            const double* w = a.W + (size_t)dm * d;
+            const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)dm * d;
             for (int j = 0; j <= dm; ++j) z = __builtin_fma(w[j], xc[j], z);
         }
         const float zf = (float)z;
@@ -1743,12 +1743,21 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
             return;
         }
     }
+    if constexpr (sizeof(T) == 8 && !FOLD) {   // 17-32 dimensions: fp64, norms added per value, two query groups per wave (sweep_qg)
+        switch (KS) {
+            case 5: hipLaunchKernelGGL((kde_sweep_kernel<T, 5, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
+            case 6: hipLaunchKernelGGL((kde_sweep_kernel<T, 6, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
+            case 7: hipLaunchKernelGGL((kde_sweep_kernel<T, 7, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
+            case 8: hipLaunchKernelGGL((kde_sweep_kernel<T, 8, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
+            default: break;
+        }
+    }
     switch (KS) {
         case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
         case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
-        default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
+        default: throw invalid_error("KDE: this many whitened dimensions per sweep are not supported for the table's type");
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1784,7 +1793,7 @@ bool sweep_folds_norm(int dtype, bool cond, int KS, int dm) {
         const char* e = getenv("PBN_SWEEP_FOLD");
         v = (e && *e) ? atoi(e) : 1;
     }
-    return v != 0 && !use_bf16x3(dtype) && !use_sparse(dtype, cond, KS) && dm % 4 != 0;
+    return v != 0 && !use_bf16x3(dtype) && !use_sparse(dtype, cond, KS) && dm % 4 != 0 && KS <= 4;   // more than 16 dimensions: one form only
 }
 
 bool sweep_weights_norm(int dtype, bool cond, int KS, int dm) {
@@ -1808,6 +1817,7 @@ bool use_sparse(int dtype, bool cond, int KS) {
 int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     if (use_sparse(dtype, cond, KS)) return 1;
     if (prune && dtype == PBN_F64) return cond ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;
+    if (dtype == PBN_F64 && KS > 4) return 2;   // more than 16 dimensions: two query groups per wave (fragment registers)
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }

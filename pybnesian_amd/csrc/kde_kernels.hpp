@@ -6,7 +6,8 @@
 
 #include "common.hpp"
 
-#define PBN_MAX_D 17       // up to 16 whitened "main" dimensions (KS <= 4) + 1 CKDE extra coordinate
+#define PBN_MAX_D 33       // up to 32 whitened "main" dimensions (fp64: KS <= 8; fp32: 16) + 1 CKDE extra coordinate
+#define PBN_W_INLINE_D 17  // whitening matrices up to this order travel inside the kernel arguments, larger ones through device memory
 
 namespace pbn {
 
@@ -32,7 +33,8 @@ struct PackArgs {
     int64_t perm_stride;  // > 1: from logical row perm[r * perm_stride] (the stratified subsample of a sorted pack)
     int64_t n;            // valid rows
     int64_t ntiles;       // ceil(n / 16)
-    double W[PBN_MAX_D * PBN_MAX_D];  // d x d row-major lower-triangular whitening matrix (kernel argument)
+    double W[PBN_W_INLINE_D * PBN_W_INLINE_D];  // d x d row-major lower-triangular whitening matrix (kernel argument), d <= PBN_W_INLINE_D
+    const double* Wdev;               // the same matrix in device memory when d > PBN_W_INLINE_D (else null)
     double mu[PBN_MAX_D];             // d centring offsets
     void* pack;           // [ntiles][KS][64]
     void* npack;          // [ntiles][16]

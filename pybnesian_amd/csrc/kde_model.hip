@@ -85,7 +85,11 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
     if (n <= 0) throw invalid_error("pbn_kde_fit: no training instances");
     if (cond && d < 2) cond = false;  // CKDE without evidence is a plain KDE (CKDE.hpp:232-241)
     const int dm = cond ? d - 1 : d;
-    if (dm > 16) throw invalid_error("KDE with more than 16 (+1 conditional) variables is not supported");
+    // fp64: up to 32 main dimensions (KS <= 8); fp32 (bf16x3 fragments: 6 slots per dimension, at most four 32-slot MFMAs): 16
+    const int max_dm = dtype == PBN_F64 ? 32 : 16;
+    if (dm > max_dm)
+        throw invalid_error(dtype == PBN_F64 ? "KDE with more than 32 (+1 conditional) variables is not supported"
+                                             : "float32 KDE with more than 16 (+1 conditional) variables is not supported (float64 tables go to 32)");
     m.dtype = dtype; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
     m.N = n; m.ntiles = ceil_div(n, 16);
     if (cond) {  // evidence first, variable last
@@ -126,11 +130,18 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
         for (int i = 0; i < d; ++i) m.mu[i] = center[m.perm[i]];
 }
 
-static void fill_pack_common(PackArgs& pa, const pbn_table* t, const int* cols, const KdeModel& m) {
+static void fill_pack_common(pbn_ctx* ctx, PackArgs& pa, const pbn_table* t, const int* cols, const KdeModel& m) {
     pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.dm; pa.KS = m.KS;
     for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
     pa.rows = nullptr;
-    for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];
+    pa.Wdev = nullptr;
+    if (m.d <= PBN_W_INLINE_D) {
+        for (int i = 0; i < m.d * m.d; ++i) pa.W[i] = m.W[i];
+    } else {   // too large for the kernel arguments: through the context's (lane's) scratch, in stream order behind its last reader
+        ctx->scratch_w.reserve((size_t)PBN_MAX_D * PBN_MAX_D);
+        HIP_CHECK(hipMemcpyAsync(ctx->scratch_w.p, m.W.data(), (size_t)m.d * m.d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        pa.Wdev = ctx->scratch_w.p;
+    }
     for (int i = 0; i < m.d; ++i) pa.mu[i] = m.mu[i];
 }
 
@@ -184,7 +195,7 @@ static SubBytes sub_bytes(const KdeModel& m, int64_t nsub) {
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
                     int64_t row1, const int32_t* dev_rows, bool prune) {
     PackArgs pa{};
-    fill_pack_common(pa, t, cols, m);
+    fill_pack_common(ctx, pa, t, cols, m);
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
@@ -275,7 +286,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + xn_b + 256);
     char* q = ctx->scratch_q.p;
     PackArgs pa{};
-    fill_pack_common(pa, test, cols, m);
+    fill_pack_common(ctx, pa, test, cols, m);
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles;
     pa.is_query = 1;

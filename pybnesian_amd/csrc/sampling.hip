@@ -216,6 +216,7 @@ int pbn_ckde_sample(pbn_kde* k, int64_t n, int64_t stream_n, const pbn_table* ev
     return guarded([&] {
         if (!k) throw invalid_error("CKDE factor not fitted.");
         if (!k->ckde || !k->train) throw invalid_error("pbn_ckde_sample: the handle was not created by pbn_ckde_fit");
+        if (k->cdf_KS == 0) throw invalid_error("CKDE.sample: at most 16 evidence variables are supported");
         if (n < 0) throw invalid_error("n should be a non-negative number");
         if (n == 0) return;
         if (!out) throw invalid_error("pbn_ckde_sample: null output");

@@ -496,3 +496,31 @@ def test_pruned_handles_full_size_properties(pbn, monkeypatch):
     monkeypatch.delenv("PBN_SWEEP_PRUNE")
     assert abs(plain.slogl(test) - s) <= 1e-10 * abs(s)
     assert np.allclose(plain.logl(test.iloc[:4096]), ll[:4096], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("d", [17, 20, 24, 29, 32])   # KS = 5 ... 8: the whitening matrix travels through device memory
+def test_more_than_16_dimensions_fp64(pbn, oracle, d):
+    """KDE / ProductKDE / CKDE over 17-32 variables in fp64 (the reference has no limit: KDE.hpp is dimension-agnostic) against the
+    oracle; cdf / sample of a CKDE stay at 16 evidence variables and say so; float32 tables stop at 16 and say so."""
+    rng = np.random.default_rng(500 + d)
+    n, m = 2501, 133
+    mix = np.tril(rng.uniform(-0.3, 0.3, size=(d, d)), -1) + np.eye(d)
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame((rng.normal(size=(n, d)) @ mix.T) * 2.0 - 3.0, columns=names)
+    test = pd.DataFrame((rng.normal(size=(m, d)) @ mix.T) * 2.0 - 3.0, columns=names)
+    for cls, fn in ((pbn.KDE, oracle.kde_logl), (pbn.ProductKDE, oracle.product_kde_logl)):
+        k = cls(names)
+        k.fit(train)
+        want = fn(train.to_numpy(), k.bandwidth, test.to_numpy())
+        assert rel_err(k.logl(test), want) < RTOL_F64, cls.__name__
+        assert abs(k.slogl(test) - want.sum()) <= RTOL_F64 * abs(want.sum())
+    cpd = pbn.CKDE(names[0], names[1:])
+    cpd.fit(train)
+    want = oracle.ckde_logl(train.to_numpy(), cpd.bandwidth, test.to_numpy())
+    assert rel_err(cpd.logl(test), want) < RTOL_F64
+    if d - 1 > 16:
+        with pytest.raises(Exception, match="16 evidence"):
+            cpd.cdf(test)
+    k32 = pbn.KDE(names)
+    with pytest.raises(Exception, match="float32"):
+        k32.fit(train.astype("float32"))

@@ -564,3 +564,18 @@ def test_gram_random_shapes_and_ranges(pbn):
             scale = np.sqrt(np.outer(np.diag(want), np.diag(want))) + 1.0
             assert np.max(np.abs(sse - want) / scale) < 1e-9, (case, n, d, dtype, row0, rows)
             assert np.max(np.abs(means - mean) / (np.abs(mean) + 1.0)) < 1e-10, (case, n, d, dtype, row0, rows)
+
+
+def test_cv_likelihood_ckde_with_18_parents(pbn, oracle):
+    """A CKDE candidate over 19 variables (more than the 16 whitened dimensions one fp64 MFMA chain of four covers): the score
+    engine's folds go through the 17-32-dimension sweeps (KS = 5, conditional form)."""
+    rng = np.random.default_rng(19)
+    n, d = 1500, 19
+    mix = np.tril(rng.uniform(-0.3, 0.3, size=(d, d)), -1) + np.eye(d)
+    data = rng.normal(size=(n, d)) @ mix.T
+    names = [f"v{i}" for i in range(d)]
+    df = pd.DataFrame(data, columns=names)
+    score = pbn.CVLikelihood(df, 3, 5)
+    got = score.local_score_node_type(pbn.SemiparametricBN(names), pbn.CKDEType(), "v0", names[1:])
+    want = oracle.cv_likelihood(data, "ckde", 3, 5)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
