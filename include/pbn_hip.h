@@ -93,8 +93,8 @@ int pbn_bandwidth(int selector, int kind, const double* cov, int d, int64_t n, i
  * `kind`; the training rows are whitened, centred and packed into MFMA fragment order on device.
  * `center` (d doubles, nullable) is any offset near the column means (the distances do not depend on
  * it; it only keeps the whitened coordinates small); NULL lets the library take pilot means.
- * Dimensions: up to 32 variables (+ the conditional one of pbn_ckde_fit) for PBN_F64 tables, up to 16 for PBN_F32 ones
- * (PBN_ERR_INVALID beyond; the reference has no limit); pbn_ckde_cdf / pbn_ckde_sample / pbn_ucv_* take up to 16. */
+ * Dimensions: up to 32 variables (+ the conditional one of pbn_ckde_fit), PBN_ERR_INVALID beyond (the reference has no
+ * limit); pbn_ckde_cdf / pbn_ckde_sample / pbn_ucv_* take up to 16. */
 int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                 const double* bandwidth, int kind, const double* center, pbn_kde** out);
 /* CKDE: replaces CKDE::_fit (factors/continuous/CKDE.hpp:182-200).  cols[0] is the variable,

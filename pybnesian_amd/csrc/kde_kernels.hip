@@ -1817,7 +1817,7 @@ bool use_sparse(int dtype, bool cond, int KS) {
 int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     if (use_sparse(dtype, cond, KS)) return 1;
     if (prune && dtype == PBN_F64) return cond ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;
-    if (dtype == PBN_F64 && KS > 4) return 2;   // more than 16 dimensions: two query groups per wave (fragment registers)
+    if (KS > 4) return 2;   // more than 16 (fp32: 20) dimensions: two query groups per wave (fragment registers); KS = MFMAs per tile pair
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }
@@ -1839,7 +1839,10 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
         case 2: hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, false>), grid, block, 0, st, a); break;
         case 3: hipLaunchKernelGGL((kde_sweep_bf16_kernel<3, COND, 4, false>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((kde_sweep_bf16_kernel<4, COND, 4, false>), grid, block, 0, st, a); break;
-        default: throw invalid_error("KDE: more than 16 whitened dimensions per sweep are not supported");
+        case 5: hipLaunchKernelGGL((kde_sweep_bf16_kernel<5, COND, 2, false>), grid, block, 0, st, a); break;   // 21-32 dimensions (sweep_qg: 2)
+        case 6: hipLaunchKernelGGL((kde_sweep_bf16_kernel<6, COND, 2, false>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((kde_sweep_bf16_kernel<7, COND, 2, false>), grid, block, 0, st, a); break;
+        default: throw invalid_error("KDE: more than 32 whitened dimensions per sweep are not supported");
     }
     HIP_CHECK(hipGetLastError());
 }

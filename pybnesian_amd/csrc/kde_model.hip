@@ -85,11 +85,10 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
     if (n <= 0) throw invalid_error("pbn_kde_fit: no training instances");
     if (cond && d < 2) cond = false;  // CKDE without evidence is a plain KDE (CKDE.hpp:232-241)
     const int dm = cond ? d - 1 : d;
-    // fp64: up to 32 main dimensions (KS <= 8); fp32 (bf16x3 fragments: 6 slots per dimension, at most four 32-slot MFMAs): 16
-    const int max_dm = dtype == PBN_F64 ? 32 : 16;
-    if (dm > max_dm)
-        throw invalid_error(dtype == PBN_F64 ? "KDE with more than 32 (+1 conditional) variables is not supported"
-                                             : "float32 KDE with more than 16 (+1 conditional) variables is not supported (float64 tables go to 32)");
+    // up to 32 main dimensions: fp64 KS <= 8 MFMAs per tile pair, fp32 (bf16x3 fragments, 6 slots per dimension + 3) <= 7; the
+    // classic fp32 fragments (PBN_F32_BF16X3=0, a measurement switch) stay at 16
+    const int max_dm = (dtype == PBN_F64 || use_bf16x3(dtype)) ? 32 : 16;
+    if (dm > max_dm) throw invalid_error("KDE with more than 32 (+1 conditional) variables is not supported");
     m.dtype = dtype; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
     m.N = n; m.ntiles = ceil_div(n, 16);
     if (cond) {  // evidence first, variable last

@@ -499,9 +499,9 @@ def test_pruned_handles_full_size_properties(pbn, monkeypatch):
 
 
 @pytest.mark.parametrize("d", [17, 20, 24, 29, 32])   # KS = 5 ... 8: the whitening matrix travels through device memory
-def test_more_than_16_dimensions_fp64(pbn, oracle, d):
+def test_more_than_16_dimensions(pbn, oracle, d):
     """KDE / ProductKDE / CKDE over 17-32 variables in fp64 (the reference has no limit: KDE.hpp is dimension-agnostic) against the
-    oracle; cdf / sample of a CKDE stay at 16 evidence variables and say so; float32 tables stop at 16 and say so."""
+    oracle, and in fp32 against the f64 oracle on the rounded data; cdf / sample of a CKDE stay at 16 evidence variables and say so."""
     rng = np.random.default_rng(500 + d)
     n, m = 2501, 133
     mix = np.tril(rng.uniform(-0.3, 0.3, size=(d, d)), -1) + np.eye(d)
@@ -521,6 +521,13 @@ def test_more_than_16_dimensions_fp64(pbn, oracle, d):
     if d - 1 > 16:
         with pytest.raises(Exception, match="16 evidence"):
             cpd.cdf(test)
+    # float32 tables: the bf16x3 sweep with 4-7 MFMAs per tile pair; the f64 oracle on the f32-rounded data is the truth
+    tr32, te32 = train.astype("float32"), test.astype("float32")
     k32 = pbn.KDE(names)
-    with pytest.raises(Exception, match="float32"):
-        k32.fit(train.astype("float32"))
+    k32.fit(tr32)
+    want32 = oracle.kde_logl(tr32.to_numpy().astype(np.float64), k32.bandwidth, te32.to_numpy().astype(np.float64))
+    assert np.allclose(k32.logl(te32), want32, atol=5e-4, rtol=1e-4)
+    c32 = pbn.CKDE(names[0], names[1:])
+    c32.fit(tr32)
+    wantc = oracle.ckde_logl(tr32.to_numpy().astype(np.float64), c32.bandwidth, te32.to_numpy().astype(np.float64))
+    assert np.allclose(c32.logl(te32), wantc, atol=2e-3, rtol=1e-3)
