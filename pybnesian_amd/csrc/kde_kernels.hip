@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 // sorted 16-row tiles, and per query tile a lower bound of its queries' largest exponents.
 // ------------------------------------------------------------------------------------------------
 #define PBN_PRUNE_CELL 2.0      // key cell edge in (base-2) whitened units; a term vanishes beyond ~11.3 of them
+
 #define PBN_PRUNE_WINDOW 32     // training rows scanned on either side of a query's Morton position
 // terms below 2^-52 of their query's largest known term are dropped: at most N * 2^-52 of a sum (2.2e-10 at 10^6 rows), a
 // tenth of the error bound of the 2^x polynomial the kept terms go through.  (Round 1 and the first half of round 2 used
@@ -317,10 +318,12 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
         z = (double)(T)z;   // the rounding the pack applies
         zrow[r * zd + i] = z;
         if (i < kd) {
-            double c = __builtin_floor(z * (1.0 / PBN_PRUNE_CELL)) + 512.0;
-            c = c < 0.0 ? 0.0 : (c > 1023.0 ? 1023.0 : c);
+            const int bits = prune_key_bits(kd);
+            const double half = (double)(1 << (bits - 1)), top = (double)((1 << bits) - 1);
+            double c = __builtin_floor(z * (1.0 / PBN_PRUNE_CELL)) + half;
+            c = c < 0.0 ? 0.0 : (c > top ? top : c);
             const uint32_t cell = (uint32_t)c;
-            for (int b = 0; b < 10; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
+            for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
         }
     }
     keys[r] = key;
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(256) void tile_box_kernel(const double* __restrict_
                                                        double* __restrict__ box, double* __restrict__ zsorted) {
     const int64_t tile = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tile * 16 >= n) return;
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double lo[PBN_PRUNE_PD], hi[PBN_PRUNE_PD];
+    for (int k = 0; k < PBN_PRUNE_PD; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
     for (int i = 0; i < 16; ++i) {
         const int64_t r = tile * 16 + i;
         if (r >= n) break;
@@ -379,12 +383,12 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
     if (qlb && q < (nq + 15) / 16 * 16) qlb[q] = valid ? best : -INFINITY;   // per query: the sweep's starting offset
     // reduce over the 16 lanes of a query tile
     double thr = valid ? best : INFINITY;
-    double lob[3], hib[3];
-    for (int k = 0; k < 3; ++k) { lob[k] = (valid && k < pd) ? z[k] : INFINITY; hib[k] = (valid && k < pd) ? z[k] : -INFINITY; }
+    double lob[PBN_PRUNE_PD], hib[PBN_PRUNE_PD];
+    for (int k = 0; k < PBN_PRUNE_PD; ++k) { lob[k] = (valid && k < pd) ? z[k] : INFINITY; hib[k] = (valid && k < pd) ? z[k] : -INFINITY; }
     for (int off = 1; off < 16; off <<= 1) {
         const double o = __shfl_xor(thr, off);
         thr = o < thr ? o : thr;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < PBN_PRUNE_PD; ++k) {
             const double l = __shfl_xor(lob[k], off), h = __shfl_xor(hib[k], off);
             lob[k] = l < lob[k] ? l : lob[k];
             hib[k] = h > hib[k] ? h : hib[k];
@@ -433,14 +437,14 @@ __device__ __forceinline__ void xcd_block(int& qx, int& split) {
 // version tested tile by tile on wave-uniform values - 15 DP instructions and three loads per tile, skipped or not:
 // a fifth of a kept tile's cost in the fp32 sweep and ALL of a skipped tile's).
 __device__ __forceinline__ unsigned long long prune_visit_mask(const double* __restrict__ tile_box, int pd, int64_t tb, int64_t t1,
-                                                               const double (&wlo)[3], const double (&whi)[3], double wthr, int lane) {
+                                                               const double (&wlo)[PBN_PRUNE_PD], const double (&whi)[PBN_PRUNE_PD], double wthr, int lane) {
     const int64_t t = tb + lane;
     bool keep = false;
     if (t < t1) {
         const double* bx = tile_box + t * 2 * pd;
         double d2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < PBN_PRUNE_PD; ++k)
             if (k < pd) {
                 const double g1 = bx[k] - whi[k], g2 = wlo[k] - bx[pd + k];
                 double g = g1 > g2 ? g1 : g2;
@@ -519,19 +523,19 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kerne
     const T ctop = Tr<T>::top();   // leading exp2 coefficient pinned in a VGPR for the whole kernel
 
     // ---- tile pruning: box of this wave's queries and the exponent below which a training tile cannot matter -------
-    double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0}, wthr = 0;
+    double wlo[PBN_PRUNE_PD] = {}, whi[PBN_PRUNE_PD] = {}, wthr = 0;
     const int pd = PRUNE ? a.pdims : 0;
     if (PRUNE) {
         wthr = INFINITY;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
+        for (int k = 0; k < PBN_PRUNE_PD; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
             const double th = a.qtile_thr[qt];
             wthr = th < wthr ? th : wthr;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < PBN_PRUNE_PD; ++k)
                 if (k < pd) {
                     const double l = a.qtile_box[qt * 2 * pd + k], h = a.qtile_box[qt * 2 * pd + pd + k];
                     wlo[k] = l < wlo[k] ? l : wlo[k];
@@ -1100,19 +1104,19 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_bf16_
         if (COND) { bx[g] = BXp[qt * 64 + lane]; xn[g] = XNp[qt * 16 + (lane & 15)]; sumj[g] = 0.0; }
     }
     // tile pruning, as in kde_sweep_kernel
-    double wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0}, wthr = 0;
+    double wlo[PBN_PRUNE_PD] = {}, whi[PBN_PRUNE_PD] = {}, wthr = 0;
     const int pd = PRUNE ? a.pdims : 0;
     if (PRUNE) {
         wthr = INFINITY;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
+        for (int k = 0; k < PBN_PRUNE_PD; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
             const double th = a.qtile_thr[qt];
             wthr = th < wthr ? th : wthr;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < PBN_PRUNE_PD; ++k)
                 if (k < pd) {
                     const double l = a.qtile_box[qt * 2 * pd + k], h = a.qtile_box[qt * 2 * pd + pd + k];
                     wlo[k] = l < wlo[k] ? l : wlo[k];

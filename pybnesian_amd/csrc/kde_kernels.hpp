@@ -9,7 +9,12 @@
 #define PBN_MAX_D 33       // up to 32 whitened "main" dimensions (fp64: KS <= 8; fp32: 16) + 1 CKDE extra coordinate
 #define PBN_W_INLINE_D 17  // whitening matrices up to this order travel inside the kernel arguments, larger ones through device memory
 
+#define PBN_PRUNE_PD 5     // most whitened dimensions the Morton keys and the boxes of the pruned sweeps cover (KdeModel::pdims <= this)
+
 namespace pbn {
+
+// bits per dimension of a 32-bit Morton key over kd dimensions: 10 up to three, 8 for four, 6 for five
+__host__ __device__ inline int prune_key_bits(int kd) { return kd <= 3 ? 10 : 32 / kd; }
 
 struct PackArgs {
     const void* base;     // device column-major table

@@ -168,7 +168,7 @@ static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackA
     s.perm = (int32_t*)p; p += ib;
     s.rest = p;
     launch_prune_keys(pa, dtype, zd, kd, s.zrow, keys_unsorted, iota, ctx->stream);
-    sort_keys(ctx->scratch_sort, keys_unsorted, s.keys, iota, s.perm, pa.n, 10 * kd, ctx->stream);
+    sort_keys(ctx->scratch_sort, keys_unsorted, s.keys, iota, s.perm, pa.n, prune_key_bits(kd) * kd, ctx->stream);
     return s;
 }
 
@@ -202,7 +202,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     if (prune && kde_prune_applies(m.dtype, m.dm, m.N)) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         m.zdims = m.d;
-        m.pdims = std::min(m.dm, 3);
+        m.pdims = std::min(m.dm, std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), PBN_PRUNE_PD));   // dimensions of the Morton keys and the boxes (<= PBN_PRUNE_PD)
         const size_t box_b = al((size_t)m.ntiles * 2 * m.pdims * sizeof(double)), zs_b = al((size_t)m.N * m.zdims * sizeof(double));
         // more dimensions than the keys cover: a stratified subsample (every N / nsub-th row of the sorted order, <= 4096
         // rows, <= 1/64 of the set) is packed as well; the queries are swept against it first (kde_eval_enqueue)
