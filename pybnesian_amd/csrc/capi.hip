@@ -326,8 +326,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         k->m.Apack = k->Apack.p; k->m.nxpack = k->nxpack.p; k->m.Axpack = k->Axpack.p;
         // low-dimensional, large models: rows packed in Morton order with per-tile boxes, so that logl / slogl skip the
         // tile pairs that cannot contribute (same rule as the score engine's sweeps)
-        // (which dimensions: kde_prune_applies - up to 7 marginal dimensions in fp64, 5 in fp32; at d = 8 the boxes over 3 of the
-        // 8 dimensions prune too little)
+        // (which dimensions: kde_prune_applies - up to 6 marginal dimensions; beyond, boxes over 4 of the dimensions prune too little)
         static const int max_dm = [] { const char* e = getenv("PBN_HANDLE_PRUNE_DIMS"); return (e && *e) ? atoi(e) : 8; }();
         const bool prune = k->m.dm <= max_dm;
         kde_pack_train(ctx, k->m, train, cols, row0, n, 0, nullptr, prune);

@@ -1714,7 +1714,7 @@ template <typename T, bool COND, bool FOLD>
 static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
     constexpr int QG = SweepQG<sizeof(T) == 8, COND>::value;
     dim3 block(256);
-    if (a.prune) {   // fp64, at most 5 marginal dimensions (KS <= 2)
+    if (a.prune) {   // fp64, at most 6 marginal dimensions (KS <= 2)
         if constexpr (sizeof(T) == 8) {
             constexpr int QGP = COND ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;   // query groups per wave of the pruned kernels
             block = dim3(sweep_block_threads(true));
@@ -1829,7 +1829,7 @@ int sweep_qg(int dtype, bool cond, int KS, bool prune) {
 template <bool COND>
 static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
     dim3 block(256);
-    if (a.prune) {   // at most 5 marginal dimensions: 33 bf16 slots, two MFMAs
+    if (a.prune) {   // at most 6 marginal dimensions: 39 bf16 slots, two MFMAs
         block = dim3(sweep_block_threads(true));
         grid = dim3((unsigned)(ceil_div(a.nqtiles, 4) * a.nsplit_grid));   // one wave (4 query groups) per workgroup, placed by pruned_block
         if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, true>), grid, block, 0, st, a);

@@ -172,12 +172,11 @@ static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackA
     return s;
 }
 
-// Up to 7 marginal dimensions in fp64, 5 in fp32 (PBN_PRUNE_MAX_DIMS overrides both): at 1e6 x 1e5 rows (tools/prune_dims67.py)
-// fp64 d = 6 / 7 gain 7-14 % / 4-6 % on correlated, independent and heavy-tailed data alike, the fp32 sweeps - 3.7x cheaper per
-// tile, the same sorting and mask work - gain on some data and lose 4-5 % on heavy-tailed; at d = 8 both lose (the boxes cover
-// 3 of the 8 dimensions).
+// Up to 6 marginal dimensions (PBN_PRUNE_MAX_DIMS overrides): at 1e6 x 1e5 rows (tools/prune_dims67.py, boxes over 4 dimensions)
+// d = 6 gains 10 % in fp64 and 9-13 % in fp32 on correlated and on independent normal data and is even on heavy-tailed data;
+// d = 7 is even at best (heavy-tailed: +3...5 %), d = 8 loses 10 %.
 bool kde_prune_applies(int dtype, int dm, int64_t n) {
-    const int max_dims = env_int("PBN_PRUNE_MAX_DIMS", dtype == PBN_F64 ? 7 : 5);
+    const int max_dims = env_int("PBN_PRUNE_MAX_DIMS", 6);
     return env_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= max_dims && n >= env_int("PBN_PRUNE_MIN_ROWS", 32768);
 }
 

@@ -1,5 +1,5 @@
 """Does tile pruning pay at 6 and 7 dimensions?  KDE.slogl at 1e6 x 1e5 rows, fp64 and fp32, correlated / independent / heavy-tailed
-data, PBN_PRUNE_MAX_DIMS = 5 against 7 (kde_prune_applies: 7 is the fp64 default, 5 the fp32 one).  python tools/prune_dims67.py"""
+data, PBN_PRUNE_MAX_DIMS = 5 against 7 (kde_prune_applies: 6 is the default).  python tools/prune_dims67.py"""
 import os, sys, time
 import numpy as np, pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
