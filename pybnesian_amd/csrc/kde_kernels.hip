@@ -189,7 +189,10 @@ struct Tr<float> {
 // measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
 __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
-// (pruned fp64 sweeps: tiles visited / tiles offered, per wave)
+// (pruned sweeps: tiles visited / tiles offered, per wave)
+#ifndef PBN_F64_PRUNE_WAVES
+#define PBN_F64_PRUNE_WAVES 2   // waves per SIMD the pruned fp64 / fp32-MFMA sweeps are compiled for
+#endif
 #ifndef PBN_SWEEP_UNCHECKED
 #define PBN_SWEEP_UNCHECKED 1   // fp64 plain unpruned sweeps: blind first pass, checked redo (kde_sweep_kernel)
 #endif
@@ -480,7 +483,7 @@ __device__ __forceinline__ void pruned_block(const SweepArgs& a, int groups_per_
 }
 
 template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
-__global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_WAVES : 2) void kde_sweep_kernel(SweepArgs a) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // waves per workgroup
@@ -1066,8 +1069,18 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
     }
 }
 
+// waves per SIMD the pruned fp32 sweeps are compiled for: 4 (<= 128 VGPRs; the fused CKDE shape needs 180 unconstrained and
+// spills a few prologue / rare-path values to scratch, none in the tile loop).  One-wave workgroups walking irregular tile
+// lists are latency-bound: 2 -> 4 resident waves is worth 12 % of C5's hill-climb and 12-14 % on the fp32 handles;
+// 5 (96 VGPRs) spills inside the loop.
+#ifndef PBN_BF16_PRUNE_WAVES
+#define PBN_BF16_PRUNE_WAVES 4
+#endif
+#ifndef PBN_BF16_QG_PRUNE
+#define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
+#endif
 template <int NB, bool COND, int QG, bool PRUNE>
-__global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_bf16_kernel(SweepArgs a) {
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_WAVES : 2) void kde_sweep_bf16_kernel(SweepArgs a) {
     using V = f4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
@@ -1297,9 +1310,11 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), 2) void kde_sweep_bf16_
 
     bf8 fA[NB], fB[NB], xA, xB;
     if constexpr (PRUNE) {
+        if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
         for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
             unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
             if (!mask) continue;
+            if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
             int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             load_tile(tb + b, fA, xA);
@@ -1831,9 +1846,10 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
     dim3 block(256);
     if (a.prune) {   // at most 6 marginal dimensions: 39 bf16 slots, two MFMAs
         block = dim3(sweep_block_threads(true));
-        grid = dim3((unsigned)(ceil_div(a.nqtiles, 4) * a.nsplit_grid));   // one wave (4 query groups) per workgroup, placed by pruned_block
-        if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, true>), grid, block, 0, st, a);
-        else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, true>), grid, block, 0, st, a);
+        constexpr int QGP = PBN_BF16_QG_PRUNE;
+        grid = dim3((unsigned)(ceil_div(a.nqtiles, QGP) * a.nsplit_grid));   // one wave (QGP query groups) per workgroup, placed by pruned_block
+        if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, QGP, true>), grid, block, 0, st, a);
+        else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, QGP, true>), grid, block, 0, st, a);
         else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;

@@ -1,5 +1,6 @@
 // Host side of KDE / ProductKDE / CKDE fitting and evaluation, shared by the public handles and the score
 // engine.  See kde_kernels.hip for the device side.
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -361,6 +362,8 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
+    static const bool log_sweeps = env_int("PBN_SWEEP_LOG", 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
+    if (log_sweeps) std::fprintf(stderr, "pbn-sweep N=%lld n=%lld d=%d cond=%d prune=%d nsub=%lld nsplit=%lld\n", (long long)m.N, (long long)n, m.d, (int)m.cond, (int)m.prune, (long long)(m.prune ? m.nsub : 0), (long long)nsplit);
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, m.dtype, m.KS, m.cond, (int)nsplit, ctx->stream); }
 
     const int64_t nblocks = ceil_div(n, 256);
