@@ -190,8 +190,10 @@ struct Tr<float> {
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
 __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
 // (pruned sweeps: tiles visited / tiles offered, per wave)
+// waves per SIMD the pruned fp64 sweeps are compiled for: 3 (<= 168 VGPRs) - the blind-batch shapes fit anyway, the checked
+// d = 4 / 5 and norm-multiplying shapes (183-207 unconstrained) gain 3-9 % on the 1e6 x 1e5 handles; 4 (128, spills) loses on C3
 #ifndef PBN_F64_PRUNE_WAVES
-#define PBN_F64_PRUNE_WAVES 2   // waves per SIMD the pruned fp64 / fp32-MFMA sweeps are compiled for
+#define PBN_F64_PRUNE_WAVES 3
 #endif
 #ifndef PBN_SWEEP_UNCHECKED
 #define PBN_SWEEP_UNCHECKED 1   // fp64 plain unpruned sweeps: blind first pass, checked redo (kde_sweep_kernel)
@@ -1076,11 +1078,14 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_PRUNE_WAVES
 #define PBN_BF16_PRUNE_WAVES 4
 #endif
+#ifndef PBN_BF16_WAVES
+#define PBN_BF16_WAVES 2   // the same for the unpruned fp32 sweeps of up to 10 dimensions (4 waves per workgroup: workgroups per CU)
+#endif
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
 template <int NB, bool COND, int QG, bool PRUNE>
-__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_WAVES : 2) void kde_sweep_bf16_kernel(SweepArgs a) {
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_WAVES : (NB <= 2 ? PBN_BF16_WAVES : 2)) void kde_sweep_bf16_kernel(SweepArgs a) {
     using V = f4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
