@@ -22,6 +22,7 @@ for dtype in ("float64", "float32"):
             for prune in ("0", "1"):
                 os.environ["PBN_SWEEP_PRUNE"] = prune
                 k = pbn.KDE(names) if what == "KDE" else pbn.CKDE(names[0], names[1:])
+                k.fit(trb)               # warm-up of the fit kernels of this shape (first use of a variant costs 10-100 ms)
                 t0 = time.perf_counter(); k.fit(trb); tf = time.perf_counter() - t0
                 k.slogl(teb); k.logl(teb)   # warm-up: arenas, first launches of these kernel variants
                 ts = tl = 1e9
