@@ -346,7 +346,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     // engine's slices are below that anyway - splitting THEM four times finer costs C5 12 %)
     if (m.prune) nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles, (int64_t)env_int("PBN_PRUNE_MAX_TILES", 1024)));
     if (nsplit > 1) nsplit = ceil_div(nsplit, 8) * 8;
-    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 32)));
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 64)));
     nsplit = std::min<int64_t>(nsplit, 4096);
     const int64_t tps = ceil_div(m.ntiles, nsplit);
     nsplit = ceil_div(m.ntiles, tps);
