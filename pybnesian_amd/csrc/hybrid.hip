@@ -432,7 +432,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         HIP_CHECK(hipMemsetAsync(dsums.p, 0, ((size_t)units * g.nc * 2 + 1) * sizeof(double), ctx->stream));
     }
     // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
-    const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes() : 1;
+    const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
     if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
     size_t issued = 0;
     auto key_of = [&](int region, int c, const int* v, int nv) {

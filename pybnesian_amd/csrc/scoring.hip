@@ -865,7 +865,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, nslots) * sizeof(double), ctx->stream));
             auto align = [](size_t x) { return (x + 255) / 256 * 256; };
             // independent evaluations alternate between the context's two issue lanes (common.hpp)
-            const int lanes = (work.size() > 1 && !ctx->profiling) ? score_lanes() : 1;
+            const int lanes = (work.size() > 1 && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
             if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
             size_t wi = 0;
             for (const Work& w : work) {

@@ -1,12 +1,14 @@
-# rocprofv3 kernel trace of config C5's hill-climb with the default issue lanes: device busy time (union of the kernel
+# rocprofv3 kernel trace of a hill-climb config (default C5) with the default issue lanes: device busy time (union of the kernel
 # intervals) against the span, per-kernel totals, and the sweep launches bucketed by grid size.
+#   bash tools/c5_trace.sh [max_iters] [output dir under gpurun_out] [hc config: c5mmhc, cv64, c3]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 ITERS=${1:-1000000}
 OUT=${2:-c5_trace}
+HC=${3:-c5mmhc}
 rm -rf $R/gpurun_out/$OUT
 mkdir -p $R/gpurun_out/$OUT
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$OUT -- python3 $R/bench.py --no-c3 --no-e2e --no-cpu-baseline --hc c5mmhc --hc-max-iters $ITERS --steps 1 --warmup 1 > $R/gpurun_out/$OUT.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$OUT -- python3 $R/bench.py --no-c3 --no-e2e --no-cpu-baseline --hc $HC --hc-max-iters $ITERS --steps 1 --warmup 1 > $R/gpurun_out/$OUT.log 2>&1
 cd $R
 t=$(find gpurun_out/$OUT -name "*kernel_trace.csv" | head -1)
 python3 - $t <<'PY'
@@ -14,9 +16,9 @@ import csv, sys, collections, re
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
         for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-# the hill-climb part: from the first to the last fp32 (bf16x3) sweep - MMPC with MutualInformation launches none
-idx = [i for i, r in enumerate(rows) if "kde_sweep_bf16" in r[2]]
-hc = rows[idx[0]:idx[-1] + 1]
+# the hill-climb part: from the first to the last launch of the pruning tables' kernel (neither the headline step nor MMPC use it)
+idx = [i for i, r in enumerate(rows) if "tile_box_kernel" in r[2]]
+hc = rows[idx[0]:min(idx[-1] + 8, len(rows))]
 span = hc[-1][1] - hc[0][0]
 busy, cur_s, cur_e = 0, hc[0][0], hc[0][1]
 for s, e, _, _ in hc[1:]:
