@@ -135,13 +135,17 @@ struct pbn_ctx {
     pbn::dev_buf<char> scratch_sort;   // radix sort temporaries
     pbn::dev_buf<double> scratch_split; // CKDE handles evaluated as two plain sweeps: joint / marginal logl or sums
     pbn::dev_buf<double> scratch_w;     // whitening matrices too large for the kernel arguments (more than 16 variables)
+    pbn::dev_buf<char> scratch_group;   // grouped KDE evaluation (kde_group.hip): tables, sorted rows, every unit's packs and partials
+    // host buffers of asynchronous uploads that must outlive the call that enqueued them; dropped by whoever synchronises next
+    std::vector<std::vector<char>> staged;
+    void drop_staged() { staged.clear(); }
     // Extra issue lanes (score engine): independent evaluations are enqueued round-robin on `stream` and on the parked lanes'
     // streams, each with its own scratch, so that the tail of one sweep - the last workgroups of a pruned sweep run 2-3 ms
     // with the slots emptying - overlaps the next evaluations' sorts, packs and sweeps.  swap_lane(k) exchanges the active
     // resources with parked lane k; every routine keeps using ctx->stream / ctx->scratch_*.
     struct Lane {
         hipStream_t stream = nullptr;
-        pbn::dev_buf<char> part, q, misc, train, prune, pruneq, sort;
+        pbn::dev_buf<char> part, q, misc, train, prune, pruneq, sort, group;
         pbn::dev_buf<double> red, split, w;
         hipEvent_t fence = nullptr;
     };
@@ -159,7 +163,7 @@ struct pbn_ctx {
         std::swap(stream, alt.stream);
         std::swap(scratch_part, alt.part); std::swap(scratch_q, alt.q); std::swap(scratch_misc, alt.misc);
         std::swap(scratch_train, alt.train); std::swap(scratch_prune, alt.prune); std::swap(scratch_pruneq, alt.pruneq);
-        std::swap(scratch_sort, alt.sort); std::swap(scratch_red, alt.red); std::swap(scratch_split, alt.split); std::swap(scratch_w, alt.w);
+        std::swap(scratch_sort, alt.sort); std::swap(scratch_group, alt.group); std::swap(scratch_red, alt.red); std::swap(scratch_split, alt.split); std::swap(scratch_w, alt.w);
     }
     // the parked lanes wait for everything enqueued so far on the active one (e.g. the zeroing of a result buffer)
     void lanes_wait_for_stream(int n_parked) {

@@ -1,0 +1,591 @@
+// Grouped KDE evaluation (see kde_group.hpp): one launch chain for all (training set, test set) units of a batch of pools.
+//
+// Replaces, for the score engine's cross-validated / held-out CKDE terms, the per-(set, fold) chain of round 2
+//   prune_keys -> rocprim sort -> tile_box -> pack | prune_keys -> rocprim sort -> pack -> prepass -> sweep -> finish -> reduce
+// (kde_model.hip: kde_pack_train + kde_eval_enqueue; reference loop learning/scores/cv_likelihood.cpp:18-22 over
+//  factors/continuous/CKDE.hpp:256-287) by
+//   keys (all pools) -> ONE sort -> gather + region counts -> scan -> pack(train, all units) -> pack(query, all units)
+//   -> boxes -> prepass -> sweep (flat grid over all units) -> finish -> reduce
+// Stage by stage the arithmetic is the one of the single-unit chain (same whitening, same fragment layout, same sweep body,
+// same merge of the split partials); what changes is the ORDER of the rows inside a unit (a compaction of the pool's Morton
+// order instead of the unit's own Morton order - any order gives the same sums up to rounding, the integer offsets of the
+// sweep keep the 2^x error attached to the pair) and the prepass bound (position by counting instead of by key search).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "kde_group.hpp"
+#include "kde_kernels.hpp"
+#include "kde_model.hpp"
+
+namespace pbn {
+
+namespace {
+
+constexpr int GB = PBN_GROUP_BLOCK;
+constexpr int MORTON_BITS = 24;   // low bits of a sort key; the pool's index inside the batch sits above them
+#define PBN_GROUP_WINDOW 32        // training rows scanned on either side of a query's position (kde_kernels.hip: PBN_PRUNE_WINDOW)
+
+__host__ __device__ inline int group_key_bits(int kd) { return kd <= 1 ? 16 : MORTON_BITS / kd; }
+
+struct GDev {   // argument block of the block-wise kernels
+    const GPool* pools;
+    const GUnit* units;
+    const int32_t* blkpool;   // flat block -> pool
+    const void* base;         // table
+    int64_t ld;
+    uint32_t* keys;           // [E]
+    uint32_t* vals;           // [E] pool position of the element
+    double* xs;               // [E][xstride] rows in sorted order
+    uint8_t* reg;             // [E] region of the element
+    int32_t* blkcnt;          // [flat blocks][Rs]: rows of region r in the block -> (after the scan) before the block
+    char* arena;
+    int xstride, Rs;
+    int nunits;
+    int use_sum_bound;
+};
+
+__device__ __forceinline__ int region_of(const GPool& P, int pp) {
+    int lo = 0, hi = P.R;   // largest r with rb[r] <= pp
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.rb[mid] <= pp) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ---- keys: Morton order of pool-standardised coordinates -----------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(GB) void group_keys_kernel(GDev g) {
+    const int fb = blockIdx.x;
+    const GPool& P = g.pools[g.blkpool[fb]];
+    const int blk = fb - P.blk0;
+    const int p = blk * GB + (int)threadIdx.x;
+    if (blk >= P.nblk || p >= P.n) return;
+    const int64_t row = P.rows ? (int64_t)P.rows[P.row_base + p] : P.row_base + p;
+    const int d = P.d, kd = P.kd;
+    double xc[PBN_GROUP_MAX_D];
+    for (int j = 0; j < kd; ++j) xc[j] = (double)((const T*)g.base + (int64_t)P.cols[j] * g.ld)[row] - P.mug[j];
+    const int bits = group_key_bits(kd);
+    const double half = (double)(1 << (bits - 1)), top = (double)((1 << bits) - 1);
+    const double scale = bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0);   // cells of sigma / 16 (8, 4): the key range covers +-8 (4) sigma at 8 (6) bits
+    uint32_t key = 0;
+    for (int i = 0; i < kd; ++i) {
+        double u = 0.0;
+        for (int j = 0; j <= i; ++j) u = __builtin_fma(P.Wg[i * d + j], xc[j], u);
+        double c = __builtin_floor(u * scale) + half;
+        c = c < 0.0 ? 0.0 : (c > top ? top : c);
+        const uint32_t cell = (uint32_t)c;
+        for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);
+    }
+    g.keys[P.elem0 + p] = key | ((uint32_t)P.local << MORTON_BITS);
+    g.vals[P.elem0 + p] = (uint32_t)p;
+}
+
+// ---- gather the rows into sorted order, region of every element, rows per (block, region) -----------------------------------
+template <typename T>
+__global__ __launch_bounds__(GB) void group_gather_kernel(GDev g) {
+    __shared__ int cnt[PBN_GROUP_MAX_R];
+    const int fb = blockIdx.x;
+    const GPool& P = g.pools[g.blkpool[fb]];
+    const int blk = fb - P.blk0;
+    if (blk >= P.nblk) return;
+    if ((int)threadIdx.x < PBN_GROUP_MAX_R) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blk * GB + (int)threadIdx.x;
+    if (i < P.n) {
+        const int pp = (int)g.vals[P.elem0 + i];
+        const int64_t row = P.rows ? (int64_t)P.rows[P.row_base + pp] : P.row_base + pp;
+        double* x = g.xs + (P.elem0 + i) * g.xstride;
+        for (int j = 0; j < P.d; ++j) x[j] = (double)((const T*)g.base + (int64_t)P.cols[j] * g.ld)[row];
+        const int r = region_of(P, pp);
+        g.reg[P.elem0 + i] = (uint8_t)r;
+        atomicAdd(&cnt[r], 1);   // integer counts: the order of the additions does not matter
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < P.R) g.blkcnt[(int64_t)fb * g.Rs + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// ---- exclusive scan of the block counts, per (pool, region) ---------------------------------------------------------------
+__global__ __launch_bounds__(64) void group_scan_kernel(GDev g) {
+    const GPool& P = g.pools[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= P.R) return;
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int b0 = 0; b0 < P.nblk; b0 += 64) {
+        const int b = b0 + lane;
+        int32_t* cell = g.blkcnt + (int64_t)(P.blk0 + b) * g.Rs + r;
+        const int v = b < P.nblk ? *cell : 0;
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (b < P.nblk) *cell = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+}
+
+// whitened coordinates of one row, fragment stores shared by the two pack kernels (fp64 classic fragments, kde_kernels.hip
+// pack_rows_kernel): training side norms in C-row order + weights 2^norm, query side norms by row
+__device__ __forceinline__ void pack_store(const GUnit& U, char* arena, const double* x, int d, int KS, int dest, bool query, int32_t tpos) {
+    const int tile = dest >> 4, idx = dest & 15;
+    double xc[PBN_GROUP_MAX_D];
+    for (int j = 0; j < d; ++j) xc[j] = x[j] - U.mu[j];
+    double* pack = (double*)(arena + (query ? U.bpack : U.apack));
+    double* zrow = (double*)(arena + (query ? U.zq : U.zs)) + (int64_t)dest * d;
+    double nrm = 0.0;
+    for (int c = 0; c < KS * 4; ++c) {
+        double z = 0.0;
+        if (c < d) {
+            for (int j = 0; j <= c; ++j) z = __builtin_fma(U.W[c * d + j], xc[j], z);
+            zrow[c] = z;
+        }
+        nrm = __builtin_fma(z, z, nrm);
+        pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = z;
+    }
+    const double nv = -0.5 * nrm;
+    if (d < KS * 4) pack[((int64_t)tile * KS + (d >> 2)) * 64 + (d & 3) * 16 + idx] = query ? 1.0 : nv;   // norm in the free K slot (FOLD)
+    if (query) {
+        ((double*)(arena + U.ny))[(int64_t)tile * 16 + idx] = nv;
+        ((int32_t*)(arena + U.qpos))[dest] = tpos;
+    } else {
+        double* np = (double*)(arena + U.npack);
+        const int lg = idx & 3, i = idx >> 2;
+        np[(int64_t)tile * 16 + lg * 4 + i] = nv;
+        np[(int64_t)U.ntiles * 16 + (int64_t)tile * 16 + lg * 4 + i] = nv < -1000.0 ? (double)NAN : exp2(nv);   // weights of the WMUL sweep
+    }
+}
+
+// ---- training side: grid (flat blocks, units per pool).  A unit's training rows are the elements of its regions, in the pool's
+// order: destination = number of such elements before it (block offsets from the scan + a ballot inside the block) ---------------
+__global__ __launch_bounds__(GB) void group_pack_train_kernel(GDev g) {
+    __shared__ int wcount[GB / 64];
+    const int fb = blockIdx.x;
+    const GPool& P = g.pools[g.blkpool[fb]];
+    const int blk = fb - P.blk0;
+    if (blk >= P.nblk || (int)blockIdx.y >= P.nunits) return;
+    const GUnit& U = g.units[P.unit0 + blockIdx.y];
+    const int i = blk * GB + (int)threadIdx.x;
+    const bool valid = i < P.n;
+    const int r = valid ? (int)g.reg[P.elem0 + i] : 0;
+    const bool in = valid && ((U.train_mask >> r) & 1ull);
+    int base = 0;
+    for (int rr = 0; rr < P.R; ++rr)
+        if ((U.train_mask >> rr) & 1ull) base += g.blkcnt[(int64_t)fb * g.Rs + rr];
+    const unsigned long long b = __ballot(in);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wcount[wave] = __builtin_popcountll(b);
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) base += wcount[w];
+    if (!in) return;
+    const int dest = base + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+    pack_store(U, g.arena, g.xs + (P.elem0 + i) * g.xstride, P.d, (P.d + 3) / 4, dest, false, 0);
+}
+
+// ---- query side + all padding: grid (flat blocks).  Every element is a test row of at most one unit of its pool (the unit whose
+// test region is the element's); its destination is its rank inside the region, and the number of the unit's TRAINING rows
+// before it - its position in the unit's training order - is what the prepass starts its neighbour scan from -------------------
+__global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
+    __shared__ unsigned long long ball[GB / 64][PBN_GROUP_MAX_R];
+    const int fb = blockIdx.x;
+    const GPool& P = g.pools[g.blkpool[fb]];
+    const int blk = fb - P.blk0;
+    const int d = P.d, KS = (d + 3) / 4;
+    if (blk >= P.nblk) {
+        // the pool's padding block: rows N .. 16 ntiles of every unit's training pack (norm -1e30: their terms vanish; weight
+        // 0), rows nq .. 16 nqtiles of its query pack (coordinates 0, norm 0: finite sums nobody reads)
+        for (int v = threadIdx.x; v < P.nunits * 32; v += GB) {
+            const GUnit& U = g.units[P.unit0 + (v >> 5)];
+            const int j = v & 31;
+            const bool query = j >= 16;
+            const int row = (query ? U.nq : U.N) + (j & 15);
+            if (row >= (query ? U.nqtiles : U.ntiles) * 16) continue;
+            const int tile = row >> 4, idx = row & 15;
+            double* pack = (double*)(g.arena + (query ? U.bpack : U.apack));
+            for (int c = 0; c < KS * 4; ++c) pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = 0.0;
+            if (d < KS * 4) pack[((int64_t)tile * KS + (d >> 2)) * 64 + (d & 3) * 16 + idx] = query ? 1.0 : -1e30;
+            if (query) {
+                ((double*)(g.arena + U.ny))[(int64_t)tile * 16 + idx] = 0.0;
+            } else {
+                double* np = (double*)(g.arena + U.npack);
+                const int lg = idx & 3, i = idx >> 2;
+                np[(int64_t)tile * 16 + lg * 4 + i] = -1e30;
+                np[(int64_t)U.ntiles * 16 + (int64_t)tile * 16 + lg * 4 + i] = 0.0;
+            }
+        }
+        return;
+    }
+    const int i = blk * GB + (int)threadIdx.x;
+    const bool valid = i < P.n;
+    const int r = valid ? (int)g.reg[P.elem0 + i] : -1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int rr = 0; rr < P.R; ++rr) {
+        const unsigned long long b = __ballot(r == rr);
+        if (lane == 0) ball[wave][rr] = b;
+    }
+    __syncthreads();
+    if (!valid) return;
+    const int uidx = P.test_unit[r];
+    if (uidx < 0) return;
+    const GUnit& U = g.units[P.unit0 + uidx];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto before = [&](int rr) {   // elements of region rr before element i
+        int c = g.blkcnt[(int64_t)fb * g.Rs + rr];
+        for (int w = 0; w < wave; ++w) c += __builtin_popcountll(ball[w][rr]);
+        return c + __builtin_popcountll(ball[wave][rr] & lt);
+    };
+    const int dest = before(r);
+    int tpos = 0;
+    for (int rr = 0; rr < P.R; ++rr)
+        if ((U.train_mask >> rr) & 1ull) tpos += before(rr);
+    pack_store(U, g.arena, g.xs + (P.elem0 + i) * g.xstride, d, KS, dest, true, tpos);
+}
+
+// ---- bounding boxes of the 16-row training tiles: grid (blocks of 256 padded rows, units) ---------------------------------------
+__global__ __launch_bounds__(256) void group_tile_box_kernel(GDev g) {
+    const GUnit& U = g.units[blockIdx.y];
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (blockIdx.x * 256 >= U.ntiles * 16) return;
+    const GPool& P = g.pools[U.pool];
+    const int d = P.d, pd = P.kd;
+    const bool valid = r < U.N;
+    double lo[PBN_PRUNE_PD], hi[PBN_PRUNE_PD];
+#pragma unroll
+    for (int k = 0; k < PBN_PRUNE_PD; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    if (valid) {
+        const double* z = (const double*)(g.arena + U.zs) + (int64_t)r * d;
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k)
+            if (k < pd) { const double v = z[k]; if (v == v) { lo[k] = v; hi[k] = v; } }
+    }
+    for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k) {
+            const double l = __shfl_xor(lo[k], off), h = __shfl_xor(hi[k], off);
+            lo[k] = l < lo[k] ? l : lo[k];
+            hi[k] = h > hi[k] ? h : hi[k];
+        }
+    }
+    if ((threadIdx.x & 15) == 0 && r < U.ntiles * 16) {
+        double* box = (double*)(g.arena + U.box) + (int64_t)(r >> 4) * 2 * pd;
+        for (int k = 0; k < pd; ++k) { box[k] = lo[k]; box[pd + k] = hi[k]; }
+    }
+}
+
+// ---- per query: a lower bound of its largest exponent (and of its whole sum) from the training rows around its position in the
+// training order; per 16-query tile the smallest bound and the box: grid (blocks of 256 padded queries, units) -----------------
+__global__ __launch_bounds__(256) void group_prepass_kernel(GDev g) {
+    const GUnit& U = g.units[blockIdx.y];
+    const int q = blockIdx.x * 256 + (int)threadIdx.x;
+    if (blockIdx.x * 256 >= U.nqtiles * 16) return;
+    const GPool& P = g.pools[U.pool];
+    const int d = P.d, pd = P.kd;
+    const bool valid = q < U.nq;
+    double z[PBN_GROUP_MAX_D];
+    double best = -INFINITY, acc = 0.0;
+    if (valid) {
+        const double* zp = (const double*)(g.arena + U.zq) + (int64_t)q * d;
+        for (int k = 0; k < d; ++k) z[k] = zp[k];
+        const int tpos = ((const int32_t*)(g.arena + U.qpos))[q];
+        const int b = tpos - PBN_GROUP_WINDOW > 0 ? tpos - PBN_GROUP_WINDOW : 0, e = tpos + PBN_GROUP_WINDOW < U.N ? tpos + PBN_GROUP_WINDOW : U.N;
+        const double* zt = (const double*)(g.arena + U.zs);
+        for (int t = b; t < e; ++t) {
+            double d2 = 0.0;
+            for (int k = 0; k < d; ++k) { const double dd = zt[(int64_t)t * d + k] - z[k]; d2 = __builtin_fma(dd, dd, d2); }
+            const double ex = -0.5 * d2;
+            if (ex > best) { acc = acc * exp2(best - ex) + 1.0; best = ex; }
+            else acc += exp2(ex - best);
+        }
+    }
+    if (q < U.nqtiles * 16) ((double*)(g.arena + U.qlb))[q] = valid ? best : -INFINITY;
+    // the pruning threshold may stand on the bound of the query's SUM (>= the sum over the scanned rows): what a skipped tile
+    // could add is then below 2^-margin of the sum itself, not merely of its largest term
+    double thr = valid ? (g.use_sum_bound && acc > 0.0 ? best + log2(acc) : best) : INFINITY;
+    double lob[PBN_PRUNE_PD], hib[PBN_PRUNE_PD];
+#pragma unroll
+    for (int k = 0; k < PBN_PRUNE_PD; ++k) { lob[k] = (valid && k < pd) ? z[k] : INFINITY; hib[k] = (valid && k < pd) ? z[k] : -INFINITY; }
+    for (int off = 1; off < 16; off <<= 1) {
+        const double o = __shfl_xor(thr, off);
+        thr = o < thr ? o : thr;
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k) {
+            const double l = __shfl_xor(lob[k], off), h = __shfl_xor(hib[k], off);
+            lob[k] = l < lob[k] ? l : lob[k];
+            hib[k] = h > hib[k] ? h : hib[k];
+        }
+    }
+    if (valid && (threadIdx.x & 15) == 0) {
+        const int tile = q >> 4;
+        ((double*)(g.arena + U.qthr))[tile] = thr;
+        double* qb = (double*)(g.arena + U.qbox) + (int64_t)tile * 2 * pd;
+        for (int k = 0; k < pd; ++k) { qb[k] = lob[k]; qb[pd + k] = hib[k]; }
+    }
+}
+
+// ---- merge the split partials per query (kde_finish_kernel's arithmetic), block sums: grid (blocks of 256 queries, units) ---------
+__global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
+    constexpr double LN2 = 0.693147180559945309417232121458;
+    const GUnit& U = g.units[blockIdx.y];
+    if (blockIdx.x * 256 >= U.nq) return;
+    const int q = blockIdx.x * 256 + (int)threadIdx.x;
+    double val = 0.0;
+    if (q < U.nq) {
+        const double* p = (const double*)(g.arena + U.part) + (int64_t)q * 2;
+        const int64_t stride = (int64_t)U.nqtiles * 16 * 2;
+        double m = p[0];
+        for (int sp = 1; sp < U.nsplit; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
+        double s = 0.0;
+#pragma unroll 4
+        for (int sp = 0; sp < U.nsplit; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
+        val = U.lognorm + LN2 * (m + log2(s));
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = val;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ((double*)(g.arena + U.bsum))[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void group_reduce_kernel(GDev g, double* out) {
+    const GUnit& U = g.units[blockIdx.x];
+    const double* in = (const double*)(g.arena + U.bsum);
+    const int n = (U.nq + 255) / 256;
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += in[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[U.sum_slot] = red[0];
+}
+
+int env_int(const char* name, int dflt) {
+    const char* s = std::getenv(name);
+    return s && *s ? std::atoi(s) : dflt;
+}
+
+size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+// one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
+void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out) {
+    const int np = (int)(p1 - p0);
+    // ---- layout ----------------------------------------------------------------------------------------------------------
+    std::vector<GPool> pools(np);
+    std::vector<GUnit> units;
+    int64_t E = 0;
+    int B = 0, Rs = 1, xstride = 1, max_units = 1;
+    for (int k = 0; k < np; ++k) {
+        GPool P = b.pools[order[p0 + k]];
+        P.local = k;
+        P.elem0 = E;
+        P.nblk = (P.n + GB - 1) / GB;
+        P.blk0 = B;
+        const int u0 = P.unit0;
+        P.unit0 = (int)units.size();
+        for (int u = 0; u < P.nunits; ++u) {
+            GUnit U = b.units[u0 + u];
+            U.pool = k;
+            units.push_back(U);
+        }
+        E += P.n;
+        B += P.nblk + 1;   // + the padding block
+        Rs = std::max(Rs, P.R);
+        xstride = std::max(xstride, P.d);
+        max_units = std::max(max_units, P.nunits);
+        pools[k] = P;
+    }
+    const int nu = (int)units.size();
+    const int d0 = pools[0].d, KS = (d0 + 3) / 4;
+    const bool fold = d0 % 4 != 0;
+    static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
+    int64_t total_wg = 0;
+    int max_ntiles = 0, max_nqtiles = 0, max_nq = 0;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return (int64_t)o; };
+    // tables first
+    const int64_t o_pools = carve((size_t)np * sizeof(GPool)), o_units = carve((size_t)nu * sizeof(GUnit)),
+                  o_sweep = carve((size_t)nu * sizeof(GSweepUnit)), o_blkpool = carve((size_t)B * sizeof(int32_t));
+    for (GUnit& U : units) {
+        const GPool& P = pools[U.pool];
+        const int d = P.d, pd = P.kd;
+        U.ntiles = (U.N + 15) / 16;
+        U.nqtiles = (U.nq + 15) / 16;
+        const int nsplit0 = std::max(1, (U.ntiles + split_tiles - 1) / split_tiles);
+        U.tps = (U.ntiles + nsplit0 - 1) / nsplit0;
+        U.nsplit = (U.ntiles + U.tps - 1) / U.tps;
+        const int qblocks = (U.nqtiles + PBN_QG_PRUNE - 1) / PBN_QG_PRUNE;
+        U.nwg = qblocks * U.nsplit;
+        U.wg0 = total_wg;
+        total_wg += ((int64_t)U.nwg + 63) / 64 * 64;
+        max_ntiles = std::max(max_ntiles, U.ntiles);
+        max_nqtiles = std::max(max_nqtiles, U.nqtiles);
+        max_nq = std::max(max_nq, U.nq);
+        U.apack = carve((size_t)U.ntiles * KS * 64 * 8);
+        U.npack = carve((size_t)U.ntiles * 16 * 8 * 2);
+        U.zs = carve((size_t)U.N * d * 8 + 8);
+        U.box = carve((size_t)U.ntiles * 2 * pd * 8);
+        U.bpack = carve((size_t)U.nqtiles * KS * 64 * 8);
+        U.ny = carve((size_t)U.nqtiles * 16 * 8);
+        U.zq = carve((size_t)U.nq * d * 8 + 8);
+        U.qpos = carve((size_t)U.nqtiles * 16 * 4);
+        U.qbox = carve((size_t)U.nqtiles * 2 * pd * 8);
+        U.qthr = carve((size_t)U.nqtiles * 8);
+        U.qlb = carve((size_t)U.nqtiles * 16 * 8);
+        U.part = carve((size_t)U.nsplit * U.nqtiles * 16 * 2 * 8);
+        U.bsum = carve((size_t)((U.nq + 255) / 256 + 1) * 8);
+    }
+    const int64_t o_wgunit = carve((size_t)(total_wg / 64 + 1) * sizeof(int32_t));
+    const size_t table_end = off;
+    (void)table_end;
+    const int64_t o_keys_a = carve((size_t)E * 4), o_keys_b = carve((size_t)E * 4), o_vals_a = carve((size_t)E * 4), o_vals_b = carve((size_t)E * 4),
+                  o_xs = carve((size_t)E * xstride * 8), o_reg = carve((size_t)E), o_blkcnt = carve((size_t)B * Rs * 4);
+    ctx->scratch_group.reserve(off + 256);
+    char* arena = ctx->scratch_group.p;
+
+    // ---- host tables -> one upload ---------------------------------------------------------------------------------------
+    // (the per-unit buffers were carved between the tables; the upload covers pools | units | sweep records | blkpool, then the
+    //  workgroup table separately)
+    std::vector<char> h((size_t)o_blkpool + al256((size_t)B * 4));
+    std::memcpy(h.data() + o_pools, pools.data(), (size_t)np * sizeof(GPool));
+    std::memcpy(h.data() + o_units, units.data(), (size_t)nu * sizeof(GUnit));
+    GSweepUnit* hs = (GSweepUnit*)(h.data() + o_sweep);
+    for (int u = 0; u < nu; ++u) {
+        const GUnit& U = units[u];
+        GSweepUnit& s = hs[u];
+        s.Apack = arena + U.apack; s.nxpack = arena + U.npack; s.Bpack = arena + U.bpack; s.nypack = arena + U.ny;
+        s.tile_box = (const double*)(arena + U.box); s.qtile_box = (const double*)(arena + U.qbox);
+        s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
+        s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
+        s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
+    }
+    int32_t* hb = (int32_t*)(h.data() + o_blkpool);
+    for (int k = 0; k < np; ++k)
+        for (int j = 0; j <= pools[k].nblk; ++j) hb[pools[k].blk0 + j] = k;
+    std::vector<int32_t> hw((size_t)(total_wg / 64 + 1));
+    for (int u = 0; u < nu; ++u) {
+        const int64_t w0 = units[u].wg0 / 64, w1 = w0 + ((int64_t)units[u].nwg + 63) / 64;
+        for (int64_t w = w0; w < w1; ++w) hw[(size_t)w] = u;
+    }
+    hipStream_t st = ctx->stream;
+    // the tables sit at the head of the arena (the units' buffers were carved behind o_blkpool); the host copies stay alive on the
+    // context until the caller has synchronised (pbn_ctx::drop_staged)
+    HIP_CHECK(hipMemcpyAsync(arena, h.data(), h.size(), hipMemcpyHostToDevice, st));
+    std::vector<char> hwb((const char*)hw.data(), (const char*)hw.data() + hw.size() * sizeof(int32_t));
+    HIP_CHECK(hipMemcpyAsync(arena + o_wgunit, hwb.data(), hwb.size(), hipMemcpyHostToDevice, st));
+    ctx->staged.push_back(std::move(h));
+    ctx->staged.push_back(std::move(hwb));
+
+    GDev g{};
+    g.pools = (const GPool*)(arena + o_pools); g.units = (const GUnit*)(arena + o_units); g.blkpool = (const int32_t*)(arena + o_blkpool);
+    g.base = t->data; g.ld = t->ld;
+    g.keys = (uint32_t*)(arena + o_keys_a); g.vals = (uint32_t*)(arena + o_vals_a);
+    g.xs = (double*)(arena + o_xs); g.reg = (uint8_t*)(arena + o_reg); g.blkcnt = (int32_t*)(arena + o_blkcnt);
+    g.arena = arena; g.xstride = xstride; g.Rs = Rs; g.nunits = nu;
+    static const int sum_bound = env_int("PBN_GROUP_SUM_BOUND", 1);
+    g.use_sum_bound = sum_bound;
+
+    const bool f64 = t->dtype == PBN_F64;
+    {
+        KernelTimer kt(ctx, PBN_K_PACK);
+        if (f64) hipLaunchKernelGGL(group_keys_kernel<double>, dim3((unsigned)B), dim3(GB), 0, st, g);
+        else hipLaunchKernelGGL(group_keys_kernel<float>, dim3((unsigned)B), dim3(GB), 0, st, g);
+        HIP_CHECK(hipGetLastError());
+        int pool_bits = 0;
+        while ((1 << pool_bits) < np) ++pool_bits;
+        sort_keys(ctx->scratch_sort, (const uint32_t*)(arena + o_keys_a), (uint32_t*)(arena + o_keys_b), (const int32_t*)(arena + o_vals_a),
+                  (int32_t*)(arena + o_vals_b), E, MORTON_BITS + pool_bits, st);
+        g.keys = (uint32_t*)(arena + o_keys_b); g.vals = (uint32_t*)(arena + o_vals_b);
+        if (f64) hipLaunchKernelGGL(group_gather_kernel<double>, dim3((unsigned)B), dim3(GB), 0, st, g);
+        else hipLaunchKernelGGL(group_gather_kernel<float>, dim3((unsigned)B), dim3(GB), 0, st, g);
+        hipLaunchKernelGGL(group_scan_kernel, dim3((unsigned)Rs, (unsigned)np), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(group_pack_train_kernel, dim3((unsigned)B, (unsigned)max_units), dim3(GB), 0, st, g);
+        hipLaunchKernelGGL(group_pack_query_kernel, dim3((unsigned)B), dim3(GB), 0, st, g);
+        hipLaunchKernelGGL(group_tile_box_kernel, dim3((unsigned)((max_ntiles * 16 + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(group_prepass_kernel, dim3((unsigned)((max_nqtiles * 16 + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        KernelTimer kt(ctx, PBN_K_SWEEP);
+        GSweepArgs sa{};
+        sa.units = (const GSweepUnit*)(arena + o_sweep); sa.wg_unit = (const int32_t*)(arena + o_wgunit); sa.total_wg = total_wg;
+        sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
+        sa.prune_margin = prune_margin(PBN_F64);
+        launch_sweep_grouped(sa, PBN_F64, KS, st);
+    }
+    {
+        KernelTimer kt(ctx, PBN_K_FINISH);
+        hipLaunchKernelGGL(group_finish_kernel, dim3((unsigned)((max_nq + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(group_reduce_kernel, dim3((unsigned)nu), dim3(256), 0, st, g, dev_out);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+// bytes of arena a pool needs (its element arrays + its units' buffers), for chunking
+size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
+    const int d = P.d, KS = (d + 3) / 4, pd = P.kd;
+    size_t s = (size_t)P.n * (16 + (size_t)PBN_GROUP_MAX_D * 8 + 1) + (size_t)((P.n + GB - 1) / GB + 1) * (PBN_GROUP_MAX_R * 4 + 4) + sizeof(GPool) + 4096;
+    for (int u = 0; u < P.nunits; ++u) {
+        const GUnit& U = b.units[P.unit0 + u];
+        const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
+        s += nt * KS * 512 + nt * 256 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 512 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
+             nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + (nsplit + 1) * nqt * 256 + (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) +
+             (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
+    }
+    return s;
+}
+
+}  // namespace
+
+bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
+    const int on = env_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
+    // fp64 classic fragments; sets whose boxes cover every dimension (no subsample bound needed); the pruned-sweep shapes
+    return on && dtype == PBN_F64 && d >= 1 && d <= std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), 4) && R >= 1 && R <= PBN_GROUP_MAX_R &&
+           kde_prune_applies(dtype, d, n_min);
+}
+
+void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums) {
+    if (b.pools.empty()) return;
+    if (t->dtype != PBN_F64) throw invalid_error("grouped KDE evaluation: fp64 tables only");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    for (const GPool& P : b.pools) {
+        if (P.d < 1 || P.d > PBN_GROUP_MAX_D || P.kd < 1 || P.kd > PBN_PRUNE_PD || P.kd > P.d || P.R < 1 || P.R > PBN_GROUP_MAX_R || P.n < 1)
+            throw invalid_error("grouped KDE evaluation: bad pool");
+        for (int u = 0; u < P.nunits; ++u) {
+            const GUnit& U = b.units[P.unit0 + u];
+            if (U.N < 1 || U.nq < 1) throw invalid_error("grouped KDE evaluation: empty unit");
+        }
+    }
+    // pools of one sweep shape together (KS, norm in a K slot or as weights), larger sets first
+    std::vector<int> order(b.pools.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    auto variant = [&](int i) { const int d = b.pools[i].d; return ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
+    const size_t budget = (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 4096)) << 20;
+    const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
+    const int max_pools = std::min(256, std::max(1, env_int("PBN_GROUP_MAX_POOLS", 256)));
+    size_t p0 = 0;
+    while (p0 < order.size()) {
+        size_t p1 = p0, bytes = 0;
+        int64_t elems = 0;
+        while (p1 < order.size() && variant(order[p1]) == variant(order[p0]) && (int)(p1 - p0) < max_pools) {
+            const size_t pb = pool_bytes(b, b.pools[order[p1]], split_tiles);
+            if (p1 > p0 && (bytes + pb > budget || elems + b.pools[order[p1]].n > 0x7ff00000ll)) break;
+            bytes += pb;
+            elems += b.pools[order[p1]].n;
+            ++p1;
+        }
+        run_chunk(ctx, t, b, order, p0, p1, dev_out_sums);
+        p0 = p1;
+    }
+}
+
+}  // namespace pbn

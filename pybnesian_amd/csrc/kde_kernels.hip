@@ -24,6 +24,7 @@
 //                 write logl and/or a deterministic tree-reduced slogl.
 #include "common.hpp"
 #include "kde_kernels.hpp"
+#include "kde_group.hpp"
 
 #include <cstdlib>
 #include <type_traits>
@@ -494,15 +495,17 @@ constexpr int sweep_block_threads(bool prune) { return prune ? 64 : 256; }
 // with the splits taken from both ends of the Morton order inwards: the corner splits - sparse regions, where a query's
 // whole neighbourhood lies in its own split and the workgroup visits nearly all of its tiles - start first.  Pure placement.
 // (Measured and dropped: every query group's nearest splits first - all splits in flight at once, the L2 sharing is gone.)
-__device__ __forceinline__ void pruned_block(const SweepArgs& a, int groups_per_block, int& qx, int& split) {
+__device__ __forceinline__ void pruned_block(const SweepArgs& a, int groups_per_block, unsigned b, int& qx, int& split) {
     const unsigned Gq = (unsigned)((a.nqtiles + groups_per_block - 1) / groups_per_block), Gs = (unsigned)a.nsplit_grid;
-    const unsigned b = blockIdx.x, k = b / Gq;
+    const unsigned k = b / Gq;
     qx = (int)(b % Gq);
     split = (k & 1u) ? (int)(Gs - 1 - (k >> 1)) : (int)(k >> 1);
 }
 
-template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
-__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_WAVES : 2) void kde_sweep_kernel(SweepArgs a) {
+// The sweep proper.  `bid` is the workgroup's index inside ITS sweep: blockIdx.x for a stand-alone launch, the offset inside
+// the unit for the grouped launches (kde_sweep_group_kernel), where `a` was assembled from the unit's record.
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL>
+__device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigned bid) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // waves per workgroup
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_W
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    if (PRUNE) pruned_block(a, WPB * QG, qx, split);
+    if (PRUNE) pruned_block(a, WPB * QG, bid, qx, split);
     else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;  // no barriers in this kernel: idle waves just leave
@@ -836,6 +839,30 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_W
     }
 }
 
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_WAVES : 2) void kde_sweep_kernel(SweepArgs a) {
+    kde_sweep_body<T, KS, COND, QG, FOLD, PRUNE, WMUL>(a, blockIdx.x);
+}
+
+// Grouped launch (kde_group.hip): the flat grid covers the sweeps of MANY units back to back, unit-major, every unit's share
+// rounded up to 64 workgroups so that one table entry per 64 workgroups names the unit.  Pruned plain fp64 sweeps only.
+template <typename T, int KS, int QG, bool FOLD, bool WMUL>
+__global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) void kde_sweep_group_kernel(GSweepArgs g) {
+    const int u = g.wg_unit[blockIdx.x >> 6];
+    const GSweepUnit& su = g.units[u];
+    const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
+    if (bid >= (unsigned)su.nwg) return;
+    SweepArgs a;
+    a.Apack = su.Apack; a.nxpack = su.nxpack; a.Axpack = nullptr;
+    a.Bpack = su.Bpack; a.nypack = su.nypack; a.Bxpack = nullptr; a.Bxnorm = nullptr;
+    a.ntiles = su.ntiles; a.nqtiles = su.nqtiles; a.tiles_per_split = su.tps;
+    a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul;
+    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
+    a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0;
+    kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL>(a, bid);
+}
+
 // ------------------------------------------------------------------------------------------------
 // kde_sweep_sparse (fp64, unconditional): the DP units are the binding resource of the fp64 sweep and the
 // 2^x polynomial is more than half of their work, while for realistic bandwidths most (train, query) pairs
@@ -1109,7 +1136,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    if (PRUNE) pruned_block(a, WPB * QG, qx, split); else xcd_block(qx, split);
+    if (PRUNE) pruned_block(a, WPB * QG, blockIdx.x, qx, split); else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
@@ -1911,6 +1938,23 @@ void launch_sweep(const SweepArgs& a_in, int dtype, int KS, bool cond, int nspli
     } else {
         if (cond) launch_sweep_t<float, true>(a, KS, grid, st); else launch_sweep_t<float, false>(a, KS, grid, st);
     }
+}
+
+// fold: d mod 4 != 0 (norm in a free K slot); wmul: d mod 4 == 0 (norms as weights) - the two pruned plain fp64 shapes
+void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st) {
+    if (g.total_wg == 0) return;
+    if (dtype != PBN_F64 || KS < 1 || KS > 2 || (g.fold != 0) == (g.wmul != 0)) throw invalid_error("grouped sweeps: fp64, at most 8 whitened dimensions");
+    if (g.total_wg > 0x7fffffffll) throw invalid_error("grouped sweeps: grid too large");
+    constexpr int QGP = PBN_QG_PRUNE;
+    const dim3 grid((unsigned)g.total_wg), block(sweep_block_threads(true));
+    if (g.fold) {
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, true, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((kde_sweep_group_kernel<double, 2, QGP, true, false>), grid, block, 0, st, g);
+    } else {
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, false, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((kde_sweep_group_kernel<double, 2, QGP, false, true>), grid, block, 0, st, g);
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st, double* dev_sum_marg_out) {

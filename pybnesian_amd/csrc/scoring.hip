@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "hostmath.hpp"
+#include "kde_group.hpp"
 #include "kde_model.hpp"
 #include "scoring_internal.hpp"
 #include "stats_kernels.hpp"
@@ -864,12 +865,9 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             dev_buf<double> dsums(std::max<size_t>(1, nslots));
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, nslots) * sizeof(double), ctx->stream));
             auto align = [](size_t x) { return (x + 255) / 256 * 256; };
-            // independent evaluations alternate between the context's two issue lanes (common.hpp)
-            const int lanes = (work.size() > 1 && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
-            if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
-            size_t wi = 0;
-            for (const Work& w : work) {
-                LaneSwitch lane(ctx, (int)(wi++ % (size_t)lanes));
+            // host side of one evaluation: columns, training moments of the region, bandwidth, whitening (KdeModel without packs)
+            struct Prep { KdeModel m; std::vector<int> use; int64_t row0, n0, row1, te0, te_n, ntrain; };
+            auto prepare = [&](const Work& w, Prep& pr) {
                 const int c = w.cand;
                 const int p = par_off[c + 1] - par_off[c], d = p + 1;
                 cols.resize(d);
@@ -877,44 +875,124 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                 for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
                 mu.resize(d); sse.resize((size_t)d * d); H.resize((size_t)d * d);
                 const Stats* tr = &sd->all;
-                int64_t row0 = 0, n0 = sd->n_cv, row1 = 0, te0 = sd->n_cv, te_n = sd->n_hold;
+                pr.row0 = 0; pr.n0 = sd->n_cv; pr.row1 = 0; pr.te0 = sd->n_cv; pr.te_n = sd->n_hold;
                 if (cv) {
                     stats_minus(sd->all, sd->fold[w.f], train);
                     tr = &train;
-                    n0 = sd->limits[w.f]; row1 = sd->limits[w.f + 1];
-                    te0 = sd->limits[w.f]; te_n = sd->limits[w.f + 1] - sd->limits[w.f];
+                    pr.n0 = sd->limits[w.f]; pr.row1 = sd->limits[w.f + 1];
+                    pr.te0 = sd->limits[w.f]; pr.te_n = sd->limits[w.f + 1] - sd->limits[w.f];
                 }
+                pr.ntrain = tr->N;
                 subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
                 const double inv = 1.0 / (double)(tr->N - 1);
                 for (auto& x : sse) x *= inv;  // covariance
                 bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
-                KdeModel m;
-                const int* use_cols = cols.data();
                 if (w.mode == 2) {            // KDE of the parents with the bandwidth block H[1:, 1:]
                     std::vector<double> Hm((size_t)p * p);
                     for (int j = 0; j < p; ++j)
                         for (int i = 0; i < p; ++i) Hm[i + (size_t)j * p] = H[(i + 1) + (size_t)(j + 1) * d];
-                    kde_prepare(m, sd->dtype, p, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
-                    use_cols = cols.data() + 1;
+                    kde_prepare(pr.m, sd->dtype, p, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
+                    pr.use.assign(cols.begin() + 1, cols.end());
                 } else {
-                    kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, w.mode == 0, mu.data());
+                    kde_prepare(pr.m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, w.mode == 0, mu.data());
+                    pr.use = cols;
                 }
-                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
+            };
+            // ---- grouped evaluation (kde_group.hip): the plain terms whose shape qualifies are collected into pools - one per
+            // variable set, its units the regions asked for - and evaluated by ONE launch chain per batch of pools ---------------
+            GroupBatch gb;
+            std::vector<std::vector<GUnit>> pool_units;
+            std::map<std::vector<int>, int> pool_of;                      // [m, sorted columns...] -> pool
+            std::vector<char> grouped(work.size(), 0);
+            const int R = cv ? sd->k : 2;
+            const int64_t min_train = cv ? sd->n_cv - (sd->limits[1] - sd->limits[0]) : sd->n_cv;
+            for (size_t wi = 0; wi < work.size(); ++wi) {
+                const Work& w = work[wi];
+                if (w.mode == 0) continue;
+                const int p = par_off[w.cand + 1] - par_off[w.cand];
+                const int dims = w.mode == 2 ? p : p + 1;
+                if (!kde_group_applies(sd->dtype, dims, min_train, R)) continue;
+                Prep pr;
+                prepare(w, pr);
+                std::vector<int> key(pr.use);
+                std::sort(key.begin(), key.end());
+                key.insert(key.begin(), p + 1);
+                auto it = pool_of.find(key);
+                int pi;
+                if (it == pool_of.end()) {
+                    pi = (int)gb.pools.size();
+                    pool_of[key] = pi;
+                    GPool P{};
+                    P.rows = nullptr; P.row_base = 0;
+                    P.n = (int32_t)(cv ? sd->n_cv : sd->n_cv + sd->n_hold);
+                    P.R = R; P.d = dims; P.kd = std::min(dims, 4);
+                    if (cv) for (int f = 0; f <= sd->k; ++f) P.rb[f] = sd->limits[f];
+                    else { P.rb[0] = 0; P.rb[1] = (int32_t)sd->n_cv; P.rb[2] = (int32_t)(sd->n_cv + sd->n_hold); }
+                    for (int r = 0; r < PBN_GROUP_MAX_R; ++r) P.test_unit[r] = -1;
+                    for (int i = 0; i < dims; ++i) P.cols[i] = pr.use[i];
+                    // pool-level standardisation for the Morton keys: L^-1 of the covariance of the whole CV / training region
+                    std::vector<double> gm(dims), gs((size_t)dims * dims), L((size_t)dims * dims), Li((size_t)dims * dims);
+                    subset_moments(sd, sd->all, pr.use.data(), dims, gm.data(), gs.data());
+                    for (auto& x : gs) x /= (double)std::max<int64_t>(1, sd->all.N - 1);
+                    if (!hm::cholesky(gs.data(), dims, L.data())) throw singular_error("KDE: covariance matrix is not positive-definite");
+                    hm::lower_inverse(L.data(), dims, Li.data());
+                    for (int i = 0; i < dims; ++i) {
+                        P.mug[i] = gm[i];
+                        for (int j = 0; j < dims; ++j) P.Wg[i * dims + j] = j <= i ? Li[i + (size_t)j * dims] : 0.0;
+                    }
+                    gb.pools.push_back(P);
+                    pool_units.emplace_back();
+                } else {
+                    pi = it->second;
+                }
+                GUnit U{};
+                U.test_region = cv ? w.f : 1;
+                U.train_mask = cv ? (((R >= 64) ? ~0ull : ((1ull << R) - 1ull)) & ~(1ull << w.f)) : 1ull;
+                U.N = (int32_t)pr.ntrain; U.nq = (int32_t)pr.te_n;
+                U.lognorm = pr.m.lognorm;
+                for (int i = 0; i < dims * dims; ++i) U.W[i] = pr.m.W[i];
+                for (int i = 0; i < dims; ++i) U.mu[i] = pr.m.mu[i];
+                U.sum_slot = w.mode == 2 ? w.slot_m : w.slot_j;
+                gb.pools[pi].test_unit[U.test_region] = (int32_t)pool_units[pi].size();
+                pool_units[pi].push_back(U);
+                grouped[wi] = 1;
+            }
+            for (size_t pi = 0; pi < gb.pools.size(); ++pi) {
+                gb.pools[pi].unit0 = (int32_t)gb.units.size();
+                gb.pools[pi].nunits = (int32_t)pool_units[pi].size();
+                gb.units.insert(gb.units.end(), pool_units[pi].begin(), pool_units[pi].end());
+            }
+            size_t n_legacy = 0;
+            for (char gflag : grouped) n_legacy += gflag ? 0 : 1;
+            // independent evaluations alternate between the context's two issue lanes (common.hpp)
+            const int lanes = (n_legacy > 1 && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
+            if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
+            if (!gb.pools.empty()) kde_group_run(ctx, t, gb, dsums.p);
+            size_t wi = 0, li = 0;
+            for (const Work& w : work) {
+                if (grouped[wi++]) continue;
+                LaneSwitch lane(ctx, (int)(li++ % (size_t)lanes));
+                Prep pr;
+                prepare(w, pr);
+                KdeModel& m = pr.m;
+                const int* use_cols = pr.use.data();
+                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, m.N);
                 ctx->scratch_train.reserve(pb.apack + pb.nxpack + pb.axpack + 768);
                 char* base = ctx->scratch_train.p;
                 m.Apack = base;
                 m.nxpack = base + align(pb.apack);
                 m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
-                kde_pack_train(ctx, m, t, use_cols, row0, n0, row1, nullptr, /*prune=*/true);
+                kde_pack_train(ctx, m, t, use_cols, pr.row0, pr.n0, pr.row1, nullptr, /*prune=*/true);
                 if (w.mode == 0 && m.cond)
-                    kde_eval_enqueue(ctx, m, t, use_cols, te0, te_n, nullptr, dsums.p + w.slot_j, nullptr, dsums.p + w.slot_m);
+                    kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + w.slot_j, nullptr, dsums.p + w.slot_m);
                 else
-                    kde_eval_enqueue(ctx, m, t, use_cols, te0, te_n, nullptr, dsums.p + (w.mode == 2 ? w.slot_m : w.slot_j));
+                    kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + (w.mode == 2 ? w.slot_m : w.slot_j));
             }
             std::vector<double> hs(std::max<size_t>(1, nslots));
             if (lanes > 1) ctx->sync_lanes(lanes - 1);
             if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ctx->drop_staged();
             for (size_t i = 0; i < nslots; ++i) sd->kde_cache[slot_key[i]] = hs[i];
             sd->kde_sweeps += (int64_t)work.size();
             for (const Pending& pd : pending) out[pd.cand] = 0.0;
