@@ -69,8 +69,165 @@ def make_dag_table(torch, device, n_rows, n_cols, seed, dtype, nonlinear=False):
     return out.to(dtype).contiguous()
 
 
-def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
+class EvalLog:
+    """Records every local-score evaluation the search asks the engine for (variable, node type, parents - as column names),
+    by wrapping the score's batched entry point: the like-for-like work list of the CPU baseline."""
+
+    def __init__(self, score):
+        self.evals = []
+        self.names = list(score._names)
+        inner = score._batch_raw
+
+        def wrapped(model, var, ntype, off, par, kind):
+            for i in range(len(var)):
+                self.evals.append((self.names[var[i]], int(ntype[i]), tuple(self.names[j] for j in par[off[i]: off[i + 1]]), int(kind)))
+            return inner(model, var, ntype, off, par, kind)
+
+        score._batch_raw = wrapped
+
+
+def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
+    """CPU side of the candidate-arcs/s metric: the SAME local-score evaluations the device run
+    made (EvalLog), evaluated by the oracle's restatement of the reference arithmetic on a bounded random sample of them and on
+    a row subsample of the same table, extrapolated per class (node type, number of parents) with the cost law of the
+    reference algorithm: CKDE likelihoods are O(train rows x test rows) pair sums -> x (rows / sample rows)^2, LinearGaussian
+    fits and likelihoods O(rows) -> x (rows / sample rows).  `host(m)` returns (columns dict of numpy arrays over the first m
+    rows, dict of discrete codes / cardinalities or None).  Returns arcs/s = cells / extrapolated seconds, single thread (the
+    reference's hill-climb is single-threaded) and on all cores (the oracle's OpenMP loop over test rows)."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(0)
+    n_rows = which["rows"]
+    classes = {}
+    for ev in log.evals:
+        ncont = sum(1 for p_ in ev[2] if not p_.startswith("D")) if which.get("hybrid") else len(ev[2])
+        classes.setdefault((ev[1], ncont), []).append(ev)
+
+    def make_score(m):
+        cols, disc = host(m)
+        if which["kind"] == "cv":
+            def f(ev):
+                data = np.column_stack([cols[ev[0]]] + [cols[p_] for p_ in ev[2]])
+                return oracle.cv_likelihood(data, "ckde" if ev[1] == 1 else "lg", which["k"], which["seed"])
+            return f
+        codes, cards = disc
+        ratio, k, seed = which["ratio"], which["k"], which["seed"]
+        tr, te = oracle.holdout_split(m, ratio, seed)
+        folds = oracle.cv_folds(tr.size, k, seed)
+
+        def f(ev):
+            var, par = ev[0], ev[2]
+            dpar = [p_ for p_ in par if p_ in codes]
+            cpar = [p_ for p_ in par if p_ not in codes]
+            if var in codes:
+                fn = lambda a, b: oracle.discrete_fit_slogl(codes[var], cards[var], [codes[q] for q in dpar], [cards[q] for q in dpar], a, b)
+            else:
+                cont = np.column_stack([cols[var]] + [cols[q] for q in cpar]).astype(np.float64)
+                fn = lambda a, b: oracle.adaptator_fit_slogl(cont, [codes[q] for q in dpar], [cards[q] for q in dpar], a, b,
+                                                             "ckde" if ev[1] == 1 else "lg")
+            if ev[3] == 3:   # hold-out (validation) score
+                return fn(tr, te)
+            return sum(fn(tr[a], tr[b]) for a, b in folds)
+        return f
+
+    def measure(m, threads, budget):
+        oracle.set_num_threads(threads)
+        f = make_score(m)
+        est, used, t_all = 0.0, 0, time.perf_counter()
+        share = budget / max(1, len(classes))
+        for (nt, ncont), evs in sorted(classes.items()):
+            pick = [evs[i] for i in rng.permutation(len(evs))[:6]]
+            t0, done = time.perf_counter(), 0
+            for ev in pick:
+                f(ev)
+                done += 1
+                if time.perf_counter() - t0 > share and done >= 2:
+                    break
+            per = (time.perf_counter() - t0) / done
+            scale = (n_rows / m) ** 2 if nt == 1 else (n_rows / m)   # CKDE: pairs; LinearGaussian / discrete: rows
+            est += per * scale * len(evs)
+            used += done
+        return est, used, time.perf_counter() - t_all
+
+    cores = oracle.num_threads()
+    out = {"unit": "arcs/s", "kind": "port",
+           "law": "CKDE evaluations scaled by (rows / sample rows)^2, LinearGaussian / discrete ones by rows / sample rows; per class "
+                  "(node type, continuous parents): mean oracle time of up to 6 sampled evaluations x the class's evaluations"}
+    try:
+        m_all = int(min(n_rows, which.get("sample_rows_all", 20000)))
+        est, used, wall = measure(m_all, cores, budget_s * 0.5)
+        out.update({"value": cells / est, "cores": cores, "cpu_seconds_extrapolated": est,
+                    "sample": f"{used} of the run's {len(log.evals)} local-score evaluations on the first {m_all} of {n_rows} rows, {wall:.1f}s wall"})
+        m_one = int(min(n_rows, which.get("sample_rows_one", 4000)))
+        est1, used1, wall1 = measure(m_one, 1, budget_s * 0.5)
+        out["single_thread"] = {"value": cells / est1, "cores": 1, "cpu_seconds_extrapolated": est1,
+                                "sample": f"{used1} evaluations on the first {m_one} rows, {wall1:.1f}s wall"}
+    except Exception as ex:
+        out["error"] = f"{type(ex).__name__}: {ex}"
+    finally:
+        oracle.set_num_threads(cores)
+    return out
+
+
+def bench_c1(pbn):
+    """BASELINE config 1 (the reference's CPU-runnable case): GaussianNetwork, 4 nodes, LinearGaussianCPD MLE fit + BIC on a
+    10 k-row table - BIC hill-climb + fit + slogl through the device engine, and the SAME search by the serial restatement
+    (oracle/hc_oracle.py over oracle.bic_lg) on the host: both complete, nothing sampled."""
+    import pandas as pd
+
+    rng = np.random.default_rng(0)
+    n = 10_000
+    a = rng.normal(size=n)
+    b = 0.7 * a + rng.normal(scale=0.8, size=n)
+    c = -0.5 * a + 1.2 * b + rng.normal(scale=0.6, size=n)
+    d = 0.9 * c + rng.normal(size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c, "d": d})
+    names = list(df.columns)
+    t0 = time.perf_counter()
+    score = pbn.BIC(df)
+    hc = pbn.GreedyHillClimbing()
+    res = hc.estimate(pbn.ArcOperatorSet(), score, pbn.GaussianNetwork(names))
+    res.fit(df)
+    sl = res.slogl(df)
+    dt = time.perf_counter() - t0
+    out = {"metric": "hill-climb candidate-arcs scored/s", "unit": "arcs/s", "value": hc.last.cells_scored / dt,
+           "config": "C1: GaussianNetwork 4 nodes, BIC hill-climb + LinearGaussianCPD MLE fit + slogl, 10000 rows fp64 (host pandas table in, "
+                     "upload + score construction + search + fit + slogl timed)",
+           "cells_scored": hc.last.cells_scored, "iterations": hc.last.iterations, "arcs_found": res.num_arcs(), "seconds": dt, "slogl": sl}
+    try:
+        from oracle import hc_oracle, oracle
+
+        data = df.to_numpy()
+        cores = oracle.num_threads()
+        oracle.set_num_threads(1)
+        t0 = time.perf_counter()
+        calls = [0]
+
+        def sc(v, _nt, par):
+            calls[0] += 1
+            return oracle.bic_lg(data[:, [v] + list(par)])
+
+        arcs, _types, trace = hc_oracle.estimate(4, 0, sc)[:3]
+        for v in range(4):   # MLE fit + log-likelihood of every node, as fit() + slogl() do
+            par = [s_ for s_, t_ in arcs if t_ == v]
+            beta, var = oracle.lg_fit(data[:, [v] + par])
+            oracle.lg_logl(data[:, [v] + par], beta, var)
+        dcpu = time.perf_counter() - t0
+        oracle.set_num_threads(cores)
+        mine = [(names.index(s_), names.index(t_)) for s_, t_ in res.arcs()]
+        out["cpu_baseline"] = {"value": hc.last.cells_scored / dcpu, "unit": "arcs/s", "cores": 1, "kind": "port", "seconds": dcpu,
+                               "same_structure": sorted(arcs) == sorted(mine),
+                               "same_skeleton": sorted(tuple(sorted(a_)) for a_ in arcs) == sorted(tuple(sorted(a_)) for a_ in mine),
+                               "sample": f"the whole search, fit and log-likelihood by the serial restatement: {calls[0]} oracle BIC calls on all 10000 rows"}
+    except Exception as ex:
+        out["cpu_baseline"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
+    return out
+
+
+def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_cols=0, cpu=True):
     """Secondary metric: candidate-arcs (delta cells) scored per second during GreedyHillClimbing.estimate."""
+    host = None
+    cpu_cfg = None
     if which == "c4":
         n_cols = 64
         n_rows = n_rows or 2_000_000
@@ -114,6 +271,11 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         t0 = time.perf_counter()
         score = pbn.ValidatedLikelihood(df, 0.2, 10, 0)
         t_ctor = time.perf_counter() - t0
+        cpu_cfg = {"kind": "validated", "ratio": 0.2, "k": 10, "seed": 0, "rows": n_rows, "hybrid": True, "sample_rows_all": 30000, "sample_rows_one": 8000}
+
+        def host(m, cols=cols, disc=disc, cards=cards):
+            return ({k_: np.asarray(v_[:m], dtype=np.float64) for k_, v_ in cols.items()},
+                    ({k_: v_[:m] for k_, v_ in disc.items()}, {f"D{j}": int(cards[j]) for j in range(len(cards))}))
         start = pbn.SemiparametricBN(names, [], [(f"D{j}", pbn.DiscreteFactorType()) for j in range(n_disc)])
         ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
         pairs = [(a, b) for a in names for b in names if a != b]
@@ -143,10 +305,11 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
     elif which == "cv64":
         # north star: "CV-likelihood hill-climbing on 64-node synthetic data" - CKDE candidates are sharded over the
         # ranks (fixed total work: strong scaling of the delta cache); bounded to cache_scores + max_iters iterations
-        n_cols = 64
+        n_cols = n_cols or 64
         n_rows = n_rows or 100_000
         max_iters = max_iters or 1
         t = make_dag_table(torch, device, n_rows, n_cols, 2, torch.float64, nonlinear=True)
+        cpu_cfg = {"kind": "cv", "k": 10, "seed": 0, "rows": n_rows}
         names = [f"x{i}" for i in range(n_cols)]
         torch.cuda.synchronize()
         table = pbn.DeviceTable.from_device_pointer(ctx, t.data_ptr(), n_rows, names, n_rows, _lib.PBN_F64, keepalive=t)
@@ -155,12 +318,13 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         t_ctor = time.perf_counter() - t0
         start = pbn.SemiparametricBN(names, [], [(n, pbn.CKDEType()) for n in names])
         ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
-        label = f"64-node SemiparametricBN (all CKDE start), 10-fold CVLikelihood, arcs+node_type, max_indegree=3, {n_rows} rows fp64"
+        label = f"{n_cols}-node SemiparametricBN (all CKDE start), 10-fold CVLikelihood, arcs+node_type, max_indegree=3, {n_rows} rows fp64"
         kw = {"max_indegree": 3}
     else:
         n_cols = 32
         n_rows = n_rows or 500_000
         t = make_dag_table(torch, device, n_rows, n_cols, 2, torch.float64, nonlinear=True)
+        cpu_cfg = {"kind": "cv", "k": 10, "seed": 0, "rows": n_rows}
         names = [f"x{i}" for i in range(n_cols)]
         torch.cuda.synchronize()
         table = pbn.DeviceTable.from_device_pointer(ctx, t.data_ptr(), n_rows, names, n_rows, _lib.PBN_F64, keepalive=t)
@@ -174,10 +338,18 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
     hc = pbn.GreedyHillClimbing()
     if max_iters:
         kw["max_iters"] = max_iters
+    want_cpu = cpu and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PBN_BENCH_NO_CPU")
+    log = EvalLog(score) if (want_cpu and cpu_cfg is not None) else None
     t0 = time.perf_counter()
     res = hc.estimate(ops, score, start, **kw)
     dt = time.perf_counter() - t0
     more = dict(extra) if which == "c5mmhc" else {}
+    if log is not None:
+        if host is None:   # device-generated table (n_cols x n_rows): the first m rows, column by column
+            def host(m, t=t, names=names):
+                a = t[:, :m].cpu().numpy().astype(np.float64)
+                return {nm: a[i] for i, nm in enumerate(names)}, None
+        more["cpu_baseline"] = cpu_arcs_baseline(cpu_cfg, log, hc.last.cells_scored, host)
     if which == "c4" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PBN_BENCH_NO_CPU"):
         # the CPU side of BGe is the constructor (means + covariance of all columns, one thread in the
         # reference); timed with the restatement on a row sample and scaled linearly
@@ -189,9 +361,10 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
             t0 = time.perf_counter()
             oracle.cov(host)
             dcpu = (time.perf_counter() - t0) * (n_rows / rows)
-            more["cpu_baseline"] = {"score_ctor_s": dcpu, "kind": "port", "cores": 1,
-                                    "sample": f"covariance of {rows} x {n_cols} rows on one thread, scaled to {n_rows} rows; "
-                                              f"per-candidate work is O(p^3) on both sides"}
+            more["cpu_baseline"] = {"value": hc.last.cells_scored / dcpu, "unit": "arcs/s", "score_ctor_s": dcpu, "kind": "port", "cores": 1,
+                                    "sample": f"covariance of {rows} x {n_cols} rows on one thread (the reference's BGe constructor, bge.hpp:52-72), "
+                                              f"scaled to {n_rows} rows; the per-candidate work is O(p^3) on the cached covariance on both sides and is "
+                                              f"left out of the CPU time (an upper bound of the CPU rate); compare with value_with_ctor"}
         except Exception as ex:
             more["cpu_baseline"] = {"score_ctor_s": None, "sample": f"failed: {ex}"}
     return {
@@ -206,6 +379,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters):
         "arcs_found": res.num_arcs(),
         "estimate_s": dt,
         "score_ctor_s": t_ctor,
+        "value_with_ctor": hc.last.cells_scored / (dt + t_ctor),
     }
 
 
@@ -351,6 +525,7 @@ def main():
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-Arrow end-to-end leg (profiling runs: keeps every sweep launch the full one)")
     ap.add_argument("--no-c3", action="store_true", help="skip the bounded config-3 (CKDE, 10-fold CV) hill-climb leg of the default run")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the secondary_* legs of the default run (C3, C5, C1, f32, weak-scaling CV)")
     ap.add_argument("--hc-rows", type=int, default=0)
     ap.add_argument("--hc-max-iters", type=int, default=0)
     args = ap.parse_args()
@@ -430,25 +605,74 @@ def main():
         elapsed = float(tmax.item())
 
     hc_out = None
+    legs = {}
+
+    def leg(name, fn):
+        try:
+            legs[name] = fn()
+        except Exception as ex:  # a secondary leg must never cost the headline line
+            legs[name] = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
+
+    if args.no_cpu_baseline:
+        os.environ["PBN_BENCH_NO_CPU"] = "1"
     if args.hc != "none":
-        if args.no_cpu_baseline:
-            os.environ["PBN_BENCH_NO_CPU"] = "1"
-        try:
-            hc_out = bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, args.hc_max_iters)
-            if dist is not None:
-                hc_out["ranks"] = world
-                hc_out["sharding"] = ("CKDE candidates of every delta-cache batch dealt to the ranks by variable set, one all_gather of "
-                                      "the batch's scores per batch; fixed total work (strong scaling of the search)")
-        except Exception as ex:  # the secondary metric must never cost the headline line
-            hc_out = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
-    c3_out = None
-    if hc_auto and world == 1 and not args.no_c3:
-        # the CKDE path of the search, driver-timed: BASELINE config 3 at FULL size (32-node SPBN, 10-fold CV, 500 k rows),
-        # bounded to the initial delta cache + one iteration
-        try:
-            c3_out = bench_hill_climb(torch, pbn, _lib, ctx, device, "c3", 0, 1)
-        except Exception as ex:
-            c3_out = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
+        # N > 1: the north star's scaling workload in its fixed-work form (64 nodes on every world size: strong scaling of the
+        # search) with update batches inside the timed region (max_iters >= 5)
+        iters = args.hc_max_iters or (5 if (args.hc == "cv64" and world > 1) else 0)
+        leg("secondary", lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, args.hc, args.hc_rows, iters))
+        hc_out = legs.pop("secondary")
+        if dist is not None and hc_out.get("value") is not None:
+            hc_out["ranks"] = world
+            hc_out["scaling"] = "strong"
+            hc_out["sharding"] = ("CKDE candidates of every delta-cache batch dealt to the ranks by variable set (longest processing time first), "
+                                  "one all_gather of the batch's scores per batch; fixed total work (strong scaling of the search)")
+    if hc_auto and not args.no_extra_legs:
+        # the north star's weak form: delta cells per rank constant - n = round(64 sqrt(N / 8)) nodes (23 on one GPU ... 64 on
+        # eight), 100 k rows, cache_scores + 5 iterations
+        wn = int(round(64.0 * (world / 8.0) ** 0.5))
+        leg("secondary_cv_weak", lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, "cv64", args.hc_rows, 5, n_cols=wn))
+        if legs["secondary_cv_weak"].get("value") is not None:
+            legs["secondary_cv_weak"].update({"ranks": world, "scaling": "weak", "nodes": wn,
+                                              "note": "cells scale with nodes^2: nodes = round(64 sqrt(ranks / 8)) keeps cells per rank constant"})
+    if hc_auto and world == 1 and not args.no_extra_legs:
+        if not args.no_c3:
+            # the CKDE path of the search, driver-timed: BASELINE config 3 at FULL size (32-node SPBN, 10-fold CV, 500 k rows),
+            # bounded to the initial delta cache + one iteration
+            leg("secondary_c3", lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, "c3", 0, 1))
+        # BASELINE config 5 end to end on one GPU: MMPC (hybrid MutualInformation) + ValidatedLikelihood hill-climb to convergence
+        leg("secondary_c5", lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, "c5mmhc", 0, 1_000_000))
+        leg("secondary_c1", lambda: bench_c1(pbn))
+
+        def f32_leg():
+            tr32, te32 = make_tables(torch, device, args.n_train, args.n_test, 0, 1, torch.float32)
+            torch.cuda.synchronize()
+            a = pbn.DeviceTable.from_device_pointer(ctx, tr32.data_ptr(), args.n_train, names, args.n_train, _lib.PBN_F32, keepalive=tr32)
+            b = pbn.DeviceTable.from_device_pointer(ctx, te32.data_ptr(), args.n_test, names, args.n_test, _lib.PBN_F32, keepalive=te32)
+            k32 = (pbn.ProductKDE if args.kde == "product" else pbn.KDE)(names)
+            k32.fit_table(a)
+            buf = torch.zeros(8, dtype=torch.float64, device=device)
+            for i in range(2):
+                k32.slogl_table_async(b, buf.data_ptr() + 8 * i)
+            ctx.sync()
+            ctx.set_profiling(True)
+            t0 = time.perf_counter()
+            for i in range(5):
+                k32.slogl_table_async(b, buf.data_ptr() + 8 * (2 + i))
+            ctx.sync()
+            el = time.perf_counter() - t0
+            ms, nl = ctx.kernel_time(_lib.PBN_K_SWEEP)
+            ctx.set_profiling(False)
+            pairs_ = float(args.n_train) * float(args.n_test)
+            peak_pairs = 256 * 4 * 2.4e9 * 64.0 / F32_VALU_CYCLES_PER_VALUE
+            return {"metric": "KDE slogl M-samples/s", "dtype": "f32", "value": args.n_test * 5 / el / 1e6, "unit": "M-samples/s", "ms_per_step": el / 5 * 1e3,
+                    "slogl": float(buf[2].item()), "rel_diff_vs_f64": abs(float(buf[2].item()) - slogl) / abs(slogl),
+                    "roofline": {"kernel": "kde_sweep_bf16_kernel", "bound": "valu-issue", "avg_launch_ms": ms / max(nl, 1),
+                                 "frac": pairs_ / (ms / max(nl, 1) * 1e-3) / peak_pairs,
+                                 "note": "against the VALU-issue bound of the fp32 sweep (one v_exp_f32 + one v_add_f32 per pair value); the f32 "
+                                         "coordinates run as bf16x3 on the bf16 matrix cores (DESIGN.md 3.1)"}}
+
+        slogl = float(partial[args.warmup].item())
+        leg("secondary_f32", f32_leg)
 
     total_samples = args.n_test * world * args.steps
     value = total_samples / elapsed / 1e6
@@ -521,8 +745,7 @@ def main():
             out["roofline"]["dp_issue_util"] = dp_issue_util()
         if hc_out is not None:
             out["secondary"] = hc_out
-        if c3_out is not None:
-            out["secondary_c3"] = c3_out
+        out.update(legs)
         if world == 1 and not args.no_e2e:
             try:
                 out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy())

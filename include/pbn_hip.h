@@ -177,12 +177,16 @@ typedef enum { PBN_NODE_LG = 0, PBN_NODE_CKDE = 1, PBN_NODE_DISCRETE = 2 } pbn_n
 int pbn_scoredata_create(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
                          pbn_scoredata** out);
 /* Row-sharded construction for one-process-per-GPU jobs (BGe / BIC / LG-CV row): every rank holds
- * the same table and takes the Gram moments of its contiguous share of each region; the host adds the ranks'
- * pbn_scoredata_moments buffers in rank order and installs the totals with set != 0 on every rank.  Until then
+ * the same table.  Each region (fold, hold-out part) is cut into a fixed number of super-blocks (PBN_MOMENT_SUPERBLOCKS,
+ * default 16; boundaries depend on the region's length only); rank r takes the Gram moments of segments
+ * [S r / world, S (r + 1) / world) and leaves the others zero; the host adds the ranks' pbn_scoredata_moments buffers
+ * (exact: a segment is non-zero on one rank only) and installs them with set != 0 on every rank, which rebuilds the
+ * regions' totals in segment order - bit-identical for every world size, world = 1 included.  Until then
  * pbn_score_batch refuses the handle.  The reference has no counterpart (single process, CPU Eigen). */
 int pbn_scoredata_create_sharded(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed,
                                  double test_ratio, int rank, int world, pbn_scoredata** out);
-/* buf: per region (k folds or the single CV/training region, then hold-out) S[n] then G[n*n]; *len = doubles. */
+/* buf: per segment (the super-blocks of the k folds or of the single CV/training region, then of the hold-out part)
+ * S[n] then G[n*n]; *len = doubles. */
 int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set);
 /* Bandwidth selector (PBN_SEL_*) of the CKDEs fitted while scoring: the reference passes it through the scores'
  * construction_args to CKDEType::new_factor (learning/scores/cv_likelihood.hpp:19-27). Default normal reference. */

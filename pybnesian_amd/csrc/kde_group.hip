@@ -519,6 +519,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         sa.units = (const GSweepUnit*)(arena + o_sweep); sa.wg_unit = (const int32_t*)(arena + o_wgunit); sa.total_wg = total_wg;
         sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
         sa.prune_margin = prune_margin(PBN_F64);
+        static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
+        sa.group_masks = gmasks;
         launch_sweep_grouped(sa, PBN_F64, KS, st);
     }
     {

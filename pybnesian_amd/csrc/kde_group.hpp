@@ -92,7 +92,7 @@ struct GSweepArgs {
     const GSweepUnit* units;
     const int32_t* wg_unit;   // [total flat workgroups / 64] -> unit
     int64_t total_wg;
-    int fold, wmul, count_redo;
+    int fold, wmul, count_redo, group_masks;
     double prune_margin;
 };
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st);

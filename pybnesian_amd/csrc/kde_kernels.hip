@@ -479,6 +479,30 @@ __device__ __forceinline__ unsigned long long prune_visit_mask(const double* __r
     return __ballot(keep);
 }
 
+// The same test against ONE 16-query group's own box and bound (fp64 pruned sweeps): a wave owns QG groups, consecutive in Morton
+// order, and the box of all of them is up to twice as wide per axis as a group's own - at 3-4 dimensions, where a wave's box is
+// as wide as the kernel's support, a third of the (tile, group) pairs of a visited tile lie beyond the group's own support.  The
+// boxes are re-read per group (uniform addresses: scalar loads; the tile's box from L1) so that no box stays in registers.
+__device__ __forceinline__ unsigned long long prune_group_mask(const double* __restrict__ tile_box, const double* __restrict__ qbox, int pd, int64_t tb,
+                                                                int64_t t1, double thr, int lane) {
+    const int64_t t = tb + lane;
+    bool keep = false;
+    if (t < t1) {
+        const double* bx = tile_box + t * 2 * pd;
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k)
+            if (k < pd) {
+                const double g1 = bx[k] - qbox[pd + k], g2 = qbox[k] - bx[pd + k];
+                double g = g1 > g2 ? g1 : g2;
+                g = g > 0.0 ? g : 0.0;
+                d2 = __builtin_fma(g, g, d2);
+            }
+        keep = !(-0.5 * d2 < thr);
+    }
+    return __ballot(keep);
+}
+
 // WMUL (d mod 4 == 0, no free K slot for the norm): the training norms enter as WEIGHTS.  The accumulator starts from the
 // per-query constant alone (a persistent register quad as the MFMA's C operand, as with FOLD) and holds
 // x' = z_t.z_q - 1/2|z_q|^2 - m_q + bias; the term is 2^x' * w_t with w_t = 2^(-1/2|z_t|^2) precomputed by the pack kernel, and
@@ -642,9 +666,15 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         if (!FOLD) n = *(const V*)((WMUL ? Wp : Np) + t * 16 + lg * 4);
         if (COND) x = Xp[t * 64 + lane];
     };
-    auto process_tile = [&](const int64_t t, const T (&af)[KS], const V& nx, const T ax) {
+    // pruned plain fp64 sweeps: visit masks per query group (GMASK), bit `bit` of gm[g] = group g needs this tile
+    constexpr bool GMASK = PRUNE && !COND && sizeof(T) == 8;
+    unsigned long long gm[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) gm[g] = ~0ull;
+    auto process_tile = [&](const int64_t t, const T (&af)[KS], const V& nx, const T ax, const int bit) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
+            if (GMASK && !((gm[g] >> bit) & 1ull)) continue;
             V acc;
             if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
 #pragma unroll
@@ -700,9 +730,10 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     V nxA, nxB;
     T axA = 0, axB = 0;
     // blind accumulation (see "Unchecked passes" below): no overflow test, no separate add
-    auto process_fast = [&](const T (&af)[KS], const V& nx) {
+    auto process_fast = [&](const T (&af)[KS], const V& nx, const int bit) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
+            if (GMASK && !((gm[g] >> bit) & 1ull)) continue;
             V acc;
             if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
 #pragma unroll
@@ -722,11 +753,11 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             for (;;) {
                 int b2 = -1;
                 if (mask) { b2 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b2, afB, nxB, axB); }
-                if constexpr (BLIND) process_fast(afA, nxA); else process_tile(tb + b, afA, nxA, axA);
+                if constexpr (BLIND) process_fast(afA, nxA, b); else process_tile(tb + b, afA, nxA, axA, b);
                 if (b2 < 0) break;
                 int b3 = -1;
                 if (mask) { b3 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b3, afA, nxA, axA); }
-                if constexpr (BLIND) process_fast(afB, nxB); else process_tile(tb + b2, afB, nxB, axB);
+                if constexpr (BLIND) process_fast(afB, nxB, b2); else process_tile(tb + b2, afB, nxB, axB, b2);
                 if (b3 < 0) break;
                 b = b3;
             }
@@ -734,11 +765,33 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // fp64 plain sweeps take a batch blind first (the offsets start from the prepass bounds: an overflow needs a term 896
         // exponent units above its query's bound) and redo it with the checked loop from the saved sums if a sum went bad
         constexpr bool FASTP = PBN_SWEEP_UNCHECKED && !COND && sizeof(T) == 8 && (FOLD || KS == 1);   // the shapes that stay <= 168 VGPRs
-        if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
+        if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0) * QG);
         for (int64_t tb = t0; tb < t1; tb += 64) {
-            const unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            unsigned long long mask;
+            if constexpr (GMASK) {
+                mask = 0;
+                if (a.group_masks) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+                        gm[g] = prune_group_mask(a.tile_box, a.qtile_box + qt * 2 * pd, pd, tb, t1, a.qtile_thr[qt] - a.prune_margin, lane);
+                        mask |= gm[g];
+                    }
+                } else {
+                    mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) gm[g] = mask;
+                }
+            } else {
+                mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            }
             if (!mask) continue;
-            if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
+            if (a.count_redo && lane == 0) {
+                unsigned long long v = 0;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) v += (unsigned long long)__builtin_popcountll(GMASK ? gm[g] : mask);
+                atomicAdd(&g_sweep_visit, v);   // (tile, group) pairs visited, out of QG x tiles offered
+            }
             if constexpr (FASTP) {
                 double saved[QG];
 #pragma unroll
@@ -775,9 +828,9 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             for (int64_t t = ta; t < tb; t += 2) {
                 const bool second = t + 1 < tb;                       // wave-uniform
                 load_tile(second ? t + 1 : t, afB, nxB, axB);
-                process_tile(t, afA, nxA, axA);
+                process_tile(t, afA, nxA, axA, 0);
                 load_tile(t + 2 < tb ? t + 2 : t, afA, nxA, axA);
-                if (second) process_tile(t + 1, afB, nxB, axB);
+                if (second) process_tile(t + 1, afB, nxB, axB, 0);
             }
         };
         if constexpr (FAST) {
@@ -791,9 +844,9 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 for (int64_t t = tc; t < te; t += 2) {
                     const bool second = t + 1 < te;                   // wave-uniform
                     load_tile(second ? t + 1 : t, afB, nxB, axB);
-                    process_fast(afA, nxA);
+                    process_fast(afA, nxA, 0);
                     load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
-                    if (second) process_fast(afB, nxB);
+                    if (second) process_fast(afB, nxB, 0);
                 }
                 bool bad = false;
 #pragma unroll
@@ -859,7 +912,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul;
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
-    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0;
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks;
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL>(a, bid);
 }
 

@@ -362,6 +362,8 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
+    static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
+    sa.group_masks = gmasks;
     static const bool log_sweeps = env_int("PBN_SWEEP_LOG", 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
     if (log_sweeps) std::fprintf(stderr, "pbn-sweep N=%lld n=%lld d=%d cond=%d prune=%d nsub=%lld nsplit=%lld\n", (long long)m.N, (long long)n, m.d, (int)m.cond, (int)m.prune, (long long)(m.prune ? m.nsub : 0), (long long)nsplit);
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, m.dtype, m.KS, m.cond, (int)nsplit, ctx->stream); }

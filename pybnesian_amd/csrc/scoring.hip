@@ -77,34 +77,77 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
         }
 }
 
-// Moments of all n columns over [row0, row0 + nrows): blocks of 32 columns, pairs of blocks per launch.
-void compute_stats(const pbn_scoredata* sd, int64_t row0, int64_t nrows, Stats& out) {
+// Moments of all n columns over each of the row ranges [r0[i], r1[i]), i in [s0, s1): ONE segmented Gram launch per block (pair)
+// of <= 64 columns.  A range is cut into pieces of SEG_ROWS rows (one workgroup each) that are added in order: the result for a
+// range depends on its rows only - not on the other ranges of the launch, not on who else computes what.
+constexpr int64_t SEG_ROWS = 2048;
+void compute_stats_segments(const pbn_scoredata* sd, const std::vector<int64_t>& r0, const std::vector<int64_t>& r1, size_t s0, size_t s1,
+                            std::vector<Stats>& out) {
     const int n = sd->n;
-    out.zero(n);
-    out.N = nrows;
-    if (nrows == 0) return;
+    for (size_t i = s0; i < s1; ++i) { out[i].zero(n); out[i].N = r1[i] - r0[i]; }
+    if (s1 <= s0) return;
     const pbn_table* t = sd->table();
+    pbn_ctx* ctx = t->ctx;
+    const int nseg = (int)(s1 - s0);
+    std::vector<int32_t> blk, off(nseg + 1, 0);
+    for (int g = 0; g < nseg; ++g) {
+        for (int64_t r = r0[s0 + g]; r < r1[s0 + g]; r += SEG_ROWS) {
+            blk.push_back(g); blk.push_back((int32_t)r); blk.push_back((int32_t)std::min(r + SEG_ROWS, r1[s0 + g])); blk.push_back(0);
+        }
+        off[g + 1] = (int32_t)(blk.size() / 4);
+    }
+    const int nblk = (int)(blk.size() / 4);
+    if (nblk == 0) return;
+    if (t->n_rows > 0x7fffffffll) throw invalid_error("score data: more than 2^31 rows");
+    dev_buf<int32_t> dblk(blk.size() + off.size());
+    HIP_CHECK(hipMemcpyAsync(dblk.p, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(dblk.p + blk.size(), off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    auto run = [&](const std::vector<int>& cols) {
+        const int d = (int)cols.size(), nct = (d + 15) / 16, WS = gram_ws(nct);
+        ctx->scratch_red.reserve(((size_t)nblk + (size_t)nseg) * WS);
+        double* partial = ctx->scratch_red.p;
+        double* outd = partial + (size_t)nblk * WS;
+        GramArgs a{};
+        a.base = t->data; a.ld = t->ld; a.n_cols = d; a.row0 = 0; a.rows = nullptr; a.n = t->n_rows;
+        for (int i = 0; i < d; ++i) a.gc.cols[i] = cols[i];
+        a.rows_per_block = SEG_ROWS; a.blk = dblk.p; a.shift = sd->shift_dev.p; a.partial = partial; a.num_cus = ctx->num_cus;
+        { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram_segments(a, t->dtype, nblk, dblk.p + blk.size(), nseg, outd, ctx->stream); }
+        std::vector<double> h((size_t)nseg * WS);
+        HIP_CHECK(hipMemcpyAsync(h.data(), outd, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int g = 0; g < nseg; ++g) {
+            const double* w = h.data() + (size_t)g * WS;
+            Stats& st = out[s0 + g];
+            for (int i = 0; i < d; ++i) st.S[cols[i]] = w[WS - nct * 16 + i];
+            int p = 0;
+            for (int I = 0; I < nct; ++I)
+                for (int J = I; J < nct; ++J, ++p) {
+                    const double* tile = w + (size_t)p * 256;
+                    for (int e = 0; e < 256; ++e) {
+                        const int reg = e >> 6, lane = e & 63;
+                        const int r = I * 16 + (lane >> 4) + 4 * reg, c = J * 16 + (lane & 15);
+                        if (r >= d || c >= d || (I == J && r > c)) continue;
+                        st.G[cols[r] + (size_t)cols[c] * n] = tile[e];
+                        st.G[cols[c] + (size_t)cols[r] * n] = tile[e];
+                    }
+                }
+        }
+    };
     if (n <= 64) {
         std::vector<int> cols(n);
         std::iota(cols.begin(), cols.end(), 0);
-        gram_raw(t, cols.data(), n, row0, nrows, nullptr, sd->shift_dev.p, out.S.data(), out.G.data());
-        return;
-    }
-    const int nb = (n + 31) / 32;
-    std::vector<double> S(64), G(64 * 64);
-    for (int bi = 0; bi < nb; ++bi)
-        for (int bj = bi + (nb > 1 ? 1 : 0); bj < nb; ++bj) {
-            std::vector<int> cols;
-            for (int c = bi * 32; c < std::min(n, bi * 32 + 32); ++c) cols.push_back(c);
-            if (bj != bi)
+        run(cols);
+    } else {
+        const int nb = (n + 31) / 32;
+        for (int bi = 0; bi < nb; ++bi)
+            for (int bj = bi + 1; bj < nb; ++bj) {
+                std::vector<int> cols;
+                for (int c = bi * 32; c < std::min(n, bi * 32 + 32); ++c) cols.push_back(c);
                 for (int c = bj * 32; c < std::min(n, bj * 32 + 32); ++c) cols.push_back(c);
-            const int d = (int)cols.size();
-            gram_raw(t, cols.data(), d, row0, nrows, nullptr, sd->shift_dev.p, S.data(), G.data());
-            for (int i = 0; i < d; ++i) {
-                out.S[cols[i]] = S[i];
-                for (int j = 0; j < d; ++j) out.G[cols[i] + (size_t)cols[j] * n] = G[i + (size_t)j * d];
+                run(cols);
             }
-        }
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));   // dblk goes out of scope
 }
 
 // means / centred SSE of a column subset from moments.
@@ -331,6 +374,29 @@ static bool score_memo_on() {
 
 extern "C" {
 
+// region moments = their segments added in segment order (see scoredata_create_impl)
+static void regions_from_segments(pbn_scoredata* sd) {
+    const int n = sd->n;
+    if (sd->k > 0) { sd->fold.resize(sd->k); for (auto& f : sd->fold) f.zero(n); } else sd->all.zero(n);
+    if (sd->n_hold > 0) sd->hold.zero(n);
+    const int hold_region = sd->k > 0 ? sd->k : 1;
+    for (size_t i = 0; i < sd->seg.size(); ++i) {
+        const int r = sd->seg_region[i];
+        Stats& dst = (sd->n_hold > 0 && r == hold_region) ? sd->hold : (sd->k > 0 ? sd->fold[r] : sd->all);
+        dst.add(sd->seg[i]);
+    }
+    if (sd->k > 0) {
+        sd->all.zero(n);
+        for (int f = 0; f < sd->k; ++f) {
+            sd->fold[f].N = sd->limits[f + 1] - sd->limits[f];
+            sd->all.add(sd->fold[f]);
+        }
+    } else {
+        sd->all.N = sd->n_cv;
+    }
+    if (sd->n_hold > 0) sd->hold.N = sd->n_hold;
+}
+
 // Row layout of the splits: HoldOut (dataset/holdout_adaptator.hpp:24-61), CrossValidation
 // (dataset/crossvalidation_adaptator.hpp:17-57) and, for PBN_SPLIT_VALIDATED, the CV of the hold-out training part
 // with the same seed (validated_likelihood.hpp:19-20).  Host only.
@@ -413,23 +479,32 @@ static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split
         sd->shift.resize(sd->n);
         HIP_CHECK(hipMemcpyAsync(sd->shift.data(), sd->shift_dev.p, sd->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        // moments: of whole regions, or (world > 1) of this rank's contiguous share of every region; the caller
-        // then adds the ranks' shares in rank order and hands the totals back (pbn_scoredata_moments).
-        auto share = [&](int64_t r0, int64_t len, Stats& st) {
-            const int64_t lo = (len * rank) / world, hi = (len * (rank + 1)) / world;
-            compute_stats(sd.get(), r0 + lo, hi - lo, st);
-        };
-        if (sd->k > 0) {
-            sd->fold.resize(sd->k);
-            sd->all.zero(sd->n);
-            for (int f = 0; f < sd->k; ++f) {
-                share(sd->limits[f], sd->limits[f + 1] - sd->limits[f], sd->fold[f]);
-                sd->all.add(sd->fold[f]);
+        // moments: every region in PBN_MOMENT_SUPERBLOCKS super-blocks (boundaries: multiples of 64 rows, a function of the
+        // region's length only); rank r of `world` computes segments [S r / world, S (r + 1) / world) and leaves the others zero;
+        // the caller adds the ranks' buffers (exact: every segment is non-zero on one rank only) and installs them
+        // (pbn_scoredata_moments), and regions_from_segments adds a region's segments in segment order: the totals are the same
+        // bit for bit for every world size.
+        static const int SB = [] { const char* e = getenv("PBN_MOMENT_SUPERBLOCKS"); const int v = (e && *e) ? atoi(e) : 16; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+        auto add_region = [&](int region, int64_t r0, int64_t len) {
+            int64_t prev = 0;
+            for (int i = 1; i <= SB; ++i) {
+                int64_t b = i == SB ? len : (len * i / SB + 63) / 64 * 64;
+                b = std::min(b, len);
+                sd->seg_region.push_back(region);
+                sd->seg_r0.push_back(r0 + prev);
+                sd->seg_r1.push_back(r0 + std::max(prev, b));
+                prev = std::max(prev, b);
             }
-        } else {
-            share(0, sd->n_cv, sd->all);
-        }
-        if (sd->n_hold > 0) share(sd->n_cv, sd->n_hold, sd->hold);
+        };
+        int region = 0;
+        if (sd->k > 0) for (int f = 0; f < sd->k; ++f) add_region(region++, sd->limits[f], sd->limits[f + 1] - sd->limits[f]);
+        else add_region(region++, 0, sd->n_cv);
+        if (sd->n_hold > 0) add_region(region++, sd->n_cv, sd->n_hold);
+        const size_t S = sd->seg_region.size();
+        sd->seg.resize(S);
+        for (auto& st : sd->seg) st.zero(sd->n);
+        compute_stats_segments(sd.get(), sd->seg_r0, sd->seg_r1, S * (size_t)rank / (size_t)world, S * (size_t)(rank + 1) / (size_t)world, sd->seg);
+        regions_from_segments(sd.get());
         sd->partial = world > 1;
         *out = sd.release();
     });
@@ -445,39 +520,28 @@ int pbn_scoredata_create_sharded(pbn_ctx* ctx, const pbn_table* table, int split
     return scoredata_create_impl(ctx, table, split, k, seed, test_ratio, rank, world, out);
 }
 
-// Serialised moments: for each region (the k folds, or the single CV/training region when k == 0, then the hold-out
-// region if any): S[n] then G[n*n].  set == 0 copies them out, set != 0 installs totals and clears the partial flag.
+// Serialised moments: for each SEGMENT (scoredata_create_impl: the regions' super-blocks, in order) S[n] then G[n*n].
+// set == 0 copies them out (segments this rank did not compute are zero), set != 0 installs all of them, rebuilds the
+// regions' totals in segment order and clears the partial flag.
 int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set) {
     return guarded([&] {
         if (!sd) throw invalid_error("pbn_scoredata_moments: null argument");
         const size_t per = (size_t)sd->n + (size_t)sd->n * sd->n;
-        std::vector<Stats*> regions;
-        if (sd->k > 0) for (auto& f : sd->fold) regions.push_back(&f); else regions.push_back(&sd->all);
-        if (sd->n_hold > 0) regions.push_back(&sd->hold);
-        if (len) *len = (int64_t)(per * regions.size());
+        if (len) *len = (int64_t)(per * sd->seg.size());
         if (!buf) return;
         double* p = buf;
-        for (Stats* st : regions) {
+        for (Stats& st : sd->seg) {
             if (set) {
-                std::memcpy(st->S.data(), p, sd->n * sizeof(double));
-                std::memcpy(st->G.data(), p + sd->n, (size_t)sd->n * sd->n * sizeof(double));
+                std::memcpy(st.S.data(), p, sd->n * sizeof(double));
+                std::memcpy(st.G.data(), p + sd->n, (size_t)sd->n * sd->n * sizeof(double));
             } else {
-                std::memcpy(p, st->S.data(), sd->n * sizeof(double));
-                std::memcpy(p + sd->n, st->G.data(), (size_t)sd->n * sd->n * sizeof(double));
+                std::memcpy(p, st.S.data(), sd->n * sizeof(double));
+                std::memcpy(p + sd->n, st.G.data(), (size_t)sd->n * sd->n * sizeof(double));
             }
             p += per;
         }
         if (!set) return;
-        if (sd->k > 0) {
-            sd->all.zero(sd->n);
-            for (int f = 0; f < sd->k; ++f) {
-                sd->fold[f].N = sd->limits[f + 1] - sd->limits[f];
-                sd->all.add(sd->fold[f]);
-            }
-        } else {
-            sd->all.N = sd->n_cv;
-        }
-        if (sd->n_hold > 0) sd->hold.N = sd->n_hold;
+        regions_from_segments(sd);
         sd->partial = false;
         sd->kde_cache.clear();
         sd->score_memo.clear();

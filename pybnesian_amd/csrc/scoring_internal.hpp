@@ -67,6 +67,13 @@ struct pbn_scoredata {
     pbn::score::Stats all;               // CV / training region
     std::vector<pbn::score::Stats> fold; // k
     pbn::score::Stats hold;              // hold-out test region
+    // World-size-invariant summation (pbn_scoredata_create_sharded): every region is cut into a FIXED number of super-blocks
+    // (boundaries a function of the region's length only); a super-block's moments come from one segment of one segmented Gram
+    // launch - a function of the segment's rows only - and a region's moments are the sum of its segments in segment order,
+    // whichever rank computed which segment.
+    std::vector<pbn::score::Stats> seg;  // per segment
+    std::vector<int> seg_region;         // 0 .. k-1 folds (or 0 = the CV / training region when k == 0), then the hold-out region
+    std::vector<int64_t> seg_r0, seg_r1; // row range of the segment
     // discrete (dictionary) columns, addressed as column ids n .. n + n_disc - 1, in permuted row order
     int n_disc = 0;
     std::vector<std::vector<int32_t>> codes;

@@ -17,15 +17,58 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
+_GATHER_BUFS = {}
+
+
 def _all_gather(dist, buf):
-    """all_gather of one float64 vector per rank -> (world * len) numpy array, on the backend's device."""
+    """all_gather of one float64 vector per rank -> (world * len) numpy array.  nccl (RCCL): through persistent pinned staging
+    and device buffers with ONE stream synchronisation (no allocation, no pageable copy per batch); gloo: host tensors."""
     import torch
 
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    send = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64)).to(dev)
-    recv = torch.empty(dist.get_world_size() * send.numel(), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(recv, send)
-    return recv.cpu().numpy()
+    buf = np.ascontiguousarray(buf, dtype=np.float64)
+    world = dist.get_world_size()
+    if dist.get_backend() != "nccl":
+        send = torch.from_numpy(buf)
+        recv = torch.empty(world * send.numel(), dtype=torch.float64)
+        dist.all_gather_into_tensor(recv, send)
+        return recv.numpy()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    key = (buf.size, dev.index)
+    if key not in _GATHER_BUFS:
+        _GATHER_BUFS[key] = (torch.empty(buf.size, dtype=torch.float64).pin_memory(), torch.empty(buf.size, dtype=torch.float64, device=dev),
+                             torch.empty(world * buf.size, dtype=torch.float64, device=dev), torch.empty(world * buf.size, dtype=torch.float64).pin_memory())
+    send_h, send_d, recv_d, recv_h = _GATHER_BUFS[key]
+    send_h.numpy()[:] = buf
+    send_d.copy_(send_h, non_blocking=True)
+    dist.all_gather_into_tensor(recv_d, send_d)
+    recv_h.copy_(recv_d, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    return recv_h.numpy().copy()
+
+
+# relative cost of one CKDE candidate by the number of variables of its joint set (variable + parents): measured sweep times at
+# 1e6 x 1e5 rows (profiles/r2/sweep_dims.txt: KDE of d dimensions = the joint term; KDE of d - 1 = the marginal term)
+_KDE_MS = {1: 15.5, 2: 11.1, 3: 12.8, 4: 19.7, 5: 36.3, 6: 45.4, 7: 50.7}
+
+
+def _kde_cost(d):
+    return _KDE_MS.get(d, 51.6 + 5.0 * max(0, d - 8)) if d >= 1 else 0.0
+
+
+def deal_sets(keys, world):
+    """Owner rank of every variable set: longest processing time first on a cost model (one joint sweep per set + one marginal
+    sweep per candidate, x folds x rows being common factors), ties by first appearance, each set to the least loaded rank
+    (lowest rank on ties).  Deterministic, identical on every rank.  keys: list of (set, number of candidates) in order of
+    first appearance."""
+    cost = [(_kde_cost(len(k)) + n * _kde_cost(len(k) - 1), -i) for i, (k, n) in enumerate(keys)]
+    order = sorted(range(len(keys)), key=lambda i: cost[i], reverse=True)
+    load = [0.0] * world
+    owner = [0] * len(keys)
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += cost[i][0]
+    return owner
 
 
 def _raise_if_failed(flags, failure, where):
@@ -74,13 +117,16 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
     rank, world = dist.get_rank(), dist.get_world_size()
     m = len(heavy)
     # candidates over the same variable set (s -> t and t -> s share their joint KDE sum in the engine's set-function
-    # cache) go to the same rank: sets are dealt round-robin in order of first appearance, identically on every rank
-    set_of, owner = {}, []
+    # cache) go to the same rank; the sets are dealt by cost (deal_sets), identically on every rank
+    set_of, counts = {}, []
     for i in heavy:
         key = tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))
         if key not in set_of:
-            set_of[key] = len(set_of) % world
-        owner.append(set_of[key])
+            set_of[key] = len(set_of)
+            counts.append([key, 0])
+        counts[set_of[key]][1] += 1
+    set_owner = deal_sets([(k, n) for k, n in counts], world)
+    owner = [set_owner[set_of[tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))]] for i in heavy]
     lists = [[heavy[j] for j in range(m) if owner[j] == r] for r in range(world)]
     mine = lists[rank]
     per = max(1, max(len(l) for l in lists))

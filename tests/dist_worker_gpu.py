@@ -39,7 +39,25 @@ def run(fail_rank=-1):
     kde = pbn.KDE(["a", "b", "c"])
     kde.fit(df)
     test = table(700, 9)
-    return {"trace": trace, "deltas": [op.delta() for op in hc.last.trace], "arcs": sorted(res.arcs()),
+    # BGe / BIC on a linear-Gaussian table (score-equivalent orientations tie to the last ulps of the moments): with
+    # torch.distributed initialised the Score takes row-sharded moments (distributed.reduce_moments); the world-size-invariant
+    # summation must reproduce the single-process deltas bit for bit, hence the same tie decisions
+    rng = np.random.default_rng(17)
+    m, cols = 40000, 12
+    g = np.zeros((m, cols))
+    for j in range(cols):
+        g[:, j] = rng.normal(scale=rng.uniform(0.5, 1.5), size=m)
+        for pj in rng.choice(j, size=min(j, int(rng.integers(0, 3))), replace=False) if j else []:
+            g[:, j] += rng.uniform(-1.5, 1.5) * g[:, pj]
+    gdf = pd.DataFrame(g, columns=[f"g{i}" for i in range(cols)])
+    gauss = {}
+    for tag, sc in (("bge", pbn.BGe(gdf)), ("bic", pbn.BIC(gdf))):
+        h2 = pbn.GreedyHillClimbing()
+        r2 = h2.estimate(pbn.ArcOperatorSet(), sc, pbn.GaussianNetwork(list(gdf.columns)))
+        gauss[tag + "_trace"] = [[kinds[type(op)], op.source(), op.target()] for op in h2.last.trace]
+        gauss[tag + "_deltas"] = [op.delta().hex() for op in h2.last.trace]
+        gauss[tag + "_arcs"] = sorted(r2.arcs())
+    return {**gauss, "trace": trace, "deltas": [op.delta() for op in hc.last.trace], "arcs": sorted(res.arcs()),
             "types": [str(res.node_type(n)) for n in names], "cells": hc.last.cells_scored, "sweeps": sweeps,
             "slogl": distributed.sharded_slogl(kde, test)}
 

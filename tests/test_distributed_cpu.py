@@ -158,3 +158,26 @@ def test_failed_rank_does_not_hang_the_collective(ensure_built):
     second = {r: v for r, v in got if not isinstance(v, str)}
     assert first[1].startswith("ValueError: boom") and first[0].startswith("RuntimeError") and "[1]" in first[0]
     assert second[0] == second[1] == [float(i) for i in range(8)]
+
+
+def test_deal_sets_longest_first_is_balanced_and_deterministic():
+    """distributed.deal_sets: CKDE variable sets are dealt longest-processing-time first on the cost model (a d = 5 candidate
+    costs 3-4x a d = 2 one): no rank carries more than the mean load + one set, and the dealing is a pure function of the
+    batch (every rank computes the same owners)."""
+    from pybnesian_amd.distributed import _kde_cost, deal_sets
+
+    rng = np.random.default_rng(5)
+    keys = []
+    for _ in range(126):
+        d = int(rng.integers(1, 6))
+        keys.append((tuple(sorted(rng.choice(64, size=d, replace=False).tolist())), int(rng.integers(1, 3))))
+    cost = [_kde_cost(len(k)) + n * _kde_cost(len(k) - 1) for k, n in keys]
+    for world in (2, 3, 8):
+        owner = deal_sets(keys, world)
+        assert owner == deal_sets(list(keys), world)
+        load = [sum(c for c, o in zip(cost, owner) if o == r) for r in range(world)]
+        assert all(0 <= o < world for o in owner)
+        assert max(load) <= sum(cost) / world + max(cost)
+        # round-robin in order of first appearance (round 2) is worse or equal on this mix
+        rr = [sum(c for i, c in enumerate(cost) if i % world == r) for r in range(world)]
+        assert max(load) <= max(rr) + 1e-9

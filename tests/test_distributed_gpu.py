@@ -53,6 +53,13 @@ def test_sharded_delta_cache_with_device_ckde_scores_world2():
         assert r["cells"] == single["cells"]
         assert np.allclose(r["deltas"], single["deltas"], rtol=1e-9, atol=1e-9)
         assert abs(r["slogl"] - single["slogl"]) <= 1e-11 * abs(single["slogl"])
+        # row-sharded moments (BGe / BIC): the summation does not depend on the number of ranks - identical deltas, bit for bit,
+        # and therefore identical decisions at every score-equivalence tie
+        for tag in ("bge", "bic"):
+            assert len(single[tag + "_trace"]) >= 8
+            assert r[tag + "_trace"] == single[tag + "_trace"]
+            assert r[tag + "_deltas"] == single[tag + "_deltas"]
+            assert r[tag + "_arcs"] == single[tag + "_arcs"]
     # the device work was split: every rank swept fewer (set, fold) units than the single process, together at least as many
     assert max(r["sweeps"] for r in ranks) < single["sweeps"]
     assert sum(r["sweeps"] for r in ranks) >= single["sweeps"]

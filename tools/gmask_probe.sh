@@ -1,0 +1,5 @@
+# per-group visit masks of the pruned fp64 sweeps (PBN_PRUNE_GROUP_MASKS) on cv64 and the first C3 iteration
+cd $GRAFT_REPO_ROOT
+run() { hc=$1; shift; env "$@" python3 bench.py --no-c3 --no-e2e --no-cpu-baseline --hc $hc --hc-max-iters 1 --steps 1 --warmup 1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read())['secondary']; print('%.3f s  cells %d' % (d['estimate_s'], d['cells_scored']))"; }
+for m in 1 0; do echo -n "cv64 PBN_PRUNE_GROUP_MASKS=$m: "; run cv64 PBN_PRUNE_GROUP_MASKS=$m; done
+for m in 1 0; do echo -n "c3 PBN_PRUNE_GROUP_MASKS=$m: "; run c3 PBN_PRUNE_GROUP_MASKS=$m; done
