@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbn_hip.so")
+# PBN_LIB: another build of the SAME library (the host-sanitizer build of `make asan`, tools/asan_cpu.sh); never a fallback
+LIB_PATH = os.environ.get("PBN_LIB") or os.path.join(_HERE, "libpbn_hip.so")
 
 PBN_OK, PBN_ERR_INVALID, PBN_ERR_SINGULAR, PBN_ERR_DEVICE = 0, 1, 2, 3
 PBN_F64, PBN_F32 = 0, 1

@@ -673,7 +673,7 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
             stats->cells_scored = e.cells_scored;
             stats->local_score_evals = e.scorer.evals;
             stats->trace_len = (int)trace.size() / 4;
-            if (stats->trace) std::memcpy(stats->trace, trace.data(), trace.size() * sizeof(int));
+            if (stats->trace && !trace.empty()) std::memcpy(stats->trace, trace.data(), trace.size() * sizeof(int));   // (an empty vector's data() may be null: UB for memcpy even with size 0 - found by the host sanitizer run)
         }
     });
 }

@@ -68,10 +68,12 @@ struct SweepArgs {
     // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first
     // `pdims` whitened dimensions, and qtile_thr holds, per query tile, a lower bound of its queries' largest exponents
     // (from a scan of the training rows next to them in Morton order).  A wave skips a training tile whose box is so far
-    // from the box of its queries that every exponent is below that bound - 64: such terms are < 2^-64 of their sums.
+    // from the box of its queries that every exponent is below that bound - prune_margin (52 fp64 / 40 fp32): such terms are
+    // < 2^-margin of their sums each, i.e. at most N 2^-margin of a sum in total (2.2e-10 at 10^6 rows in fp64) - a bound that
+    // grows linearly with the number of training rows; PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override.
     int prune;
     int pdims;
-    double prune_margin;       // base-2 exponent distance below the queries' bound beyond which a tile is skipped (64 / 40)
+    double prune_margin;       // base-2 exponent distance below the queries' bound beyond which a tile is skipped (52 / 40)
     const double* tile_box;    // [ntiles][2 * pdims]: lo..., hi...
     const double* qtile_box;   // [nqtiles][2 * pdims]
     const double* qtile_thr;   // [nqtiles]
@@ -126,7 +128,7 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
                           const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);
-double prune_margin(int dtype);   // 64 (fp64) / 40 (fp32 on the bf16 cores); PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override
+double prune_margin(int dtype);   // 52 (fp64) / 40 (fp32 on the bf16 cores); PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 

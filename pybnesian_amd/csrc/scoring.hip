@@ -560,6 +560,13 @@ int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* con
     return guarded([&] {
         if (!sd || (n_disc > 0 && (!codes || !cardinality))) throw invalid_error("pbn_scoredata_set_discrete: null argument");
         const int64_t rows = (int64_t)sd->perm.size();
+        // everything derived from the previous codes (device row lists of the groupings, per-configuration KDE sums, memoised
+        // local scores) is stale: let the work in flight finish, then drop it
+        HIP_CHECK(hipStreamSynchronize(sd->ctx->stream));
+        sd->ctx->sync_lanes(pbn_ctx::MAX_PARKED);
+        sd->groupings.clear();
+        sd->kde_cache.clear();
+        sd->score_memo.clear();
         sd->n_disc = n_disc;
         sd->codes.assign(n_disc, std::vector<int32_t>((size_t)rows));
         sd->card.assign(cardinality, cardinality + n_disc);
@@ -729,6 +736,13 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
         if ((kind == PBN_SCORE_CVLIK) && sd->k <= 0) throw invalid_error("pbn_score_batch: score data has no CV folds");
         if ((kind == PBN_SCORE_HOLDOUT) && sd->n_hold <= 0) throw invalid_error("pbn_score_batch: score data has no hold-out split");
         const pbn_table* t = sd->table();
+        // The set-function cache and the local-score memo grow by one entry per (region, configuration, term) and per hybrid
+        // candidate (~150 B a node): a long search over hybrid candidates would take gigabytes.  Both are pure accelerators -
+        // beyond PBN_SCORE_CACHE_ENTRIES entries (default 2^21, ~300 MB) they start over, at a batch boundary (no entry of
+        // the batch being assembled is lost).
+        static const size_t cache_budget = [] { const char* e = getenv("PBN_SCORE_CACHE_ENTRIES"); const long long v = (e && *e) ? atoll(e) : (1ll << 21); return (size_t)(v < 1 ? 1 : v); }();
+        if (sd->kde_cache.size() > cache_budget) { sd->kde_cache.clear(); ++sd->cache_resets; }
+        if (sd->score_memo.size() > cache_budget) { sd->score_memo.clear(); ++sd->cache_resets; }
         // BGe parameters
         double iss_mu = 1, iss_w = sd->n + 2;
         int total_nodes = sd->n;

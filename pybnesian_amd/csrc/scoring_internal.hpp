@@ -54,6 +54,7 @@ struct pbn_scoredata {
     // hybrid likelihood local scores by [kind, node type, variable, sorted parents...] (see pbn_score_batch)
     std::map<std::vector<int>, double> score_memo;
     int64_t memo_hits = 0;
+    int64_t cache_resets = 0;   // times kde_cache / score_memo started over (PBN_SCORE_CACHE_ENTRIES)
     bool partial = false;  // moments hold only this rank's row share (pbn_scoredata_create_sharded)
     const pbn_table* src = nullptr;  // caller's table (borrowed)
     pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)

@@ -837,10 +837,14 @@ static int launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st
         if (gram_variant() >= 2) {
             if (a.num_cus > 0 && nblocks > GD_BLOCKS_PER_CU * a.num_cus) grid.x = GD_BLOCKS_PER_CU * a.num_cus;   // one block per slot
             const int dbg = a.debug_skip == 1 ? 1 : a.debug_skip >= 2 ? 2 : 0;
+#ifdef PBN_GRAM_MEASURE   // measurement builds only (tools/gram_variants.sh): the floor variants produce garbage statistics
 #define PBN_GLDS_K(K, N)                                                                                \
         if (dbg == 0) hipLaunchKernelGGL((K<N, 0>), grid, block, 0, st, a);                            \
         else if (dbg == 1) hipLaunchKernelGGL((K<N, 1>), grid, block, 0, st, a);                       \
         else hipLaunchKernelGGL((K<N, 2>), grid, block, 0, st, a);
+#else
+#define PBN_GLDS_K(K, N) (void)dbg; hipLaunchKernelGGL((K<N, 0>), grid, block, 0, st, a);
+#endif
 #define PBN_GLDS(N)                                                                                     \
     case N:                                                                                             \
         if constexpr (sizeof(T) == 8) { PBN_GLDS_K(gram_glds_kernel, N) } else { PBN_GLDS_K(gram_glds_f32_kernel, N) }   \
@@ -890,8 +894,15 @@ void launch_pilot(const void* base, int64_t ld, const GramCols& gc, int n_cols, 
 
 void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipStream_t st) {
     GramArgs a = a_in;
+    // PBN_GRAM_DEBUG (1 = no MFMAs, 2 = no loads: floors of the two halves, garbage statistics) exists in measurement builds only
+    // (-DPBN_GRAM_MEASURE, tools/gram_variants.sh); the production library refuses it instead of silently returning garbage
     static const int dbg = [] { const char* e = getenv("PBN_GRAM_DEBUG"); return (e && *e) ? atoi(e) : 0; }();
+#ifdef PBN_GRAM_MEASURE
     a.debug_skip = dbg;
+#else
+    if (dbg != 0) throw invalid_error("PBN_GRAM_DEBUG needs a library built with -DPBN_GRAM_MEASURE (tools/gram_variants.sh)");
+    a.debug_skip = 0;
+#endif
     // PBN_GRAM_STAMPS=1: gram_glds_kernel's blocks record their start / end (10 ns ticks) and hardware slot; printed to stderr
     static const bool want_stamps = [] { const char* e = getenv("PBN_GRAM_STAMPS"); return e && *e && atoi(e) != 0; }();
     static long long* stamps_dev = nullptr;

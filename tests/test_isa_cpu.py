@@ -1,0 +1,46 @@
+"""CPU tier (cross-compile only): ISA invariants the hand-scheduled kernels rely on.
+
+gram_glds_kernel / gram_glds_f32_kernel (stats_kernels.hip) issue their LDS-DMA loads through inline asm - invisible to hipcc's
+wait-count bookkeeping - and order the per-wave ring with hand-written `s_waitcnt vmcnt(N)`.  That count is right only while the
+compiler puts NO other vector-memory instruction into the steady-state loop: a scratch spill or a re-materialised global load
+would shift it, and the MFMAs would read a stage before it has landed - silently wrong moments.  This test compiles the file for
+gfx950 and checks every basic block that holds both MFMAs and LDS-DMA loads."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pybnesian_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def stats_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "stats_kernels.s"
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                        "stats_kernels.hip", "-o", str(out)], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return out.read_text()
+
+
+def kernels(asm, pattern):
+    for f in re.split(r"\n(?=_Z[A-Za-z0-9_]+:)", asm):
+        name = f.split(":", 1)[0]
+        if re.search(pattern, name):
+            yield name, f.split("s_endpgm")[0]
+
+
+def test_glds_ring_loops_hold_no_other_vector_memory_instruction(stats_asm):
+    seen = 0
+    for name, body in kernels(stats_asm, r"gram_glds(_f32)?_kernelILi[1-4]ELi0E"):
+        seen += 1
+        assert "scratch_" not in body, f"{name}: scratch spill"
+        assert not re.search(r"\bbuffer_(load|store)", body), name
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        ring = [b for b in blocks if "v_mfma_f64" in b and "global_load_lds" in b]
+        assert ring, f"{name}: no steady-state block with MFMAs and LDS-DMA loads found"
+        for b in ring:
+            other = re.findall(r"^\s*(global_load_dword\w*|global_store\w*|flat_load\w*|flat_store\w*|global_atomic\w*)", b, flags=re.M)
+            assert not other, f"{name}: {other[:3]} inside the ring loop shifts the hand-counted vmcnt"
+    assert seen == 8   # NCT = 1..4, double and float tables
