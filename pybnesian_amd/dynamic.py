@@ -491,10 +491,10 @@ class DMMHC:
         g0 = mmhc.estimate(hypot_test.static_tests(), operators, score.static_score(), static_nodes, bn_type,
                            arc_blacklist=static_blacklist(variables, markovian_order), callback=static_callback,
                            max_indegree=max_indegree, max_iters=max_iters, epsilon=epsilon, patience=patience, alpha=alpha)
-        self.static_tests = mmhc.last_tests
+        self.static_tests, self.static_cpcs, self.static_search = mmhc.last_tests, mmhc.last_cpcs, mmhc.hc.last
         transition_nodes = temporal_names(variables, 0, 0)
         gt = mmhc.estimate_conditional(hypot_test.transition_tests(), operators, score.transition_score(), transition_nodes,
                                        static_nodes, bn_type, callback=transition_callback, max_indegree=max_indegree,
                                        max_iters=max_iters, epsilon=epsilon, patience=patience, alpha=alpha)
-        self.transition_tests = mmhc.last_tests
+        self.transition_tests, self.transition_cpcs, self.transition_search = mmhc.last_tests, mmhc.last_cpcs, mmhc.hc.last
         return DynamicBayesianNetwork(variables, markovian_order, g0, gt)

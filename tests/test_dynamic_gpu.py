@@ -162,3 +162,60 @@ def test_dbn_sample(pbn):
     assert dbn.sample(1, 3).num_rows == 1 and dbn.sample(0, 3).num_rows == 0
     with pytest.raises(ValueError, match="non-negative"):
         dbn.sample(-1, 0)
+
+
+@pytest.mark.parametrize("order,spbn", [(1, False), (2, False), (1, True)])
+def test_dmmhc_matches_the_serial_restatement(pbn, order, spbn):
+    """DMMHC with device scores against oracle/dmmhc_oracle.py (dmmhc.cpp:34-118 + DynamicScoreAdaptator, scores.hpp:74-101, restated
+    over mmpc_oracle / hc_oracle / the oracle's local scores): the same CPC sets and numbers of independence tests in both phases,
+    the same operator sequences of the two hill-climbs (static network; conditional transition network with the static nodes as
+    interface), the same arcs and node types.  Likelihood scores (cross-validated LinearGaussian; validated CKDE / LinearGaussian with
+    node-type changes): no score-equivalence ties, so the sequences are comparable step by step."""
+    from oracle import dmmhc_oracle, oracle
+
+    rng = np.random.default_rng(7 + order)
+    n = 2500
+    a, b, c = np.zeros(n), np.zeros(n), np.zeros(n)
+    for t in range(2, n):
+        a[t] = 0.7 * a[t - 1] + rng.normal(scale=0.5)
+        b[t] = 0.4 * b[t - 1] + np.tanh(1.5 * a[t]) + (0.5 * a[t - 2] if order > 1 else 0.0) + rng.normal(scale=0.4)
+        c[t] = -0.8 * b[t - 1] + 0.3 * c[t - 1] + rng.normal(scale=0.5)
+    df = pd.DataFrame({"a": a, "b": b, "c": c})
+    names = list(df.columns)
+    ddf = pbn.DynamicDataFrame(df, order)
+    k, seed, ratio, alpha = 3, 0, 0.2, 0.01
+    if spbn:
+        score = pbn.DynamicValidatedLikelihood(ddf, ratio, k, seed)
+        ops, bn_type = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]), pbn.SemiparametricBNType()
+
+        def make_score(table):
+            return (lambda v, t, ps: oracle.validated_cv_likelihood(table[:, [v] + list(ps)], "ckde" if t == 1 else "lg", ratio, k, seed),
+                    lambda v, t, ps: oracle.holdout_likelihood(table[:, [v] + list(ps)], "ckde" if t == 1 else "lg", ratio, seed))
+    else:
+        score = pbn.DynamicCVLikelihood(ddf, k, seed)
+        ops, bn_type = pbn.ArcOperatorSet(), pbn.GaussianNetworkType()
+
+        def make_score(table):
+            return (lambda v, t, ps: oracle.cv_likelihood(table[:, [v] + list(ps)], "lg", k, seed)), None
+    dm = pbn.DMMHC()
+    dbn = dm.estimate(pbn.DynamicLinearCorrelation(ddf), ops, score, bn_type=bn_type, markovian_order=order, alpha=alpha, max_indegree=3)
+    want = dmmhc_oracle.dmmhc(df.to_numpy(), names, order, alpha, make_score, bn_type=1 if spbn else 0, op_types=spbn, max_indegree=3)
+
+    kinds = {pbn.AddArc: 0, pbn.RemoveArc: 1, pbn.FlipArc: 2}
+    tcode = {pbn.LinearGaussianCPDType(): 0, pbn.CKDEType(): 1}
+    for phase, net, cpcs, tests, search in (("static", dbn.static_bn(), dm.static_cpcs, dm.static_tests, dm.static_search),
+                                            ("transition", dbn.transition_bn(), dm.transition_cpcs, dm.transition_tests, dm.transition_search)):
+        w = want[phase]
+        joint = w["nodes"] + w.get("interface", [])
+        col = {v: i for i, v in enumerate(joint)}
+        assert net.nodes() == w["nodes"]
+        assert [[col[v] for v in cpc] for cpc in cpcs] == w["cpcs"], phase
+        assert tests == w["tests"], phase
+        got = [(3, col[op.node()], tcode[op.node_type()]) if isinstance(op, pbn.ChangeNodeType) else (kinds[type(op)], col[op.source()], col[op.target()])
+               for op in search.trace]
+        assert got == [tuple(t) for t in w["trace"]], (phase, got, w["trace"])
+        assert np.allclose([op.delta() for op in search.trace], w["deltas"], rtol=1e-6, atol=1e-6)
+        assert sorted((col[s], col[t]) for s, t in net.arcs()) == w["arcs"], phase
+        assert [tcode[net.node_type(v)] for v in w["nodes"]] == w["types"][: len(w["nodes"])]
+        assert search.cells_scored == w["cells"]
+    assert dbn.transition_bn().num_arcs() >= 3

@@ -89,3 +89,128 @@ def test_c4_fullsize_properties(env):
     cpd = pbn.LinearGaussianCPD(node, res.parents(node))
     cpd.fit_table(table)
     assert np.allclose(beta, cpd.beta, rtol=1e-9) and np.isclose(var, cpd.variance, rtol=1e-9)
+
+
+def _trace(pbn, hc):
+    return [(repr(op), op.delta()) for op in hc.last.trace]
+
+
+def test_c3_fullsize_properties(env, monkeypatch):
+    """BASELINE config 3 at full size (32-node SemiparametricBN, all-CKDE start, 10-fold CVLikelihood, 500 000 rows fp64): what the
+    miniature oracle comparisons of test_hc_gpu.py cannot reach, through properties - decomposability of the applied deltas,
+    pruned / grouped evaluation against the unpruned per-(set, fold) sweeps on three candidates, fold additivity against explicit
+    CKDE handles, and a bit-identical second run from a fresh score object."""
+    torch, pbn, _lib, ctx = env
+    import bench
+
+    dev = torch.device("cuda", 0)
+    t = bench.make_dag_table(torch, dev, 500_000, 32, 2, torch.float64, nonlinear=True)
+    names = [f"x{i}" for i in range(32)]
+    table = _table(torch, pbn, _lib, ctx, t, names)
+    ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
+    start = pbn.SemiparametricBN(names, [], [(n_, pbn.CKDEType()) for n_ in names])
+
+    def run():
+        score = pbn.CVLikelihood(None, 10, 0, table=table)
+        hc = pbn.GreedyHillClimbing()
+        res = hc.estimate(ops, score, start, max_indegree=3, max_iters=3)
+        return score, hc, res
+
+    score, hc, res = run()
+    trace = _trace(pbn, hc)
+    assert len(trace) == 3 and hc.last.cells_scored > 1000
+    # decomposability: every applied delta is the change of the sum of local scores
+    model = start.clone()
+    total = score.score(model)
+    for op in hc.last.trace:
+        op.apply(model)
+        new = score.score(model)
+        assert abs((new - total) - op.delta()) <= 1e-9 * abs(new), repr(op)
+        total = new
+    # three candidates (1, 2, 3 parents): grouped + pruned (default) = per-unit pruned = unpruned, from fresh score objects
+    cands = [("x5", ["x1"]), ("x9", ["x2", "x4"]), ("x20", ["x3", "x7", "x11"])]
+    ref = [score.local_score_node_type(start, pbn.CKDEType(), v, p) for v, p in cands]
+    for env_kv, tol in (({"PBN_SCORE_GROUPED": "0"}, 1e-11), ({"PBN_SWEEP_PRUNE": "0"}, 1e-10)):
+        for k_, v_ in env_kv.items():
+            monkeypatch.setenv(k_, v_)
+        other = pbn.CVLikelihood(None, 10, 0, table=table)
+        got = [other.local_score_node_type(start, pbn.CKDEType(), v, p) for v, p in cands]
+        for k_ in env_kv:
+            monkeypatch.delenv(k_)
+        assert np.allclose(got, ref, rtol=tol, atol=0), (env_kv, got, ref)
+    # fold additivity against explicit factors: the CV score of x5 | x1 is the sum over the folds of CKDE.fit(train).slogl(test)
+    import pandas as pd
+
+    host = pd.DataFrame(t[[5, 1]].T.cpu().numpy(), columns=["x5", "x1"])
+    acc = 0.0
+    for tr_idx, te_idx in pbn.CrossValidation(host, 10, 0).indices():
+        cpd = pbn.CKDE("x5", ["x1"])
+        cpd.fit(host.iloc[tr_idx])
+        acc += cpd.slogl(host.iloc[te_idx])
+    assert abs(acc - ref[0]) <= 1e-9 * abs(acc)
+    # run-to-run: a fresh score object and search take bit-identical decisions
+    _, hc2, res2 = run()
+    assert _trace(pbn, hc2) == trace and sorted(res2.arcs()) == sorted(res.arcs())
+
+
+def test_c5_fullsize_properties(env, monkeypatch):
+    """BASELINE config 5 at full size (48 columns, 16 discrete, 1 000 000 rows fp32, ValidatedLikelihood(0.2, 10)): decomposability
+    of the applied deltas, pruned against unpruned slices on three hybrid candidates, validation-score additivity against explicit
+    factors over the hold-out split, and a bit-identical second run."""
+    torch, pbn, _lib, ctx = env
+    import pandas as pd
+
+    n_rows, n_disc, n_cont = 1_000_000, 16, 32
+    rng = np.random.default_rng(3)
+    cards = rng.integers(2, 5, size=n_disc)
+    disc = {}
+    for j in range(n_disc):
+        base = rng.integers(0, cards[j], size=n_rows)
+        if j > 0:
+            base = np.where(rng.random(n_rows) < 0.3, disc[f"D{j - 1}"] % cards[j], base)
+        disc[f"D{j}"] = base.astype(np.int32)
+    import bench
+
+    t = bench.make_dag_table(torch, torch.device("cuda", 0), n_rows, n_cont, 3, torch.float32, nonlinear=True).cpu().numpy()
+    df = pd.DataFrame({f"x{j}": t[j] + 1.5 * disc[f"D{j % n_disc}"].astype(np.float32) for j in range(n_cont)})
+    for j in range(n_disc):
+        df[f"D{j}"] = pd.Categorical.from_codes(disc[f"D{j}"], [f"c{v}" for v in range(cards[j])])
+    names = list(df.columns)
+    pairs = [(a, b) for a in names for b in names if a != b]
+    keep = rng.random(len(pairs)) < 0.15
+    blacklist = [p for p, k_ in zip(pairs, keep) if not k_]
+    start = pbn.SemiparametricBN(names, [], [(f"D{j}", pbn.DiscreteFactorType()) for j in range(n_disc)])
+    ops = pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()])
+
+    def run():
+        score = pbn.ValidatedLikelihood(df, 0.2, 10, 0)
+        hc = pbn.GreedyHillClimbing()
+        res = hc.estimate(ops, score, start, max_indegree=3, arc_blacklist=blacklist, max_iters=4)
+        return score, hc, res
+
+    score, hc, res = run()
+    trace = _trace(pbn, hc)
+    assert len(trace) >= 2
+    model = start.clone()
+    total = score.score(model)
+    for op in hc.last.trace:
+        op.apply(model)
+        new = score.score(model)
+        assert abs((new - total) - op.delta()) <= 2e-6 * abs(new), repr(op)     # fp32 table: sums of ~1e6 float-accurate terms
+        total = new
+    cands = [("x3", pbn.CKDEType(), ["D3"]), ("x8", pbn.CKDEType(), ["x2", "D8"]), ("x17", pbn.LinearGaussianCPDType(), ["x4", "D1", "D2"])]
+    ref = [score.local_score_node_type(start, ty, v, p) for v, ty, p in cands]
+    vref = [score.vlocal_score_node_type(start, ty, v, p) for v, ty, p in cands]
+    monkeypatch.setenv("PBN_SWEEP_PRUNE", "0")
+    other = pbn.ValidatedLikelihood(df, 0.2, 10, 0)
+    got = [other.local_score_node_type(start, ty, v, p) for v, ty, p in cands]
+    monkeypatch.delenv("PBN_SWEEP_PRUNE")
+    assert np.allclose(got, ref, rtol=2e-6, atol=0), (got, ref)
+    # validation score of x3 | D3 (HCKDE) = the factor fitted on the hold-out training part, evaluated on its test part
+    ho = pbn.HoldOut(df[["x3", "D3"]], 0.2, 0)
+    f = pbn.HCKDE("x3", ["D3"])
+    f.fit(ho.training_data())
+    v_direct = f.slogl(ho.test_data())
+    assert abs(v_direct - vref[0]) <= 1e-3 * abs(v_direct)                      # fp32 slices: the north star's fp32 bar
+    _, hc2, res2 = run()
+    assert _trace(pbn, hc2) == trace and sorted(res2.arcs()) == sorted(res.arcs())

@@ -124,3 +124,51 @@ def test_lg_cdf_and_sample(pbn, df, golden):   # LinearGaussianCPD_test.py:211-2
     a.fit(df)
     b.fit(df)
     assert np.all(np.isclose(a.cdf(test_df), b.cdf(test_df)))
+
+
+@pytest.mark.parametrize("kind", ["gbn", "mixed"])
+def test_network_logl_vs_oracle_factors(pbn, df, golden, kind):
+    """BayesianNetwork::logl / slogl (models/BayesianNetwork.hpp:930-958: the sum of the factors' log-likelihoods) against the
+    ORACLE's factors on the golden table - LinearGaussianCPD by the restated MLE (mle_LinearGaussianCPD.hpp:11-193) + normal
+    log-density, CKDE by the restated normal-reference bandwidth + per-pair sums - not against the product's own factor objects
+    (test_network_logl_is_sum_of_factors above)."""
+    from oracle import oracle
+
+    types = [("a", pbn.CKDEType()), ("c", pbn.CKDEType())] if kind == "mixed" else []
+    net = pbn.SemiparametricBN(FULL, types) if kind == "mixed" else pbn.GaussianNetwork(FULL)
+    net.fit(df)
+    test_df = frame(golden["train500"])
+    tr, te = df, test_df
+    want = np.zeros(te.shape[0])
+    for v in net.nodes():
+        cols = [v] + list(net.parents(v))
+        if net.node_type(v) == pbn.CKDEType():
+            H = oracle.nr_bandwidth(tr[cols].to_numpy())
+            want += oracle.ckde_logl(tr[cols].to_numpy(), H, te[cols].to_numpy())
+        else:
+            beta, var = oracle.lg_fit(tr[cols].to_numpy())
+            want += oracle.lg_logl(te[cols].to_numpy(), beta, var)
+    got = net.logl(test_df)
+    assert np.allclose(got, want, rtol=1e-8, atol=1e-8)
+    assert abs(net.slogl(test_df) - want.sum()) <= 1e-9 * abs(want.sum())
+
+
+def test_network_sample_order_is_pinned(pbn, df):
+    """BNGeneric::sample (BayesianNetwork.hpp:960-994) seeds node i of the topological order with seed + i.  The reference's order
+    comes out of libstdc++ unordered_sets (roots, children: generic_graph.hpp:2659-2710) and depends on the graph's edit history;
+    here the order is the documented index-ordered one (models.BayesianNetwork.topological_sort).  This pins it: the joint sample
+    is reproduced column by column from the factors' own samplers with seed + position in THAT order - per-factor parity with the
+    reference's samplers is tested in test_sampling_gpu.py, the order is a documented divergence."""
+    import pyarrow as pa
+
+    net = pbn.GaussianNetwork(["a", "b", "c", "d"], [("c", "a"), ("a", "b"), ("d", "b")])
+    net.fit(df)
+    order = net.topological_sort()
+    assert order == ["d", "c", "a", "b"]          # stack-driven Kahn: roots in index order (c, d) pushed, d popped first
+    s = net.sample(257, 11)
+    assert s.schema.names == order                # unordered output: columns in sampling order
+    cols = {}
+    for i, v in enumerate(order):
+        ev = pa.RecordBatch.from_arrays([pa.array(cols[p]) for p in net.parents(v)], names=list(net.parents(v))) if net.parents(v) else None
+        cols[v] = np.asarray(net.cpd(v).sample(257, ev, 11 + i))
+        assert np.array_equal(s.column(i).to_numpy(), cols[v]), v

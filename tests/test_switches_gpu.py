@@ -4,6 +4,10 @@ compared with the default run:
  * PBN_SCORE_LANES=1 (one issue lane) - the sums do not depend on the issue order: identical to the last bit;
  * PBN_SWEEP_QLB=0 (offsets from the split's first tile instead of the prepass bounds) and PBN_SWEEP_PRUNE=0 (no tile
    pruning) - other offsets / other partitions of the same sums: equal to rounding, the fp32 sweeps to their own precision;
+ * PBN_SCORE_GROUPED=0 (one launch chain per (set, fold) as in round 2 instead of the grouped evaluation of kde_group.hip),
+   PBN_PRUNE_GROUP_MASKS=0 (one visit mask per wave instead of one per 16-query group), PBN_GROUP_SUM_BOUND=0 (pruning
+   threshold on the largest known term instead of the known part of the sum), PBN_GROUP_SPLIT_TILES / PBN_GROUP_MAX_POOLS
+   (other partitions of the same work);
  * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_FULL_BUDGET_MB=0 (their cache
    budget exhausted: the same fallback), PBN_MI_THREADS=1;
  * PBN_GRAM_LDS=1 / 0 (the older Gram kernels)."""
@@ -44,7 +48,8 @@ def test_one_issue_lane_is_bit_identical(default):
     assert got == default
 
 
-@pytest.mark.parametrize("env", [{"PBN_SWEEP_QLB": "0"}, {"PBN_SWEEP_PRUNE": "0"}])
+@pytest.mark.parametrize("env", [{"PBN_SWEEP_QLB": "0"}, {"PBN_SWEEP_PRUNE": "0"}, {"PBN_SCORE_GROUPED": "0"}, {"PBN_PRUNE_GROUP_MASKS": "0"},
+                                 {"PBN_GROUP_SUM_BOUND": "0"}, {"PBN_GROUP_SPLIT_TILES": "64"}, {"PBN_GROUP_MAX_POOLS": "1"}])
 def test_sweep_switches(default, env):
     got = run(env)
     assert close(got["cv_ckde_float64"], default["cv_ckde_float64"], 1e-10)
