@@ -22,6 +22,7 @@
 #include <numeric>
 
 #include "hostmath.hpp"
+#include "kde_group.hpp"
 #include "kde_kernels.hpp"
 #include "kde_model.hpp"
 #include "scoring_internal.hpp"
@@ -447,6 +448,70 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         return k;
     };
     auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    // Grouped evaluation (kde_group.hip): the slices of one configuration and one term (joint / marginal variable set) share a
+    // POOL - the configuration's block of the grouped row list, its regions the folds (or hold-out train / test) - and are
+    // evaluated by one launch chain for the whole candidate instead of one chain per (fold, configuration, term).  A pool takes
+    // this path when every training slice of the configuration is large enough for the pruned sweeps.
+    GroupBatch gb;
+    std::vector<std::vector<GUnit>> pool_units;
+    std::vector<int> pool_of((size_t)g.nc * 2, -1);   // (configuration, which) -> pool
+    std::vector<char> elig((size_t)g.nc * 2, 0);
+    if (node_type == PBN_NODE_CKDE) {
+        for (int c = 0; c < g.nc; ++c) {
+            int64_t min_train = -1;
+            for (int u = 0; u < units; ++u) {
+                const int64_t ntr = cv ? allc[c].N - M[cell(c, u)].N : M[cell(c, 0)].N;
+                const int64_t nte = cv ? M[cell(c, u)].N : M[cell(c, 1)].N;
+                if (ntr <= 1 || nte == 0) continue;
+                min_train = min_train < 0 ? ntr : std::min(min_train, ntr);
+            }
+            for (int which = 0; which < (pc > 0 ? 2 : 1); ++which)
+                elig[(size_t)c * 2 + which] = min_train > 0 && kde_group_applies(sd->dtype, d - which, min_train, R);
+        }
+    }
+    auto group_unit = [&](int c, int u, int which, const KdeModel& m, const int* v, int nv, int64_t ntrain, int64_t ntest, int slot) {
+        int& pi = pool_of[(size_t)c * 2 + which];
+        if (pi < 0) {
+            pi = (int)gb.pools.size();
+            GPool P{};
+            const int64_t base = g.off[cell(c, 0)];
+            P.rows = g.rows.p; P.row_base = base;
+            P.n = (int32_t)(g.off[cell(c, R - 1) + 1] - base);
+            P.R = R; P.d = nv; P.kd = std::min(nv, 4);
+            for (int r = 0; r < R; ++r) P.rb[r] = (int32_t)(g.off[cell(c, r)] - base);
+            P.rb[R] = P.n;
+            for (int r = 0; r < PBN_GROUP_MAX_R; ++r) P.test_unit[r] = -1;
+            for (int i = 0; i < nv; ++i) P.cols[i] = v[i];
+            // pool-level standardisation for the Morton keys: the configuration's own covariance of the term's columns (training
+            // part for the hold-out score); a singular one falls back to the diagonal - the keys only order the rows
+            const Stats& all = cv ? allc[c] : M[cell(c, 0)];
+            std::vector<double> gm(d), gs((size_t)d * d), sub((size_t)nv * nv), L((size_t)nv * nv), Li((size_t)nv * nv);
+            local_moments(sd, all, cols.data(), d, gm.data(), gs.data());
+            for (int j = 0; j < nv; ++j)
+                for (int i = 0; i < nv; ++i) sub[i + (size_t)j * nv] = gs[(i + which) + (size_t)(j + which) * d] / (double)std::max<int64_t>(1, all.N - 1);
+            if (!hm::cholesky(sub.data(), nv, L.data())) {
+                std::fill(L.begin(), L.end(), 0.0);
+                for (int i = 0; i < nv; ++i) L[i + (size_t)i * nv] = std::sqrt(std::max(sub[i + (size_t)i * nv], 1e-300));
+            }
+            hm::lower_inverse(L.data(), nv, Li.data());
+            for (int i = 0; i < nv; ++i) {
+                P.mug[i] = gm[i + which];
+                for (int j = 0; j < nv; ++j) P.Wg[i * nv + j] = j <= i ? Li[i + (size_t)j * nv] : 0.0;
+            }
+            gb.pools.push_back(P);
+            pool_units.emplace_back();
+        }
+        GUnit U{};
+        U.test_region = cv ? u : 1;
+        U.train_mask = cv ? (((R >= 64) ? ~0ull : ((1ull << R) - 1ull)) & ~(1ull << u)) : 1ull;
+        U.N = (int32_t)ntrain; U.nq = (int32_t)ntest;
+        U.lognorm = m.lognorm;
+        for (int i = 0; i < nv * nv; ++i) U.W[i] = m.W[i];
+        for (int i = 0; i < nv; ++i) U.mu[i] = m.mu[i];
+        U.sum_slot = slot;
+        gb.pools[pi].test_unit[U.test_region] = (int32_t)pool_units[pi].size();
+        pool_units[pi].push_back(U);
+    };
     for (int u = 0; u < units; ++u) {
         for (int c = 0; c < g.nc; ++c) {
             const Stats* tr;
@@ -489,7 +554,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             // two plain ones); fp64 slices and slices with one term cached take the plain sweeps
             static const int fused_mode = [] { const char* e = getenv("PBN_HYBRID_FUSED"); return (e && *e) ? atoi(e) : -1; }();
             const bool want_fused = fused_mode < 0 ? (use_bf16x3(sd->dtype) && d > PBN_HYBRID_SPLIT_MAX_D) : fused_mode != 0;
-            if (pc > 0 && want_fused && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
+            const bool grouped_both = elig[(size_t)c * 2] && (pc == 0 || elig[(size_t)c * 2 + 1]);
+            if (pc > 0 && want_fused && !grouped_both && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
                 sd->kde_cache.find(key_of(u, c, cols.data() + 1, pc)) == sd->kde_cache.end()) {
                 KdeModel m;
                 try {
@@ -537,6 +603,11 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 }
                 term.slot = (int)slot_key.size();
                 slot_key.push_back(key);
+                if (elig[(size_t)c * 2 + which]) {   // evaluated with the candidate's other grouped slices, after the loops
+                    group_unit(c, u, which, m, v, nv, tr->N, te->N, term.slot);
+                    ++sd->kde_sweeps;
+                    continue;
+                }
                 const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, false, tr->N);
                 LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
@@ -552,11 +623,20 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             slices.push_back(sl);
         }
     }
+    if (!gb.pools.empty()) {
+        for (size_t pi = 0; pi < gb.pools.size(); ++pi) {
+            gb.pools[pi].unit0 = (int32_t)gb.units.size();
+            gb.pools[pi].nunits = (int32_t)pool_units[pi].size();
+            gb.units.insert(gb.units.end(), pool_units[pi].begin(), pool_units[pi].end());
+        }
+        kde_group_run(ctx, t, gb, dsums.p);   // on the context's own stream, next to the lanes' per-slice chains
+    }
     if (node_type == PBN_NODE_CKDE && !slices.empty()) {
         std::vector<double> hs(std::max<size_t>(1, slot_key.size()));
         if (lanes > 1) ctx->sync_lanes(lanes - 1);
         if (!slot_key.empty()) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, slot_key.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->drop_staged();
         for (size_t i = 0; i < slot_key.size(); ++i) sd->kde_cache[slot_key[i]] = hs[i];
         for (const Slice& sl : slices) {
             const double jv = sl.joint.slot >= 0 ? hs[sl.joint.slot] : sl.joint.value;
@@ -566,6 +646,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     } else if (node_type == PBN_NODE_CKDE) {
         if (lanes > 1) ctx->sync_lanes(lanes - 1);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->drop_staged();
     }
     return acc;
 }

@@ -44,6 +44,8 @@ struct GDev {   // argument block of the block-wise kernels
     int xstride, Rs;
     int nunits;
     int use_sum_bound;
+    int bf16;                 // fp32 table: bf16x3 fragments (kde_kernels.hip pack_rows_bf16_kernel), KS = number of bf16 MFMAs
+    int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
 };
 
 __device__ __forceinline__ int region_of(const GPool& P, int pp) {
@@ -126,14 +128,68 @@ __global__ __launch_bounds__(64) void group_scan_kernel(GDev g) {
     }
 }
 
+typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void gsplit3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {   // kde_kernels.hip split3
+    p1 = (__bf16)x;
+    const float r1 = x - (float)p1;
+    p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    p3 = (__bf16)r2;
+}
+
+// bf16x3 fragments of one row (pack_rows_bf16_kernel): slot s = 6 k + role for dimension k, then the three pieces of the training
+// norm against ones; slot s lives in MFMA s / 32, lane group (s % 32) / 8, element s % 8
+__device__ __forceinline__ void store_bf16_row(gbf8* pack, int NB, int tile, int idx, int dm, const __bf16* p1, const __bf16* p2, const __bf16* p3,
+                                               float nv, bool query) {
+    __bf16 n1, n2, n3;
+    gsplit3(nv, n1, n2, n3);
+    const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+    auto slot = [&](int sl) -> __bf16 {
+        if (sl < 6 * dm) {
+            const int k = sl / 6, role = sl % 6;
+            if (!query) return role == 2 || role == 5 ? p2[k] : (role == 4 ? p3[k] : p1[k]);   // a1 a1 a2 a1 a3 a2
+            return role == 1 || role == 5 ? p2[k] : (role == 3 ? p3[k] : p1[k]);                // b1 b2 b1 b3 b1 b2
+        }
+        const int t = sl - 6 * dm;
+        if (t < 3) return query ? one : (t == 0 ? n1 : (t == 1 ? n2 : n3));
+        return zero;
+    };
+    for (int mb = 0; mb < NB; ++mb)
+        for (int gq = 0; gq < 4; ++gq) {
+            gbf8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = slot(mb * 32 + gq * 8 + j);
+            pack[((int64_t)tile * NB + mb) * 64 + gq * 16 + idx] = v;
+        }
+}
+
 // whitened coordinates of one row, fragment stores shared by the two pack kernels (fp64 classic fragments, kde_kernels.hip
-// pack_rows_kernel): training side norms in C-row order + weights 2^norm, query side norms by row
-__device__ __forceinline__ void pack_store(const GUnit& U, char* arena, const double* x, int d, int KS, int dest, bool query, int32_t tpos) {
+// pack_rows_kernel: training side norms in C-row order + weights 2^norm, query side norms by row; fp32: bf16x3 fragments)
+__device__ __forceinline__ void pack_store(const GDev& g, const GUnit& U, const double* x, int d, int dest, bool query, int32_t tpos) {
+    char* arena = g.arena;
+    const int KS = g.KS;
     const int tile = dest >> 4, idx = dest & 15;
     double xc[PBN_GROUP_MAX_D];
     for (int j = 0; j < d; ++j) xc[j] = x[j] - U.mu[j];
-    double* pack = (double*)(arena + (query ? U.bpack : U.apack));
     double* zrow = (double*)(arena + (query ? U.zq : U.zs)) + (int64_t)dest * d;
+    if (query) ((int32_t*)(arena + U.qpos))[dest] = tpos;
+    if (g.bf16) {
+        __bf16 p1[PBN_GROUP_MAX_D], p2[PBN_GROUP_MAX_D], p3[PBN_GROUP_MAX_D];
+        double nrm = 0.0;
+        for (int c = 0; c < d; ++c) {
+            double z = 0.0;
+            for (int j = 0; j <= c; ++j) z = __builtin_fma(U.W[c * d + j], xc[j], z);
+            const float zf = (float)z;
+            zrow[c] = (double)zf;            // the rounding the fragments carry
+            nrm = __builtin_fma((double)zf, (double)zf, nrm);
+            gsplit3(zf, p1[c], p2[c], p3[c]);
+        }
+        const float nv = (float)(-0.5 * nrm);
+        store_bf16_row((gbf8*)(arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, p1, p2, p3, nv, query);
+        if (query) ((float*)(arena + U.ny))[(int64_t)tile * 16 + idx] = nv;
+        return;
+    }
+    double* pack = (double*)(arena + (query ? U.bpack : U.apack));
     double nrm = 0.0;
     for (int c = 0; c < KS * 4; ++c) {
         double z = 0.0;
@@ -148,7 +204,6 @@ __device__ __forceinline__ void pack_store(const GUnit& U, char* arena, const do
     if (d < KS * 4) pack[((int64_t)tile * KS + (d >> 2)) * 64 + (d & 3) * 16 + idx] = query ? 1.0 : nv;   // norm in the free K slot (FOLD)
     if (query) {
         ((double*)(arena + U.ny))[(int64_t)tile * 16 + idx] = nv;
-        ((int32_t*)(arena + U.qpos))[dest] = tpos;
     } else {
         double* np = (double*)(arena + U.npack);
         const int lg = idx & 3, i = idx >> 2;
@@ -180,7 +235,7 @@ __global__ __launch_bounds__(GB) void group_pack_train_kernel(GDev g) {
     for (int w = 0; w < wave; ++w) base += wcount[w];
     if (!in) return;
     const int dest = base + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-    pack_store(U, g.arena, g.xs + (P.elem0 + i) * g.xstride, P.d, (P.d + 3) / 4, dest, false, 0);
+    pack_store(g, U, g.xs + (P.elem0 + i) * g.xstride, P.d, dest, false, 0);
 }
 
 // ---- query side + all padding: grid (flat blocks).  Every element is a test row of at most one unit of its pool (the unit whose
@@ -191,7 +246,7 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
     const int fb = blockIdx.x;
     const GPool& P = g.pools[g.blkpool[fb]];
     const int blk = fb - P.blk0;
-    const int d = P.d, KS = (d + 3) / 4;
+    const int d = P.d, KS = g.KS;
     if (blk >= P.nblk) {
         // the pool's padding block: rows N .. 16 ntiles of every unit's training pack (norm -1e30: their terms vanish; weight
         // 0), rows nq .. 16 nqtiles of its query pack (coordinates 0, norm 0: finite sums nobody reads)
@@ -202,6 +257,14 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
             const int row = (query ? U.nq : U.N) + (j & 15);
             if (row >= (query ? U.nqtiles : U.ntiles) * 16) continue;
             const int tile = row >> 4, idx = row & 15;
+            if (g.bf16) {
+                __bf16 z1[PBN_GROUP_MAX_D], z2[PBN_GROUP_MAX_D], z3[PBN_GROUP_MAX_D];
+                for (int c = 0; c < d; ++c) z1[c] = z2[c] = z3[c] = (__bf16)0.0f;
+                const float nv = query ? 0.0f : -1e30f;
+                store_bf16_row((gbf8*)(g.arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, z1, z2, z3, nv, query);
+                if (query) ((float*)(g.arena + U.ny))[(int64_t)tile * 16 + idx] = 0.0f;
+                continue;
+            }
             double* pack = (double*)(g.arena + (query ? U.bpack : U.apack));
             for (int c = 0; c < KS * 4; ++c) pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = 0.0;
             if (d < KS * 4) pack[((int64_t)tile * KS + (d >> 2)) * 64 + (d & 3) * 16 + idx] = query ? 1.0 : -1e30;
@@ -239,7 +302,7 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
     int tpos = 0;
     for (int rr = 0; rr < P.R; ++rr)
         if ((U.train_mask >> rr) & 1ull) tpos += before(rr);
-    pack_store(U, g.arena, g.xs + (P.elem0 + i) * g.xstride, d, KS, dest, true, tpos);
+    pack_store(g, U, g.xs + (P.elem0 + i) * g.xstride, d, dest, true, tpos);
 }
 
 // ---- bounding boxes of the 16-row training tiles: grid (blocks of 256 padded rows, units) ---------------------------------------
@@ -404,8 +467,10 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         pools[k] = P;
     }
     const int nu = (int)units.size();
-    const int d0 = pools[0].d, KS = (d0 + 3) / 4;
+    const bool bf16 = use_bf16x3(t->dtype);
+    const int d0 = pools[0].d, KS = bf16 ? bf16x3_mfmas(d0) : (d0 + 3) / 4;
     const bool fold = d0 % 4 != 0;
+    const size_t frag_b = bf16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
     static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
     int64_t total_wg = 0;
     int max_ntiles = 0, max_nqtiles = 0, max_nq = 0;
@@ -429,12 +494,12 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         max_ntiles = std::max(max_ntiles, U.ntiles);
         max_nqtiles = std::max(max_nqtiles, U.nqtiles);
         max_nq = std::max(max_nq, U.nq);
-        U.apack = carve((size_t)U.ntiles * KS * 64 * 8);
-        U.npack = carve((size_t)U.ntiles * 16 * 8 * 2);
+        U.apack = carve((size_t)U.ntiles * frag_b);
+        U.npack = carve(bf16 ? 256 : (size_t)U.ntiles * 16 * 8 * 2);
         U.zs = carve((size_t)U.N * d * 8 + 8);
         U.box = carve((size_t)U.ntiles * 2 * pd * 8);
-        U.bpack = carve((size_t)U.nqtiles * KS * 64 * 8);
-        U.ny = carve((size_t)U.nqtiles * 16 * 8);
+        U.bpack = carve((size_t)U.nqtiles * frag_b);
+        U.ny = carve((size_t)U.nqtiles * 16 * (bf16 ? 4 : 8));
         U.zq = carve((size_t)U.nq * d * 8 + 8);
         U.qpos = carve((size_t)U.nqtiles * 16 * 4);
         U.qbox = carve((size_t)U.nqtiles * 2 * pd * 8);
@@ -492,6 +557,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.arena = arena; g.xstride = xstride; g.Rs = Rs; g.nunits = nu;
     static const int sum_bound = env_int("PBN_GROUP_SUM_BOUND", 1);
     g.use_sum_bound = sum_bound;
+    g.bf16 = bf16 ? 1 : 0; g.KS = KS;
 
     const bool f64 = t->dtype == PBN_F64;
     {
@@ -518,10 +584,10 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         GSweepArgs sa{};
         sa.units = (const GSweepUnit*)(arena + o_sweep); sa.wg_unit = (const int32_t*)(arena + o_wgunit); sa.total_wg = total_wg;
         sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-        sa.prune_margin = prune_margin(PBN_F64);
+        sa.prune_margin = prune_margin(t->dtype);
         static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
         sa.group_masks = gmasks;
-        launch_sweep_grouped(sa, PBN_F64, KS, st);
+        launch_sweep_grouped(sa, t->dtype, KS, st);
     }
     {
         KernelTimer kt(ctx, PBN_K_FINISH);
@@ -538,7 +604,7 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
     for (int u = 0; u < P.nunits; ++u) {
         const GUnit& U = b.units[P.unit0 + u];
         const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
-        s += nt * KS * 512 + nt * 256 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 512 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
+        s += nt * KS * 1024 + nt * 256 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
              nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + (nsplit + 1) * nqt * 256 + (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) +
              (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
     }
@@ -550,13 +616,13 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
 bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
     const int on = env_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
     // fp64 classic fragments; sets whose boxes cover every dimension (no subsample bound needed); the pruned-sweep shapes
-    return on && dtype == PBN_F64 && d >= 1 && d <= std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), 4) && R >= 1 && R <= PBN_GROUP_MAX_R &&
-           kde_prune_applies(dtype, d, n_min);
+    return on && (dtype == PBN_F64 || use_bf16x3(dtype)) && d >= 1 && d <= std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), 4) && R >= 1 &&
+           R <= PBN_GROUP_MAX_R && kde_prune_applies(dtype, d, n_min);
 }
 
 void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums) {
     if (b.pools.empty()) return;
-    if (t->dtype != PBN_F64) throw invalid_error("grouped KDE evaluation: fp64 tables only");
+    if (t->dtype != PBN_F64 && !use_bf16x3(t->dtype)) throw invalid_error("grouped KDE evaluation: fp64 tables, or fp32 tables on the bf16 matrix cores");
     HIP_CHECK(hipSetDevice(ctx->device));
     for (const GPool& P : b.pools) {
         if (P.d < 1 || P.d > PBN_GROUP_MAX_D || P.kd < 1 || P.kd > PBN_PRUNE_PD || P.kd > P.d || P.R < 1 || P.R > PBN_GROUP_MAX_R || P.n < 1)
@@ -569,7 +635,8 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     // pools of one sweep shape together (KS, norm in a K slot or as weights), larger sets first
     std::vector<int> order(b.pools.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    auto variant = [&](int i) { const int d = b.pools[i].d; return ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
+    const bool bf16 = use_bf16x3(t->dtype);
+    auto variant = [&](int i) { const int d = b.pools[i].d; return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
     const size_t budget = (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 4096)) << 20;
     const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));

@@ -1182,14 +1182,14 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
 template <int NB, bool COND, int QG, bool PRUNE>
-__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_WAVES : (NB <= 2 ? PBN_BF16_WAVES : 2)) void kde_sweep_bf16_kernel(SweepArgs a) {
+__device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const unsigned bid) {
     using V = f4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int lg = lane >> 4;
     int qx, split;
-    if (PRUNE) pruned_block(a, WPB * QG, blockIdx.x, qx, split); else xcd_block(qx, split);
+    if (PRUNE) pruned_block(a, WPB * QG, bid, qx, split); else xcd_block(qx, split);
     const int64_t qt0 = ((int64_t)qx * WPB + wave) * QG;
     if (qt0 >= a.nqtiles) return;
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
@@ -1414,6 +1414,8 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_
     if constexpr (PRUNE) {
         if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
         for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
+            // (one mask per WAVE here: per-group masks as in the fp64 kernel - prune_group_mask - were measured and dropped for the
+            //  fp32 kernels, which live on occupancy and straight-line issue: 1e6 x 1e5 handles +15...20 %, C5 15.8 -> 16.4 s)
             unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
             if (!mask) continue;
             if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
@@ -1470,6 +1472,29 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_
             if (COND) { o[2] = (double)mj[g]; o[3] = sj; }
         }
     }
+}
+
+template <int NB, bool COND, int QG, bool PRUNE>
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_WAVES : (NB <= 2 ? PBN_BF16_WAVES : 2)) void kde_sweep_bf16_kernel(SweepArgs a) {
+    kde_sweep_bf16_body<NB, COND, QG, PRUNE>(a, blockIdx.x);
+}
+
+// grouped launch of the pruned plain fp32 sweeps (see kde_sweep_group_kernel)
+template <int NB>
+__global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) void kde_sweep_bf16_group_kernel(GSweepArgs g) {
+    const int u = g.wg_unit[blockIdx.x >> 6];
+    const GSweepUnit& su = g.units[u];
+    const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
+    if (bid >= (unsigned)su.nwg) return;
+    SweepArgs a;
+    a.Apack = su.Apack; a.nxpack = su.nxpack; a.Axpack = nullptr;
+    a.Bpack = su.Bpack; a.nypack = su.nypack; a.Bxpack = nullptr; a.Bxnorm = nullptr;
+    a.ntiles = su.ntiles; a.nqtiles = su.nqtiles; a.tiles_per_split = su.tps;
+    a.fold = 0; a.count_redo = g.count_redo; a.wmul = 0;
+    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
+    a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = 0;
+    kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true>(a, bid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1996,10 +2021,17 @@ void launch_sweep(const SweepArgs& a_in, int dtype, int KS, bool cond, int nspli
 // fold: d mod 4 != 0 (norm in a free K slot); wmul: d mod 4 == 0 (norms as weights) - the two pruned plain fp64 shapes
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st) {
     if (g.total_wg == 0) return;
-    if (dtype != PBN_F64 || KS < 1 || KS > 2 || (g.fold != 0) == (g.wmul != 0)) throw invalid_error("grouped sweeps: fp64, at most 8 whitened dimensions");
     if (g.total_wg > 0x7fffffffll) throw invalid_error("grouped sweeps: grid too large");
-    constexpr int QGP = PBN_QG_PRUNE;
     const dim3 grid((unsigned)g.total_wg), block(sweep_block_threads(true));
+    if (use_bf16x3(dtype)) {   // KS carries the number of bf16 MFMAs
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1>), grid, block, 0, st, g);
+        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2>), grid, block, 0, st, g);
+        else throw invalid_error("grouped fp32 sweeps: at most 10 whitened dimensions");
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (dtype != PBN_F64 || KS < 1 || KS > 2 || (g.fold != 0) == (g.wmul != 0)) throw invalid_error("grouped sweeps: fp64 / fp32 on the bf16 cores, at most 8 whitened dimensions");
+    constexpr int QGP = PBN_QG_PRUNE;
     if (g.fold) {
         if (KS == 1) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, true, false>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((kde_sweep_group_kernel<double, 2, QGP, true, false>), grid, block, 0, st, g);

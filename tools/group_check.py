@@ -52,4 +52,35 @@ for n, min_rows in ((3000, 64), (60000, None), (300000, None)):
             print(f"   vs oracle: {relo:.3e}")
             worst = max(worst, relo)
 assert worst < 1e-9, worst
+
+# hybrid candidates (discrete parents: one pool per configuration and term), fp64 and fp32 (bf16x3 fragments), CV and validation scores
+def hybrid(n, dtype, seed=9):
+    rng = np.random.default_rng(seed)
+    A = rng.integers(0, 3, size=n)
+    B = rng.integers(0, 2, size=n)
+    x = rng.normal(size=n) + 1.5 * A
+    y = 0.6 * x + np.where(B == 1, 1.0, -1.0) + rng.normal(scale=0.7, size=n)
+    z = np.tanh(y) + 0.4 * x + rng.normal(scale=0.5, size=n)
+    df = pd.DataFrame({"x": x.astype(dtype), "y": y.astype(dtype), "z": z.astype(dtype)})
+    df["A"] = pd.Categorical.from_codes(A, ["a0", "a1", "a2"])
+    df["B"] = pd.Categorical.from_codes(B, ["b0", "b1"])
+    return df
+
+
+HC = (("y", ["x", "B"]), ("z", ["x", "y", "A"]), ("x", ["A"]), ("z", ["A", "B"]), ("y", ["x", "z", "A", "B"]))
+for dtype, tol in (("float64", 1e-9), ("float32", 2e-5)):
+    df = hybrid(400000, dtype)
+    bn = pbn.SemiparametricBN(list(df.columns), [], [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType())])
+    res = {}
+    for grouped in (True, False):
+        os.environ["PBN_SCORE_GROUPED"] = "1" if grouped else "0"
+        os.environ.pop("PBN_PRUNE_MIN_ROWS", None)
+        score = pbn.ValidatedLikelihood(df, 0.2, 5, 1)
+        t0 = time.perf_counter()
+        res[grouped] = ([score.local_score_node_type(bn, pbn.CKDEType(), v, p) for v, p in HC] +
+                        [score.vlocal_score_node_type(bn, pbn.CKDEType(), v, p) for v, p in HC], time.perf_counter() - t0)
+    a, b = np.array(res[True][0]), np.array(res[False][0])
+    rel = np.max(np.abs(a - b) / np.abs(b))
+    print(f"hybrid {dtype}: grouped vs per-slice max rel diff {rel:.3e}  ({res[True][1]:.3f}s vs {res[False][1]:.3f}s)", flush=True)
+    assert rel < tol, (dtype, rel)
 print("group_check ok")
