@@ -13,7 +13,7 @@ cd $R
 t=$(find gpurun_out/$OUT -name "*kernel_trace.csv" | head -1)
 python3 - $t <<'PY'
 import csv, sys, collections, re
-rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", ""), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
         for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
 # the hill-climb part: from the first to the last launch of the pruning tables' kernel (neither the headline step nor MMPC use it)
