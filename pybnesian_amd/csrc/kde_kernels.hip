@@ -31,6 +31,12 @@
 
 namespace pbn {
 
+// Device pointers of the sweeps are typed as GLOBAL-address-space pointers.  A pointer that reaches a kernel through a record in
+// memory (the grouped launches' per-unit table) is otherwise a generic pointer: its loads become flat_load, whose completion order
+// against LDS traffic is unknown, so every wait is a full `s_waitcnt vmcnt(0) lgkmcnt(0)` - the prefetch of the next tile is waited
+// for before the current one is used.  (The kernel-argument pointers of the stand-alone launches are inferred global anyway.)
+#define PBN_GLOBAL __attribute__((address_space(1)))
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -459,12 +465,13 @@ __device__ __forceinline__ void xcd_block(int& qx, int& split) {
 // tiles.  The sweeps then walk the set bits only: a skipped tile costs 1/64 of a test and no fragment load (the first
 // version tested tile by tile on wave-uniform values - 15 DP instructions and three loads per tile, skipped or not:
 // a fifth of a kept tile's cost in the fp32 sweep and ALL of a skipped tile's).
-__device__ __forceinline__ unsigned long long prune_visit_mask(const double* __restrict__ tile_box, int pd, int64_t tb, int64_t t1,
+template <typename BP>
+__device__ __forceinline__ unsigned long long prune_visit_mask(BP tile_box, int pd, int64_t tb, int64_t t1,
                                                                const double (&wlo)[PBN_PRUNE_PD], const double (&whi)[PBN_PRUNE_PD], double wthr, int lane) {
     const int64_t t = tb + lane;
     bool keep = false;
     if (t < t1) {
-        const double* bx = tile_box + t * 2 * pd;
+        const BP bx = tile_box + t * 2 * pd;
         double d2 = 0.0;
 #pragma unroll
         for (int k = 0; k < PBN_PRUNE_PD; ++k)
@@ -483,12 +490,12 @@ __device__ __forceinline__ unsigned long long prune_visit_mask(const double* __r
 // order, and the box of all of them is up to twice as wide per axis as a group's own - at 3-4 dimensions, where a wave's box is
 // as wide as the kernel's support, a third of the (tile, group) pairs of a visited tile lie beyond the group's own support.  The
 // boxes are re-read per group (uniform addresses: scalar loads; the tile's box from L1) so that no box stays in registers.
-__device__ __forceinline__ unsigned long long prune_group_mask(const double* __restrict__ tile_box, const double* __restrict__ qbox, int pd, int64_t tb,
-                                                                int64_t t1, double thr, int lane) {
+template <typename BP>
+__device__ __forceinline__ unsigned long long prune_group_mask(BP tile_box, BP qbox, int pd, int64_t tb, int64_t t1, double thr, int lane) {
     const int64_t t = tb + lane;
     bool keep = false;
     if (t < t1) {
-        const double* bx = tile_box + t * 2 * pd;
+        const BP bx = tile_box + t * 2 * pd;
         double d2 = 0.0;
 #pragma unroll
         for (int k = 0; k < PBN_PRUNE_PD; ++k)
@@ -544,13 +551,17 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
 
-    const T* __restrict__ Ap = (const T*)a.Apack;
-    const T* __restrict__ Np = (const T*)a.nxpack;
-    const T* __restrict__ Wp = Np + a.ntiles * 16;   // WMUL: weights 2^norm behind the norms (PackArgs::write_w)
-    const T* __restrict__ Xp = (const T*)a.Axpack;
-    const T* __restrict__ Bp = (const T*)a.Bpack;
-    const T* __restrict__ NYp = (const T*)a.nypack;
-    const T* __restrict__ BXp = (const T*)a.Bxpack;
+    const PBN_GLOBAL T* __restrict__ Ap = (const PBN_GLOBAL T*)a.Apack;
+    const PBN_GLOBAL T* __restrict__ Np = (const PBN_GLOBAL T*)a.nxpack;
+    const PBN_GLOBAL T* __restrict__ Wp = Np + a.ntiles * 16;   // WMUL: weights 2^norm behind the norms (PackArgs::write_w)
+    const PBN_GLOBAL T* __restrict__ Xp = (const PBN_GLOBAL T*)a.Axpack;
+    const PBN_GLOBAL T* __restrict__ Bp = (const PBN_GLOBAL T*)a.Bpack;
+    const PBN_GLOBAL T* __restrict__ NYp = (const PBN_GLOBAL T*)a.nypack;
+    const PBN_GLOBAL T* __restrict__ BXp = (const PBN_GLOBAL T*)a.Bxpack;
+    const PBN_GLOBAL double* __restrict__ TBp = (const PBN_GLOBAL double*)a.tile_box;
+    const PBN_GLOBAL double* __restrict__ QBp = (const PBN_GLOBAL double*)a.qtile_box;
+    const PBN_GLOBAL double* __restrict__ QTp = (const PBN_GLOBAL double*)a.qtile_thr;
+    const PBN_GLOBAL double* __restrict__ QLp = (const PBN_GLOBAL double*)a.qlb;
 
     // ---- query-side fragments and per-query state -------------------------------------------
     T b[QG][KS];
@@ -581,12 +592,12 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-            const double th = a.qtile_thr[qt];
+            const double th = QTp[qt];
             wthr = th < wthr ? th : wthr;
 #pragma unroll
             for (int k = 0; k < PBN_PRUNE_PD; ++k)
                 if (k < pd) {
-                    const double l = a.qtile_box[qt * 2 * pd + k], h = a.qtile_box[qt * 2 * pd + pd + k];
+                    const double l = QBp[qt * 2 * pd + k], h = QBp[qt * 2 * pd + pd + k];
                     wlo[k] = l < wlo[k] ? l : wlo[k];
                     whi[k] = h > whi[k] ? h : whi[k];
                 }
@@ -600,7 +611,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         T ax = 0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t0 * KS + ks) * 64 + lane];
-        if (!FOLD) nx = *(const V*)(Np + t0 * 16 + lg * 4);
+        if (!FOLD) nx = *(const PBN_GLOBAL V*)(Np + t0 * 16 + lg * 4);
         if (COND) ax = Xp[t0 * 64 + lane];
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
@@ -640,7 +651,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-                const T lb = __builtin_ceil((T)a.qlb[qt * 16 + (lane & 15)]);
+                const T lb = __builtin_ceil((T)QLp[qt * 16 + (lane & 15)]);
                 // (a bound too large for T to hold to a fraction of a unit is not used: see kde_sweep_bf16_kernel)
                 const bool fin = (lb < (T)0 ? -lb : lb) < (sizeof(T) == 8 ? (T)0x1p50 : (T)0x1p22);
                 lbm[g] = fin && lb > m[g];
@@ -663,7 +674,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     auto load_tile = [&](int64_t t, T (&f)[KS], V& n, T& x) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) f[ks] = Ap[(t * KS + ks) * 64 + lane];
-        if (!FOLD) n = *(const V*)((WMUL ? Wp : Np) + t * 16 + lg * 4);
+        if (!FOLD) n = *(const PBN_GLOBAL V*)((WMUL ? Wp : Np) + t * 16 + lg * 4);
         if (COND) x = Xp[t * 64 + lane];
     };
     // pruned plain fp64 sweeps: visit masks per query group (GMASK), bit `bit` of gm[g] = group g needs this tile
@@ -695,7 +706,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             }
             if (__builtin_expect(__any(bad), 0)) {
                 // Rare wave-uniform slow path: raise the offsets to the tile maximum and redo the tile.
-                if (WMUL) acc += *(const V*)(Np + t * 16 + lg * 4);   // the classic exponents: norms added
+                if (WMUL) acc += *(const PBN_GLOBAL V*)(Np + t * 16 + lg * 4);   // the classic exponents: norms added
                 T mx = __builtin_ceil(colmax<T>(max4<T>(acc)) - Tr<T>::bias());
                 if (mx > (T)0) {
                     m[g] += mx;
@@ -747,18 +758,25 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // 64 tiles per visit mask; inside a batch the kept tiles are processed two at a time with ping-pong fragment buffers
         auto run_batch = [&](int64_t tb, unsigned long long mask, auto blind) {
             constexpr bool BLIND = decltype(blind)::value;
+            // The prefetch of the next kept tile is UNCONDITIONAL (after the last one the current tile is simply loaded again):
+            // with `if (mask) load` the two paths into the next MFMA differ in their number of loads in flight, and the compiler
+            // must wait for ALL of them (s_waitcnt vmcnt(0)) - i.e. for the prefetch it has just issued - before every tile.
             int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             load_tile(tb + b, afA, nxA, axA);
             for (;;) {
-                int b2 = -1;
-                if (mask) { b2 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b2, afB, nxB, axB); }
+                const bool more = mask != 0;
+                const int b2 = more ? __builtin_ctzll(mask) : b;
+                mask &= mask - 1;
+                load_tile(tb + b2, afB, nxB, axB);
                 if constexpr (BLIND) process_fast(afA, nxA, b); else process_tile(tb + b, afA, nxA, axA, b);
-                if (b2 < 0) break;
-                int b3 = -1;
-                if (mask) { b3 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b3, afA, nxA, axA); }
+                if (!more) break;
+                const bool more2 = mask != 0;
+                const int b3 = more2 ? __builtin_ctzll(mask) : b2;
+                mask &= mask - 1;
+                load_tile(tb + b3, afA, nxA, axA);
                 if constexpr (BLIND) process_fast(afB, nxB, b2); else process_tile(tb + b2, afB, nxB, axB, b2);
-                if (b3 < 0) break;
+                if (!more2) break;
                 b = b3;
             }
         };
@@ -774,16 +792,16 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                     for (int g = 0; g < QG; ++g) {
                         const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-                        gm[g] = prune_group_mask(a.tile_box, a.qtile_box + qt * 2 * pd, pd, tb, t1, a.qtile_thr[qt] - a.prune_margin, lane);
+                        gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
                         mask |= gm[g];
                     }
                 } else {
-                    mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+                    mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
 #pragma unroll
                     for (int g = 0; g < QG; ++g) gm[g] = mask;
                 }
             } else {
-                mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+                mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
             }
             if (!mask) continue;
             if (a.count_redo && lane == 0) {
@@ -865,7 +883,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     }
 
     // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
-    double* part = a.part;
+    PBN_GLOBAL double* part = (PBN_GLOBAL double*)a.part;
     constexpr int P = COND ? 4 : 2;
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -884,7 +902,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         if (s == 0.0 && mfin && !lbm[g]) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (COND && sj == 0.0 && (mj[g] - mj[g]) == (T)0 && !lbmj[g]) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (lg == 0 && qt0 + g < a.nqtiles) {
-            double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
+            PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g] - (double)Tr<T>::bias();   // the sums carry 2^bias
             o[1] = s;
             if (COND) { o[2] = (double)mj[g] - (double)Tr<T>::bias(); o[3] = sj; }
@@ -1195,12 +1213,16 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
 
-    const bf8* __restrict__ Ap = (const bf8*)a.Apack;
-    const bf8* __restrict__ Xp = (const bf8*)a.Axpack;
-    const bf8* __restrict__ Bp = (const bf8*)a.Bpack;
-    const float* __restrict__ NYp = (const float*)a.nypack;
-    const bf8* __restrict__ BXp = (const bf8*)a.Bxpack;
-    const float* __restrict__ XNp = (const float*)a.Bxnorm;
+    const PBN_GLOBAL bf8* __restrict__ Ap = (const PBN_GLOBAL bf8*)a.Apack;
+    const PBN_GLOBAL bf8* __restrict__ Xp = (const PBN_GLOBAL bf8*)a.Axpack;
+    const PBN_GLOBAL bf8* __restrict__ Bp = (const PBN_GLOBAL bf8*)a.Bpack;
+    const PBN_GLOBAL float* __restrict__ NYp = (const PBN_GLOBAL float*)a.nypack;
+    const PBN_GLOBAL bf8* __restrict__ BXp = (const PBN_GLOBAL bf8*)a.Bxpack;
+    const PBN_GLOBAL float* __restrict__ XNp = (const PBN_GLOBAL float*)a.Bxnorm;
+    const PBN_GLOBAL double* __restrict__ TBp = (const PBN_GLOBAL double*)a.tile_box;
+    const PBN_GLOBAL double* __restrict__ QBp = (const PBN_GLOBAL double*)a.qtile_box;
+    const PBN_GLOBAL double* __restrict__ QTp = (const PBN_GLOBAL double*)a.qtile_thr;
+    const PBN_GLOBAL double* __restrict__ QLp = (const PBN_GLOBAL double*)a.qlb;
 
     bf8 b[QG][NB];
     float ny[QG], m[QG];
@@ -1228,12 +1250,12 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-            const double th = a.qtile_thr[qt];
+            const double th = QTp[qt];
             wthr = th < wthr ? th : wthr;
 #pragma unroll
             for (int k = 0; k < PBN_PRUNE_PD; ++k)
                 if (k < pd) {
-                    const double l = a.qtile_box[qt * 2 * pd + k], h = a.qtile_box[qt * 2 * pd + pd + k];
+                    const double l = QBp[qt * 2 * pd + k], h = QBp[qt * 2 * pd + pd + k];
                     wlo[k] = l < wlo[k] ? l : wlo[k];
                     whi[k] = h > whi[k] ? h : whi[k];
                 }
@@ -1287,7 +1309,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-                const float lb = (float)a.qlb[qt * 16 + (lane & 15)];
+                const float lb = (float)QLp[qt * 16 + (lane & 15)];
                 // a bound so large that fp32 cannot hold it to a fraction of a unit (a query ~2000 bandwidths out) is not used:
                 // the first tile's offset comes with a term that is known to survive the rounding, the bound does not
                 const bool fin = __builtin_fabsf(lb) < 0x1p22f;
@@ -1416,21 +1438,26 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
             // (one mask per WAVE here: per-group masks as in the fp64 kernel - prune_group_mask - were measured and dropped for the
             //  fp32 kernels, which live on occupancy and straight-line issue: 1e6 x 1e5 handles +15...20 %, C5 15.8 -> 16.4 s)
-            unsigned long long mask = prune_visit_mask(a.tile_box, pd, tb, t1, wlo, whi, wthr, lane);
+            unsigned long long mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
             if (!mask) continue;
             if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
+            // unconditional prefetch of the next kept tile (see kde_sweep_body: a conditional one costs a vmcnt(0) per tile)
             int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             load_tile(tb + b, fA, xA);
             for (;;) {
-                int b2 = -1;
-                if (mask) { b2 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b2, fB, xB); }
+                const bool more = mask != 0;
+                const int b2 = more ? __builtin_ctzll(mask) : b;
+                mask &= mask - 1;
+                load_tile(tb + b2, fB, xB);
                 process_tile(fA, xA);
-                if (b2 < 0) break;
-                int b3 = -1;
-                if (mask) { b3 = __builtin_ctzll(mask); mask &= mask - 1; load_tile(tb + b3, fA, xA); }
+                if (!more) break;
+                const bool more2 = mask != 0;
+                const int b3 = more2 ? __builtin_ctzll(mask) : b2;
+                mask &= mask - 1;
+                load_tile(tb + b3, fA, xA);
                 process_tile(fB, xB);
-                if (b3 < 0) break;
+                if (!more2) break;
                 b = b3;
             }
         }
@@ -1445,7 +1472,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         }
     }
 
-    double* part = a.part;
+    PBN_GLOBAL double* part = (PBN_GLOBAL double*)a.part;
     constexpr int P = COND ? 4 : 2;
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -1466,7 +1493,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         if (s == 0.0 && (m[g] - m[g]) == 0.f && !lbm[g]) s = 1.0;
         if (COND && sj == 0.0 && (mj[g] - mj[g]) == 0.f && !lbmj[g]) sj = 1.0;
         if (lg == 0 && qt0 + g < a.nqtiles) {
-            double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
+            PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
             o[0] = (double)m[g];
             o[1] = s;
             if (COND) { o[2] = (double)mj[g]; o[3] = sj; }

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch first: it ships its own HIP runtime, and a process in which libpbn_hip.so (linked against /opt/rocm) has touched the
+    # GPU before torch was imported ends up with torch.cuda.is_available() == False (measured on the GPU box, tools/torch_after.py).
+    # bench.py imports torch first for the same reason; the library itself never needs torch.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is only plumbing for a few tests
+        pass
 
 
 @pytest.fixture(scope="session")
