@@ -46,6 +46,7 @@ struct GDev {   // argument block of the block-wise kernels
     int use_sum_bound;
     int bf16;                 // fp32 table: bf16x3 fragments (kde_kernels.hip pack_rows_bf16_kernel), KS = number of bf16 MFMAs
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
+    int ring_nb;              // > 0: fp64 table with a RING pass - also write bf16x3 fragments (ring_nb MFMAs) of every row
 };
 
 __device__ __forceinline__ int region_of(const GPool& P, int pp) {
@@ -191,14 +192,26 @@ __device__ __forceinline__ void pack_store(const GDev& g, const GUnit& U, const 
     }
     double* pack = (double*)(arena + (query ? U.bpack : U.apack));
     double nrm = 0.0;
+    __bf16 p1[PBN_GROUP_MAX_D], p2[PBN_GROUP_MAX_D], p3[PBN_GROUP_MAX_D];
+    double nrm16 = 0.0;
     for (int c = 0; c < KS * 4; ++c) {
         double z = 0.0;
         if (c < d) {
             for (int j = 0; j <= c; ++j) z = __builtin_fma(U.W[c * d + j], xc[j], z);
             zrow[c] = z;
+            if (g.ring_nb) {   // the same coordinate for the far-field pass: rounded to float, three bf16 pieces
+                const float zf = (float)z;
+                nrm16 = __builtin_fma((double)zf, (double)zf, nrm16);
+                gsplit3(zf, p1[c], p2[c], p3[c]);
+            }
         }
         nrm = __builtin_fma(z, z, nrm);
         pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = z;
+    }
+    if (g.ring_nb) {
+        const float nv16 = (float)(-0.5 * nrm16);
+        store_bf16_row((gbf8*)(arena + (query ? U.bpack16 : U.apack16)), g.ring_nb, tile, idx, d, p1, p2, p3, nv16, query);
+        if (query) ((float*)(arena + U.ny16))[(int64_t)tile * 16 + idx] = nv16;
     }
     const double nv = -0.5 * nrm;
     if (d < KS * 4) pack[((int64_t)tile * KS + (d >> 2)) * 64 + (d & 3) * 16 + idx] = query ? 1.0 : nv;   // norm in the free K slot (FOLD)
@@ -264,6 +277,12 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
                 store_bf16_row((gbf8*)(g.arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, z1, z2, z3, nv, query);
                 if (query) ((float*)(g.arena + U.ny))[(int64_t)tile * 16 + idx] = 0.0f;
                 continue;
+            }
+            if (g.ring_nb) {
+                __bf16 z1[PBN_GROUP_MAX_D], z2[PBN_GROUP_MAX_D], z3[PBN_GROUP_MAX_D];
+                for (int c = 0; c < d; ++c) z1[c] = z2[c] = z3[c] = (__bf16)0.0f;
+                store_bf16_row((gbf8*)(g.arena + (query ? U.bpack16 : U.apack16)), g.ring_nb, tile, idx, d, z1, z2, z3, query ? 0.0f : -1e30f, query);
+                if (query) ((float*)(g.arena + U.ny16))[(int64_t)tile * 16 + idx] = 0.0f;
             }
             double* pack = (double*)(g.arena + (query ? U.bpack : U.apack));
             for (int c = 0; c < KS * 4; ++c) pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = 0.0;
@@ -397,10 +416,10 @@ __global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
         const double* p = (const double*)(g.arena + U.part) + (int64_t)q * 2;
         const int64_t stride = (int64_t)U.nqtiles * 16 * 2;
         double m = p[0];
-        for (int sp = 1; sp < U.nsplit; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
+        for (int sp = 1; sp < U.nsplit_fin; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
         double s = 0.0;
 #pragma unroll 4
-        for (int sp = 0; sp < U.nsplit; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
+        for (int sp = 0; sp < U.nsplit_fin; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
         val = U.lognorm + LN2 * (m + log2(s));
     }
     __shared__ double red[256];
@@ -471,6 +490,16 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     const int d0 = pools[0].d, KS = bf16 ? bf16x3_mfmas(d0) : (d0 + 3) / 4;
     const bool fold = d0 % 4 != 0;
     const size_t frag_b = bf16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
+    // RING pass (fp64 tables, opt-in: PBN_RING_NEAR=<exponent distance>, default 0 = off): pairs whose bound lies below 2^-ring_near of
+    // the sum go through the bf16 kernel instead of the fp64 one.  Measured (tools/ring_probe.sh, profiles/r3/ring_probe.txt): results
+    // agree with the one-pass evaluation to 1.5e-13, but the gain is small - the far field is a thin shell of (tile, group) pairs
+    // spread over as many workgroups as the main pass, each paying its prologue for a few tiles: hand-over at 2^-32 cv64 3.56 -> 3.68 s
+    // (slower), at 2^-24 3.56 -> 3.33 s and C3's first iteration 16.05 -> 15.58 s.  Kept as a switch, not as the default.
+    static const double ring_near_env = [] { const char* e = std::getenv("PBN_RING_NEAR"); return (e && *e) ? std::atof(e) : 0.0; }();
+    const double far = prune_margin(t->dtype);
+    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < far;
+    const int NB16 = ring ? bf16x3_mfmas(d0) : 0;
+    const size_t frag16_b = (size_t)NB16 * 64 * 16;
     static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
     int64_t total_wg = 0;
     int max_ntiles = 0, max_nqtiles = 0, max_nq = 0;
@@ -478,7 +507,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     auto carve = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return (int64_t)o; };
     // tables first
     const int64_t o_pools = carve((size_t)np * sizeof(GPool)), o_units = carve((size_t)nu * sizeof(GUnit)),
-                  o_sweep = carve((size_t)nu * sizeof(GSweepUnit)), o_blkpool = carve((size_t)B * sizeof(int32_t));
+                  o_sweep = carve((size_t)nu * sizeof(GSweepUnit) * 2), o_blkpool = carve((size_t)B * sizeof(int32_t));   // sweep records: fp64 / main pass, then the RING pass
     for (GUnit& U : units) {
         const GPool& P = pools[U.pool];
         const int d = P.d, pd = P.kd;
@@ -505,7 +534,11 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         U.qbox = carve((size_t)U.nqtiles * 2 * pd * 8);
         U.qthr = carve((size_t)U.nqtiles * 8);
         U.qlb = carve((size_t)U.nqtiles * 16 * 8);
-        U.part = carve((size_t)U.nsplit * U.nqtiles * 16 * 2 * 8);
+        U.nsplit_fin = ring ? 2 * U.nsplit : U.nsplit;
+        U.part = carve((size_t)U.nsplit_fin * U.nqtiles * 16 * 2 * 8);
+        U.apack16 = ring ? carve((size_t)U.ntiles * frag16_b) : 0;
+        U.bpack16 = ring ? carve((size_t)U.nqtiles * frag16_b) : 0;
+        U.ny16 = ring ? carve((size_t)U.nqtiles * 16 * 4) : 0;
         U.bsum = carve((size_t)((U.nq + 255) / 256 + 1) * 8);
     }
     const int64_t o_wgunit = carve((size_t)(total_wg / 64 + 1) * sizeof(int32_t));
@@ -531,6 +564,12 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
         s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
+        GSweepUnit& r = hs[nu + u];   // the RING pass: the bf16 fragments of the same rows, partials behind the fp64 pass's
+        r = s;
+        if (ring) {
+            r.Apack = arena + U.apack16; r.Bpack = arena + U.bpack16; r.nypack = arena + U.ny16;
+            r.part = (double*)(arena + U.part) + (size_t)U.nsplit * U.nqtiles * 16 * 2;
+        }
     }
     int32_t* hb = (int32_t*)(h.data() + o_blkpool);
     for (int k = 0; k < np; ++k)
@@ -557,7 +596,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.arena = arena; g.xstride = xstride; g.Rs = Rs; g.nunits = nu;
     static const int sum_bound = env_int("PBN_GROUP_SUM_BOUND", 1);
     g.use_sum_bound = sum_bound;
-    g.bf16 = bf16 ? 1 : 0; g.KS = KS;
+    g.bf16 = bf16 ? 1 : 0; g.KS = KS; g.ring_nb = NB16;
 
     const bool f64 = t->dtype == PBN_F64;
     {
@@ -584,10 +623,16 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         GSweepArgs sa{};
         sa.units = (const GSweepUnit*)(arena + o_sweep); sa.wg_unit = (const int32_t*)(arena + o_wgunit); sa.total_wg = total_wg;
         sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-        sa.prune_margin = prune_margin(t->dtype);
+        sa.prune_margin = ring ? ring_near_env : far;   // with a RING pass the fp64 kernel stops at the hand-over radius
         static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
-        sa.group_masks = gmasks;
+        sa.group_masks = ring ? 1 : gmasks;             // (the two passes split the pairs by the per-group test)
         launch_sweep_grouped(sa, t->dtype, KS, st);
+        if (ring) {
+            GSweepArgs ra = sa;
+            ra.units = (const GSweepUnit*)(arena + o_sweep) + nu;
+            ra.ring = 1; ra.prune_margin = far; ra.ring_near = ring_near_env;
+            launch_sweep_grouped(ra, t->dtype, NB16, st);
+        }
     }
     {
         KernelTimer kt(ctx, PBN_K_FINISH);
@@ -604,8 +649,8 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
     for (int u = 0; u < P.nunits; ++u) {
         const GUnit& U = b.units[P.unit0 + u];
         const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
-        s += nt * KS * 1024 + nt * 256 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
-             nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + (nsplit + 1) * nqt * 256 + (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) +
+        s += nt * KS * 1024 + nt * 256 + (nt + nqt) * 2048 + nqt * 64 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
+             nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 + (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) +
              (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
     }
     return s;

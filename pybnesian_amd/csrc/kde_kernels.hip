@@ -381,11 +381,12 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
                                                             const uint32_t* __restrict__ qkeys, const double* __restrict__ zt,
                                                             const uint32_t* __restrict__ tkeys, int64_t n, int zd, int pd,
                                                             double* __restrict__ qbox, double* __restrict__ qthr, double* __restrict__ qlb,
-                                                            const double* __restrict__ subpart, int P, int which, double log2_nsub) {
+                                                            const double* __restrict__ subpart, int P, int which, double log2_nsub, int sum_bound) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = q < nq;
     double z[PBN_MAX_D];
     double best = -INFINITY;
+    double sumb = -INFINITY;   // lower bound of log2 of the query's WHOLE sum: the part of it that has been looked at
     if (valid) {
         const double* zp = zq_row + (int64_t)qperm[q] * zd;
         for (int k = 0; k < zd; ++k) z[k] = zp[k];
@@ -393,25 +394,34 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
         int64_t lo = 0, hi = n;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tkeys[mid] < key) lo = mid + 1; else hi = mid; }
         const int64_t b = lo - PBN_PRUNE_WINDOW > 0 ? lo - PBN_PRUNE_WINDOW : 0, e = lo + PBN_PRUNE_WINDOW < n ? lo + PBN_PRUNE_WINDOW : n;
+        double acc = 0.0;
         for (int64_t t = b; t < e; ++t) {
             double d2 = 0.0;
             for (int k = 0; k < zd; ++k) { const double dd = zt[t * zd + k] - z[k]; d2 = __builtin_fma(dd, dd, d2); }
             const double ex = -0.5 * d2;
-            best = ex > best ? ex : best;
+            if (ex > best) { acc = acc * exp2(best - ex) + 1.0; best = ex; }
+            else acc += exp2(ex - best);
         }
+        if (acc > 0.0) sumb = best + log2(acc);
         // Neighbours in Morton order are neighbours in the keyed (<= 3) dimensions only: with more dimensions than that the
         // scan above finds rows that are close in 3 coordinates and anywhere in the others - a loose bound (d = 4: 6 % of the
         // tiles pruned where 70 % could be).  The sweep over a stratified subsample of the training rows bounds the largest
         // exponent whatever the dimension: max_t s2 >= log2(sum over the subsample of 2^s2) - log2(size of the subsample).
         if (subpart) {
             const double* sp = subpart + q * P + which;
-            const double lb = sp[0] + log2(sp[1]) - log2_nsub;
+            const double ls = sp[0] + log2(sp[1]);   // log2 of the sum over the subsample: a part of the whole sum
+            const double lb = ls - log2_nsub;        // ... and its mean term: a lower bound of the LARGEST term
             best = lb > best ? lb : best;
+            sumb = ls > sumb ? ls : sumb;
         }
     }
     if (qlb && q < (nq + 15) / 16 * 16) qlb[q] = valid ? best : -INFINITY;   // per query: the sweep's starting offset
+    // The pruning threshold stands on the bound of the query's SUM (the scanned neighbours' terms added up, or the subsample's sum -
+    // log2(nsub) = up to 12 units above its mean term): what a skipped tile could add is then below 2^-margin of the sum itself, not
+    // merely of its largest term - the same "at most N 2^-margin of a sum" as before, with a radius that is 5-10 % smaller per axis.
+    // (PBN_GROUP_SUM_BOUND=0 restores the largest-term threshold, here and in the grouped evaluation.)
     // reduce over the 16 lanes of a query tile
-    double thr = valid ? best : INFINITY;
+    double thr = valid ? ((sum_bound && sumb > best) ? sumb : best) : INFINITY;
     double lob[PBN_PRUNE_PD], hib[PBN_PRUNE_PD];
     for (int k = 0; k < PBN_PRUNE_PD; ++k) { lob[k] = (valid && k < pd) ? z[k] : INFINITY; hib[k] = (valid && k < pd) ? z[k] : -INFINITY; }
     for (int off = 1; off < 16; off <<= 1) {
@@ -930,7 +940,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul;
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
-    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks;
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks; a.ring_near = 0;
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL>(a, bid);
 }
 
@@ -1199,8 +1209,14 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
-template <int NB, bool COND, int QG, bool PRUNE>
+// RING (grouped evaluation of fp64 tables, kde_group.hip): the far field of an fp64 sweep.  The fp64 kernel visits the (tile, group)
+// pairs whose box distance allows a term within 2^-ring_near of the group's sum bound; this kernel visits the pairs BETWEEN that
+// radius and the pruning radius (2^-prune_margin) - terms below 2^-ring_near of their sums, for which fp32 arithmetic (6e-8 relative,
+// exponents good to ~1e-4) is far more than enough - at a third of the fp64 kernel's cost per pair.  Masks per 16-query group, with
+// the fp64 kernel's own test (prune_group_mask), so that every (tile, group) pair is taken by exactly one of the two passes.
+template <int NB, bool COND, int QG, bool PRUNE, bool RING = false>
 __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const unsigned bid) {
+    static_assert(!RING || (PRUNE && !COND), "RING: pruned plain sweeps only");
     using V = f4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
@@ -1332,10 +1348,12 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     // VALU's exponentials, one overflow test per tile, the rare path redoes a group (C2 fp32: 15.2 -> 14.1 ms).  The
     // fused CKDE sweep and the pruned sweeps keep the group-by-group form: with two accumulator sets per group in flight,
     // or one wave per SIMD less, the other form loses (C5's sweeps 33 -> 40 s; pruned d = 1 plain sweep 8.3 -> 10.2 ms).
-    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x) {
+    unsigned long long gm[RING ? QG : 1];
+    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x, const int bit = 0) {
         if constexpr (COND || PRUNE) {
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
+                if constexpr (RING) { if (!((gm[g] >> bit) & 1ull)) continue; }
                 V acc = mfma_main(f, g, cmv[g]);
                 V accj;
                 if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);
@@ -1438,7 +1456,20 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
             // (one mask per WAVE here: per-group masks as in the fp64 kernel - prune_group_mask - were measured and dropped for the
             //  fp32 kernels, which live on occupancy and straight-line issue: 1e6 x 1e5 handles +15...20 %, C5 15.8 -> 16.4 s)
-            unsigned long long mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
+            unsigned long long mask;
+            if constexpr (RING) {
+                mask = 0;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+                    const double th = QTp[qt];
+                    gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, th - a.prune_margin, lane) &
+                            ~prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, th - a.ring_near, lane);
+                    mask |= gm[g];
+                }
+            } else {
+                mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
+            }
             if (!mask) continue;
             if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
             // unconditional prefetch of the next kept tile (see kde_sweep_body: a conditional one costs a vmcnt(0) per tile)
@@ -1450,13 +1481,13 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                 const int b2 = more ? __builtin_ctzll(mask) : b;
                 mask &= mask - 1;
                 load_tile(tb + b2, fB, xB);
-                process_tile(fA, xA);
+                process_tile(fA, xA, b);
                 if (!more) break;
                 const bool more2 = mask != 0;
                 const int b3 = more2 ? __builtin_ctzll(mask) : b2;
                 mask &= mask - 1;
                 load_tile(tb + b3, fA, xA);
-                process_tile(fB, xB);
+                process_tile(fB, xB, b2);
                 if (!more2) break;
                 b = b3;
             }
@@ -1490,7 +1521,8 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         // sum can come out empty although it holds at least the offset's own term: count that term.  (A split whose tiles
         // were all pruned gets the same term: below 2^-64 of the query's sum by the pruning rule.)
         // (not when the offset is a prepass bound: no term of this split stands behind it, an empty sum is empty)
-        if (s == 0.0 && (m[g] - m[g]) == 0.f && !lbm[g]) s = 1.0;
+        // (not in the RING pass: the offset's own term belongs to the fp64 pass there)
+        if (!RING && s == 0.0 && (m[g] - m[g]) == 0.f && !lbm[g]) s = 1.0;
         if (COND && sj == 0.0 && (mj[g] - mj[g]) == 0.f && !lbmj[g]) sj = 1.0;
         if (lg == 0 && qt0 + g < a.nqtiles) {
             PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
@@ -1507,7 +1539,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_
 }
 
 // grouped launch of the pruned plain fp32 sweeps (see kde_sweep_group_kernel)
-template <int NB>
+template <int NB, bool RING>
 __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) void kde_sweep_bf16_group_kernel(GSweepArgs g) {
     const int u = g.wg_unit[blockIdx.x >> 6];
     const GSweepUnit& su = g.units[u];
@@ -1520,8 +1552,8 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) vo
     a.fold = 0; a.count_redo = g.count_redo; a.wmul = 0;
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
-    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = 0;
-    kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true>(a, bid);
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = 0; a.ring_near = g.ring_near;
+    kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true, RING>(a, bid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1957,8 +1989,9 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
                           const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
                           const double* subpart, int P, int which, double log2_nsub) {
     if (nq == 0) return;
+    static const int sum_bound = [] { const char* e = getenv("PBN_GROUP_SUM_BOUND"); return (e && *e) ? atoi(e) : 1; }();
     hipLaunchKernelGGL(query_prepass_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, zq_row, qperm, nq, qkeys_sorted, ztrain_sorted,
-                       tkeys_sorted, n, zd, pd, qbox, qthr, qlb, subpart, P, which, log2_nsub);
+                       tkeys_sorted, n, zd, pd, qbox, qthr, qlb, subpart, P, which, log2_nsub, sum_bound);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -2050,9 +2083,17 @@ void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st
     if (g.total_wg == 0) return;
     if (g.total_wg > 0x7fffffffll) throw invalid_error("grouped sweeps: grid too large");
     const dim3 grid((unsigned)g.total_wg), block(sweep_block_threads(true));
+    if (g.ring) {   // the far field of an fp64 sweep on the bf16 cores; KS carries the number of bf16 MFMAs
+        static_assert(PBN_QG_PRUNE == PBN_BF16_QG_PRUNE, "the two passes of a ring sweep share the workgroup table");
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1, true>), grid, block, 0, st, g);
+        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2, true>), grid, block, 0, st, g);
+        else throw invalid_error("grouped ring sweeps: at most 10 whitened dimensions");
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (use_bf16x3(dtype)) {   // KS carries the number of bf16 MFMAs
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1>), grid, block, 0, st, g);
-        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2>), grid, block, 0, st, g);
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1, false>), grid, block, 0, st, g);
+        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2, false>), grid, block, 0, st, g);
         else throw invalid_error("grouped fp32 sweeps: at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;

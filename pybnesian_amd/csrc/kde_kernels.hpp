@@ -80,6 +80,7 @@ struct SweepArgs {
     const double* qlb;         // [nqtiles * 16] per (sorted) query: lower bound of its largest exponent, -inf = none; nullable
     int nsplit_grid;           // pruned sweeps: number of splits (their grid is one-dimensional; launch_sweep sets this)
     int group_masks;           // pruned plain fp64 sweeps: test every 16-query group against its own box and bound (prune_group_mask)
+    double ring_near;          // RING pass of the bf16 kernel: visit only pairs whose bound lies between 2^-prune_margin and 2^-ring_near of the sum
     double* part;  // [nsplit][nqtiles*16][P]
     double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
     int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
