@@ -389,7 +389,7 @@ def pmc_traffic(args):
     MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload; null otherwise."""
     if (args.n_train, args.n_test, args.dtype, args.kde) != (1_000_000, 100_000, "f64", "product"):
         return None, None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")
         try:
             with open(path) as f:
@@ -492,7 +492,7 @@ def e2e_host(pbn, kde, names, test_np, repeats=3):
 def dp_issue_util():
     """Share of the FP64 issue slots the sweep kept busy, from the committed rocprofv3 PMC pass of this command:
     (MFMA busy cycles + 4 cycles per VALU wave-instruction) / (cycles x 1024 SIMDs)."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")) as f:
                 d = json.load(f)
