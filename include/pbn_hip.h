@@ -224,7 +224,12 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
                double* out);
 /* Score::local_score for a batch of candidates (replaces the serial double loop of
  * learning/operators/operators.cpp:100-132,296-347): candidate c scores column var[c] given
- * parents[par_off[c] .. par_off[c+1]) with node type node_type[c] (NULL = all LinearGaussian). */
+ * parents[par_off[c] .. par_off[c+1]) with node type node_type[c] (NULL = all LinearGaussian).
+ * This is SURVEY.md 8b's `pbn_lg_score_batch` and `pbn_ckde_slogl_batch` in one call ("one call per batch"): LinearGaussian
+ * candidates are host arithmetic on the handle's moments; the CKDE candidates of a likelihood kind are reduced to their unknown
+ * (variable set, region) terms, and ALL folds of ALL sets of the batch are evaluated by one launch chain (one ordering of every
+ * set's rows, one sweep launch - learning/scores/cv_likelihood.cpp:18-22 x factors/continuous/CKDE.hpp:256-287 fit and
+ * evaluate per fold and candidate). */
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                     const int* parents, const double* params, int n_params, double* out);
 

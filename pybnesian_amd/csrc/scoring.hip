@@ -1012,7 +1012,10 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                     std::vector<double> gm(dims), gs((size_t)dims * dims), L((size_t)dims * dims), Li((size_t)dims * dims);
                     subset_moments(sd, sd->all, pr.use.data(), dims, gm.data(), gs.data());
                     for (auto& x : gs) x /= (double)std::max<int64_t>(1, sd->all.N - 1);
-                    if (!hm::cholesky(gs.data(), dims, L.data())) throw singular_error("KDE: covariance matrix is not positive-definite");
+                    if (!hm::cholesky(gs.data(), dims, L.data())) {   // the keys only order the rows: fall back to the diagonal
+                        std::fill(L.begin(), L.end(), 0.0);
+                        for (int i = 0; i < dims; ++i) L[i + (size_t)i * dims] = std::sqrt(std::max(gs[i + (size_t)i * dims], 1e-300));
+                    }
                     hm::lower_inverse(L.data(), dims, Li.data());
                     for (int i = 0; i < dims; ++i) {
                         P.mug[i] = gm[i];
