@@ -64,7 +64,7 @@ void pbn_ctx_destroy(pbn_ctx* ctx) {
 }
 
 int pbn_ctx_sync(pbn_ctx* ctx) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         HIP_CHECK(hipSetDevice(ctx->device));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
@@ -87,7 +87,7 @@ static void drain_timers(pbn_ctx* ctx) {
 }
 
 int pbn_ctx_set_profiling(pbn_ctx* ctx, int on) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx) throw invalid_error("pbn_ctx_set_profiling: null context");
         HIP_CHECK(hipSetDevice(ctx->device));
         drain_timers(ctx);
@@ -97,7 +97,7 @@ int pbn_ctx_set_profiling(pbn_ctx* ctx, int on) {
 }
 
 int pbn_ctx_kernel_time(pbn_ctx* ctx, int kernel_class, double* total_ms, int64_t* launches) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || kernel_class < 0 || kernel_class >= PBN_NUM_KERNEL_CLASSES) throw invalid_error("pbn_ctx_kernel_time: bad argument");
         HIP_CHECK(hipSetDevice(ctx->device));
         drain_timers(ctx);
@@ -111,7 +111,7 @@ static inline bool bit_set(const uint8_t* bm, int64_t i) { return (bm[i >> 3] >>
 
 int pbn_table_create(pbn_ctx* ctx, const void* const* cols, int n_cols, int64_t n_rows, int dtype,
                      const uint8_t* valid, int64_t valid_offset, pbn_table** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || !out || (n_cols > 0 && !cols)) throw invalid_error("pbn_table_create: null argument");
         if (dtype != PBN_F64 && dtype != PBN_F32) throw invalid_error("Wrong data type. [double] or [float] data is expected.");
         if (n_cols < 0 || n_rows < 0) throw invalid_error("pbn_table_create: negative size");
@@ -153,7 +153,7 @@ int pbn_table_create(pbn_ctx* ctx, const void* const* cols, int n_cols, int64_t 
 
 int pbn_table_from_device(pbn_ctx* ctx, void* dev_base, int64_t ld, int n_cols, int64_t n_rows, int dtype,
                           pbn_table** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || !out || !dev_base) throw invalid_error("pbn_table_from_device: null argument");
         if (dtype != PBN_F64 && dtype != PBN_F32) throw invalid_error("Wrong data type. [double] or [float] data is expected.");
         if (ld < n_rows) throw invalid_error("pbn_table_from_device: ld < n_rows");
@@ -166,7 +166,7 @@ int pbn_table_from_device(pbn_ctx* ctx, void* dev_base, int64_t ld, int n_cols, 
 
 void pbn_table_destroy(pbn_table* t) {
     if (!t) return;
-    PBN_API_LOCK;
+    std::lock_guard<std::recursive_mutex> lock_(mu_of(t));
     if (t->owns && t->data) {
         (void)hipSetDevice(t->ctx->device);
         (void)hipStreamSynchronize(t->ctx->stream);
@@ -179,7 +179,7 @@ int64_t pbn_table_rows(const pbn_table* t) { return t ? t->n_rows : 0; }
 int pbn_table_cols(const pbn_table* t) { return t ? t->n_cols : 0; }
 
 int pbn_table_take(const pbn_table* t, const int32_t* rows, int64_t n, pbn_table** out) {
-    return guarded([&] {
+    return guarded(mu_of(t), [&] {
         if (!t || !out || (n > 0 && !rows)) throw invalid_error("pbn_table_take: null argument");
         for (int64_t i = 0; i < n; ++i)
             if (rows[i] < 0 || rows[i] >= t->n_rows) throw invalid_error("pbn_table_take: row index out of range");
@@ -200,7 +200,7 @@ int pbn_table_take(const pbn_table* t, const int32_t* rows, int64_t n, pbn_table
 }
 
 int pbn_table_read(const pbn_table* t, const int* cols, int n_sel, void* outp) {
-    return guarded([&] {
+    return guarded(mu_of(t), [&] {
         if (!t || !cols || !outp) throw invalid_error("pbn_table_read: null argument");
         HIP_CHECK(hipSetDevice(t->ctx->device));
         HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
@@ -261,7 +261,7 @@ static void sse_block(const pbn_table* t, const int* cols, int d, int64_t row0, 
 }
 
 int pbn_table_sse(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, double* means, double* sse) {
-    return guarded([&] {
+    return guarded(mu_of(t), [&] {
         check_cols(t, cols, d, "pbn_table_sse");
         check_range(t, row0, n, "pbn_table_sse");
         if (!means || !sse) throw invalid_error("pbn_table_sse: null output");
@@ -363,7 +363,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
 
 int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                 const double* bandwidth, int kind, const double* center, pbn_kde** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (kind != PBN_BW_FULL && kind != PBN_BW_DIAG) throw invalid_error("pbn_kde_fit: unknown bandwidth kind");
         kde_fit_impl(ctx, train, cols, d, row0, n, bandwidth, kind, false, center, out);
     });
@@ -371,12 +371,12 @@ int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, in
 
 int pbn_ckde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                  const double* H, const double* center, pbn_kde** out) {
-    return guarded([&] { kde_fit_impl(ctx, train, cols, d, row0, n, H, PBN_BW_FULL, true, center, out, true); });
+    return guarded(mu_of(ctx), [&] { kde_fit_impl(ctx, train, cols, d, row0, n, H, PBN_BW_FULL, true, center, out, true); });
 }
 
 void pbn_kde_destroy(pbn_kde* k) {
     if (!k) return;
-    PBN_API_LOCK;
+    std::lock_guard<std::recursive_mutex> lock_(mu_of(k));
     (void)hipSetDevice(k->ctx->device);
     (void)hipStreamSynchronize(k->ctx->stream);
     delete k;
@@ -415,14 +415,14 @@ static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols,
 }
 
 int pbn_kde_logl_dev(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* dev_out) {
-    return guarded([&] {
+    return guarded(mu_of(k), [&] {
         if (!dev_out && n > 0) throw invalid_error("pbn_kde_logl_dev: null output");
         kde_eval_enqueue(k, test, cols, row0, n, dev_out, nullptr);
     });
 }
 
 int pbn_kde_logl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out) {
-    return guarded([&] {
+    return guarded(mu_of(k), [&] {
         if (!out && n > 0) throw invalid_error("pbn_kde_logl: null output");
         if (!k) throw invalid_error("KDE factor not fitted.");
         dev_buf<double> tmp((size_t)std::max<int64_t>(n, 1));
@@ -433,7 +433,7 @@ int pbn_kde_logl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
 }
 
 int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out) {
-    return guarded([&] {
+    return guarded(mu_of(k), [&] {
         if (!k) throw invalid_error("CKDE factor not fitted.");
         if (!k->ckde) throw invalid_error("pbn_ckde_cdf: the handle was not created by pbn_ckde_fit");
         if (k->cdf_KS == 0) throw invalid_error("CKDE.cdf: at most 16 evidence variables are supported");
@@ -476,14 +476,14 @@ int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
 }
 
 int pbn_kde_slogl_async(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* dev_out) {
-    return guarded([&] {
+    return guarded(mu_of(k), [&] {
         if (!dev_out) throw invalid_error("pbn_kde_slogl_async: null output");
         kde_eval_enqueue(k, test, cols, row0, n, nullptr, dev_out);
     });
 }
 
 int pbn_kde_slogl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* out) {
-    return guarded([&] {
+    return guarded(mu_of(k), [&] {
         if (!out) throw invalid_error("pbn_kde_slogl: null output");
         if (!k) throw invalid_error("KDE factor not fitted.");
         k->ctx->scratch_red.reserve(8);

@@ -37,11 +37,16 @@ struct device_error : std::runtime_error {
 
 void set_last_error(const std::string& s);
 
-// One lock for the whole C ABI.  A context has ONE stream and grow-only scratch arenas that every call re-carves
-// (scratch_q, scratch_part, ...), and the Python layer loads the library with ctypes.CDLL, which drops the GIL around
-// calls - the reference holds the GIL through its pybind11 calls (SURVEY.md §8b "Threading"), so there two Python
-// threads can never be inside the library at once; here this mutex gives the same guarantee.  Recursive: entry points
-// call each other, and Python callbacks (user-defined scores / independence tests) re-enter on the same thread.
+// Locking of the C ABI.  A context has ONE stream and grow-only scratch arenas that every call re-carves (scratch_q, scratch_part,
+// ...), and the Python layer loads the library with ctypes.CDLL, which drops the GIL around calls - the reference holds the GIL
+// through its pybind11 calls (SURVEY.md 8b "Threading"), so there two Python threads can never be inside the library at once.
+// Here every entry point that works on a context - directly or through a handle that belongs to one (table, KDE, score data, MI /
+// kMI engines) - takes THAT CONTEXT's recursive mutex (pbn_ctx::mu, mu_of below): two threads on the same context are serialised as
+// before, threads driving different contexts (GPUs) are not.  A hill-climb handle and the stand-alone search entry points
+// (pbn_hc_*, pbn_mmpc_*) hold only their own state's lock while they run - their score / independence-test callbacks take the lock
+// of whatever context they touch - so a search no longer blocks the rest of the process for its whole duration (round 2: one
+// process-wide mutex).  Host-only entry points (bandwidths, split layouts, samplers) and creation / destruction of contexts use the
+// process-wide mutex.  All mutexes are recursive: entry points call each other, and Python callbacks re-enter on the same thread.
 std::recursive_mutex& api_mutex();
 #define PBN_API_LOCK std::lock_guard<std::recursive_mutex> pbn_api_lock_(::pbn::api_mutex())
 
@@ -54,11 +59,11 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define HIP_CHECK(x) ::pbn::hip_check((x), #x, __FILE__, __LINE__)
 
-// Translate C++ exceptions into status codes at the C-ABI boundary.
+// Translate C++ exceptions into status codes at the C-ABI boundary; `mu` is the lock of the state the call works on (see above).
 template <typename F>
-int guarded(F&& f) noexcept {
+int guarded(std::recursive_mutex& mu, F&& f) noexcept {
     try {
-        PBN_API_LOCK;
+        std::lock_guard<std::recursive_mutex> lock(mu);
         f();
         return PBN_OK;
     } catch (const invalid_error& e) {
@@ -77,6 +82,10 @@ int guarded(F&& f) noexcept {
         set_last_error(e.what());
         return PBN_ERR_INVALID;
     }
+}
+template <typename F>
+int guarded(F&& f) noexcept {   // host-only entry points: the process-wide mutex
+    return guarded(api_mutex(), std::forward<F>(f));
 }
 
 // RAII device buffer bound to a device; freed with hipFree.
@@ -121,6 +130,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- handle definitions (opaque in the C header) ---------------------------------------------
 
 struct pbn_ctx {
+    std::recursive_mutex mu;   // every entry point working on this context holds it (pbn::mu_of)
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
@@ -188,6 +198,14 @@ struct pbn_ctx {
     double kernel_ms[PBN_NUM_KERNEL_CLASSES] = {0};
     int64_t kernel_launches[PBN_NUM_KERNEL_CLASSES] = {0};
 };
+
+namespace pbn {
+// the lock an entry point takes: the context's own, through any handle that carries a `ctx` member; a null handle falls back to
+// the process-wide mutex (the call then fails on its own null check)
+inline std::recursive_mutex& mu_of(const pbn_ctx* c) { return c ? const_cast<pbn_ctx*>(c)->mu : api_mutex(); }
+template <typename H>
+inline std::recursive_mutex& mu_of(const H* h) { return h ? mu_of(static_cast<const pbn_ctx*>(h->ctx)) : api_mutex(); }
+}  // namespace pbn
 
 namespace pbn {
 // PBN_SCORE_LANES (at most 4): issue lanes of the score engine's independent evaluations; 1 keeps everything on the

@@ -491,9 +491,11 @@ static void init_engine(Engine& e, const pbn_hc_config* cfg, pbn_hc_score_fn fn,
 }
 
 struct pbn_hc {
+    std::recursive_mutex mu;   // the handle's own state; its score callback takes the lock of whatever context it touches
     Engine e;
     bool cached = false;
 };
+static std::recursive_mutex& hc_mu(pbn_hc* h) { return h ? h->mu : pbn::api_mutex(); }
 
 extern "C" {
 
@@ -508,10 +510,10 @@ int pbn_hc_create(const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user, pbn_
     });
 }
 
-void pbn_hc_destroy(pbn_hc* h) { PBN_API_LOCK; delete h; }
+void pbn_hc_destroy(pbn_hc* h) { delete h; }   // (the caller owns the handle: nobody else may be inside it)
 
 int pbn_hc_set_model(pbn_hc* h, int n_arcs, const int* arcs, const int* node_types) {
-    return guarded([&] {
+    return guarded(hc_mu(h), [&] {
         if (!h || (n_arcs > 0 && !arcs)) throw invalid_error("pbn_hc_set_model: null argument");
         Model& m = h->e.cur;
         const int n = m.n;
@@ -527,7 +529,7 @@ int pbn_hc_set_model(pbn_hc* h, int n_arcs, const int* arcs, const int* node_typ
 }
 
 int pbn_hc_cache_scores(pbn_hc* h) {
-    return guarded([&] {
+    return guarded(hc_mu(h), [&] {
         if (!h) throw invalid_error("pbn_hc_cache_scores: null handle");
         h->e.cache_scores();
         h->cached = true;
@@ -535,7 +537,7 @@ int pbn_hc_cache_scores(pbn_hc* h) {
 }
 
 int pbn_hc_find_max(pbn_hc* h, int n_tabu, const int* tabu, int* op, double* delta) {
-    return guarded([&] {
+    return guarded(hc_mu(h), [&] {
         if (!h || !op || !delta) throw invalid_error("pbn_hc_find_max: null argument");
         if (!h->cached) throw invalid_error("Local cache not initialized. Call cache_scores() before find_max()");
         std::vector<Op> tb((size_t)n_tabu);
@@ -553,7 +555,7 @@ int pbn_hc_find_max(pbn_hc* h, int n_tabu, const int* tabu, int* op, double* del
 }
 
 int pbn_hc_update_scores(pbn_hc* h, int n, const int* nodes) {
-    return guarded([&] {
+    return guarded(hc_mu(h), [&] {
         if (!h || (n > 0 && !nodes)) throw invalid_error("pbn_hc_update_scores: null argument");
         if (!h->cached) throw invalid_error("Local cache not initialized. Call cache_scores() before update_scores()");
         std::vector<int> changed(nodes, nodes + n);
@@ -564,7 +566,7 @@ int pbn_hc_update_scores(pbn_hc* h, int n, const int* nodes) {
 }
 
 int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types) {
-    return guarded([&] {
+    return guarded(hc_mu(h), [&] {
         if (!h) throw invalid_error("pbn_hc_get: null handle");
         const int n = h->e.cur.n;
         if (local && (int)h->e.local.size() == n) std::memcpy(local, h->e.local.data(), n * sizeof(double));
@@ -578,7 +580,8 @@ int pbn_hc_get(pbn_hc* h, double* local, double* delta_arcs, double* delta_types
 
 extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, void* user, int* out_arcs, int* out_n_arcs,
                                int* out_node_types, pbn_hc_stats* stats) {
-    return guarded([&] {
+    std::recursive_mutex own;   // a search holds no shared state of the library: its callbacks lock the contexts they use
+    return guarded(own, [&] {
         if (!cfg || !fn || !out_arcs || !out_n_arcs || !out_node_types) throw invalid_error("pbn_hc_estimate: null argument");
         Engine e;
         init_engine(e, cfg, fn, user);

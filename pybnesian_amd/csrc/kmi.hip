@@ -381,7 +381,7 @@ extern "C" {
 // taken as rank_data does (mutual_information.hpp:17-52): ONE index vector, std::sort'ed column after column.
 int pbn_kmi_create(pbn_ctx* ctx, const double* const* cols, int n_vars, int64_t N, int k, uint32_t seed, int shuffle_neighbors,
                    int samples, pbn_kmi** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || !cols || !out) throw invalid_error("pbn_kmi_create: null argument");
         if (n_vars < 2) throw invalid_error("DataFrame does not contain enough continuous columns.");
         if (k < 1 || k > KMI_MAX_K || k >= N) throw invalid_error("KMutualInformation: k must be between 1 and min(64, rows - 1)");
@@ -417,7 +417,7 @@ int pbn_kmi_create(pbn_ctx* ctx, const double* const* cols, int n_vars, int64_t 
 
 void pbn_kmi_destroy(pbn_kmi* h) {
     if (!h) return;
-    PBN_API_LOCK;
+    std::lock_guard<std::recursive_mutex> lock_(mu_of(h));
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     delete h;
@@ -425,7 +425,7 @@ void pbn_kmi_destroy(pbn_kmi* h) {
 
 // KMutualInformation::mi (mutual_information.cpp:142-155)
 int pbn_kmi_value(pbn_kmi* h, int v1, int v2, int n_cond, const int* cond, double* mi) {
-    return guarded([&] {
+    return guarded(mu_of(h), [&] {
         if (!h || !mi || (n_cond > 0 && !cond)) throw invalid_error("pbn_kmi_value: null argument");
         std::vector<int> vars{v1, v2};
         vars.insert(vars.end(), cond, cond + n_cond);

@@ -955,7 +955,7 @@ extern "C" {
 // (table order), then the discrete ones.
 int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_disc, const int32_t* const* codes,
                   const int* cardinality, int asymptotic_df, pbn_mi** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || !out || (n_disc > 0 && (!codes || !cardinality))) throw invalid_error("pbn_mi_create: null argument");
         if (table && table->n_rows != n_rows) throw invalid_error("pbn_mi_create: row counts differ");
         HIP_CHECK(hipSetDevice(ctx->device));
@@ -1003,7 +1003,7 @@ int pbn_mi_create(pbn_ctx* ctx, const pbn_table* table, int64_t n_rows, int n_di
 // would be NaN).  A test then runs over the rows valid in all of its variables, as the reference's contains_null
 // overloads do (hybrid/mutual_information.cpp:152-215).
 int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const double* shift) {
-    return guarded([&] {
+    return guarded(mu_of(h), [&] {
         if (!h || !flags || !shift) throw invalid_error("pbn_mi_set_continuous_nulls: null argument");
         for (int i = 0; i < h->n_cont; ++i) {
             h->cont_null[i] = flags[i] ? 1 : 0;
@@ -1014,7 +1014,7 @@ int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const dou
 
 void pbn_mi_destroy(pbn_mi* h) {
     if (!h) return;
-    PBN_API_LOCK;
+    std::lock_guard<std::recursive_mutex> lock_(mu_of(h));
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     const char* tm = std::getenv("PBN_MI_TIMING");
@@ -1027,7 +1027,7 @@ void pbn_mi_destroy(pbn_mi* h) {
 
 // MI(v1; v2 | cond) and the degrees of freedom of its chi-square statistic; either output may be NULL.
 int pbn_mi_value(pbn_mi* h, int v1, int v2, int n_cond, const int* cond, double* mi, double* df) {
-    return guarded([&] {
+    return guarded(mu_of(h), [&] {
         if (!h || (n_cond > 0 && !cond)) throw invalid_error("pbn_mi_value: null argument");
         Engine e{h};
         const Query q = e.make(v1, v2, n_cond, cond);
@@ -1169,7 +1169,7 @@ void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, 
 
 // Index space of pbn_mi_pvalue: external index i stands for variable ids[i] (n == 0 restores the identity).
 int pbn_mi_set_order(pbn_mi* h, int n, const int* ids) {
-    return guarded([&] {
+    return guarded(mu_of(h), [&] {
         if (!h || (n > 0 && !ids)) throw invalid_error("pbn_mi_set_order: null argument");
         for (int i = 0; i < n; ++i)
             if (ids[i] < 0 || ids[i] >= h->n_cont + h->n_disc) throw invalid_error("pbn_mi_set_order: variable id out of range");
@@ -1230,7 +1230,7 @@ double pbn_chisq_pvalue(void* user, int v1, int v2, int n_cond, const int* cond)
 // stride_i], the first variable fastest, prod(cardinality) entries, rows with a null in any of the variables left out.
 // The counts are the segment lengths of the cached row grouping of that variable set.
 int pbn_mi_counts(pbn_mi* h, int n_vars, const int* vars, double* out) {
-    return guarded([&] {
+    return guarded(mu_of(h), [&] {
         if (!h || !vars || !out || n_vars < 1) throw invalid_error("pbn_mi_counts: null argument");
         std::vector<int> v(vars, vars + n_vars);
         if (!h->order.empty())
@@ -1248,7 +1248,7 @@ int pbn_mi_counts(pbn_mi* h, int n_vars, const int* vars, double* out) {
 }
 
 int pbn_mi_stats(const pbn_mi* h, int64_t* device_passes, int64_t* host_passes) {
-    return guarded([&] {
+    return guarded(mu_of(h), [&] {
         if (!h) throw invalid_error("pbn_mi_stats: null argument");
         if (device_passes) *device_passes = h->device_passes;
         if (host_passes) *host_passes = h->host_passes;

@@ -462,7 +462,7 @@ struct Mmpc {
 extern "C" {
 
 int pbn_lincor_create(pbn_ctx* ctx, const pbn_table* table, pbn_lincor** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || !table || !out) throw invalid_error("pbn_lincor_create: null argument");
         const int n = table->n_cols;
         if (n < 2) throw invalid_error("DataFrame does not contain enough continuous columns.");
@@ -525,7 +525,8 @@ double pbn_lincor_pvalue(void* user, int v1, int v2, int n_cond, const int* cond
 static int mmpc_cpcs_impl(int n, int n_interface, pbn_ci_pvalue_fn fn, pbn_ci_pvalue_batch_fn batch_fn, void* user, double alpha, int n_arc_whitelist,
                           const int* arc_whitelist, int n_edge_blacklist, const int* edge_blacklist, int n_edge_whitelist,
                           const int* edge_whitelist, int symmetric, int* cpc_off, int* cpc, int64_t* n_tests) {
-    return guarded([&] {
+    std::recursive_mutex own;   // host-only search; the independence-test callbacks lock the contexts they use
+    return guarded(own, [&] {
         if (n <= 0 || n_interface < 0 || n_interface >= n || !fn || !cpc_off || !cpc) throw invalid_error("pbn_mmpc_cpcs: bad argument");
         if (!(alpha > 0 && alpha < 1)) throw invalid_error("alpha must be a number between 0 and 1.");
         Mmpc m{n, alpha, fn, user};

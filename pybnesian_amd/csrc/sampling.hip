@@ -213,7 +213,7 @@ extern "C" {
 
 int pbn_ckde_sample(pbn_kde* k, int64_t n, int64_t stream_n, const pbn_table* evidence, const int* ev_cols, uint32_t seed,
                     void* out) {
-    return guarded([&] {
+    return guarded(mu_of(k), [&] {
         if (!k) throw invalid_error("CKDE factor not fitted.");
         if (!k->ckde || !k->train) throw invalid_error("pbn_ckde_sample: the handle was not created by pbn_ckde_fit");
         if (k->cdf_KS == 0) throw invalid_error("CKDE.sample: at most 16 evidence variables are supported");

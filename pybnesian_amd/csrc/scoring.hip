@@ -449,7 +449,7 @@ static SplitLayout split_layout(int64_t rows, int split, int k, uint32_t seed, d
 
 static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split, int k, uint32_t seed, double test_ratio,
                                  int rank, int world, pbn_scoredata** out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!ctx || !table || !out) throw invalid_error("pbn_scoredata_create: null argument");
         if (world < 1 || rank < 0 || rank >= world) throw invalid_error("pbn_scoredata_create_sharded: rank / world out of range");
         if (table->n_cols <= 0) throw invalid_error("pbn_scoredata_create: table has no columns");
@@ -524,7 +524,7 @@ int pbn_scoredata_create_sharded(pbn_ctx* ctx, const pbn_table* table, int split
 // set == 0 copies them out (segments this rank did not compute are zero), set != 0 installs all of them, rebuilds the
 // regions' totals in segment order and clears the partial flag.
 int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd) throw invalid_error("pbn_scoredata_moments: null argument");
         const size_t per = (size_t)sd->n + (size_t)sd->n * sd->n;
         if (len) *len = (int64_t)(per * sd->seg.size());
@@ -550,14 +550,14 @@ int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set)
 
 void pbn_scoredata_destroy(pbn_scoredata* sd) {
     if (!sd) return;
-    PBN_API_LOCK;
+    std::lock_guard<std::recursive_mutex> lock_(mu_of(sd));
     if (sd->perm_table) pbn_table_destroy(sd->perm_table);
     delete sd;
 }
 
 // Attach the dictionary-encoded (discrete) columns: codes[j][r] = dictionary index of SOURCE row r.
 int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* const* codes, const int* cardinality) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd || (n_disc > 0 && (!codes || !cardinality))) throw invalid_error("pbn_scoredata_set_discrete: null argument");
         const int64_t rows = (int64_t)sd->perm.size();
         // everything derived from the previous codes (device row lists of the groupings, per-configuration KDE sums, memoised
@@ -584,7 +584,7 @@ int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* con
 // array (1 = valid) in source row order, or NULL when column c has no nulls.  Likelihood scores never see nulls:
 // CrossValidation / HoldOut keep only rows valid in every column (crossvalidation_adaptator.hpp:24-37).
 int pbn_scoredata_set_validity(pbn_scoredata* sd, const uint8_t* const* masks) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd || !masks) throw invalid_error("pbn_scoredata_set_validity: null argument");
         if (sd->split != PBN_SPLIT_NONE) throw invalid_error("pbn_scoredata_set_validity: only for BIC / BGe score data");
         const int64_t rows = (int64_t)sd->perm.size();
@@ -601,7 +601,7 @@ int pbn_scoredata_set_validity(pbn_scoredata* sd, const uint8_t* const* masks) {
 // Bandwidth selector used for every CKDE the engine fits while scoring (CKDEType::new_factor with construction
 // arguments, cv_likelihood.hpp:19-27; selectors kde/NormalReferenceRule.hpp, kde/ScottsBandwidth.hpp).
 int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd) throw invalid_error("pbn_scoredata_set_selector: null argument");
         if (selector != PBN_SEL_NORMAL_REFERENCE && selector != PBN_SEL_SCOTT) throw invalid_error("pbn_scoredata_set_selector: unknown selector");
         sd->selector = selector;
@@ -612,7 +612,7 @@ int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
 
 // Set-function cache of the CKDE likelihood scores: entries held, sweeps launched so far.
 int pbn_scoredata_cache_stats(const pbn_scoredata* sd, int64_t* entries, int64_t* sweeps) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd) throw invalid_error("pbn_scoredata_cache_stats: null argument");
         if (entries) *entries = (int64_t)sd->kde_cache.size();
         if (sweeps) *sweeps = sd->kde_sweeps;
@@ -634,7 +634,7 @@ int pbn_split_layout(int64_t n_rows, int split, int k, uint32_t seed, double tes
 }
 
 int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits, int64_t* n_cv, int64_t* n_hold) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd) throw invalid_error("pbn_scoredata_layout: null argument");
         if (perm) std::memcpy(perm, sd->perm.data(), sd->perm.size() * sizeof(int32_t));
         if (limits && sd->k > 0) std::memcpy(limits, sd->limits.data(), sd->limits.size() * sizeof(int32_t));
@@ -645,7 +645,7 @@ int pbn_scoredata_layout(const pbn_scoredata* sd, int32_t* perm, int32_t* limits
 
 // MLE<LinearGaussianCPD>::estimate over the CV/training region (all rows for PBN_SPLIT_NONE).
 int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, double* beta, double* variance) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd || !beta || !variance) throw invalid_error("pbn_lg_fit: null argument");
         if (sd->partial) throw invalid_error("pbn_lg_fit: row-sharded score data needs pbn_scoredata_moments(set) first");
         std::vector<int> cols(p + 1);
@@ -664,7 +664,7 @@ int pbn_lg_fit(const pbn_scoredata* sd, int var, const int* parents, int p, doub
 
 // MLE<LinearGaussianCPD>::estimate on a table row range (one Gram pass + host solve).
 int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, double* beta, double* variance) {
-    return guarded([&] {
+    return guarded(mu_of(t), [&] {
         if (!beta || !variance) throw invalid_error("pbn_lg_fit_table: null output");
         check_cols(t, cols, d, "pbn_lg_fit_table");
         check_range(t, row0, n, "pbn_lg_fit_table");
@@ -682,7 +682,7 @@ int pbn_lg_fit_table(const pbn_table* t, const int* cols, int d, int64_t row0, i
 // LinearGaussianCPD::logl / slogl (factors/continuous/LinearGaussianCPD.cpp:92-149,251-292).
 static int lg_eval(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t n, const double* beta, double variance,
                    double* out_logl, double* out_slogl, int want_cdf) {
-    return guarded([&] {
+    return guarded(mu_of(t), [&] {
         check_cols(t, cols, d, "pbn_lg_logl");
         check_range(t, row0, n, "pbn_lg_logl");
         if (!beta) throw invalid_error("pbn_lg_logl: null beta");
@@ -728,7 +728,7 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
 
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                     const int* parents, const double* params, int n_params, double* out) {
-    return guarded([&] {
+    return guarded(mu_of(sd), [&] {
         if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
         pbn_ctx* ctx = sd->ctx;
         if (sd->partial) throw invalid_error("pbn_score_batch: row-sharded score data needs pbn_scoredata_moments(set) first");

@@ -200,7 +200,7 @@ extern "C" {
 // UCVScorer::score_unconstrained / score_diagonal (kde/UCV.cpp:226-360): N * UCV of the given bandwidth.
 int pbn_ucv_score(pbn_ctx* ctx, const pbn_table* table, const int* cols, int d, int64_t row0, int64_t n, const double* bandwidth,
                   int kind, double* out) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!bandwidth || !out) throw invalid_error("pbn_ucv_score: null argument");
         if (kind != PBN_BW_FULL && kind != PBN_BW_DIAG) throw invalid_error("pbn_ucv_score: unknown bandwidth kind");
         UcvScorer s = make_scorer(ctx, table, cols, d, row0, n);
@@ -213,7 +213,7 @@ int pbn_ucv_score(pbn_ctx* ctx, const pbn_table* table, const int* cols, int d, 
 // reference's guards on the determinant and on the score (wrap_ucv_optim / wrap_ucv_diag_optim, :395-450).
 int pbn_ucv_bandwidth(pbn_ctx* ctx, const pbn_table* table, const int* cols, int d, int64_t row0, int64_t n, int kind,
                       const double* start, double* out, int64_t* n_evals) {
-    return guarded([&] {
+    return guarded(mu_of(ctx), [&] {
         if (!start || !out) throw invalid_error("pbn_ucv_bandwidth: null argument");
         UcvScorer s = make_scorer(ctx, table, cols, d, row0, n);
         if (kind == PBN_BW_DIAG) {
