@@ -81,7 +81,7 @@ def test_another_thread_gets_through_during_a_search(pbn):
             return True
 
         def local_score(self, model, variable, evidence=None):
-            time.sleep(0.004)
+            time.sleep(0.02)
             return bic.local_score(model, variable, model.parents(variable) if evidence is None else evidence)
 
     done = {}
@@ -102,4 +102,4 @@ def test_another_thread_gets_through_during_a_search(pbn):
     t.join(timeout=300)
     assert np.isfinite(val) and done["search"][1] >= 2
     assert t_other < done["search"][0], "the other thread's calls waited for the whole search"
-    assert done["search"][0] - t0 > 0.25
+    assert done["search"][0] - t0 > 0.3   # the search was long enough for the comparison to mean something
