@@ -1206,6 +1206,9 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_WAVES
 #define PBN_BF16_WAVES 2   // the same for the unpruned fp32 sweeps of up to 10 dimensions (4 waves per workgroup: workgroups per CU)
 #endif
+// (Measured again in round 3 and dropped again: the tile sums of 8 / 16 consecutive tiles added in fp32 before they join the fp64 sums -
+//  one v_add_f32 instead of v_cvt_f64_f32 + v_add_f64 per (tile, group).  The allocator answers with +35 VGPRs (138 -> 173: two
+//  waves per SIMD instead of three): fp32 headline 14.5 -> 17.7 ms, 16.2 ms when held to three waves; tools/f32_variants.sh.)
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
