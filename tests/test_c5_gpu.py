@@ -182,3 +182,33 @@ def test_mmhc_hybrid_end_to_end_vs_oracles(pbn, oracle):
     assert [tcode[res.node_type(c)] for c in names] == list(o_types)
     assert mm.hc.last.cells_scored == info["cells_scored"]
     assert res.num_arcs() >= 3
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-5)])
+def test_grouped_hybrid_slices_match_per_slice_chains(pbn, monkeypatch, dtype, tol):
+    """Hybrid CKDE candidates through the grouped evaluation (kde_group.hip: one pool per configuration and term, all folds of all
+    configurations in one launch chain; fp32: bf16x3 fragments, two plain terms) against the per-(fold, configuration) chains of
+    round 2 (fp32: the fused joint + marginal sweep): CV and validation scores of five candidates with one and two discrete parents.
+    fp64: the same pairs in another order, equal to rounding; fp32: also another split of the terms."""
+    rng = np.random.default_rng(9)
+    n = 300_000
+    A, B = rng.integers(0, 3, size=n), rng.integers(0, 2, size=n)
+    x = rng.normal(size=n) + 1.5 * A
+    y = 0.6 * x + np.where(B == 1, 1.0, -1.0) + rng.normal(scale=0.7, size=n)
+    z = np.tanh(y) + 0.4 * x + rng.normal(scale=0.5, size=n)
+    df = pd.DataFrame({"x": x.astype(dtype), "y": y.astype(dtype), "z": z.astype(dtype)})
+    df["A"] = pd.Categorical.from_codes(A, ["a0", "a1", "a2"])
+    df["B"] = pd.Categorical.from_codes(B, ["b0", "b1"])
+    bn = pbn.SemiparametricBN(list(df.columns), [], [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType())])
+    cands = (("y", ["x", "B"]), ("z", ["x", "y", "A"]), ("x", ["A"]), ("z", ["A", "B"]), ("y", ["x", "z", "A", "B"]))
+    res = {}
+    for grouped in ("1", "0"):
+        monkeypatch.setenv("PBN_SCORE_GROUPED", grouped)
+        score = pbn.ValidatedLikelihood(df, 0.2, 4, 1)
+        res[grouped] = np.array([score.local_score_node_type(bn, pbn.CKDEType(), v, p) for v, p in cands] +
+                                [score.vlocal_score_node_type(bn, pbn.CKDEType(), v, p) for v, p in cands])
+        entries, sweeps = score.kde_cache_stats()
+        assert sweeps > 0
+    monkeypatch.delenv("PBN_SCORE_GROUPED")
+    assert np.all(np.isfinite(res["1"]))
+    assert np.allclose(res["1"], res["0"], rtol=tol, atol=0), (res["1"] - res["0"]) / res["0"]
