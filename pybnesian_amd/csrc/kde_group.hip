@@ -46,6 +46,7 @@ struct GDev {   // argument block of the block-wise kernels
     int use_sum_bound;
     int bf16;                 // fp32 table: bf16x3 fragments (kde_kernels.hip pack_rows_bf16_kernel), KS = number of bf16 MFMAs
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
+    int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     int ring_nb;              // > 0: fp64 table with a RING pass - also write bf16x3 fragments (ring_nb MFMAs) of every row
 };
 
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void group_prepass_kernel(GDev g) {
         const double* zp = (const double*)(g.arena + U.zq) + (int64_t)q * d;
         for (int k = 0; k < d; ++k) z[k] = zp[k];
         const int tpos = ((const int32_t*)(g.arena + U.qpos))[q];
-        const int b = tpos - PBN_GROUP_WINDOW > 0 ? tpos - PBN_GROUP_WINDOW : 0, e = tpos + PBN_GROUP_WINDOW < U.N ? tpos + PBN_GROUP_WINDOW : U.N;
+        const int b = tpos - g.window > 0 ? tpos - g.window : 0, e = tpos + g.window < U.N ? tpos + g.window : U.N;
         const double* zt = (const double*)(g.arena + U.zs);
         for (int t = b; t < e; ++t) {
             double d2 = 0.0;
@@ -597,6 +598,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     static const int sum_bound = env_int("PBN_GROUP_SUM_BOUND", 1);
     g.use_sum_bound = sum_bound;
     g.bf16 = bf16 ? 1 : 0; g.KS = KS; g.ring_nb = NB16;
+    static const int window = std::max(1, env_int("PBN_GROUP_WINDOW", PBN_GROUP_WINDOW));
+    g.window = window;
 
     const bool f64 = t->dtype == PBN_F64;
     {
