@@ -497,8 +497,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     // spread over as many workgroups as the main pass, each paying its prologue for a few tiles: hand-over at 2^-32 cv64 3.56 -> 3.68 s
     // (slower), at 2^-24 3.56 -> 3.33 s and C3's first iteration 16.05 -> 15.58 s.  Kept as a switch, not as the default.
     static const double ring_near_env = [] { const char* e = std::getenv("PBN_RING_NEAR"); return (e && *e) ? std::atof(e) : 0.0; }();
-    const double far = prune_margin(t->dtype);
-    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < far;
+    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(t->dtype, 0) - 8.0;
     const int NB16 = ring ? bf16x3_mfmas(d0) : 0;
     const size_t frag16_b = (size_t)NB16 * 64 * 16;
     static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
@@ -565,6 +564,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
         s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
+        s.margin = (float)prune_margin(t->dtype, U.N); s.pad_ = 0.f;
         GSweepUnit& r = hs[nu + u];   // the RING pass: the bf16 fragments of the same rows, partials behind the fp64 pass's
         r = s;
         if (ring) {
@@ -626,14 +626,14 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         GSweepArgs sa{};
         sa.units = (const GSweepUnit*)(arena + o_sweep); sa.wg_unit = (const int32_t*)(arena + o_wgunit); sa.total_wg = total_wg;
         sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-        sa.prune_margin = ring ? ring_near_env : far;   // with a RING pass the fp64 kernel stops at the hand-over radius
+        sa.prune_margin = ring ? ring_near_env : 0.0;   // the units' own margins; with a RING pass the fp64 kernel stops at the hand-over radius
         static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
         sa.group_masks = ring ? 1 : gmasks;             // (the two passes split the pairs by the per-group test)
         launch_sweep_grouped(sa, t->dtype, KS, st);
         if (ring) {
             GSweepArgs ra = sa;
             ra.units = (const GSweepUnit*)(arena + o_sweep) + nu;
-            ra.ring = 1; ra.prune_margin = far; ra.ring_near = ring_near_env;
+            ra.ring = 1; ra.prune_margin = 0.0; ra.ring_near = ring_near_env;
             launch_sweep_grouped(ra, t->dtype, NB16, st);
         }
     }

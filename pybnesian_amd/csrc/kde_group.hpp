@@ -89,6 +89,7 @@ struct GSweepUnit {
     double* part;
     int64_t wg0;
     int32_t ntiles, nqtiles, tps, nsplit, nwg, pdims;
+    float margin, pad_;   // the unit's pruning margin (prune_margin(dtype, training rows))
 };
 struct GSweepArgs {
     const GSweepUnit* units;
@@ -96,7 +97,7 @@ struct GSweepArgs {
     int64_t total_wg;
     int fold, wmul, count_redo, group_masks;
     int ring;              // this launch is the RING (far-field, bf16) pass of an fp64 sweep
-    double prune_margin;
+    double prune_margin;   // > 0: one margin for every unit of the launch (the near pass of a RING sweep); 0: the units' own
     double ring_near;      // exponent distance below the sum bound at which the fp64 pass hands over to the RING pass
 };
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st);

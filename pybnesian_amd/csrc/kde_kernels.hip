@@ -26,6 +26,7 @@
 #include "kde_kernels.hpp"
 #include "kde_group.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 // terms below 2^-52 of their query's largest known term are dropped: at most N * 2^-52 of a sum (2.2e-10 at 10^6 rows), a
 // tenth of the error bound of the 2^x polynomial the kept terms go through.  (Round 1 and the first half of round 2 used
 // 2^-64: C3's first iteration 28.2 s instead of 26.4 s, a pruned d = 2 sweep at 10^6 x 10^5 rows 15.0 ms instead of 13.6;
-// 2^-44 would give 24.9 s / 12.5 ms at a worst case of 6e-8.)  PBN_PRUNE_MARGIN overrides at run time.
+// 2^-44 would give 24.9 s / 12.5 ms at a worst case of 6e-8.)  PBN_PRUNE_MARGIN overrides at run time.  Since round 3 the value is
+// the margin at 10^6 training rows and follows log2(n / 10^6) (prune_margin below): the BOUND is what is held constant.
 #ifndef PBN_PRUNE_MARGIN
 #define PBN_PRUNE_MARGIN 52.0
 #endif
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.Bpack = su.Bpack; a.nypack = su.nypack; a.Bxpack = nullptr; a.Bxnorm = nullptr;
     a.ntiles = su.ntiles; a.nqtiles = su.nqtiles; a.tiles_per_split = su.tps;
     a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul;
-    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
+    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks; a.ring_near = 0;
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL>(a, bid);
@@ -1553,7 +1555,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) vo
     a.Bpack = su.Bpack; a.nypack = su.nypack; a.Bxpack = nullptr; a.Bxnorm = nullptr;
     a.ntiles = su.ntiles; a.nqtiles = su.nqtiles; a.tiles_per_split = su.tps;
     a.fold = 0; a.count_redo = g.count_redo; a.wmul = 0;
-    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin;
+    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = 0; a.ring_near = g.ring_near;
     kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true, RING>(a, bid);
@@ -1887,10 +1889,20 @@ void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t 
     HIP_CHECK(hipGetLastError());
 }
 
-double prune_margin(int dtype) {
+// Exponent distance below the queries' sum bound beyond which a training tile is skipped.  PBN_PRUNE_MARGIN (fp64, 52) /
+// PBN_PRUNE_MARGIN_F32 (fp32, 40) are the values AT 10^6 TRAINING ROWS; for n rows the margin is that + log2(n / 10^6), so that the
+// bound of what pruning can drop - at most n terms of 2^-margin of the sum each - is the same fraction of the sum whatever the size
+// of the training set: 10^6 x 2^-52 = 2.2e-10 (fp32: 10^6 x 2^-40 = 9.1e-7).  With a constant margin the bound grew linearly with n
+// (and was needlessly tight for the 10^4-10^5-row folds and slices of the score engine: 90 000 rows -> 48.5, 450 000 -> 50.9;
+// 4 x 10^6 -> 54).  PBN_PRUNE_MARGIN_ADAPT=0 keeps the constant.
+double prune_margin(int dtype, int64_t n_train) {
     static const double m64 = [] { const char* e = getenv("PBN_PRUNE_MARGIN"); return (e && *e) ? atof(e) : (double)PBN_PRUNE_MARGIN; }();
     static const double m32 = [] { const char* e = getenv("PBN_PRUNE_MARGIN_F32"); return (e && *e) ? atof(e) : (double)PBN_PRUNE_MARGIN_F32; }();
-    return use_bf16x3(dtype) ? m32 : m64;
+    static const bool adapt = [] { const char* e = getenv("PBN_PRUNE_MARGIN_ADAPT"); return !(e && *e) || atoi(e) != 0; }();
+    const double base = use_bf16x3(dtype) ? m32 : m64;
+    if (!adapt || n_train <= 0) return base;
+    const double m = base + std::log2((double)n_train / 1e6);
+    return m < 8.0 ? 8.0 : m;
 }
 
 bool use_bf16x3(int dtype) {

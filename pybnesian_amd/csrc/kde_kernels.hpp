@@ -68,9 +68,9 @@ struct SweepArgs {
     // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first
     // `pdims` whitened dimensions, and qtile_thr holds, per query tile, a lower bound of its queries' largest exponents
     // (from a scan of the training rows next to them in Morton order).  A wave skips a training tile whose box is so far
-    // from the box of its queries that every exponent is below that bound - prune_margin (52 fp64 / 40 fp32): such terms are
-    // < 2^-margin of their sums each, i.e. at most N 2^-margin of a sum in total (2.2e-10 at 10^6 rows in fp64) - a bound that
-    // grows linearly with the number of training rows; PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override.
+    // from the box of its queries that every exponent is below that bound - prune_margin: such terms are < 2^-margin of their sums
+    // each, i.e. at most N 2^-margin of a sum in total; the margin is 52 (fp64) / 40 (fp32) at 10^6 training rows and follows
+    // log2(N / 10^6), so that bound is 2.2e-10 (9.1e-7) of a sum for every N (kde_kernels.hip: prune_margin).
     int prune;
     int pdims;
     double prune_margin;       // base-2 exponent distance below the queries' bound beyond which a tile is skipped (52 / 40)
@@ -129,7 +129,9 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
                           const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);
-double prune_margin(int dtype);   // 52 (fp64) / 40 (fp32 on the bf16 cores); PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override
+// 52 (fp64) / 40 (fp32 on the bf16 cores) at 10^6 training rows, + log2(n_train / 10^6): a constant bound (2.2e-10 / 9.1e-7 of a sum) on what
+// pruning drops; PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override the base, PBN_PRUNE_MARGIN_ADAPT=0 the scaling
+double prune_margin(int dtype, int64_t n_train);
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 
