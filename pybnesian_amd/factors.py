@@ -222,12 +222,14 @@ class CKDE(Factor):
                 joint = ([state["variable"]] + list(state["evidence"]), True, state["selector"], state["bandwidth"], state["training"], -1.0,
                          state["N"], 12 if state["dtype"] == _lib.PBN_F64 else 11)
             extra = (state["marg_bandwidth"],) if "marg_bandwidth" in state else ()
+            legacy_selector = state.get("selector")   # an UNFITTED legacy state has no joint tuple to carry its selector
             state = (state["variable"], state["evidence"], state["fitted"], joint) + extra
-            selector = None if not joint else joint[2]
+        else:
+            legacy_selector = None
         if len(state) not in (4, 5):
             raise RuntimeError("Not valid CKDE.")                   # CKDE.cpp:177
         variable, evidence, fitted, joint = state[:4]
-        self.__init__(variable, evidence, joint[2] if fitted else None)
+        self.__init__(variable, evidence, joint[2] if fitted else legacy_selector)
         if fitted:
             if len(joint) != 8:
                 raise RuntimeError("Not valid KDE.")
