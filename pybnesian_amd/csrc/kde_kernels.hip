@@ -1211,6 +1211,9 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 // (Measured again in round 3 and dropped again: the tile sums of 8 / 16 consecutive tiles added in fp32 before they join the fp64 sums -
 //  one v_add_f32 instead of v_cvt_f64_f32 + v_add_f64 per (tile, group).  The allocator answers with +35 VGPRs (138 -> 173: two
 //  waves per SIMD instead of three): fp32 headline 14.5 -> 17.7 ms, 16.2 ms when held to three waves; tools/f32_variants.sh.)
+#ifndef PBN_BF16_PAIRSUM
+#define PBN_BF16_PAIRSUM 1
+#endif
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
@@ -1354,7 +1357,13 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     // fused CKDE sweep and the pruned sweeps keep the group-by-group form: with two accumulator sets per group in flight,
     // or one wave per SIMD less, the other form loses (C5's sweeps 33 -> 40 s; pruned d = 1 plain sweep 8.3 -> 10.2 ms).
     unsigned long long gm[RING ? QG : 1];
-    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x, const int bit = 0) {
+    // plain unpruned sweeps (PBN_BF16_PAIRSUM): the sums of the two tiles of a loop iteration are added in fp32 and join the fp64 sums
+    // together - one v_cvt_f64_f32 + v_add_f64 per group and TWO tiles
+    constexpr bool PAIRSUM = !COND && !PRUNE && PBN_BF16_PAIRSUM;
+    float pend[PAIRSUM ? QG : 1];
+#pragma unroll
+    for (int g = 0; g < (PAIRSUM ? QG : 1); ++g) pend[g] = 0.f;
+    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x, const int bit = 0, const bool flush = true) {
         if constexpr (COND || PRUNE) {
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
@@ -1429,6 +1438,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                         m[g] += mx;
                         const float cm = ny[g] - m[g];
                         cmv[g] = V{cm, cm, cm, cm};
+                        if constexpr (PAIRSUM) { sum[g] += (double)pend[g]; pend[g] = 0.f; }
                         sum[g] *= exp2(-(double)mx);
                         acc[g] -= mx;
                     }
@@ -1449,7 +1459,11 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
             }
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
-                sum[g] += (double)ts[g];
+                if constexpr (PAIRSUM) {
+                    if (flush) { sum[g] += (double)(pend[g] + ts[g]); pend[g] = 0.f; } else pend[g] = ts[g];
+                } else {
+                    sum[g] += (double)ts[g];
+                }
                 if (COND) sumj[g] += (double)tsj[g];
             }
         }
@@ -1502,9 +1516,9 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         for (int64_t t = t0; t < t1; t += 2) {
             const bool second = t + 1 < t1;
             load_tile(second ? t + 1 : t, fB, xB);
-            process_tile(fA, xA);
+            process_tile(fA, xA, 0, !second);          // PAIRSUM: the first tile's sums wait for the second one's
             load_tile(t + 2 < t1 ? t + 2 : t, fA, xA);
-            if (second) process_tile(fB, xB);
+            if (second) process_tile(fB, xB, 0, true);
         }
     }
 
