@@ -165,7 +165,7 @@ class CKDE(Factor):
         dtype = same_type(rb, self._variables)
         ctx = default_context()
         table, _ = DeviceTable.from_dataframe(ctx, rb, self._variables)
-        self._fit_table(table, list(range(len(self._variables))), rb)
+        self._fit_table(table, table.index(self._variables), rb)
 
     def fit_table(self, table):
         self._fit_table(table, table.index(self._variables), None)
@@ -264,7 +264,7 @@ class CKDE(Factor):
         m = table.num_rows
         vals = np.empty(m, dtype=np.float64)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_kde_logl(self._handle, table.handle, _lib.int_array(range(d)), 0, m, _lib.dptr(vals)))
+        _lib.check(_lib.load().pbn_kde_logl(self._handle, table.handle, _lib.int_array(table.index(self._variables)), 0, m, _lib.dptr(vals)))
         if mask is None:
             return vals
         out = np.full(rb.num_rows, np.nan)
@@ -277,7 +277,7 @@ class CKDE(Factor):
         m = table.num_rows
         vals = np.empty(m, dtype=np.float64)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_ckde_cdf(self._handle, table.handle, _lib.int_array(range(d)), 0, m, _lib.dptr(vals)))
+        _lib.check(_lib.load().pbn_ckde_cdf(self._handle, table.handle, _lib.int_array(table.index(self._variables)), 0, m, _lib.dptr(vals)))
         if mask is None:
             return vals
         out = np.full(rb.num_rows, np.nan)
@@ -301,7 +301,7 @@ class CKDE(Factor):
             table, mask = DeviceTable.from_dataframe(self._train.ctx, rb, self._evidence)
             if mask is not None:
                 raise ValueError("Evidence values contain null rows in the evidence variables.")
-            cols = _lib.int_array(range(len(self._evidence)))
+            cols = _lib.int_array(table.index(self._evidence))
         _lib.check(_lib.load().pbn_ckde_sample(self._handle, n, int(_stream_n), table.handle if table is not None else None, cols,
                                                C.c_uint32(seed), out.ctypes.data_as(C.c_void_p)))
         return pa.array(out)
@@ -312,7 +312,7 @@ class CKDE(Factor):
         _, table, _ = self._upload_test(df)
         res = C.c_double(0.0)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(range(d)), 0, table.num_rows, C.byref(res)))
+        _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(table.index(self._variables)), 0, table.num_rows, C.byref(res)))
         return res.value
 
     def slogl_table(self, table, row0=0, n=None):
@@ -392,7 +392,7 @@ class LinearGaussianCPD(Factor):
         vals = np.empty(m) if want_logl else None
         s = C.c_double(0.0)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_lg_logl(table.handle, _lib.int_array(range(d)), d, 0, m, _lib.dptr(np.ascontiguousarray(self.beta)),
+        _lib.check(_lib.load().pbn_lg_logl(table.handle, _lib.int_array(table.index(self._variables)), d, 0, m, _lib.dptr(np.ascontiguousarray(self.beta)),
                                            float(self.variance), _lib.dptr(vals) if want_logl else None, C.byref(s)))
         return rb, mask, vals, s.value
 
@@ -419,7 +419,7 @@ class LinearGaussianCPD(Factor):
         m = table.num_rows
         vals = np.empty(m)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_lg_cdf(table.handle, _lib.int_array(range(d)), d, 0, m, _lib.dptr(np.ascontiguousarray(self.beta)),
+        _lib.check(_lib.load().pbn_lg_cdf(table.handle, _lib.int_array(table.index(self._variables)), d, 0, m, _lib.dptr(np.ascontiguousarray(self.beta)),
                                           float(self.variance), _lib.dptr(vals)))
         if mask is None:
             return vals

@@ -107,7 +107,7 @@ class UCV(BandwidthSelector):
         d = len(variables)
         out = np.zeros((d, d), order="F") if kind == _lib.PBN_BW_FULL else np.zeros(d)
         ev = C.c_int64(0)
-        _lib.check(_lib.load().pbn_ucv_bandwidth(ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, n, kind,
+        _lib.check(_lib.load().pbn_ucv_bandwidth(ctx.handle, table.handle, _lib.int_array(table.index(variables)), d, 0, n, kind,
                                                  _lib.dptr(np.asfortranarray(start)), _lib.dptr(out), C.byref(ev)))
         self.last_evaluations = ev.value
         return out
@@ -132,7 +132,7 @@ class UCV(BandwidthSelector):
         if bw.shape != ((d, d) if bw.ndim == 2 else (d,)):
             raise ValueError(f"Wrong dimension for bandwidth. it should be a {d}x{d} matrix or a {d} vector.")
         out = C.c_double(0.0)
-        _lib.check(_lib.load().pbn_ucv_score(ctx.handle, table.handle, _lib.int_array(range(d)), d, 0, table.num_rows,
+        _lib.check(_lib.load().pbn_ucv_score(ctx.handle, table.handle, _lib.int_array(table.index(variables)), d, 0, table.num_rows,
                                              _lib.dptr(np.asfortranarray(bw)), kind, C.byref(out)))
         return out.value
 
@@ -226,7 +226,7 @@ class _KDEBase:
         n = table.num_rows
         self._bandwidth = self._select_bandwidth(rb, table, n, dtype)
         self._train, self._dtype, self._N = table, dtype, n
-        self._train_idx = list(range(len(self._variables)))
+        self._train_idx = table.index(self._variables)
         self._device_fit()
         self._fitted = True
 
@@ -269,7 +269,7 @@ class _KDEBase:
         m = table.num_rows
         vals = np.empty(m, dtype=np.float64)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_kde_logl(self._handle, table.handle, _lib.int_array(range(d)), 0, m, _lib.dptr(vals)))
+        _lib.check(_lib.load().pbn_kde_logl(self._handle, table.handle, _lib.int_array(table.index(self._variables)), 0, m, _lib.dptr(vals)))
         if mask is None:
             return vals
         out = np.full(rb.num_rows, np.nan)
@@ -280,7 +280,7 @@ class _KDEBase:
         _, table, _ = self._upload_test(df)
         res = C.c_double(0.0)
         d = len(self._variables)
-        _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(range(d)), 0, table.num_rows, C.byref(res)))
+        _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(table.index(self._variables)), 0, table.num_rows, C.byref(res)))
         return res.value
 
     # device-resident entry used by bench.py / scores: no host round trip of the test rows

@@ -858,11 +858,14 @@ class BayesianNetwork(BayesianNetworkBase):
             self._cpds = {}
         if self.has_unknown_node_types():
             self.set_unknown_node_types(df)
-        for n in self._nodes:
-            if not self._cpd_valid(n):
-                self._cpds[n] = self._new_factor(df, n)
-            if not self._cpds[n].fitted():
-                self._cpds[n].fit(df)
+        from .dataset import default_context, shared_upload
+
+        with shared_upload(default_context(), df):   # one PCIe pass over the table for all factors
+            for n in self._nodes:
+                if not self._cpd_valid(n):
+                    self._cpds[n] = self._new_factor(df, n)
+                if not self._cpds[n].fitted():
+                    self._cpds[n].fit(df)
 
     def fitted(self):
         cp = getattr(self, "_cpds", None)
@@ -881,22 +884,24 @@ class BayesianNetwork(BayesianNetworkBase):
             raise ValueError("Model not fitted.")  # BayesianNetwork.hpp check_fitted
         import numpy as np
 
-        from .dataset import as_record_batch
+        from .dataset import as_record_batch, default_context, shared_upload
 
         df = as_record_batch(df)
         out = None
-        for n in self._nodes:
-            ll = np.asarray(self._cpds[n].logl(df), dtype=np.float64)
-            out = ll if out is None else out + ll
+        with shared_upload(default_context(), df):
+            for n in self._nodes:
+                ll = np.asarray(self._cpds[n].logl(df), dtype=np.float64)
+                out = ll if out is None else out + ll
         return out if out is not None else np.zeros(0)
 
     def slogl(self, df):
         if not self.fitted():
             raise ValueError("Model not fitted.")
-        from .dataset import as_record_batch
+        from .dataset import as_record_batch, default_context, shared_upload
 
         df = as_record_batch(df)
-        return float(sum(self._cpds[n].slogl(df) for n in self._nodes))
+        with shared_upload(default_context(), df):
+            return float(sum(self._cpds[n].slogl(df) for n in self._nodes))
 
     # -- graph queries of models/BayesianNetwork.hpp / graph/generic_graph.hpp the callers of the hot path use -------
     def num_children(self, node):

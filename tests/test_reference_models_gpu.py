@@ -172,3 +172,50 @@ def test_network_sample_order_is_pinned(pbn, df):
         ev = pa.RecordBatch.from_arrays([pa.array(cols[p]) for p in net.parents(v)], names=list(net.parents(v))) if net.parents(v) else None
         cols[v] = np.asarray(net.cpd(v).sample(257, ev, 11 + i))
         assert np.array_equal(s.column(i).to_numpy(), cols[v]), v
+
+
+@pytest.mark.parametrize("kind", ["gbn", "spbn", "kdebn"])
+def test_shared_upload_gives_the_per_factor_values(pbn, df, golden, kind):
+    """The one-upload scope of BayesianNetwork.fit / logl / slogl (dataset.shared_upload) addresses columns of the whole table by index:
+    parameters, per-row values and sums are bit-identical to factors fitted / evaluated one by one on their own uploads; columns with
+    nulls fall back to the per-factor path."""
+    import pyarrow as pa
+
+    from pybnesian_amd.dataset import DeviceTable, as_record_batch, default_context, shared_upload
+
+    nodes = ["d", "b", "a", "c"]   # node order differs from column order
+    arcs = [("a", "b"), ("a", "c"), ("b", "d"), ("c", "d")]
+    types = {"gbn": [], "spbn": [("d", pbn.CKDEType()), ("c", pbn.CKDEType())], "kdebn": []}[kind]
+    make = {"gbn": lambda: pbn.GaussianNetwork(nodes, arcs), "spbn": lambda: pbn.SemiparametricBN(nodes, arcs, types),
+            "kdebn": lambda: pbn.KDENetwork(nodes, arcs)}[kind]
+    rb = as_record_batch(df)
+    test = as_record_batch(frame(golden["train500"]))
+    net = make()
+    net.fit(rb)
+    lone = {}
+    for n in nodes:                    # the same factors, each on its own upload
+        f = type(net.cpd(n))(n, net.parents(n))
+        f.fit(rb)
+        lone[n] = f
+    with shared_upload(default_context(), rb) as table:
+        assert table is not None and DeviceTable.from_dataframe(default_context(), rb, ["c", "a"])[0] is table
+    assert DeviceTable.from_dataframe(default_context(), rb, ["c", "a"])[0].names == ["c", "a"]   # outside the scope: its own table
+    total = np.zeros(test.num_rows)
+    for n in nodes:
+        f = net.cpd(n)
+        if hasattr(f, "beta"):
+            assert np.array_equal(f.beta, lone[n].beta) and f.variance == lone[n].variance
+        total += lone[n].logl(test)
+    assert np.array_equal(net.logl(test), total)
+    assert net.slogl(test) == pytest.approx(sum(lone[n].slogl(test) for n in nodes), rel=1e-14)
+    # nulls in one column: that column leaves the shared table, everything still agrees with the per-factor path
+    a = test.column(test.schema.get_field_index("a")).to_numpy().copy()
+    mask = np.zeros(a.size, bool)
+    mask[::7] = True
+    holes = pa.RecordBatch.from_arrays([pa.array(a, mask=mask) if f.name == "a" else test.column(i) for i, f in enumerate(test.schema)],
+                                       names=test.schema.names)
+    total = np.zeros(holes.num_rows)
+    for n in nodes:
+        total += lone[n].logl(holes)
+    got = net.logl(holes)
+    assert np.array_equal(np.isnan(got), np.isnan(total)) and np.array_equal(got[~np.isnan(total)], total[~np.isnan(total)])
