@@ -48,8 +48,11 @@ int pbn_ctx_create(int device, pbn_ctx** out) {
     });
 }
 
-void pbn_ctx_destroy(pbn_ctx* ctx) {
-    if (!ctx) return;
+}  // extern "C"
+
+// the last reference is gone: nobody can be inside the context any more
+void pbn::ctx_release(pbn_ctx* ctx) {
+    if (ctx->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
     PBN_API_LOCK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -61,6 +64,14 @@ void pbn_ctx_destroy(pbn_ctx* ctx) {
     for (auto& ln : ctx->parked)
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); (void)hipEventDestroy(ln.fence); }
     delete ctx;
+}
+
+extern "C" {
+
+// Drops the creator's reference: the context goes now if no handle created on it is alive, with the last of them otherwise
+// (common.hpp, "Lifetime").
+void pbn_ctx_destroy(pbn_ctx* ctx) {
+    if (ctx) pbn::ctx_release(ctx);
 }
 
 int pbn_ctx_sync(pbn_ctx* ctx) {
@@ -166,6 +177,7 @@ int pbn_table_from_device(pbn_ctx* ctx, void* dev_base, int64_t ld, int n_cols, 
 
 void pbn_table_destroy(pbn_table* t) {
     if (!t) return;
+    pbn::ctx_pin pin_(t->ctx);
     std::lock_guard<std::recursive_mutex> lock_(mu_of(t));
     if (t->owns && t->data) {
         (void)hipSetDevice(t->ctx->device);
@@ -376,6 +388,7 @@ int pbn_ckde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, i
 
 void pbn_kde_destroy(pbn_kde* k) {
     if (!k) return;
+    pbn::ctx_pin pin_(k->ctx);
     std::lock_guard<std::recursive_mutex> lock_(mu_of(k));
     (void)hipSetDevice(k->ctx->device);
     (void)hipStreamSynchronize(k->ctx->stream);

@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -131,6 +132,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 struct pbn_ctx {
     std::recursive_mutex mu;   // every entry point working on this context holds it (pbn::mu_of)
+    std::atomic<int> refs{1};  // the creator's reference + one per live handle (pbn::ctx_ptr): see pbn_ctx_destroy
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
@@ -200,6 +202,40 @@ struct pbn_ctx {
 };
 
 namespace pbn {
+// Lifetime.  Every handle created on a context (tables, KDE models, score data, MI / kMI engines) holds a counted reference on it:
+// pbn_ctx_destroy only drops the creator's reference, and the streams, arenas and the mutex go with the LAST one.  A garbage
+// collector finalises the objects of a reference cycle in no particular order (CPython, PEP 442): a handle's destroy call that
+// arrives after its context's must still find the mutex it locks - before this count such a call locked freed memory, and a test
+// run hung in DeviceTable.__del__ once in a few hundred runs.
+void ctx_release(pbn_ctx* c);   // capi.hip
+inline void ctx_retain(pbn_ctx* c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
+struct ctx_ptr {   // a handle's `ctx` member: reads like the plain pointer, owns one reference
+    pbn_ctx* p = nullptr;
+    ctx_ptr() = default;
+    ctx_ptr(const ctx_ptr&) = delete;
+    ctx_ptr& operator=(const ctx_ptr&) = delete;
+    ctx_ptr& operator=(pbn_ctx* c) {
+        if (c) ctx_retain(c);
+        if (p) ctx_release(p);
+        p = c;
+        return *this;
+    }
+    ~ctx_ptr() { if (p) ctx_release(p); }
+    operator pbn_ctx*() const { return p; }
+    pbn_ctx* operator->() const { return p; }
+};
+// A destroy entry point pins the context BEFORE it takes the context's lock: the handle's own reference goes with `delete h` inside
+// the locked region, and the mutex must outlive the unlock.
+struct ctx_pin {
+    pbn_ctx* c;
+    explicit ctx_pin(pbn_ctx* c_) : c(c_) { if (c) ctx_retain(c); }
+    ~ctx_pin() { if (c) ctx_release(c); }
+    ctx_pin(const ctx_pin&) = delete;
+    ctx_pin& operator=(const ctx_pin&) = delete;
+};
+}  // namespace pbn
+
+namespace pbn {
 // the lock an entry point takes: the context's own, through any handle that carries a `ctx` member; a null handle falls back to
 // the process-wide mutex (the call then fails on its own null check)
 inline std::recursive_mutex& mu_of(const pbn_ctx* c) { return c ? const_cast<pbn_ctx*>(c)->mu : api_mutex(); }
@@ -248,7 +284,7 @@ struct KernelTimer {
 
 // Column-major device table: column c lives at base + c*ld elements.
 struct pbn_table {
-    pbn_ctx* ctx = nullptr;
+    pbn::ctx_ptr ctx;
     int dtype = PBN_F64;
     int n_cols = 0;
     int64_t n_rows = 0;

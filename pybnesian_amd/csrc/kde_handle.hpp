@@ -10,7 +10,7 @@ using pbn::PackArgs;
 using pbn::dev_buf;
 
 struct pbn_kde {
-    pbn_ctx* ctx = nullptr;
+    pbn::ctx_ptr ctx;
     KdeModel m;
     dev_buf<char> Apack, nxpack, Axpack;
     dev_buf<char> prune_store;          // tile boxes | Morton-ordered whitened rows | keys (when m.prune)

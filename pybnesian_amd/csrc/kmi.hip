@@ -27,7 +27,7 @@ using namespace pbn;
 #define KMI_TILE 256
 
 struct pbn_kmi {
-    pbn_ctx* ctx = nullptr;
+    pbn::ctx_ptr ctx;
     int64_t N = 0;
     int n_vars = 0, k = 0, shuffle_neighbors = 5, samples = 1000;
     uint32_t seed = 0;
@@ -417,6 +417,7 @@ int pbn_kmi_create(pbn_ctx* ctx, const double* const* cols, int n_vars, int64_t 
 
 void pbn_kmi_destroy(pbn_kmi* h) {
     if (!h) return;
+    pbn::ctx_pin pin_(h->ctx);
     std::lock_guard<std::recursive_mutex> lock_(mu_of(h));
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);

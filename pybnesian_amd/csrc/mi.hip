@@ -55,7 +55,7 @@ struct DiscGroup {
 };
 
 struct pbn_mi {
-    pbn_ctx* ctx = nullptr;
+    pbn::ctx_ptr ctx;
     const pbn_table* table = nullptr;  // continuous columns (borrowed), null when there are none
     int n_cont = 0, n_disc = 0;
     int64_t N = 0;
@@ -75,6 +75,8 @@ struct pbn_mi {
     dev_buf<int32_t> first;      // [G] first sorted position of every configuration
     dev_buf<char> sort_tmp;
     dev_buf<double> shift_dev;   // the pilot means on the device, indexed by table column (Engine::ensure_full)
+    dev_buf<char> rowmajor;      // row-major mirror of the continuous columns for the gathered Gram of the groupings (Engine::ensure_full)
+    bool rowmajor_tried = false;
     int64_t full_grams = 0;      // groupings whose full per-configuration moments were taken
     size_t full_bytes_held = 0;  // host bytes of the cached full moments
     // PBN_MI_TIMING=1: wall seconds per phase, printed when the handle is destroyed
@@ -541,7 +543,8 @@ struct Engine {
         for (int c = 0; c < g->G; ++c) {
             g->blk_off[c] = (int)(blk.size() / 4);
             for (int64_t r = g->off[c]; r < g->off[c + 1]; r += MI_SORTED_ROWS) {
-                blk.push_back(c); blk.push_back((int32_t)r); blk.push_back((int32_t)std::min<int64_t>(r + MI_SORTED_ROWS, g->off[c + 1])); blk.push_back(0);
+                const int32_t slot = (int32_t)(blk.size() / 4);
+                blk.push_back(c); blk.push_back((int32_t)r); blk.push_back((int32_t)std::min<int64_t>(r + MI_SORTED_ROWS, g->off[c + 1])); blk.push_back(slot);
             }
         }
         g->nblk = (int)(blk.size() / 4);
@@ -593,9 +596,80 @@ struct Engine {
         a.base = h->table->data; a.ld = h->table->ld; a.n_cols = nc;
         for (int i = 0; i < nc; ++i) a.gc.cols[i] = i;
         a.row0 = 0; a.rows = g.vars.empty() ? nullptr : g.perm.p; a.n = h->N;
+        // The first grouping with a row list builds a row-major mirror of the continuous columns (N x 16 ceil(nc / 16) elements, kept
+        // with the handle): every grouping's rows are then read as whole contiguous rows - the same bytes for 4 configurations as for
+        // 4096 - instead of one 64-byte sector per element of a sparse list.  MMPC builds hundreds of groupings per handle (config 5:
+        // 347); the mirror costs one read and one write of the table, less than one gathered pass.  PBN_MI_MIRROR_MB (default 16384):
+        // larger mirrors are not built and the rows are gathered from the columns.
+        if (a.rows && !h->rowmajor_tried) {
+            h->rowmajor_tried = true;
+            static const size_t budget = [] { const char* e = getenv("PBN_MI_MIRROR_MB"); return (size_t)((e && *e) ? atoll(e) : 16384) << 20; }();
+            const size_t bytes = rowmajor_mirror_elems(h->table->n_rows, nc) * dtype_size(h->table->dtype);
+            if (bytes <= budget) {
+                h->rowmajor.alloc(bytes);
+                build_rowmajor_mirror(h->table->data, h->table->ld, a.gc, nc, h->table->n_rows, h->table->dtype, h->rowmajor.p, ctx->stream);
+            }
+        }
+        a.rowmajor = (a.rows && h->rowmajor.n) ? h->rowmajor.p : nullptr;
         a.rows_per_block = MI_SORTED_ROWS; a.blk = g.blk.p;
         a.shift = h->shift_dev.p; a.partial = partial; a.num_cus = ctx->num_cus;
-        launch_gram_segments(a, h->table->dtype, g.nblk, g.blk.p + 4 * (size_t)g.nblk, g.G, out, ctx->stream);
+        // Launch order of the pieces.  A grouping's row list is increasing inside every configuration, so piece p of P_c pieces of
+        // configuration c reads the table stripe around (p + 1/2) / P_c - the same 128-byte lines as the matching pieces of the
+        // other configurations, each of which uses only its own rows of them.  Configuration-major (the order of the partial
+        // slots) runs those pieces a whole configuration apart and every line comes from HBM once per configuration; stripe-major
+        // runs them together, so that the line is fetched once and served on-die to the others.  PBN_MI_GRAM_ORDER: 0 =
+        // configuration-major, 1 = stripe-major, 2 (default) = stripe-major with the pieces of stripe s on launch indices = s mod 8
+        // (one XCD and its L2 under the usual round-robin; padding blocks without a piece keep the residues when few are needed).
+        // The partial slots, and with them the order of every sum, do not change.
+        static const int order = [] { const char* e = getenv("PBN_MI_GRAM_ORDER"); return (e && *e) ? atoi(e) : 2; }();
+        dev_buf<int32_t> ordered;
+        int nlaunch = g.nblk;
+        if (order != 0 && g.G > 1) {
+            int T = 1;
+            for (int cg = 0; cg < g.G; ++cg) T = std::max(T, g.blk_off[cg + 1] - g.blk_off[cg]);
+            std::vector<std::vector<int32_t>> cell((size_t)T);   // stripe -> slots of its pieces, configuration order
+            for (int cg = 0; cg < g.G; ++cg) {
+                const int P = g.blk_off[cg + 1] - g.blk_off[cg];
+                for (int pc = 0; pc < P; ++pc) cell[(size_t)(((2 * (int64_t)pc + 1) * T) / (2 * (int64_t)P))].push_back(g.blk_off[cg] + pc);
+            }
+            auto piece = [&](std::vector<int32_t>& t, int32_t slot) {
+                const int cg = (int)(std::upper_bound(g.blk_off.begin(), g.blk_off.end(), slot) - g.blk_off.begin()) - 1;
+                const int64_t r = g.off[cg] + (int64_t)(slot - g.blk_off[cg]) * MI_SORTED_ROWS;
+                t.push_back(cg); t.push_back((int32_t)r); t.push_back((int32_t)std::min<int64_t>(r + MI_SORTED_ROWS, g.off[cg + 1])); t.push_back(slot);
+            };
+            std::vector<int32_t> t;
+            t.reserve(4 * (size_t)g.nblk);
+            bool aligned = order >= 2;
+            if (aligned) {   // groups of 8 stripes, round k of a group = the k-th piece of each of its stripes (padding where one has fewer)
+                size_t cells = 0;
+                for (int s0 = 0; s0 < T; s0 += 8) {
+                    size_t deep = 0;
+                    for (int s8 = 0; s8 < 8 && s0 + s8 < T; ++s8) deep = std::max(deep, cell[(size_t)(s0 + s8)].size());
+                    cells += 8 * deep;
+                }
+                aligned = cells <= 2 * (size_t)g.nblk + 64;   // very uneven configurations: the padding would outnumber the pieces
+            }
+            if (aligned) {
+                for (int s0 = 0; s0 < T; s0 += 8) {
+                    size_t deep = 0;
+                    for (int s8 = 0; s8 < 8 && s0 + s8 < T; ++s8) deep = std::max(deep, cell[(size_t)(s0 + s8)].size());
+                    for (size_t k = 0; k < deep; ++k)
+                        for (int s8 = 0; s8 < 8; ++s8) {
+                            if (s0 + s8 < T && k < cell[(size_t)(s0 + s8)].size()) piece(t, cell[(size_t)(s0 + s8)][k]);
+                            else { t.push_back(0); t.push_back(0); t.push_back(0); t.push_back(0); }
+                        }
+                }
+            } else {
+                for (int st = 0; st < T; ++st)
+                    for (int32_t slot : cell[(size_t)st]) piece(t, slot);
+            }
+            nlaunch = (int)(t.size() / 4);
+            ordered.alloc(t.size());
+            HIP_CHECK(hipMemcpyAsync(ordered.p, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));   // t is a local
+            a.blk = ordered.p;
+        }
+        launch_gram_segments(a, h->table->dtype, nlaunch, g.blk.p + 4 * (size_t)g.nblk, g.G, out, ctx->stream);
         std::vector<double> hs((size_t)g.G * WS);
         HIP_CHECK(hipMemcpyAsync(hs.data(), out, hs.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1014,6 +1088,7 @@ int pbn_mi_set_continuous_nulls(pbn_mi* h, const unsigned char* flags, const dou
 
 void pbn_mi_destroy(pbn_mi* h) {
     if (!h) return;
+    pbn::ctx_pin pin_(h->ctx);
     std::lock_guard<std::recursive_mutex> lock_(mu_of(h));
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);

@@ -80,10 +80,21 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
 // Moments of all n columns over each of the row ranges [r0[i], r1[i]), i in [s0, s1): ONE segmented Gram launch per block (pair)
 // of <= 64 columns.  A range is cut into pieces of SEG_ROWS rows (one workgroup each) that are added in order: the result for a
 // range depends on its rows only - not on the other ranges of the launch, not on who else computes what.
-constexpr int64_t SEG_ROWS = 2048;
+// PBN_MOMENT_SEG_ROWS (default 4096, a multiple of 128; 2M x 64 doubles: 231 / 212 / 196 / 203 us at 1024 / 2048 / 4096 / 8192 - pieces on
+// 512 resident workgroup slots): the piece size is part of the summation order - like PBN_MOMENT_SUPERBLOCKS it must
+// be the same on every rank of a job, and another value gives other last bits.
+static int64_t seg_rows() {
+    static const int64_t v = [] {
+        const char* e = getenv("PBN_MOMENT_SEG_ROWS");
+        const int64_t r = (e && *e) ? atoll(e) : 4096;
+        return std::max<int64_t>(128, r / 128 * 128);
+    }();
+    return v;
+}
 void compute_stats_segments(const pbn_scoredata* sd, const std::vector<int64_t>& r0, const std::vector<int64_t>& r1, size_t s0, size_t s1,
                             std::vector<Stats>& out) {
     const int n = sd->n;
+    const int64_t SEG_ROWS = seg_rows();
     for (size_t i = s0; i < s1; ++i) { out[i].zero(n); out[i].N = r1[i] - r0[i]; }
     if (s1 <= s0) return;
     const pbn_table* t = sd->table();
@@ -92,7 +103,8 @@ void compute_stats_segments(const pbn_scoredata* sd, const std::vector<int64_t>&
     std::vector<int32_t> blk, off(nseg + 1, 0);
     for (int g = 0; g < nseg; ++g) {
         for (int64_t r = r0[s0 + g]; r < r1[s0 + g]; r += SEG_ROWS) {
-            blk.push_back(g); blk.push_back((int32_t)r); blk.push_back((int32_t)std::min(r + SEG_ROWS, r1[s0 + g])); blk.push_back(0);
+            const int32_t slot = (int32_t)(blk.size() / 4);   // the piece's partial: pieces of a segment are consecutive slots
+            blk.push_back(g); blk.push_back((int32_t)r); blk.push_back((int32_t)std::min(r + SEG_ROWS, r1[s0 + g])); blk.push_back(slot);
         }
         off[g + 1] = (int32_t)(blk.size() / 4);
     }
@@ -550,6 +562,7 @@ int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set)
 
 void pbn_scoredata_destroy(pbn_scoredata* sd) {
     if (!sd) return;
+    pbn::ctx_pin pin_(sd->ctx);
     std::lock_guard<std::recursive_mutex> lock_(mu_of(sd));
     if (sd->perm_table) pbn_table_destroy(sd->perm_table);
     delete sd;

@@ -42,7 +42,7 @@ struct HybridGrouping {
 };
 
 struct pbn_scoredata {
-    pbn_ctx* ctx = nullptr;
+    pbn::ctx_ptr ctx;
     int dtype = PBN_F64;
     int n = 0;  // continuous columns
     int split = PBN_SPLIT_NONE;

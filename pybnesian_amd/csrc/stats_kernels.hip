@@ -240,7 +240,10 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
     int64_t rb0 = (int64_t)blockIdx.x * a.rows_per_block;
     int64_t rb1 = rb0 + a.rows_per_block;
     if (rb1 > a.n) rb1 = a.n;
-    if (a.blk) { rb0 = a.blk[4 * blockIdx.x + 1]; rb1 = a.blk[4 * blockIdx.x + 2]; }   // a piece of one segment (launch_gram_segments)
+    if (a.blk) {   // a piece of one segment (launch_gram_segments)
+        rb0 = a.blk[4 * blockIdx.x + 1]; rb1 = a.blk[4 * blockIdx.x + 2];
+        if (rb1 <= rb0) return;   // a padding entry of an aligned launch order: no piece, no partial
+    }
 
     // loader role: thread t -> column t >> 2 (of the first NC columns), rows (t & 3) * 8 .. + 7 of the chunk
     const int lcol = tid >> 2, lrg = tid & 3;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void gram_lds_kernel(GramArgs a) {
         }
         __syncthreads();
     }
-    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    double* out = a.partial + (int64_t)(a.blk ? a.blk[4 * blockIdx.x + 3] : blockIdx.x) * WS;
     for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
     // column sums: the 4 loader threads of a column are adjacent lanes
     double s = csum;
@@ -423,9 +426,21 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_kernel(GramAr
     const int slot = wave_slot();
     const long long t_start = a.stamps ? wall_clock64() : 0;
 
-    const int64_t nchunks = (a.n + GD_ROWS - 1) / GD_ROWS, B = gridDim.x, b = blockIdx.x;
-    const int64_t mine = b < nchunks ? (nchunks - 1 - b) / B + 1 : 0;
-    const bool partial_last = mine > 0 && ((mine - 1) * B + b + 1) * GD_ROWS > a.n;   // the range's last chunk, cut short
+    // chunk i of the block: rows first + i stride .. + GD_ROWS - 1 of the range, cut at `end`.  Plain form: the block's chunks are
+    // interleaved with the other blocks' (see above); segmented form (a.blk, launch_gram_segments): the block owns the contiguous
+    // piece [blk[4b + 1], blk[4b + 2]) and writes its partial to slot blk[4b + 3]
+    const int64_t b = blockIdx.x;
+    int64_t first, stride, end, mine, out_slot = b;
+    if (a.blk) {
+        first = a.blk[4 * b + 1]; end = a.blk[4 * b + 2]; stride = GD_ROWS; out_slot = a.blk[4 * b + 3];
+        if (end <= first) return;   // a padding entry of an aligned launch order: no piece, no partial
+        mine = (end - first + GD_ROWS - 1) / GD_ROWS;
+    } else {
+        const int64_t nchunks = (a.n + GD_ROWS - 1) / GD_ROWS, B = gridDim.x;
+        first = b * GD_ROWS; end = a.n; stride = B * GD_ROWS;
+        mine = b < nchunks ? (nchunks - 1 - b) / B + 1 : 0;
+    }
+    const bool partial_last = mine > 0 && first + (mine - 1) * stride + GD_ROWS > end;   // the range's last chunk, cut short
     const int64_t nfull = mine - (partial_last ? 1 : 0);   // whole chunks (LDS-DMA); the cut one goes through registers
 
     // operand role: lane (c, kq) holds column 16 I + c; shift, column sums
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_kernel(GramAr
         const int cc = 8 * q + (lane >> 3);
         const int col = cc < a.n_cols ? a.gc.cols[cc] : a.gc.cols[0];
         const int m = (lane & 7) ^ ((cc & 15) >> 1);
-        dsrc[q] = (const double*)a.base + (int64_t)col * a.ld + a.row0 + b * GD_ROWS + 16 * wave + 2 * m;
+        dsrc[q] = (const double*)a.base + (int64_t)col * a.ld + a.row0 + first + 16 * wave + 2 * m;
     }
     // doubles from a stage's start to this lane's row pairs kq (rows 2kq, +1) and kq + 4 (rows 8 + 2kq, +1) of group 0
     const int rd0 = (c >> 3) * 128 + ((c & 7) * 8 + (kq ^ (c >> 1))) * 2, rd1 = (c >> 3) * 128 + ((c & 7) * 8 + ((kq + 4) ^ (c >> 1))) * 2;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_kernel(GramAr
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_ptr)ring);   // LDS byte address
     auto dma1 = [&](int64_t i, int st, int q) {   // instruction q of chunk i of the block into stage st
         if (DBG >= 2) return;
-        glds16(dsrc[q] + i * B * GD_ROWS, ring_addr + (st * STAGE + q * 128) * 8);
+        glds16(dsrc[q] + i * stride, ring_addr + (st * STAGE + q * 128) * 8);
     };
     auto read_stage = [&](int st, d2v (&x2)[NQ]) {   // x2[2I + h]: rows 8h + 2kq, + 1 of column 16 I + c
 #pragma unroll
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_kernel(GramAr
     }
     __builtin_amdgcn_s_setprio(0);
     if (partial_last) {   // rows past the range read as the shift: x - shift = 0 exactly
-        const int64_t r = (nfull * B + b) * GD_ROWS + 16 * wave + 2 * kq, left = a.n - r;   // this lane's first row; rows from it on
+        const int64_t r = first + nfull * stride + 16 * wave + 2 * kq, left = end - r;   // this lane's first row; rows from it on
         d2v x2[NQ];
 #pragma unroll
         for (int I = 0; I < NCT; ++I) {
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_kernel(GramAr
         }
         __syncthreads();
     }
-    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    double* out = a.partial + out_slot * WS;
     for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
     if (tid < NC) {
         double s = 0.0;
@@ -651,9 +666,18 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(Gr
     const int slot = wave_slot();
     const long long t_start = a.stamps ? wall_clock64() : 0;
 
-    const int64_t nchunks = (a.n + GF_ROWS - 1) / GF_ROWS, B = gridDim.x, b = blockIdx.x;
-    const int64_t mine = b < nchunks ? (nchunks - 1 - b) / B + 1 : 0;
-    const bool partial_last = mine > 0 && ((mine - 1) * B + b + 1) * GF_ROWS > a.n;
+    const int64_t b = blockIdx.x;   // plain / segmented form: see gram_glds_kernel
+    int64_t first, stride, end, mine, out_slot = b;
+    if (a.blk) {
+        first = a.blk[4 * b + 1]; end = a.blk[4 * b + 2]; stride = GF_ROWS; out_slot = a.blk[4 * b + 3];
+        if (end <= first) return;
+        mine = (end - first + GF_ROWS - 1) / GF_ROWS;
+    } else {
+        const int64_t nchunks = (a.n + GF_ROWS - 1) / GF_ROWS, B = gridDim.x;
+        first = b * GF_ROWS; end = a.n; stride = B * GF_ROWS;
+        mine = b < nchunks ? (nchunks - 1 - b) / B + 1 : 0;
+    }
+    const bool partial_last = mine > 0 && first + (mine - 1) * stride + GF_ROWS > end;
     const int64_t nfull = mine - (partial_last ? 1 : 0);
 
     double sh[NCT], cs[NCT];
@@ -672,7 +696,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(Gr
         const int cc = 8 * q + (lane >> 3);
         const int col = cc < a.n_cols ? a.gc.cols[cc] : a.gc.cols[0];
         const int m = (lane & 7) ^ ((cc & 15) >> 1);
-        dsrc[q] = (const float*)a.base + (int64_t)col * a.ld + a.row0 + b * GF_ROWS + 32 * wave + 4 * m;
+        dsrc[q] = (const float*)a.base + (int64_t)col * a.ld + a.row0 + first + 32 * wave + 4 * m;
     }
     // floats from a stage's start to this lane's row quads kq and kq + 4 of group 0
     const int rd0 = (c >> 3) * 256 + ((c & 7) * 8 + (kq ^ (c >> 1))) * 4, rd1 = (c >> 3) * 256 + ((c & 7) * 8 + ((kq + 4) ^ (c >> 1))) * 4;
@@ -686,7 +710,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(Gr
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_ptr)ring);
     auto dma1 = [&](int64_t i, int st, int q) {
         if (DBG >= 2) return;
-        glds16(dsrc[q] + i * B * GF_ROWS, ring_addr + (st * STAGE + q * 256) * 4);
+        glds16(dsrc[q] + i * stride, ring_addr + (st * STAGE + q * 256) * 4);
     };
     auto read_stage = [&](int st, f4v (&raw)[NQ]) {   // raw[2I + h][e]: row 16h + 4kq + e of column 16 I + c
 #pragma unroll
@@ -760,7 +784,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(Gr
     }
     __builtin_amdgcn_s_setprio(0);
     if (partial_last) {   // the cut chunk through registers: rows past the range contribute nothing
-        const int64_t r = (nfull * B + b) * GF_ROWS + 32 * wave + 4 * kq, left = a.n - r;
+        const int64_t r = first + nfull * stride + 32 * wave + 4 * kq, left = end - r;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int h = k >> 2, e = k & 3;
@@ -797,7 +821,7 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(Gr
         }
         __syncthreads();
     }
-    double* out = a.partial + (int64_t)blockIdx.x * WS;
+    double* out = a.partial + out_slot * WS;
     for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
     if (tid < NC) {
         double s = 0.0;
@@ -812,14 +836,231 @@ __global__ __launch_bounds__(256, GD_BLOCKS_PER_CU) void gram_glds_f32_kernel(Gr
     }
 }
 
-// one thread per (segment, element): the segment's block partials in block order
+// ------------------------------------------------------------------------------------------------------------------
+// gram_gring_kernel: the Gram over a ROW LIST (a.rows: null-free rows of a candidate's columns, the rows of a discrete configuration,
+// a MutualInformation grouping's permutation).  A gathered element is 8 (4) bytes at its own address: the LDS-DMA moves 4 or 16
+// bytes per lane, so the ring of gram_glds_kernel is kept in REGISTERS instead - the operand layout itself is the load layout.
+// Wave w of a block owns list positions 16w .. 16w + 15 of each 64-position chunk; lane (c, kq) reads the four rows at positions
+// 4kq .. 4kq + 3 for column 16 I + c (k-step j contracts the rows at positions j, 4 + j, 8 + j, 12 + j: the contraction does not
+// care which rows share a k-step), straight into the MFMA operands: no LDS, no barrier, no transposition.  Three chunks of
+// operands rotate (multiplied / landed or landing / in flight, 4 NCT loads per lane and chunk each) and the row indices run one
+// chunk further ahead (one 16-byte read per lane and chunk); the compiler counts the waits (every load is its own).  The lanes of
+// a load instruction touch 16 columns x 4 rows: with a dense, increasing list the 4 rows and the chunk's other 3 loads of the
+// column group share a 128-byte line, with a sparse one every element is its own 64-byte sector and the pass is bound by the
+// sectors it drags in.
+// gram_lds_kernel<T, NCT, true> - a block-wide 32-row LDS image, one chunk of 8 single-element loads per thread in flight, the
+// row index read again by each of the 64 column threads - took 637 us for a 4-category grouping of the 2M x 64 table.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N> struct IdxVec;
+template <> struct IdxVec<4> { typedef int type __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct IdxVec<2> { typedef int type __attribute__((ext_vector_type(2), aligned(4))); };
+
+template <typename T, int N> struct RowVec { typedef T type __attribute__((ext_vector_type(N), aligned(sizeof(T)))); };
+template <typename T> struct RowVec<T, 1> { typedef T type; };
+
+// RM: the rows come from a ROW-MAJOR mirror of the launch's columns (GramArgs::rowmajor, build_rowmajor_mirror) in which the NCT
+// columns of a lane are adjacent: a gathered row is 16 NCT contiguous elements (512 bytes at 64 double columns), read by the 16
+// lanes of a row quarter with one 8 NCT-byte load each - whole lines whatever the list looks like, where the column-major table
+// gives every element of a sparse list a 64-byte sector of its own (2M x 64 doubles, rows of 4 / 64 configurations: 565 / 1210 us
+// through the columns - the first figure only with the pieces launched stripe-major).
+template <typename T, int NCT, bool RM>
+__global__ __launch_bounds__(256, 2) void gram_gring_kernel(GramArgs a) {
+    constexpr int NP = NPairs<NCT>::value;
+    constexpr int NC = NCT * 16;
+    constexpr int WS = NP * 256 + NCT * 16;
+    // a stage holds RL rows per lane (= RL k-steps, 16 RL list positions per block step); 64 double columns: stages of two rows and a
+    // ring of four, so that three are in flight beside the 80 accumulator registers (12 KiB per wave); otherwise four rows, ring of three
+    constexpr int RL = (sizeof(T) == 8 && NCT == 4) ? 2 : 4;   // (RM with four rows and a ring of three: the same 199 us)
+    constexpr int D = RL == 2 ? 4 : 3;
+    constexpr int STEP = 16 * RL;   // list positions per block step
+    typedef typename IdxVec<RL>::type idx_t;
+    constexpr TilePairs<NCT> PAIRS{};
+    __shared__ double lds[NP * 256 + 4 * NCT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+
+    int64_t rb0, rb1, out_slot = blockIdx.x;
+    if (a.blk) {
+        rb0 = a.blk[4 * blockIdx.x + 1]; rb1 = a.blk[4 * blockIdx.x + 2]; out_slot = a.blk[4 * blockIdx.x + 3];
+        if (rb1 <= rb0) return;   // a padding block of an XCD-aligned launch order: no piece, no partial
+    } else {
+        rb0 = (int64_t)blockIdx.x * a.rows_per_block;
+        rb1 = rb0 + a.rows_per_block;
+        if (rb1 > a.n) rb1 = a.n;
+    }
+    const int64_t nsteps = rb1 > rb0 ? (rb1 - rb0 + STEP - 1) / STEP : 0;
+
+    const T* colp[NCT];
+    double sh[NCT], cs[NCT];
+    bool cvalid[NCT];
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) {
+        cvalid[I] = 16 * I + c < a.n_cols;
+        const int src = cvalid[I] ? a.gc.cols[16 * I + c] : a.gc.cols[0];
+        colp[I] = (const T*)a.base + (int64_t)src * a.ld;
+        sh[I] = a.shift[src];
+        cs[I] = 0.0;
+    }
+    d4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = d4{0, 0, 0, 0};
+
+    const int32_t* rows = a.rows;
+    const int64_t p0 = rb0 + 4 * RL * wave + RL * kq;   // this lane's first position of step 0
+    // row indices of step t; `cut`: positions past the piece read as the piece's first row (their operands are zeroed in `mult`)
+    auto load_idx = [&](int64_t t, idx_t& idx, bool cut) {
+        const int64_t p = p0 + STEP * t;
+        if (!cut) { idx = *(const idx_t*)(rows + p); return; }
+#pragma unroll
+        for (int j = 0; j < RL; ++j) idx[j] = rows[p + j < rb1 ? p + j : rb0];
+    };
+    // element address = column + row * sizeof(T) as ONE v_mad_u64_u32 on the 32-bit row (an opaque multiplier, or the compiler
+    // widens the row into a register pair first: the pairs' copies end up behind the loads at the loop's end, with a vmcnt(0))
+    unsigned esize = RM ? sizeof(T) * NC : sizeof(T);   // bytes from a row to the next
+    asm volatile("" : "+s"(esize));
+    typedef typename RowVec<T, NCT>::type rowvec_t;
+    const uint64_t rmp = (uint64_t)(uintptr_t)a.rowmajor + (uint64_t)(NCT * c) * sizeof(T);   // RM: this lane's NCT columns of row 0
+    auto load_data = [&](const idx_t& idx, T (&raw)[NCT][RL]) {
+        if constexpr (RM) {
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                const uint64_t row = rmp + (uint64_t)(uint32_t)idx[j] * (uint64_t)esize;
+                if constexpr (NCT == 3) {
+                    // two elements and one: a 3-vector is read as four, and the compiler gives the fourth's registers to live
+                    // values - every one of them then waits for the load to land before it may be written
+                    typedef typename RowVec<T, 2>::type pair_t;
+                    const pair_t v = *(const __attribute__((address_space(1))) pair_t*)row;
+                    raw[0][j] = v[0]; raw[1][j] = v[1];
+                    raw[2][j] = *(const __attribute__((address_space(1))) T*)(row + 2 * sizeof(T));
+                } else {
+                    const rowvec_t v = *(const __attribute__((address_space(1))) rowvec_t*)row;
+#pragma unroll
+                    for (int I = 0; I < NCT; ++I) {
+                        if constexpr (NCT == 1) raw[I][j] = v; else raw[I][j] = v[I];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int I = 0; I < NCT; ++I)
+#pragma unroll
+                for (int j = 0; j < RL; ++j)
+                    raw[I][j] = *(const __attribute__((address_space(1))) T*)((uint64_t)(uintptr_t)colp[I] + (uint64_t)(uint32_t)idx[j] * (uint64_t)esize);   // global_load: a flat one waits for everything
+        }
+    };
+    auto mult = [&](int64_t t, const T (&raw)[NCT][RL], bool cut) {
+        const int64_t left = cut ? rb1 - (p0 + STEP * t) : RL;   // rows of the piece from this lane's first position on
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            double x[NCT];
+#pragma unroll
+            for (int I = 0; I < NCT; ++I) {
+                x[I] = (double)raw[I][j] - sh[I];
+                if (I == NCT - 1) x[I] = cvalid[I] ? x[I] : 0.0;
+                if (cut) x[I] = left > j ? x[I] : 0.0;
+                cs[I] += x[I];
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[PAIRS.I[p]], x[PAIRS.J[p]], acc[p], 0, 0, 0);
+        }
+    };
+
+    // The ring.  Before step t: the data of steps t .. t + D - 2 are in flight or landed in stages (t .. t + D - 2) mod D, the indices
+    // of steps t + D - 1 .. t + 2 D - 3 in their slots (step mod D).  Step t issues the data of step t + D - 1, asks for the indices
+    // of step t + 2 D - 2 and multiplies stage t mod D.  Loads return in order: the indices a step needs were asked for D - 1 steps
+    // ago, right behind the data of the step it multiplies - waiting for them leaves the D - 2 younger stages in flight (one step
+    // ahead only, the wait for the indices would drain every stage each step).  Trips of D steps keep every stage and slot a
+    // compile-time name; the steady trips run without a condition (the compiler counts its waits over straight-line code: a
+    // conditional load would make it assume the shorter queue and wait for more than it needs), the last steps repeat the trip
+    // with theirs.
+    T r[D][NCT][RL];
+    idx_t ix[D];
+    int64_t t = 0;
+    if (nsteps >= 3 * D) {
+        // a long piece: the ring is filled without a condition and in this order - the waits of the loop's first trip are counted
+        // from here too, and a load that may not have been issued (or an index load sunk behind the data) would make the loop wait
+        // for nearly everything at its top, every trip
+        idx_t first[D - 1];
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load_idx(j, first[j], false);
+#pragma unroll
+        for (int j = D - 1; j <= 2 * D - 3; ++j) load_idx(j, ix[j % D], false);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load_data(first[j], r[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; t + 3 * D - 1 < nsteps; t += D) {   // every step the trip issues or asks indices for is a whole one
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                load_data(ix[(s + D - 1) % D], r[(s + D - 1) % D]);
+                load_idx(t + s + 2 * D - 2, ix[(s + 2 * D - 2) % D], false);
+                __builtin_amdgcn_sched_barrier(0);   // the loads of a step stay in their step: hoisted, they would lengthen the stages' lives
+                mult(t + s, r[s], false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        idx_t first[D - 1];
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load_idx(j, first[j], true);
+#pragma unroll
+        for (int j = D - 1; j <= 2 * D - 3; ++j) load_idx(j, ix[j % D], true);
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j)
+            if (j < nsteps) load_data(first[j], r[j]);
+    }
+    for (; t < nsteps; t += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            if (t + s + D - 1 < nsteps) load_data(ix[(s + D - 1) % D], r[(s + D - 1) % D]);
+            if (t + s + 2 * D - 2 < nsteps) load_idx(t + s + 2 * D - 2, ix[(s + 2 * D - 2) % D], true);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + s < nsteps) mult(t + s, r[s], true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- block combine, as in gram_glds_kernel: tiles in wave order, column sums per (wave, group, lane) ------------------
+    double* lcs = lds + NP * 256;
+#pragma unroll
+    for (int I = 0; I < NCT; ++I) lcs[(wave * NCT + I) * 64 + lane] = cs[I];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = p * 256 + e4 * 64 + lane;
+                    lds[e] = (w == 0) ? acc[p][e4] : lds[e] + acc[p][e4];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double* out = a.partial + out_slot * WS;
+    for (int e = threadIdx.x; e < NP * 256; e += 256) out[e] = lds[e];
+    if (tid < NC) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < 4; ++k) s += lcs[(w * NCT + (tid >> 4)) * 64 + k * 16 + (tid & 15)];
+        out[NP * 256 + tid] = s;
+    }
+}
+
+// four threads per (segment, element): the segment's partial slots blk_off[g] .. blk_off[g + 1] - 1 are cut into four runs of
+// ceil(count / 4), each added in slot order, and the four run sums are added in run order - a fixed association that depends on the
+// segment's number of pieces only
 __global__ __launch_bounds__(256) void gram_seg_reduce_kernel(const double* __restrict__ partial, const int32_t* __restrict__ blk_off, int WS,
                                                                double* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (e >= WS) return;
+    __shared__ double run[4][64];
+    const int e = blockIdx.x * 64 + threadIdx.x, g = blockIdx.y, q = threadIdx.y;
+    const int b0 = blk_off[g], b1 = blk_off[g + 1], len = (b1 - b0 + 3) / 4;
     double v = 0.0;
-    for (int b = blk_off[g]; b < blk_off[g + 1]; ++b) v += partial[(size_t)b * WS + e];
-    out[(size_t)g * WS + e] = v;
+    if (e < WS)
+        for (int b = b0 + q * len; b < b1 && b < b0 + (q + 1) * len; ++b) v += partial[(size_t)b * WS + e];
+    run[q][threadIdx.x] = v;
+    __syncthreads();
+    if (q == 0 && e < WS) out[(size_t)g * WS + e] = ((run[0][threadIdx.x] + run[1][threadIdx.x]) + run[2][threadIdx.x]) + run[3][threadIdx.x];
 }
 
 // PBN_GRAM_LDS: 0 = gram_kernel (rows in registers), 1 = gram_lds_kernel, 2 (default) = the LDS-DMA ring kernels where they apply
@@ -859,6 +1100,19 @@ static int launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st
             return (int)grid.x;
         }
     }
+    if constexpr (GATHER) {
+        if (gram_variant() >= 2) {
+            switch (nct) {
+                case 1: hipLaunchKernelGGL((gram_gring_kernel<T, 1, false>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((gram_gring_kernel<T, 2, false>), grid, block, 0, st, a); break;
+                case 3: hipLaunchKernelGGL((gram_gring_kernel<T, 3, false>), grid, block, 0, st, a); break;
+                case 4: hipLaunchKernelGGL((gram_gring_kernel<T, 4, false>), grid, block, 0, st, a); break;
+                default: throw invalid_error("gram: at most 64 columns per launch");
+            }
+            HIP_CHECK(hipGetLastError());
+            return nblocks;
+        }
+    }
     if (gram_variant() >= 1) {
         switch (nct) {
             case 1: hipLaunchKernelGGL((gram_lds_kernel<T, 1, GATHER>), grid, block, 0, st, a); break;
@@ -879,6 +1133,51 @@ static int launch_gram_t(const GramArgs& a, int nct, int nblocks, hipStream_t st
     }
     HIP_CHECK(hipGetLastError());
     return nblocks;
+}
+
+// 64 rows per block through an LDS tile: column reads and row writes both run along their contiguous direction; a thread's 4 NCT
+// column reads are issued together
+template <typename T, int NCT>
+__global__ __launch_bounds__(256) void rowmajor_mirror_kernel(const T* __restrict__ base, int64_t ld, GramCols gc, int n_cols, int64_t n,
+                                                              T* __restrict__ out) {
+    constexpr int W = 16 * NCT;
+    __shared__ T tile[64 * (W + 1)];
+    const int tid = threadIdx.x, r = tid & 63, cq = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    T v[4 * NCT];
+#pragma unroll
+    for (int k = 0; k < 4 * NCT; ++k) {
+        const int col = 4 * k + cq;
+        v[k] = (col < n_cols && r0 + r < n) ? base[(int64_t)gc.cols[col < n_cols ? col : 0] * ld + r0 + r] : (T)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4 * NCT; ++k) {
+        const int col = 4 * k + cq;
+        tile[r * (W + 1) + NCT * (col & 15) + (col >> 4)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16 * NCT / 4; ++k) {
+        const int e = k * 256 + tid, rr = e / W, kk = e % W;
+        if (r0 + rr < n) out[(r0 + rr) * W + kk] = tile[rr * (W + 1) + kk];
+    }
+}
+
+size_t rowmajor_mirror_elems(int64_t n, int n_cols) { return (size_t)n * (size_t)(16 * ((n_cols + 15) / 16)) + 16; }
+
+void build_rowmajor_mirror(const void* base, int64_t ld, const GramCols& gc, int n_cols, int64_t n, int dtype, void* out, hipStream_t st) {
+    if (n <= 0) return;
+    const int nct = (n_cols + 15) / 16;
+    if (nct < 1 || nct > 4) throw invalid_error("gram: at most 64 columns per mirror");
+    const dim3 grid((unsigned)((n + 63) / 64)), block(256);
+#define PBN_MIRROR(N)                                                                                                                         \
+    case N:                                                                                                                                   \
+        if (dtype == PBN_F64) hipLaunchKernelGGL((rowmajor_mirror_kernel<double, N>), grid, block, 0, st, (const double*)base, ld, gc, n_cols, n, (double*)out); \
+        else hipLaunchKernelGGL((rowmajor_mirror_kernel<float, N>), grid, block, 0, st, (const float*)base, ld, gc, n_cols, n, (float*)out);       \
+        break;
+    switch (nct) { PBN_MIRROR(1) PBN_MIRROR(2) PBN_MIRROR(3) PBN_MIRROR(4) }
+#undef PBN_MIRROR
+    HIP_CHECK(hipGetLastError());
 }
 
 int gram_ws(int nct) { return nct * (nct + 1) / 2 * 256 + nct * 16; }
@@ -945,21 +1244,50 @@ void launch_gram_segments(const GramArgs& a_in, int dtype, int nblocks, const in
     if (nblocks > 0) {
         const bool gather = a.rows != nullptr;
         const dim3 grid(nblocks), block(256);
-#define PBN_SEG(T, N, GA) hipLaunchKernelGGL((gram_lds_kernel<T, N, GA>), grid, block, 0, st, a)
-#define PBN_SEG_N(T, GA)                                                                        \
+        // the kernels of the plain form, block b on the piece blk[4b + 1 .. 2] -> partial slot blk[4b + 3]: the LDS-DMA rings for
+        // contiguous rows, the register ring for row lists (PBN_GRAM_LDS < 2: gram_lds_kernel for both)
+        const bool ring = gram_variant() >= 2;
+#define PBN_SEG_N(K_RING, K_LDS)                                                                \
     switch (nct) {                                                                              \
-        case 1: PBN_SEG(T, 1, GA); break;                                                       \
-        case 2: PBN_SEG(T, 2, GA); break;                                                       \
-        case 3: PBN_SEG(T, 3, GA); break;                                                       \
-        case 4: PBN_SEG(T, 4, GA); break;                                                       \
+        case 1: if (ring) hipLaunchKernelGGL((K_RING(1)), grid, block, 0, st, a); else hipLaunchKernelGGL((K_LDS(1)), grid, block, 0, st, a); break; \
+        case 2: if (ring) hipLaunchKernelGGL((K_RING(2)), grid, block, 0, st, a); else hipLaunchKernelGGL((K_LDS(2)), grid, block, 0, st, a); break; \
+        case 3: if (ring) hipLaunchKernelGGL((K_RING(3)), grid, block, 0, st, a); else hipLaunchKernelGGL((K_LDS(3)), grid, block, 0, st, a); break; \
+        case 4: if (ring) hipLaunchKernelGGL((K_RING(4)), grid, block, 0, st, a); else hipLaunchKernelGGL((K_LDS(4)), grid, block, 0, st, a); break; \
         default: throw invalid_error("gram: at most 64 columns per launch");                    \
     }
-        if (dtype == PBN_F64) { if (gather) { PBN_SEG_N(double, true) } else { PBN_SEG_N(double, false) } }
-        else { if (gather) { PBN_SEG_N(float, true) } else { PBN_SEG_N(float, false) } }
+#define PBN_K_GLDS64(N) gram_glds_kernel<N, 0>
+#define PBN_K_GLDS32(N) gram_glds_f32_kernel<N, 0>
+#define PBN_K_GRING64(N) gram_gring_kernel<double, N, false>
+#define PBN_K_GRING32(N) gram_gring_kernel<float, N, false>
+#define PBN_K_GROWS64(N) gram_gring_kernel<double, N, true>
+#define PBN_K_GROWS32(N) gram_gring_kernel<float, N, true>
+#define PBN_K_LDS64(N) gram_lds_kernel<double, N, false>
+#define PBN_K_LDS32(N) gram_lds_kernel<float, N, false>
+#define PBN_K_LDS64G(N) gram_lds_kernel<double, N, true>
+#define PBN_K_LDS32G(N) gram_lds_kernel<float, N, true>
+        const bool mirror = gather && ring && a.rowmajor != nullptr;
+        if (dtype == PBN_F64) {
+            if (mirror) { PBN_SEG_N(PBN_K_GROWS64, PBN_K_LDS64G) }
+            else if (gather) { PBN_SEG_N(PBN_K_GRING64, PBN_K_LDS64G) }
+            else { PBN_SEG_N(PBN_K_GLDS64, PBN_K_LDS64) }
+        } else {
+            if (mirror) { PBN_SEG_N(PBN_K_GROWS32, PBN_K_LDS32G) }
+            else if (gather) { PBN_SEG_N(PBN_K_GRING32, PBN_K_LDS32G) }
+            else { PBN_SEG_N(PBN_K_GLDS32, PBN_K_LDS32) }
+        }
 #undef PBN_SEG_N
-#undef PBN_SEG
+#undef PBN_K_GLDS64
+#undef PBN_K_GLDS32
+#undef PBN_K_GRING64
+#undef PBN_K_GRING32
+#undef PBN_K_GROWS64
+#undef PBN_K_GROWS32
+#undef PBN_K_LDS64
+#undef PBN_K_LDS32
+#undef PBN_K_LDS64G
+#undef PBN_K_LDS32G
     }
-    if (n_seg > 0) hipLaunchKernelGGL(gram_seg_reduce_kernel, dim3((WS + 255) / 256, n_seg), dim3(256), 0, st, a.partial, blk_off, WS, out);
+    if (n_seg > 0) hipLaunchKernelGGL(gram_seg_reduce_kernel, dim3((WS + 63) / 64, n_seg), dim3(64, 4), 0, st, a.partial, blk_off, WS, out);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -28,7 +28,7 @@ def kernels(asm, pattern):
     for f in re.split(r"\n(?=_Z[A-Za-z0-9_]+:)", asm):
         name = f.split(":", 1)[0]
         if re.search(pattern, name):
-            yield name, f.split("s_endpgm")[0]
+            yield name, f.split(".Lfunc_end")[0]   # the whole function: an early exit gives it more than one s_endpgm
 
 
 def test_glds_ring_loops_hold_no_other_vector_memory_instruction(stats_asm):
@@ -44,3 +44,21 @@ def test_glds_ring_loops_hold_no_other_vector_memory_instruction(stats_asm):
             other = re.findall(r"^\s*(global_load_dword\w*|global_store\w*|flat_load\w*|flat_store\w*|global_atomic\w*)", b, flags=re.M)
             assert not other, f"{name}: {other[:3]} inside the ring loop shifts the hand-counted vmcnt"
     assert seen == 8   # NCT = 1..4, double and float tables
+
+
+def test_gather_ring_kernels_keep_their_stages_in_flight(stats_asm):
+    """gram_gring_kernel leaves its waits to the compiler, which counts them only for global_ loads in straight-line code: a flat_load
+    (a pointer whose address space was lost) waits for everything, a scratch spill drains the queue, and a steady loop whose index
+    wait is vmcnt(0) has one stage in flight instead of its ring."""
+    seen = 0
+    for name, body in kernels(stats_asm, r"gram_gring_kernelI[df]Li[1-4]ELb[01]E"):
+        seen += 1
+        assert "scratch_" not in body, f"{name}: scratch spill"
+        assert "flat_load" not in body, f"{name}: flat load"
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        steady = [b for b in blocks if "Inner Loop Header" in b and len(re.findall(r"v_mfma_f64", b)) >= 12 and "global_load_dword" in b]
+        assert steady, f"{name}: no steady loop found"
+        for b in steady[:1]:
+            waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", b)]
+            assert waits and min(waits) >= 4, f"{name}: the steady loop waits with vmcnt({min(waits) if waits else None})"
+    assert seen == 16

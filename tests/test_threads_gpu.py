@@ -103,3 +103,41 @@ def test_another_thread_gets_through_during_a_search(pbn):
     assert np.isfinite(val) and done["search"][1] >= 2
     assert t_other < done["search"][0], "the other thread's calls waited for the whole search"
     assert done["search"][0] - t0 > 0.3   # the search was long enough for the comparison to mean something
+
+
+def test_handles_may_outlive_their_context(pbn):
+    """A garbage collector finalises the objects of a reference cycle in no particular order: the context's destroy call may arrive
+    before those of the tables and models created on it.  Every handle holds a counted reference (csrc/common.hpp, "Lifetime"), so
+    the late destroy calls find a live mutex - and the handles keep working until then."""
+    import ctypes as C
+    import gc
+
+    from pybnesian_amd import _lib
+
+    lib = _lib.load()
+    for _ in range(20):
+        ctx = pbn.Context(0)
+        tr, te = _tables(3, 5000, 500)
+        ttab, _ = pbn.DeviceTable.from_dataframe(ctx, tr, list("abc"))
+        qtab, _ = pbn.DeviceTable.from_dataframe(ctx, te, list("abc"))
+        k = pbn.KDE(list("abc"))
+        k.fit_table(ttab)
+        want = k.slogl_table(qtab)
+        handle, ctx.handle = ctx.handle, None          # the context's destroy call comes first ...
+        lib.pbn_ctx_destroy(handle)
+        assert k.slogl_table(qtab) == want             # ... the handles still work ...
+        del k, qtab, ttab                              # ... and their destroy calls release the context with the last of them
+        gc.collect()
+
+    class Node:   # the same through a real cycle: context, table and model only reachable from it
+        pass
+
+    for _ in range(20):
+        n = Node()
+        n.self = n
+        n.ctx = pbn.Context(0)
+        n.tab, _ = pbn.DeviceTable.from_dataframe(n.ctx, _tables(4, 3000, 10)[0], list("abc"))
+        n.k = pbn.KDE(list("abc"))
+        n.k.fit_table(n.tab)
+        del n
+        gc.collect()

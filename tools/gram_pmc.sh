@@ -1,7 +1,8 @@
 # Counters of the Gram kernel (2M x 64 fp64, tools/gram_bench.py), one --pmc pass per group (never with a trace domain):
 # SQ issue / MFMA counters, LDS counters, FETCH_SIZE.  Prints per-dispatch averages; FETCH_SIZE is doubled as
 # MI355X_MICROARCH.md "HBM" prescribes for 16-byte-per-lane streaming reads on gfx950 (raw value kept beside it).
-# bash tools/gram_pmc.sh <outdir under gpurun_out>   (PBN_GRAM_LDS / PBN_GRAM_DEBUG are inherited)
+# bash tools/gram_pmc.sh <outdir under gpurun_out>   (PBN_GRAM_LDS / PBN_GRAM_DEBUG / GRAM_MODE are inherited; GRAM_KERNEL = substring of
+# the kernel name to aggregate, default gram_)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-gram_pmc}
@@ -12,7 +13,7 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CON
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/tools/gram_bench.py > $OUT/fetch.log 2>&1
 cd $R
 python3 - $OUT <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 out = sys.argv[1]
 vals = {}
 for grp in ("sq", "lds", "fetch"):
@@ -20,7 +21,7 @@ for grp in ("sq", "lds", "fetch"):
     name = None
     for f in glob.glob(f"{out}/{grp}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "gram_" in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"]:
+            if os.environ.get("GRAM_KERNEL", "gram_") in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"]:
                 name = row["Kernel_Name"].split("(")[0]
                 a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
     for k, (v, n) in sorted(acc.items()):
