@@ -49,6 +49,10 @@ const char* pbn_version(void);
 
 /* ---- context: replaces opencl/opencl_config.cpp:149-220 (platform/device/queue singleton) ------ */
 int pbn_ctx_create(int device, pbn_ctx** out);
+/* Drops the creator's reference.  Every handle created on the context (tables, KDE models, score data, MI / kMI engines) holds one
+ * of its own: the stream, the arenas and the lock go with the LAST reference, so destroy calls may arrive in any order (a garbage
+ * collector finalises the members of a reference cycle in no particular order).  The pointer must not be passed to another
+ * pbn_ctx_* function afterwards. */
 void pbn_ctx_destroy(pbn_ctx* ctx);
 int pbn_ctx_sync(pbn_ctx* ctx);
 void* pbn_ctx_stream(pbn_ctx* ctx); /* hipStream_t the kernels are launched on (for event timing)    */
