@@ -237,6 +237,21 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                     const int* parents, const double* params, int n_params, double* out);
 
+/* The two halves of a CKDE likelihood score as functions of a variable SET: local(v | P) = A({v} u P, d) - A(P, d), d = |P| + 1, with
+ * A(S, m) = sum over the split's test regions of sum_q log KDE_S(q) under the bandwidth rule for m dimensions on the region's training
+ * rows (CKDE.hpp:186-199: the marginal of the reference is the KDE of the parents with H[1:, 1:]).  A({s, t}, 2) serves s -> t and t -> s,
+ * A({s}, 2) every child of s - so a job with one process per GPU deals the TERMS of a delta-cache batch, not its candidates (SURVEY.md
+ * section 8e; the reference has no counterpart).  Term i = columns vars[off[i] .. off[i+1]) (continuous, any order) with m[i] = their
+ * number (a joint term) or one more (the marginal term of a candidate with these parents).
+ *   pbn_score_terms          evaluates the terms (grouped engine, set-function cache) -> out[i] = total over the regions;
+ *   pbn_score_terms_put      installs totals computed elsewhere: pbn_score_batch prefers them, and assembles every CKDE candidate as
+ *                            (sum of joint terms in region order) - (sum of marginal terms in region order) with or without them, so
+ *                            every rank - and the one-process run - produce the same doubles;
+ *   pbn_score_terms_missing  missing[i] = 1 where no total is installed. */
+int pbn_score_terms(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, double* out);
+int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, const double* values);
+int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, int* missing);
+
 /* ---- greedy hill-climbing (host logic; replaces learning/algorithms/hillclimbing.hpp:62-199 driving
  * learning/operators/operators.{hpp,cpp}).  Nodes are 0..n_nodes-1 in model.nodes() order.  Every step's
  * Score::local_score requests are handed to `score` as ONE batch (same layout as pbn_score_batch);

@@ -556,6 +556,7 @@ int pbn_scoredata_moments(pbn_scoredata* sd, double* buf, int64_t* len, int set)
         regions_from_segments(sd);
         sd->partial = false;
         sd->kde_cache.clear();
+        sd->term_total.clear();
         sd->score_memo.clear();
     });
 }
@@ -579,6 +580,7 @@ int pbn_scoredata_set_discrete(pbn_scoredata* sd, int n_disc, const int32_t* con
         sd->ctx->sync_lanes(pbn_ctx::MAX_PARKED);
         sd->groupings.clear();
         sd->kde_cache.clear();
+        sd->term_total.clear();
         sd->score_memo.clear();
         sd->n_disc = n_disc;
         sd->codes.assign(n_disc, std::vector<int32_t>((size_t)rows));
@@ -619,6 +621,7 @@ int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
         if (selector != PBN_SEL_NORMAL_REFERENCE && selector != PBN_SEL_SCOTT) throw invalid_error("pbn_scoredata_set_selector: unknown selector");
         sd->selector = selector;
         sd->kde_cache.clear();
+        sd->term_total.clear();
         sd->score_memo.clear();
     });
 }
@@ -739,8 +742,10 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
     return lg_eval(t, cols, d, row0, n, beta, variance, out, nullptr, 1);
 }
 
-int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
-                    const int* parents, const double* params, int n_params, double* out) {
+// `want` (nullable, per candidate): 0 = the local score; 1 / 2 = only the joint / only the marginal CKDE term of the candidate, summed
+// over the regions (pbn_score_terms)
+static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
+                            const int* parents, const double* params, int n_params, double* out, const int* want) {
     return guarded(mu_of(sd), [&] {
         if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
         pbn_ctx* ctx = sd->ctx;
@@ -755,6 +760,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
         // the batch being assembled is lost).
         static const size_t cache_budget = [] { const char* e = getenv("PBN_SCORE_CACHE_ENTRIES"); const long long v = (e && *e) ? atoll(e) : (1ll << 21); return (size_t)(v < 1 ? 1 : v); }();
         if (sd->kde_cache.size() > cache_budget) { sd->kde_cache.clear(); ++sd->cache_resets; }
+        if (sd->term_total.size() > cache_budget) { sd->term_total.clear(); ++sd->cache_resets; }
         if (sd->score_memo.size() > cache_budget) { sd->score_memo.clear(); ++sd->cache_resets; }
         // BGe parameters
         double iss_mu = 1, iss_w = sd->n + 2;
@@ -911,7 +917,18 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                 scheduled[key] = slot;
                 return slot;
             };
-            struct Unit { int cand; Term joint, marg; bool has_marg; };
+            struct Unit { int cand; Term joint, marg; bool has_marg; int want; };
+            // a term whose total over the regions was installed (pbn_score_terms_put): the total stands for region 0, the others add 0
+            auto lookup_total = [&](int m, const int* v, int nv, int region_index, Term& t) {
+                if (sd->term_total.empty()) return false;
+                std::vector<int> k(v, v + nv);
+                std::sort(k.begin(), k.end());
+                k.insert(k.begin(), m);
+                auto it = sd->term_total.find(k);
+                if (it == sd->term_total.end()) return false;
+                t.value = region_index == 0 ? it->second : 0.0;
+                return true;
+            };
             std::vector<Unit> units_v;
             struct Work { int cand, f, mode, slot_j, slot_m; };          // mode 0 fused, 1 joint only, 2 marginal only
             std::vector<Work> work;
@@ -929,12 +946,13 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
                 for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
                 for (int f = 0; f < pd.units; ++f) {
                     const int region = cv ? f : sd->k;                    // fold index, or the hold-out region
-                    Unit u{c, {}, {}, p > 0};
+                    const int wnt = want ? want[c] : 0;
+                    Unit u{c, {}, {}, p > 0 && wnt != 1, wnt};
                     const std::vector<int> kj = key_of(region, d, cols.data(), d);
-                    const bool have_j = lookup(kj, u.joint);
+                    const bool have_j = wnt == 2 || lookup_total(d, cols.data(), d, f, u.joint) || lookup(kj, u.joint);
                     bool have_m = true;
                     std::vector<int> km;
-                    if (p > 0) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup(km, u.marg); }
+                    if (u.has_marg) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup_total(d, cols.data() + 1, p, f, u.marg) || lookup(km, u.marg); }
                     if (!have_j && !have_m && fused) {
                         u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
                         work.push_back({c, f, 0, u.joint.slot, u.marg.slot});
@@ -1089,13 +1107,91 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
             ctx->drop_staged();
             for (size_t i = 0; i < nslots; ++i) sd->kde_cache[slot_key[i]] = hs[i];
             sd->kde_sweeps += (int64_t)work.size();
-            for (const Pending& pd : pending) out[pd.cand] = 0.0;
+            // a candidate = (its joint terms added in region order) - (its marginal terms added in region order): the two sums are
+            // what pbn_score_terms hands out, so a job that computes the terms on different ranks assembles the same doubles
+            std::vector<double> jsum((size_t)n_cand, 0.0), msum((size_t)n_cand, 0.0);
             for (const Unit& u : units_v) {
-                const double j = u.joint.slot >= 0 ? hs[u.joint.slot] : u.joint.value;
-                const double mg = !u.has_marg ? 0.0 : (u.marg.slot >= 0 ? hs[u.marg.slot] : u.marg.value);
-                out[u.cand] += j - mg;
+                if (u.want != 2) jsum[u.cand] += u.joint.slot >= 0 ? hs[u.joint.slot] : u.joint.value;
+                if (u.has_marg) msum[u.cand] += u.marg.slot >= 0 ? hs[u.marg.slot] : u.marg.value;
+            }
+            for (const Pending& pd : pending) {
+                const int wnt = want ? want[pd.cand] : 0;
+                out[pd.cand] = wnt == 2 ? msum[pd.cand] : (wnt == 1 ? jsum[pd.cand] : jsum[pd.cand] - msum[pd.cand]);
             }
         }
+    });
+}
+
+int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
+                    const int* parents, const double* params, int n_params, double* out) {
+    return score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, params, n_params, out, nullptr);
+}
+
+namespace {
+// term i = columns vars[off[i] .. off[i + 1]) under the bandwidth rule for m[i] dimensions: m = the number of columns for a joint term,
+// one more for the marginal term of a candidate with those parents
+void check_terms(const pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, const char* who) {
+    if (!sd || (n_terms > 0 && (!off || !vars || !m))) throw invalid_error(std::string(who) + ": null argument");
+    if (kind != PBN_SCORE_CVLIK && kind != PBN_SCORE_HOLDOUT) throw invalid_error(std::string(who) + ": likelihood scores only");
+    for (int i = 0; i < n_terms; ++i) {
+        const int nv = off[i + 1] - off[i];
+        if (nv < 1 || (m[i] != nv && m[i] != nv + 1)) throw invalid_error(std::string(who) + ": a term has m = its columns (joint) or one more (marginal)");
+        for (int j = off[i]; j < off[i + 1]; ++j)
+            if (vars[j] < 0 || vars[j] >= sd->n) throw invalid_error(std::string(who) + ": continuous columns only");
+    }
+}
+std::vector<int> term_key(const int* v, int nv, int m) {
+    std::vector<int> k(v, v + nv);
+    std::sort(k.begin(), k.end());
+    k.insert(k.begin(), m);
+    return k;
+}
+}  // namespace
+
+int pbn_score_terms(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, double* out) {
+    return guarded(mu_of(sd), [&] {
+        check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms");
+        if (n_terms > 0 && !out) throw invalid_error("pbn_score_terms: null output");
+        // every term as a pseudo-candidate of the batch engine: a joint term = (first column | the others), joint half only; a marginal
+        // term = (any other column | the term's columns), marginal half only - the bandwidth block of the parents does not depend on
+        // the child (H = k(N, d) cov for the library selectors)
+        std::vector<int> var((size_t)n_terms), nt((size_t)n_terms, PBN_NODE_CKDE), po{0}, par, want((size_t)n_terms);
+        for (int i = 0; i < n_terms; ++i) {
+            const int nv = off[i + 1] - off[i];
+            const int* v = vars + off[i];
+            if (m[i] == nv) {
+                var[i] = v[0]; want[i] = 1;
+                par.insert(par.end(), v + 1, v + nv);
+            } else {
+                int child = 0;
+                while (std::find(v, v + nv, child) != v + nv) ++child;
+                if (child >= sd->n) throw invalid_error("pbn_score_terms: a marginal term needs a column outside it");
+                var[i] = child; want[i] = 2;
+                par.insert(par.end(), v, v + nv);
+            }
+            po.push_back((int)par.size());
+        }
+        if (n_terms > 0) {
+            const int rc = score_batch_impl(sd, kind, n_terms, var.data(), nt.data(), po.data(), par.data(), nullptr, 0, out, want.data());
+            if (rc != PBN_OK) throw device_error(pbn_last_error());
+        }
+    });
+}
+
+int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, const double* values) {
+    return guarded(mu_of(sd), [&] {
+        check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_put");
+        if (n_terms > 0 && !values) throw invalid_error("pbn_score_terms_put: null values");
+        for (int i = 0; i < n_terms; ++i) sd->term_total[term_key(vars + off[i], off[i + 1] - off[i], m[i])] = values[i];
+    });
+}
+
+int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, int* missing) {
+    return guarded(mu_of(sd), [&] {
+        check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_missing");
+        if (n_terms > 0 && !missing) throw invalid_error("pbn_score_terms_missing: null output");
+        for (int i = 0; i < n_terms; ++i)
+            missing[i] = sd->term_total.find(term_key(vars + off[i], off[i + 1] - off[i], m[i])) == sd->term_total.end() ? 1 : 0;
     });
 }
 

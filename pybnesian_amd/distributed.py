@@ -9,7 +9,12 @@ No other collective is on the data path.
 import numpy as np
 
 
+_EMULATED = None   # measurement aid (tools/scale_emulate.py): an object with get_rank / get_world_size / emulate(times per rank)
+
+
 def _dist():
+    if _EMULATED is not None:
+        return _EMULATED
     try:
         import torch.distributed as dist
     except Exception:  # pragma: no cover
@@ -57,10 +62,20 @@ def _kde_cost(d):
 
 def deal_sets(keys, world):
     """Owner rank of every variable set: longest processing time first on a cost model (one joint sweep per set + one marginal
-    sweep per candidate, x folds x rows being common factors), ties by first appearance, each set to the least loaded rank
+    sweep per candidate, x folds x rows being common factors), ties by a hash of the set, each set to the least loaded rank
     (lowest rank on ties).  Deterministic, identical on every rank.  keys: list of (set, number of candidates) in order of
     first appearance."""
-    cost = [(_kde_cost(len(k)) + n * _kde_cost(len(k) - 1), -i) for i, (k, n) in enumerate(keys)]
+    # equal costs (the initial cache: every set a pair) are ordered by a hash of the set, not by appearance: in order of appearance
+    # rank r gets the sets i = r mod world, i.e. the pairs of the SAME few variables - and a variable whose sweeps prune badly made
+    # its rank 25 % slower than the mean of eight (tools/scale_emulate.py); scattered, the ranks' sums differ by a few percent
+    def mix(key):
+        h = 0x9E3779B9
+        for v in key:
+            h = ((h ^ (int(v) + 0x7F4A7C15)) * 0x85EBCA6B) & 0xFFFFFFFF
+            h ^= h >> 13
+        return h
+
+    cost = [(_kde_cost(len(k)) + n * _kde_cost(len(k) - 1), mix(k), -i) for i, (k, n) in enumerate(keys)]
     order = sorted(range(len(keys)), key=lambda i: cost[i], reverse=True)
     load = [0.0] * world
     owner = [0] * len(keys)
@@ -84,11 +99,48 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
+def _gather_shares(dist, world, rank, lists, compute, where):
+    """Rank r evaluates compute(lists[r]) -> values; every rank gets every rank's values (one all_gather; a failure anywhere raises
+    everywhere).  Under the emulation hook one process plays the ranks in turn and reports each share's seconds."""
+    if hasattr(dist, "emulate"):
+        import time
+
+        times, vals = [], []
+        for r in range(world):
+            t0 = time.perf_counter()
+            vals.append(np.asarray(compute(lists[r]), dtype=np.float64) if lists[r] else np.zeros(0))
+            times.append(time.perf_counter() - t0)
+        dist.emulate(times, [len(l) for l in lists])
+        return vals
+    mine = lists[rank]
+    per = max(1, max(len(l) for l in lists))
+    buf = np.zeros(per + 1)                    # last slot: this rank's error flag
+    failure = None
+    try:
+        buf[: len(mine)] = compute(mine) if mine else np.zeros(0)
+    except Exception as ex:                    # never skip the collective: the other ranks are already on their way to it
+        failure = ex
+        buf[:] = np.nan
+        buf[per] = 1.0
+    allv = _all_gather(dist, buf).reshape(world, per + 1)
+    _raise_if_failed(allv[:, per], failure, where)
+    return [allv[r, : len(lists[r])] for r in range(world)]
+
+
+def _deal(keys, world):
+    owner = deal_sets(keys, world)
+    return [[i for i in range(len(keys)) if owner[i] == r] for r in range(world)]
+
+
 def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
-    """Score a batch; with torch.distributed initialised the device-heavy candidates (CKDE node type under a
-    likelihood score: k sweeps each) are sharded over the ranks, while LinearGaussian candidates - O(p^3) host
-    arithmetic on replicated moments - are computed redundantly by every rank (sharding
-    them buys nothing and costs a collective)."""
+    """Score a batch; with torch.distributed initialised the device-heavy work (CKDE node type under a likelihood score: k sweeps
+    per term) is sharded over the ranks, while LinearGaussian candidates - O(p^3) host arithmetic on replicated moments - are computed
+    redundantly by every rank (sharding them buys nothing and costs a collective).
+    Continuous CKDE candidates are sharded by TERM: local(v | P) = A({v} u P) - A(P), and A({s}) serves every child of s, A({s, t})
+    both directions of the arc - dealing candidates made every rank sweep all 64 single-variable terms of the initial cache itself
+    (150 of its 535 ms at eight ranks, tools/scale_emulate.py).  The unknown terms of the batch are dealt by cost, evaluated
+    (pbn_score_terms), all-gathered and installed on every rank (pbn_score_terms_put); every rank then assembles the candidates from
+    the same doubles - the very sums the one-process run forms.  Candidates with discrete parents (hybrid scores) are dealt whole."""
     from . import _lib
 
     dist = _dist()
@@ -96,7 +148,6 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
     if dist is None or n == 0:
         return score._batch_raw(model, var, ntype, off, par, kind)
     heavy = [i for i in range(n) if shard_all or ntype[i] == _lib.PBN_NODE_CKDE]
-    light = [i for i in range(n) if not (shard_all or ntype[i] == _lib.PBN_NODE_CKDE)]
     out = np.zeros(n)
 
     def sub(idx):
@@ -106,18 +157,40 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
             o.append(len(p))
         return score._batch_raw(model, [var[i] for i in idx], [ntype[i] for i in idx], o, p, kind)
 
-    if light:
-        out[light] = sub(light)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_cont = len(score._table.names) if getattr(score, "_table", None) is not None else None   # column ids below it are continuous
+    by_term = [i for i in heavy if ntype[i] == _lib.PBN_NODE_CKDE and kind in (_lib.PBN_SCORE_CVLIK, _lib.PBN_SCORE_HOLDOUT) and n_cont is not None
+               and var[i] < n_cont and all(q < n_cont for q in par[off[i]: off[i + 1]]) and hasattr(score, "_terms")]
+    if len(by_term) >= 2:
+        terms, seen = [], {}
+        for i in by_term:
+            ps = list(par[off[i]: off[i + 1]])
+            d = len(ps) + 1
+            for key in ((d,) + tuple(sorted([var[i]] + ps)), ((d,) + tuple(sorted(ps))) if ps else None):
+                if key is not None and key not in seen:
+                    seen[key] = len(terms)
+                    terms.append(key)
+        missing = score._terms("missing", kind, terms)
+        todo = [t for t, mflag in zip(terms, missing) if mflag]
+        if todo:
+            lists = _deal([(t[1:], 0) for t in todo], world)
+            vals = _gather_shares(dist, world, rank, lists, lambda idx: score._terms("eval", kind, [todo[j] for j in idx]), "sharded_batch")
+            flat_t = [todo[j] for r in range(world) for j in lists[r]]
+            flat_v = np.concatenate([np.asarray(v, dtype=np.float64) for v in vals]) if flat_t else np.zeros(0)
+            score._terms("put", kind, flat_t, flat_v)
+        taken = set(by_term)
+        heavy = [i for i in heavy if i not in taken]
+    else:
+        by_term = []
+    rest = [i for i in range(n) if i not in set(heavy)]   # light candidates + the term-sharded ones: every rank, from the shared terms
+    if rest:
+        out[rest] = sub(rest)
     if len(heavy) < 2:
         if heavy:
             out[heavy] = sub(heavy)
         return out
-    import torch
-
-    rank, world = dist.get_rank(), dist.get_world_size()
-    m = len(heavy)
-    # candidates over the same variable set (s -> t and t -> s share their joint KDE sum in the engine's set-function
-    # cache) go to the same rank; the sets are dealt by cost (deal_sets), identically on every rank
+    # whole candidates (hybrid): those over the same variable set share their sums in the engine's set-function cache and go to the
+    # same rank; the sets are dealt by cost (deal_sets), identically on every rank
     set_of, counts = {}, []
     for i in heavy:
         key = tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))
@@ -125,24 +198,12 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
             set_of[key] = len(set_of)
             counts.append([key, 0])
         counts[set_of[key]][1] += 1
-    set_owner = deal_sets([(k, n) for k, n in counts], world)
+    set_owner = deal_sets([(k, c) for k, c in counts], world)
     owner = [set_owner[set_of[tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))]] for i in heavy]
-    lists = [[heavy[j] for j in range(m) if owner[j] == r] for r in range(world)]
-    mine = lists[rank]
-    per = max(1, max(len(l) for l in lists))
-    buf = np.zeros(per + 1)                    # last slot: this rank's error flag
-    failure = None
-    try:
-        local = sub(mine) if mine else np.zeros(0)
-        buf[: len(mine)] = local
-    except Exception as ex:                    # never skip the collective: the other ranks are already on their way to it
-        failure = ex
-        buf[:] = np.nan
-        buf[per] = 1.0
-    allv = _all_gather(dist, buf).reshape(world, per + 1)
-    _raise_if_failed(allv[:, per], failure, "sharded_batch")
+    lists = [[heavy[j] for j in range(len(heavy)) if owner[j] == r] for r in range(world)]
+    vals = _gather_shares(dist, world, rank, lists, sub, "sharded_batch")
     for r in range(world):
-        out[lists[r]] = allv[r, : len(lists[r])]
+        out[lists[r]] = vals[r]
     return out
 
 

@@ -185,7 +185,7 @@ class _DeviceScore(Score):
         from .distributed import reduce_moments, _dist
 
         dist = _dist()
-        if dist is None:
+        if dist is None or hasattr(dist, "emulate"):   # (emulate: the one-process scaling estimate of tools/scale_emulate.py)
             _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
                                                         float(ratio), C.byref(h)))
         else:
@@ -288,6 +288,30 @@ class _DeviceScore(Score):
                                                _lib.int_array(off), _lib.int_array(par if par else [0]),
                                                _lib.dptr(params) if params.size else None, int(params.size), _lib.dptr(out)))
         return out
+
+    def _terms(self, what, kind, terms, values=None):
+        """The CKDE likelihood terms of the engine (pbn_score_terms*): terms = [(m, column, column, ...)] over continuous column ids.
+        what = "eval" -> totals, "missing" -> flags, "put" -> install `values`."""
+        if not terms:
+            return np.zeros(0) if what == "eval" else []
+        off, vs, ms = [0], [], []
+        for t in terms:
+            ms.append(int(t[0]))
+            vs.extend(int(v) for v in t[1:])
+            off.append(len(vs))
+        lib, n = _lib.load(), len(terms)
+        args = (self._handle, kind, n, _lib.int_array(off), _lib.int_array(vs), _lib.int_array(ms))
+        if what == "eval":
+            out = np.zeros(n)
+            _lib.check(lib.pbn_score_terms(*args, _lib.dptr(out)))
+            return out
+        if what == "missing":
+            flags = (C.c_int * n)()
+            _lib.check(lib.pbn_score_terms_missing(*args, flags))
+            return list(flags)
+        vals = np.ascontiguousarray(values, dtype=np.float64)
+        _lib.check(lib.pbn_score_terms_put(*args, _lib.dptr(vals)))
+        return None
 
     def _batch_params(self, model):
         return self._params

@@ -581,3 +581,49 @@ def test_cv_likelihood_ckde_with_18_parents(pbn, oracle):
     got = score.local_score_node_type(pbn.SemiparametricBN(names), pbn.CKDEType(), "v0", names[1:])
     want = oracle.cv_likelihood(data, "ckde", 3, 5)
     assert abs(got - want) <= RTOL_F64 * abs(want)
+
+
+@pytest.mark.parametrize("kind", ["cv", "holdout"])
+def test_ckde_terms_are_the_halves_of_the_local_score(pbn, kind):
+    """pbn_score_terms / _put / _missing (a job with one process per GPU deals the TERMS of a delta-cache batch):
+    local(v | P) = A({v} u P, d) - A(P, d) bit for bit; totals installed in a fresh handle reproduce the scores without a sweep."""
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(8)
+    n = 6000
+    a = rng.normal(size=n)
+    b = 0.6 * a + rng.normal(scale=0.7, size=n)
+    c = np.sin(a) + 0.3 * b + rng.normal(scale=0.5, size=n)
+    d = rng.normal(size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c, "d": d})
+    make = (lambda: pbn.CVLikelihood(df, k=4, seed=1)) if kind == "cv" else (lambda: pbn.HoldoutLikelihood(df, test_ratio=0.25, seed=1))
+    code = _lib.PBN_SCORE_CVLIK if kind == "cv" else _lib.PBN_SCORE_HOLDOUT
+    net = pbn.SemiparametricBN(list("abcd"), [], [(v, pbn.CKDEType()) for v in "abcd"])
+    cands = [("c", ["a", "b"]), ("b", ["a"]), ("a", ["b"]), ("d", []), ("c", ["b", "a"])]
+    col = {v: i for i, v in enumerate("abcd")}
+    score = make()
+    want = [score.local_score(net, v, p) for v, p in cands]
+    terms = []
+    for v, p in cands:
+        m = len(p) + 1
+        terms.append((m,) + tuple(col[x] for x in [v] + p))
+        if p:
+            terms.append((m,) + tuple(col[x] for x in p))
+    fresh = make()
+    assert fresh._terms("missing", code, terms) == [1] * len(terms)
+    vals = fresh._terms("eval", code, terms)
+    it = iter(vals)
+    for (v, p), w in zip(cands, want):
+        j = next(it)
+        mg = next(it) if p else 0.0
+        assert j - mg == w, (v, p)
+    # A({a, b}, 2) serves a -> b and b -> a; the column order of a term does not matter
+    assert fresh._terms("eval", code, [(2, col["a"], col["b"]), (2, col["b"], col["a"])]).tolist() == [vals[2], vals[2]]
+    other = make()
+    other._terms("put", code, terms, vals)
+    assert other._terms("missing", code, terms + [(2, col["d"], col["a"])]) == [0] * len(terms) + [1]
+    before = other.kde_cache_stats()[1]
+    assert [other.local_score(net, v, p) for v, p in cands] == want
+    assert other.kde_cache_stats()[1] == before        # assembled from the installed totals: not one sweep
+    with pytest.raises(ValueError, match="term"):
+        fresh._terms("eval", code, [(4, col["a"], col["b"])])
