@@ -182,7 +182,8 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
         heavy = [i for i in heavy if i not in taken]
     else:
         by_term = []
-    rest = [i for i in range(n) if i not in set(heavy)]   # light candidates + the term-sharded ones: every rank, from the shared terms
+    whole = set(heavy)
+    rest = [i for i in range(n) if i not in whole]   # light candidates + the term-sharded ones: every rank, from the shared terms
     if rest:
         out[rest] = sub(rest)
     if len(heavy) < 2:

@@ -8,5 +8,7 @@ python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --hc c3 --hc-ma
 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --hc cv64 --no-c3 > $O/bench_cv64.json 2> $O/bench_cv64.err
 (time python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err) 2> $O/bench_default.time
 PBN_BENCH_DEVICE=0 python3 bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 > $O/bench_gloo2.json 2> $O/bench_gloo2.err
+SCALE_DETAIL=1 python3 tools/scale_emulate.py 1,2,4,8 2>&1 | grep -v amdgpu.ids > $O/scale_emulate.txt
+bash tools/gram_evidence.sh > $O/gram_paths.txt 2>&1
 find $O -name "*.csv" -size +2M -delete
 ls -la $O
