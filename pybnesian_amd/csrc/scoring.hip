@@ -1127,6 +1127,7 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
     return score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, params, n_params, out, nullptr);
 }
 
+extern "C++" {
 namespace {
 // term i = columns vars[off[i] .. off[i + 1]) under the bandwidth rule for m[i] dimensions: m = the number of columns for a joint term,
 // one more for the marginal term of a candidate with those parents
@@ -1147,6 +1148,7 @@ std::vector<int> term_key(const int* v, int nv, int m) {
     return k;
 }
 }  // namespace
+}  // extern "C++"
 
 int pbn_score_terms(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, double* out) {
     return guarded(mu_of(sd), [&] {
