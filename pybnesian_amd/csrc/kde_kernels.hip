@@ -1470,6 +1470,11 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     };
 
     bf8 fA[NB], fB[NB], xA, xB;
+    // (Measured and dropped, profiles/r3/prune_stream_probe.txt: the visit masks of the whole split taken first - lane w keeping the mask of
+    //  batch w - and the kept tiles then walked as ONE stream across the batches through a ring of 3 or 4 tile fragments, the next set bit
+    //  coming from scalar code on a v_readlane'd word.  The fp32 slice sweeps ran 9-12 % SLOWER (1.92 against 1.71 ms at 720 000 x 80 000,
+    //  d = 2), C5 9.67 against 9.36 s, with 3 waves per SIMD 10.7 s: the loop is not waiting for its tiles - four waves per SIMD cover the
+    //  one tile of prefetch - and the ring's 8-12 registers push the 128-register kernel into scratch.)
     if constexpr (PRUNE) {
         if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
         for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
