@@ -923,7 +923,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 if (sd->term_total.empty()) return false;
                 std::vector<int> k(v, v + nv);
                 std::sort(k.begin(), k.end());
-                k.insert(k.begin(), m);
+                k.insert(k.begin(), {kind, m});   // a validated score asks one handle for both kinds
                 auto it = sd->term_total.find(k);
                 if (it == sd->term_total.end()) return false;
                 t.value = region_index == 0 ? it->second : 0.0;
@@ -1141,10 +1141,10 @@ void check_terms(const pbn_scoredata* sd, int kind, int n_terms, const int* off,
             if (vars[j] < 0 || vars[j] >= sd->n) throw invalid_error(std::string(who) + ": continuous columns only");
     }
 }
-std::vector<int> term_key(const int* v, int nv, int m) {
+std::vector<int> term_key(int kind, const int* v, int nv, int m) {
     std::vector<int> k(v, v + nv);
     std::sort(k.begin(), k.end());
-    k.insert(k.begin(), m);
+    k.insert(k.begin(), {kind, m});
     return k;
 }
 }  // namespace
@@ -1184,7 +1184,7 @@ int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off
     return guarded(mu_of(sd), [&] {
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_put");
         if (n_terms > 0 && !values) throw invalid_error("pbn_score_terms_put: null values");
-        for (int i = 0; i < n_terms; ++i) sd->term_total[term_key(vars + off[i], off[i + 1] - off[i], m[i])] = values[i];
+        for (int i = 0; i < n_terms; ++i) sd->term_total[term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])] = values[i];
     });
 }
 
@@ -1193,7 +1193,7 @@ int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int*
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_missing");
         if (n_terms > 0 && !missing) throw invalid_error("pbn_score_terms_missing: null output");
         for (int i = 0; i < n_terms; ++i)
-            missing[i] = sd->term_total.find(term_key(vars + off[i], off[i + 1] - off[i], m[i])) == sd->term_total.end() ? 1 : 0;
+            missing[i] = sd->term_total.find(term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])) == sd->term_total.end() ? 1 : 0;
     });
 }
 

@@ -50,7 +50,7 @@ struct pbn_scoredata {
     int selector = PBN_SEL_NORMAL_REFERENCE;  // bandwidth selector of the CKDEs fitted while scoring
     // A(S, m) of the CKDE likelihood scores, keyed by [region, m, sorted columns...] (see pbn_score_batch)
     std::map<std::vector<int>, double> kde_cache;
-    // totals of A(S, m) over the split's test regions, keyed by [m, sorted columns...]: installed by pbn_score_terms_put (values another
+    // totals of A(S, m) over the test regions of a score kind, keyed by [kind, m, sorted columns...]: installed by pbn_score_terms_put (values another
     // rank computed) and preferred over kde_cache, so that every rank of a job assembles a candidate from the very same doubles
     std::map<std::vector<int>, double> term_total;
     int64_t kde_sweeps = 0;

@@ -627,3 +627,29 @@ def test_ckde_terms_are_the_halves_of_the_local_score(pbn, kind):
     assert other.kde_cache_stats()[1] == before        # assembled from the installed totals: not one sweep
     with pytest.raises(ValueError, match="term"):
         fresh._terms("eval", code, [(4, col["a"], col["b"])])
+
+
+def test_ckde_terms_of_a_validated_score_keep_their_kind(pbn):
+    """ValidatedLikelihood asks ONE handle for both kinds (CV over the training part: local_score; the hold-out part: vlocal_score).
+    The installed totals are keyed by kind: the same variable set has one total per kind."""
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(9)
+    n = 5000
+    a = rng.normal(size=n)
+    b = 0.5 * a + rng.normal(scale=0.8, size=n)
+    c = np.cos(a) + 0.4 * b + rng.normal(scale=0.5, size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c})
+    make = lambda: pbn.ValidatedLikelihood(df, test_ratio=0.3, k=3, seed=4)
+    net = pbn.SemiparametricBN(list("abc"), [], [(v, pbn.CKDEType()) for v in "abc"])
+    ref = make()
+    want = [(ref.local_score(net, "c", ["a", "b"]), ref.vlocal_score(net, "c", ["a", "b"])), (ref.local_score(net, "b", ["a"]), ref.vlocal_score(net, "b", ["a"]))]
+    terms = [(3, 2, 0, 1), (3, 0, 1), (2, 1, 0), (2, 0)]
+    src, dst = make(), make()
+    for kind in (_lib.PBN_SCORE_CVLIK, _lib.PBN_SCORE_HOLDOUT):
+        dst._terms("put", kind, terms, src._terms("eval", kind, terms))
+    assert dst._terms("missing", _lib.PBN_SCORE_CVLIK, terms) == [0] * 4 and dst._terms("missing", _lib.PBN_SCORE_HOLDOUT, terms) == [0] * 4
+    before = dst.kde_cache_stats()[1]
+    got = [(dst.local_score(net, "c", ["a", "b"]), dst.vlocal_score(net, "c", ["a", "b"])), (dst.local_score(net, "b", ["a"]), dst.vlocal_score(net, "b", ["a"]))]
+    assert got == want and want[0][0] != want[0][1]
+    assert dst.kde_cache_stats()[1] == before
