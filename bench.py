@@ -630,8 +630,9 @@ def main():
         if dist is not None and hc_out.get("value") is not None:
             hc_out["ranks"] = world
             hc_out["scaling"] = "strong"
-            hc_out["sharding"] = ("CKDE candidates of every delta-cache batch dealt to the ranks by variable set (longest processing time first), "
-                                  "one all_gather of the batch's scores per batch; fixed total work (strong scaling of the search)")
+            hc_out["sharding"] = ("the unknown CKDE terms A(joint), A(marginal) of every delta-cache batch dealt to the ranks (longest processing time first), "
+                                  "one all_gather of their totals per batch, every rank assembles the deltas from the same doubles; fixed total work "
+                                  "(strong scaling of the search)")
     if hc_auto and not args.no_extra_legs:
         # the north star's weak form: delta cells per rank constant - n = round(64 sqrt(N / 8)) nodes (23 on one GPU ... 64 on
         # eight), 100 k rows, cache_scores + 5 iterations
@@ -640,6 +641,39 @@ def main():
         if legs["secondary_cv_weak"].get("value") is not None:
             legs["secondary_cv_weak"].update({"ranks": world, "scaling": "weak", "nodes": wn,
                                               "note": "cells scale with nodes^2: nodes = round(64 sqrt(ranks / 8)) keeps cells per rank constant"})
+        if world == 1 and dist is None and legs["secondary_cv_weak"].get("value") is not None:
+            # No 8-GPU node at hand: ONE process plays the eight ranks of the same leg in turn (64 nodes) and times every rank's share
+            # of every batch (distributed.sharded_batch's emulation hook, tools/scale_emulate.py).  An 8-rank job waits per batch for
+            # its slowest share and repeats the unsharded work: T_8 ~ (time - sum of the shares) + sum over batches of the slowest
+            # share.  An ESTIMATE: no collective latency, one process's caches - never the leg's `value`.
+            try:
+                from pybnesian_amd import distributed as pdist
+
+                class _Eight:
+                    batches = []
+                    get_rank = staticmethod(lambda: 0)
+                    get_world_size = staticmethod(lambda: 8)
+                    get_backend = staticmethod(lambda: "emulated")
+                    emulate = staticmethod(lambda times, counts: _Eight.batches.append(times))
+
+                pdist._EMULATED = _Eight
+                try:
+                    r8 = bench_hill_climb(torch, pbn, _lib, ctx, device, "cv64", args.hc_rows, 5, n_cols=64, cpu=False)
+                finally:
+                    pdist._EMULATED = None
+                one = r8["estimate_s"] + r8.get("score_ctor_s", 0.0)
+                shares = sum(sum(t) for t in _Eight.batches)
+                slow = sum(max(t) for t in _Eight.batches)
+                t8 = one - shares + slow
+                w1 = legs["secondary_cv_weak"]
+                t1 = w1["estimate_s"] + w1.get("score_ctor_s", 0.0)
+                legs["secondary_cv_weak"]["eight_rank_estimate"] = {
+                    "kind": "one-process emulation, not a multi-GPU measurement", "nodes": 64, "cells_scored": r8["cells_scored"], "batches": len(_Eight.batches),
+                    "one_process_s": one, "per_rank_s": t8, "slowest_over_mean_share": slow / (shares / 8.0) if shares else None,
+                    "arcs_per_s": r8["cells_scored"] / t8, "ratio_to_one_rank_leg": (r8["cells_scored"] / t8) / (w1["cells_scored"] / t1),
+                    "method": "per batch the slowest of the eight shares (terms dealt by cost), plus the unsharded time; collective latency and per-rank caches not modelled"}
+            except Exception as ex:   # an estimate must never cost the line
+                legs["secondary_cv_weak"]["eight_rank_estimate"] = {"error": f"{type(ex).__name__}: {ex}"}
     if hc_auto and world == 1 and not args.no_extra_legs:
         if not args.no_c3:
             # the CKDE path of the search, driver-timed: BASELINE config 3 at FULL size (32-node SPBN, 10-fold CV, 500 k rows),
