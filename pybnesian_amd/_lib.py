@@ -81,6 +81,7 @@ SIGNATURES = {
     "pbn_lg_logl": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp, _dp]),
     "pbn_lg_cdf": (_int, [_vp, _ip, _int, _i64, _i64, _dp, C.c_double, _dp]),
     "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
+    "pbn_score_batch_parts": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _int, _int, _dp]),
     "pbn_score_terms": (_int, [_vp, _int, _int, _ip, _ip, _ip, _dp]),
     "pbn_score_terms_put": (_int, [_vp, _int, _int, _ip, _ip, _ip, _dp]),
     "pbn_score_terms_missing": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip]),

@@ -338,8 +338,10 @@ double local_lg_slogl(const pbn_scoredata* sd, const Stats& test, const int* col
 
 }  // namespace
 
-double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p) {
+double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts) {
     const int n = sd->n;
+    if (parts && (node_type != PBN_NODE_CKDE || var >= n || (kind != PBN_SCORE_CVLIK && kind != PBN_SCORE_HOLDOUT)))
+        throw invalid_error("pbn_score_batch_parts: CKDE candidates of a likelihood score only");
     if (kind == PBN_SCORE_BGE) throw invalid_error("BGe is not defined for networks with discrete variables.");
     if (var >= n) {
         if (node_type != PBN_NODE_DISCRETE) throw invalid_error("pbn_score_batch: discrete column scored with a continuous node type");
@@ -424,7 +426,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     // A({y}) serves every child of y under D.  All sweeps of the candidate are enqueued back to back - gather lists are
     // device resident - with ONE synchronisation at the end.
     struct Term { double value = 0; int slot = -1; };
-    struct Slice { Term joint, marg; bool has_marg; };
+    struct Slice { Term joint, marg; bool has_marg; int part; };
     std::vector<Slice> slices;
     std::vector<std::vector<int>> slot_key;
     dev_buf<double> dsums;
@@ -518,6 +520,10 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             const Stats* te;
             if (cv) { stats_minus(allc[c], M[cell(c, u)], train); tr = &train; te = &M[cell(c, u)]; }
             else { tr = &M[cell(c, 0)]; te = &M[cell(c, 1)]; }
+            // the slice's part (scoring_internal.hpp): folds of one configuration are consecutive parts, so that the ranks of a job
+            // share every configuration's sweeps - the large configurations above all
+            const int part = (int)(((int64_t)c * units + u) % PBN_HYBRID_PARTS);
+            if (parts && !((parts->owned >> part) & 1ull)) continue;
             if (tr->N == 0) continue;  // empty training slice -> no factor (DiscreteAdaptator.hpp:266-268)
             local_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
             if (node_type == PBN_NODE_LG) {
@@ -548,7 +554,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             const int64_t base = g.off[cell(c, 0)];
             int64_t tr_row0 = base, tr_n0 = tr->N, tr_row1 = 0, te0 = g.off[cell(c, 1)];
             if (cv) { tr_n0 = g.off[cell(c, u)] - base; tr_row1 = g.off[cell(c, u) + 1]; te0 = g.off[cell(c, u)]; }
-            Slice sl{{}, {}, pc > 0};
+            Slice sl{{}, {}, pc > 0, part};
             // fp32 (bf16x3) slices with neither term known: the fused joint + marginal sweep - there the extra MFMA step hides
             // under the exponentials and one pack / one launch serves both terms (C5: 22.3 s of sweeps fused against 24.2 s as
             // two plain ones); fp64 slices and slices with one term cached take the plain sweeps
@@ -638,15 +644,22 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->drop_staged();
         for (size_t i = 0; i < slot_key.size(); ++i) sd->kde_cache[slot_key[i]] = hs[i];
+        // per-part sums in slice order, then the parts in part order: what a job with one process per GPU adds up, too
+        double pacc[PBN_HYBRID_PARTS] = {};
         for (const Slice& sl : slices) {
             const double jv = sl.joint.slot >= 0 ? hs[sl.joint.slot] : sl.joint.value;
             const double mv = !sl.has_marg ? 0.0 : (sl.marg.slot >= 0 ? hs[sl.marg.slot] : sl.marg.value);
-            acc += jv - mv;
+            pacc[sl.part] += jv - mv;
         }
+        for (int q = 0; q < PBN_HYBRID_PARTS; ++q) acc += pacc[q];
+        if (parts)
+            for (int q = 0; q < PBN_HYBRID_PARTS; ++q) parts->out[q] = pacc[q];
     } else if (node_type == PBN_NODE_CKDE) {
         if (lanes > 1) ctx->sync_lanes(lanes - 1);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->drop_staged();
+        if (parts)
+            for (int q = 0; q < PBN_HYBRID_PARTS; ++q) parts->out[q] = 0.0;
     }
     return acc;
 }

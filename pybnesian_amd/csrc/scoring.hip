@@ -744,8 +744,11 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
 
 // `want` (nullable, per candidate): 0 = the local score; 1 / 2 = only the joint / only the marginal CKDE term of the candidate, summed
 // over the regions (pbn_score_terms)
+// `parts_owned` / `parts_out` (pbn_score_batch_parts): hybrid CKDE candidates evaluated on the owned parts only, per-part sums to
+// parts_out[c * PBN_HYBRID_PARTS ...]
 static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
-                            const int* parents, const double* params, int n_params, double* out, const int* want) {
+                            const int* parents, const double* params, int n_params, double* out, const int* want,
+                            unsigned long long parts_owned = 0, double* parts_out = nullptr) {
     return guarded(mu_of(sd), [&] {
         if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
         pbn_ctx* ctx = sd->ctx;
@@ -796,6 +799,11 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 // local score the node had before that arc was added, every FlipArc cell's source side likewise.  They
                 // are remembered by parent set (the value depends on the parent ORDER only through rounding, ~1e-13,
                 // and these scores are not score-equivalent: no exact ties to flip).  BIC stays out: bic_clg ties.
+                if (parts_out) {   // a share of the candidate: never memoised
+                    HybridParts hp{parts_owned, parts_out + (size_t)c * PBN_HYBRID_PARTS};
+                    out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp);
+                    continue;
+                }
                 const bool memo = score_memo_on() && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT) && nt != PBN_NODE_DISCRETE;
                 std::vector<int> key;
                 if (memo) {
@@ -1185,6 +1193,27 @@ int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_put");
         if (n_terms > 0 && !values) throw invalid_error("pbn_score_terms_put: null values");
         for (int i = 0; i < n_terms; ++i) sd->term_total[term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])] = values[i];
+    });
+}
+
+int pbn_score_batch_parts(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
+                          const int* parents, int part, int n_parts, double* out) {
+    return guarded(mu_of(sd), [&] {
+        if (!sd || !var || !node_type || !par_off || !out) throw invalid_error("pbn_score_batch_parts: null argument");
+        if (n_parts < 1 || n_parts > PBN_HYBRID_PARTS || part < 0 || part >= n_parts) throw invalid_error("pbn_score_batch_parts: part / n_parts out of range (at most 64 parts)");
+        for (int c = 0; c < n_cand; ++c) {
+            bool disc = false;
+            for (int j = par_off[c]; j < par_off[c + 1]; ++j) disc = disc || parents[j] >= sd->n;
+            if (!disc || node_type[c] != PBN_NODE_CKDE) throw invalid_error("pbn_score_batch_parts: CKDE candidates with discrete parents only");
+        }
+        unsigned long long owned = 0;
+        for (int q = part; q < PBN_HYBRID_PARTS; q += n_parts) owned |= 1ull << q;
+        std::vector<double> whole((size_t)std::max(n_cand, 1));
+        std::fill(out, out + (size_t)n_cand * PBN_HYBRID_PARTS, 0.0);
+        if (n_cand > 0) {
+            const int rc = score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, nullptr, 0, whole.data(), nullptr, owned, out);
+            if (rc != PBN_OK) throw device_error(pbn_last_error());
+        }
     });
 }
 

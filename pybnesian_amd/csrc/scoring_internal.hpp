@@ -110,7 +110,15 @@ double lg_slogl_from_rows(const pbn_table* t, const int* cols, int d, int64_t ro
 double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const int* cols, int p, const double* beta,
                              double variance);
 // hybrid.hip: candidates with a discrete variable or discrete parents (synchronous)
-double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p);
+// The CKDE slices (configuration c, region u) of a hybrid candidate fall into PBN_HYBRID_PARTS = 64 fixed PARTS, part = (c * regions + u) mod 64,
+// and the candidate's score is the sum of its parts in part order - with one process as with many: a job with one process per GPU
+// evaluates on rank r only the parts p = r (mod world) (HybridParts::owned) and hands out the per-part sums (pbn_score_batch_parts).
+constexpr int PBN_HYBRID_PARTS = 64;
+struct HybridParts {
+    unsigned long long owned;   // bit p: evaluate part p
+    double* out;                // [PBN_HYBRID_PARTS] per-part sums (0 for the parts not owned)
+};
+double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts = nullptr);
 
 }  // namespace score
 }  // namespace pbn

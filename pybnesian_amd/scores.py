@@ -289,6 +289,15 @@ class _DeviceScore(Score):
                                                _lib.dptr(params) if params.size else None, int(params.size), _lib.dptr(out)))
         return out
 
+    def _batch_parts(self, model, var, ntype, off, par, kind, part, n_parts):
+        """Per-part sums (len(var) x 64) of hybrid CKDE candidates on the parts p = part (mod n_parts): pbn_score_batch_parts."""
+        n = len(var)
+        out = np.zeros((n, 64))
+        if n:
+            _lib.check(_lib.load().pbn_score_batch_parts(self._handle, kind, n, _lib.int_array(var), _lib.int_array(ntype), _lib.int_array(off),
+                                                         _lib.int_array(par if par else [0]), int(part), int(n_parts), _lib.dptr(out)))
+        return out
+
     def _terms(self, what, kind, terms, values=None):
         """The CKDE likelihood terms of the engine (pbn_score_terms*): terms = [(m, column, column, ...)] over continuous column ids.
         what = "eval" -> totals, "missing" -> flags, "put" -> install `values`."""

@@ -57,7 +57,26 @@ def run(fail_rank=-1):
         gauss[tag + "_trace"] = [[kinds[type(op)], op.source(), op.target()] for op in h2.last.trace]
         gauss[tag + "_deltas"] = [op.delta().hex() for op in h2.last.trace]
         gauss[tag + "_arcs"] = sorted(r2.arcs())
-    return {**gauss, "trace": trace, "deltas": [op.delta() for op in hc.last.trace], "arcs": sorted(res.arcs()),
+    # hybrid table (CKDE children of discrete parents): the slices of every such candidate are shared by the ranks (64 fixed parts,
+    # pbn_score_batch_parts) - the per-part sums added over the ranks and then in part order are the one-process score, bit for bit
+    hr = np.random.default_rng(23)
+    hn = 9000
+    d1 = hr.integers(0, 3, size=hn)
+    d2 = (hr.random(hn) < 0.35).astype(np.int64)
+    x = hr.normal(size=hn) + 0.9 * d1
+    y = np.tanh(x) * (1 + 0.5 * d2) + hr.normal(scale=0.4, size=hn)
+    z = 0.5 * y + hr.normal(scale=0.7, size=hn) - 0.6 * d2
+    hdf = pd.DataFrame({"x": x, "y": y, "z": z})
+    hdf["d1"] = pd.Categorical.from_codes(d1, ["a", "b", "c"])
+    hdf["d2"] = pd.Categorical.from_codes(d2, ["p", "q"])
+    hs = pbn.CVLikelihood(hdf, 4, 2)
+    hstart = pbn.SemiparametricBN(list(hdf.columns), [], [(n, pbn.CKDEType()) for n in "xyz"])
+    h3 = pbn.GreedyHillClimbing()
+    r3 = h3.estimate(pbn.OperatorPool([pbn.ArcOperatorSet(), pbn.ChangeNodeTypeSet()]), hs, hstart, max_indegree=3)
+    hyb = {"hyb_trace": [[3, op.node(), str(op.node_type())] if isinstance(op, pbn.ChangeNodeType) else [kinds[type(op)], op.source(), op.target()]
+                         for op in h3.last.trace],
+           "hyb_deltas": [op.delta().hex() for op in h3.last.trace], "hyb_arcs": sorted(r3.arcs()), "hyb_sweeps": hs.kde_cache_stats()[1]}
+    return {**gauss, **hyb, "trace": trace, "deltas": [op.delta() for op in hc.last.trace], "arcs": sorted(res.arcs()),
             "types": [str(res.node_type(n)) for n in names], "cells": hc.last.cells_scored, "sweeps": sweeps,
             "slogl": distributed.sharded_slogl(kde, test)}
 

@@ -61,6 +61,10 @@ def test_sharded_delta_cache_with_device_ckde_scores_world2():
             assert r[tag + "_trace"] == single[tag + "_trace"]
             assert r[tag + "_deltas"] == single[tag + "_deltas"]
             assert r[tag + "_arcs"] == single[tag + "_arcs"]
+        # hybrid candidates: their slices shared by the ranks, per-part sums added in part order - the one-process deltas, bit for bit
+        assert len(single["hyb_trace"]) >= 3 and any(a in ("d1", "d2") for a, _ in single["hyb_arcs"])
+        assert r["hyb_trace"] == single["hyb_trace"] and r["hyb_deltas"] == single["hyb_deltas"] and r["hyb_arcs"] == single["hyb_arcs"]
+    assert max(r["hyb_sweeps"] for r in ranks) < single["hyb_sweeps"]
     # the device work was split, and no term was swept twice: together the ranks made exactly the single process's (term, fold) sweeps
     assert max(r["sweeps"] for r in ranks) < single["sweeps"]
     assert sum(r["sweeps"] for r in ranks) == single["sweeps"]

@@ -213,3 +213,45 @@ def test_conditional_factor_by_assignment(pbn):
     asg = pbn.Assignment({"A": "a0", "B": "b1"})
     assert asg.size() == 2 and not asg.empty() and asg.value("B") == "b1" and asg == pbn.Assignment({"B": "b1", "A": "a0"})
     assert dict(iter(asg)) == {"A": "a0", "B": "b1"} and hash(asg) == hash(pbn.Assignment({"B": "b1", "A": "a0"}))
+
+
+@pytest.mark.parametrize("dtype,kind", [("float64", "cv"), ("float32", "cv"), ("float64", "holdout")])
+def test_hybrid_ckde_parts_add_up_to_the_local_score(pbn, dtype, kind):
+    """pbn_score_batch_parts: the slices (configuration, fold) of a CKDE candidate with discrete parents fall into 64 fixed parts; the
+    per-part sums of any split into n ranks, added over the ranks and then over the parts in order, are pbn_score_batch's value bit
+    for bit (the ranks of a job share a candidate's slices)."""
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(31)
+    n = 12000
+    d1 = rng.integers(0, 3, size=n)
+    d2 = (rng.random(n) < 0.3).astype(np.int64)
+    x = rng.normal(size=n) + 0.7 * d1
+    y = np.sin(x) * (1 + 0.4 * d2) + rng.normal(scale=0.5, size=n)
+    z = 0.6 * y - 0.3 * x + rng.normal(scale=0.6, size=n)
+    df = pd.DataFrame({"x": x, "y": y, "z": z}).astype(dtype)
+    df["d1"] = pd.Categorical.from_codes(d1, ["a", "b", "c"])
+    df["d2"] = pd.Categorical.from_codes(d2, ["p", "q"])
+    make = (lambda: pbn.CVLikelihood(df, k=5, seed=3)) if kind == "cv" else (lambda: pbn.HoldoutLikelihood(df, test_ratio=0.25, seed=3))
+    code = _lib.PBN_SCORE_CVLIK if kind == "cv" else _lib.PBN_SCORE_HOLDOUT
+    net = pbn.SemiparametricBN(list(df.columns), [], [(v, pbn.CKDEType()) for v in "xyz"])
+    cands = [("y", ["x", "d1"]), ("z", ["d2", "y", "d1"]), ("x", ["d1"]), ("z", ["y", "x", "d2"])]
+    ref = make()
+    want = [ref.local_score(net, v, p) for v, p in cands]
+    var, ntype, off, par = ref._encode([(v, pbn.CKDEType(), p) for v, p in cands])
+    for world in (1, 3, 8, 64):
+        score = make()   # fresh caches: every rank's share is really evaluated
+        total = np.zeros((len(cands), 64))
+        for r in range(world):
+            share = score._batch_parts(net, var, ntype, off, par, code, r, world)
+            assert np.all((share == 0) | (total == 0))   # a part is non-zero on one rank only
+            total += share
+        got = []
+        for row in total:
+            acc = 0.0
+            for v in row.tolist():
+                acc += v
+            got.append(acc)
+        assert got == want, (world, got, want)
+    with pytest.raises(ValueError, match="discrete parents"):
+        ref._batch_parts(net, [0], [_lib.PBN_NODE_CKDE], [0, 1], [1], code, 0, 2)

@@ -15,6 +15,8 @@ from pybnesian_amd import _lib, distributed
 worlds = [int(w) for w in (sys.argv[1] if len(sys.argv) > 1 else "1,2,4,8").split(",")]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+# SCALE_WHICH=c5: BASELINE config 5's hill-climb (hybrid candidates, dealt whole by variable set) with FIXED work on every world size
+which = os.environ.get("SCALE_WHICH", "cv64")
 
 
 class Fake:
@@ -34,11 +36,14 @@ dev = torch.device("cuda", 0)
 ctx = pbn.default_context()
 base = None
 for w in worlds:
-    nodes = round(64 * (w / 8) ** 0.5)
+    nodes = round(64 * (w / 8) ** 0.5) if which == "cv64" else 48
     fake = Fake(w)
     distributed._EMULATED = fake if w > 1 else None
     t0 = time.perf_counter()
-    res = bench.bench_hill_climb(torch, pbn, _lib, ctx, dev, "cv64", rows, iters, n_cols=nodes, cpu=False)
+    if which == "cv64":
+        res = bench.bench_hill_climb(torch, pbn, _lib, ctx, dev, "cv64", rows, iters, n_cols=nodes, cpu=False)
+    else:
+        res = bench.bench_hill_climb(torch, pbn, _lib, ctx, dev, "c5", 0, 1_000_000, cpu=False)
     wall = time.perf_counter() - t0
     est = res["estimate_s"] + res.get("score_ctor_s", 0.0)
     if w == 1:
