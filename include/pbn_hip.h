@@ -253,9 +253,10 @@ int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off
 int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, int* missing);
 /* CKDE candidates with discrete parents (DiscreteAdaptator.hpp:201-348: one CKDE per configuration of the discrete parents): the
  * slices (configuration c, test region u) of a candidate fall into 64 fixed parts, part = (c * regions + u) mod 64, and
- * pbn_score_batch forms the score as the sum of the parts in part order.  pbn_score_batch_parts evaluates only the parts
- * p = part (mod n_parts) (n_parts <= 64: the ranks of a job) and returns the per-part sums, out[c * 64 + p]: added over the ranks
- * (every part is non-zero on one rank only) and then over p in order they give pbn_score_batch's value bit for bit.  The update
+ * pbn_score_batch forms the score as the sum of the parts in part order.  pbn_score_batch_parts evaluates only the parts dealt
+ * to rank `part` of `n_parts` (<= 64) - longest-processing-time first on the slices' training x test rows, the same dealing on
+ * every rank - and returns the per-part sums, out[c * 64 + p]: added over the ranks (every part is non-zero on one rank only) and
+ * then over p in order they give pbn_score_batch's value bit for bit.  The update
  * batches of a restricted hill-climb hold a handful of such candidates - fewer than ranks; their slices are what can be shared. */
 int pbn_score_batch_parts(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                           const int* parents, int part, int n_parts, double* out);

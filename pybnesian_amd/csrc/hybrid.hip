@@ -514,16 +514,39 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         gb.pools[pi].test_unit[U.test_region] = (int32_t)pool_units[pi].size();
         pool_units[pi].push_back(U);
     };
+    // the parts this call evaluates (scoring_internal.hpp): all of them, or those dealt to one rank of a job
+    unsigned long long owned = ~0ull;
+    if (parts && parts->world > 1) {
+        double cost[PBN_HYBRID_PARTS] = {};
+        for (int u = 0; u < units; ++u)
+            for (int c = 0; c < g.nc; ++c) {
+                const double ntr = (double)(cv ? allc[c].N - M[cell(c, u)].N : M[cell(c, 0)].N);
+                const double nte = (double)(cv ? M[cell(c, u)].N : M[cell(c, 1)].N);
+                cost[((int64_t)c * units + u) % PBN_HYBRID_PARTS] += ntr * nte;
+            }
+        int order[PBN_HYBRID_PARTS];
+        for (int q = 0; q < PBN_HYBRID_PARTS; ++q) order[q] = q;
+        std::stable_sort(order, order + PBN_HYBRID_PARTS, [&](int a, int b) { return cost[a] > cost[b]; });
+        std::vector<double> load((size_t)parts->world, 0.0);
+        owned = 0;
+        for (int i = 0; i < PBN_HYBRID_PARTS; ++i) {
+            const int q = order[i];
+            int best = 0;
+            for (int r = 1; r < parts->world; ++r)
+                if (load[r] < load[best]) best = r;
+            load[best] += cost[q];
+            if (best == parts->rank) owned |= 1ull << q;
+        }
+    }
     for (int u = 0; u < units; ++u) {
         for (int c = 0; c < g.nc; ++c) {
             const Stats* tr;
             const Stats* te;
             if (cv) { stats_minus(allc[c], M[cell(c, u)], train); tr = &train; te = &M[cell(c, u)]; }
             else { tr = &M[cell(c, 0)]; te = &M[cell(c, 1)]; }
-            // the slice's part (scoring_internal.hpp): folds of one configuration are consecutive parts, so that the ranks of a job
-            // share every configuration's sweeps - the large configurations above all
+            // the slice's part: folds of one configuration are consecutive parts
             const int part = (int)(((int64_t)c * units + u) % PBN_HYBRID_PARTS);
-            if (parts && !((parts->owned >> part) & 1ull)) continue;
+            if (!((owned >> part) & 1ull)) continue;
             if (tr->N == 0) continue;  // empty training slice -> no factor (DiscreteAdaptator.hpp:266-268)
             local_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
             if (node_type == PBN_NODE_LG) {

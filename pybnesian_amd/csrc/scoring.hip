@@ -744,11 +744,11 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
 
 // `want` (nullable, per candidate): 0 = the local score; 1 / 2 = only the joint / only the marginal CKDE term of the candidate, summed
 // over the regions (pbn_score_terms)
-// `parts_owned` / `parts_out` (pbn_score_batch_parts): hybrid CKDE candidates evaluated on the owned parts only, per-part sums to
+// `parts_rank` / `parts_world` / `parts_out` (pbn_score_batch_parts): hybrid CKDE candidates evaluated on one rank's parts only, per-part sums to
 // parts_out[c * PBN_HYBRID_PARTS ...]
 static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                             const int* parents, const double* params, int n_params, double* out, const int* want,
-                            unsigned long long parts_owned = 0, double* parts_out = nullptr) {
+                            int parts_rank = 0, int parts_world = 0, double* parts_out = nullptr) {
     return guarded(mu_of(sd), [&] {
         if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
         pbn_ctx* ctx = sd->ctx;
@@ -800,7 +800,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 // are remembered by parent set (the value depends on the parent ORDER only through rounding, ~1e-13,
                 // and these scores are not score-equivalent: no exact ties to flip).  BIC stays out: bic_clg ties.
                 if (parts_out) {   // a share of the candidate: never memoised
-                    HybridParts hp{parts_owned, parts_out + (size_t)c * PBN_HYBRID_PARTS};
+                    HybridParts hp{parts_rank, parts_world, parts_out + (size_t)c * PBN_HYBRID_PARTS};
                     out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp);
                     continue;
                 }
@@ -1206,12 +1206,10 @@ int pbn_score_batch_parts(pbn_scoredata* sd, int kind, int n_cand, const int* va
             for (int j = par_off[c]; j < par_off[c + 1]; ++j) disc = disc || parents[j] >= sd->n;
             if (!disc || node_type[c] != PBN_NODE_CKDE) throw invalid_error("pbn_score_batch_parts: CKDE candidates with discrete parents only");
         }
-        unsigned long long owned = 0;
-        for (int q = part; q < PBN_HYBRID_PARTS; q += n_parts) owned |= 1ull << q;
         std::vector<double> whole((size_t)std::max(n_cand, 1));
         std::fill(out, out + (size_t)n_cand * PBN_HYBRID_PARTS, 0.0);
         if (n_cand > 0) {
-            const int rc = score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, nullptr, 0, whole.data(), nullptr, owned, out);
+            const int rc = score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, nullptr, 0, whole.data(), nullptr, part, n_parts, out);
             if (rc != PBN_OK) throw device_error(pbn_last_error());
         }
     });

@@ -112,10 +112,13 @@ double lg_slogl_from_moments(const pbn_scoredata* sd, const Stats& test, const i
 // hybrid.hip: candidates with a discrete variable or discrete parents (synchronous)
 // The CKDE slices (configuration c, region u) of a hybrid candidate fall into PBN_HYBRID_PARTS = 64 fixed PARTS, part = (c * regions + u) mod 64,
 // and the candidate's score is the sum of its parts in part order - with one process as with many: a job with one process per GPU
-// evaluates on rank r only the parts p = r (mod world) (HybridParts::owned) and hands out the per-part sums (pbn_score_batch_parts).
+// evaluates on rank r only the parts that rank owns and hands out the per-part sums (pbn_score_batch_parts).  Owners: the parts are dealt
+// longest-processing-time first on their slices' training x test rows - every rank computes the same dealing from the same counts - so
+// that the folds of a large configuration do not pile up on the ranks a fixed pattern would give them; which rank owns a part changes no
+// bit of the result.
 constexpr int PBN_HYBRID_PARTS = 64;
 struct HybridParts {
-    unsigned long long owned;   // bit p: evaluate part p
+    int rank, world;            // evaluate the parts dealt to `rank` of `world`
     double* out;                // [PBN_HYBRID_PARTS] per-part sums (0 for the parts not owned)
 };
 double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts = nullptr);

@@ -187,8 +187,8 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
     if rest:
         out[rest] = sub(rest)
     # CKDE candidates with discrete parents: the update batches of a restricted search hold a handful of them - fewer than ranks, each
-    # 10-50 ms of sweeps - so the ranks share every candidate's SLICES (configuration x fold): rank r evaluates the parts p = r (mod
-    # world) of the engine's 64 fixed parts (pbn_score_batch_parts), the per-part sums are all-gathered, added over the ranks (a part
+    # 10-50 ms of sweeps - so the ranks share every candidate's SLICES (configuration x fold): rank r evaluates the parts dealt to it
+    # (by cost, identically on every rank) of the engine's 64 fixed parts (pbn_score_batch_parts), the per-part sums are all-gathered, added over the ranks (a part
     # is non-zero on one rank only) and then over the parts in order - the one-process sum, bit for bit (tools/scale_emulate.py on
     # BASELINE config 5, eight ranks: 3.1 s dealing whole candidates, a third of the batches unsharded for holding one candidate)
     sliced = [i for i in heavy if hasattr(score, "_batch_parts") and world <= 64 and ntype[i] == _lib.PBN_NODE_CKDE and n_cont is not None
