@@ -455,7 +455,7 @@ static SplitLayout split_layout(int64_t rows, int split, int k, uint32_t seed, d
         for (int i = 0; i < extra; ++i) { cur += fold_size + 1; sd->limits.push_back(cur); }
         for (int i = extra; i < k; ++i) { cur += fold_size; sd->limits.push_back(cur); }
     }
-    L.idx = idx;
+    L.idx = std::move(idx);
     return L;
 }
 
@@ -470,9 +470,9 @@ static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split
         sd->ctx = ctx; sd->dtype = table->dtype; sd->n = table->n_cols; sd->split = split; sd->src = table;
         const int64_t rows = table->n_rows;
         SplitLayout lay = split_layout(rows, split, k, seed, test_ratio);
-        const std::vector<int32_t>& idx = lay.idx;
         sd->n_cv = lay.n_cv; sd->n_hold = lay.n_hold; sd->k = lay.k; sd->limits = lay.limits;
-        sd->perm = idx;
+        sd->perm = std::move(lay.idx);   // (2M rows: 8 MB - moved, not copied twice)
+        const std::vector<int32_t>& idx = sd->perm;
         if (split != PBN_SPLIT_NONE) {
             pbn_table* pt = nullptr;
             int rc = pbn_table_take(table, idx.data(), rows, &pt);
