@@ -606,8 +606,13 @@ struct Engine {
             static const size_t budget = [] { const char* e = getenv("PBN_MI_MIRROR_MB"); return (size_t)((e && *e) ? atoll(e) : 16384) << 20; }();
             const size_t bytes = rowmajor_mirror_elems(h->table->n_rows, nc) * dtype_size(h->table->dtype);
             if (bytes <= budget) {
-                h->rowmajor.alloc(bytes);
-                build_rowmajor_mirror(h->table->data, h->table->ld, a.gc, nc, h->table->n_rows, h->table->dtype, h->rowmajor.p, ctx->stream);
+                try {
+                    h->rowmajor.alloc(bytes);
+                    build_rowmajor_mirror(h->table->data, h->table->ld, a.gc, nc, h->table->n_rows, h->table->dtype, h->rowmajor.p, ctx->stream);
+                } catch (const device_error&) {   // no room for the mirror: the rows are gathered from the columns
+                    (void)hipGetLastError();
+                    h->rowmajor.release();
+                }
             }
         }
         a.rowmajor = (a.rows && h->rowmajor.n) ? h->rowmajor.p : nullptr;
