@@ -181,3 +181,114 @@ def test_deal_sets_longest_first_is_balanced_and_deterministic():
         # round-robin in order of first appearance (round 2) is worse or equal on this mix
         rr = [sum(c for i, c in enumerate(cost) if i % world == r) for r in range(world)]
         assert max(load) <= max(rr) + 1e-9
+
+
+class _FakeEngineScore:
+    """Stands in for a device Score in distributed.sharded_batch: 4 continuous columns (ids 0-3), 2 discrete (4, 5); deterministic
+    closed-form 'sweeps' with the engine's term / part interfaces, and a record of what was evaluated where."""
+
+    class _T:
+        names = ["a", "b", "c", "d"]
+
+    def __init__(self):
+        self._table = self._T()
+        self.totals, self.evaluated, self.part_calls, self.raw_calls = {}, [], [], 0
+
+    @staticmethod
+    def _a(kind, term):
+        m, vs = term[0], sorted(term[1:])
+        return float(np.sin(1.0 + kind + 0.37 * m + sum((i + 1) * 0.913 * (v + 1) for i, v in enumerate(vs))) * 1e3)
+
+    @staticmethod
+    def _part(kind, v, ps, q):
+        return float(np.cos(0.1 * q + kind + v + 0.77 * sum(ps))) if q % 5 else 0.0
+
+    def _terms(self, what, kind, terms, values=None):
+        if what == "missing":
+            return [0 if (kind,) + tuple([t[0]] + sorted(t[1:])) in self.totals else 1 for t in terms]
+        if what == "eval":
+            self.evaluated += [(kind,) + tuple([t[0]] + sorted(t[1:])) for t in terms]
+            return np.array([self._a(kind, t) for t in terms])
+        for t, v in zip(terms, values):
+            self.totals[(kind,) + tuple([t[0]] + sorted(t[1:]))] = float(v)
+        return None
+
+    def _batch_parts(self, model, var, ntype, off, par, kind, part, n_parts):
+        self.part_calls.append((part, n_parts, len(var)))
+        out = np.zeros((len(var), 64))
+        for i, v in enumerate(var):
+            for q in range(part, 64, n_parts):
+                out[i, q] = self._part(kind, v, par[off[i]: off[i + 1]], q)
+        return out
+
+    def _batch_raw(self, model, var, ntype, off, par, kind):
+        self.raw_calls += 1
+        out = np.zeros(len(var))
+        for i, v in enumerate(var):
+            ps = list(par[off[i]: off[i + 1]])
+            if ntype[i] != 1:                                   # LinearGaussian / discrete: host arithmetic
+                out[i] = 0.5 * v - 0.25 * sum(ps) + kind
+            elif any(q >= 4 for q in ps):                       # hybrid CKDE: the 64 parts in order
+                acc = 0.0
+                for q in range(64):
+                    acc += self._part(kind, v, ps, q)
+                out[i] = acc
+            else:                                               # continuous CKDE: joint term - marginal term
+                d = len(ps) + 1
+                key = lambda t: self.totals.get((kind,) + tuple([t[0]] + sorted(t[1:])), self._a(kind, t))
+                out[i] = key((d, v) + tuple(ps)) - (key((d,) + tuple(ps)) if ps else 0.0)
+        return out
+
+
+_BATCH = dict(var=[0, 1, 2, 3, 0, 1, 2, 3, 0, 4, 2, 1], ntype=[1, 1, 1, 1, 1, 1, 0, 1, 1, 2, 1, 0],
+              off=[0, 0, 1, 3, 4, 6, 8, 9, 11, 12, 13, 16, 17], par=[0, 0, 1, 0, 1, 4, 2, 5, 3, 4, 5, 2, 5, 0, 4, 3, 4])
+
+
+def _term_worker(rank, world, port, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pybnesian_amd import _lib
+        from pybnesian_amd.distributed import sharded_batch
+
+        s = _FakeEngineScore()
+        first = sharded_batch(s, None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK)
+        again = sharded_batch(s, None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK)   # every term known now
+        queue.put((rank, first.tolist(), again.tolist(), s.evaluated, s.part_calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_batch_deals_terms_and_slices_world2(ensure_built):
+    """distributed.sharded_batch with an engine score: continuous CKDE candidates by TERM (each unknown term evaluated on exactly one
+    rank, totals installed everywhere, nothing evaluated again), hybrid CKDE candidates by SLICE (every rank its parts of every
+    candidate), the rest redundantly - and every rank returns the one-process values bit for bit."""
+    from pybnesian_amd import _lib
+
+    world = 2
+    ref = _FakeEngineScore()._batch_raw(None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK).tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_term_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    evaluated = []
+    for rank, first, again, ev, part_calls in results:
+        assert first == ref and again == ref
+        evaluated += ev
+        assert part_calls == [(rank, world, 4), (rank, world, 4)]          # the four hybrid CKDE candidates, in both batches
+    terms = set()
+    for i, v in enumerate(_BATCH["var"]):
+        ps = _BATCH["par"][_BATCH["off"][i]: _BATCH["off"][i + 1]]
+        if _BATCH["ntype"][i] == 1 and v < 4 and all(q < 4 for q in ps):
+            terms.add((_lib.PBN_SCORE_CVLIK, len(ps) + 1) + tuple(sorted([v] + ps)))
+            if ps:
+                terms.add((_lib.PBN_SCORE_CVLIK, len(ps) + 1) + tuple(sorted(ps)))
+    assert len(terms) >= 6
+    assert len(evaluated) == len(set(evaluated)) and set(evaluated) == terms      # each term once, on one rank, in the first batch only
