@@ -350,7 +350,20 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     if (node_type == PBN_NODE_DISCRETE) throw invalid_error("pbn_score_batch: continuous column scored as DiscreteFactor");
     std::vector<int> dpar, cols{var};
     for (int i = 0; i < p; ++i) (parents[i] >= n ? dpar : cols).push_back(parents[i]);
+    // continuous parents in ascending order (the discrete ones are canonicalised below): the score of (variable | parent SET) is then
+    // one number down to the last bit - the memo returns what a fresh evaluation would, and a job that shares the slices over its ranks
+    // (pbn_score_batch_parts) adds up the same doubles
+    std::sort(cols.begin() + 1, cols.end());
+    std::sort(dpar.begin(), dpar.end());   // and the configurations in the canonical numbering: the slices are visited - and added - in one order
     const int d = (int)cols.size(), pc = d - 1;
+    // the JOINT term of a CKDE slice is evaluated over all of its columns in ascending order - x | {y} + D and y | {x} + D share it, and
+    // the shared value must not depend on who asked first; jperm[i] = index in `cols` of the i-th smallest column
+    std::vector<int> jperm(d), jcols(d);
+    {
+        const int vpos = (int)(std::lower_bound(cols.begin() + 1, cols.end(), var) - (cols.begin() + 1));   // parents below the variable
+        for (int i = 0; i < d; ++i) jperm[i] = i < vpos ? i + 1 : (i == vpos ? 0 : i);
+        for (int i = 0; i < d; ++i) jcols[i] = cols[jperm[i]];
+    }
     if (d > 17) throw invalid_error("pbn_score_batch: too many continuous parents");
     pbn_ctx* ctx = sd->ctx;
     const pbn_table* t = sd->table();
@@ -471,7 +484,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 elig[(size_t)c * 2 + which] = min_train > 0 && kde_group_applies(sd->dtype, d - which, min_train, R);
         }
     }
-    auto group_unit = [&](int c, int u, int which, const KdeModel& m, const int* v, int nv, int64_t ntrain, int64_t ntest, int slot) {
+    // v: the term's columns, colidx: their indices in `cols` (the joint in ascending order, the marginal = cols[1:])
+    auto group_unit = [&](int c, int u, int which, const KdeModel& m, const int* v, const int* colidx, int nv, int64_t ntrain, int64_t ntest, int slot) {
         int& pi = pool_of[(size_t)c * 2 + which];
         if (pi < 0) {
             pi = (int)gb.pools.size();
@@ -490,14 +504,14 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             std::vector<double> gm(d), gs((size_t)d * d), sub((size_t)nv * nv), L((size_t)nv * nv), Li((size_t)nv * nv);
             local_moments(sd, all, cols.data(), d, gm.data(), gs.data());
             for (int j = 0; j < nv; ++j)
-                for (int i = 0; i < nv; ++i) sub[i + (size_t)j * nv] = gs[(i + which) + (size_t)(j + which) * d] / (double)std::max<int64_t>(1, all.N - 1);
+                for (int i = 0; i < nv; ++i) sub[i + (size_t)j * nv] = gs[colidx[i] + (size_t)colidx[j] * d] / (double)std::max<int64_t>(1, all.N - 1);
             if (!hm::cholesky(sub.data(), nv, L.data())) {
                 std::fill(L.begin(), L.end(), 0.0);
                 for (int i = 0; i < nv; ++i) L[i + (size_t)i * nv] = std::sqrt(std::max(sub[i + (size_t)i * nv], 1e-300));
             }
             hm::lower_inverse(L.data(), nv, Li.data());
             for (int i = 0; i < nv; ++i) {
-                P.mug[i] = gm[i + which];
+                P.mug[i] = gm[colidx[i]];
                 for (int j = 0; j < nv; ++j) P.Wg[i * nv + j] = j <= i ? Li[i + (size_t)j * nv] : 0.0;
             }
             gb.pools.push_back(P);
@@ -582,7 +596,10 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             // under the exponentials and one pack / one launch serves both terms (C5: 22.3 s of sweeps fused against 24.2 s as
             // two plain ones); fp64 slices and slices with one term cached take the plain sweeps
             static const int fused_mode = [] { const char* e = getenv("PBN_HYBRID_FUSED"); return (e && *e) ? atoi(e) : -1; }();
-            const bool want_fused = fused_mode < 0 ? (use_bf16x3(sd->dtype) && d > PBN_HYBRID_SPLIT_MAX_D) : fused_mode != 0;
+            // (default off since the terms are canonical: the fused sweep evaluates the joint with the variable first - another
+            //  rounding of the shared joint term than the plain sweep's, chosen by what happened to be cached; it only ever applied to
+            //  slices too small for the grouped path, a sliver of C5's time)
+            const bool want_fused = fused_mode < 0 ? false : fused_mode != 0;
             const bool grouped_both = elig[(size_t)c * 2] && (pc == 0 || elig[(size_t)c * 2 + 1]);
             if (pc > 0 && want_fused && !grouped_both && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
                 sd->kde_cache.find(key_of(u, c, cols.data() + 1, pc)) == sd->kde_cache.end()) {
@@ -609,9 +626,12 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 slices.push_back(sl);
                 continue;
             }
-            for (int which = 0; which < (pc > 0 ? 2 : 1); ++which) {   // 0: joint over cols, 1: marginal over cols[1:]
+            std::vector<int> midx(std::max(pc, 1));
+            for (int i = 0; i < pc; ++i) midx[i] = i + 1;
+            for (int which = 0; which < (pc > 0 ? 2 : 1); ++which) {   // 0: joint over its columns in ascending order, 1: marginal over cols[1:]
                 Term& term = which ? sl.marg : sl.joint;
-                const int* v = cols.data() + which;
+                const int* v = which ? cols.data() + 1 : jcols.data();
+                const int* colidx = which ? midx.data() : jperm.data();
                 const int nv = d - which;
                 const std::vector<int> key = key_of(u, c, v, nv);
                 auto itc = sd->kde_cache.find(key);
@@ -624,7 +644,12 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                             for (int ii = 0; ii < pc; ++ii) Hm[ii + (size_t)jj * pc] = H[(ii + 1) + (size_t)(jj + 1) * d];
                         kde_prepare(m, sd->dtype, pc, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
                     } else {
-                        kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, false, mu.data());
+                        std::vector<double> Hs((size_t)d * d), mus((size_t)d);
+                        for (int jj = 0; jj < d; ++jj) {
+                            mus[jj] = mu[jperm[jj]];
+                            for (int ii = 0; ii < d; ++ii) Hs[ii + (size_t)jj * d] = H[jperm[ii] + (size_t)jperm[jj] * d];
+                        }
+                        kde_prepare(m, sd->dtype, d, tr->N, Hs.data(), PBN_BW_FULL, false, mus.data());
                     }
                 } catch (const singular_error&) {
                     term.slot = -2;   // no factor for this slice
@@ -633,7 +658,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 term.slot = (int)slot_key.size();
                 slot_key.push_back(key);
                 if (elig[(size_t)c * 2 + which]) {   // evaluated with the candidate's other grouped slices, after the loops
-                    group_unit(c, u, which, m, v, nv, tr->N, te->N, term.slot);
+                    group_unit(c, u, which, m, v, colidx, nv, tr->N, te->N, term.slot);
                     ++sd->kde_sweeps;
                     continue;
                 }

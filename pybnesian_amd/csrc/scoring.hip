@@ -797,8 +797,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 // Likelihood scores of DiscreteAdaptator factors cost k x configurations sweeps / Gram passes each, and a
                 // hill-climb asks for the same (variable, type, parent SET) again and again: every RemoveArc cell is the
                 // local score the node had before that arc was added, every FlipArc cell's source side likewise.  They
-                // are remembered by parent set (the value depends on the parent ORDER only through rounding, ~1e-13,
-                // and these scores are not score-equivalent: no exact ties to flip).  BIC stays out: bic_clg ties.
+                // are remembered by parent set (score_hybrid evaluates the continuous parents in ascending order and the discrete
+                // ones in canonical order: the value does not depend on the order they were given in).  BIC stays out: bic_clg ties.
                 if (parts_out) {   // a share of the candidate: never memoised
                     HybridParts hp{parts_rank, parts_world, parts_out + (size_t)c * PBN_HYBRID_PARTS};
                     out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp);
@@ -1000,16 +1000,32 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     pr.te0 = sd->limits[w.f]; pr.te_n = sd->limits[w.f + 1] - sd->limits[w.f];
                 }
                 pr.ntrain = tr->N;
+                // The plain terms are evaluated over their columns in ASCENDING order, whatever the candidate's orientation and the order
+                // of its parents: A(S, m) is then a function of the set alone down to the last bit - the value a term gets does not
+                // depend on which candidate asked for it first, and a job that evaluates the terms on other ranks (pbn_score_terms)
+                // computes the very same doubles.  (H = k(N, d) cov: the bandwidth of a subset is the sub-block of the set's.)
+                const int var0 = cols[0];
+                if (w.mode != 0) std::sort(cols.begin(), cols.end());
                 subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
                 const double inv = 1.0 / (double)(tr->N - 1);
                 for (auto& x : sse) x *= inv;  // covariance
                 bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
-                if (w.mode == 2) {            // KDE of the parents with the bandwidth block H[1:, 1:]
-                    std::vector<double> Hm((size_t)p * p);
-                    for (int j = 0; j < p; ++j)
-                        for (int i = 0; i < p; ++i) Hm[i + (size_t)j * p] = H[(i + 1) + (size_t)(j + 1) * d];
-                    kde_prepare(pr.m, sd->dtype, p, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
-                    pr.use.assign(cols.begin() + 1, cols.end());
+                if (w.mode == 2) {            // KDE of the parents with the bandwidth block of the parents
+                    const int vp = (int)(std::find(cols.begin(), cols.end(), var0) - cols.begin());
+                    std::vector<double> Hm((size_t)p * p), mum((size_t)p);
+                    pr.use.clear();
+                    for (int j = 0, jj = 0; j < d; ++j) {
+                        if (j == vp) continue;
+                        for (int i = 0, ii = 0; i < d; ++i) {
+                            if (i == vp) continue;
+                            Hm[ii + (size_t)jj * p] = H[i + (size_t)j * d];
+                            ++ii;
+                        }
+                        mum[jj] = mu[j];
+                        pr.use.push_back(cols[j]);
+                        ++jj;
+                    }
+                    kde_prepare(pr.m, sd->dtype, p, tr->N, Hm.data(), PBN_BW_FULL, false, mum.data());
                 } else {
                     kde_prepare(pr.m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, w.mode == 0, mu.data());
                     pr.use = cols;
