@@ -169,6 +169,40 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
     return out
 
 
+def eight_rank_estimate(run, one_rank_leg):
+    """No 8-GPU node at hand: ONE process plays the eight ranks of a hill-climb in turn and times every rank's share of every batch
+    (distributed.sharded_batch's emulation hook, tools/scale_emulate.py).  An 8-rank job waits per batch for its slowest share and
+    repeats the unsharded work: T_8 ~ (time - sum of the shares) + sum over batches of the slowest share.  An ESTIMATE - no collective
+    latency, one process's caches, the score engine's phase only - never a leg's `value`."""
+    try:
+        from pybnesian_amd import distributed as pdist
+
+        class _Eight:
+            batches = []
+            get_rank = staticmethod(lambda: 0)
+            get_world_size = staticmethod(lambda: 8)
+            get_backend = staticmethod(lambda: "emulated")
+            emulate = staticmethod(lambda times, counts: _Eight.batches.append(times))
+
+        pdist._EMULATED = _Eight
+        try:
+            r8 = run()
+        finally:
+            pdist._EMULATED = None
+        one = r8["estimate_s"] + r8.get("score_ctor_s", 0.0)
+        shares = sum(sum(t) for t in _Eight.batches)
+        slow = sum(max(t) for t in _Eight.batches)
+        t8 = one - shares + slow
+        t1 = one_rank_leg["estimate_s"] + one_rank_leg.get("score_ctor_s", 0.0)
+        return {"kind": "one-process emulation, not a multi-GPU measurement", "cells_scored": r8["cells_scored"], "batches": len(_Eight.batches),
+                "one_process_s": one, "per_rank_s": t8, "slowest_over_mean_share": slow / (shares / 8.0) if shares else None,
+                "arcs_per_s": r8["cells_scored"] / t8, "ratio_to_one_rank_leg": (r8["cells_scored"] / t8) / (one_rank_leg["cells_scored"] / t1),
+                "method": "per batch the slowest of the eight shares (CKDE terms dealt by cost, the slices of hybrid candidates shared), plus the unsharded "
+                          "time; collective latency and per-rank caches not modelled"}
+    except Exception as ex:   # an estimate must never cost the line
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def bench_c1(pbn):
     """BASELINE config 1 (the reference's CPU-runnable case): GaussianNetwork, 4 nodes, LinearGaussianCPD MLE fit + BIC on a
     10 k-row table - BIC hill-climb + fit + slogl through the device engine, and the SAME search by the serial restatement
@@ -642,38 +676,8 @@ def main():
             legs["secondary_cv_weak"].update({"ranks": world, "scaling": "weak", "nodes": wn,
                                               "note": "cells scale with nodes^2: nodes = round(64 sqrt(ranks / 8)) keeps cells per rank constant"})
         if world == 1 and dist is None and legs["secondary_cv_weak"].get("value") is not None:
-            # No 8-GPU node at hand: ONE process plays the eight ranks of the same leg in turn (64 nodes) and times every rank's share
-            # of every batch (distributed.sharded_batch's emulation hook, tools/scale_emulate.py).  An 8-rank job waits per batch for
-            # its slowest share and repeats the unsharded work: T_8 ~ (time - sum of the shares) + sum over batches of the slowest
-            # share.  An ESTIMATE: no collective latency, one process's caches - never the leg's `value`.
-            try:
-                from pybnesian_amd import distributed as pdist
-
-                class _Eight:
-                    batches = []
-                    get_rank = staticmethod(lambda: 0)
-                    get_world_size = staticmethod(lambda: 8)
-                    get_backend = staticmethod(lambda: "emulated")
-                    emulate = staticmethod(lambda times, counts: _Eight.batches.append(times))
-
-                pdist._EMULATED = _Eight
-                try:
-                    r8 = bench_hill_climb(torch, pbn, _lib, ctx, device, "cv64", args.hc_rows, 5, n_cols=64, cpu=False)
-                finally:
-                    pdist._EMULATED = None
-                one = r8["estimate_s"] + r8.get("score_ctor_s", 0.0)
-                shares = sum(sum(t) for t in _Eight.batches)
-                slow = sum(max(t) for t in _Eight.batches)
-                t8 = one - shares + slow
-                w1 = legs["secondary_cv_weak"]
-                t1 = w1["estimate_s"] + w1.get("score_ctor_s", 0.0)
-                legs["secondary_cv_weak"]["eight_rank_estimate"] = {
-                    "kind": "one-process emulation, not a multi-GPU measurement", "nodes": 64, "cells_scored": r8["cells_scored"], "batches": len(_Eight.batches),
-                    "one_process_s": one, "per_rank_s": t8, "slowest_over_mean_share": slow / (shares / 8.0) if shares else None,
-                    "arcs_per_s": r8["cells_scored"] / t8, "ratio_to_one_rank_leg": (r8["cells_scored"] / t8) / (w1["cells_scored"] / t1),
-                    "method": "per batch the slowest of the eight shares (terms dealt by cost), plus the unsharded time; collective latency and per-rank caches not modelled"}
-            except Exception as ex:   # an estimate must never cost the line
-                legs["secondary_cv_weak"]["eight_rank_estimate"] = {"error": f"{type(ex).__name__}: {ex}"}
+            legs["secondary_cv_weak"]["eight_rank_estimate"] = eight_rank_estimate(
+                lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, "cv64", args.hc_rows, 5, n_cols=64, cpu=False), legs["secondary_cv_weak"])
     if hc_auto and world == 1 and not args.no_extra_legs:
         if not args.no_c3:
             # the CKDE path of the search, driver-timed: BASELINE config 3 at FULL size (32-node SPBN, 10-fold CV, 500 k rows),
@@ -681,6 +685,15 @@ def main():
             leg("secondary_c3", lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, "c3", 0, 1))
         # BASELINE config 5 end to end on one GPU: MMPC (hybrid MutualInformation) + ValidatedLikelihood hill-climb to convergence
         leg("secondary_c5", lambda: bench_hill_climb(torch, pbn, _lib, ctx, device, "c5mmhc", 0, 1_000_000))
+        if dist is None and legs["secondary_c5"].get("value") is not None:
+            # BASELINE config 5 is an 8-GPU configuration: the same estimate for its hill-climb phase (fixed work: strong scaling; the
+            # stand-in skeleton of `--hc c5`, the MMPC phase in front of it is not part of the estimate)
+            def c5_one():
+                return bench_hill_climb(torch, pbn, _lib, ctx, device, "c5", 0, 1_000_000, cpu=False)
+
+            base5 = c5_one()
+            legs["secondary_c5"]["eight_rank_estimate"] = dict(eight_rank_estimate(c5_one, base5), one_rank_s=base5["estimate_s"],
+                                                               phase="hill-climb over a random 15 % skeleton (--hc c5), fixed work")
         leg("secondary_c1", lambda: bench_c1(pbn))
 
         def f32_leg():
