@@ -39,6 +39,10 @@ struct HybridGrouping {
     pbn::dev_buf<int32_t> piece;       // device [npieces][3]: cell, first, last + 1 (pieces of <= 4096 rows)
     pbn::dev_buf<int32_t> piece_off;   // device [cells + 1]
     int npieces = 0;
+    // moments of ALL continuous columns per cell (hybrid.hip group_moments): one gathered, segmented MFMA Gram per grouping - every
+    // candidate over this grouping then takes its columns' entries on the host instead of a launch and a synchronisation of its own
+    mutable std::vector<pbn::score::Stats> full;
+    mutable int full_state = 0;        // 0 not tried, 1 ready, -1 not applicable (more than 64 continuous columns / too many cells)
 };
 
 struct pbn_scoredata {
