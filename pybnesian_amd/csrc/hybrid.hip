@@ -49,11 +49,16 @@ std::vector<Region> regions_of(const pbn_scoredata* sd, int kind) {
 }
 
 // ---- discrete variable: DiscreteFactor MLE + slogl, bic_discrete --------------------------------------------
-double score_discrete(const pbn_scoredata* sd, int kind, int var, const int* parents, int p) {
+double score_discrete(const pbn_scoredata* sd, int kind, int var, const int* parents_in, int p) {
     const int n = sd->n;
     for (int i = 0; i < p; ++i)
-        if (parents[i] < n)
+        if (parents_in[i] < n)
             throw invalid_error("Local score for a discrete variable cannot be calculated because the parents/evidence contains non-discrete variables.");
+    // parents in ascending order: the configurations are then visited - and their terms added - in one order whatever order the
+    // parents came in, so the score is a function of (variable, parent SET) to the last bit and can be memoised like the others
+    std::vector<int> psorted(parents_in, parents_in + p);
+    std::sort(psorted.begin(), psorted.end());
+    const int* parents = psorted.data();
     const int card0 = sd->card[var - n];
     std::vector<int> strides(p + 1);
     int joint = card0;

@@ -804,7 +804,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp);
                     continue;
                 }
-                const bool memo = score_memo_on() && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT) && nt != PBN_NODE_DISCRETE;
+                const bool memo = score_memo_on() && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT);   // (discrete factors too: a count over all rows on the host each)
                 std::vector<int> key;
                 if (memo) {
                     key.assign(cols.begin() + 1, cols.end());
