@@ -56,4 +56,13 @@ g = pd.DataFrame(rng.normal(size=(30001, 20)) @ (np.eye(20) + 0.2 * np.tril(rng.
 bic = pbn.BIC(g)
 gbn = pbn.GaussianNetwork(list(g.columns))
 out["bic"] = [bic.local_score(gbn, "x7", ["x1", "x19", "x4"]), bic.local_score(gbn, "x0", []), bic.local_score(gbn, "x12", ["x3"])]
+# (4) likelihood scores of hybrid candidates (CKDE and LinearGaussian children of discrete parents, a discrete child): the per-grouping
+#     moments (PBN_HYBRID_FULLMOMENTS), the fused slice sweep (PBN_HYBRID_FUSED) and the segmented per-candidate moments they replace
+for dtype in ("float64", "float32"):
+    hdf = hybrid_table(40000, 13, dtype)
+    hs = pbn.CVLikelihood(hdf, 4, 1)
+    hnet = pbn.SemiparametricBN(list(hdf.columns))
+    cands = [("c2", pbn.CKDEType(), ["c1", "d1"]), ("c4", pbn.CKDEType(), ["d2", "c2", "d3"]), ("c3", pbn.LinearGaussianCPDType(), ["d3", "c1"]),
+             ("c1", pbn.CKDEType(), ["d1"]), ("d2", pbn.DiscreteFactorType(), ["d1", "d3"]), ("c2", pbn.LinearGaussianCPDType(), ["d1", "d2", "c1", "c3"])]
+    out[f"hybrid_{dtype}"] = [hs.local_score_node_type(hnet, t, v, p) for v, t, p in cands]
 print("RESULT " + json.dumps(out))

@@ -10,7 +10,8 @@ compared with the default run:
    (other partitions of the same work);
  * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_FULL_BUDGET_MB=0 (their cache
    budget exhausted: the same fallback), PBN_MI_THREADS=1;
- * PBN_GRAM_LDS=1 / 0 (the older Gram kernels), PBN_MI_GRAM_ORDER=0 / 1 (launch order of a grouping's Gram pieces)."""
+ * PBN_GRAM_LDS=1 / 0 (the older Gram kernels), PBN_MI_GRAM_ORDER=0 / 1 (launch order of a grouping's Gram pieces);
+ * PBN_HYBRID_FULLMOMENTS=0, PBN_HYBRID_FUSED=1, PBN_HYBRID_SEGMENTED=0, PBN_SCORE_MEMO=0 (hybrid candidates)."""
 import json
 import os
 import subprocess
@@ -63,6 +64,17 @@ def test_mi_switches(default, env):
     got = run(env)
     for key in ("mi_plain", "mi_nulls"):
         assert close(got[key], default[key], 1e-9), key
+
+
+@pytest.mark.parametrize("env", [{"PBN_HYBRID_FULLMOMENTS": "0"}, {"PBN_HYBRID_FUSED": "1"}, {"PBN_HYBRID_SEGMENTED": "0"}, {"PBN_SCORE_MEMO": "0"}])
+def test_hybrid_score_switches(default, env):
+    """Hybrid candidates: moments from the per-grouping Gram or from per-candidate launches, slices fused or split, with and without
+    the local-score memo - the same scores to rounding (the fp32 tables to their own precision)."""
+    got = run(env)
+    assert close(got["hybrid_float64"], default["hybrid_float64"], 1e-10)
+    assert close(got["hybrid_float32"], default["hybrid_float32"], 1e-4)
+    if env == {"PBN_SCORE_MEMO": "0"}:
+        assert got["hybrid_float64"] == default["hybrid_float64"]      # the memo returns what a fresh evaluation gives
 
 
 @pytest.mark.parametrize("order", ["0", "1"])
