@@ -1214,6 +1214,20 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_PAIRSUM
 #define PBN_BF16_PAIRSUM 1
 #endif
+#ifndef PBN_BF16_BLIND
+#define PBN_BF16_BLIND 1   // plain fp32 sweeps: batches / chunks of tiles without the per-tile overflow test, checked once at their end
+#endif
+// Measured (tools/lib_variants.sh, profiles/r3/bf16_blind_probe.txt): pruned fp32 slice sweeps -5...6 % (C5 9.25 -> 9.04 s), unpruned sweeps
+// with one MFMA per tile pair -3.6 %; with two (d = 8 headline) +3 %: an unpruned split starts from the offsets of its own first tile, a near
+// row later in the split overflows against them (whitened squared distances differ by hundreds), and every such chunk is swept twice - chunks
+// of 256 / 1024 tiles 16.3 / 23.9 ms against 13.7.  So: always for the pruned sweeps (offsets from the prepass bounds: nothing to redo), chunks
+// of 64 tiles for the one-MFMA unpruned sweeps, not for the two-MFMA ones.
+#ifndef PBN_BF16_BLIND_CHUNK
+#define PBN_BF16_BLIND_CHUNK 64
+#endif
+#ifndef PBN_BF16_BLIND_NB2
+#define PBN_BF16_BLIND_NB2 0
+#endif
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
@@ -1363,7 +1377,11 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     float pend[PAIRSUM ? QG : 1];
 #pragma unroll
     for (int g = 0; g < (PAIRSUM ? QG : 1); ++g) pend[g] = 0.f;
-    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x, const int bit = 0, const bool flush = true) {
+    // `blind` (plain sweeps, PBN_BF16_BLIND): no overflow test and no rescue path - the caller looks at the fp64 sums once per batch / chunk
+    // of tiles and redoes it checked if one of them went bad (as the fp64 sweeps do).  An exponent overflows only 128 units above its
+    // query's offset, and the offsets start from the prepass bounds (pruned) or from a tile of the split itself.
+    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x, const int bit = 0, const bool flush = true, auto blind = std::false_type{}) {
+        constexpr bool BLIND = decltype(blind)::value;
         if constexpr (COND || PRUNE) {
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
@@ -1374,13 +1392,13 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                 float e0 = Tr<float>::ex2(acc[0]), e1 = Tr<float>::ex2(acc[1]), e2 = Tr<float>::ex2(acc[2]), e3 = Tr<float>::ex2(acc[3]);
                 float ts = (e0 + e1) + (e2 + e3);
                 float tsj = 0;
-                bool bad = !(ts < Tr<float>::big());
+                bool bad = BLIND ? false : !(ts < Tr<float>::big());
                 if (COND) {
                     float j0 = Tr<float>::ex2(accj[0]), j1 = Tr<float>::ex2(accj[1]), j2 = Tr<float>::ex2(accj[2]), j3 = Tr<float>::ex2(accj[3]);
                     tsj = (j0 + j1) + (j2 + j3);
                     bad = bad || !(tsj < Tr<float>::big());
                 }
-                if (__builtin_expect(__any(bad), 0)) {
+                if (!BLIND && __builtin_expect(__any(bad), 0)) {
                     float mx = colmax<float>(max4<float>(acc));
                     if (mx > 0.f) {
                         m[g] += mx;
@@ -1420,14 +1438,14 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                 const float e0 = Tr<float>::ex2(acc[g][0]), e1 = Tr<float>::ex2(acc[g][1]), e2 = Tr<float>::ex2(acc[g][2]), e3 = Tr<float>::ex2(acc[g][3]);
                 ts[g] = (e0 + e1) + (e2 + e3);
                 tsj[g] = 0;
-                bad = bad || !(ts[g] < Tr<float>::big());
+                if constexpr (!BLIND) bad = bad || !(ts[g] < Tr<float>::big());
                 if (COND) {
                     const float j0 = Tr<float>::ex2(accj[g][0]), j1 = Tr<float>::ex2(accj[g][1]), j2 = Tr<float>::ex2(accj[g][2]), j3 = Tr<float>::ex2(accj[g][3]);
                     tsj[g] = (j0 + j1) + (j2 + j3);
                     bad = bad || !(tsj[g] < Tr<float>::big());
                 }
             }
-            if (__builtin_expect(__any(bad), 0)) {
+            if (!BLIND && __builtin_expect(__any(bad), 0)) {
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
                     bool badg = !(ts[g] < Tr<float>::big());
@@ -1496,34 +1514,74 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
             }
             if (!mask) continue;
             if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
-            // unconditional prefetch of the next kept tile (see kde_sweep_body: a conditional one costs a vmcnt(0) per tile)
-            int b = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            load_tile(tb + b, fA, xA);
-            for (;;) {
-                const bool more = mask != 0;
-                const int b2 = more ? __builtin_ctzll(mask) : b;
-                mask &= mask - 1;
-                load_tile(tb + b2, fB, xB);
-                process_tile(fA, xA, b);
-                if (!more) break;
-                const bool more2 = mask != 0;
-                const int b3 = more2 ? __builtin_ctzll(mask) : b2;
-                mask &= mask - 1;
-                load_tile(tb + b3, fA, xA);
-                process_tile(fB, xB, b2);
-                if (!more2) break;
-                b = b3;
+            auto run_batch = [&](unsigned long long mk, auto blind) {
+                // unconditional prefetch of the next kept tile (see kde_sweep_body: a conditional one costs a vmcnt(0) per tile)
+                int b = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                load_tile(tb + b, fA, xA);
+                for (;;) {
+                    const bool more = mk != 0;
+                    const int b2 = more ? __builtin_ctzll(mk) : b;
+                    mk &= mk - 1;
+                    load_tile(tb + b2, fB, xB);
+                    process_tile(fA, xA, b, true, blind);
+                    if (!more) break;
+                    const bool more2 = mk != 0;
+                    const int b3 = more2 ? __builtin_ctzll(mk) : b2;
+                    mk &= mk - 1;
+                    load_tile(tb + b3, fA, xA);
+                    process_tile(fB, xB, b2, true, blind);
+                    if (!more2) break;
+                    b = b3;
+                }
+            };
+            if constexpr (!COND && !RING && PBN_BF16_BLIND) {
+                double saved[QG];
+#pragma unroll
+                for (int g = 0; g < QG; ++g) saved[g] = sum[g];
+                run_batch(mask, std::true_type{});
+                bool bad = false;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
+                if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) sum[g] = saved[g];
+                    run_batch(mask, std::false_type{});
+                }
+            } else {
+                run_batch(mask, std::false_type{});
             }
         }
     } else {
-        load_tile(t0, fA, xA);
-        for (int64_t t = t0; t < t1; t += 2) {
-            const bool second = t + 1 < t1;
-            load_tile(second ? t + 1 : t, fB, xB);
-            process_tile(fA, xA, 0, !second);          // PAIRSUM: the first tile's sums wait for the second one's
-            load_tile(t + 2 < t1 ? t + 2 : t, fA, xA);
-            if (second) process_tile(fB, xB, 0, true);
+        auto run_range = [&](int64_t c0, int64_t c1, auto blind) {
+            load_tile(c0, fA, xA);
+            for (int64_t t = c0; t < c1; t += 2) {
+                const bool second = t + 1 < c1;
+                load_tile(second ? t + 1 : t, fB, xB);
+                process_tile(fA, xA, 0, !second, blind);          // PAIRSUM: the first tile's sums wait for the second one's
+                load_tile(t + 2 < c1 ? t + 2 : t, fA, xA);
+                if (second) process_tile(fB, xB, 0, true, blind);
+            }
+        };
+        if constexpr (!COND && PBN_BF16_BLIND && (NB == 1 || PBN_BF16_BLIND_NB2)) {
+            constexpr int64_t CHUNK = PBN_BF16_BLIND_CHUNK;   // tiles (an even number: the pair sums are flushed at its end)
+            for (int64_t c0 = t0; c0 < t1; c0 += CHUNK) {
+                const int64_t c1 = c0 + CHUNK < t1 ? c0 + CHUNK : t1;
+                double saved[QG];
+#pragma unroll
+                for (int g = 0; g < QG; ++g) saved[g] = sum[g];
+                run_range(c0, c1, std::true_type{});
+                bool bad = false;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
+                if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) sum[g] = saved[g];
+                    run_range(c0, c1, std::false_type{});
+                }
+            }
+        } else {
+            run_range(t0, t1, std::false_type{});
         }
     }
 
