@@ -1221,12 +1221,15 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 // with one MFMA per tile pair -3.6 %; with two (d = 8 headline) +3 %: an unpruned split starts from the offsets of its own first tile, a near
 // row later in the split overflows against them (whitened squared distances differ by hundreds), and every such chunk is swept twice - chunks
 // of 256 / 1024 tiles 16.3 / 23.9 ms against 13.7.  So: always for the pruned sweeps (offsets from the prepass bounds: nothing to redo), chunks
-// of 64 tiles for the one-MFMA unpruned sweeps, not for the two-MFMA ones.
+// of 64 tiles for the unpruned sweeps - the two-MFMA ones only since their offsets look at 16 tiles spread over the split (PBN_BF16_PROBES).
+#ifndef PBN_BF16_PROBES
+#define PBN_BF16_PROBES 16   // with them the two-MFMA unpruned sweep gains from the blind chunks too: d = 8 headline 13.89 -> 13.56 ms (4 probes: 13.82)
+#endif
 #ifndef PBN_BF16_BLIND_CHUNK
 #define PBN_BF16_BLIND_CHUNK 64
 #endif
 #ifndef PBN_BF16_BLIND_NB2
-#define PBN_BF16_BLIND_NB2 0
+#define PBN_BF16_BLIND_NB2 1   // (0 without the probe tiles of PBN_BF16_PROBES: see above)
 #endif
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
@@ -1334,6 +1337,26 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                 V accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);  // slots 9..11 hold xn (m = mj = 0)
                 mj[g] = colmax<float>(max4<float>(accj));
                 set_bx(g);
+            }
+        }
+        // plain unpruned sweeps: the offsets also look at PBN_BF16_PROBES - 1 more tiles spread over the split - a split whose first 16
+        // rows all lie far from a query otherwise meets rows hundreds of exponent units above its offset, and every such tile takes the
+        // rescue path (or, in a blind chunk, costs the chunk a second pass)
+        if constexpr (!COND && !PRUNE && PBN_BF16_PROBES > 1) {
+#pragma unroll 1
+            for (int pz = 1; pz < PBN_BF16_PROBES; ++pz) {
+                load_tile(t0 + (t1 - t0) * pz / PBN_BF16_PROBES, f, x);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    const V c0 = {ny[g], ny[g], ny[g], ny[g]};
+                    const V acc = mfma_main(f, g, c0);
+                    const float mx = colmax<float>(max4<float>(acc));
+                    if (mx > m[g]) {
+                        m[g] = mx;
+                        const float cm = ny[g] - mx;
+                        cmv[g] = V{cm, cm, cm, cm};
+                    }
+                }
             }
         }
     }
