@@ -203,6 +203,37 @@ def eight_rank_estimate(run, one_rank_leg):
         return {"error": f"{type(ex).__name__}: {ex}"}
 
 
+TIE_TOL = 1e-9
+
+
+def tie_accounting(pbn, hc, names, score_fn, **kw):
+    """Driver-visible form of tests/test_tieflip_gpu.py (north star: "bit-exact node/arc indices"): the product's operator sequence
+    is REPLAYED inside the serial restatement (oracle/hc_oracle.py, `follow=`), which takes its own greedy decision from its own
+    (reference-arithmetic) deltas at every step.  Every step where the two differ is classified: a TIE of the restatement's own
+    deltas (gap <= 1e-9 relative: score-equivalent orientations decided in the last ulps by find_max's unstable sort,
+    operators.hpp:489-525) or a real divergence.  `non_tie_divergences` must be 0; `end_gain` is what the restatement could still
+    gain where the product stopped (0 = the product's graph is a local optimum of the reference's score)."""
+    from oracle import hc_oracle
+
+    idx = {c: i for i, c in enumerate(names)}
+    kinds = {pbn.AddArc: 0, pbn.RemoveArc: 1, pbn.FlipArc: 2}
+    trace = [(kinds[type(op)], idx[op.source()], idx[op.target()]) for op in hc.last.trace]
+    deltas = [op.delta() for op in hc.last.trace]
+    t0 = time.perf_counter()
+    _arcs, _types, r_trace, info = hc_oracle.estimate(len(names), 0, score_fn, follow=trace, tie_tol=float("inf"), **kw)
+    flips = info["flips"]
+    ties = [f for f in flips if f["gap"] <= TIE_TOL * max(1.0, abs(f["followed_delta"]))]
+    end_gain = info.get("end_gain")
+    return {"replayed_iterations": len(trace), "tie_flips": len(ties), "non_tie_divergences": len(flips) - len(ties),
+            "max_gap": max((f["gap"] for f in flips), default=0.0),
+            "max_rel_gap": max((f["gap"] / max(1.0, abs(f["followed_delta"])) for f in flips), default=0.0),
+            "flip_iterations": [f["iteration"] for f in flips][:32],
+            "max_delta_rel_diff": float(max((abs(a - b[3]) / max(1.0, abs(b[3])) for a, b in zip(deltas, r_trace)), default=0.0)),
+            "end_gain": end_gain, "product_graph_is_oracle_local_optimum": end_gain is not None and end_gain <= TIE_TOL,
+            "tie_tol_rel": TIE_TOL, "replay_s": time.perf_counter() - t0,
+            "how": "the product's trace replayed in oracle/hc_oracle.estimate(follow=...) over the oracle's own scores on the same rows"}
+
+
 def bench_c1(pbn):
     """BASELINE config 1 (the reference's CPU-runnable case): GaussianNetwork, 4 nodes, LinearGaussianCPD MLE fit + BIC on a
     10 k-row table - BIC hill-climb + fit + slogl through the device engine, and the SAME search by the serial restatement
@@ -259,6 +290,7 @@ def bench_c1(pbn):
                                "same_structure": sorted(arcs) == sorted(mine),
                                "same_skeleton": sorted(tuple(sorted(a_)) for a_ in arcs) == sorted(tuple(sorted(a_)) for a_ in mine),
                                "sample": f"the whole search, fit and log-likelihood by the serial restatement: {calls[0]} oracle BIC calls on all 10000 rows"}
+        out["tie_accounting"] = tie_accounting(pbn, hc, names, sc)
     except Exception as ex:
         out["cpu_baseline"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
     return out
@@ -398,15 +430,39 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
 
             rows = min(n_rows, 200_000)
             host = t[:, :rows].T.cpu().numpy()
+            cores = oracle.num_threads()
+            oracle.set_num_threads(1)
             t0 = time.perf_counter()
             oracle.cov(host)
             dcpu = (time.perf_counter() - t0) * (n_rows / rows)
+            oracle.set_num_threads(cores)
             more["cpu_baseline"] = {"value": hc.last.cells_scored / dcpu, "unit": "arcs/s", "score_ctor_s": dcpu, "kind": "port", "cores": 1,
                                     "sample": f"covariance of {rows} x {n_cols} rows on one thread (the reference's BGe constructor, bge.hpp:52-72), "
                                               f"scaled to {n_rows} rows; the per-candidate work is O(p^3) on the cached covariance on both sides and is "
                                               f"left out of the CPU time (an upper bound of the CPU rate); compare with value_with_ctor"}
         except Exception as ex:
             more["cpu_baseline"] = {"score_ctor_s": None, "sample": f"failed: {ex}"}
+        try:
+            # tie accounting on ALL rows: the oracle's whole-table moments once (two-pass, all cores - the sums do not depend on the
+            # thread count), then the reference's BGe arithmetic per local score from them (bge.hpp:52-68 caches exactly these)
+            from oracle import oracle
+
+            t0 = time.perf_counter()
+            full = np.asfortranarray(t.T.cpu().numpy())
+            cov_all, means_all = oracle.cov(full)
+            del full
+            t_cov = time.perf_counter() - t0
+            memo = {}
+
+            def sc(v, _nt, par):
+                key = (v, tuple(par))
+                if key not in memo:
+                    memo[key] = oracle.bge_cached(cov_all, means_all, n_rows, [v] + list(par), n_cols)
+                return memo[key]
+
+            more["tie_accounting"] = dict(tie_accounting(pbn, hc, names, sc), rows=n_rows, oracle_moments_s=t_cov)
+        except Exception as ex:
+            more["tie_accounting"] = {"error": f"{type(ex).__name__}: {ex}"}
     return {
         **more,
         "metric": "hill-climb candidate-arcs scored/s",
@@ -423,71 +479,181 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
     }
 
 
-def pmc_traffic(args):
-    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/r1/pmc_per_dispatch.json:
-    FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc runs of this same command; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the default workload; null otherwise."""
-    if (args.n_train, args.n_test, args.dtype, args.kde) != (1_000_000, 100_000, "f64", "product"):
-        return None, None
-    for rnd in ("r3", "r2", "r1"):
+def git_blob_sha1(path):
+    """`git hash-object` of a working-tree file (sha1 of "blob <size>\\0" + content), without calling git."""
+    import hashlib
+
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_record(kernel_substr):
+    """The committed rocprofv3 PMC record of one kernel (profiles/r*/pmc_per_dispatch.json, newest round first) - but only if it
+    was taken on THIS revision of the kernel source: the file stores the git blob hash of pybnesian_amd/csrc/kde_kernels.hip it was
+    collected on (`_source_blob`), and a record whose hash differs from the working tree's is stale evidence -> (None, reason)."""
+    src = os.path.join(ROOT, "pybnesian_amd", "csrc", "kde_kernels.hip")
+    try:
+        now = git_blob_sha1(src)
+    except OSError as ex:
+        return None, f"kernel source not readable: {ex}"
+    reason = "no profiles/r*/pmc_per_dispatch.json"
+    for rnd in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")
         try:
             with open(path) as f:
                 d = json.load(f)
-            k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4" in name)
-            return (2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0,
-                    f"committed rocprofv3 --pmc passes of this command (profiles/{rnd}/pmc_per_dispatch.json: 2 x FETCH_SIZE + "
-                    f"WRITE_SIZE), not measured in this run")
         except Exception:
             continue
-    return None, None
+        blob = d.get("_source_blob", {}).get("kde_kernels.hip")
+        if blob != now:
+            reason = (f"stale: profiles/{rnd}/pmc_per_dispatch.json was collected on kde_kernels.hip blob {str(blob)[:12]}, the working tree "
+                      f"has {now[:12]} - re-run tools/profile_bench.sh")
+            return None, reason
+        try:
+            k = next(v for name, v in d.items() if kernel_substr in name)
+        except StopIteration:
+            return None, f"profiles/{rnd}/pmc_per_dispatch.json has no record of {kernel_substr}"
+        return dict(k, _round=rnd, _blob=now), None
+    return None, reason
+
+
+SWEEP_KERNEL = "kde_sweep_kernel<double, 2, false, 4"
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in KB, collected in
+    separate --pmc runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the
+    default workload and for the kernel source the passes were taken on (pmc_record); null with the reason otherwise."""
+    if (args.n_train, args.n_test, args.dtype, args.kde) != (1_000_000, 100_000, "f64", "product"):
+        return None, "not the default workload"
+    k, why = pmc_record(SWEEP_KERNEL)
+    if k is None:
+        return None, why
+    return (2.0 * k["FETCH_SIZE"] * 1024.0 + k["WRITE_SIZE"] * 1024.0,
+            f"committed rocprofv3 --pmc passes of this command (profiles/{k['_round']}/pmc_per_dispatch.json: 2 x FETCH_SIZE + "
+            f"WRITE_SIZE; collected on kde_kernels.hip blob {k['_blob'][:12]} = the working tree's), not measured in this run")
+
+
+def parity_rows(torch, train_t, test_t, h_diag, n_first=1024, n_far=8, n_near=8):
+    """Rows of the test table the oracle is run on: the first `n_first` (random rows of the table) plus, for each of the `n_far`
+    training rows farthest from the centre in bandwidth units (the rows whose norms take the sweep's rare paths: WMUL weights that
+    underflow, redone chunks - DESIGN.md 3.1), the `n_near` test rows nearest to it."""
+    sd = torch.sqrt(torch.as_tensor(h_diag, dtype=torch.float64, device=train_t.device))[:, None]
+    zt = (train_t.double() - train_t.double().mean(dim=1, keepdim=True)) / sd
+    far = torch.topk((zt * zt).sum(dim=0), n_far).indices
+    zq = (test_t.double() - train_t.double().mean(dim=1, keepdim=True)) / sd
+    rows = [torch.arange(min(n_first, test_t.shape[1]), device=train_t.device)]
+    for i in far.tolist():
+        d2 = ((zq - zt[:, i:i + 1]) ** 2).sum(dim=0)
+        rows.append(torch.topk(d2, n_near, largest=False).indices)
+    rows = torch.unique(torch.cat(rows))
+    return rows.cpu().numpy(), float((zt * zt).sum(dim=0).max().item())
+
+
+def parity_block(torch, kde, test_table, train_t, test_t, slogl_step, tol, abs_tol=None):
+    """Oracle numbers against the BASELINE-size run itself: per-row logl of the WHOLE test table through the same device sweep the
+    timed steps ran (its sum must reproduce the timed step's slogl), and the oracle's logl (pbn_oracle.cpp: the reference's
+    arithmetic, fp64, all N_train rows) on `parity_rows`.  `ok` = relative slogl difference over those rows <= tol and every
+    per-row logl within tol relative (fp32 tables: within abs_tol absolute, the reference tests' own fp32 tolerance)."""
+    from oracle import oracle
+
+    t0 = time.perf_counter()
+    got_all = kde.logl_table(test_table)
+    bw = np.asarray(kde.bandwidth, dtype=np.float64)
+    h_diag = bw if bw.ndim == 1 else np.diag(bw)
+    rows, max_z2 = parity_rows(torch, train_t, test_t, h_diag)
+    train_np = train_t.T.cpu().numpy().astype(np.float64)
+    test_np = test_t.T.cpu().numpy().astype(np.float64)[rows]
+    fn = oracle.product_kde_logl if bw.ndim == 1 else oracle.kde_logl
+    want = fn(train_np, bw, test_np)
+    got = got_all[rows]
+    rel = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    rel_slogl = abs(got.sum() - want.sum()) / abs(want.sum())
+    sum_rel = abs(got_all.sum() - slogl_step) / abs(slogl_step)
+    ok = bool(rel_slogl <= tol and sum_rel <= 1e-9 and np.isfinite(got_all).all()
+              and (np.abs(got - want).max() <= abs_tol if abs_tol is not None else rel.max() <= tol))
+    return {"ok": ok, "rows": int(rows.size), "n_train": int(train_np.shape[0]), "max_rel_logl": float(rel.max()), "max_abs_logl": float(np.abs(got - want).max()),
+            "rel_slogl": float(rel_slogl), "tol": tol, "abs_tol": abs_tol, "sum_of_device_logl_vs_timed_slogl_rel": float(sum_rel),
+            "max_whitened_norm2_of_training_rows": max_z2, "seconds": time.perf_counter() - t0,
+            "how": "device logl of all test rows (the timed sweep's shape) vs oracle/pbn_oracle.cpp (reference arithmetic, fp64) on the first 1024 "
+                   "test rows + the 8 test rows nearest each of the 8 farthest-out training rows, against ALL training rows"}
 
 
 def cpu_baseline(train_np, test_np, h, budget_s=12.0):
-    """Oracle (port of the reference algorithm, kde/ProductKDE.hpp:240-293) on all host cores, bounded sample."""
-    from oracle import oracle
+    """CPU side of the headline metric on the host cores of the GPU box, bounded sample.  `value` = the tuned CPU form
+    (oracle/pbn_baseline.cpp: whitened once, training tiles reused by blocks of 16 test rows, vectorised exponentials, OpenMP over
+    query blocks; built here with -Ofast -march=native) on all cores; beside it the same on ONE thread (the reference's KDE path is
+    single-threaded on the host side), the scaling efficiency, and `reference_arithmetic_port` = the checker (pbn_oracle.cpp: the
+    reference's per-pair arithmetic, kde/ProductKDE.hpp:240-293, scalar exp, -O2) that round 1-3 reported as the baseline."""
+    from oracle import baseline, oracle
 
-    cores = oracle.num_threads()
-    probe = max(cores, 8)
-    t0 = time.perf_counter()
-    oracle.product_kde_logl(train_np, h, test_np[:probe])
-    dt = time.perf_counter() - t0
-    rows = int(min(test_np.shape[0], max(probe, probe * budget_s / max(dt, 1e-3))))
-    rows = max(cores, rows // cores * cores)
-    t0 = time.perf_counter()
-    oracle.product_kde_logl(train_np, h, test_np[:rows])
-    dt = time.perf_counter() - t0
-    out = {
-        "value": rows / dt / 1e6,
-        "unit": "M-samples/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{rows} test rows x {train_np.shape[0]} training rows, d={D}, fp64, {dt:.1f}s wall, OpenMP over test rows",
-    }
-    # SURVEY.md §8d also asks for the single-thread port (the reference itself is single-threaded) and for scipy's
-    # gaussian_kde, the oracle of the reference's own tests (full covariance, so not the same kernel as C2's diagonal one)
-    try:
-        one = max(8, min(64, rows // max(cores, 1)))
-        oracle.set_num_threads(1)
+    full = np.ndim(h) == 2
+    fast = baseline.kde_logl if full else baseline.product_kde_logl
+    slow = oracle.kde_logl if full else oracle.product_kde_logl
+    cores = baseline.num_threads()
+    n_train = train_np.shape[0]
+
+    def timed(fn, rows):
         t0 = time.perf_counter()
-        oracle.product_kde_logl(train_np, h, test_np[:one])
-        d1 = time.perf_counter() - t0
-        oracle.set_num_threads(cores)
-        out["single_thread"] = {"value": one / d1 / 1e6, "unit": "M-samples/s", "sample": f"{one} test rows, {d1:.1f}s wall"}
+        r = fn(train_np, h, test_np[:rows])
+        return time.perf_counter() - t0, r
+
+    def sized(fn, threads, budget):
+        probe = max(threads, 16)
+        probe = min(test_np.shape[0], (probe + 15) // 16 * 16)
+        dt, _ = timed(fn, probe)
+        rows = int(min(test_np.shape[0], max(probe, probe * budget / max(dt, 1e-3))))
+        rows = max(probe, rows // (16 * threads) * (16 * threads))
+        dt, r = timed(fn, rows)
+        return rows, dt, r
+
+    fast(train_np[:4096], h, test_np[:16])                      # build / load outside the timed calls
+    rows, dt, r_fast = sized(fast, cores, budget_s * 0.45)
+    chk = slow(train_np, h, test_np[:min(rows, 4 * oracle.num_threads())])   # the tuned form against the checker
+    out = {
+        "value": rows / dt / 1e6, "unit": "M-samples/s", "cores": cores, "kind": "port",
+        "pairs_per_s": rows * n_train / dt, "pairs_per_s_per_thread": rows * n_train / dt / cores,
+        "max_rel_vs_checker": float(np.max(np.abs(r_fast[:chk.size] - chk) / np.maximum(1.0, np.abs(chk)))),
+        "cpu": baseline.cpu_model(),
+        "sample": f"{rows} test rows x {n_train} training rows, d={D}, fp64, {dt:.1f}s wall; oracle/pbn_baseline.cpp (whitened, blocked 16 x 2048, "
+                  f"libmvec exponentials, -Ofast -march=native), OpenMP over blocks of 16 test rows",
+    }
+    try:
+        baseline.set_num_threads(1)
+        rows1, d1, _ = sized(fast, 1, budget_s * 0.2)
+        baseline.set_num_threads(cores)
+        out["single_thread"] = {"value": rows1 / d1 / 1e6, "unit": "M-samples/s", "pairs_per_s": rows1 * n_train / d1,
+                                "sample": f"{rows1} test rows, {d1:.1f}s wall, same code on one thread"}
+        out["all_cores_over_one_thread"] = (rows / dt) / (rows1 / d1)
+        out["scaling_efficiency"] = (rows / dt) / (rows1 / d1) / cores
+        # the checker's own speed (what rounds 1-3 reported as the CPU baseline): reference arithmetic, scalar exp
+        ocores = oracle.num_threads()
+        rows_o, d_o, _ = sized(slow, ocores, budget_s * 0.2)
+        oracle.set_num_threads(1)
+        one = max(8, min(32, rows_o // max(ocores, 1)))
+        d_o1, _ = timed(slow, one)
+        oracle.set_num_threads(ocores)
+        out["reference_arithmetic_port"] = {"value": rows_o / d_o / 1e6, "unit": "M-samples/s", "cores": ocores,
+                                            "single_thread": one / d_o1 / 1e6,
+                                            "sample": f"{rows_o} test rows in {d_o:.1f}s on {ocores} threads, {one} rows in {d_o1:.1f}s on one: pbn_oracle.cpp, "
+                                                      f"the reference's operation order (difference, divide, square per pair; max -> exp -> sum -> log), -O2"}
         from scipy.stats import gaussian_kde
 
-        sub = train_np[:: max(1, train_np.shape[0] // 100_000)]          # scipy needs N x m memory: 1e5 training rows
+        sub = train_np[:: max(1, n_train // 100_000)]          # scipy needs N x m memory: 1e5 training rows
         k = gaussian_kde(sub.T)
         m = min(200, test_np.shape[0])
         t0 = time.perf_counter()
         k.logpdf(test_np[:m].T)
         d2 = time.perf_counter() - t0
-        scale = train_np.shape[0] / sub.shape[0]
+        scale = n_train / sub.shape[0]
         out["scipy_gaussian_kde"] = {"value": m / (d2 * scale) / 1e6, "unit": "M-samples/s",
                                      "sample": f"full-covariance gaussian_kde.logpdf, {m} test rows x {sub.shape[0]} training rows in {d2:.1f}s, "
-                                               f"scaled linearly to {train_np.shape[0]} training rows"}
+                                               f"scaled linearly to {n_train} training rows"}
     except Exception as ex:
         out["extra_error"] = f"{type(ex).__name__}: {ex}"
+    finally:
+        baseline.set_num_threads(cores)
     return out
 
 
@@ -531,20 +697,16 @@ def e2e_host(pbn, kde, names, test_np, repeats=3):
 
 def dp_issue_util():
     """Share of the FP64 issue slots the sweep kept busy, from the committed rocprofv3 PMC pass of this command:
-    (MFMA busy cycles + 4 cycles per VALU wave-instruction) / (cycles x 1024 SIMDs)."""
-    for rnd in ("r3", "r2", "r1"):
-        try:
-            with open(os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")) as f:
-                d = json.load(f)
-            k = next(v for name, v in d.items() if "kde_sweep_kernel<double, 2, false, 4" in name)
-            simd_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-            return {"value": (k["SQ_VALU_MFMA_BUSY_CYCLES"] + 4.0 * k["SQ_INSTS_VALU"]) / simd_cycles,
-                    "mfma_busy_frac": k["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
-                    "valu_insts_per_pair_value": k["SQ_INSTS_VALU"] * 64.0 / 1e11,
-                    "source": f"profiles/{rnd}/pmc_per_dispatch.json (separate rocprofv3 --pmc pass, not this run)"}
-        except Exception:
-            continue
-    return None
+    (MFMA busy cycles + 4 cycles per VALU wave-instruction) / (cycles x 1024 SIMDs).  Null with the reason when the pass was
+    taken on another revision of the kernel source (pmc_record)."""
+    k, why = pmc_record(SWEEP_KERNEL)
+    if k is None:
+        return {"value": None, "reason": why}
+    simd_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+    return {"value": (k["SQ_VALU_MFMA_BUSY_CYCLES"] + 4.0 * k["SQ_INSTS_VALU"]) / simd_cycles,
+            "mfma_busy_frac": k["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
+            "valu_insts_per_pair_value": k["SQ_INSTS_VALU"] * 64.0 / 1e11,
+            "source": f"profiles/{k['_round']}/pmc_per_dispatch.json (separate rocprofv3 --pmc pass on kde_kernels.hip blob {k['_blob'][:12]}, not this run)"}
 
 
 def main():
@@ -588,6 +750,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen, devs = None, None
     if world > 1:
         import torch.distributed as dist
 
@@ -596,6 +759,12 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
+        # the collective really runs over `world` ranks of this backend: one all_reduce of ones (nccl: on the device = RCCL over xGMI)
+        ones = torch.ones(1, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        devs = [None] * world
+        dist.all_gather_object(devs, (rank, local_rank, torch.cuda.get_device_properties(local_rank).name))
 
     import pybnesian_amd as pbn
     from pybnesian_amd import _lib
@@ -646,12 +815,17 @@ def main():
 
     hc_out = None
     legs = {}
+    exit_code = 0
 
     def leg(name, fn):
         try:
             legs[name] = fn()
         except Exception as ex:  # a secondary leg must never cost the headline line
             legs[name] = {"metric": "hill-climb candidate-arcs scored/s", "value": None, "error": f"{type(ex).__name__}: {ex}"}
+        if dist is not None:     # every rank's own time for the leg (the value is rank 0's; all ranks run the same search in lock step)
+            per = [None] * world
+            dist.all_gather_object(per, legs[name].get("estimate_s"))
+            legs[name]["per_rank_estimate_s"] = per
 
     if args.no_cpu_baseline:
         os.environ["PBN_BENCH_NO_CPU"] = "1"
@@ -717,7 +891,13 @@ def main():
             ctx.set_profiling(False)
             pairs_ = float(args.n_train) * float(args.n_test)
             peak_pairs = 256 * 4 * 2.4e9 * 64.0 / F32_VALU_CYCLES_PER_VALUE
-            return {"metric": "KDE slogl M-samples/s", "dtype": "f32", "value": args.n_test * 5 / el / 1e6, "unit": "M-samples/s", "ms_per_step": el / 5 * 1e3,
+            par32 = None
+            if not args.no_cpu_baseline:
+                try:   # north star: fp32 slogl within 1e-3 relative; per row the reference tests' own fp32 tolerance (atol 5e-4; 5e-3 ProductKDE)
+                    par32 = parity_block(torch, k32, b, tr32, te32, float(buf[2].item()), 1e-3, abs_tol=5e-3 if args.kde == "product" else 5e-4)
+                except Exception as ex:
+                    par32 = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+            return {"metric": "KDE slogl M-samples/s", "dtype": "f32", "parity": par32, "value": args.n_test * 5 / el / 1e6, "unit": "M-samples/s", "ms_per_step": el / 5 * 1e3,
                     "slogl": float(buf[2].item()), "rel_diff_vs_f64": abs(float(buf[2].item()) - slogl) / abs(slogl),
                     "roofline": {"kernel": "kde_sweep_bf16_kernel", "bound": "valu-issue", "avg_launch_ms": ms / max(nl, 1),
                                  "frac": pairs_ / (ms / max(nl, 1) * 1e-3) / peak_pairs,
@@ -771,6 +951,9 @@ def main():
                 "parallelism": f"test rows sharded over {world} GPU(s), training set replicated",
                 "ranks": world,
                 "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+                "rccl_ranks_seen": ranks_seen if args.backend == "nccl" else None,
+                "ranks_seen": ranks_seen,
+                "rank_devices": devs,
                 "pairs_per_step_per_gpu": pairs,
                 "slogl_step0_rank_sum": slogl,
             },
@@ -794,7 +977,7 @@ def main():
                 "finish_ms": fin_ms / max(sweep_n, 1),
             },
         }
-        if args.dtype == "f64" and traffic is not None:
+        if args.dtype == "f64":
             out["roofline"]["dp_issue_util"] = dp_issue_util()
         if hc_out is not None:
             out["secondary"] = hc_out
@@ -805,6 +988,12 @@ def main():
             except Exception as ex:
                 out["e2e_host"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not args.no_cpu_baseline:
+            # the oracle against THIS run (BASELINE size): north star bar 1e-6 relative in fp64, 1e-3 in fp32
+            try:
+                out["parity"] = parity_block(torch, kde, test, train_t, test_t, slogl, 1e-6 if args.dtype == "f64" else 1e-3,
+                                             abs_tol=None if args.dtype == "f64" else (5e-3 if args.kde == "product" else 5e-4))
+            except Exception as ex:
+                out["parity"] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
             h = np.asarray(kde.bandwidth, dtype=np.float64)
             sample_rows = min(args.n_test, 16384)
             train_np = train_t.T.cpu().numpy().astype(np.float64)
@@ -814,8 +1003,15 @@ def main():
             except Exception as ex:  # never lose the headline line to the baseline leg
                 out["cpu_baseline"] = {"value": None, "unit": "M-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out), flush=True)
+        bad = [k_ for k_, v_ in [("headline", out)] + list(legs.items()) if isinstance(v_.get("parity"), dict) and not v_["parity"].get("ok")]
+        bad += [k_ for k_, v_ in [("secondary", hc_out or {})] + list(legs.items())
+                if isinstance(v_.get("tie_accounting"), dict) and v_["tie_accounting"].get("non_tie_divergences", 0) > 0]
+        if bad:
+            print(f"bench.py: PARITY FAILED in {bad} (see the `parity` / `tie_accounting` objects of the line above)", file=sys.stderr, flush=True)
+            exit_code = 3
     if dist is not None:
         dist.destroy_process_group()
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -301,6 +301,7 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
             cache_arcs()
     p, offset, tabu, trace, it = 0, 0.0, [], [], 0
     flips = []
+    end_gain = [None]
 
     def delta_of(kind, a, b):
         if kind == 3:
@@ -315,6 +316,7 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
         if follow is not None:
             stop = op is None or (op[3] - epsilon) < MACHINE_TOL
             if it - 1 >= len(follow):
+                end_gain[0] = 0.0 if stop else float(op[3])   # what the restatement would still gain where the followed trace stops
                 if not stop and op[3] > tie_tol * max(1.0, abs(op[3])) + MACHINE_TOL:
                     raise AssertionError(f"followed trace stops at iteration {it} but the restatement still improves by {op[3]} with {op[:3]}")
                 break
@@ -367,4 +369,4 @@ def estimate(n, bn_type, score, vscore=None, node_types=None, arcs=(), arc_black
             update_types(changed)
     res = m if best_is_current else best_model
     arcs_out = [(s, t) for t in range(n) for s in res.parents[t]]
-    return arcs_out, list(res.node_type), trace, {"iterations": it, "cells_scored": cells[0], "flips": flips}
+    return arcs_out, list(res.node_type), trace, {"iterations": it, "cells_scored": cells[0], "flips": flips, "end_gain": end_gain[0]}

@@ -70,6 +70,20 @@ void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_
     for (int i = 0; i < d; ++i) out[i] = f * cov[i + (size_t)i * d];
 }
 
+// The d x d block a FULL bandwidth matrix of `rule_d` >= d variables has over d of them, from THEIR covariance alone: both library
+// selectors are H = k(N, rule_d) cov (kde/ScottsBandwidth.hpp:100-117, kde/NormalReferenceRule.hpp:109-134), so the block is
+// k(N, rule_d) cov_sub - the very doubles of the sub-block of bandwidth_from_cov on the whole set.  Pre-checks on the block's own columns.
+void bandwidth_full_block(int selector, const double* cov, int d, int rule_d, int64_t n, int dtype, double* out) {
+    if (!cov || !out || d <= 0 || rule_d < d) throw invalid_error("pbn_bandwidth: bad argument");
+    if (selector != PBN_SEL_SCOTT && selector != PBN_SEL_NORMAL_REFERENCE) throw invalid_error("pbn_bandwidth: unknown selector");
+    if (n <= d)
+        throw singular_error("Bandwidth matrix of " + std::to_string(d) + " variables cannot be estimated with " + std::to_string(n) + " instances");
+    if (!hm::is_psd(cov, d, dtype == PBN_F32)) throw singular_error("Covariance matrix is not positive-definite.");
+    const double N = (double)n, D = (double)rule_d;
+    const double k = selector == PBN_SEL_SCOTT ? std::pow(N, -2.0 / (D + 4.0)) : std::pow(4.0 / (N * (D + 2.0)), 2.0 / (D + 4.0));
+    for (int i = 0; i < d * d; ++i) out[i] = k * cov[i];
+}
+
 KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n) {
     const size_t es = dtype_size(dtype);
     const int64_t ntiles = ceil_div(n, 16);

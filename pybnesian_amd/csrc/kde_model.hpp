@@ -66,6 +66,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
 
 // Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
 void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);
+void bandwidth_full_block(int selector, const double* cov, int d, int rule_d, int64_t n, int dtype, double* out);
 
 void check_cols(const pbn_table* t, const int* cols, int d, const char* who);
 void check_range(const pbn_table* t, int64_t row0, int64_t n, const char* who);

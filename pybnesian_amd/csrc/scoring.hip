@@ -763,7 +763,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
         // the batch being assembled is lost).
         static const size_t cache_budget = [] { const char* e = getenv("PBN_SCORE_CACHE_ENTRIES"); const long long v = (e && *e) ? atoll(e) : (1ll << 21); return (size_t)(v < 1 ? 1 : v); }();
         if (sd->kde_cache.size() > cache_budget) { sd->kde_cache.clear(); ++sd->cache_resets; }
-        if (sd->term_total.size() > cache_budget) { sd->term_total.clear(); ++sd->cache_resets; }
+        // (term_total is trimmed in pbn_score_terms_put only: every rank of a job reaches that call with the same state, whereas a rank
+        //  whose dealt list is empty skips the evaluation call - trimming here would let the ranks' "missing" lists drift apart)
         if (sd->score_memo.size() > cache_budget) { sd->score_memo.clear(); ++sd->cache_resets; }
         // BGe parameters
         double iss_mu = 1, iss_w = sd->n + 2;
@@ -955,12 +956,15 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 for (int f = 0; f < pd.units; ++f) {
                     const int region = cv ? f : sd->k;                    // fold index, or the hold-out region
                     const int wnt = want ? want[c] : 0;
-                    Unit u{c, {}, {}, p > 0 && wnt != 1, wnt};
+                    Unit u{c, {}, {}, wnt == 3 || (p > 0 && wnt != 1), wnt};
                     const std::vector<int> kj = key_of(region, d, cols.data(), d);
-                    const bool have_j = wnt == 2 || lookup_total(d, cols.data(), d, f, u.joint) || lookup(kj, u.joint);
+                    const bool have_j = wnt >= 2 || lookup_total(d, cols.data(), d, f, u.joint) || lookup(kj, u.joint);
                     bool have_m = true;
                     std::vector<int> km;
-                    if (u.has_marg) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup_total(d, cols.data() + 1, p, f, u.marg) || lookup(km, u.marg); }
+                    if (wnt == 3) {   // a marginal TERM (pbn_score_terms): all d columns of the pseudo-candidate under the rule for d + 1 dimensions, no child
+                        km = key_of(region, d + 1, cols.data(), d);
+                        have_m = lookup_total(d + 1, cols.data(), d, f, u.marg) || lookup(km, u.marg);
+                    } else if (u.has_marg) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup_total(d, cols.data() + 1, p, f, u.marg) || lookup(km, u.marg); }
                     if (!have_j && !have_m && fused) {
                         u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
                         work.push_back({c, f, 0, u.joint.slot, u.marg.slot});
@@ -1009,6 +1013,17 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
                 const double inv = 1.0 / (double)(tr->N - 1);
                 for (auto& x : sse) x *= inv;  // covariance
+                if (w.mode == 2 && want && want[c] == 3) {
+                    // a marginal term evaluated for itself (a job that deals the terms to its ranks): KDE of these d columns with
+                    // H = k(N, d + 1) cov - the block the joint bandwidth of ANY child over them would have (H = k(N, dims) cov for the
+                    // library selectors), bit for bit, without a child whose own degeneracy (a constant column ...) has nothing to do
+                    // with the term.  The pre-checks of the selector stand on the term's own columns; the real candidate's set is
+                    // checked by its joint term.
+                    bandwidth_full_block(sd->selector, sse.data(), d, d + 1, tr->N, sd->dtype, H.data());
+                    kde_prepare(pr.m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, false, mu.data());
+                    pr.use = cols;
+                    return;
+                }
                 bandwidth_from_cov(sd->selector, PBN_BW_FULL, sse.data(), d, tr->N, sd->dtype, H.data());
                 if (w.mode == 2) {            // KDE of the parents with the bandwidth block of the parents
                     const int vp = (int)(std::find(cols.begin(), cols.end(), var0) - cols.begin());
@@ -1043,13 +1058,14 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 const Work& w = work[wi];
                 if (w.mode == 0) continue;
                 const int p = par_off[w.cand + 1] - par_off[w.cand];
-                const int dims = w.mode == 2 ? p : p + 1;
+                const bool own_term = w.mode == 2 && want && want[w.cand] == 3;   // marginal term over all p + 1 columns, rule for p + 2
+                const int dims = own_term ? p + 1 : (w.mode == 2 ? p : p + 1);
                 if (!kde_group_applies(sd->dtype, dims, min_train, R)) continue;
                 Prep pr;
                 prepare(w, pr);
                 std::vector<int> key(pr.use);
                 std::sort(key.begin(), key.end());
-                key.insert(key.begin(), p + 1);
+                key.insert(key.begin(), own_term ? p + 2 : p + 1);
                 auto it = pool_of.find(key);
                 int pi;
                 if (it == pool_of.end()) {
@@ -1135,12 +1151,12 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             // what pbn_score_terms hands out, so a job that computes the terms on different ranks assembles the same doubles
             std::vector<double> jsum((size_t)n_cand, 0.0), msum((size_t)n_cand, 0.0);
             for (const Unit& u : units_v) {
-                if (u.want != 2) jsum[u.cand] += u.joint.slot >= 0 ? hs[u.joint.slot] : u.joint.value;
+                if (u.want < 2) jsum[u.cand] += u.joint.slot >= 0 ? hs[u.joint.slot] : u.joint.value;
                 if (u.has_marg) msum[u.cand] += u.marg.slot >= 0 ? hs[u.marg.slot] : u.marg.value;
             }
             for (const Pending& pd : pending) {
                 const int wnt = want ? want[pd.cand] : 0;
-                out[pd.cand] = wnt == 2 ? msum[pd.cand] : (wnt == 1 ? jsum[pd.cand] : jsum[pd.cand] - msum[pd.cand]);
+                out[pd.cand] = wnt >= 2 ? msum[pd.cand] : (wnt == 1 ? jsum[pd.cand] : jsum[pd.cand] - msum[pd.cand]);
             }
         }
     });
@@ -1178,27 +1194,24 @@ int pbn_score_terms(pbn_scoredata* sd, int kind, int n_terms, const int* off, co
     return guarded(mu_of(sd), [&] {
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms");
         if (n_terms > 0 && !out) throw invalid_error("pbn_score_terms: null output");
-        // every term as a pseudo-candidate of the batch engine: a joint term = (first column | the others), joint half only; a marginal
-        // term = (any other column | the term's columns), marginal half only - the bandwidth block of the parents does not depend on
-        // the child (H = k(N, d) cov for the library selectors)
+        // every term as a pseudo-candidate of the batch engine over the term's OWN columns (first column | the others): a joint term
+        // asks for the joint half only (want 1), a marginal term for "the KDE of all my columns under the rule for one more dimension"
+        // (want 3) - no pseudo-child: the bandwidth block of the parents does not depend on the child (H = k(N, d) cov for the library
+        // selectors), and a degenerate unrelated column must not fail a term no real candidate pairs with it
         std::vector<int> var((size_t)n_terms), nt((size_t)n_terms, PBN_NODE_CKDE), po{0}, par, want((size_t)n_terms);
         for (int i = 0; i < n_terms; ++i) {
             const int nv = off[i + 1] - off[i];
             const int* v = vars + off[i];
-            if (m[i] == nv) {
-                var[i] = v[0]; want[i] = 1;
-                par.insert(par.end(), v + 1, v + nv);
-            } else {
-                int child = 0;
-                while (std::find(v, v + nv, child) != v + nv) ++child;
-                if (child >= sd->n) throw invalid_error("pbn_score_terms: a marginal term needs a column outside it");
-                var[i] = child; want[i] = 2;
-                par.insert(par.end(), v, v + nv);
-            }
+            var[i] = v[0];
+            want[i] = m[i] == nv ? 1 : 3;
+            par.insert(par.end(), v + 1, v + nv);
             po.push_back((int)par.size());
         }
         if (n_terms > 0) {
             const int rc = score_batch_impl(sd, kind, n_terms, var.data(), nt.data(), po.data(), par.data(), nullptr, 0, out, want.data());
+            // the inner status class goes out unchanged: a SingularCovarianceData of a term is one on every rank, not a device error
+            if (rc == PBN_ERR_SINGULAR) throw singular_error(pbn_last_error());
+            if (rc == PBN_ERR_INVALID) throw invalid_error(pbn_last_error());
             if (rc != PBN_OK) throw device_error(pbn_last_error());
         }
     });
@@ -1208,6 +1221,8 @@ int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off
     return guarded(mu_of(sd), [&] {
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_put");
         if (n_terms > 0 && !values) throw invalid_error("pbn_score_terms_put: null values");
+        static const size_t budget = [] { const char* e = getenv("PBN_SCORE_CACHE_ENTRIES"); const long long v = (e && *e) ? atoll(e) : (1ll << 21); return (size_t)(v < 1 ? 1 : v); }();
+        if (sd->term_total.size() > budget) { sd->term_total.clear(); ++sd->cache_resets; }   // before the new terms go in: the batch being assembled keeps its own
         for (int i = 0; i < n_terms; ++i) sd->term_total[term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])] = values[i];
     });
 }
@@ -1226,6 +1241,8 @@ int pbn_score_batch_parts(pbn_scoredata* sd, int kind, int n_cand, const int* va
         std::fill(out, out + (size_t)n_cand * PBN_HYBRID_PARTS, 0.0);
         if (n_cand > 0) {
             const int rc = score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, nullptr, 0, whole.data(), nullptr, part, n_parts, out);
+            if (rc == PBN_ERR_SINGULAR) throw singular_error(pbn_last_error());
+            if (rc == PBN_ERR_INVALID) throw invalid_error(pbn_last_error());
             if (rc != PBN_OK) throw device_error(pbn_last_error());
         }
     });

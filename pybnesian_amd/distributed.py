@@ -38,11 +38,16 @@ def _all_gather(dist, buf):
         dist.all_gather_into_tensor(recv, send)
         return recv.numpy()
     dev = torch.device("cuda", torch.cuda.current_device())
-    key = (buf.size, dev.index)
-    if key not in _GATHER_BUFS:
-        _GATHER_BUFS[key] = (torch.empty(buf.size, dtype=torch.float64).pin_memory(), torch.empty(buf.size, dtype=torch.float64, device=dev),
-                             torch.empty(world * buf.size, dtype=torch.float64, device=dev), torch.empty(world * buf.size, dtype=torch.float64).pin_memory())
-    send_h, send_d, recv_d, recv_h = _GATHER_BUFS[key]
+    # ONE set of staging buffers per device, grown to the next power of two and sliced for the current length (batch lengths vary over
+    # a search: a set per exact length would accumulate pinned allocations, each costing more than the pageable copy it replaces)
+    cap = 1 << max(10, int(buf.size - 1).bit_length())
+    have = _GATHER_BUFS.get(dev.index)
+    if have is None or have[0].numel() < cap:
+        have = (torch.empty(cap, dtype=torch.float64).pin_memory(), torch.empty(cap, dtype=torch.float64, device=dev),
+                torch.empty(world * cap, dtype=torch.float64, device=dev), torch.empty(world * cap, dtype=torch.float64).pin_memory())
+        _GATHER_BUFS[dev.index] = have
+    n = buf.size
+    send_h, send_d, recv_d, recv_h = have[0][:n], have[1][:n], have[2][: world * n], have[3][: world * n]
     send_h.numpy()[:] = buf
     send_d.copy_(send_h, non_blocking=True)
     dist.all_gather_into_tensor(recv_d, send_d)

@@ -294,6 +294,17 @@ class _KDEBase:
         _lib.check(_lib.load().pbn_kde_slogl(self._handle, table.handle, _lib.int_array(idx), row0, n, C.byref(res)))
         return res.value
 
+    def logl_table(self, table, names=None, row0=0, n=None):
+        """Per-row logl of rows [row0, row0 + n) of a device-resident table (the bench's parity block, the full-size tests)."""
+        self._check_fitted()
+        if table.dtype != self._dtype:
+            raise ValueError("Data type of training and test datasets is different.")
+        idx = table.index(self._variables if names is None else names)
+        n = table.num_rows - row0 if n is None else n
+        vals = np.empty(n, dtype=np.float64)
+        _lib.check(_lib.load().pbn_kde_logl(self._handle, table.handle, _lib.int_array(idx), row0, n, _lib.dptr(vals)))
+        return vals
+
     def slogl_table_async(self, table, dev_out_ptr, names=None, row0=0, n=None):
         """Enqueue one slogl on the context stream; the scalar lands at DEVICE address dev_out_ptr."""
         self._check_fitted()

@@ -85,10 +85,24 @@ if __name__ == "__main__":
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else "gloo"
+    seen = None
     if world > 1:
-        dist.init_process_group("gloo")
+        if backend == "nccl":   # RCCL over xGMI: one device per rank (PBN_DEVICE = LOCAL_RANK, set by the launcher)
+            import torch
+
+            dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=dev)
+            ones = torch.ones(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(ones)
+            seen = int(ones.item())
+        else:
+            dist.init_process_group("gloo")
     out = run()
     out["rank"] = int(os.environ.get("RANK", "0"))
+    out["backend"] = backend if world > 1 else None
+    out["ranks_seen"] = seen
     print("RESULT " + json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

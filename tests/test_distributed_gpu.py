@@ -25,15 +25,15 @@ def _free_port():
     return port
 
 
-def _launch(world):
+def _launch(world, backend="gloo"):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ)
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   PBN_DEVICE="0",   # one GPU: every rank's context on device 0
+                   PBN_DEVICE="0" if backend == "gloo" else str(rank),   # gloo on one GPU: every rank's context on device 0; nccl: one device per rank
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker_gpu.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker_gpu.py"), "--backend", backend], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     results = [p.communicate(timeout=600) for p in procs]
@@ -44,9 +44,23 @@ def _launch(world):
     return outs
 
 
-def test_sharded_delta_cache_with_device_ckde_scores_world2():
+def _device_count():
+    import torch
+
+    return torch.cuda.device_count()   # does not initialise the GPU in this process
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_sharded_delta_cache_with_device_ckde_scores_world2(backend):
+    """gloo: two ranks on ONE GPU (what a gpurun box has).  nccl: the same job over RCCL / xGMI with one device per rank - runs
+    wherever two GPUs are visible (the driver's 8-GPU node), skipped otherwise: same assertions, the only code that differs is the
+    staging of the gathered vector (distributed._all_gather)."""
+    if backend == "nccl" and _device_count() < 2:
+        pytest.skip("RCCL needs one device per rank: fewer than 2 GPUs visible")
     single = _launch(1)[0]
-    ranks = _launch(2)
+    ranks = _launch(2, backend)
+    if backend == "nccl":
+        assert all(r["ranks_seen"] == 2 and r["backend"] == "nccl" for r in ranks)
     assert len(single["trace"]) >= 3 and any(t[0] == 3 for t in single["trace"]) or len(single["arcs"]) >= 2
     for r in ranks:
         assert r["trace"] == single["trace"], (r["trace"], single["trace"])

@@ -1,5 +1,10 @@
-"""GPU tier: BASELINE.json full sizes through size-independent properties (the oracle cannot finish these):
-C2 (ProductKDE.slogl fp64, 1e6 x 1e5, d = 8) and C4 (64-node BGe hill-climb on 2M rows)."""
+"""GPU tier: BASELINE.json full sizes.  Size-independent properties (the oracle cannot finish the whole configurations): C2
+(ProductKDE.slogl fp64, 1e6 x 1e5, d = 8), C4 (64-node BGe hill-climb on 2M rows), C3, C5 - and, since round 4, ORACLE VALUES at
+those sizes wherever the oracle finishes in seconds: ~1 100 test rows of C2 against all 1e6 training rows (incl. the queries next to
+the farthest-out training rows, where the sweep's rare paths run), C3 candidates on one full-size fold (CKDE handles: 512 test rows
+against 450 000 training rows; the score engine's grouped path: a hold-out score with 499 000 training and 1 000 test rows), C5's
+fp32 hybrid slices the same way, C4's BGe local scores on all 2M rows.  The reference's tests compare values, not properties
+(tests/factors/continuous/KDE_test.py:167-203, CKDE_test.py:316-349)."""
 import numpy as np
 import pytest
 
@@ -52,6 +57,92 @@ def test_c2_fullsize_properties(env):
     kde3.fit_table(_table(torch, pbn, _lib, ctx, (train_t + shift).contiguous(), names))
     got = kde3.slogl_table(_table(torch, pbn, _lib, ctx, (test_t[:, :20_000] + shift).contiguous(), names))
     assert abs(got - kde.slogl_table(test, row0=0, n=20_000)) <= 1e-7 * abs(got)
+
+
+def test_c2_fullsize_against_the_oracle(env):
+    """bench.py's parity block as a test: the per-row logl of the whole C2 test table (the timed sweep's own launch shape) against
+    oracle/pbn_oracle.cpp on the first 1024 rows + the 8 test rows nearest each of the 8 farthest-out training rows (||z||^2 > 1780:
+    weights that underflow, redone chunks), all 1e6 training rows each - 1.1e9 pairs on the host."""
+    torch, pbn, _lib, ctx = env
+    import bench
+
+    dev = torch.device("cuda", 0)
+    train_t, test_t = bench.make_tables(torch, dev, 1_000_000, 100_000, 0, 1, torch.float64)
+    names = [f"v{i}" for i in range(8)]
+    train, test = _table(torch, pbn, _lib, ctx, train_t, names), _table(torch, pbn, _lib, ctx, test_t, names)
+    kde = pbn.ProductKDE(names)
+    kde.fit_table(train)
+    par = bench.parity_block(torch, kde, test, train_t, test_t, kde.slogl_table(test), 1e-6)
+    assert par["ok"], par
+    assert par["rows"] >= 1024 + 8 and par["max_whitened_norm2_of_training_rows"] > 1000.0
+    assert par["max_rel_logl"] <= 1e-8 and par["rel_slogl"] <= 1e-9, par     # the bar is 1e-6; the degree-6 2^x bounds a logl at 2.3e-9 absolute
+    # the full-covariance KDE (the fused sweep without the diagonal shortcut) on a 4-column subset, same rows
+    kf = pbn.KDE(names[:4])
+    kf.fit_table(train)
+    from oracle import oracle
+
+    rows = np.arange(0, 100_000, 390)
+    got = kf.logl_table(test)[rows]
+    want = oracle.kde_logl(train_t[:4].T.cpu().numpy(), np.asarray(kf.bandwidth), test_t[:4].T.cpu().numpy()[rows])
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-8
+
+
+def test_c4_fullsize_against_the_oracle(env):
+    """BGe local scores and the BIC fit on ALL 2M rows against the oracle (two-pass covariance, the reference's BGe arithmetic)."""
+    torch, pbn, _lib, ctx = env
+    import bench
+    from oracle import oracle
+
+    dev = torch.device("cuda", 0)
+    t = bench.make_dag_table(torch, dev, 2_000_000, 64, 2, torch.float64)
+    names = [f"x{i}" for i in range(64)]
+    table = _table(torch, pbn, _lib, ctx, t, names)
+    score = pbn.BGe(None, table=table)
+    bic = pbn.BIC(None, table=table)
+    net = pbn.GaussianNetwork(names)
+    for v, par in ((7, []), (12, [3]), (40, [5, 17, 33]), (63, [1, 2, 30, 44, 60])):
+        cols = t[[v] + par].T.cpu().numpy()
+        want = oracle.bge(cols, 64)
+        got = score.local_score(net, names[v], [names[p_] for p_ in par])
+        assert abs(got - want) <= 1e-9 * abs(want), (v, par, got, want)
+        want_b = oracle.bic_lg(cols)
+        got_b = bic.local_score(net, names[v], [names[p_] for p_ in par])
+        assert abs(got_b - want_b) <= 1e-9 * abs(want_b), (v, par, got_b, want_b)
+
+
+def test_c3_fullsize_against_the_oracle(env):
+    """C3's table (500 000 rows, fp64): (1) CKDE handles fitted on the training part of fold 0 (450 000 rows) - logl of 512 test-fold
+    rows vs oracle.ckde_logl, one candidate with 1 parent (pruned, split into two plain sweeps) and one with 2; (2) the SCORE ENGINE's
+    grouped, pruned path at full training size: HoldoutLikelihood with 1 000 test rows (499 000 training rows) vs
+    oracle.holdout_likelihood, for 1, 2 and 3 parents."""
+    torch, pbn, _lib, ctx = env
+    import bench
+    import pandas as pd
+    from oracle import oracle
+
+    dev = torch.device("cuda", 0)
+    t = bench.make_dag_table(torch, dev, 500_000, 32, 2, torch.float64, nonlinear=True)
+    names = [f"x{i}" for i in range(32)]
+    for var, par in (("x5", ["x1"]), ("x9", ["x2", "x4"])):
+        cols = [var] + par
+        host = pd.DataFrame(t[[int(c[1:]) for c in cols]].T.cpu().numpy(), columns=cols)
+        tr_idx, te_idx = next(iter(pbn.CrossValidation(host, 10, 0).indices()))
+        cpd = pbn.CKDE(var, par)
+        cpd.fit(host.iloc[tr_idx])
+        test = host.iloc[te_idx[:512]]
+        got = cpd.logl(test)
+        want = oracle.ckde_logl(host.to_numpy()[tr_idx], np.asarray(cpd.bandwidth), test.to_numpy())
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= 1e-6, (var, par)
+        assert abs(got.sum() - want.sum()) <= 1e-8 * abs(want.sum())
+    table = _table(torch, pbn, _lib, ctx, t, names)
+    score = pbn.HoldoutLikelihood(None, 0.002, 0, table=table)
+    start = pbn.SemiparametricBN(names, [], [(n_, pbn.CKDEType()) for n_ in names])
+    for var, par in (("x5", ["x1"]), ("x9", ["x2", "x4"]), ("x20", ["x3", "x7", "x11"])):
+        data = t[[int(c[1:]) for c in [var] + par]].T.cpu().numpy()
+        want = oracle.holdout_likelihood(data, "ckde", 0.002, 0)
+        got = score.local_score_node_type(start, pbn.CKDEType(), var, par)
+        assert abs(got - want) <= 1e-6 * abs(want), (var, par, got, want)
+        assert abs(got - want) <= 1e-8 * abs(want), (var, par, got, want)    # measured far inside the bar
 
 
 def test_c4_fullsize_properties(env):
@@ -213,3 +304,15 @@ def test_c5_fullsize_properties(env, monkeypatch):
     assert abs(v_direct - vref[0]) <= 1e-3 * abs(v_direct)                      # fp32 slices: the north star's fp32 bar
     _, hc2, res2 = run()
     assert _trace(pbn, hc2) == trace and sorted(res2.arcs()) == sorted(res.arcs())
+    # ORACLE values for fp32 hybrid slices at full slice size: a hold-out score with 1 000 test rows (999 000 training rows, cut by the
+    # discrete parents into slices of 250-500 k rows: the grouped, pruned bf16x3 sweeps) against the per-slice restatement
+    # (DiscreteAdaptator.hpp:201-348) in fp64 arithmetic on the same float data, at the north star's fp32 bar
+    from oracle import oracle
+
+    small = pbn.HoldoutLikelihood(df, 0.001, 0)
+    tr, te = oracle.holdout_split(n_rows, 0.001, 0)
+    for var, dpar, cpar in (("x3", ["D3"], []), ("x8", ["D8"], ["x2"]), ("x21", ["D5"], ["x4", "x9"])):
+        cont = df[[var] + cpar].to_numpy().astype(np.float64)
+        want = oracle.adaptator_fit_slogl(cont, [disc[d_] for d_ in dpar], [int(cards[int(d_[1:])]) for d_ in dpar], tr, te, "ckde")
+        got = small.local_score_node_type(start, pbn.CKDEType(), var, cpar + dpar)
+        assert abs(got - want) <= 1e-3 * abs(want), (var, dpar, cpar, got, want)

@@ -94,3 +94,45 @@ def test_cv_limits():
         oracle.cv_limits(5, 6)
     assert oracle.holdout_test_rows(10000, 0.2) == 2000
     assert oracle.holdout_test_rows(13, 0.5) == 7  # std::round half away from zero
+
+
+# ---- the tuned CPU baseline (oracle/pbn_baseline.cpp: only ever TIMED by bench.py) is held to the checker and the golden recipes ----
+@pytest.mark.parametrize("variables", VARSETS)
+def test_tuned_cpu_baseline_matches_golden_and_checker(golden, variables):
+    from oracle import baseline
+
+    key = "".join(variables)
+    tr, te = _sel(golden["train500"], variables), _sel(golden["test50"], variables)
+    H, h = golden[f"kde_bw_nr_{key}_500"], golden[f"pkde_bw_nr_{key}_500"]
+    assert np.allclose(baseline.kde_logl(tr, H, te), golden[f"kde_logl_{key}_f64"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(baseline.product_kde_logl(tr, h, te), golden[f"pkde_logl_{key}_f64"], rtol=1e-9, atol=1e-10)
+    rng = np.random.default_rng(len(variables))
+    big = rng.normal(size=(5000, len(variables))) @ (np.eye(len(variables)) + 0.3 * np.tril(np.ones((len(variables),) * 2), -1)).T
+    q = rng.normal(size=(37, len(variables))) * 2.0
+    cov, _ = oracle.cov(big)
+    Hb = oracle.bandwidth(0, 0, cov, big.shape[0])
+    assert np.allclose(baseline.kde_logl(big, Hb, q), oracle.kde_logl(big, Hb, q), rtol=1e-10, atol=1e-10)
+    assert np.allclose(baseline.ckde_logl(big, Hb, q), oracle.ckde_logl(big, Hb, q), rtol=1e-9, atol=1e-9)
+    one = baseline.num_threads()
+    baseline.set_num_threads(1)
+    try:
+        assert np.array_equal(baseline.kde_logl(big, Hb, q), baseline.kde_logl(big, Hb, q))
+    finally:
+        baseline.set_num_threads(one)
+
+
+def test_bge_from_cached_moments_is_bge_from_rows():
+    """bench.py's C4 tie accounting scores through the whole-table moments (bge.hpp:52-68 caches them): bit-identical to the per-call form."""
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(3000, 7))
+    a[:, 3] += 0.8 * a[:, 1] - 0.4 * a[:, 6]
+    cov, means = oracle.cov(a)
+    for sel in ([0], [3, 1], [3, 6, 1], [5, 0, 1, 2, 4]):
+        assert oracle.bge_cached(cov, means, a.shape[0], sel, 7) == oracle.bge(a[:, sel], 7)
+    threads = oracle.num_threads()
+    oracle.set_num_threads(1)
+    try:
+        cov1, means1 = oracle.cov(a)
+    finally:
+        oracle.set_num_threads(threads)
+    assert np.array_equal(cov, cov1) and np.array_equal(means, means1)   # the parallel covariance does not depend on the thread count

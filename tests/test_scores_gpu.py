@@ -629,6 +629,39 @@ def test_ckde_terms_are_the_halves_of_the_local_score(pbn, kind):
         fresh._terms("eval", code, [(4, col["a"], col["b"])])
 
 
+def test_marginal_terms_do_not_depend_on_an_unrelated_column(pbn):
+    """A marginal term A(P, m) is the KDE of P under the rule for m dimensions - no child in it (advisor, round 3: it used to be
+    evaluated as a pseudo-candidate whose child was the smallest column outside P, so a constant / collinear column 0 failed terms
+    no real candidate of a restricted search pairs with it).  With a constant first column every term over the other columns
+    still evaluates, equals the halves of the real candidates' local scores bit for bit, and a term that DOES contain the
+    degenerate column raises SingularCovarianceData - not a generic device error."""
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(12)
+    n = 5000
+    a = rng.normal(size=n)
+    b = 0.6 * a + rng.normal(scale=0.7, size=n)
+    c = np.tanh(a) + 0.3 * b + rng.normal(scale=0.5, size=n)
+    df = pd.DataFrame({"k": np.full(n, 3.25), "a": a, "b": b, "c": c})
+    score = pbn.CVLikelihood(df, k=4, seed=3)
+    code = _lib.PBN_SCORE_CVLIK
+    net = pbn.SemiparametricBN(list(df.columns), [], [(v, pbn.CKDEType()) for v in df.columns])
+    col = {v: i for i, v in enumerate(df.columns)}
+    cands = [("c", ["a", "b"]), ("b", ["a"]), ("a", ["c"])]
+    want = [score.local_score(net, v, p) for v, p in cands]
+    fresh = pbn.CVLikelihood(df, k=4, seed=3)
+    for (v, p), w in zip(cands, want):
+        m = len(p) + 1
+        j, mg = fresh._terms("eval", code, [(m,) + tuple(col[x] for x in [v] + p), (m,) + tuple(col[x] for x in p)])
+        assert j - mg == w, (v, p)
+    # every column but the constant one in one marginal term: there is no column outside it to borrow as a child any more
+    assert np.isfinite(fresh._terms("eval", code, [(4, col["a"], col["b"], col["c"])])).all()
+    with pytest.raises(pbn.SingularCovarianceData):
+        fresh._terms("eval", code, [(3, col["k"], col["a"])])
+    with pytest.raises(pbn.SingularCovarianceData):
+        fresh._terms("eval", code, [(2, col["k"])])
+
+
 def test_ckde_terms_of_a_validated_score_keep_their_kind(pbn):
     """ValidatedLikelihood asks ONE handle for both kinds (CV over the training part: local_score; the hold-out part: vlocal_score).
     The installed totals are keyed by kind: the same variable set has one total per kind."""

@@ -23,6 +23,15 @@ for name, counters in sorted(acc.items()):
     for cname, (total, disp) in sorted(counters.items()):
         res[name][cname] = total / max(len(disp), 1)
         res[name]["dispatches_" + cname] = len(disp)
+# the revision of the kernel sources these counters belong to: bench.py refuses a record whose blob differs from the working tree's
+import hashlib
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+res["_source_blob"] = {}
+for src in ("kde_kernels.hip", "kde_group.hip", "stats_kernels.hip"):
+    with open(os.path.join(root, "pybnesian_amd", "csrc", src), "rb") as f:
+        data = f.read()
+    res["_source_blob"][src] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 with open(out, "w") as f:
     json.dump(res, f, indent=1)
 print("kernels:", len(res))
