@@ -582,7 +582,7 @@ def parity_block(torch, kde, test_table, train_t, test_t, slogl_step, tol, abs_t
 
 def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     """CPU side of the headline metric on the host cores of the GPU box, bounded sample.  `value` = the tuned CPU form
-    (oracle/pbn_baseline.cpp: whitened once, training tiles reused by blocks of 16 test rows, vectorised exponentials, OpenMP over
+    (oracle/pbn_baseline.cpp: whitened once, training tiles reused by blocks of 64 test rows, vectorised exponentials, OpenMP over
     query blocks; built here with -Ofast -march=native) on all cores; beside it the same on ONE thread (the reference's KDE path is
     single-threaded on the host side), the scaling efficiency, and `reference_arithmetic_port` = the checker (pbn_oracle.cpp: the
     reference's per-pair arithmetic, kde/ProductKDE.hpp:240-293, scalar exp, -O2) that round 1-3 reported as the baseline."""
@@ -600,24 +600,28 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
         return time.perf_counter() - t0, r
 
     def sized(fn, threads, budget):
-        probe = max(threads, 16)
-        probe = min(test_np.shape[0], (probe + 15) // 16 * 16)
+        probe = min(test_np.shape[0], 64 * threads)             # one block of 64 test rows per thread
         dt, _ = timed(fn, probe)
         rows = int(min(test_np.shape[0], max(probe, probe * budget / max(dt, 1e-3))))
-        rows = max(probe, rows // (16 * threads) * (16 * threads))
+        rows = max(probe, rows // (64 * threads) * (64 * threads))
         dt, r = timed(fn, rows)
         return rows, dt, r
 
     fast(train_np[:4096], h, test_np[:16])                      # build / load outside the timed calls
     rows, dt, r_fast = sized(fast, cores, budget_s * 0.45)
     chk = slow(train_np, h, test_np[:min(rows, 4 * oracle.num_threads())])   # the tuned form against the checker
+    try:
+        phys = len({l_.strip() for l_ in open("/proc/cpuinfo") if l_.startswith(("physical id", "core id"))}) and \
+            len(set(zip(*[[l_.split(":")[1].strip() for l_ in open("/proc/cpuinfo") if l_.startswith(key)] for key in ("physical id", "core id")])))
+    except Exception:
+        phys = None
     out = {
         "value": rows / dt / 1e6, "unit": "M-samples/s", "cores": cores, "kind": "port",
         "pairs_per_s": rows * n_train / dt, "pairs_per_s_per_thread": rows * n_train / dt / cores,
         "max_rel_vs_checker": float(np.max(np.abs(r_fast[:chk.size] - chk) / np.maximum(1.0, np.abs(chk)))),
-        "cpu": baseline.cpu_model(),
-        "sample": f"{rows} test rows x {n_train} training rows, d={D}, fp64, {dt:.1f}s wall; oracle/pbn_baseline.cpp (whitened, blocked 16 x 2048, "
-                  f"libmvec exponentials, -Ofast -march=native), OpenMP over blocks of 16 test rows",
+        "cpu": baseline.cpu_model(), "physical_cores": phys,
+        "sample": f"{rows} test rows x {n_train} training rows, d={D}, fp64, {dt:.1f}s wall; oracle/pbn_baseline.cpp (whitened, blocked 64 x 1024, "
+                  f"libmvec exponentials, -Ofast -march=native), OpenMP over blocks of 64 test rows",
     }
     try:
         baseline.set_num_threads(1)
@@ -995,7 +999,7 @@ def main():
             except Exception as ex:
                 out["parity"] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
             h = np.asarray(kde.bandwidth, dtype=np.float64)
-            sample_rows = min(args.n_test, 16384)
+            sample_rows = min(args.n_test, 65536)
             train_np = train_t.T.cpu().numpy().astype(np.float64)
             test_np = test_t[:, :sample_rows].T.cpu().numpy().astype(np.float64)
             try:

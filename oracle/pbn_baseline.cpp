@@ -7,7 +7,7 @@
 // GPU/CPU ratio in the bench line is not inflated by a naive port:
 //   * the training set is whitened once (z = L^-1 x, or x / sqrt(h) for the diagonal bandwidth): no forward substitution
 //     and no division per pair;
-//   * a tile of TB training rows (L2-resident) is reused by a block of QB test rows per thread;
+//   * a tile of TB = 1024 training rows (L2-resident) is reused by a block of QB = 64 test rows per thread;
 //   * the exponentials are vectorised (glibc libmvec through -Ofast + omp simd), logsumexp is kept online per tile.
 // pbn_oracle.cpp stays the CHECKER (it follows the reference's arithmetic operation by operation); this file is only ever
 // TIMED, and tests/test_oracle_golden.py holds it to the checker at 1e-10.  Built on the box that times it:
@@ -27,8 +27,8 @@
 namespace {
 
 constexpr double PI = 3.14159265358979323846264338327950288;
-constexpr int TB = 2048;  // training rows per tile: 2048 x 8 doubles = 128 KB
-constexpr int QB = 16;    // test rows per block
+constexpr int TB = 1024;  // training rows per tile: 1024 x 8 doubles = 64 KB, L2-resident while a block of queries goes over it
+constexpr int QB = 64;    // test rows per block: the training set is streamed once per 64 queries (16 made 128 threads DRAM-bound)
 
 bool chol(const double* a, int n, double* L) {
     std::fill(L, L + (size_t)n * n, 0.0);

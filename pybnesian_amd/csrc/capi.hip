@@ -313,13 +313,17 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         center = pilot.data();
     }
     kde_prepare(k->m, train->dtype, d, n, bw, kind, cond, center);
+    // fp32 table whose whitened rows reach too far from the centre for the fp32 Gram form (tiny bandwidths on spread-out data:
+    // diagonal bandwidths of nearly collinear columns, user-set bandwidths): fp64 fragments + fp64 sweep on the float columns
+    if (train->dtype == PBN_F32 && n > 0 && kde_wants_widening(kde_max_norm2(ctx, k->m, train, cols, row0, n, 0))) kde_widen(k->m);
+    const int fdt = k->m.fdtype();
     // Low-dimensional CKDE on a large training set: two pruned plain sweeps (joint over [variable, evidence], marginal over
     // the evidence with H[1:, 1:] - CKDE.hpp:186-199) beat the fused sweep, whose pruning can only use the marginal box
     // (tools/prune_handles_timing.py; fp64 up to 3 variables - 4 is a tie, 5 goes to the fused sweep -, fp32 up to 4).  PBN_CKDE_SPLIT=0 keeps the fused sweep, =1 splits
     // whenever the marginal qualifies for pruning.
     static const int split_mode = [] { const char* e = getenv("PBN_CKDE_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
-    const bool split = ckde && k->m.cond && split_mode != 0 && kde_prune_applies(train->dtype, d - 1, n) &&
-                       (split_mode > 0 || d <= (train->dtype == PBN_F64 ? 3 : 4));
+    const bool split = ckde && k->m.cond && split_mode != 0 && kde_prune_applies(fdt, d - 1, n) &&
+                       (split_mode > 0 || d <= (fdt == PBN_F64 ? 3 : 4));
     if (split) {
         std::vector<double> Hm((size_t)(d - 1) * (d - 1));
         for (int j = 1; j < d; ++j)
@@ -331,7 +335,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         kde_fit_impl(ctx, train, cols + 1, d - 1, row0, n, Hm.data(), PBN_BW_FULL, false, center ? center + 1 : nullptr, &km);
         k->split_marg.reset(km);
     } else {
-        const KdePackBytes pb = kde_pack_bytes(train->dtype, k->m.dm, k->m.cond, n);
+        const KdePackBytes pb = kde_pack_bytes(fdt, k->m.dm, k->m.cond, n);
         k->Apack.alloc(pb.apack);
         k->nxpack.alloc(pb.nxpack);
         if (k->m.cond) k->Axpack.alloc(pb.axpack);

@@ -215,7 +215,8 @@ __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
 //   extra component (CKDE)   -> xpack[tile*64 + k*16 + idx]:
 //        training: k0 z_e, k1 -1/2 z_e^2, k2 1, k3 0      query: k0 z_e, k1 1, k2 -1/2 z_e^2, k3 0
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// T = fragment type, TS = element type of the table (float under double fragments: PackArgs::src_f32)
+template <typename T, typename TS = T>
 __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t npad = a.ntiles * 16;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
         const int64_t lr = rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0);
         const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
         for (int j = 0; j < d; ++j) {
-            const T* col = (const T*)a.base + (int64_t)a.cols[j] * a.ld;
+            const TS* col = (const TS*)a.base + (int64_t)a.cols[j] * a.ld;
             xc[j] = (double)col[src] - a.mu[j];
         }
     }
@@ -314,7 +315,41 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 #define PBN_PRUNE_MARGIN_F32 40.0
 #endif
 
-template <typename T>
+// largest |z|^2 of the whitened rows (all d coordinates): one atomic max per block on the bits of a non-negative double
+template <typename TS>
+__global__ __launch_bounds__(256) void max_norm2_kernel(PackArgs a, unsigned long long* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double nrm = 0.0;
+    if (r < a.n) {
+        const int d = a.d;
+        const int64_t lr = r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0);
+        const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
+        double xc[PBN_MAX_D];
+        for (int j = 0; j < d; ++j) xc[j] = (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
+        for (int i = 0; i < d; ++i) {
+            double z = 0.0;
+            const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
+            for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
+            nrm = __builtin_fma(z, z, nrm);
+        }
+        if (!(nrm == nrm)) nrm = INFINITY;   // a NaN row: as far out as it gets
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(nrm, off);
+        nrm = o > nrm ? o : nrm;
+    }
+    __shared__ double wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = nrm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = wmax[0];
+        for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
+        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// T = fragment type (the rounding the keys see), TS = element type of the table
+template <typename T, typename TS = T>
 __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int kd, double* __restrict__ zrow, uint32_t* __restrict__ keys,
                                                          int32_t* __restrict__ iota) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -323,7 +358,7 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
     const int64_t lr = r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0);
     const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
     double xc[PBN_MAX_D];
-    for (int j = 0; j < d; ++j) xc[j] = (double)((const T*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
+    for (int j = 0; j < d; ++j) xc[j] = (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
     uint32_t key = 0;
     for (int i = 0; i < zd; ++i) {
         double z = 0.0;
@@ -1919,8 +1954,17 @@ void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st) {
     const int64_t npad = a.ntiles * 16;
     if (npad == 0) return;
     dim3 grid((unsigned)ceil_div(npad, 256)), block(256);
-    if (dtype == PBN_F64) hipLaunchKernelGGL(pack_rows_kernel<double>, grid, block, 0, st, a);
+    if (dtype == PBN_F64 && a.src_f32) hipLaunchKernelGGL((pack_rows_kernel<double, float>), grid, block, 0, st, a);
+    else if (dtype == PBN_F64) hipLaunchKernelGGL(pack_rows_kernel<double>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_max_norm2(const PackArgs& a, int src_dtype, double* dev_out, hipStream_t st) {
+    if (a.n <= 0) return;
+    dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
+    if (src_dtype == PBN_F64) hipLaunchKernelGGL(max_norm2_kernel<double>, grid, block, 0, st, a, (unsigned long long*)dev_out);
+    else hipLaunchKernelGGL(max_norm2_kernel<float>, grid, block, 0, st, a, (unsigned long long*)dev_out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -2021,7 +2065,9 @@ void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
         HIP_CHECK(hipGetLastError());
         return;
     }
-    if (dtype == PBN_F64)
+    if (dtype == PBN_F64 && a.src_f32)
+        hipLaunchKernelGGL((pack_rows_kernel<double, float>), grid, block, 0, st, a);
+    else if (dtype == PBN_F64)
         hipLaunchKernelGGL(pack_rows_kernel<double>, grid, block, 0, st, a);
     else
         hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, a);
@@ -2091,7 +2137,8 @@ static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st
 void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st) {
     if (a.n == 0) return;
     const dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
-    if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
+    if (dtype == PBN_F64 && a.src_f32) hipLaunchKernelGGL((prune_keys_kernel<double, float>), grid, block, 0, st, a, zd, kd, zrow, keys, iota);
+    else if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
     else hipLaunchKernelGGL(prune_keys_kernel<float>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
     HIP_CHECK(hipGetLastError());
 }

@@ -24,6 +24,9 @@ struct PackArgs {
     int dm;               // main (marginal) dimensions written to `pack`; d == dm or dm + 1
     int KS;               // ceil(dm / 4)
     int is_query;
+    // the table holds float while the fragments are packed (and swept) in double: fp32 models whose whitened training rows reach so
+    // far from the centre that the Gram-form distances would lose them in fp32 (KdeModel::widen); classic fp64 pack only
+    int src_f32;
     // classic (non-bf16) pack, dm % 4 != 0: the first unused K slot of the last MFMA carries the norm - training side
     // -1/2|z|^2, query side 1 - so the sweep's accumulator starts from a per-query constant (no add per value).  A
     // query pack that leaves the slot 0 (CKDE::cdf, UCV) makes the training side's entry inert.
@@ -136,6 +139,9 @@ bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix co
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
+// dev_out[0] = max over the rows described by `a` of |z|^2 (all a.d whitened coordinates, base-2 units), as the bits of a non-negative
+// double (atomic max: the caller zeroes it); src_dtype = element type of the table
+void launch_max_norm2(const PackArgs& a, int src_dtype, double* dev_out, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);
 void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st, double* dev_sum_marg_out = nullptr);
 // out[i] = a[i] - b[i] (CKDE as joint - marginal when the two come from separate sweeps)

@@ -104,7 +104,7 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
     // classic fp32 fragments (PBN_F32_BF16X3=0, a measurement switch) stay at 16
     const int max_dm = (dtype == PBN_F64 || use_bf16x3(dtype)) ? 32 : 16;
     if (dm > max_dm) throw invalid_error("KDE with more than 32 (+1 conditional) variables is not supported");
-    m.dtype = dtype; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
+    m.dtype = dtype; m.widen = false; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
     m.N = n; m.ntiles = ceil_div(n, 16);
     if (cond) {  // evidence first, variable last
         for (int i = 0; i < d - 1; ++i) m.perm[i] = i + 1;
@@ -146,6 +146,7 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
 
 static void fill_pack_common(pbn_ctx* ctx, PackArgs& pa, const pbn_table* t, const int* cols, const KdeModel& m) {
     pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.dm; pa.KS = m.KS;
+    pa.src_f32 = (m.widen && m.dtype == PBN_F32) ? 1 : 0;
     for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
     pa.rows = nullptr;
     pa.Wdev = nullptr;
@@ -160,6 +161,35 @@ static void fill_pack_common(pbn_ctx* ctx, PackArgs& pa, const pbn_table* t, con
 }
 
 static int env_int(const char* name, int dflt);
+
+double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0, int64_t row1,
+                     const int32_t* dev_rows) {
+    PackArgs pa{};
+    fill_pack_common(ctx, pa, t, cols, m);
+    pa.rows = dev_rows;
+    pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
+    ctx->scratch_misc.reserve(sizeof(double));
+    double* slot = (double*)ctx->scratch_misc.p;
+    HIP_CHECK(hipMemsetAsync(slot, 0, sizeof(double), ctx->stream));
+    launch_max_norm2(pa, t->dtype, slot, ctx->stream);
+    double v = 0.0;
+    HIP_CHECK(hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return v;
+}
+
+bool kde_wants_widening(double max_norm2) {
+    const bool on = env_int("PBN_F32_WIDEN", 1) != 0;   // read per fit (a fit synchronises anyway): tests flip it inside one process
+    const char* e = std::getenv("PBN_F32_WIDEN_AT");
+    const double at = (e && *e) ? std::atof(e) : 5e-4;
+    return on && !(max_norm2 * 5.9604644775390625e-08 <= at);   // 2^-24 |z|^2: the size of the fp32 Gram form's error on an exponent
+}
+
+void kde_widen(KdeModel& m) {
+    if (m.dtype != PBN_F32 || m.widen) return;
+    m.widen = true;
+    m.KS = (m.dm + 3) / 4;   // classic fp64 fragments: 4 coordinates per MFMA
+}
 
 // Morton order of the logical rows described by `pa` (already filled): whitened rows -> keys -> stable sort.  Returns the
 // carved buffers inside `arena`.
@@ -199,7 +229,7 @@ bool kde_prune_applies(int dtype, int dm, int64_t n) {
 struct SubBytes { size_t a, n, x, total; };
 static SubBytes sub_bytes(const KdeModel& m, int64_t nsub) {
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    const KdePackBytes pb = kde_pack_bytes(m.dtype, m.dm, m.cond, nsub);
+    const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, m.cond, nsub);
     SubBytes b{al(pb.apack), al(pb.nxpack), al(pb.axpack), 0};
     b.total = b.a + b.n + b.x;
     return b;
@@ -213,7 +243,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
     m.prune = false;
-    if (prune && kde_prune_applies(m.dtype, m.dm, m.N)) {
+    if (prune && kde_prune_applies(m.fdtype(), m.dm, m.N)) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         m.zdims = m.d;
         m.pdims = std::min(m.dm, std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), PBN_PRUNE_PD));   // dimensions of the Morton keys and the boxes (<= PBN_PRUNE_PD)
@@ -223,7 +253,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
         m.nsub = 0;
         if (m.d > m.pdims && env_int("PBN_PRUNE_SUBSAMPLE", 1)) m.nsub = std::min<int64_t>(4096, m.N / 64) / 16 * 16;
         const SubBytes sb = sub_bytes(m, m.nsub);
-        const PruneSide s = prune_sort_side(ctx, ctx->scratch_prune, pa, m.dtype, m.zdims, m.pdims, box_b + zs_b + (m.nsub ? sb.total : 0));
+        const PruneSide s = prune_sort_side(ctx, ctx->scratch_prune, pa, m.fdtype(), m.zdims, m.pdims, box_b + zs_b + (m.nsub ? sb.total : 0));
         double* box = (double*)s.rest;
         double* zsorted = (double*)(s.rest + box_b);
         launch_tile_boxes(s.zrow, s.perm, m.N, m.zdims, m.pdims, box, zsorted, ctx->stream);
@@ -237,16 +267,16 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
         }
     }
     pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
-    pa.write_w = !use_bf16x3(m.dtype);
+    pa.write_w = !use_bf16x3(m.fdtype());
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
-    launch_pack(pa, m.dtype, ctx->stream);
+    launch_pack(pa, m.fdtype(), ctx->stream);
     if (m.prune && m.nsub) {
         PackArgs ps = pa;
         ps.perm_stride = m.N / m.nsub;
         ps.n = m.nsub; ps.ntiles = m.ntiles_sub;
         ps.pack = m.Asub; ps.npack = m.nxsub; ps.xpack = m.Axsub;
-        launch_pack(ps, m.dtype, ctx->stream);
+        launch_pack(ps, m.fdtype(), ctx->stream);
     }
 }
 
@@ -281,6 +311,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     check_cols(test, cols, m.d, "pbn_kde_logl");
     if (!dev_rows) check_range(test, row0, n, "pbn_kde_logl");
     if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
+    const int fdt = m.fdtype();   // type of the fragments and of the sweep (double for a widened fp32 model)
     if (test->ctx->device != ctx->device) throw invalid_error("pbn_kde_logl: test table lives on another device");
     HIP_CHECK(hipSetDevice(ctx->device));
     if (n == 0) {
@@ -288,10 +319,10 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
         if (dev_sum_marg) HIP_CHECK(hipMemsetAsync(dev_sum_marg, 0, sizeof(double), ctx->stream));
         return;
     }
-    const size_t es = dtype_size(m.dtype);
+    const size_t es = dtype_size(fdt);
     const int64_t nqtiles = ceil_div(n, 16);
     // query fragments in scratch: Bpack | nypack | Bxpack
-    const bool b3 = use_bf16x3(m.dtype);
+    const bool b3 = use_bf16x3(fdt);
     const size_t bpack_b = b3 ? (size_t)nqtiles * m.KS * 64 * 16 : (size_t)nqtiles * m.KS * 64 * es,
                  ny_b = (size_t)nqtiles * 16 * es,
                  bx_b = m.cond ? (b3 ? (size_t)nqtiles * 64 * 16 : (size_t)nqtiles * 64 * es) : 0,
@@ -303,7 +334,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles;
     pa.is_query = 1;
-    const bool fold = sweep_folds_norm(m.dtype, m.cond, m.KS, m.dm);
+    const bool fold = sweep_folds_norm(fdt, m.cond, m.KS, m.dm);
     pa.fold_norm = fold ? 1 : 0;
     const double* qbox = nullptr;
     const double* qthr = nullptr;
@@ -314,7 +345,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         const size_t qbox_b = al((size_t)nqtiles * 2 * m.pdims * sizeof(double)), qthr_b = al((size_t)nqtiles * sizeof(double));
         const size_t qlb_b = al((size_t)nqtiles * 16 * sizeof(double));
-        qs = prune_sort_side(ctx, ctx->scratch_pruneq, pa, m.dtype, m.zdims, m.pdims, qbox_b + qthr_b + qlb_b);
+        qs = prune_sort_side(ctx, ctx->scratch_pruneq, pa, fdt, m.zdims, m.pdims, qbox_b + qthr_b + qlb_b);
         pa.perm = qs.perm;
         qperm = qs.perm;
         qbox = (double*)qs.rest; qthr = (double*)(qs.rest + qbox_b);
@@ -323,9 +354,9 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
     pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
-    { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, m.dtype, ctx->stream); }
+    { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, fdt, ctx->stream); }
     const int P = m.cond ? 4 : 2;
-    const bool wmul = !fold && sweep_weights_norm(m.dtype, m.cond, m.KS, m.dm);
+    const bool wmul = !fold && sweep_weights_norm(fdt, m.cond, m.KS, m.dm);
     if (m.prune) {
         // bounds of the queries' largest exponents: neighbours in Morton order, and (more dimensions than keys) one sweep over
         // the subsample of the training rows; then per query tile the smallest bound and the box
@@ -339,7 +370,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
             ss.fold = fold ? 1 : 0; ss.wmul = wmul ? 1 : 0; ss.prune = 0;
             ss.part = (double*)ctx->scratch_part.p;
             ss.soft = env_int("PBN_SPARSE_SOFT", 8); ss.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
-            { KernelTimer kt(ctx, PBN_K_PACK); launch_sweep(ss, m.dtype, m.KS, m.cond, 1, ctx->stream); }
+            { KernelTimer kt(ctx, PBN_K_PACK); launch_sweep(ss, fdt, m.KS, m.cond, 1, ctx->stream); }
             subpart = ss.part;
         }
         launch_query_prepass(qs.zrow, qs.perm, n, qs.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, (double*)qbox, (double*)qthr, (double*)qlb,
@@ -347,7 +378,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     }
 
     // split the training tiles so that the grid is a few waves deep on every CU
-    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(m.dtype, m.cond, m.KS, m.prune));
+    const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(fdt, m.cond, m.KS, m.prune));
     const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
     int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
     // with the XCD-aware block order (xcd_block) the blocks resident on one XCD share a split: keep a split's training
@@ -372,7 +403,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.fold = fold ? 1 : 0;
     sa.wmul = wmul ? 1 : 0;
     sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(m.dtype, m.N); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
+    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
@@ -380,7 +411,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.group_masks = gmasks;
     static const bool log_sweeps = env_int("PBN_SWEEP_LOG", 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
     if (log_sweeps) std::fprintf(stderr, "pbn-sweep N=%lld n=%lld d=%d cond=%d prune=%d nsub=%lld nsplit=%lld\n", (long long)m.N, (long long)n, m.d, (int)m.cond, (int)m.prune, (long long)(m.prune ? m.nsub : 0), (long long)nsplit);
-    { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, m.dtype, m.KS, m.cond, (int)nsplit, ctx->stream); }
+    { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, fdt, m.KS, m.cond, (int)nsplit, ctx->stream); }
 
     const int64_t nblocks = ceil_div(n, 256);
     ctx->scratch_misc.reserve((size_t)nblocks * 2 * sizeof(double));

@@ -8,7 +8,14 @@
 namespace pbn {
 
 struct KdeModel {
-    int dtype = PBN_F64;
+    int dtype = PBN_F64;   // element type of the TABLES (training and test)
+    // fp32 table, fp64 fragments and sweep (kde_widen): the Gram-form distance z_t.z_q - |z_t|^2/2 - |z_q|^2/2 carries an absolute error
+    // of ~2^-24 (|z_t|^2 + |z_q|^2) in fp32 - harmless while the whitened rows stay within tens of bandwidths of the centre, 1e-3...1e-2
+    // on a logl when bandwidths are tiny against the spread of the data (diagonal bandwidths of nearly collinear columns, user-set
+    // bandwidths), where the reference's fp32 differences (KDE.cl.src:173-226) hold 1e-5.  Such models pack double fragments from the
+    // float columns and run the fp64 kernels; fdtype() is the type of the packs and sweeps, dtype stays the tables'.
+    bool widen = false;
+    int fdtype() const { return widen ? PBN_F64 : dtype; }
     int d = 0;         // number of variables
     int dm = 0;        // dimensions in the main MFMA contraction (d, or d-1 for CKDE)
     int KS = 0;        // ceil(dm / 4)
@@ -44,6 +51,14 @@ KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n);
 // whitening matrix, log-normalisation constants.  bw: H (d*d col-major, caller's order) or h (d).
 // center: d offsets in the caller's order.  Throws singular_error when H is not PD.
 void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int kind, bool cond, const double* center);
+
+// fp32 tables: |z|^2 of the farthest whitened training row (one pass + one synchronisation), and the switch to fp64 fragments
+// (before kde_pack_bytes / kde_pack_train).  kde_wants_widening: 2^-24 max|z|^2 > PBN_F32_WIDEN_AT (default 5e-4, the reference tests'
+// own fp32 tolerance per logl; PBN_F32_WIDEN=0 switches the test off).
+double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0, int64_t row1,
+                     const int32_t* dev_rows = nullptr);
+bool kde_wants_widening(double max_norm2);
+void kde_widen(KdeModel& m);
 
 // Whiten + pack training rows (two contiguous ranges: [row0, row0+n0) ++ [row1, row1 + n - n0)).
 // dev_rows (nullable): device gather list of m.N row ids, used instead of the ranges.

@@ -538,3 +538,65 @@ def test_more_than_16_dimensions(pbn, oracle, d):
     c32.fit(tr32)
     wantc = oracle.ckde_logl(tr32.to_numpy().astype(np.float64), c32.bandwidth, te32.to_numpy().astype(np.float64))
     assert np.allclose(c32.logl(te32), wantc, atol=2e-3, rtol=1e-3)
+
+
+def test_fp32_tables_with_tiny_bandwidths_take_fp64_fragments(pbn, monkeypatch):
+    """fp32 tables whose whitened rows lie hundreds of bandwidths from the centre (diagonal bandwidths of nearly collinear columns;
+    a user-set bandwidth far below the spread): the fp32 Gram form z_t.z_q - |z_t|^2/2 - |z_q|^2/2 loses ~2^-24 |z|^2 on every
+    exponent - 1e-3...1e-2 on a logl - where the reference's fp32 path subtracts BEFORE squaring (KDE.cl.src:173-226) and holds
+    1e-5.  Such models are packed into fp64 fragments and swept by the fp64 kernels (KdeModel::widen, decided at fit time from the
+    farthest whitened training row).  Checked against the oracle in fp64 arithmetic on the same float data at the reference
+    tests' fp32 tolerance (atol 5e-4 per logl, KDE_test.py:181-182), with the oracle's own fp32 arithmetic beside it; the switch
+    PBN_F32_WIDEN=0 shows what the fp32 fragments would have given."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(77)
+    n, m, d = 40_000, 600, 3
+    def draw(k):
+        t = rng.normal(size=(k, 1))
+        return (t @ np.ones((1, d)) + rng.normal(scale=0.02, size=(k, d))).astype(np.float32)
+    names = [f"v{i}" for i in range(d)]
+    train, test = pd.DataFrame(draw(n), columns=names), pd.DataFrame(draw(m), columns=names)
+    tr64, te64 = train.to_numpy().astype(np.float64), test.to_numpy().astype(np.float64)
+
+    def models():
+        a = pbn.ProductKDE(names)                  # the diagonal rule on collinear columns: bandwidths ~1e-5 of the variances
+        a.fit(train)
+        b = pbn.KDE(names)                         # a user-set bandwidth far below the spread of the data
+        b.fit(train)
+        b.bandwidth = np.eye(d) * 4e-5
+        c = pbn.CKDE(names[0], names[1:])
+        c.fit(train)
+        Hc = np.eye(d) * 4e-5 + 1e-5
+        c.kde_joint().bandwidth = Hc               # the reference's way of setting a CKDE's bandwidth: through its member KDEs
+        c.kde_marg().bandwidth = Hc[1:, 1:]
+        return [(a, oracle.product_kde_logl), (b, oracle.kde_logl), (c, oracle.ckde_logl)]
+
+    worst_widened = 0.0
+    for k, fn in models():
+        bw = np.asarray(k.bandwidth, dtype=np.float64)
+        truth = fn(tr64, bw, te64)
+        ref32 = fn(train.to_numpy(), bw, test.to_numpy())          # the reference's fp32 arithmetic (differences first)
+        got = k.logl(test)
+        fin = np.isfinite(truth)
+        assert np.abs(ref32[fin] - truth[fin]).max() <= 5e-4 * np.maximum(1.0, np.abs(truth[fin])).max()
+        err = np.abs(got[fin] - truth[fin]).max()
+        worst_widened = max(worst_widened, err)
+        assert err <= 5e-4, (type(k).__name__, err)
+        assert abs(k.slogl(test) - truth[fin].sum()) <= 1e-6 * abs(truth[fin].sum()) or not fin.all()
+    # the same models on fp32 fragments: the error this routing removes (otherwise the test above proves nothing)
+    monkeypatch.setenv("PBN_F32_WIDEN", "0")
+    worst_f32 = 0.0
+    for k, fn in models():
+        truth = fn(tr64, np.asarray(k.bandwidth, dtype=np.float64), te64)
+        fin = np.isfinite(truth)
+        worst_f32 = max(worst_f32, np.abs(k.logl(test)[fin] - truth[fin]).max())
+    assert worst_f32 > 10 * max(worst_widened, 1e-6), (worst_f32, worst_widened)
+    monkeypatch.delenv("PBN_F32_WIDEN")
+    # ordinary fp32 tables stay on the fp32 (bf16x3) path: same numbers with the test switched off
+    g = pd.DataFrame(rng.normal(size=(20_000, 3)).astype(np.float32), columns=names)
+    q = pd.DataFrame(rng.normal(size=(300, 3)).astype(np.float32), columns=names)
+    k1 = pbn.KDE(names); k1.fit(g); l1 = k1.logl(q)
+    monkeypatch.setenv("PBN_F32_WIDEN", "0")
+    k2 = pbn.KDE(names); k2.fit(g)
+    assert np.array_equal(l1, k2.logl(q))
