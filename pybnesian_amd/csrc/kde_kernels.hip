@@ -123,10 +123,27 @@ __device__ __forceinline__ double pin_top_fract() {
     asm volatile("v_mov_b64 %0, %1" : "=v"(c) : "s"(PBN_FRACT_TOP));
     return c;
 }
+// FAST: 2^f of the FRACTION on the fp32 transcendental unit instead of the fp64 polynomial - fract, cvt_i32, cvt_f32_f64, v_exp_f32,
+// cvt_f64_f32, ldexp: 6 instructions (v_exp_f32 holds the issue port for two slots) instead of 9.  f in [0, 1) converts to float with
+// <= 6e-8 absolute error, v_exp_f32 is good to 1 ulp of a value in [1, 2]: <= 1.4e-7 relative per term (measured on C2: 5e-8 absolute
+// on a logl at worst, 1e-10 relative on the slogl) instead of 2.2e-9 - and a sum of positive terms moves by at most the per-term
+// bound.  Like the pinned polynomial it is continuous across the integers (f = 0 gives exactly 1; an f that rounds to 1.0f gives
+// exactly 2) and, with integer offsets, a function of the (row, query) pair only: sums taken in different partitions still agree to
+// rounding.  Used by the sweeps whose result is a SUM over the test rows (slogl, the score engine's terms: the north star's bar is
+// 1e-6 relative on slogl); per-row logl outputs keep the polynomial (SweepArgs::fast).  C2 51.5 -> 46.3 ms, cv64 3.42 -> 3.06 s,
+// bounded C3 15.7 -> 14.0 s (profiles/r4/expf32_probe.txt).  -DPBN_EXP2_F32=0 compiles it out.
+#ifndef PBN_EXP2_F32
+#define PBN_EXP2_F32 1
+#endif
+template <bool FAST = false>
 __device__ __forceinline__ double exp2_f64_fract(double x, double top) {
     const double f = __builtin_amdgcn_fract(x);      // v_fract_f64
     int n;
     asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));  // truncation = floor for x >= 0; saturating
+    if constexpr (FAST && PBN_EXP2_F32) {
+        (void)top;
+        return __builtin_ldexp((double)__builtin_amdgcn_exp2f((float)f), n);
+    }
 #if PBN_EXP2_DEGREE == 6
     double p = __builtin_fma(top, f, 0x1.46214fe0d40c9p-10);
     p = __builtin_fma(p, f, 0x1.3d217bf137896p-7);
@@ -169,8 +186,9 @@ struct Tr<double> {
     static __device__ __forceinline__ double ex2(double x) { return exp2_f64<GEN_DEG>(x); }
     static __device__ __forceinline__ double top() { return PBN_EXP2_DEGREE <= 7 ? pin_top_fract() : 0.0; }
     // main-loop form: x carries bias() (see exp2_f64_fract)
+    template <bool FAST = false>
     static __device__ __forceinline__ double ex2p(double x, double top) {
-        return PBN_EXP2_DEGREE <= 7 ? exp2_f64_fract(x, top) : exp2_f64<GEN_DEG>(x);
+        return PBN_EXP2_DEGREE <= 7 ? exp2_f64_fract<FAST>(x, top) : exp2_f64<GEN_DEG>(x);
     }
     static __device__ __forceinline__ double bias() { return PBN_EXP2_BIAS; }
     static __device__ __forceinline__ double ex2_hi(double x) { return exp2_f64<8>(x); }
@@ -187,6 +205,7 @@ struct Tr<float> {
     static __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
     static __device__ __forceinline__ float ex2_hi(float x) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float top() { return 0.0f; }
+    template <bool FAST = false>
     static __device__ __forceinline__ float ex2p(float x, float) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float bias() { return 0.0f; }
     static __device__ __forceinline__ float big() { return 0x1p100f; }
@@ -582,7 +601,8 @@ __device__ __forceinline__ void pruned_block(const SweepArgs& a, int groups_per_
 
 // The sweep proper.  `bid` is the workgroup's index inside ITS sweep: blockIdx.x for a stand-alone launch, the offset inside
 // the unit for the grouped launches (kde_sweep_group_kernel), where `a` was assembled from the unit's record.
-template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL>
+// EF32: 2^f of the main loop on the fp32 transcendental unit (exp2_f64_fract<true>; sweeps whose result is a sum)
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL, bool EF32 = false>
 __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigned bid) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
@@ -740,14 +760,14 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             V accj;
             if (COND) accj = Tr<T>::mfma(ax, bx[g], acc);
 
-            T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
+            T e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop), e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop), e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop), e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
             T ts;
             if (WMUL) ts = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], e0 * nx[0])));   // nx holds the weights
             else ts = (e0 + e1) + (e2 + e3);
             T tsj = 0;
             bool bad = !(ts < Tr<T>::big());
             if (COND) {
-                T j0 = Tr<T>::ex2p(accj[0], ctop), j1 = Tr<T>::ex2p(accj[1], ctop), j2 = Tr<T>::ex2p(accj[2], ctop), j3 = Tr<T>::ex2p(accj[3], ctop);
+                T j0 = Tr<T>::template ex2p<EF32>(accj[0], ctop), j1 = Tr<T>::template ex2p<EF32>(accj[1], ctop), j2 = Tr<T>::template ex2p<EF32>(accj[2], ctop), j3 = Tr<T>::template ex2p<EF32>(accj[3], ctop);
                 tsj = (j0 + j1) + (j2 + j3);
                 bad = bad || !(tsj < Tr<T>::big());
             }
@@ -765,7 +785,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 // the SAME 2^x as the main loop (the exponents are still biased, the offsets integers): a term must come out
                 // identical whichever path evaluates it, or sums taken in another tile order would differ by the polynomial's
                 // error (the Morton-ordered sweeps come through here often, table-ordered ones hardly ever)
-                e0 = Tr<T>::ex2p(acc[0], ctop); e1 = Tr<T>::ex2p(acc[1], ctop); e2 = Tr<T>::ex2p(acc[2], ctop); e3 = Tr<T>::ex2p(acc[3], ctop);
+                e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop); e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop); e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop); e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
                 ts = (e0 + e1) + (e2 + e3);
                 if (COND) {
                     T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)) - Tr<T>::bias());
@@ -775,7 +795,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                         accj -= mxj;
                     }
                     bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
-                    T j0 = Tr<T>::ex2p(accj[0], ctop), j1 = Tr<T>::ex2p(accj[1], ctop), j2 = Tr<T>::ex2p(accj[2], ctop), j3 = Tr<T>::ex2p(accj[3], ctop);
+                    T j0 = Tr<T>::template ex2p<EF32>(accj[0], ctop), j1 = Tr<T>::template ex2p<EF32>(accj[1], ctop), j2 = Tr<T>::template ex2p<EF32>(accj[2], ctop), j3 = Tr<T>::template ex2p<EF32>(accj[3], ctop);
                     tsj = (j0 + j1) + (j2 + j3);
                 }
             }
@@ -796,7 +816,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
-            const T e0 = Tr<T>::ex2p(acc[0], ctop), e1 = Tr<T>::ex2p(acc[1], ctop), e2 = Tr<T>::ex2p(acc[2], ctop), e3 = Tr<T>::ex2p(acc[3], ctop);
+            const T e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop), e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop), e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop), e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
             if (WMUL) sum[g] = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], __builtin_fma(e0, nx[0], sum[g]))));
             else sum[g] += (e0 + e1) + (e2 + e3);
         }
@@ -957,9 +977,9 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     }
 }
 
-template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false>
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL = false, bool EF32 = false>
 __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_WAVES : 2) void kde_sweep_kernel(SweepArgs a) {
-    kde_sweep_body<T, KS, COND, QG, FOLD, PRUNE, WMUL>(a, blockIdx.x);
+    kde_sweep_body<T, KS, COND, QG, FOLD, PRUNE, WMUL, EF32>(a, blockIdx.x);
 }
 
 // Grouped launch (kde_group.hip): the flat grid covers the sweeps of MANY units back to back, unit-major, every unit's share
@@ -978,7 +998,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks; a.ring_near = 0;
-    kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL>(a, bid);
+    kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true>(a, bid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2074,6 +2094,19 @@ void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
+// one launch site of kde_sweep_kernel: the plain fp64 shapes exist twice - FAST (SweepArgs::fast: the sweep's result is a sum over the
+// test rows) and exact-polynomial (per-row logl outputs); CKDE-fused and fp32 shapes only in the second form
+#define PBN_LAUNCH_SWEEP(KSv, CONDv, QGv, FOLDv, PRUNEv, WMULv)                                                                            \
+    do {                                                                                                                                 \
+        if constexpr (sizeof(T) == 8 && !(CONDv)) {                                                                                      \
+            if (a.fast) {                                                                                                                \
+                hipLaunchKernelGGL((kde_sweep_kernel<T, KSv, CONDv, QGv, FOLDv, PRUNEv, WMULv, true>), grid, block, 0, st, a);             \
+                break;                                                                                                                   \
+            }                                                                                                                            \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((kde_sweep_kernel<T, KSv, CONDv, QGv, FOLDv, PRUNEv, WMULv, false>), grid, block, 0, st, a);                    \
+    } while (0)
+
 template <typename T, bool COND, bool FOLD>
 static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t st) {
     constexpr int QG = SweepQG<sizeof(T) == 8, COND>::value;
@@ -2085,14 +2118,14 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
             grid = dim3((unsigned)(ceil_div(a.nqtiles, QGP) * a.nsplit_grid));   // one wave per workgroup, placed by pruned_block
             if constexpr (!COND && !FOLD) {
                 if (a.wmul && KS <= 2) {   // 4 / 8 marginal dimensions: the pruned shapes without a free K slot
-                    if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QGP, false, true, true>), grid, block, 0, st, a);
-                    else hipLaunchKernelGGL((kde_sweep_kernel<T, 2, false, QGP, false, true, true>), grid, block, 0, st, a);
+                    if (KS == 1) PBN_LAUNCH_SWEEP(1, false, QGP, false, true, true);
+                    else PBN_LAUNCH_SWEEP(2, false, QGP, false, true, true);
                     HIP_CHECK(hipGetLastError());
                     return;
                 }
             }
-            if (KS == 1) hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QGP, FOLD, true>), grid, block, 0, st, a);
-            else if (KS == 2) hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QGP, FOLD, true>), grid, block, 0, st, a);
+            if (KS == 1) PBN_LAUNCH_SWEEP(1, COND, QGP, FOLD, true, false);
+            else if (KS == 2) PBN_LAUNCH_SWEEP(2, COND, QGP, FOLD, true, false);
             else throw invalid_error("KDE: pruned sweeps cover at most 8 whitened dimensions");
             HIP_CHECK(hipGetLastError());
             return;
@@ -2103,8 +2136,8 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
     if constexpr (sizeof(T) == 8 && !COND && !FOLD) {
         if (a.wmul) {
             switch (KS) {
-                case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, false, QG, false, false, true>), grid, block, 0, st, a); break;
-                case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, false, QG, false, false, true>), grid, block, 0, st, a); break;
+                case 1: PBN_LAUNCH_SWEEP(1, false, QG, false, false, true); break;
+                case 2: PBN_LAUNCH_SWEEP(2, false, QG, false, false, true); break;
                 default: throw invalid_error("KDE: weighted-norm sweeps cover at most 8 whitened dimensions");
             }
             HIP_CHECK(hipGetLastError());
@@ -2113,18 +2146,18 @@ static void launch_sweep_tf(const SweepArgs& a, int KS, dim3 grid, hipStream_t s
     }
     if constexpr (sizeof(T) == 8 && !FOLD) {   // 17-32 dimensions: fp64, norms added per value, two query groups per wave (sweep_qg)
         switch (KS) {
-            case 5: hipLaunchKernelGGL((kde_sweep_kernel<T, 5, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
-            case 6: hipLaunchKernelGGL((kde_sweep_kernel<T, 6, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
-            case 7: hipLaunchKernelGGL((kde_sweep_kernel<T, 7, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
-            case 8: hipLaunchKernelGGL((kde_sweep_kernel<T, 8, COND, 2, false, false>), grid, block, 0, st, a); HIP_CHECK(hipGetLastError()); return;
+            case 5: PBN_LAUNCH_SWEEP(5, COND, 2, false, false, false); HIP_CHECK(hipGetLastError()); return;
+            case 6: PBN_LAUNCH_SWEEP(6, COND, 2, false, false, false); HIP_CHECK(hipGetLastError()); return;
+            case 7: PBN_LAUNCH_SWEEP(7, COND, 2, false, false, false); HIP_CHECK(hipGetLastError()); return;
+            case 8: PBN_LAUNCH_SWEEP(8, COND, 2, false, false, false); HIP_CHECK(hipGetLastError()); return;
             default: break;
         }
     }
     switch (KS) {
-        case 1: hipLaunchKernelGGL((kde_sweep_kernel<T, 1, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((kde_sweep_kernel<T, 2, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((kde_sweep_kernel<T, 3, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((kde_sweep_kernel<T, 4, COND, QG, FOLD, false>), grid, block, 0, st, a); break;
+        case 1: PBN_LAUNCH_SWEEP(1, COND, QG, FOLD, false, false); break;
+        case 2: PBN_LAUNCH_SWEEP(2, COND, QG, FOLD, false, false); break;
+        case 3: PBN_LAUNCH_SWEEP(3, COND, QG, FOLD, false, false); break;
+        case 4: PBN_LAUNCH_SWEEP(4, COND, QG, FOLD, false, false); break;
         default: throw invalid_error("KDE: this many whitened dimensions per sweep are not supported for the table's type");
     }
     HIP_CHECK(hipGetLastError());

@@ -66,6 +66,7 @@ struct SweepArgs {
     int64_t tiles_per_split;
     int fold;      // the packs carry the training norms in a free K slot (PackArgs::fold_norm)
     int count_redo; // measurement aid (PBN_SWEEP_COUNT_REDO): count the units of the unchecked pass that redo their split
+    int fast;      // fp64 plain sweeps whose result is a SUM over the test rows: 2^f on the fp32 transcendental unit (kde_kernels.hip: exp2_f64_fract<true>)
     int wmul;      // fp64 plain sweeps with d mod 4 == 0: training norms as weights 2^norm behind the norms (PackArgs::write_w)
     // Tile pruning (low-dimensional fp64 sweeps of the score engine): both sides are packed in Morton order of their
     // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first

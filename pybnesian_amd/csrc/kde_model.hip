@@ -402,6 +402,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
     sa.wmul = wmul ? 1 : 0;
+    sa.fast = dev_logl == nullptr ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;

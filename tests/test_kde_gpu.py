@@ -471,7 +471,9 @@ def test_unchecked_passes_with_stale_offsets(pbn, oracle, monkeypatch, d):
     got = plain.logl(test)
     s = plain.slogl(test)
     monkeypatch.delenv("PBN_SWEEP_PRUNE")
-    assert np.all(np.isfinite(got)) and np.isfinite(s) and abs(s - got.sum()) <= 1e-10 * abs(s)
+    # slogl (a sum: 2^f on the fp32 transcendental unit, <= 1.4e-7 per term) against the sum of the per-row logl (fp64 polynomial,
+    # 2.2e-9): 1e-8 relative - the north star's bar is 1e-6
+    assert np.all(np.isfinite(got)) and np.isfinite(s) and abs(s - got.sum()) <= 1e-8 * abs(s)
     pruned = pbn.KDE(names)
     pruned.fit(train)
     assert np.allclose(pruned.logl(test), got, rtol=1e-10, atol=1e-10)
@@ -493,7 +495,7 @@ def test_pruned_handles_full_size_properties(pbn, monkeypatch):
     k = pbn.KDE(names)
     k.fit(train)
     ll, s = k.logl(test), k.slogl(test)
-    assert np.all(np.isfinite(ll)) and abs(s - ll.sum()) <= 1e-10 * abs(s)
+    assert np.all(np.isfinite(ll)) and abs(s - ll.sum()) <= 1e-8 * abs(s)     # sum-only sweeps take the fp32-unit 2^f, per-row logl the polynomial
     s1, s2 = k.slogl(test.iloc[:33_333]), k.slogl(test.iloc[33_333:])
     assert abs((s1 + s2) - s) <= 1e-10 * abs(s)
     assert np.allclose(k.logl(test.iloc[50_000:50_100]), ll[50_000:50_100], rtol=1e-11, atol=1e-11)

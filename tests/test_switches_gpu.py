@@ -71,7 +71,9 @@ def test_hybrid_score_switches(default, env):
     """Hybrid candidates: moments from the per-grouping Gram or from per-candidate launches, slices fused or split, with and without
     the local-score memo - the same scores to rounding (the fp32 tables to their own precision)."""
     got = run(env)
-    assert close(got["hybrid_float64"], default["hybrid_float64"], 1e-10)
+    # (PBN_HYBRID_FUSED=1 evaluates a slice by the fused joint + marginal kernel - fp64 polynomial - instead of two plain sum-only
+    #  sweeps - 2^f on the fp32 transcendental unit: 1e-8, both far inside the 1e-6 bar)
+    assert close(got["hybrid_float64"], default["hybrid_float64"], 1e-8 if env == {"PBN_HYBRID_FUSED": "1"} else 1e-10)
     assert close(got["hybrid_float32"], default["hybrid_float32"], 1e-4)
     if env == {"PBN_SCORE_MEMO": "0"}:
         assert got["hybrid_float64"] == default["hybrid_float64"]      # the memo returns what a fresh evaluation gives
