@@ -618,15 +618,30 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     rows, dt, r_fast = sized(fast, cores, budget_s * 0.45)
     chk = slow(train_np, h, test_np[:min(rows, 4 * oracle.num_threads())])   # the tuned form against the checker
     try:
-        phys = len({l_.strip() for l_ in open("/proc/cpuinfo") if l_.startswith(("physical id", "core id"))}) and \
-            len(set(zip(*[[l_.split(":")[1].strip() for l_ in open("/proc/cpuinfo") if l_.startswith(key)] for key in ("physical id", "core id")])))
+        phys = len(set(zip(*[[l_.split(":")[1].strip() for l_ in open("/proc/cpuinfo") if l_.startswith(key)] for key in ("physical id", "core id")])))
     except Exception:
         phys = None
+    quota = None   # a container may see every core and still be held to a CPU-time quota: the all-cores figure cannot exceed it
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q_, per_ = f.read().split()[:2]
+            quota = None if q_ == "max" else float(q_) / float(per_)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q_ = float(f.read())
+                quota = None if q_ <= 0 else q_ / float(g.read())
+        except Exception:
+            pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = None
     out = {
         "value": rows / dt / 1e6, "unit": "M-samples/s", "cores": cores, "kind": "port",
         "pairs_per_s": rows * n_train / dt, "pairs_per_s_per_thread": rows * n_train / dt / cores,
         "max_rel_vs_checker": float(np.max(np.abs(r_fast[:chk.size] - chk) / np.maximum(1.0, np.abs(chk)))),
-        "cpu": baseline.cpu_model(), "physical_cores": phys,
+        "cpu": baseline.cpu_model(), "physical_cores": phys, "cpu_quota_cores": quota, "cpu_affinity": affinity,
         "sample": f"{rows} test rows x {n_train} training rows, d={D}, fp64, {dt:.1f}s wall; oracle/pbn_baseline.cpp (whitened, blocked 64 x 1024, "
                   f"libmvec exponentials, -Ofast -march=native), OpenMP over blocks of 64 test rows",
     }
