@@ -278,9 +278,34 @@ int pbn_table_sse(const pbn_table* t, const int* cols, int d, int64_t row0, int6
         check_range(t, row0, n, "pbn_table_sse");
         if (!means || !sse) throw invalid_error("pbn_table_sse: null output");
         if (d <= 0) return;
-        if (d > 64) throw invalid_error("pbn_table_sse: more than 64 columns per call is not supported yet");
         HIP_CHECK(hipSetDevice(t->ctx->device));
-        sse_block(t, cols, d, row0, n, means, sse);
+        if (d <= 64) { sse_block(t, cols, d, row0, n, means, sse); return; }
+        // more than 64 columns: the Gram kernels take 64 at a time - every pair of 32-column blocks (I <= J) is one call over I u J,
+        // whose cross block (and, for I == J, diagonal block) lands in the result; an entry is the centred dot product of its two
+        // columns whatever else shares the launch, up to the pilot shift's rounding
+        const int B = 32, nb = (d + B - 1) / B;
+        std::vector<int> sel;
+        std::vector<double> mu2(2 * B), s2((size_t)4 * B * B);
+        for (int I = 0; I < nb; ++I)
+            for (int J = I; J < nb; ++J) {
+                const int i0 = I * B, i1 = std::min(d, i0 + B), j0 = J * B, j1 = std::min(d, j0 + B);
+                sel.assign(cols + i0, cols + i1);
+                if (J != I) sel.insert(sel.end(), cols + j0, cols + j1);
+                const int dd = (int)sel.size(), ni = i1 - i0;
+                sse_block(t, sel.data(), dd, row0, n, mu2.data(), s2.data());
+                for (int a = 0; a < ni; ++a) means[i0 + a] = mu2[a];
+                if (J == I) {
+                    for (int a = 0; a < ni; ++a)
+                        for (int b = 0; b < ni; ++b) sse[(i0 + a) + (size_t)(i0 + b) * d] = s2[a + (size_t)b * dd];
+                } else {
+                    for (int a = 0; a < ni; ++a)
+                        for (int b = 0; b < j1 - j0; ++b) {
+                            const double v = s2[a + (size_t)(ni + b) * dd];
+                            sse[(i0 + a) + (size_t)(j0 + b) * d] = v;
+                            sse[(j0 + b) + (size_t)(i0 + a) * d] = v;
+                        }
+                }
+            }
     });
 }
 
@@ -299,12 +324,15 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     auto k = std::make_unique<pbn_kde>();
     k->ctx = ctx;
     std::vector<double> pilot;
-    if (!center && d > 0 && d <= 64 && n > 0) {
-        // centring offsets = pilot means (any offset is exact in the distances; it only keeps |z| small)
-        GramCols sel{};
-        for (int i = 0; i < d; ++i) sel.cols[i] = cols[i];
+    if (!center && d > 0 && n > 0) {
+        // centring offsets = pilot means (any offset is exact in the distances; it only keeps |z| small); 64 columns per launch
         ctx->scratch_red.reserve((size_t)train->n_cols + 8);
-        launch_pilot(train->data, train->ld, sel, d, row0, nullptr, n, train->dtype, ctx->scratch_red.p, ctx->stream);
+        for (int c0 = 0; c0 < d; c0 += 64) {
+            GramCols sel{};
+            const int dc = std::min(64, d - c0);
+            for (int i = 0; i < dc; ++i) sel.cols[i] = cols[c0 + i];
+            launch_pilot(train->data, train->ld, sel, dc, row0, nullptr, n, train->dtype, ctx->scratch_red.p, ctx->stream);
+        }
         std::vector<double> all((size_t)train->n_cols);
         HIP_CHECK(hipMemcpyAsync(all.data(), ctx->scratch_red.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -322,8 +350,8 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     // (tools/prune_handles_timing.py; fp64 up to 3 variables - 4 is a tie, 5 goes to the fused sweep -, fp32 up to 4).  PBN_CKDE_SPLIT=0 keeps the fused sweep, =1 splits
     // whenever the marginal qualifies for pruning.
     static const int split_mode = [] { const char* e = getenv("PBN_CKDE_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
-    const bool split = ckde && k->m.cond && split_mode != 0 && kde_prune_applies(fdt, d - 1, n) &&
-                       (split_mode > 0 || d <= (fdt == PBN_F64 ? 3 : 4));
+    const bool split = ckde && k->m.cond && ((split_mode != 0 && kde_prune_applies(fdt, d - 1, n) && (split_mode > 0 || d <= (fdt == PBN_F64 ? 3 : 4))) ||
+                                             k->m.wide);   // more than 32 evidence variables: no fused form - joint minus marginal
     if (split) {
         std::vector<double> Hm((size_t)(d - 1) * (d - 1));
         for (int j = 1; j < d; ++j)
@@ -357,6 +385,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         k->train = train;
         k->train_row0 = row0;
         const double sc = std::sqrt(2.0 * 1.4426950408889634073599246810019);
+        k->wu.assign((size_t)m.d, 0.0);
         for (int j = 0; j < m.d; ++j) k->wu[j] = m.W[(size_t)(m.d - 1) * m.d + j] / sc;
         if (m.d <= PBN_W_INLINE_D) {   // cdf / sample fragments: up to 16 evidence variables (logl / slogl go to 32 in fp64)
             k->cdf_KS = std::max(1, (m.d - 1 + 3) / 4);

@@ -497,7 +497,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     // spread over as many workgroups as the main pass, each paying its prologue for a few tiles: hand-over at 2^-32 cv64 3.56 -> 3.68 s
     // (slower), at 2^-24 3.56 -> 3.33 s and C3's first iteration 16.05 -> 15.58 s.  Kept as a switch, not as the default.
     static const double ring_near_env = [] { const char* e = std::getenv("PBN_RING_NEAR"); return (e && *e) ? std::atof(e) : 0.0; }();
-    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(t->dtype, 0) - 8.0;
+    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(t->dtype, 0, true) - 8.0;
     const int NB16 = ring ? bf16x3_mfmas(d0) : 0;
     const size_t frag16_b = (size_t)NB16 * 64 * 16;
     static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
@@ -564,7 +564,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
         s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
-        s.margin = (float)prune_margin(t->dtype, U.N); s.pad_ = 0.f;
+        s.margin = (float)prune_margin(t->dtype, U.N, /*the engine's terms are sums*/ true); s.pad_ = 0.f;
         GSweepUnit& r = hs[nu + u];   // the RING pass: the bf16 fragments of the same rows, partials behind the fp64 pass's
         r = s;
         if (ring) {

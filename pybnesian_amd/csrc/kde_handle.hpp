@@ -20,7 +20,7 @@ struct pbn_kde {
     std::vector<int> cols_fit;          // caller's column order (variable first)
     const pbn_table* train = nullptr;   // borrowed: CKDE::sample reads the sampled training rows from it
     int64_t train_row0 = 0;
-    double wu[PBN_MAX_D_HOST];
+    std::vector<double> wu;
     dev_buf<char> cA, cN, cU;
     // Low-dimensional CKDE handles (where tile pruning pays, see kde_fit_impl): logl = logl_joint - logl_marginal from two
     // pruned PLAIN sweeps - the reference's own formulation (factors/continuous/CKDE.hpp:256-287) - instead of the fused

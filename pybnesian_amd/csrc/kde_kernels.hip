@@ -331,7 +331,10 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 // 1e-3 and fp32's own 6e-8 per term); the support shrinks from 9.4 to 7.4 bandwidths per axis (a third of the tiles at 2-3
 // dimensions).
 #ifndef PBN_PRUNE_MARGIN_F32
-#define PBN_PRUNE_MARGIN_F32 40.0
+#define PBN_PRUNE_MARGIN_F32 36.0   // round 4 (40 until then): N * 2^-36 = 1.5e-5 of a sum at 10^6 rows - the size of the fp32 Gram form's own error
+#endif
+#ifndef PBN_PRUNE_MARGIN_SUM
+#define PBN_PRUNE_MARGIN_SUM 43.0   // fp64 sweeps whose result is a sum: 1.1e-7 of a sum at 10^6 rows, beside the 1.4e-7 of their 2^f (prune_margin)
 #endif
 
 // largest |z|^2 of the whitened rows (all d coordinates): one atomic max per block on the bits of a non-negative double
@@ -1980,6 +1983,98 @@ void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide models (more than 32 whitened dimensions): generic pack and sweep, see kde_kernels.hpp
+// ------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(256) void pack_rows_wide_kernel(WidePackArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.ntiles * 16) return;
+    const int64_t tile = r >> 4;
+    const int idx = (int)(r & 15);
+    const int d = a.d, KS = a.KS;
+    const bool valid = r < a.n;
+    int64_t src = 0;
+    if (valid) {
+        const int64_t lr = r < a.n0 ? a.row0 + r : a.row1 + (r - a.n0);
+        src = a.rows ? (int64_t)a.rows[lr] : lr;
+    }
+    double nrm = 0.0;
+    for (int i = 0; i < KS * 4; ++i) {
+        double z = 0.0;
+        if (valid && i < d) {
+            // z_i = sum_{j <= i} W[i][j] (x_j - mu_j): the row's coordinates are re-read per i (L1 / L2 hits) instead of living in a
+            // per-thread array of unknown size
+            const double* w = a.W + (size_t)i * d;
+            for (int j = 0; j <= i; ++j) {
+                const double x = (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
+                z = __builtin_fma(w[j], x, z);
+            }
+        }
+        nrm = __builtin_fma(z, z, nrm);
+        a.pack[(tile * KS + (i >> 2)) * 64 + (i & 3) * 16 + idx] = z;
+    }
+    double nv = -0.5 * nrm;
+    if (!valid) nv = a.is_query ? 0.0 : PBN_PAD_NORM;
+    if (a.is_query) {
+        a.npack[tile * 16 + idx] = nv;
+    } else {
+        const int lg = idx & 3, i = idx >> 2;   // f64 C-row order: crow(lg, i) == idx
+        a.npack[tile * 16 + lg * 4 + i] = nv;
+    }
+}
+
+void launch_pack_wide(const WidePackArgs& a, hipStream_t st) {
+    const int64_t npad = a.ntiles * 16;
+    if (npad == 0) return;
+    dim3 grid((unsigned)ceil_div(npad, 256)), block(256);
+    if (a.src_f32) hipLaunchKernelGGL(pack_rows_wide_kernel<float>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(pack_rows_wide_kernel<double>, grid, block, 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// one wave = one group of 16 queries; the B fragments come from memory at every K step (the wave's 16 queries are the same for all
+// tiles: L1 hits), the offset is raised tile by tile (online logsumexp, integer offsets), 2^x by the degree-8 polynomial
+__global__ __launch_bounds__(256) void kde_sweep_wide_kernel(SweepArgs a, int KS) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane >> 4;
+    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    const int split = blockIdx.y;
+    if (qt >= a.nqtiles) return;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+    const PBN_GLOBAL double* __restrict__ Ap = (const PBN_GLOBAL double*)a.Apack;
+    const PBN_GLOBAL double* __restrict__ Np = (const PBN_GLOBAL double*)a.nxpack;
+    const PBN_GLOBAL double* __restrict__ Bp = (const PBN_GLOBAL double*)a.Bpack + qt * KS * 64 + lane;
+    const double ny = ((const PBN_GLOBAL double*)a.nypack)[qt * 16 + (lane & 15)];
+    double m = -INFINITY, sum = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        d4 acc = *(const PBN_GLOBAL d4*)(Np + t * 16 + lg * 4) + ny;
+        const PBN_GLOBAL double* __restrict__ At = Ap + t * KS * 64 + lane;
+        for (int ks = 0; ks < KS; ++ks) acc = Tr<double>::mfma(At[ks * 64], Bp[ks * 64], acc);
+        const double vmax = colmax<double>(max4<double>(acc));   // uniform over the four lanes of a query column
+        if (vmax > m) {
+            const double nm = __builtin_ceil(vmax);
+            sum *= exp2(m - nm);   // m = -inf: the sum is still 0
+            m = nm;
+        }
+        sum += (Tr<double>::ex2_hi(acc[0] - m) + Tr<double>::ex2_hi(acc[1] - m)) + (Tr<double>::ex2_hi(acc[2] - m) + Tr<double>::ex2_hi(acc[3] - m));
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (lg == 0) {
+        PBN_GLOBAL double* o = (PBN_GLOBAL double*)a.part + ((int64_t)split * a.nqtiles * 16 + qt * 16 + lane) * 2;
+        o[0] = m;
+        o[1] = sum;
+    }
+}
+
+void launch_sweep_wide(const SweepArgs& a, int KS, int nsplit, hipStream_t st) {
+    if (a.nqtiles == 0) return;
+    dim3 grid((unsigned)ceil_div(a.nqtiles, 4), (unsigned)nsplit), block(256);
+    hipLaunchKernelGGL(kde_sweep_wide_kernel, grid, block, 0, st, a, KS);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_max_norm2(const PackArgs& a, int src_dtype, double* dev_out, hipStream_t st) {
     if (a.n <= 0) return;
     dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
@@ -2059,11 +2154,19 @@ void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t 
 // of the training set: 10^6 x 2^-52 = 2.2e-10 (fp32: 10^6 x 2^-40 = 9.1e-7).  With a constant margin the bound grew linearly with n
 // (and was needlessly tight for the 10^4-10^5-row folds and slices of the score engine: 90 000 rows -> 48.5, 450 000 -> 50.9;
 // 4 x 10^6 -> 54).  PBN_PRUNE_MARGIN_ADAPT=0 keeps the constant.
-double prune_margin(int dtype, int64_t n_train) {
-    static const double m64 = [] { const char* e = getenv("PBN_PRUNE_MARGIN"); return (e && *e) ? atof(e) : (double)PBN_PRUNE_MARGIN; }();
-    static const double m32 = [] { const char* e = getenv("PBN_PRUNE_MARGIN_F32"); return (e && *e) ? atof(e) : (double)PBN_PRUNE_MARGIN_F32; }();
-    static const bool adapt = [] { const char* e = getenv("PBN_PRUNE_MARGIN_ADAPT"); return !(e && *e) || atoi(e) != 0; }();
-    const double base = use_bf16x3(dtype) ? m32 : m64;
+// Round 4: sweeps whose result is a SUM over the test rows (slogl, the score engine's terms: `sum_only`) carry a per-term arithmetic
+// error of 1.4e-7 anyway (2^f on the fp32 transcendental unit), fp32 tables one of ~1e-5 (2^-24 |z|^2): their margins are set so that
+// the dropped-mass bound matches - fp64 sums 43 at 10^6 rows (1.1e-7 of a sum), fp32 36 (1.5e-5) - while per-row logl outputs keep 52
+// (2.2e-10).  cv64 3.06 -> 2.74 s, C3's first iteration 14.1 -> 12.6 s, C5 9.1 -> 8.7 s with the same operator sequences
+// (profiles/r4/margin_probe4.txt).  PBN_PRUNE_MARGIN pins the fp64 value for both kinds, PBN_PRUNE_MARGIN_SUM the sum-only one,
+// PBN_PRUNE_MARGIN_F32 the fp32 one; read per call (a host getenv per sweep launch) so that tests can pin them inside one process.
+double prune_margin(int dtype, int64_t n_train, bool sum_only) {
+    auto env = [](const char* name, double dflt) { const char* e = getenv(name); return (e && *e) ? atof(e) : dflt; };
+    const char* ea = getenv("PBN_PRUNE_MARGIN_ADAPT");
+    const bool adapt = !(ea && *ea) || atoi(ea) != 0;
+    double base;
+    if (use_bf16x3(dtype)) base = env("PBN_PRUNE_MARGIN_F32", (double)PBN_PRUNE_MARGIN_F32);
+    else base = env("PBN_PRUNE_MARGIN", sum_only ? env("PBN_PRUNE_MARGIN_SUM", (double)PBN_PRUNE_MARGIN_SUM) : (double)PBN_PRUNE_MARGIN);
     if (!adapt || n_train <= 0) return base;
     const double m = base + std::log2((double)n_train / 1e6);
     return m < 8.0 ? 8.0 : m;

@@ -135,9 +135,29 @@ void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_
                int bits, hipStream_t st);
 // 52 (fp64) / 40 (fp32 on the bf16 cores) at 10^6 training rows, + log2(n_train / 10^6): a constant bound (2.2e-10 / 9.1e-7 of a sum) on what
 // pruning drops; PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override the base, PBN_PRUNE_MARGIN_ADAPT=0 the scaling
-double prune_margin(int dtype, int64_t n_train);
+double prune_margin(int dtype, int64_t n_train, bool sum_only = false);
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
 int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
+
+// ---- more than 32 whitened dimensions (the reference's kernels loop over any d: kde/KDE.hpp:592-640): a generic, runtime-sized form of
+// the pack and of the sweep.  fp64 fragments in the classic order (fp32 tables are packed into doubles), norms added per value, the
+// columns / centring offsets / whitening matrix in device memory; no folding, no weights, no pruning: correctness path, any d.
+struct WidePackArgs {
+    const void* base;      // device column-major table
+    int64_t ld;
+    const int* cols;       // device: d selected columns, whitening order
+    const double* mu;      // device: d centring offsets
+    const double* W;       // device: d x d row-major lower whitening matrix
+    int d, KS, is_query, src_f32;
+    int64_t row0, n0, row1;
+    const int32_t* rows;   // device gather list (nullable)
+    int64_t n, ntiles;
+    double* pack;          // [ntiles][KS][64]
+    double* npack;         // [ntiles][16]
+};
+void launch_pack_wide(const WidePackArgs& a, hipStream_t st);
+// plain fp64 sweep with a runtime number of K steps: Apack / nxpack / Bpack / nypack / ntiles / nqtiles / tiles_per_split / part of `a`
+void launch_sweep_wide(const SweepArgs& a, int KS, int nsplit, hipStream_t st);
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 // dev_out[0] = max over the rows described by `a` of |z|^2 (all a.d whitened coordinates, base-2 units), as the bits of a non-negative

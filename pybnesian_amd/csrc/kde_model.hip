@@ -103,8 +103,13 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
     // up to 32 main dimensions: fp64 KS <= 8 MFMAs per tile pair, fp32 (bf16x3 fragments, 6 slots per dimension + 3) <= 7; the
     // classic fp32 fragments (PBN_F32_BF16X3=0, a measurement switch) stay at 16
     const int max_dm = (dtype == PBN_F64 || use_bf16x3(dtype)) ? 32 : 16;
-    if (dm > max_dm) throw invalid_error("KDE with more than 32 (+1 conditional) variables is not supported");
     m.dtype = dtype; m.widen = false; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
+    // beyond the templated shapes: the generic runtime-sized pack / sweep in fp64 fragments (kde_kernels.hpp "wide"); a conditional
+    // model of that size has no fused sweep - its owner evaluates joint - marginal (capi.hip: split handles; the score engine's terms
+    // are plain anyway) and kde_pack_train refuses it
+    m.wide = dm > max_dm;
+    if (m.wide) { m.widen = dtype == PBN_F32; m.KS = (dm + 3) / 4; }
+    m.perm.assign((size_t)d, 0);
     m.N = n; m.ntiles = ceil_div(n, 16);
     if (cond) {  // evidence first, variable last
         for (int i = 0; i < d - 1; ++i) m.perm[i] = i + 1;
@@ -235,8 +240,36 @@ static SubBytes sub_bytes(const KdeModel& m, int64_t nsub) {
     return b;
 }
 
+// wide models: columns, centring offsets and whitening matrix through the context's (lane's) scratch, in stream order
+static void fill_wide_pack(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, const int* cols, const KdeModel& m) {
+    const size_t d = (size_t)m.d;
+    auto al = [](size_t x) { return (x + 7) / 8 * 8; };
+    ctx->scratch_w.reserve(d * d + d + al(d) / 2 + 8);   // doubles: W | mu | cols (ints)
+    double* Wd = ctx->scratch_w.p;
+    double* mud = Wd + d * d;
+    int* colsd = (int*)(mud + d);
+    std::vector<int> hc(d);
+    for (size_t i = 0; i < d; ++i) hc[i] = cols[m.perm[i]];
+    HIP_CHECK(hipMemcpyAsync(Wd, m.W.data(), d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(mud, m.mu.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(colsd, hc.data(), d * sizeof(int), hipMemcpyHostToDevice, ctx->stream));   // pageable source: staged before the call returns
+    wa.base = t->data; wa.ld = t->ld; wa.cols = colsd; wa.mu = mud; wa.W = Wd;
+    wa.d = m.d; wa.KS = m.KS; wa.src_f32 = t->dtype == PBN_F32 ? 1 : 0;
+}
+
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
                     int64_t row1, const int32_t* dev_rows, bool prune) {
+    if (m.wide) {
+        if (m.cond) throw invalid_error("KDE: a conditional model of more than 32 evidence variables is evaluated as joint - marginal");
+        WidePackArgs wa{};
+        fill_wide_pack(ctx, wa, t, cols, m);
+        wa.rows = dev_rows; wa.row0 = row0; wa.n0 = n0; wa.row1 = row1; wa.n = m.N; wa.ntiles = m.ntiles; wa.is_query = 0;
+        wa.pack = (double*)m.Apack; wa.npack = (double*)m.nxpack;
+        m.prune = false;
+        KernelTimer kt(ctx, PBN_K_PACK);
+        launch_pack_wide(wa, ctx->stream);
+        return;
+    }
     PackArgs pa{};
     fill_pack_common(ctx, pa, t, cols, m);
     pa.rows = dev_rows;
@@ -312,6 +345,40 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     if (!dev_rows) check_range(test, row0, n, "pbn_kde_logl");
     if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
     const int fdt = m.fdtype();   // type of the fragments and of the sweep (double for a widened fp32 model)
+    if (m.wide) {   // more than 32 dimensions: generic pack + sweep, plain, fp64 fragments
+        if (m.cond) throw invalid_error("KDE: a conditional model of more than 32 evidence variables is evaluated as joint - marginal");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (n == 0) {
+            if (dev_sum) HIP_CHECK(hipMemsetAsync(dev_sum, 0, sizeof(double), ctx->stream));
+            return;
+        }
+        const int64_t nqt = ceil_div(n, 16);
+        const size_t bp = (size_t)nqt * m.KS * 64 * sizeof(double), nyb = (size_t)nqt * 16 * sizeof(double);
+        ctx->scratch_q.reserve(bp + nyb + 256);
+        WidePackArgs wq{};
+        fill_wide_pack(ctx, wq, test, cols, m);
+        wq.rows = dev_rows; wq.row0 = row0; wq.n0 = n; wq.row1 = 0; wq.n = n; wq.ntiles = nqt; wq.is_query = 1;
+        wq.pack = (double*)ctx->scratch_q.p; wq.npack = (double*)(ctx->scratch_q.p + bp);
+        { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_wide(wq, ctx->stream); }
+        int64_t ns = std::max<int64_t>(1, ceil_div((int64_t)ctx->num_cus * 8, ceil_div(nqt, 4)));
+        ns = std::min<int64_t>(ns, std::max<int64_t>(1, m.ntiles / 16));
+        ns = std::min<int64_t>(ns, 1024);
+        const int64_t tpsw = ceil_div(m.ntiles, ns);
+        ns = ceil_div(m.ntiles, tpsw);
+        ctx->scratch_part.reserve((size_t)ns * nqt * 16 * 2 * sizeof(double));
+        SweepArgs sw{};
+        sw.Apack = m.Apack; sw.nxpack = m.nxpack; sw.Bpack = wq.pack; sw.nypack = wq.npack;
+        sw.ntiles = m.ntiles; sw.nqtiles = nqt; sw.tiles_per_split = tpsw; sw.part = (double*)ctx->scratch_part.p;
+        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep_wide(sw, m.KS, (int)ns, ctx->stream); }
+        const int64_t nb = ceil_div(n, 256);
+        ctx->scratch_misc.reserve((size_t)nb * 2 * sizeof(double));
+        FinishArgs fw{};
+        fw.part = sw.part; fw.nsplit = (int)ns; fw.nqtiles = nqt; fw.nq = n;
+        fw.lognorm = m.lognorm; fw.lognorm_marg = m.lognorm_marg;
+        fw.logl = dev_logl; fw.scatter = nullptr; fw.block_sums = dev_sum ? (double*)ctx->scratch_misc.p : nullptr;
+        { KernelTimer kt(ctx, PBN_K_FINISH); launch_finish(fw, false, dev_sum, ctx->stream, nullptr); }
+        return;
+    }
     if (test->ctx->device != ctx->device) throw invalid_error("pbn_kde_logl: test table lives on another device");
     HIP_CHECK(hipSetDevice(ctx->device));
     if (n == 0) {
@@ -404,7 +471,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.wmul = wmul ? 1 : 0;
     sa.fast = dev_logl == nullptr ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
+    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, dev_logl == nullptr); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
     sa.soft = env_int("PBN_SPARSE_SOFT", 8);
     sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);

@@ -23,7 +23,10 @@ struct KdeModel {
     int64_t N = 0;
     int64_t ntiles = 0;
     double lognorm = 0.0, lognorm_marg = 0.0;
-    int perm[PBN_MAX_D_HOST];  // whitening order -> position in the caller's column list
+    std::vector<int> perm;     // whitening order -> position in the caller's column list
+    // more than 32 main dimensions: the generic runtime-sized pack / sweep (kde_kernels.hpp "wide"), always in fp64 fragments,
+    // plain sweeps only (a CKDE of that size is evaluated as joint - marginal, the reference's own formulation: CKDE.hpp:256-287)
+    bool wide = false;
     std::vector<double> W, mu; // d x d row-major lower whitening matrix; d centring offsets (whitening order)
     void* Apack = nullptr;     // device [ntiles][KS][64]
     void* nxpack = nullptr;    // device [ntiles][16]

@@ -113,8 +113,8 @@ def test_fp32_hybrid_large_slices_pruned(pbn, oracle):
 
 
 def test_fp32_pruned_equals_unpruned(pbn, monkeypatch):
-    """The tile-pruned sweeps drop only terms below 2^-64 of their sums: same scores as the unpruned sweeps far inside the
-    fp32 bar."""
+    """The tile-pruned fp32 sweeps drop at most 1.5e-5 of a sum (margin 36 at 10^6 rows - the size of the fp32 Gram form's own
+    error): same scores as the unpruned sweeps far inside the fp32 bar of 1e-3."""
     n = 40_000
     df, _, _ = make_c5(n, seed=8)
     net = spbn(pbn, df)
@@ -124,7 +124,7 @@ def test_fp32_pruned_equals_unpruned(pbn, monkeypatch):
         monkeypatch.setenv("PBN_PRUNE_MIN_ROWS", "2048")
         vl = pbn.ValidatedLikelihood(df, 0.2, 2, 0)
         got[prune] = [vl.local_score_node_type(net, pbn.CKDEType(), v, p) for v, p in (("y", ["x", "B"]), ("z", ["x", "y", "A"]), ("w", ["z"]))]
-    assert np.allclose(got["0"], got["1"], rtol=1e-6), got
+    assert np.allclose(got["0"], got["1"], rtol=3e-5), got     # fp32 margin 36 (round 4): the bound on the dropped mass is 1.5e-5 of a sum
 
 
 def test_mmhc_hybrid_end_to_end_vs_oracles(pbn, oracle):

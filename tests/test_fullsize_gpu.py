@@ -220,7 +220,9 @@ def test_c3_fullsize_properties(env, monkeypatch):
     # three candidates (1, 2, 3 parents): grouped + pruned (default) = per-unit pruned = unpruned, from fresh score objects
     cands = [("x5", ["x1"]), ("x9", ["x2", "x4"]), ("x20", ["x3", "x7", "x11"])]
     ref = [score.local_score_node_type(start, pbn.CKDEType(), v, p) for v, p in cands]
-    for env_kv, tol in (({"PBN_SCORE_GROUPED": "0"}, 1e-11), ({"PBN_SWEEP_PRUNE": "0"}, 1e-10)):
+    # (the default margin of the sum-only sweeps bounds the dropped mass at 1.1e-7 of a sum, and which tiles are dropped depends on
+    #  the boxes of the evaluation form: 3e-7; tests/test_switches_gpu.py compares the forms with the margin pinned at 52, at 1e-10)
+    for env_kv, tol in (({"PBN_SCORE_GROUPED": "0"}, 3e-7), ({"PBN_SWEEP_PRUNE": "0"}, 3e-7)):
         for k_, v_ in env_kv.items():
             monkeypatch.setenv(k_, v_)
         other = pbn.CVLikelihood(None, 10, 0, table=table)
@@ -295,7 +297,7 @@ def test_c5_fullsize_properties(env, monkeypatch):
     other = pbn.ValidatedLikelihood(df, 0.2, 10, 0)
     got = [other.local_score_node_type(start, ty, v, p) for v, ty, p in cands]
     monkeypatch.delenv("PBN_SWEEP_PRUNE")
-    assert np.allclose(got, ref, rtol=2e-6, atol=0), (got, ref)
+    assert np.allclose(got, ref, rtol=3e-5, atol=0), (got, ref)       # fp32 margin 36: at most 1.5e-5 of a sum dropped
     # validation score of x3 | D3 (HCKDE) = the factor fitted on the hold-out training part, evaluated on its test part
     ho = pbn.HoldOut(df[["x3", "D3"]], 0.2, 0)
     f = pbn.HCKDE("x3", ["D3"])

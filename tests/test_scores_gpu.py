@@ -486,11 +486,17 @@ def test_ckde_set_function_cache_paths(pbn):
     assert score.kde_cache_stats() == (entries, sweeps) and np.array_equal(vals, again)
 
 
-@pytest.mark.parametrize("dtype,rel", [("float64", 1e-11), ("float32", 2e-6)])
-def test_pruned_sweeps_match_unpruned(pbn, dtype, rel):
+@pytest.mark.parametrize("dtype,pin,rel", [("float64", {"PBN_PRUNE_MARGIN": "52"}, 1e-11), ("float64", {}, 3e-7),
+                                           ("float32", {"PBN_PRUNE_MARGIN_F32": "40"}, 2e-6), ("float32", {}, 3e-5)])
+def test_pruned_sweeps_match_unpruned(pbn, dtype, pin, rel, monkeypatch):
     """Low-dimensional CKDE candidates of the score engine run the Morton-sorted, tile-pruned sweep once the training folds
-    are large enough; dropping the tiles whose terms are below 2^-64 of their sums must not move the scores."""
+    are large enough.  With the margin pinned at 52 (fp32: 40) what is dropped is below 2.2e-10 (9e-7) of a sum: the machinery
+    reproduces the unpruned scores to 1e-11 (2e-6).  The default margins of the sum-only sweeps (43 / 36 at 10^6 rows, prune_margin)
+    are chosen so that the dropped-mass BOUND equals the arithmetic's own error - 1.1e-7 (1.5e-5) of a sum - and are held to it."""
     import os
+
+    for k_, v_ in pin.items():
+        monkeypatch.setenv(k_, v_)
 
     rng = np.random.default_rng(11)
     n = 90000
@@ -580,6 +586,26 @@ def test_cv_likelihood_ckde_with_18_parents(pbn, oracle):
     score = pbn.CVLikelihood(df, 3, 5)
     got = score.local_score_node_type(pbn.SemiparametricBN(names), pbn.CKDEType(), "v0", names[1:])
     want = oracle.cv_likelihood(data, "ckde", 3, 5)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+
+
+def test_cv_likelihood_ckde_with_40_parents(pbn, oracle):
+    """A CKDE candidate over 41 variables: beyond the templated sweeps (32 whitened dimensions) the score engine's terms - plain
+    joint and marginal sweeps - take the generic runtime-sized path (kde_kernels.hpp "wide"); a KDENetwork search without
+    max_indegree on a wide table can reach such candidates (the reference's kernels loop over any d: KDE.hpp:592-640)."""
+    rng = np.random.default_rng(41)
+    n, d = 1200, 41
+    mix = np.tril(rng.uniform(-0.2, 0.2, size=(d, d)), -1) + np.eye(d)
+    data = rng.normal(size=(n, d)) @ mix.T
+    names = [f"v{i}" for i in range(d)]
+    df = pd.DataFrame(data, columns=names)
+    score = pbn.CVLikelihood(df, 3, 7)
+    got = score.local_score_node_type(pbn.SemiparametricBN(names), pbn.CKDEType(), "v0", names[1:])
+    want = oracle.cv_likelihood(data, "ckde", 3, 7)
+    assert abs(got - want) <= RTOL_F64 * abs(want)
+    hold = pbn.HoldoutLikelihood(df, 0.25, 7)
+    got = hold.local_score_node_type(pbn.SemiparametricBN(names), pbn.CKDEType(), "v3", names[4:40])
+    want = oracle.holdout_likelihood(data[:, [3] + list(range(4, 40))], "ckde", 0.25, 7)
     assert abs(got - want) <= RTOL_F64 * abs(want)
 
 
