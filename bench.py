@@ -598,7 +598,26 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     full = np.ndim(h) == 2
     fast = baseline.kde_logl if full else baseline.product_kde_logl
     slow = oracle.kde_logl if full else oracle.product_kde_logl
-    cores = baseline.num_threads()
+    visible = baseline.num_threads()
+    quota = None   # a container may see every core and still be held to a CPU-time quota: more threads than that only thrash
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q_, per_ = f.read().split()[:2]
+            quota = None if q_ == "max" else float(q_) / float(per_)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q_ = float(f.read())
+                quota = None if q_ <= 0 else q_ / float(g.read())
+        except Exception:
+            pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = None
+    cores = int(max(1, min(visible, affinity or visible, int(np.ceil(quota)) if quota else visible)))
+    baseline.set_num_threads(cores)
+    oracle.set_num_threads(cores)
     n_train = train_np.shape[0]
 
     def timed(fn, rows):
@@ -621,27 +640,12 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
         phys = len(set(zip(*[[l_.split(":")[1].strip() for l_ in open("/proc/cpuinfo") if l_.startswith(key)] for key in ("physical id", "core id")])))
     except Exception:
         phys = None
-    quota = None   # a container may see every core and still be held to a CPU-time quota: the all-cores figure cannot exceed it
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q_, per_ = f.read().split()[:2]
-            quota = None if q_ == "max" else float(q_) / float(per_)
-    except Exception:
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
-                q_ = float(f.read())
-                quota = None if q_ <= 0 else q_ / float(g.read())
-        except Exception:
-            pass
-    try:
-        affinity = len(os.sched_getaffinity(0))
-    except Exception:
-        affinity = None
     out = {
         "value": rows / dt / 1e6, "unit": "M-samples/s", "cores": cores, "kind": "port",
         "pairs_per_s": rows * n_train / dt, "pairs_per_s_per_thread": rows * n_train / dt / cores,
         "max_rel_vs_checker": float(np.max(np.abs(r_fast[:chk.size] - chk) / np.maximum(1.0, np.abs(chk)))),
-        "cpu": baseline.cpu_model(), "physical_cores": phys, "cpu_quota_cores": quota, "cpu_affinity": affinity,
+        "cpu": baseline.cpu_model(), "physical_cores": phys, "visible_cpus": visible, "cpu_quota_cores": quota, "cpu_affinity": affinity,
+        "cores_note": "threads = min(visible CPUs, affinity, the container's cgroup CPU quota): the GPU boxes of this pool show 256 CPUs under a 16-CPU quota",
         "sample": f"{rows} test rows x {n_train} training rows, d={D}, fp64, {dt:.1f}s wall; oracle/pbn_baseline.cpp (whitened, blocked 64 x 1024, "
                   f"libmvec exponentials, -Ofast -march=native), OpenMP over blocks of 64 test rows",
     }
@@ -679,7 +683,8 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     except Exception as ex:
         out["extra_error"] = f"{type(ex).__name__}: {ex}"
     finally:
-        baseline.set_num_threads(cores)
+        baseline.set_num_threads(visible)
+        oracle.set_num_threads(visible)
     return out
 
 
