@@ -150,6 +150,7 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
 }
 
 static void fill_pack_common(pbn_ctx* ctx, PackArgs& pa, const pbn_table* t, const int* cols, const KdeModel& m) {
+    if (m.d > PBN_MAX_D) throw invalid_error("internal: a wide model reached the fixed-size pack arguments");
     pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.dm; pa.KS = m.KS;
     pa.src_f32 = (m.widen && m.dtype == PBN_F32) ? 1 : 0;
     for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];
