@@ -401,7 +401,19 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
             KernelTimer kt(ctx, PBN_K_PACK);
             launch_pack_classic(pa, m.dtype, ctx->stream);
         } else {
-            k->cdf_KS = 0;   // pbn_ckde_cdf / pbn_ckde_sample refuse such a handle
+            // more than 16 evidence variables (the reference's cdf / sample loop over any number: CKDE.hpp:289-735): fp64 fragments in
+            // the classic order through the generic pack, runtime-sized kernels (kde_cdf_kernel<double, 0, ...>)
+            k->cdf_wide = true;
+            k->cdf_KS = (m.d - 1 + 3) / 4;
+            k->cA.alloc((size_t)m.ntiles * k->cdf_KS * 64 * sizeof(double));
+            k->cN.alloc((size_t)m.ntiles * 16 * sizeof(double));
+            k->cU.alloc((size_t)m.ntiles * 16 * sizeof(double));
+            pbn::WidePackArgs wa{};
+            fill_cdf_pack_wide(ctx, wa, *k, train, cols);
+            wa.rows = nullptr; wa.row0 = row0; wa.n0 = n; wa.row1 = 0; wa.n = n; wa.ntiles = m.ntiles; wa.is_query = 0;
+            wa.pack = (double*)k->cA.p; wa.npack = (double*)k->cN.p; wa.upack = (double*)k->cU.p;
+            KernelTimer kt(ctx, PBN_K_PACK);
+            launch_pack_wide(wa, ctx->stream);
         }
     }
     *out = k.release();
@@ -483,7 +495,6 @@ int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
     return guarded(mu_of(k), [&] {
         if (!k) throw invalid_error("CKDE factor not fitted.");
         if (!k->ckde) throw invalid_error("pbn_ckde_cdf: the handle was not created by pbn_ckde_fit");
-        if (k->cdf_KS == 0) throw invalid_error("CKDE.cdf: at most 16 evidence variables are supported");
         if (!out && n > 0) throw invalid_error("pbn_ckde_cdf: null output");
         pbn_ctx* ctx = k->ctx;
         const KdeModel& m = k->m;
@@ -493,16 +504,28 @@ int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
         if (test->ctx->device != ctx->device) throw invalid_error("pbn_ckde_cdf: test table lives on another device");
         HIP_CHECK(hipSetDevice(ctx->device));
         if (n == 0) return;
-        const size_t es = dtype_size(m.dtype);
+        const int fdt = k->cdf_wide ? PBN_F64 : m.dtype;   // type of the cdf fragments
+        const size_t es = dtype_size(fdt);
         const int64_t nqtiles = ceil_div(n, 16);
         const size_t b_b = (size_t)nqtiles * k->cdf_KS * 64 * es, n_b = (size_t)nqtiles * 16 * es;
         ctx->scratch_q.reserve(b_b + 2 * n_b + 256);
         char* q = ctx->scratch_q.p;
-        PackArgs pa{};
-        fill_cdf_pack(pa, *k, test, cols);
-        pa.row0 = row0; pa.n0 = n; pa.row1 = 0; pa.n = n; pa.ntiles = nqtiles; pa.is_query = 1;
-        pa.pack = q; pa.npack = q + b_b; pa.upack = q + b_b + n_b;
-        { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pa, m.dtype, ctx->stream); }
+        struct { void* pack; void* npack; void* upack; } pa{q, q + b_b, q + b_b + n_b};
+        if (k->cdf_wide) {
+            pbn::WidePackArgs wq{};
+            fill_cdf_pack_wide(ctx, wq, *k, test, cols);
+            wq.rows = nullptr; wq.row0 = row0; wq.n0 = n; wq.row1 = 0; wq.n = n; wq.ntiles = nqtiles; wq.is_query = 1;
+            wq.pack = (double*)pa.pack; wq.npack = (double*)pa.npack; wq.upack = (double*)pa.upack;
+            KernelTimer kt(ctx, PBN_K_PACK);
+            launch_pack_wide(wq, ctx->stream);
+        } else {
+            PackArgs pq{};
+            fill_cdf_pack(pq, *k, test, cols);
+            pq.row0 = row0; pq.n0 = n; pq.row1 = 0; pq.n = n; pq.ntiles = nqtiles; pq.is_query = 1;
+            pq.pack = pa.pack; pq.npack = pa.npack; pq.upack = pa.upack;
+            KernelTimer kt(ctx, PBN_K_PACK);
+            launch_pack_classic(pq, m.dtype, ctx->stream);
+        }
         const int64_t qblocks = ceil_div(nqtiles, 8);
         int64_t nsplit = std::max<int64_t>(1, ceil_div((int64_t)ctx->num_cus * 16, qblocks));
         nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / 16));
@@ -514,7 +537,7 @@ int pbn_ckde_cdf(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row
         ca.Bpack = pa.pack; ca.nypack = pa.npack; ca.uquery = pa.upack;
         ca.ntiles = m.ntiles; ca.nqtiles = nqtiles; ca.tiles_per_split = tps;
         ca.part = (double*)ctx->scratch_part.p;
-        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_cdf(ca, m.dtype, k->cdf_KS, (int)nsplit, ctx->stream); }
+        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_cdf(ca, fdt, k->cdf_KS, (int)nsplit, ctx->stream); }
         dev_buf<double> tmp((size_t)n);
         { KernelTimer kt(ctx, PBN_K_FINISH); launch_cdf_finish(ca.part, (int)nsplit, nqtiles, n, tmp.p, ctx->stream); }
         HIP_CHECK(hipMemcpyAsync(out, tmp.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -17,6 +17,7 @@ struct pbn_kde {
     // CKDE::cdf state (pbn_ckde_fit only): classic fragments of the evidence dimensions + u = (x - b.e)/(sigma_c sqrt 2)
     bool ckde = false;
     int cdf_KS = 0;
+    bool cdf_wide = false;              // more than 16 evidence variables: fp64 fragments (whatever the table's type), runtime-sized kernels
     std::vector<int> cols_fit;          // caller's column order (variable first)
     const pbn_table* train = nullptr;   // borrowed: CKDE::sample reads the sampled training rows from it
     int64_t train_row0 = 0;
@@ -28,10 +29,19 @@ struct pbn_kde {
     std::unique_ptr<pbn_kde> split_joint, split_marg;
 };
 
+// WidePackArgs of the cdf fragments of a handle with more than 16 evidence variables: whitening order (evidence first, variable last),
+// contraction over the evidence only, u from all d columns (kde_model.hpp: kde_wide_pack_args)
+inline void fill_cdf_pack_wide(pbn_ctx* ctx, pbn::WidePackArgs& wa, const pbn_kde& k, const pbn_table* t, const int* cols) {
+    const KdeModel& m = k.m;
+    std::vector<int> hc((size_t)m.d);
+    for (int i = 0; i < m.d; ++i) hc[i] = cols[m.perm[i]];
+    pbn::kde_wide_pack_args(ctx, wa, t, hc.data(), m.d, m.d - 1, m.W.data(), m.d, m.mu.data(), k.wu.data());
+}
+
 // PackArgs for the cdf fragments: whitening order (evidence first, variable last), contraction over the evidence only.
 inline void fill_cdf_pack(PackArgs& pa, const pbn_kde& k, const pbn_table* t, const int* cols) {
     const KdeModel& m = k.m;
-    if (m.d > PBN_W_INLINE_D) throw pbn::invalid_error("CKDE.cdf / sample: at most 16 evidence variables are supported");
+    if (m.d > PBN_W_INLINE_D) throw pbn::invalid_error("internal: a wide CKDE reached the fixed-size cdf pack");
     pa.Wdev = nullptr;
     pa.base = t->data; pa.ld = t->ld; pa.d = m.d; pa.dm = m.d - 1; pa.KS = k.cdf_KS;
     for (int i = 0; i < m.d; ++i) pa.cols[i] = cols[m.perm[i]];

@@ -1767,6 +1767,11 @@ __device__ __forceinline__ float half_erfc<float>(float x) { return 0.5f * erfcf
 template <typename T, int KS, int QG, int MODE>
 __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
     constexpr bool CDF = MODE == 1;
+    // KS == 0: the number of K steps is a run-time value (more than 16 evidence variables / UCV dimensions): the fragments of both
+    // sides are read at every step instead of living in registers
+    constexpr bool RT = KS == 0;
+    constexpr int KSR = RT ? 1 : KS;
+    const int ksn = RT ? a.KS : KS;
     using V = typename Tr<T>::vec4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1790,13 +1795,17 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
     const T* __restrict__ NYp = (const T*)a.nypack;
     const T* __restrict__ UQp = (const T*)a.uquery;
 
-    T b[QG][KS], ny[QG], cm[QG], m[QG], uq[QG];
+    T b[QG][KSR], ny[QG], cm[QG], m[QG], uq[QG];
+    int64_t qtg[QG];
     double sw[QG], sc[QG];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+        qtg[g] = qt;
+        if constexpr (!RT) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bp[(qt * KS + ks) * 64 + lane];
+            for (int ks = 0; ks < KS; ++ks) b[g][ks] = Bp[(qt * KS + ks) * 64 + lane];
+        }
         ny[g] = NYp[qt * 16 + (lane & 15)];
         uq[g] = CDF ? UQp[qt * 16 + (lane & 15)] : (T)0;
         sw[g] = 0.0; sc[g] = 0.0;
@@ -1806,24 +1815,34 @@ __global__ __launch_bounds__(256, 2) void kde_cdf_kernel(CdfArgs a) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             V acc = nx + ny[g];
+            if constexpr (RT) {
+                for (int ks = 0; ks < ksn; ++ks) acc = Tr<T>::mfma(Ap[(t0 * ksn + ks) * 64 + lane], Bp[(qtg[g] * ksn + ks) * 64 + lane], acc);
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(Ap[(t0 * KS + ks) * 64 + lane], b[g][ks], acc);
+                for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(Ap[(t0 * KS + ks) * 64 + lane], b[g][ks], acc);
+            }
             m[g] = MODE == 2 ? (T)0 : colmax<T>(max4<T>(acc));
             cm[g] = ny[g] - m[g];
         }
     }
     for (int64_t t = t0; t < t1; ++t) {
-        T af[KS];
+        T af[KSR];
+        if constexpr (!RT) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t * KS + ks) * 64 + lane];
+            for (int ks = 0; ks < KS; ++ks) af[ks] = Ap[(t * KS + ks) * 64 + lane];
+        }
         const V nx = *(const V*)(Np + t * 16 + lg * 4);
         V ut = {0, 0, 0, 0};
         if (CDF) ut = *(const V*)(Up + t * 16 + lg * 4);
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             V acc = nx + cm[g];
+            if constexpr (RT) {
+                for (int ks = 0; ks < ksn; ++ks) acc = Tr<T>::mfma(Ap[(t * ksn + ks) * 64 + lane], Bp[(qtg[g] * ksn + ks) * 64 + lane], acc);
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+                for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+            }
             T w0 = Tr<T>::ex2_hi(acc[0]), w1 = Tr<T>::ex2_hi(acc[1]), w2 = Tr<T>::ex2_hi(acc[2]), w3 = Tr<T>::ex2_hi(acc[3]);
             T ts = (w0 + w1) + (w2 + w3);
             if (MODE != 2 && __builtin_expect(__any(!(ts < Tr<T>::big())), 0)) {
@@ -2002,10 +2021,10 @@ __global__ __launch_bounds__(256) void pack_rows_wide_kernel(WidePackArgs a) {
     double nrm = 0.0;
     for (int i = 0; i < KS * 4; ++i) {
         double z = 0.0;
-        if (valid && i < d) {
+        if (valid && i < a.dm) {
             // z_i = sum_{j <= i} W[i][j] (x_j - mu_j): the row's coordinates are re-read per i (L1 / L2 hits) instead of living in a
             // per-thread array of unknown size
-            const double* w = a.W + (size_t)i * d;
+            const double* w = a.W + (size_t)i * a.ldw;
             for (int j = 0; j <= i; ++j) {
                 const double x = (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
                 z = __builtin_fma(w[j], x, z);
@@ -2021,6 +2040,13 @@ __global__ __launch_bounds__(256) void pack_rows_wide_kernel(WidePackArgs a) {
     } else {
         const int lg = idx & 3, i = idx >> 2;   // f64 C-row order: crow(lg, i) == idx
         a.npack[tile * 16 + lg * 4 + i] = nv;
+    }
+    if (a.upack) {   // CKDE::cdf: standardised "x - b.e" of the row, in the norm's layout
+        double u = 0.0;
+        if (valid)
+            for (int j = 0; j < d; ++j) u = __builtin_fma(a.wu[j], (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j], u);
+        if (a.is_query) a.upack[tile * 16 + idx] = u;
+        else a.upack[tile * 16 + (idx & 3) * 4 + (idx >> 2)] = u;
     }
 }
 
@@ -2091,13 +2117,17 @@ static void launch_cdf_t(const CdfArgs& a, int KS, dim3 grid, hipStream_t st) {
         case 2: hipLaunchKernelGGL((kde_cdf_kernel<T, 2, 2, CDF>), grid, block, 0, st, a); break;
         case 3: hipLaunchKernelGGL((kde_cdf_kernel<T, 3, 2, CDF>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((kde_cdf_kernel<T, 4, 2, CDF>), grid, block, 0, st, a); break;
-        default: throw invalid_error("CKDE::cdf: more than 16 evidence variables are not supported");
+        default:
+            if constexpr (sizeof(T) == 8) hipLaunchKernelGGL((kde_cdf_kernel<T, 0, 2, CDF>), grid, block, 0, st, a);   // runtime-sized (a.KS)
+            else throw invalid_error("CKDE::cdf / sample / UCV: more than 16 dimensions take fp64 fragments");
     }
     HIP_CHECK(hipGetLastError());
 }
 
 // utrain == nullptr: weights only (sum w per split; used by CKDE::sample to locate the sampled instance).
-void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st) {
+void launch_cdf(const CdfArgs& a_in, int dtype, int KS, int nsplit, hipStream_t st) {
+    CdfArgs a = a_in;
+    a.KS = KS;
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * 2), (unsigned)nsplit);
     const bool cdf = a.utrain != nullptr;
     if (dtype == PBN_F64) { if (cdf) launch_cdf_t<double, 1>(a, KS, grid, st); else launch_cdf_t<double, 0>(a, KS, grid, st); }
@@ -2131,7 +2161,9 @@ __global__ __launch_bounds__(256) void ucv_block_sums_kernel(const double* __res
     }
 }
 
-void launch_ucv(const CdfArgs& a, int dtype, int KS, int nsplit, int64_t nq, double* block_scratch, double* dev_out2, hipStream_t st) {
+void launch_ucv(const CdfArgs& a_in, int dtype, int KS, int nsplit, int64_t nq, double* block_scratch, double* dev_out2, hipStream_t st) {
+    CdfArgs a = a_in;
+    a.KS = KS;
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * 2), (unsigned)nsplit);
     if (dtype == PBN_F64) launch_cdf_t<double, 2>(a, KS, grid, st); else launch_cdf_t<float, 2>(a, KS, grid, st);
     const int64_t nblocks = ceil_div(nq, 256);

@@ -149,11 +149,15 @@ struct WidePackArgs {
     const double* mu;      // device: d centring offsets
     const double* W;       // device: d x d row-major lower whitening matrix
     int d, KS, is_query, src_f32;
+    int dm;                // whitened coordinates written to `pack` (<= d; the CKDE::cdf fragments contract over the evidence only: d - 1)
+    int ldw;               // row stride of W (>= d: CKDE::sample packs the evidence with the leading block of the joint matrix)
     int64_t row0, n0, row1;
     const int32_t* rows;   // device gather list (nullable)
     int64_t n, ntiles;
     double* pack;          // [ntiles][KS][64]
     double* npack;         // [ntiles][16]
+    const double* wu;      // device, nullable: CKDE::cdf - u = sum_j wu[j] (x_j - mu_j) over all d columns -> upack (npack layout)
+    double* upack;
 };
 void launch_pack_wide(const WidePackArgs& a, hipStream_t st);
 // plain fp64 sweep with a runtime number of K steps: Apack / nxpack / Bpack / nypack / ntiles / nqtiles / tiles_per_split / part of `a`
@@ -178,6 +182,7 @@ struct CdfArgs {
     const void* uquery;  // [nqtiles][16]
     int64_t ntiles, nqtiles, tiles_per_split;
     double* part;        // [nsplit][nqtiles*16][4] : m, sum w, sum w*cdf, 0
+    int KS;              // number of K steps (launch_cdf / launch_ucv fill it); beyond 4 the runtime-sized kernel reads it (fp64 fragments only)
 };
 void launch_pack_classic(const PackArgs& a, int dtype, hipStream_t st);
 void launch_cdf(const CdfArgs& a, int dtype, int KS, int nsplit, hipStream_t st);

@@ -242,20 +242,27 @@ static SubBytes sub_bytes(const KdeModel& m, int64_t nsub) {
 }
 
 // wide models: columns, centring offsets and whitening matrix through the context's (lane's) scratch, in stream order
-static void fill_wide_pack(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, const int* cols, const KdeModel& m) {
-    const size_t d = (size_t)m.d;
-    auto al = [](size_t x) { return (x + 7) / 8 * 8; };
-    ctx->scratch_w.reserve(d * d + d + al(d) / 2 + 8);   // doubles: W | mu | cols (ints)
+void kde_wide_pack_args(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, const int* cols_whitened, int d_, int dm, const double* W, int ldw,
+                        const double* mu, const double* wu) {
+    const size_t d = (size_t)d_, wn = (size_t)d_ * (size_t)ldw;
+    ctx->scratch_w.reserve(wn + 2 * d + d / 2 + 8);   // doubles: W | mu | wu | cols (ints)
     double* Wd = ctx->scratch_w.p;
-    double* mud = Wd + d * d;
-    int* colsd = (int*)(mud + d);
-    std::vector<int> hc(d);
-    for (size_t i = 0; i < d; ++i) hc[i] = cols[m.perm[i]];
-    HIP_CHECK(hipMemcpyAsync(Wd, m.W.data(), d * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(mud, m.mu.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(colsd, hc.data(), d * sizeof(int), hipMemcpyHostToDevice, ctx->stream));   // pageable source: staged before the call returns
-    wa.base = t->data; wa.ld = t->ld; wa.cols = colsd; wa.mu = mud; wa.W = Wd;
-    wa.d = m.d; wa.KS = m.KS; wa.src_f32 = t->dtype == PBN_F32 ? 1 : 0;
+    double* mud = Wd + wn;
+    double* wud = mud + d;
+    int* colsd = (int*)(wud + d);
+    HIP_CHECK(hipMemcpyAsync(Wd, W, wn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));   // pageable sources: staged before the call returns
+    HIP_CHECK(hipMemcpyAsync(mud, mu, d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (wu) HIP_CHECK(hipMemcpyAsync(wud, wu, d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(colsd, cols_whitened, d * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    wa.base = t->data; wa.ld = t->ld; wa.cols = colsd; wa.mu = mud; wa.W = Wd; wa.wu = wu ? wud : nullptr;
+    wa.d = d_; wa.dm = dm; wa.ldw = ldw; wa.KS = (dm + 3) / 4; wa.src_f32 = t->dtype == PBN_F32 ? 1 : 0;
+}
+
+static void fill_wide_pack(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, const int* cols, const KdeModel& m) {
+    std::vector<int> hc((size_t)m.d);
+    for (int i = 0; i < m.d; ++i) hc[i] = cols[m.perm[i]];
+    kde_wide_pack_args(ctx, wa, t, hc.data(), m.d, m.d, m.W.data(), m.d, m.mu.data(), nullptr);
+    wa.KS = m.KS;
 }
 
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "kde_kernels.hpp"
 
 namespace pbn {
 
@@ -62,6 +63,12 @@ double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const 
                      const int32_t* dev_rows = nullptr);
 bool kde_wants_widening(double max_norm2);
 void kde_widen(KdeModel& m);
+
+// Wide packs (kde_kernels.hpp: WidePackArgs) for the consumers that keep their own fragments (CKDE::cdf / sample, UCV) when they hold more
+// than 16 dimensions: uploads the columns (already in whitening order), centring offsets, whitening matrix (d rows of stride ldw) and
+// - nullable - the cdf weights through the context's scratch, in stream order, and fills the pointers / sizes of `wa`.
+void kde_wide_pack_args(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, const int* cols_whitened, int d, int dm, const double* W, int ldw,
+                        const double* mu, const double* wu);
 
 // Whiten + pack training rows (two contiguous ranges: [row0, row0+n0) ++ [row1, row1 + n - n0)).
 // dev_rows (nullable): device gather list of m.N row ids, used instead of the ranges.

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void pick_scan_kernel(const T* __restrict__ Ap,
     if (q >= nq) return;
     const int64_t qt = q >> 4;
     const int qi = (int)(q & 15);
-    double zq[16];
+    double zq[16];   // the query's whitened coordinates, cached up to 16 dimensions (beyond: read from the fragments at every term)
     for (int i = 0; i < 16; ++i) zq[i] = i < dm ? (double)Bp[(qt * KS + (i >> 2)) * 64 + (i & 3) * 16 + qi] : 0.0;
     const double ny = (double)NYp[qt * 16 + qi];
     auto s2 = [&](int64_t r) {
@@ -69,7 +69,12 @@ __global__ __launch_bounds__(64) void pick_scan_kernel(const T* __restrict__ Ap,
         int lg, i;
         if (sizeof(T) == 8) { lg = idx & 3; i = idx >> 2; } else { lg = idx >> 2; i = idx & 3; }
         double acc = (double)Np[t * 16 + lg * 4 + i] + ny;
-        for (int k = 0; k < dm; ++k) acc = __builtin_fma((double)Ap[(t * KS + (k >> 2)) * 64 + (k & 3) * 16 + idx], zq[k], acc);
+        if (dm <= 16) {
+            for (int k = 0; k < dm; ++k) acc = __builtin_fma((double)Ap[(t * KS + (k >> 2)) * 64 + (k & 3) * 16 + idx], zq[k], acc);
+        } else {
+            for (int k = 0; k < dm; ++k)
+                acc = __builtin_fma((double)Ap[(t * KS + (k >> 2)) * 64 + (k & 3) * 16 + idx], (double)Bp[(qt * KS + (k >> 2)) * 64 + (k & 3) * 16 + qi], acc);
+        }
         return acc;
     };
     log2w0[q] = s2(0);
@@ -125,7 +130,8 @@ void ckde_sample_t(pbn_kde* k, int64_t n, int64_t stream_n, const pbn_table* ev,
         for (int64_t i = n; i < stream_n; ++i) (void)uniform(rng);  // the reference draws all of them before the normals
     }
     // query fragments of the evidence rows: whitening order = caller's evidence order, W = leading p x p block
-    const size_t es = sizeof(T);
+    const bool wide = k->cdf_wide;               // more than 16 evidence variables: fp64 fragments, runtime-sized kernels
+    const size_t es = wide ? sizeof(double) : sizeof(T);
     const int KS = k->cdf_KS;
     const int64_t tps = std::min<int64_t>(m.ntiles, 64);
     const int64_t nsplit = ceil_div(m.ntiles, tps);
@@ -140,28 +146,47 @@ void ckde_sample_t(pbn_kde* k, int64_t n, int64_t stream_n, const pbn_table* ev,
     for (int64_t q0 = 0; q0 < n; q0 += chunk) {
         const int64_t nq = std::min<int64_t>(chunk, n - q0), nqtiles = ceil_div(nq, 16);
         char* qb = ctx->scratch_q.p;
-        PackArgs pa{};
-        pa.base = ev->data; pa.ld = ev->ld; pa.d = p; pa.dm = p; pa.KS = KS;
-        for (int i = 0; i < p; ++i) {
-            pa.cols[i] = ev_cols[m.perm[i] - 1];
-            pa.mu[i] = m.mu[i];
-            for (int j = 0; j < p; ++j) pa.W[i * p + j] = m.W[(size_t)i * d + j];
+        struct { void* pack; void* npack; } pa{qb, qb + (size_t)nqtiles * KS * 64 * es};
+        if (wide) {
+            std::vector<int> hc((size_t)p);
+            for (int i = 0; i < p; ++i) hc[i] = ev_cols[m.perm[i] - 1];
+            pbn::WidePackArgs wq{};
+            // the evidence's whitening = the leading p x p block of the joint matrix (rows of stride d)
+            pbn::kde_wide_pack_args(ctx, wq, ev, hc.data(), p, p, m.W.data(), d, m.mu.data(), nullptr);
+            wq.rows = nullptr; wq.row0 = q0; wq.n0 = nq; wq.row1 = 0; wq.n = nq; wq.ntiles = nqtiles; wq.is_query = 1;
+            wq.pack = (double*)pa.pack; wq.npack = (double*)pa.npack; wq.upack = nullptr;
+            KernelTimer kt(ctx, PBN_K_PACK);
+            pbn::launch_pack_wide(wq, ctx->stream);
+        } else {
+            PackArgs pq{};
+            pq.base = ev->data; pq.ld = ev->ld; pq.d = p; pq.dm = p; pq.KS = KS;
+            for (int i = 0; i < p; ++i) {
+                pq.cols[i] = ev_cols[m.perm[i] - 1];
+                pq.mu[i] = m.mu[i];
+                for (int j = 0; j < p; ++j) pq.W[i * p + j] = m.W[(size_t)i * d + j];
+            }
+            pq.row0 = q0; pq.n0 = nq; pq.row1 = 0; pq.n = nq; pq.ntiles = nqtiles; pq.is_query = 1;
+            pq.pack = pa.pack; pq.npack = pa.npack;
+            KernelTimer kt(ctx, PBN_K_PACK);
+            launch_pack_classic(pq, m.dtype, ctx->stream);
         }
-        pa.row0 = q0; pa.n0 = nq; pa.row1 = 0; pa.n = nq; pa.ntiles = nqtiles; pa.is_query = 1;
-        pa.pack = qb; pa.npack = qb + (size_t)nqtiles * KS * 64 * es;
-        { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pa, m.dtype, ctx->stream); }
         CdfArgs ca{};
         ca.Apack = k->cA.p; ca.nxpack = k->cN.p; ca.utrain = nullptr;
         ca.Bpack = pa.pack; ca.nypack = pa.npack; ca.uquery = nullptr;
         ca.ntiles = m.ntiles; ca.nqtiles = nqtiles; ca.tiles_per_split = tps;
         ca.part = (double*)ctx->scratch_part.p;
-        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_cdf(ca, m.dtype, KS, (int)nsplit, ctx->stream); }
+        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_cdf(ca, wide ? PBN_F64 : m.dtype, KS, (int)nsplit, ctx->stream); }
         KernelTimer kt(ctx, PBN_K_FINISH);
         hipLaunchKernelGGL(pick_locate_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, ctx->stream, ca.part, (int)nsplit,
                            nqtiles, nq, d_rn.p + q0, d_split.p, d_resid.p, d_m.p);
-        hipLaunchKernelGGL(pick_scan_kernel<T>, dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, ctx->stream, (const T*)k->cA.p,
-                           (const T*)k->cN.p, (const T*)pa.pack, (const T*)pa.npack, KS, p, N, m.ntiles, tps, nq, d_split.p,
-                           d_resid.p, d_m.p, d_j.p + q0, d_w0.p + q0);
+        if (wide)
+            hipLaunchKernelGGL(pick_scan_kernel<double>, dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, ctx->stream, (const double*)k->cA.p,
+                               (const double*)k->cN.p, (const double*)pa.pack, (const double*)pa.npack, KS, p, N, m.ntiles, tps, nq, d_split.p,
+                               d_resid.p, d_m.p, d_j.p + q0, d_w0.p + q0);
+        else
+            hipLaunchKernelGGL(pick_scan_kernel<T>, dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, ctx->stream, (const T*)k->cA.p,
+                               (const T*)k->cN.p, (const T*)pa.pack, (const T*)pa.npack, KS, p, N, m.ntiles, tps, nq, d_split.p,
+                               d_resid.p, d_m.p, d_j.p + q0, d_w0.p + q0);
         HIP_CHECK(hipGetLastError());
     }
     std::vector<int32_t> jsel((size_t)n);
@@ -216,7 +241,6 @@ int pbn_ckde_sample(pbn_kde* k, int64_t n, int64_t stream_n, const pbn_table* ev
     return guarded(mu_of(k), [&] {
         if (!k) throw invalid_error("CKDE factor not fitted.");
         if (!k->ckde || !k->train) throw invalid_error("pbn_ckde_sample: the handle was not created by pbn_ckde_fit");
-        if (k->cdf_KS == 0) throw invalid_error("CKDE.sample: at most 16 evidence variables are supported");
         if (n < 0) throw invalid_error("n should be a non-negative number");
         if (n == 0) return;
         if (!out) throw invalid_error("pbn_ckde_sample: null output");

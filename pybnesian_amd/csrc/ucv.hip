@@ -43,22 +43,35 @@ struct UcvScorer {
         KdeModel m;
         kde_prepare(m, t->dtype, d, N, bw, kind, false, center.data());   // throws singular_error when H is not PD
         const int KS = (d + 3) / 4;
-        const size_t es = dtype_size(t->dtype);
+        const bool wide = d > 16;                     // beyond the templated shapes: fp64 fragments through the generic pack, runtime-sized kernel
+        const int fdt = wide ? PBN_F64 : t->dtype;
+        const size_t es = dtype_size(fdt);
         const int64_t ntiles = ceil_div(N, 16);
         const size_t frag = (size_t)ntiles * KS * 64 * es, nrm = (size_t)ntiles * 16 * es;
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         ctx->scratch_train.reserve(al(frag) + al(nrm) + 256);
         ctx->scratch_q.reserve(al(frag) + al(nrm) + 256);
-        PackArgs pa{};
-        pa.base = t->data; pa.ld = t->ld; pa.d = d; pa.dm = d; pa.KS = KS;
-        for (int i = 0; i < d; ++i) { pa.cols[i] = cols[i]; pa.mu[i] = m.mu[i]; }
-        for (int i = 0; i < d * d; ++i) pa.W[i] = m.W[i];
-        pa.row0 = row0; pa.n0 = N; pa.row1 = 0; pa.n = N; pa.ntiles = ntiles;
-        pa.is_query = 0; pa.pack = ctx->scratch_train.p; pa.npack = ctx->scratch_train.p + al(frag);
-        { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pa, t->dtype, ctx->stream); }
-        PackArgs pq = pa;
-        pq.is_query = 1; pq.pack = ctx->scratch_q.p; pq.npack = ctx->scratch_q.p + al(frag);
-        { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pq, t->dtype, ctx->stream); }
+        struct { void* pack; void* npack; } pa{ctx->scratch_train.p, ctx->scratch_train.p + al(frag)}, pq{ctx->scratch_q.p, ctx->scratch_q.p + al(frag)};
+        if (wide) {
+            WidePackArgs wa{};
+            kde_wide_pack_args(ctx, wa, t, cols.data(), d, d, m.W.data(), d, m.mu.data(), nullptr);
+            wa.rows = nullptr; wa.row0 = row0; wa.n0 = N; wa.row1 = 0; wa.n = N; wa.ntiles = ntiles; wa.upack = nullptr;
+            wa.is_query = 0; wa.pack = (double*)pa.pack; wa.npack = (double*)pa.npack;
+            { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_wide(wa, ctx->stream); }
+            wa.is_query = 1; wa.pack = (double*)pq.pack; wa.npack = (double*)pq.npack;
+            { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_wide(wa, ctx->stream); }
+        } else {
+            PackArgs pt{};
+            pt.base = t->data; pt.ld = t->ld; pt.d = d; pt.dm = d; pt.KS = KS;
+            for (int i = 0; i < d; ++i) { pt.cols[i] = cols[i]; pt.mu[i] = m.mu[i]; }
+            for (int i = 0; i < d * d; ++i) pt.W[i] = m.W[i];
+            pt.row0 = row0; pt.n0 = N; pt.row1 = 0; pt.n = N; pt.ntiles = ntiles;
+            pt.is_query = 0; pt.pack = pa.pack; pt.npack = pa.npack;
+            { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pt, t->dtype, ctx->stream); }
+            PackArgs pu = pt;
+            pu.is_query = 1; pu.pack = pq.pack; pu.npack = pq.npack;
+            { KernelTimer kt(ctx, PBN_K_PACK); launch_pack_classic(pu, t->dtype, ctx->stream); }
+        }
         const int64_t qblocks = ceil_div(ntiles, 8);
         int64_t nsplit = std::max<int64_t>(1, ceil_div((int64_t)ctx->num_cus * 16, qblocks));
         nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, ntiles / 16));
@@ -74,7 +87,7 @@ struct UcvScorer {
         ca.part = (double*)ctx->scratch_part.p;
         double* blk = (double*)ctx->scratch_misc.p;
         double* dout = blk + 2 * nblocks;
-        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_ucv(ca, t->dtype, KS, (int)nsplit, N, blk, dout, ctx->stream); }
+        { KernelTimer kt(ctx, PBN_K_SWEEP); launch_ucv(ca, fdt, KS, (int)nsplit, N, blk, dout, ctx->stream); }
         double tot[2];
         HIP_CHECK(hipMemcpyAsync(tot, dout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -177,15 +190,18 @@ UcvScorer make_scorer(pbn_ctx* ctx, const pbn_table* table, const int* cols, int
     if (!ctx || !table) throw invalid_error("pbn_ucv: null argument");
     check_cols(table, cols, d, "pbn_ucv");
     check_range(table, row0, n, "pbn_ucv");
-    if (d < 1 || d > 16) throw invalid_error("UCV: between 1 and 16 variables are supported");
+    if (d < 1) throw invalid_error("UCV: at least one variable is needed");
     if (n < 2) throw invalid_error("UCV: at least two training instances are needed");
     HIP_CHECK(hipSetDevice(ctx->device));
     UcvScorer s{ctx, table, std::vector<int>(cols, cols + d), d, row0, n, std::vector<double>(d, 0.0)};
     // centre at the pilot means (any offset is exact in the differences)
-    GramCols sel{};
-    for (int i = 0; i < d; ++i) sel.cols[i] = cols[i];
     ctx->scratch_red.reserve((size_t)table->n_cols + 8);
-    launch_pilot(table->data, table->ld, sel, d, row0, nullptr, n, table->dtype, ctx->scratch_red.p, ctx->stream);
+    for (int c0 = 0; c0 < d; c0 += 64) {   // 64 columns per pilot launch
+        GramCols sel{};
+        const int dc = std::min(64, d - c0);
+        for (int i = 0; i < dc; ++i) sel.cols[i] = cols[c0 + i];
+        launch_pilot(table->data, table->ld, sel, dc, row0, nullptr, n, table->dtype, ctx->scratch_red.p, ctx->stream);
+    }
     std::vector<double> all((size_t)table->n_cols);
     HIP_CHECK(hipMemcpyAsync(all.data(), ctx->scratch_red.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));

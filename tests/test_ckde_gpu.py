@@ -150,9 +150,10 @@ def test_ckde_cdf_nulls_and_order(pbn, golden):
     assert not hasattr(kde, "cdf")
 
 
-@pytest.mark.parametrize("p", [0, 1, 3, 4, 5, 9, 13])
+@pytest.mark.parametrize("p", [0, 1, 3, 4, 5, 9, 13, 16, 17, 20, 33])
 def test_ckde_cdf_oracle_parity_random(pbn, oracle, p):
-    """Ragged sizes, KS = 1..4, evidence outliers (weights underflow in the reference's exp(logl) form only when ALL
+    """Ragged sizes, KS = 1..4 and - beyond 16 evidence variables, where the reference's cdf loops on (CKDE.hpp:509-735) - the
+    runtime-sized fp64 kernels (p = 17, 20, 33); evidence outliers (weights underflow in the reference's exp(logl) form only when ALL
     of them do; here the offset keeps the ratio defined) and variable outliers (cdf -> 0 / 1)."""
     rng = np.random.default_rng(90 + p)
     n, m = 1237, 77

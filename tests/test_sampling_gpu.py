@@ -41,7 +41,7 @@ def test_ckde_sample_reference_cases(pbn, golden):
             assert not np.array_equal(s.to_numpy(), cpd.sample(n, ev, 1).to_numpy())
 
 
-@pytest.mark.parametrize("p", [0, 1, 2, 5])
+@pytest.mark.parametrize("p", [0, 1, 2, 5, 16, 20, 33])     # beyond 16 evidence variables: the runtime-sized fp64 weight kernels
 def test_ckde_sample_matches_oracle_f64(pbn, oracle, p):
     rng = np.random.default_rng(30 + p)
     N, n = 1500, 700

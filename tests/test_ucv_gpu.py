@@ -24,7 +24,7 @@ def table(n, d, seed, dtype="float64"):
     return pd.DataFrame(x.astype(dtype), columns=[f"v{i}" for i in range(d)])
 
 
-@pytest.mark.parametrize("n,d", [(257, 1), (700, 2), (1203, 4), (500, 7)])
+@pytest.mark.parametrize("n,d", [(257, 1), (700, 2), (1203, 4), (500, 7), (611, 16), (903, 17), (700, 24)])   # d > 16: runtime-sized fp64 kernel
 def test_ucv_score_matches_oracle(pbn, n, d):
     from oracle import oracle
 
