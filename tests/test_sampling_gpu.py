@@ -53,7 +53,10 @@ def test_ckde_sample_matches_oracle_f64(pbn, oracle, p):
     cpd.fit(train)
     evq = pd.DataFrame(ev[N:], columns=names[1:]) if p else None
     if p:
-        evq.iloc[:4] = 6.0          # far evidence: a handful of training rows carry all the weight
+        # far evidence: a handful of training rows carry all the weight.  (With many evidence variables 6.0 in EVERY coordinate puts
+        # all weights below the smallest double: the reference's exp(logl) form then divides 0 by 0 and returns row N - 1, the
+        # oracle restates that, the device's offset form still finds the nearest rows - a degenerate input, kept out of the comparison)
+        evq.iloc[:4] = 6.0 if p <= 5 else 1.2
     for seed in (0, 123):
         got = cpd.sample(n, evq, seed).to_numpy()
         want, idx = oracle.ckde_sample(train.to_numpy(), cpd.bandwidth, evq.to_numpy() if p else None, n, seed)
