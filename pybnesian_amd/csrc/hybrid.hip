@@ -444,7 +444,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         for (int i = 0; i < d; ++i) jperm[i] = i < vpos ? i + 1 : (i == vpos ? 0 : i);
         for (int i = 0; i < d; ++i) jcols[i] = cols[jperm[i]];
     }
-    if (d > 17) throw invalid_error("pbn_score_batch: too many continuous parents");
+    if (d > 64) throw invalid_error("pbn_score_batch: more than 63 continuous parents in one hybrid candidate (the per-cell Gram takes 64 columns)");
     pbn_ctx* ctx = sd->ctx;
     const pbn_table* t = sd->table();
     std::vector<Region> regions = regions_of(sd, kind);

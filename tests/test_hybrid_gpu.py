@@ -255,3 +255,25 @@ def test_hybrid_ckde_parts_add_up_to_the_local_score(pbn, dtype, kind):
         assert got == want, (world, got, want)
     with pytest.raises(ValueError, match="discrete parents"):
         ref._batch_parts(net, [0], [_lib.PBN_NODE_CKDE], [0, 1], [1], code, 0, 2)
+
+
+@pytest.mark.parametrize("node_type", ["lg", "ckde"])
+def test_hybrid_candidate_with_20_continuous_parents(pbn, oracle, node_type):
+    """A child of one discrete and 20 continuous parents (DiscreteAdaptator slices over 21 continuous columns): the per-cell Gram
+    of more than 8 columns and, for CKDE, the 17-32-dimension sweeps - the reference has no limit here
+    (factors/discrete/DiscreteAdaptator.hpp:201-348); the library's was 16 continuous parents until round 4."""
+    rng = np.random.default_rng(2)
+    n, p = 2400, 20
+    A = rng.integers(0, 2, size=n)
+    ev = rng.normal(size=(n, p)) @ (np.eye(p) + np.tril(rng.uniform(-0.3, 0.3, (p, p)), -1)).T + 0.8 * A[:, None]
+    y = 0.2 * ev.sum(axis=1) + np.where(A == 0, -1.0, 1.5) + rng.normal(scale=0.6, size=n)
+    names = ["y"] + [f"e{i}" for i in range(p)]
+    df = pd.DataFrame(np.column_stack([y, ev]), columns=names)
+    df["A"] = pd.Categorical.from_codes(A, ["a0", "a1"])
+    net = pbn.SemiparametricBN(list(df.columns), [], [("A", pbn.DiscreteFactorType())])
+    nt = pbn.LinearGaussianCPDType() if node_type == "lg" else pbn.CKDEType()
+    ho = pbn.HoldoutLikelihood(df, 0.25, 3)
+    tr, te = oracle.holdout_split(n, 0.25, 3)
+    want = oracle.adaptator_fit_slogl(df[names].to_numpy(), [A.astype(np.int32)], [2], tr, te, node_type)
+    got = ho.local_score_node_type(net, nt, "y", names[1:] + ["A"])
+    assert close(got, want), (got, want)
