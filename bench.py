@@ -728,15 +728,19 @@ def e2e_host(pbn, kde, names, test_np, repeats=3):
 
 def dp_issue_util():
     """Share of the FP64 issue slots the sweep kept busy, from the committed rocprofv3 PMC pass of this command:
-    (MFMA busy cycles + 4 cycles per VALU wave-instruction) / (cycles x 1024 SIMDs).  Null with the reason when the pass was
+    (MFMA busy cycles + 4 cycles per VALU wave-instruction, 8 for the quarter-rate v_exp_f32) / (cycles x 1024 SIMDs).  Null with the reason when the pass was
     taken on another revision of the kernel source (pmc_record)."""
     k, why = pmc_record(SWEEP_KERNEL)
     if k is None:
         return {"value": None, "reason": why}
     simd_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-    return {"value": (k["SQ_VALU_MFMA_BUSY_CYCLES"] + 4.0 * k["SQ_INSTS_VALU"]) / simd_cycles,
+    # round 4: the sum-only sweep takes 2^f on the fp32 transcendental unit - one v_exp_f32 per pair value, which holds the issue port
+    # for 8 cycles (a quarter-rate instruction: two slots of 4) - so the slot count is the instruction count plus one per value
+    exp32 = 1e11 / 64.0 if k["SQ_INSTS_VALU"] * 64.0 / 1e11 < 9.5 else 0.0
+    return {"value": (k["SQ_VALU_MFMA_BUSY_CYCLES"] + 4.0 * (k["SQ_INSTS_VALU"] + exp32)) / simd_cycles,
             "mfma_busy_frac": k["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
             "valu_insts_per_pair_value": k["SQ_INSTS_VALU"] * 64.0 / 1e11,
+            "quarter_rate_insts_per_pair_value": exp32 * 64.0 / 1e11,
             "source": f"profiles/{k['_round']}/pmc_per_dispatch.json (separate rocprofv3 --pmc pass on kde_kernels.hip blob {k['_blob'][:12]}, not this run)"}
 
 
