@@ -523,10 +523,20 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     std::vector<Slice> slices;
     std::vector<std::vector<int>> slot_key;
     dev_buf<double> dsums;
+    // fp32 tables: behind the sums, one slot per sum for |z|^2 of the farthest whitened training row of its evaluation (reported by the
+    // pack kernels) - an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used, and its
+    // continuous column set goes to fp64 fragments from then on (pbn_scoredata::widen_sets; scoring.hip does the same for plain terms)
+    const bool f32 = sd->dtype == PBN_F32;
+    const size_t max_slots = (size_t)units * g.nc * 2 + 1;
+    struct Redo { KdeModel m; std::vector<int> v; int64_t r0, n0, r1, te0, nte; };
+    std::vector<Redo> redo_info;
     if (node_type == PBN_NODE_CKDE) {
-        dsums.alloc((size_t)units * g.nc * 2 + 1);
-        HIP_CHECK(hipMemsetAsync(dsums.p, 0, ((size_t)units * g.nc * 2 + 1) * sizeof(double), ctx->stream));
+        dsums.alloc(2 * max_slots);
+        HIP_CHECK(hipMemsetAsync(dsums.p, 0, 2 * max_slots * sizeof(double), ctx->stream));
+        if (f32) redo_info.resize(max_slots);
     }
+    double* const dmax = (f32 && node_type == PBN_NODE_CKDE) ? dsums.p + max_slots : nullptr;
+    auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
     // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
     const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
     if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
@@ -737,19 +747,22 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 }
                 term.slot = (int)slot_key.size();
                 slot_key.push_back(key);
-                if (elig[(size_t)c * 2 + which]) {   // evaluated with the candidate's other grouped slices, after the loops
+                const bool w64 = f32 && sd->widen_sets.count(set_key(v, nv)) != 0;   // a set already known to need fp64 fragments
+                if (f32 && !w64) redo_info[(size_t)term.slot] = Redo{m, std::vector<int>(v, v + nv), tr_row0, tr_n0, tr_row1, te0, te->N};
+                if (elig[(size_t)c * 2 + which] && !w64) {   // evaluated with the candidate's other grouped slices, after the loops
                     group_unit(c, u, which, m, v, colidx, nv, tr->N, te->N, term.slot);
                     ++sd->kde_sweeps;
                     continue;
                 }
-                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, false, tr->N);
+                if (w64) kde_widen(m);
+                const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, false, tr->N);
                 LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
                 char* arena = ctx->scratch_train.p;
                 m.Apack = arena;
                 m.nxpack = arena + align(pb.apack);
                 m.Axpack = nullptr;
-                kde_pack_train(ctx, m, t, v, tr_row0, tr_n0, tr_row1, g.rows.p, /*prune=*/true);
+                kde_pack_train(ctx, m, t, v, tr_row0, tr_n0, tr_row1, g.rows.p, /*prune=*/true, dmax ? dmax + term.slot : nullptr);
                 kde_eval_enqueue(ctx, m, t, v, te0, te->N, nullptr, dsums.p + term.slot, g.rows.p);
                 ++sd->kde_sweeps;
             }
@@ -763,13 +776,38 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             gb.pools[pi].nunits = (int32_t)pool_units[pi].size();
             gb.units.insert(gb.units.end(), pool_units[pi].begin(), pool_units[pi].end());
         }
-        kde_group_run(ctx, t, gb, dsums.p);   // on the context's own stream, next to the lanes' per-slice chains
+        kde_group_run(ctx, t, gb, dsums.p, dmax);   // on the context's own stream, next to the lanes' per-slice chains
     }
     if (node_type == PBN_NODE_CKDE && !slices.empty()) {
-        std::vector<double> hs(std::max<size_t>(1, slot_key.size()));
+        const size_t ns = slot_key.size();
+        std::vector<double> hs(std::max<size_t>(1, ns)), hmax(f32 ? ns : 0);
         if (lanes > 1) ctx->sync_lanes(lanes - 1);
-        if (!slot_key.empty()) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, slot_key.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (ns) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (f32 && ns) HIP_CHECK(hipMemcpyAsync(hmax.data(), dmax, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (f32) {   // check-after (see above): flagged evaluations once more, on fp64 fragments, through the per-slice chain
+            bool any = false;
+            for (size_t i = 0; i < ns; ++i) {
+                if (!kde_wants_widening(hmax[i]) || redo_info[i].v.empty()) continue;
+                Redo& r = redo_info[i];
+                sd->widen_sets.insert(set_key(r.v.data(), (int)r.v.size()));
+                kde_widen(r.m);
+                const KdePackBytes pb = kde_pack_bytes(r.m.fdtype(), r.m.dm, false, r.m.N);
+                ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
+                r.m.Apack = ctx->scratch_train.p;
+                r.m.nxpack = ctx->scratch_train.p + align(pb.apack);
+                r.m.Axpack = nullptr;
+                HIP_CHECK(hipMemsetAsync(dsums.p + i, 0, sizeof(double), ctx->stream));
+                kde_pack_train(ctx, r.m, t, r.v.data(), r.r0, r.n0, r.r1, g.rows.p, /*prune=*/true);
+                kde_eval_enqueue(ctx, r.m, t, r.v.data(), r.te0, r.nte, nullptr, dsums.p + i, g.rows.p);
+                ++sd->kde_sweeps;
+                any = true;
+            }
+            if (any) {
+                HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            }
+        }
         ctx->drop_staged();
         for (size_t i = 0; i < slot_key.size(); ++i) sd->kde_cache[slot_key[i]] = hs[i];
         // per-part sums in slice order, then the parts in part order: what a job with one process per GPU adds up, too

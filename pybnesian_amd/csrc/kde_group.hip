@@ -48,6 +48,7 @@ struct GDev {   // argument block of the block-wise kernels
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     int ring_nb;              // > 0: fp64 table with a RING pass - also write bf16x3 fragments (ring_nb MFMAs) of every row
+    unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
 };
 
 __device__ __forceinline__ int region_of(const GPool& P, int pp) {
@@ -167,7 +168,8 @@ __device__ __forceinline__ void store_bf16_row(gbf8* pack, int NB, int tile, int
 
 // whitened coordinates of one row, fragment stores shared by the two pack kernels (fp64 classic fragments, kde_kernels.hip
 // pack_rows_kernel: training side norms in C-row order + weights 2^norm, query side norms by row; fp32: bf16x3 fragments)
-__device__ __forceinline__ void pack_store(const GDev& g, const GUnit& U, const double* x, int d, int dest, bool query, int32_t tpos) {
+// returns |z|^2 of the row (bf16 chunks; 0 otherwise)
+__device__ __forceinline__ double pack_store(const GDev& g, const GUnit& U, const double* x, int d, int dest, bool query, int32_t tpos) {
     char* arena = g.arena;
     const int KS = g.KS;
     const int tile = dest >> 4, idx = dest & 15;
@@ -189,7 +191,7 @@ __device__ __forceinline__ void pack_store(const GDev& g, const GUnit& U, const 
         const float nv = (float)(-0.5 * nrm);
         store_bf16_row((gbf8*)(arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, p1, p2, p3, nv, query);
         if (query) ((float*)(arena + U.ny))[(int64_t)tile * 16 + idx] = nv;
-        return;
+        return nrm;
     }
     double* pack = (double*)(arena + (query ? U.bpack : U.apack));
     double nrm = 0.0;
@@ -224,6 +226,7 @@ __device__ __forceinline__ void pack_store(const GDev& g, const GUnit& U, const 
         np[(int64_t)tile * 16 + lg * 4 + i] = nv;
         np[(int64_t)U.ntiles * 16 + (int64_t)tile * 16 + lg * 4 + i] = nv < -1000.0 ? (double)NAN : exp2(nv);   // weights of the WMUL sweep
     }
+    return 0.0;
 }
 
 // ---- training side: grid (flat blocks, units per pool).  A unit's training rows are the elements of its regions, in the pool's
@@ -247,9 +250,19 @@ __global__ __launch_bounds__(GB) void group_pack_train_kernel(GDev g) {
     if (lane == 0) wcount[wave] = __builtin_popcountll(b);
     __syncthreads();
     for (int w = 0; w < wave; ++w) base += wcount[w];
-    if (!in) return;
-    const int dest = base + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-    pack_store(g, U, g.xs + (P.elem0 + i) * g.xstride, P.d, dest, false, 0);
+    double z2 = 0.0;
+    if (in) {
+        const int dest = base + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+        z2 = pack_store(g, U, g.xs + (P.elem0 + i) * g.xstride, P.d, dest, false, 0);
+    }
+    if (g.out_max) {   // the unit's farthest whitened training row: one atomic per wave
+        if (!(z2 == z2)) z2 = INFINITY;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(z2, off);
+            z2 = o > z2 ? o : z2;
+        }
+        if (lane == 0 && z2 > 0.0) atomicMax(g.out_max + U.sum_slot, (unsigned long long)__double_as_longlong(z2));
+    }
 }
 
 // ---- query side + all padding: grid (flat blocks).  Every element is a test row of at most one unit of its pool (the unit whose
@@ -459,7 +472,8 @@ int env_int(const char* name, int dflt) {
 size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 // one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
-void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out) {
+void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out,
+               double* dev_out_max, bool force_f64) {
     const int np = (int)(p1 - p0);
     // ---- layout ----------------------------------------------------------------------------------------------------------
     std::vector<GPool> pools(np);
@@ -487,7 +501,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         pools[k] = P;
     }
     const int nu = (int)units.size();
-    const bool bf16 = use_bf16x3(t->dtype);
+    const int fdt = force_f64 ? PBN_F64 : t->dtype;   // type of the fragments and of the sweep (fp64 on float columns for widened units)
+    const bool bf16 = use_bf16x3(fdt);
     const int d0 = pools[0].d, KS = bf16 ? bf16x3_mfmas(d0) : (d0 + 3) / 4;
     const bool fold = d0 % 4 != 0;
     const size_t frag_b = bf16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
@@ -497,7 +512,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     // spread over as many workgroups as the main pass, each paying its prologue for a few tiles: hand-over at 2^-32 cv64 3.56 -> 3.68 s
     // (slower), at 2^-24 3.56 -> 3.33 s and C3's first iteration 16.05 -> 15.58 s.  Kept as a switch, not as the default.
     static const double ring_near_env = [] { const char* e = std::getenv("PBN_RING_NEAR"); return (e && *e) ? std::atof(e) : 0.0; }();
-    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(t->dtype, 0, true) - 8.0;
+    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(fdt, 0, true) - 8.0;
     const int NB16 = ring ? bf16x3_mfmas(d0) : 0;
     const size_t frag16_b = (size_t)NB16 * 64 * 16;
     static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
@@ -564,7 +579,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
         s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
-        s.margin = (float)prune_margin(t->dtype, U.N, /*the engine's terms are sums*/ true); s.pad_ = 0.f;
+        s.margin = (float)prune_margin(fdt, U.N, /*the engine's terms are sums*/ true); s.pad_ = 0.f;
         GSweepUnit& r = hs[nu + u];   // the RING pass: the bf16 fragments of the same rows, partials behind the fp64 pass's
         r = s;
         if (ring) {
@@ -598,6 +613,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     static const int sum_bound = env_int("PBN_GROUP_SUM_BOUND", 1);
     g.use_sum_bound = sum_bound;
     g.bf16 = bf16 ? 1 : 0; g.KS = KS; g.ring_nb = NB16;
+    g.out_max = bf16 ? (unsigned long long*)dev_out_max : nullptr;
     static const int window = std::max(1, env_int("PBN_GROUP_WINDOW", PBN_GROUP_WINDOW));
     g.window = window;
 
@@ -629,12 +645,12 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         sa.prune_margin = ring ? ring_near_env : 0.0;   // the units' own margins; with a RING pass the fp64 kernel stops at the hand-over radius
         static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
         sa.group_masks = ring ? 1 : gmasks;             // (the two passes split the pairs by the per-group test)
-        launch_sweep_grouped(sa, t->dtype, KS, st);
+        launch_sweep_grouped(sa, fdt, KS, st);
         if (ring) {
             GSweepArgs ra = sa;
             ra.units = (const GSweepUnit*)(arena + o_sweep) + nu;
             ra.ring = 1; ra.prune_margin = 0.0; ra.ring_near = ring_near_env;
-            launch_sweep_grouped(ra, t->dtype, NB16, st);
+            launch_sweep_grouped(ra, fdt, NB16, st);
         }
     }
     {
@@ -668,9 +684,9 @@ bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
            R <= PBN_GROUP_MAX_R && kde_prune_applies(dtype, d, n_min);
 }
 
-void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums) {
+void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max, bool force_f64) {
     if (b.pools.empty()) return;
-    if (t->dtype != PBN_F64 && !use_bf16x3(t->dtype)) throw invalid_error("grouped KDE evaluation: fp64 tables, or fp32 tables on the bf16 matrix cores");
+    if (!force_f64 && t->dtype != PBN_F64 && !use_bf16x3(t->dtype)) throw invalid_error("grouped KDE evaluation: fp64 tables, or fp32 tables on the bf16 matrix cores");
     HIP_CHECK(hipSetDevice(ctx->device));
     for (const GPool& P : b.pools) {
         if (P.d < 1 || P.d > PBN_GROUP_MAX_D || P.kd < 1 || P.kd > PBN_PRUNE_PD || P.kd > P.d || P.R < 1 || P.R > PBN_GROUP_MAX_R || P.n < 1)
@@ -683,7 +699,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     // pools of one sweep shape together (KS, norm in a K slot or as weights), larger sets first
     std::vector<int> order(b.pools.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    const bool bf16 = use_bf16x3(t->dtype);
+    const bool bf16 = !force_f64 && use_bf16x3(t->dtype);
     auto variant = [&](int i) { const int d = b.pools[i].d; return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
     const size_t budget = (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 4096)) << 20;
@@ -700,7 +716,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
             elems += b.pools[order[p1]].n;
             ++p1;
         }
-        run_chunk(ctx, t, b, order, p0, p1, dev_out_sums);
+        run_chunk(ctx, t, b, order, p0, p1, dev_out_sums, dev_out_max, force_f64);
         p0 = p1;
     }
 }

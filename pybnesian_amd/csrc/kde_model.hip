@@ -266,7 +266,7 @@ static void fill_wide_pack(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, c
 }
 
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
-                    int64_t row1, const int32_t* dev_rows, bool prune) {
+                    int64_t row1, const int32_t* dev_rows, bool prune, double* dev_max_norm2) {
     if (m.wide) {
         if (m.cond) throw invalid_error("KDE: a conditional model of more than 32 evidence variables is evaluated as joint - marginal");
         WidePackArgs wa{};
@@ -283,6 +283,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     pa.rows = dev_rows;
     pa.row0 = row0; pa.n0 = n0; pa.row1 = row1; pa.n = m.N; pa.ntiles = m.ntiles;
     pa.is_query = 0;
+    if (dev_max_norm2 && m.dtype == PBN_F32 && !m.widen) launch_max_norm2(pa, t->dtype, dev_max_norm2, ctx->stream);
     m.prune = false;
     if (prune && kde_prune_applies(m.fdtype(), m.dm, m.N)) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };

@@ -76,8 +76,10 @@ void kde_wide_pack_args(pbn_ctx* ctx, WidePackArgs& wa, const pbn_table* t, cons
 // otherwise ignored).  The training order inside the pack is then NOT the table order: only for consumers that need
 // sums over the training rows (the score engine, logl / slogl of fitted handles); CKDE::sample / cdf keep their own
 // table-ordered fragments.  Queries are evaluated in Morton order too and scattered back by the finish kernel.
+// dev_max_norm2 (nullable; fp32 models on fp32 fragments only): receives |z|^2 of the farthest whitened training row as the bits of a
+// non-negative double (atomic max into a slot the caller zeroed) - the score engine's check-after of kde_wants_widening().
 void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0,
-                    int64_t row1, const int32_t* dev_rows = nullptr, bool prune = false);
+                    int64_t row1, const int32_t* dev_rows = nullptr, bool prune = false, double* dev_max_norm2 = nullptr);
 // Whether kde_pack_train(prune = true) would build the Morton-ordered pack for a model of `dm` main dimensions and n rows.
 bool kde_prune_applies(int dtype, int dm, int64_t n);
 // Copies the pruning tables of a pruned pack out of the context arena into `store` (handles that outlive the call).

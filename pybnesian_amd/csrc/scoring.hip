@@ -983,8 +983,14 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 }
             }
             const size_t nslots = slot_key.size();
-            dev_buf<double> dsums(std::max<size_t>(1, nslots));
-            HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, nslots) * sizeof(double), ctx->stream));
+            // fp32 tables: behind the sums, one slot per sum for |z|^2 of the evaluation's farthest whitened training row (the pack
+            // kernels report it): an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used,
+            // and its variable set goes to fp64 fragments from then on (pbn_scoredata::widen_sets, KdeModel::widen)
+            const bool f32 = sd->dtype == PBN_F32;
+            dev_buf<double> dsums(std::max<size_t>(1, 2 * nslots));
+            HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, 2 * nslots) * sizeof(double), ctx->stream));
+            double* const dmax = f32 ? dsums.p + nslots : nullptr;
+            auto set_key = [](const std::vector<int>& use) { std::vector<int> k(use); std::sort(k.begin(), k.end()); return k; };
             auto align = [](size_t x) { return (x + 255) / 256 * 256; };
             // host side of one evaluation: columns, training moments of the region, bandwidth, whitening (KdeModel without packs)
             struct Prep { KdeModel m; std::vector<int> use; int64_t row0, n0, row1, te0, te_n, ntrain; };
@@ -1048,9 +1054,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             };
             // ---- grouped evaluation (kde_group.hip): the plain terms whose shape qualifies are collected into pools - one per
             // variable set, its units the regions asked for - and evaluated by ONE launch chain per batch of pools ---------------
-            GroupBatch gb;
-            std::vector<std::vector<GUnit>> pool_units;
-            std::map<std::vector<int>, int> pool_of;                      // [m, sorted columns...] -> pool
+            struct Batch { GroupBatch gb; std::vector<std::vector<GUnit>> pool_units; std::map<std::vector<int>, int> pool_of; };   // pool_of: [m, sorted columns...] -> pool
+            Batch bt[2];                                                  // [1]: fp32 table, variable sets on fp64 fragments (widen_sets)
             std::vector<char> grouped(work.size(), 0);
             const int R = cv ? sd->k : 2;
             const int64_t min_train = cv ? sd->n_cv - (sd->limits[1] - sd->limits[0]) : sd->n_cv;
@@ -1065,12 +1070,15 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 prepare(w, pr);
                 std::vector<int> key(pr.use);
                 std::sort(key.begin(), key.end());
+                Batch& B = bt[(f32 && sd->widen_sets.count(key)) ? 1 : 0];
+                GroupBatch& gb = B.gb;
+                std::vector<std::vector<GUnit>>& pool_units = B.pool_units;
                 key.insert(key.begin(), own_term ? p + 2 : p + 1);
-                auto it = pool_of.find(key);
+                auto it = B.pool_of.find(key);
                 int pi;
-                if (it == pool_of.end()) {
+                if (it == B.pool_of.end()) {
                     pi = (int)gb.pools.size();
-                    pool_of[key] = pi;
+                    B.pool_of[key] = pi;
                     GPool P{};
                     P.rows = nullptr; P.row_base = 0;
                     P.n = (int32_t)(cv ? sd->n_cv : sd->n_cv + sd->n_hold);
@@ -1109,41 +1117,72 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 pool_units[pi].push_back(U);
                 grouped[wi] = 1;
             }
-            for (size_t pi = 0; pi < gb.pools.size(); ++pi) {
-                gb.pools[pi].unit0 = (int32_t)gb.units.size();
-                gb.pools[pi].nunits = (int32_t)pool_units[pi].size();
-                gb.units.insert(gb.units.end(), pool_units[pi].begin(), pool_units[pi].end());
-            }
+            for (Batch& B : bt)
+                for (size_t pi = 0; pi < B.gb.pools.size(); ++pi) {
+                    B.gb.pools[pi].unit0 = (int32_t)B.gb.units.size();
+                    B.gb.pools[pi].nunits = (int32_t)B.pool_units[pi].size();
+                    B.gb.units.insert(B.gb.units.end(), B.pool_units[pi].begin(), B.pool_units[pi].end());
+                }
             size_t n_legacy = 0;
             for (char gflag : grouped) n_legacy += gflag ? 0 : 1;
             // independent evaluations alternate between the context's two issue lanes (common.hpp)
             const int lanes = (n_legacy > 1 && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
             if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
-            if (!gb.pools.empty()) kde_group_run(ctx, t, gb, dsums.p);
-            size_t wi = 0, li = 0;
-            for (const Work& w : work) {
-                if (grouped[wi++]) continue;
-                LaneSwitch lane(ctx, (int)(li++ % (size_t)lanes));
+            if (!bt[0].gb.pools.empty()) kde_group_run(ctx, t, bt[0].gb, dsums.p, dmax, false);
+            if (!bt[1].gb.pools.empty()) kde_group_run(ctx, t, bt[1].gb, dsums.p, nullptr, /*force_f64=*/true);
+            // one evaluation through its own launch chain (shapes the grouped path does not take; the redo of a flagged evaluation)
+            auto run_single = [&](const Work& w, bool force64) {
                 Prep pr;
                 prepare(w, pr);
                 KdeModel& m = pr.m;
                 const int* use_cols = pr.use.data();
-                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, m.N);
+                const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
+                if (f32 && (force64 || sd->widen_sets.count(set_key(pr.use)))) kde_widen(m);
+                const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, m.cond, m.N);
                 ctx->scratch_train.reserve(pb.apack + pb.nxpack + pb.axpack + 768);
                 char* base = ctx->scratch_train.p;
                 m.Apack = base;
                 m.nxpack = base + align(pb.apack);
                 m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
-                kde_pack_train(ctx, m, t, use_cols, pr.row0, pr.n0, pr.row1, nullptr, /*prune=*/true);
+                kde_pack_train(ctx, m, t, use_cols, pr.row0, pr.n0, pr.row1, nullptr, /*prune=*/true, dmax ? dmax + slot : nullptr);
                 if (w.mode == 0 && m.cond)
                     kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + w.slot_j, nullptr, dsums.p + w.slot_m);
                 else
-                    kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + (w.mode == 2 ? w.slot_m : w.slot_j));
+                    kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + slot);
+            };
+            size_t wi = 0, li = 0;
+            for (const Work& w : work) {
+                if (grouped[wi++]) continue;
+                LaneSwitch lane(ctx, (int)(li++ % (size_t)lanes));
+                run_single(w, false);
             }
-            std::vector<double> hs(std::max<size_t>(1, nslots));
+            std::vector<double> hs(std::max<size_t>(1, 2 * nslots));
             if (lanes > 1) ctx->sync_lanes(lanes - 1);
-            if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, (f32 ? 2 : 1) * nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (f32 && nslots) {
+                // check-after: evaluations whose training rows reach beyond what fp32 fragments hold (2^-24 max|z|^2 above the threshold of
+                // kde_wants_widening) are redone on fp64 fragments, their variable sets remembered
+                std::vector<const Work*> redo;
+                for (const Work& w : work) {
+                    const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
+                    if (kde_wants_widening(hs[nslots + (size_t)slot])) redo.push_back(&w);
+                }
+                if (!redo.empty()) {
+                    for (const Work* w : redo) {
+                        Prep pr;
+                        prepare(*w, pr);
+                        sd->widen_sets.insert(set_key(pr.use));
+                        const int slot = w->mode == 2 ? w->slot_m : w->slot_j;
+                        HIP_CHECK(hipMemsetAsync(dsums.p + slot, 0, sizeof(double), ctx->stream));
+                        if (w->mode == 0) HIP_CHECK(hipMemsetAsync(dsums.p + w->slot_m, 0, sizeof(double), ctx->stream));
+                        run_single(*w, true);
+                    }
+                    HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    sd->kde_sweeps += (int64_t)redo.size();
+                }
+            }
             ctx->drop_staged();
             for (size_t i = 0; i < nslots; ++i) sd->kde_cache[slot_key[i]] = hs[i];
             sd->kde_sweeps += (int64_t)work.size();

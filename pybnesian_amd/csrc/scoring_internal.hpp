@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <limits>
 #include <map>
+#include <set>
 #include <memory>
 #include <vector>
 
@@ -57,6 +58,10 @@ struct pbn_scoredata {
     // totals of A(S, m) over the test regions of a score kind, keyed by [kind, m, sorted columns...]: installed by pbn_score_terms_put (values another
     // rank computed) and preferred over kde_cache, so that every rank of a job assembles a candidate from the very same doubles
     std::map<std::vector<int>, double> term_total;
+    // fp32 tables: variable sets ([sorted continuous columns...]) one of whose evaluations met a whitened training row so far from the
+    // centre that the fp32 Gram form loses it (kde_wants_widening on the max-norm the pack kernels report): such sets are evaluated on
+    // fp64 fragments from then on (KdeModel::widen; the evaluation that found out is redone that way before its value is used)
+    std::set<std::vector<int>> widen_sets;
     int64_t kde_sweeps = 0;
     // hybrid likelihood local scores by [kind, node type, variable, sorted parents...] (see pbn_score_batch)
     std::map<std::vector<int>, double> score_memo;

@@ -212,3 +212,45 @@ def test_grouped_hybrid_slices_match_per_slice_chains(pbn, monkeypatch, dtype, t
     monkeypatch.delenv("PBN_SCORE_GROUPED")
     assert np.all(np.isfinite(res["1"]))
     assert np.allclose(res["1"], res["0"], rtol=tol, atol=0), (res["1"] - res["0"]) / res["0"]
+
+
+def test_fp32_engine_redoes_far_out_sets_on_fp64_fragments(pbn, oracle, monkeypatch):
+    """fp32 tables in the SCORE ENGINE: the pack kernels report |z|^2 of every evaluation's farthest whitened training row; an
+    evaluation beyond what the fp32 Gram form holds (2^-24 |z|^2 > 5e-4: here a small cluster 40 sigma from the bulk) is redone on
+    fp64 fragments before its value is used and its variable set stays on them (pbn_scoredata::widen_sets).  Plain CKDE terms
+    (CVLikelihood) and hybrid slices (discrete parent), against the oracle in fp64 arithmetic on the same float data; with the
+    check switched off the error of the fp32 fragments on the cluster's rows is what is left."""
+    rng = np.random.default_rng(123)
+    n, far = 60_000, 60
+    a = rng.normal(size=n)
+    b = np.tanh(a) + 0.5 * rng.normal(size=n)
+    idx = rng.choice(n, size=far, replace=False)
+    a[idx] = 400.0 + 0.3 * rng.normal(size=far)
+    b[idx] = -250.0 + 0.3 * rng.normal(size=far)
+    D = rng.integers(0, 2, size=n)
+    df = pd.DataFrame({"a": a, "b": b}).astype(np.float32)
+    df["D"] = pd.Categorical.from_codes(D, ["d0", "d1"])
+    net = pbn.SemiparametricBN(list(df.columns), [], [("D", pbn.DiscreteFactorType())])
+    data64 = df[["b", "a"]].to_numpy().astype(np.float64)
+    want_plain = oracle.cv_likelihood(data64, "ckde", 3, 2)
+    tr, te = oracle.holdout_split(n, 0.2, 2)
+    want_hyb = oracle.adaptator_fit_slogl(data64, [D.astype(np.int32)], [2], tr, te, "ckde")
+
+    def run():
+        cv = pbn.CVLikelihood(df, 3, 2)
+        ho = pbn.HoldoutLikelihood(df, 0.2, 2)
+        plain = cv.local_score_node_type(net, pbn.CKDEType(), "b", ["a"])
+        hyb = ho.local_score_node_type(net, pbn.CKDEType(), "b", ["a", "D"])
+        again = cv.local_score_node_type(net, pbn.CKDEType(), "a", ["b"])      # the joint set {a, b} is known by now: straight to fp64
+        return plain, hyb, again, cv.kde_cache_stats()[1]
+
+    plain, hyb, again, sweeps = run()
+    assert abs(plain - want_plain) <= 2e-6 * abs(want_plain), (plain, want_plain)
+    assert abs(hyb - want_hyb) <= 2e-6 * abs(want_hyb), (hyb, want_hyb)
+    want_again = oracle.cv_likelihood(data64[:, ::-1].copy(), "ckde", 3, 2)
+    assert abs(again - want_again) <= 2e-6 * abs(want_again)
+    monkeypatch.setenv("PBN_F32_WIDEN", "0")
+    plain32, hyb32, _, sweeps32 = run()
+    assert sweeps > sweeps32                                   # the flagged evaluations were made twice
+    assert abs(plain32 - want_plain) > 5 * abs(plain - want_plain) and abs(hyb32 - want_hyb) > 5 * abs(hyb - want_hyb)
+    assert abs(plain32 - want_plain) <= RTOL_F32 * abs(want_plain)   # (a handful of rows: still inside the fp32 bar - see DESIGN.md 4)
