@@ -526,16 +526,21 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     // fp32 tables: behind the sums, one slot per sum for |z|^2 of the farthest whitened training row of its evaluation (reported by the
     // pack kernels) - an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used, and its
     // continuous column set goes to fp64 fragments from then on (pbn_scoredata::widen_sets; scoring.hip does the same for plain terms)
-    const bool f32 = sd->dtype == PBN_F32;
+    static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
+    const bool f32 = sd->dtype == PBN_F32 && check_after;
     const size_t max_slots = (size_t)units * g.nc * 2 + 1;
-    struct Redo { KdeModel m; std::vector<int> v; int64_t r0, n0, r1, te0, nte; };
+    // what a redo needs, flat (one candidate makes ~100 terms, a search thousands of candidates: no per-term allocations): the term's
+    // bandwidth and centre in `rstore`, its columns in `rcols`
+    struct Redo { int slot, nv; size_t off, coff; int64_t N, r0, n0, r1, te0, nte; };
     std::vector<Redo> redo_info;
+    std::vector<double> rstore;
+    std::vector<int> rcols;
     if (node_type == PBN_NODE_CKDE) {
         dsums.alloc(2 * max_slots);
         HIP_CHECK(hipMemsetAsync(dsums.p, 0, 2 * max_slots * sizeof(double), ctx->stream));
-        if (f32) redo_info.resize(max_slots);
     }
     double* const dmax = (f32 && node_type == PBN_NODE_CKDE) ? dsums.p + max_slots : nullptr;
+    std::vector<double> Hterm, muterm;   // bandwidth / centre of the term being built (reused)
     auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
     // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
     const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
@@ -718,6 +723,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             }
             std::vector<int> midx(std::max(pc, 1));
             for (int i = 0; i < pc; ++i) midx[i] = i + 1;
+            std::vector<double>& Ht = Hterm;
+            std::vector<double>& mut = muterm;
             for (int which = 0; which < (pc > 0 ? 2 : 1); ++which) {   // 0: joint over its columns in ascending order, 1: marginal over cols[1:]
                 Term& term = which ? sl.marg : sl.joint;
                 const int* v = which ? cols.data() + 1 : jcols.data();
@@ -727,20 +734,20 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 auto itc = sd->kde_cache.find(key);
                 if (itc != sd->kde_cache.end()) { term.value = itc->second; continue; }
                 KdeModel m;
+                Ht.resize((size_t)nv * nv); mut.resize((size_t)nv);
                 try {
                     if (which) {
-                        std::vector<double> Hm((size_t)pc * pc);
-                        for (int jj = 0; jj < pc; ++jj)
-                            for (int ii = 0; ii < pc; ++ii) Hm[ii + (size_t)jj * pc] = H[(ii + 1) + (size_t)(jj + 1) * d];
-                        kde_prepare(m, sd->dtype, pc, tr->N, Hm.data(), PBN_BW_FULL, false, mu.data() + 1);
-                    } else {
-                        std::vector<double> Hs((size_t)d * d), mus((size_t)d);
-                        for (int jj = 0; jj < d; ++jj) {
-                            mus[jj] = mu[jperm[jj]];
-                            for (int ii = 0; ii < d; ++ii) Hs[ii + (size_t)jj * d] = H[jperm[ii] + (size_t)jperm[jj] * d];
+                        for (int jj = 0; jj < pc; ++jj) {
+                            mut[jj] = mu[jj + 1];
+                            for (int ii = 0; ii < pc; ++ii) Ht[ii + (size_t)jj * pc] = H[(ii + 1) + (size_t)(jj + 1) * d];
                         }
-                        kde_prepare(m, sd->dtype, d, tr->N, Hs.data(), PBN_BW_FULL, false, mus.data());
+                    } else {
+                        for (int jj = 0; jj < d; ++jj) {
+                            mut[jj] = mu[jperm[jj]];
+                            for (int ii = 0; ii < d; ++ii) Ht[ii + (size_t)jj * d] = H[jperm[ii] + (size_t)jperm[jj] * d];
+                        }
                     }
+                    kde_prepare(m, sd->dtype, nv, tr->N, Ht.data(), PBN_BW_FULL, false, mut.data());
                 } catch (const singular_error&) {
                     term.slot = -2;   // no factor for this slice
                     break;
@@ -748,7 +755,12 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 term.slot = (int)slot_key.size();
                 slot_key.push_back(key);
                 const bool w64 = f32 && sd->widen_sets.count(set_key(v, nv)) != 0;   // a set already known to need fp64 fragments
-                if (f32 && !w64) redo_info[(size_t)term.slot] = Redo{m, std::vector<int>(v, v + nv), tr_row0, tr_n0, tr_row1, te0, te->N};
+                if (f32 && !w64) {
+                    redo_info.push_back(Redo{term.slot, nv, rstore.size(), rcols.size(), tr->N, tr_row0, tr_n0, tr_row1, te0, te->N});
+                    rstore.insert(rstore.end(), Ht.begin(), Ht.end());
+                    rstore.insert(rstore.end(), mut.begin(), mut.end());
+                    rcols.insert(rcols.end(), v, v + nv);
+                }
                 if (elig[(size_t)c * 2 + which] && !w64) {   // evaluated with the candidate's other grouped slices, after the loops
                     group_unit(c, u, which, m, v, colidx, nv, tr->N, te->N, term.slot);
                     ++sd->kde_sweeps;
@@ -787,19 +799,21 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (f32) {   // check-after (see above): flagged evaluations once more, on fp64 fragments, through the per-slice chain
             bool any = false;
-            for (size_t i = 0; i < ns; ++i) {
-                if (!kde_wants_widening(hmax[i]) || redo_info[i].v.empty()) continue;
-                Redo& r = redo_info[i];
-                sd->widen_sets.insert(set_key(r.v.data(), (int)r.v.size()));
-                kde_widen(r.m);
-                const KdePackBytes pb = kde_pack_bytes(r.m.fdtype(), r.m.dm, false, r.m.N);
+            for (const Redo& r : redo_info) {
+                if (!kde_wants_widening(hmax[(size_t)r.slot])) continue;
+                const int* v = rcols.data() + r.coff;
+                sd->widen_sets.insert(set_key(v, r.nv));
+                KdeModel m;
+                kde_prepare(m, sd->dtype, r.nv, r.N, rstore.data() + r.off, PBN_BW_FULL, false, rstore.data() + r.off + (size_t)r.nv * r.nv);
+                kde_widen(m);
+                const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, false, m.N);
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
-                r.m.Apack = ctx->scratch_train.p;
-                r.m.nxpack = ctx->scratch_train.p + align(pb.apack);
-                r.m.Axpack = nullptr;
-                HIP_CHECK(hipMemsetAsync(dsums.p + i, 0, sizeof(double), ctx->stream));
-                kde_pack_train(ctx, r.m, t, r.v.data(), r.r0, r.n0, r.r1, g.rows.p, /*prune=*/true);
-                kde_eval_enqueue(ctx, r.m, t, r.v.data(), r.te0, r.nte, nullptr, dsums.p + i, g.rows.p);
+                m.Apack = ctx->scratch_train.p;
+                m.nxpack = ctx->scratch_train.p + align(pb.apack);
+                m.Axpack = nullptr;
+                HIP_CHECK(hipMemsetAsync(dsums.p + r.slot, 0, sizeof(double), ctx->stream));
+                kde_pack_train(ctx, m, t, v, r.r0, r.n0, r.r1, g.rows.p, /*prune=*/true);
+                kde_eval_enqueue(ctx, m, t, v, r.te0, r.nte, nullptr, dsums.p + r.slot, g.rows.p);
                 ++sd->kde_sweeps;
                 any = true;
             }

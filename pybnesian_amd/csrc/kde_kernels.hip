@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void max_norm2_kernel(PackArgs a, unsigned lon
     if (threadIdx.x == 0) {
         double m = wmax[0];
         for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
-        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        if (bits > *(volatile unsigned long long*)out) atomicMax(out, bits);   // (see group_pack_train_kernel)
     }
 }
 
@@ -1283,6 +1284,9 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_PROBES
 #define PBN_BF16_PROBES 16   // with them the two-MFMA unpruned sweep gains from the blind chunks too: d = 8 headline 13.89 -> 13.56 ms (4 probes: 13.82)
 #endif
+#ifndef PBN_BF16_FSUM
+#define PBN_BF16_FSUM 1
+#endif
 #ifndef PBN_BF16_BLIND_CHUNK
 #define PBN_BF16_BLIND_CHUNK 64
 #endif
@@ -1458,6 +1462,19 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     float pend[PAIRSUM ? QG : 1];
 #pragma unroll
     for (int g = 0; g < (PAIRSUM ? QG : 1); ++g) pend[g] = 0.f;
+    // PBN_BF16_FSUM (round 4): inside a BLIND batch / chunk (at most 64 tiles, looked at once at its end) the tile sums are added in fp32 and
+    // join the fp64 sums once per batch - the v_cvt_f64_f32 + v_add_f64 per (tile, group) were 8 of the ~60 issue slots of a tile's four
+    // groups.  At most 64 fp32 additions of positive terms: <= 4e-6 relative on a sum, against the fp32 bar of 1e-3.
+    constexpr bool FSUM = !COND && PBN_BF16_BLIND && PBN_BF16_FSUM;
+    float fs[FSUM ? QG : 1];
+#pragma unroll
+    for (int g = 0; g < (FSUM ? QG : 1); ++g) fs[g] = 0.f;
+    auto flush_fs = [&]() {
+        if constexpr (FSUM) {
+#pragma unroll
+            for (int g = 0; g < QG; ++g) { sum[g] += (double)fs[g]; fs[g] = 0.f; }
+        }
+    };
     // `blind` (plain sweeps, PBN_BF16_BLIND): no overflow test and no rescue path - the caller looks at the fp64 sums once per batch / chunk
     // of tiles and redoes it checked if one of them went bad (as the fp64 sweeps do).  An exponent overflows only 128 units above its
     // query's offset, and the offsets start from the prepass bounds (pruned) or from a tile of the split itself.
@@ -1502,7 +1519,8 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                         tsj = (j0 + j1) + (j2 + j3);
                     }
                 }
-                sum[g] += (double)ts;
+                if constexpr (BLIND && FSUM) fs[g] += ts;
+                else sum[g] += (double)ts;
                 if (COND) sumj[g] += (double)tsj;
             }
         } else {
@@ -1558,7 +1576,9 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
             }
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
-                if constexpr (PAIRSUM) {
+                if constexpr (BLIND && FSUM) {
+                    fs[g] += ts[g];
+                } else if constexpr (PAIRSUM) {
                     if (flush) { sum[g] += (double)(pend[g] + ts[g]); pend[g] = 0.f; } else pend[g] = ts[g];
                 } else {
                     sum[g] += (double)ts[g];
@@ -1621,6 +1641,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
                 run_batch(mask, std::true_type{});
+                flush_fs();
                 bool bad = false;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
@@ -1652,6 +1673,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
                 run_range(c0, c1, std::true_type{});
+                flush_fs();
                 bool bad = false;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);

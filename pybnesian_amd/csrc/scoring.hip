@@ -986,7 +986,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             // fp32 tables: behind the sums, one slot per sum for |z|^2 of the evaluation's farthest whitened training row (the pack
             // kernels report it): an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used,
             // and its variable set goes to fp64 fragments from then on (pbn_scoredata::widen_sets, KdeModel::widen)
-            const bool f32 = sd->dtype == PBN_F32;
+            static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
+            const bool f32 = sd->dtype == PBN_F32 && check_after;
             dev_buf<double> dsums(std::max<size_t>(1, 2 * nslots));
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, 2 * nslots) * sizeof(double), ctx->stream));
             double* const dmax = f32 ? dsums.p + nslots : nullptr;
