@@ -97,8 +97,11 @@ int pbn_bandwidth(int selector, int kind, const double* cov, int d, int64_t n, i
  * `kind`; the training rows are whitened, centred and packed into MFMA fragment order on device.
  * `center` (d doubles, nullable) is any offset near the column means (the distances do not depend on
  * it; it only keeps the whitened coordinates small); NULL lets the library take pilot means.
- * Dimensions: up to 32 variables (+ the conditional one of pbn_ckde_fit), PBN_ERR_INVALID beyond (the reference has no
- * limit); pbn_ckde_cdf / pbn_ckde_sample / pbn_ucv_* take up to 16. */
+ * Dimensions: any number of variables, as in the reference (KDE.hpp:592-640 loops over d).  Up to 32 (+ the conditional one of
+ * pbn_ckde_fit) run the templated MFMA shapes; beyond, a generic runtime-sized pack + sweep in fp64 fragments (a CKDE of that size as
+ * joint - marginal, CKDE.hpp:256-287); pbn_ckde_cdf / pbn_ckde_sample / pbn_ucv_* likewise beyond 16.
+ * fp32 tables: fragments and sweeps are fp32 (bf16x3 on the matrix cores) unless the whitened training rows reach so far from the centre
+ * that the Gram-form distances would lose them (2^-24 max|z|^2 > 5e-4) - then fp64 fragments are packed from the float columns. */
 int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                 const double* bandwidth, int kind, const double* center, pbn_kde** out);
 /* CKDE: replaces CKDE::_fit (factors/continuous/CKDE.hpp:182-200).  cols[0] is the variable,
