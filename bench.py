@@ -790,6 +790,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the backends' own chatter ("[Gloo] Rank 0 is connected to ...", NCCL_DEBUG lines) goes to C-level stdout: send it to stderr while
+        # the group comes up, so that stdout carries the ONE JSON line only
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -800,6 +805,10 @@ def main():
         ranks_seen = int(round(float(ones.item())))
         devs = [None] * world
         dist.all_gather_object(devs, (rank, local_rank, torch.cuda.get_device_properties(local_rank).name))
+        dist.barrier()
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
     import pybnesian_amd as pbn
     from pybnesian_amd import _lib

@@ -148,6 +148,9 @@ struct pbn_ctx {
     pbn::dev_buf<double> scratch_split; // CKDE handles evaluated as two plain sweeps: joint / marginal logl or sums
     pbn::dev_buf<double> scratch_w;     // whitening matrices too large for the kernel arguments (more than 16 variables)
     pbn::dev_buf<char> scratch_group;   // grouped KDE evaluation (kde_group.hip): tables, sorted rows, every unit's packs and partials
+    // the score engine's result slots (sums, max-norms) of the batch / candidate being evaluated: NOT part of a lane (every lane's
+    // evaluations write into it), grow-only - a hipMalloc + hipFree per hybrid candidate (the free synchronises the device) was 0.2 s of C5
+    pbn::dev_buf<double> scratch_sums;
     // host buffers of asynchronous uploads that must outlive the call that enqueued them; dropped by whoever synchronises next
     std::vector<std::vector<char>> staged;
     void drop_staged() { staged.clear(); }

@@ -522,7 +522,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     struct Slice { Term joint, marg; bool has_marg; int part; };
     std::vector<Slice> slices;
     std::vector<std::vector<int>> slot_key;
-    dev_buf<double> dsums;
+    struct { double* p = nullptr; } dsums;   // slots in the context's scratch_sums (grow-only; no allocation per candidate)
     // fp32 tables: behind the sums, one slot per sum for |z|^2 of the farthest whitened training row of its evaluation (reported by the
     // pack kernels) - an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used, and its
     // continuous column set goes to fp64 fragments from then on (pbn_scoredata::widen_sets; scoring.hip does the same for plain terms)
@@ -536,7 +536,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     std::vector<double> rstore;
     std::vector<int> rcols;
     if (node_type == PBN_NODE_CKDE) {
-        dsums.alloc(2 * max_slots);
+        ctx->scratch_sums.reserve(2 * max_slots);
+        dsums.p = ctx->scratch_sums.p;
         HIP_CHECK(hipMemsetAsync(dsums.p, 0, 2 * max_slots * sizeof(double), ctx->stream));
     }
     double* const dmax = (f32 && node_type == PBN_NODE_CKDE) ? dsums.p + max_slots : nullptr;

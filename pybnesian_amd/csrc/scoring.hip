@@ -988,7 +988,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             // and its variable set goes to fp64 fragments from then on (pbn_scoredata::widen_sets, KdeModel::widen)
             static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
             const bool f32 = sd->dtype == PBN_F32 && check_after;
-            dev_buf<double> dsums(std::max<size_t>(1, 2 * nslots));
+            ctx->scratch_sums.reserve(std::max<size_t>(1, 2 * nslots));   // (grow-only: no hipMalloc / hipFree per batch)
+            struct { double* p; } dsums{ctx->scratch_sums.p};
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, 2 * nslots) * sizeof(double), ctx->stream));
             double* const dmax = f32 ? dsums.p + nslots : nullptr;
             auto set_key = [](const std::vector<int>& use) { std::vector<int> k(use); std::sort(k.begin(), k.end()); return k; };
