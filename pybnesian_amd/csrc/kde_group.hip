@@ -651,6 +651,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         sa.prune_margin = ring ? ring_near_env : 0.0;   // the units' own margins; with a RING pass the fp64 kernel stops at the hand-over radius
         static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
         sa.group_masks = ring ? 1 : gmasks;             // (the two passes split the pairs by the per-group test)
+        sa.far_span = ring ? 0.0 : (double)env_int("PBN_FAR_SPAN", 17);   // fp64 FOLD shapes: far tiles through the fp32 unit (kde_sweep_body: FARP)
         launch_sweep_grouped(sa, fdt, KS, st);
         if (ring) {
             GSweepArgs ra = sa;

@@ -102,6 +102,7 @@ struct GSweepArgs {
     int ring;              // this launch is the RING (far-field, bf16) pass of an fp64 sweep
     double prune_margin;   // > 0: one margin for every unit of the launch (the near pass of a RING sweep); 0: the units' own
     double ring_near;      // exponent distance below the sum bound at which the fp64 pass hands over to the RING pass
+    double far_span;       // SweepArgs::far_span of every unit of the launch
 };
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st);
 

@@ -222,6 +222,9 @@ __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
 #ifndef PBN_F64_PRUNE_WAVES
 #define PBN_F64_PRUNE_WAVES 3
 #endif
+#ifndef PBN_FAR_F32
+#define PBN_FAR_F32 1   // pruned plain fp64 sum-only sweeps: far tiles through the fp32 unit (kde_sweep_body: FARP; SweepArgs::far_span)
+#endif
 #ifndef PBN_SWEEP_UNCHECKED
 #define PBN_SWEEP_UNCHECKED 1   // fp64 plain unpruned sweeps: blind first pass, checked redo (kde_sweep_kernel)
 #endif
@@ -580,6 +583,31 @@ __device__ __forceinline__ unsigned long long prune_group_mask(BP tile_box, BP q
     return __ballot(keep);
 }
 
+// ... with a second, nearer threshold: `near` = the tiles that hold a term above thr_near (the others of the returned mask are the
+// far tiles of the fp32 tail path)
+template <typename BP>
+__device__ __forceinline__ unsigned long long prune_group_mask2(BP tile_box, BP qbox, int pd, int64_t tb, int64_t t1, double thr, double thr_near, int lane,
+                                                                unsigned long long& near) {
+    const int64_t t = tb + lane;
+    bool keep = false, kn = false;
+    if (t < t1) {
+        const BP bx = tile_box + t * 2 * pd;
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k)
+            if (k < pd) {
+                const double g1 = bx[k] - qbox[pd + k], g2 = qbox[k] - bx[pd + k];
+                double g = g1 > g2 ? g1 : g2;
+                g = g > 0.0 ? g : 0.0;
+                d2 = __builtin_fma(g, g, d2);
+            }
+        keep = !(-0.5 * d2 < thr);
+        kn = !(-0.5 * d2 < thr_near);
+    }
+    near = __ballot(kn);
+    return __ballot(keep);
+}
+
 // WMUL (d mod 4 == 0, no free K slot for the norm): the training norms enter as WEIGHTS.  The accumulator starts from the
 // per-query constant alone (a persistent register quad as the MFMA's C operand, as with FOLD) and holds
 // x' = z_t.z_q - 1/2|z_q|^2 - m_q + bias; the term is 2^x' * w_t with w_t = 2^(-1/2|z_t|^2) precomputed by the pack kernel, and
@@ -753,6 +781,18 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     unsigned long long gm[QG];
 #pragma unroll
     for (int g = 0; g < QG; ++g) gm[g] = ~0ull;
+    // FARP (round 4; sum-only pruned sweeps of the FOLD shapes, per-group masks): a tile ALL of whose terms lie more than
+    // prune_margin - far_span (26 at 10^6 rows) below the group's sum bound contributes less than 2^-26 of the sum per term: its 2^x go
+    // through the fp32 unit directly - cvt_f32_f64, v_exp_f32, v_add_f32: 4 issue slots per value instead of 8 - and are added in fp32
+    // until the end of the blind batch.  The exponents are biased by +128 and the offsets lie within 6 units of the sum bound (the
+    // prepass bounds), so x' <= 108: no overflow, and 2^x' carries the same 2^bias as the fp64 sums.  Relative error of such a term
+    // 2^-24 |x'| ln 2 <= 5.3e-6, of the sum <= 5.3e-6 N 2^-26 = 8e-8 (the margin follows log2(N / 10^6), so the bound does not depend
+    // on N).  A batch redone by the checked loop takes every tile through the full path.
+    constexpr bool FARP = GMASK && FOLD && EF32 && PBN_FAR_F32;
+    unsigned long long gn[FARP ? QG : 1];
+    float fs[FARP ? QG : 1];
+#pragma unroll
+    for (int g = 0; g < (FARP ? QG : 1); ++g) { gn[g] = ~0ull; fs[g] = 0.f; }
     auto process_tile = [&](const int64_t t, const T (&af)[KS], const V& nx, const T ax, const int bit) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
@@ -820,6 +860,14 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             if (FOLD || WMUL) acc = cmv[g]; else acc = nx + cm[g];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
+            if constexpr (FARP) {
+                if (!((gn[g] >> bit) & 1ull)) {   // a far tile of this group: the fp32 tail path
+                    const float f0 = __builtin_amdgcn_exp2f((float)acc[0]), f1 = __builtin_amdgcn_exp2f((float)acc[1]);
+                    const float f2 = __builtin_amdgcn_exp2f((float)acc[2]), f3 = __builtin_amdgcn_exp2f((float)acc[3]);
+                    fs[g] += (f0 + f1) + (f2 + f3);
+                    continue;
+                }
+            }
             const T e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop), e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop), e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop), e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
             if (WMUL) sum[g] = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], __builtin_fma(e0, nx[0], sum[g]))));
             else sum[g] += (e0 + e1) + (e2 + e3);
@@ -863,13 +911,26 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                     for (int g = 0; g < QG; ++g) {
                         const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-                        gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
+                        if constexpr (FARP) {
+                            if (a.far_span > 0.0) {
+                                gm[g] = prune_group_mask2(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, QTp[qt] - (a.prune_margin - a.far_span), lane, gn[g]);
+                            } else {
+                                gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
+                                gn[g] = ~0ull;
+                            }
+                        } else {
+                            gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
+                        }
                         mask |= gm[g];
                     }
                 } else {
                     mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
 #pragma unroll
                     for (int g = 0; g < QG; ++g) gm[g] = mask;
+                    if constexpr (FARP) {
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) gn[g] = ~0ull;
+                    }
                 }
             } else {
                 mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
@@ -886,6 +947,10 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
                 run_batch(tb, mask, std::true_type{});
+                if constexpr (FARP) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) { sum[g] += (double)fs[g]; fs[g] = 0.f; }   // (an overflowed fp32 tail arrives as inf: the batch is redone)
+                }
                 bool bad = false;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
@@ -1002,6 +1067,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks; a.ring_near = 0;
+    a.far_span = g.far_span;
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true>(a, bid);
 }
 

@@ -84,6 +84,8 @@ struct SweepArgs {
     const double* qlb;         // [nqtiles * 16] per (sorted) query: lower bound of its largest exponent, -inf = none; nullable
     int nsplit_grid;           // pruned sweeps: number of splits (their grid is one-dimensional; launch_sweep sets this)
     int group_masks;           // pruned plain fp64 sweeps: test every 16-query group against its own box and bound (prune_group_mask)
+    double far_span;           // pruned plain fp64 sum-only sweeps (FOLD shapes): > 0 = tiles whose every term lies more than prune_margin - far_span
+                               // below the group's sum bound take the fp32 tail path (kde_sweep_body: FARP); 0 = off
     double ring_near;          // RING pass of the bf16 kernel: visit only pairs whose bound lies between 2^-prune_margin and 2^-ring_near of the sum
     double* part;  // [nsplit][nqtiles*16][P]
     double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
