@@ -496,7 +496,11 @@ static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split
         // the caller adds the ranks' buffers (exact: every segment is non-zero on one rank only) and installs them
         // (pbn_scoredata_moments), and regions_from_segments adds a region's segments in segment order: the totals are the same
         // bit for bit for every world size.
-        static const int SB = [] { const char* e = getenv("PBN_MOMENT_SUPERBLOCKS"); const int v = (e && *e) ? atoi(e) : 16; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+        // (16 super-blocks up to 128 columns; wider tables fewer - a segment is n + n^2 doubles on every rank, 176 of them at 10 folds +
+        //  hold-out: 350 MB per rank at n = 500 - down to 2 from 512 columns: the count is part of the summation order, so it is a
+        //  function of n alone)
+        static const int SB_env = [] { const char* e = getenv("PBN_MOMENT_SUPERBLOCKS"); const int v = (e && *e) ? atoi(e) : 0; return v < 0 ? 0 : (v > 1024 ? 1024 : v); }();
+        const int SB = SB_env > 0 ? SB_env : (sd->n <= 128 ? 16 : (sd->n <= 256 ? 8 : (sd->n <= 512 ? 4 : 2)));
         auto add_region = [&](int region, int64_t r0, int64_t len) {
             int64_t prev = 0;
             for (int i = 1; i <= SB; ++i) {

@@ -264,9 +264,11 @@ _shared = __import__("threading").local()
 
 
 @__import__("contextlib").contextmanager
-def shared_upload(ctx, df):
+def shared_upload(ctx, df, columns=None):
     """One upload for many factors: inside the scope, `DeviceTable.from_dataframe(ctx, df, variables)` hands out ONE table
-    holding every null-free floating-point column of `df` (all of one type) instead of uploading `variables` again - the model-level
+    holding the null-free floating-point columns of `df` (all of one type; only those named in `columns` when given - a model's
+    own nodes: a 4-node network on a 500-column frame must not upload, and keep alive, the other 496) instead of uploading
+    `variables` again - the model-level
     fit / logl / slogl of a network make one PCIe pass over the table instead of one per factor (a 64-node network over 2M rows
     uploaded ~3 GB for a 1 GB table).  Columns with nulls, dictionary columns and mixed float types keep the per-factor upload (their
     row sets differ from factor to factor).  `df` must be the very RecordBatch the factors are given."""
@@ -274,7 +276,9 @@ def shared_upload(ctx, df):
 
     rb = as_record_batch(df)
     prev = getattr(_shared, "entry", None)
-    cols = [f.name for i, f in enumerate(rb.schema) if (pa.types.is_float64(f.type) or pa.types.is_float32(f.type)) and rb.column(i).null_count == 0]
+    wanted = None if columns is None else set(columns)
+    cols = [f.name for i, f in enumerate(rb.schema) if (pa.types.is_float64(f.type) or pa.types.is_float32(f.type)) and rb.column(i).null_count == 0
+            and (wanted is None or f.name in wanted)]
     table = None
     if len(cols) >= 2 and len({rb.schema.field(c).type for c in cols}) == 1 and rb.num_rows > 0:
         table, _ = DeviceTable.from_dataframe(ctx, rb, cols, drop_null=False)

@@ -860,12 +860,16 @@ class BayesianNetwork(BayesianNetworkBase):
             self.set_unknown_node_types(df)
         from .dataset import default_context, shared_upload
 
-        with shared_upload(default_context(), df):   # one PCIe pass over the table for all factors
+        with shared_upload(default_context(), df, self._upload_columns()):   # one PCIe pass over the model's columns for all factors
             for n in self._nodes:
                 if not self._cpd_valid(n):
                     self._cpds[n] = self._new_factor(df, n)
                 if not self._cpds[n].fitted():
                     self._cpds[n].fit(df)
+
+    def _upload_columns(self):
+        """The columns the factors of this model read: its nodes and, for a conditional network, its interface nodes."""
+        return list(self._nodes) + list(getattr(self, "_interface", ()))
 
     def fitted(self):
         cp = getattr(self, "_cpds", None)
@@ -888,7 +892,7 @@ class BayesianNetwork(BayesianNetworkBase):
 
         df = as_record_batch(df)
         out = None
-        with shared_upload(default_context(), df):
+        with shared_upload(default_context(), df, self._upload_columns()):
             for n in self._nodes:
                 ll = np.asarray(self._cpds[n].logl(df), dtype=np.float64)
                 out = ll if out is None else out + ll
@@ -900,7 +904,7 @@ class BayesianNetwork(BayesianNetworkBase):
         from .dataset import as_record_batch, default_context, shared_upload
 
         df = as_record_batch(df)
-        with shared_upload(default_context(), df):
+        with shared_upload(default_context(), df, self._upload_columns()):
             return float(sum(self._cpds[n].slogl(df) for n in self._nodes))
 
     # -- graph queries of models/BayesianNetwork.hpp / graph/generic_graph.hpp the callers of the hot path use -------

@@ -290,7 +290,8 @@ class _DeviceScore(Score):
         return out
 
     def _batch_parts(self, model, var, ntype, off, par, kind, part, n_parts):
-        """Per-part sums (len(var) x 64) of hybrid CKDE candidates on the parts p = part (mod n_parts): pbn_score_batch_parts."""
+        """Per-part sums (len(var) x 64) of hybrid CKDE candidates on the parts dealt to rank `part` of `n_parts` - longest processing
+        time first on the slices' training x test rows, the same dealing on every rank (hybrid.hip): pbn_score_batch_parts."""
         n = len(var)
         out = np.zeros((n, 64))
         if n:
