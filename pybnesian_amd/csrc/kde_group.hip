@@ -49,6 +49,7 @@ struct GDev {   // argument block of the block-wise kernels
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     int ring_nb;              // > 0: fp64 table with a RING pass - also write bf16x3 fragments (ring_nb MFMAs) of every row
     unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
+    int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
 };
 
 __device__ __forceinline__ int region_of(const GPool& P, int pp) {
@@ -400,7 +401,6 @@ __global__ __launch_bounds__(256) void group_prepass_kernel(GDev g) {
             else acc += exp2(ex - best);
         }
     }
-    if (q < U.nqtiles * 16) ((double*)(g.arena + U.qlb))[q] = valid ? best : -INFINITY;
     // the pruning threshold may stand on the bound of the query's SUM (>= the sum over the scanned rows): what a skipped tile
     // could add is then below 2^-margin of the sum itself, not merely of its largest term
     double thr = valid ? (g.use_sum_bound && acc > 0.0 ? best + log2(acc) : best) : INFINITY;
@@ -417,6 +417,49 @@ __global__ __launch_bounds__(256) void group_prepass_kernel(GDev g) {
             hib[k] = h > hib[k] ? h : hib[k];
         }
     }
+    // Round 4: a second lower bound of the 16 queries' sums, from the BOXES of the training tiles around their position in the training
+    // order (the boxes cover every dimension on this path): every row of a tile T lies within maxdist(query box, box_T) of every query,
+    // so S_q >= sum_T 16 * 2^(-1/2 maxdist^2) over any set of full tiles.  The 64 scanned ROWS above reach 2^6 at best where the sum of
+    // a query in a dense region holds thousands of comparable terms; a window of +-256 TILES (8 192 rows, 32 boxes per lane) recovers 4-6 of
+    // those bits, and every bit of the bound is a bit of pruning radius: cv64 2.52 -> 2.45 s, C3's first iteration 11.56 -> 10.95 s, C5
+    // 8.37 -> 8.14 s (profiles/r4/tile_window_probe.txt; PBN_GROUP_TILE_WINDOW, 0 = off).  The largest single box term also raises the
+    // queries' offsets (qlb), which keeps them within log2(16 x 512 tiles) = 13 units of the threshold (the fp32 tail path of far tiles
+    // needs less than 26).
+    if (g.tile_window > 0 && g.use_sum_bound && pd == d) {
+        const int l16 = threadIdx.x & 15;
+        const int tp0 = __shfl(valid ? ((const int32_t*)(g.arena + U.qpos))[q] : 0, 0, 16);   // position of the tile's first query
+        const int full = U.N >> 4;                                                           // tiles whose 16 rows are all real
+        const int tt = tp0 >> 4;
+        const int t_lo = tt - g.tile_window > 0 ? tt - g.tile_window : 0, t_hi = tt + g.tile_window < full ? tt + g.tile_window : full;
+        const double* boxes = (const double*)(g.arena + U.box);
+        double bmax = -INFINITY, bacc = 0.0;
+        const bool boxok = lob[0] <= hib[0];   // the tile holds a valid query
+        if (boxok)
+            for (int t = t_lo + l16; t < t_hi; t += 16) {
+                const double* bx = boxes + (int64_t)t * 2 * pd;
+                double d2 = 0.0;
+                for (int k = 0; k < pd; ++k) {
+                    const double a1 = bx[pd + k] - lob[k], a2 = hib[k] - bx[k];
+                    const double a = a1 > a2 ? a1 : a2;
+                    d2 = __builtin_fma(a, a, d2);
+                }
+                const double ex = -0.5 * d2;
+                if (!(ex == ex)) continue;
+                if (ex > bmax) { bacc = bacc * exp2(bmax - ex) + 1.0; bmax = ex; }
+                else bacc += exp2(ex - bmax);
+            }
+        for (int off = 1; off < 16; off <<= 1) {   // merge the 16 lanes' (max, sum) pairs
+            const double om = __shfl_xor(bmax, off), oa = __shfl_xor(bacc, off);
+            if (om > bmax) { bacc = bacc * exp2(bmax - om) + oa; bmax = om; }
+            else if (om > -INFINITY) bacc += oa * exp2(om - bmax);
+        }
+        if (bacc > 0.0) {
+            const double tb = bmax + log2(bacc) + 4.0;   // 16 rows per tile
+            if (tb > thr && thr < INFINITY) thr = tb;
+            if (valid && bmax > best) best = bmax;       // a valid lower bound of this query's largest exponent, too
+        }
+    }
+    if (q < U.nqtiles * 16) ((double*)(g.arena + U.qlb))[q] = valid ? best : -INFINITY;
     if (valid && (threadIdx.x & 15) == 0) {
         const int tile = q >> 4;
         ((double*)(g.arena + U.qthr))[tile] = thr;
@@ -620,6 +663,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.use_sum_bound = sum_bound;
     g.bf16 = bf16 ? 1 : 0; g.KS = KS; g.ring_nb = NB16;
     g.out_max = bf16 ? (unsigned long long*)dev_out_max : nullptr;
+    static const int tile_window = std::max(0, env_int("PBN_GROUP_TILE_WINDOW", 256));
+    g.tile_window = tile_window;
     static const int window = std::max(1, env_int("PBN_GROUP_WINDOW", PBN_GROUP_WINDOW));
     g.window = window;
 

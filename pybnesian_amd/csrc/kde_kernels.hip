@@ -444,18 +444,21 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
                                                             const uint32_t* __restrict__ qkeys, const double* __restrict__ zt,
                                                             const uint32_t* __restrict__ tkeys, int64_t n, int zd, int pd,
                                                             double* __restrict__ qbox, double* __restrict__ qthr, double* __restrict__ qlb,
-                                                            const double* __restrict__ subpart, int P, int which, double log2_nsub, int sum_bound) {
+                                                            const double* __restrict__ subpart, int P, int which, double log2_nsub, int sum_bound,
+                                                            const double* __restrict__ tile_box, int tile_window) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = q < nq;
     double z[PBN_MAX_D];
     double best = -INFINITY;
     double sumb = -INFINITY;   // lower bound of log2 of the query's WHOLE sum: the part of it that has been looked at
+    int64_t tpos_ = 0;   // the query's position in the (Morton-sorted) training order
     if (valid) {
         const double* zp = zq_row + (int64_t)qperm[q] * zd;
         for (int k = 0; k < zd; ++k) z[k] = zp[k];
         const uint32_t key = qkeys[q];
         int64_t lo = 0, hi = n;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tkeys[mid] < key) lo = mid + 1; else hi = mid; }
+        tpos_ = lo;
         const int64_t b = lo - PBN_PRUNE_WINDOW > 0 ? lo - PBN_PRUNE_WINDOW : 0, e = lo + PBN_PRUNE_WINDOW < n ? lo + PBN_PRUNE_WINDOW : n;
         double acc = 0.0;
         for (int64_t t = b; t < e; ++t) {
@@ -478,7 +481,6 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
             sumb = ls > sumb ? ls : sumb;
         }
     }
-    if (qlb && q < (nq + 15) / 16 * 16) qlb[q] = valid ? best : -INFINITY;   // per query: the sweep's starting offset
     // The pruning threshold stands on the bound of the query's SUM (the scanned neighbours' terms added up, or the subsample's sum -
     // log2(nsub) = up to 12 units above its mean term): what a skipped tile could add is then below 2^-margin of the sum itself, not
     // merely of its largest term - the same "at most N 2^-margin of a sum" as before, with a radius that is 5-10 % smaller per axis.
@@ -496,6 +498,40 @@ __global__ __launch_bounds__(256) void query_prepass_kernel(const double* __rest
             hib[k] = h > hib[k] ? h : hib[k];
         }
     }
+    // Round 4: the boxes of the training tiles around the queries' position bound their sums from below, too (see group_prepass_kernel):
+    // only where the boxes cover every dimension (pd == zd)
+    if (tile_box && tile_window > 0 && sum_bound && pd == zd) {
+        const int l16 = threadIdx.x & 15;
+        const int64_t tp0 = __shfl(valid ? tpos_ : (int64_t)0, 0, 16);
+        const int64_t full = n >> 4, tt = tp0 >> 4;
+        const int64_t t_lo = tt - tile_window > 0 ? tt - tile_window : 0, t_hi = tt + tile_window < full ? tt + tile_window : full;
+        double bmax = -INFINITY, bacc = 0.0;
+        if (lob[0] <= hib[0])
+            for (int64_t t = t_lo + l16; t < t_hi; t += 16) {
+                const double* bx = tile_box + t * 2 * pd;
+                double d2 = 0.0;
+                for (int k = 0; k < pd; ++k) {
+                    const double a1 = bx[pd + k] - lob[k], a2 = hib[k] - bx[k];
+                    const double a = a1 > a2 ? a1 : a2;
+                    d2 = __builtin_fma(a, a, d2);
+                }
+                const double ex = -0.5 * d2;
+                if (!(ex == ex)) continue;
+                if (ex > bmax) { bacc = bacc * exp2(bmax - ex) + 1.0; bmax = ex; }
+                else bacc += exp2(ex - bmax);
+            }
+        for (int off = 1; off < 16; off <<= 1) {
+            const double om = __shfl_xor(bmax, off), oa = __shfl_xor(bacc, off);
+            if (om > bmax) { bacc = bacc * exp2(bmax - om) + oa; bmax = om; }
+            else if (om > -INFINITY) bacc += oa * exp2(om - bmax);
+        }
+        if (bacc > 0.0) {
+            const double tb = bmax + log2(bacc) + 4.0;
+            if (tb > thr && thr < INFINITY) thr = tb;
+            if (valid && bmax > best) best = bmax;
+        }
+    }
+    if (qlb && q < (nq + 15) / 16 * 16) qlb[q] = valid ? best : -INFINITY;   // per query: the sweep's starting offset
     if (valid && (threadIdx.x & 15) == 0) {
         const int64_t tile = q >> 4;
         qthr[tile] = thr;
@@ -2405,11 +2441,12 @@ void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int z
 }
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
                           const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
-                          const double* subpart, int P, int which, double log2_nsub) {
+                          const double* subpart, int P, int which, double log2_nsub, const double* tile_box) {
     if (nq == 0) return;
     static const int sum_bound = [] { const char* e = getenv("PBN_GROUP_SUM_BOUND"); return (e && *e) ? atoi(e) : 1; }();
+    static const int tile_window = [] { const char* e = getenv("PBN_GROUP_TILE_WINDOW"); const int v = (e && *e) ? atoi(e) : 256; return v < 0 ? 0 : v; }();
     hipLaunchKernelGGL(query_prepass_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, zq_row, qperm, nq, qkeys_sorted, ztrain_sorted,
-                       tkeys_sorted, n, zd, pd, qbox, qthr, qlb, subpart, P, which, log2_nsub, sum_bound);
+                       tkeys_sorted, n, zd, pd, qbox, qthr, qlb, subpart, P, which, log2_nsub, sum_bound, tile_box, tile_window);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -132,7 +132,7 @@ void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int z
 // largest exponent
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
                           const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
-                          const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0);
+                          const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0, const double* tile_box = nullptr);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);
 // 52 (fp64) / 40 (fp32 on the bf16 cores) at 10^6 training rows, + log2(n_train / 10^6): a constant bound (2.2e-10 / 9.1e-7 of a sum) on what

@@ -450,7 +450,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
             subpart = ss.part;
         }
         launch_query_prepass(qs.zrow, qs.perm, n, qs.keys, m.zsorted, m.keys_sorted, m.N, m.zdims, m.pdims, (double*)qbox, (double*)qthr, (double*)qlb,
-                             ctx->stream, subpart, P, m.cond ? 2 : 0, subpart ? std::log2((double)m.nsub) : 0.0);
+                             ctx->stream, subpart, P, m.cond ? 2 : 0, subpart ? std::log2((double)m.nsub) : 0.0, m.cond ? nullptr : m.tile_box);
     }
 
     // split the training tiles so that the grid is a few waves deep on every CU

@@ -202,6 +202,10 @@ def test_grouped_hybrid_slices_match_per_slice_chains(pbn, monkeypatch, dtype, t
     bn = pbn.SemiparametricBN(list(df.columns), [], [("A", pbn.DiscreteFactorType()), ("B", pbn.DiscreteFactorType())])
     cands = (("y", ["x", "B"]), ("z", ["x", "y", "A"]), ("x", ["A"]), ("z", ["A", "B"]), ("y", ["x", "z", "A", "B"]))
     res = {}
+    # two implementations of the same sums: compared with the pruning margins pinned where what is dropped is below the tolerance
+    # (the two forms bound the queries' sums differently, so at the shipped margins they drop different - equally negligible - tiles)
+    monkeypatch.setenv("PBN_PRUNE_MARGIN", "52")
+    monkeypatch.setenv("PBN_PRUNE_MARGIN_F32", "40")
     for grouped in ("1", "0"):
         monkeypatch.setenv("PBN_SCORE_GROUPED", grouped)
         score = pbn.ValidatedLikelihood(df, 0.2, 4, 1)
@@ -210,8 +214,15 @@ def test_grouped_hybrid_slices_match_per_slice_chains(pbn, monkeypatch, dtype, t
         entries, sweeps = score.kde_cache_stats()
         assert sweeps > 0
     monkeypatch.delenv("PBN_SCORE_GROUPED")
+    monkeypatch.delenv("PBN_PRUNE_MARGIN")
+    monkeypatch.delenv("PBN_PRUNE_MARGIN_F32")
     assert np.all(np.isfinite(res["1"]))
     assert np.allclose(res["1"], res["0"], rtol=tol, atol=0), (res["1"] - res["0"]) / res["0"]
+    # the shipped margins: inside their dropped-mass bound (3e-7 / 3e-5 of a sum)
+    score = pbn.ValidatedLikelihood(df, 0.2, 4, 1)
+    shipped = np.array([score.local_score_node_type(bn, pbn.CKDEType(), v, p) for v, p in cands] +
+                       [score.vlocal_score_node_type(bn, pbn.CKDEType(), v, p) for v, p in cands])
+    assert np.allclose(shipped, res["1"], rtol=3e-7 if dtype == "float64" else 3e-5, atol=0)
 
 
 def test_fp32_engine_redoes_far_out_sets_on_fp64_fragments(pbn, oracle, monkeypatch):
