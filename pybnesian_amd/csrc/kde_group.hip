@@ -25,7 +25,10 @@ namespace {
 
 constexpr int GB = PBN_GROUP_BLOCK;
 constexpr int MORTON_BITS = 24;   // low bits of a sort key; the pool's index inside the batch sits above them
-#define PBN_GROUP_WINDOW 32        // training rows scanned on either side of a query's position (kde_kernels.hip: PBN_PRUNE_WINDOW)
+// training rows scanned on either side of a query's position (kde_kernels.hip: PBN_PRUNE_WINDOW is the per-unit form's, 32).  Round 4: 8 - the
+// sum bound now comes from the boxes of the surrounding tiles, the row scan only has to find a near row for the offsets; the 64-row scan was
+// 0.36 s of C5's 8.2 s (8.17 -> 7.92 s, cv64 / C3 unchanged: profiles/r4/row_window_probe.txt)
+#define PBN_GROUP_WINDOW 8
 
 __host__ __device__ inline int group_key_bits(int kd) { return kd <= 1 ? 16 : MORTON_BITS / kd; }
 
