@@ -86,6 +86,30 @@ class EvalLog:
         score._batch_raw = wrapped
 
 
+def cpu_quota():
+    """CPUs the container's cgroup grants (None = no quota): a box may show 256 CPUs under a 16-CPU quota, and more threads than that only thrash."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q_, per_ = f.read().split()[:2]
+            return None if q_ == "max" else float(q_) / float(per_)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q_ = float(f.read())
+                return None if q_ <= 0 else q_ / float(g.read())
+        except Exception:
+            return None
+
+
+def host_cores(visible):
+    quota = cpu_quota()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = visible
+    return int(max(1, min(visible, affinity, int(np.ceil(quota)) if quota else visible)))
+
+
 def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
     """CPU side of the candidate-arcs/s metric: the SAME local-score evaluations the device run
     made (EvalLog), evaluated by the oracle's restatement of the reference arithmetic on a bounded random sample of them and on
@@ -94,7 +118,7 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
     fits and likelihoods O(rows) -> x (rows / sample rows).  `host(m)` returns (columns dict of numpy arrays over the first m
     rows, dict of discrete codes / cardinalities or None).  Returns arcs/s = cells / extrapolated seconds, single thread (the
     reference's hill-climb is single-threaded) and on all cores (the oracle's OpenMP loop over test rows)."""
-    from oracle import oracle
+    from oracle import baseline, oracle
 
     rng = np.random.default_rng(0)
     n_rows = which["rows"]
@@ -132,6 +156,7 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
 
     def measure(m, threads, budget):
         oracle.set_num_threads(threads)
+        baseline.set_num_threads(threads)
         f = make_score(m)
         est, used, t_all = 0.0, 0, time.perf_counter()
         share = budget / max(1, len(classes))
@@ -149,10 +174,15 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
             used += done
         return est, used, time.perf_counter() - t_all
 
-    cores = oracle.num_threads()
-    out = {"unit": "arcs/s", "kind": "port",
+    visible = oracle.num_threads()
+    cores = host_cores(visible)
+    out = {"unit": "arcs/s", "kind": "port", "visible_cpus": visible,
            "law": "CKDE evaluations scaled by (rows / sample rows)^2, LinearGaussian / discrete ones by rows / sample rows; per class "
-                  "(node type, continuous parents): mean oracle time of up to 6 sampled evaluations x the class's evaluations"}
+                  "(node type, continuous parents): mean oracle time of up to 6 sampled evaluations x the class's evaluations",
+           "ckde": "the CKDE log-likelihoods inside the sampled evaluations come from the tuned port (oracle/pbn_baseline.cpp: whitened, blocked, "
+                   "vectorised exponentials), the fits / folds / LinearGaussian parts from the reference-arithmetic restatement; threads = the "
+                   "container's CPU quota"}
+    oracle.use_tuned_ckde(True)
     try:
         m_all = int(min(n_rows, which.get("sample_rows_all", 20000)))
         est, used, wall = measure(m_all, cores, budget_s * 0.5)
@@ -165,7 +195,9 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
     except Exception as ex:
         out["error"] = f"{type(ex).__name__}: {ex}"
     finally:
-        oracle.set_num_threads(cores)
+        oracle.use_tuned_ckde(False)
+        oracle.set_num_threads(visible)
+        baseline.set_num_threads(visible)
     return out
 
 

@@ -95,6 +95,22 @@ def product_kde_logl(train, h, test):
     return _logl(lib().oracle_product_kde_logl_f32, lib().oracle_product_kde_logl_f64, train, h, test)
 
 
+# TIMING ONLY (bench.py's CPU baselines of the hill-climb legs): when set, the CKDE log-likelihoods inside the likelihood scores below
+# come from the tuned port (oracle/baseline.py: whitened, blocked, vectorised; fp64 data) instead of the reference-arithmetic checker.
+# Tests never set it.
+_TIMED_CKDE = None
+
+
+def use_tuned_ckde(on):
+    global _TIMED_CKDE
+    if on:
+        from . import baseline
+
+        _TIMED_CKDE = baseline.ckde_logl
+    else:
+        _TIMED_CKDE = None
+
+
 def ckde_logl(train, H, test):
     """Column 0 = variable, columns 1.. = evidence."""
     return _logl(lib().oracle_ckde_logl_f32, lib().oracle_ckde_logl_f64, train, H, test)
@@ -332,6 +348,8 @@ def _fit_slogl(train, test, node_type):
         beta, var = lg_fit(train)
         return float(lg_logl(test, beta, var).sum())
     H = nr_bandwidth(train)
+    if _TIMED_CKDE is not None and np.asarray(train).dtype == np.float64:
+        return float(_TIMED_CKDE(train, H, test).sum())
     return float(ckde_logl(train, H, test).sum())
 
 
@@ -430,7 +448,7 @@ def adaptator_fit_slogl(cont, dcodes, dcards, train, test, node_type):
                 continue  # is_psd fails -> SingularCovarianceData
             H = bandwidth(0, 0, c_, tr.size)
             if te.size:
-                total += float(ckde_logl(cont[tr], H, cont[te]).sum())
+                total += float((_TIMED_CKDE if (_TIMED_CKDE is not None and cont.dtype == np.float64) else ckde_logl)(cont[tr], H, cont[te]).sum())
     return total
 
 
