@@ -184,11 +184,11 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
                    "container's CPU quota"}
     oracle.use_tuned_ckde(True)
     try:
-        m_all = int(min(n_rows, which.get("sample_rows_all", 20000)))
+        m_all = int(min(n_rows, which.get("sample_rows_all", 50000)))
         est, used, wall = measure(m_all, cores, budget_s * 0.5)
         out.update({"value": cells / est, "cores": cores, "cpu_seconds_extrapolated": est,
                     "sample": f"{used} of the run's {len(log.evals)} local-score evaluations on the first {m_all} of {n_rows} rows, {wall:.1f}s wall"})
-        m_one = int(min(n_rows, which.get("sample_rows_one", 4000)))
+        m_one = int(min(n_rows, which.get("sample_rows_one", 10000)))
         est1, used1, wall1 = measure(m_one, 1, budget_s * 0.5)
         out["single_thread"] = {"value": cells / est1, "cores": 1, "cpu_seconds_extrapolated": est1,
                                 "sample": f"{used1} evaluations on the first {m_one} rows, {wall1:.1f}s wall"}
@@ -375,7 +375,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         t0 = time.perf_counter()
         score = pbn.ValidatedLikelihood(df, 0.2, 10, 0)
         t_ctor = time.perf_counter() - t0
-        cpu_cfg = {"kind": "validated", "ratio": 0.2, "k": 10, "seed": 0, "rows": n_rows, "hybrid": True, "sample_rows_all": 30000, "sample_rows_one": 8000}
+        cpu_cfg = {"kind": "validated", "ratio": 0.2, "k": 10, "seed": 0, "rows": n_rows, "hybrid": True, "sample_rows_all": 60000, "sample_rows_one": 16000}
 
         def host(m, cols=cols, disc=disc, cards=cards):
             return ({k_: np.asarray(v_[:m], dtype=np.float64) for k_, v_ in cols.items()},
