@@ -827,20 +827,22 @@ def main():
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
-        # the collective really runs over `world` ranks of this backend: one all_reduce of ones (nccl: on the device = RCCL over xGMI)
-        ones = torch.ones(1, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(ones)
-        ranks_seen = int(round(float(ones.item())))
-        devs = [None] * world
-        dist.all_gather_object(devs, (rank, local_rank, torch.cuda.get_device_properties(local_rank).name))
-        dist.barrier()
-        sys.stdout.flush()
-        os.dup2(saved_fd, 1)
-        os.close(saved_fd)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group("gloo")
+            # the collective really runs over `world` ranks of this backend: one all_reduce of ones (nccl: on the device = RCCL over xGMI)
+            ones = torch.ones(1, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(ones)
+            ranks_seen = int(round(float(ones.item())))
+            devs = [None] * world
+            dist.all_gather_object(devs, (rank, local_rank, torch.cuda.get_device_properties(local_rank).name))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import pybnesian_amd as pbn
     from pybnesian_amd import _lib
