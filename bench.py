@@ -631,23 +631,12 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
     fast = baseline.kde_logl if full else baseline.product_kde_logl
     slow = oracle.kde_logl if full else oracle.product_kde_logl
     visible = baseline.num_threads()
-    quota = None   # a container may see every core and still be held to a CPU-time quota: more threads than that only thrash
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q_, per_ = f.read().split()[:2]
-            quota = None if q_ == "max" else float(q_) / float(per_)
-    except Exception:
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
-                q_ = float(f.read())
-                quota = None if q_ <= 0 else q_ / float(g.read())
-        except Exception:
-            pass
+    quota = cpu_quota()   # a container may see every core and still be held to a CPU-time quota: more threads than that only thrash
     try:
         affinity = len(os.sched_getaffinity(0))
     except Exception:
         affinity = None
-    cores = int(max(1, min(visible, affinity or visible, int(np.ceil(quota)) if quota else visible)))
+    cores = host_cores(visible)
     baseline.set_num_threads(cores)
     oracle.set_num_threads(cores)
     n_train = train_np.shape[0]
