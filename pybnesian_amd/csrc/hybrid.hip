@@ -416,9 +416,147 @@ double local_lg_slogl(const pbn_scoredata* sd, const Stats& test, const int* col
     return -0.5 * Nt * (std::log(variance) + LOG_2PI) - 0.5 * rss / variance;
 }
 
+struct Term { double value = 0; int slot = -1; };
+struct Slice { Term joint, marg; bool has_marg; int part; };
+// what a check-after redo needs, flat (one candidate makes ~100 terms, a search thousands of candidates: no per-term allocations): the
+// term's bandwidth and centre in `rstore`, its columns in `rcols`
+struct Redo { int slot, nv; size_t off, coff; int64_t N, r0, n0, r1, te0, nte; const int32_t* rows; };
+
 }  // namespace
 
-double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts) {
+// The CKDE candidates of one pbn_score_batch call that are in flight together (hill-climbing asks for the cells of a delta-cache update in
+// one call): their grouped pools join ONE kde_group_run - one keys / sort / pack / prepass / sweep / finish chain per arena-full of pools
+// instead of one per candidate - their small slices keep going round the issue lanes, and the host waits ONCE, at flush().  Result slots
+// are numbered across the batch; `scheduled` lets a later candidate of the batch share a term an earlier one already enqueued (the marginal
+// A({y}) of every child of y, the joint of x | {y} and y | {x}) exactly as the set-function cache does between batches.
+struct HybridBatch {
+    pbn_scoredata* sd;
+    pbn_ctx* ctx;
+    bool f32 = false;          // fp32 table with the check-after on: max-norm slots behind the sums
+    bool active = false;       // slots zeroed, candidates may enqueue
+    size_t capacity = 0;       // result slots of the batch (sums; the max-norms start at dsums + capacity)
+    double* dsums = nullptr;
+    double* dmax = nullptr;
+    int lanes = 1;
+    GroupBatch gb;
+    std::vector<std::vector<int>> slot_key;        // [slot] -> set-function cache key
+    std::map<std::vector<int>, int> scheduled;     // key -> slot, terms enqueued by this batch
+    std::vector<Redo> redo_info;
+    std::vector<double> rstore;
+    std::vector<int> rcols;
+    struct Job { std::vector<Slice> slices; bool has_parts; HybridParts parts; bool has_sink; HybridSink sink; };
+    std::vector<Job> jobs;
+    double last_value = 0;     // score of the last finished job (the synchronous form of score_hybrid)
+
+    HybridBatch(pbn_scoredata* s, bool f32_) : sd(s), ctx(s->ctx), f32(f32_) {}
+    ~HybridBatch() {           // abandoned with work in flight (an exception on the way): nothing may outlive the scratch it writes
+        if (active) {
+            ctx->sync_lanes(pbn_ctx::MAX_PARKED);
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->drop_staged();
+        }
+    }
+    // room for a candidate of up to max_slots terms (finishing what is in flight when the slots run out)
+    void begin_candidate(size_t max_slots) {
+        if (active && slot_key.size() + max_slots > capacity) flush();
+        if (!active) {
+            static const size_t min_slots = [] { const char* e = getenv("PBN_HYBRID_BATCH_SLOTS"); const long long v = (e && *e) ? atoll(e) : (1ll << 15); return (size_t)(v < 1 ? 1 : v); }();
+            capacity = std::max(std::max(capacity, max_slots), min_slots);
+            ctx->scratch_sums.reserve(2 * capacity);   // (grow-only; nothing of this batch is in flight here)
+            dsums = ctx->scratch_sums.p;
+            dmax = f32 ? dsums + capacity : nullptr;
+            HIP_CHECK(hipMemsetAsync(dsums, 0, 2 * capacity * sizeof(double), ctx->stream));
+            active = true;
+        }
+    }
+    size_t pool_bytes = 0;     // arena bytes of the pools collected since the last chain
+    // the collected pools' chain, enqueued without waiting for it: the device works on it while the host prepares the next candidates
+    void kick() {
+        if (gb.pools.empty()) return;
+        kde_group_run(ctx, sd->table(), gb, dsums, dmax);   // on the context's own stream, next to the lanes' per-slice chains
+        gb = GroupBatch{};
+        pool_bytes = 0;
+    }
+    void flush();
+};
+
+void HybridBatch::flush() {
+    if (!active) return;
+    const pbn_table* t = sd->table();
+    auto align = [](size_t x) { return (x + 255) / 256 * 256; };
+    auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
+    kick();
+    const size_t ns = slot_key.size();
+    std::vector<double> hs(std::max<size_t>(1, ns)), hmax(f32 ? ns : 0);
+    if (lanes > 1) ctx->sync_lanes(lanes - 1);
+    if (ns) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (f32 && ns) HIP_CHECK(hipMemcpyAsync(hmax.data(), dmax, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (f32) {   // check-after (score_hybrid): flagged evaluations once more, on fp64 fragments, through the per-slice chain
+        bool any = false;
+        for (const Redo& r : redo_info) {
+            if (!kde_wants_widening(hmax[(size_t)r.slot])) continue;
+            const int* v = rcols.data() + r.coff;
+            sd->widen_sets.insert(set_key(v, r.nv));
+            KdeModel m;
+            kde_prepare(m, sd->dtype, r.nv, r.N, rstore.data() + r.off, PBN_BW_FULL, false, rstore.data() + r.off + (size_t)r.nv * r.nv);
+            kde_widen(m);
+            const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, false, m.N);
+            ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
+            m.Apack = ctx->scratch_train.p;
+            m.nxpack = ctx->scratch_train.p + align(pb.apack);
+            m.Axpack = nullptr;
+            HIP_CHECK(hipMemsetAsync(dsums + r.slot, 0, sizeof(double), ctx->stream));
+            kde_pack_train(ctx, m, t, v, r.r0, r.n0, r.r1, r.rows, /*prune=*/true);
+            kde_eval_enqueue(ctx, m, t, v, r.te0, r.nte, nullptr, dsums + r.slot, r.rows);
+            ++sd->kde_sweeps;
+            any = true;
+        }
+        if (any) {
+            HIP_CHECK(hipMemcpyAsync(hs.data(), dsums, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    ctx->drop_staged();
+    active = false;
+    for (size_t i = 0; i < ns; ++i) sd->kde_cache[slot_key[i]] = hs[i];
+    for (const Job& j : jobs) {
+        // per-part sums in slice order, then the parts in part order: what a job with one process per GPU adds up, too
+        double pacc[PBN_HYBRID_PARTS] = {};
+        for (const Slice& sl : j.slices) {
+            const double jv = sl.joint.slot >= 0 ? hs[sl.joint.slot] : sl.joint.value;
+            const double mv = !sl.has_marg ? 0.0 : (sl.marg.slot >= 0 ? hs[sl.marg.slot] : sl.marg.value);
+            pacc[sl.part] += jv - mv;
+        }
+        double acc = 0;
+        for (int q = 0; q < PBN_HYBRID_PARTS; ++q) acc += pacc[q];
+        if (j.has_parts)
+            for (int q = 0; q < PBN_HYBRID_PARTS; ++q) j.parts.out[q] = pacc[q];
+        if (j.has_sink) {
+            *j.sink.out = acc;
+            if (!j.sink.memo_key.empty()) sd->score_memo[j.sink.memo_key] = acc;
+        }
+        last_value = acc;
+    }
+    jobs.clear();
+    slot_key.clear();
+    scheduled.clear();
+    redo_info.clear();
+    rstore.clear();
+    rcols.clear();
+    lanes = 1;
+}
+
+HybridBatch* hybrid_batch_begin(pbn_scoredata* sd) {
+    static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
+    return new HybridBatch(sd, sd->dtype == PBN_F32 && check_after);
+}
+void hybrid_batch_flush(HybridBatch* hb) { if (hb) hb->flush(); }
+void hybrid_batch_end(HybridBatch* hb) noexcept { delete hb; }
+
+double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts, HybridBatch* hb,
+                    const HybridSink* sink, bool* deferred) {
+    if (deferred) *deferred = false;
     const int n = sd->n;
     if (parts && (node_type != PBN_NODE_CKDE || var >= n || (kind != PBN_SCORE_CVLIK && kind != PBN_SCORE_HOLDOUT)))
         throw invalid_error("pbn_score_batch_parts: CKDE candidates of a likelihood score only");
@@ -518,34 +656,26 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     // kind, discrete parents, configuration]: the joint of x | {y} + D and of y | {x} + D is the same number, the marginal
     // A({y}) serves every child of y under D.  All sweeps of the candidate are enqueued back to back - gather lists are
     // device resident - with ONE synchronisation at the end.
-    struct Term { double value = 0; int slot = -1; };
-    struct Slice { Term joint, marg; bool has_marg; int part; };
     std::vector<Slice> slices;
-    std::vector<std::vector<int>> slot_key;
-    struct { double* p = nullptr; } dsums;   // slots in the context's scratch_sums (grow-only; no allocation per candidate)
     // fp32 tables: behind the sums, one slot per sum for |z|^2 of the farthest whitened training row of its evaluation (reported by the
     // pack kernels) - an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used, and its
     // continuous column set goes to fp64 fragments from then on (pbn_scoredata::widen_sets; scoring.hip does the same for plain terms)
-    static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
-    const bool f32 = sd->dtype == PBN_F32 && check_after;
     const size_t max_slots = (size_t)units * g.nc * 2 + 1;
-    // what a redo needs, flat (one candidate makes ~100 terms, a search thousands of candidates: no per-term allocations): the term's
-    // bandwidth and centre in `rstore`, its columns in `rcols`
-    struct Redo { int slot, nv; size_t off, coff; int64_t N, r0, n0, r1, te0, nte; };
-    std::vector<Redo> redo_info;
-    std::vector<double> rstore;
-    std::vector<int> rcols;
+    // the batch this candidate's evaluations join: the caller's (its score arrives at flush()), or one of its own, flushed below
+    std::unique_ptr<HybridBatch> own;
+    if (node_type == PBN_NODE_CKDE && !hb) { own.reset(hybrid_batch_begin(sd)); hb = own.get(); }
+    const bool f32 = node_type == PBN_NODE_CKDE && hb->f32;
+    struct { double* p = nullptr; } dsums;   // slots in the context's scratch_sums (grow-only; no allocation per candidate)
     if (node_type == PBN_NODE_CKDE) {
-        ctx->scratch_sums.reserve(2 * max_slots);
-        dsums.p = ctx->scratch_sums.p;
-        HIP_CHECK(hipMemsetAsync(dsums.p, 0, 2 * max_slots * sizeof(double), ctx->stream));
+        hb->begin_candidate(max_slots);
+        dsums.p = hb->dsums;
     }
-    double* const dmax = (f32 && node_type == PBN_NODE_CKDE) ? dsums.p + max_slots : nullptr;
+    double* const dmax = f32 ? hb->dmax : nullptr;
     std::vector<double> Hterm, muterm;   // bandwidth / centre of the term being built (reused)
     auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
     // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
     const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
-    if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
+    if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); hb->lanes = std::max(hb->lanes, lanes); }
     size_t issued = 0;
     auto key_of = [&](int region, int c, const int* v, int nv) {
         std::vector<int> k(v, v + nv);
@@ -697,18 +827,20 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             //  slices too small for the grouped path, a sliver of C5's time)
             const bool want_fused = fused_mode < 0 ? false : fused_mode != 0;
             const bool grouped_both = elig[(size_t)c * 2] && (pc == 0 || elig[(size_t)c * 2 + 1]);
-            if (pc > 0 && want_fused && !grouped_both && sd->kde_cache.find(key_of(u, c, cols.data(), d)) == sd->kde_cache.end() &&
-                sd->kde_cache.find(key_of(u, c, cols.data() + 1, pc)) == sd->kde_cache.end()) {
+            auto unknown = [&](const std::vector<int>& k) { return sd->kde_cache.find(k) == sd->kde_cache.end() && hb->scheduled.find(k) == hb->scheduled.end(); };
+            if (pc > 0 && want_fused && !grouped_both && unknown(key_of(u, c, cols.data(), d)) && unknown(key_of(u, c, cols.data() + 1, pc))) {
                 KdeModel m;
                 try {
                     kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
                 } catch (const singular_error&) {
                     continue;
                 }
-                sl.joint.slot = (int)slot_key.size();
-                slot_key.push_back(key_of(u, c, cols.data(), d));
-                sl.marg.slot = (int)slot_key.size();
-                slot_key.push_back(key_of(u, c, cols.data() + 1, pc));
+                sl.joint.slot = (int)hb->slot_key.size();
+                hb->slot_key.push_back(key_of(u, c, cols.data(), d));
+                hb->scheduled.emplace(hb->slot_key.back(), sl.joint.slot);
+                sl.marg.slot = (int)hb->slot_key.size();
+                hb->slot_key.push_back(key_of(u, c, cols.data() + 1, pc));
+                hb->scheduled.emplace(hb->slot_key.back(), sl.marg.slot);
                 const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
                 LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + align(pb.axpack) + 256);
@@ -734,6 +866,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 const std::vector<int> key = key_of(u, c, v, nv);
                 auto itc = sd->kde_cache.find(key);
                 if (itc != sd->kde_cache.end()) { term.value = itc->second; continue; }
+                auto its = hb->scheduled.find(key);   // enqueued by an earlier candidate of the batch: its slot
+                if (its != hb->scheduled.end()) { term.slot = its->second; continue; }
                 KdeModel m;
                 Ht.resize((size_t)nv * nv); mut.resize((size_t)nv);
                 try {
@@ -753,14 +887,15 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                     term.slot = -2;   // no factor for this slice
                     break;
                 }
-                term.slot = (int)slot_key.size();
-                slot_key.push_back(key);
+                term.slot = (int)hb->slot_key.size();
+                hb->slot_key.push_back(key);
+                hb->scheduled.emplace(key, term.slot);
                 const bool w64 = f32 && sd->widen_sets.count(set_key(v, nv)) != 0;   // a set already known to need fp64 fragments
                 if (f32 && !w64) {
-                    redo_info.push_back(Redo{term.slot, nv, rstore.size(), rcols.size(), tr->N, tr_row0, tr_n0, tr_row1, te0, te->N});
-                    rstore.insert(rstore.end(), Ht.begin(), Ht.end());
-                    rstore.insert(rstore.end(), mut.begin(), mut.end());
-                    rcols.insert(rcols.end(), v, v + nv);
+                    hb->redo_info.push_back(Redo{term.slot, nv, hb->rstore.size(), hb->rcols.size(), tr->N, tr_row0, tr_n0, tr_row1, te0, te->N, g.rows.p});
+                    hb->rstore.insert(hb->rstore.end(), Ht.begin(), Ht.end());
+                    hb->rstore.insert(hb->rstore.end(), mut.begin(), mut.end());
+                    hb->rcols.insert(hb->rcols.end(), v, v + nv);
                 }
                 if (elig[(size_t)c * 2 + which] && !w64) {   // evaluated with the candidate's other grouped slices, after the loops
                     group_unit(c, u, which, m, v, colidx, nv, tr->N, te->N, term.slot);
@@ -783,66 +918,23 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             slices.push_back(sl);
         }
     }
-    if (!gb.pools.empty()) {
-        for (size_t pi = 0; pi < gb.pools.size(); ++pi) {
-            gb.pools[pi].unit0 = (int32_t)gb.units.size();
-            gb.pools[pi].nunits = (int32_t)pool_units[pi].size();
-            gb.units.insert(gb.units.end(), pool_units[pi].begin(), pool_units[pi].end());
-        }
-        kde_group_run(ctx, t, gb, dsums.p, dmax);   // on the context's own stream, next to the lanes' per-slice chains
+    if (node_type != PBN_NODE_CKDE) return acc;
+    for (size_t pi = 0; pi < gb.pools.size(); ++pi) {   // the candidate's pools behind the batch's
+        gb.pools[pi].unit0 = (int32_t)hb->gb.units.size();
+        gb.pools[pi].nunits = (int32_t)pool_units[pi].size();
+        hb->gb.units.insert(hb->gb.units.end(), pool_units[pi].begin(), pool_units[pi].end());
+        hb->gb.pools.push_back(gb.pools[pi]);
+        hb->pool_bytes += kde_group_pool_bytes(hb->gb, hb->gb.pools.back());
     }
-    if (node_type == PBN_NODE_CKDE && !slices.empty()) {
-        const size_t ns = slot_key.size();
-        std::vector<double> hs(std::max<size_t>(1, ns)), hmax(f32 ? ns : 0);
-        if (lanes > 1) ctx->sync_lanes(lanes - 1);
-        if (ns) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (f32 && ns) HIP_CHECK(hipMemcpyAsync(hmax.data(), dmax, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (f32) {   // check-after (see above): flagged evaluations once more, on fp64 fragments, through the per-slice chain
-            bool any = false;
-            for (const Redo& r : redo_info) {
-                if (!kde_wants_widening(hmax[(size_t)r.slot])) continue;
-                const int* v = rcols.data() + r.coff;
-                sd->widen_sets.insert(set_key(v, r.nv));
-                KdeModel m;
-                kde_prepare(m, sd->dtype, r.nv, r.N, rstore.data() + r.off, PBN_BW_FULL, false, rstore.data() + r.off + (size_t)r.nv * r.nv);
-                kde_widen(m);
-                const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, false, m.N);
-                ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
-                m.Apack = ctx->scratch_train.p;
-                m.nxpack = ctx->scratch_train.p + align(pb.apack);
-                m.Axpack = nullptr;
-                HIP_CHECK(hipMemsetAsync(dsums.p + r.slot, 0, sizeof(double), ctx->stream));
-                kde_pack_train(ctx, m, t, v, r.r0, r.n0, r.r1, g.rows.p, /*prune=*/true);
-                kde_eval_enqueue(ctx, m, t, v, r.te0, r.nte, nullptr, dsums.p + r.slot, g.rows.p);
-                ++sd->kde_sweeps;
-                any = true;
-            }
-            if (any) {
-                HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            }
-        }
-        ctx->drop_staged();
-        for (size_t i = 0; i < slot_key.size(); ++i) sd->kde_cache[slot_key[i]] = hs[i];
-        // per-part sums in slice order, then the parts in part order: what a job with one process per GPU adds up, too
-        double pacc[PBN_HYBRID_PARTS] = {};
-        for (const Slice& sl : slices) {
-            const double jv = sl.joint.slot >= 0 ? hs[sl.joint.slot] : sl.joint.value;
-            const double mv = !sl.has_marg ? 0.0 : (sl.marg.slot >= 0 ? hs[sl.marg.slot] : sl.marg.value);
-            pacc[sl.part] += jv - mv;
-        }
-        for (int q = 0; q < PBN_HYBRID_PARTS; ++q) acc += pacc[q];
-        if (parts)
-            for (int q = 0; q < PBN_HYBRID_PARTS; ++q) parts->out[q] = pacc[q];
-    } else if (node_type == PBN_NODE_CKDE) {
-        if (lanes > 1) ctx->sync_lanes(lanes - 1);
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        ctx->drop_staged();
-        if (parts)
-            for (int q = 0; q < PBN_HYBRID_PARTS; ++q) parts->out[q] = 0.0;
+    if (hb->pool_bytes >= kde_group_arena_budget()) hb->kick();   // an arena-full: one chain's worth
+    HybridBatch::Job job{std::move(slices), parts != nullptr, parts ? *parts : HybridParts{0, 0, nullptr}, sink != nullptr, sink ? *sink : HybridSink{nullptr, {}}};
+    hb->jobs.push_back(std::move(job));
+    if (own) {   // synchronous form: this candidate alone
+        own->flush();
+        return own->last_value;
     }
-    return acc;
+    if (deferred) *deferred = true;
+    return 0.0;
 }
 
 }  // namespace score

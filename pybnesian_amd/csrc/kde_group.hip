@@ -613,7 +613,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     (void)table_end;
     const int64_t o_keys_a = carve((size_t)E * 4), o_keys_b = carve((size_t)E * 4), o_vals_a = carve((size_t)E * 4), o_vals_b = carve((size_t)E * 4),
                   o_xs = carve((size_t)E * xstride * 8), o_reg = carve((size_t)E), o_blkcnt = carve((size_t)B * Rs * 4);
-    ctx->scratch_group.reserve(off + 256);
+    if (off + 256 > ctx->scratch_group.n)   // grow in few, large steps (a hipFree + hipMalloc of gigabytes each)
+        ctx->scratch_group.reserve(std::max(off + 256, std::min(ctx->scratch_group.n * 2, kde_group_arena_budget() + (64u << 20))));
     char* arena = ctx->scratch_group.p;
 
     // ---- host tables -> one upload ---------------------------------------------------------------------------------------
@@ -732,6 +733,13 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
 
 }  // namespace
 
+// 16 GB of the 288: a hill-climb's delta-cache update hands over ~10 hybrid candidates at a time, ~1.6 GB of arena each at 1M rows (every row is
+// whitened once per unit it trains).  C5 (tools/hybrid_batch_probe.sh): 4 GB 7.89 s, 8 GB 7.77 s, 16 GB 7.73 s, 32 GB 7.65 s - or 8.97 s when the
+// allocation itself (hipMalloc of the grown arena) lands in the run; 16 GB keeps most of the gain at a quarter of the allocation
+size_t kde_group_arena_budget() { return (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 16384)) << 20; }
+
+size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P) { return pool_bytes(b, P, std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512))); }
+
 bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
     const int on = env_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
     // fp64 classic fragments; sets whose boxes cover every dimension (no subsample bound needed); the pruned-sweep shapes
@@ -757,7 +765,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     const bool bf16 = !force_f64 && use_bf16x3(t->dtype);
     auto variant = [&](int i) { const int d = b.pools[i].d; return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
-    const size_t budget = (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 4096)) << 20;
+    const size_t budget = kde_group_arena_budget();
     const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
     const int max_pools = std::min(256, std::max(1, env_int("PBN_GROUP_MAX_POOLS", 256)));
     size_t p0 = 0;

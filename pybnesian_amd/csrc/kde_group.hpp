@@ -76,6 +76,11 @@ struct GroupBatch {
 // kde_wants_widening() flags with force_f64 = true: fp64 fragments and fp64 sweeps on the float columns (KdeModel::widen).
 void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max = nullptr, bool force_f64 = false);
 
+// Arena bytes one chain may take (PBN_GROUP_ARENA_MB) and the bytes a pool with its units needs: a caller that collects pools over many
+// candidates hands them over about an arena-full at a time.
+size_t kde_group_arena_budget();
+size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P);
+
 // Whether a set of d variables over training sets of at least n_min rows takes this path.
 bool kde_group_applies(int dtype, int d, int64_t n_min, int R);
 

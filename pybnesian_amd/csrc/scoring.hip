@@ -782,6 +782,14 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
         }
         struct Pending { int cand; int unit0; int units; };
         std::vector<Pending> pending;
+        // hybrid CKDE candidates of this call go into one HybridBatch (hybrid.hip): enqueued as they come, finished together after the loop
+        static const bool hybrid_batched = [] { const char* e = getenv("PBN_HYBRID_BATCH"); return !(e && *e) || atoi(e) != 0; }();
+        std::unique_ptr<HybridBatch, void (*)(HybridBatch*) noexcept> hbatch(nullptr, hybrid_batch_end);
+        auto hybrid_batch = [&]() -> HybridBatch* {
+            if (!hybrid_batched) return nullptr;
+            if (!hbatch) hbatch.reset(hybrid_batch_begin(sd));
+            return hbatch.get();
+        };
         int n_units = 0;
         Stats train;
         std::vector<int> cols;
@@ -806,7 +814,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 // ones in canonical order: the value does not depend on the order they were given in).  BIC stays out: bic_clg ties.
                 if (parts_out) {   // a share of the candidate: never memoised
                     HybridParts hp{parts_rank, parts_world, parts_out + (size_t)c * PBN_HYBRID_PARTS};
-                    out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp);
+                    HybridSink sink{out + c, {}};
+                    out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp, hybrid_batch(), &sink);
                     continue;
                 }
                 const bool memo = score_memo_on() && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT);   // (discrete factors too: a count over all rows on the host each)
@@ -818,8 +827,10 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     auto it = sd->score_memo.find(key);
                     if (it != sd->score_memo.end()) { out[c] = it->second; ++sd->memo_hits; continue; }
                 }
-                out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p);
-                if (memo) sd->score_memo[key] = out[c];
+                HybridSink sink{out + c, key};   // (key empty without the memo)
+                bool deferred = false;
+                out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, nullptr, hybrid_batch(), &sink, &deferred);
+                if (memo && !deferred) sd->score_memo[key] = out[c];
                 continue;
             }
             mu.resize(d); sse.resize((size_t)d * d); beta.resize(d);
@@ -900,6 +911,8 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             pending.push_back({c, n_units, units});
             n_units += units;
         }
+        hybrid_batch_flush(hbatch.get());   // (before the plain CKDE units below take the context's result slots)
+        hbatch.reset();
         if (!pending.empty()) {
             // ---- CKDE likelihood units through the set-function cache ------------------------------------------------
             // slogl of a CKDE on a test region = A(vars, d) - A(parents, d), with A(S, m) = sum_q log KDE(S) under the

@@ -130,7 +130,20 @@ struct HybridParts {
     int rank, world;            // evaluate the parts dealt to `rank` of `world`
     double* out;                // [PBN_HYBRID_PARTS] per-part sums (0 for the parts not owned)
 };
-double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts = nullptr);
+// CKDE candidates of one pbn_score_batch call evaluated together (hybrid.hip: HybridBatch): score_hybrid(..., hb, sink, &deferred) enqueues
+// the candidate's sweeps and returns at once with *deferred = true; hybrid_batch_flush() runs the batch's one grouped chain, waits once and
+// delivers every pending score through its sink (and its per-part sums through `parts->out`, which must stay valid until then).  Without a
+// batch score_hybrid is synchronous.  hybrid_batch_end() frees the batch (waiting for whatever an exception left in flight).
+struct HybridSink {
+    double* out;                  // where the candidate's score goes
+    std::vector<int> memo_key;    // non-empty: also remembered in pbn_scoredata::score_memo under this key
+};
+struct HybridBatch;
+HybridBatch* hybrid_batch_begin(pbn_scoredata* sd);
+void hybrid_batch_flush(HybridBatch* hb);
+void hybrid_batch_end(HybridBatch* hb) noexcept;
+double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const int* parents, int p, const HybridParts* parts = nullptr,
+                    HybridBatch* hb = nullptr, const HybridSink* sink = nullptr, bool* deferred = nullptr);
 
 }  // namespace score
 }  // namespace pbn
