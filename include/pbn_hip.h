@@ -253,6 +253,11 @@ int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, con
  *   pbn_score_terms_missing  missing[i] = 1 where no total is installed. */
 int pbn_score_terms(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, double* out);
 int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, const double* values);
+/* One REGION of a term: out[i] = the part of term i's total that region[i] contributes (a CV fold 0 .. k-1 of pbn_scoredata_create; 0 for the
+ * hold-out score).  A term's total is its regions added in region order (cv_likelihood.cpp:18-22 adds the folds' slogl in fold order), so an
+ * update batch with fewer unknown terms than ranks is dealt (term, fold) by (term, fold), the per-region values gathered, added in region order
+ * by every rank and installed with pbn_score_terms_put: the same doubles as pbn_score_terms.  Totals installed earlier are not consulted. */
+int pbn_score_term_regions(pbn_scoredata* sd, int kind, int n_items, const int* off, const int* vars, const int* m, const int* region, double* out);
 int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int* off, const int* vars, const int* m, int* missing);
 /* CKDE candidates with discrete parents (DiscreteAdaptator.hpp:201-348: one CKDE per configuration of the discrete parents): the
  * slices (configuration c, test region u) of a candidate fall into 64 fixed parts, part = (c * regions + u) mod 64, and

@@ -83,6 +83,7 @@ SIGNATURES = {
     "pbn_score_batch": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp, _int, _dp]),
     "pbn_score_batch_parts": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _int, _int, _dp]),
     "pbn_score_terms": (_int, [_vp, _int, _int, _ip, _ip, _ip, _dp]),
+    "pbn_score_term_regions": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip, _dp]),
     "pbn_score_terms_put": (_int, [_vp, _int, _int, _ip, _ip, _ip, _dp]),
     "pbn_score_terms_missing": (_int, [_vp, _int, _int, _ip, _ip, _ip, _ip]),
     "pbn_lincor_create": (_int, [_vp, _vp, C.POINTER(_vp)]),

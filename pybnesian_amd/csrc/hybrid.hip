@@ -469,6 +469,7 @@ struct HybridBatch {
             active = true;
         }
     }
+    std::vector<double> deal_load;   // jobs with one process per GPU: cost dealt to every rank so far (score_hybrid: `owned`)
     size_t pool_bytes = 0;     // arena bytes of the pools collected since the last chain
     // the collected pools' chain, enqueued without waiting for it: the device works on it while the host prepares the next candidates
     void kick() {
@@ -762,12 +763,23 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             for (int c = 0; c < g.nc; ++c) {
                 const double ntr = (double)(cv ? allc[c].N - M[cell(c, u)].N : M[cell(c, 0)].N);
                 const double nte = (double)(cv ? M[cell(c, u)].N : M[cell(c, 1)].N);
-                cost[((int64_t)c * units + u) % PBN_HYBRID_PARTS] += ntr * nte;
+                // training rows a query meets, joint + marginal term: all of them in an unpruned sweep; in a pruned one the rows within the
+                // margin of the query, ~ N h^d = N^(4 / (d + 4)) under the normal-reference bandwidth (constants: profiles/r4/prune_visits.txt)
+                auto met = [&](int dd, int which) {
+                    if (dd < 1) return 0.0;
+                    static const double cd[5] = {0, 4.6, 18.0, 67.0, 243.0};
+                    if (dd > 4 || !elig[(size_t)c * 2 + which]) return ntr;
+                    return std::min(ntr, cd[dd] * std::pow(ntr, 4.0 / (dd + 4.0)));
+                };
+                cost[((int64_t)c * units + u) % PBN_HYBRID_PARTS] += nte * (met(d, 0) + met(pc, 1));
             }
         int order[PBN_HYBRID_PARTS];
         for (int q = 0; q < PBN_HYBRID_PARTS; ++q) order[q] = q;
         std::stable_sort(order, order + PBN_HYBRID_PARTS, [&](int a, int b) { return cost[a] > cost[b]; });
-        std::vector<double> load((size_t)parts->world, 0.0);
+        // the ranks' loads carry over from the batch's earlier candidates: ten equal folds dealt to eight ranks leave two of them with
+        // double work, and the next candidate's parts then go to the other six first
+        std::vector<double>& load = hb->deal_load;
+        if (load.size() != (size_t)parts->world) load.assign((size_t)parts->world, 0.0);
         owned = 0;
         for (int i = 0; i < PBN_HYBRID_PARTS; ++i) {
             const int q = order[i];

@@ -733,10 +733,11 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
 
 }  // namespace
 
-// 16 GB of the 288: a hill-climb's delta-cache update hands over ~10 hybrid candidates at a time, ~1.6 GB of arena each at 1M rows (every row is
-// whitened once per unit it trains).  C5 (tools/hybrid_batch_probe.sh): 4 GB 7.89 s, 8 GB 7.77 s, 16 GB 7.73 s, 32 GB 7.65 s - or 8.97 s when the
-// allocation itself (hipMalloc of the grown arena) lands in the run; 16 GB keeps most of the gain at a quarter of the allocation
-size_t kde_group_arena_budget() { return (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 16384)) << 20; }
+// 8 GB of the 288: a hill-climb's delta-cache update hands over ~10 hybrid candidates at a time, ~1.6 GB of arena each at 1M rows (every row is
+// whitened once per unit it trains, every query keeps a partial per training split).  C5 alone (tools/hybrid_batch_probe.sh): 4 GB 7.89 s,
+// 8 GB 7.77 s, 16 GB 7.73 s, 32 GB 7.65 s - but the hipMalloc of a 16 GB arena in a process that has used the memory before costs 0.4 s
+// (tools/arena_bench_probe.sh: the bench line's 0.62 s cv_weak leg became 1.00 s), so the default stops at 8
+size_t kde_group_arena_budget() { return (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 8192)) << 20; }
 
 size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P) { return pool_bytes(b, P, std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512))); }
 

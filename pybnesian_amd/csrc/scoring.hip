@@ -748,11 +748,12 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
 
 // `want` (nullable, per candidate): 0 = the local score; 1 / 2 = only the joint / only the marginal CKDE term of the candidate, summed
 // over the regions (pbn_score_terms)
+// `only_region` (nullable, per candidate; pbn_score_term_regions): >= 0 = that region's contribution alone (a CV fold; 0 for the hold-out score)
 // `parts_rank` / `parts_world` / `parts_out` (pbn_score_batch_parts): hybrid CKDE candidates evaluated on one rank's parts only, per-part sums to
 // parts_out[c * PBN_HYBRID_PARTS ...]
 static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                             const int* parents, const double* params, int n_params, double* out, const int* want,
-                            int parts_rank = 0, int parts_world = 0, double* parts_out = nullptr) {
+                            int parts_rank = 0, int parts_world = 0, double* parts_out = nullptr, const int* only_region = nullptr) {
     return guarded(mu_of(sd), [&] {
         if (!sd || !var || !par_off || !out) throw invalid_error("pbn_score_batch: null argument");
         pbn_ctx* ctx = sd->ctx;
@@ -783,7 +784,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
         struct Pending { int cand; int unit0; int units; };
         std::vector<Pending> pending;
         // hybrid CKDE candidates of this call go into one HybridBatch (hybrid.hip): enqueued as they come, finished together after the loop
-        static const bool hybrid_batched = [] { const char* e = getenv("PBN_HYBRID_BATCH"); return !(e && *e) || atoi(e) != 0; }();
+        const bool hybrid_batched = [] { const char* e = getenv("PBN_HYBRID_BATCH"); return !(e && *e) || atoi(e) != 0; }();   // (per call: the tests switch it)
         std::unique_ptr<HybridBatch, void (*)(HybridBatch*) noexcept> hbatch(nullptr, hybrid_batch_end);
         auto hybrid_batch = [&]() -> HybridBatch* {
             if (!hybrid_batched) return nullptr;
@@ -946,7 +947,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             struct Unit { int cand; Term joint, marg; bool has_marg; int want; };
             // a term whose total over the regions was installed (pbn_score_terms_put): the total stands for region 0, the others add 0
             auto lookup_total = [&](int m, const int* v, int nv, int region_index, Term& t) {
-                if (sd->term_total.empty()) return false;
+                if (sd->term_total.empty() || only_region) return false;   // (one region of a term: never its total)
                 std::vector<int> k(v, v + nv);
                 std::sort(k.begin(), k.end());
                 k.insert(k.begin(), {kind, m});   // a validated score asks one handle for both kinds
@@ -971,6 +972,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 cols[0] = var[c];
                 for (int i = 0; i < p; ++i) cols[i + 1] = parents[par_off[c] + i];
                 for (int f = 0; f < pd.units; ++f) {
+                    if (only_region && only_region[c] >= 0 && f != only_region[c]) continue;
                     const int region = cv ? f : sd->k;                    // fold index, or the hold-out region
                     const int wnt = want ? want[c] : 0;
                     Unit u{c, {}, {}, wnt == 3 || (p > 0 && wnt != 1), wnt};
@@ -1268,6 +1270,30 @@ int pbn_score_terms(pbn_scoredata* sd, int kind, int n_terms, const int* off, co
         if (n_terms > 0) {
             const int rc = score_batch_impl(sd, kind, n_terms, var.data(), nt.data(), po.data(), par.data(), nullptr, 0, out, want.data());
             // the inner status class goes out unchanged: a SingularCovarianceData of a term is one on every rank, not a device error
+            if (rc == PBN_ERR_SINGULAR) throw singular_error(pbn_last_error());
+            if (rc == PBN_ERR_INVALID) throw invalid_error(pbn_last_error());
+            if (rc != PBN_OK) throw device_error(pbn_last_error());
+        }
+    });
+}
+
+int pbn_score_term_regions(pbn_scoredata* sd, int kind, int n_items, const int* off, const int* vars, const int* m, const int* region, double* out) {
+    return guarded(mu_of(sd), [&] {
+        check_terms(sd, kind, n_items, off, vars, m, "pbn_score_term_regions");
+        if (n_items > 0 && (!out || !region)) throw invalid_error("pbn_score_term_regions: null argument");
+        const int regions = kind == PBN_SCORE_CVLIK ? sd->k : 1;
+        std::vector<int> var((size_t)n_items), nt((size_t)n_items, PBN_NODE_CKDE), po{0}, par, want((size_t)n_items);
+        for (int i = 0; i < n_items; ++i) {
+            if (region[i] < 0 || region[i] >= regions) throw invalid_error("pbn_score_term_regions: region out of range (CV folds; 0 for the hold-out score)");
+            const int nv = off[i + 1] - off[i];
+            const int* v = vars + off[i];
+            var[i] = v[0];
+            want[i] = m[i] == nv ? 1 : 3;   // as in pbn_score_terms
+            par.insert(par.end(), v + 1, v + nv);
+            po.push_back((int)par.size());
+        }
+        if (n_items > 0) {
+            const int rc = score_batch_impl(sd, kind, n_items, var.data(), nt.data(), po.data(), par.data(), nullptr, 0, out, want.data(), 0, 0, nullptr, region);
             if (rc == PBN_ERR_SINGULAR) throw singular_error(pbn_last_error());
             if (rc == PBN_ERR_INVALID) throw invalid_error(pbn_last_error());
             if (rc != PBN_OK) throw device_error(pbn_last_error());

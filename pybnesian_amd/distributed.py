@@ -61,6 +61,10 @@ def _all_gather(dist, buf):
 _KDE_MS = {1: 15.5, 2: 11.1, 3: 12.8, 4: 19.7, 5: 36.3, 6: 45.4, 7: 50.7}
 
 
+# batches with fewer unknown terms than this many per rank are dealt by (term, fold) instead of by term (sharded_batch)
+_SPLIT_TERMS_BELOW = 4
+
+
 def _kde_cost(d):
     return _KDE_MS.get(d, 51.6 + 5.0 * max(0, d - 8)) if d >= 1 else 0.0
 
@@ -177,7 +181,33 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
                     terms.append(key)
         missing = score._terms("missing", kind, terms)
         todo = [t for t, mflag in zip(terms, missing) if mflag]
-        if todo:
+        regions = score._term_regions(kind) if hasattr(score, "_term_regions") else 1
+        if todo and regions > 1 and len(todo) < _SPLIT_TERMS_BELOW * world:
+            # an update batch of a search: a handful of terms, fewer than ranks or not many more - dealt whole, five terms leave three
+            # of eight ranks idle and two with double work.  Dealt (term, fold) by (term, fold) instead: a term's total is its folds
+            # added in fold order, so the per-fold values are gathered and every rank adds them in that order - the one-process double.
+            items = [(j, f) for j in range(len(todo)) for f in range(regions)]
+            cost = [_kde_cost(len(todo[j]) - 1) for j, _ in items]
+            order = sorted(range(len(items)), key=lambda i: (-cost[i], i))
+            load, lists = [0.0] * world, [[] for _ in range(world)]
+            for i in order:
+                r = min(range(world), key=lambda q: (load[q], q))
+                lists[r].append(i)
+                load[r] += cost[i]
+            vals = _gather_shares(dist, world, rank, lists, lambda idx: score._terms("eval_regions", kind, [todo[items[i][0]] for i in idx],
+                                                                                     regions=[items[i][1] for i in idx]), "sharded_batch")
+            per = np.zeros((len(todo), regions))
+            for r in range(world):
+                for i, v in zip(lists[r], np.asarray(vals[r], dtype=np.float64)):
+                    per[items[i][0], items[i][1]] = v
+            totals = []
+            for j in range(len(todo)):
+                acc = 0.0
+                for x in per[j].tolist():   # the folds in order, as the engine adds them
+                    acc += x
+                totals.append(acc)
+            score._terms("put", kind, todo, np.asarray(totals))
+        elif todo:
             lists = _deal([(t[1:], 0) for t in todo], world)
             vals = _gather_shares(dist, world, rank, lists, lambda idx: score._terms("eval", kind, [todo[j] for j in idx]), "sharded_batch")
             flat_t = [todo[j] for r in range(world) for j in lists[r]]

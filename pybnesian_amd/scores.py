@@ -299,11 +299,15 @@ class _DeviceScore(Score):
                                                          _lib.int_array(par if par else [0]), int(part), int(n_parts), _lib.dptr(out)))
         return out
 
-    def _terms(self, what, kind, terms, values=None):
+    def _term_regions(self, kind):
+        """Regions a term of this score adds up: the CV folds, or the one hold-out region."""
+        return int(getattr(self, "_k", 1)) if kind == _lib.PBN_SCORE_CVLIK else 1
+
+    def _terms(self, what, kind, terms, values=None, regions=None):
         """The CKDE likelihood terms of the engine (pbn_score_terms*): terms = [(m, column, column, ...)] over continuous column ids.
-        what = "eval" -> totals, "missing" -> flags, "put" -> install `values`."""
+        what = "eval" -> totals, "missing" -> flags, "put" -> install `values`, "eval_regions" -> item i = region regions[i] of terms[i]."""
         if not terms:
-            return np.zeros(0) if what == "eval" else []
+            return np.zeros(0) if what in ("eval", "eval_regions") else []
         off, vs, ms = [0], [], []
         for t in terms:
             ms.append(int(t[0]))
@@ -314,6 +318,10 @@ class _DeviceScore(Score):
         if what == "eval":
             out = np.zeros(n)
             _lib.check(lib.pbn_score_terms(*args, _lib.dptr(out)))
+            return out
+        if what == "eval_regions":
+            out = np.zeros(n)
+            _lib.check(lib.pbn_score_term_regions(*args, _lib.int_array([int(r) for r in regions]), _lib.dptr(out)))
             return out
         if what == "missing":
             flags = (C.c_int * n)()

@@ -65,4 +65,9 @@ for dtype in ("float64", "float32"):
     cands = [("c2", pbn.CKDEType(), ["c1", "d1"]), ("c4", pbn.CKDEType(), ["d2", "c2", "d3"]), ("c3", pbn.LinearGaussianCPDType(), ["d3", "c1"]),
              ("c1", pbn.CKDEType(), ["d1"]), ("d2", pbn.DiscreteFactorType(), ["d1", "d3"]), ("c2", pbn.LinearGaussianCPDType(), ["d1", "d2", "c1", "c3"])]
     out[f"hybrid_{dtype}"] = [hs.local_score_node_type(hnet, t, v, p) for v, t, p in cands]
+    # the same candidates - and some that share terms with them, one of them twice - as ONE batch of a fresh engine: their slices go
+    # through one grouped chain (PBN_HYBRID_BATCH=0: one chain per candidate)
+    hb = pbn.CVLikelihood(hdf, 4, 1)
+    more = [("c1", pbn.CKDEType(), ["c2", "d1"]), ("c2", pbn.CKDEType(), ["d1", "c1"]), ("c3", pbn.CKDEType(), ["d1"]), ("c4", pbn.CKDEType(), ["c1", "d1"])]
+    out[f"hybrid_batch_{dtype}"] = [float(x) for x in hb._batch(hnet, [(v, t, p) for v, t, p in cands + more], hb._kind)]
 print("RESULT " + json.dumps(out))

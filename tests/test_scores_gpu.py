@@ -653,6 +653,23 @@ def test_ckde_terms_are_the_halves_of_the_local_score(pbn, kind):
     assert other.kde_cache_stats()[1] == before        # assembled from the installed totals: not one sweep
     with pytest.raises(ValueError, match="term"):
         fresh._terms("eval", code, [(4, col["a"], col["b"])])
+    # pbn_score_term_regions: a term's total is its regions (CV folds; one hold-out region) added in region order - evaluated one region
+    # at a time, in any order, by a handle that has seen nothing else
+    regions = fresh._term_regions(code)
+    assert regions == (4 if kind == "cv" else 1)
+    single = make()
+    items = [(t, f) for f in reversed(range(regions)) for t in terms]
+    got = single._terms("eval_regions", code, [t for t, _ in items], regions=[f for _, f in items])
+    per = {}
+    for (t, f), v in zip(items, got):
+        per[(t, f)] = v
+    for t, total in zip(terms, vals):
+        acc = 0.0
+        for f in range(regions):
+            acc += per[(t, f)]
+        assert acc == total, t
+    with pytest.raises(ValueError, match="region"):
+        single._terms("eval_regions", code, [terms[0]], regions=[regions])
 
 
 def test_marginal_terms_do_not_depend_on_an_unrelated_column(pbn):

@@ -11,7 +11,8 @@ compared with the default run:
  * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_FULL_BUDGET_MB=0 (their cache
    budget exhausted: the same fallback), PBN_MI_THREADS=1;
  * PBN_GRAM_LDS=1 / 0 (the older Gram kernels), PBN_MI_GRAM_ORDER=0 / 1 (launch order of a grouping's Gram pieces);
- * PBN_HYBRID_FULLMOMENTS=0, PBN_HYBRID_FUSED=1, PBN_HYBRID_SEGMENTED=0, PBN_SCORE_MEMO=0 (hybrid candidates)."""
+ * PBN_HYBRID_FULLMOMENTS=0, PBN_HYBRID_FUSED=1, PBN_HYBRID_SEGMENTED=0, PBN_SCORE_MEMO=0 (hybrid candidates); PBN_HYBRID_BATCH=0
+   (the hybrid candidates of a batch one by one instead of in one chain)."""
 import json
 import os
 import subprocess
@@ -96,6 +97,18 @@ def test_hybrid_score_switches(default, env):
     assert close(got["hybrid_float32"], default["hybrid_float32"], 1e-4)
     if env == {"PBN_SCORE_MEMO": "0"}:
         assert got["hybrid_float64"] == default["hybrid_float64"]      # the memo returns what a fresh evaluation gives
+
+
+def test_hybrid_candidates_batched_or_one_by_one_are_bit_identical(default):
+    """PBN_HYBRID_BATCH=0 finishes every hybrid candidate before the next is prepared; the default enqueues the candidates of a
+    pbn_score_batch call together (one grouped chain, one wait, terms shared inside the batch).  Every term is the same evaluation
+    either way - and the same as when each candidate is asked for on its own."""
+    got = run({"PBN_HYBRID_BATCH": "0"})
+    for dtype in ("float64", "float32"):
+        assert got[f"hybrid_batch_{dtype}"] == default[f"hybrid_batch_{dtype}"], dtype
+        n = len(default[f"hybrid_{dtype}"])
+        assert default[f"hybrid_batch_{dtype}"][:n] == default[f"hybrid_{dtype}"], dtype
+        assert default[f"hybrid_batch_{dtype}"][0] == default[f"hybrid_batch_{dtype}"][n + 1], dtype   # c2 | {c1, d1} twice (parents in another order)
 
 
 @pytest.mark.parametrize("order", ["0", "1"])
