@@ -190,22 +190,35 @@ class _FakeEngineScore:
     class _T:
         names = ["a", "b", "c", "d"]
 
-    def __init__(self):
+    def __init__(self, regions=1):
         self._table = self._T()
-        self.totals, self.evaluated, self.part_calls, self.raw_calls = {}, [], [], 0
+        self.regions = regions
+        self.totals, self.evaluated, self.region_items, self.part_calls, self.raw_calls = {}, [], [], [], 0
+
+    def _term_regions(self, kind):
+        return self.regions
 
     @staticmethod
-    def _a(kind, term):
+    def _a_region(kind, term, f):
         m, vs = term[0], sorted(term[1:])
-        return float(np.sin(1.0 + kind + 0.37 * m + sum((i + 1) * 0.913 * (v + 1) for i, v in enumerate(vs))) * 1e3)
+        return float(np.sin(1.0 + kind + 0.37 * m + 1.7 * f + sum((i + 1) * 0.913 * (v + 1) for i, v in enumerate(vs))) * 1e3)
+
+    def _a(self, kind, term):
+        acc = 0.0
+        for f in range(self.regions):   # a term's total: its regions added in region order
+            acc += self._a_region(kind, term, f)
+        return acc
 
     @staticmethod
     def _part(kind, v, ps, q):
         return float(np.cos(0.1 * q + kind + v + 0.77 * sum(ps))) if q % 5 else 0.0
 
-    def _terms(self, what, kind, terms, values=None):
+    def _terms(self, what, kind, terms, values=None, regions=None):
         if what == "missing":
             return [0 if (kind,) + tuple([t[0]] + sorted(t[1:])) in self.totals else 1 for t in terms]
+        if what == "eval_regions":
+            self.region_items += [(kind,) + tuple([t[0]] + sorted(t[1:])) + (-1, f) for t, f in zip(terms, regions)]
+            return np.array([self._a_region(kind, t, f) for t, f in zip(terms, regions)])
         if what == "eval":
             self.evaluated += [(kind,) + tuple([t[0]] + sorted(t[1:])) for t in terms]
             return np.array([self._a(kind, t) for t in terms])
@@ -244,34 +257,38 @@ _BATCH = dict(var=[0, 1, 2, 3, 0, 1, 2, 3, 0, 4, 2, 1], ntype=[1, 1, 1, 1, 1, 1,
               off=[0, 0, 1, 3, 4, 6, 8, 9, 11, 12, 13, 16, 17], par=[0, 0, 1, 0, 1, 4, 2, 5, 3, 4, 5, 2, 5, 0, 4, 3, 4])
 
 
-def _term_worker(rank, world, port, queue):
+def _term_worker(rank, world, port, queue, regions=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from pybnesian_amd import _lib
+        from pybnesian_amd import _lib, distributed
         from pybnesian_amd.distributed import sharded_batch
 
-        s = _FakeEngineScore()
+        if regions > 1:
+            distributed._SPLIT_TERMS_BELOW = 100   # this batch's dozen terms count as "few": dealt (term, fold) by (term, fold)
+        s = _FakeEngineScore(regions)
         first = sharded_batch(s, None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK)
         again = sharded_batch(s, None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK)   # every term known now
-        queue.put((rank, first.tolist(), again.tolist(), s.evaluated, s.part_calls))
+        queue.put((rank, first.tolist(), again.tolist(), s.evaluated + s.region_items, s.part_calls))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_batch_deals_terms_and_slices_world2(ensure_built):
+@pytest.mark.parametrize("regions", [1, 3])
+def test_sharded_batch_deals_terms_and_slices_world2(ensure_built, regions):
     """distributed.sharded_batch with an engine score: continuous CKDE candidates by TERM (each unknown term evaluated on exactly one
-    rank, totals installed everywhere, nothing evaluated again), hybrid CKDE candidates by SLICE (every rank its parts of every
-    candidate), the rest redundantly - and every rank returns the one-process values bit for bit."""
+    rank, totals installed everywhere, nothing evaluated again) - or, for a batch of few terms over several folds (regions = 3), by
+    (term, fold): each pair on exactly one rank, the folds added in fold order everywhere; hybrid CKDE candidates by SLICE (every rank
+    its parts of every candidate), the rest redundantly - and every rank returns the one-process values bit for bit."""
     from pybnesian_amd import _lib
 
     world = 2
-    ref = _FakeEngineScore()._batch_raw(None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK).tolist()
+    ref = _FakeEngineScore(regions)._batch_raw(None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK).tolist()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_term_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_term_worker, args=(r, world, port, q, regions)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=120) for _ in range(world))
@@ -291,4 +308,8 @@ def test_sharded_batch_deals_terms_and_slices_world2(ensure_built):
             if ps:
                 terms.add((_lib.PBN_SCORE_CVLIK, len(ps) + 1) + tuple(sorted(ps)))
     assert len(terms) >= 6
-    assert len(evaluated) == len(set(evaluated)) and set(evaluated) == terms      # each term once, on one rank, in the first batch only
+    if regions > 1:
+        terms = {t + (-1, f) for t in terms for f in range(regions)}
+        per_rank = [len(ev) for _, _, _, ev, _ in results]
+        assert max(per_rank) - min(per_rank) <= 2                                 # (term, fold) pairs of equal cost: dealt evenly
+    assert len(evaluated) == len(set(evaluated)) and set(evaluated) == terms      # each term (or pair) once, on one rank, in the first batch only
