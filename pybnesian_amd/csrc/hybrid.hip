@@ -457,8 +457,10 @@ struct HybridBatch {
         }
     }
     // room for a candidate of up to max_slots terms (finishing what is in flight when the slots run out)
-    void begin_candidate(size_t max_slots) {
+    // -> true when the slots were zeroed just now (on the context's stream: the issue lanes have to wait for that, and for nothing else)
+    bool begin_candidate(size_t max_slots) {
         if (active && slot_key.size() + max_slots > capacity) flush();
+        const bool fresh = !active;
         if (!active) {
             static const size_t min_slots = [] { const char* e = getenv("PBN_HYBRID_BATCH_SLOTS"); const long long v = (e && *e) ? atoll(e) : (1ll << 15); return (size_t)(v < 1 ? 1 : v); }();
             capacity = std::max(std::max(capacity, max_slots), min_slots);
@@ -468,6 +470,7 @@ struct HybridBatch {
             HIP_CHECK(hipMemsetAsync(dsums, 0, 2 * capacity * sizeof(double), ctx->stream));
             active = true;
         }
+        return fresh;
     }
     std::vector<double> deal_load;   // jobs with one process per GPU: cost dealt to every rank so far (score_hybrid: `owned`)
     size_t pool_bytes = 0;     // arena bytes of the pools collected since the last chain
@@ -667,8 +670,9 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     if (node_type == PBN_NODE_CKDE && !hb) { own.reset(hybrid_batch_begin(sd)); hb = own.get(); }
     const bool f32 = node_type == PBN_NODE_CKDE && hb->f32;
     struct { double* p = nullptr; } dsums;   // slots in the context's scratch_sums (grow-only; no allocation per candidate)
+    bool fresh_slots = false;
     if (node_type == PBN_NODE_CKDE) {
-        hb->begin_candidate(max_slots);
+        fresh_slots = hb->begin_candidate(max_slots);
         dsums.p = hb->dsums;
     }
     double* const dmax = f32 ? hb->dmax : nullptr;
@@ -676,7 +680,12 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
     // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
     const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
-    if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); hb->lanes = std::max(hb->lanes, lanes); }
+    if (lanes > 1) {
+        ctx->ensure_lanes(lanes - 1);
+        // (not per candidate: a lane that waited for the stream again would also wait for the grouped chains handed over since)
+        if (fresh_slots || lanes > hb->lanes) ctx->lanes_wait_for_stream(lanes - 1);
+        hb->lanes = std::max(hb->lanes, lanes);
+    }
     size_t issued = 0;
     auto key_of = [&](int region, int c, const int* v, int nv) {
         std::vector<int> k(v, v + nv);
