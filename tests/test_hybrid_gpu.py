@@ -257,6 +257,36 @@ def test_hybrid_ckde_parts_add_up_to_the_local_score(pbn, dtype, kind):
         ref._batch_parts(net, [0], [_lib.PBN_NODE_CKDE], [0, 1], [1], code, 0, 2)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_a_failing_candidate_does_not_poison_the_batch_engine(pbn, dtype):
+    """The hybrid candidates of a pbn_score_batch call are in flight together (hybrid.hip: HybridBatch).  A call whose LAST candidate is
+    invalid fails as a whole - after the earlier candidates' sweeps were enqueued - and must leave nothing behind: the same handle then
+    scores the valid candidates to the bits a fresh handle gives."""
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(5)
+    n = 9000
+    d1 = rng.integers(0, 3, size=n)
+    x = rng.normal(size=n) + 0.5 * d1
+    y = np.cos(x) + 0.3 * d1 + rng.normal(scale=0.5, size=n)
+    z = 0.5 * y + rng.normal(scale=0.7, size=n)
+    df = pd.DataFrame({"x": x, "y": y, "z": z}).astype(dtype)
+    df["d1"] = pd.Categorical.from_codes(d1, ["a", "b", "c"])
+    net = pbn.SemiparametricBN(list(df.columns), [], [(v, pbn.CKDEType()) for v in "xyz"])
+    good = [("y", pbn.CKDEType(), ["x", "d1"]), ("z", pbn.CKDEType(), ["y", "d1"]), ("x", pbn.CKDEType(), ["d1"])]
+    fresh = pbn.CVLikelihood(df, k=4, seed=2)
+    want = fresh._batch(net, good, fresh._kind).tolist()
+    score = pbn.CVLikelihood(df, k=4, seed=2)
+    var, ntype, off, par = score._encode(good)
+    col = score._col
+    # a discrete column asked for as a CKDE node: rejected by the engine after the three good candidates were enqueued
+    bad = (var + [col["d1"]], ntype + [_lib.PBN_NODE_CKDE], off + [off[-1] + 1], par + [col["x"]])
+    with pytest.raises(ValueError, match="discrete column"):
+        score._batch_raw(net, *bad, score._kind)
+    assert score._batch(net, good, score._kind).tolist() == want
+    assert [score.local_score_node_type(net, t, v, p) for v, t, p in good] == want
+
+
 @pytest.mark.parametrize("node_type", ["lg", "ckde"])
 def test_hybrid_candidate_with_20_continuous_parents(pbn, oracle, node_type):
     """A child of one discrete and 20 continuous parents (DiscreteAdaptator slices over 21 continuous columns): the per-cell Gram

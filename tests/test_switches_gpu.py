@@ -111,6 +111,17 @@ def test_hybrid_candidates_batched_or_one_by_one_are_bit_identical(default):
         assert default[f"hybrid_batch_{dtype}"][0] == default[f"hybrid_batch_{dtype}"][n + 1], dtype   # c2 | {c1, d1} twice (parents in another order)
 
 
+@pytest.mark.parametrize("env", [{"PBN_HYBRID_BATCH_SLOTS": "8"}, {"PBN_GROUP_ARENA_MB": "64"}])
+def test_hybrid_batch_cut_by_its_slots_or_its_arena_is_bit_identical(default, env):
+    """A batch that runs out of result slots finishes what is in flight and starts over; one whose pools exceed the arena budget hands
+    them over early.  Neither changes a bit of any score (the 64 MB arena also cuts the plain engine's chains)."""
+    got = run(env)
+    for dtype in ("float64", "float32"):
+        assert got[f"hybrid_batch_{dtype}"] == default[f"hybrid_batch_{dtype}"], dtype
+        assert got[f"hybrid_{dtype}"] == default[f"hybrid_{dtype}"], dtype
+        assert got[f"cv_ckde_{dtype}"] == default[f"cv_ckde_{dtype}"], dtype
+
+
 @pytest.mark.parametrize("order", ["0", "1"])
 def test_grouping_gram_launch_order_is_bit_identical(default, order):
     """PBN_MI_GRAM_ORDER: the pieces of a grouping's Gram in configuration-major / stripe-major order instead of the XCD-aligned
