@@ -1,6 +1,7 @@
 """Shape fuzz of the multi-GPU building blocks on one GPU: (1) pbn_score_terms - A(joint) - A(marginal) of random CKDE candidates is the local
 score bit for bit, and totals installed in a fresh handle reproduce it without a sweep; (2) pbn_score_batch_parts - the per-part sums of random
 hybrid CKDE candidates, split over a random number of ranks, added over the ranks and then in part order, are the local score bit for bit; (3) a local score is a function of (variable, parent set): another order of evaluation / of the parents, same bits.
+(4) pbn_score_term_regions - a term's regions, evaluated in any order, add up to its total in region order; (5) hybrid candidates as one batch = one by one.
 Random rows, dimensions, dtypes, fold counts / hold-out ratios, cardinalities.     python3 tools/fuzz_sharding.py [cases, default 30] [seed]"""
 import os, sys, time
 import numpy as np
@@ -55,6 +56,21 @@ for case in range(cases):
     got = [dst.local_score(net, cont[v], [cont[q] for q in ps]) for v, ps in cands]
     if got != want or dst.kde_cache_stats()[1] != before:
         bad += 1; print("MISMATCH installed totals", case, n, nc, dtype, got, want)
+    # ---- (1c) a term's total = its regions (pbn_score_term_regions) added in region order, evaluated in a random order on a fresh handle
+    regions = src._term_regions(code)
+    items = [(i, f) for i in range(len(terms)) for f in range(regions)]
+    rng.shuffle(items)
+    reg = make(df)
+    rv = reg._terms("eval_regions", code, [terms[i] for i, _ in items], regions=[f for _, f in items])
+    per = np.zeros((len(terms), regions))
+    for (i, f), v in zip(items, rv):
+        per[i, f] = v
+    for i in range(len(terms)):
+        acc = 0.0
+        for x in per[i].tolist():
+            acc += x
+        if acc != vals[i]:
+            bad += 1; print("MISMATCH regions", case, n, nc, dtype, "cv" if cv else "holdout", terms[i], acc, vals[i])
     # ---- (1b) a score is a function of (variable, parent SET): another order of evaluation and of the parents gives the same bits
     other = make(df)
     for (v, ps), w in reversed(list(zip(cands, want))):
@@ -97,6 +113,10 @@ for case in range(cases):
             print("   the candidate alone on a fresh handle:", alone, "| in the list after the others:", w, "| candidates:", hc)
             print("   parts differing between the one-rank and the", world, "-rank evaluation:", d.tolist(), [(one[q], row[q]) for q in d[:4]],
                   "| one-rank parts in order:", float(np.add.reduce(one)), "sequential", sum(one.tolist(), 0.0))
+    # ---- (2b) the hybrid candidates as ONE batch of a fresh handle (one HybridBatch: shared chain, terms shared inside the batch)
+    hbatch = make(hdf)
+    if hbatch._batch(hnet, [(v, pbn.CKDEType(), ps) for v, ps in hc] * 2, code).tolist() != hwant * 2:
+        bad += 1; print("MISMATCH hybrid batch", case, n, nc, dtype, hc)
     hother = make(hdf)
     for (v, ps), w in reversed(list(zip(hc, hwant))):
         q = list(ps)
