@@ -282,16 +282,14 @@ void launch_seg(const SegArgs& a, int d, hipStream_t st) {
 // discrete parent set (C5: 1 671 hybrid evaluations over a few dozen groupings), each of which used to launch its own segmented
 // moments and wait for them.  One gathered, segmented Gram (launch_gram_segments: gram_gring_kernel through the grouping's row list)
 // gives every cell's n + n^2 numbers; a candidate's d x d moments are entries of them.
-static bool ensure_full_moments(pbn_scoredata* sd, const HybridGrouping& g) {
-    if (g.full_state != 0) return g.full_state > 0;
-    static const bool on = [] { const char* e = getenv("PBN_HYBRID_FULLMOMENTS"); return !(e && *e) || atoi(e) != 0; }();
-    const int n = sd->n;
-    const size_t cells = (size_t)g.nc * g.nregions;
-    // (not with validity masks: a row that is null in another column still counts for this candidate's own)
-    if (!on || sd->has_nulls || n > 64 || cells * ((size_t)n * n + n) > ((size_t)1 << 24)) { g.full_state = -1; return false; }
+// Shifted moments of the columns `cols` (nc of them, <= 64) for EVERY cell of the grouping in one segmented, gathered Gram launch: a cell is a
+// segment of the grouped row list cut into pieces of 4 096 rows, the pieces' partials added in order per cell (launch_gram_segments).
+// out[cell]: S[i], G[i + j nc] indexed by position in `cols`.
+static void cells_gram(pbn_scoredata* sd, const HybridGrouping& g, const int* cols, int nc, std::vector<Stats>& out) {
     pbn_ctx* ctx = sd->ctx;
     const pbn_table* t = sd->table();
-    const int nct = (n + 15) / 16, WS = gram_ws(nct);
+    const size_t cells = (size_t)g.nc * g.nregions;
+    const int nct = (nc + 15) / 16, WS = gram_ws(nct);
     constexpr int64_t PIECE = 4096;
     std::vector<int32_t> blk, off(cells + 1, 0);
     for (size_t c = 0; c < cells; ++c) {
@@ -302,41 +300,52 @@ static bool ensure_full_moments(pbn_scoredata* sd, const HybridGrouping& g) {
         off[c + 1] = (int32_t)(blk.size() / 4);
     }
     const int nblk = (int)(blk.size() / 4);
-    g.full.assign(cells, Stats());
-    for (size_t c = 0; c < cells; ++c) { g.full[c].zero(n); g.full[c].N = g.off[c + 1] - g.off[c]; }
-    if (nblk > 0) {
-        dev_buf<int32_t> dblk(blk.size() + off.size());
-        HIP_CHECK(hipMemcpyAsync(dblk.p, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(dblk.p + blk.size(), off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        ctx->scratch_red.reserve(((size_t)nblk + cells) * WS);
-        double* partial = ctx->scratch_red.p;
-        double* outd = partial + (size_t)nblk * WS;
-        GramArgs a{};
-        a.base = t->data; a.ld = t->ld; a.n_cols = n; a.row0 = 0; a.rows = g.rows.p; a.n = g.off[cells];
-        for (int i = 0; i < n; ++i) a.gc.cols[i] = i;
-        a.rows_per_block = PIECE; a.blk = dblk.p; a.shift = sd->shift_dev.p; a.partial = partial; a.num_cus = ctx->num_cus;
-        { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram_segments(a, t->dtype, nblk, dblk.p + blk.size(), (int)cells, outd, ctx->stream); }
-        std::vector<double> h(cells * (size_t)WS);
-        HIP_CHECK(hipMemcpyAsync(h.data(), outd, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (size_t c = 0; c < cells; ++c) {
-            const double* w = h.data() + c * (size_t)WS;
-            Stats& st = g.full[c];
-            for (int i = 0; i < n; ++i) st.S[i] = w[WS - nct * 16 + i];
-            int pr = 0;
-            for (int I = 0; I < nct; ++I)
-                for (int J = I; J < nct; ++J, ++pr) {
-                    const double* tile = w + (size_t)pr * 256;
-                    for (int e = 0; e < 256; ++e) {
-                        const int reg = e >> 6, lane = e & 63;
-                        const int r = I * 16 + (lane >> 4) + 4 * reg, cc = J * 16 + (lane & 15);
-                        if (r >= n || cc >= n || (I == J && r > cc)) continue;
-                        st.G[r + (size_t)cc * n] = tile[e];
-                        st.G[cc + (size_t)r * n] = tile[e];
-                    }
+    out.assign(cells, Stats());
+    for (size_t c = 0; c < cells; ++c) { out[c].zero(nc); out[c].N = g.off[c + 1] - g.off[c]; }
+    if (nblk == 0) return;
+    dev_buf<int32_t> dblk(blk.size() + off.size());
+    HIP_CHECK(hipMemcpyAsync(dblk.p, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(dblk.p + blk.size(), off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    ctx->scratch_red.reserve(((size_t)nblk + cells) * WS);
+    double* partial = ctx->scratch_red.p;
+    double* outd = partial + (size_t)nblk * WS;
+    GramArgs a{};
+    a.base = t->data; a.ld = t->ld; a.n_cols = nc; a.row0 = 0; a.rows = g.rows.p; a.n = g.off[cells];
+    for (int i = 0; i < nc; ++i) a.gc.cols[i] = cols[i];
+    a.rows_per_block = PIECE; a.blk = dblk.p; a.shift = sd->shift_dev.p /* by table column */; a.partial = partial; a.num_cus = ctx->num_cus;
+    { KernelTimer kt(ctx, PBN_K_GRAM); launch_gram_segments(a, t->dtype, nblk, dblk.p + blk.size(), (int)cells, outd, ctx->stream); }
+    std::vector<double> h(cells * (size_t)WS);
+    HIP_CHECK(hipMemcpyAsync(h.data(), outd, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t c = 0; c < cells; ++c) {
+        const double* w = h.data() + c * (size_t)WS;
+        Stats& st = out[c];
+        for (int i = 0; i < nc; ++i) st.S[i] = w[WS - nct * 16 + i];
+        int pr = 0;
+        for (int I = 0; I < nct; ++I)
+            for (int J = I; J < nct; ++J, ++pr) {
+                const double* tile = w + (size_t)pr * 256;
+                for (int e = 0; e < 256; ++e) {
+                    const int reg = e >> 6, lane = e & 63;
+                    const int r = I * 16 + (lane >> 4) + 4 * reg, cc = J * 16 + (lane & 15);
+                    if (r >= nc || cc >= nc || (I == J && r > cc)) continue;
+                    st.G[r + (size_t)cc * nc] = tile[e];
+                    st.G[cc + (size_t)r * nc] = tile[e];
                 }
-        }
+            }
     }
+}
+
+static bool ensure_full_moments(pbn_scoredata* sd, const HybridGrouping& g) {
+    if (g.full_state != 0) return g.full_state > 0;
+    static const bool on = [] { const char* e = getenv("PBN_HYBRID_FULLMOMENTS"); return !(e && *e) || atoi(e) != 0; }();
+    const int n = sd->n;
+    const size_t cells = (size_t)g.nc * g.nregions;
+    // (not with validity masks: a row that is null in another column still counts for this candidate's own)
+    if (!on || sd->has_nulls || n > 64 || cells * ((size_t)n * n + n) > ((size_t)1 << 24)) { g.full_state = -1; return false; }
+    std::vector<int> all((size_t)n);
+    for (int i = 0; i < n; ++i) all[i] = i;
+    cells_gram(sd, g, all.data(), n, g.full);
     g.full_state = 1;
     return true;
 }
@@ -387,6 +396,13 @@ void group_moments(pbn_scoredata* sd, const HybridGrouping& g, const int* cols, 
                 for (int j = i; j < d; ++j) { st.G[i + (size_t)j * d] = st.G[j + (size_t)i * d] = o[pos]; ++pos; }
             }
         }
+        return;
+    }
+    // more than 8 columns (or the segmented register kernel switched off): the candidate's own columns through the segmented MFMA Gram - one
+    // launch for all cells (round 3 took one Gram launch + one wait per cell here)
+    static const bool cellwise = [] { const char* e = getenv("PBN_HYBRID_CELLWISE_GRAM"); return e && *e && atoi(e) != 0; }();
+    if (!cellwise && d <= 64) {
+        cells_gram(sd, g, cols, d, M);
         return;
     }
     for (size_t c = 0; c < cells; ++c)

@@ -86,10 +86,14 @@ def test_mi_switches(default, env):
         assert close(got[key], default[key], 1e-9), key
 
 
-@pytest.mark.parametrize("env", [{"PBN_HYBRID_FULLMOMENTS": "0"}, {"PBN_HYBRID_FUSED": "1"}, {"PBN_HYBRID_SEGMENTED": "0"}, {"PBN_SCORE_MEMO": "0"}])
+@pytest.mark.parametrize("env", [{"PBN_HYBRID_FULLMOMENTS": "0"}, {"PBN_HYBRID_FUSED": "1"}, {"PBN_HYBRID_SEGMENTED": "0"}, {"PBN_SCORE_MEMO": "0"},
+                                 {"PBN_HYBRID_FULLMOMENTS": "0", "PBN_HYBRID_SEGMENTED": "0"},
+                                 {"PBN_HYBRID_FULLMOMENTS": "0", "PBN_HYBRID_SEGMENTED": "0", "PBN_HYBRID_CELLWISE_GRAM": "1"}])
 def test_hybrid_score_switches(default, env):
-    """Hybrid candidates: moments from the per-grouping Gram or from per-candidate launches, slices fused or split, with and without
-    the local-score memo - the same scores to rounding (the fp32 tables to their own precision)."""
+    """Hybrid candidates: moments from the per-grouping Gram or from per-candidate launches (the register kernel for up to 8 columns;
+    without it - as for wider candidates - the candidate's columns through one segmented MFMA Gram for all cells, or one launch per cell
+    as in round 3), slices fused or split, with and without the local-score memo - the same scores to rounding (the fp32 tables to
+    their own precision)."""
     got = run(env)
     # (PBN_HYBRID_FUSED=1 evaluates a slice by the fused joint + marginal kernel - fp64 polynomial - instead of two plain sum-only
     #  sweeps - 2^f on the fp32 transcendental unit: 1e-8, both far inside the 1e-6 bar)
