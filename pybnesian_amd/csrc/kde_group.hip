@@ -523,6 +523,16 @@ int env_int(const char* name, int dflt) {
 
 size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
+// Training tiles per split of a unit's sweep.  PBN_GROUP_SPLIT_TILES pins it; otherwise 512 up to 16 384 tiles (cv64's 90 000-row folds:
+// 512 measures best, 1 024 +2-3 %), 1 024 up to 32 768 (C3's 450 000-row folds: 10.72 against 10.79 s) and 2 048 beyond (C5's 720 000-row
+// slices: within noise of 512 in time, `profiles/r4/split_tiles_probe.txt` - but every query keeps a partial per split, 60 % of a
+// candidate's arena at 512, so the coarser split lets an arena-full hold twice the candidates).
+int split_tiles_for(int ntiles) {
+    const int pinned = env_int("PBN_GROUP_SPLIT_TILES", 0);   // read per call: the tests switch it
+    if (pinned > 0) return std::max(16, pinned);
+    return ntiles <= 16384 ? 512 : (ntiles <= 32768 ? 1024 : 2048);
+}
+
 // one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
 void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out,
                double* dev_out_max, bool force_f64) {
@@ -567,7 +577,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(fdt, 0, true) - 8.0;
     const int NB16 = ring ? bf16x3_mfmas(d0) : 0;
     const size_t frag16_b = (size_t)NB16 * 64 * 16;
-    static const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
     int64_t total_wg = 0;
     int max_ntiles = 0, max_nqtiles = 0, max_nq = 0;
     size_t off = 0;
@@ -580,6 +589,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         const int d = P.d, pd = P.kd;
         U.ntiles = (U.N + 15) / 16;
         U.nqtiles = (U.nq + 15) / 16;
+        const int split_tiles = split_tiles_for(U.ntiles);
         const int nsplit0 = std::max(1, (U.ntiles + split_tiles - 1) / split_tiles);
         U.tps = (U.ntiles + nsplit0 - 1) / nsplit0;
         U.nsplit = (U.ntiles + U.tps - 1) / U.tps;
@@ -718,12 +728,12 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
 }
 
 // bytes of arena a pool needs (its element arrays + its units' buffers), for chunking
-size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
+size_t pool_bytes(const GroupBatch& b, const GPool& P) {
     const int d = P.d, KS = (d + 3) / 4, pd = P.kd;
     size_t s = (size_t)P.n * (16 + (size_t)PBN_GROUP_MAX_D * 8 + 1) + (size_t)((P.n + GB - 1) / GB + 1) * (PBN_GROUP_MAX_R * 4 + 4) + sizeof(GPool) + 4096;
     for (int u = 0; u < P.nunits; ++u) {
         const GUnit& U = b.units[P.unit0 + u];
-        const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
+        const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, split_tiles = (size_t)split_tiles_for((int)nt), nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
         s += nt * KS * 1024 + nt * 256 + (nt + nqt) * 2048 + nqt * 64 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
              nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 + (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) +
              (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
@@ -739,7 +749,7 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P, int split_tiles) {
 // (tools/arena_bench_probe.sh: the bench line's 0.62 s cv_weak leg became 1.00 s), so the default stops at 8
 size_t kde_group_arena_budget() { return (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 8192)) << 20; }
 
-size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P) { return pool_bytes(b, P, std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512))); }
+size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P) { return pool_bytes(b, P); }
 
 bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
     const int on = env_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
@@ -767,14 +777,13 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     auto variant = [&](int i) { const int d = b.pools[i].d; return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
     const size_t budget = kde_group_arena_budget();
-    const int split_tiles = std::max(16, env_int("PBN_GROUP_SPLIT_TILES", 512));
     const int max_pools = std::min(256, std::max(1, env_int("PBN_GROUP_MAX_POOLS", 256)));
     size_t p0 = 0;
     while (p0 < order.size()) {
         size_t p1 = p0, bytes = 0;
         int64_t elems = 0;
         while (p1 < order.size() && variant(order[p1]) == variant(order[p0]) && (int)(p1 - p0) < max_pools) {
-            const size_t pb = pool_bytes(b, b.pools[order[p1]], split_tiles);
+            const size_t pb = pool_bytes(b, b.pools[order[p1]]);
             if (p1 > p0 && (bytes + pb > budget || elems + b.pools[order[p1]].n > 0x7ff00000ll)) break;
             bytes += pb;
             elems += b.pools[order[p1]].n;
