@@ -134,17 +134,21 @@ constexpr int SEG_PIECE = 4096;
 #define PBN_HYBRID_SPLIT_MAX_D 1   // fp32 CKDE slices with more variables than this: the fused sweep (C5: 21.3 s fused, 22.1 s with slices up to 4 variables split - fewer exponentials, more launches)
 #endif
 
-const HybridGrouping& grouping_for(pbn_scoredata* sd, int kind, const std::vector<int>& dpar_sorted, const std::vector<Region>& regions) {
+// -> shared: whoever enqueues device work that reads the grouping's row list keeps the pointer until that work has finished (a
+// HybridBatch holds the groupings of its candidates until flush()), so the cache starting over cannot free a list in flight
+std::shared_ptr<const HybridGrouping> grouping_for(pbn_scoredata* sd, int kind, const std::vector<int>& dpar_sorted, const std::vector<Region>& regions) {
     std::vector<int> key{kind};
     key.insert(key.end(), dpar_sorted.begin(), dpar_sorted.end());
     auto it = sd->groupings.find(key);
-    if (it != sd->groupings.end()) return *it->second;
+    if (it != sd->groupings.end()) return it->second;
     // each grouping holds a 4 B / row device list: beyond 256 of them (a search over very many discrete parent sets) start over
-    if (sd->groupings.size() >= 256) {
+    // (PBN_HYBRID_GROUPINGS: the cap, lowered by the test that crosses the reset inside one batch)
+    static const size_t cap = [] { const char* e = getenv("PBN_HYBRID_GROUPINGS"); const long long v = (e && *e) ? atoll(e) : 256; return (size_t)(v < 1 ? 1 : v); }();
+    if (sd->groupings.size() >= cap) {
         HIP_CHECK(hipStreamSynchronize(sd->ctx->stream));
         sd->groupings.clear();
     }
-    auto gp = std::make_unique<HybridGrouping>();
+    auto gp = std::make_shared<HybridGrouping>();
     HybridGrouping& g = *gp;
     std::vector<int> strides(dpar_sorted.size(), 1);
     int nc = 1;
@@ -187,9 +191,8 @@ const HybridGrouping& grouping_for(pbn_scoredata* sd, int kind, const std::vecto
     if (!piece.empty()) HIP_CHECK(hipMemcpyAsync(g.piece.p, piece.data(), piece.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(g.piece_off.p, piece_off.data(), piece_off.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope
-    const HybridGrouping& ref = g;
-    sd->groupings[key] = std::move(gp);
-    return ref;
+    sd->groupings[key] = gp;
+    return gp;
 }
 
 // ---- segmented Gram: pilot-shifted moments of D columns for EVERY (configuration, region) cell in one launch pair ---------
@@ -462,6 +465,7 @@ struct HybridBatch {
     std::vector<int> rcols;
     struct Job { std::vector<Slice> slices; bool has_parts; HybridParts parts; bool has_sink; HybridSink sink; };
     std::vector<Job> jobs;
+    std::vector<std::shared_ptr<const HybridGrouping>> keep;   // groupings whose device row lists the enqueued pools / slices / redo records read
     double last_value = 0;     // score of the last finished job (the synchronous form of score_hybrid)
 
     HybridBatch(pbn_scoredata* s, bool f32_) : sd(s), ctx(s->ctx), f32(f32_) {}
@@ -504,7 +508,6 @@ void HybridBatch::flush() {
     if (!active) return;
     const pbn_table* t = sd->table();
     auto align = [](size_t x) { return (x + 255) / 256 * 256; };
-    auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
     kick();
     const size_t ns = slot_key.size();
     std::vector<double> hs(std::max<size_t>(1, ns)), hmax(f32 ? ns : 0);
@@ -517,7 +520,6 @@ void HybridBatch::flush() {
         for (const Redo& r : redo_info) {
             if (!kde_wants_widening(hmax[(size_t)r.slot])) continue;
             const int* v = rcols.data() + r.coff;
-            sd->widen_sets.insert(set_key(v, r.nv));
             KdeModel m;
             kde_prepare(m, sd->dtype, r.nv, r.N, rstore.data() + r.off, PBN_BW_FULL, false, rstore.data() + r.off + (size_t)r.nv * r.nv);
             kde_widen(m);
@@ -559,6 +561,7 @@ void HybridBatch::flush() {
         last_value = acc;
     }
     jobs.clear();
+    keep.clear();              // (everything that read them has finished: lanes and stream were waited for above)
     slot_key.clear();
     scheduled.clear();
     redo_info.clear();
@@ -610,7 +613,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     // canonical grouping (parents sorted) and the map from the candidate's configuration numbering onto it
     std::vector<int> dsorted(dpar);
     std::sort(dsorted.begin(), dsorted.end());
-    const HybridGrouping& g = grouping_for(sd, kind, dsorted, regions);
+    const std::shared_ptr<const HybridGrouping> g_hold = grouping_for(sd, kind, dsorted, regions);
+    const HybridGrouping& g = *g_hold;
     std::vector<int> canon(g.nc);
     {
         std::vector<int> cstride(dsorted.size(), 1);
@@ -678,8 +682,8 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     // device resident - with ONE synchronisation at the end.
     std::vector<Slice> slices;
     // fp32 tables: behind the sums, one slot per sum for |z|^2 of the farthest whitened training row of its evaluation (reported by the
-    // pack kernels) - an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used, and its
-    // continuous column set goes to fp64 fragments from then on (pbn_scoredata::widen_sets; scoring.hip does the same for plain terms)
+    // pack kernels) - an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used (decided per
+    // evaluation, nothing remembered per column set: scoring.hip does the same for plain terms)
     const size_t max_slots = (size_t)units * g.nc * 2 + 1;
     // the batch this candidate's evaluations join: the caller's (its score arrives at flush()), or one of its own, flushed below
     std::unique_ptr<HybridBatch> own;
@@ -690,10 +694,10 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
     if (node_type == PBN_NODE_CKDE) {
         fresh_slots = hb->begin_candidate(max_slots);
         dsums.p = hb->dsums;
+        if (hb->keep.empty() || hb->keep.back() != g_hold) hb->keep.push_back(g_hold);   // (after a flush begin_candidate may have made: `keep` is cleared there)
     }
     double* const dmax = f32 ? hb->dmax : nullptr;
     std::vector<double> Hterm, muterm;   // bandwidth / centre of the term being built (reused)
-    auto set_key = [](const int* v, int nv) { std::vector<int> k(v, v + nv); std::sort(k.begin(), k.end()); return k; };
     // the slices' sweeps go round-robin over the context's issue lanes (common.hpp): a sweep's tail overlaps the next slice
     const int lanes = (node_type == PBN_NODE_CKDE && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
     if (lanes > 1) {
@@ -927,19 +931,17 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 term.slot = (int)hb->slot_key.size();
                 hb->slot_key.push_back(key);
                 hb->scheduled.emplace(key, term.slot);
-                const bool w64 = f32 && sd->widen_sets.count(set_key(v, nv)) != 0;   // a set already known to need fp64 fragments
-                if (f32 && !w64) {
+                if (f32) {
                     hb->redo_info.push_back(Redo{term.slot, nv, hb->rstore.size(), hb->rcols.size(), tr->N, tr_row0, tr_n0, tr_row1, te0, te->N, g.rows.p});
                     hb->rstore.insert(hb->rstore.end(), Ht.begin(), Ht.end());
                     hb->rstore.insert(hb->rstore.end(), mut.begin(), mut.end());
                     hb->rcols.insert(hb->rcols.end(), v, v + nv);
                 }
-                if (elig[(size_t)c * 2 + which] && !w64) {   // evaluated with the candidate's other grouped slices, after the loops
+                if (elig[(size_t)c * 2 + which]) {   // evaluated with the candidate's other grouped slices, after the loops
                     group_unit(c, u, which, m, v, colidx, nv, tr->N, te->N, term.slot);
                     ++sd->kde_sweeps;
                     continue;
                 }
-                if (w64) kde_widen(m);
                 const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, false, tr->N);
                 LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
                 ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);

@@ -1003,15 +1003,15 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             }
             const size_t nslots = slot_key.size();
             // fp32 tables: behind the sums, one slot per sum for |z|^2 of the evaluation's farthest whitened training row (the pack
-            // kernels report it): an evaluation that kde_wants_widening() flags is redone on fp64 fragments before its value is used,
-            // and its variable set goes to fp64 fragments from then on (pbn_scoredata::widen_sets, KdeModel::widen)
+            // kernels report it): an evaluation that kde_wants_widening() flags is redone on fp64 fragments (KdeModel::widen) before its
+            // value is used.  The choice is a function of that evaluation alone - nothing is remembered per variable set, so the double
+            // a (term, region) gets does not depend on what this process evaluated before or on how a job dealt its terms
             static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
             const bool f32 = sd->dtype == PBN_F32 && check_after;
             ctx->scratch_sums.reserve(std::max<size_t>(1, 2 * nslots));   // (grow-only: no hipMalloc / hipFree per batch)
             struct { double* p; } dsums{ctx->scratch_sums.p};
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, 2 * nslots) * sizeof(double), ctx->stream));
             double* const dmax = f32 ? dsums.p + nslots : nullptr;
-            auto set_key = [](const std::vector<int>& use) { std::vector<int> k(use); std::sort(k.begin(), k.end()); return k; };
             auto align = [](size_t x) { return (x + 255) / 256 * 256; };
             // host side of one evaluation: columns, training moments of the region, bandwidth, whitening (KdeModel without packs)
             struct Prep { KdeModel m; std::vector<int> use; int64_t row0, n0, row1, te0, te_n, ntrain; };
@@ -1076,7 +1076,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             // ---- grouped evaluation (kde_group.hip): the plain terms whose shape qualifies are collected into pools - one per
             // variable set, its units the regions asked for - and evaluated by ONE launch chain per batch of pools ---------------
             struct Batch { GroupBatch gb; std::vector<std::vector<GUnit>> pool_units; std::map<std::vector<int>, int> pool_of; };   // pool_of: [m, sorted columns...] -> pool
-            Batch bt[2];                                                  // [1]: fp32 table, variable sets on fp64 fragments (widen_sets)
+            Batch bt[1];
             std::vector<char> grouped(work.size(), 0);
             const int R = cv ? sd->k : 2;
             const int64_t min_train = cv ? sd->n_cv - (sd->limits[1] - sd->limits[0]) : sd->n_cv;
@@ -1091,7 +1091,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 prepare(w, pr);
                 std::vector<int> key(pr.use);
                 std::sort(key.begin(), key.end());
-                Batch& B = bt[(f32 && sd->widen_sets.count(key)) ? 1 : 0];
+                Batch& B = bt[0];
                 GroupBatch& gb = B.gb;
                 std::vector<std::vector<GUnit>>& pool_units = B.pool_units;
                 key.insert(key.begin(), own_term ? p + 2 : p + 1);
@@ -1150,7 +1150,6 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             const int lanes = (n_legacy > 1 && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
             if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
             if (!bt[0].gb.pools.empty()) kde_group_run(ctx, t, bt[0].gb, dsums.p, dmax, false);
-            if (!bt[1].gb.pools.empty()) kde_group_run(ctx, t, bt[1].gb, dsums.p, nullptr, /*force_f64=*/true);
             // one evaluation through its own launch chain (shapes the grouped path does not take; the redo of a flagged evaluation)
             auto run_single = [&](const Work& w, bool force64) {
                 Prep pr;
@@ -1158,7 +1157,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 KdeModel& m = pr.m;
                 const int* use_cols = pr.use.data();
                 const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
-                if (f32 && (force64 || sd->widen_sets.count(set_key(pr.use)))) kde_widen(m);
+                if (f32 && force64) kde_widen(m);
                 const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, m.cond, m.N);
                 ctx->scratch_train.reserve(pb.apack + pb.nxpack + pb.axpack + 768);
                 char* base = ctx->scratch_train.p;
@@ -1183,7 +1182,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             if (f32 && nslots) {
                 // check-after: evaluations whose training rows reach beyond what fp32 fragments hold (2^-24 max|z|^2 above the threshold of
-                // kde_wants_widening) are redone on fp64 fragments, their variable sets remembered
+                // kde_wants_widening) are redone on fp64 fragments
                 std::vector<const Work*> redo;
                 for (const Work& w : work) {
                     const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
@@ -1193,7 +1192,6 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     for (const Work* w : redo) {
                         Prep pr;
                         prepare(*w, pr);
-                        sd->widen_sets.insert(set_key(pr.use));
                         const int slot = w->mode == 2 ? w->slot_m : w->slot_j;
                         HIP_CHECK(hipMemsetAsync(dsums.p + slot, 0, sizeof(double), ctx->stream));
                         if (w->mode == 0) HIP_CHECK(hipMemsetAsync(dsums.p + w->slot_m, 0, sizeof(double), ctx->stream));

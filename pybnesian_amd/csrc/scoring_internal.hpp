@@ -58,10 +58,6 @@ struct pbn_scoredata {
     // totals of A(S, m) over the test regions of a score kind, keyed by [kind, m, sorted columns...]: installed by pbn_score_terms_put (values another
     // rank computed) and preferred over kde_cache, so that every rank of a job assembles a candidate from the very same doubles
     std::map<std::vector<int>, double> term_total;
-    // fp32 tables: variable sets ([sorted continuous columns...]) one of whose evaluations met a whitened training row so far from the
-    // centre that the fp32 Gram form loses it (kde_wants_widening on the max-norm the pack kernels report): such sets are evaluated on
-    // fp64 fragments from then on (KdeModel::widen; the evaluation that found out is redone that way before its value is used)
-    std::set<std::vector<int>> widen_sets;
     int64_t kde_sweeps = 0;
     // hybrid likelihood local scores by [kind, node type, variable, sorted parents...] (see pbn_score_batch)
     std::map<std::vector<int>, double> score_memo;
@@ -92,7 +88,8 @@ struct pbn_scoredata {
     std::vector<std::vector<int32_t>> codes;
     std::vector<int> card;
     pbn::dev_buf<int32_t> rows_dev;  // gather lists (valid rows of BIC / BGe candidates on tables with nulls)
-    std::map<std::vector<int>, std::unique_ptr<HybridGrouping>> groupings;  // by [kind, sorted discrete parents...]
+    // by [kind, sorted discrete parents...]; shared: a HybridBatch keeps the groupings its enqueued work reads alive until it has flushed
+    std::map<std::vector<int>, std::shared_ptr<HybridGrouping>> groupings;
     // validity of the continuous columns (BIC / BGe on tables with nulls): byte masks, empty = no nulls
     std::vector<std::vector<uint8_t>> valid;
     bool has_nulls = false;

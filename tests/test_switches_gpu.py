@@ -115,10 +115,12 @@ def test_hybrid_candidates_batched_or_one_by_one_are_bit_identical(default):
         assert default[f"hybrid_batch_{dtype}"][0] == default[f"hybrid_batch_{dtype}"][n + 1], dtype   # c2 | {c1, d1} twice (parents in another order)
 
 
-@pytest.mark.parametrize("env", [{"PBN_HYBRID_BATCH_SLOTS": "8"}, {"PBN_GROUP_ARENA_MB": "64"}])
+@pytest.mark.parametrize("env", [{"PBN_HYBRID_BATCH_SLOTS": "8"}, {"PBN_GROUP_ARENA_MB": "64"}, {"PBN_HYBRID_GROUPINGS": "1"}])
 def test_hybrid_batch_cut_by_its_slots_or_its_arena_is_bit_identical(default, env):
     """A batch that runs out of result slots finishes what is in flight and starts over; one whose pools exceed the arena budget hands
-    them over early.  Neither changes a bit of any score (the 64 MB arena also cuts the plain engine's chains)."""
+    them over early.  Neither changes a bit of any score (the 64 MB arena also cuts the plain engine's chains).  PBN_HYBRID_GROUPINGS=1:
+    the cache of row groupings (one per set of discrete parents, 256 by default) starts over at every new parent set - inside the batch,
+    while earlier candidates' pools still read their grouping's device row list (the batch keeps those alive until it has flushed)."""
     got = run(env)
     for dtype in ("float64", "float32"):
         assert got[f"hybrid_batch_{dtype}"] == default[f"hybrid_batch_{dtype}"], dtype
