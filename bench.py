@@ -202,35 +202,26 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
 
 
 def eight_rank_estimate(run, one_rank_leg):
-    """No 8-GPU node at hand: ONE process plays the eight ranks of a hill-climb in turn and times every rank's share of every batch
-    (distributed.sharded_batch's emulation hook, tools/scale_emulate.py).  An 8-rank job waits per batch for its slowest share and
-    repeats the unsharded work: T_8 ~ (time - sum of the shares) + sum over batches of the slowest share.  An ESTIMATE - no collective
-    latency, one process's caches, the score engine's phase only - never a leg's `value`."""
+    """No 8-GPU node at hand: ONE process plays the eight ranks of a hill-climb in turn through the library's own sharding
+    (pbn_scoredata_set_comm) and times every rank's share of every batch (tools/shard_emulate.py).  An 8-rank job waits per batch for
+    its slowest share and repeats the unsharded work: T_8 ~ (time - sum of the shares) + sum over batches of the slowest share.  An
+    ESTIMATE - no collective latency, one process's caches, the score engine's phase only - never a leg's `value`."""
     try:
-        from pybnesian_amd import distributed as pdist
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        from shard_emulate import EmulatedRanks
 
-        class _Eight:
-            batches = []
-            get_rank = staticmethod(lambda: 0)
-            get_world_size = staticmethod(lambda: 8)
-            get_backend = staticmethod(lambda: "emulated")
-            emulate = staticmethod(lambda times, counts: _Eight.batches.append(times))
-
-        pdist._EMULATED = _Eight
-        try:
+        with EmulatedRanks(8) as em:
             r8 = run()
-        finally:
-            pdist._EMULATED = None
         one = r8["estimate_s"] + r8.get("score_ctor_s", 0.0)
-        shares = sum(sum(t) for t in _Eight.batches)
-        slow = sum(max(t) for t in _Eight.batches)
-        t8 = one - shares + slow
+        est = em.estimate(one)
+        t8 = est["per_rank_s"]
         t1 = one_rank_leg["estimate_s"] + one_rank_leg.get("score_ctor_s", 0.0)
-        return {"kind": "one-process emulation, not a multi-GPU measurement", "cells_scored": r8["cells_scored"], "batches": len(_Eight.batches),
-                "one_process_s": one, "per_rank_s": t8, "slowest_over_mean_share": slow / (shares / 8.0) if shares else None,
+        return {"kind": "one-process emulation, not a multi-GPU measurement", "cells_scored": r8["cells_scored"], "batches": len(em.batches),
+                "one_process_s": one, "per_rank_s": t8, "slowest_over_mean_share": est["slowest_over_mean_share"],
                 "arcs_per_s": r8["cells_scored"] / t8, "ratio_to_one_rank_leg": (r8["cells_scored"] / t8) / (one_rank_leg["cells_scored"] / t1),
-                "method": "per batch the slowest of the eight shares (CKDE terms dealt by cost, the slices of hybrid candidates shared), plus the unsharded "
-                          "time; collective latency and per-rank caches not modelled"}
+                "method": "per batch the slowest of the eight shares (CKDE terms dealt by cost, the slices of hybrid candidates shared: the plan of "
+                          "csrc/shard.hip, every rank played in turn by one process), plus the unsharded time; collective latency and per-rank "
+                          "caches not modelled"}
     except Exception as ex:   # an estimate must never cost the line
         return {"error": f"{type(ex).__name__}: {ex}"}
 
@@ -729,6 +720,34 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_world1():
+    """Runs tools/rccl_world1.py as a child process (it initialises its own GPU context and a one-rank RCCL communicator) and returns its
+    JSON; a failure is reported in the object, it never costs the line."""
+    import socket
+    import subprocess
+
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.pop("PBN_FORCE_DIST", None)
+        p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rccl_world1.py")], env=env,
+                           capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+        if not lines:
+            return {"ok": False, "error": f"exit code {p.returncode}: {p.stderr[-600:]}"}
+        res = json.loads(lines[-1][len("RESULT "):])
+        res["what"] = ("a fresh child process: torch.distributed 'nccl' (RCCL) with ONE rank on this GPU, the one-process-per-GPU mode forced "
+                       "(PBN_FORCE_DIST): CV-likelihood CKDE / hybrid / BGe / BIC hill-climbs and a sharded KDE slogl with every batch's all-gather "
+                       "through RCCL, compared bit for bit with the plain calls; `mapped` = the HIP / RCCL libraries that process loaded")
+        return res
+    except Exception as ex:
+        return {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+
+
 def e2e_host(pbn, kde, names, test_np, repeats=3):
     """the same slogl with the test table in HOST Arrow memory - upload (PCIe), query pack, sweep, finish,
     scalar back - through the reference-shaped Python call `ProductKDE.slogl(record_batch)`.  Never the headline value."""
@@ -1049,6 +1068,13 @@ def main():
         if hc_out is not None:
             out["secondary"] = hc_out
         out.update(legs)
+        if world == 1 and hc_auto and not args.no_extra_legs:
+            # the RCCL path of the sharded delta cache, executed on this one GPU by a fresh child process (tools/rccl_world1.py): a
+            # one-rank "nccl" group, the product's one-process-per-GPU mode forced, every batch's all-gather through RCCL on device
+            # buffers, results bit-identical to the plain calls; never part of a timed region
+            out["rccl_world1"] = rccl_world1()
+            out["config"]["rccl_ranks_seen"] = out["rccl_world1"].get("rccl_ranks_seen")
+            out["config"]["backend"] = "nccl (RCCL), one rank: tools/rccl_world1.py"
         if world == 1 and not args.no_e2e:
             try:
                 out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy())

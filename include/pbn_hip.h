@@ -269,6 +269,59 @@ int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int*
 int pbn_score_batch_parts(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                           const int* parents, int part, int n_parts, double* out);
 
+/* ---- one process per GPU: the delta-score cache sharded BEHIND the boundary (shards the serial double
+ * loops of learning/operators/operators.cpp:100-132,296-347 and the fold loop of learning/scores/cv_likelihood.cpp:5-25; the
+ * reference is one process and has no counterpart).  The host supplies ONE collective - an all-gather of doubles - as a function
+ * pointer (RCCL `ncclAllGather` on a device staging buffer, MPI_Allgather, torch.distributed ...: INTEGRATION.md shows the RCCL
+ * form); the library plans every batch (which rank evaluates which CKDE term, (term, fold) pair, hybrid slice part or whole
+ * candidate - a pure function of the batch, identical on every rank), evaluates this rank's share, makes ONE all-gather per batch,
+ * installs the gathered terms and assembles every candidate from the same doubles on every rank: the one-process score, bit for
+ * bit, for every world size.
+ *   all_gather(user, send, count, recv): every rank contributes `count` doubles; recv[r * count .. (r + 1) * count) = rank r's, in
+ *   rank order on every rank.  HOST pointers.  Returns 0 on success.  Every rank of the job makes the same sequence of calls. */
+typedef int (*pbn_allgather_fn)(void* user, const double* send, int64_t count, double* recv);
+typedef struct {
+    int rank, world;              /* 0 <= rank < world; world = 1 is allowed (the collective is still made)          */
+    pbn_allgather_fn all_gather;
+    void* user;
+} pbn_comm;
+/* Binds the job's communicator to a score handle (copied; NULL unbinds): from then on pbn_score_batch - and therefore every
+ * pbn_hc_score_fn that calls it, i.e. OperatorSet::cache_scores / update_scores of a hill-climb - evaluates only this rank's share of
+ * the batch's device work and completes it through the collective.  LinearGaussian / discrete candidates (O(p^3) host arithmetic on
+ * replicated moments) are computed by every rank. */
+int pbn_scoredata_set_comm(pbn_scoredata* sd, const pbn_comm* comm);
+/* The exchange of pbn_scoredata_create_sharded in one call: all-gathers the ranks' segment moments, adds them in rank order and
+ * installs the totals (see there: bit-identical for every world size). */
+int pbn_scoredata_reduce_moments(pbn_scoredata* sd, const pbn_comm* comm);
+/* KDE / ProductKDE / CKDE slogl with the TEST rows split over the ranks (the fitted model replicated): rank r evaluates
+ * rows [row0 + n r / world, row0 + n (r + 1) / world), the partial sums are gathered and added in rank order. */
+int pbn_kde_slogl_sharded(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, const pbn_comm* comm, double* out);
+/* The planner and driver behind pbn_scoredata_set_comm, over an abstract engine (what a batch is made of, as function pointers with the
+ * signatures of pbn_score_batch / pbn_score_terms* / pbn_score_batch_parts minus the handle): pbn_score_batch binds it to its own handle;
+ * hosts with their own evaluator - and the CPU tests of this repository - bind theirs.  `shape` reports, for a score kind, the number of
+ * regions a term adds up (CV folds; 1 for hold-out) and the training / test rows of one region: the plan prices a term by the rows a
+ * sweep of its dimension meets (pruned sweeps: ~ N^(4/(d+4)) rows per query), not by a fixed table.  terms* / batch_parts may be NULL (then
+ * CKDE candidates are dealt whole, by variable set).  shard_all != 0 deals every candidate, whatever its node type. */
+typedef struct {
+    void* user;
+    int n_cont;                   /* column ids below it are continuous, the others dictionary columns */
+    int (*shape)(void* user, int kind, int* regions, int64_t* train_rows, int64_t* test_rows);
+    int (*batch)(void* user, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents, double* out);
+    int (*terms_missing)(void* user, int kind, int n_terms, const int* off, const int* vars, const int* m, int* missing);
+    int (*terms)(void* user, int kind, int n_terms, const int* off, const int* vars, const int* m, double* out);
+    int (*term_regions)(void* user, int kind, int n_items, const int* off, const int* vars, const int* m, const int* region, double* out);
+    int (*terms_put)(void* user, int kind, int n_terms, const int* off, const int* vars, const int* m, const double* values);
+    int (*batch_parts)(void* user, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents,
+                       int part, int n_parts, double* out);
+} pbn_shard_engine;
+int pbn_shard_batch(const pbn_shard_engine* engine, const pbn_comm* comm, int kind, int n_cand, const int* var, const int* node_type,
+                    const int* par_off, const int* parents, int shard_all, double* out);
+/* The dealing rule itself (host only): items in order of decreasing cost - equal costs by decreasing tie[] (NULL: none), then by
+ * index - each to the least loaded rank (lowest rank on ties); load[world] is read and updated when given (loads carried over from
+ * earlier dealings), else starts at zero.  pbn_shard_term_cost: the price of sweeping one region of a term of `dims` columns. */
+int pbn_shard_deal(int n_items, const double* cost, const uint32_t* tie, int world, double* load, int* owner);
+double pbn_shard_term_cost(int dims, int64_t train_rows, int64_t test_rows);
+
 /* ---- greedy hill-climbing (host logic; replaces learning/algorithms/hillclimbing.hpp:62-199 driving
  * learning/operators/operators.{hpp,cpp}).  Nodes are 0..n_nodes-1 in model.nodes() order.  Every step's
  * Score::local_score requests are handed to `score` as ONE batch (same layout as pbn_score_batch);

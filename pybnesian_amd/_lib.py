@@ -117,12 +117,36 @@ SIGNATURES = {
     "pbn_hc_find_max": (_int, [_vp, _int, _ip, _ip, _dp]),
     "pbn_hc_update_scores": (_int, [_vp, _int, _ip]),
     "pbn_hc_get": (_int, [_vp, _dp, _dp, _dp]),
+    "pbn_scoredata_set_comm": (_int, [_vp, _vp]),
+    "pbn_scoredata_reduce_moments": (_int, [_vp, _vp]),
+    "pbn_kde_slogl_sharded": (_int, [_vp, _vp, _ip, _i64, _i64, _vp, _dp]),
+    "pbn_shard_batch": (_int, [_vp, _vp, _int, _int, _ip, _ip, _ip, _ip, _int, _dp]),
+    "pbn_shard_deal": (_int, [_int, _dp, C.POINTER(C.c_uint32), _int, _dp, _ip]),
+    "pbn_shard_term_cost": (C.c_double, [_int, _i64, _i64]),
 }
 
 HC_SCORE_FN = C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)
 CI_PVALUE_FN = C.CFUNCTYPE(C.c_double, _vp, _int, _int, _int, _ip)
 CI_BATCH_FN = C.CFUNCTYPE(None, _vp, _int, _ip, _ip, _ip, _ip, _dp)
 HC_ITER_FN = C.CFUNCTYPE(_int, _vp, _int, _ip, C.c_double, _int, _ip, _ip)
+ALLGATHER_FN = C.CFUNCTYPE(_int, _vp, _dp, _i64, _dp)   # pbn_allgather_fn
+
+
+class Comm(C.Structure):   # pbn_comm
+    _fields_ = [("rank", _int), ("world", _int), ("all_gather", ALLGATHER_FN), ("user", _vp)]
+
+
+class ShardEngine(C.Structure):   # pbn_shard_engine
+    _fields_ = [
+        ("user", _vp), ("n_cont", _int),
+        ("shape", C.CFUNCTYPE(_int, _vp, _int, _ip, C.POINTER(_i64), C.POINTER(_i64))),
+        ("batch", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)),
+        ("terms_missing", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip)),
+        ("terms", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _dp)),
+        ("term_regions", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)),
+        ("terms_put", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _dp)),
+        ("batch_parts", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _int, _int, _dp)),
+    ]
 
 
 class HCConfig(C.Structure):

@@ -1222,8 +1222,28 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
 
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                     const int* parents, const double* params, int n_params, double* out) {
+    if (sd && sd->has_comm) {   // one process per GPU (pbn_scoredata_set_comm): this rank's share + one all-gather (shard.hip)
+        // (no lock held across the host's collective: the evaluations inside take the handle's lock themselves)
+        try {
+            pbn::score::score_batch_sharded(sd, kind, n_cand, var, node_type, par_off, parents, params, n_params, out);
+            return PBN_OK;
+        } catch (const invalid_error& e) { set_last_error(e.what()); return PBN_ERR_INVALID;
+        } catch (const singular_error& e) { set_last_error(e.what()); return PBN_ERR_SINGULAR;
+        } catch (const std::exception& e) { set_last_error(e.what()); return PBN_ERR_DEVICE; }
+    }
     return score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, params, n_params, out, nullptr);
 }
+
+extern "C++" {
+namespace pbn {
+namespace score {
+int score_batch_local(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents,
+                      const double* params, int n_params, double* out) {
+    return score_batch_impl(sd, kind, n_cand, var, node_type, par_off, parents, params, n_params, out, nullptr);
+}
+}  // namespace score
+}  // namespace pbn
+}  // extern "C++"
 
 extern "C++" {
 namespace {

@@ -64,6 +64,10 @@ struct pbn_scoredata {
     int64_t memo_hits = 0;
     int64_t cache_resets = 0;   // times kde_cache / score_memo started over (PBN_SCORE_CACHE_ENTRIES)
     bool partial = false;  // moments hold only this rank's row share (pbn_scoredata_create_sharded)
+    // one process per GPU (pbn_scoredata_set_comm): pbn_score_batch evaluates this rank's share and completes the batch through the
+    // host's all-gather (shard.hip)
+    bool has_comm = false;
+    pbn_comm comm{};
     const pbn_table* src = nullptr;  // caller's table (borrowed)
     pbn_table* perm_table = nullptr; // owned permuted copy (null for PBN_SPLIT_NONE)
     const pbn_table* table() const { return perm_table ? perm_table : src; }
@@ -135,6 +139,11 @@ struct HybridSink {
     double* out;                  // where the candidate's score goes
     std::vector<int> memo_key;    // non-empty: also remembered in pbn_scoredata::score_memo under this key
 };
+// pbn_score_batch without / with the job's communicator (scoring.hip / shard.hip)
+int score_batch_local(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents,
+                      const double* params, int n_params, double* out);
+void score_batch_sharded(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents,
+                         const double* params, int n_params, double* out);
 struct HybridBatch;
 HybridBatch* hybrid_batch_begin(pbn_scoredata* sd);
 void hybrid_batch_flush(HybridBatch* hb);

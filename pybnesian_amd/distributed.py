@@ -1,25 +1,40 @@
-"""Sharding of a score batch over the GPUs of one node (one process per GPU, torch.distributed with the
-"nccl" backend = RCCL over xGMI; "gloo" on CPU for tests).
+"""One process per GPU (torch.distributed: "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU for tests): the thin caller of the
+library's sharded delta cache.
 
-Independent units = candidates: every rank holds the whole table, scores its share of the candidates
-(dealt by variable set, see sharded_batch) on its own GPU, and one all_gather of <= n^2 doubles per batch gives every
-rank the full result in fixed rank order, so that all ranks take the same deterministic find_max decision.
-No other collective is on the data path.
+The planning - which rank evaluates which CKDE term, (term, fold) pair, hybrid slice part or whole candidate - the evaluation of a
+rank's share and the assembly of every candidate from the gathered doubles live BEHIND the C ABI (csrc/shard.hip: pbn_scoredata_set_comm,
+pbn_shard_batch, pbn_scoredata_reduce_moments, pbn_kde_slogl_sharded; include/pbn_hip.h "one process per GPU").  This module only supplies
+the ONE collective the library asks its host for: an all-gather of doubles, here through torch.distributed.  A C++ host supplies
+ncclAllGather instead and needs nothing of this file.
+
+Independent units = candidates / terms / slices / test rows: every rank holds the whole table, one all_gather of a few
+hundred doubles per batch gives every rank the full result in fixed rank order, so that all ranks take the same deterministic find_max
+decision.  No other collective is on the data path.
 """
+import ctypes as C
+import os
+
 import numpy as np
 
+from . import _lib
 
-_EMULATED = None   # measurement aid (tools/scale_emulate.py): an object with get_rank / get_world_size / emulate(times per rank)
+# The collective path normally needs world_size > 1.  FORCE (or PBN_FORCE_DIST=1) takes it at world size 1 as well - one rank dealing
+# everything to itself through a real all_gather: how a one-GPU box executes the RCCL path (tests/test_distributed_gpu.py, bench.py).
+FORCE = False
+
+
+def _forced():
+    return FORCE or os.environ.get("PBN_FORCE_DIST", "") not in ("", "0")
 
 
 def _dist():
-    if _EMULATED is not None:
-        return _EMULATED
     try:
         import torch.distributed as dist
     except Exception:  # pragma: no cover
         return None
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dist if (dist.get_world_size() > 1 or _forced()) else None
 
 
 _GATHER_BUFS = {}
@@ -42,7 +57,7 @@ def _all_gather(dist, buf):
     # a search: a set per exact length would accumulate pinned allocations, each costing more than the pageable copy it replaces)
     cap = 1 << max(10, int(buf.size - 1).bit_length())
     have = _GATHER_BUFS.get(dev.index)
-    if have is None or have[0].numel() < cap:
+    if have is None or have[0].numel() < cap or have[2].numel() < world * cap:
         have = (torch.empty(cap, dtype=torch.float64).pin_memory(), torch.empty(cap, dtype=torch.float64, device=dev),
                 torch.empty(world * cap, dtype=torch.float64, device=dev), torch.empty(world * cap, dtype=torch.float64).pin_memory())
         _GATHER_BUFS[dev.index] = have
@@ -56,27 +71,56 @@ def _all_gather(dist, buf):
     return recv_h.numpy().copy()
 
 
-# relative cost of one CKDE candidate by the number of variables of its joint set (variable + parents): measured sweep times at
-# 1e6 x 1e5 rows (profiles/r2/sweep_dims.txt: KDE of d dimensions = the joint term; KDE of d - 1 = the marginal term)
-_KDE_MS = {1: 15.5, 2: 11.1, 3: 12.8, 4: 19.7, 5: 36.3, 6: 45.4, 7: 50.7}
+class Comm:
+    """pbn_comm over a torch.distributed process group: rank, world and the all-gather callback (kept alive with the object).  An
+    exception inside the collective is kept in `errors` and re-raised by `check` once the C call has returned."""
+
+    def __init__(self, dist):
+        self.dist, self.errors, self.gathers = dist, [], 0
+
+        def gather(_user, send, count, recv):
+            try:
+                allv = _all_gather(dist, np.ctypeslib.as_array(send, shape=(int(count),)))
+                C.memmove(recv, allv.ctypes.data, allv.nbytes)
+                self.gathers += 1
+                return 0
+            except Exception as ex:  # surfaced after the C call returns
+                self.errors.append(ex)
+                return 1
+
+        self._cb = _lib.ALLGATHER_FN(gather)
+        self.struct = _lib.Comm(int(dist.get_rank()), int(dist.get_world_size()), self._cb, None)
+
+    def ref(self):
+        return C.byref(self.struct)
+
+    def check(self, rc):
+        if self.errors:
+            err, self.errors = self.errors[0], []
+            raise err
+        _lib.check(rc)
 
 
-# batches with fewer unknown terms than this many per rank are dealt by (term, fold) instead of by term (sharded_batch)
-_SPLIT_TERMS_BELOW = 4
+_COMM = None
 
 
-def _kde_cost(d):
-    return _KDE_MS.get(d, 51.6 + 5.0 * max(0, d - 8)) if d >= 1 else 0.0
+def comm():
+    """The process's communicator, or None without torch.distributed (or at world size 1 unless forced)."""
+    global _COMM
+    dist = _dist()
+    if dist is None:
+        return None
+    if _COMM is None or _COMM.dist is not dist or _COMM.struct.world != dist.get_world_size() or _COMM.struct.rank != dist.get_rank():
+        _COMM = Comm(dist)
+    return _COMM
 
 
-def deal_sets(keys, world):
-    """Owner rank of every variable set: longest processing time first on a cost model (one joint sweep per set + one marginal
-    sweep per candidate, x folds x rows being common factors), ties by a hash of the set, each set to the least loaded rank
-    (lowest rank on ties).  Deterministic, identical on every rank.  keys: list of (set, number of candidates) in order of
-    first appearance."""
-    # equal costs (the initial cache: every set a pair) are ordered by a hash of the set, not by appearance: in order of appearance
-    # rank r gets the sets i = r mod world, i.e. the pairs of the SAME few variables - and a variable whose sweeps prune badly made
-    # its rank 25 % slower than the mean of eight (tools/scale_emulate.py); scattered, the ranks' sums differ by a few percent
+def deal_sets(keys, world, rows=(1_000_000, 100_000), regions=1):
+    """Owner rank of every variable set (pbn_shard_deal on pbn_shard_term_cost: one joint sweep per set + one marginal sweep per
+    candidate; longest processing time first, equal costs by a hash of the set, each set to the least loaded rank).  Deterministic,
+    identical on every rank.  keys: list of (set, number of candidates)."""
+    lib = _lib.load()
+
     def mix(key):
         h = 0x9E3779B9
         for v in key:
@@ -84,268 +128,173 @@ def deal_sets(keys, world):
             h ^= h >> 13
         return h
 
-    cost = [(_kde_cost(len(k)) + n * _kde_cost(len(k) - 1), mix(k), -i) for i, (k, n) in enumerate(keys)]
-    order = sorted(range(len(keys)), key=lambda i: cost[i], reverse=True)
-    load = [0.0] * world
-    owner = [0] * len(keys)
-    for i in order:
-        r = min(range(world), key=lambda q: (load[q], q))
-        owner[i] = r
-        load[r] += cost[i][0]
-    return owner
+    n = len(keys)
+    cost = np.asarray([regions * (term_cost(len(k), *rows) + c * term_cost(len(k) - 1, *rows)) for k, c in keys], dtype=np.float64)
+    tie = (C.c_uint32 * max(1, n))(*[mix(k) for k, _ in keys])
+    owner = (C.c_int * max(1, n))()
+    _lib.check(lib.pbn_shard_deal(n, _lib.dptr(cost) if n else None, tie, int(world), None, owner))
+    return list(owner)[:n]
 
 
-def _raise_if_failed(flags, failure, where):
-    """Every rank took part in the collective; if any of them failed while computing its share, all raise together."""
-    bad = [r for r, f in enumerate(flags) if f != 0.0]
-    if failure is not None:
-        raise failure
-    if bad:
-        raise RuntimeError(f"{where}: rank(s) {bad} failed while computing their share of the batch")
+def term_cost(dims, train_rows=1_000_000, test_rows=100_000):
+    return float(_lib.load().pbn_shard_term_cost(int(dims), int(train_rows), int(test_rows)))
 
 
 def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
-def _gather_shares(dist, world, rank, lists, compute, where):
-    """Rank r evaluates compute(lists[r]) -> values; every rank gets every rank's values (one all_gather; a failure anywhere raises
-    everywhere).  Under the emulation hook one process plays the ranks in turn and reports each share's seconds."""
-    if hasattr(dist, "emulate"):
-        import time
+class _PyEngine:
+    """pbn_shard_engine over a Python score object (`_batch_raw`, optionally `_terms` / `_term_regions` / `_batch_parts` / `_shard_shape`):
+    scores that are not bound to the library's own handle - user-defined ones, the stand-ins of the CPU tests."""
 
-        times, vals = [], []
-        for r in range(world):
-            t0 = time.perf_counter()
-            vals.append(np.asarray(compute(lists[r]), dtype=np.float64) if lists[r] else np.zeros(0))
-            times.append(time.perf_counter() - t0)
-        dist.emulate(times, [len(l) for l in lists])
-        return vals
-    mine = lists[rank]
-    per = max(1, max(len(l) for l in lists))
-    buf = np.zeros(per + 1)                    # last slot: this rank's error flag
-    failure = None
-    try:
-        buf[: len(mine)] = compute(mine) if mine else np.zeros(0)
-    except Exception as ex:                    # never skip the collective: the other ranks are already on their way to it
-        failure = ex
-        buf[:] = np.nan
-        buf[per] = 1.0
-    allv = _all_gather(dist, buf).reshape(world, per + 1)
-    _raise_if_failed(allv[:, per], failure, where)
-    return [allv[r, : len(lists[r])] for r in range(world)]
+    def __init__(self, score, model):
+        self.errors = []
+        ip, dp = _lib._ip, _lib._dp
+        n_cont = len(score._table.names) if getattr(score, "_table", None) is not None else None
 
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as ex:  # surfaced after the C call returns
+                    self.errors.append(ex)
+                    return 1
+            return wrapped
 
-def _deal(keys, world):
-    owner = deal_sets(keys, world)
-    return [[i for i in range(len(keys)) if owner[i] == r] for r in range(world)]
+        def cands(n, var, nt, off, par):
+            o = [off[i] for i in range(n + 1)]
+            return [var[i] for i in range(n)], [nt[i] for i in range(n)], o, [par[i] for i in range(o[-1])]
+
+        def terms_of(n, off, vars_, m):
+            return [(m[i],) + tuple(vars_[j] for j in range(off[i], off[i + 1])) for i in range(n)]
+
+        def shape(_u, kind, regions, ntr, nte):
+            regions[0] = int(score._term_regions(kind)) if hasattr(score, "_term_regions") else 1
+            rows = score._shard_shape(kind) if hasattr(score, "_shard_shape") else (0, 0)
+            ntr[0], nte[0] = int(rows[0]), int(rows[1])
+
+        def batch(_u, kind, n, var, nt, off, par, out):
+            v, t, o, p = cands(n, var, nt, off, par)
+            res = score._batch_raw(model, v, t, o, p, kind)
+            for i in range(n):
+                out[i] = res[i]
+
+        def missing(_u, kind, n, off, vars_, m, flags):
+            res = score._terms("missing", kind, terms_of(n, off, vars_, m))
+            for i in range(n):
+                flags[i] = int(res[i])
+
+        def terms(_u, kind, n, off, vars_, m, out):
+            res = score._terms("eval", kind, terms_of(n, off, vars_, m))
+            for i in range(n):
+                out[i] = res[i]
+
+        def term_regions(_u, kind, n, off, vars_, m, region, out):
+            res = score._terms("eval_regions", kind, terms_of(n, off, vars_, m), regions=[region[i] for i in range(n)])
+            for i in range(n):
+                out[i] = res[i]
+
+        def put(_u, kind, n, off, vars_, m, values):
+            score._terms("put", kind, terms_of(n, off, vars_, m), np.asarray([values[i] for i in range(n)], dtype=np.float64))
+
+        def parts(_u, kind, n, var, nt, off, par, part, n_parts, out):
+            v, t, o, p = cands(n, var, nt, off, par)
+            res = np.asarray(score._batch_parts(model, v, t, o, p, kind, part, n_parts), dtype=np.float64).reshape(-1)
+            for i in range(n * 64):
+                out[i] = res[i]
+
+        E = _lib.ShardEngine
+        f = dict(E._fields_)
+        has_terms = n_cont is not None and hasattr(score, "_terms")
+        has_parts = n_cont is not None and hasattr(score, "_batch_parts")
+        self._cbs = dict(shape=f["shape"](guard(shape)), batch=f["batch"](guard(batch)),
+                         terms_missing=f["terms_missing"](guard(missing)) if has_terms else f["terms_missing"](),
+                         terms=f["terms"](guard(terms)) if has_terms else f["terms"](),
+                         term_regions=f["term_regions"](guard(term_regions)) if has_terms and hasattr(score, "_term_regions") else f["term_regions"](),
+                         terms_put=f["terms_put"](guard(put)) if has_terms else f["terms_put"](),
+                         batch_parts=f["batch_parts"](guard(parts)) if has_parts else f["batch_parts"]())
+        self.struct = E(None, int(n_cont) if n_cont is not None else 0, *[self._cbs[k] for k in ("shape", "batch", "terms_missing", "terms", "term_regions",
+                                                                                                   "terms_put", "batch_parts")])
 
 
 def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
-    """Score a batch; with torch.distributed initialised the device-heavy work (CKDE node type under a likelihood score: k sweeps
-    per term) is sharded over the ranks, while LinearGaussian candidates - O(p^3) host arithmetic on replicated moments - are computed
-    redundantly by every rank (sharding them buys nothing and costs a collective).
-    Continuous CKDE candidates are sharded by TERM: local(v | P) = A({v} u P) - A(P), and A({s}) serves every child of s, A({s, t})
-    both directions of the arc - dealing candidates made every rank sweep all 64 single-variable terms of the initial cache itself
-    (150 of its 535 ms at eight ranks, tools/scale_emulate.py).  The unknown terms of the batch are dealt by cost, evaluated
-    (pbn_score_terms), all-gathered and installed on every rank (pbn_score_terms_put); every rank then assembles the candidates from
-    the same doubles - the very sums the one-process run forms.  Candidates with discrete parents (hybrid scores) are dealt whole."""
-    from . import _lib
-
-    dist = _dist()
+    """Score a batch; with torch.distributed initialised the device-heavy work is sharded over the ranks by the library (shard.hip).  A device
+    score created under the process group has the communicator bound to its handle: its plain `_batch_raw` (pbn_score_batch) IS the sharded
+    call.  Any other score object goes through pbn_shard_batch with its Python methods as the engine."""
+    cm = comm()
     n = len(var)
-    if dist is None or n == 0:
+    if cm is None or n == 0:
         return score._batch_raw(model, var, ntype, off, par, kind)
-    heavy = [i for i in range(n) if shard_all or ntype[i] == _lib.PBN_NODE_CKDE]
+    if getattr(score, "_comm", None) is cm and not shard_all:
+        try:
+            return score._batch_raw(model, var, ntype, off, par, kind)
+        finally:
+            if cm.errors:   # the collective itself failed inside the library call: its own exception
+                err, cm.errors = cm.errors[0], []
+                raise err
+    eng = _PyEngine(score, model)
     out = np.zeros(n)
-
-    def sub(idx):
-        o, p = [0], []
-        for i in idx:
-            p.extend(par[off[i]: off[i + 1]])
-            o.append(len(p))
-        return score._batch_raw(model, [var[i] for i in idx], [ntype[i] for i in idx], o, p, kind)
-
-    rank, world = dist.get_rank(), dist.get_world_size()
-    n_cont = len(score._table.names) if getattr(score, "_table", None) is not None else None   # column ids below it are continuous
-    by_term = [i for i in heavy if ntype[i] == _lib.PBN_NODE_CKDE and kind in (_lib.PBN_SCORE_CVLIK, _lib.PBN_SCORE_HOLDOUT) and n_cont is not None
-               and var[i] < n_cont and all(q < n_cont for q in par[off[i]: off[i + 1]]) and hasattr(score, "_terms")]
-    if len(by_term) >= 2:
-        terms, seen = [], {}
-        for i in by_term:
-            ps = list(par[off[i]: off[i + 1]])
-            d = len(ps) + 1
-            for key in ((d,) + tuple(sorted([var[i]] + ps)), ((d,) + tuple(sorted(ps))) if ps else None):
-                if key is not None and key not in seen:
-                    seen[key] = len(terms)
-                    terms.append(key)
-        missing = score._terms("missing", kind, terms)
-        todo = [t for t, mflag in zip(terms, missing) if mflag]
-        regions = score._term_regions(kind) if hasattr(score, "_term_regions") else 1
-        if todo and regions > 1 and len(todo) < _SPLIT_TERMS_BELOW * world:
-            # an update batch of a search: a handful of terms, fewer than ranks or not many more - dealt whole, five terms leave three
-            # of eight ranks idle and two with double work.  Dealt (term, fold) by (term, fold) instead: a term's total is its folds
-            # added in fold order, so the per-fold values are gathered and every rank adds them in that order - the one-process double.
-            items = [(j, f) for j in range(len(todo)) for f in range(regions)]
-            cost = [_kde_cost(len(todo[j]) - 1) for j, _ in items]
-            order = sorted(range(len(items)), key=lambda i: (-cost[i], i))
-            load, lists = [0.0] * world, [[] for _ in range(world)]
-            for i in order:
-                r = min(range(world), key=lambda q: (load[q], q))
-                lists[r].append(i)
-                load[r] += cost[i]
-            vals = _gather_shares(dist, world, rank, lists, lambda idx: score._terms("eval_regions", kind, [todo[items[i][0]] for i in idx],
-                                                                                     regions=[items[i][1] for i in idx]), "sharded_batch")
-            per = np.zeros((len(todo), regions))
-            for r in range(world):
-                for i, v in zip(lists[r], np.asarray(vals[r], dtype=np.float64)):
-                    per[items[i][0], items[i][1]] = v
-            totals = []
-            for j in range(len(todo)):
-                acc = 0.0
-                for x in per[j].tolist():   # the folds in order, as the engine adds them
-                    acc += x
-                totals.append(acc)
-            score._terms("put", kind, todo, np.asarray(totals))
-        elif todo:
-            lists = _deal([(t[1:], 0) for t in todo], world)
-            vals = _gather_shares(dist, world, rank, lists, lambda idx: score._terms("eval", kind, [todo[j] for j in idx]), "sharded_batch")
-            flat_t = [todo[j] for r in range(world) for j in lists[r]]
-            flat_v = np.concatenate([np.asarray(v, dtype=np.float64) for v in vals]) if flat_t else np.zeros(0)
-            score._terms("put", kind, flat_t, flat_v)
-        taken = set(by_term)
-        heavy = [i for i in heavy if i not in taken]
-    else:
-        by_term = []
-    whole = set(heavy)
-    rest = [i for i in range(n) if i not in whole]   # light candidates + the term-sharded ones: every rank, from the shared terms
-    if rest:
-        out[rest] = sub(rest)
-    # CKDE candidates with discrete parents: the update batches of a restricted search hold a handful of them - fewer than ranks, each
-    # 10-50 ms of sweeps - so the ranks share every candidate's SLICES (configuration x fold): rank r evaluates the parts dealt to it
-    # (by cost, identically on every rank) of the engine's 64 fixed parts (pbn_score_batch_parts), the per-part sums are all-gathered, added over the ranks (a part
-    # is non-zero on one rank only) and then over the parts in order - the one-process sum, bit for bit (tools/scale_emulate.py on
-    # BASELINE config 5, eight ranks: 3.1 s dealing whole candidates, a third of the batches unsharded for holding one candidate)
-    sliced = [i for i in heavy if hasattr(score, "_batch_parts") and world <= 64 and ntype[i] == _lib.PBN_NODE_CKDE and n_cont is not None
-              and kind in (_lib.PBN_SCORE_CVLIK, _lib.PBN_SCORE_HOLDOUT) and var[i] < n_cont and any(q >= n_cont for q in par[off[i]: off[i + 1]])]
-    if sliced:
-        o, p = [0], []
-        for i in sliced:
-            p.extend(par[off[i]: off[i + 1]])
-            o.append(len(p))
-        sv, st = [var[i] for i in sliced], [ntype[i] for i in sliced]
-        share = lambda r: score._batch_parts(model, sv, st, o, p, kind, r, world).reshape(-1)
-        if hasattr(dist, "emulate"):
-            import time
-
-            times, total = [], np.zeros(len(sliced) * 64)
-            for r in range(world):
-                t0 = time.perf_counter()
-                total += share(r)
-                times.append(time.perf_counter() - t0)
-            dist.emulate(times, [len(sliced)] * world)
-        else:
-            buf = np.zeros(len(sliced) * 64 + 1)
-            failure = None
-            try:
-                buf[:-1] = share(rank)
-            except Exception as ex:                # never skip the collective
-                failure = ex
-                buf[:] = np.nan
-                buf[-1] = 1.0
-            allv = _all_gather(dist, buf).reshape(world, -1)
-            _raise_if_failed(allv[:, -1], failure, "sharded_batch")
-            total = np.zeros(len(sliced) * 64)
-            for r in range(world):                 # exact: every part is non-zero on one rank only
-                total += allv[r, :-1]
-        total = total.reshape(len(sliced), 64)
-        for j, i in enumerate(sliced):
-            acc = 0.0
-            for x in total[j].tolist():            # the parts in order, as the engine adds them
-                acc += x
-            out[i] = acc
-        done = set(sliced)
-        heavy = [i for i in heavy if i not in done]
-    if len(heavy) < 2:
-        if heavy:
-            out[heavy] = sub(heavy)
-        return out
-    # whole candidates (anything else that is heavy): those over the same variable set share their sums in the engine's set-function
-    # cache and go to the same rank; the sets are dealt by cost (deal_sets), identically on every rank
-    set_of, counts = {}, []
-    for i in heavy:
-        key = tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))
-        if key not in set_of:
-            set_of[key] = len(set_of)
-            counts.append([key, 0])
-        counts[set_of[key]][1] += 1
-    set_owner = deal_sets([(k, c) for k, c in counts], world)
-    owner = [set_owner[set_of[tuple(sorted([var[i]] + list(par[off[i]: off[i + 1]])))]] for i in heavy]
-    lists = [[heavy[j] for j in range(len(heavy)) if owner[j] == r] for r in range(world)]
-    vals = _gather_shares(dist, world, rank, lists, sub, "sharded_batch")
-    for r in range(world):
-        out[lists[r]] = vals[r]
+    rc = _lib.load().pbn_shard_batch(C.byref(eng.struct), cm.ref(), int(kind), n, _lib.int_array(var), _lib.int_array(ntype), _lib.int_array(off),
+                                     _lib.int_array(par if par else [0]), int(bool(shard_all)), _lib.dptr(out))
+    if eng.errors:
+        raise eng.errors[0]
+    cm.check(rc)
     return out
 
 
 def sharded_slogl(factor, df):
-    """KDE / ProductKDE / CKDE `slogl(df)` with the test rows split over the ranks (independent units =
-    test rows, fitted model replicated).  Every rank passes the same `df`; rank r evaluates the contiguous slice
-    [r*m/W, (r+1)*m/W), the W partial sums are all-gathered and added in rank order (deterministic), and every rank
-    returns the same total.  Without torch.distributed it is `factor.slogl(df)`."""
-    dist = _dist()
-    if dist is None:
+    """KDE / ProductKDE / CKDE `slogl(df)` with the test rows split over the ranks (independent units = test rows, fitted
+    model replicated): pbn_kde_slogl_sharded - rank r evaluates the contiguous slice [r*m/W, (r+1)*m/W), the W partial sums are
+    all-gathered and added in rank order, every rank returns the same total.  Without torch.distributed it is `factor.slogl(df)`."""
+    cm = comm()
+    if cm is None:
         return factor.slogl(df)
-    import torch
+    if getattr(factor, "_split", False) or not hasattr(factor, "_upload_test") or not hasattr(factor, "_handle"):
+        # factors that are not one library handle: this rank's rows through the factor's own slogl, the same gather
+        from .dataset import as_record_batch
 
-    from .dataset import as_record_batch
-
-    rb = as_record_batch(df)
-    rank, world = dist.get_rank(), dist.get_world_size()
-    m = rb.num_rows
-    lo, hi = (m * rank) // world, (m * (rank + 1)) // world
-    buf = np.zeros(2)
-    failure = None
-    try:
-        buf[0] = factor.slogl(rb.slice(lo, hi - lo)) if hi > lo else 0.0
-    except Exception as ex:
-        failure = ex
-        buf[:] = (np.nan, 1.0)
-    allv = _all_gather(dist, buf).reshape(world, 2)
-    _raise_if_failed(allv[:, 1], failure, "sharded_slogl")
-    total = 0.0
-    for v in allv[:, 0].tolist():
-        total += v
-    return total
+        rb = as_record_batch(df)
+        rank, world, m = cm.struct.rank, cm.struct.world, rb.num_rows
+        lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+        buf, failure = np.zeros(2), None
+        try:
+            buf[0] = factor.slogl(rb.slice(lo, hi - lo)) if hi > lo else 0.0
+        except Exception as ex:
+            failure, buf[:] = ex, (np.nan, 1.0)
+        allv = _all_gather(cm.dist, buf).reshape(world, 2)
+        if failure is not None:
+            raise failure
+        bad = [r for r in range(world) if allv[r, 1] != 0.0]
+        if bad:
+            raise RuntimeError(f"sharded_slogl: rank(s) {bad} failed while computing their share of the batch")
+        total = 0.0
+        for v in allv[:, 0].tolist():
+            total += v
+        return total
+    _, table, _ = factor._upload_test(df)
+    res = C.c_double(0.0)
+    rc = _lib.load().pbn_kde_slogl_sharded(factor._handle, table.handle, _lib.int_array(table.index(factor._variables)), 0, table.num_rows,
+                                           cm.ref(), C.byref(res))
+    cm.check(rc)
+    return res.value
 
 
 def reduce_moments(handle):
-    """Row-sharded Gram (BGe / BIC / LG-CV row): every rank computed the moments of its share of
-    each region (pbn_scoredata_create_sharded); all-gather the (k+1) * (n + n^2) doubles, add them in rank order on
-    the host (deterministic, identical on every rank) and install the totals."""
-    import ctypes as C
-
-    import torch
-
-    from . import _lib
-
-    dist = _dist()
-    lib = _lib.load()
-    ln = C.c_int64(0)
-    _lib.check(lib.pbn_scoredata_moments(handle, None, C.byref(ln), 0))
-    buf = np.zeros(ln.value)
-    _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 0))
-    if dist is not None:
-        world = dist.get_world_size()
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        send = torch.from_numpy(buf).to(dev)
-        recv = torch.empty(world * buf.size, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(recv, send)
-        parts = recv.cpu().numpy().reshape(world, buf.size)
-        buf = parts[0].copy()
-        for r in range(1, world):
-            buf += parts[r]
-    _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 1))
+    """Row-sharded Gram (BGe / BIC / LG-CV row): every rank computed the moments of its share of each region
+    (pbn_scoredata_create_sharded); pbn_scoredata_reduce_moments all-gathers them, adds them in rank order (deterministic, identical on
+    every rank) and installs the totals."""
+    cm = comm()
+    if cm is None:
+        ln = C.c_int64(0)
+        lib = _lib.load()
+        _lib.check(lib.pbn_scoredata_moments(handle, None, C.byref(ln), 0))
+        buf = np.zeros(ln.value)
+        _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 0))
+        _lib.check(lib.pbn_scoredata_moments(handle, _lib.dptr(buf), C.byref(ln), 1))
+        return
+    cm.check(_lib.load().pbn_scoredata_reduce_moments(handle, cm.ref()))
 
 
 def sharded_ci_batch(fn, native_batch, user, errors):
@@ -353,20 +302,13 @@ def sharded_ci_batch(fn, native_batch, user, errors):
     all_gather per batch).  Every rank runs the same search; test i of a batch is evaluated by rank i % world - through
     the native batched callback when the test has one, else one by one - and the p-values are gathered, so every rank
     sees bit-identical numbers and takes identical decisions.  Returns (batch callback or None, keep-alive)."""
-    import ctypes as C
-
-    from . import _lib
-
-    dist = _dist()
-    if dist is None:
+    cm = comm()
+    if cm is None:
         return native_batch, None
-    import torch
-
-    rank, world = dist.get_rank(), dist.get_world_size()
+    dist = cm.dist
+    rank, world = cm.struct.rank, cm.struct.world
     single = fn if callable(fn) else _lib.CI_PVALUE_FN(fn.value)
     native = _lib.CI_BATCH_FN(native_batch.value) if native_batch is not None else None
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
     def batch(_user, n, v1, v2, off, cond, out):
         mine = list(range(rank, n, world))

@@ -182,18 +182,21 @@ class _DeviceScore(Score):
         self._col = {n: i for i, n in enumerate(self._names)}
         k, seed, ratio = split_args
         h = C.c_void_p()
-        from .distributed import reduce_moments, _dist
+        from .distributed import comm
 
-        dist = _dist()
-        if dist is None or hasattr(dist, "emulate"):   # (emulate: the one-process scaling estimate of tools/scale_emulate.py)
+        cm = comm()
+        self._comm = cm
+        if cm is None:
             _lib.check(_lib.load().pbn_scoredata_create(self._ctx.handle, table.handle, self._split, int(k), C.c_uint32(int(seed)),
                                                         float(ratio), C.byref(h)))
         else:
-            # one process per GPU: each rank takes the Gram of its share of the rows, one exchange of the moments
+            # one process per GPU: each rank takes the Gram of its share of the rows, one exchange of the moments; from then on
+            # pbn_score_batch on this handle evaluates this rank's share of every batch and completes it through the job's all-gather
             _lib.check(_lib.load().pbn_scoredata_create_sharded(self._ctx.handle, table.handle, self._split, int(k),
-                                                                C.c_uint32(int(seed)), float(ratio), dist.get_rank(),
-                                                                dist.get_world_size(), C.byref(h)))
-            reduce_moments(h)
+                                                                C.c_uint32(int(seed)), float(ratio), cm.struct.rank,
+                                                                cm.struct.world, C.byref(h)))
+            cm.check(_lib.load().pbn_scoredata_reduce_moments(h, cm.ref()))
+            _lib.check(_lib.load().pbn_scoredata_set_comm(h, cm.ref()))
         self._handle = h
         if getattr(self, "_masks", None):
             keep = [np.ascontiguousarray(self._masks[c].astype(np.uint8)) if c in self._masks else None for c in self._cont_names]

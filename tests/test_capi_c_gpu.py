@@ -1,5 +1,6 @@
-"""GPU tier: a plain-C program (tests/c/capi_demo.c) drives the C ABI directly — no Python, no torch — and
-must agree with the Python mirror on the same data."""
+"""GPU tier: plain-C programs (tests/c/*.c) drive the C ABI directly - no Python, no torch - and a C caller must get the REFERENCE's
+numbers: the outputs are compared with the oracle (oracle/pbn_oracle.cpp, the reference's arithmetic) on the same xorshift tables, and
+only in second place with the Python mirror of the same library."""
 import os
 import subprocess
 
@@ -31,8 +32,9 @@ def _table(u, n):
     return pd.DataFrame({"a": a, "b": 0.6 * a + b, "c": a - 0.4 * b + c})
 
 
-def test_c_program_matches_python(tmp_path):
+def test_c_program_matches_the_oracle(tmp_path):
     import pybnesian_amd as pbn
+    from oracle import oracle
 
     exe = str(tmp_path / "capi_demo")
     subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "capi_demo.c"),
@@ -44,12 +46,53 @@ def test_c_program_matches_python(tmp_path):
     n, m = 5000, 700
     u = _xorshift_stream(6 * (n + m))
     train, test = _table(u[: 6 * n], n), _table(u[6 * n:], m)
+    tr, te = train.to_numpy(), test.to_numpy()
+    # the reference's arithmetic on the same rows (north star: slogl within 1e-6 relative in fp64; held to 1e-9 here)
+    H = oracle.bandwidth(0, 0, oracle.cov(tr), n)          # NormalReferenceRule, full matrix (NormalReferenceRule.hpp:72-134)
+    want_kde = oracle.kde_logl(tr, H, te).sum()
+    want_ckde = oracle.ckde_logl(tr, H, te).sum()          # column 0 given columns 1, 2 (CKDE.hpp:256-287)
+    want_bic = oracle.bic_lg(tr[:, [2, 0, 1]])             # c | a, b (bic.cpp:29-64)
+    assert abs(float(vals["kde_slogl"]) - want_kde) <= 1e-9 * abs(want_kde)
+    assert abs(float(vals["ckde_slogl"]) - want_ckde) <= 1e-9 * abs(want_ckde)
+    assert abs(float(vals["bic_c_ab"]) - want_bic) <= 1e-9 * abs(want_bic)
+    assert int(vals["bad_rc"]) == 1  # PBN_ERR_INVALID
+    # and the Python mirror gives what the C caller got
     kde = pbn.KDE(["a", "b", "c"])
     kde.fit(train)
-    assert abs(float(vals["kde_slogl"]) - kde.slogl(test)) <= 1e-9 * abs(kde.slogl(test))
+    assert abs(float(vals["kde_slogl"]) - kde.slogl(test)) <= 1e-12 * abs(kde.slogl(test))
     ckde = pbn.CKDE("a", ["b", "c"])
     ckde.fit(train)
-    assert abs(float(vals["ckde_slogl"]) - ckde.slogl(test)) <= 1e-9 * abs(ckde.slogl(test))
-    bic = pbn.BIC(train).local_score(pbn.GaussianNetwork(["a", "b", "c"]), "c", ["a", "b"])
-    assert abs(float(vals["bic_c_ab"]) - bic) <= 1e-9 * abs(bic)
-    assert int(vals["bad_rc"]) == 1  # PBN_ERR_INVALID
+    assert abs(float(vals["ckde_slogl"]) - ckde.slogl(test)) <= 1e-12 * abs(ckde.slogl(test))
+
+
+def test_c_host_with_rccl_shards_the_delta_cache(tmp_path):
+    """tests/c/shard_rccl_demo.c: a C host that owns an RCCL communicator (one rank on this GPU) and hands the library ONE function, an
+    all-gather over ncclAllGather on device memory.  pbn_score_batch on the handle with the communicator bound plans the batch, evaluates
+    this rank's share, makes one collective and assembles - the scores must be the one-process scores bit for bit (the program checks), and
+    the CV likelihoods the oracle's (checked here)."""
+    from oracle import oracle
+
+    exe = str(tmp_path / "shard_rccl_demo")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "c", "shard_rccl_demo.c"), "-L" + os.path.join(ROOT, "pybnesian_amd"), "-lpbn_hip",
+                           "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "pybnesian_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                           "-lm", "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    vals = dict(line.split() for line in out.stdout.strip().splitlines() if len(line.split()) == 2)
+    assert int(vals["rccl_ranks"]) == 1 and int(vals["bit_identical"]) == 1
+    assert int(vals["collectives_first_batch"]) == 1            # ONE all-gather per batch
+    assert int(vals["collectives_total"]) == 3                  # moments + two batches
+    assert int(vals["sweeps_sharded"]) == int(vals["sweeps_one"])   # one rank: dealt everything, nothing swept twice
+    n = 3000
+    u = _xorshift_stream(8 * n).reshape(n, 8)
+    a = u[:, 0] + u[:, 1] + u[:, 2] - 1.5
+    b = u[:, 3] + u[:, 4] - 1.0
+    c = u[:, 5] - 0.5
+    e = u[:, 6] + u[:, 7] - 1.0
+    x = np.column_stack([a, 0.6 * a + b, a - 0.4 * b + c, 0.3 * c + e])
+    cands = [(1, [0], "ckde"), (0, [1], "ckde"), (2, [0, 1], "ckde"), (3, [], "ckde"), (3, [2], "ckde"), (2, [0], "lg")]
+    for i, (v, ps, kind) in enumerate(cands):
+        want = oracle.cv_likelihood(x[:, [v] + ps], kind, 3, 7)
+        assert abs(float(vals[f"score_{i}"]) - want) <= 1e-6 * abs(want), (i, vals[f"score_{i}"], want)

@@ -160,18 +160,21 @@ def test_failed_rank_does_not_hang_the_collective(ensure_built):
     assert second[0] == second[1] == [float(i) for i in range(8)]
 
 
-def test_deal_sets_longest_first_is_balanced_and_deterministic():
-    """distributed.deal_sets: CKDE variable sets are dealt longest-processing-time first on the cost model (a d = 5 candidate
-    costs 3-4x a d = 2 one): no rank carries more than the mean load + one set, and the dealing is a pure function of the
-    batch (every rank computes the same owners)."""
-    from pybnesian_amd.distributed import _kde_cost, deal_sets
+def test_deal_sets_longest_first_is_balanced_and_deterministic(ensure_built):
+    """pbn_shard_deal on pbn_shard_term_cost (distributed.deal_sets): CKDE variable sets are dealt longest-processing-time first on the
+    cost model (rows a sweep of the term's dimension meets x test rows): no rank carries more than the mean load + one set, and the
+    dealing is a pure function of the batch (every rank computes the same owners)."""
+    from pybnesian_amd.distributed import deal_sets, term_cost
 
     rng = np.random.default_rng(5)
     keys = []
     for _ in range(126):
         d = int(rng.integers(1, 6))
         keys.append((tuple(sorted(rng.choice(64, size=d, replace=False).tolist())), int(rng.integers(1, 3))))
-    cost = [_kde_cost(len(k)) + n * _kde_cost(len(k) - 1) for k, n in keys]
+    cost = [term_cost(len(k)) + n * term_cost(len(k) - 1) for k, n in keys]
+    assert term_cost(5) > 2.5 * term_cost(2) > 0 and term_cost(0) == 0.0
+    # pruned sweeps (d <= 4 on >= 32 768 training rows) meet ~ N^(4/(d+4)) rows per query: sub-linear in the training rows
+    assert term_cost(2, 4_000_000, 1000) < 3.0 * term_cost(2, 1_000_000, 1000) and term_cost(6, 4_000_000, 1000) == 4.0 * term_cost(6, 1_000_000, 1000)
     for world in (2, 3, 8):
         owner = deal_sets(keys, world)
         assert owner == deal_sets(list(keys), world)
@@ -262,11 +265,9 @@ def _term_worker(rank, world, port, queue, regions=1):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from pybnesian_amd import _lib, distributed
+        from pybnesian_amd import _lib
         from pybnesian_amd.distributed import sharded_batch
 
-        if regions > 1:
-            distributed._SPLIT_TERMS_BELOW = 100   # this batch's dozen terms count as "few": dealt (term, fold) by (term, fold)
         s = _FakeEngineScore(regions)
         first = sharded_batch(s, None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK)
         again = sharded_batch(s, None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK)   # every term known now
@@ -275,15 +276,15 @@ def _term_worker(rank, world, port, queue, regions=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("regions", [1, 3])
-def test_sharded_batch_deals_terms_and_slices_world2(ensure_built, regions):
-    """distributed.sharded_batch with an engine score: continuous CKDE candidates by TERM (each unknown term evaluated on exactly one
-    rank, totals installed everywhere, nothing evaluated again) - or, for a batch of few terms over several folds (regions = 3), by
-    (term, fold): each pair on exactly one rank, the folds added in fold order everywhere; hybrid CKDE candidates by SLICE (every rank
-    its parts of every candidate), the rest redundantly - and every rank returns the one-process values bit for bit."""
+@pytest.mark.parametrize("regions,world", [(1, 2), (3, 3)])
+def test_sharded_batch_deals_terms_and_slices_world2(ensure_built, regions, world):
+    """pbn_shard_batch (through distributed.sharded_batch) with an engine score: continuous CKDE candidates by TERM (each unknown term
+    evaluated on exactly one rank, totals installed everywhere, nothing evaluated again) - or, for a batch of few terms over several
+    folds (regions = 3 on three ranks: the batch's 8 terms are fewer than 4 per rank), by (term, fold): each pair on exactly one rank, the
+    folds added in fold order everywhere; hybrid CKDE candidates by SLICE (every rank its parts of every candidate), the rest
+    redundantly - and every rank returns the one-process values bit for bit."""
     from pybnesian_amd import _lib
 
-    world = 2
     ref = _FakeEngineScore(regions)._batch_raw(None, _BATCH["var"], _BATCH["ntype"], _BATCH["off"], _BATCH["par"], _lib.PBN_SCORE_CVLIK).tolist()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

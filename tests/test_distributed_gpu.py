@@ -82,3 +82,22 @@ def test_sharded_delta_cache_with_device_ckde_scores_world2(backend):
     # the device work was split, and no term was swept twice: together the ranks made exactly the single process's (term, fold) sweeps
     assert max(r["sweeps"] for r in ranks) < single["sweeps"]
     assert sum(r["sweeps"] for r in ranks) == single["sweeps"]
+
+
+def test_rccl_world1_on_one_gpu():
+    """The RCCL path EXECUTED on the one GPU a box has: a fresh child (tools/rccl_world1.py) initialises torch.distributed's "nccl"
+    backend with one rank, forces the product's one-process-per-GPU path (PBN_FORCE_DIST / distributed.FORCE) and runs the searches of
+    dist_worker_gpu.py through it - every delta-cache batch planned by csrc/shard.hip, gathered by RCCL on device buffers
+    (distributed._all_gather's nccl branch), the moments row-sharded and reduced (pbn_scoredata_reduce_moments), the KDE slogl through
+    pbn_kde_slogl_sharded - and compares every trace, delta and score with the plain calls, bit for bit.  Also records which
+    libamdhip64 / librccl the process mapped (libpbn_hip.so is linked against /opt/rocm's runtime, torch brings its own)."""
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", PBN_DEVICE="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert p.returncode == 0 and lines, (p.stdout[-1500:], p.stderr[-3000:])
+    out = json.loads(lines[-1][len("RESULT "):])
+    assert out["ok"] and out["rccl_ranks_seen"] == 1 and out["all_gather_identity"]
+    assert all(out["bit_identical"].values()), out["bit_identical"]
+    assert out["collectives"] >= 10                       # one all-gather per delta-cache batch + the moments
+    assert out["mapped"].get("librccl") and out["mapped"].get("libamdhip64") and out["mapped"].get("libpbn_hip")
