@@ -330,9 +330,12 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         names = [f"x{i}" for i in range(n_cols)]
         torch.cuda.synchronize()
         table = pbn.DeviceTable.from_device_pointer(ctx, t.data_ptr(), n_rows, names, n_rows, _lib.PBN_F64, keepalive=t)
+        ctx.set_profiling(2)
         t0 = time.perf_counter()
         score = pbn.BGe(None, table=table)
         t_ctor = time.perf_counter() - t0
+        gram_ms, gram_n = ctx.kernel_time(_lib.PBN_K_GRAM)
+        ctx.set_profiling(False)
         start, ops = pbn.GaussianNetwork(names), pbn.ArcOperatorSet()
         label = f"C4: 64-node GaussianNetwork, BGe, ArcOperatorSet, {n_rows} rows fp64"
         kw = {}
@@ -435,10 +438,23 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         kw["max_iters"] = max_iters
     want_cpu = cpu and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PBN_BENCH_NO_CPU")
     log = EvalLog(score) if (want_cpu and cpu_cfg is not None) else None
+    ctx.set_profiling(2)   # HIP events around the library's launches, nothing else changes (pbn_ctx_set_profiling: 2 = timing only)
     t0 = time.perf_counter()
     res = hc.estimate(ops, score, start, **kw)
     dt = time.perf_counter() - t0
+    kt = {name: ctx.kernel_time(cls) for name, cls in (("pack", _lib.PBN_K_PACK), ("sweep", _lib.PBN_K_SWEEP), ("finish", _lib.PBN_K_FINISH), ("gram", _lib.PBN_K_GRAM))}
+    ctx.set_profiling(False)
     more = dict(extra) if which == "c5mmhc" else {}
+    if which != "c4":
+        # the leg's dominant kernel and its share of the timed search, from the library's own HIP events (no profiler)
+        kname = {"c3": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only)",
+                 "cv64": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only)"}.get(
+                     which, "kde_sweep_bf16_group_kernel<1> (grouped pruned fp32 sweep on bf16x3 fragments) + the per-slice kde_sweep_bf16_kernel")
+        more["roofline"] = {"kernel": kname, "bound": "valu-issue (v_exp + add per pair value inside the pruning radius; DESIGN.md 3.1)",
+                            "device_s": kt["sweep"][0] * 1e-3, "launches": kt["sweep"][1], "share_of_estimate_s": kt["sweep"][0] * 1e-3 / dt,
+                            "pack_s": kt["pack"][0] * 1e-3, "finish_s": kt["finish"][0] * 1e-3, "gram_s": kt["gram"][0] * 1e-3,
+                            "note": "HIP events on the launching stream (issue lanes overlap: the classes' device seconds may add up to more "
+                                    "than the wall time); sort / key / box / prepass kernels are not in a class"}
     if log is not None:
         if host is None:   # device-generated table (n_cols x n_rows): the first m rows, column by column
             def host(m, t=t, names=names):
@@ -486,6 +502,29 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
             more["tie_accounting"] = dict(tie_accounting(pbn, hc, names, sc), rows=n_rows, oracle_moments_s=t_cov)
         except Exception as ex:
             more["tie_accounting"] = {"error": f"{type(ex).__name__}: {ex}"}
+    if which == "c4":
+        # north star: "MFMA utilisation for the covariance batch stated against gfx950 peak".  The BGe constructor's moments are ONE
+        # segmented Gram launch over the whole table (scoring.hip: compute_stats_segments -> gram_glds_kernel + the segment reduce):
+        # algorithmic bytes = rows x columns x 8 (every value read once), duration = HIP events of THIS run's constructor
+        gbytes = float(n_rows) * n_cols * 8.0
+        gsec = gram_ms * 1e-3 / max(gram_n, 1)
+        rec, why = pmc_record("gram_glds_kernel", "gram_pmc.json", "stats_kernels.hip")
+        roof = {"kernel": "gram_glds_kernel<4> (segmented form) + segment reduce", "bound": "hbm", "achieved": gbytes / gsec / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": gbytes / gsec / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": gbytes / gsec / 1e9 / 6290.0,
+                "algorithmic_bytes": gbytes, "launch_us": gsec * 1e6, "launches": gram_n,
+                "note": "HIP events around the constructor's Gram launch pair in this run; 6.29 TB/s = the best device-to-device copy measured on "
+                        "this part (profiles/r2/gram_floors.txt); flops = rows x n^2 x 2 on v_mfma_f64_16x16x4_f64"}
+        roof["mfma_tflops"] = float(n_rows) * n_cols * n_cols * 2.0 / gsec / 1e12
+        roof["mfma_frac_of_fp64_peak"] = roof["mfma_tflops"] / FP64_PEAK_TFLOPS
+        if rec is not None:
+            cyc = rec["GRBM_GUI_ACTIVE"] / 8.0
+            roof["mfma_busy"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc
+            roof["traffic"] = 2.0 * rec["FETCH_SIZE"] * 1024.0 if "FETCH_SIZE" in rec else None
+            roof["pmc_source"] = (f"profiles/{rec['_round']}/gram_pmc.json (separate rocprofv3 --pmc passes of tools/gram_bench.py on stats_kernels.hip blob "
+                                  f"{rec['_blob'][:12]} = the working tree's; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / GPU cycles; traffic = 2 x FETCH_SIZE)")
+        else:
+            roof["mfma_busy"], roof["traffic"], roof["pmc_source"] = None, None, why
+        more["roofline"] = roof
     return {
         **more,
         "metric": "hill-climb candidate-arcs scored/s",
@@ -511,32 +550,32 @@ def git_blob_sha1(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def pmc_record(kernel_substr):
-    """The committed rocprofv3 PMC record of one kernel (profiles/r*/pmc_per_dispatch.json, newest round first) - but only if it
-    was taken on THIS revision of the kernel source: the file stores the git blob hash of pybnesian_amd/csrc/kde_kernels.hip it was
-    collected on (`_source_blob`), and a record whose hash differs from the working tree's is stale evidence -> (None, reason)."""
-    src = os.path.join(ROOT, "pybnesian_amd", "csrc", "kde_kernels.hip")
+def pmc_record(kernel_substr, fname="pmc_per_dispatch.json", src_name="kde_kernels.hip"):
+    """The committed rocprofv3 PMC record of one kernel (profiles/r*/<fname>, newest round first) - but only if it was taken on THIS
+    revision of the kernel source: the file stores the git blob hash of pybnesian_amd/csrc/<src_name> it was collected on
+    (`_source_blob`), and a record whose hash differs from the working tree's is stale evidence -> (None, reason)."""
+    src = os.path.join(ROOT, "pybnesian_amd", "csrc", src_name)
     try:
         now = git_blob_sha1(src)
     except OSError as ex:
         return None, f"kernel source not readable: {ex}"
-    reason = "no profiles/r*/pmc_per_dispatch.json"
-    for rnd in ("r4", "r3", "r2", "r1"):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")
+    reason = f"no profiles/r*/{fname}"
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, fname)
         try:
             with open(path) as f:
                 d = json.load(f)
         except Exception:
             continue
-        blob = d.get("_source_blob", {}).get("kde_kernels.hip")
+        blob = d.get("_source_blob", {}).get(src_name)
         if blob != now:
-            reason = (f"stale: profiles/{rnd}/pmc_per_dispatch.json was collected on kde_kernels.hip blob {str(blob)[:12]}, the working tree "
-                      f"has {now[:12]} - re-run tools/profile_bench.sh")
+            reason = (f"stale: profiles/{rnd}/{fname} was collected on {src_name} blob {str(blob)[:12]}, the working tree "
+                      f"has {now[:12]} - re-run the profiling script (tools/profile_bench.sh / tools/gram_pmc.sh)")
             return None, reason
         try:
             k = next(v for name, v in d.items() if kernel_substr in name)
         except StopIteration:
-            return None, f"profiles/{rnd}/pmc_per_dispatch.json has no record of {kernel_substr}"
+            return None, f"profiles/{rnd}/{fname} has no record of {kernel_substr}"
         return dict(k, _round=rnd, _blob=now), None
     return None, reason
 
@@ -748,7 +787,7 @@ def rccl_world1():
         return {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
 
 
-def e2e_host(pbn, kde, names, test_np, repeats=3):
+def e2e_host(pbn, kde, names, test_np, repeats=3, train_np=None):
     """the same slogl with the test table in HOST Arrow memory - upload (PCIe), query pack, sweep, finish,
     scalar back - through the reference-shaped Python call `ProductKDE.slogl(record_batch)`.  Never the headline value."""
     import pyarrow as pa
@@ -761,9 +800,24 @@ def e2e_host(pbn, kde, names, test_np, repeats=3):
         val = kde.slogl(rb)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {"value": rb.num_rows / best / 1e6, "unit": "M-samples/s", "ms": best * 1e3, "slogl": val,
-            "what": f"{kde.__class__.__name__}.slogl(pyarrow.RecordBatch in host memory, {rb.num_rows} rows): H2D of the test "
-                    f"columns + query pack + sweep + finish + D2H of the scalar, best of {repeats}"}
+    out = {"value": rb.num_rows / best / 1e6, "unit": "M-samples/s", "ms": best * 1e3, "slogl": val,
+           "what": f"{kde.__class__.__name__}.slogl(pyarrow.RecordBatch in host memory, {rb.num_rows} rows): H2D of the test "
+                   f"columns + query pack + sweep + finish + D2H of the scalar, best of {repeats}"}
+    if train_np is not None:
+        # the fit a reference user pays before the first slogl (KDE::fit: upload, covariance, bandwidth, whitening + packing of the training rows)
+        trb = pa.RecordBatch.from_arrays([pa.array(np.ascontiguousarray(train_np[:, i])) for i in range(train_np.shape[1])], names=names)
+        fit_best = None
+        for _ in range(2):
+            k2 = kde.__class__(names)
+            t0 = time.perf_counter()
+            k2.fit(trb)
+            pbn.default_context().sync() if hasattr(pbn, "default_context") else None
+            dt = time.perf_counter() - t0
+            fit_best = dt if fit_best is None else min(fit_best, dt)
+        out["fit_ms"] = fit_best * 1e3
+        out["fit_what"] = (f"{kde.__class__.__name__}.fit(pyarrow.RecordBatch in host memory, {trb.num_rows} rows x {trb.num_columns}): H2D of the "
+                           f"training columns + covariance (device Gram) + bandwidth + whitening / packing, best of 2")
+    return out
 
 
 def dp_issue_util():
@@ -1077,7 +1131,7 @@ def main():
             out["config"]["backend"] = "nccl (RCCL), one rank: tools/rccl_world1.py"
         if world == 1 and not args.no_e2e:
             try:
-                out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy())
+                out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy(), train_np=train_t.T.cpu().numpy())
             except Exception as ex:
                 out["e2e_host"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -102,7 +102,8 @@ int pbn_ctx_set_profiling(pbn_ctx* ctx, int on) {
         if (!ctx) throw invalid_error("pbn_ctx_set_profiling: null context");
         HIP_CHECK(hipSetDevice(ctx->device));
         drain_timers(ctx);
-        ctx->profiling = on != 0;
+        ctx->profiling = on == 1;   // 1: events + the score engine on ONE stream (per-kernel attribution under a profiler)
+        ctx->timing = on == 2;      // 2: events only - issue lanes, batching and every other behaviour unchanged
         for (int i = 0; i < PBN_NUM_KERNEL_CLASSES; ++i) { ctx->kernel_ms[i] = 0; ctx->kernel_launches[i] = 0; }
     });
 }

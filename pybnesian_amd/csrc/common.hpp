@@ -198,6 +198,7 @@ struct pbn_ctx {
     }
     // optional per-kernel timing (pbn_ctx_set_profiling): HIP events recorded on `stream` around launches
     bool profiling = false;
+    bool timing = false;   // events recorded (KernelTimer), behaviour unchanged: pbn_ctx_set_profiling(ctx, 2)
     struct Timed { hipEvent_t e0, e1; int which; };
     std::vector<Timed> pending;
     double kernel_ms[PBN_NUM_KERNEL_CLASSES] = {0};
@@ -273,7 +274,7 @@ struct LaneSwitch {
 struct KernelTimer {
     pbn_ctx* ctx; int which; hipEvent_t e0 = nullptr;
     KernelTimer(pbn_ctx* c, int w) : ctx(c), which(w) {
-        if (ctx->profiling) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
+        if (ctx->profiling || ctx->timing) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
     }
     ~KernelTimer() {
         if (e0) {

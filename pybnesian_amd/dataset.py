@@ -111,7 +111,8 @@ class Context:
         return _lib.load().pbn_ctx_stream(self.handle)
 
     def set_profiling(self, on=True):
-        _lib.check(_lib.load().pbn_ctx_set_profiling(self.handle, int(bool(on))))
+        """True / 1: per-class kernel timing with the score engine on one stream; 2: timing only, behaviour unchanged; False: off."""
+        _lib.check(_lib.load().pbn_ctx_set_profiling(self.handle, int(on)))
 
     def kernel_time(self, kernel_class):
         """(total_ms, launches) of a kernel class (0 pack, 1 sweep, 2 finish, 3 gram) since profiling was enabled."""

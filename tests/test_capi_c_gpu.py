@@ -47,13 +47,14 @@ def test_c_program_matches_the_oracle(tmp_path):
     u = _xorshift_stream(6 * (n + m))
     train, test = _table(u[: 6 * n], n), _table(u[6 * n:], m)
     tr, te = train.to_numpy(), test.to_numpy()
-    # the reference's arithmetic on the same rows (north star: slogl within 1e-6 relative in fp64; held to 1e-9 here)
-    H = oracle.bandwidth(0, 0, oracle.cov(tr), n)          # NormalReferenceRule, full matrix (NormalReferenceRule.hpp:72-134)
+    # the reference's arithmetic on the same rows (north star: slogl within 1e-6 relative in fp64; held to 1e-8 here - slogl takes the
+    # sum-only sweep, 2^f on the fp32 transcendental unit: measured 1.2e-9 on this table)
+    H = oracle.bandwidth(0, 0, oracle.cov(tr)[0], n)          # NormalReferenceRule, full matrix (NormalReferenceRule.hpp:72-134)
     want_kde = oracle.kde_logl(tr, H, te).sum()
     want_ckde = oracle.ckde_logl(tr, H, te).sum()          # column 0 given columns 1, 2 (CKDE.hpp:256-287)
     want_bic = oracle.bic_lg(tr[:, [2, 0, 1]])             # c | a, b (bic.cpp:29-64)
-    assert abs(float(vals["kde_slogl"]) - want_kde) <= 1e-9 * abs(want_kde)
-    assert abs(float(vals["ckde_slogl"]) - want_ckde) <= 1e-9 * abs(want_ckde)
+    assert abs(float(vals["kde_slogl"]) - want_kde) <= 1e-8 * abs(want_kde)
+    assert abs(float(vals["ckde_slogl"]) - want_ckde) <= 1e-8 * abs(want_ckde)
     assert abs(float(vals["bic_c_ab"]) - want_bic) <= 1e-9 * abs(want_bic)
     assert int(vals["bad_rc"]) == 1  # PBN_ERR_INVALID
     # and the Python mirror gives what the C caller got

@@ -1,0 +1,166 @@
+"""GPU tier, fp64: adversarial inputs for the error budget of the SUM-ONLY sweeps (slogl, the score engine's terms).  Those sweeps take
+2^f of a term's fractional exponent on the fp32 transcendental unit (<= 1.4e-7 relative per term), prune at the margin whose dropped-mass
+bound is 1.1e-7 of a sum and send far tiles through fp32 (<= 8e-8 of a sum): bounds that ordinary data stays orders of magnitude inside
+because the per-term errors average.  Here they are made NOT to average (kde/opencl_kernels/KDE.cl.src:115-121,227-233 is what the numbers
+are held against, through oracle/pbn_oracle.cpp):
+  (i)   N_train in {2, 17, 64} with one or two terms carrying every query's sum and ALL fractional exponents of the table at one value
+        (the rounding of v_exp_f32 at one argument is one-sided) - swept over 96 values of the fraction;
+  (ii)  the same with the bandwidth chosen so that every logl lies within +-0.05 of 0: the absolute error of a logl is then as large
+        as it gets relative to the slogl;
+  (iii) a pruned sweep (>= 32 768 training rows) whose far mass sits exactly at the pruning margin - just outside (dropped) and just
+        inside (far-tile path) - beside ONE near row per query, so that the dropped-mass bound is met as closely as the geometry allows;
+  (iv)  CV-likelihood CKDE scores of a table scaled so that the scores are near 0.
+Every case: |slogl - oracle| <= 1e-6 |slogl| (the north star's bar), and the worst ratio to the stated bounds is printed."""
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOG2E = 1.4426950408889634
+BOUND_EXP, BOUND_DROP, BOUND_FAR = 1.4e-7, 1.1e-7, 8e-8
+
+
+def _oracle():
+    from oracle import oracle
+
+    return oracle
+
+
+def _kde(train, h2):
+    import pybnesian_amd as pbn
+
+    d = train.shape[1]
+    names = [f"v{i}" for i in range(d)]
+    k = pbn.KDE(names)
+    k.fit(pd.DataFrame(train, columns=names))
+    k.bandwidth = np.eye(d) * h2          # H = h^2 I: the whitened distance is |x - y| / h
+    return k, names
+
+
+def _clustered_case(n_train, frac, h, two_terms, d=1, n_q=2048, fixed_j=None):
+    """All training rows within 1e-7 h of the origin (non-singular covariance for fit(); the explicit bandwidth replaces the rule's);
+    queries at distances r with -r^2 / (2 h^2) log2(e) = -(j + frac), j = 0 .. 5 (or fixed_j): every term of every query has the
+    fractional exponent 1 - frac (or 0).  two_terms: a second training cluster at a distance that puts ITS terms at the same fraction."""
+    rng = np.random.default_rng(n_train + int(frac * 1000))
+    train = rng.normal(scale=1e-7 * h, size=(n_train, d))
+    js = rng.integers(0, 6, size=n_q) if fixed_j is None else np.full(n_q, fixed_j)
+    r = h * np.sqrt(2.0 * (js + frac) / LOG2E)
+    test = np.zeros((n_q, d))
+    test[:, 0] = r * np.where(rng.random(n_q) < 0.5, 1.0, -1.0)
+    if two_terms:
+        # second cluster on the axis orthogonal to the queries (d = 2): its distance^2 to a query is r^2 + s^2; s^2 / (2 h^2) log2(e) = 3
+        assert d == 2
+        s = h * np.sqrt(2.0 * 3.0 / LOG2E)
+        train[n_train // 2:, 1] += s
+    return train, test
+
+
+@pytest.mark.parametrize("n_train", [2, 17, 64])
+@pytest.mark.parametrize("near_zero", [False, True])
+def test_few_dominant_terms_with_clustered_fractions(n_train, near_zero, capsys):
+    oracle = _oracle()
+    worst, worst_abs, worst_at = 0.0, 0.0, None
+    for two in (False, True):
+        d = 2 if two else 1
+        for frac in np.linspace(0.0, 0.99, 96):
+            h = 1.0
+            if near_zero:
+                # (ii) the geometry scales with h, so logl(h) = logl(1) - d log h: the h that puts every logl at ~0 (all queries at one
+                # distance: fixed_j), then every logl lies within the placement's rounding of 0
+                tr1, te1 = _clustered_case(n_train, frac, 1.0, two, d, fixed_j=2)
+                h = float(np.exp(oracle.kde_logl(tr1, np.eye(d), te1).mean() / d))
+            train, test = _clustered_case(n_train, frac, h, two, d, fixed_j=2 if near_zero else None)
+            kde, names = _kde(train, h * h)
+            tdf = pd.DataFrame(test, columns=names)
+            got = kde.slogl(tdf)                      # the sum-only sweep
+            want_rows = oracle.kde_logl(train, np.eye(d) * h * h, test)
+            want = want_rows.sum()
+            if near_zero:
+                assert np.abs(want_rows).max() < 0.05
+            # the north star's bar is relative to the slogl; where every logl is ~0 by construction the slogl is a cancellation and the
+            # scale of the quantity is the 0.05 per row it was confined to
+            scale = max(abs(want), 0.05 * len(test)) if near_zero else abs(want)
+            rel = abs(got - want) / scale
+            per_logl = abs(got - want) / len(test)    # mean absolute error per logl, against the per-term bound
+            if rel > worst:
+                worst, worst_at = rel, (two, float(frac), float(np.abs(want_rows).mean()))
+            worst_abs = max(worst_abs, per_logl)
+            assert rel <= 1e-6, (n_train, near_zero, two, frac, got, want)
+    with capsys.disabled():
+        print(f"\n[error budget] N_train={n_train} near_zero={near_zero}: worst rel slogl {worst:.2e} at (two_terms, frac, mean|logl|)={worst_at}; "
+              f"worst mean |d logl| {worst_abs:.2e} = {worst_abs / BOUND_EXP:.3f} of the 2^f bound {BOUND_EXP:.1e}")
+    assert worst_abs <= BOUND_EXP
+
+
+@pytest.mark.parametrize("side", ["outside", "inside"])
+def test_mass_at_the_pruning_margin(side, capsys):
+    """(iii) d = 2, bandwidth I: 1 024 queries on top of ONE training row (a query's sum bound is that one term); 400 000 more training
+    rows on a circle around them at the radius where a term is 2^-(margin -+ 0.75) of the bound: outside, everything is dropped (at most
+    N 2^-margin of a sum); inside, everything goes through the far-tile path."""
+    oracle = _oracle()
+    rng = np.random.default_rng(5)
+    n_ring, n_near = 400_000, 1
+    n = n_ring + n_near
+    margin = 43.0 + np.log2(n / 1e6)                      # prune_margin(fp64, N, sum-only)
+    e = margin + (0.75 if side == "outside" else -0.75)
+    r = np.sqrt(2.0 * e / LOG2E)
+    near = np.zeros((n_near, 2))                          # the queries' own row: every query's sum is this one term (~1) + the ring
+    ang = rng.uniform(0, 2 * np.pi, size=n_ring)
+    ring = np.column_stack([r * np.cos(ang), r * np.sin(ang)]) * (1.0 + rng.normal(scale=1e-4, size=(n_ring, 1)))
+    train = np.vstack([near, ring])
+    test = rng.normal(scale=0.002, size=(1024, 2))        # (a query box 0.01 wide moves the box distance by 0.1 exponent units)
+    kde, names = _kde(train, 1.0)
+    got = kde.slogl(pd.DataFrame(test, columns=names))
+    want_rows = oracle.kde_logl(train, np.eye(2), test)
+    want = want_rows.sum()
+    # what the ring contributes to a sum, relative to it: n_ring 2^-e / (n_near terms of ~1)
+    share = n_ring * 2.0 ** (-e) / n_near
+    per_logl = abs(got - want) / len(test)
+    with capsys.disabled():
+        print(f"\n[error budget] mass {side} the margin ({margin:.2f}): ring share of a sum {share:.2e}; mean |d logl| {per_logl:.2e} "
+              f"= {per_logl / (BOUND_DROP if side == 'outside' else BOUND_FAR):.3f} of the {'dropped-mass' if side == 'outside' else 'far-tile'} bound; "
+              f"rel slogl {abs(got - want) / abs(want):.2e}")
+    assert abs(got - want) <= 1e-6 * abs(want)
+    assert per_logl <= (BOUND_DROP if side == "outside" else BOUND_FAR) + BOUND_EXP
+
+
+def test_cv_scores_near_zero(capsys):
+    """(iv) CV-likelihood CKDE local scores of a table scaled so that the mean log-density is ~0 (|score| / rows < 0.05): score engine
+    (grouped evaluation when the folds are large enough, per-fold otherwise) against the oracle at 1e-6 of the SCORE."""
+    import pybnesian_amd as pbn
+
+    oracle = _oracle()
+    rng = np.random.default_rng(11)
+    n = 6000
+    a = rng.normal(size=n)
+    b = 0.7 * a + rng.normal(scale=0.6, size=n)
+    base = np.column_stack([a, b])
+    worst = 0.0
+    for cols, name in (([0], "a"), ([1, 0], "b|a")):
+        d = len(cols)
+        # scale both columns by s: the CKDE log-density of the child shifts by -log s per row -> bisect s for a mean of ~0
+        x = base[:, cols]
+        s_lo, s_hi = 0.05, 5.0
+        for _ in range(40):
+            s = np.sqrt(s_lo * s_hi)
+            val = oracle.cv_likelihood(x * s, "ckde", 5, 3)
+            if val > 0:
+                s_lo = s
+            else:
+                s_hi = s
+        xs = x * s
+        want = oracle.cv_likelihood(xs, "ckde", 5, 3)
+        assert abs(want) / n < 0.05
+        names = ["c", "p"][:d]
+        df = pd.DataFrame(xs, columns=names)
+        score = pbn.CVLikelihood(df, 5, 3)
+        got = score.local_score_node_type(pbn.SemiparametricBN(names), pbn.CKDEType(), "c", names[1:])
+        # the score's own scale: the sum of |log-density| of its rows (the value itself is a cancellation to ~0 by construction)
+        scale = n * 0.05
+        worst = max(worst, abs(got - want) / scale)
+        with capsys.disabled():
+            print(f"\n[error budget] CV score {name} scaled to ~0: oracle {want:.6f}, device {got:.6f}, |diff| {abs(got - want):.2e} "
+                  f"= {abs(got - want) / n:.2e} per row ({abs(got - want) / n / BOUND_EXP:.3f} of the 2^f bound)")
+        assert abs(got - want) / n <= BOUND_EXP + BOUND_DROP
+        assert abs(got - want) <= 1e-6 * scale

@@ -34,4 +34,6 @@ if "GRBM_GUI_ACTIVE" in vals and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
 if "FETCH_SIZE" in vals:   # KB
     print(f"derived: FETCH_SIZE {vals['FETCH_SIZE'] / 1e6:.4f} GB raw, x2 = {2 * vals['FETCH_SIZE'] / 1e6:.4f} GB (algorithmic 1.024 GB)")
 PY
+# per-kernel per-dispatch averages + the blob hash of stats_kernels.hip they were taken on: copy to profiles/rN/gram_pmc.json (bench.py: secondary.roofline.mfma_busy)
+python3 tools/pmc_aggregate.py $OUT/gram_pmc.json $OUT/sq $OUT/lds $OUT/fetch
 find $OUT -name "*counter_collection.csv" -size +2M -delete
