@@ -60,8 +60,8 @@ void* pbn_ctx_stream(pbn_ctx* ctx); /* hipStream_t the kernels are launched on (
  * queue, opencl_config.cpp:175).  Classes: 0 pack, 1 KDE sweep, 2 finish/reduce, 3 Gram/SSE.
  * pbn_ctx_kernel_time synchronises the stream and returns the accumulated ms and launch count.
  * on = 1: events, and the score engine issues everything on the context's one stream (attribution under a profiler);
- * on = 2: events only, nothing else changes (launches on the engine's issue lanes are timed on their lane - the classes' totals are
- * device time and may overlap); 0: off.  Switching resets the totals. */
+ * on = 2: events around the sweep and Gram classes only, nothing else changes (launches on the engine's issue lanes are timed on their
+ * lane - the classes' totals are device time and may overlap); 0: off.  Switching resets the totals. */
 #define PBN_NUM_KERNEL_CLASSES 8
 typedef enum { PBN_K_PACK = 0, PBN_K_SWEEP = 1, PBN_K_FINISH = 2, PBN_K_GRAM = 3 } pbn_kernel_class;
 int pbn_ctx_set_profiling(pbn_ctx* ctx, int on);

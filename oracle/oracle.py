@@ -422,9 +422,16 @@ def discrete_fit_slogl(vcodes, card0, pcodes, pcards, train, test):
     return float(res)
 
 
-def adaptator_fit_slogl(cont, dcodes, dcards, train, test, node_type):
-    """DiscreteAdaptator<LinearGaussianCPD | CKDE>::fit on train rows + slogl on test rows."""
+def adaptator_fit_slogl(cont, dcodes, dcards, train, test, node_type, arithmetic=None):
+    """DiscreteAdaptator<LinearGaussianCPD | CKDE>::fit on train rows + slogl on test rows.
+    The arithmetic follows the dtype of `cont`, as the reference's does the Arrow type of the columns: float32 data -> covariance in
+    float (dataset.hpp:429-481 through NormalReferenceRule.hpp:124-133: `df.cov<ArrowType>`, then `k * cov.cast<double>()`), distances,
+    exponentials, sums and logl in float (KDE.hpp:466-470, KDE.cl.src with @dt@ = float; pbn_oracle.cpp kde_full<float>, cov_T<float>).
+    arithmetic = "float32" / "float64" casts `cont` first - "float64" on float data is the TRUTH for those values, "float32" what the
+    reference computes."""
     cont = np.asarray(cont)
+    if arithmetic is not None:
+        cont = cont.astype({"float32": np.float32, "float64": np.float64}[arithmetic])
     cfg, ncfg = config_index(dcodes, dcards, cont.shape[0])
     total = 0.0
     for c in range(ncfg):

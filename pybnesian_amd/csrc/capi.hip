@@ -351,7 +351,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     // the evidence with H[1:, 1:] - CKDE.hpp:186-199) beat the fused sweep, whose pruning can only use the marginal box
     // (tools/prune_handles_timing.py; fp64 up to 3 variables - 4 is a tie, 5 goes to the fused sweep -, fp32 up to 4).  PBN_CKDE_SPLIT=0 keeps the fused sweep, =1 splits
     // whenever the marginal qualifies for pruning.
-    static const int split_mode = [] { const char* e = getenv("PBN_CKDE_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
+    static const int split_mode = PBN_TUNE(CKDE_SPLIT, -1);
     const bool split = ckde && k->m.cond && ((split_mode != 0 && kde_prune_applies(fdt, d - 1, n) && (split_mode > 0 || d <= (fdt == PBN_F64 ? 3 : 4))) ||
                                              k->m.wide);   // more than 32 evidence variables: no fused form - joint minus marginal
     if (split) {
@@ -373,7 +373,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
         // low-dimensional, large models: rows packed in Morton order with per-tile boxes, so that logl / slogl skip the
         // tile pairs that cannot contribute (same rule as the score engine's sweeps)
         // (which dimensions: kde_prune_applies - up to 6 marginal dimensions; beyond, boxes over 4 of the dimensions prune too little)
-        static const int max_dm = [] { const char* e = getenv("PBN_HANDLE_PRUNE_DIMS"); return (e && *e) ? atoi(e) : 8; }();
+        static const int max_dm = PBN_TUNE(HANDLE_PRUNE_DIMS, 8);
         const bool prune = k->m.dm <= max_dm;
         kde_pack_train(ctx, k->m, train, cols, row0, n, 0, nullptr, prune);
         kde_prune_persist(ctx, k->m, k->prune_store);
@@ -446,7 +446,7 @@ int64_t pbn_kde_num_instances(const pbn_kde* k) { return k ? k->m.N : 0; }
 double pbn_kde_lognorm(const pbn_kde* k, int which) { return which ? k->m.lognorm_marg : k->m.lognorm; }
 
 static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                             double* dev_logl, double* dev_sum) {
+                             double* dev_logl, double* dev_sum, bool precise = false) {
     if (!k) throw invalid_error("KDE factor not fitted.");
     if (k->split_joint) {   // CKDE as joint - marginal from two plain (pruned) sweeps
         pbn_ctx* ctx = k->ctx;
@@ -461,17 +461,17 @@ static void kde_eval_enqueue(pbn_kde* k, const pbn_table* test, const int* cols,
         // last workgroups of a pruned sweep drain for 2-3 ms) runs under it; the difference waits for both on the device
         const bool lanes = pbn::score_lanes() > 1 && !ctx->profiling;
         if (lanes) { ctx->ensure_lanes(1); ctx->lanes_wait_for_stream(1); }
-        pbn::kde_eval_enqueue(ctx, k->split_joint->m, test, cols, row0, n, lj, sj);
+        pbn::kde_eval_enqueue(ctx, k->split_joint->m, test, cols, row0, n, lj, sj, nullptr, nullptr, precise);
         {
             pbn::LaneSwitch lane(ctx, lanes ? 1 : 0);
-            pbn::kde_eval_enqueue(ctx, k->split_marg->m, test, cols + 1, row0, n, lm, sm);
+            pbn::kde_eval_enqueue(ctx, k->split_marg->m, test, cols + 1, row0, n, lm, sm, nullptr, nullptr, precise);
         }
         if (lanes) ctx->stream_waits_for_lane(0);
         if (dev_logl) launch_diff(dev_logl, lj, lm, n, ctx->stream);
         if (dev_sum) launch_diff(dev_sum, sj, sm, 1, ctx->stream);
         return;
     }
-    pbn::kde_eval_enqueue(k->ctx, k->m, test, cols, row0, n, dev_logl, dev_sum);
+    pbn::kde_eval_enqueue(k->ctx, k->m, test, cols, row0, n, dev_logl, dev_sum, nullptr, nullptr, precise);
 }
 
 int pbn_kde_logl_dev(pbn_kde* k, const pbn_table* test, const int* cols, int64_t row0, int64_t n, double* dev_out) {
@@ -562,6 +562,13 @@ int pbn_kde_slogl(pbn_kde* k, const pbn_table* test, const int* cols, int64_t ro
         kde_eval_enqueue(k, test, cols, row0, n, nullptr, dsum);
         HIP_CHECK(hipMemcpyAsync(out, dsum, sizeof(double), hipMemcpyDeviceToHost, k->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
+        // a sum that is a cancellation to ~0: once more at the accuracy of the per-row path (kde_sum_needs_precision; fp64 fragments only -
+        // the fp32 sweeps have their own, wider tolerance)
+        if (k->m.fdtype() == PBN_F64 && kde_sum_needs_precision(*out, n)) {
+            kde_eval_enqueue(k, test, cols, row0, n, nullptr, dsum, /*precise=*/true);
+            HIP_CHECK(hipMemcpyAsync(out, dsum, sizeof(double), hipMemcpyDeviceToHost, k->ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
+        }
     });
 }
 

@@ -247,6 +247,23 @@ template <typename H>
 inline std::recursive_mutex& mu_of(const H* h) { return h ? mu_of(static_cast<const pbn_ctx*>(h->ctx)) : api_mutex(); }
 }  // namespace pbn
 
+// ---- run-time switches ---------------------------------------------------------------------------------------------------------------
+// knob_*(): the documented environment switches of the product (DESIGN.md 6b holds the one table of them).  PBN_TUNE(NAME, default):
+// tuning constants and alternative paths kept from past measurements - compiled to their defaults; only a library built with
+// -DPBN_EXPERIMENTS (the probe scripts under tools/: `make EXPERIMENTS=1`) reads PBN_<NAME> from the environment.
+namespace pbn {
+inline long long knob_ll(const char* name, long long dflt) { const char* e = std::getenv(name); return (e && *e) ? std::atoll(e) : dflt; }
+inline int knob_int(const char* name, int dflt) { return (int)knob_ll(name, dflt); }
+inline double knob_double(const char* name, double dflt) { const char* e = std::getenv(name); return (e && *e) ? std::atof(e) : dflt; }
+}  // namespace pbn
+#ifdef PBN_EXPERIMENTS
+#define PBN_TUNE(NAME, dflt) (::pbn::knob_int("PBN_" #NAME, (int)(dflt)))
+#define PBN_TUNE_D(NAME, dflt) (::pbn::knob_double("PBN_" #NAME, (double)(dflt)))
+#else
+#define PBN_TUNE(NAME, dflt) ((int)(dflt))
+#define PBN_TUNE_D(NAME, dflt) ((double)(dflt))
+#endif
+
 namespace pbn {
 // PBN_SCORE_LANES (at most 4): issue lanes of the score engine's independent evaluations; 1 keeps everything on the
 // context's own stream.  Default 2; 3 for tables of at most 250 000 rows, whose evaluations are chains of short launches
@@ -254,8 +271,7 @@ namespace pbn {
 // tables a third lane only takes CUs from the other two's sweeps (C5 +5 %).
 inline int score_lanes(int64_t table_rows = -1) {
     static const int v = [] {
-        const char* e = getenv("PBN_SCORE_LANES");
-        const int n = (e && *e) ? atoi(e) : 0;
+        const int n = knob_int("PBN_SCORE_LANES", 0);
         return n < 1 ? 0 : (n > 1 + pbn_ctx::MAX_PARKED ? 1 + pbn_ctx::MAX_PARKED : n);
     }();
     if (v) return v;
@@ -274,7 +290,9 @@ struct LaneSwitch {
 struct KernelTimer {
     pbn_ctx* ctx; int which; hipEvent_t e0 = nullptr;
     KernelTimer(pbn_ctx* c, int w) : ctx(c), which(w) {
-        if (ctx->profiling || ctx->timing) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
+        // timing-only mode brackets the dominant classes only (sweeps, Gram passes: long kernels) - events around the short pack / finish
+        // launches of a chain cost more than they measure (cv64's weak leg 0.61 -> 0.91 s with every launch bracketed)
+        if (ctx->profiling || (ctx->timing && (w == PBN_K_SWEEP || w == PBN_K_GRAM))) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
     }
     ~KernelTimer() {
         if (e0) {

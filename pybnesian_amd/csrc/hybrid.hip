@@ -143,7 +143,7 @@ std::shared_ptr<const HybridGrouping> grouping_for(pbn_scoredata* sd, int kind, 
     if (it != sd->groupings.end()) return it->second;
     // each grouping holds a 4 B / row device list: beyond 256 of them (a search over very many discrete parent sets) start over
     // (PBN_HYBRID_GROUPINGS: the cap, lowered by the test that crosses the reset inside one batch)
-    static const size_t cap = [] { const char* e = getenv("PBN_HYBRID_GROUPINGS"); const long long v = (e && *e) ? atoll(e) : 256; return (size_t)(v < 1 ? 1 : v); }();
+    static const size_t cap = (size_t)std::max(1ll, knob_ll("PBN_HYBRID_GROUPINGS", 256));
     if (sd->groupings.size() >= cap) {
         HIP_CHECK(hipStreamSynchronize(sd->ctx->stream));
         sd->groupings.clear();
@@ -341,7 +341,7 @@ static void cells_gram(pbn_scoredata* sd, const HybridGrouping& g, const int* co
 
 static bool ensure_full_moments(pbn_scoredata* sd, const HybridGrouping& g) {
     if (g.full_state != 0) return g.full_state > 0;
-    static const bool on = [] { const char* e = getenv("PBN_HYBRID_FULLMOMENTS"); return !(e && *e) || atoi(e) != 0; }();
+    static const bool on = PBN_TUNE(HYBRID_FULLMOMENTS, 1) != 0;
     const int n = sd->n;
     const size_t cells = (size_t)g.nc * g.nregions;
     // (not with validity masks: a row that is null in another column still counts for this candidate's own)
@@ -372,7 +372,7 @@ void group_moments(pbn_scoredata* sd, const HybridGrouping& g, const int* cols, 
     }
     pbn_ctx* ctx = sd->ctx;
     const pbn_table* t = sd->table();
-    static const bool batched = [] { const char* e = getenv("PBN_HYBRID_SEGMENTED"); return !(e && *e) || atoi(e) != 0; }();
+    static const bool batched = PBN_TUNE(HYBRID_SEGMENTED, 1) != 0;
     if (d <= 8 && batched && g.npieces > 0) {
         const int S = d + d * (d + 1) / 2;
         ctx->scratch_red.reserve((size_t)(g.npieces + cells) * S);
@@ -403,7 +403,7 @@ void group_moments(pbn_scoredata* sd, const HybridGrouping& g, const int* cols, 
     }
     // more than 8 columns (or the segmented register kernel switched off): the candidate's own columns through the segmented MFMA Gram - one
     // launch for all cells (round 3 took one Gram launch + one wait per cell here)
-    static const bool cellwise = [] { const char* e = getenv("PBN_HYBRID_CELLWISE_GRAM"); return e && *e && atoi(e) != 0; }();
+    static const bool cellwise = PBN_TUNE(HYBRID_CELLWISE_GRAM, 0) != 0;
     if (!cellwise && d <= 64) {
         cells_gram(sd, g, cols, d, M);
         return;
@@ -482,7 +482,7 @@ struct HybridBatch {
         if (active && slot_key.size() + max_slots > capacity) flush();
         const bool fresh = !active;
         if (!active) {
-            static const size_t min_slots = [] { const char* e = getenv("PBN_HYBRID_BATCH_SLOTS"); const long long v = (e && *e) ? atoll(e) : (1ll << 15); return (size_t)(v < 1 ? 1 : v); }();
+            static const size_t min_slots = (size_t)std::max(1ll, knob_ll("PBN_HYBRID_BATCH_SLOTS", 1ll << 15));
             capacity = std::max(std::max(capacity, max_slots), min_slots);
             ctx->scratch_sums.reserve(2 * capacity);   // (grow-only; nothing of this batch is in flight here)
             dsums = ctx->scratch_sums.p;
@@ -515,14 +515,19 @@ void HybridBatch::flush() {
     if (ns) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (f32 && ns) HIP_CHECK(hipMemcpyAsync(hmax.data(), dmax, ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (f32) {   // check-after (score_hybrid): flagged evaluations once more, on fp64 fragments, through the per-slice chain
+    const bool f64 = sd->dtype == PBN_F64;
+    if (f32 || f64) {
+        // check-after (score_hybrid), through the per-slice chain.  fp32 tables: evaluations whose training rows reach beyond what fp32
+        // fragments hold, once more on fp64 fragments; fp64 tables: sums that are a cancellation to ~0 (kde_sum_needs_precision), once more
+        // at the accuracy of the per-row path
         bool any = false;
         for (const Redo& r : redo_info) {
-            if (!kde_wants_widening(hmax[(size_t)r.slot])) continue;
+            if (f32 ? !kde_wants_widening(hmax[(size_t)r.slot]) : !kde_sum_needs_precision(hs[(size_t)r.slot], r.nte)) continue;
             const int* v = rcols.data() + r.coff;
             KdeModel m;
             kde_prepare(m, sd->dtype, r.nv, r.N, rstore.data() + r.off, PBN_BW_FULL, false, rstore.data() + r.off + (size_t)r.nv * r.nv);
-            kde_widen(m);
+            if (f32) kde_widen(m);
+            else ++sd->precise_redos;
             const KdePackBytes pb = kde_pack_bytes(m.fdtype(), m.dm, false, m.N);
             ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + 256);
             m.Apack = ctx->scratch_train.p;
@@ -530,7 +535,7 @@ void HybridBatch::flush() {
             m.Axpack = nullptr;
             HIP_CHECK(hipMemsetAsync(dsums + r.slot, 0, sizeof(double), ctx->stream));
             kde_pack_train(ctx, m, t, v, r.r0, r.n0, r.r1, r.rows, /*prune=*/true);
-            kde_eval_enqueue(ctx, m, t, v, r.te0, r.nte, nullptr, dsums + r.slot, r.rows);
+            kde_eval_enqueue(ctx, m, t, v, r.te0, r.nte, nullptr, dsums + r.slot, r.rows, nullptr, /*precise=*/f64);
             ++sd->kde_sweeps;
             any = true;
         }
@@ -571,7 +576,7 @@ void HybridBatch::flush() {
 }
 
 HybridBatch* hybrid_batch_begin(pbn_scoredata* sd) {
-    static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
+    static const bool check_after = PBN_TUNE(F32_CHECK, 1) != 0;   // 0: measurement only
     return new HybridBatch(sd, sd->dtype == PBN_F32 && check_after);
 }
 void hybrid_batch_flush(HybridBatch* hb) { if (hb) hb->flush(); }
@@ -859,42 +864,6 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
             int64_t tr_row0 = base, tr_n0 = tr->N, tr_row1 = 0, te0 = g.off[cell(c, 1)];
             if (cv) { tr_n0 = g.off[cell(c, u)] - base; tr_row1 = g.off[cell(c, u) + 1]; te0 = g.off[cell(c, u)]; }
             Slice sl{{}, {}, pc > 0, part};
-            // fp32 (bf16x3) slices with neither term known: the fused joint + marginal sweep - there the extra MFMA step hides
-            // under the exponentials and one pack / one launch serves both terms (C5: 22.3 s of sweeps fused against 24.2 s as
-            // two plain ones); fp64 slices and slices with one term cached take the plain sweeps
-            static const int fused_mode = [] { const char* e = getenv("PBN_HYBRID_FUSED"); return (e && *e) ? atoi(e) : -1; }();
-            // (default off since the terms are canonical: the fused sweep evaluates the joint with the variable first - another
-            //  rounding of the shared joint term than the plain sweep's, chosen by what happened to be cached; it only ever applied to
-            //  slices too small for the grouped path, a sliver of C5's time)
-            const bool want_fused = fused_mode < 0 ? false : fused_mode != 0;
-            const bool grouped_both = elig[(size_t)c * 2] && (pc == 0 || elig[(size_t)c * 2 + 1]);
-            auto unknown = [&](const std::vector<int>& k) { return sd->kde_cache.find(k) == sd->kde_cache.end() && hb->scheduled.find(k) == hb->scheduled.end(); };
-            if (pc > 0 && want_fused && !grouped_both && unknown(key_of(u, c, cols.data(), d)) && unknown(key_of(u, c, cols.data() + 1, pc))) {
-                KdeModel m;
-                try {
-                    kde_prepare(m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, true, mu.data());
-                } catch (const singular_error&) {
-                    continue;
-                }
-                sl.joint.slot = (int)hb->slot_key.size();
-                hb->slot_key.push_back(key_of(u, c, cols.data(), d));
-                hb->scheduled.emplace(hb->slot_key.back(), sl.joint.slot);
-                sl.marg.slot = (int)hb->slot_key.size();
-                hb->slot_key.push_back(key_of(u, c, cols.data() + 1, pc));
-                hb->scheduled.emplace(hb->slot_key.back(), sl.marg.slot);
-                const KdePackBytes pb = kde_pack_bytes(sd->dtype, m.dm, m.cond, tr->N);
-                LaneSwitch lane(ctx, (int)(issued++ % (size_t)lanes));   // before the lane's scratch is touched
-                ctx->scratch_train.reserve(align(pb.apack) + align(pb.nxpack) + align(pb.axpack) + 256);
-                char* arena = ctx->scratch_train.p;
-                m.Apack = arena;
-                m.nxpack = arena + align(pb.apack);
-                m.Axpack = arena + align(pb.apack) + align(pb.nxpack);
-                kde_pack_train(ctx, m, t, cols.data(), tr_row0, tr_n0, tr_row1, g.rows.p, /*prune=*/true);
-                kde_eval_enqueue(ctx, m, t, cols.data(), te0, te->N, nullptr, dsums.p + sl.joint.slot, g.rows.p, dsums.p + sl.marg.slot);
-                ++sd->kde_sweeps;
-                slices.push_back(sl);
-                continue;
-            }
             std::vector<int> midx(std::max(pc, 1));
             for (int i = 0; i < pc; ++i) midx[i] = i + 1;
             std::vector<double>& Ht = Hterm;
@@ -931,7 +900,7 @@ double score_hybrid(pbn_scoredata* sd, int kind, int var, int node_type, const i
                 term.slot = (int)hb->slot_key.size();
                 hb->slot_key.push_back(key);
                 hb->scheduled.emplace(key, term.slot);
-                if (f32) {
+                if (f32 || sd->dtype == PBN_F64) {
                     hb->redo_info.push_back(Redo{term.slot, nv, hb->rstore.size(), hb->rcols.size(), tr->N, tr_row0, tr_n0, tr_row1, te0, te->N, g.rows.p});
                     hb->rstore.insert(hb->rstore.end(), Ht.begin(), Ht.end());
                     hb->rstore.insert(hb->rstore.end(), mut.begin(), mut.end());

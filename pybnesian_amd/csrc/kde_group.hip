@@ -50,7 +50,6 @@ struct GDev {   // argument block of the block-wise kernels
     int bf16;                 // fp32 table: bf16x3 fragments (kde_kernels.hip pack_rows_bf16_kernel), KS = number of bf16 MFMAs
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
-    int ring_nb;              // > 0: fp64 table with a RING pass - also write bf16x3 fragments (ring_nb MFMAs) of every row
     unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
     int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
 };
@@ -75,7 +74,11 @@ __global__ __launch_bounds__(GB) void group_keys_kernel(GDev g) {
     for (int j = 0; j < kd; ++j) xc[j] = (double)((const T*)g.base + (int64_t)P.cols[j] * g.ld)[row] - P.mug[j];
     const int bits = group_key_bits(kd);
     const double half = (double)(1 << (bits - 1)), top = (double)((1 << bits) - 1);
-    const double scale = bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0);   // cells of sigma / 16 (8, 4): the key range covers +-8 (4) sigma at 8 (6) bits
+    // cells of sigma / 16 (8, 4) at 8 (6, fewer) bits per axis: the key range covers +-8 (4) sigma.  One or two key dimensions have 16 / 12
+    // bits per axis: the same +-8 sigma in cells of sigma / 4096 (sigma / 256) - round 5: with sigma / 16 cells a cell of a 450 000-row fold held
+    // ~280 rows (d = 2; ~11 000 at d = 1) in arbitrary order, i.e. a 16-row tile was 16 random rows of a box half a bandwidth wide
+    // (tools/farfield_feasibility.py: median tile radius 0.34 bandwidths against 0.15 with fine cells)
+    const double scale = bits >= 12 ? (double)(1 << (bits - 4)) : (bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0));
     uint32_t key = 0;
     for (int i = 0; i < kd; ++i) {
         double u = 0.0;
@@ -199,26 +202,14 @@ __device__ __forceinline__ double pack_store(const GDev& g, const GUnit& U, cons
     }
     double* pack = (double*)(arena + (query ? U.bpack : U.apack));
     double nrm = 0.0;
-    __bf16 p1[PBN_GROUP_MAX_D], p2[PBN_GROUP_MAX_D], p3[PBN_GROUP_MAX_D];
-    double nrm16 = 0.0;
     for (int c = 0; c < KS * 4; ++c) {
         double z = 0.0;
         if (c < d) {
             for (int j = 0; j <= c; ++j) z = __builtin_fma(U.W[c * d + j], xc[j], z);
             zrow[c] = z;
-            if (g.ring_nb) {   // the same coordinate for the far-field pass: rounded to float, three bf16 pieces
-                const float zf = (float)z;
-                nrm16 = __builtin_fma((double)zf, (double)zf, nrm16);
-                gsplit3(zf, p1[c], p2[c], p3[c]);
-            }
         }
         nrm = __builtin_fma(z, z, nrm);
         pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = z;
-    }
-    if (g.ring_nb) {
-        const float nv16 = (float)(-0.5 * nrm16);
-        store_bf16_row((gbf8*)(arena + (query ? U.bpack16 : U.apack16)), g.ring_nb, tile, idx, d, p1, p2, p3, nv16, query);
-        if (query) ((float*)(arena + U.ny16))[(int64_t)tile * 16 + idx] = nv16;
     }
     const double nv = -0.5 * nrm;
     if (d < KS * 4) pack[((int64_t)tile * KS + (d >> 2)) * 64 + (d & 3) * 16 + idx] = query ? 1.0 : nv;   // norm in the free K slot (FOLD)
@@ -301,12 +292,6 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
                 store_bf16_row((gbf8*)(g.arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, z1, z2, z3, nv, query);
                 if (query) ((float*)(g.arena + U.ny))[(int64_t)tile * 16 + idx] = 0.0f;
                 continue;
-            }
-            if (g.ring_nb) {
-                __bf16 z1[PBN_GROUP_MAX_D], z2[PBN_GROUP_MAX_D], z3[PBN_GROUP_MAX_D];
-                for (int c = 0; c < d; ++c) z1[c] = z2[c] = z3[c] = (__bf16)0.0f;
-                store_bf16_row((gbf8*)(g.arena + (query ? U.bpack16 : U.apack16)), g.ring_nb, tile, idx, d, z1, z2, z3, query ? 0.0f : -1e30f, query);
-                if (query) ((float*)(g.arena + U.ny16))[(int64_t)tile * 16 + idx] = 0.0f;
             }
             double* pack = (double*)(g.arena + (query ? U.bpack : U.apack));
             for (int c = 0; c < KS * 4; ++c) pack[((int64_t)tile * KS + (c >> 2)) * 64 + (c & 3) * 16 + idx] = 0.0;
@@ -482,10 +467,10 @@ __global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
         const double* p = (const double*)(g.arena + U.part) + (int64_t)q * 2;
         const int64_t stride = (int64_t)U.nqtiles * 16 * 2;
         double m = p[0];
-        for (int sp = 1; sp < U.nsplit_fin; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
+        for (int sp = 1; sp < U.nsplit; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
         double s = 0.0;
 #pragma unroll 4
-        for (int sp = 0; sp < U.nsplit_fin; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
+        for (int sp = 0; sp < U.nsplit; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
         val = U.lognorm + LN2 * (m + log2(s));
     }
     __shared__ double red[256];
@@ -516,11 +501,6 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(GDev g, double* out) 
     if (threadIdx.x == 0) out[U.sum_slot] = red[0];
 }
 
-int env_int(const char* name, int dflt) {
-    const char* s = std::getenv(name);
-    return s && *s ? std::atoi(s) : dflt;
-}
-
 size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 // Training tiles per split of a unit's sweep.  PBN_GROUP_SPLIT_TILES pins it; otherwise 512 up to 16 384 tiles (cv64's 90 000-row folds:
@@ -528,7 +508,7 @@ size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 // slices: within noise of 512 in time, `profiles/r4/split_tiles_probe.txt` - but every query keeps a partial per split, 60 % of a
 // candidate's arena at 512, so the coarser split lets an arena-full hold twice the candidates).
 int split_tiles_for(int ntiles) {
-    const int pinned = env_int("PBN_GROUP_SPLIT_TILES", 0);   // read per call: the tests switch it
+    const int pinned = knob_int("PBN_GROUP_SPLIT_TILES", 0);   // read per call: the tests switch it
     if (pinned > 0) return std::max(16, pinned);
     return ntiles <= 16384 ? 512 : (ntiles <= 32768 ? 1024 : 2048);
 }
@@ -568,22 +548,13 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     const int d0 = pools[0].d, KS = bf16 ? bf16x3_mfmas(d0) : (d0 + 3) / 4;
     const bool fold = d0 % 4 != 0;
     const size_t frag_b = bf16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
-    // RING pass (fp64 tables, opt-in: PBN_RING_NEAR=<exponent distance>, default 0 = off): pairs whose bound lies below 2^-ring_near of
-    // the sum go through the bf16 kernel instead of the fp64 one.  Measured (tools/ring_probe.sh, profiles/r3/ring_probe.txt): results
-    // agree with the one-pass evaluation to 1.5e-13, but the gain is small - the far field is a thin shell of (tile, group) pairs
-    // spread over as many workgroups as the main pass, each paying its prologue for a few tiles: hand-over at 2^-32 cv64 3.56 -> 3.68 s
-    // (slower), at 2^-24 3.56 -> 3.33 s and C3's first iteration 16.05 -> 15.58 s.  Kept as a switch, not as the default.
-    static const double ring_near_env = [] { const char* e = std::getenv("PBN_RING_NEAR"); return (e && *e) ? std::atof(e) : 0.0; }();
-    const bool ring = !bf16 && ring_near_env > 0.0 && ring_near_env < prune_margin(fdt, 0, true) - 8.0;
-    const int NB16 = ring ? bf16x3_mfmas(d0) : 0;
-    const size_t frag16_b = (size_t)NB16 * 64 * 16;
     int64_t total_wg = 0;
     int max_ntiles = 0, max_nqtiles = 0, max_nq = 0;
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return (int64_t)o; };
     // tables first
     const int64_t o_pools = carve((size_t)np * sizeof(GPool)), o_units = carve((size_t)nu * sizeof(GUnit)),
-                  o_sweep = carve((size_t)nu * sizeof(GSweepUnit) * 2), o_blkpool = carve((size_t)B * sizeof(int32_t));   // sweep records: fp64 / main pass, then the RING pass
+                  o_sweep = carve((size_t)nu * sizeof(GSweepUnit)), o_blkpool = carve((size_t)B * sizeof(int32_t));
     for (GUnit& U : units) {
         const GPool& P = pools[U.pool];
         const int d = P.d, pd = P.kd;
@@ -611,11 +582,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         U.qbox = carve((size_t)U.nqtiles * 2 * pd * 8);
         U.qthr = carve((size_t)U.nqtiles * 8);
         U.qlb = carve((size_t)U.nqtiles * 16 * 8);
-        U.nsplit_fin = ring ? 2 * U.nsplit : U.nsplit;
-        U.part = carve((size_t)U.nsplit_fin * U.nqtiles * 16 * 2 * 8);
-        U.apack16 = ring ? carve((size_t)U.ntiles * frag16_b) : 0;
-        U.bpack16 = ring ? carve((size_t)U.nqtiles * frag16_b) : 0;
-        U.ny16 = ring ? carve((size_t)U.nqtiles * 16 * 4) : 0;
+        U.part = carve((size_t)U.nsplit * U.nqtiles * 16 * 2 * 8);
         U.bsum = carve((size_t)((U.nq + 255) / 256 + 1) * 8);
     }
     const int64_t o_wgunit = carve((size_t)(total_wg / 64 + 1) * sizeof(int32_t));
@@ -643,12 +610,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
         s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
         s.margin = (float)prune_margin(fdt, U.N, /*the engine's terms are sums*/ true); s.pad_ = 0.f;
-        GSweepUnit& r = hs[nu + u];   // the RING pass: the bf16 fragments of the same rows, partials behind the fp64 pass's
-        r = s;
-        if (ring) {
-            r.Apack = arena + U.apack16; r.Bpack = arena + U.bpack16; r.nypack = arena + U.ny16;
-            r.part = (double*)(arena + U.part) + (size_t)U.nsplit * U.nqtiles * 16 * 2;
-        }
     }
     int32_t* hb = (int32_t*)(h.data() + o_blkpool);
     for (int k = 0; k < np; ++k)
@@ -673,13 +634,13 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.keys = (uint32_t*)(arena + o_keys_a); g.vals = (uint32_t*)(arena + o_vals_a);
     g.xs = (double*)(arena + o_xs); g.reg = (uint8_t*)(arena + o_reg); g.blkcnt = (int32_t*)(arena + o_blkcnt);
     g.arena = arena; g.xstride = xstride; g.Rs = Rs; g.nunits = nu;
-    static const int sum_bound = env_int("PBN_GROUP_SUM_BOUND", 1);
+    static const int sum_bound = PBN_TUNE(GROUP_SUM_BOUND, 1);
     g.use_sum_bound = sum_bound;
-    g.bf16 = bf16 ? 1 : 0; g.KS = KS; g.ring_nb = NB16;
+    g.bf16 = bf16 ? 1 : 0; g.KS = KS;
     g.out_max = bf16 ? (unsigned long long*)dev_out_max : nullptr;
-    static const int tile_window = std::max(0, env_int("PBN_GROUP_TILE_WINDOW", 256));
+    static const int tile_window = std::max(0, PBN_TUNE(GROUP_TILE_WINDOW, 256));
     g.tile_window = tile_window;
-    static const int window = std::max(1, env_int("PBN_GROUP_WINDOW", PBN_GROUP_WINDOW));
+    static const int window = std::max(1, PBN_TUNE(GROUP_WINDOW, PBN_GROUP_WINDOW));
     g.window = window;
 
     const bool f64 = t->dtype == PBN_F64;
@@ -706,18 +667,12 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         KernelTimer kt(ctx, PBN_K_SWEEP);
         GSweepArgs sa{};
         sa.units = (const GSweepUnit*)(arena + o_sweep); sa.wg_unit = (const int32_t*)(arena + o_wgunit); sa.total_wg = total_wg;
-        sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-        sa.prune_margin = ring ? ring_near_env : 0.0;   // the units' own margins; with a RING pass the fp64 kernel stops at the hand-over radius
-        static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
-        sa.group_masks = ring ? 1 : gmasks;             // (the two passes split the pairs by the per-group test)
-        sa.far_span = ring ? 0.0 : (double)env_int("PBN_FAR_SPAN", 17);   // fp64 FOLD shapes: far tiles through the fp32 unit (kde_sweep_body: FARP)
+        sa.fold = fold ? 1 : 0; sa.wmul = fold ? 0 : 1; sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
+        sa.prune_margin = 0.0;   // the units' own margins
+        static const int gmasks = PBN_TUNE(PRUNE_GROUP_MASKS, 1);
+        sa.group_masks = gmasks;
+        sa.far_span = (double)knob_int("PBN_FAR_SPAN", 17);   // fp64 FOLD shapes: far tiles through the fp32 unit (kde_sweep_body: FARP)
         launch_sweep_grouped(sa, fdt, KS, st);
-        if (ring) {
-            GSweepArgs ra = sa;
-            ra.units = (const GSweepUnit*)(arena + o_sweep) + nu;
-            ra.ring = 1; ra.prune_margin = 0.0; ra.ring_near = ring_near_env;
-            launch_sweep_grouped(ra, fdt, NB16, st);
-        }
     }
     {
         KernelTimer kt(ctx, PBN_K_FINISH);
@@ -747,14 +702,14 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P) {
 // whitened once per unit it trains, every query keeps a partial per training split).  C5 alone (tools/hybrid_batch_probe.sh): 4 GB 7.89 s,
 // 8 GB 7.77 s, 16 GB 7.73 s, 32 GB 7.65 s - but the hipMalloc of a 16 GB arena in a process that has used the memory before costs 0.4 s
 // (tools/arena_bench_probe.sh: the bench line's 0.62 s cv_weak leg became 1.00 s), so the default stops at 8
-size_t kde_group_arena_budget() { return (size_t)std::max(64, env_int("PBN_GROUP_ARENA_MB", 8192)) << 20; }
+size_t kde_group_arena_budget() { return (size_t)std::max(64, knob_int("PBN_GROUP_ARENA_MB", 8192)) << 20; }
 
 size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P) { return pool_bytes(b, P); }
 
 bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
-    const int on = env_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
+    const int on = knob_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
     // fp64 classic fragments; sets whose boxes cover every dimension (no subsample bound needed); the pruned-sweep shapes
-    return on && (dtype == PBN_F64 || use_bf16x3(dtype)) && d >= 1 && d <= std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), 4) && R >= 1 &&
+    return on && (dtype == PBN_F64 || use_bf16x3(dtype)) && d >= 1 && d <= std::min(PBN_TUNE(PRUNE_BOX_DIMS, 4), 4) && R >= 1 &&
            R <= PBN_GROUP_MAX_R && kde_prune_applies(dtype, d, n_min);
 }
 
@@ -777,7 +732,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     auto variant = [&](int i) { const int d = b.pools[i].d; return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
     const size_t budget = kde_group_arena_budget();
-    const int max_pools = std::min(256, std::max(1, env_int("PBN_GROUP_MAX_POOLS", 256)));
+    const int max_pools = std::min(256, std::max(1, PBN_TUNE(GROUP_MAX_POOLS, 256)));
     size_t p0 = 0;
     while (p0 < order.size()) {
         size_t p1 = p0, bytes = 0;

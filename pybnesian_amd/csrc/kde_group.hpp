@@ -54,8 +54,6 @@ struct GUnit {
     int64_t wg0;           // first flat sweep workgroup
     // byte offsets into the batch arena
     int64_t apack, npack, zs, box, bpack, ny, zq, qpos, qbox, qthr, qlb, part, bsum;
-    int64_t apack16, bpack16, ny16;   // bf16x3 fragments of the same rows (RING pass of fp64 tables), or 0
-    int32_t nsplit_fin, pad2_;       // split partials per query the finish merges (2 x nsplit with a RING pass)
     double lognorm;
     double W[PBN_GROUP_MAX_D * PBN_GROUP_MAX_D];    // whitening, row-major lower, base-2 units (kde_prepare)
     double mu[PBN_GROUP_MAX_D];
@@ -104,9 +102,7 @@ struct GSweepArgs {
     const int32_t* wg_unit;   // [total flat workgroups / 64] -> unit
     int64_t total_wg;
     int fold, wmul, count_redo, group_masks;
-    int ring;              // this launch is the RING (far-field, bf16) pass of an fp64 sweep
-    double prune_margin;   // > 0: one margin for every unit of the launch (the near pass of a RING sweep); 0: the units' own
-    double ring_near;      // exponent distance below the sum bound at which the fp64 pass hands over to the RING pass
+    double prune_margin;   // > 0: one margin for every unit of the launch; 0: the units' own
     double far_span;       // SweepArgs::far_span of every unit of the launch
 };
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st);

@@ -1102,149 +1102,9 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul;
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
-    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = g.group_masks; a.ring_near = 0;
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = g.group_masks;
     a.far_span = g.far_span;
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true>(a, bid);
-}
-
-// ------------------------------------------------------------------------------------------------
-// kde_sweep_sparse (fp64, unconditional): the DP units are the binding resource of the fp64 sweep and the
-// 2^x polynomial is more than half of their work, while for realistic bandwidths most (train, query) pairs
-// are negligible: a term with s2 - m_q <= -60 is below 2^-60 of its query's running sum (>= 1), i.e. below
-// the rounding of the sum even when a million of them are dropped (< 1e-12 relative).  So the exponential is
-// evaluated ONLY for "alive" values: after the MFMAs each lane pushes its alive accumulator values onto a
-// private LDS stack (conflict-free: slot-major, lane-minor), and when a stack gets full the wave pops in
-// lock-step and runs the polynomial densely on the popped values.  One query group per wave and TB
-// training tiles per iteration, so that all 16 values a lane produces per iteration belong to the same query
-// (no tags, one running sum per lane).  The offset m_q (uniform over the 4 lanes of a query column) starts as the
-// maximum over a max-only scan of the first `prologue_tiles` tiles and is raised whenever a popped value exceeds
-// `soft`, which keeps it within 2^soft of the running maximum - the alive test stays sharp and nothing can
-// overflow; queued values are re-based in that (rare, wave-uniform) path.
-// ------------------------------------------------------------------------------------------------
-#define PBN_SPARSE_TB 4
-#define PBN_SPARSE_CAP 24
-#define PBN_SPARSE_DEAD (-60.0)
-
-template <int KS>
-__global__ __launch_bounds__(256, 3) void kde_sweep_sparse_kernel(SweepArgs a) {
-    constexpr int TB = PBN_SPARSE_TB;
-    constexpr int CAP = PBN_SPARSE_CAP;
-    __shared__ double queue[4][CAP][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int lg = lane >> 4;
-    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
-    if (qt >= a.nqtiles) return;  // no workgroup barriers in this kernel
-    const int split = blockIdx.y;
-    const int64_t t0 = (int64_t)split * a.tiles_per_split;
-    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
-
-    const double* __restrict__ Ap = (const double*)a.Apack;
-    const double* __restrict__ Np = (const double*)a.nxpack;
-    const double* __restrict__ Bp = (const double*)a.Bpack;
-    const double* __restrict__ NYp = (const double*)a.nypack;
-
-    double b[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) b[ks] = Bp[(qt * KS + ks) * 64 + lane];
-    const double ny = NYp[qt * 16 + (lane & 15)];
-
-    // ---- prologue: offset from the first TB tiles -----------------------------------------------
-    double m;
-    {
-        double mx = -INFINITY;
-        for (int j = 0; j < a.prologue_tiles; ++j) {
-            const int64_t t = t0 + j;
-            if (t >= t1) break;
-            d4 acc = *(const d4*)(Np + t * 16 + lg * 4) + ny;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = Tr<double>::mfma(Ap[(t * KS + ks) * 64 + lane], b[ks], acc);
-            const double v = max4<double>(acc);
-            mx = v > mx ? v : mx;
-        }
-        m = colmax<double>(mx);
-    }
-    double cm = ny - m;
-    double sum = 0.0;
-    double* const qbase = &queue[wave][0][lane];
-    double* qtop = qbase;                                   // next free slot (slot stride = 64 doubles)
-    double* const qhigh = qbase + (CAP - 4 * TB) * 64;      // above this a further iteration could overflow
-
-    // pop one value per non-empty lane, raise the offset if needed, accumulate 2^v
-    auto pop_round = [&]() {
-        const bool has = qtop > qbase;
-        double v = -1e30;
-        if (has) { qtop -= 64; v = *qtop; }
-        if (__builtin_expect(__any(v > a.soft), 0)) {
-            double mx = colmax<double>(v > 0.0 ? v : 0.0);  // uniform over the 4 lanes of the query column
-            if (mx > 0.0) {
-                m += mx;
-                cm = ny - m;
-                sum *= exp2(-mx);
-                v -= mx;
-                for (double* q = qbase; q < qtop; q += 64) *q -= mx;
-            }
-        }
-        if (has) sum += Tr<double>::ex2(v);
-    };
-
-    // fragments of the first TB tiles (clamped; tiles past t1 are masked out below)
-    double af[TB][KS];
-    d4 nx[TB];
-    auto load_tiles = [&](int64_t t, double (&f)[TB][KS], d4 (&n)[TB]) {
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int64_t tj = t + j < t1 ? t + j : t1 - 1;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) f[j][ks] = Ap[(tj * KS + ks) * 64 + lane];
-            n[j] = *(const d4*)(Np + tj * 16 + lg * 4);
-        }
-    };
-    load_tiles(t0, af, nx);
-
-    for (int64_t t = t0; t < t1; t += TB) {
-        double afn[TB][KS];
-        d4 nxn[TB];
-        load_tiles(t + TB < t1 ? t + TB : t, afn, nxn);  // prefetch the next iteration
-
-        d4 acc[TB];
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            acc[j] = nx[j] + cm;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc[j] = Tr<double>::mfma(af[j][ks], b[ks], acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const bool live = t + j < t1;  // wave-uniform
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const double v = acc[j][i];
-                if (live && v > PBN_SPARSE_DEAD) { *qtop = v; qtop += 64; }
-            }
-        }
-        if (__any(qtop > qhigh)) {
-            // lock-step pops while most lanes have work, then whatever is needed to make room
-            while (__popcll(__ballot(qtop > qbase)) >= 48) pop_round();
-            while (__any(qtop > qhigh)) pop_round();
-        }
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) af[j][ks] = afn[j][ks];
-            nx[j] = nxn[j];
-        }
-    }
-    while (__any(qtop > qbase)) pop_round();
-
-    double s = sum;
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (lg == 0) {
-        double* o = a.part + ((int64_t)split * a.nqtiles * 16 + qt * 16 + lane) * 2;
-        o[0] = m;
-        o[1] = s;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1398,14 +1258,8 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_QG_PRUNE
 #define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
-// RING (grouped evaluation of fp64 tables, kde_group.hip): the far field of an fp64 sweep.  The fp64 kernel visits the (tile, group)
-// pairs whose box distance allows a term within 2^-ring_near of the group's sum bound; this kernel visits the pairs BETWEEN that
-// radius and the pruning radius (2^-prune_margin) - terms below 2^-ring_near of their sums, for which fp32 arithmetic (6e-8 relative,
-// exponents good to ~1e-4) is far more than enough - at a third of the fp64 kernel's cost per pair.  Masks per 16-query group, with
-// the fp64 kernel's own test (prune_group_mask), so that every (tile, group) pair is taken by exactly one of the two passes.
-template <int NB, bool COND, int QG, bool PRUNE, bool RING = false>
+template <int NB, bool COND, int QG, bool PRUNE>
 __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const unsigned bid) {
-    static_assert(!RING || (PRUNE && !COND), "RING: pruned plain sweeps only");
     using V = f4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
@@ -1557,7 +1411,6 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     // VALU's exponentials, one overflow test per tile, the rare path redoes a group (C2 fp32: 15.2 -> 14.1 ms).  The
     // fused CKDE sweep and the pruned sweeps keep the group-by-group form: with two accumulator sets per group in flight,
     // or one wave per SIMD less, the other form loses (C5's sweeps 33 -> 40 s; pruned d = 1 plain sweep 8.3 -> 10.2 ms).
-    unsigned long long gm[RING ? QG : 1];
     // plain unpruned sweeps (PBN_BF16_PAIRSUM): the sums of the two tiles of a loop iteration are added in fp32 and join the fp64 sums
     // together - one v_cvt_f64_f32 + v_add_f64 per group and TWO tiles
     constexpr bool PAIRSUM = !COND && !PRUNE && PBN_BF16_PAIRSUM;
@@ -1585,7 +1438,6 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         if constexpr (COND || PRUNE) {
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
-                if constexpr (RING) { if (!((gm[g] >> bit) & 1ull)) continue; }
                 V acc = mfma_main(f, g, cmv[g]);
                 V accj;
                 if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);
@@ -1701,20 +1553,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         for (int64_t tb = t0; tb < t1; tb += 64) {   // see kde_sweep_kernel
             // (one mask per WAVE here: per-group masks as in the fp64 kernel - prune_group_mask - were measured and dropped for the
             //  fp32 kernels, which live on occupancy and straight-line issue: 1e6 x 1e5 handles +15...20 %, C5 15.8 -> 16.4 s)
-            unsigned long long mask;
-            if constexpr (RING) {
-                mask = 0;
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-                    const double th = QTp[qt];
-                    gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, th - a.prune_margin, lane) &
-                            ~prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, th - a.ring_near, lane);
-                    mask |= gm[g];
-                }
-            } else {
-                mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
-            }
+            const unsigned long long mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
             if (!mask) continue;
             if (a.count_redo && lane == 0) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(mask));
             auto run_batch = [&](unsigned long long mk, auto blind) {
@@ -1738,7 +1577,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                     b = b3;
                 }
             };
-            if constexpr (!COND && !RING && PBN_BF16_BLIND) {
+            if constexpr (!COND && PBN_BF16_BLIND) {
                 double saved[QG];
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
@@ -1808,8 +1647,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         // sum can come out empty although it holds at least the offset's own term: count that term.  (A split whose tiles
         // were all pruned gets the same term: below 2^-64 of the query's sum by the pruning rule.)
         // (not when the offset is a prepass bound: no term of this split stands behind it, an empty sum is empty)
-        // (not in the RING pass: the offset's own term belongs to the fp64 pass there)
-        if (!RING && s == 0.0 && (m[g] - m[g]) == 0.f && !lbm[g]) s = 1.0;
+        if (s == 0.0 && (m[g] - m[g]) == 0.f && !lbm[g]) s = 1.0;
         if (COND && sj == 0.0 && (mj[g] - mj[g]) == 0.f && !lbmj[g]) sj = 1.0;
         if (lg == 0 && qt0 + g < a.nqtiles) {
             PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
@@ -1826,7 +1664,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_
 }
 
 // grouped launch of the pruned plain fp32 sweeps (see kde_sweep_group_kernel)
-template <int NB, bool RING>
+template <int NB>
 __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) void kde_sweep_bf16_group_kernel(GSweepArgs g) {
     const int u = g.wg_unit[blockIdx.x >> 6];
     const GSweepUnit& su = g.units[u];
@@ -1839,8 +1677,8 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) vo
     a.fold = 0; a.count_redo = g.count_redo; a.wmul = 0;
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
-    a.nsplit_grid = su.nsplit; a.part = su.part; a.soft = 0; a.prologue_tiles = 0; a.group_masks = 0; a.ring_near = g.ring_near;
-    kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true, RING>(a, bid);
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = 0;
+    kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true>(a, bid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2317,19 +2155,17 @@ void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t 
 // (profiles/r4/margin_probe4.txt).  PBN_PRUNE_MARGIN pins the fp64 value for both kinds, PBN_PRUNE_MARGIN_SUM the sum-only one,
 // PBN_PRUNE_MARGIN_F32 the fp32 one; read per call (a host getenv per sweep launch) so that tests can pin them inside one process.
 double prune_margin(int dtype, int64_t n_train, bool sum_only) {
-    auto env = [](const char* name, double dflt) { const char* e = getenv(name); return (e && *e) ? atof(e) : dflt; };
-    const char* ea = getenv("PBN_PRUNE_MARGIN_ADAPT");
-    const bool adapt = !(ea && *ea) || atoi(ea) != 0;
+    const bool adapt = PBN_TUNE(PRUNE_MARGIN_ADAPT, 1) != 0;
     double base;
-    if (use_bf16x3(dtype)) base = env("PBN_PRUNE_MARGIN_F32", (double)PBN_PRUNE_MARGIN_F32);
-    else base = env("PBN_PRUNE_MARGIN", sum_only ? env("PBN_PRUNE_MARGIN_SUM", (double)PBN_PRUNE_MARGIN_SUM) : (double)PBN_PRUNE_MARGIN);
+    if (use_bf16x3(dtype)) base = knob_double("PBN_PRUNE_MARGIN_F32", (double)PBN_PRUNE_MARGIN_F32);
+    else base = knob_double("PBN_PRUNE_MARGIN", sum_only ? knob_double("PBN_PRUNE_MARGIN_SUM", (double)PBN_PRUNE_MARGIN_SUM) : (double)PBN_PRUNE_MARGIN);
     if (!adapt || n_train <= 0) return base;
     const double m = base + std::log2((double)n_train / 1e6);
     return m < 8.0 ? 8.0 : m;
 }
 
 bool use_bf16x3(int dtype) {
-    static const int v = [] { const char* e = getenv("PBN_F32_BF16X3"); return (e && *e) ? atoi(e) : 1; }();
+    static const int v = PBN_TUNE(F32_BF16X3, 1);   // (0: fp32 tables on the f32 MFMA kernels - the round-1 path, kept for comparisons)
     return v != 0 && dtype == PBN_F32;
 }
 
@@ -2443,42 +2279,24 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
                           const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
                           const double* subpart, int P, int which, double log2_nsub, const double* tile_box) {
     if (nq == 0) return;
-    static const int sum_bound = [] { const char* e = getenv("PBN_GROUP_SUM_BOUND"); return (e && *e) ? atoi(e) : 1; }();
-    static const int tile_window = [] { const char* e = getenv("PBN_GROUP_TILE_WINDOW"); const int v = (e && *e) ? atoi(e) : 256; return v < 0 ? 0 : v; }();
+    static const int sum_bound = PBN_TUNE(GROUP_SUM_BOUND, 1);
+    static const int tile_window = std::max(0, PBN_TUNE(GROUP_TILE_WINDOW, 256));
     hipLaunchKernelGGL(query_prepass_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, st, zq_row, qperm, nq, qkeys_sorted, ztrain_sorted,
                        tkeys_sorted, n, zd, pd, qbox, qthr, qlb, subpart, P, which, log2_nsub, sum_bound, tile_box, tile_window);
     HIP_CHECK(hipGetLastError());
 }
 
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm) {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PBN_SWEEP_FOLD");
-        v = (e && *e) ? atoi(e) : 1;
-    }
-    return v != 0 && !use_bf16x3(dtype) && !use_sparse(dtype, cond, KS) && dm % 4 != 0 && KS <= 4;   // more than 16 dimensions: one form only
+    static const int v = PBN_TUNE(SWEEP_FOLD, 1);
+    return v != 0 && !use_bf16x3(dtype) && dm % 4 != 0 && KS <= 4;   // more than 16 dimensions: one form only
 }
 
 bool sweep_weights_norm(int dtype, bool cond, int KS, int dm) {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PBN_SWEEP_WMUL");
-        v = (e && *e) ? atoi(e) : 1;
-    }
-    return v != 0 && dtype == PBN_F64 && !cond && !use_sparse(dtype, cond, KS) && dm % 4 == 0 && KS <= 2;   // KS 3, 4: 169 / 181 VGPRs, a wave per SIMD lost
-}
-
-bool use_sparse(int dtype, bool cond, int KS) {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PBN_SWEEP_SPARSE");
-        v = (e && *e) ? atoi(e) : 0;  // opt-in experiment, see DESIGN.md §3.1 "sparse exp"
-    }
-    return v != 0 && dtype == PBN_F64 && !cond && KS <= 2;
+    static const int v = PBN_TUNE(SWEEP_WMUL, 1);
+    return v != 0 && dtype == PBN_F64 && !cond && dm % 4 == 0 && KS <= 2;   // KS 3, 4: 169 / 181 VGPRs, a wave per SIMD lost
 }
 
 int sweep_qg(int dtype, bool cond, int KS, bool prune) {
-    if (use_sparse(dtype, cond, KS)) return 1;
     if (prune && dtype == PBN_F64) return cond ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;
     if (KS > 4) return 2;   // more than 16 (fp32: 20) dimensions: two query groups per wave (fragment registers); KS = MFMAs per tile pair
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
@@ -2519,13 +2337,6 @@ void launch_sweep(const SweepArgs& a_in, int dtype, int KS, bool cond, int nspli
         if (cond) launch_sweep_bf16<true>(a, KS, grid, st); else launch_sweep_bf16<false>(a, KS, grid, st);
         return;
     }
-    if (use_sparse(dtype, cond, KS)) {
-        dim3 block(256);
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_sparse_kernel<1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((kde_sweep_sparse_kernel<2>), grid, block, 0, st, a);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
     if (dtype == PBN_F64) {
         if (cond) launch_sweep_t<double, true>(a, KS, grid, st); else launch_sweep_t<double, false>(a, KS, grid, st);
     } else {
@@ -2538,17 +2349,9 @@ void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st
     if (g.total_wg == 0) return;
     if (g.total_wg > 0x7fffffffll) throw invalid_error("grouped sweeps: grid too large");
     const dim3 grid((unsigned)g.total_wg), block(sweep_block_threads(true));
-    if (g.ring) {   // the far field of an fp64 sweep on the bf16 cores; KS carries the number of bf16 MFMAs
-        static_assert(PBN_QG_PRUNE == PBN_BF16_QG_PRUNE, "the two passes of a ring sweep share the workgroup table");
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1, true>), grid, block, 0, st, g);
-        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2, true>), grid, block, 0, st, g);
-        else throw invalid_error("grouped ring sweeps: at most 10 whitened dimensions");
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
     if (use_bf16x3(dtype)) {   // KS carries the number of bf16 MFMAs
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1, false>), grid, block, 0, st, g);
-        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2, false>), grid, block, 0, st, g);
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1>), grid, block, 0, st, g);
+        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2>), grid, block, 0, st, g);
         else throw invalid_error("grouped fp32 sweeps: at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;

@@ -86,10 +86,7 @@ struct SweepArgs {
     int group_masks;           // pruned plain fp64 sweeps: test every 16-query group against its own box and bound (prune_group_mask)
     double far_span;           // pruned plain fp64 sum-only sweeps (FOLD shapes): > 0 = tiles whose every term lies more than prune_margin - far_span
                                // below the group's sum bound take the fp32 tail path (kde_sweep_body: FARP); 0 = off
-    double ring_near;          // RING pass of the bf16 kernel: visit only pairs whose bound lies between 2^-prune_margin and 2^-ring_near of the sum
     double* part;  // [nsplit][nqtiles*16][P]
-    double soft;         // sparse sweep: raise the offset when a popped value exceeds this (base-2 units)
-    int prologue_tiles;  // sparse sweep: tiles scanned (max only) to initialise the offsets
 };
 
 struct FinishArgs {
@@ -121,7 +118,6 @@ struct SweepQG {
 #define PBN_QG_PRUNE_COND 2
 #endif
 int sweep_qg(int dtype, bool cond, int KS, bool prune = false);
-bool use_sparse(int dtype, bool cond, int KS);
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm);   // see PackArgs::fold_norm
 bool sweep_weights_norm(int dtype, bool cond, int KS, int dm); // see SweepArgs::wmul
 // spatial sort + bounding boxes + exponent bounds of the pruned sweeps (SweepArgs::prune)

@@ -166,7 +166,6 @@ static void fill_pack_common(pbn_ctx* ctx, PackArgs& pa, const pbn_table* t, con
     for (int i = 0; i < m.d; ++i) pa.mu[i] = m.mu[i];
 }
 
-static int env_int(const char* name, int dflt);
 
 double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0, int64_t row1,
                      const int32_t* dev_rows) {
@@ -185,10 +184,8 @@ double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const 
 }
 
 bool kde_wants_widening(double max_norm2) {
-    const bool on = env_int("PBN_F32_WIDEN", 1) != 0;   // read per fit (a fit synchronises anyway): tests flip it inside one process
-    const char* e = std::getenv("PBN_F32_WIDEN_AT");
-    const double at = (e && *e) ? std::atof(e) : 5e-4;
-    return on && !(max_norm2 * 5.9604644775390625e-08 <= at);   // 2^-24 |z|^2: the size of the fp32 Gram form's error on an exponent
+    const double at = knob_double("PBN_F32_WIDEN_AT", 5e-4);   // (read per call: tests move it inside one process; inf switches the widening off)
+    return !(max_norm2 * 5.9604644775390625e-08 <= at);   // 2^-24 |z|^2: the size of the fp32 Gram form's error on an exponent
 }
 
 void kde_widen(KdeModel& m) {
@@ -227,8 +224,8 @@ static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackA
 // d = 6 gains 10 % in fp64 and 9-13 % in fp32 on correlated and on independent normal data and is even on heavy-tailed data;
 // d = 7 is even at best (heavy-tailed: +3...5 %), d = 8 loses 10 %.
 bool kde_prune_applies(int dtype, int dm, int64_t n) {
-    const int max_dims = env_int("PBN_PRUNE_MAX_DIMS", 6);
-    return env_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= max_dims && n >= env_int("PBN_PRUNE_MIN_ROWS", 32768);
+    const int max_dims = PBN_TUNE(PRUNE_MAX_DIMS, 6);
+    return knob_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= max_dims && n >= knob_int("PBN_PRUNE_MIN_ROWS", 32768);
 }
 
 // bytes of the subsample packs (kde_pack_bytes of nsub rows, each part 256-aligned)
@@ -288,12 +285,12 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     if (prune && kde_prune_applies(m.fdtype(), m.dm, m.N)) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
         m.zdims = m.d;
-        m.pdims = std::min(m.dm, std::min(env_int("PBN_PRUNE_BOX_DIMS", 4), PBN_PRUNE_PD));   // dimensions of the Morton keys and the boxes (<= PBN_PRUNE_PD)
+        m.pdims = std::min(m.dm, std::min(PBN_TUNE(PRUNE_BOX_DIMS, 4), PBN_PRUNE_PD));   // dimensions of the Morton keys and the boxes (<= PBN_PRUNE_PD)
         const size_t box_b = al((size_t)m.ntiles * 2 * m.pdims * sizeof(double)), zs_b = al((size_t)m.N * m.zdims * sizeof(double));
         // more dimensions than the keys cover: a stratified subsample (every N / nsub-th row of the sorted order, <= 4096
         // rows, <= 1/64 of the set) is packed as well; the queries are swept against it first (kde_eval_enqueue)
         m.nsub = 0;
-        if (m.d > m.pdims && env_int("PBN_PRUNE_SUBSAMPLE", 1)) m.nsub = std::min<int64_t>(4096, m.N / 64) / 16 * 16;
+        if (m.d > m.pdims && PBN_TUNE(PRUNE_SUBSAMPLE, 1)) m.nsub = std::min<int64_t>(4096, m.N / 64) / 16 * 16;
         const SubBytes sb = sub_bytes(m, m.nsub);
         const PruneSide s = prune_sort_side(ctx, ctx->scratch_prune, pa, m.fdtype(), m.zdims, m.pdims, box_b + zs_b + (m.nsub ? sb.total : 0));
         double* box = (double*)s.rest;
@@ -343,14 +340,10 @@ void kde_prune_persist(pbn_ctx* ctx, KdeModel& m, dev_buf<char>& store) {
     }
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* s = std::getenv(name);
-    return s && *s ? std::atoi(s) : dflt;
-}
-
 void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                      double* dev_logl, double* dev_sum, const int32_t* dev_rows, double* dev_sum_marg) {
+                      double* dev_logl, double* dev_sum, const int32_t* dev_rows, double* dev_sum_marg, bool precise) {
     check_cols(test, cols, m.d, "pbn_kde_logl");
+    const bool sum_only = dev_logl == nullptr && !precise;   // only sums leave this call, at the sum-only error budget
     if (!dev_rows) check_range(test, row0, n, "pbn_kde_logl");
     if (test->dtype != m.dtype) throw invalid_error("Data type of training and test datasets is different.");
     const int fdt = m.fdtype();   // type of the fragments and of the sweep (double for a widened fp32 model)
@@ -425,7 +418,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
         pa.perm = qs.perm;
         qperm = qs.perm;
         qbox = (double*)qs.rest; qthr = (double*)(qs.rest + qbox_b);
-        static const bool use_qlb = env_int("PBN_SWEEP_QLB", 1) != 0;   // offsets of the pruned plain sweeps from the prepass bounds
+        static const bool use_qlb = PBN_TUNE(SWEEP_QLB, 1) != 0;   // offsets of the pruned plain sweeps from the prepass bounds
         if (use_qlb) qlb = (double*)(qs.rest + qbox_b + qthr_b);
     }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
@@ -445,7 +438,6 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
             ss.ntiles = m.ntiles_sub; ss.nqtiles = nqtiles; ss.tiles_per_split = m.ntiles_sub;
             ss.fold = fold ? 1 : 0; ss.wmul = wmul ? 1 : 0; ss.prune = 0;
             ss.part = (double*)ctx->scratch_part.p;
-            ss.soft = env_int("PBN_SPARSE_SOFT", 8); ss.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
             { KernelTimer kt(ctx, PBN_K_PACK); launch_sweep(ss, fdt, m.KS, m.cond, 1, ctx->stream); }
             subpart = ss.part;
         }
@@ -455,19 +447,19 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
 
     // split the training tiles so that the grid is a few waves deep on every CU
     const int64_t qblocks = ceil_div(nqtiles, 4 * sweep_qg(fdt, m.cond, m.KS, m.prune));
-    const int64_t target = (int64_t)ctx->num_cus * env_int("PBN_SWEEP_BLOCKS_PER_CU", 24);
+    const int64_t target = (int64_t)ctx->num_cus * PBN_TUNE(SWEEP_BLOCKS_PER_CU, 24);
     int64_t nsplit = std::max<int64_t>(1, ceil_div(target, qblocks));
     // with the XCD-aware block order (xcd_block) the blocks resident on one XCD share a split: keep a split's training
     // fragments within half of the 4 MB L2, and the number of splits a multiple of 8 so that the XCDs get equal shares
     const int64_t tile_bytes = b3 ? (int64_t)m.KS * 64 * 16 + (m.cond ? 64 * 16 : 0)
                                   : ((int64_t)m.KS * 64 + 16 + (m.cond ? 64 : 0)) * (int64_t)es;
-    nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles * tile_bytes, (int64_t)env_int("PBN_SWEEP_SPLIT_KB", 2048) * 1024));
+    nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles * tile_bytes, (int64_t)PBN_TUNE(SWEEP_SPLIT_KB, 2048) * 1024));
     // pruned sweeps: a workgroup of the queries' own neighbourhood visits most tiles of its split, and those long workgroups are
     // the sweep's tail - at most PBN_PRUNE_MAX_TILES tiles per split (1e6 x 1e5 handles: fp64 -5...9 %, fp32 -7 %; the score
     // engine's slices are below that anyway - splitting THEM four times finer costs C5 12 %)
-    if (m.prune) nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles, (int64_t)env_int("PBN_PRUNE_MAX_TILES", 1024)));
+    if (m.prune) nsplit = std::max<int64_t>(nsplit, ceil_div(m.ntiles, (int64_t)PBN_TUNE(PRUNE_MAX_TILES, 1024)));
     if (nsplit > 1) nsplit = ceil_div(nsplit, 8) * 8;
-    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / env_int("PBN_SWEEP_MIN_TILES", 64)));
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, m.ntiles / PBN_TUNE(SWEEP_MIN_TILES, 64)));
     nsplit = std::min<int64_t>(nsplit, 4096);
     const int64_t tps = ceil_div(m.ntiles, nsplit);
     nsplit = ceil_div(m.ntiles, tps);
@@ -478,16 +470,14 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
     sa.wmul = wmul ? 1 : 0;
-    sa.far_span = (dev_logl == nullptr && m.prune) ? (double)env_int("PBN_FAR_SPAN", 17) : 0.0;   // sum-only pruned sweeps: fp32 tail for tiles 26+ bits below the sum bound
-    sa.fast = dev_logl == nullptr ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
-    sa.count_redo = env_int("PBN_SWEEP_COUNT_REDO", 0);
-    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, dev_logl == nullptr); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
+    sa.far_span = (sum_only && m.prune) ? (double)knob_int("PBN_FAR_SPAN", 17) : 0.0;   // sum-only pruned sweeps: fp32 tail for tiles 26+ bits below the sum bound
+    sa.fast = sum_only ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
+    sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
+    sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, sum_only); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
-    sa.soft = env_int("PBN_SPARSE_SOFT", 8);
-    sa.prologue_tiles = env_int("PBN_SPARSE_PROLOGUE", 64);
-    static const int gmasks = env_int("PBN_PRUNE_GROUP_MASKS", 1);
+    static const int gmasks = PBN_TUNE(PRUNE_GROUP_MASKS, 1);
     sa.group_masks = gmasks;
-    static const bool log_sweeps = env_int("PBN_SWEEP_LOG", 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
+    static const bool log_sweeps = PBN_TUNE(SWEEP_LOG, 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
     if (log_sweeps) std::fprintf(stderr, "pbn-sweep N=%lld n=%lld d=%d cond=%d prune=%d nsub=%lld nsplit=%lld\n", (long long)m.N, (long long)n, m.d, (int)m.cond, (int)m.prune, (long long)(m.prune ? m.nsub : 0), (long long)nsplit);
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, fdt, m.KS, m.cond, (int)nsplit, ctx->stream); }
 

@@ -1,6 +1,7 @@
 // Non-owning fitted-KDE description shared by the public KDE handles (capi.hip) and the score engine
 // (scoring.hip): host-side whitening/normalisation data + pointers to packed training fragments.
 #pragma once
+#include <cmath>
 #include <vector>
 
 #include "common.hpp"
@@ -88,8 +89,16 @@ void kde_prune_persist(pbn_ctx* ctx, KdeModel& m, dev_buf<char>& store);
 // pack(queries) -> sweep -> finish on the context stream; dev_logl / dev_sum nullable (device pointers).
 // dev_sum_marg (CKDE only, nullable): dev_sum then receives the sum of the JOINT log-densities and dev_sum_marg the sum
 // of the marginal ones, instead of their difference.
+// precise: a sum is wanted (dev_logl == nullptr) but at the accuracy of the per-row path - the polynomial 2^f, the pruning margin of the
+// per-row sweeps, no fp32 tail.  The callers' second evaluation of a sum that came out too close to zero for the sum-only path's
+// absolute error budget (kde_sum_needs_precision).
 void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, const int* cols, int64_t row0, int64_t n,
-                      double* dev_logl, double* dev_sum, const int32_t* dev_rows = nullptr, double* dev_sum_marg = nullptr);
+                      double* dev_logl, double* dev_sum, const int32_t* dev_rows = nullptr, double* dev_sum_marg = nullptr, bool precise = false);
+// The sum-only fp64 sweeps carry an ABSOLUTE error per log-density of at most 1.4e-7 (2^f on the fp32 unit) + 1.1e-7 (dropped mass) +
+// 8e-8 (fp32 far tail) = 3.3e-7; measured with every rounding made one-sided (tests/test_error_budget_gpu.py): 3e-8.  Relative to a sum
+// of n log-densities that is harmless unless the sum is a cancellation to ~0 (a table whose density happens to sit near 1 in its units):
+// |sum| < 0.66 n is where the bound would exceed 5e-7 of the sum - such a sum is evaluated once more at full precision.
+inline bool kde_sum_needs_precision(double sum, int64_t n) { return n > 0 && std::fabs(sum) < 0.66 * (double)n; }
 
 // Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
 void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);

@@ -566,7 +566,7 @@ struct Engine {
     // per set of discrete variables (config 5: 514 k tests over 347 sets), each of which used to gather its own few columns
     // through the permutation - 4-byte reads 64 bytes apart, 5.8 of the 6.9 s of that MMPC.
     static bool full_gram_on() {
-        static const bool v = [] { const char* e = getenv("PBN_MI_FULLGRAM"); return !(e && *e) || atoi(e) != 0; }();
+        static const bool v = PBN_TUNE(MI_FULLGRAM, 1) != 0;
         return v;
     }
     // host bytes of a grouping's full moments; all cached groupings together stay below PBN_MI_FULL_BUDGET_MB (default 1024) -
@@ -575,7 +575,7 @@ struct Engine {
     bool full_applies(const DiscGroup& g) const {
         if (!(full_gram_on() && h->table && h->n_cont >= 1 && h->n_cont <= 64 && g.G <= 4096 && g.nblk > 0)) return false;
         if (g.full_ready) return true;
-        static const size_t budget = [] { const char* e = getenv("PBN_MI_FULL_BUDGET_MB"); return (size_t)((e && *e) ? atoll(e) : 1024) << 20; }();
+        static const size_t budget = (size_t)std::max(0ll, knob_ll("PBN_MI_FULL_BUDGET_MB", 1024)) << 20;
         return h->full_bytes_held + full_bytes(g) <= budget;
     }
     void ensure_full(DiscGroup& g) {
@@ -603,7 +603,7 @@ struct Engine {
         // larger mirrors are not built and the rows are gathered from the columns.
         if (a.rows && !h->rowmajor_tried) {
             h->rowmajor_tried = true;
-            static const size_t budget = [] { const char* e = getenv("PBN_MI_MIRROR_MB"); return (size_t)((e && *e) ? atoll(e) : 16384) << 20; }();
+            static const size_t budget = (size_t)PBN_TUNE(MI_MIRROR_MB, 16384) << 20;
             const size_t bytes = rowmajor_mirror_elems(h->table->n_rows, nc) * dtype_size(h->table->dtype);
             if (bytes <= budget) {
                 try {
@@ -626,7 +626,7 @@ struct Engine {
         // configuration-major, 1 = stripe-major, 2 (default) = stripe-major with the pieces of stripe s on launch indices = s mod 8
         // (one XCD and its L2 under the usual round-robin; padding blocks without a piece keep the residues when few are needed).
         // The partial slots, and with them the order of every sum, do not change.
-        static const int order = [] { const char* e = getenv("PBN_MI_GRAM_ORDER"); return (e && *e) ? atoi(e) : 2; }();
+        static const int order = PBN_TUNE(MI_GRAM_ORDER, 2);
         dev_buf<int32_t> ordered;
         int nlaunch = g.nblk;
         if (order != 0 && g.G > 1) {
@@ -1097,8 +1097,7 @@ void pbn_mi_destroy(pbn_mi* h) {
     std::lock_guard<std::recursive_mutex> lock_(mu_of(h));
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
-    const char* tm = std::getenv("PBN_MI_TIMING");
-    if (tm && *tm == '1')
+    if (PBN_TUNE(MI_TIMING, 0) == 1)
         std::fprintf(stderr, "[pbn_mi] tests %lld (count-only %lld), batches %lld, launches %lld, groupings built %lld: build %.2f s, "
                      "plan/map %.2f s, device %.2f s, host statistics %.2f s\n", (long long)h->device_passes, (long long)h->count_only,
                      (long long)h->batches, (long long)h->device_launches, (long long)h->groups_built, h->t_group, h->t_prep, h->t_device, h->t_host);
@@ -1219,9 +1218,8 @@ void pbn_mi_pvalue_batch(void* user, int n_tests, const int* v1, const int* v2, 
             out[i] = gamma_q(0.5 * e.df(qs[i]), 0.5 * (mi * 2.0 * e.rows_of(plans[i], st[i])));
         };
         static const int max_threads = [] {
-            const char* ev = getenv("PBN_MI_THREADS");
             const int hw = (int)std::thread::hardware_concurrency();
-            const int n = (ev && *ev) ? atoi(ev) : std::min(hw > 0 ? hw : 1, 16);
+            const int n = knob_int("PBN_MI_THREADS", std::min(hw > 0 ? hw : 1, 16));
             return n < 1 ? 1 : n;
         }();
         const int nth = std::min(max_threads, n_tests / 64);

@@ -85,8 +85,7 @@ void gram_raw(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t 
 // be the same on every rank of a job, and another value gives other last bits.
 static int64_t seg_rows() {
     static const int64_t v = [] {
-        const char* e = getenv("PBN_MOMENT_SEG_ROWS");
-        const int64_t r = (e && *e) ? atoll(e) : 4096;
+        const int64_t r = PBN_TUNE(MOMENT_SEG_ROWS, 4096);
         return std::max<int64_t>(128, r / 128 * 128);
     }();
     return v;
@@ -374,13 +373,12 @@ double bge_score(const pbn_scoredata* sd, const Stats& st, const int* cols, int 
 
 namespace pbn { namespace score {
 bool lg_guard_on() {
-    const char* e = getenv("PBN_LG_GUARD");   // read per call: the tests switch it
-    return !(e && *e) || atoi(e) != 0;
+    return knob_int("PBN_LG_GUARD", 1) != 0;   // read per call: the tests switch it
 }
 } }
 
 static bool score_memo_on() {
-    static const bool v = [] { const char* e = getenv("PBN_SCORE_MEMO"); return !(e && *e) || atoi(e) != 0; }();
+    static const bool v = PBN_TUNE(SCORE_MEMO, 1) != 0;
     return v;
 }
 
@@ -499,7 +497,7 @@ static int scoredata_create_impl(pbn_ctx* ctx, const pbn_table* table, int split
         // (16 super-blocks up to 128 columns; wider tables fewer - a segment is n + n^2 doubles on every rank, 176 of them at 10 folds +
         //  hold-out: 350 MB per rank at n = 500 - down to 2 from 512 columns: the count is part of the summation order, so it is a
         //  function of n alone)
-        static const int SB_env = [] { const char* e = getenv("PBN_MOMENT_SUPERBLOCKS"); const int v = (e && *e) ? atoi(e) : 0; return v < 0 ? 0 : (v > 1024 ? 1024 : v); }();
+        static const int SB_env = std::min(1024, std::max(0, PBN_TUNE(MOMENT_SUPERBLOCKS, 0)));
         const int SB = SB_env > 0 ? SB_env : (sd->n <= 128 ? 16 : (sd->n <= 256 ? 8 : (sd->n <= 512 ? 4 : 2)));
         auto add_region = [&](int region, int64_t r0, int64_t len) {
             int64_t prev = 0;
@@ -766,7 +764,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
         // candidate (~150 B a node): a long search over hybrid candidates would take gigabytes.  Both are pure accelerators -
         // beyond PBN_SCORE_CACHE_ENTRIES entries (default 2^21, ~300 MB) they start over, at a batch boundary (no entry of
         // the batch being assembled is lost).
-        static const size_t cache_budget = [] { const char* e = getenv("PBN_SCORE_CACHE_ENTRIES"); const long long v = (e && *e) ? atoll(e) : (1ll << 21); return (size_t)(v < 1 ? 1 : v); }();
+        static const size_t cache_budget = (size_t)std::max(1ll, knob_ll("PBN_SCORE_CACHE_ENTRIES", 1ll << 21));
         if (sd->kde_cache.size() > cache_budget) { sd->kde_cache.clear(); ++sd->cache_resets; }
         // (term_total is trimmed in pbn_score_terms_put only: every rank of a job reaches that call with the same state, whereas a rank
         //  whose dealt list is empty skips the evaluation call - trimming here would let the ranks' "missing" lists drift apart)
@@ -784,7 +782,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
         struct Pending { int cand; int unit0; int units; };
         std::vector<Pending> pending;
         // hybrid CKDE candidates of this call go into one HybridBatch (hybrid.hip): enqueued as they come, finished together after the loop
-        const bool hybrid_batched = [] { const char* e = getenv("PBN_HYBRID_BATCH"); return !(e && *e) || atoi(e) != 0; }();   // (per call: the tests switch it)
+        const bool hybrid_batched = knob_int("PBN_HYBRID_BATCH", 1) != 0;   // (per call: the tests switch it)
         std::unique_ptr<HybridBatch, void (*)(HybridBatch*) noexcept> hbatch(nullptr, hybrid_batch_end);
         auto hybrid_batch = [&]() -> HybridBatch* {
             if (!hybrid_batched) return nullptr;
@@ -957,14 +955,13 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 return true;
             };
             std::vector<Unit> units_v;
-            struct Work { int cand, f, mode, slot_j, slot_m; };          // mode 0 fused, 1 joint only, 2 marginal only
+            struct Work { int cand, f, mode, slot_j, slot_m; };          // mode 1 joint term, 2 marginal term
             std::vector<Work> work;
             const bool cv = kind == PBN_SCORE_CVLIK;
-            // Neither term known: two plain sweeps (joint, marginal), each pruned on its own box.  The fused joint+marginal
-            // sweep costs exactly two sweeps' worth of exponentials anyway (they, not the MFMAs, are the cost) and under tile
-            // pruning it can only prune on the marginal box (C3: 16-21 ms fused against 2 x 7 ms plain per fold), so the
-            // engine no longer uses it; PBN_SCORE_FUSED=1 brings it back for comparison.
-            static const bool fused = [] { const char* e = getenv("PBN_SCORE_FUSED"); return e && *e && atoi(e) != 0; }();
+            // Neither term known: two plain sweeps (joint, marginal), each pruned on its own box.  (The fused joint + marginal sweep costs
+            // exactly two sweeps' worth of exponentials anyway - they, not the MFMAs, are the cost - and under tile pruning it can only
+            // prune on the marginal box: C3 16-21 ms fused against 2 x 7 ms plain per fold.  The engine dropped it in round 2; the
+            // stand-alone CKDE handles keep the fused kernel.)
             for (const Pending& pd : pending) {
                 const int c = pd.cand;
                 const int p = par_off[c + 1] - par_off[c], d = p + 1;
@@ -984,10 +981,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                         km = key_of(region, d + 1, cols.data(), d);
                         have_m = lookup_total(d + 1, cols.data(), d, f, u.marg) || lookup(km, u.marg);
                     } else if (u.has_marg) { km = key_of(region, d, cols.data() + 1, p); have_m = lookup_total(d, cols.data() + 1, p, f, u.marg) || lookup(km, u.marg); }
-                    if (!have_j && !have_m && fused) {
-                        u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
-                        work.push_back({c, f, 0, u.joint.slot, u.marg.slot});
-                    } else if (!have_j && !have_m) {
+                    if (!have_j && !have_m) {
                         u.joint.slot = new_slot(kj); u.marg.slot = new_slot(km);
                         work.push_back({c, f, 1, u.joint.slot, -1});
                         work.push_back({c, f, 2, -1, u.marg.slot});
@@ -1006,7 +1000,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             // kernels report it): an evaluation that kde_wants_widening() flags is redone on fp64 fragments (KdeModel::widen) before its
             // value is used.  The choice is a function of that evaluation alone - nothing is remembered per variable set, so the double
             // a (term, region) gets does not depend on what this process evaluated before or on how a job dealt its terms
-            static const bool check_after = [] { const char* e = getenv("PBN_F32_CHECK"); return !(e && *e) || atoi(e) != 0; }();   // 0: measurement only
+            static const bool check_after = PBN_TUNE(F32_CHECK, 1) != 0;   // 0: measurement only
             const bool f32 = sd->dtype == PBN_F32 && check_after;
             ctx->scratch_sums.reserve(std::max<size_t>(1, 2 * nslots));   // (grow-only: no hipMalloc / hipFree per batch)
             struct { double* p; } dsums{ctx->scratch_sums.p};
@@ -1036,7 +1030,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 // depend on which candidate asked for it first, and a job that evaluates the terms on other ranks (pbn_score_terms)
                 // computes the very same doubles.  (H = k(N, d) cov: the bandwidth of a subset is the sub-block of the set's.)
                 const int var0 = cols[0];
-                if (w.mode != 0) std::sort(cols.begin(), cols.end());
+                std::sort(cols.begin(), cols.end());
                 subset_moments(sd, *tr, cols.data(), d, mu.data(), sse.data());
                 const double inv = 1.0 / (double)(tr->N - 1);
                 for (auto& x : sse) x *= inv;  // covariance
@@ -1069,7 +1063,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     }
                     kde_prepare(pr.m, sd->dtype, p, tr->N, Hm.data(), PBN_BW_FULL, false, mum.data());
                 } else {
-                    kde_prepare(pr.m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, w.mode == 0, mu.data());
+                    kde_prepare(pr.m, sd->dtype, d, tr->N, H.data(), PBN_BW_FULL, false, mu.data());
                     pr.use = cols;
                 }
             };
@@ -1082,7 +1076,6 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             const int64_t min_train = cv ? sd->n_cv - (sd->limits[1] - sd->limits[0]) : sd->n_cv;
             for (size_t wi = 0; wi < work.size(); ++wi) {
                 const Work& w = work[wi];
-                if (w.mode == 0) continue;
                 const int p = par_off[w.cand + 1] - par_off[w.cand];
                 const bool own_term = w.mode == 2 && want && want[w.cand] == 3;   // marginal term over all p + 1 columns, rule for p + 2
                 const int dims = own_term ? p + 1 : (w.mode == 2 ? p : p + 1);
@@ -1151,7 +1144,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
             if (!bt[0].gb.pools.empty()) kde_group_run(ctx, t, bt[0].gb, dsums.p, dmax, false);
             // one evaluation through its own launch chain (shapes the grouped path does not take; the redo of a flagged evaluation)
-            auto run_single = [&](const Work& w, bool force64) {
+            auto run_single = [&](const Work& w, bool force64, bool precise = false) {
                 Prep pr;
                 prepare(w, pr);
                 KdeModel& m = pr.m;
@@ -1165,10 +1158,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 m.nxpack = base + align(pb.apack);
                 m.Axpack = m.cond ? base + align(pb.apack) + align(pb.nxpack) : nullptr;
                 kde_pack_train(ctx, m, t, use_cols, pr.row0, pr.n0, pr.row1, nullptr, /*prune=*/true, dmax ? dmax + slot : nullptr);
-                if (w.mode == 0 && m.cond)
-                    kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + w.slot_j, nullptr, dsums.p + w.slot_m);
-                else
-                    kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + slot);
+                kde_eval_enqueue(ctx, m, t, use_cols, pr.te0, pr.te_n, nullptr, dsums.p + slot, nullptr, nullptr, precise);
             };
             size_t wi = 0, li = 0;
             for (const Work& w : work) {
@@ -1194,12 +1184,32 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                         prepare(*w, pr);
                         const int slot = w->mode == 2 ? w->slot_m : w->slot_j;
                         HIP_CHECK(hipMemsetAsync(dsums.p + slot, 0, sizeof(double), ctx->stream));
-                        if (w->mode == 0) HIP_CHECK(hipMemsetAsync(dsums.p + w->slot_m, 0, sizeof(double), ctx->stream));
                         run_single(*w, true);
                     }
                     HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                     HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     sd->kde_sweeps += (int64_t)redo.size();
+                }
+            }
+            if (sd->dtype == PBN_F64 && nslots) {
+                // fp64 tables: a term whose sum over its test rows is a cancellation to ~0 (kde_sum_needs_precision: the sum-only sweeps'
+                // absolute error budget would exceed 5e-7 of it) is evaluated once more at the accuracy of the per-row path
+                std::vector<const Work*> redo;
+                for (const Work& w : work) {
+                    const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
+                    const int64_t nq = cv ? sd->limits[w.f + 1] - sd->limits[w.f] : sd->n_hold;
+                    if (kde_sum_needs_precision(hs[(size_t)slot], nq)) redo.push_back(&w);
+                }
+                if (!redo.empty()) {
+                    for (const Work* w : redo) {
+                        const int slot = w->mode == 2 ? w->slot_m : w->slot_j;
+                        HIP_CHECK(hipMemsetAsync(dsums.p + slot, 0, sizeof(double), ctx->stream));
+                        run_single(*w, false, /*precise=*/true);
+                    }
+                    HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    sd->kde_sweeps += (int64_t)redo.size();
+                    sd->precise_redos += (int64_t)redo.size();
                 }
             }
             ctx->drop_staged();
@@ -1323,7 +1333,7 @@ int pbn_score_terms_put(pbn_scoredata* sd, int kind, int n_terms, const int* off
     return guarded(mu_of(sd), [&] {
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_put");
         if (n_terms > 0 && !values) throw invalid_error("pbn_score_terms_put: null values");
-        static const size_t budget = [] { const char* e = getenv("PBN_SCORE_CACHE_ENTRIES"); const long long v = (e && *e) ? atoll(e) : (1ll << 21); return (size_t)(v < 1 ? 1 : v); }();
+        static const size_t budget = (size_t)std::max(1ll, knob_ll("PBN_SCORE_CACHE_ENTRIES", 1ll << 21));
         if (sd->term_total.size() > budget) { sd->term_total.clear(); ++sd->cache_resets; }   // before the new terms go in: the batch being assembled keeps its own
         for (int i = 0; i < n_terms; ++i) sd->term_total[term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])] = values[i];
     });

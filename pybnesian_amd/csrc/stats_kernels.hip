@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256) void gram_seg_reduce_kernel(const double* __re
 // PBN_GRAM_LDS: 0 = gram_kernel (rows in registers), 1 = gram_lds_kernel, 2 (default) = the LDS-DMA ring kernels where they apply
 // (contiguous rows: gram_glds_kernel for double tables, gram_glds_f32_kernel for float ones) and gram_lds_kernel elsewhere.
 static int gram_variant() {
-    static const int v = [] { const char* e = getenv("PBN_GRAM_LDS"); return (e && *e) ? atoi(e) : 2; }();
+    static const int v = PBN_TUNE(GRAM_LDS, 2);
     return v;
 }
 
@@ -1195,7 +1195,7 @@ void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipS
     GramArgs a = a_in;
     // PBN_GRAM_DEBUG (1 = no MFMAs, 2 = no loads: floors of the two halves, garbage statistics) exists in measurement builds only
     // (-DPBN_GRAM_MEASURE, tools/gram_variants.sh); the production library refuses it instead of silently returning garbage
-    static const int dbg = [] { const char* e = getenv("PBN_GRAM_DEBUG"); return (e && *e) ? atoi(e) : 0; }();
+    static const int dbg = PBN_TUNE(GRAM_DEBUG, 0);
 #ifdef PBN_GRAM_MEASURE
     a.debug_skip = dbg;
 #else
@@ -1203,7 +1203,7 @@ void launch_gram(const GramArgs& a_in, int dtype, int nblocks, double* out, hipS
     a.debug_skip = 0;
 #endif
     // PBN_GRAM_STAMPS=1: gram_glds_kernel's blocks record their start / end (10 ns ticks) and hardware slot; printed to stderr
-    static const bool want_stamps = [] { const char* e = getenv("PBN_GRAM_STAMPS"); return e && *e && atoi(e) != 0; }();
+    static const bool want_stamps = PBN_TUNE(GRAM_STAMPS, 0) != 0;
     static long long* stamps_dev = nullptr;
     if (want_stamps && !stamps_dev) HIP_CHECK(hipMalloc(&stamps_dev, 4096 * 3 * sizeof(long long)));
     a.stamps = want_stamps && nblocks <= 4096 ? stamps_dev : nullptr;

@@ -233,10 +233,6 @@ class MutualInformation(IndependenceTest):
 
     def _ci_batch_callback(self):
         """Batched native callback (same handle / index order as _ci_callback): independent tests share a launch."""
-        import os
-
-        if os.environ.get("PBN_MI_BATCH", "1") == "0":
-            return None
         return C.cast(_lib.load().pbn_mi_pvalue_batch, C.c_void_p)
 
     def __del__(self):

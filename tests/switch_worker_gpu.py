@@ -56,8 +56,7 @@ g = pd.DataFrame(rng.normal(size=(30001, 20)) @ (np.eye(20) + 0.2 * np.tril(rng.
 bic = pbn.BIC(g)
 gbn = pbn.GaussianNetwork(list(g.columns))
 out["bic"] = [bic.local_score(gbn, "x7", ["x1", "x19", "x4"]), bic.local_score(gbn, "x0", []), bic.local_score(gbn, "x12", ["x3"])]
-# (4) likelihood scores of hybrid candidates (CKDE and LinearGaussian children of discrete parents, a discrete child): the per-grouping
-#     moments (PBN_HYBRID_FULLMOMENTS), the fused slice sweep (PBN_HYBRID_FUSED) and the segmented per-candidate moments they replace
+# (4) likelihood scores of hybrid candidates (CKDE and LinearGaussian children of discrete parents, a discrete child)
 for dtype in ("float64", "float32"):
     hdf = hybrid_table(40000, 13, dtype)
     hs = pbn.CVLikelihood(hdf, 4, 1)

@@ -89,6 +89,38 @@ def test_fp32_hybrid_validated_scores(pbn, oracle, node_type, prune_rows, monkey
         assert close(got_v, want_v, RTOL_F32), (var, dpar, cpar, got_v, want_v)
 
 
+def test_fp32_hybrid_scores_vs_the_float_arithmetic_of_the_reference(pbn, oracle):
+    """The same fp32 scores against the oracle in the reference's OWN float arithmetic (cov, bandwidth rule input, distances, logsumexp
+    and logl in float: NormalReferenceRule.hpp:124-133, KDE.hpp:466-470, KDE.cl.src with float) at the reference tests' own fp32
+    tolerance - atol 5e-4 per logl (tests/factors/continuous/KDE_test.py:181-182), i.e. 5e-4 x the rows a score sums over - and, beside
+    it, against fp64 arithmetic on the same float values (the truth for those values): the device sits between the two."""
+    n = 6000
+    df, codes, cards = make_c5(n, seed=3)
+    net = spbn(pbn, df)
+    vl = pbn.ValidatedLikelihood(df, 0.2, 3, 4)
+    tr, te = oracle.holdout_split(n, 0.2, 4)
+    worst32 = worst64 = 0.0
+    for var, dpar, cpar in CASES:
+        cont = df[[var] + cpar].to_numpy()
+        assert cont.dtype == np.float32
+        dc, dk = [codes[d] for d in dpar], [cards[d] for d in dpar]
+        got_v = vl.vlocal_score_node_type(net, pbn.CKDEType(), var, cpar + dpar)
+        got_l = vl.local_score_node_type(net, pbn.CKDEType(), var, dpar + cpar)
+        for arith in ("float32", "float64"):
+            fn = lambda a, b: oracle.adaptator_fit_slogl(cont, dc, dk, a, b, "ckde", arithmetic=arith)
+            want_v = fn(tr, te)
+            want_l = sum(fn(tr[a], tr[b]) for a, b in oracle.cv_folds(tr.size, 3, 4))
+            per_v, per_l = abs(got_v - want_v) / te.size, abs(got_l - want_l) / tr.size
+            assert per_v <= 5e-4 and per_l <= 5e-4, (var, dpar, cpar, arith, per_v, per_l)
+            if arith == "float32":
+                worst32 = max(worst32, per_v, per_l)
+            else:
+                worst64 = max(worst64, per_v, per_l)
+    # fp64 arithmetic on the float values is what the device's bf16x3 / fp32-accumulated sweeps approximate: closer to it than the
+    # reference's float arithmetic is
+    assert worst64 <= 5e-5, (worst32, worst64)
+
+
 def test_fp32_hybrid_large_slices_pruned(pbn, oracle):
     """Slices of >= 32 768 training rows: the default pruned bf16x3 path of C5's per-configuration sweeps (hold-out
     likelihood: 96 000 training rows over 2 configurations, 24 000 test rows), and a no-discrete-parent CKDE whose 2-fold CV
@@ -260,7 +292,7 @@ def test_fp32_engine_redoes_far_out_sets_on_fp64_fragments(pbn, oracle, monkeypa
     assert abs(hyb - want_hyb) <= 2e-6 * abs(want_hyb), (hyb, want_hyb)
     want_again = oracle.cv_likelihood(data64[:, ::-1].copy(), "ckde", 3, 2)
     assert abs(again - want_again) <= 2e-6 * abs(want_again)
-    monkeypatch.setenv("PBN_F32_WIDEN", "0")
+    monkeypatch.setenv("PBN_F32_WIDEN_AT", "inf")
     plain32, hyb32, _, sweeps32 = run()
     assert sweeps > sweeps32                                   # the flagged evaluations were made twice
     assert abs(plain32 - want_plain) > 5 * abs(plain - want_plain) and abs(hyb32 - want_hyb) > 5 * abs(hyb - want_hyb)

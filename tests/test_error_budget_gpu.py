@@ -63,6 +63,8 @@ def test_few_dominant_terms_with_clustered_fractions(n_train, near_zero, capsys)
     worst, worst_abs, worst_at = 0.0, 0.0, None
     for two in (False, True):
         d = 2 if two else 1
+        if n_train <= d:
+            continue                                  # (a covariance needs more rows than columns: the two-cluster form starts at 17 rows)
         for frac in np.linspace(0.0, 0.99, 96):
             h = 1.0
             if near_zero:

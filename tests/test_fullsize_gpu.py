@@ -318,3 +318,7 @@ def test_c5_fullsize_properties(env, monkeypatch):
         want = oracle.adaptator_fit_slogl(cont, [disc[d_] for d_ in dpar], [int(cards[int(d_[1:])]) for d_ in dpar], tr, te, "ckde")
         got = small.local_score_node_type(start, pbn.CKDEType(), var, cpar + dpar)
         assert abs(got - want) <= 1e-3 * abs(want), (var, dpar, cpar, got, want)
+        # ... and against the reference's OWN float arithmetic on these slices (covariance, distances, logsumexp, logl in float:
+        # NormalReferenceRule.hpp:124-133, KDE.hpp:466-470) at the reference tests' fp32 tolerance, atol 5e-4 per logl (KDE_test.py:181-182)
+        want32 = oracle.adaptator_fit_slogl(cont, [disc[d_] for d_ in dpar], [int(cards[int(d_[1:])]) for d_ in dpar], tr, te, "ckde", arithmetic="float32")
+        assert abs(got - want32) <= 5e-4 * te.size, (var, dpar, cpar, got, want32, want)

@@ -593,7 +593,7 @@ def test_fp32_tables_with_tiny_bandwidths_take_fp64_fragments(pbn, monkeypatch):
     1e-5.  Such models are packed into fp64 fragments and swept by the fp64 kernels (KdeModel::widen, decided at fit time from the
     farthest whitened training row).  Checked against the oracle in fp64 arithmetic on the same float data at the reference
     tests' fp32 tolerance (atol 5e-4 per logl, KDE_test.py:181-182), with the oracle's own fp32 arithmetic beside it; the switch
-    PBN_F32_WIDEN=0 shows what the fp32 fragments would have given."""
+    PBN_F32_WIDEN_AT=inf shows what the fp32 fragments would have given."""
     from oracle import oracle
 
     rng = np.random.default_rng(77)
@@ -631,18 +631,18 @@ def test_fp32_tables_with_tiny_bandwidths_take_fp64_fragments(pbn, monkeypatch):
         assert err <= 5e-4, (type(k).__name__, err)
         assert abs(k.slogl(test) - truth[fin].sum()) <= 1e-6 * abs(truth[fin].sum()) or not fin.all()
     # the same models on fp32 fragments: the error this routing removes (otherwise the test above proves nothing)
-    monkeypatch.setenv("PBN_F32_WIDEN", "0")
+    monkeypatch.setenv("PBN_F32_WIDEN_AT", "inf")
     worst_f32 = 0.0
     for k, fn in models():
         truth = fn(tr64, np.asarray(k.bandwidth, dtype=np.float64), te64)
         fin = np.isfinite(truth)
         worst_f32 = max(worst_f32, np.abs(k.logl(test)[fin] - truth[fin]).max())
     assert worst_f32 > 10 * max(worst_widened, 1e-6), (worst_f32, worst_widened)
-    monkeypatch.delenv("PBN_F32_WIDEN")
+    monkeypatch.delenv("PBN_F32_WIDEN_AT")
     # ordinary fp32 tables stay on the fp32 (bf16x3) path: same numbers with the test switched off
     g = pd.DataFrame(rng.normal(size=(20_000, 3)).astype(np.float32), columns=names)
     q = pd.DataFrame(rng.normal(size=(300, 3)).astype(np.float32), columns=names)
     k1 = pbn.KDE(names); k1.fit(g); l1 = k1.logl(q)
-    monkeypatch.setenv("PBN_F32_WIDEN", "0")
+    monkeypatch.setenv("PBN_F32_WIDEN_AT", "inf")
     k2 = pbn.KDE(names); k2.fit(g)
     assert np.array_equal(l1, k2.logl(q))

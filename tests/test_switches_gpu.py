@@ -1,18 +1,13 @@
-"""GPU tier: the run-time switches that select between implementations of the same quantity must not change it.  Each
-configuration runs tests/switch_worker_gpu.py in its own process (the switches are read once per process) and the outputs are
-compared with the default run:
+"""GPU tier: the run-time switches that select between implementations or partitions of the same quantity must not change it.
+Round 5 cut the switchboard to the documented knobs (tuning constants and the alternative paths of past experiments are
+compiled to their defaults unless the library is built with `make EXPERIMENTS=1`) - what is left to hold is:
  * PBN_SCORE_LANES=1 (one issue lane) - the sums do not depend on the issue order: identical to the last bit;
- * PBN_SWEEP_QLB=0 (offsets from the split's first tile instead of the prepass bounds) and PBN_SWEEP_PRUNE=0 (no tile
-   pruning) - other offsets / other partitions of the same sums: equal to rounding, the fp32 sweeps to their own precision;
- * PBN_SCORE_GROUPED=0 (one launch chain per (set, fold) as in round 2 instead of the grouped evaluation of kde_group.hip),
-   PBN_PRUNE_GROUP_MASKS=0 (one visit mask per wave instead of one per 16-query group), PBN_GROUP_SUM_BOUND=0 (pruning
-   threshold on the largest known term instead of the known part of the sum), PBN_GROUP_SPLIT_TILES / PBN_GROUP_MAX_POOLS
-   (other partitions of the same work);
- * PBN_MI_FULLGRAM=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_FULL_BUDGET_MB=0 (their cache
-   budget exhausted: the same fallback), PBN_MI_THREADS=1;
- * PBN_GRAM_LDS=1 / 0 (the older Gram kernels), PBN_MI_GRAM_ORDER=0 / 1 (launch order of a grouping's Gram pieces);
- * PBN_HYBRID_FULLMOMENTS=0, PBN_HYBRID_FUSED=1, PBN_HYBRID_SEGMENTED=0, PBN_SCORE_MEMO=0 (hybrid candidates); PBN_HYBRID_BATCH=0
-   (the hybrid candidates of a batch one by one instead of in one chain)."""
+ * PBN_SWEEP_PRUNE=0 (no tile pruning), PBN_SCORE_GROUPED=0 (one launch chain per (set, fold) instead of the grouped evaluation of
+   kde_group.hip), PBN_GROUP_SPLIT_TILES (another partition of the same work), PBN_FAR_SPAN=0 (no fp32 tail for far tiles) - other
+   partitions / paths of the same sums: equal to rounding, the fp32 sweeps to their own precision;
+ * PBN_MI_FULL_BUDGET_MB=0 (per-test moment kernels instead of the per-grouping moments), PBN_MI_THREADS=1;
+ * PBN_HYBRID_BATCH=0 (the hybrid candidates of a batch one by one instead of in one chain), PBN_HYBRID_BATCH_SLOTS, PBN_GROUP_ARENA_MB,
+   PBN_HYBRID_GROUPINGS (batches cut by their slots, their arena, a reset of the grouping cache): bit-identical."""
 import json
 import os
 import subprocess
@@ -59,8 +54,7 @@ def test_one_issue_lane_is_bit_identical(default):
     assert got == default
 
 
-@pytest.mark.parametrize("env", [{"PBN_SWEEP_QLB": "0"}, {"PBN_SWEEP_PRUNE": "0"}, {"PBN_SCORE_GROUPED": "0"}, {"PBN_PRUNE_GROUP_MASKS": "0"},
-                                 {"PBN_GROUP_SUM_BOUND": "0"}, {"PBN_GROUP_SPLIT_TILES": "64"}, {"PBN_GROUP_MAX_POOLS": "1"}])
+@pytest.mark.parametrize("env", [{"PBN_SWEEP_PRUNE": "0"}, {"PBN_SCORE_GROUPED": "0"}, {"PBN_GROUP_SPLIT_TILES": "64"}])
 def test_sweep_switches(default, env):
     got = run(env)
     assert close(got["cv_ckde_float64"], default["cv_ckde_float64"], 1e-10)
@@ -79,28 +73,20 @@ def test_default_margins_stay_inside_their_bound(default):
     assert got["hc_arcs_float64"] == default["hc_arcs_float64"] and got["hc_arcs_float32"] == default["hc_arcs_float32"]
 
 
-@pytest.mark.parametrize("env", [{"PBN_MI_FULLGRAM": "0"}, {"PBN_MI_THREADS": "1"}, {"PBN_MI_FULL_BUDGET_MB": "0"}])
+def test_far_tiles_through_the_fp32_unit_stay_inside_their_bound(default):
+    """PBN_FAR_SPAN=0: every visited tile through the full 2^f path instead of the fp32 tail for tiles 26+ bits below the sum bound
+    (at most 8e-8 of a sum): same searches, scores within that bound."""
+    got = run({"PBN_FAR_SPAN": "0"})
+    assert close(got["cv_ckde_float64"], default["cv_ckde_float64"], 1e-7)
+    assert close(got["hybrid_float64"], default["hybrid_float64"], 1e-7)
+    assert got["hc_arcs_float64"] == default["hc_arcs_float64"]
+
+
+@pytest.mark.parametrize("env", [{"PBN_MI_THREADS": "1"}, {"PBN_MI_FULL_BUDGET_MB": "0"}])
 def test_mi_switches(default, env):
     got = run(env)
     for key in ("mi_plain", "mi_nulls"):
         assert close(got[key], default[key], 1e-9), key
-
-
-@pytest.mark.parametrize("env", [{"PBN_HYBRID_FULLMOMENTS": "0"}, {"PBN_HYBRID_FUSED": "1"}, {"PBN_HYBRID_SEGMENTED": "0"}, {"PBN_SCORE_MEMO": "0"},
-                                 {"PBN_HYBRID_FULLMOMENTS": "0", "PBN_HYBRID_SEGMENTED": "0"},
-                                 {"PBN_HYBRID_FULLMOMENTS": "0", "PBN_HYBRID_SEGMENTED": "0", "PBN_HYBRID_CELLWISE_GRAM": "1"}])
-def test_hybrid_score_switches(default, env):
-    """Hybrid candidates: moments from the per-grouping Gram or from per-candidate launches (the register kernel for up to 8 columns;
-    without it - as for wider candidates - the candidate's columns through one segmented MFMA Gram for all cells, or one launch per cell
-    as in round 3), slices fused or split, with and without the local-score memo - the same scores to rounding (the fp32 tables to
-    their own precision)."""
-    got = run(env)
-    # (PBN_HYBRID_FUSED=1 evaluates a slice by the fused joint + marginal kernel - fp64 polynomial - instead of two plain sum-only
-    #  sweeps - 2^f on the fp32 transcendental unit: 1e-8, both far inside the 1e-6 bar)
-    assert close(got["hybrid_float64"], default["hybrid_float64"], 1e-8 if env == {"PBN_HYBRID_FUSED": "1"} else 1e-10)
-    assert close(got["hybrid_float32"], default["hybrid_float32"], 1e-4)
-    if env == {"PBN_SCORE_MEMO": "0"}:
-        assert got["hybrid_float64"] == default["hybrid_float64"]      # the memo returns what a fresh evaluation gives
 
 
 def test_hybrid_candidates_batched_or_one_by_one_are_bit_identical(default):
@@ -126,18 +112,3 @@ def test_hybrid_batch_cut_by_its_slots_or_its_arena_is_bit_identical(default, en
         assert got[f"hybrid_batch_{dtype}"] == default[f"hybrid_batch_{dtype}"], dtype
         assert got[f"hybrid_{dtype}"] == default[f"hybrid_{dtype}"], dtype
         assert got[f"cv_ckde_{dtype}"] == default[f"cv_ckde_{dtype}"], dtype
-
-
-@pytest.mark.parametrize("order", ["0", "1"])
-def test_grouping_gram_launch_order_is_bit_identical(default, order):
-    """PBN_MI_GRAM_ORDER: the pieces of a grouping's Gram in configuration-major / stripe-major order instead of the XCD-aligned
-    stripe-major default - the partial slots and the order of every sum are the same, so are the bits."""
-    got = run({"PBN_MI_GRAM_ORDER": order})
-    assert got["mi_plain"] == default["mi_plain"] and got["mi_nulls"] == default["mi_nulls"]
-
-
-@pytest.mark.parametrize("variant", ["1", "0"])
-def test_gram_kernel_variants(default, variant):
-    got = run({"PBN_GRAM_LDS": variant})
-    assert close(got["bic"], default["bic"], 1e-11)
-    assert close(got["mi_plain"], default["mi_plain"], 1e-7)   # p-values of sums taken in another order: rounding times the statistic
