@@ -51,6 +51,7 @@ struct GDev {   // argument block of the block-wise kernels
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
+    int fine_keys;                 // 1-2 key dimensions: cells of sigma / 4096 (256) instead of sigma / 16 (group_keys_kernel)
     int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
 };
 
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(GB) void group_keys_kernel(GDev g) {
     // bits per axis: the same +-8 sigma in cells of sigma / 4096 (sigma / 256) - round 5: with sigma / 16 cells a cell of a 450 000-row fold held
     // ~280 rows (d = 2; ~11 000 at d = 1) in arbitrary order, i.e. a 16-row tile was 16 random rows of a box half a bandwidth wide
     // (tools/farfield_feasibility.py: median tile radius 0.34 bandwidths against 0.15 with fine cells)
-    const double scale = bits >= 12 ? (double)(1 << (bits - 4)) : (bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0));
+    const double scale = (bits >= 12 && g.fine_keys) ? (double)(1 << (bits - 4)) : (bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0));
     uint32_t key = 0;
     for (int i = 0; i < kd; ++i) {
         double u = 0.0;
@@ -414,37 +415,43 @@ __global__ __launch_bounds__(256) void group_prepass_kernel(GDev g) {
     // queries' offsets (qlb), which keeps them within log2(16 x 512 tiles) = 13 units of the threshold (the fp32 tail path of far tiles
     // needs less than 26).
     if (g.tile_window > 0 && g.use_sum_bound && pd == d) {
-        const int l16 = threadIdx.x & 15;
         const int tp0 = __shfl(valid ? ((const int32_t*)(g.arena + U.qpos))[q] : 0, 0, 16);   // position of the tile's first query
         const int full = U.N >> 4;                                                           // tiles whose 16 rows are all real
         const int tt = tp0 >> 4;
         const int t_lo = tt - g.tile_window > 0 ? tt - g.tile_window : 0, t_hi = tt + g.tile_window < full ? tt + g.tile_window : full;
         const double* boxes = (const double*)(g.arena + U.box);
-        double bmax = -INFINITY, bacc = 0.0;
-        const bool boxok = lob[0] <= hib[0];   // the tile holds a valid query
-        if (boxok)
-            for (int t = t_lo + l16; t < t_hi; t += 16) {
-                const double* bx = boxes + (int64_t)t * 2 * pd;
-                double d2 = 0.0;
-                for (int k = 0; k < pd; ++k) {
-                    const double a1 = bx[pd + k] - lob[k], a2 = hib[k] - bx[k];
-                    const double a = a1 > a2 ? a1 : a2;
-                    d2 = __builtin_fma(a, a, d2);
+        {
+            // (Round 5, measured and dropped: the box bound per QUERY - point-to-box distances, the group's threshold the smallest of its
+            //  queries' bounds - is 1.5 bits tighter on C3's folds and 2-3 on cv64's (tools/sum_bound_slack.py), and the sweeps get 1-3 %
+            //  faster; but every lane then walks the 512 boxes of the window itself, a latency-bound loop: cv64 2.36 -> 2.48 s, C3's first
+            //  iteration 10.26 -> 10.38 s, C5 7.31 -> 7.78 s, profiles/r5/query_bounds_probe.txt.)
+            const int l16 = threadIdx.x & 15;
+            double bmax = -INFINITY, bacc = 0.0;
+            const bool boxok = lob[0] <= hib[0];   // the tile holds a valid query
+            if (boxok)
+                for (int t = t_lo + l16; t < t_hi; t += 16) {
+                    const double* bx = boxes + (int64_t)t * 2 * pd;
+                    double d2 = 0.0;
+                    for (int k = 0; k < pd; ++k) {
+                        const double a1 = bx[pd + k] - lob[k], a2 = hib[k] - bx[k];
+                        const double a = a1 > a2 ? a1 : a2;
+                        d2 = __builtin_fma(a, a, d2);
+                    }
+                    const double ex = -0.5 * d2;
+                    if (!(ex == ex)) continue;
+                    if (ex > bmax) { bacc = bacc * exp2(bmax - ex) + 1.0; bmax = ex; }
+                    else bacc += exp2(ex - bmax);
                 }
-                const double ex = -0.5 * d2;
-                if (!(ex == ex)) continue;
-                if (ex > bmax) { bacc = bacc * exp2(bmax - ex) + 1.0; bmax = ex; }
-                else bacc += exp2(ex - bmax);
+            for (int off = 1; off < 16; off <<= 1) {   // merge the 16 lanes' (max, sum) pairs
+                const double om = __shfl_xor(bmax, off), oa = __shfl_xor(bacc, off);
+                if (om > bmax) { bacc = bacc * exp2(bmax - om) + oa; bmax = om; }
+                else if (om > -INFINITY) bacc += oa * exp2(om - bmax);
             }
-        for (int off = 1; off < 16; off <<= 1) {   // merge the 16 lanes' (max, sum) pairs
-            const double om = __shfl_xor(bmax, off), oa = __shfl_xor(bacc, off);
-            if (om > bmax) { bacc = bacc * exp2(bmax - om) + oa; bmax = om; }
-            else if (om > -INFINITY) bacc += oa * exp2(om - bmax);
-        }
-        if (bacc > 0.0) {
-            const double tb = bmax + log2(bacc) + 4.0;   // 16 rows per tile
-            if (tb > thr && thr < INFINITY) thr = tb;
-            if (valid && bmax > best) best = bmax;       // a valid lower bound of this query's largest exponent, too
+            if (bacc > 0.0) {
+                const double tb = bmax + log2(bacc) + 4.0;   // 16 rows per tile
+                if (tb > thr && thr < INFINITY) thr = tb;
+                if (valid && bmax > best) best = bmax;       // a valid lower bound of this query's largest exponent, too
+            }
         }
     }
     if (q < U.nqtiles * 16) ((double*)(g.arena + U.qlb))[q] = valid ? best : -INFINITY;
@@ -640,6 +647,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.out_max = bf16 ? (unsigned long long*)dev_out_max : nullptr;
     static const int tile_window = std::max(0, PBN_TUNE(GROUP_TILE_WINDOW, 256));
     g.tile_window = tile_window;
+    static const int fine_keys = PBN_TUNE(GROUP_FINE_KEYS, 1);
+    g.fine_keys = fine_keys;
     static const int window = std::max(1, PBN_TUNE(GROUP_WINDOW, PBN_GROUP_WINDOW));
     g.window = window;
 

@@ -98,7 +98,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
 // 8e-8 (fp32 far tail) = 3.3e-7; measured with every rounding made one-sided (tests/test_error_budget_gpu.py): 3e-8.  Relative to a sum
 // of n log-densities that is harmless unless the sum is a cancellation to ~0 (a table whose density happens to sit near 1 in its units):
 // |sum| < 0.66 n is where the bound would exceed 5e-7 of the sum - such a sum is evaluated once more at full precision.
-inline bool kde_sum_needs_precision(double sum, int64_t n) { return n > 0 && std::fabs(sum) < 0.66 * (double)n; }
+inline bool kde_sum_needs_precision(double sum, int64_t n) { return n > 0 && std::fabs(sum) < PBN_TUNE_D(NEAR_ZERO_LOGL, 0.66) * (double)n; }
 
 // Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
 void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);
