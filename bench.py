@@ -334,8 +334,14 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         t0 = time.perf_counter()
         score = pbn.BGe(None, table=table)
         t_ctor = time.perf_counter() - t0
+        gram_first_ms, gram_n = ctx.kernel_time(_lib.PBN_K_GRAM)
+        # the same construction once more: the first launch of a kernel in a process also pays its code-object load and finds the clocks
+        # where the previous leg left them - the roofline below prices the second, `first_launch_us` keeps the first
+        ctx.set_profiling(2)
+        score2 = pbn.BGe(None, table=table)
         gram_ms, gram_n = ctx.kernel_time(_lib.PBN_K_GRAM)
         ctx.set_profiling(False)
+        del score2
         start, ops = pbn.GaussianNetwork(names), pbn.ArcOperatorSet()
         label = f"C4: 64-node GaussianNetwork, BGe, ArcOperatorSet, {n_rows} rows fp64"
         kw = {}
@@ -512,8 +518,9 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         rec, why = pmc_record("gram_glds_kernel", "gram_pmc.json", "stats_kernels.hip")
         roof = {"kernel": "gram_glds_kernel<4> (segmented form) + segment reduce", "bound": "hbm", "achieved": gbytes / gsec / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": gbytes / gsec / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": gbytes / gsec / 1e9 / 6290.0,
-                "algorithmic_bytes": gbytes, "launch_us": gsec * 1e6, "launches": gram_n,
-                "note": "HIP events around the constructor's Gram launch pair in this run; 6.29 TB/s = the best device-to-device copy measured on "
+                "algorithmic_bytes": gbytes, "launch_us": gsec * 1e6, "launches": gram_n, "first_launch_us": gram_first_ms * 1e3 / max(gram_n, 1),
+                "note": "HIP events around the score constructor's Gram launch pair in this run (the second construction; first_launch_us = the "
+                        "first, which `score_ctor_s` times); 6.29 TB/s = the best device-to-device copy measured on "
                         "this part (profiles/r2/gram_floors.txt); flops = rows x n^2 x 2 on v_mfma_f64_16x16x4_f64"}
         roof["mfma_tflops"] = float(n_rows) * n_cols * n_cols * 2.0 / gsec / 1e12
         roof["mfma_frac_of_fp64_peak"] = roof["mfma_tflops"] / FP64_PEAK_TFLOPS

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(GB) void group_keys_kernel(GDev g) {
     // bits per axis: the same +-8 sigma in cells of sigma / 4096 (sigma / 256) - round 5: with sigma / 16 cells a cell of a 450 000-row fold held
     // ~280 rows (d = 2; ~11 000 at d = 1) in arbitrary order, i.e. a 16-row tile was 16 random rows of a box half a bandwidth wide
     // (tools/farfield_feasibility.py: median tile radius 0.34 bandwidths against 0.15 with fine cells)
-    const double scale = (bits >= 12 && g.fine_keys) ? (double)(1 << (bits - 4)) : (bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0));
+    const double scale = (bits >= 12 && g.fine_keys) ? (double)(1 << (bits - 4)) : (bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0));   // (3 / 4 key dimensions: finer cells change nothing, the cells are smaller than the tiles already)
     uint32_t key = 0;
     for (int i = 0; i < kd; ++i) {
         double u = 0.0;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 // Tile pruning support (SweepArgs::prune): whitened coordinates + Morton keys of the logical rows, bounding boxes of the
 // sorted 16-row tiles, and per query tile a lower bound of its queries' largest exponents.
 // ------------------------------------------------------------------------------------------------
-#define PBN_PRUNE_CELL 2.0      // key cell edge in (base-2) whitened units; a term vanishes beyond ~11.3 of them
+// (key cells: prune_key_bits / prune_key_cell in kde_kernels.hpp)
 
 #define PBN_PRUNE_WINDOW 32     // training rows scanned on either side of a query's Morton position
 // terms below 2^-52 of their query's largest known term are dropped: at most N * 2^-52 of a sum (2.2e-10 at 10^6 rows), a
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void max_norm2_kernel(PackArgs a, unsigned lon
 // T = fragment type (the rounding the keys see), TS = element type of the table
 template <typename T, typename TS = T>
 __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int kd, double* __restrict__ zrow, uint32_t* __restrict__ keys,
-                                                         int32_t* __restrict__ iota) {
+                                                         int32_t* __restrict__ iota, double inv_cell) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= a.n) return;
     const int d = a.d;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
         if (i < kd) {
             const int bits = prune_key_bits(kd);
             const double half = (double)(1 << (bits - 1)), top = (double)((1 << bits) - 1);
-            double c = __builtin_floor(z * (1.0 / PBN_PRUNE_CELL)) + half;
+            double c = __builtin_floor(z * inv_cell) + half;
             c = c < 0.0 ? 0.0 : (c > top ? top : c);
             const uint32_t cell = (uint32_t)c;
             for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
@@ -2265,9 +2265,10 @@ static void launch_sweep_t(const SweepArgs& a, int KS, dim3 grid, hipStream_t st
 void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st) {
     if (a.n == 0) return;
     const dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
-    if (dtype == PBN_F64 && a.src_f32) hipLaunchKernelGGL((prune_keys_kernel<double, float>), grid, block, 0, st, a, zd, kd, zrow, keys, iota);
-    else if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
-    else hipLaunchKernelGGL(prune_keys_kernel<float>, grid, block, 0, st, a, zd, kd, zrow, keys, iota);
+    const double inv_cell = 1.0 / prune_key_cell(kd);
+    if (dtype == PBN_F64 && a.src_f32) hipLaunchKernelGGL((prune_keys_kernel<double, float>), grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell);
+    else if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell);
+    else hipLaunchKernelGGL(prune_keys_kernel<float>, grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell);
     HIP_CHECK(hipGetLastError());
 }
 void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st) {

@@ -14,7 +14,13 @@
 namespace pbn {
 
 // bits per dimension of a 32-bit Morton key over kd dimensions: 10 up to three, 8 for four, 6 for five
-__host__ __device__ inline int prune_key_bits(int kd) { return kd <= 3 ? 10 : 32 / kd; }
+// Morton keys of the stand-alone pruned sweeps: bits per key dimension and the edge of a key cell in (base-2) whitened units.  Round 5:
+// one or two key dimensions take 16 bits per axis in cells of 1/32 unit (the same +-1024 units of range as the 10 bits x 2.0 units before),
+// three and four dimensions cells of 0.5 (+-256 / +-64 units), five of 1.0 (1e6 x 1e5 handles d = 1 ... 5: 10.2 / 7.2 / 7.9 / 11.8 / 20.0 ->
+// 8.5 / 5.4 / 6.7 / 11.5 / 19.0 ms, profiles/r5/prune_visits.txt): with 2.0-unit cells (1.7 bandwidths) a cell of a 10^6-row set held hundreds of rows in
+// arbitrary order, and a 16-row tile was 16 random rows of it (the grouped evaluation had the same flaw: kde_group.hip group_keys_kernel)
+__host__ __device__ inline int prune_key_bits(int kd) { return kd <= 2 ? 16 : (kd == 3 ? 10 : 32 / kd); }
+inline double prune_key_cell(int kd) { return kd <= 2 ? 0.03125 : (kd <= 4 ? 0.5 : (kd == 5 ? 1.0 : 2.0)); }   // 4 / 5 dimensions: 8 / 6 bits, +-64 / +-32 units
 
 struct PackArgs {
     const void* base;     // device column-major table
