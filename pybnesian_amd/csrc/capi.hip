@@ -294,8 +294,9 @@ int pbn_table_sse(const pbn_table* t, const int* cols, int d, int64_t row0, int6
                 if (J != I) sel.insert(sel.end(), cols + j0, cols + j1);
                 const int dd = (int)sel.size(), ni = i1 - i0;
                 sse_block(t, sel.data(), dd, row0, n, mu2.data(), s2.data());
-                for (int a = 0; a < ni; ++a) means[i0 + a] = mu2[a];
                 if (J == I) {
+                    for (int a = 0; a < ni; ++a) means[i0 + a] = mu2[a];   // a block's means come from ONE launch, its own (the pilot shift of a column is
+                                                                          // a function of the column and the row range alone: every launch centres it alike)
                     for (int a = 0; a < ni; ++a)
                         for (int b = 0; b < ni; ++b) sse[(i0 + a) + (size_t)(i0 + b) * d] = s2[a + (size_t)b * dd];
                 } else {

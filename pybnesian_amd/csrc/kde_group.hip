@@ -51,6 +51,7 @@ struct GDev {   // argument block of the block-wise kernels
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
+    int hilbert;                   // two key dimensions: Hilbert order instead of Z-order (group_keys_kernel)
     int fine_keys;                 // 1-2 key dimensions: cells of sigma / 4096 (256) instead of sigma / 16 (group_keys_kernel)
     int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
 };
@@ -81,13 +82,30 @@ __global__ __launch_bounds__(GB) void group_keys_kernel(GDev g) {
     // (tools/farfield_feasibility.py: median tile radius 0.34 bandwidths against 0.15 with fine cells)
     const double scale = (bits >= 12 && g.fine_keys) ? (double)(1 << (bits - 4)) : (bits >= 8 ? 16.0 : (bits >= 6 ? 8.0 : 4.0));   // (3 / 4 key dimensions: finer cells change nothing, the cells are smaller than the tiles already)
     uint32_t key = 0;
+    uint32_t cells[PBN_PRUNE_PD];
     for (int i = 0; i < kd; ++i) {
         double u = 0.0;
         for (int j = 0; j <= i; ++j) u = __builtin_fma(P.Wg[i * d + j], xc[j], u);
         double c = __builtin_floor(u * scale) + half;
         c = c < 0.0 ? 0.0 : (c > top ? top : c);
-        const uint32_t cell = (uint32_t)c;
-        for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);
+        cells[i] = (uint32_t)c;
+    }
+    if (kd == 2 && g.hilbert) {
+        // two key dimensions: position along the HILBERT curve instead of the Z-order - consecutive rows stay neighbours across every
+        // quadrant boundary, where the Z-order jumps (a tile that straddles a jump has a box as large as the jump)
+        uint32_t x = cells[0], y = cells[1];
+        const uint32_t n1 = (1u << bits) - 1u;
+        for (uint32_t sq = 1u << (bits - 1); sq > 0; sq >>= 1) {
+            const uint32_t rx = (x & sq) ? 1u : 0u, ry = (y & sq) ? 1u : 0u;
+            key += sq * sq * ((3u * rx) ^ ry);
+            if (ry == 0) {
+                if (rx == 1) { x = n1 - x; y = n1 - y; }
+                const uint32_t tmp = x; x = y; y = tmp;
+            }
+        }
+    } else {
+        for (int i = 0; i < kd; ++i)
+            for (int b = 0; b < bits; ++b) key |= ((cells[i] >> b) & 1u) << (b * kd + i);
     }
     g.keys[P.elem0 + p] = key | ((uint32_t)P.local << MORTON_BITS);
     g.vals[P.elem0 + p] = (uint32_t)p;
@@ -649,6 +667,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.tile_window = tile_window;
     static const int fine_keys = PBN_TUNE(GROUP_FINE_KEYS, 1);
     g.fine_keys = fine_keys;
+    static const int hilbert = PBN_TUNE(GROUP_HILBERT, 1);
+    g.hilbert = hilbert;
     static const int window = std::max(1, PBN_TUNE(GROUP_WINDOW, PBN_GROUP_WINDOW));
     g.window = window;
 

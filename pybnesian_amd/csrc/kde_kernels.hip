@@ -386,6 +386,8 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
     double xc[PBN_MAX_D];
     for (int j = 0; j < d; ++j) xc[j] = (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
     uint32_t key = 0;
+    uint32_t cells[2] = {0, 0};
+    const int bits = prune_key_bits(kd);
     for (int i = 0; i < zd; ++i) {
         double z = 0.0;
         const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
@@ -393,12 +395,24 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
         z = (double)(T)z;   // the rounding the pack applies
         zrow[r * zd + i] = z;
         if (i < kd) {
-            const int bits = prune_key_bits(kd);
             const double half = (double)(1 << (bits - 1)), top = (double)((1 << bits) - 1);
             double c = __builtin_floor(z * inv_cell) + half;
             c = c < 0.0 ? 0.0 : (c > top ? top : c);
             const uint32_t cell = (uint32_t)c;
-            for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
+            if (kd == 2) cells[i] = cell;
+            else for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
+        }
+    }
+    if (kd == 2) {   // two key dimensions: position along the Hilbert curve (see kde_group.hip group_keys_kernel); 16 bits per axis
+        uint32_t x = cells[0], y = cells[1];
+        const uint32_t n1 = (1u << bits) - 1u;
+        for (uint32_t sq = 1u << (bits - 1); sq > 0; sq >>= 1) {
+            const uint32_t rx = (x & sq) ? 1u : 0u, ry = (y & sq) ? 1u : 0u;
+            key += sq * sq * ((3u * rx) ^ ry);
+            if (ry == 0) {
+                if (rx == 1) { x = n1 - x; y = n1 - y; }
+                const uint32_t tmp = x; x = y; y = tmp;
+            }
         }
     }
     keys[r] = key;
