@@ -12,6 +12,7 @@
 // sweep keep the 2^x error attached to the pair) and the prepass bound (position by counting instead of by key search).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -701,7 +702,20 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         static const int gmasks = PBN_TUNE(PRUNE_GROUP_MASKS, 1);
         sa.group_masks = gmasks;
         sa.far_span = (double)knob_int("PBN_FAR_SPAN", 17);   // fp64 FOLD shapes: far tiles through the fp32 unit (kde_sweep_body: FARP)
+        static const int log_chunks = PBN_TUNE(SWEEP_LOG, 0);   // experiments build: one line per grouped sweep launch (synchronises)
+        hipEvent_t le0 = nullptr, le1 = nullptr;
+        if (log_chunks) { HIP_CHECK(hipEventCreate(&le0)); HIP_CHECK(hipEventCreate(&le1)); HIP_CHECK(hipEventRecord(le0, st)); }
         launch_sweep_grouped(sa, fdt, KS, st);
+        if (log_chunks) {
+            HIP_CHECK(hipEventRecord(le1, st));
+            HIP_CHECK(hipEventSynchronize(le1));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, le0, le1));
+            int64_t pairs = 0;
+            for (const GUnit& U : units) pairs += (int64_t)U.N * U.nq;
+            std::fprintf(stderr, "pbn-group-sweep d=%d %s pools=%d units=%d pairs=%lld ms=%.3f\n", d0, bf16 ? "f32" : "f64", np, nu, (long long)pairs, ms);
+            (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
+        }
     }
     {
         KernelTimer kt(ctx, PBN_K_FINISH);

@@ -55,4 +55,7 @@ for case in range(n_cases):
     worst[dtype][1] = max(worst[dtype][1], r2)
     print(f"case {case:3d} {dtype} {kind:8s} n={n} k={k}: grouped vs per-unit {r1:.2e}, vs unpruned {r2:.2e}", flush=True)
 print("worst (grouped vs per-unit, grouped vs unpruned):", worst)
-assert worst["float64"][0] < 1e-9 and worst["float64"][1] < 1e-9 and worst["float32"][0] < 1e-4 and worst["float32"][1] < 1e-4, worst
+# what the three forms may differ by is the mass their own pruning drops: at most 1.1e-7 (+ 8e-8 fp32 tail) of a sum per form at the shipped
+# sum-only margin (fp32: 1.5e-5) - DESIGN.md section 4.  Measured: 5e-10 with the sigma/16 key cells of round 3, 2e-9 with the compact tiles of
+# round 5 (their boxes leave less slack, so more of the allowed mass is really dropped); with the margins pinned (52 / 40) the forms agree to 1e-11.
+assert worst["float64"][0] < 3e-7 and worst["float64"][1] < 3e-7 and worst["float32"][0] < 1e-4 and worst["float32"][1] < 1e-4, worst

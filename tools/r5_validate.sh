@@ -1,0 +1,10 @@
+# round 5: the randomised checks against the oracle on the final code (new tile composition: finer key cells, Hilbert order; sharding in shard.hip)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5_val
+python3 tools/fuzz_pruned.py > gpurun_out/r5_val/fuzz_pruned.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_pruned.txt
+python3 tools/fuzz_grouped.py > gpurun_out/r5_val/fuzz_grouped.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_grouped.txt
+python3 tools/fuzz_sharding.py > gpurun_out/r5_val/fuzz_sharding.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_sharding.txt
+python3 tools/fuzz_hc.py > gpurun_out/r5_val/fuzz_hc.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_hc.txt
+PBN_PRUNE_MIN_ROWS=256 python3 tools/fuzz_hc.py > gpurun_out/r5_val/fuzz_hc_pruned.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_hc_pruned.txt
+python3 tools/fuzz_mmhc.py > gpurun_out/r5_val/fuzz_mmhc.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_mmhc.txt
+python3 tools/group_check.py > gpurun_out/r5_val/group_check.txt 2>&1; tail -3 gpurun_out/r5_val/group_check.txt
