@@ -384,6 +384,120 @@ __global__ __launch_bounds__(256) void group_tile_box_kernel(GDev g) {
     }
 }
 
+// ---- boxes of the 64-tile batches the sweeps walk: batch k of split s = tiles [s * tps + 64 k, ...) of the unit: grid (batches, units) ------
+__global__ __launch_bounds__(64) void group_batch_box_kernel(GDev g) {
+    const GUnit& U = g.units[blockIdx.y];
+    const int nbps = (U.tps + 63) / 64;
+    if ((int)blockIdx.x >= U.nsplit * nbps) return;
+    const GPool& P = g.pools[U.pool];
+    const int pd = P.kd;
+    const int split = blockIdx.x / nbps, k = blockIdx.x - split * nbps;
+    const int t0 = split * U.tps, t1 = t0 + U.tps < U.ntiles ? t0 + U.tps : U.ntiles;
+    const int t = t0 + 64 * k + (int)threadIdx.x;
+    double lo[PBN_PRUNE_PD], hi[PBN_PRUNE_PD];
+#pragma unroll
+    for (int i = 0; i < PBN_PRUNE_PD; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+    if (t < t1) {
+        const double* bx = (const double*)(g.arena + U.box) + (int64_t)t * 2 * pd;
+#pragma unroll
+        for (int i = 0; i < PBN_PRUNE_PD; ++i)
+            if (i < pd) { lo[i] = bx[i]; hi[i] = bx[pd + i]; }
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < PBN_PRUNE_PD; ++i) {
+            const double l = __shfl_xor(lo[i], off), h = __shfl_xor(hi[i], off);
+            lo[i] = l < lo[i] ? l : lo[i];
+            hi[i] = h > hi[i] ? h : hi[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        double* bb = (double*)(g.arena + U.bbox) + (int64_t)blockIdx.x * 2 * pd;
+        for (int i = 0; i < pd; ++i) { bb[i] = lo[i]; bb[pd + i] = hi[i]; }
+    }
+}
+
+// ---- tile moments (round 5; units of one or two dimensions on fp64 fragments): per 16-row training tile its centroid c, the squared
+// radius rho^2 = max_t |z_t - c|^2 and the coefficients of the order-8 expansion of its contribution about c,
+//   sum_t 2^(-|u - delta_t|^2 / 2) = 2^(-|u|^2 / 2) sum_alpha C_alpha u^alpha,   C_alpha = a^|alpha| / alpha! sum_t 2^(-|delta_t|^2 / 2) delta_t^alpha,  a = ln 2,
+// in the order the Horner scheme of kde_moment_group_kernel reads them (kde_kernels.hpp: PBN_MOM_ORDER, pbn_mom_rec).  Padding rows of the
+// last tile carry no weight.  grid (blocks of 16 tiles, units), one lane per row --------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void group_tile_moments_kernel(GDev g) {
+    const GUnit& U = g.units[blockIdx.y];
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (blockIdx.x * 256 >= U.ntiles * 16 || U.mom == 0) return;
+    const GPool& P = g.pools[U.pool];
+    if (P.d != D) return;
+    constexpr int ORD = PBN_MOM_ORDER;
+    const int64_t mstride = ((int64_t)U.ntiles + 63) / 64 * 64;   // structure of arrays: value k of tile t at [k * mstride + t]
+    constexpr double A = 0.693147180559945309417232121458;
+    const bool valid = r < U.N;
+    double z[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) z[k] = valid ? ((const double*)(g.arena + U.zs))[(int64_t)r * D + k] : 0.0;
+    // centroid of the tile's real rows
+    double cnt = valid ? 1.0 : 0.0, c[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = z[k];
+    for (int off = 1; off < 16; off <<= 1) {
+        cnt += __shfl_xor(cnt, off);
+#pragma unroll
+        for (int k = 0; k < D; ++k) c[k] += __shfl_xor(c[k], off);
+    }
+    double dl[D], r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        c[k] = cnt > 0.0 ? c[k] / cnt : 0.0;
+        dl[k] = valid ? z[k] - c[k] : 0.0;
+        r2 = __builtin_fma(dl[k], dl[k], r2);
+    }
+    const double w = valid ? exp2(-0.5 * r2) : 0.0;
+    double rmax = r2;
+    for (int off = 1; off < 16; off <<= 1) { const double o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
+    // powers of the offsets, then every coefficient as a 16-lane sum
+    double px[ORD + 1], py[ORD + 1];
+    px[0] = 1.0; py[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= ORD; ++i) { px[i] = px[i - 1] * dl[0]; py[i] = D == 2 ? py[i - 1] * dl[D - 1] : 0.0; }
+    const int tile = r >> 4;
+    const bool writer = (threadIdx.x & 15) == 0 && tile < U.ntiles;
+    double* rec = (double*)(g.arena + U.mom) + tile;
+    if (writer) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) rec[k * mstride] = c[k];
+        ((float*)(g.arena + U.rad2))[tile] = (float)rmax * 1.000001f + 1e-30f;   // rounded up
+    }
+    double fact[ORD + 1];
+    fact[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= ORD; ++i) fact[i] = fact[i - 1] * (double)i;
+    double apow[ORD + 1];
+    apow[0] = 1.0;
+#pragma unroll
+    for (int i = 1; i <= ORD; ++i) apow[i] = apow[i - 1] * A;
+    int k = D;
+    if constexpr (D == 1) {
+#pragma unroll
+        for (int i = ORD; i >= 0; --i) {
+            double v = w * px[i];
+            for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+            if (writer) rec[k * mstride] = v * apow[i] / fact[i];
+            ++k;
+        }
+    } else {
+#pragma unroll
+        for (int j = ORD; j >= 0; --j)
+#pragma unroll
+            for (int i = ORD - j; i >= 0; --i) {
+                double v = w * px[i] * py[j];
+                for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+                if (writer) rec[k * mstride] = v * apow[i + j] / (fact[i] * fact[j]);
+                ++k;
+            }
+    }
+}
+
 // ---- per query: a lower bound of its largest exponent (and of its whole sum) from the training rows around its position in the
 // training order; per 16-query tile the smallest bound and the box: grid (blocks of 256 padded queries, units) -----------------
 __global__ __launch_bounds__(256) void group_prepass_kernel(GDev g) {
@@ -493,10 +607,10 @@ __global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
         const double* p = (const double*)(g.arena + U.part) + (int64_t)q * 2;
         const int64_t stride = (int64_t)U.nqtiles * 16 * 2;
         double m = p[0];
-        for (int sp = 1; sp < U.nsplit; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
+        for (int sp = 1; sp < U.nsplit_fin; ++sp) { const double m2 = p[sp * stride]; m = m > m2 ? m : m2; }
         double s = 0.0;
 #pragma unroll 4
-        for (int sp = 0; sp < U.nsplit; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
+        for (int sp = 0; sp < U.nsplit_fin; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
         val = U.lognorm + LN2 * (m + log2(s));
     }
     __shared__ double red[256];
@@ -539,6 +653,12 @@ int split_tiles_for(int ntiles) {
     return ntiles <= 16384 ? 512 : (ntiles <= 32768 ? 1024 : 2048);
 }
 
+// The moment pass pays from a density of training rows on: a 16-row tile must be small against the bandwidth for many of its (tile, group)
+// pairs to pass the criterion.  Measured on CV terms of one and two variables (tools/moment_visits.py, profiles/r5/moment_pass.txt): 32 000
+// training rows - 40 of 64 lanes busy, a third of the pairs left to the sweep, no gain (cv64's first iteration 2.3 -> 2.9 s); 150 000 (C3's
+// folds) - 9.1 -> 8.3 s; 450 000 - 56-62 lanes, 40 -> 24 ms per two-variable term, 21 -> 8 ms per one-variable term.
+int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 100000); }
+
 // one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
 void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out,
                double* dev_out_max, bool force_f64) {
@@ -574,8 +694,15 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     const int d0 = pools[0].d, KS = bf16 ? bf16x3_mfmas(d0) : (d0 + 3) / 4;
     const bool fold = d0 % 4 != 0;
     const size_t frag_b = bf16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
+    // Moment pass (round 5): units of one or two dimensions on fp64 fragments - every term here is a sum (EF32 sweeps) - whose training
+    // sets are dense enough for it to pay (moment_pass_rows; kde_group_run gives such sets chunks of their own).  PBN_MOMENT_PASS=0
+    // switches it off (the sweep then takes every pair, as until round 4).
+    bool dense = true;
+    for (const GUnit& U : units) dense = dense && U.N >= moment_pass_rows();
+    const bool moments = !bf16 && d0 <= 2 && dense && knob_int("PBN_MOMENT_PASS", 1) != 0 && PBN_TUNE(PRUNE_GROUP_MASKS, 1) != 0;
+    const bool bboxes = !bf16 && PBN_TUNE(GROUP_BATCH_BOXES, 1) != 0;   // fp64 sweeps with per-group masks: one uniform test per (batch, group) first
     int64_t total_wg = 0;
-    int max_ntiles = 0, max_nqtiles = 0, max_nq = 0;
+    int max_ntiles = 0, max_nqtiles = 0, max_nq = 0, max_nbatch = 1;
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return (int64_t)o; };
     // tables first
@@ -597,6 +724,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         max_ntiles = std::max(max_ntiles, U.ntiles);
         max_nqtiles = std::max(max_nqtiles, U.nqtiles);
         max_nq = std::max(max_nq, U.nq);
+        max_nbatch = std::max(max_nbatch, U.nsplit * ((U.tps + 63) / 64));
         U.apack = carve((size_t)U.ntiles * frag_b);
         U.npack = carve(bf16 ? 256 : (size_t)U.ntiles * 16 * 8 * 2);
         U.zs = carve((size_t)U.N * d * 8 + 8);
@@ -608,7 +736,11 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         U.qbox = carve((size_t)U.nqtiles * 2 * pd * 8);
         U.qthr = carve((size_t)U.nqtiles * 8);
         U.qlb = carve((size_t)U.nqtiles * 16 * 8);
-        U.part = carve((size_t)U.nsplit * U.nqtiles * 16 * 2 * 8);
+        U.nsplit_fin = moments ? 2 * U.nsplit : U.nsplit;   // the moment pass's partials behind the sweep's
+        U.part = carve((size_t)U.nsplit_fin * U.nqtiles * 16 * 2 * 8);
+        U.bbox = bboxes ? carve((size_t)U.nsplit * ((U.tps + 63) / 64) * 2 * pd * 8) : 0;
+        U.mom = moments ? carve((size_t)((U.ntiles + 63) / 64 * 64) * pbn_mom_rec(d) * 8) : 0;
+        U.rad2 = moments ? carve((size_t)U.ntiles * 4) : 0;
         U.bsum = carve((size_t)((U.nq + 255) / 256 + 1) * 8);
     }
     const int64_t o_wgunit = carve((size_t)(total_wg / 64 + 1) * sizeof(int32_t));
@@ -634,8 +766,13 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.tile_box = (const double*)(arena + U.box); s.qtile_box = (const double*)(arena + U.qbox);
         s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
+        s.batch_box = bboxes ? (const double*)(arena + U.bbox) : nullptr; s.nbps = (U.tps + 63) / 64;
+        s.tile_rad2 = moments ? (const float*)(arena + U.rad2) : nullptr;
+        s.tile_mom = moments ? (const double*)(arena + U.mom) : nullptr;
+        s.zq = (const double*)(arena + U.zq);
+        s.part_mom = moments ? (double*)(arena + U.part) + (size_t)U.nsplit * U.nqtiles * 16 * 2 : nullptr;
         s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd;
-        s.margin = (float)prune_margin(fdt, U.N, /*the engine's terms are sums*/ true); s.pad_ = 0.f;
+        s.margin = (float)prune_margin(fdt, U.N, /*the engine's terms are sums*/ true); s.mom_stride = (U.ntiles + 63) / 64 * 64;
     }
     int32_t* hb = (int32_t*)(h.data() + o_blkpool);
     for (int k = 0; k < np; ++k)
@@ -690,6 +827,11 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         hipLaunchKernelGGL(group_pack_train_kernel, dim3((unsigned)B, (unsigned)max_units), dim3(GB), 0, st, g);
         hipLaunchKernelGGL(group_pack_query_kernel, dim3((unsigned)B), dim3(GB), 0, st, g);
         hipLaunchKernelGGL(group_tile_box_kernel, dim3((unsigned)((max_ntiles * 16 + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
+        if (bboxes) hipLaunchKernelGGL(group_batch_box_kernel, dim3((unsigned)max_nbatch, (unsigned)nu), dim3(64), 0, st, g);
+        if (moments) {
+            if (d0 == 1) hipLaunchKernelGGL(group_tile_moments_kernel<1>, dim3((unsigned)((max_ntiles * 16 + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL(group_tile_moments_kernel<2>, dim3((unsigned)((max_ntiles * 16 + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
+        }
         hipLaunchKernelGGL(group_prepass_kernel, dim3((unsigned)((max_nqtiles * 16 + 255) / 256), (unsigned)nu), dim3(256), 0, st, g);
         HIP_CHECK(hipGetLastError());
     }
@@ -706,6 +848,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         hipEvent_t le0 = nullptr, le1 = nullptr;
         if (log_chunks) { HIP_CHECK(hipEventCreate(&le0)); HIP_CHECK(hipEventCreate(&le1)); HIP_CHECK(hipEventRecord(le0, st)); }
         launch_sweep_grouped(sa, fdt, KS, st);
+        if (moments) launch_moment_grouped(sa, d0, st);
         if (log_chunks) {
             HIP_CHECK(hipEventRecord(le1, st));
             HIP_CHECK(hipEventSynchronize(le1));
@@ -733,7 +876,8 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P) {
         const GUnit& U = b.units[P.unit0 + u];
         const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, split_tiles = (size_t)split_tiles_for((int)nt), nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
         s += nt * KS * 1024 + nt * 256 + (nt + nqt) * 2048 + nqt * 64 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
-             nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 + (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) +
+             nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 * (d <= 2 ? 2 : 1) + (d <= 2 ? (nt + 64) * (pbn_mom_rec(d <= 1 ? 1 : 2) * 8 + 4) + 512 : 0) +
+             (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) + (nsplit + 1) * ((nt / nsplit + 127) / 64) * 2 * pd * 8 + 256 +
              (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
     }
     return s;
@@ -772,7 +916,18 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     std::vector<int> order(b.pools.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
     const bool bf16 = !force_f64 && use_bf16x3(t->dtype);
-    auto variant = [&](int i) { const int d = b.pools[i].d; return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0); };
+    // (fp64 sets of one and of two variables get chunks of their own: their units take the moment pass, whose records and kernel depend on d)
+    // (... and only when every training set of the pool is dense enough: moment_pass_rows)
+    const int mom_rows = moment_pass_rows();
+    auto dense = [&](const GPool& P) {
+        for (int u = 0; u < P.nunits; ++u)
+            if (b.units[P.unit0 + u].N < mom_rows) return false;
+        return true;
+    };
+    auto variant = [&](int i) {
+        const int d = b.pools[i].d;
+        return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0) + (d <= 2 ? 16 * d + (dense(b.pools[i]) ? 64 : 0) : 0);
+    };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
     const size_t budget = kde_group_arena_budget();
     const int max_pools = std::min(256, std::max(1, PBN_TUNE(GROUP_MAX_POOLS, 256)));

@@ -54,6 +54,9 @@ struct GUnit {
     int64_t wg0;           // first flat sweep workgroup
     // byte offsets into the batch arena
     int64_t apack, npack, zs, box, bpack, ny, zq, qpos, qbox, qthr, qlb, part, bsum;
+    int64_t bbox;                    // boxes of the 64-tile batches of every split (sweeps: one uniform test per batch before the 64 tile tests)
+    int64_t mom, rad2;               // tile-moment records / squared tile radii (0 = the chunk does not take the moment pass)
+    int32_t nsplit_fin, pad2_;       // split partials per query the finish merges (2 x nsplit with a moment pass: its partials behind the sweep's)
     double lognorm;
     double W[PBN_GROUP_MAX_D * PBN_GROUP_MAX_D];    // whitening, row-major lower, base-2 units (kde_prepare)
     double mu[PBN_GROUP_MAX_D];
@@ -93,9 +96,16 @@ struct GSweepUnit {
     const double* qtile_thr;
     const double* qlb;
     double* part;
+    const float* tile_rad2;    // moment pass (or null): squared tile radii, tile-moment records, the queries' whitened rows, the pass's partials
+    const double* tile_mom;
+    const double* zq;
+    double* part_mom;
     int64_t wg0;
     int32_t ntiles, nqtiles, tps, nsplit, nwg, pdims;
-    float margin, pad_;   // the unit's pruning margin (prune_margin(dtype, training rows))
+    float margin;         // the unit's pruning margin (prune_margin(dtype, training rows))
+    int32_t nbps;         // 64-tile batches per split (batch_box rows per split)
+    const double* batch_box;
+    int32_t mom_stride;   // doubles between consecutive values of the tile-moment records (tiles rounded up to 64)
 };
 struct GSweepArgs {
     const GSweepUnit* units;
@@ -106,5 +116,7 @@ struct GSweepArgs {
     double far_span;       // SweepArgs::far_span of every unit of the launch
 };
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st);
+// the moment pass of the same units (same flat workgroup table): d = 1 or 2, fp64 sum-only
+void launch_moment_grouped(const GSweepArgs& g, int d, hipStream_t st);
 
 }  // namespace pbn

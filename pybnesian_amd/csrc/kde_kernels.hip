@@ -216,6 +216,7 @@ struct Tr<float> {
 // measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
 __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
+__device__ unsigned long long g_mom_pairs = 0, g_mom_batches = 0, g_mom_visits = 0;   // moment pass (PBN_SWEEP_COUNT_REDO): pairs taken / (batch, group) passes made
 // (pruned sweeps: tiles visited / tiles offered, per wave)
 // waves per SIMD the pruned fp64 sweeps are compiled for: 3 (<= 168 VGPRs) - the blind-batch shapes fit anyway, the checked
 // d = 4 / 5 and norm-multiplying shapes (183-207 unconstrained) gain 3-9 % on the 1e6 x 1e5 handles; 4 (128, spills) loses on C3
@@ -658,6 +659,66 @@ __device__ __forceinline__ unsigned long long prune_group_mask2(BP tile_box, BP 
     return __ballot(keep);
 }
 
+// One uniform test per (64-tile batch, query group): does the batch's box come within the drop threshold of the group's box at all?
+template <typename BP>
+__device__ __forceinline__ bool batch_in_reach(BP bb, BP qbox, int pd, double thr) {
+    double d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PBN_PRUNE_PD; ++k)
+        if (k < pd) {
+            const double g1 = bb[k] - qbox[pd + k], g2 = qbox[k] - bb[pd + k];
+            double g = g1 > g2 ? g1 : g2;
+            g = g > 0.0 ? g : 0.0;
+            d2 = __builtin_fma(g, g, d2);
+        }
+    return !(-0.5 * d2 < thr);
+}
+
+// ... and with the MOMENT pass (round 5): `mom` = the (tile, group) pairs whose contribution is taken from the tile's moments instead
+// (kde_moment_group_kernel).  The tile's rows are z_t = c + delta_t, |delta_t| <= rho; for a query at u = z_q - c the tile adds
+// 2^(-|u|^2 / 2) sum_t 2^(-|delta_t|^2 / 2) e^(a u.delta_t), a = ln 2, and e^(a u.delta) is replaced by its Taylor polynomial of order P.  The
+// relative error of the tile's contribution is at most R_P(w) = w^(P+1) / (P+1)! e^w with w = a |u| rho (|u| <= the largest distance between the
+// two boxes); a tile whose terms lie 2^E below the group's sum bound may therefore be expanded when E + log2 R_P(w) <= -(margin + PBN_MOM_EXTRA): all
+// expanded tiles together then err by at most N 2^-(margin + extra) of a sum - a quarter of what pruning may drop.  The bound is proved,
+// the realised error is 5-6 orders smaller (tools/moment_prototype.py: 2e-13 of a sum on C3's folds).  Near tiles qualify through small
+// |u|, far ones through small terms; the middle distances are what stays with the sweep (12-15 % of the pairs at C3's density).
+// Both kernels classify with this one function on the same inputs, so every (tile, group) pair is taken by exactly one of them.
+#ifndef PBN_MOM_EXTRA
+#define PBN_MOM_EXTRA 2.0
+#endif
+template <typename BP, typename RP>
+__device__ __forceinline__ unsigned long long prune_group_mask3(BP tile_box, BP qbox, RP rad2, int pd, int64_t tb, int64_t t1, double thr, double thr_near,
+                                                                double thr_mom, int lane, unsigned long long& near, unsigned long long& mom) {
+#pragma clang fp contract(off)   // both kernels must take bit-identical decisions: no fused multiply-adds the inliner could place differently
+    const int64_t t = tb + lane;
+    bool keep = false, kn = false, km = false;
+    if (t < t1) {
+        const BP bx = tile_box + t * 2 * pd;
+        double d2 = 0.0, f2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k)
+            if (k < pd) {
+                const double g1 = bx[k] - qbox[pd + k], g2 = qbox[k] - bx[pd + k];
+                double g = g1 > g2 ? g1 : g2;
+                g = g > 0.0 ? g : 0.0;
+                d2 = __builtin_fma(g, g, d2);   // (explicit fmas are kept as written)
+                const double h1 = bx[pd + k] - qbox[k], h2 = qbox[pd + k] - bx[k];
+                const double h = h1 > h2 ? h1 : h2;
+                f2 = __builtin_fma(h, h, f2);
+            }
+        const double ex = -0.5 * d2;
+        keep = !(ex < thr);
+        kn = !(ex < thr_near);
+        // w = ln 2 * |u|max * rho, rounded up; log2 R_8(w) = 9 log2 w - log2 9! + w log2 e (v_sqrt_f32 / v_log_f32: 1 ulp, covered by the + 0.02)
+        const float w = 0.69314724f * __builtin_amdgcn_sqrtf((float)f2 * 1.000001f * rad2[t]) * 1.000001f;
+        const float logr = (float)(PBN_MOM_ORDER + 1) * __builtin_amdgcn_logf(w) - PBN_MOM_LOG2_FACT + 1.4426951f * w + 0.02f;
+        km = keep && w < 4.0f && ((double)logr + ex <= thr_mom);
+    }
+    near = __ballot(kn);
+    mom = __ballot(km);
+    return __ballot(keep);
+}
+
 // WMUL (d mod 4 == 0, no free K slot for the norm): the training norms enter as WEIGHTS.  The accumulator starts from the
 // per-query constant alone (a persistent register quad as the MFMA's C operand, as with FOLD) and holds
 // x' = z_t.z_q - 1/2|z_q|^2 - m_q + bias; the term is 2^x' * w_t with w_t = 2^(-1/2|z_t|^2) precomputed by the pack kernel, and
@@ -953,7 +1014,10 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // exponent units above its query's bound) and redo it with the checked loop from the saved sums if a sum went bad
         constexpr bool FASTP = PBN_SWEEP_UNCHECKED && !COND && sizeof(T) == 8 && (FOLD || KS == 1);   // the shapes that stay <= 168 VGPRs
         if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0) * QG);
-        for (int64_t tb = t0; tb < t1; tb += 64) {
+        // Two levels: a SUPER-BATCH of 64 batches (4096 tiles) is classified first, lane = batch, against the batches' own boxes (grouped
+        // sweeps: GSweepUnit::batch_box) - one round trip to L2 for 64 batches instead of one per batch, which is what the walk over a
+        // split's tiles costs where most batches hold nothing for the wave (the test below is latency, not arithmetic).
+        auto do_batch = [&](const int64_t tb, const unsigned gsel) {
             unsigned long long mask;
             if constexpr (GMASK) {
                 mask = 0;
@@ -961,8 +1025,19 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                     for (int g = 0; g < QG; ++g) {
                         const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+                        if (!((gsel >> g) & 1u)) {   // the whole batch beyond this group's reach
+                            gm[g] = 0;
+                            if constexpr (FARP) gn[g] = ~0ull;
+                            continue;
+                        }
                         if constexpr (FARP) {
-                            if (a.far_span > 0.0) {
+                            if (a.tile_rad2) {   // the moment pass takes the pairs it can expand: this sweep skips them
+                                unsigned long long mx;
+                                gm[g] = prune_group_mask3(TBp, QBp + qt * 2 * pd, (const PBN_GLOBAL float*)a.tile_rad2, pd, tb, t1, QTp[qt] - a.prune_margin,
+                                                          a.far_span > 0.0 ? QTp[qt] - (a.prune_margin - a.far_span) : -INFINITY,
+                                                          QTp[qt] - (a.prune_margin + PBN_MOM_EXTRA), lane, gn[g], mx);
+                                gm[g] &= ~mx;
+                            } else if (a.far_span > 0.0) {
                                 gm[g] = prune_group_mask2(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, QTp[qt] - (a.prune_margin - a.far_span), lane, gn[g]);
                             } else {
                                 gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
@@ -985,7 +1060,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             } else {
                 mask = prune_visit_mask(TBp, pd, tb, t1, wlo, whi, wthr, lane);
             }
-            if (!mask) continue;
+            if (!mask) return;
             if (a.count_redo && lane == 0) {
                 unsigned long long v = 0;
 #pragma unroll
@@ -1013,6 +1088,32 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 }
             } else {
                 run_batch(tb, mask, std::false_type{});
+            }
+        };
+        for (int64_t sb = t0; sb < t1; sb += 4096) {
+            const int64_t bt = sb + 64 * lane;   // my batch's first tile
+            unsigned long long bm = __ballot(bt < t1), bmg[QG];
+#pragma unroll
+            for (int g = 0; g < QG; ++g) bmg[g] = bm;
+            if constexpr (GMASK) {
+                if (a.group_masks && a.batch_box) {
+                    const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)a.batch_box + ((int64_t)split * a.batches_per_split + ((bt - t0) >> 6)) * 2 * pd;
+                    bm = 0;
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+                        bmg[g] = __ballot(bt < t1 && batch_in_reach(bb, QBp + qt * 2 * pd, pd, QTp[qt] - a.prune_margin));
+                        bm |= bmg[g];
+                    }
+                }
+            }
+            while (bm) {
+                const int j = __builtin_ctzll(bm);
+                bm &= bm - 1;
+                unsigned gsel = 0;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) gsel |= (unsigned)((bmg[g] >> j) & 1ull) << g;
+                do_batch(sb + 64 * (int64_t)j, gsel);
             }
         }
     } else {
@@ -1085,7 +1186,8 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // an empty sum still holds the term its offset came from (see kde_sweep_bf16_kernel; 2^bias is that term here)
         // (only when the offset is a real exponent: a NaN / infinite offset - NaN queries, an all-padding split - keeps its sum)
         const bool mfin = (m[g] - m[g]) == (T)0;
-        if (s == 0.0 && mfin && !lbm[g]) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        // (not with a moment pass beside this sweep: the tile the offset came from may be the other pass's - an empty sum is empty)
+        if (s == 0.0 && mfin && !lbm[g] && !a.tile_rad2) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (COND && sj == 0.0 && (mj[g] - mj[g]) == (T)0 && !lbmj[g]) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (lg == 0 && qt0 + g < a.nqtiles) {
             PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
@@ -1118,7 +1220,166 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = g.group_masks;
     a.far_span = g.far_span;
+    a.tile_rad2 = su.tile_rad2; a.tile_mom = su.tile_mom; a.batch_box = su.batch_box; a.batches_per_split = su.nbps;
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true>(a, bid);
+}
+
+// The moment pass of a grouped fp64 sum-only sweep of D = 1 or 2 dimensions (round 5).  Same flat grid and the same (unit, query block,
+// split) mapping as kde_sweep_group_kernel, a wave owns the same four 16-query groups - but here LANE = TILE: per 64-tile batch every lane
+// loads the record of its own tile (structure of arrays: 47 | 10 coalesced loads, once per batch and group that has a pair in it), and the 16
+// queries of the group are taken one after the other - their coordinates and offsets are uniform (v_readlane from the lanes that hold
+// them), the tile's coefficients per-lane registers.  A (tile, group) pair then costs 16 x (2 D + 12 + (44 | 8)) / 64 fp64 instructions:
+// ~17 issue slots at D = 2 against ~44 for the MFMA + 2^f form of the sweep, ~7 at D = 1 - and a lane idles only where ITS tile is not this
+// group's (the first forms of this kernel - lane = query with the records through scalar loads, then 4 tile slots x 16 queries with per-lane
+// record loads - paid for the union of the four groups' tiles resp. for 23 vector loads per four tiles: no faster than the sweep).
+// The exponent of the common factor is split as in the sweep (biased, integer offset from the prepass bound); 2^x takes the fp64 polynomial -
+// one per (tile, query), so the pass's own arithmetic error is 2.3e-9 per term.  Partials go behind the sweep's own (GSweepUnit::part_mom).
+__device__ __forceinline__ double readlane_f64(double v, int l) {   // lane l's value, uniform (two v_readlane_b32 into scalar registers)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+#ifndef PBN_MOM_WAVES2
+#define PBN_MOM_WAVES2 2   // D = 2: 45 coefficients per lane - 3 waves / SIMD (168 VGPRs) spill them
+#endif
+#ifndef PBN_MOM_UNROLL
+#define PBN_MOM_UNROLL 16
+#endif
+#ifndef PBN_MOM_EXP_F32
+#define PBN_MOM_EXP_F32 1
+#endif
+template <int D>
+__global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_group_kernel(GSweepArgs g) {
+    // per (query, lane) running sums: in LDS - 16 x 64 doubles per wave; as registers they push the 45 coefficients of D = 2 into scratch
+    __shared__ double accs[16][64];
+    const int u = g.wg_unit[blockIdx.x >> 6];
+    const GSweepUnit& su = g.units[u];
+    const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
+    if (bid >= (unsigned)su.nwg) return;
+    constexpr int QG = PBN_QG_PRUNE;
+    constexpr int NC = pbn_mom_coefs(D);
+    const int lane = threadIdx.x & 63;
+    const unsigned Gq = (unsigned)((su.nqtiles + QG - 1) / QG), Gs = (unsigned)su.nsplit;
+    const unsigned kk = bid / Gq;
+    const int qx = (int)(bid % Gq);
+    const int split = (kk & 1u) ? (int)(Gs - 1 - (kk >> 1)) : (int)(kk >> 1);   // pruned_block's order
+    const int64_t qt0 = (int64_t)qx * QG;
+    if (qt0 >= su.nqtiles) return;
+    const int64_t t0 = (int64_t)split * su.tps;
+    const int64_t t1 = (t0 + su.tps < su.ntiles) ? t0 + su.tps : su.ntiles;
+    const int pd = su.pdims;
+    const int64_t ms = su.mom_stride;
+    const PBN_GLOBAL double* __restrict__ TBp = (const PBN_GLOBAL double*)su.tile_box;
+    const PBN_GLOBAL double* __restrict__ QBp = (const PBN_GLOBAL double*)su.qtile_box;
+    const PBN_GLOBAL double* __restrict__ QTp = (const PBN_GLOBAL double*)su.qtile_thr;
+    const PBN_GLOBAL double* __restrict__ QLp = (const PBN_GLOBAL double*)su.qlb;
+    const PBN_GLOBAL float* __restrict__ R2p = (const PBN_GLOBAL float*)su.tile_rad2;
+    const PBN_GLOBAL double* __restrict__ MOp = (const PBN_GLOBAL double*)su.tile_mom;
+    const PBN_GLOBAL double* __restrict__ ZQp = (const PBN_GLOBAL double*)su.zq;
+    const double margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
+    PBN_GLOBAL double* part = (PBN_GLOBAL double*)su.part_mom;
+
+    for (int gi = 0; gi < QG; ++gi) {
+        const int64_t qg = qt0 + gi;
+        if (qg >= su.nqtiles) break;
+        // the group's 16 queries live in lanes 0..15 (copies in the other lanes): coordinates and the exponent offset - the prepass's lower
+        // bound of the query's largest exponent, an integer as in the sweep.  A padding row (bound -inf) gets an offset that kills its terms.
+        const int64_t q = qg * 16 + (lane & 15);
+        const double lb = __builtin_ceil(QLp[q]);
+        const bool qok = (lb < 0.0 ? -lb : lb) < 0x1p50;
+        double mqv = qok ? lb : 0.0;
+        double cmv = qok ? Tr<double>::bias() - lb : -0x1p60;
+        double zv[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) zv[k] = qok ? ZQp[q * D + k] : 0.0;
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) accs[qi][lane] = 0.0;
+        const double thr = QTp[qg];
+        for (int64_t sb = t0; sb < t1; sb += 4096) {
+          // (the sweep's two levels: 64 batches classified at once, lane = batch, then the batches in reach)
+          const int64_t bt = sb + 64 * lane;
+          unsigned long long bm;
+          if (su.batch_box) {
+              const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)su.batch_box + ((int64_t)split * su.nbps + ((bt - t0) >> 6)) * 2 * pd;
+              bm = __ballot(bt < t1 && batch_in_reach(bb, QBp + qg * 2 * pd, pd, thr - margin));
+          } else {
+              bm = __ballot(bt < t1);
+          }
+          while (bm) {
+            const int64_t tb = sb + 64 * (int64_t)__builtin_ctzll(bm);
+            bm &= bm - 1;
+            unsigned long long nr, m;
+            if (g.count_redo && lane == 0) atomicAdd(&g_mom_visits, 1ull);
+            (void)prune_group_mask3(TBp, QBp + qg * 2 * pd, R2p, pd, tb, t1, thr - margin, g.far_span > 0.0 ? thr - (margin - g.far_span) : -INFINITY,
+                                    thr - (margin + PBN_MOM_EXTRA), lane, nr, m);
+            if (!m) continue;
+            if (g.count_redo && lane == 0) { atomicAdd(&g_mom_pairs, (unsigned long long)__builtin_popcountll(m)); atomicAdd(&g_mom_batches, 1ull); }
+            const bool act = (m >> lane) & 1ull;
+            // my tile's record; a lane without a pair keeps zeros: its polynomial is 0 and (its exponent forced to 0 below) adds nothing
+            double c[D], cf[NC];
+#pragma unroll
+            for (int k = 0; k < D; ++k) c[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) cf[k] = 0.0;
+            if (act) {
+                const PBN_GLOBAL double* __restrict__ rec = MOp + (tb + lane);
+#pragma unroll
+                for (int k = 0; k < D; ++k) c[k] = rec[(int64_t)k * ms];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) cf[k] = rec[(int64_t)(D + k) * ms];
+            }
+#pragma unroll PBN_MOM_UNROLL
+            for (int qi = 0; qi < 16; ++qi) {
+                const double ux = readlane_f64(zv[0], qi) - c[0];
+                double d2 = ux * ux, uy = 0.0;
+                if constexpr (D == 2) { uy = readlane_f64(zv[1], qi) - c[1]; d2 = __builtin_fma(uy, uy, d2); }
+                double x = __builtin_fma(-0.5, d2, readlane_f64(cmv, qi));
+                x = act ? x : 0.0;
+                while (__builtin_expect(__any(x > 900.0), 0)) {
+                    // the offset is a LOWER bound of the query's largest exponent: a far-out query (heavy tails) can sit thousands of units
+                    // below a row its short neighbour scan missed.  Rebase the query (uniform: every lane's sum for it, and the offset it
+                    // lives with from here on) by a fixed integer number of units
+                    accs[qi][lane] *= 0x1p-512;
+                    if ((lane & 15) == qi) { cmv -= 512.0; mqv += 512.0; }
+                    x = act ? x - 512.0 : 0.0;
+                }
+                // 2^x as in the sweep this pass stands in for: 2^f of the fraction on the fp32 unit (<= 1.4e-7 of the pair's contribution, the
+                // budget's first entry); x >= 0 for every pair that matters (the biased offset), a negative x comes out <= 2x too large
+                const double e = PBN_MOM_EXP_F32 ? exp2_f64_fract<true>(x, 0.0) : Tr<double>::ex2_hi(x);
+                double pv;
+                if constexpr (D == 1) {
+                    pv = cf[0];
+#pragma unroll
+                    for (int i = 1; i <= PBN_MOM_ORDER; ++i) pv = __builtin_fma(pv, ux, cf[i]);
+                } else {
+                    int k = 0;
+                    pv = 0.0;
+#pragma unroll
+                    for (int j = PBN_MOM_ORDER; j >= 0; --j) {
+                        double qj = cf[k++];
+#pragma unroll
+                        for (int i = PBN_MOM_ORDER - j - 1; i >= 0; --i) qj = __builtin_fma(qj, ux, cf[k++]);
+                        pv = __builtin_fma(pv, uy, qj);
+                    }
+                }
+                accs[qi][lane] = __builtin_fma(e, pv, accs[qi][lane]);
+            }
+          }
+        }
+        // the group's sums: add the 64 lanes' (tiles') parts per query, lane qi writes query qi
+        double mine = 0.0;
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) {
+            double v = accs[qi][lane];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == qi) mine = v;
+        }
+        if (lane < 16) {
+            PBN_GLOBAL double* o = part + ((int64_t)split * su.nqtiles * 16 + q) * 2;
+            o[0] = mqv - Tr<double>::bias();   // the sums carry 2^bias, as the sweep's
+            o[1] = mine;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2359,6 +2620,15 @@ void launch_sweep(const SweepArgs& a_in, int dtype, int KS, bool cond, int nspli
     }
 }
 
+void launch_moment_grouped(const GSweepArgs& g, int d, hipStream_t st) {
+    if (g.total_wg == 0) return;
+    const dim3 grid((unsigned)g.total_wg), block(64);
+    if (d == 1) hipLaunchKernelGGL(kde_moment_group_kernel<1>, grid, block, 0, st, g);
+    else if (d == 2) hipLaunchKernelGGL(kde_moment_group_kernel<2>, grid, block, 0, st, g);
+    else throw invalid_error("moment pass: one or two dimensions");
+    HIP_CHECK(hipGetLastError());
+}
+
 // fold: d mod 4 != 0 (norm in a free K slot); wmul: d mod 4 == 0 (norms as weights) - the two pruned plain fp64 shapes
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st) {
     if (g.total_wg == 0) return;
@@ -2412,6 +2682,15 @@ extern "C" void pbn_debug_sweep_redo(unsigned long long* redo, unsigned long lon
 }
 // measurement aid like the above: tiles visited / tiles offered to the waves of the pruned fp64 sweeps since the last reset
 // measurement aid like the above: tiles visited / tiles offered to the waves of the pruned fp64 sweeps since the last reset
+extern "C" void pbn_debug_moment_visits(unsigned long long* visits) {
+    if (visits) (void)hipMemcpyFromSymbol(visits, HIP_SYMBOL(pbn::g_mom_visits), sizeof(unsigned long long));
+}
+extern "C" void pbn_debug_moment_pairs(unsigned long long* pairs, unsigned long long* batches, int reset) {
+    unsigned long long z = 0;
+    if (pairs) (void)hipMemcpyFromSymbol(pairs, HIP_SYMBOL(pbn::g_mom_pairs), sizeof z);
+    if (batches) (void)hipMemcpyFromSymbol(batches, HIP_SYMBOL(pbn::g_mom_batches), sizeof z);
+    if (reset) { (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_mom_pairs), &z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_mom_batches), &z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_mom_visits), &z, sizeof z); }
+}
 extern "C" void pbn_debug_sweep_visits(unsigned long long* visited, unsigned long long* tiles, int reset) {
     unsigned long long z = 0;
     if (visited) (void)hipMemcpyFromSymbol(visited, HIP_SYMBOL(pbn::g_sweep_visit), sizeof z);

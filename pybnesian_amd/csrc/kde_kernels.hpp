@@ -92,8 +92,30 @@ struct SweepArgs {
     int group_masks;           // pruned plain fp64 sweeps: test every 16-query group against its own box and bound (prune_group_mask)
     double far_span;           // pruned plain fp64 sum-only sweeps (FOLD shapes): > 0 = tiles whose every term lies more than prune_margin - far_span
                                // below the group's sum bound take the fp32 tail path (kde_sweep_body: FARP); 0 = off
+    // Tile moments (round 5; grouped sum-only fp64 sweeps of one or two dimensions, kde_group.hip): tile_rad2[t] = squared radius of tile t
+    // about its centroid (rounded up), tile_mom = per tile a record of PBN_MOM_REC(d) doubles: centroid, then the coefficients of the
+    // order-PBN_MOM_ORDER expansion of the tile's contribution about it.  A (tile, group) pair whose expansion error is below the pruning
+    // bound is left to the moment pass (kde_moment_group_kernel) by the sweep; null = off.
+    const float* tile_rad2;
+    const double* tile_mom;
+    // Batch boxes (round 5, grouped sweeps): the bounding box of every 64-tile batch of a split - [split * batches_per_split + k][2 * pdims] -
+    // lets a wave drop a batch for a query group with ONE uniform test before it loads and tests the 64 tile boxes; null = off.
+    const double* batch_box;
+    int batches_per_split;
     double* part;  // [nsplit][nqtiles*16][P]
 };
+
+// Tile-moment expansions: order and record layout.  Per tile NREC = D + ncoef doubles - the centroid, then the coefficients in the order the
+// Horner scheme of kde_moment_group_kernel reads them (D = 2: j = 8 ... 0; within j, i = 8 - j ... 0) - stored STRUCTURE-OF-ARRAYS: value k of
+// tile t at mom[k * stride + t] (stride = tiles rounded up to 64), so that the 64 lanes of a wave, one tile each, load a value of 64
+// consecutive tiles with one coalesced instruction.
+#ifndef PBN_MOM_ORDER
+#define PBN_MOM_ORDER 8
+#endif
+// log2((P + 1)!) of the remainder bound
+#define PBN_MOM_LOG2_FACT (PBN_MOM_ORDER == 8 ? 18.469133f : PBN_MOM_ORDER == 6 ? 12.299208f : PBN_MOM_ORDER == 5 ? 9.491853f : PBN_MOM_ORDER == 4 ? 6.906891f : PBN_MOM_ORDER == 10 ? 25.250475f : -1.f)
+constexpr int pbn_mom_coefs(int d) { return d == 1 ? PBN_MOM_ORDER + 1 : (PBN_MOM_ORDER + 1) * (PBN_MOM_ORDER + 2) / 2; }
+constexpr int pbn_mom_rec(int d) { return d + pbn_mom_coefs(d); }   // 10 | 47
 
 struct FinishArgs {
     const double* part;
