@@ -454,7 +454,8 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
     more = dict(extra) if which == "c5mmhc" else {}
     if which != "c4":
         # the leg's dominant kernel and its share of the timed search, from the library's own HIP events (no profiler)
-        kname = {"c3": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only)",
+        kname = {"c3": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only) + kde_moment_group_kernel<1 | 2> "
+                       "(the tile-moment pass of its one- and two-variable terms: one event pair spans both launches)",
                  "cv64": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only)"}.get(
                      which, "kde_sweep_bf16_group_kernel<1> (grouped pruned fp32 sweep on bf16x3 fragments) + the per-slice kde_sweep_bf16_kernel")
         more["roofline"] = {"kernel": kname, "bound": "valu-issue (v_exp + add per pair value inside the pruning radius; DESIGN.md 3.1)",
