@@ -644,20 +644,24 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(GDev g, double* out) 
 size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 // Training tiles per split of a unit's sweep.  PBN_GROUP_SPLIT_TILES pins it; otherwise 512 up to 16 384 tiles (cv64's 90 000-row folds:
-// 512 measures best, 1 024 +2-3 %), 1 024 up to 32 768 (C3's 450 000-row folds: 10.72 against 10.79 s) and 2 048 beyond (C5's 720 000-row
-// slices: within noise of 512 in time, `profiles/r4/split_tiles_probe.txt` - but every query keeps a partial per split, 60 % of a
-// candidate's arena at 512, so the coarser split lets an arena-full hold twice the candidates).
-int split_tiles_for(int ntiles) {
+// 256 ... 1 024 measure within 1 %, 2 048 +2 %).  Beyond that the fp32 sweeps take 1 024 up to 32 768 tiles and 2 048 above (C5's 720 000-row
+// slices: within noise of 512 in time, `profiles/r4/split_tiles_probe.txt` - but every query keeps a partial per split, 60 % of a candidate's
+// arena at 512, so the coarser split lets an arena-full hold twice the candidates); the fp64 sweeps take 4 096 since round 5: with the two-level
+// walk a longer split costs one more ballot per 4 096 tiles, and the moment pass beside the sweep halves the work per workgroup - C3's 450 000-row
+// folds: first iteration 8.08 (1 024) / 7.83 (2 048) / 7.79 (4 096) / 7.97 s (16 384), six iterations 12.68 -> 12.00 s (`profiles/r5/moment_pass.txt` section 8).
+int split_tiles_for(int ntiles, bool f64) {
     const int pinned = knob_int("PBN_GROUP_SPLIT_TILES", 0);   // read per call: the tests switch it
     if (pinned > 0) return std::max(16, pinned);
-    return ntiles <= 16384 ? 512 : (ntiles <= 32768 ? 1024 : 2048);
+    if (ntiles <= 16384) return 512;
+    return f64 ? 4096 : (ntiles <= 32768 ? 1024 : 2048);
 }
 
 // The moment pass pays from a density of training rows on: a 16-row tile must be small against the bandwidth for many of its (tile, group)
-// pairs to pass the criterion.  Measured on CV terms of one and two variables (tools/moment_visits.py, profiles/r5/moment_pass.txt): 32 000
-// training rows - 40 of 64 lanes busy, a third of the pairs left to the sweep, no gain (cv64's first iteration 2.3 -> 2.9 s); 150 000 (C3's
-// folds) - 9.1 -> 8.3 s; 450 000 - 56-62 lanes, 40 -> 24 ms per two-variable term, 21 -> 8 ms per one-variable term.
-int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 100000); }
+// pairs to pass the criterion.  cv64-shaped searches (64 nodes, 10 folds, first iteration) with the pass forced on against off
+// (tools/r5_probe_m.sh, profiles/r5/moment_pass.txt): 90 000 training rows 2.26 -> 2.99 s, 135 000 4.08 -> 5.28 s, 180 000 6.65 -> 8.07 s,
+// 270 000 12.79 -> 13.56 s; C3 (450 000) 9.04 -> 8.08 s.  Lane utilisation (tools/moment_visits.py): 40-44 of 64 at 57 600 rows with a third
+// of the pairs left to the sweep, 56-62 at 450 000 with 6 % left.
+int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 400000); }
 
 // one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
 void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out,
@@ -713,7 +717,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         const int d = P.d, pd = P.kd;
         U.ntiles = (U.N + 15) / 16;
         U.nqtiles = (U.nq + 15) / 16;
-        const int split_tiles = split_tiles_for(U.ntiles);
+        const int split_tiles = split_tiles_for(U.ntiles, !bf16);
         const int nsplit0 = std::max(1, (U.ntiles + split_tiles - 1) / split_tiles);
         U.tps = (U.ntiles + nsplit0 - 1) / nsplit0;
         U.nsplit = (U.ntiles + U.tps - 1) / U.tps;
@@ -847,6 +851,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         static const int log_chunks = PBN_TUNE(SWEEP_LOG, 0);   // experiments build: one line per grouped sweep launch (synchronises)
         hipEvent_t le0 = nullptr, le1 = nullptr;
         if (log_chunks) { HIP_CHECK(hipEventCreate(&le0)); HIP_CHECK(hipEventCreate(&le1)); HIP_CHECK(hipEventRecord(le0, st)); }
+        sa.moments = moments ? 1 : 0;
         launch_sweep_grouped(sa, fdt, KS, st);
         if (moments) launch_moment_grouped(sa, d0, st);
         if (log_chunks) {
@@ -874,7 +879,7 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P) {
     size_t s = (size_t)P.n * (16 + (size_t)PBN_GROUP_MAX_D * 8 + 1) + (size_t)((P.n + GB - 1) / GB + 1) * (PBN_GROUP_MAX_R * 4 + 4) + sizeof(GPool) + 4096;
     for (int u = 0; u < P.nunits; ++u) {
         const GUnit& U = b.units[P.unit0 + u];
-        const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, split_tiles = (size_t)split_tiles_for((int)nt), nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
+        const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, split_tiles = (size_t)split_tiles_for((int)nt, /*the finer rule: an upper bound for both*/ false), nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
         s += nt * KS * 1024 + nt * 256 + (nt + nqt) * 2048 + nqt * 64 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
              nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 * (d <= 2 ? 2 : 1) + (d <= 2 ? (nt + 64) * (pbn_mom_rec(d <= 1 ? 1 : 2) * 8 + 4) + 512 : 0) +
              (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) + (nsplit + 1) * ((nt / nsplit + 127) / 64) * 2 * pd * 8 + 256 +

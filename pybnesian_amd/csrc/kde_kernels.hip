@@ -216,7 +216,7 @@ struct Tr<float> {
 // measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
 __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
-__device__ unsigned long long g_mom_pairs = 0, g_mom_batches = 0, g_mom_visits = 0;   // moment pass (PBN_SWEEP_COUNT_REDO): pairs taken / (batch, group) passes made
+__device__ unsigned long long g_mom_pairs = 0, g_mom_batches = 0, g_mom_visits = 0, g_mom_left = 0;   // moment pass (PBN_SWEEP_COUNT_REDO): pairs taken / (batch, group) passes made
 // (pruned sweeps: tiles visited / tiles offered, per wave)
 // waves per SIMD the pruned fp64 sweeps are compiled for: 3 (<= 168 VGPRs) - the blind-batch shapes fit anyway, the checked
 // d = 4 / 5 and norm-multiplying shapes (183-207 unconstrained) gain 3-9 % on the 1e6 x 1e5 handles; 4 (128, spills) loses on C3
@@ -745,7 +745,10 @@ __device__ __forceinline__ void pruned_block(const SweepArgs& a, int groups_per_
 // The sweep proper.  `bid` is the workgroup's index inside ITS sweep: blockIdx.x for a stand-alone launch, the offset inside
 // the unit for the grouped launches (kde_sweep_group_kernel), where `a` was assembled from the unit's record.
 // EF32: 2^f of the main loop on the fp32 transcendental unit (exp2_f64_fract<true>; sweeps whose result is a sum)
-template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL, bool EF32 = false>
+// MOM (round 5): the moment pass runs beside this sweep (grouped fp64 sum-only launches of one- and two-variable units) - the sweep skips the
+// pairs the pass takes (prune_group_mask3).  A template parameter, not a run-time branch:
+// the kernel sits at its register limit and the extra paths cost the plain sweep 25 % when compiled in.
+template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMUL, bool EF32 = false, bool MOM = false>
 __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigned bid) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
@@ -900,6 +903,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     // 2^-24 |x'| ln 2 <= 5.3e-6, of the sum <= 5.3e-6 N 2^-26 = 8e-8 (the margin follows log2(N / 10^6), so the bound does not depend
     // on N).  A batch redone by the checked loop takes every tile through the full path.
     constexpr bool FARP = GMASK && FOLD && EF32 && PBN_FAR_F32;
+    static_assert(!MOM || FARP, "the moment pass stands beside the FARP shapes only");
     unsigned long long gn[FARP ? QG : 1];
     float fs[FARP ? QG : 1];
 #pragma unroll
@@ -1021,7 +1025,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             unsigned long long mask;
             if constexpr (GMASK) {
                 mask = 0;
-                if (a.group_masks) {
+                if (MOM || a.group_masks) {
 #pragma unroll
                     for (int g = 0; g < QG; ++g) {
                         const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
@@ -1031,7 +1035,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                             continue;
                         }
                         if constexpr (FARP) {
-                            if (a.tile_rad2) {   // the moment pass takes the pairs it can expand: this sweep skips them
+                            if constexpr (MOM) {   // the moment pass takes the pairs it can expand: this sweep skips them
                                 unsigned long long mx;
                                 gm[g] = prune_group_mask3(TBp, QBp + qt * 2 * pd, (const PBN_GLOBAL float*)a.tile_rad2, pd, tb, t1, QTp[qt] - a.prune_margin,
                                                           a.far_span > 0.0 ? QTp[qt] - (a.prune_margin - a.far_span) : -INFINITY,
@@ -1096,7 +1100,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
             for (int g = 0; g < QG; ++g) bmg[g] = bm;
             if constexpr (GMASK) {
-                if (a.group_masks && a.batch_box) {
+                if ((MOM || a.group_masks) && a.batch_box) {
                     const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)a.batch_box + ((int64_t)split * a.batches_per_split + ((bt - t0) >> 6)) * 2 * pd;
                     bm = 0;
 #pragma unroll
@@ -1187,7 +1191,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // (only when the offset is a real exponent: a NaN / infinite offset - NaN queries, an all-padding split - keeps its sum)
         const bool mfin = (m[g] - m[g]) == (T)0;
         // (not with a moment pass beside this sweep: the tile the offset came from may be the other pass's - an empty sum is empty)
-        if (s == 0.0 && mfin && !lbm[g] && !a.tile_rad2) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
+        if (s == 0.0 && mfin && !lbm[g] && !MOM) s = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (COND && sj == 0.0 && (mj[g] - mj[g]) == (T)0 && !lbmj[g]) sj = __builtin_ldexp(1.0, (int)Tr<T>::bias());
         if (lg == 0 && qt0 + g < a.nqtiles) {
             PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + (qt0 + g) * 16 + lane) * P;
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_W
 
 // Grouped launch (kde_group.hip): the flat grid covers the sweeps of MANY units back to back, unit-major, every unit's share
 // rounded up to 64 workgroups so that one table entry per 64 workgroups names the unit.  Pruned plain fp64 sweeps only.
-template <typename T, int KS, int QG, bool FOLD, bool WMUL>
+template <typename T, int KS, int QG, bool FOLD, bool WMUL, bool MOM = false>
 __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) void kde_sweep_group_kernel(GSweepArgs g) {
     const int u = g.wg_unit[blockIdx.x >> 6];
     const GSweepUnit& su = g.units[u];
@@ -1221,7 +1225,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = g.group_masks;
     a.far_span = g.far_span;
     a.tile_rad2 = su.tile_rad2; a.tile_mom = su.tile_mom; a.batch_box = su.batch_box; a.batches_per_split = su.nbps;
-    kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true>(a, bid);
+    kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true, MOM>(a, bid);
 }
 
 // The moment pass of a grouped fp64 sum-only sweep of D = 1 or 2 dimensions (round 5).  Same flat grid and the same (unit, query block,
@@ -1305,12 +1309,14 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
               bm = __ballot(bt < t1);
           }
           while (bm) {
-            const int64_t tb = sb + 64 * (int64_t)__builtin_ctzll(bm);
+            const int bj = __builtin_ctzll(bm);
+            const int64_t tb = sb + 64 * (int64_t)bj;
             bm &= bm - 1;
             unsigned long long nr, m;
             if (g.count_redo && lane == 0) atomicAdd(&g_mom_visits, 1ull);
-            (void)prune_group_mask3(TBp, QBp + qg * 2 * pd, R2p, pd, tb, t1, thr - margin, g.far_span > 0.0 ? thr - (margin - g.far_span) : -INFINITY,
+            const unsigned long long kept = prune_group_mask3(TBp, QBp + qg * 2 * pd, R2p, pd, tb, t1, thr - margin, g.far_span > 0.0 ? thr - (margin - g.far_span) : -INFINITY,
                                     thr - (margin + PBN_MOM_EXTRA), lane, nr, m);
+            if (g.count_redo && lane == 0 && (kept & ~m)) atomicAdd(&g_mom_left, 1ull);
             if (!m) continue;
             if (g.count_redo && lane == 0) { atomicAdd(&g_mom_pairs, (unsigned long long)__builtin_popcountll(m)); atomicAdd(&g_mom_batches, 1ull); }
             const bool act = (m >> lane) & 1ull;
@@ -2644,7 +2650,9 @@ void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st
     if (dtype != PBN_F64 || KS < 1 || KS > 2 || (g.fold != 0) == (g.wmul != 0)) throw invalid_error("grouped sweeps: fp64 / fp32 on the bf16 cores, at most 8 whitened dimensions");
     constexpr int QGP = PBN_QG_PRUNE;
     if (g.fold) {
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, true, false>), grid, block, 0, st, g);
+        if (g.moments && (KS != 1 || !g.group_masks)) throw invalid_error("grouped sweeps: the moment pass stands beside one- and two-variable units with per-group masks");
+        if (KS == 1 && g.moments) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, true, false, true>), grid, block, 0, st, g);
+        else if (KS == 1) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, true, false>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((kde_sweep_group_kernel<double, 2, QGP, true, false>), grid, block, 0, st, g);
     } else {
         if (KS == 1) hipLaunchKernelGGL((kde_sweep_group_kernel<double, 1, QGP, false, true>), grid, block, 0, st, g);
@@ -2684,6 +2692,11 @@ extern "C" void pbn_debug_sweep_redo(unsigned long long* redo, unsigned long lon
 // measurement aid like the above: tiles visited / tiles offered to the waves of the pruned fp64 sweeps since the last reset
 extern "C" void pbn_debug_moment_visits(unsigned long long* visits) {
     if (visits) (void)hipMemcpyFromSymbol(visits, HIP_SYMBOL(pbn::g_mom_visits), sizeof(unsigned long long));
+}
+extern "C" void pbn_debug_moment_left(unsigned long long* left, int reset) {
+    unsigned long long z = 0;
+    if (left) (void)hipMemcpyFromSymbol(left, HIP_SYMBOL(pbn::g_mom_left), sizeof z);
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_mom_left), &z, sizeof z);
 }
 extern "C" void pbn_debug_moment_pairs(unsigned long long* pairs, unsigned long long* batches, int reset) {
     unsigned long long z = 0;

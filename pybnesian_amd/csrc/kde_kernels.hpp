@@ -102,6 +102,8 @@ struct SweepArgs {
     // lets a wave drop a batch for a query group with ONE uniform test before it loads and tests the 64 tile boxes; null = off.
     const double* batch_box;
     int batches_per_split;
+    // (Measured and dropped, round 5: a bitmap written by the moment pass - the batches that still hold pairs for the sweep, 24 % of the
+    //  (batch, group) masks at 300 000 rows - instead of the sweep's own batch test: sweep 2.03 -> 1.90 s, moment kernel 4.93 -> 5.04 s on C3's first iteration.)
     double* part;  // [nsplit][nqtiles*16][P]
 };
 

@@ -2,7 +2,7 @@
 and two variables, where the pass takes the (tile, group) pairs whose order-8 expansion error is proved below the pruning bound and the sweep
 keeps the rest.  What the numbers are held against is the reference's arithmetic (kde/opencl_kernels/KDE.cl.src:115-121,227-233 through
 oracle/): the pass on, off, and the oracle must agree; the pass must really have taken pairs (debug counters), or the test proves nothing.
-The shipped rule switches the pass on from 100 000 training rows (PBN_MOMENT_MIN_ROWS); the small cases lower it to 0."""
+The shipped rule switches the pass on from 400 000 training rows (PBN_MOMENT_MIN_ROWS); the small cases lower it to 0."""
 import ctypes as C
 
 import numpy as np
@@ -93,13 +93,13 @@ def test_pinned_margin_the_two_passes_partition_the_pairs(monkeypatch):
 
 
 def test_shipped_rule_takes_dense_folds_only(monkeypatch):
-    """Default knobs: folds of 125 000 training rows take the pass, folds of 30 000 do not; on and off agree inside the budget."""
+    """Default knobs: folds of 450 000 training rows take the pass, folds of 125 000 do not; on and off agree inside the budget."""
     from pybnesian_amd import _lib
 
     lib = _lib.load()
     rng = np.random.default_rng(8)
     monkeypatch.setenv("PBN_SWEEP_COUNT_REDO", "1")
-    for n, expect in ((250_000, True), (60_000, False)):
+    for n, expect in ((900_000, True), (250_000, False)):
         a = rng.normal(size=n)
         df = pd.DataFrame({"a": a, "b": 0.6 * a + rng.normal(scale=0.7, size=n)})
         _pairs(lib, reset=True)
