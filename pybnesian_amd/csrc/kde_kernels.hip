@@ -675,14 +675,16 @@ __device__ __forceinline__ bool batch_in_reach(BP bb, BP qbox, int pd, double th
 }
 
 // ... and with the MOMENT pass (round 5): `mom` = the (tile, group) pairs whose contribution is taken from the tile's moments instead
-// (kde_moment_group_kernel).  The tile's rows are z_t = c + delta_t, |delta_t| <= rho; for a query at u = z_q - c the tile adds
-// 2^(-|u|^2 / 2) sum_t 2^(-|delta_t|^2 / 2) e^(a u.delta_t), a = ln 2, and e^(a u.delta) is replaced by its Taylor polynomial of order P.  The
-// relative error of the tile's contribution is at most R_P(w) = w^(P+1) / (P+1)! e^w with w = a |u| rho (|u| <= the largest distance between the
-// two boxes); a tile whose terms lie 2^E below the group's sum bound may therefore be expanded when E + log2 R_P(w) <= -(margin + PBN_MOM_EXTRA): all
-// expanded tiles together then err by at most N 2^-(margin + extra) of a sum - a quarter of what pruning may drop.  The bound is proved,
-// the realised error is 5-6 orders smaller (tools/moment_prototype.py: 2e-13 of a sum on C3's folds).  Near tiles qualify through small
-// |u|, far ones through small terms; the middle distances are what stays with the sweep (12-15 % of the pairs at C3's density).
-// Both kernels classify with this one function on the same inputs, so every (tile, group) pair is taken by exactly one of them.
+// (kde_moment_group_kernel).  The tile's rows are z_t = c + delta_t, |delta_t| <= rho; for a query at u = z_q - c a row's term is
+// 2^(-|u|^2 / 2) 2^(-|delta_t|^2 / 2) e^(s_t), s_t = a u.delta_t, a = ln 2, and e^s is replaced by its Taylor polynomial T_P(s).  By Lagrange's
+// remainder |e^s - T_P(s)| <= |s|^(P+1) / (P+1)! max(1, e^s), so the row's error is at most |s|^(P+1) / (P+1)! times the larger of its own term
+// and 2^(-|u|^2 / 2 - |delta_t|^2 / 2) - and BOTH are at most 2^(-d2min / 2), d2min the smallest distance between the tile's and the group's box (the
+// centroid lies in the tile's box).  With |s| <= w = a |u|max rho (|u|max: the largest distance between the two boxes) a tile whose terms lie 2^E below the
+// group's sum bound may therefore be expanded when E + log2(w^(P+1) / (P+1)!) <= -(margin + PBN_MOM_EXTRA): all expanded tiles together then err by at
+// most N 2^-(margin + extra) of a sum - a quarter of what pruning may drop.  The bound is proved, the realised error is 5-6 orders smaller
+// (tools/moment_prototype.py: 2e-13 of a sum on C3's folds).  Near tiles qualify through small |u|, far ones through small terms; the middle
+// distances are what stays with the sweep.  Both kernels classify with this one function on the same inputs, so every (tile, group) pair is
+// taken by exactly one of them.
 #ifndef PBN_MOM_EXTRA
 #define PBN_MOM_EXTRA 2.0
 #endif
@@ -709,10 +711,10 @@ __device__ __forceinline__ unsigned long long prune_group_mask3(BP tile_box, BP 
         const double ex = -0.5 * d2;
         keep = !(ex < thr);
         kn = !(ex < thr_near);
-        // w = ln 2 * |u|max * rho, rounded up; log2 R_8(w) = 9 log2 w - log2 9! + w log2 e (v_sqrt_f32 / v_log_f32: 1 ulp, covered by the + 0.02)
+        // w = ln 2 * |u|max * rho, rounded up; log2(w^9 / 9!) = 9 log2 w - log2 9! (v_sqrt_f32 / v_log_f32: 1 ulp, covered by the + 0.02)
         const float w = 0.69314724f * __builtin_amdgcn_sqrtf((float)f2 * 1.000001f * rad2[t]) * 1.000001f;
-        const float logr = (float)(PBN_MOM_ORDER + 1) * __builtin_amdgcn_logf(w) - PBN_MOM_LOG2_FACT + 1.4426951f * w + 0.02f;
-        km = keep && w < 4.0f && ((double)logr + ex <= thr_mom);
+        const float logr = (float)(PBN_MOM_ORDER + 1) * __builtin_amdgcn_logf(w) - PBN_MOM_LOG2_FACT + 0.02f;
+        km = keep && ((double)logr + ex <= thr_mom);
     }
     near = __ballot(kn);
     mom = __ballot(km);

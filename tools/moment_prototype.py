@@ -60,8 +60,8 @@ for pair in sys.argv[3:]:
         E = -0.5 * d2min[cand] - thr
         inside = E > -marg
         w = A * np.sqrt(d2max[cand]) * rho[cand]
-        logR = (P + 1) * np.log2(np.maximum(w, 1e-300)) - math.log2(math.factorial(P + 1)) + w * np.log2(np.e)
-        ok = inside & (E + logR <= -marg)
+        logR = (P + 1) * np.log2(np.maximum(w, 1e-300)) - math.log2(math.factorial(P + 1))   # (Lagrange remainder; the e^s factor is inside the term bound 2^E)
+        ok = inside & (E + logR <= -(marg + 2))
         u = q[:, None, :] - cen[cand][None]                                        # [query, tile, 2]
         poly = sum(coef[cand][None, :, k] * u[:, :, 0] ** a * u[:, :, 1] ** b for k, (a, b) in enumerate(alphas))
         approx_tile = np.exp2(-0.5 * (u ** 2).sum(2)) * poly
