@@ -2559,6 +2559,39 @@ void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int z
     hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ceil_div(ceil_div(n, 16) * 16, 256)), dim3(256), 0, st, zrow, perm, n, zd, pd, box, zsorted);
     HIP_CHECK(hipGetLastError());
 }
+// one 64-lane block per (split, batch): the bounding box of up to 64 tile boxes (the first level of the pruned sweeps' tile walk)
+__global__ __launch_bounds__(64) void batch_box_kernel(const double* __restrict__ tile_box, int pd, int64_t ntiles, int64_t tps, int nbps, double* __restrict__ out) {
+    const int split = blockIdx.x / nbps, k = blockIdx.x - split * nbps;
+    const int64_t t0 = (int64_t)split * tps, t1 = t0 + tps < ntiles ? t0 + tps : ntiles;
+    const int64_t t = t0 + 64 * (int64_t)k + (int)threadIdx.x;
+    double lo[PBN_PRUNE_PD], hi[PBN_PRUNE_PD];
+#pragma unroll
+    for (int i = 0; i < PBN_PRUNE_PD; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+    if (t < t1) {
+        const double* bx = tile_box + t * 2 * pd;
+#pragma unroll
+        for (int i = 0; i < PBN_PRUNE_PD; ++i)
+            if (i < pd) { lo[i] = bx[i]; hi[i] = bx[pd + i]; }
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < PBN_PRUNE_PD; ++i) {
+            const double l = __shfl_xor(lo[i], off), h = __shfl_xor(hi[i], off);
+            lo[i] = l < lo[i] ? l : lo[i];
+            hi[i] = h > hi[i] ? h : hi[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        double* bb = out + (int64_t)blockIdx.x * 2 * pd;
+        for (int i = 0; i < pd; ++i) { bb[i] = lo[i]; bb[pd + i] = hi[i]; }
+    }
+}
+void launch_batch_boxes(const double* tile_box, int pd, int64_t ntiles, int64_t tiles_per_split, int nsplit, double* out, hipStream_t st) {
+    const int nbps = (int)ceil_div(tiles_per_split, 64);
+    if (ntiles == 0 || nsplit <= 0) return;
+    hipLaunchKernelGGL(batch_box_kernel, dim3((unsigned)((int64_t)nsplit * nbps)), dim3(64), 0, st, tile_box, pd, ntiles, tiles_per_split, nbps, out);
+    HIP_CHECK(hipGetLastError());
+}
 void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq, const uint32_t* qkeys_sorted, const double* ztrain_sorted,
                           const uint32_t* tkeys_sorted, int64_t n, int zd, int pd, double* qbox, double* qthr, double* qlb, hipStream_t st,
                           const double* subpart, int P, int which, double log2_nsub, const double* tile_box) {

@@ -98,8 +98,8 @@ struct SweepArgs {
     // bound is left to the moment pass (kde_moment_group_kernel) by the sweep; null = off.
     const float* tile_rad2;
     const double* tile_mom;
-    // Batch boxes (round 5, grouped sweeps): the bounding box of every 64-tile batch of a split - [split * batches_per_split + k][2 * pdims] -
-    // lets a wave drop a batch for a query group with ONE uniform test before it loads and tests the 64 tile boxes; null = off.
+    // Batch boxes (round 5, pruned fp64 plain sweeps): the bounding box of every 64-tile batch of a split - [split * batches_per_split + k][2 * pdims].
+    // A wave classifies 64 BATCHES with one ballot (lane = batch) before it loads and tests the tile boxes of the batches in reach; null = off.
     const double* batch_box;
     int batches_per_split;
     // (Measured and dropped, round 5: a bitmap written by the moment pass - the batches that still hold pairs for the sweep, 24 % of the
@@ -153,6 +153,8 @@ bool sweep_weights_norm(int dtype, bool cond, int KS, int dm); // see SweepArgs:
 // spatial sort + bounding boxes + exponent bounds of the pruned sweeps (SweepArgs::prune)
 void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zrow, uint32_t* keys, int32_t* iota, hipStream_t st);
 void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st);
+// boxes of the 64-tile batches of every split of a pruned sweep (SweepArgs::batch_box): out[(split * batches_per_split + k)][2 * pd]
+void launch_batch_boxes(const double* tile_box, int pd, int64_t ntiles, int64_t tiles_per_split, int nsplit, double* out, hipStream_t st);
 // subpart (nullable): per query (in sorted order) the (offset, sum) partials of a sweep over a subsample of nsub training rows,
 // P doubles per query, the pair to use at [which]: offset + log2(sum) - log2(nsub) is a second lower bound of the query's
 // largest exponent

@@ -463,7 +463,13 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     nsplit = std::min<int64_t>(nsplit, 4096);
     const int64_t tps = ceil_div(m.ntiles, nsplit);
     nsplit = ceil_div(m.ntiles, tps);
-    ctx->scratch_part.reserve((size_t)nsplit * nqtiles * 16 * P * sizeof(double));
+    // pruned fp64 plain sweeps with per-group masks walk their tiles in two levels (kde_sweep_body): the boxes of the 64-tile batches of every split,
+    // behind the partials (they depend on the split size, which depends on the number of queries)
+    static const int gmasks = PBN_TUNE(PRUNE_GROUP_MASKS, 1);
+    const bool bboxes = m.prune && gmasks && !m.cond && fdt == PBN_F64 && PBN_TUNE(GROUP_BATCH_BOXES, 1) != 0;
+    const size_t part_b = ((size_t)nsplit * nqtiles * 16 * P * sizeof(double) + 255) / 256 * 256;
+    const size_t bbox_b = bboxes ? (size_t)nsplit * ceil_div(tps, 64) * 2 * m.pdims * sizeof(double) : 0;
+    ctx->scratch_part.reserve(part_b + bbox_b);
     SweepArgs sa{};
     sa.Apack = m.Apack; sa.nxpack = m.nxpack; sa.Axpack = m.Axpack;
     sa.Bpack = pa.pack; sa.nypack = pa.npack; sa.Bxpack = pa.xpack; sa.Bxnorm = pa.xnorm;
@@ -475,8 +481,12 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, sum_only); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
-    static const int gmasks = PBN_TUNE(PRUNE_GROUP_MASKS, 1);
     sa.group_masks = gmasks;
+    if (bboxes) {
+        double* bb = (double*)((char*)ctx->scratch_part.p + part_b);
+        launch_batch_boxes(m.tile_box, m.pdims, m.ntiles, tps, (int)nsplit, bb, ctx->stream);
+        sa.batch_box = bb; sa.batches_per_split = (int)ceil_div(tps, 64);
+    }
     static const bool log_sweeps = PBN_TUNE(SWEEP_LOG, 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
     if (log_sweeps) std::fprintf(stderr, "pbn-sweep N=%lld n=%lld d=%d cond=%d prune=%d nsub=%lld nsplit=%lld\n", (long long)m.N, (long long)n, m.d, (int)m.cond, (int)m.prune, (long long)(m.prune ? m.nsub : 0), (long long)nsplit);
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, fdt, m.KS, m.cond, (int)nsplit, ctx->stream); }
