@@ -109,3 +109,27 @@ def test_shipped_rule_takes_dense_folds_only(monkeypatch):
         off = _score(df, ["b", "a"], 2, 0)
         monkeypatch.delenv("PBN_MOMENT_PASS")
         assert abs(on - off) <= 3e-7 * abs(off)
+
+
+@pytest.mark.parametrize("moments", ["0", "1"])
+def test_splits_longer_than_one_super_batch(moments, monkeypatch):
+    """The two-level walk classifies 64 batches (4 096 tiles) per ballot.  A split of 9 375 tiles is three such super-batches, the last one partly
+    filled: the same sums in another partition - the scores of the shipped split size and of ONE split per unit agree to rounding, with and
+    without the moment pass, for one, two and three variables."""
+    rng = np.random.default_rng(17)
+    n = 300_000
+    a = rng.normal(size=n)
+    b = np.tanh(a) + 0.4 * rng.normal(size=n)
+    c = 0.5 * a - 0.3 * b + rng.normal(scale=0.8, size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c})
+    monkeypatch.setenv("PBN_MOMENT_PASS", moments)
+    monkeypatch.setenv("PBN_MOMENT_MIN_ROWS", "0")
+    for cols in (["a"], ["b", "a"], ["c", "a", "b"]):
+        base = _score(df, cols, 2, 1)
+        monkeypatch.setenv("PBN_GROUP_SPLIT_TILES", "16384")
+        one = _score(df, cols, 2, 1)
+        monkeypatch.setenv("PBN_GROUP_SPLIT_TILES", "5000")    # two splits, the second one 4 375 tiles: a second super-batch with 5 batches
+        two = _score(df, cols, 2, 1)
+        monkeypatch.delenv("PBN_GROUP_SPLIT_TILES")
+        assert abs(one - base) <= 1e-11 * abs(base), (cols, one, base)
+        assert abs(two - base) <= 1e-11 * abs(base), (cols, two, base)
