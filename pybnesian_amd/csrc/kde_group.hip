@@ -52,7 +52,7 @@ struct GDev {   // argument block of the block-wise kernels
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
-    int hilbert;                   // two key dimensions: Hilbert order instead of Z-order (group_keys_kernel)
+    int hilbert;                   // Hilbert order instead of Z-order: 1 = at two key dimensions, 2 = at three and four as well (group_keys_kernel)
     int fine_keys;                 // 1-2 key dimensions: cells of sigma / 4096 (256) instead of sigma / 16 (group_keys_kernel)
     int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
 };
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(GB) void group_keys_kernel(GDev g) {
                 const uint32_t tmp = x; x = y; y = tmp;
             }
         }
+    } else if (kd >= 3 && g.hilbert >= 2) {
+        key = hilbert_key(cells, kd, bits);   // three / four key dimensions (8 / 6 bits per axis): the same curve in its n-dimensional form
     } else {
         for (int i = 0; i < kd; ++i)
             for (int b = 0; b < bits; ++b) key |= ((cells[i] >> b) & 1u) << (b * kd + i);
@@ -809,7 +811,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.tile_window = tile_window;
     static const int fine_keys = PBN_TUNE(GROUP_FINE_KEYS, 1);
     g.fine_keys = fine_keys;
-    static const int hilbert = PBN_TUNE(GROUP_HILBERT, 1);
+    static const int hilbert = PBN_TUNE(GROUP_HILBERT, 2);   // 1: two key dimensions only, 2: three and four as well
     g.hilbert = hilbert;
     static const int window = std::max(1, PBN_TUNE(GROUP_WINDOW, PBN_GROUP_WINDOW));
     g.window = window;

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void max_norm2_kernel(PackArgs a, unsigned lon
 // T = fragment type (the rounding the keys see), TS = element type of the table
 template <typename T, typename TS = T>
 __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int kd, double* __restrict__ zrow, uint32_t* __restrict__ keys,
-                                                         int32_t* __restrict__ iota, double inv_cell) {
+                                                         int32_t* __restrict__ iota, double inv_cell, int hilbert_nd) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= a.n) return;
     const int d = a.d;
@@ -387,8 +387,9 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
     double xc[PBN_MAX_D];
     for (int j = 0; j < d; ++j) xc[j] = (double)((const TS*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
     uint32_t key = 0;
-    uint32_t cells[2] = {0, 0};
+    uint32_t cells[4] = {0, 0, 0, 0};
     const int bits = prune_key_bits(kd);
+    const bool curve = kd == 2 || (hilbert_nd && (kd == 3 || kd == 4));
     for (int i = 0; i < zd; ++i) {
         double z = 0.0;
         const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
             double c = __builtin_floor(z * inv_cell) + half;
             c = c < 0.0 ? 0.0 : (c > top ? top : c);
             const uint32_t cell = (uint32_t)c;
-            if (kd == 2) cells[i] = cell;
+            if (curve) cells[i] = cell;
             else for (int b = 0; b < bits; ++b) key |= ((cell >> b) & 1u) << (b * kd + i);   // Morton interleave
         }
     }
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void prune_keys_kernel(PackArgs a, int zd, int
             }
         }
     }
+    if (curve && kd > 2) key = hilbert_key(cells, kd, bits);   // three / four key dimensions: the n-dimensional form of the same curve
     keys[r] = key;
     iota[r] = (int32_t)r;
 }
@@ -2549,9 +2551,10 @@ void launch_prune_keys(const PackArgs& a, int dtype, int zd, int kd, double* zro
     if (a.n == 0) return;
     const dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
     const double inv_cell = 1.0 / prune_key_cell(kd);
-    if (dtype == PBN_F64 && a.src_f32) hipLaunchKernelGGL((prune_keys_kernel<double, float>), grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell);
-    else if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell);
-    else hipLaunchKernelGGL(prune_keys_kernel<float>, grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell);
+    static const int hnd = PBN_TUNE(PRUNE_HILBERT_ND, 1);   // Hilbert order at three / four key dimensions too (two: always)
+    if (dtype == PBN_F64 && a.src_f32) hipLaunchKernelGGL((prune_keys_kernel<double, float>), grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell, hnd);
+    else if (dtype == PBN_F64) hipLaunchKernelGGL(prune_keys_kernel<double>, grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell, hnd);
+    else hipLaunchKernelGGL(prune_keys_kernel<float>, grid, block, 0, st, a, zd, kd, zrow, keys, iota, inv_cell, hnd);
     HIP_CHECK(hipGetLastError());
 }
 void launch_tile_boxes(const double* zrow, const int32_t* perm, int64_t n, int zd, int pd, double* box, double* zsorted, hipStream_t st) {

@@ -107,6 +107,31 @@ struct SweepArgs {
     double* part;  // [nsplit][nqtiles*16][P]
 };
 
+// Position along the Hilbert curve of a cell in n = 2 ... 4 dimensions, `bits` bits per axis (Skilling's transpose form: undo the excess rotations
+// from the top bit down, Gray-encode, interleave with axis 0 most significant) - consecutive keys are neighbouring cells, so 16 consecutive rows of
+// the sorted order form a compact tile where the Z-order jumps at every power-of-two boundary.  Used for the pruned sweeps' row order only:
+// nothing numeric depends on it.  X is overwritten.
+__host__ __device__ inline uint32_t hilbert_key(uint32_t* X, int n, int bits) {
+    const uint32_t M = 1u << (bits - 1);
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+        for (int i = 0; i < n; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    for (int i = 1; i < n; ++i) X[i] ^= X[i - 1];
+    uint32_t t = 0;
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[n - 1] & Q) t ^= Q - 1;
+    uint32_t key = 0;
+    for (int i = 0; i < n; ++i) {
+        X[i] ^= t;
+        for (int q = 0; q < bits; ++q) key |= ((X[i] >> q) & 1u) << (q * n + (n - 1 - i));
+    }
+    return key;
+}
+
 // Tile-moment expansions: order and record layout.  Per tile NREC = D + ncoef doubles - the centroid, then the coefficients in the order the
 // Horner scheme of kde_moment_group_kernel reads them (D = 2: j = 8 ... 0; within j, i = 8 - j ... 0) - stored STRUCTURE-OF-ARRAYS: value k of
 // tile t at mom[k * stride + t] (stride = tiles rounded up to 64), so that the 64 lanes of a wave, one tile each, load a value of 64

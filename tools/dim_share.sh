@@ -1,7 +1,7 @@
 # where the grouped sweeps' time goes by dimension of the term (experiments build, PBN_SWEEP_LOG=1: one line per grouped sweep launch)   bash tools/dim_share.sh
 cd $GRAFT_REPO_ROOT
 export PBN_LIB=$GRAFT_REPO_ROOT/pybnesian_amd/libpbn_hip_exp.so PBN_SWEEP_LOG=1
-for leg in "cv64 1" "c3 1" "c3 6" "c5mmhc 1000000"; do
+for leg in ${LEGS:-"cv64 1" "c3 1" "c3 6" "c5mmhc 1000000"}; do
   set -- $leg
   python3 bench.py --no-c3 --no-e2e --no-cpu-baseline --no-extra-legs --hc $1 --hc-max-iters $2 --steps 1 --warmup 1 2>gpurun_out/dim_share.err >/dev/null
   python3 - "$leg" <<'PY'
