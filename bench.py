@@ -452,13 +452,6 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
     kt = {name: sctx.kernel_time(cls) for name, cls in (("sweep", _lib.PBN_K_SWEEP), ("gram", _lib.PBN_K_GRAM))}
     sctx.set_profiling(False)
     more = dict(extra) if which == "c5mmhc" else {}
-    handle = getattr(score, "_handle", None)
-    if handle is not None and which != "c4":
-        # terms the engine evaluated a second time: sums that cancel to ~0 (per-row accuracy) / units whose a-posteriori pruning radius failed its proof
-        import ctypes as C
-        pr, dr = C.c_int64(0), C.c_int64(0)
-        if _lib.load().pbn_debug_scoredata_redos(C.c_void_p(handle) if isinstance(handle, int) else handle, C.byref(pr), C.byref(dr)) == 0:
-            more["redone_terms"] = {"near_zero_sum": pr.value, "dropped_mass_over_budget": dr.value}
     if which != "c4":
         # the leg's dominant kernel and its share of the timed search, from the library's own HIP events (no profiler)
         kname = {"c3": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only) + kde_moment_group_kernel<1 | 2> "

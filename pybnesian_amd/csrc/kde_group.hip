@@ -52,7 +52,6 @@ struct GDev {   // argument block of the block-wise kernels
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
     unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
-    double* out_drop;              // nullable: [sum_slot] log2 of the worst (dropped-mass bound / budget) of a unit's queries (a-posteriori radius)
     int hilbert;                   // Hilbert order instead of Z-order: 1 = at two key dimensions, 2 = at three and four as well (group_keys_kernel)
     int fine_keys;                 // 1-2 key dimensions: cells of sigma / 4096 (256) instead of sigma / 16 (group_keys_kernel)
     int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
@@ -605,7 +604,7 @@ __global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
     const GUnit& U = g.units[blockIdx.y];
     if (blockIdx.x * 256 >= U.nq) return;
     const int q = blockIdx.x * 256 + (int)threadIdx.x;
-    double val = 0.0, viol = -INFINITY;
+    double val = 0.0;
     if (q < U.nq) {
         const double* p = (const double*)(g.arena + U.part) + (int64_t)q * 2;
         const int64_t stride = (int64_t)U.nqtiles * 16 * 2;
@@ -615,14 +614,6 @@ __global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
 #pragma unroll 4
         for (int sp = 0; sp < U.nsplit_fin; ++sp) { const double* pp = p + sp * stride; s += pp[1] * exp2(pp[0] - m); }
         val = U.lognorm + LN2 * (m + log2(s));
-        if (U.drop) {
-            // a-posteriori radius: what the sweeps dropped for this query's group, summed over the splits (units of 2^(thr - rmargin) per tile),
-            // against the query's own sum: log2(16 rows D 2^(thr - rmargin)) - log2(budget x sum) = log2 D + thr + drop_scale - log2 sum
-            const float* dp = (const float*)(g.arena + U.drop) + (q >> 4);
-            float D = 0.f;
-            for (int sp = 0; sp < U.nsplit; ++sp) D += dp[(int64_t)sp * U.nqtiles];
-            if (D > 0.f) viol = log2((double)D * 1.01) + ((const double*)(g.arena + U.qthr))[q >> 4] + U.drop_scale - (m + log2(s));
-        }
     }
     __shared__ double red[256];
     red[threadIdx.x] = val;
@@ -633,17 +624,6 @@ __global__ __launch_bounds__(256) void group_finish_kernel(GDev g) {
         __syncthreads();
     }
     if (threadIdx.x == 0) ((double*)(g.arena + U.bsum))[blockIdx.x] = red[0];
-    if (U.drop) {   // (uniform per block)
-        __syncthreads();
-        red[threadIdx.x] = viol;
-        __syncthreads();
-#pragma unroll
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) ((double*)(g.arena + U.bmax))[blockIdx.x] = red[0];
-    }
 }
 
 __global__ __launch_bounds__(256) void group_reduce_kernel(GDev g, double* out) {
@@ -661,23 +641,6 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(GDev g, double* out) 
         __syncthreads();
     }
     if (threadIdx.x == 0) out[U.sum_slot] = red[0];
-    if (g.out_drop) {
-        double w = -INFINITY;
-        if (U.drop) {
-            const double* im = (const double*)(g.arena + U.bmax);
-            for (int i = threadIdx.x; i < n; i += 256) w = im[i] > w ? im[i] : w;
-            if (w != w) w = INFINITY;   // a NaN is a violation
-        }
-        __syncthreads();
-        red[threadIdx.x] = w;
-        __syncthreads();
-#pragma unroll
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) g.out_drop[U.sum_slot] = red[0];
-    }
 }
 
 size_t al256(size_t x) { return (x + 255) / 256 * 256; }
@@ -704,7 +667,7 @@ int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 400000); }
 
 // one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
 void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out,
-               double* dev_out_max, bool force_f64, double* dev_out_drop) {
+               double* dev_out_max, bool force_f64) {
     const int np = (int)(p1 - p0);
     // ---- layout ----------------------------------------------------------------------------------------------------------
     std::vector<GPool> pools(np);
@@ -743,11 +706,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     bool dense = true;
     for (const GUnit& U : units) dense = dense && U.N >= moment_pass_rows();
     const bool moments = !bf16 && d0 <= 2 && dense && knob_int("PBN_MOMENT_PASS", 1) != 0 && PBN_TUNE(PRUNE_GROUP_MASKS, 1) != 0;
-    // A-posteriori radius (round 5): callers that can re-evaluate a unit hand in dev_out_drop; the sweeps then prune PBN_MARGIN_CUT bits inside the
-    // a-priori margin and prove per query that what they dropped stays inside the same budget (0 = off; pinned margins are taken as they are)
-    const double margin_cut = (dev_out_drop && !bf16 && PBN_TUNE(PRUNE_GROUP_MASKS, 1) != 0 && knob_double("PBN_PRUNE_MARGIN", 0.0) <= 0.0)
-                                  ? std::max(0.0, knob_double("PBN_MARGIN_CUT", 10.0)) : 0.0;
-    const bool drops = margin_cut > 0.0;
     const bool bboxes = !bf16 && PBN_TUNE(GROUP_BATCH_BOXES, 1) != 0;   // fp64 sweeps with per-group masks: one uniform test per (batch, group) first
     int64_t total_wg = 0;
     int max_ntiles = 0, max_nqtiles = 0, max_nq = 0, max_nbatch = 1;
@@ -786,10 +744,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         U.qlb = carve((size_t)U.nqtiles * 16 * 8);
         U.nsplit_fin = moments ? 2 * U.nsplit : U.nsplit;   // the moment pass's partials behind the sweep's
         U.part = carve((size_t)U.nsplit_fin * U.nqtiles * 16 * 2 * 8);
-        // (the a-priori margin cancels: kept radius margin - cut, budget N 2^-margin of a sum -> 16 D 2^(thr + cut) / (N sum))
-        U.drop_scale = 4.0 + margin_cut - std::log2((double)std::max(1, U.N));
-        U.drop = drops ? carve((size_t)U.nsplit * U.nqtiles * 4) : 0;
-        U.bmax = drops ? carve((size_t)((U.nq + 255) / 256 + 1) * 8) : 0;
         U.bbox = bboxes ? carve((size_t)U.nsplit * ((U.tps + 63) / 64) * 2 * pd * 8) : 0;
         U.mom = moments ? carve((size_t)((U.ntiles + 63) / 64 * 64) * pbn_mom_rec(d) * 8) : 0;
         U.rad2 = moments ? carve((size_t)U.ntiles * 4) : 0;
@@ -818,7 +772,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.tile_box = (const double*)(arena + U.box); s.qtile_box = (const double*)(arena + U.qbox);
         s.qtile_thr = (const double*)(arena + U.qthr); s.qlb = (const double*)(arena + U.qlb);
         s.part = (double*)(arena + U.part); s.wg0 = U.wg0;
-        s.drop = drops ? (float*)(arena + U.drop) : nullptr;
         s.batch_box = bboxes ? (const double*)(arena + U.bbox) : nullptr; s.nbps = (U.tps + 63) / 64;
         s.tile_rad2 = moments ? (const float*)(arena + U.rad2) : nullptr;
         s.tile_mom = moments ? (const double*)(arena + U.mom) : nullptr;
@@ -854,7 +807,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.use_sum_bound = sum_bound;
     g.bf16 = bf16 ? 1 : 0; g.KS = KS;
     g.out_max = bf16 ? (unsigned long long*)dev_out_max : nullptr;
-    g.out_drop = drops ? dev_out_drop : nullptr;
     static const int tile_window = std::max(0, PBN_TUNE(GROUP_TILE_WINDOW, 256));
     g.tile_window = tile_window;
     static const int fine_keys = PBN_TUNE(GROUP_FINE_KEYS, 1);
@@ -902,7 +854,6 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         hipEvent_t le0 = nullptr, le1 = nullptr;
         if (log_chunks) { HIP_CHECK(hipEventCreate(&le0)); HIP_CHECK(hipEventCreate(&le1)); HIP_CHECK(hipEventRecord(le0, st)); }
         sa.moments = moments ? 1 : 0;
-        sa.margin_cut = margin_cut;
         launch_sweep_grouped(sa, fdt, KS, st);
         if (moments) launch_moment_grouped(sa, d0, st);
         if (log_chunks) {
@@ -933,7 +884,7 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P) {
         const size_t nt = (U.N + 15) / 16, nqt = (U.nq + 15) / 16, split_tiles = (size_t)split_tiles_for((int)nt, /*the finer rule: an upper bound for both*/ false), nsplit = std::max<size_t>(1, (nt + split_tiles - 1) / split_tiles);
         s += nt * KS * 1024 + nt * 256 + (nt + nqt) * 2048 + nqt * 64 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
              nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 * (d <= 2 ? 2 : 1) + (d <= 2 ? (nt + 64) * (pbn_mom_rec(d <= 1 ? 1 : 2) * 8 + 4) + 512 : 0) +
-             (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) + (nsplit + 1) * ((nt / nsplit + 127) / 64) * 2 * pd * 8 + 256 + (nsplit + 1) * nqt * 4 + nqt / 16 * 8 + 1024 +
+             (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) + (nsplit + 1) * ((nt / nsplit + 127) / 64) * 2 * pd * 8 + 256 +
              (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
     }
     return s;
@@ -956,7 +907,7 @@ bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
            R <= PBN_GROUP_MAX_R && kde_prune_applies(dtype, d, n_min);
 }
 
-void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max, bool force_f64, double* dev_out_drop) {
+void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max, bool force_f64) {
     if (b.pools.empty()) return;
     if (!force_f64 && t->dtype != PBN_F64 && !use_bf16x3(t->dtype)) throw invalid_error("grouped KDE evaluation: fp64 tables, or fp32 tables on the bf16 matrix cores");
     HIP_CHECK(hipSetDevice(ctx->device));
@@ -998,7 +949,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
             elems += b.pools[order[p1]].n;
             ++p1;
         }
-        run_chunk(ctx, t, b, order, p0, p1, dev_out_sums, dev_out_max, force_f64, dev_out_drop);
+        run_chunk(ctx, t, b, order, p0, p1, dev_out_sums, dev_out_max, force_f64);
         p0 = p1;
     }
 }

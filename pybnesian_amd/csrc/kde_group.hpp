@@ -54,11 +54,9 @@ struct GUnit {
     int64_t wg0;           // first flat sweep workgroup
     // byte offsets into the batch arena
     int64_t apack, npack, zs, box, bpack, ny, zq, qpos, qbox, qthr, qlb, part, bsum;
-    int64_t drop, bmax;              // dropped-mass bounds [nsplit][nqtiles] floats; per finish block the worst (bound / budget) of its queries
     int64_t bbox;                    // boxes of the 64-tile batches of every split (sweeps: one uniform test per batch before the 64 tile tests)
     int64_t mom, rad2;               // tile-moment records / squared tile radii (0 = the chunk does not take the moment pass)
     int32_t nsplit_fin, pad2_;       // split partials per query the finish merges (2 x nsplit with a moment pass: its partials behind the sweep's)
-    double drop_scale;               // a-posteriori radius: log2 of (16 rows x 2^-(margin - cut) / budget), budget = N 2^-margin of a sum (group_finish_kernel)
     double lognorm;
     double W[PBN_GROUP_MAX_D * PBN_GROUP_MAX_D];    // whitening, row-major lower, base-2 units (kde_prepare)
     double mu[PBN_GROUP_MAX_D];
@@ -77,11 +75,7 @@ struct GroupBatch {
 // dev_out_max (nullable, fp32 tables on bf16x3 fragments): dev_out_max[unit.sum_slot] receives |z|^2 of the unit's farthest whitened
 // training row, as the bits of a non-negative double (atomic max: the caller zeroes it) - the caller re-evaluates the units that
 // kde_wants_widening() flags with force_f64 = true: fp64 fragments and fp64 sweeps on the float columns (KdeModel::widen).
-// dev_out_drop (nullable, fp64 fragments): switches the A-POSTERIORI pruning radius on - the sweeps keep the tiles within margin - PBN_MARGIN_CUT of the
-// sum bound, add up a bound of everything they drop and dev_out_drop[unit.sum_slot] receives log2 of the worst (dropped bound / budget) over the unit's
-// queries: a value > 0 means the unit must be evaluated again with the a-priori margin (the per-unit chain does that); <= 0 proves the budget held.
-void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max = nullptr, bool force_f64 = false,
-                   double* dev_out_drop = nullptr);
+void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max = nullptr, bool force_f64 = false);
 
 // Arena bytes one chain may take (PBN_GROUP_ARENA_MB) and the bytes a pool with its units needs: a caller that collects pools over many
 // candidates hands them over about an arena-full at a time.
@@ -109,7 +103,6 @@ struct GSweepUnit {
     int64_t wg0;
     int32_t ntiles, nqtiles, tps, nsplit, nwg, pdims;
     float margin;         // the unit's pruning margin (prune_margin(dtype, training rows))
-    float* drop;          // a-posteriori radius: dropped-mass bounds per (split, query group), SweepArgs::drop
     int32_t nbps;         // 64-tile batches per split (batch_box rows per split)
     const double* batch_box;
     int32_t mom_stride;   // doubles between consecutive values of the tile-moment records (tiles rounded up to 64)
@@ -122,7 +115,6 @@ struct GSweepArgs {
     int moments;           // the units carry tile-moment records and the moment pass runs before the sweep (kde_sweep_group_kernel<..., MOM = true>)
     double prune_margin;   // > 0: one margin for every unit of the launch; 0: the units' own
     double far_span;       // SweepArgs::far_span of every unit of the launch
-    double margin_cut;     // SweepArgs::margin_cut (a-posteriori radius; 0 = the a-priori margin alone)
 };
 void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st);
 // the moment pass of the same units (same flat workgroup table): d = 1 or 2, fp64 sum-only

@@ -616,10 +616,8 @@ __device__ __forceinline__ unsigned long long prune_visit_mask(BP tile_box, int 
 // order, and the box of all of them is up to twice as wide per axis as a group's own - at 3-4 dimensions, where a wave's box is
 // as wide as the kernel's support, a third of the (tile, group) pairs of a visited tile lie beyond the group's own support.  The
 // boxes are re-read per group (uniform addresses: scalar loads; the tile's box from L1) so that no box stays in registers.
-// `dacc` (every form below): the lane's running upper bound of what the sweep drops for this group, in units of 2^(thr): a tile that fails the
-// test adds 2^(ex - thr) < 1 (SweepArgs::drop)
 template <typename BP>
-__device__ __forceinline__ unsigned long long prune_group_mask(BP tile_box, BP qbox, int pd, int64_t tb, int64_t t1, double thr, int lane, float& dacc) {
+__device__ __forceinline__ unsigned long long prune_group_mask(BP tile_box, BP qbox, int pd, int64_t tb, int64_t t1, double thr, int lane) {
     const int64_t t = tb + lane;
     bool keep = false;
     if (t < t1) {
@@ -634,7 +632,6 @@ __device__ __forceinline__ unsigned long long prune_group_mask(BP tile_box, BP q
                 d2 = __builtin_fma(g, g, d2);
             }
         keep = !(-0.5 * d2 < thr);
-        if (!keep) dacc += __builtin_amdgcn_exp2f((float)(-0.5 * d2 - thr));
     }
     return __ballot(keep);
 }
@@ -643,7 +640,7 @@ __device__ __forceinline__ unsigned long long prune_group_mask(BP tile_box, BP q
 // far tiles of the fp32 tail path)
 template <typename BP>
 __device__ __forceinline__ unsigned long long prune_group_mask2(BP tile_box, BP qbox, int pd, int64_t tb, int64_t t1, double thr, double thr_near, int lane,
-                                                                unsigned long long& near, float& dacc) {
+                                                                unsigned long long& near) {
     const int64_t t = tb + lane;
     bool keep = false, kn = false;
     if (t < t1) {
@@ -659,45 +656,12 @@ __device__ __forceinline__ unsigned long long prune_group_mask2(BP tile_box, BP 
             }
         keep = !(-0.5 * d2 < thr);
         kn = !(-0.5 * d2 < thr_near);
-        if (!keep) dacc += __builtin_amdgcn_exp2f((float)(-0.5 * d2 - thr));
     }
     near = __ballot(kn);
     return __ballot(keep);
 }
 
 // One uniform test per (64-tile batch, query group): does the batch's box come within the drop threshold of the group's box at all?
-template <typename BP>
-__device__ __forceinline__ double batch_exponent(BP bb, BP qbox, int pd) {   // the largest exponent a row of the batch can have against a query of the group
-    double d2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < PBN_PRUNE_PD; ++k)
-        if (k < pd) {
-            const double g1 = bb[k] - qbox[pd + k], g2 = qbox[k] - bb[pd + k];
-            double g = g1 > g2 ? g1 : g2;
-            g = g > 0.0 ? g : 0.0;
-            d2 = __builtin_fma(g, g, d2);
-        }
-    return -0.5 * d2;
-}
-// accounting-only visit of a batch that is out of a group's reach but near its boundary: every tile is dropped, each at its OWN box distance
-// (the batch's box would price them all at the batch's nearest corner: 10-16 bits too high at the boundary)
-template <typename BP>
-__device__ __forceinline__ float tile_drop(BP tile_box, BP qbox, int pd, int64_t tb, int64_t t1, double thr, int lane) {
-    const int64_t t = tb + lane;
-    if (t >= t1) return 0.f;
-    const BP bx = tile_box + t * 2 * pd;
-    double d2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < PBN_PRUNE_PD; ++k)
-        if (k < pd) {
-            const double g1 = bx[k] - qbox[pd + k], g2 = qbox[k] - bx[pd + k];
-            double g = g1 > g2 ? g1 : g2;
-            g = g > 0.0 ? g : 0.0;
-            d2 = __builtin_fma(g, g, d2);
-        }
-    const float e = (float)(-0.5 * d2 - thr);
-    return __builtin_amdgcn_exp2f(e < 0.f ? e : 0.f);
-}
 template <typename BP>
 __device__ __forceinline__ bool batch_in_reach(BP bb, BP qbox, int pd, double thr) {
     double d2 = 0.0;
@@ -728,7 +692,7 @@ __device__ __forceinline__ bool batch_in_reach(BP bb, BP qbox, int pd, double th
 #endif
 template <typename BP, typename RP>
 __device__ __forceinline__ unsigned long long prune_group_mask3(BP tile_box, BP qbox, RP rad2, int pd, int64_t tb, int64_t t1, double thr, double thr_near,
-                                                                double thr_mom, int lane, unsigned long long& near, unsigned long long& mom, float& dacc) {
+                                                                double thr_mom, int lane, unsigned long long& near, unsigned long long& mom) {
 #pragma clang fp contract(off)   // both kernels must take bit-identical decisions: no fused multiply-adds the inliner could place differently
     const int64_t t = tb + lane;
     bool keep = false, kn = false, km = false;
@@ -749,7 +713,6 @@ __device__ __forceinline__ unsigned long long prune_group_mask3(BP tile_box, BP 
         const double ex = -0.5 * d2;
         keep = !(ex < thr);
         kn = !(ex < thr_near);
-        if (!keep) dacc += __builtin_amdgcn_exp2f((float)(ex - thr));
         // w = ln 2 * |u|max * rho, rounded up; log2(w^9 / 9!) = 9 log2 w - log2 9! (v_sqrt_f32 / v_log_f32: 1 ulp, covered by the + 0.02)
         const float w = 0.69314724f * __builtin_amdgcn_sqrtf((float)f2 * 1.000001f * rad2[t]) * 1.000001f;
         const float logr = (float)(PBN_MOM_ORDER + 1) * __builtin_amdgcn_logf(w) - PBN_MOM_LOG2_FACT + 0.02f;
@@ -945,11 +908,6 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     // on N).  A batch redone by the checked loop takes every tile through the full path.
     constexpr bool FARP = GMASK && FOLD && EF32 && PBN_FAR_F32;
     static_assert(!MOM || FARP, "the moment pass stands beside the FARP shapes only");
-    // a-posteriori radius (SweepArgs::drop): tiles are kept within rmargin of the sum bound, what is dropped is added up per group (units of 2^(thr - rmargin))
-    const double rmargin = a.prune_margin - a.margin_cut;
-    float dacc[GMASK ? QG : 1];
-#pragma unroll
-    for (int g = 0; g < (GMASK ? QG : 1); ++g) dacc[g] = 0.f;
     unsigned long long gn[FARP ? QG : 1];
     float fs[FARP ? QG : 1];
 #pragma unroll
@@ -1067,7 +1025,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // Two levels: a SUPER-BATCH of 64 batches (4096 tiles) is classified first, lane = batch, against the batches' own boxes (grouped
         // sweeps: GSweepUnit::batch_box) - one round trip to L2 for 64 batches instead of one per batch, which is what the walk over a
         // split's tiles costs where most batches hold nothing for the wave (the test below is latency, not arithmetic).
-        auto do_batch = [&](const int64_t tb, const unsigned gsel, const unsigned gband) {
+        auto do_batch = [&](const int64_t tb, const unsigned gsel) {
             unsigned long long mask;
             if constexpr (GMASK) {
                 mask = 0;
@@ -1078,24 +1036,23 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                         if (!((gsel >> g) & 1u)) {   // the whole batch beyond this group's reach
                             gm[g] = 0;
                             if constexpr (FARP) gn[g] = ~0ull;
-                            if ((gband >> g) & 1u) dacc[g] += tile_drop(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - rmargin, lane);   // ... but near it: priced tile by tile
                             continue;
                         }
                         if constexpr (FARP) {
                             if constexpr (MOM) {   // the moment pass takes the pairs it can expand: this sweep skips them
                                 unsigned long long mx;
-                                gm[g] = prune_group_mask3(TBp, QBp + qt * 2 * pd, (const PBN_GLOBAL float*)a.tile_rad2, pd, tb, t1, QTp[qt] - rmargin,
+                                gm[g] = prune_group_mask3(TBp, QBp + qt * 2 * pd, (const PBN_GLOBAL float*)a.tile_rad2, pd, tb, t1, QTp[qt] - a.prune_margin,
                                                           a.far_span > 0.0 ? QTp[qt] - (a.prune_margin - a.far_span) : -INFINITY,
-                                                          QTp[qt] - (a.prune_margin + PBN_MOM_EXTRA), lane, gn[g], mx, dacc[g]);
+                                                          QTp[qt] - (a.prune_margin + PBN_MOM_EXTRA), lane, gn[g], mx);
                                 gm[g] &= ~mx;
                             } else if (a.far_span > 0.0) {
-                                gm[g] = prune_group_mask2(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - rmargin, QTp[qt] - (a.prune_margin - a.far_span), lane, gn[g], dacc[g]);
+                                gm[g] = prune_group_mask2(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, QTp[qt] - (a.prune_margin - a.far_span), lane, gn[g]);
                             } else {
-                                gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - rmargin, lane, dacc[g]);
+                                gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
                                 gn[g] = ~0ull;
                             }
                         } else {
-                            gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - rmargin, lane, dacc[g]);
+                            gm[g] = prune_group_mask(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, lane);
                         }
                         mask |= gm[g];
                     }
@@ -1143,9 +1100,9 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         };
         for (int64_t sb = t0; sb < t1; sb += 4096) {
             const int64_t bt = sb + 64 * lane;   // my batch's first tile
-            unsigned long long bm = __ballot(bt < t1), bmg[QG], bbg[QG];
+            unsigned long long bm = __ballot(bt < t1), bmg[QG];
 #pragma unroll
-            for (int g = 0; g < QG; ++g) { bmg[g] = bm; bbg[g] = 0; }
+            for (int g = 0; g < QG; ++g) bmg[g] = bm;
             if constexpr (GMASK) {
                 if ((MOM || a.group_masks) && a.batch_box) {
                     const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)a.batch_box + ((int64_t)split * a.batches_per_split + ((bt - t0) >> 6)) * 2 * pd;
@@ -1153,28 +1110,18 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                     for (int g = 0; g < QG; ++g) {
                         const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
-                        bool reach = false, band = false;
-                        if (bt < t1) {
-                            const double exb = batch_exponent(bb, QBp + qt * 2 * pd, pd), thb = QTp[qt] - rmargin;
-                            reach = !(exb < thb);
-                            // a whole batch beyond the group's reach: every one of its tiles is dropped.  Far beyond (16 bits: a batch's box is ~2 bandwidths
-                            // wide, i.e. worth that much at the boundary) the batch's own exponent prices them; nearer, the batch is visited for its tiles' own
-                            band = !reach && a.drop && !(exb < thb - 16.0);
-                            if (!reach && !band) dacc[g] += (float)(t1 - bt < 64 ? t1 - bt : 64) * __builtin_amdgcn_exp2f((float)(exb - thb));
-                        }
-                        bmg[g] = __ballot(reach);
-                        bbg[g] = __ballot(band);
-                        bm |= bmg[g] | bbg[g];
+                        bmg[g] = __ballot(bt < t1 && batch_in_reach(bb, QBp + qt * 2 * pd, pd, QTp[qt] - a.prune_margin));
+                        bm |= bmg[g];
                     }
                 }
             }
             while (bm) {
                 const int j = __builtin_ctzll(bm);
                 bm &= bm - 1;
-                unsigned gsel = 0, gband = 0;
+                unsigned gsel = 0;
 #pragma unroll
-                for (int g = 0; g < QG; ++g) { gsel |= (unsigned)((bmg[g] >> j) & 1ull) << g; gband |= (unsigned)((bbg[g] >> j) & 1ull) << g; }
-                do_batch(sb + 64 * (int64_t)j, gsel, gband);
+                for (int g = 0; g < QG; ++g) gsel |= (unsigned)((bmg[g] >> j) & 1ull) << g;
+                do_batch(sb + 64 * (int64_t)j, gsel);
             }
         }
     } else {
@@ -1230,17 +1177,6 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         }
     }
 
-    if constexpr (GMASK) {
-        if (a.drop) {   // what this wave dropped for each of its groups in this split (every lane tested other tiles / batches: add the lanes up)
-#pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                float v = dacc[g];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0 && qt0 + g < a.nqtiles) ((PBN_GLOBAL float*)a.drop)[(int64_t)split * a.nqtiles + qt0 + g] = v;
-            }
-        }
-    }
     // ---- epilogue: combine the 4 row-lanes of each query column, write (m, sum) partials ---------
     PBN_GLOBAL double* part = (PBN_GLOBAL double*)a.part;
     constexpr int P = COND ? 4 : 2;
@@ -1293,7 +1229,6 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) voi
     a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = g.group_masks;
     a.far_span = g.far_span;
     a.tile_rad2 = su.tile_rad2; a.tile_mom = su.tile_mom; a.batch_box = su.batch_box; a.batches_per_split = su.nbps;
-    a.drop = su.drop; a.margin_cut = (g.prune_margin > 0.0 || !su.drop) ? 0.0 : g.margin_cut;   // (a pinned margin is taken as it is)
     kde_sweep_body<T, KS, false, QG, FOLD, true, WMUL, /*EF32: the engine's terms are sums*/ true, MOM>(a, bid);
 }
 
@@ -1349,7 +1284,6 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
     const PBN_GLOBAL double* __restrict__ MOp = (const PBN_GLOBAL double*)su.tile_mom;
     const PBN_GLOBAL double* __restrict__ ZQp = (const PBN_GLOBAL double*)su.zq;
     const double margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
-    const double rmargin = margin - ((g.prune_margin > 0.0 || !su.drop) ? 0.0 : g.margin_cut);   // the sweep's radius (it accounts for what both drop)
     PBN_GLOBAL double* part = (PBN_GLOBAL double*)su.part_mom;
 
     for (int gi = 0; gi < QG; ++gi) {
@@ -1374,7 +1308,7 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
           unsigned long long bm;
           if (su.batch_box) {
               const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)su.batch_box + ((int64_t)split * su.nbps + ((bt - t0) >> 6)) * 2 * pd;
-              bm = __ballot(bt < t1 && batch_in_reach(bb, QBp + qg * 2 * pd, pd, thr - rmargin));
+              bm = __ballot(bt < t1 && batch_in_reach(bb, QBp + qg * 2 * pd, pd, thr - margin));
           } else {
               bm = __ballot(bt < t1);
           }
@@ -1384,9 +1318,8 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
             bm &= bm - 1;
             unsigned long long nr, m;
             if (g.count_redo && lane == 0) atomicAdd(&g_mom_visits, 1ull);
-            float dummy = 0.f;
-            const unsigned long long kept = prune_group_mask3(TBp, QBp + qg * 2 * pd, R2p, pd, tb, t1, thr - rmargin, g.far_span > 0.0 ? thr - (margin - g.far_span) : -INFINITY,
-                                    thr - (margin + PBN_MOM_EXTRA), lane, nr, m, dummy);
+            const unsigned long long kept = prune_group_mask3(TBp, QBp + qg * 2 * pd, R2p, pd, tb, t1, thr - margin, g.far_span > 0.0 ? thr - (margin - g.far_span) : -INFINITY,
+                                    thr - (margin + PBN_MOM_EXTRA), lane, nr, m);
             if (g.count_redo && lane == 0 && (kept & ~m)) atomicAdd(&g_mom_left, 1ull);
             if (!m) continue;
             if (g.count_redo && lane == 0) { atomicAdd(&g_mom_pairs, (unsigned long long)__builtin_popcountll(m)); atomicAdd(&g_mom_batches, 1ull); }

@@ -104,13 +104,6 @@ struct SweepArgs {
     int batches_per_split;
     // (Measured and dropped, round 5: a bitmap written by the moment pass - the batches that still hold pairs for the sweep, 24 % of the
     //  (batch, group) masks at 300 000 rows - instead of the sweep's own batch test: sweep 2.03 -> 1.90 s, moment kernel 4.93 -> 5.04 s on C3's first iteration.)
-    // A-posteriori pruning radius (round 5, grouped fp64 sum-only sweeps): the sweep keeps the tiles within prune_margin - margin_cut of the group's
-    // sum bound and ADDS UP an upper bound of everything it drops - per dropped tile (or batch of tiles) 2^(E + margin - cut), E from the same box
-    // distance the test uses - into drop[split * nqtiles + group] (floats; x 16 rows x 2^-(margin - cut) = the dropped mass relative to the sum
-    // bound).  The finish kernel holds it against the query's actual sum; a unit over the budget is evaluated once more with the full margin.
-    // The far-tile and moment thresholds keep the full margin.  null / 0 = off.
-    float* drop;
-    double margin_cut;
     double* part;  // [nsplit][nqtiles*16][P]
 };
 

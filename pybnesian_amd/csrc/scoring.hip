@@ -628,16 +628,6 @@ int pbn_scoredata_set_selector(pbn_scoredata* sd, int selector) {
     });
 }
 
-// measurement aid, not part of the C ABI header: terms evaluated a second time - at per-row accuracy (sums near 0) / with the a-priori pruning
-// margin (the a-posteriori radius failed its proof)
-extern "C" int pbn_debug_scoredata_redos(const pbn_scoredata* sd, int64_t* precise, int64_t* drop) {
-    return guarded(mu_of(sd), [&] {
-        if (!sd) throw invalid_error("pbn_debug_scoredata_redos: null argument");
-        if (precise) *precise = sd->precise_redos;
-        if (drop) *drop = sd->drop_redos;
-    });
-}
-
 // Set-function cache of the CKDE likelihood scores: entries held, sweeps launched so far.
 int pbn_scoredata_cache_stats(const pbn_scoredata* sd, int64_t* entries, int64_t* sweeps) {
     return guarded(mu_of(sd), [&] {
@@ -1016,10 +1006,6 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             struct { double* p; } dsums{ctx->scratch_sums.p};
             HIP_CHECK(hipMemsetAsync(dsums.p, 0, std::max<size_t>(1, 2 * nslots) * sizeof(double), ctx->stream));
             double* const dmax = f32 ? dsums.p + nslots : nullptr;
-            // fp64 tables: the second half receives, per grouped term, the proof of the a-posteriori pruning radius (kde_group.hpp: dev_out_drop) -
-            // log2(dropped-mass bound / budget) of the term's worst query; a term above 0 is evaluated again below with the a-priori margin
-            const bool f64 = sd->dtype == PBN_F64;
-            double* const ddrop = f64 ? dsums.p + nslots : nullptr;
             auto align = [](size_t x) { return (x + 255) / 256 * 256; };
             // host side of one evaluation: columns, training moments of the region, bandwidth, whitening (KdeModel without packs)
             struct Prep { KdeModel m; std::vector<int> use; int64_t row0, n0, row1, te0, te_n, ntrain; };
@@ -1156,7 +1142,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             // independent evaluations alternate between the context's two issue lanes (common.hpp)
             const int lanes = (n_legacy > 1 && !ctx->profiling) ? score_lanes(t->n_rows) : 1;
             if (lanes > 1) { ctx->ensure_lanes(lanes - 1); ctx->lanes_wait_for_stream(lanes - 1); }
-            if (!bt[0].gb.pools.empty()) kde_group_run(ctx, t, bt[0].gb, dsums.p, dmax, false, ddrop);
+            if (!bt[0].gb.pools.empty()) kde_group_run(ctx, t, bt[0].gb, dsums.p, dmax, false);
             // one evaluation through its own launch chain (shapes the grouped path does not take; the redo of a flagged evaluation)
             auto run_single = [&](const Work& w, bool force64, bool precise = false) {
                 Prep pr;
@@ -1182,7 +1168,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             }
             std::vector<double> hs(std::max<size_t>(1, 2 * nslots));
             if (lanes > 1) ctx->sync_lanes(lanes - 1);
-            if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, ((f32 || f64) ? 2 : 1) * nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (nslots) HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, (f32 ? 2 : 1) * nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             if (f32 && nslots) {
                 // check-after: evaluations whose training rows reach beyond what fp32 fragments hold (2^-24 max|z|^2 above the threshold of
@@ -1205,28 +1191,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     sd->kde_sweeps += (int64_t)redo.size();
                 }
             }
-            if (f64 && nslots) {
-                // a-posteriori radius: grouped terms whose dropped-mass bound exceeded the budget for some query (ordinary tables: none) take
-                // their own launch chain with the a-priori margin - the same evaluation the per-unit path makes
-                std::vector<const Work*> redo;
-                size_t wj = 0;
-                for (const Work& w : work) {
-                    const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
-                    if (grouped[wj++] && hs[nslots + (size_t)slot] > 0.0) redo.push_back(&w);
-                }
-                if (!redo.empty()) {
-                    for (const Work* w : redo) {
-                        const int slot = w->mode == 2 ? w->slot_m : w->slot_j;
-                        HIP_CHECK(hipMemsetAsync(dsums.p + slot, 0, sizeof(double), ctx->stream));
-                        run_single(*w, false);
-                    }
-                    HIP_CHECK(hipMemcpyAsync(hs.data(), dsums.p, nslots * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                    sd->kde_sweeps += (int64_t)redo.size();
-                    sd->drop_redos += (int64_t)redo.size();
-                }
-            }
-            if (f64 && nslots) {
+            if (sd->dtype == PBN_F64 && nslots) {
                 // fp64 tables: a term whose sum over its test rows is a cancellation to ~0 (kde_sum_needs_precision: the sum-only sweeps'
                 // absolute error budget would exceed 5e-7 of it) is evaluated once more at the accuracy of the per-row path
                 std::vector<const Work*> redo;

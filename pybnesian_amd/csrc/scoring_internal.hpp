@@ -59,7 +59,6 @@ struct pbn_scoredata {
     // rank computed) and preferred over kde_cache, so that every rank of a job assembles a candidate from the very same doubles
     std::map<std::vector<int>, double> term_total;
     int64_t kde_sweeps = 0;
-    int64_t drop_redos = 0;      // fp64 grouped terms evaluated again with the a-priori margin (the a-posteriori radius failed its proof for a query)
     int64_t precise_redos = 0;   // fp64 terms evaluated a second time at per-row accuracy (kde_sum_needs_precision)
     // hybrid likelihood local scores by [kind, node type, variable, sorted parents...] (see pbn_score_batch)
     std::map<std::vector<int>, double> score_memo;
