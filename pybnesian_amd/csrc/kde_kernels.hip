@@ -1213,8 +1213,13 @@ __global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F64_PRUNE_W
 
 // Grouped launch (kde_group.hip): the flat grid covers the sweeps of MANY units back to back, unit-major, every unit's share
 // rounded up to 64 workgroups so that one table entry per 64 workgroups names the unit.  Pruned plain fp64 sweeps only.
+// (four waves per SIMD here, three for the stand-alone launches: the grouped sweeps spend more of their time in the tile walk, whose latency a
+//  fourth wave covers - cv64 2.25 -> 2.19 s, C3 with 24 iterations 26.66 -> 26.04 s; the stand-alone handles lose 2-5 % at four, tools/r5_probe_q.sh)
+#ifndef PBN_F64_GROUP_WAVES
+#define PBN_F64_GROUP_WAVES 4
+#endif
 template <typename T, int KS, int QG, bool FOLD, bool WMUL, bool MOM = false>
-__global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_PRUNE_WAVES) void kde_sweep_group_kernel(GSweepArgs g) {
+__global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_GROUP_WAVES) void kde_sweep_group_kernel(GSweepArgs g) {
     const int u = g.wg_unit[blockIdx.x >> 6];
     const GSweepUnit& su = g.units[u];
     const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
