@@ -166,8 +166,12 @@ template <bool F64, bool COND>
 struct SweepQG {
     static constexpr int value = (F64 && COND) ? 2 : (F64 ? PBN_QG_F64 : 4);
 };
+// Pruned fp64 sweeps: 2 groups per wave since round 5 (4 before).  With per-group visit masks a wave visits the UNION of its groups' tiles and pays the
+// mask test for every group; two groups halve that union's excess and the register need (fewer spills at four waves per SIMD), at twice the fragment
+// loads per pair - cv64 2.32 -> 2.05 s, C3's first iteration 7.76 -> 7.22 s, 24 iterations 26.1 -> 24.8 s, handles d = 2 / 3 4.5 / 5.4 -> 4.2 / 4.9 ms
+// (one group per wave: cv64 2.27 s, C3 6.91 / 25.3 s; profiles/r5/waves_probe.txt).  The moment pass follows (same grid mapping).
 #ifndef PBN_QG_PRUNE
-#define PBN_QG_PRUNE 4
+#define PBN_QG_PRUNE 2
 #endif
 #ifndef PBN_QG_PRUNE_COND
 #define PBN_QG_PRUNE_COND 2
