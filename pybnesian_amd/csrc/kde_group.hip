@@ -723,7 +723,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         const int nsplit0 = std::max(1, (U.ntiles + split_tiles - 1) / split_tiles);
         U.tps = (U.ntiles + nsplit0 - 1) / nsplit0;
         U.nsplit = (U.ntiles + U.tps - 1) / U.tps;
-        const int qblocks = (U.nqtiles + PBN_QG_PRUNE - 1) / PBN_QG_PRUNE;
+        const int qg = bf16 ? PBN_BF16_QG_PRUNE : PBN_QG_PRUNE;   // query groups per wave of the chunk's sweep kernel
+        const int qblocks = (U.nqtiles + qg - 1) / qg;
         U.nwg = qblocks * U.nsplit;
         U.wg0 = total_wg;
         total_wg += ((int64_t)U.nwg + 63) / 64 * 64;
@@ -885,7 +886,7 @@ size_t pool_bytes(const GroupBatch& b, const GPool& P) {
         s += nt * KS * 1024 + nt * 256 + (nt + nqt) * 2048 + nqt * 64 + (size_t)U.N * d * 8 + nt * 2 * pd * 8 + nqt * KS * 1024 + nqt * 128 + (size_t)U.nq * d * 8 + nqt * 64 +
              nqt * 2 * pd * 8 + nqt * 8 + nqt * 128 + 2 * (nsplit + 1) * nqt * 256 * (d <= 2 ? 2 : 1) + (d <= 2 ? (nt + 64) * (pbn_mom_rec(d <= 1 ? 1 : 2) * 8 + 4) + 512 : 0) +
              (size_t)U.nq / 32 + sizeof(GUnit) + sizeof(GSweepUnit) + (nsplit + 1) * ((nt / nsplit + 127) / 64) * 2 * pd * 8 + 256 +
-             (nqt / 4 + 1) * nsplit / 16 + 13 * 256 + 64;
+             (nqt / 2 + 1) * nsplit / 16 + 13 * 256 + 64;   // (workgroup table: one entry per 64 workgroups of nqt / PBN_QG_PRUNE x nsplit)
     }
     return s;
 }

@@ -1545,9 +1545,6 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 #ifndef PBN_BF16_BLIND_NB2
 #define PBN_BF16_BLIND_NB2 1   // (0 without the probe tiles of PBN_BF16_PROBES: see above)
 #endif
-#ifndef PBN_BF16_QG_PRUNE
-#define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
-#endif
 template <int NB, bool COND, int QG, bool PRUNE>
 __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const unsigned bid) {
     using V = f4;

@@ -173,6 +173,9 @@ struct SweepQG {
 #ifndef PBN_QG_PRUNE
 #define PBN_QG_PRUNE 2
 #endif
+#ifndef PBN_BF16_QG_PRUNE
+#define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
+#endif
 #ifndef PBN_QG_PRUNE_COND
 #define PBN_QG_PRUNE_COND 2
 #endif
