@@ -723,7 +723,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         const int nsplit0 = std::max(1, (U.ntiles + split_tiles - 1) / split_tiles);
         U.tps = (U.ntiles + nsplit0 - 1) / nsplit0;
         U.nsplit = (U.ntiles + U.tps - 1) / U.tps;
-        const int qg = bf16 ? PBN_BF16_QG_PRUNE : PBN_QG_PRUNE;   // query groups per wave of the chunk's sweep kernel
+        const int qg = sweep_qg(fdt, /*cond=*/false, KS, /*prune=*/true);   // query groups per wave of the chunk's sweep kernel: the ONE place that knows
+                                                                             // (a count from the other type's constant ran every fp32 workgroup twice - same sums, twice the time)
         const int qblocks = (U.nqtiles + qg - 1) / qg;
         U.nwg = qblocks * U.nsplit;
         U.wg0 = total_wg;

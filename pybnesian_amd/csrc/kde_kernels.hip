@@ -2620,6 +2620,7 @@ bool sweep_weights_norm(int dtype, bool cond, int KS, int dm) {
 
 int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     if (prune && dtype == PBN_F64) return cond ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;
+    if (prune && use_bf16x3(dtype) && !cond) return PBN_BF16_QG_PRUNE;   // (what the grids of the pruned launches - stand-alone and grouped - are sized with)
     if (KS > 4) return 2;   // more than 16 (fp32: 20) dimensions: two query groups per wave (fragment registers); KS = MFMAs per tile pair
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
