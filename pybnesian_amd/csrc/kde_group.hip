@@ -645,17 +645,17 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(GDev g, double* out) 
 
 size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
-// Training tiles per split of a unit's sweep.  PBN_GROUP_SPLIT_TILES pins it; otherwise 512 up to 16 384 tiles (cv64's 90 000-row folds:
-// 256 ... 1 024 measure within 1 %, 2 048 +2 %).  Beyond that the fp32 sweeps take 1 024 up to 32 768 tiles and 2 048 above (C5's 720 000-row
+// Training tiles per split of a unit's sweep.  PBN_GROUP_SPLIT_TILES pins it.  fp32 sweeps: 512 up to 16 384 tiles, 1 024 up to 32 768 tiles and 2 048 above (C5's 720 000-row
 // slices: within noise of 512 in time, `profiles/r4/split_tiles_probe.txt` - but every query keeps a partial per split, 60 % of a candidate's
 // arena at 512, so the coarser split lets an arena-full hold twice the candidates); the fp64 sweeps take 4 096 since round 5: with the two-level
 // walk a longer split costs one more ballot per 4 096 tiles, and the moment pass beside the sweep halves the work per workgroup - C3's 450 000-row
-// folds: first iteration 8.08 (1 024) / 7.83 (2 048) / 7.79 (4 096) / 7.97 s (16 384), six iterations 12.68 -> 12.00 s (`profiles/r5/moment_pass.txt` section 8).
+// folds: first iteration 8.08 (1 024) / 7.83 (2 048) / 7.79 (4 096) / 7.97 s (16 384), six iterations 12.68 -> 12.00 s (`profiles/r5/moment_pass.txt` section 8);
+// with two query groups per wave also below 16 384 tiles (cv64's 90 000-row folds: 2.059 (512) / 2.043 (1 024) / 2.05 (2 048) / 2.022 s (4 096); 256: 2.12 s).
 int split_tiles_for(int ntiles, bool f64) {
     const int pinned = knob_int("PBN_GROUP_SPLIT_TILES", 0);   // read per call: the tests switch it
     if (pinned > 0) return std::max(16, pinned);
-    if (ntiles <= 16384) return 512;
-    return f64 ? 4096 : (ntiles <= 32768 ? 1024 : 2048);
+    if (f64) return 4096;
+    return ntiles <= 16384 ? 512 : (ntiles <= 32768 ? 1024 : 2048);
 }
 
 // The moment pass pays from a density of training rows on: a 16-row tile must be small against the bandwidth for many of its (tile, group)
