@@ -1238,15 +1238,17 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_GROUP_WAVES) voi
 }
 
 // The moment pass of a grouped fp64 sum-only sweep of D = 1 or 2 dimensions (round 5).  Same flat grid and the same (unit, query block,
-// split) mapping as kde_sweep_group_kernel, a wave owns the same four 16-query groups - but here LANE = TILE: per 64-tile batch every lane
-// loads the record of its own tile (structure of arrays: 47 | 10 coalesced loads, once per batch and group that has a pair in it), and the 16
-// queries of the group are taken one after the other - their coordinates and offsets are uniform (v_readlane from the lanes that hold
-// them), the tile's coefficients per-lane registers.  A (tile, group) pair then costs 16 x (2 D + 12 + (44 | 8)) / 64 fp64 instructions:
-// ~17 issue slots at D = 2 against ~44 for the MFMA + 2^f form of the sweep, ~7 at D = 1 - and a lane idles only where ITS tile is not this
-// group's (the first forms of this kernel - lane = query with the records through scalar loads, then 4 tile slots x 16 queries with per-lane
-// record loads - paid for the union of the four groups' tiles resp. for 23 vector loads per four tiles: no faster than the sweep).
-// The exponent of the common factor is split as in the sweep (biased, integer offset from the prepass bound); 2^x takes the fp64 polynomial -
-// one per (tile, query), so the pass's own arithmetic error is 2.3e-9 per term.  Partials go behind the sweep's own (GSweepUnit::part_mom).
+// split) mapping as kde_sweep_group_kernel, a wave owns the same 16-query groups - but here LANE = TILE: per 64-tile batch every lane with a
+// pair loads the record of its own tile (structure of arrays: 47 | 10 coalesced loads, once per batch and group that has a pair in it), and the
+// 16 queries of the group are taken one after the other - their coordinates and offsets are uniform (v_readlane from the lanes that hold
+// them), the tile's coefficients per-lane registers.  Per (tile, query): 2 D + ~19 instructions + 44 | 8 FMAs of the Horner scheme, i.e. ~65
+// fp64 issue slots per pair at D = 2 when all 64 lanes hold a pair (measured ~85 cycles at 56-62 busy lanes) against ~180 for the sweep's MFMA +
+// 2^f form - and a lane idles only where ITS tile is not this group's (the first forms of this kernel - lane = query with the records through
+// scalar loads, then 4 tile slots x 16 queries with per-lane record loads - paid for the union of the wave's groups' tiles resp. for 23 vector
+// loads per four tiles: no faster than the sweep).  The exponent of the common factor is split as in the sweep (biased, integer offset from the
+// prepass bound) and 2^x takes the sweep's own form (2^f of the fraction on the fp32 unit: the budget's first entry covers it; with the fp64
+// polynomial the pass differed from the sweep by the fp32 unit's MEAN error, 1.3e-9 per term).  Running sums per (query, lane) in LDS, one
+// cross-lane reduction per group; partials go behind the sweep's own (GSweepUnit::part_mom).
 __device__ __forceinline__ double readlane_f64(double v, int l) {   // lane l's value, uniform (two v_readlane_b32 into scalar registers)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
