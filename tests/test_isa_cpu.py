@@ -62,3 +62,33 @@ def test_gather_ring_kernels_keep_their_stages_in_flight(stats_asm):
             waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", b)]
             assert waits and min(waits) >= 4, f"{name}: the steady loop waits with vmcnt({min(waits) if waits else None})"
     assert seen == 16
+
+
+@pytest.fixture(scope="module")
+def kde_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "kde_kernels.s"
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                        "kde_kernels.hip", "-o", str(out)], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return out.read_text()
+
+
+def test_grouped_kernels_keep_their_register_budgets(kde_asm):
+    """The grouped score-engine kernels live on their occupancy (profiles/r5/waves_probe.txt): the moment kernel of two-variable
+    terms once ran 2x slower when a build spilled 42 of its coefficient registers, the fp64 sweeps are compiled for four waves per SIMD with two
+    query groups per wave BECAUSE that shape fits 128 VGPRs nearly without scratch.  A compiler or source change that breaks this shows here,
+    not as a silent slow-down."""
+    found = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", kde_asm, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        found[name] = (int(re.search(r"private_segment_fixed_size (\d+)", body).group(1)), int(re.search(r"next_free_vgpr (\d+)", body).group(1)))
+    mom1, mom2 = found["_ZN3pbn23kde_moment_group_kernelILi1EEEvNS_10GSweepArgsE"], found["_ZN3pbn23kde_moment_group_kernelILi2EEEvNS_10GSweepArgsE"]
+    assert mom1[0] == 0 and mom1[1] <= 168, mom1          # three waves per SIMD, nothing in scratch
+    assert mom2[0] == 0 and mom2[1] <= 256, mom2          # two waves per SIMD (45 coefficients per lane), nothing in scratch
+    sweeps = {n: v for n, v in found.items() if n.startswith("_ZN3pbn22kde_sweep_group_kernelId")}
+    assert len(sweeps) == 5, sorted(sweeps)               # KS = 1, 2 x norm folded / as weights, + the variant beside the moment pass
+    for n, (scratch, vgpr) in sweeps.items():
+        assert vgpr <= 128, (n, vgpr)                     # four waves per SIMD
+        assert scratch <= 160, (n, scratch)               # (0-92 bytes today: the unit's argument block, no loop-carried spill)
+    c5 = found["_ZN3pbn27kde_sweep_bf16_group_kernelILi1EEEvNS_10GSweepArgsE"]
+    assert c5[0] == 0 and c5[1] <= 128, c5                # C5's kernel: four waves per SIMD, nothing in scratch
