@@ -454,11 +454,12 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
     more = dict(extra) if which == "c5mmhc" else {}
     if which != "c4":
         # the leg's dominant kernel and its share of the timed search, from the library's own HIP events (no profiler)
-        kname = {"c3": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only) + kde_moment_group_kernel<1 | 2> "
+        kname = {"c3": "kde_sweep_group_kernel<double, 1, 2, FOLD> (grouped pruned fp64 sweep, sum-only) + kde_moment_group_kernel<1 | 2> "
                        "(the tile-moment pass of its one- and two-variable terms: one event pair spans both launches)",
-                 "cv64": "kde_sweep_group_kernel<double, 1, 4, FOLD> (grouped pruned fp64 sweep, sum-only)"}.get(
+                 "cv64": "kde_sweep_group_kernel<double, 1, 2, FOLD> (grouped pruned fp64 sweep, sum-only)"}.get(
                      which, "kde_sweep_bf16_group_kernel<1> (grouped pruned fp32 sweep on bf16x3 fragments) + the per-slice kde_sweep_bf16_kernel")
-        more["roofline"] = {"kernel": kname, "bound": "valu-issue (v_exp + add per pair value inside the pruning radius; DESIGN.md 3.1)",
+        kshort = {"c3": "kde_moment_group_kernel<2> + kde_sweep_group_kernel<double>", "cv64": "kde_sweep_group_kernel<double>"}.get(which, "kde_sweep_bf16_group_kernel")
+        more["roofline"] = {"kernel": kname, "kernel_short": kshort, "bound": "valu-issue (v_exp + add per pair value inside the pruning radius; DESIGN.md 3.1)",
                             "device_s": kt["sweep"][0] * 1e-3, "launches": kt["sweep"][1], "share_of_estimate_s": kt["sweep"][0] * 1e-3 / dt,
                             "gram_s": kt["gram"][0] * 1e-3, "gram_launches": kt["gram"][1],
                             "note": "HIP events on the launching stream around the sweep and Gram launches only (issue lanes overlap: device "
@@ -522,9 +523,15 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
                 "algorithmic_bytes": gbytes, "launch_us": gsec * 1e6, "launches": gram_n, "first_launch_us": gram_first_ms * 1e3 / max(gram_n, 1),
                 "note": "HIP events around the score constructor's Gram launch pair in this run (the second construction; first_launch_us = the "
                         "first, which `score_ctor_s` times); 6.29 TB/s = the best device-to-device copy measured on "
-                        "this part (profiles/r2/gram_floors.txt); flops = rows x n^2 x 2 on v_mfma_f64_16x16x4_f64"}
-        roof["mfma_tflops"] = float(n_rows) * n_cols * n_cols * 2.0 / gsec / 1e12
+                        "this part (profiles/r2/gram_floors.txt); mfma_tflops = EXECUTED flops (upper-triangle tile pairs) on v_mfma_f64_16x16x4_f64"}
+        # EXECUTED flops: the kernel computes the upper triangle of 16 x 16 column-tile pairs (stats_kernels.hip: 10 of 16 at 64 columns), one
+        # v_mfma_f64_16x16x4_f64 (2 048 flop) per tile pair and 4 rows - the count SQ_INSTS_MFMA reports; the full n x n product the
+        # triangle stands for is kept under its own name
+        nct = (n_cols + 15) // 16
+        roof["mfma_tflops"] = float(n_rows) / 4.0 * (nct * (nct + 1) // 2) * 2048.0 / gsec / 1e12
         roof["mfma_frac_of_fp64_peak"] = roof["mfma_tflops"] / FP64_PEAK_TFLOPS
+        roof["algorithmic_full_matrix_tflops"] = float(n_rows) * n_cols * n_cols * 2.0 / gsec / 1e12
+        roof["kernel_short"] = "gram_glds_kernel<4>"
         if rec is not None:
             cyc = rec["GRBM_GUI_ACTIVE"] / 8.0
             roof["mfma_busy"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc
@@ -746,6 +753,123 @@ def cpu_baseline(train_np, test_np, h, budget_s=12.0):
         baseline.set_num_threads(visible)
         oracle.set_num_threads(visible)
     return out
+
+
+def _num(v, sig=6):
+    """Numbers of the compact line: 6 significant digits (the verbose object keeps the full doubles)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{sig}g}")
+    return v
+
+
+def _pick(src, *keys, **renamed):
+    """{key: number} of the keys `src` holds (dict values and prose are left to the verbose object)."""
+    out = {}
+    if not isinstance(src, dict):
+        return out
+    for k in keys:
+        if k in src and not isinstance(src[k], (dict, list)):
+            out[k] = _num(src[k])
+    for new, old in renamed.items():
+        if old in src and not isinstance(src[old], (dict, list)):
+            out[new] = _num(src[old])
+    return out
+
+
+def compact_line(out, full_name):
+    """The ONE stdout line, numbers only and under 5 KB (the driver's record keeps the parsed headline keys and the last ~6 KB of the line:
+    round 5's 25 KB line lost its C3 / C4 / cv_weak legs there).  Everything else - prose, methods, samples, per-flip lists - goes to the
+    verbose object `full_name` beside it."""
+    head = {k: _num(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config", {})
+    head["config"] = {k: _num(cfg.get(k), 13) for k in ("workload", "parallelism", "ranks", "backend", "ranks_seen", "rccl_world1_child",
+                                                    "pairs_per_step_per_gpu", "slogl_step0_rank_sum") if k in cfg}
+    if cfg.get("rank_devices"):
+        head["config"]["rank_devices"] = [list(d[:2]) for d in cfg["rank_devices"] if d]
+    r = out.get("roofline", {})
+    head["roofline"] = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "exp_unit")
+    if isinstance(r.get("dp_issue_util"), dict):
+        head["roofline"].update(_pick(r["dp_issue_util"], dp_issue_util="value", mfma_busy="mfma_busy_frac"))
+    c = out.get("cpu_baseline")
+    if isinstance(c, dict):
+        head["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind", "pairs_per_s_per_thread", "scaling_efficiency")
+        head["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:96]
+        if isinstance(c.get("single_thread"), dict):
+            head["cpu_baseline"]["single_thread"] = _num(c["single_thread"].get("value"))
+        if isinstance(c.get("reference_arithmetic_port"), dict):
+            head["cpu_baseline"]["reference_arithmetic"] = _num(c["reference_arithmetic_port"].get("value"))
+    par = ("ok", "rows", "rel_slogl", "max_rel_logl", "max_abs_logl", "tol", "error")
+    if isinstance(out.get("parity"), dict):
+        head["parity"] = _pick(out["parity"], *par)
+
+    def search_leg(v):
+        o = _pick(v, "value", "unit", "estimate_s", "score_ctor_s", "cells_scored", "local_score_evals", "iterations", "arcs_found", "ranks", "nodes",
+                  "scaling", "mmpc_s", "ci_tests", "cpc_edges", "seconds", "cold_seconds", "near_tie_redos", "error")
+        rf = v.get("roofline")
+        if isinstance(rf, dict):
+            o["roofline"] = _pick(rf, "achieved", "peak", "unit", "frac", "frac_of_measured_copy", "launch_us", "mfma_tflops", "mfma_frac_of_fp64_peak",
+                                  "mfma_busy", "traffic", "device_s", "launches", "share_of_estimate_s", "moment_s", "moment_pairs", "moment_frac",
+                                  "moment_cycles_per_pair", kernel="kernel_short")
+            o["roofline"]["bound"] = str(rf.get("bound", "")).split(" ")[0]
+        cb = v.get("cpu_baseline")
+        if isinstance(cb, dict):
+            o["cpu"] = _pick(cb, "value", "cores", "kind", "extrapolated", "same_structure", "same_skeleton")
+            if isinstance(cb.get("single_thread"), dict):
+                o["cpu"]["single_thread"] = _num(cb["single_thread"].get("value"))
+        ta = v.get("tie_accounting")
+        if isinstance(ta, dict):
+            o["ties"] = _pick(ta, "replayed_iterations", "tie_flips", "non_tie_divergences", "max_rel_gap", "end_gain", "error")
+        er = v.get("eight_rank_estimate")
+        if isinstance(er, dict):
+            o["eight_rank_emulation"] = _pick(er, "per_rank_s", "slowest_over_mean_share", "ratio_to_one_rank_leg")
+        if v.get("per_rank_estimate_s"):
+            o["per_rank_estimate_s"] = [_num(x, 4) for x in v["per_rank_estimate_s"]]
+        return o
+
+    legs = {}
+    for name, key in (("c4" if "C4" in str((out.get("secondary") or {}).get("config", "")) else "cv64", "secondary"), ("c1", "secondary_c1"),
+                      ("c3", "secondary_c3"), ("c5", "secondary_c5"), ("cv_weak", "secondary_cv_weak")):
+        if isinstance(out.get(key), dict):
+            legs[name] = search_leg(out[key])
+    f = out.get("secondary_f32")
+    if isinstance(f, dict):
+        legs["f32"] = _pick(f, "value", "unit", "ms_per_step", "rel_diff_vs_f64", "error")
+        if isinstance(f.get("roofline"), dict):
+            legs["f32"]["roofline"] = _pick(f["roofline"], "kernel", "bound", "avg_launch_ms", "frac", "frac_of_issue_bound")
+        if isinstance(f.get("parity"), dict):
+            legs["f32"]["parity"] = _pick(f["parity"], *par)
+    w = out.get("rccl_world1")
+    if isinstance(w, dict):
+        legs["rccl_world1"] = _pick(w, "ok", "world", "rccl_ranks_seen", "collectives", "all_gather_identity", "hip_runtime_of_torch", "hip_runtime_pairing", "seconds")
+        if isinstance(w.get("bit_identical"), dict):
+            legs["rccl_world1"]["bit_identical"] = all(bool(x) for x in w["bit_identical"].values())
+        if "error" in w:
+            legs["rccl_world1"]["error"] = str(w["error"])[:160]
+    e = out.get("e2e_host")
+    if isinstance(e, dict):
+        legs["e2e_host"] = _pick(e, "value", "unit", "ms", "fit_ms", "fit_first_ms")
+    if legs:
+        head["legs"] = legs
+    head["full"] = full_name
+    return head
+
+
+def write_full(out, name="bench_full.json"):
+    """The verbose object (every leg with its prose) beside the line: ./bench_full.json, and gpurun_out/ when that directory exists."""
+    text = json.dumps(out, indent=1)
+    for d in (os.getcwd(), os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, name), "w") as fh:
+                    fh.write(text)
+        except OSError:
+            pass
+    return name
 
 
 def launch_ranks(args):
@@ -1138,8 +1262,7 @@ def main():
             # one-rank "nccl" group, the product's one-process-per-GPU mode forced, every batch's all-gather through RCCL on device
             # buffers, results bit-identical to the plain calls; never part of a timed region
             out["rccl_world1"] = rccl_world1()
-            out["config"]["rccl_ranks_seen"] = out["rccl_world1"].get("rccl_ranks_seen")
-            out["config"]["backend"] = "nccl (RCCL), one rank: tools/rccl_world1.py"
+            out["config"]["rccl_world1_child"] = True   # the collective evidence of this one-GPU line is that child; the timed region ran with dist = None
         if world == 1 and not args.no_e2e:
             try:
                 out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy(), train_np=train_t.T.cpu().numpy())
@@ -1160,7 +1283,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(train_np, test_np, h)
             except Exception as ex:  # never lose the headline line to the baseline leg
                 out["cpu_baseline"] = {"value": None, "unit": "M-samples/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact_line(out, write_full(out)), separators=(",", ":")), flush=True)
         bad = [k_ for k_, v_ in [("headline", out)] + list(legs.items()) if isinstance(v_.get("parity"), dict) and not v_["parity"].get("ok")]
         bad += [k_ for k_, v_ in [("secondary", hc_out or {})] + list(legs.items())
                 if isinstance(v_.get("tie_accounting"), dict) and v_["tie_accounting"].get("non_tie_divergences", 0) > 0]

@@ -124,3 +124,38 @@ def test_tie_accounting_classifies_flips():
     hc.last.trace = [AddArc(names[a], names[b], 0.0) for _, a, b in own]
     out = bench.tie_accounting(pbn, hc, names, sc)
     assert out["tie_flips"] == 0 and out["non_tie_divergences"] == 0 and out["product_graph_is_oracle_local_optimum"]
+
+
+def test_compact_line_carries_every_leg_in_under_6000_bytes():
+    """The driver's record keeps the parsed headline keys and the last ~6 KB of the stdout line: the line is numbers only and every leg's
+    figures (C1, C3, C4 + Gram roofline, C5, f32, cv_weak, rccl_world1) are in it; prose lives in bench_full.json.  Input: the verbose
+    object of a real run (profiles/r5/bench_default.json, 19 KB)."""
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r5", "bench_default.json")) as fh:
+        full = json.load(fh)
+    line = json.dumps(bench.compact_line(full, "bench_full.json"), separators=(",", ":"))
+    assert len(line) < 6000, len(line)
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert out[k] == full[k] or abs(out[k] - full[k]) <= 1e-5 * abs(full[k])
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    legs = out["legs"]
+    assert set(legs) >= {"c1", "c3", "c4", "c5", "f32", "cv_weak", "rccl_world1", "e2e_host"}
+    assert legs["c3"]["estimate_s"] > 0 and legs["c5"]["estimate_s"] > 0 and legs["cv_weak"]["nodes"] == 23
+    assert legs["c4"]["roofline"]["launch_us"] > 0 and legs["c4"]["ties"]["non_tie_divergences"] == 0
+    assert legs["f32"]["roofline"]["frac"] > 0 and legs["f32"]["parity"]["ok"] is True
+    assert legs["rccl_world1"]["ok"] is True and legs["rccl_world1"]["bit_identical"] is True
+
+    def no_prose(o, path=""):
+        for k, v in o.items():
+            if isinstance(v, dict):
+                no_prose(v, path + k + ".")
+            elif isinstance(v, str):
+                assert len(v) <= 140, (path + k, len(v))
+    no_prose(out)
+    assert out["full"] == "bench_full.json"

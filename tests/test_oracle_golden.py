@@ -136,3 +136,19 @@ def test_bge_from_cached_moments_is_bge_from_rows():
     finally:
         oracle.set_num_threads(threads)
     assert np.array_equal(cov, cov1) and np.array_equal(means, means1)   # the parallel covariance does not depend on the thread count
+
+
+@pytest.mark.parametrize("variable,evidence", CKDE_SETS)
+def test_linear_gaussian_fit_bic_logl(golden, variable, evidence):
+    """The LinearGaussian half of the oracle held to the reference tests' numpy recipes directly (mle_test.py:10-56 lstsq beta and
+    residual variance, bic_test.py:10-43 numpy_local_score, LinearGaussianCPD_test.py norm.logpdf) - until round 6 it was pinned only
+    through the device (device = golden, device = oracle)."""
+    key = variable + "_" + "".join(evidence)
+    cols = [COLS.index(v) for v in [variable] + list(evidence)]
+    data = np.asarray(golden["train10k"])[:, cols]
+    beta, var = oracle.lg_fit(data)
+    assert np.allclose(beta, golden[f"lg_beta_{key}"], rtol=1e-9, atol=1e-12)
+    assert abs(var - golden[f"lg_var_{key}"]) <= 1e-9 * abs(golden[f"lg_var_{key}"])
+    assert abs(oracle.bic_lg(data) - golden[f"bic_{key}"]) <= 1e-9 * abs(golden[f"bic_{key}"])
+    test = np.asarray(golden["test50"])[:, cols]
+    assert np.allclose(oracle.lg_logl(test, beta, var), golden[f"lg_logl_{key}"], rtol=1e-9, atol=1e-11)
