@@ -14,7 +14,7 @@ def test_self_launch_starts_the_ranks_and_fails_loudly_without_gpu(ensure_built)
     if torch.cuda.is_available():
         import pytest
 
-        pytest.skip("GPU present: the launcher is exercised by the gpu tier / the driver")
+        pytest.skip("GPU present: the launcher is exercised by the gpu tier (test_distributed_gpu.py::test_bench_two_ranks_on_one_gpu)")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"],
                          env=env, capture_output=True, text=True, timeout=300)

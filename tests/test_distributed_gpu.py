@@ -101,3 +101,51 @@ def test_rccl_world1_on_one_gpu():
     assert all(out["bit_identical"].values()), out["bit_identical"]
     assert out["collectives"] >= 10                       # one all-gather per delta-cache batch + the moments
     assert out["mapped"].get("librccl") and out["mapped"].get("libamdhip64") and out["mapped"].get("libpbn_hip")
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's own N > 1 path (launch_ranks -> torch.distributed.run -> init_process_group, the fixed-work cv64 leg sharded over the ranks,
+    the weak-scaling leg, per-rank estimates) as the driver's SCALE run would start it - two gloo ranks on the ONE device a box has.  The launcher
+    is a fresh child that spawns torch.distributed.run before any HIP call.  Shards learning/operators/operators.cpp:100-132,296-347,
+    learning/scores/cv_likelihood.cpp:5-25."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PBN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 6000
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["ranks_seen"] == 2
+    assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
+    legs = out["legs"]
+    strong = legs["cv64"]
+    assert strong["ranks"] == 2 and strong["scaling"] == "strong" and strong["iterations"] == 5
+    assert len(strong["per_rank_estimate_s"]) == 2 and all(x > 0 for x in strong["per_rank_estimate_s"])
+    weak = legs["cv_weak"]
+    assert weak["nodes"] == 32 and weak["ranks"] == 2 and weak["scaling"] == "weak" and len(weak["per_rank_estimate_s"]) == 2
+    # the headline's exchange: the all_reduce of the per-step partial sums = the sum of the two ranks' own one-rank calls
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+    import pybnesian_amd as pbn
+    from pybnesian_amd import _lib
+
+    ctx = pbn.Context(0)
+    dev = torch.device("cuda", 0)
+    names = [f"v{i}" for i in range(bench.D)]
+    want = 0.0
+    for rank in range(2):
+        tr, te = bench.make_tables(torch, dev, 1_000_000, 100_000, 0, 1 + rank, torch.float64)
+        torch.cuda.synchronize()
+        a = pbn.DeviceTable.from_device_pointer(ctx, tr.data_ptr(), 1_000_000, names, 1_000_000, _lib.PBN_F64, keepalive=tr)
+        b = pbn.DeviceTable.from_device_pointer(ctx, te.data_ptr(), 100_000, names, 100_000, _lib.PBN_F64, keepalive=te)
+        k = pbn.ProductKDE(names)
+        k.fit_table(a)
+        buf = torch.zeros(1, dtype=torch.float64, device=dev)
+        k.slogl_table_async(b, buf.data_ptr())
+        ctx.sync()
+        want += float(buf.item())
+    assert abs(out["config"]["slogl_step0_rank_sum"] - want) <= 1e-11 * abs(want)
