@@ -23,6 +23,7 @@
 //   kde_finish    merge the per-split (m, sum) partials in fixed order, add the log-normalisation,
 //                 write logl and/or a deterministic tree-reduced slogl.
 #include "common.hpp"
+#include <atomic>
 #include "kde_kernels.hpp"
 #include "kde_group.hpp"
 
@@ -1469,6 +1470,9 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
         }
         const int t = s - 6 * dm;
         if (t < 3) return a.is_query ? one : (t == 0 ? n1 : (t == 1 ? n2 : n3));
+        // the last three slots of the contraction: ones on the training side when they are free - kde_sweep_bf16_w32_kernel puts the query
+        // norm and offset there (the query fragments hold zeros: nothing changes for the 16x16 kernels)
+        if (!a.is_query && s >= 32 * NB - 3 && 6 * dm + 6 <= 32 * NB) return one;
         return zero;
     };
     bf8* pack = (bf8*)a.pack;
@@ -1971,6 +1975,235 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) vo
 }
 
 // ------------------------------------------------------------------------------------------------
+// W32 form of the plain unpruned fp32 sweep (round 6): the SAME packed bf16x3 fragments contracted by v_mfma_f32_32x32x16_bf16 -
+// 32 training rows x 32 queries per accumulator, 16 pair values per lane and MFMA chain instead of 4.  An MFMA holds the SIMD's vector
+// issue for 8 cycles whatever its shape (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), so the matrix side of a pair value
+// costs 2 issue cycles at two 32-slot blocks (d = 5...9) instead of 4: the instruction-count bound of the d = 8 headline falls from
+// 64 to 56 issue cycles per 256 pair values (v_exp_f32 8 + v_add_f32 4 per value, + the MFMAs).  Round 4 measured this shape
+// compiler-scheduled and dropped it (14.1 against 13.05 ms: the four dependent 32-cycle MFMAs of a super-group are a longer chain than
+// the wave's own exponentials cover).  Here the stream is PLACED: the loop is software-pipelined by one super-group - the chain of
+// (tile pair, super-group s) issues while the 16 exponentials and 16 additions of the previous chain's accumulator run -, and
+// __builtin_amdgcn_sched_group_barrier pins the order [MFMA, 4 x v_exp_f32, 4 x v_add_f32] x 4 per phase, so that no MFMA waits for
+// its predecessor and no v_exp_f32 reads an accumulator younger than one phase.
+//   * lane l: query column l % 32 of the super-group, half h = l / 32.  MFMA j of a chain takes slots 16 j + 8 h ... + 7 = block j / 2,
+//     lane group 2 (j % 2) + h of the 16x16x32 fragment layout: the fragment arrays are read through another index map, nothing is repacked.
+//     A training tile PAIR (rows 0-15 from one 16-row tile, 16-31 from another) feeds the A operand: lanes with (l % 32) < 16 read the first.
+//   * the query side -1/2|z_q|^2 - m_q cannot be the C operand (16 registers per super-group): it rides in the three LAST slots of the
+//     contraction (32 NB - 3 ...: split3 on the query side, rewritten when an offset moves; ones on the training side, written by
+//     pack_rows_bf16_kernel when 6 dm + 6 <= 32 NB - the 16x16 kernels meet zeros on the query side there), and C is the inline constant 0.
+//   * accumulator row of register r: 8 (r / 4) + 4 h + r % 4 - registers 8...15 are the second tile of the pair (dropped for an odd tail).
+//   * blind chunks of 64 tiles with fp32 tile sums, offsets from 16 probe tile pairs, checked redo: as kde_sweep_bf16_body.
+// Replaces kde/opencl_kernels/KDE.cl.src:115-121,143-170 for fp32 tables of 5...9 whitened dimensions.
+// ------------------------------------------------------------------------------------------------
+typedef float f16v __attribute__((ext_vector_type(16)));
+#ifndef PBN_BF16_W32_WAVES
+#define PBN_BF16_W32_WAVES 2
+#endif
+#ifndef PBN_BF16_W32_SCHED
+#define PBN_BF16_W32_SCHED 1
+#endif
+
+template <int NB>
+__global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_kernel(SweepArgs a) {
+    constexpr int NJ = 2 * NB;   // MFMAs per chain
+    constexpr int S = 2;         // super-groups of 32 queries per wave (= the 4 x 16 queries of the 16x16 kernel's wave: same grid)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31, sub = col >> 4, idx = col & 15;
+    int qx, split;
+    xcd_block(qx, split);
+    const int64_t qt0 = ((int64_t)qx * 4 + wave) * (2 * S);
+    if (qt0 >= a.nqtiles) return;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+
+    const PBN_GLOBAL bf8* __restrict__ Ap = (const PBN_GLOBAL bf8*)a.Apack;
+    const PBN_GLOBAL bf8* __restrict__ Bp = (const PBN_GLOBAL bf8*)a.Bpack;
+    const PBN_GLOBAL float* __restrict__ NYp = (const PBN_GLOBAL float*)a.nypack;
+    const int loff = half * 16 + idx;   // lane's place inside a (tile, block, j % 2) group of 32 fragment lanes
+
+    bf8 b[S][NJ];
+    float ny[S], m[S];
+    double sum[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int64_t qt = qt0 + 2 * s + sub;
+        qt = qt < a.nqtiles ? qt : a.nqtiles - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[s][j] = Bp[(qt * NB + (j >> 1)) * 64 + (j & 1) * 32 + loff];
+        ny[s] = NYp[qt * 16 + idx];
+        m[s] = 0.f;
+        sum[s] = 0.0;
+    }
+    auto set_off = [&](int s) {   // slots 32 NB - 3 ... of the query side <- split3(-1/2|z_q|^2 - m_q)
+        __bf16 q1, q2, q3;
+        split3(ny[s] - m[s], q1, q2, q3);
+        if (half == 1) { b[s][NJ - 1][5] = q1; b[s][NJ - 1][6] = q2; b[s][NJ - 1][7] = q3; }
+    };
+    auto load_pair = [&](int64_t ta, int64_t tb, bf8 (&f)[NJ]) {
+        const int64_t t = sub ? tb : ta;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f[j] = Ap[(t * NB + (j >> 1)) * 64 + (j & 1) * 32 + loff];
+    };
+    auto chain = [&](const bf8 (&f)[NJ], int s) {
+        f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], b[s][j], c, 0, 0, 0);
+        return c;
+    };
+    auto colmax32 = [&](const f16v& v, int nr) {   // largest of the lane's first nr registers, then over the two halves of the column
+        float mx = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            if (r < nr) mx = v[r] > mx ? v[r] : mx;
+        const float o = __shfl_xor(mx, 32);
+        return mx > o ? mx : o;
+    };
+
+    // ---- offsets: the largest exponent of PBN_BF16_PROBES tile pairs spread over the split (see kde_sweep_bf16_body) ----
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) set_off(s);   // m = 0
+        float mm[S];
+#pragma unroll 1
+        for (int pz = 0; pz < PBN_BF16_PROBES; ++pz) {
+            const int64_t ta = t0 + (t1 - t0) * pz / PBN_BF16_PROBES;
+            const int64_t tb = ta + 1 < t1 ? ta + 1 : ta;
+            bf8 f[NJ];
+            load_pair(ta, tb, f);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float mx = colmax32(chain(f, s), 16);
+                mm[s] = (pz == 0 || mx > mm[s]) ? mx : mm[s];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) { m[s] = mm[s]; set_off(s); }
+    }
+
+    // ---- checked form (the redo of a chunk whose sums overflowed, and the odd tail): one tile pair, super-group by super-group ----
+    auto checked_pair = [&](int64_t ta, int64_t tb, const bool second) {
+        bf8 f[NJ];
+        load_pair(ta, tb, f);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f16v acc = chain(f, s);
+            const int nr = second ? 16 : 8;
+            auto tile_sum = [&]() {
+                float ts = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < nr) ts += Tr<float>::ex2(acc[r]);
+                return ts;
+            };
+            float ts = tile_sum();
+            if (__builtin_expect(__any(!(ts < Tr<float>::big())), 0)) {
+                const float mx = colmax32(acc, nr);
+                if (mx > 0.f) {
+                    m[s] += mx;
+                    set_off(s);
+                    sum[s] *= exp2(-(double)mx);
+                    acc -= mx;
+                }
+                ts = tile_sum();
+            }
+            sum[s] += (double)ts;
+        }
+    };
+
+    // ---- blind run of nbody x 4 tiles from c0: software-pipelined by one super-group, the stream placed by hand ----
+    float fs[S];
+    auto expsum = [&](const f16v& v) {   // 16 v_exp_f32 + 15 v_add_f32: four quads (e0 + e1) + (e2 + e3), added in order
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float e0 = Tr<float>::ex2(v[4 * k]), e1 = Tr<float>::ex2(v[4 * k + 1]), e2 = Tr<float>::ex2(v[4 * k + 2]), e3 = Tr<float>::ex2(v[4 * k + 3]);
+            q[k] = (e0 + e1) + (e2 + e3);
+        }
+        return ((q[0] + q[1]) + q[2]) + q[3];
+    };
+    auto place = [&]() {   // [MFMA, 4 trans, 4 VALU] x NJ
+#if PBN_BF16_W32_SCHED
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 16 / NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 16 / NJ, 0);
+        }
+#endif
+    };
+    // contiguous tile pairs: the lane's byte offset inside a pair is fixed, the pair's base is wave-uniform (scalar address arithmetic)
+    const uint32_t lane_b = (uint32_t)((sub * NB * 64 + loff) * 16);
+    auto load_run = [&](int64_t t, bf8 (&f)[NJ]) {
+        const PBN_GLOBAL char* base = (const PBN_GLOBAL char*)Ap + t * (int64_t)(NB * 64 * 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f[j] = *(const PBN_GLOBAL bf8*)(base + lane_b + (uint32_t)(((j >> 1) * 64 + (j & 1) * 32) * 16));
+    };
+    auto blind_run = [&](int64_t c0, int nbody) {
+        bf8 fA[NJ], fB[NJ];
+        f16v acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = -1000.f;   // the pipeline's first exponentials: 2^-1000 = 0
+        load_run(c0, fA);
+        int64_t t = c0;
+#pragma unroll 1
+        for (int i = 0; i < nbody; ++i, t += 4) {
+            load_run(t + 2, fB);
+            acc0 = chain(fA, 0);
+            fs[1] += expsum(acc1);
+            place();
+            acc1 = chain(fA, 1);
+            fs[0] += expsum(acc0);
+            place();
+            load_run(i + 1 < nbody ? t + 4 : t, fA);   // the last body's prefetch stays inside the run
+            acc0 = chain(fB, 0);
+            fs[1] += expsum(acc1);
+            place();
+            acc1 = chain(fB, 1);
+            fs[0] += expsum(acc0);
+            place();
+        }
+        fs[1] += expsum(acc1);
+    };
+
+    for (int64_t c0 = t0; c0 < t1; c0 += PBN_BF16_BLIND_CHUNK) {
+        const int64_t c1 = c0 + PBN_BF16_BLIND_CHUNK < t1 ? c0 + PBN_BF16_BLIND_CHUNK : t1;
+        const int nbody = (int)((c1 - c0) >> 2);
+        const int64_t cb = c0 + 4 * (int64_t)nbody;   // [cb, c1): at most three tiles, checked
+        if (nbody) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) fs[s] = 0.f;
+            blind_run(c0, nbody);
+            bool bad = false;
+#pragma unroll
+            for (int s = 0; s < S; ++s) bad = bad || !(fs[s] < Tr<float>::big());
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll 1
+                for (int64_t t = c0; t < cb; t += 2) checked_pair(t, t + 1, true);
+            } else {
+#pragma unroll
+                for (int s = 0; s < S; ++s) sum[s] += (double)fs[s];
+            }
+        }
+#pragma unroll 1
+        for (int64_t t = cb; t < c1; t += 2) checked_pair(t, t + 1 < c1 ? t + 1 : t, t + 1 < c1);
+    }
+
+    PBN_GLOBAL double* part = (PBN_GLOBAL double*)a.part;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        double v = sum[s];
+        v += __shfl_xor(v, 32);
+        if (v == 0.0 && (m[s] - m[s]) == 0.f) v = 1.0;   // an empty sum holds at least the offset's own term (see kde_sweep_bf16_body)
+        const int64_t qt = qt0 + 2 * s + sub;
+        if (half == 0 && qt < a.nqtiles) {
+            PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + qt * 16 + idx) * 2;
+            o[0] = (double)m[s];
+            o[1] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kde_cdf: CKDE::cdf.  The reference (CKDE.hpp:560-735 + KDE.cl.src:376-468) materialises, per tile of 64 test rows,
 // the N x 64 weight matrix W (marginal KDE terms), the N x 64 conditional means, their normal cdf, the element-wise
 // product and two column sums.  Here: the weights are the marginal sweep's 2^(s2 - m) (same MFMA + offset machinery),
@@ -2460,6 +2693,11 @@ bool use_bf16x3(int dtype) {
 
 int bf16x3_mfmas(int dm) { return (6 * dm + 3 + 31) / 32; }
 
+// the W32 form of the plain unpruned fp32 sweep: two 32-slot blocks (5...9 whitened dimensions) whose last three slots are free
+bool bf16x3_w32(int dm, int NB) {
+    return knob_int("PBN_BF16_W32", 1) != 0 && NB == 2 && 6 * dm + 6 <= 32 * NB;   // read per call: tests compare the two forms in one process
+}
+
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
     const int64_t npad = a.ntiles * 16;
     if (npad == 0) return;
@@ -2628,6 +2866,7 @@ int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
 }
 
+static std::atomic<unsigned long long> g_w32_launches{0};   // measurement aid (pbn_debug_w32_launches): launches of the W32 form
 template <bool COND>
 static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
     dim3 block(256);
@@ -2640,6 +2879,14 @@ static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t
         else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;
+    }
+    if constexpr (!COND) {
+        if (a.w32 && NB == 2) {   // same grid: a wave's four 16-query groups are its two 32-query super-groups
+            ++g_w32_launches;
+            hipLaunchKernelGGL((kde_sweep_bf16_w32_kernel<2>), grid, block, 0, st, a);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
     }
     switch (NB) {
         case 1: hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, false>), grid, block, 0, st, a); break;
@@ -2725,6 +2972,10 @@ void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStrea
 
 }  // namespace pbn
 
+extern "C" void pbn_debug_w32_launches(unsigned long long* n, int reset) {
+    if (n) *n = pbn::g_w32_launches.load();
+    if (reset) pbn::g_w32_launches.store(0);
+}
 extern "C" void pbn_debug_sweep_redo(unsigned long long* redo, unsigned long long* units, int reset) {
     unsigned long long z = 0;
     if (redo) (void)hipMemcpyFromSymbol(redo, HIP_SYMBOL(pbn::g_sweep_redo), sizeof z);

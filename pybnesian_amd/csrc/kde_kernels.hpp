@@ -74,6 +74,7 @@ struct SweepArgs {
     int count_redo; // measurement aid (PBN_SWEEP_COUNT_REDO): count the units of the unchecked pass that redo their split
     int fast;      // fp64 plain sweeps whose result is a SUM over the test rows: 2^f on the fp32 transcendental unit (kde_kernels.hip: exp2_f64_fract<true>)
     int wmul;      // fp64 plain sweeps with d mod 4 == 0: training norms as weights 2^norm behind the norms (PackArgs::write_w)
+    int w32;       // fp32 plain unpruned sweeps of 5...9 whitened dimensions: the 32x32x16 bf16 form (kde_sweep_bf16_w32_kernel; bf16x3_w32)
     // Tile pruning (low-dimensional fp64 sweeps of the score engine): both sides are packed in Morton order of their
     // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first
     // `pdims` whitened dimensions, and qtile_thr holds, per query tile, a lower bound of its queries' largest exponents
@@ -199,7 +200,8 @@ void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_
 // pruning drops; PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override the base, PBN_PRUNE_MARGIN_ADAPT=0 the scaling
 double prune_margin(int dtype, int64_t n_train, bool sum_only = false);
 bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
-int bf16x3_mfmas(int dm);     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
+int bf16x3_mfmas(int dm);
+bool bf16x3_w32(int dm, int NB);   // the training fragments carry ones in the last three slots and kde_sweep_bf16_w32_kernel applies     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
 
 // ---- more than 32 whitened dimensions (the reference's kernels loop over any d: kde/KDE.hpp:592-640): a generic, runtime-sized form of
 // the pack and of the sweep.  fp64 fragments in the classic order (fp32 tables are packed into doubles), norms added per value, the

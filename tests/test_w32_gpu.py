@@ -1,0 +1,106 @@
+"""GPU tier: the W32 form of the plain unpruned fp32 sweep (kde_sweep_bf16_w32_kernel: v_mfma_f32_32x32x16_bf16 on the bf16x3 fragments, the
+stream placed by hand) against the f64 oracle on the f32-rounded data and against the 16x16 form it replaces (PBN_BF16_W32=0, read per call).
+Covers: every dimension the form applies to (5...9), full and diagonal bandwidths, training sizes with an odd number of 16-row tiles, fewer
+tiles than one blind run, splits that end inside a chunk, and a table whose probe tiles all lie far from the queries (the blind chunks overflow
+and are redone checked: the offset-raise path).  Replaces kde/opencl_kernels/KDE.cl.src:115-121,143-170 for float tables."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pbn():
+    import pybnesian_amd
+
+    pybnesian_amd.load_library()
+    return pybnesian_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def _both(fn):
+    """fn() under the W32 form and under the 16x16 form."""
+    out = []
+    for v in ("1", "0"):
+        os.environ["PBN_BF16_W32"] = v
+        try:
+            out.append(fn())
+        finally:
+            os.environ.pop("PBN_BF16_W32", None)
+    return out
+
+
+@pytest.mark.parametrize("d", [5, 6, 7, 8, 9])
+@pytest.mark.parametrize("n,m", [(17, 5), (1000, 33), (3010, 257), (70001, 1025)])
+def test_w32_matches_the_oracle_and_the_16x16_form(pbn, oracle, d, n, m):
+    rng = np.random.default_rng(1000 * d + n)
+    mix = np.tril(rng.uniform(-0.5, 0.5, size=(d, d)), -1) + np.eye(d)
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame((rng.normal(size=(n, d)) @ mix.T) * 2.0 + 5.0, columns=names).astype("float32")
+    test = pd.DataFrame((rng.normal(size=(m, d)) @ mix.T) * 2.0 + 5.0, columns=names).astype("float32")
+    for cls, fn in ((pbn.KDE, oracle.kde_logl), (pbn.ProductKDE, oracle.product_kde_logl)):
+        k = cls(names)
+        k.fit(train)
+        want = fn(train.to_numpy().astype(np.float64), k.bandwidth, test.to_numpy().astype(np.float64))
+        w32, w16 = _both(lambda: (k.logl(test), k.slogl(test)))
+        assert np.allclose(w32[0], want, atol=5e-4, rtol=1e-4), "W32 against the f64 truth on the rounded data"
+        assert np.allclose(w32[0], w16[0], atol=2e-4, rtol=2e-5), "W32 against the 16x16 form"
+        assert abs(w32[1] - want.sum()) <= 1e-4 * abs(want.sum())
+        assert abs(w32[1] - w16[1]) <= 2e-5 * abs(w16[1])
+
+
+def test_w32_counts_the_sweeps_it_takes(pbn):
+    """The W32 kernel is the one that runs for d = 8 float tables (and is not for d = 4 / d = 10): the library's launch log says which."""
+    import ctypes as C
+
+    from pybnesian_amd import _lib
+
+    lib = _lib.load()
+    if not hasattr(lib, "pbn_debug_w32_launches"):
+        pytest.skip("no launch counter in this build")
+    rng = np.random.default_rng(5)
+    for d, expect in ((4, 0), (8, 1), (10, 0)):
+        names = [f"v{i}" for i in range(d)]
+        train = pd.DataFrame(rng.normal(size=(5000, d)), columns=names).astype("float32")
+        k = pbn.ProductKDE(names)
+        k.fit(train)
+        c = C.c_ulonglong(0)
+        lib.pbn_debug_w32_launches(C.byref(c), 1)
+        k.slogl(train.iloc[:500])
+        lib.pbn_debug_w32_launches(C.byref(c), 0)
+        assert (c.value > 0) == bool(expect), (d, c.value)
+
+
+def test_w32_offsets_are_raised_when_every_probe_is_far(pbn, oracle):
+    """4 000 training rows 30 bandwidth units away from the queries and 24 rows among them (between two probe tiles) right beside the queries:
+    the probes see only far rows, the near rows' exponents overflow against those offsets, the chunk is redone checked and the offsets rise."""
+    rng = np.random.default_rng(12)
+    d = 8
+    names = [f"v{i}" for i in range(d)]
+    far = rng.normal(loc=30.0, scale=0.5, size=(4000, d))
+    near = rng.normal(loc=0.0, scale=0.5, size=(24, d))
+    rows = np.vstack([far[:1100], near, far[1100:]])
+    train = pd.DataFrame(rows, columns=names).astype("float32")
+    test = pd.DataFrame(rng.normal(loc=0.0, scale=0.5, size=(300, d)), columns=names).astype("float32")
+    k = pbn.ProductKDE(names)
+    k.fit(train)
+    k.bandwidth = np.full(d, 0.04)
+    want = oracle.product_kde_logl(train.to_numpy().astype(np.float64), k.bandwidth, test.to_numpy().astype(np.float64))
+    w32, w16 = _both(lambda: k.logl(test))
+    assert np.all(np.isfinite(w32))
+    assert np.allclose(w32, want, atol=5e-4, rtol=1e-4)
+    assert np.allclose(w32, w16, atol=2e-4, rtol=2e-5)
+    # queries far from everything: every term underflows against nothing - the sums stay finite and equal to the oracle's
+    lost = pd.DataFrame(rng.normal(loc=-40.0, scale=0.5, size=(40, d)), columns=names).astype("float32")
+    want = oracle.product_kde_logl(train.to_numpy().astype(np.float64), k.bandwidth, lost.to_numpy().astype(np.float64))
+    got = _both(lambda: k.logl(lost))[0]
+    assert np.all(np.isfinite(got)) and np.allclose(got, want, rtol=1e-4, atol=5e-4)
