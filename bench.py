@@ -457,8 +457,8 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         kname = {"c3": "kde_sweep_group_kernel<double, 1, 2, FOLD> (grouped pruned fp64 sweep, sum-only) + kde_moment_group_kernel<1 | 2> "
                        "(the tile-moment pass of its one- and two-variable terms: one event pair spans both launches)",
                  "cv64": "kde_sweep_group_kernel<double, 1, 2, FOLD> (grouped pruned fp64 sweep, sum-only)"}.get(
-                     which, "kde_sweep_bf16_group_kernel<1> (grouped pruned fp32 sweep on bf16x3 fragments) + the per-slice kde_sweep_bf16_kernel")
-        kshort = {"c3": "kde_moment_group_kernel<2> + kde_sweep_group_kernel<double>", "cv64": "kde_sweep_group_kernel<double>"}.get(which, "kde_sweep_bf16_group_kernel")
+                     which, "kde_sweep_f16_group_kernel<1> (grouped pruned fp32 sweep on f16x2 fragments) + the per-slice kde_sweep_f16_kernel")
+        kshort = {"c3": "kde_moment_group_kernel<2> + kde_sweep_group_kernel<double>", "cv64": "kde_sweep_group_kernel<double>"}.get(which, "kde_sweep_f16_group_kernel")
         more["roofline"] = {"kernel": kname, "kernel_short": kshort, "bound": "valu-issue (v_exp + add per pair value inside the pruning radius; DESIGN.md 3.1)",
                             "device_s": kt["sweep"][0] * 1e-3, "launches": kt["sweep"][1], "share_of_estimate_s": kt["sweep"][0] * 1e-3 / dt,
                             "gram_s": kt["gram"][0] * 1e-3, "gram_launches": kt["gram"][1],
@@ -1172,12 +1172,16 @@ def main():
                     par32 = parity_block(torch, k32, b, tr32, te32, float(buf[2].item()), 1e-3, abs_tol=5e-3 if args.kde == "product" else 5e-4)
                 except Exception as ex:
                     par32 = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+            # the whole instruction stream of the W32 kernel at d = 8: per 1 024 pair values (16 per lane) 16 v_exp_f32 (8 issue cycles) + 16 v_add_f32 (4)
+            # + two v_mfma_f32_32x32x16_f16 (8 each) = 13 issue cycles per value
+            issue_pairs = 256 * 4 * 2.4e9 * 64.0 / 13.0
             return {"metric": "KDE slogl M-samples/s", "dtype": "f32", "parity": par32, "value": args.n_test * 5 / el / 1e6, "unit": "M-samples/s", "ms_per_step": el / 5 * 1e3,
                     "slogl": float(buf[2].item()), "rel_diff_vs_f64": abs(float(buf[2].item()) - slogl) / abs(slogl),
-                    "roofline": {"kernel": "kde_sweep_bf16_kernel", "bound": "valu-issue", "avg_launch_ms": ms / max(nl, 1),
+                    "roofline": {"kernel": "kde_sweep_f16_w32_kernel", "bound": "valu-issue", "avg_launch_ms": ms / max(nl, 1),
                                  "frac": pairs_ / (ms / max(nl, 1) * 1e-3) / peak_pairs,
+                                 "frac_of_issue_bound": pairs_ / (ms / max(nl, 1) * 1e-3) / issue_pairs,
                                  "note": "against the VALU-issue bound of the fp32 sweep (one v_exp_f32 + one v_add_f32 per pair value); the f32 "
-                                         "coordinates run as bf16x3 on the bf16 matrix cores (DESIGN.md 3.1)"}}
+                                         "coordinates run as two f16 pieces on the 16-bit matrix cores (DESIGN.md 3.1)"}}
 
         slogl = float(partial[args.warmup].item())
         leg("secondary_f32", f32_leg)
@@ -1197,14 +1201,14 @@ def main():
             peak_note = ("against the FP64 vector==matrix peak (v_mfma_f64 and the FP64 VALU share their issue slots on MI355X: "
                          "DESIGN.md §3.1)")
         else:
-            # fp32 sweep: the dot products run as bf16x3 on the bf16 matrix cores and overlap with the VALU, which is
+            # fp32 sweep: the dot products run as f16x2 on the 16-bit matrix cores and overlap with the VALU, which is
             # the binding unit: per pair value one v_exp_f32 (quarter rate: 8 issue cycles per wave64 on this part,
             # profiles/r1/microbench_r1.txt) and one v_add_f32 (4) at least.  Peak pair rate by VALU issue =
             # SIMDs x clock x 64 / 12 cycles, expressed in the same algorithmic flops (3d+2 per pair)
             peak_pairs = 256 * 4 * 2.4e9 * 64.0 / F32_VALU_CYCLES_PER_VALUE
             peak_tf = peak_pairs * FLOPS_PER_PAIR / 1e12
             peak_note = (f"against the VALU-issue bound of the fp32 sweep: one v_exp_f32 (8 issue cycles per wave64) + one v_add_f32 (4) per "
-                         f"pair value -> {peak_pairs / 1e12:.2f}e12 pairs/s x (3d+2) flop; the distances run as bf16x3 on the bf16 matrix "
+                         f"pair value -> {peak_pairs / 1e12:.2f}e12 pairs/s x (3d+2) flop; the distances run as f16x2 on the 16-bit matrix "
                          f"cores under the VALU work (the FP32 vector peak, {FP32_PEAK_TFLOPS} TFLOP/s, is not the binding unit)")
         traffic, traffic_source = pmc_traffic(args)
         out = {
@@ -1233,7 +1237,7 @@ def main():
                 "slogl_step0_rank_sum": slogl,
             },
             "roofline": {
-                "kernel": "kde_sweep_kernel" if args.dtype == "f64" else "kde_sweep_bf16_kernel",
+                "kernel": "kde_sweep_kernel" if args.dtype == "f64" else "kde_sweep_f16_w32_kernel",
                 "bound": "mfma",
                 "achieved": achieved_tf,
                 "peak": peak_tf,

@@ -103,8 +103,10 @@ int pbn_bandwidth(int selector, int kind, const double* cov, int d, int64_t n, i
  * Dimensions: any number of variables, as in the reference (KDE.hpp:592-640 loops over d).  Up to 32 (+ the conditional one of
  * pbn_ckde_fit) run the templated MFMA shapes; beyond, a generic runtime-sized pack + sweep in fp64 fragments (a CKDE of that size as
  * joint - marginal, CKDE.hpp:256-287); pbn_ckde_cdf / pbn_ckde_sample / pbn_ucv_* likewise beyond 16.
- * fp32 tables: fragments and sweeps are fp32 (bf16x3 on the matrix cores) unless the whitened training rows reach so far from the centre
- * that the Gram-form distances would lose them (2^-24 max|z|^2 > 5e-4) - then fp64 fragments are packed from the float columns. */
+ * fp32 tables: every whitened coordinate is cut into two f16 pieces and contracted on the matrix cores with f32 accumulation (as accurate as
+ * the f32 Gram form: DESIGN.md 4) unless the whitened training rows reach so far from the centre that the Gram-form distances would lose
+ * them (2^-24 max|z|^2 > 5e-4; 2^-22 max|z|^2 > 1e-3 for the dimensions whose fragments drop the product of the low pieces: 8, 9, 16-20) -
+ * then fp64 fragments are packed from the float columns.  A query more than 65504 whitened units from the centre is evaluated in fp64. */
 int pbn_kde_fit(pbn_ctx* ctx, const pbn_table* train, const int* cols, int d, int64_t row0, int64_t n,
                 const double* bandwidth, int kind, const double* center, pbn_kde** out);
 /* CKDE: replaces CKDE::_fit (factors/continuous/CKDE.hpp:182-200).  cols[0] is the variable,

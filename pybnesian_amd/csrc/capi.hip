@@ -346,7 +346,7 @@ static void kde_fit_impl(pbn_ctx* ctx, const pbn_table* train, const int* cols, 
     // fp32 table whose whitened rows reach too far from the centre for the fp32 Gram form (tiny bandwidths on spread-out data:
     // diagonal bandwidths of nearly collinear columns, user-set bandwidths): fp64 fragments + fp64 sweep on the float columns
     // (wide models - more than 32 dimensions - are packed into doubles anyway)
-    if (train->dtype == PBN_F32 && n > 0 && !k->m.wide && kde_wants_widening(kde_max_norm2(ctx, k->m, train, cols, row0, n, 0))) kde_widen(k->m);
+    if (train->dtype == PBN_F32 && n > 0 && !k->m.wide && kde_wants_widening(kde_max_norm2(ctx, k->m, train, cols, row0, n, 0), k->m.dm)) kde_widen(k->m);
     const int fdt = k->m.fdtype();
     // Low-dimensional CKDE on a large training set: two pruned plain sweeps (joint over [variable, evidence], marginal over
     // the evidence with H[1:, 1:] - CKDE.hpp:186-199) beat the fused sweep, whose pruning can only use the marginal box

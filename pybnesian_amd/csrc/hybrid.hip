@@ -522,7 +522,7 @@ void HybridBatch::flush() {
         // at the accuracy of the per-row path
         bool any = false;
         for (const Redo& r : redo_info) {
-            if (f32 ? !kde_wants_widening(hmax[(size_t)r.slot]) : !kde_sum_needs_precision(hs[(size_t)r.slot], r.nte)) continue;
+            if (f32 ? !kde_wants_widening(hmax[(size_t)r.slot], r.nv) : !kde_sum_needs_precision(hs[(size_t)r.slot], r.nte)) continue;
             const int* v = rcols.data() + r.coff;
             KdeModel m;
             kde_prepare(m, sd->dtype, r.nv, r.N, rstore.data() + r.off, PBN_BW_FULL, false, rstore.data() + r.off + (size_t)r.nv * r.nv);

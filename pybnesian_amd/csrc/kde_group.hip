@@ -48,10 +48,10 @@ struct GDev {   // argument block of the block-wise kernels
     int xstride, Rs;
     int nunits;
     int use_sum_bound;
-    int bf16;                 // fp32 table: bf16x3 fragments (kde_kernels.hip pack_rows_bf16_kernel), KS = number of bf16 MFMAs
+    int f16;                 // fp32 table: f16x2 fragments (kde_kernels.hip pack_rows_f16_kernel), KS = number of f16 MFMAs
     int KS;                   // MFMAs per (tile, group) of the chunk's sweep shape
     int window;               // training rows the prepass scans on either side of a query's position (PBN_GROUP_WINDOW)
-    unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (bf16 chunks)
+    unsigned long long* out_max;   // nullable: [sum_slot] bits of the largest |z|^2 of a unit's training rows (f16 chunks)
     int hilbert;                   // Hilbert order instead of Z-order: 1 = at two key dimensions, 2 = at three and four as well (group_keys_kernel)
     int fine_keys;                 // 1-2 key dimensions: cells of sigma / 4096 (256) instead of sigma / 16 (group_keys_kernel)
     int tile_window;               // training TILES on either side of a query tile's position whose boxes bound the queries' sums from below (0 = off)
@@ -160,44 +160,9 @@ __global__ __launch_bounds__(64) void group_scan_kernel(GDev g) {
     }
 }
 
-typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void gsplit3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {   // kde_kernels.hip split3
-    p1 = (__bf16)x;
-    const float r1 = x - (float)p1;
-    p2 = (__bf16)r1;
-    const float r2 = r1 - (float)p2;
-    p3 = (__bf16)r2;
-}
-
-// bf16x3 fragments of one row (pack_rows_bf16_kernel): slot s = 6 k + role for dimension k, then the three pieces of the training
-// norm against ones; slot s lives in MFMA s / 32, lane group (s % 32) / 8, element s % 8
-__device__ __forceinline__ void store_bf16_row(gbf8* pack, int NB, int tile, int idx, int dm, const __bf16* p1, const __bf16* p2, const __bf16* p3,
-                                               float nv, bool query) {
-    __bf16 n1, n2, n3;
-    gsplit3(nv, n1, n2, n3);
-    const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
-    auto slot = [&](int sl) -> __bf16 {
-        if (sl < 6 * dm) {
-            const int k = sl / 6, role = sl % 6;
-            if (!query) return role == 2 || role == 5 ? p2[k] : (role == 4 ? p3[k] : p1[k]);   // a1 a1 a2 a1 a3 a2
-            return role == 1 || role == 5 ? p2[k] : (role == 3 ? p3[k] : p1[k]);                // b1 b2 b1 b3 b1 b2
-        }
-        const int t = sl - 6 * dm;
-        if (t < 3) return query ? one : (t == 0 ? n1 : (t == 1 ? n2 : n3));
-        return zero;
-    };
-    for (int mb = 0; mb < NB; ++mb)
-        for (int gq = 0; gq < 4; ++gq) {
-            gbf8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = slot(mb * 32 + gq * 8 + j);
-            pack[((int64_t)tile * NB + mb) * 64 + gq * 16 + idx] = v;
-        }
-}
-
 // whitened coordinates of one row, fragment stores shared by the two pack kernels (fp64 classic fragments, kde_kernels.hip
-// pack_rows_kernel: training side norms in C-row order + weights 2^norm, query side norms by row; fp32: bf16x3 fragments)
-// returns |z|^2 of the row (bf16 chunks; 0 otherwise)
+// pack_rows_kernel: training side norms in C-row order + weights 2^norm, query side norms by row; fp32: f16x2 fragments)
+// returns |z|^2 of the row (f16 chunks; 0 otherwise)
 __device__ __forceinline__ double pack_store(const GDev& g, const GUnit& U, const double* x, int d, int dest, bool query, int32_t tpos) {
     char* arena = g.arena;
     const int KS = g.KS;
@@ -206,21 +171,23 @@ __device__ __forceinline__ double pack_store(const GDev& g, const GUnit& U, cons
     for (int j = 0; j < d; ++j) xc[j] = x[j] - U.mu[j];
     double* zrow = (double*)(arena + (query ? U.zq : U.zs)) + (int64_t)dest * d;
     if (query) ((int32_t*)(arena + U.qpos))[dest] = tpos;
-    if (g.bf16) {
-        __bf16 p1[PBN_GROUP_MAX_D], p2[PBN_GROUP_MAX_D], p3[PBN_GROUP_MAX_D];
+    if (g.f16) {
+        hpiece p1[PBN_GROUP_MAX_D], p2[PBN_GROUP_MAX_D];
         double nrm = 0.0;
+        bool far = false;
         for (int c = 0; c < d; ++c) {
             double z = 0.0;
             for (int j = 0; j <= c; ++j) z = __builtin_fma(U.W[c * d + j], xc[j], z);
-            const float zf = (float)z;
-            zrow[c] = (double)zf;            // the rounding the fragments carry
-            nrm = __builtin_fma((double)zf, (double)zf, nrm);
-            gsplit3(zf, p1[c], p2[c], p3[c]);
+            bool cl;
+            const double zr = split2(z, p1[c], p2[c], cl);
+            far = far || cl;
+            zrow[c] = zr;            // the value the fragments carry
+            nrm = __builtin_fma(zr, zr, nrm);
         }
         const float nv = (float)(-0.5 * nrm);
-        store_bf16_row((gbf8*)(arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, p1, p2, p3, nv, query);
+        f16x2_store_row((hf8*)(arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, p1, p2, nv, query);
         if (query) ((float*)(arena + U.ny))[(int64_t)tile * 16 + idx] = nv;
-        return nrm;
+        return far ? INFINITY : nrm;   // a row beyond the f16 range: the caller's |z|^2 check sends the unit to fp64 fragments
     }
     double* pack = (double*)(arena + (query ? U.bpack : U.apack));
     double nrm = 0.0;
@@ -307,11 +274,11 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
             const int row = (query ? U.nq : U.N) + (j & 15);
             if (row >= (query ? U.nqtiles : U.ntiles) * 16) continue;
             const int tile = row >> 4, idx = row & 15;
-            if (g.bf16) {
-                __bf16 z1[PBN_GROUP_MAX_D], z2[PBN_GROUP_MAX_D], z3[PBN_GROUP_MAX_D];
-                for (int c = 0; c < d; ++c) z1[c] = z2[c] = z3[c] = (__bf16)0.0f;
+            if (g.f16) {
+                hpiece z1[PBN_GROUP_MAX_D], z2[PBN_GROUP_MAX_D];
+                for (int c = 0; c < d; ++c) z1[c] = z2[c] = (hpiece)0.0f;
                 const float nv = query ? 0.0f : -1e30f;
-                store_bf16_row((gbf8*)(g.arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, z1, z2, z3, nv, query);
+                f16x2_store_row((hf8*)(g.arena + (query ? U.bpack : U.apack)), KS, tile, idx, d, z1, z2, nv, query);
                 if (query) ((float*)(g.arena + U.ny))[(int64_t)tile * 16 + idx] = 0.0f;
                 continue;
             }
@@ -352,7 +319,9 @@ __global__ __launch_bounds__(GB) void group_pack_query_kernel(GDev g) {
     int tpos = 0;
     for (int rr = 0; rr < P.R; ++rr)
         if ((U.train_mask >> rr) & 1ull) tpos += before(rr);
-    pack_store(g, U, g.xs + (P.elem0 + i) * g.xstride, d, dest, true, tpos);
+    const double z2 = pack_store(g, U, g.xs + (P.elem0 + i) * g.xstride, d, dest, true, tpos);
+    // a test row beyond the f16 range of the fp32 fragments: the unit is redone on fp64 fragments like one with far training rows
+    if (g.out_max && !(z2 < INFINITY)) atomicMax(g.out_max + U.sum_slot, (unsigned long long)__double_as_longlong((double)INFINITY));
 }
 
 // ---- bounding boxes of the 16-row training tiles: grid (blocks of 256 padded rows, units) ---------------------------------------
@@ -696,17 +665,17 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     }
     const int nu = (int)units.size();
     const int fdt = force_f64 ? PBN_F64 : t->dtype;   // type of the fragments and of the sweep (fp64 on float columns for widened units)
-    const bool bf16 = use_bf16x3(fdt);
-    const int d0 = pools[0].d, KS = bf16 ? bf16x3_mfmas(d0) : (d0 + 3) / 4;
+    const bool f16 = use_f16x2(fdt);
+    const int d0 = pools[0].d, KS = f16 ? f16x2_mfmas(d0) : (d0 + 3) / 4;
     const bool fold = d0 % 4 != 0;
-    const size_t frag_b = bf16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
+    const size_t frag_b = f16 ? (size_t)KS * 64 * 16 : (size_t)KS * 64 * 8;   // bytes of a 16-row tile's fragments
     // Moment pass (round 5): units of one or two dimensions on fp64 fragments - every term here is a sum (EF32 sweeps) - whose training
     // sets are dense enough for it to pay (moment_pass_rows; kde_group_run gives such sets chunks of their own).  PBN_MOMENT_PASS=0
     // switches it off (the sweep then takes every pair, as until round 4).
     bool dense = true;
     for (const GUnit& U : units) dense = dense && U.N >= moment_pass_rows();
-    const bool moments = !bf16 && d0 <= 2 && dense && knob_int("PBN_MOMENT_PASS", 1) != 0 && PBN_TUNE(PRUNE_GROUP_MASKS, 1) != 0;
-    const bool bboxes = !bf16 && PBN_TUNE(GROUP_BATCH_BOXES, 1) != 0;   // fp64 sweeps with per-group masks: one uniform test per (batch, group) first
+    const bool moments = !f16 && d0 <= 2 && dense && knob_int("PBN_MOMENT_PASS", 1) != 0 && PBN_TUNE(PRUNE_GROUP_MASKS, 1) != 0;
+    const bool bboxes = !f16 && PBN_TUNE(GROUP_BATCH_BOXES, 1) != 0;   // fp64 sweeps with per-group masks: one uniform test per (batch, group) first
     int64_t total_wg = 0;
     int max_ntiles = 0, max_nqtiles = 0, max_nq = 0, max_nbatch = 1;
     size_t off = 0;
@@ -719,7 +688,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         const int d = P.d, pd = P.kd;
         U.ntiles = (U.N + 15) / 16;
         U.nqtiles = (U.nq + 15) / 16;
-        const int split_tiles = split_tiles_for(U.ntiles, !bf16);
+        const int split_tiles = split_tiles_for(U.ntiles, !f16);
         const int nsplit0 = std::max(1, (U.ntiles + split_tiles - 1) / split_tiles);
         U.tps = (U.ntiles + nsplit0 - 1) / nsplit0;
         U.nsplit = (U.ntiles + U.tps - 1) / U.tps;
@@ -734,11 +703,11 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         max_nq = std::max(max_nq, U.nq);
         max_nbatch = std::max(max_nbatch, U.nsplit * ((U.tps + 63) / 64));
         U.apack = carve((size_t)U.ntiles * frag_b);
-        U.npack = carve(bf16 ? 256 : (size_t)U.ntiles * 16 * 8 * 2);
+        U.npack = carve(f16 ? 256 : (size_t)U.ntiles * 16 * 8 * 2);
         U.zs = carve((size_t)U.N * d * 8 + 8);
         U.box = carve((size_t)U.ntiles * 2 * pd * 8);
         U.bpack = carve((size_t)U.nqtiles * frag_b);
-        U.ny = carve((size_t)U.nqtiles * 16 * (bf16 ? 4 : 8));
+        U.ny = carve((size_t)U.nqtiles * 16 * (f16 ? 4 : 8));
         U.zq = carve((size_t)U.nq * d * 8 + 8);
         U.qpos = carve((size_t)U.nqtiles * 16 * 4);
         U.qbox = carve((size_t)U.nqtiles * 2 * pd * 8);
@@ -807,8 +776,8 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     g.arena = arena; g.xstride = xstride; g.Rs = Rs; g.nunits = nu;
     static const int sum_bound = PBN_TUNE(GROUP_SUM_BOUND, 1);
     g.use_sum_bound = sum_bound;
-    g.bf16 = bf16 ? 1 : 0; g.KS = KS;
-    g.out_max = bf16 ? (unsigned long long*)dev_out_max : nullptr;
+    g.f16 = f16 ? 1 : 0; g.KS = KS;
+    g.out_max = f16 ? (unsigned long long*)dev_out_max : nullptr;
     static const int tile_window = std::max(0, PBN_TUNE(GROUP_TILE_WINDOW, 256));
     g.tile_window = tile_window;
     static const int fine_keys = PBN_TUNE(GROUP_FINE_KEYS, 1);
@@ -865,7 +834,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
             HIP_CHECK(hipEventElapsedTime(&ms, le0, le1));
             int64_t pairs = 0;
             for (const GUnit& U : units) pairs += (int64_t)U.N * U.nq;
-            std::fprintf(stderr, "pbn-group-sweep d=%d %s pools=%d units=%d pairs=%lld ms=%.3f\n", d0, bf16 ? "f32" : "f64", np, nu, (long long)pairs, ms);
+            std::fprintf(stderr, "pbn-group-sweep d=%d %s pools=%d units=%d pairs=%lld ms=%.3f\n", d0, f16 ? "f32" : "f64", np, nu, (long long)pairs, ms);
             (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
         }
     }
@@ -905,13 +874,13 @@ size_t kde_group_pool_bytes(const GroupBatch& b, const GPool& P) { return pool_b
 bool kde_group_applies(int dtype, int d, int64_t n_min, int R) {
     const int on = knob_int("PBN_SCORE_GROUPED", 1);   // read per call: the tests switch it
     // fp64 classic fragments; sets whose boxes cover every dimension (no subsample bound needed); the pruned-sweep shapes
-    return on && (dtype == PBN_F64 || use_bf16x3(dtype)) && d >= 1 && d <= std::min(PBN_TUNE(PRUNE_BOX_DIMS, 4), 4) && R >= 1 &&
+    return on && (dtype == PBN_F64 || use_f16x2(dtype)) && d >= 1 && d <= std::min(PBN_TUNE(PRUNE_BOX_DIMS, 4), 4) && R >= 1 &&
            R <= PBN_GROUP_MAX_R && kde_prune_applies(dtype, d, n_min);
 }
 
 void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max, bool force_f64) {
     if (b.pools.empty()) return;
-    if (!force_f64 && t->dtype != PBN_F64 && !use_bf16x3(t->dtype)) throw invalid_error("grouped KDE evaluation: fp64 tables, or fp32 tables on the bf16 matrix cores");
+    if (!force_f64 && t->dtype != PBN_F64 && !use_f16x2(t->dtype)) throw invalid_error("grouped KDE evaluation: fp64 tables, or fp32 tables on the f16 matrix cores");
     HIP_CHECK(hipSetDevice(ctx->device));
     for (const GPool& P : b.pools) {
         if (P.d < 1 || P.d > PBN_GROUP_MAX_D || P.kd < 1 || P.kd > PBN_PRUNE_PD || P.kd > P.d || P.R < 1 || P.R > PBN_GROUP_MAX_R || P.n < 1)
@@ -924,7 +893,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     // pools of one sweep shape together (KS, norm in a K slot or as weights), larger sets first
     std::vector<int> order(b.pools.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    const bool bf16 = !force_f64 && use_bf16x3(t->dtype);
+    const bool f16 = !force_f64 && use_f16x2(t->dtype);
     // (fp64 sets of one and of two variables get chunks of their own: their units take the moment pass, whose records and kernel depend on d)
     // (... and only when every training set of the pool is dense enough: moment_pass_rows)
     const int mom_rows = moment_pass_rows();
@@ -935,7 +904,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     };
     auto variant = [&](int i) {
         const int d = b.pools[i].d;
-        return bf16 ? bf16x3_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0) + (d <= 2 ? 16 * d + (dense(b.pools[i]) ? 64 : 0) : 0);
+        return f16 ? f16x2_mfmas(d) * 2 : ((d + 3) / 4) * 2 + (d % 4 == 0 ? 1 : 0) + (d <= 2 ? 16 * d + (dense(b.pools[i]) ? 64 : 0) : 0);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return variant(x) < variant(y); });
     const size_t budget = kde_group_arena_budget();

@@ -72,7 +72,7 @@ struct GroupBatch {
 // Runs the whole chain on ctx->stream for an f64 table and adds nothing to the host: out_sums[unit.sum_slot] receives the
 // unit's sum of log-densities (device pointer).  The batch may hold any number of pools; it is cut into chunks that fit
 // `arena_budget` bytes of the context's arena.
-// dev_out_max (nullable, fp32 tables on bf16x3 fragments): dev_out_max[unit.sum_slot] receives |z|^2 of the unit's farthest whitened
+// dev_out_max (nullable, fp32 tables on f16x2 fragments): dev_out_max[unit.sum_slot] receives |z|^2 of the unit's farthest whitened
 // training row, as the bits of a non-negative double (atomic max: the caller zeroes it) - the caller re-evaluates the units that
 // kde_wants_widening() flags with force_f64 = true: fp64 fragments and fp64 sweeps on the float columns (KdeModel::widen).
 void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_out_sums, double* dev_out_max = nullptr, bool force_f64 = false);

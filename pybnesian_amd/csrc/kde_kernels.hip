@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
 #ifndef PBN_PRUNE_MARGIN
 #define PBN_PRUNE_MARGIN 52.0
 #endif
-// fp32 (bf16x3) sweeps: 2^-40.  What is dropped is at most N * 2^-40 of a sum (9e-7 at 10^6 rows, against the fp32 bar of
+// fp32 (f16x2) sweeps: 2^-40.  What is dropped is at most N * 2^-40 of a sum (9e-7 at 10^6 rows, against the fp32 bar of
 // 1e-3 and fp32's own 6e-8 per term); the support shrinks from 9.4 to 7.4 bandwidths per axis (a third of the tiles at 2-3
 // dimensions).
 #ifndef PBN_PRUNE_MARGIN_F32
@@ -870,7 +870,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             for (int g = 0; g < QG; ++g) {
                 const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
                 const T lb = __builtin_ceil((T)QLp[qt * 16 + (lane & 15)]);
-                // (a bound too large for T to hold to a fraction of a unit is not used: see kde_sweep_bf16_kernel)
+                // (a bound too large for T to hold to a fraction of a unit is not used: see kde_sweep_f16_kernel)
                 const bool fin = (lb < (T)0 ? -lb : lb) < (sizeof(T) == 8 ? (T)0x1p50 : (T)0x1p22);
                 lbm[g] = fin && lb > m[g];
                 if (lbm[g]) {
@@ -1192,7 +1192,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             sj += __shfl_xor(sj, 16);
             sj += __shfl_xor(sj, 32);
         }
-        // an empty sum still holds the term its offset came from (see kde_sweep_bf16_kernel; 2^bias is that term here)
+        // an empty sum still holds the term its offset came from (see kde_sweep_f16_kernel; 2^bias is that term here)
         // (only when the offset is a real exponent: a NaN / infinite offset - NaN queries, an all-padding split - keeps its sum)
         const bool mfin = (m[g] - m[g]) == (T)0;
         // (not with a moment pass beside this sweep: the tile the offset came from may be the other pass's - an empty sum is empty)
@@ -1401,36 +1401,37 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32 path on the bf16 matrix cores ("bf16x3"): v_mfma_f32_16x16x4_f32 runs on the same FMA units as the
-// VALU (measured: no overlap, tools/microbench.hip), v_mfma_f32_16x16x32_bf16 does not (a 16-cycle MFMA costs the
-// VALU ~8 issue cycles).  Every f32 coordinate is split into three bf16 pieces z = a1 + a2 + a3 (24 mantissa
-// bits); the six products with combined weight >= 2^-24 (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2) are exact in the
-// f32 accumulator, so z_t.z_q is obtained to f32 accuracy from K = 6 d slots.  The training norm -1/2|z_t|^2 rides
-// along as three more slots against ones, the query side -1/2|z_q|^2 - m_q is the MFMA's C operand (a persistent
-// register quad), so the VALU does nothing but v_exp_f32 and the sums.
-// Slot s of a row: s = 6 k + r (dimension k, role r) for s < 6 dm, then the three norm pieces; slot s lives in MFMA
-// s / 32, lane group (s % 32) / 8, element s % 8.   Fragment arrays: [tile][NB][64 lanes][8 bf16].
-// CKDE: one extra MFMA whose 12 slots are the extra coordinate (6), its training norm against ones (3) and ones
-// against the query norm + (m_marg - m_joint) (3, rewritten by the lanes of group 1 when an offset is raised).
+// fp32 path on the 16-bit matrix cores ("f16x2", round 6; rounds 1-5: "bf16x3"): v_mfma_f32_16x16x4_f32 runs on the same FMA units as
+// the VALU (measured: no overlap, tools/microbench.hip), v_mfma_f32_16x16x32_f16 does not (a 16-cycle MFMA costs the VALU ~8 issue
+// cycles).  Round 6 measured the f16x2 sweep POWER-bound (profiles/r6/f32_power_bound.txt: 19 % fewer cycles bought a 19 % lower
+// clock; 2.0 PFLOP/s of dense bf16 MFMA work): what a pair value costs in wall time is its matrix work, so the contraction is halved -
+// every whitened coordinate is split into TWO f16 pieces z^ = a1 + a2 (a1 = f16(z), a2 = f16(z - a1): 22 mantissa bits, |z - z^| <=
+// 2^-22 |z|), the three products with weight >= 2^-11 (a1 b1, a1 b2, a2 b1) are exact in the f32 accumulator, the fourth (a2 b2,
+// <= 2^-22 |a||b|) is dropped, and the norms are taken from the REPRESENTED z^: what the sweep evaluates is -1/2 |z^_t - z^_q|^2 up to
+// the dropped products - an input perturbation of 2^-22 relative (fp32 inputs carry 2^-24 themselves) plus <= 2^-22 sum |a2 b2|, where
+// bf16x3 paid 2^-24 |z|^2 of cancellation error with its norms from the unsplit z.  K = 3 d + 3 slots instead of 6 d + 3: ONE 32-slot
+// MFMA per tile pair up to 9 dimensions (two before), two up to 20.
+// f16 has 5 exponent bits: pieces are kept out of its subnormal range and inside its finite range by power-of-two slot scales -
+//   coordinate k, slots 3k ... 3k+2:   training (a1, a1 2^-6, a2 2^6)   x   query (b1, b2 2^6, b1 2^-6);
+//   a scalar that rides in slots (the training norm -1/2|z^_t|^2, the CKDE / W32 query offsets) is cut by split3s into three pieces
+//   x = 2^15 p1 + 2^5 p2 + 2^-6 p3 against the constants (2^15, 2^5, 2^-6) on the other side: |x| <= 2^31, residual <= 2^-33 |x|;
+//   a piece that would be subnormal is stored as zero (its value stays in the residual the next piece takes), so the result does not
+//   depend on whether the matrix cores flush f16 subnormals.
+// Query coordinates beyond +-65504 (54 000 bandwidths from the centre of the training set) are clamped and counted (PackArgs::far_count).
+// Slot s of a row: s = 3 k + r (dimension k, role r) for s < 3 dm, then the three norm pieces; slot s lives in MFMA s / 32, lane group
+// (s % 32) / 8, element s % 8.   Fragment arrays: [tile][NB][64 lanes][8 f16].  The query side -1/2|z^_q|^2 - m_q is the MFMA's C operand
+// (a persistent register quad), so the VALU does nothing but v_exp_f32 and the sums.
+// CKDE: one extra MFMA whose slots are the extra coordinate (0-2), its training norm against the constants (3-5) and the constants against
+// the query norm + (m_marg - m_joint) (8-10, rewritten by the lanes of group 1 when an offset is raised).
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
-    p1 = (__bf16)x;
-    const float r1 = x - (float)p1;
-    p2 = (__bf16)r1;
-    const float r2 = r1 - (float)p2;
-    p3 = (__bf16)r2;
-}
-
-__global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
+__global__ __launch_bounds__(256) void pack_rows_f16_kernel(PackArgs a) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t npad = a.ntiles * 16;
     if (r >= npad) return;
     const int64_t tile = r >> 4;
     const int idx = (int)(r & 15);
     const int d = a.d, dm = a.dm;
-    const int NB = a.KS;  // number of bf16 MFMAs of the main contraction
+    const int NB = a.KS;  // number of 32-slot MFMAs of the main contraction
     const bool valid = r < a.n;
 
     double xc[PBN_MAX_D];
@@ -1443,46 +1444,24 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
             xc[j] = (double)col[src] - a.mu[j];
         }
     }
-    __bf16 p1[PBN_MAX_D], p2[PBN_MAX_D], p3[PBN_MAX_D];
+    hpiece p1[PBN_MAX_D], p2[PBN_MAX_D];
     double nrm = 0.0;
+    bool far = false;
     for (int i = 0; i < dm; ++i) {
         double z = 0.0;
         if (valid) {
             const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
             for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
         }
-        const float zf = (float)z;
-        nrm = __builtin_fma((double)zf, (double)zf, nrm);
-        split3(zf, p1[i], p2[i], p3[i]);
+        bool cl;
+        const double zr = split2(z, p1[i], p2[i], cl);
+        far = far || cl;
+        nrm = __builtin_fma(zr, zr, nrm);
     }
     float nv = (float)(-0.5 * nrm);
     if (!valid) nv = a.is_query ? 0.0f : (float)PBN_PAD_NORM;
-    __bf16 n1, n2, n3;
-    split3(nv, n1, n2, n3);
-    const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
-    auto slot = [&](int s) -> __bf16 {
-        if (s < 6 * dm) {
-            const int k = s / 6, role = s % 6;
-            if (!a.is_query) {  // a1 a1 a2 a1 a3 a2
-                return role == 2 || role == 5 ? p2[k] : (role == 4 ? p3[k] : p1[k]);
-            }                   // b1 b2 b1 b3 b1 b2
-            return role == 1 || role == 5 ? p2[k] : (role == 3 ? p3[k] : p1[k]);
-        }
-        const int t = s - 6 * dm;
-        if (t < 3) return a.is_query ? one : (t == 0 ? n1 : (t == 1 ? n2 : n3));
-        // the last three slots of the contraction: ones on the training side when they are free - kde_sweep_bf16_w32_kernel puts the query
-        // norm and offset there (the query fragments hold zeros: nothing changes for the 16x16 kernels)
-        if (!a.is_query && s >= 32 * NB - 3 && 6 * dm + 6 <= 32 * NB) return one;
-        return zero;
-    };
-    bf8* pack = (bf8*)a.pack;
-    for (int mb = 0; mb < NB; ++mb)
-        for (int g = 0; g < 4; ++g) {
-            bf8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = slot(mb * 32 + g * 8 + j);
-            pack[(tile * NB + mb) * 64 + g * 16 + idx] = v;
-        }
+    const hpiece zero = (hpiece)0.0f, c1 = (hpiece)PBN_H_C1, c2 = (hpiece)PBN_H_C2, c3 = (hpiece)PBN_H_C3;
+    f16x2_store_row((hf8*)a.pack, NB, tile, idx, dm, p1, p2, nv, a.is_query != 0);
     if (a.is_query) ((float*)a.npack)[tile * 16 + idx] = nv;
     if (a.xpack) {
         double z = 0.0;
@@ -1490,28 +1469,105 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
             const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)dm * d;
             for (int j = 0; j <= dm; ++j) z = __builtin_fma(w[j], xc[j], z);
         }
-        const float zf = (float)z;
-        const float hn = (float)(-0.5 * (double)zf * (double)zf);
-        __bf16 e1, e2, e3, h1, h2, h3;
-        split3(zf, e1, e2, e3);
-        split3(hn, h1, h2, h3);
-        bf8* xp = (bf8*)a.xpack;
-        bf8 g0, g1, gz;
+        hpiece e1, e2, h1, h2, h3;
+        bool cl;
+        const double zr = split2(z, e1, e2, cl);
+        far = far || cl;
+        const float hn = (float)(-0.5 * zr * zr);
+        split3s(hn, h1, h2, h3);
+        const hpiece e1s = h_piece((float)e1 * (1.0f / PBN_H_LO));
+        hf8* xp = (hf8*)a.xpack;
+        hf8 g0, g1, gz;
 #pragma unroll
         for (int j = 0; j < 8; ++j) gz[j] = zero;
-        g1 = gz;
+        g0 = gz; g1 = gz;
         if (!a.is_query) {
-            g0[0] = e1; g0[1] = e1; g0[2] = e2; g0[3] = e1; g0[4] = e3; g0[5] = e2; g0[6] = h1; g0[7] = h2;
-            g1[0] = h3; g1[1] = one; g1[2] = one; g1[3] = one;
+            g0[0] = e1; g0[1] = e1s; g0[2] = e2; g0[3] = h1; g0[4] = h2; g0[5] = h3;
+            g1[0] = c1; g1[1] = c2; g1[2] = c3;
         } else {
-            g0[0] = e1; g0[1] = e2; g0[2] = e1; g0[3] = e3; g0[4] = e1; g0[5] = e2; g0[6] = one; g0[7] = one;
-            g1[0] = one; g1[1] = h1; g1[2] = h2; g1[3] = h3;
-            ((float*)a.xnorm)[tile * 16 + idx] = hn;  // base of the rewritable slots 9..11
+            g0[0] = e1; g0[1] = e2; g0[2] = e1s; g0[3] = c1; g0[4] = c2; g0[5] = c3;
+            g1[0] = h1; g1[1] = h2; g1[2] = h3;
+            ((float*)a.xnorm)[tile * 16 + idx] = hn;  // base of the rewritable slots 8..10
         }
         xp[tile * 64 + 0 * 16 + idx] = g0;
         xp[tile * 64 + 1 * 16 + idx] = g1;
         xp[tile * 64 + 2 * 16 + idx] = gz;
         xp[tile * 64 + 3 * 16 + idx] = gz;
+    }
+    if (a.is_query && a.far_flag) a.far_flag[r] = (far && valid) ? 1 : 0;
+}
+
+// Queries beyond the f16 range (PackArgs::far_flag; tens of thousands of bandwidths from the training set): one 256-thread block per query tile;
+// a flagged query is evaluated in fp64 against every training row DECODED from the fragments (a1 + a2 - the values the sweeps use), its
+// coordinates recomputed unclamped from the table, and its partials are replaced: split 0 gets (max exponent, sum), the others (the same
+// offset, 0).  Nothing but a flag test when no query is flagged.
+template <bool COND>
+__global__ __launch_bounds__(256) void kde_far_fix_kernel(PackArgs a, const hf8* __restrict__ Apack, const hf8* __restrict__ Axpack, int NB, int64_t n_train,
+                                                          int64_t ntiles, double* __restrict__ part, int nsplit, int64_t nqtiles) {
+    constexpr int P = COND ? 4 : 2;
+    __shared__ double zq[PBN_MAX_D + 1];
+    __shared__ double red[4][4];
+    const int64_t qtile = blockIdx.x;
+    for (int qi = 0; qi < 16; ++qi) {
+        const int64_t r = qtile * 16 + qi;
+        if (r >= a.n || !a.far_flag[r]) continue;   // (uniform over the block)
+        const int d = a.d, dm = a.dm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int64_t rr = a.perm ? (int64_t)a.perm[a.perm_stride > 1 ? r * a.perm_stride : r] : r;
+            const int64_t lr = rr < a.n0 ? a.row0 + rr : a.row1 + (rr - a.n0);
+            const int64_t src = a.rows ? (int64_t)a.rows[lr] : lr;
+            double xc[PBN_MAX_D];
+            for (int j = 0; j < d; ++j) xc[j] = (double)((const float*)a.base + (int64_t)a.cols[j] * a.ld)[src] - a.mu[j];
+            for (int i = 0; i < d; ++i) {
+                const double* w = (a.Wdev ? a.Wdev : a.W) + (size_t)i * d;
+                double z = 0.0;
+                for (int j = 0; j <= i; ++j) z = __builtin_fma(w[j], xc[j], z);
+                zq[i] = z;
+            }
+        }
+        __syncthreads();
+        double m = -INFINITY, s = 0.0, mj = -INFINITY, sj = 0.0;
+        const int spd = f16x2_spd(dm);
+        for (int64_t t = threadIdx.x; t < n_train; t += 256) {
+            const int64_t tile = t >> 4;
+            const int idx = (int)(t & 15);
+            double e = 0.0;
+            for (int k = 0; k < dm; ++k) {
+                const int s1 = spd * k, s2 = spd * k + 2;
+                const double a1 = (double)(float)Apack[(tile * NB + (s1 >> 5)) * 64 + ((s1 & 31) >> 3) * 16 + idx][s1 & 7];
+                const double a2 = (double)(float)Apack[(tile * NB + (s2 >> 5)) * 64 + ((s2 & 31) >> 3) * 16 + idx][s2 & 7];
+                const double df = a1 + a2 * (1.0 / (double)PBN_H_LO) - zq[k];
+                e = __builtin_fma(-0.5 * df, df, e);
+            }
+            if (e > m) { s = s * exp2(m - e) + 1.0; m = e; } else s += exp2(e - m);
+            if (COND) {
+                const double x1 = (double)(float)Axpack[tile * 64 + idx][0], x2 = (double)(float)Axpack[tile * 64 + idx][2];
+                const double df = x1 + x2 * (1.0 / (double)PBN_H_LO) - zq[dm];
+                const double ej = __builtin_fma(-0.5 * df, df, e);
+                if (ej > mj) { sj = sj * exp2(mj - ej) + 1.0; mj = ej; } else sj += exp2(ej - mj);
+            }
+        }
+        auto merge = [](double& m1, double& s1, double m2, double s2) {
+            if (m2 > m1) { s1 = s1 * exp2(m1 - m2) + s2; m1 = m2; } else if (m2 > -INFINITY) s1 += s2 * exp2(m2 - m1);
+        };
+        for (int off = 32; off >= 1; off >>= 1) {
+            merge(m, s, __shfl_xor(m, off), __shfl_xor(s, off));
+            if (COND) merge(mj, sj, __shfl_xor(mj, off), __shfl_xor(sj, off));
+        }
+        if ((threadIdx.x & 63) == 0) { double* o = red[threadIdx.x >> 6]; o[0] = m; o[1] = s; o[2] = mj; o[3] = sj; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) {
+                merge(m, s, red[w][0], red[w][1]);
+                if (COND) merge(mj, sj, red[w][2], red[w][3]);
+            }
+            for (int sp = 0; sp < nsplit; ++sp) {
+                double* o = part + ((int64_t)sp * nqtiles * 16 + r) * P;
+                o[0] = m; o[1] = sp == 0 ? s : 0.0;
+                if (COND) { o[2] = mj; o[3] = sp == 0 ? sj : 0.0; }
+            }
+        }
     }
 }
 
@@ -1519,40 +1575,40 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(PackArgs a) {
 // spills a few prologue / rare-path values to scratch, none in the tile loop).  One-wave workgroups walking irregular tile
 // lists are latency-bound: 2 -> 4 resident waves is worth 12 % of C5's hill-climb and 12-14 % on the fp32 handles;
 // 5 (96 VGPRs) spills inside the loop.
-#ifndef PBN_BF16_PRUNE_WAVES
-#define PBN_BF16_PRUNE_WAVES 4
+#ifndef PBN_F16_PRUNE_WAVES
+#define PBN_F16_PRUNE_WAVES 4
 #endif
-#ifndef PBN_BF16_WAVES
-#define PBN_BF16_WAVES 2   // the same for the unpruned fp32 sweeps of up to 10 dimensions (4 waves per workgroup: workgroups per CU)
+#ifndef PBN_F16_WAVES
+#define PBN_F16_WAVES 2   // the same for the unpruned fp32 sweeps of up to 10 dimensions (4 waves per workgroup: workgroups per CU)
 #endif
 // (Measured again in round 3 and dropped again: the tile sums of 8 / 16 consecutive tiles added in fp32 before they join the fp64 sums -
 //  one v_add_f32 instead of v_cvt_f64_f32 + v_add_f64 per (tile, group).  The allocator answers with +35 VGPRs (138 -> 173: two
 //  waves per SIMD instead of three): fp32 headline 14.5 -> 17.7 ms, 16.2 ms when held to three waves; tools/f32_variants.sh.)
-#ifndef PBN_BF16_PAIRSUM
-#define PBN_BF16_PAIRSUM 1
+#ifndef PBN_F16_PAIRSUM
+#define PBN_F16_PAIRSUM 1
 #endif
-#ifndef PBN_BF16_BLIND
-#define PBN_BF16_BLIND 1   // plain fp32 sweeps: batches / chunks of tiles without the per-tile overflow test, checked once at their end
+#ifndef PBN_F16_BLIND
+#define PBN_F16_BLIND 1   // plain fp32 sweeps: batches / chunks of tiles without the per-tile overflow test, checked once at their end
 #endif
 // Measured (tools/lib_variants.sh, profiles/r3/bf16_blind_probe.txt): pruned fp32 slice sweeps -5...6 % (C5 9.25 -> 9.04 s), unpruned sweeps
 // with one MFMA per tile pair -3.6 %; with two (d = 8 headline) +3 %: an unpruned split starts from the offsets of its own first tile, a near
 // row later in the split overflows against them (whitened squared distances differ by hundreds), and every such chunk is swept twice - chunks
 // of 256 / 1024 tiles 16.3 / 23.9 ms against 13.7.  So: always for the pruned sweeps (offsets from the prepass bounds: nothing to redo), chunks
-// of 64 tiles for the unpruned sweeps - the two-MFMA ones only since their offsets look at 16 tiles spread over the split (PBN_BF16_PROBES).
-#ifndef PBN_BF16_PROBES
-#define PBN_BF16_PROBES 16   // with them the two-MFMA unpruned sweep gains from the blind chunks too: d = 8 headline 13.89 -> 13.56 ms (4 probes: 13.82)
+// of 64 tiles for the unpruned sweeps - the two-MFMA ones only since their offsets look at 16 tiles spread over the split (PBN_F16_PROBES).
+#ifndef PBN_F16_PROBES
+#define PBN_F16_PROBES 16   // with them the two-MFMA unpruned sweep gains from the blind chunks too: d = 8 headline 13.89 -> 13.56 ms (4 probes: 13.82)
 #endif
-#ifndef PBN_BF16_FSUM
-#define PBN_BF16_FSUM 1
+#ifndef PBN_F16_FSUM
+#define PBN_F16_FSUM 1
 #endif
-#ifndef PBN_BF16_BLIND_CHUNK
-#define PBN_BF16_BLIND_CHUNK 64
+#ifndef PBN_F16_BLIND_CHUNK
+#define PBN_F16_BLIND_CHUNK 64
 #endif
-#ifndef PBN_BF16_BLIND_NB2
-#define PBN_BF16_BLIND_NB2 1   // (0 without the probe tiles of PBN_BF16_PROBES: see above)
+#ifndef PBN_F16_BLIND_NB2
+#define PBN_F16_BLIND_NB2 1   // (0 without the probe tiles of PBN_F16_PROBES: see above)
 #endif
 template <int NB, bool COND, int QG, bool PRUNE>
-__device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const unsigned bid) {
+__device__ __forceinline__ void kde_sweep_f16_body(const SweepArgs& a, const unsigned bid) {
     using V = f4;
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // pruned: one wave per workgroup (see kde_sweep_kernel)
     const int lane = threadIdx.x & 63;
@@ -1565,22 +1621,22 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
 
-    const PBN_GLOBAL bf8* __restrict__ Ap = (const PBN_GLOBAL bf8*)a.Apack;
-    const PBN_GLOBAL bf8* __restrict__ Xp = (const PBN_GLOBAL bf8*)a.Axpack;
-    const PBN_GLOBAL bf8* __restrict__ Bp = (const PBN_GLOBAL bf8*)a.Bpack;
+    const PBN_GLOBAL hf8* __restrict__ Ap = (const PBN_GLOBAL hf8*)a.Apack;
+    const PBN_GLOBAL hf8* __restrict__ Xp = (const PBN_GLOBAL hf8*)a.Axpack;
+    const PBN_GLOBAL hf8* __restrict__ Bp = (const PBN_GLOBAL hf8*)a.Bpack;
     const PBN_GLOBAL float* __restrict__ NYp = (const PBN_GLOBAL float*)a.nypack;
-    const PBN_GLOBAL bf8* __restrict__ BXp = (const PBN_GLOBAL bf8*)a.Bxpack;
+    const PBN_GLOBAL hf8* __restrict__ BXp = (const PBN_GLOBAL hf8*)a.Bxpack;
     const PBN_GLOBAL float* __restrict__ XNp = (const PBN_GLOBAL float*)a.Bxnorm;
     const PBN_GLOBAL double* __restrict__ TBp = (const PBN_GLOBAL double*)a.tile_box;
     const PBN_GLOBAL double* __restrict__ QBp = (const PBN_GLOBAL double*)a.qtile_box;
     const PBN_GLOBAL double* __restrict__ QTp = (const PBN_GLOBAL double*)a.qtile_thr;
     const PBN_GLOBAL double* __restrict__ QLp = (const PBN_GLOBAL double*)a.qlb;
 
-    bf8 b[QG][NB];
+    hf8 b[QG][NB];
     float ny[QG], m[QG];
     V cmv[QG];
     double sum[QG];
-    bf8 bx[QG];
+    hf8 bx[QG];
     float xn[QG], mj[QG];
     double sumj[QG];
 #pragma unroll
@@ -1614,27 +1670,27 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         }
         wthr -= a.prune_margin;
     }
-    auto set_bx = [&](int g) {  // slots 9..11 (lane group 1, elements 1..3) <- split3(xn + m - mj)
+    auto set_bx = [&](int g) {  // slots 8..10 (lane group 1, elements 0..2) <- split3s(xn + m - mj)
         if (lg == 1) {
-            __bf16 q1, q2, q3;
-            split3(xn[g] + (m[g] - mj[g]), q1, q2, q3);
-            bx[g][1] = q1; bx[g][2] = q2; bx[g][3] = q3;
+            hpiece q1, q2, q3;
+            split3s(xn[g] + (m[g] - mj[g]), q1, q2, q3);
+            bx[g][0] = q1; bx[g][1] = q2; bx[g][2] = q3;
         }
     };
-    auto load_tile = [&](int64_t t, bf8 (&f)[NB], bf8& x) {
+    auto load_tile = [&](int64_t t, hf8 (&f)[NB], hf8& x) {
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) f[mb] = Ap[(t * NB + mb) * 64 + lane];
         if (COND) x = Xp[t * 64 + lane];
     };
-    auto mfma_main = [&](const bf8 (&f)[NB], int g, V c) {
+    auto mfma_main = [&](const hf8 (&f)[NB], int g, V c) {
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[mb], b[g][mb], c, 0, 0, 0);
+        for (int mb = 0; mb < NB; ++mb) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[mb], b[g][mb], c, 0, 0, 0);
         return c;
     };
 
     // ---- prologue: offsets from the first tile ------------------------------------------------------------
     {
-        bf8 f[NB], x;
+        hf8 f[NB], x;
         load_tile(t0, f, x);
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
@@ -1645,18 +1701,18 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
             const float cm = ny[g] - mx;
             cmv[g] = V{cm, cm, cm, cm};
             if (COND) {
-                V accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);  // slots 9..11 hold xn (m = mj = 0)
+                V accj = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bx[g], acc, 0, 0, 0);  // slots 8..10 hold xn (m = mj = 0)
                 mj[g] = colmax<float>(max4<float>(accj));
                 set_bx(g);
             }
         }
-        // plain unpruned sweeps: the offsets also look at PBN_BF16_PROBES - 1 more tiles spread over the split - a split whose first 16
+        // plain unpruned sweeps: the offsets also look at PBN_F16_PROBES - 1 more tiles spread over the split - a split whose first 16
         // rows all lie far from a query otherwise meets rows hundreds of exponent units above its offset, and every such tile takes the
         // rescue path (or, in a blind chunk, costs the chunk a second pass)
-        if constexpr (!COND && !PRUNE && PBN_BF16_PROBES > 1) {
+        if constexpr (!COND && !PRUNE && PBN_F16_PROBES > 1) {
 #pragma unroll 1
-            for (int pz = 1; pz < PBN_BF16_PROBES; ++pz) {
-                load_tile(t0 + (t1 - t0) * pz / PBN_BF16_PROBES, f, x);
+            for (int pz = 1; pz < PBN_F16_PROBES; ++pz) {
+                load_tile(t0 + (t1 - t0) * pz / PBN_F16_PROBES, f, x);
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
                     const V c0 = {ny[g], ny[g], ny[g], ny[g]};
@@ -1704,16 +1760,16 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
     // VALU's exponentials, one overflow test per tile, the rare path redoes a group (C2 fp32: 15.2 -> 14.1 ms).  The
     // fused CKDE sweep and the pruned sweeps keep the group-by-group form: with two accumulator sets per group in flight,
     // or one wave per SIMD less, the other form loses (C5's sweeps 33 -> 40 s; pruned d = 1 plain sweep 8.3 -> 10.2 ms).
-    // plain unpruned sweeps (PBN_BF16_PAIRSUM): the sums of the two tiles of a loop iteration are added in fp32 and join the fp64 sums
+    // plain unpruned sweeps (PBN_F16_PAIRSUM): the sums of the two tiles of a loop iteration are added in fp32 and join the fp64 sums
     // together - one v_cvt_f64_f32 + v_add_f64 per group and TWO tiles
-    constexpr bool PAIRSUM = !COND && !PRUNE && PBN_BF16_PAIRSUM;
+    constexpr bool PAIRSUM = !COND && !PRUNE && PBN_F16_PAIRSUM;
     float pend[PAIRSUM ? QG : 1];
 #pragma unroll
     for (int g = 0; g < (PAIRSUM ? QG : 1); ++g) pend[g] = 0.f;
-    // PBN_BF16_FSUM (round 4): inside a BLIND batch / chunk (at most 64 tiles, looked at once at its end) the tile sums are added in fp32 and
+    // PBN_F16_FSUM (round 4): inside a BLIND batch / chunk (at most 64 tiles, looked at once at its end) the tile sums are added in fp32 and
     // join the fp64 sums once per batch - the v_cvt_f64_f32 + v_add_f64 per (tile, group) were 8 of the ~60 issue slots of a tile's four
     // groups.  At most 64 fp32 additions of positive terms: <= 4e-6 relative on a sum, against the fp32 bar of 1e-3.
-    constexpr bool FSUM = !COND && PBN_BF16_BLIND && PBN_BF16_FSUM;
+    constexpr bool FSUM = !COND && PBN_F16_BLIND && PBN_F16_FSUM;
     float fs[FSUM ? QG : 1];
 #pragma unroll
     for (int g = 0; g < (FSUM ? QG : 1); ++g) fs[g] = 0.f;
@@ -1723,17 +1779,17 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
             for (int g = 0; g < QG; ++g) { sum[g] += (double)fs[g]; fs[g] = 0.f; }
         }
     };
-    // `blind` (plain sweeps, PBN_BF16_BLIND): no overflow test and no rescue path - the caller looks at the fp64 sums once per batch / chunk
+    // `blind` (plain sweeps, PBN_F16_BLIND): no overflow test and no rescue path - the caller looks at the fp64 sums once per batch / chunk
     // of tiles and redoes it checked if one of them went bad (as the fp64 sweeps do).  An exponent overflows only 128 units above its
     // query's offset, and the offsets start from the prepass bounds (pruned) or from a tile of the split itself.
-    auto process_tile = [&](const bf8 (&f)[NB], const bf8& x, const int bit = 0, const bool flush = true, auto blind = std::false_type{}) {
+    auto process_tile = [&](const hf8 (&f)[NB], const hf8& x, const int bit = 0, const bool flush = true, auto blind = std::false_type{}) {
         constexpr bool BLIND = decltype(blind)::value;
         if constexpr (COND || PRUNE) {
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 V acc = mfma_main(f, g, cmv[g]);
                 V accj;
-                if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc, 0, 0, 0);
+                if (COND) accj = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bx[g], acc, 0, 0, 0);
                 float e0 = Tr<float>::ex2(acc[0]), e1 = Tr<float>::ex2(acc[1]), e2 = Tr<float>::ex2(acc[2]), e3 = Tr<float>::ex2(acc[3]);
                 float ts = (e0 + e1) + (e2 + e3);
                 float tsj = 0;
@@ -1776,7 +1832,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 acc[g] = mfma_main(f, g, cmv[g]);
-                if (COND) accj[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, bx[g], acc[g], 0, 0, 0);
+                if (COND) accj[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, bx[g], acc[g], 0, 0, 0);
             }
             bool bad = false;
 #pragma unroll
@@ -1835,7 +1891,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
         }
     };
 
-    bf8 fA[NB], fB[NB], xA, xB;
+    hf8 fA[NB], fB[NB], xA, xB;
     // (Measured and dropped, profiles/r3/prune_stream_probe.txt: the visit masks of the whole split taken first - lane w keeping the mask of
     //  batch w - and the kept tiles then walked as ONE stream across the batches through a ring of 3 or 4 tile fragments, the next set bit
     //  coming from scalar code on a v_readlane'd word.  The fp32 slice sweeps ran 9-12 % SLOWER (1.92 against 1.71 ms at 720 000 x 80 000,
@@ -1870,7 +1926,7 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                     b = b3;
                 }
             };
-            if constexpr (!COND && PBN_BF16_BLIND) {
+            if constexpr (!COND && PBN_F16_BLIND) {
                 double saved[QG];
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
@@ -1899,8 +1955,8 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
                 if (second) process_tile(fB, xB, 0, true, blind);
             }
         };
-        if constexpr (!COND && PBN_BF16_BLIND && (NB == 1 || PBN_BF16_BLIND_NB2)) {
-            constexpr int64_t CHUNK = PBN_BF16_BLIND_CHUNK;   // tiles (an even number: the pair sums are flushed at its end)
+        if constexpr (!COND && PBN_F16_BLIND && (NB == 1 || PBN_F16_BLIND_NB2)) {
+            constexpr int64_t CHUNK = PBN_F16_BLIND_CHUNK;   // tiles (an even number: the pair sums are flushed at its end)
             for (int64_t c0 = t0; c0 < t1; c0 += CHUNK) {
                 const int64_t c1 = c0 + CHUNK < t1 ? c0 + CHUNK : t1;
                 double saved[QG];
@@ -1952,13 +2008,13 @@ __device__ __forceinline__ void kde_sweep_bf16_body(const SweepArgs& a, const un
 }
 
 template <int NB, bool COND, int QG, bool PRUNE>
-__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_BF16_PRUNE_WAVES : (NB <= 2 ? PBN_BF16_WAVES : 2)) void kde_sweep_bf16_kernel(SweepArgs a) {
-    kde_sweep_bf16_body<NB, COND, QG, PRUNE>(a, blockIdx.x);
+__global__ __launch_bounds__(sweep_block_threads(PRUNE), PRUNE ? PBN_F16_PRUNE_WAVES : (NB <= 2 ? PBN_F16_WAVES : 2)) void kde_sweep_f16_kernel(SweepArgs a) {
+    kde_sweep_f16_body<NB, COND, QG, PRUNE>(a, blockIdx.x);
 }
 
 // grouped launch of the pruned plain fp32 sweeps (see kde_sweep_group_kernel)
 template <int NB>
-__global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) void kde_sweep_bf16_group_kernel(GSweepArgs g) {
+__global__ __launch_bounds__(sweep_block_threads(true), PBN_F16_PRUNE_WAVES) void kde_sweep_f16_group_kernel(GSweepArgs g) {
     const int u = g.wg_unit[blockIdx.x >> 6];
     const GSweepUnit& su = g.units[u];
     const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
@@ -1971,11 +2027,11 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) vo
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = 0;
-    kde_sweep_bf16_body<NB, false, PBN_BF16_QG_PRUNE, true>(a, bid);
+    kde_sweep_f16_body<NB, false, PBN_F16_QG_PRUNE, true>(a, bid);
 }
 
 // ------------------------------------------------------------------------------------------------
-// W32 form of the plain unpruned fp32 sweep (round 6): the SAME packed bf16x3 fragments contracted by v_mfma_f32_32x32x16_bf16 -
+// W32 form of the plain unpruned fp32 sweep (round 6): the SAME packed f16x2 fragments contracted by v_mfma_f32_32x32x16_f16 -
 // 32 training rows x 32 queries per accumulator, 16 pair values per lane and MFMA chain instead of 4.  An MFMA holds the SIMD's vector
 // issue for 8 cycles whatever its shape (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), so the matrix side of a pair value
 // costs 2 issue cycles at two 32-slot blocks (d = 5...9) instead of 4: the instruction-count bound of the d = 8 headline falls from
@@ -1990,21 +2046,21 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_BF16_PRUNE_WAVES) vo
 //     A training tile PAIR (rows 0-15 from one 16-row tile, 16-31 from another) feeds the A operand: lanes with (l % 32) < 16 read the first.
 //   * the query side -1/2|z_q|^2 - m_q cannot be the C operand (16 registers per super-group): it rides in the three LAST slots of the
 //     contraction (32 NB - 3 ...: split3 on the query side, rewritten when an offset moves; ones on the training side, written by
-//     pack_rows_bf16_kernel when 6 dm + 6 <= 32 NB - the 16x16 kernels meet zeros on the query side there), and C is the inline constant 0.
+//     pack_rows_f16_kernel when 6 dm + 6 <= 32 NB - the 16x16 kernels meet zeros on the query side there), and C is the inline constant 0.
 //   * accumulator row of register r: 8 (r / 4) + 4 h + r % 4 - registers 8...15 are the second tile of the pair (dropped for an odd tail).
-//   * blind chunks of 64 tiles with fp32 tile sums, offsets from 16 probe tile pairs, checked redo: as kde_sweep_bf16_body.
+//   * blind chunks of 64 tiles with fp32 tile sums, offsets from 16 probe tile pairs, checked redo: as kde_sweep_f16_body.
 // Replaces kde/opencl_kernels/KDE.cl.src:115-121,143-170 for fp32 tables of 5...9 whitened dimensions.
 // ------------------------------------------------------------------------------------------------
 typedef float f16v __attribute__((ext_vector_type(16)));
-#ifndef PBN_BF16_W32_WAVES
-#define PBN_BF16_W32_WAVES 2
+#ifndef PBN_F16_W32_WAVES
+#define PBN_F16_W32_WAVES 2
 #endif
-#ifndef PBN_BF16_W32_SCHED
-#define PBN_BF16_W32_SCHED 1
+#ifndef PBN_F16_W32_SCHED
+#define PBN_F16_W32_SCHED 1
 #endif
 
 template <int NB>
-__global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_kernel(SweepArgs a) {
+__global__ __launch_bounds__(256, PBN_F16_W32_WAVES) void kde_sweep_f16_w32_kernel(SweepArgs a) {
     constexpr int NJ = 2 * NB;   // MFMAs per chain
     constexpr int S = 2;         // super-groups of 32 queries per wave (= the 4 x 16 queries of the 16x16 kernel's wave: same grid)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2016,12 +2072,12 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
     const int64_t t0 = (int64_t)split * a.tiles_per_split;
     const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
 
-    const PBN_GLOBAL bf8* __restrict__ Ap = (const PBN_GLOBAL bf8*)a.Apack;
-    const PBN_GLOBAL bf8* __restrict__ Bp = (const PBN_GLOBAL bf8*)a.Bpack;
+    const PBN_GLOBAL hf8* __restrict__ Ap = (const PBN_GLOBAL hf8*)a.Apack;
+    const PBN_GLOBAL hf8* __restrict__ Bp = (const PBN_GLOBAL hf8*)a.Bpack;
     const PBN_GLOBAL float* __restrict__ NYp = (const PBN_GLOBAL float*)a.nypack;
     const int loff = half * 16 + idx;   // lane's place inside a (tile, block, j % 2) group of 32 fragment lanes
 
-    bf8 b[S][NJ];
+    hf8 b[S][NJ];
     float ny[S], m[S];
     double sum[S];
 #pragma unroll
@@ -2035,19 +2091,19 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
         sum[s] = 0.0;
     }
     auto set_off = [&](int s) {   // slots 32 NB - 3 ... of the query side <- split3(-1/2|z_q|^2 - m_q)
-        __bf16 q1, q2, q3;
-        split3(ny[s] - m[s], q1, q2, q3);
+        hpiece q1, q2, q3;
+        split3s(ny[s] - m[s], q1, q2, q3);
         if (half == 1) { b[s][NJ - 1][5] = q1; b[s][NJ - 1][6] = q2; b[s][NJ - 1][7] = q3; }
     };
-    auto load_pair = [&](int64_t ta, int64_t tb, bf8 (&f)[NJ]) {
+    auto load_pair = [&](int64_t ta, int64_t tb, hf8 (&f)[NJ]) {
         const int64_t t = sub ? tb : ta;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) f[j] = Ap[(t * NB + (j >> 1)) * 64 + (j & 1) * 32 + loff];
     };
-    auto chain = [&](const bf8 (&f)[NJ], int s) {
+    auto chain = [&](const hf8 (&f)[NJ], int s) {
         f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], b[s][j], c, 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[j], b[s][j], c, 0, 0, 0);
         return c;
     };
     auto colmax32 = [&](const f16v& v, int nr) {   // largest of the lane's first nr registers, then over the two halves of the column
@@ -2059,16 +2115,16 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
         return mx > o ? mx : o;
     };
 
-    // ---- offsets: the largest exponent of PBN_BF16_PROBES tile pairs spread over the split (see kde_sweep_bf16_body) ----
+    // ---- offsets: the largest exponent of PBN_F16_PROBES tile pairs spread over the split (see kde_sweep_f16_body) ----
     {
 #pragma unroll
         for (int s = 0; s < S; ++s) set_off(s);   // m = 0
         float mm[S];
 #pragma unroll 1
-        for (int pz = 0; pz < PBN_BF16_PROBES; ++pz) {
-            const int64_t ta = t0 + (t1 - t0) * pz / PBN_BF16_PROBES;
+        for (int pz = 0; pz < PBN_F16_PROBES; ++pz) {
+            const int64_t ta = t0 + (t1 - t0) * pz / PBN_F16_PROBES;
             const int64_t tb = ta + 1 < t1 ? ta + 1 : ta;
-            bf8 f[NJ];
+            hf8 f[NJ];
             load_pair(ta, tb, f);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -2082,7 +2138,7 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
 
     // ---- checked form (the redo of a chunk whose sums overflowed, and the odd tail): one tile pair, super-group by super-group ----
     auto checked_pair = [&](int64_t ta, int64_t tb, const bool second) {
-        bf8 f[NJ];
+        hf8 f[NJ];
         load_pair(ta, tb, f);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -2122,7 +2178,7 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
         return ((q[0] + q[1]) + q[2]) + q[3];
     };
     auto place = [&]() {   // [MFMA, 4 trans, 4 VALU] x NJ
-#if PBN_BF16_W32_SCHED
+#if PBN_F16_W32_SCHED
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -2133,13 +2189,13 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
     };
     // contiguous tile pairs: the lane's byte offset inside a pair is fixed, the pair's base is wave-uniform (scalar address arithmetic)
     const uint32_t lane_b = (uint32_t)((sub * NB * 64 + loff) * 16);
-    auto load_run = [&](int64_t t, bf8 (&f)[NJ]) {
+    auto load_run = [&](int64_t t, hf8 (&f)[NJ]) {
         const PBN_GLOBAL char* base = (const PBN_GLOBAL char*)Ap + t * (int64_t)(NB * 64 * 16);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) f[j] = *(const PBN_GLOBAL bf8*)(base + lane_b + (uint32_t)(((j >> 1) * 64 + (j & 1) * 32) * 16));
+        for (int j = 0; j < NJ; ++j) f[j] = *(const PBN_GLOBAL hf8*)(base + lane_b + (uint32_t)(((j >> 1) * 64 + (j & 1) * 32) * 16));
     };
     auto blind_run = [&](int64_t c0, int nbody) {
-        bf8 fA[NJ], fB[NJ];
+        hf8 fA[NJ], fB[NJ];
         f16v acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = -1000.f;   // the pipeline's first exponentials: 2^-1000 = 0
@@ -2165,8 +2221,8 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
         fs[1] += expsum(acc1);
     };
 
-    for (int64_t c0 = t0; c0 < t1; c0 += PBN_BF16_BLIND_CHUNK) {
-        const int64_t c1 = c0 + PBN_BF16_BLIND_CHUNK < t1 ? c0 + PBN_BF16_BLIND_CHUNK : t1;
+    for (int64_t c0 = t0; c0 < t1; c0 += PBN_F16_BLIND_CHUNK) {
+        const int64_t c1 = c0 + PBN_F16_BLIND_CHUNK < t1 ? c0 + PBN_F16_BLIND_CHUNK : t1;
         const int nbody = (int)((c1 - c0) >> 2);
         const int64_t cb = c0 + 4 * (int64_t)nbody;   // [cb, c1): at most three tiles, checked
         if (nbody) {
@@ -2193,7 +2249,7 @@ __global__ __launch_bounds__(256, PBN_BF16_W32_WAVES) void kde_sweep_bf16_w32_ke
     for (int s = 0; s < S; ++s) {
         double v = sum[s];
         v += __shfl_xor(v, 32);
-        if (v == 0.0 && (m[s] - m[s]) == 0.f) v = 1.0;   // an empty sum holds at least the offset's own term (see kde_sweep_bf16_body)
+        if (v == 0.0 && (m[s] - m[s]) == 0.f) v = 1.0;   // an empty sum holds at least the offset's own term (see kde_sweep_f16_body)
         const int64_t qt = qt0 + 2 * s + sub;
         if (half == 0 && qt < a.nqtiles) {
             PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + qt * 16 + idx) * 2;
@@ -2585,6 +2641,15 @@ void launch_sweep_wide(const SweepArgs& a, int KS, int nsplit, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
+void launch_far_fix(const PackArgs& q, const void* Apack, const void* Axpack, int NB, int64_t n_train, int64_t ntiles, double* part, int nsplit, int64_t nqtiles,
+                    bool cond, hipStream_t st) {
+    if (!q.far_flag || nqtiles == 0) return;
+    const dim3 grid((unsigned)nqtiles), block(256);
+    if (cond) hipLaunchKernelGGL(kde_far_fix_kernel<true>, grid, block, 0, st, q, (const hf8*)Apack, (const hf8*)Axpack, NB, n_train, ntiles, part, nsplit, nqtiles);
+    else hipLaunchKernelGGL(kde_far_fix_kernel<false>, grid, block, 0, st, q, (const hf8*)Apack, (const hf8*)Axpack, NB, n_train, ntiles, part, nsplit, nqtiles);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_max_norm2(const PackArgs& a, int src_dtype, double* dev_out, hipStream_t st) {
     if (a.n <= 0) return;
     dim3 grid((unsigned)ceil_div(a.n, 256)), block(256);
@@ -2679,31 +2744,31 @@ void launch_cdf_finish(const double* part, int nsplit, int64_t nqtiles, int64_t 
 double prune_margin(int dtype, int64_t n_train, bool sum_only) {
     const bool adapt = PBN_TUNE(PRUNE_MARGIN_ADAPT, 1) != 0;
     double base;
-    if (use_bf16x3(dtype)) base = knob_double("PBN_PRUNE_MARGIN_F32", (double)PBN_PRUNE_MARGIN_F32);
+    if (use_f16x2(dtype)) base = knob_double("PBN_PRUNE_MARGIN_F32", (double)PBN_PRUNE_MARGIN_F32);
     else base = knob_double("PBN_PRUNE_MARGIN", sum_only ? knob_double("PBN_PRUNE_MARGIN_SUM", (double)PBN_PRUNE_MARGIN_SUM) : (double)PBN_PRUNE_MARGIN);
     if (!adapt || n_train <= 0) return base;
     const double m = base + std::log2((double)n_train / 1e6);
     return m < 8.0 ? 8.0 : m;
 }
 
-bool use_bf16x3(int dtype) {
-    static const int v = PBN_TUNE(F32_BF16X3, 1);   // (0: fp32 tables on the f32 MFMA kernels - the round-1 path, kept for comparisons)
+bool use_f16x2(int dtype) {
+    static const int v = PBN_TUNE(F32_F16X2, 1);   // (0: fp32 tables on the f32 MFMA kernels - the round-1 path, kept for comparisons)
     return v != 0 && dtype == PBN_F32;
 }
 
-int bf16x3_mfmas(int dm) { return (6 * dm + 3 + 31) / 32; }
+int f16x2_mfmas(int dm) { return f16x2_blocks(dm); }   // f16x2: three (four where they fit) slots per dimension + the training norm
 
-// the W32 form of the plain unpruned fp32 sweep: two 32-slot blocks (5...9 whitened dimensions) whose last three slots are free
-bool bf16x3_w32(int dm, int NB) {
-    return knob_int("PBN_BF16_W32", 1) != 0 && NB == 2 && 6 * dm + 6 <= 32 * NB;   // read per call: tests compare the two forms in one process
+// the W32 form of the plain unpruned fp32 sweep: one or two 32-slot blocks whose last three slots are free (up to 8 / 19 whitened dimensions)
+bool f16x2_w32(int dm, int NB) {
+    return knob_int("PBN_F32_W32", 1) != 0 && (NB == 1 || NB == 2) && f16x2_spd(dm) * dm + 6 <= 32 * NB;   // read per call: tests compare the two forms in one process
 }
 
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
     const int64_t npad = a.ntiles * 16;
     if (npad == 0) return;
     dim3 grid((unsigned)ceil_div(npad, 256)), block(256);
-    if (use_bf16x3(dtype)) {
-        hipLaunchKernelGGL(pack_rows_bf16_kernel, grid, block, 0, st, a);
+    if (use_f16x2(dtype)) {
+        hipLaunchKernelGGL(pack_rows_f16_kernel, grid, block, 0, st, a);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -2850,7 +2915,7 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
 
 bool sweep_folds_norm(int dtype, bool cond, int KS, int dm) {
     static const int v = PBN_TUNE(SWEEP_FOLD, 1);
-    return v != 0 && !use_bf16x3(dtype) && dm % 4 != 0 && KS <= 4;   // more than 16 dimensions: one form only
+    return v != 0 && !use_f16x2(dtype) && dm % 4 != 0 && KS <= 4;   // more than 16 dimensions: one form only
 }
 
 bool sweep_weights_norm(int dtype, bool cond, int KS, int dm) {
@@ -2860,7 +2925,7 @@ bool sweep_weights_norm(int dtype, bool cond, int KS, int dm) {
 
 int sweep_qg(int dtype, bool cond, int KS, bool prune) {
     if (prune && dtype == PBN_F64) return cond ? PBN_QG_PRUNE_COND : PBN_QG_PRUNE;
-    if (prune && use_bf16x3(dtype) && !cond) return PBN_BF16_QG_PRUNE;   // (what the grids of the pruned launches - stand-alone and grouped - are sized with)
+    if (prune && use_f16x2(dtype) && !cond) return PBN_F16_QG_PRUNE;   // (what the grids of the pruned launches - stand-alone and grouped - are sized with)
     if (KS > 4) return 2;   // more than 16 (fp32: 20) dimensions: two query groups per wave (fragment registers); KS = MFMAs per tile pair
     if (dtype == PBN_F64) return cond ? SweepQG<true, true>::value : SweepQG<true, false>::value;
     return cond ? SweepQG<false, true>::value : SweepQG<false, false>::value;
@@ -2868,34 +2933,35 @@ int sweep_qg(int dtype, bool cond, int KS, bool prune) {
 
 static std::atomic<unsigned long long> g_w32_launches{0};   // measurement aid (pbn_debug_w32_launches): launches of the W32 form
 template <bool COND>
-static void launch_sweep_bf16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
+static void launch_sweep_f16(const SweepArgs& a, int NB, dim3 grid, hipStream_t st) {
     dim3 block(256);
-    if (a.prune) {   // at most 6 marginal dimensions: 39 bf16 slots, two MFMAs
+    if (a.prune) {   // at most 6 marginal dimensions: 27 f16 slots, one MFMA (two are kept instantiated)
         block = dim3(sweep_block_threads(true));
-        constexpr int QGP = PBN_BF16_QG_PRUNE;
+        constexpr int QGP = PBN_F16_QG_PRUNE;
         grid = dim3((unsigned)(ceil_div(a.nqtiles, QGP) * a.nsplit_grid));   // one wave (QGP query groups) per workgroup, placed by pruned_block
-        if (NB == 1) hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, QGP, true>), grid, block, 0, st, a);
-        else if (NB == 2) hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, QGP, true>), grid, block, 0, st, a);
+        if (NB == 1) hipLaunchKernelGGL((kde_sweep_f16_kernel<1, COND, QGP, true>), grid, block, 0, st, a);
+        else if (NB == 2) hipLaunchKernelGGL((kde_sweep_f16_kernel<2, COND, QGP, true>), grid, block, 0, st, a);
         else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;
     }
     if constexpr (!COND) {
-        if (a.w32 && NB == 2) {   // same grid: a wave's four 16-query groups are its two 32-query super-groups
+        if (a.w32 && (NB == 1 || NB == 2)) {   // same grid: a wave's four 16-query groups are its two 32-query super-groups
             ++g_w32_launches;
-            hipLaunchKernelGGL((kde_sweep_bf16_w32_kernel<2>), grid, block, 0, st, a);
+            if (NB == 1) hipLaunchKernelGGL((kde_sweep_f16_w32_kernel<1>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((kde_sweep_f16_w32_kernel<2>), grid, block, 0, st, a);
             HIP_CHECK(hipGetLastError());
             return;
         }
     }
     switch (NB) {
-        case 1: hipLaunchKernelGGL((kde_sweep_bf16_kernel<1, COND, 4, false>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((kde_sweep_bf16_kernel<2, COND, 4, false>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((kde_sweep_bf16_kernel<3, COND, 4, false>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((kde_sweep_bf16_kernel<4, COND, 4, false>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((kde_sweep_bf16_kernel<5, COND, 2, false>), grid, block, 0, st, a); break;   // 21-32 dimensions (sweep_qg: 2)
-        case 6: hipLaunchKernelGGL((kde_sweep_bf16_kernel<6, COND, 2, false>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((kde_sweep_bf16_kernel<7, COND, 2, false>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((kde_sweep_f16_kernel<1, COND, 4, false>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((kde_sweep_f16_kernel<2, COND, 4, false>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((kde_sweep_f16_kernel<3, COND, 4, false>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((kde_sweep_f16_kernel<4, COND, 4, false>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((kde_sweep_f16_kernel<5, COND, 2, false>), grid, block, 0, st, a); break;   // 21-32 dimensions (sweep_qg: 2)
+        case 6: hipLaunchKernelGGL((kde_sweep_f16_kernel<6, COND, 2, false>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((kde_sweep_f16_kernel<7, COND, 2, false>), grid, block, 0, st, a); break;
         default: throw invalid_error("KDE: more than 32 whitened dimensions per sweep are not supported");
     }
     HIP_CHECK(hipGetLastError());
@@ -2905,8 +2971,8 @@ void launch_sweep(const SweepArgs& a_in, int dtype, int KS, bool cond, int nspli
     SweepArgs a = a_in;
     a.nsplit_grid = nsplit;
     dim3 grid((unsigned)ceil_div(a.nqtiles, 4 * sweep_qg(dtype, cond, KS, a.prune != 0)), (unsigned)nsplit);
-    if (use_bf16x3(dtype)) {  // KS carries the number of bf16 MFMAs
-        if (cond) launch_sweep_bf16<true>(a, KS, grid, st); else launch_sweep_bf16<false>(a, KS, grid, st);
+    if (use_f16x2(dtype)) {  // KS carries the number of 32-slot f16 MFMAs
+        if (cond) launch_sweep_f16<true>(a, KS, grid, st); else launch_sweep_f16<false>(a, KS, grid, st);
         return;
     }
     if (dtype == PBN_F64) {
@@ -2930,14 +2996,14 @@ void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st
     if (g.total_wg == 0) return;
     if (g.total_wg > 0x7fffffffll) throw invalid_error("grouped sweeps: grid too large");
     const dim3 grid((unsigned)g.total_wg), block(sweep_block_threads(true));
-    if (use_bf16x3(dtype)) {   // KS carries the number of bf16 MFMAs
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<1>), grid, block, 0, st, g);
-        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_bf16_group_kernel<2>), grid, block, 0, st, g);
+    if (use_f16x2(dtype)) {   // KS carries the number of 32-slot f16 MFMAs
+        if (KS == 1) hipLaunchKernelGGL((kde_sweep_f16_group_kernel<1>), grid, block, 0, st, g);
+        else if (KS == 2) hipLaunchKernelGGL((kde_sweep_f16_group_kernel<2>), grid, block, 0, st, g);
         else throw invalid_error("grouped fp32 sweeps: at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());
         return;
     }
-    if (dtype != PBN_F64 || KS < 1 || KS > 2 || (g.fold != 0) == (g.wmul != 0)) throw invalid_error("grouped sweeps: fp64 / fp32 on the bf16 cores, at most 8 whitened dimensions");
+    if (dtype != PBN_F64 || KS < 1 || KS > 2 || (g.fold != 0) == (g.wmul != 0)) throw invalid_error("grouped sweeps: fp64 / fp32 on the f16 cores, at most 8 whitened dimensions");
     constexpr int QGP = PBN_QG_PRUNE;
     if (g.fold) {
         if (g.moments && (KS != 1 || !g.group_masks)) throw invalid_error("grouped sweeps: the moment pass stands beside one- and two-variable units with per-group masks");

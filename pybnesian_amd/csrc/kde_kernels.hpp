@@ -33,7 +33,7 @@ struct PackArgs {
     // the table holds float while the fragments are packed (and swept) in double: fp32 models whose whitened training rows reach so
     // far from the centre that the Gram-form distances would lose them in fp32 (KdeModel::widen); classic fp64 pack only
     int src_f32;
-    // classic (non-bf16) pack, dm % 4 != 0: the first unused K slot of the last MFMA carries the norm - training side
+    // classic (non-f16x2) pack, dm % 4 != 0: the first unused K slot of the last MFMA carries the norm - training side
     // -1/2|z|^2, query side 1 - so the sweep's accumulator starts from a per-query constant (no add per value).  A
     // query pack that leaves the slot 0 (CKDE::cdf, UCV) makes the training side's entry inert.
     int fold_norm;
@@ -53,11 +53,85 @@ struct PackArgs {
     void* pack;           // [ntiles][KS][64]
     void* npack;          // [ntiles][16]
     void* xpack;          // [ntiles][64] or null
-    void* xnorm;          // bf16x3 query side only: [ntiles][16] f32 base of the rewritable CKDE slots
+    void* xnorm;          // f16x2 query side only: [ntiles][16] f32 base of the rewritable CKDE slots
     // CKDE::cdf: u = sum_j wu[j] * (x_j - mu_j) over the d selected columns -> upack (npack layout); classic pack only
     double wu[PBN_MAX_D];
     void* upack;          // nullable
+    unsigned char* far_flag;  // nullable; f16x2 query pack: [16 ntiles] 1 for a row with a whitened coordinate beyond the f16 range (clamped in the fragments; kde_far_fix_kernel)
 };
+
+
+// ---- f16x2 fragments of fp32 tables (kde_kernels.hip, "fp32 path on the 16-bit matrix cores"): device helpers shared by the pack kernels ----
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));   // (eight 16-bit pieces of a fragment lane)
+typedef _Float16 hpiece;
+#define PBN_H_C1 32768.0f      // 2^15
+#define PBN_H_C2 32.0f         // 2^5
+#define PBN_H_C3 0.015625f     // 2^-6
+#define PBN_H_LO 64.0f         // scale of the low coordinate piece (its partner carries 2^-6)
+#define PBN_H_MAX 65504.0f
+
+__device__ __forceinline__ hpiece h_piece(float x) {   // f16(x), never subnormal
+    const hpiece h = (hpiece)x;
+    return __builtin_fabsf((float)h) < 0x1p-14f ? (hpiece)0.0f : h;
+}
+// z -> (a1, a2 2^6) and the represented value a1 + a2
+__device__ __forceinline__ double split2(double z, hpiece& hi, hpiece& lo, bool& clamped) {
+    clamped = !(__builtin_fabs(z) <= (double)PBN_H_MAX);
+    z = z > (double)PBN_H_MAX ? (double)PBN_H_MAX : (z < -(double)PBN_H_MAX ? -(double)PBN_H_MAX : z);
+    if (!(z == z)) z = 0.0;
+    hi = h_piece((float)z);
+    const double r = z - (double)(float)hi;
+    lo = h_piece((float)(r * (double)PBN_H_LO));
+    return (double)(float)hi + (double)(float)lo * (1.0 / (double)PBN_H_LO);
+}
+// x = 2^15 p1 + 2^5 p2 + 2^-6 p3 (|x| clamped to 65504 x 2^15 = 2.1e9: the padding norm -1e30 becomes that, far below every real exponent)
+__device__ __forceinline__ void split3s(float x, hpiece& p1, hpiece& p2, hpiece& p3) {
+    constexpr float XMAX = PBN_H_MAX * PBN_H_C1;
+    x = x > XMAX ? XMAX : (x < -XMAX ? -XMAX : x);
+    if (!(x == x)) x = -XMAX;
+    p1 = h_piece(x * (1.0f / PBN_H_C1));
+    float r = x - (float)p1 * PBN_H_C1;
+    p2 = h_piece(r * (1.0f / PBN_H_C2));
+    r -= (float)p2 * PBN_H_C2;
+    p3 = h_piece(r * (1.0f / PBN_H_C3));
+}
+
+// Slots per dimension: the fourth product a2 b2 rides along where the 32-slot blocks the three-product layout needs have room for it
+// (1...7, 10...15, 21...23 dimensions): then nothing is dropped and what is left is the input perturbation and the f32 accumulation,
+// 2^-24 |z|^2 on an exponent as for the f16x2 fragments of rounds 1-5; with three products (8, 9, 16...20, ... dimensions) <= 2^-22 |z|^2.
+__host__ __device__ inline int f16x2_blocks(int dm) { return (3 * dm + 3 + 31) / 32; }
+__host__ __device__ inline int f16x2_spd(int dm) { return 4 * dm + 3 <= 32 * f16x2_blocks(dm) ? 4 : 3; }
+// f16x2 fragments of one row: slot s = spd k + role for dimension k, then the three pieces of the training norm against the constants; the last
+// three slots of the contraction carry the constants on the training side when they are free (the W32 sweep's query offsets);
+// slot s lives in MFMA s / 32, lane group (s % 32) / 8, element s % 8.  Roles: training (a1, a1 2^-6, a2 2^6, a2), query (b1, b2 2^6, b1 2^-6, b2).
+__device__ __forceinline__ void f16x2_store_row(hf8* pack, int NB, int64_t tile, int idx, int dm, const hpiece* p1, const hpiece* p2, float nv, bool query) {
+    hpiece n1, n2, n3;
+    split3s(nv, n1, n2, n3);
+    const int spd = f16x2_spd(dm);
+    const hpiece zero = (hpiece)0.0f, c1 = (hpiece)PBN_H_C1, c2 = (hpiece)PBN_H_C2, c3 = (hpiece)PBN_H_C3;
+    auto konst = [&](int t) { return t == 0 ? c1 : (t == 1 ? c2 : c3); };
+    auto slot = [&](int s) -> hpiece {
+        if (s < spd * dm) {
+            const int k = s / spd, role = s % spd;
+            const hpiece hi_s = h_piece((float)p1[k] * (1.0f / PBN_H_LO)), lo_u = h_piece((float)p2[k] * (1.0f / PBN_H_LO));
+            if (role == 0) return p1[k];
+            if (role == 3) return lo_u;
+            if (!query) return role == 1 ? hi_s : p2[k];
+            return role == 1 ? p2[k] : hi_s;
+        }
+        const int t = s - spd * dm;
+        if (t < 3) return query ? konst(t) : (t == 0 ? n1 : (t == 1 ? n2 : n3));
+        if (!query && s >= 32 * NB - 3 && spd * dm + 6 <= 32 * NB) return konst(s - (32 * NB - 3));
+        return zero;
+    };
+    for (int mb = 0; mb < NB; ++mb)
+        for (int g = 0; g < 4; ++g) {
+            hf8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = slot(mb * 32 + g * 8 + j);
+            pack[(tile * NB + mb) * 64 + g * 16 + idx] = v;
+        }
+}
 
 struct SweepArgs {
     const void* Apack;
@@ -66,7 +140,7 @@ struct SweepArgs {
     const void* Bpack;
     const void* nypack;
     const void* Bxpack;
-    const void* Bxnorm;  // bf16x3 CKDE: f32 [nqtiles][16]
+    const void* Bxnorm;  // f16x2 CKDE: f32 [nqtiles][16]
     int64_t ntiles;
     int64_t nqtiles;
     int64_t tiles_per_split;
@@ -74,7 +148,7 @@ struct SweepArgs {
     int count_redo; // measurement aid (PBN_SWEEP_COUNT_REDO): count the units of the unchecked pass that redo their split
     int fast;      // fp64 plain sweeps whose result is a SUM over the test rows: 2^f on the fp32 transcendental unit (kde_kernels.hip: exp2_f64_fract<true>)
     int wmul;      // fp64 plain sweeps with d mod 4 == 0: training norms as weights 2^norm behind the norms (PackArgs::write_w)
-    int w32;       // fp32 plain unpruned sweeps of 5...9 whitened dimensions: the 32x32x16 bf16 form (kde_sweep_bf16_w32_kernel; bf16x3_w32)
+    int w32;       // fp32 plain unpruned sweeps whose contraction leaves three slots free: the 32x32x16 f16 form (kde_sweep_f16_w32_kernel; f16x2_w32)
     // Tile pruning (low-dimensional fp64 sweeps of the score engine): both sides are packed in Morton order of their
     // whitened coordinates, every 16-row training tile and every 16-row query tile has a bounding box over the first
     // `pdims` whitened dimensions, and qtile_thr holds, per query tile, a lower bound of its queries' largest exponents
@@ -174,8 +248,8 @@ struct SweepQG {
 #ifndef PBN_QG_PRUNE
 #define PBN_QG_PRUNE 2
 #endif
-#ifndef PBN_BF16_QG_PRUNE
-#define PBN_BF16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
+#ifndef PBN_F16_QG_PRUNE
+#define PBN_F16_QG_PRUNE 4   // query groups (tiles of 16 queries) per wave of the pruned fp32 sweeps
 #endif
 #ifndef PBN_QG_PRUNE_COND
 #define PBN_QG_PRUNE_COND 2
@@ -196,12 +270,12 @@ void launch_query_prepass(const double* zq_row, const int32_t* qperm, int64_t nq
                           const double* subpart = nullptr, int P = 2, int which = 0, double log2_nsub = 0.0, const double* tile_box = nullptr);
 void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                int bits, hipStream_t st);
-// 52 (fp64) / 40 (fp32 on the bf16 cores) at 10^6 training rows, + log2(n_train / 10^6): a constant bound (2.2e-10 / 9.1e-7 of a sum) on what
+// 52 (fp64) / 40 (fp32 on the f16 cores) at 10^6 training rows, + log2(n_train / 10^6): a constant bound (2.2e-10 / 9.1e-7 of a sum) on what
 // pruning drops; PBN_PRUNE_MARGIN / PBN_PRUNE_MARGIN_F32 override the base, PBN_PRUNE_MARGIN_ADAPT=0 the scaling
 double prune_margin(int dtype, int64_t n_train, bool sum_only = false);
-bool use_bf16x3(int dtype);   // fp32 tables: bf16x3 split on the bf16 matrix cores (default on)
-int bf16x3_mfmas(int dm);
-bool bf16x3_w32(int dm, int NB);   // the training fragments carry ones in the last three slots and kde_sweep_bf16_w32_kernel applies     // number of v_mfma_f32_16x16x32_bf16 per (tile, group) for dm whitened dimensions
+bool use_f16x2(int dtype);   // fp32 tables: f16x2 split on the 16-bit matrix cores (default on)
+int f16x2_mfmas(int dm);   // number of v_mfma_f32_16x16x32_f16 per (tile, group) for dm whitened dimensions
+bool f16x2_w32(int dm, int NB);   // the training fragments carry the constants in the last three slots and kde_sweep_f16_w32_kernel applies
 
 // ---- more than 32 whitened dimensions (the reference's kernels loop over any d: kde/KDE.hpp:592-640): a generic, runtime-sized form of
 // the pack and of the sweep.  fp64 fragments in the classic order (fp32 tables are packed into doubles), norms added per value, the
@@ -231,6 +305,10 @@ void launch_pack(const PackArgs& a, int dtype, hipStream_t st);
 // dev_out[0] = max over the rows described by `a` of |z|^2 (all a.d whitened coordinates, base-2 units), as the bits of a non-negative
 // double (atomic max: the caller zeroes it); src_dtype = element type of the table
 void launch_max_norm2(const PackArgs& a, int src_dtype, double* dev_out, hipStream_t st);
+// f16x2 fragments: the queries the pack flagged as beyond the f16 range (PackArgs::far_flag) are evaluated again in fp64 against the decoded
+// training fragments and their partials are overwritten before the finish (exact to fp64; a few ms per 1 000 such queries at 1e6 training rows)
+void launch_far_fix(const PackArgs& query_pack, const void* Apack, const void* Axpack, int NB, int64_t n_train, int64_t ntiles, double* part, int nsplit,
+                    int64_t nqtiles, bool cond, hipStream_t st);
 void launch_sweep(const SweepArgs& a, int dtype, int KS, bool cond, int nsplit, hipStream_t st);
 void launch_finish(const FinishArgs& a, bool cond, double* dev_sum_out, hipStream_t st, double* dev_sum_marg_out = nullptr);
 // out[i] = a[i] - b[i] (CKDE as joint - marginal when the two come from separate sweeps)

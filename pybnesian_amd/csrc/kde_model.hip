@@ -87,8 +87,8 @@ void bandwidth_full_block(int selector, const double* cov, int d, int rule_d, in
 KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n) {
     const size_t es = dtype_size(dtype);
     const int64_t ntiles = ceil_div(n, 16);
-    if (use_bf16x3(dtype))  // [ntiles][NB][64][8 bf16]; the training norm lives inside the fragments
-        return {(size_t)ntiles * bf16x3_mfmas(dm) * 64 * 16, 64, cond ? (size_t)ntiles * 64 * 16 : 0};
+    if (use_f16x2(dtype))  // [ntiles][NB][64][8 f16]; the training norm lives inside the fragments
+        return {(size_t)ntiles * f16x2_mfmas(dm) * 64 * 16, 64, cond ? (size_t)ntiles * 64 * 16 : 0};
     const int KS = (dm + 3) / 4;
     // norms [ntiles][16], then the weights 2^norm [ntiles][16] of the WMUL sweep
     return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es * 2, cond ? (size_t)ntiles * 64 * es : 0};
@@ -100,10 +100,10 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
     if (n <= 0) throw invalid_error("pbn_kde_fit: no training instances");
     if (cond && d < 2) cond = false;  // CKDE without evidence is a plain KDE (CKDE.hpp:232-241)
     const int dm = cond ? d - 1 : d;
-    // up to 32 main dimensions: fp64 KS <= 8 MFMAs per tile pair, fp32 (bf16x3 fragments, 6 slots per dimension + 3) <= 7; the
-    // classic fp32 fragments (PBN_F32_BF16X3=0, a measurement switch) stay at 16
-    const int max_dm = (dtype == PBN_F64 || use_bf16x3(dtype)) ? 32 : 16;
-    m.dtype = dtype; m.widen = false; m.d = d; m.dm = dm; m.KS = use_bf16x3(dtype) ? bf16x3_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
+    // up to 32 main dimensions: fp64 KS <= 8 MFMAs per tile pair, fp32 (f16x2 fragments, 6 slots per dimension + 3) <= 7; the
+    // classic fp32 fragments (PBN_F32_F16X2=0, a measurement switch) stay at 16
+    const int max_dm = (dtype == PBN_F64 || use_f16x2(dtype)) ? 32 : 16;
+    m.dtype = dtype; m.widen = false; m.d = d; m.dm = dm; m.KS = use_f16x2(dtype) ? f16x2_mfmas(dm) : (dm + 3) / 4; m.cond = cond;
     // beyond the templated shapes: the generic runtime-sized pack / sweep in fp64 fragments (kde_kernels.hpp "wide"); a conditional
     // model of that size has no fused sweep - its owner evaluates joint - marginal (capi.hip: split handles; the score engine's terms
     // are plain anyway) and kde_pack_train refuses it
@@ -183,9 +183,14 @@ double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const 
     return v;
 }
 
-bool kde_wants_widening(double max_norm2) {
-    const double at = knob_double("PBN_F32_WIDEN_AT", 5e-4);   // (read per call: tests move it inside one process; inf switches the widening off)
-    return !(max_norm2 * 5.9604644775390625e-08 <= at);   // 2^-24 |z|^2: the size of the fp32 Gram form's error on an exponent
+bool kde_wants_widening(double max_norm2, int dm) {
+    // (read per call: tests move it inside one process; inf switches the widening off)
+    // four-product fragments: the f32 accumulation of the Gram form, 2^-24 |z|^2 on an exponent, against 5e-4 (the reference tests' fp32 tolerance per
+    // logl); three-product fragments (8, 9, 16...20, ... dimensions): the dropped products a2 b2, <= 2^-22 |z|^2 in the worst alignment of the
+    // rounding residuals and a tenth of that typically, against twice that - both limits scale with PBN_F32_WIDEN_AT
+    const double at = knob_double("PBN_F32_WIDEN_AT", 5e-4);
+    if (f16x2_spd(dm) == 4) return !(max_norm2 * 5.9604644775390625e-08 <= at);
+    return !(max_norm2 * 2.384185791015625e-07 <= 2.0 * at);
 }
 
 void kde_widen(KdeModel& m) {
@@ -225,7 +230,7 @@ static PruneSide prune_sort_side(pbn_ctx* ctx, dev_buf<char>& arena, const PackA
 // d = 7 is even at best (heavy-tailed: +3...5 %), d = 8 loses 10 %.
 bool kde_prune_applies(int dtype, int dm, int64_t n) {
     const int max_dims = PBN_TUNE(PRUNE_MAX_DIMS, 6);
-    return knob_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_bf16x3(dtype)) && dm <= max_dims && n >= knob_int("PBN_PRUNE_MIN_ROWS", 32768);
+    return knob_int("PBN_SWEEP_PRUNE", 1) && (dtype == PBN_F64 || use_f16x2(dtype)) && dm <= max_dims && n >= knob_int("PBN_PRUNE_MIN_ROWS", 32768);
 }
 
 // bytes of the subsample packs (kde_pack_bytes of nsub rows, each part 256-aligned)
@@ -306,7 +311,7 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
         }
     }
     pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
-    pa.write_w = !use_bf16x3(m.fdtype());
+    pa.write_w = !use_f16x2(m.fdtype());
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
     launch_pack(pa, m.fdtype(), ctx->stream);
@@ -391,12 +396,13 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     const size_t es = dtype_size(fdt);
     const int64_t nqtiles = ceil_div(n, 16);
     // query fragments in scratch: Bpack | nypack | Bxpack
-    const bool b3 = use_bf16x3(fdt);
+    const bool b3 = use_f16x2(fdt);
     const size_t bpack_b = b3 ? (size_t)nqtiles * m.KS * 64 * 16 : (size_t)nqtiles * m.KS * 64 * es,
                  ny_b = (size_t)nqtiles * 16 * es,
                  bx_b = m.cond ? (b3 ? (size_t)nqtiles * 64 * 16 : (size_t)nqtiles * 64 * es) : 0,
-                 xn_b = (m.cond && b3) ? (size_t)nqtiles * 16 * 4 : 0;
-    ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + xn_b + 256);
+                 xn_b = (m.cond && b3) ? (size_t)nqtiles * 16 * 4 : 0,
+                 ff_b = b3 ? ((size_t)nqtiles * 16 + 255) / 256 * 256 : 0;   // f16x2 fragments: one flag per query row (beyond the f16 range)
+    ctx->scratch_q.reserve(bpack_b + ny_b + bx_b + xn_b + ff_b + 512);
     char* q = ctx->scratch_q.p;
     PackArgs pa{};
     fill_pack_common(ctx, pa, test, cols, m);
@@ -423,6 +429,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     }
     pa.pack = q; pa.npack = q + bpack_b; pa.xpack = m.cond ? q + bpack_b + ny_b : nullptr;
     pa.xnorm = xn_b ? q + bpack_b + ny_b + bx_b : nullptr;
+    pa.far_flag = ff_b ? (unsigned char*)(q + ((bpack_b + ny_b + bx_b + xn_b + 255) / 256) * 256) : nullptr;
     { KernelTimer kt(ctx, PBN_K_PACK); launch_pack(pa, fdt, ctx->stream); }
     const int P = m.cond ? 4 : 2;
     const bool wmul = !fold && sweep_weights_norm(fdt, m.cond, m.KS, m.dm);
@@ -476,7 +483,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
     sa.wmul = wmul ? 1 : 0;
-    sa.w32 = (b3 && !m.cond && !m.prune && bf16x3_w32(m.dm, m.KS)) ? 1 : 0;
+    sa.w32 = (b3 && !m.cond && !m.prune && f16x2_w32(m.dm, m.KS)) ? 1 : 0;
     sa.far_span = (sum_only && m.prune) ? (double)knob_int("PBN_FAR_SPAN", 17) : 0.0;   // sum-only pruned sweeps: fp32 tail for tiles 26+ bits below the sum bound
     sa.fast = sum_only ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
@@ -491,6 +498,8 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     static const bool log_sweeps = PBN_TUNE(SWEEP_LOG, 0) != 0;   // one line per sweep on stderr (tools/c5_sweeps.py)
     if (log_sweeps) std::fprintf(stderr, "pbn-sweep N=%lld n=%lld d=%d cond=%d prune=%d nsub=%lld nsplit=%lld\n", (long long)m.N, (long long)n, m.d, (int)m.cond, (int)m.prune, (long long)(m.prune ? m.nsub : 0), (long long)nsplit);
     { KernelTimer kt(ctx, PBN_K_SWEEP); launch_sweep(sa, fdt, m.KS, m.cond, (int)nsplit, ctx->stream); }
+    // f16x2 fragments: queries beyond the f16 range were clamped by the pack - their partials are recomputed in fp64 (a flag test otherwise)
+    if (b3) launch_far_fix(pa, m.Apack, m.Axpack, m.KS, m.N, m.ntiles, sa.part, (int)nsplit, nqtiles, m.cond, ctx->stream);
 
     const int64_t nblocks = ceil_div(n, 256);
     ctx->scratch_misc.reserve((size_t)nblocks * 2 * sizeof(double));

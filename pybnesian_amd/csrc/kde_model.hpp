@@ -62,7 +62,7 @@ void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int
 // own fp32 tolerance per logl; PBN_F32_WIDEN=0 switches the test off).
 double kde_max_norm2(pbn_ctx* ctx, const KdeModel& m, const pbn_table* t, const int* cols, int64_t row0, int64_t n0, int64_t row1,
                      const int32_t* dev_rows = nullptr);
-bool kde_wants_widening(double max_norm2);
+bool kde_wants_widening(double max_norm2, int dm);
 void kde_widen(KdeModel& m);
 
 // Wide packs (kde_kernels.hpp: WidePackArgs) for the consumers that keep their own fragments (CKDE::cdf / sample, UCV) when they hold more

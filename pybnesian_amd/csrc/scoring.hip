@@ -1176,7 +1176,11 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 std::vector<const Work*> redo;
                 for (const Work& w : work) {
                     const int slot = w.mode == 2 ? w.slot_m : w.slot_j;
-                    if (kde_wants_widening(hs[nslots + (size_t)slot])) redo.push_back(&w);
+                    // the criterion follows the fragments' layout, i.e. the number of variables of the term: p + 1 for a joint term, p or (a
+                    // marginal TERM of pbn_score_terms) p + 1 for a marginal one - the stricter of the two there
+                    const int pw = par_off[w.cand + 1] - par_off[w.cand];
+                    const double far2 = hs[nslots + (size_t)slot];
+                    if (kde_wants_widening(far2, pw + 1) || (w.mode == 2 && kde_wants_widening(far2, pw))) redo.push_back(&w);
                 }
                 if (!redo.empty()) {
                     for (const Work* w : redo) {

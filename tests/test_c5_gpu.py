@@ -1,7 +1,7 @@
 """GPU tier: BASELINE config 5 in miniature - hybrid table in **fp32**, ValidatedLikelihood local scores of HCKDE and
 CLinearGaussianCPD candidates (DiscreteAdaptator slices, a8 of SURVEY.md §8a) against the oracle's per-slice restatement at
 the north star's fp32 tolerance (1e-3 relative), including slices large enough (>= 32 768 training rows) for the pruned
-bf16x3 sweeps, and MMHC end to end (hybrid MutualInformation -> CPCs -> restricted hill-climb) against
+f16x2 sweeps, and MMHC end to end (hybrid MutualInformation -> CPCs -> restricted hill-climb) against
 `mmpc_oracle` + `hc_oracle` driven by oracle scores.
 
 Reference: factors/discrete/DiscreteAdaptator.hpp:201-348, learning/scores/validated_likelihood.hpp:12-75,
@@ -70,7 +70,7 @@ CASES = [("x", ["A"], []), ("y", ["B"], ["x"]), ("z", ["B", "A"], ["x", "y"]), (
 @pytest.mark.parametrize("prune_rows", [None, 1024])
 def test_fp32_hybrid_validated_scores(pbn, oracle, node_type, prune_rows, monkeypatch):
     """HCKDE / CLG slices in fp32 through ValidatedLikelihood.  prune_rows = 1024 lowers the pruning threshold so that the
-    Morton-ordered, tile-pruned bf16x3 sweeps run on every slice of this small table (default: 32 768 rows)."""
+    Morton-ordered, tile-pruned f16x2 sweeps run on every slice of this small table (default: 32 768 rows)."""
     if prune_rows is not None:
         monkeypatch.setenv("PBN_PRUNE_MIN_ROWS", str(prune_rows))
     n = 6000
@@ -122,7 +122,7 @@ def test_fp32_hybrid_scores_vs_the_float_arithmetic_of_the_reference(pbn, oracle
 
 
 def test_fp32_hybrid_large_slices_pruned(pbn, oracle):
-    """Slices of >= 32 768 training rows: the default pruned bf16x3 path of C5's per-configuration sweeps (hold-out
+    """Slices of >= 32 768 training rows: the default pruned f16x2 path of C5's per-configuration sweeps (hold-out
     likelihood: 96 000 training rows over 2 configurations, 24 000 test rows), and a no-discrete-parent CKDE whose 2-fold CV
     trains on 48 000 rows."""
     n = 120_000
@@ -219,7 +219,7 @@ def test_mmhc_hybrid_end_to_end_vs_oracles(pbn, oracle):
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-5)])
 def test_grouped_hybrid_slices_match_per_slice_chains(pbn, monkeypatch, dtype, tol):
     """Hybrid CKDE candidates through the grouped evaluation (kde_group.hip: one pool per configuration and term, all folds of all
-    configurations in one launch chain; fp32: bf16x3 fragments, two plain terms) against the per-(fold, configuration) chains of
+    configurations in one launch chain; fp32: f16x2 fragments, two plain terms) against the per-(fold, configuration) chains of
     round 2 (fp32: the fused joint + marginal sweep): CV and validation scores of five candidates with one and two discrete parents.
     fp64: the same pairs in another order, equal to rounding; fp32: also another split of the terms."""
     rng = np.random.default_rng(9)

@@ -99,7 +99,7 @@ def test_ckde_oracle_parity_random(pbn, oracle, p):
 
 @pytest.mark.parametrize("p", [2, 6, 11])
 def test_ckde_oracle_parity_random_f32(pbn, oracle, p):
-    """fp32 CKDE on the bf16 matrix cores (bf16x3 split), incl. NB = 1..3 MFMAs per tile: reference tolerances for
+    """fp32 CKDE on the bf16 matrix cores (f16x2 split), incl. NB = 1..3 MFMAs per tile: reference tolerances for
     float data (atol 5e-4 per value, CKDE_test.py:231-232) against the fp64 oracle on the same rounded data."""
     rng = np.random.default_rng(70 + p)
     n, m = 3001, 203

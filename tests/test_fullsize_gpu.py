@@ -307,7 +307,7 @@ def test_c5_fullsize_properties(env, monkeypatch):
     _, hc2, res2 = run()
     assert _trace(pbn, hc2) == trace and sorted(res2.arcs()) == sorted(res.arcs())
     # ORACLE values for fp32 hybrid slices at full slice size: a hold-out score with 1 000 test rows (999 000 training rows, cut by the
-    # discrete parents into slices of 250-500 k rows: the grouped, pruned bf16x3 sweeps) against the per-slice restatement
+    # discrete parents into slices of 250-500 k rows: the grouped, pruned f16x2 sweeps) against the per-slice restatement
     # (DiscreteAdaptator.hpp:201-348) in fp64 arithmetic on the same float data, at the north star's fp32 bar
     from oracle import oracle
 

@@ -90,5 +90,31 @@ def test_grouped_kernels_keep_their_register_budgets(kde_asm):
     for n, (scratch, vgpr) in sweeps.items():
         assert vgpr <= 128, (n, vgpr)                     # four waves per SIMD
         assert scratch <= 160, (n, scratch)               # (0-92 bytes today: the unit's argument block, no loop-carried spill)
-    c5 = found["_ZN3pbn27kde_sweep_bf16_group_kernelILi1EEEvNS_10GSweepArgsE"]
+    c5 = found["_ZN3pbn26kde_sweep_f16_group_kernelILi1EEEvNS_10GSweepArgsE"]
     assert c5[0] == 0 and c5[1] <= 128, c5                # C5's kernel: four waves per SIMD, nothing in scratch
+
+
+def test_w32_sweep_stream_is_placed(kde_asm):
+    """kde_sweep_f16_w32_kernel (the plain unpruned fp32 sweep): the steady loop is ONE basic block of four phases, and in every phase each
+    v_mfma_f32_32x32x16_f16 is followed by its share of the previous accumulator's work - 16 / NJ v_exp_f32 and as many v_add_f32 - before the
+    next MFMA issues (__builtin_amdgcn_sched_group_barrier in the source): no two MFMAs back to back, no exponential reading an accumulator
+    younger than one phase (so no s_nop beyond the one slot the hazard recogniser wants at a phase boundary), nothing in scratch, and the
+    register budgets of four (one 32-slot block) / three (two blocks) waves per SIMD."""
+    seen = 0
+    for nb, nj, vgpr_cap in ((1, 2, 128), (2, 4, 168)):
+        m = re.search(r"\.amdhsa_kernel (_ZN3pbn24kde_sweep_f16_w32_kernelILi%dEEEvNS_9SweepArgsE)\n(.*?)\.end_amdhsa_kernel" % nb, kde_asm, flags=re.S)
+        assert m, nb
+        assert int(re.search(r"private_segment_fixed_size (\d+)", m.group(2)).group(1)) == 0
+        assert int(re.search(r"next_free_vgpr (\d+)", m.group(2)).group(1)) <= vgpr_cap
+        (name, body), = kernels(kde_asm, r"kde_sweep_f16_w32_kernelILi%dE" % nb)
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        steady = [b for b in blocks if len(re.findall(r"v_mfma_f32_32x32x16_f16", b)) == 4 * nj and "Loop" in "\n".join(b.split("\n")[:3])]
+        assert len(steady) == 1, (nb, len(steady))
+        gaps = re.split(r"v_mfma_f32_32x32x16_f16[^\n]*\n", steady[0])[1:]
+        for g in gaps:
+            assert len(re.findall(r"\bv_exp_f32", g)) == 16 // nj, (nb, g)
+            assert 16 // nj - 1 <= len(re.findall(r"\bv_add_f32", g)) <= 16 // nj + 2, (nb, g)
+            assert all(int(x) <= 2 for x in re.findall(r"s_nop (\d+)", g)), (nb, g)
+        assert "scratch_" not in steady[0]
+        seen += 1
+    assert seen == 2

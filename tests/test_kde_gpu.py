@@ -534,7 +534,7 @@ def test_more_than_16_dimensions(pbn, oracle, d):
     assert rel_err(cpd.logl(test), want) < RTOL_F64
     if d - 1 > 16:   # the cdf beyond 16 evidence variables: runtime-sized fp64 kernels (round 4)
         assert np.allclose(cpd.cdf(test), oracle.ckde_cdf(train.to_numpy(), cpd.bandwidth, test.to_numpy()), rtol=1e-8, atol=1e-13)
-    # float32 tables: the bf16x3 sweep with 4-7 MFMAs per tile pair; the f64 oracle on the f32-rounded data is the truth
+    # float32 tables: the f16x2 sweep with 4-7 MFMAs per tile pair; the f64 oracle on the f32-rounded data is the truth
     tr32, te32 = train.astype("float32"), test.astype("float32")
     k32 = pbn.KDE(names)
     k32.fit(tr32)

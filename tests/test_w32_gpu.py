@@ -1,5 +1,5 @@
-"""GPU tier: the W32 form of the plain unpruned fp32 sweep (kde_sweep_bf16_w32_kernel: v_mfma_f32_32x32x16_bf16 on the bf16x3 fragments, the
-stream placed by hand) against the f64 oracle on the f32-rounded data and against the 16x16 form it replaces (PBN_BF16_W32=0, read per call).
+"""GPU tier: the W32 form of the plain unpruned fp32 sweep (kde_sweep_f16_w32_kernel: v_mfma_f32_32x32x16_bf16 on the f16x2 fragments, the
+stream placed by hand) against the f64 oracle on the f32-rounded data and against the 16x16 form it replaces (PBN_F32_W32=0, read per call).
 Covers: every dimension the form applies to (5...9), full and diagonal bandwidths, training sizes with an odd number of 16-row tiles, fewer
 tiles than one blind run, splits that end inside a chunk, and a table whose probe tiles all lie far from the queries (the blind chunks overflow
 and are redone checked: the offset-raise path).  Replaces kde/opencl_kernels/KDE.cl.src:115-121,143-170 for float tables."""
@@ -31,11 +31,11 @@ def _both(fn):
     """fn() under the W32 form and under the 16x16 form."""
     out = []
     for v in ("1", "0"):
-        os.environ["PBN_BF16_W32"] = v
+        os.environ["PBN_F32_W32"] = v
         try:
             out.append(fn())
         finally:
-            os.environ.pop("PBN_BF16_W32", None)
+            os.environ.pop("PBN_F32_W32", None)
     return out
 
 
@@ -59,16 +59,15 @@ def test_w32_matches_the_oracle_and_the_16x16_form(pbn, oracle, d, n, m):
 
 
 def test_w32_counts_the_sweeps_it_takes(pbn):
-    """The W32 kernel is the one that runs for d = 8 float tables (and is not for d = 4 / d = 10): the library's launch log says which."""
+    """The W32 kernel is the one that runs for unpruned float tables whose contraction leaves its last three slots free (3 d + 6 <= 32 blocks,
+    one or two blocks: d <= 8 and 10 ... 19) and is not for d = 9, 20, 24: the library's launch counter says which."""
     import ctypes as C
 
     from pybnesian_amd import _lib
 
     lib = _lib.load()
-    if not hasattr(lib, "pbn_debug_w32_launches"):
-        pytest.skip("no launch counter in this build")
     rng = np.random.default_rng(5)
-    for d, expect in ((4, 0), (8, 1), (10, 0)):
+    for d, expect in ((4, 1), (8, 1), (9, 0), (10, 1), (19, 1), (20, 0), (24, 0)):
         names = [f"v{i}" for i in range(d)]
         train = pd.DataFrame(rng.normal(size=(5000, d)), columns=names).astype("float32")
         k = pbn.ProductKDE(names)
@@ -81,26 +80,58 @@ def test_w32_counts_the_sweeps_it_takes(pbn):
 
 
 def test_w32_offsets_are_raised_when_every_probe_is_far(pbn, oracle):
-    """4 000 training rows 30 bandwidth units away from the queries and 24 rows among them (between two probe tiles) right beside the queries:
-    the probes see only far rows, the near rows' exponents overflow against those offsets, the chunk is redone checked and the offsets rise."""
+    """4 000 training rows 15 bandwidths away from the queries and 24 rows among them (between two probe tiles) right beside the queries:
+    the probes see only far rows, the near rows' exponents (~ +1 300) overflow against those offsets, the chunk is redone checked and the offsets
+    rise.  (Inside the fp32-fragment criterion: |z|^2 ~ 2 600 < 4 194, PBN_F32_WIDEN_AT.)"""
     rng = np.random.default_rng(12)
     d = 8
     names = [f"v{i}" for i in range(d)]
-    far = rng.normal(loc=30.0, scale=0.5, size=(4000, d))
-    near = rng.normal(loc=0.0, scale=0.5, size=(24, d))
+    far = rng.normal(loc=3.0, scale=0.05, size=(4000, d))
+    near = rng.normal(loc=0.0, scale=0.05, size=(24, d))
     rows = np.vstack([far[:1100], near, far[1100:]])
     train = pd.DataFrame(rows, columns=names).astype("float32")
-    test = pd.DataFrame(rng.normal(loc=0.0, scale=0.5, size=(300, d)), columns=names).astype("float32")
+    test = pd.DataFrame(rng.normal(loc=0.0, scale=0.05, size=(300, d)), columns=names).astype("float32")
     k = pbn.ProductKDE(names)
     k.fit(train)
     k.bandwidth = np.full(d, 0.04)
+    import ctypes as C
+
+    from pybnesian_amd import _lib
+
+    c = C.c_ulonglong(0)
+    _lib.load().pbn_debug_w32_launches(C.byref(c), 1)
     want = oracle.product_kde_logl(train.to_numpy().astype(np.float64), k.bandwidth, test.to_numpy().astype(np.float64))
     w32, w16 = _both(lambda: k.logl(test))
+    _lib.load().pbn_debug_w32_launches(C.byref(c), 0)
+    assert c.value == 1, "the model was not widened to fp64 fragments: the W32 form ran once"
     assert np.all(np.isfinite(w32))
     assert np.allclose(w32, want, atol=5e-4, rtol=1e-4)
     assert np.allclose(w32, w16, atol=2e-4, rtol=2e-5)
-    # queries far from everything: every term underflows against nothing - the sums stay finite and equal to the oracle's
-    lost = pd.DataFrame(rng.normal(loc=-40.0, scale=0.5, size=(40, d)), columns=names).astype("float32")
+    # queries far from everything: the sums stay finite and equal to the oracle's
+    lost = pd.DataFrame(rng.normal(loc=-3.0, scale=0.05, size=(40, d)), columns=names).astype("float32")
     want = oracle.product_kde_logl(train.to_numpy().astype(np.float64), k.bandwidth, lost.to_numpy().astype(np.float64))
     got = _both(lambda: k.logl(lost))[0]
     assert np.all(np.isfinite(got)) and np.allclose(got, want, rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("cls", ["KDE", "ProductKDE", "CKDE"])
+def test_queries_beyond_the_f16_range_are_evaluated_in_fp64(pbn, cls):
+    """The f16x2 fragments clamp a whitened query coordinate beyond +-65504 (tens of thousands of bandwidths out); the pack flags such rows and
+    kde_far_fix_kernel evaluates them in fp64 against the decoded training fragments: the result is the fp64 model's, to 1e-6 relative."""
+    rng = np.random.default_rng(3)
+    names = ["a", "b", "c"]
+    train = pd.DataFrame(rng.normal(size=(5000, 3)), columns=names)
+    q = rng.normal(size=(100, 3))
+    q[7] = [9e4, 0.0, 0.0]; q[31] = [-2e5, 3e5, 1.0]; q[99] = [0.0, 0.0, -7e4]; q[50] = [40.0, -40.0, 40.0]
+    test = pd.DataFrame(q, columns=names)
+    def make():
+        return pbn.CKDE("a", ["b", "c"]) if cls == "CKDE" else getattr(pbn, cls)(names)
+    k32, k64 = make(), make()
+    k32.fit(train.astype("float32"))
+    k64.fit(train.astype("float32").astype("float64"))
+    got, want = k32.logl(test.astype("float32")), k64.logl(test.astype("float32").astype("float64"))
+    assert np.all(np.isfinite(got))
+    far = [7, 31, 99]
+    assert np.allclose(got[far], want[far], rtol=1e-6 if cls != "CKDE" else 1e-5)
+    rest = [i for i in range(100) if i not in far]
+    assert np.allclose(got[rest], want[rest], rtol=1e-4, atol=5e-4)

@@ -1,5 +1,5 @@
-# fp32 sweeps with / without the fp32 accumulation inside blind batches (PBN_BF16_FSUM), and the cost of the engine's check-after (PBN_F32_WIDEN_AT=inf)
-#   bash tools/fsum_probe.sh   (build/variants/libpbn_nofsum.so = the library built with -DPBN_BF16_FSUM=0)
+# fp32 sweeps with / without the fp32 accumulation inside blind batches (PBN_F16_FSUM), and the cost of the engine's check-after (PBN_F32_WIDEN_AT=inf)
+#   bash tools/fsum_probe.sh   (build/variants/libpbn_nofsum.so = the library built with -DPBN_F16_FSUM=0)
 cd $GRAFT_REPO_ROOT
 cp pybnesian_amd/libpbn_hip.so /tmp/libpbn_base.so
 f32() { python3 bench.py --dtype f32 --hc none --no-e2e --no-cpu-baseline --no-c3 --no-extra-legs --steps 10 --warmup 3 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('fp32 headline ms/step %.3f  frac %.4f slogl %.10g' % (d['ms_per_step'], d['roofline']['frac'], d['config']['slogl_step0_rank_sum']))"; }

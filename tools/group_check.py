@@ -53,7 +53,7 @@ for n, min_rows in ((3000, 64), (60000, None), (300000, None)):
             worst = max(worst, relo)
 assert worst < 3e-7, worst   # two pruned forms: each may drop up to 1.1e-7 (+ 8e-8) of a sum; measured 1.2e-9
 
-# hybrid candidates (discrete parents: one pool per configuration and term), fp64 and fp32 (bf16x3 fragments), CV and validation scores
+# hybrid candidates (discrete parents: one pool per configuration and term), fp64 and fp32 (f16x2 fragments), CV and validation scores
 def hybrid(n, dtype, seed=9):
     rng = np.random.default_rng(seed)
     A = rng.integers(0, 3, size=n)

@@ -14,7 +14,7 @@ for grp in ("sq", "sq2"):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(f"{out}/{grp}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "kde_sweep_bf16_kernel" in row["Kernel_Name"]:
+            if "kde_sweep_f16_kernel" in row["Kernel_Name"]:
                 a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
     for k, (v, n) in sorted(acc.items()):
         vals[k] = v / max(n, 1)

@@ -1,4 +1,4 @@
-# round 5: the pruned fp32 sweeps compiled for 5 instead of 4 waves per SIMD (-DPBN_BF16_PRUNE_WAVES=5), C5's hill-climb   bash tools/r5_probe_r.sh
+# round 5: the pruned fp32 sweeps compiled for 5 instead of 4 waves per SIMD (-DPBN_F16_PRUNE_WAVES=5), C5's hill-climb   bash tools/r5_probe_r.sh
 cd $GRAFT_REPO_ROOT
 hc() { python3 bench.py --no-c3 --no-e2e --no-cpu-baseline --no-extra-legs --hc $1 --hc-max-iters $2 --steps 1 --warmup 1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read())['secondary']; print('$1 %.3f s  cells %d iterations %d arcs %d' % (d['estimate_s'], d['cells_scored'], d['iterations'], d['arcs_found']))"; }
 hc cv64 1 > /dev/null
