@@ -446,10 +446,15 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
     log = EvalLog(score) if (want_cpu and cpu_cfg is not None) else None
     sctx = getattr(score, "_ctx", ctx)   # the context the score's launches go to (a score built from a host frame takes the default one)
     sctx.set_profiling(2)   # HIP events around the library's sweep / Gram launches, nothing else changes (pbn_ctx_set_profiling: 2 = timing only)
+    import ctypes as C
+    lib = _lib.load()
+    lib.pbn_debug_moment_totals(None, None, 1)   # (tile, group) pairs the tile-moment pass takes: one atomic per wave, always on
     t0 = time.perf_counter()
     res = hc.estimate(ops, score, start, **kw)
     dt = time.perf_counter() - t0
-    kt = {name: sctx.kernel_time(cls) for name, cls in (("sweep", _lib.PBN_K_SWEEP), ("gram", _lib.PBN_K_GRAM))}
+    kt = {name: sctx.kernel_time(cls) for name, cls in (("sweep", _lib.PBN_K_SWEEP), ("gram", _lib.PBN_K_GRAM), ("moment", _lib.PBN_K_MOMENT))}
+    mp1, mp2 = C.c_ulonglong(0), C.c_ulonglong(0)
+    lib.pbn_debug_moment_totals(C.byref(mp1), C.byref(mp2), 0)
     sctx.set_profiling(False)
     more = dict(extra) if which == "c5mmhc" else {}
     if which != "c4":
@@ -462,6 +467,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         more["roofline"] = {"kernel": kname, "kernel_short": kshort, "bound": "valu-issue (v_exp + add per pair value inside the pruning radius; DESIGN.md 3.1)",
                             "device_s": kt["sweep"][0] * 1e-3, "launches": kt["sweep"][1], "share_of_estimate_s": kt["sweep"][0] * 1e-3 / dt,
                             "gram_s": kt["gram"][0] * 1e-3, "gram_launches": kt["gram"][1],
+                            **moment_roofline(kt["moment"][0] * 1e-3, kt["moment"][1], mp1.value, mp2.value),
                             "note": "HIP events on the launching stream around the sweep and Gram launches only (issue lanes overlap: device "
                                     "seconds may add up to more than the wall time)"}
     if log is not None:
@@ -544,6 +550,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
     return {
         **more,
         "metric": "hill-climb candidate-arcs scored/s",
+        "which": {"c5mmhc": "c5"}.get(which, which),
         "value": hc.last.cells_scored / dt,
         "unit": "arcs/s",
         "config": label + (f", max_iters={max_iters}" if max_iters else ""),
@@ -555,6 +562,20 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         "score_ctor_s": t_ctor,
         "value_with_ctor": hc.last.cells_scored / (dt + t_ctor),
     }
+
+
+def moment_roofline(moment_s, launches, pairs_d1, pairs_d2):
+    """The tile-moment pass (kde_moment_group_kernel<1 | 2>) against the FP64 vector peak: a (tile, group) pair is 16 queries x
+    the Horner scheme of the order-8 polynomial - 8 FMAs in one dimension, 44 in two - so its algorithmic flops are pairs x 16 x FMAs x 2; the
+    device seconds are the library's own HIP events around the pass (they lie INSIDE the sweep class's bracket: `device_s` includes them)."""
+    if not launches or moment_s <= 0:
+        return {}
+    flops = (pairs_d1 * 8.0 + pairs_d2 * 44.0) * 16.0 * 2.0
+    return {"moment_s": moment_s, "moment_launches": launches, "moment_pairs": pairs_d1 + pairs_d2, "moment_pairs_d2": pairs_d2,
+            "moment_frac": flops / moment_s / (FP64_PEAK_TFLOPS * 1e12),
+            "moment_cycles_per_pair": moment_s * 2.4e9 * 1024.0 / max(pairs_d1 + pairs_d2, 1),
+            "moment_note": "FMAs of the Horner schemes alone against the FP64 vector peak (the kernel issues ~65 instructions per 44 FMAs at two "
+                           "dimensions: its own instruction-count bound is 0.68 of this peak); cycles per (tile, group) pair at 2.4 GHz on 1 024 SIMDs"}
 
 
 def git_blob_sha1(path):
@@ -832,7 +853,8 @@ def compact_line(out, full_name):
         return o
 
     legs = {}
-    for name, key in (("c4" if "C4" in str((out.get("secondary") or {}).get("config", "")) else "cv64", "secondary"), ("c1", "secondary_c1"),
+    sec = out.get("secondary") or {}
+    for name, key in ((sec.get("which") or ("c4" if "C4" in str(sec.get("config", "")) else "cv64"), "secondary"), ("c1", "secondary_c1"),
                       ("c3", "secondary_c3"), ("c5", "secondary_c5"), ("cv_weak", "secondary_cv_weak")):
         if isinstance(out.get(key), dict):
             legs[name] = search_leg(out[key])

@@ -63,7 +63,7 @@ void* pbn_ctx_stream(pbn_ctx* ctx); /* hipStream_t the kernels are launched on (
  * on = 2: events around the sweep and Gram classes only, nothing else changes (launches on the engine's issue lanes are timed on their
  * lane - the classes' totals are device time and may overlap); 0: off.  Switching resets the totals. */
 #define PBN_NUM_KERNEL_CLASSES 8
-typedef enum { PBN_K_PACK = 0, PBN_K_SWEEP = 1, PBN_K_FINISH = 2, PBN_K_GRAM = 3 } pbn_kernel_class;
+typedef enum { PBN_K_PACK = 0, PBN_K_SWEEP = 1, PBN_K_FINISH = 2, PBN_K_GRAM = 3, PBN_K_MOMENT = 4 } pbn_kernel_class;   /* MOMENT: the tile-moment pass beside the grouped fp64 sweeps */
 int pbn_ctx_set_profiling(pbn_ctx* ctx, int on);
 int pbn_ctx_kernel_time(pbn_ctx* ctx, int kernel_class, double* total_ms, int64_t* launches);
 

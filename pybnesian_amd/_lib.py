@@ -15,7 +15,7 @@ PBN_OK, PBN_ERR_INVALID, PBN_ERR_SINGULAR, PBN_ERR_DEVICE = 0, 1, 2, 3
 PBN_F64, PBN_F32 = 0, 1
 PBN_BW_FULL, PBN_BW_DIAG = 0, 1
 PBN_SEL_NORMAL_REFERENCE, PBN_SEL_SCOTT = 0, 1
-PBN_K_PACK, PBN_K_SWEEP, PBN_K_FINISH, PBN_K_GRAM = 0, 1, 2, 3
+PBN_K_PACK, PBN_K_SWEEP, PBN_K_FINISH, PBN_K_GRAM, PBN_K_MOMENT = 0, 1, 2, 3, 4
 PBN_SPLIT_NONE, PBN_SPLIT_CV, PBN_SPLIT_HOLDOUT, PBN_SPLIT_VALIDATED = 0, 1, 2, 3
 PBN_SCORE_BIC, PBN_SCORE_BGE, PBN_SCORE_CVLIK, PBN_SCORE_HOLDOUT = 0, 1, 2, 3
 PBN_NODE_LG, PBN_NODE_CKDE, PBN_NODE_DISCRETE = 0, 1, 2

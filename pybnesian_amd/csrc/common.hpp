@@ -292,7 +292,7 @@ struct KernelTimer {
     KernelTimer(pbn_ctx* c, int w) : ctx(c), which(w) {
         // timing-only mode brackets the dominant classes only (sweeps, Gram passes: long kernels) - events around the short pack / finish
         // launches of a chain cost more than they measure (cv64's weak leg 0.61 -> 0.91 s with every launch bracketed)
-        if (ctx->profiling || (ctx->timing && (w == PBN_K_SWEEP || w == PBN_K_GRAM))) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
+        if (ctx->profiling || (ctx->timing && (w == PBN_K_SWEEP || w == PBN_K_GRAM || w == PBN_K_MOMENT))) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventRecord(e0, ctx->stream)); }
     }
     ~KernelTimer() {
         if (e0) {

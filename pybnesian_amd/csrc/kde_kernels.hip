@@ -217,7 +217,8 @@ struct Tr<float> {
 // measurement aid, not part of the C ABI header: (wave, split) units of the fp64 sweep that had to redo their split checked
 __device__ unsigned long long g_sweep_redo = 0, g_sweep_units = 0;
 __device__ unsigned long long g_sweep_visit = 0, g_sweep_tiles = 0;
-__device__ unsigned long long g_mom_pairs = 0, g_mom_batches = 0, g_mom_visits = 0, g_mom_left = 0;   // moment pass (PBN_SWEEP_COUNT_REDO): pairs taken / (batch, group) passes made
+__device__ unsigned long long g_mom_pairs = 0, g_mom_batches = 0, g_mom_visits = 0, g_mom_left = 0;
+__device__ unsigned long long g_mom_taken[2] = {0, 0};   // always on: (tile, group) pairs the moment pass took, by dimension - one atomic per wave (pbn_debug_moment_totals)   // moment pass (PBN_SWEEP_COUNT_REDO): pairs taken / (batch, group) passes made
 // (pruned sweeps: tiles visited / tiles offered, per wave)
 // waves per SIMD the pruned fp64 sweeps are compiled for: 3 (<= 168 VGPRs) - the blind-batch shapes fit anyway, the checked
 // d = 4 / 5 and norm-multiplying shapes (183-207 unconstrained) gain 3-9 % on the 1e6 x 1e5 handles; 4 (128, spills) loses on C3
@@ -1265,8 +1266,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {   // lane l's 
 #endif
 template <int D>
 __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_group_kernel(GSweepArgs g) {
-    // per (query, lane) running sums: in LDS - 16 x 64 doubles per wave; as registers they push the 45 coefficients of D = 2 into scratch
-    __shared__ double accs[16][64];
+    // per (group, query, lane) running sums: in LDS - QG x 16 x 64 doubles per wave (as registers they cost the D = 2 kernel 4 %: 256 VGPRs and
+    // scratch, profiles/r6/moment_probes.txt)
+    __shared__ double accs[PBN_QG_PRUNE * 16][64];
     const int u = g.wg_unit[blockIdx.x >> 6];
     const GSweepUnit& su = g.units[u];
     const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
@@ -1294,107 +1296,154 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
     const double margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     PBN_GLOBAL double* part = (PBN_GLOBAL double*)su.part_mom;
 
+    // Round 6: the wave's QG query groups share ONE walk over the tiles - a batch's boxes are tested for every group, the records of the lanes
+    // that have a pair with ANY of them are loaded once (47 | 10 coalesced loads) and each group's 16 queries run against them: half the record
+    // loads and half the exposed load latency per pair at QG = 2 (the kernel spent 28 % of its wave time in s_waitcnt).  Every (query, lane) sum
+    // still meets its batches in ascending order: the partials are the ones of the group-by-group form, bit for bit.
+    // The groups' 16 queries live in lanes 0..15 (copies in the other lanes): coordinates and the exponent offset - the prepass's lower bound of
+    // the query's largest exponent, an integer as in the sweep.  A padding row (bound -inf) gets an offset that kills its terms.
+    double mqv[QG], cmv[QG], zv[QG][D], thr[QG];
+    bool gok[QG], chk[QG];
+#pragma unroll
     for (int gi = 0; gi < QG; ++gi) {
-        const int64_t qg = qt0 + gi;
-        if (qg >= su.nqtiles) break;
-        // the group's 16 queries live in lanes 0..15 (copies in the other lanes): coordinates and the exponent offset - the prepass's lower
-        // bound of the query's largest exponent, an integer as in the sweep.  A padding row (bound -inf) gets an offset that kills its terms.
+        gok[gi] = qt0 + gi < su.nqtiles;
+        const int64_t qg = gok[gi] ? qt0 + gi : qt0;
         const int64_t q = qg * 16 + (lane & 15);
         const double lb = __builtin_ceil(QLp[q]);
         const bool qok = (lb < 0.0 ? -lb : lb) < 0x1p50;
-        double mqv = qok ? lb : 0.0;
-        double cmv = qok ? Tr<double>::bias() - lb : -0x1p60;
-        double zv[D];
+        mqv[gi] = qok ? lb : 0.0;
+        cmv[gi] = qok ? Tr<double>::bias() - lb : -0x1p60;
+        // x = -d2 / 2 + cmv <= cmv: a group none of whose queries can reach 900 exponent units (the prepass bound of its largest exponent lies
+        // within ~870 units of 0: every query with a training row within 41 bandwidths) runs its 16 queries without the overflow test - one
+        // basic block of 16 independent Horner schemes instead of 16 blocks with a branch between them
+        chk[gi] = __any(cmv[gi] > 900.0) != 0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) zv[k] = qok ? ZQp[q * D + k] : 0.0;
+        for (int k = 0; k < D; ++k) zv[gi][k] = qok ? ZQp[q * D + k] : 0.0;
 #pragma unroll
-        for (int qi = 0; qi < 16; ++qi) accs[qi][lane] = 0.0;
-        const double thr = QTp[qg];
-        for (int64_t sb = t0; sb < t1; sb += 4096) {
-          // (the sweep's two levels: 64 batches classified at once, lane = batch, then the batches in reach)
-          const int64_t bt = sb + 64 * lane;
-          unsigned long long bm;
-          if (su.batch_box) {
-              const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)su.batch_box + ((int64_t)split * su.nbps + ((bt - t0) >> 6)) * 2 * pd;
-              bm = __ballot(bt < t1 && batch_in_reach(bb, QBp + qg * 2 * pd, pd, thr - margin));
-          } else {
-              bm = __ballot(bt < t1);
-          }
-          while (bm) {
-            const int bj = __builtin_ctzll(bm);
+        for (int qi = 0; qi < 16; ++qi) accs[gi * 16 + qi][lane] = 0.0;
+        thr[gi] = QTp[qg];
+    }
+    unsigned long long taken = 0;
+    for (int64_t sb = t0; sb < t1; sb += 4096) {
+        // (the sweep's two levels: 64 batches classified at once, lane = batch, then the batches in reach)
+        const int64_t bt = sb + 64 * lane;
+        unsigned long long bm[QG], bmu = 0;
+#pragma unroll
+        for (int gi = 0; gi < QG; ++gi) {
+            if (su.batch_box) {
+                const PBN_GLOBAL double* bb = (const PBN_GLOBAL double*)su.batch_box + ((int64_t)split * su.nbps + ((bt - t0) >> 6)) * 2 * pd;
+                bm[gi] = __ballot(gok[gi] && bt < t1 && batch_in_reach(bb, QBp + (qt0 + (gok[gi] ? gi : 0)) * 2 * pd, pd, thr[gi] - margin));
+            } else {
+                bm[gi] = __ballot(gok[gi] && bt < t1);
+            }
+            bmu |= bm[gi];
+        }
+        while (bmu) {
+            const int bj = __builtin_ctzll(bmu);
             const int64_t tb = sb + 64 * (int64_t)bj;
-            bm &= bm - 1;
-            unsigned long long nr, m;
-            if (g.count_redo && lane == 0) atomicAdd(&g_mom_visits, 1ull);
-            const unsigned long long kept = prune_group_mask3(TBp, QBp + qg * 2 * pd, R2p, pd, tb, t1, thr - margin, g.far_span > 0.0 ? thr - (margin - g.far_span) : -INFINITY,
-                                    thr - (margin + PBN_MOM_EXTRA), lane, nr, m);
-            if (g.count_redo && lane == 0 && (kept & ~m)) atomicAdd(&g_mom_left, 1ull);
-            if (!m) continue;
-            if (g.count_redo && lane == 0) { atomicAdd(&g_mom_pairs, (unsigned long long)__builtin_popcountll(m)); atomicAdd(&g_mom_batches, 1ull); }
-            const bool act = (m >> lane) & 1ull;
-            // my tile's record; a lane without a pair keeps zeros: its polynomial is 0 and (its exponent forced to 0 below) adds nothing
+            bmu &= bmu - 1;
+            unsigned long long m[QG], mu = 0;
+#pragma unroll
+            for (int gi = 0; gi < QG; ++gi) {
+                m[gi] = 0;
+                if ((bm[gi] >> bj) & 1ull) {
+                    unsigned long long nr;
+                    if (g.count_redo && lane == 0) atomicAdd(&g_mom_visits, 1ull);
+                    const unsigned long long kept = prune_group_mask3(TBp, QBp + (qt0 + gi) * 2 * pd, R2p, pd, tb, t1, thr[gi] - margin,
+                                                                      g.far_span > 0.0 ? thr[gi] - (margin - g.far_span) : -INFINITY,
+                                                                      thr[gi] - (margin + PBN_MOM_EXTRA), lane, nr, m[gi]);
+                    if (g.count_redo && lane == 0 && (kept & ~m[gi])) atomicAdd(&g_mom_left, 1ull);
+                    if (g.count_redo && lane == 0 && m[gi]) { atomicAdd(&g_mom_pairs, (unsigned long long)__builtin_popcountll(m[gi])); atomicAdd(&g_mom_batches, 1ull); }
+                }
+                mu |= m[gi];
+                taken += (unsigned long long)__builtin_popcountll(m[gi]);
+            }
+            if (!mu) continue;
+            // my tile's record; a lane without a pair keeps zero coefficients and a centroid 10^10 units away: its polynomial is 0 and its
+            // exponent -5e19, whose 2^x is an exact 0 (v_fract_f64 of an integer, the saturated v_cvt_i32_f64, v_ldexp_f64): it adds nothing,
+            // without a select per query
             double c[D], cf[NC];
 #pragma unroll
-            for (int k = 0; k < D; ++k) c[k] = 0.0;
+            for (int k = 0; k < D; ++k) c[k] = 1e10;
 #pragma unroll
             for (int k = 0; k < NC; ++k) cf[k] = 0.0;
-            if (act) {
+            if ((mu >> lane) & 1ull) {
                 const PBN_GLOBAL double* __restrict__ rec = MOp + (tb + lane);
 #pragma unroll
                 for (int k = 0; k < D; ++k) c[k] = rec[(int64_t)k * ms];
 #pragma unroll
                 for (int k = 0; k < NC; ++k) cf[k] = rec[(int64_t)(D + k) * ms];
             }
+#pragma unroll
+            for (int gi = 0; gi < QG; ++gi) {
+                if (!m[gi]) continue;
+                const bool act = (m[gi] >> lane) & 1ull;
+                // MASK: some lane holds a record for ANOTHER group of the wave and no pair with this one - its exponent is forced to -5e19 as
+                // well (a select per query; not needed while the groups' masks agree, the common case for neighbouring groups)
+                auto run = [&](auto checked, auto masked) {
+                    constexpr bool CHECK = decltype(checked)::value, MASK = decltype(masked)::value;
 #pragma unroll PBN_MOM_UNROLL
-            for (int qi = 0; qi < 16; ++qi) {
-                const double ux = readlane_f64(zv[0], qi) - c[0];
-                double d2 = ux * ux, uy = 0.0;
-                if constexpr (D == 2) { uy = readlane_f64(zv[1], qi) - c[1]; d2 = __builtin_fma(uy, uy, d2); }
-                double x = __builtin_fma(-0.5, d2, readlane_f64(cmv, qi));
-                x = act ? x : 0.0;
-                while (__builtin_expect(__any(x > 900.0), 0)) {
-                    // the offset is a LOWER bound of the query's largest exponent: a far-out query (heavy tails) can sit thousands of units
-                    // below a row its short neighbour scan missed.  Rebase the query (uniform: every lane's sum for it, and the offset it
-                    // lives with from here on) by a fixed integer number of units
-                    accs[qi][lane] *= 0x1p-512;
-                    if ((lane & 15) == qi) { cmv -= 512.0; mqv += 512.0; }
-                    x = act ? x - 512.0 : 0.0;
-                }
-                // 2^x as in the sweep this pass stands in for: 2^f of the fraction on the fp32 unit (<= 1.4e-7 of the pair's contribution, the
-                // budget's first entry); x >= 0 for every pair that matters (the biased offset), a negative x comes out <= 2x too large
-                const double e = PBN_MOM_EXP_F32 ? exp2_f64_fract<true>(x, 0.0) : Tr<double>::ex2_hi(x);
-                double pv;
-                if constexpr (D == 1) {
-                    pv = cf[0];
+                    for (int qi = 0; qi < 16; ++qi) {
+                        const double ux = readlane_f64(zv[gi][0], qi) - c[0];
+                        double d2 = ux * ux, uy = 0.0;
+                        if constexpr (D == 2) { uy = readlane_f64(zv[gi][1], qi) - c[1]; d2 = __builtin_fma(uy, uy, d2); }
+                        double x = __builtin_fma(-0.5, d2, readlane_f64(cmv[gi], qi));
+                        if constexpr (MASK) x = act ? x : -5e19;
+                        if constexpr (CHECK) {
+                            while (__builtin_expect(__any(x > 900.0), 0)) {
+                                // the offset is a LOWER bound of the query's largest exponent: a far-out query (heavy tails) can sit thousands of
+                                // units below a row its short neighbour scan missed.  Rebase the query (uniform: every lane's sum for it, and the
+                                // offset it lives with from here on) by a fixed integer number of units
+                                accs[gi * 16 + qi][lane] *= 0x1p-512;
+                                if ((lane & 15) == qi) { cmv[gi] -= 512.0; mqv[gi] += 512.0; }
+                                x = act ? x - 512.0 : -5e19;
+                            }
+                        }
+                        // 2^x as in the sweep this pass stands in for: 2^f of the fraction on the fp32 unit (<= 1.4e-7 of the pair's contribution,
+                        // the budget's first entry); x >= 0 for every pair that matters (the biased offset), a negative x comes out <= 2x too large
+                        const double e = PBN_MOM_EXP_F32 ? exp2_f64_fract<true>(x, 0.0) : Tr<double>::ex2_hi(x);
+                        double pv;
+                        if constexpr (D == 1) {
+                            pv = cf[0];
 #pragma unroll
-                    for (int i = 1; i <= PBN_MOM_ORDER; ++i) pv = __builtin_fma(pv, ux, cf[i]);
-                } else {
-                    int k = 0;
-                    pv = 0.0;
+                            for (int i = 1; i <= PBN_MOM_ORDER; ++i) pv = __builtin_fma(pv, ux, cf[i]);
+                        } else {
+                            int k = 0;
+                            pv = 0.0;
 #pragma unroll
-                    for (int j = PBN_MOM_ORDER; j >= 0; --j) {
-                        double qj = cf[k++];
+                            for (int j = PBN_MOM_ORDER; j >= 0; --j) {
+                                double qj = cf[k++];
 #pragma unroll
-                        for (int i = PBN_MOM_ORDER - j - 1; i >= 0; --i) qj = __builtin_fma(qj, ux, cf[k++]);
-                        pv = __builtin_fma(pv, uy, qj);
+                                for (int i = PBN_MOM_ORDER - j - 1; i >= 0; --i) qj = __builtin_fma(qj, ux, cf[k++]);
+                                pv = __builtin_fma(pv, uy, qj);
+                            }
+                        }
+                        accs[gi * 16 + qi][lane] = __builtin_fma(e, pv, accs[gi * 16 + qi][lane]);
                     }
-                }
-                accs[qi][lane] = __builtin_fma(e, pv, accs[qi][lane]);
+                };
+                if (chk[gi]) run(std::true_type{}, std::true_type{});
+                else if (m[gi] != mu) run(std::false_type{}, std::true_type{});
+                else run(std::false_type{}, std::false_type{});
             }
-          }
         }
-        // the group's sums: add the 64 lanes' (tiles') parts per query, lane qi writes query qi
+    }
+    if (lane == 0 && taken) atomicAdd(&g_mom_taken[D - 1], taken);
+    // the groups' sums: add the 64 lanes' (tiles') parts per query, lane qi writes query qi
+#pragma unroll
+    for (int gi = 0; gi < QG; ++gi) {
+        if (!gok[gi]) continue;
         double mine = 0.0;
 #pragma unroll
         for (int qi = 0; qi < 16; ++qi) {
-            double v = accs[qi][lane];
+            double v = accs[gi * 16 + qi][lane];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
             if (lane == qi) mine = v;
         }
         if (lane < 16) {
+            const int64_t q = (qt0 + gi) * 16 + lane;
             PBN_GLOBAL double* o = part + ((int64_t)split * su.nqtiles * 16 + q) * 2;
-            o[0] = mqv - Tr<double>::bias();   // the sums carry 2^bias, as the sweep's
+            o[0] = mqv[gi] - Tr<double>::bias();   // the sums carry 2^bias, as the sweep's
             o[1] = mine;
         }
     }
@@ -3057,6 +3106,13 @@ extern "C" void pbn_debug_moment_left(unsigned long long* left, int reset) {
     unsigned long long z = 0;
     if (left) (void)hipMemcpyFromSymbol(left, HIP_SYMBOL(pbn::g_mom_left), sizeof z);
     if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_mom_left), &z, sizeof z);
+}
+extern "C" void pbn_debug_moment_totals(unsigned long long* pairs_d1, unsigned long long* pairs_d2, int reset) {
+    unsigned long long v[2] = {0, 0}, z[2] = {0, 0};
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(pbn::g_mom_taken), sizeof v);
+    if (pairs_d1) *pairs_d1 = v[0];
+    if (pairs_d2) *pairs_d2 = v[1];
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(pbn::g_mom_taken), z, sizeof z);
 }
 extern "C" void pbn_debug_moment_pairs(unsigned long long* pairs, unsigned long long* batches, int reset) {
     unsigned long long z = 0;

@@ -8,6 +8,6 @@ python3 tools/fuzz_hc.py > gpurun_out/r5_val/fuzz_hc.txt 2>&1; tail -2 gpurun_ou
 PBN_PRUNE_MIN_ROWS=256 python3 tools/fuzz_hc.py > gpurun_out/r5_val/fuzz_hc_pruned.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_hc_pruned.txt
 python3 tools/fuzz_mmhc.py > gpurun_out/r5_val/fuzz_mmhc.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_mmhc.txt
 python3 tools/group_check.py > gpurun_out/r5_val/group_check.txt 2>&1; tail -3 gpurun_out/r5_val/group_check.txt
-# ... and with the tile-moment pass forced on every fp64 unit of one or two variables (the shipped rule takes it from 100 000 training rows)
+# ... and with the tile-moment pass forced on every fp64 unit of one or two variables (the shipped rule takes it from 400 000 training rows)
 PBN_MOMENT_MIN_ROWS=0 python3 tools/fuzz_grouped.py 40 7 > gpurun_out/r5_val/fuzz_grouped_moments.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_grouped_moments.txt
 PBN_MOMENT_MIN_ROWS=0 PBN_PRUNE_MIN_ROWS=256 python3 tools/fuzz_hc.py > gpurun_out/r5_val/fuzz_hc_moments.txt 2>&1; tail -2 gpurun_out/r5_val/fuzz_hc_moments.txt
