@@ -633,6 +633,16 @@ int split_tiles_for(int ntiles, bool f64) {
 // 270 000 12.79 -> 13.56 s; C3 (450 000) 9.04 -> 8.08 s.  Lane utilisation (tools/moment_visits.py): 40-44 of 64 at 57 600 rows with a third
 // of the pairs left to the sweep, 56-62 at 450 000 with 6 % left.
 int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 400000); }
+// The training rows the moment-pass rule looks at.  A leave-one-region-out unit (a cross-validation fold: it trains on at least two
+// regions) answers with the size of its pool's SMALLEST training set, T - ceil(T / k) for T = training + test rows - the same number
+// for every fold of the pool, so whether a (term, fold) takes the pass does not depend on which folds of the pool share the call (fold
+// sizes differ by a row: a call holding one fold and a call holding all ten must give that fold the same double).  Any other unit: its own.
+static int64_t moment_rule_rows(const GUnit& U) {
+    const int k = __builtin_popcountll(U.train_mask) + 1;
+    if (k < 3) return U.N;
+    const int64_t T = (int64_t)U.N + U.nq;
+    return T - (T + k - 1) / k;
+}
 
 // one chunk: pools [p0, p1) of the (variant-sorted) order; all of one variant (same KS, fold / wmul)
 void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vector<int>& order, size_t p0, size_t p1, double* dev_out,
@@ -673,7 +683,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     // sets are dense enough for it to pay (moment_pass_rows; kde_group_run gives such sets chunks of their own).  PBN_MOMENT_PASS=0
     // switches it off (the sweep then takes every pair, as until round 4).
     bool dense = true;
-    for (const GUnit& U : units) dense = dense && U.N >= moment_pass_rows();
+    for (const GUnit& U : units) dense = dense && moment_rule_rows(U) >= moment_pass_rows();
     const bool moments = !f16 && d0 <= 2 && dense && knob_int("PBN_MOMENT_PASS", 1) != 0 && PBN_TUNE(PRUNE_GROUP_MASKS, 1) != 0;
     const bool bboxes = !f16 && PBN_TUNE(GROUP_BATCH_BOXES, 1) != 0;   // fp64 sweeps with per-group masks: one uniform test per (batch, group) first
     int64_t total_wg = 0;
@@ -899,7 +909,7 @@ void kde_group_run(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, double* dev_
     const int mom_rows = moment_pass_rows();
     auto dense = [&](const GPool& P) {
         for (int u = 0; u < P.nunits; ++u)
-            if (b.units[P.unit0 + u].N < mom_rows) return false;
+            if (moment_rule_rows(b.units[P.unit0 + u]) < mom_rows) return false;
         return true;
     };
     auto variant = [&](int i) {

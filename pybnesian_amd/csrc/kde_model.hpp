@@ -97,8 +97,10 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
 // The sum-only fp64 sweeps carry an ABSOLUTE error per log-density of at most 1.4e-7 (2^f on the fp32 unit) + 1.1e-7 (dropped mass) +
 // 8e-8 (fp32 far tail) = 3.3e-7; measured with every rounding made one-sided (tests/test_error_budget_gpu.py): 3e-8.  Relative to a sum
 // of n log-densities that is harmless unless the sum is a cancellation to ~0 (a table whose density happens to sit near 1 in its units):
-// |sum| < 0.66 n is where the bound would exceed 5e-7 of the sum - such a sum is evaluated once more at full precision.
-inline bool kde_sum_needs_precision(double sum, int64_t n) { return n > 0 && std::fabs(sum) < PBN_TUNE_D(NEAR_ZERO_LOGL, 0.66) * (double)n; }
+// |sum| < 0.33 n is where the BOUND would reach the north star's bar, 1e-6 of the sum (the measured one-sided error reaches it at 0.03 n) - such
+// a sum is evaluated once more at full precision.  (Rounds 4-5 drew the line at 0.66 n, 5e-7 of the sum: ordinary conditional log-likelihoods
+// and one-variable terms with sigma ~ 0.13-0.47 sit at |mean logl| < 0.66 and paid two evaluations for a margin nobody asked for.)
+inline bool kde_sum_needs_precision(double sum, int64_t n) { return n > 0 && std::fabs(sum) < PBN_TUNE_D(NEAR_ZERO_LOGL, 0.33) * (double)n; }
 
 // Bandwidth selectors on a covariance (kde/NormalReferenceRule.hpp:72-134, kde/ScottsBandwidth.hpp:66-117).
 void bandwidth_from_cov(int selector, int kind, const double* cov, int d, int64_t n, int dtype, double* out);

@@ -13,8 +13,14 @@
 //   * LinearGaussian / discrete candidates and the assembly of the term-sharded ones -> every rank (host arithmetic on replicated moments).
 // The plan is a pure function of the batch and of the engine's replicated state (which totals are installed), so every rank computes the
 // same one; this rank evaluates its share, ONE all-gather per batch (terms | parts | whole candidates | error flag) hands every rank
-// everything, and every rank assembles the same doubles.  A rank that fails while evaluating still enters the collective (flag set, NaNs)
-// and every rank fails afterwards - the failing one with its own error, the others naming it.
+// everything, and every rank assembles the same doubles.  A rank that fails while evaluating its share still enters the collective (flag set,
+// NaNs) and every rank fails afterwards - the failing one with its own error, the others naming it.  What that does NOT cover: the plan
+// before the collective and the assembly after it.  Both work on replicated inputs only (the batch, the installed totals, host allocations
+// of a few KB), so a failure there is the same failure on every rank; a rank-LOCAL one (a device error in the light candidates' Gram
+// solves, host out of memory) leaves the other ranks in the next batch's collective - bind a communicator whose collective times out
+// (torch: init_process_group(timeout=...); RCCL: NCCL_ASYNC_ERROR_HANDLING), as INTEGRATION.md says.
+// A batch in which nothing is dealt (LinearGaussian / discrete candidates only, every term already installed) makes NO collective call:
+// the plan is the same on every rank, so every rank knows, evaluates locally, and a local error stays local.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -146,7 +152,7 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
     std::vector<std::vector<int>> term_lists((size_t)world);
     std::vector<std::pair<int, int>> items;             // (term, fold) dealing: item -> (index in todo, region)
     bool by_fold = false;
-    if (by_term.size() >= 2) {
+    if (!by_term.empty()) {   // (one candidate too: its one or two terms are dealt fold by fold instead of being swept by every rank)
         std::vector<std::vector<int>> terms;
         std::map<std::vector<int>, int> seen;
         for (int i : by_term) {
@@ -179,8 +185,6 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
         }
         for (size_t i = 0; i < owner.size(); ++i) term_lists[(size_t)owner[i]].push_back((int)i);
         for (int i : by_term) heavy[i] = 0;   // assembled by every rank from the shared terms
-    } else {
-        by_term.clear();
     }
     // (b) the slices of CKDE candidates with discrete parents
     std::vector<int> sliced;
@@ -196,7 +200,7 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
     for (int i = 0; i < n; ++i)
         if (heavy[i]) whole.push_back(i);
     std::vector<std::vector<int>> whole_lists((size_t)world);
-    if (whole.size() >= 2) {
+    if (!whole.empty()) {   // (a lone one goes to one rank: evaluated once in the job)
         std::map<std::vector<int>, int> set_of;
         std::vector<std::vector<int>> sets;
         std::vector<int> count, cand_set;
@@ -225,6 +229,10 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
     size_t per_terms = 0, per_whole = 0;
     for (int r = 0; r < world; ++r) { per_terms = std::max(per_terms, term_lists[(size_t)r].size()); per_whole = std::max(per_whole, whole_lists[(size_t)r].size()); }
     const size_t n_parts = sliced.size() * (size_t)PARTS;
+    if (per_terms + n_parts + per_whole == 0) {   // nothing dealt: no collective (every rank takes this branch: the plan is replicated)
+        must(eng->batch(eng->user, kind, n, var, ntype, off, par, out), "engine batch");
+        return;
+    }
     const size_t count = per_terms + n_parts + per_whole + 1;
     const size_t o_parts = per_terms, o_whole = per_terms + n_parts, o_flag = count - 1;
     std::vector<double> send(count, 0.0), recv(count * (size_t)world, 0.0);
@@ -298,7 +306,7 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
         }
         must(eng->terms_put(eng->user, kind, tl.n(), tl.off.data(), tl.vars.data(), tl.m.data(), values.data()), "engine terms_put");
     }
-    {   // light candidates, the term-sharded ones (from the shared terms) and a lone heavy one: every rank
+    {   // light candidates and the term-sharded ones (from the shared terms): every rank
         Sub rest;
         std::vector<int> idx;
         for (int i = 0; i < n; ++i)

@@ -115,6 +115,11 @@ def comm():
     return _COMM
 
 
+def collective_calls():
+    """All-gather calls the process's communicator has made so far (0 without one): what the tests count."""
+    return 0 if _COMM is None else _COMM.gathers
+
+
 def deal_sets(keys, world, rows=(1_000_000, 100_000), regions=1):
     """Owner rank of every variable set (pbn_shard_deal on pbn_shard_term_cost: one joint sweep per set + one marginal sweep per
     candidate; longest processing time first, equal costs by a hash of the set, each set to the least loaded rank).  Deterministic,
@@ -225,6 +230,16 @@ def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
     call.  Any other score object goes through pbn_shard_batch with its Python methods as the engine."""
     cm = comm()
     n = len(var)
+    bound = getattr(score, "_comm", None)
+    if bound is not None and bound is not cm and getattr(score, "_handle", None) is not None:
+        # the process group the score was created under is gone (destroy_process_group, or another group / world size since): the handle
+        # still holds that communicator's rank, world and callback.  Its moments were reduced over the old group and are complete, so the
+        # handle is re-bound to the current communicator - or un-bound (one process) - instead of running a dead closure
+        if bound.errors:
+            err, bound.errors = bound.errors[0], []
+            raise err
+        _lib.check(_lib.load().pbn_scoredata_set_comm(score._handle, cm.ref() if cm is not None else None))
+        score._comm = cm
     if cm is None or n == 0:
         return score._batch_raw(model, var, ntype, off, par, kind)
     if getattr(score, "_comm", None) is cm and not shard_all:

@@ -195,6 +195,7 @@ class _DeviceScore(Score):
             _lib.check(_lib.load().pbn_scoredata_create_sharded(self._ctx.handle, table.handle, self._split, int(k),
                                                                 C.c_uint32(int(seed)), float(ratio), cm.struct.rank,
                                                                 cm.struct.world, C.byref(h)))
+            self._handle = h   # owned from here on: a failing collective below must not leak it (__del__ destroys it)
             cm.check(_lib.load().pbn_scoredata_reduce_moments(h, cm.ref()))
             _lib.check(_lib.load().pbn_scoredata_set_comm(h, cm.ref()))
         self._handle = h

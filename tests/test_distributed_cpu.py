@@ -314,3 +314,59 @@ def test_sharded_batch_deals_terms_and_slices_world2(ensure_built, regions, worl
         per_rank = [len(ev) for _, _, _, ev, _ in results]
         assert max(per_rank) - min(per_rank) <= 2                                 # (term, fold) pairs of equal cost: dealt evenly
     assert len(evaluated) == len(set(evaluated)) and set(evaluated) == terms      # each term (or pair) once, on one rank, in the first batch only
+
+
+def _lone_worker(rank, world, port, queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pybnesian_amd import _lib, distributed
+        from pybnesian_amd.distributed import sharded_batch
+
+        calls = {"n": 0}
+        real = distributed.Comm._all_gather if hasattr(distributed.Comm, "_all_gather") else None
+        s = _FakeEngineScore(regions=5)
+        # (1) ONE continuous CKDE candidate (2 | 0, 1): its two terms are dealt fold by fold - 10 (term, fold) pairs over the job, each once
+        lone = sharded_batch(s, None, [2], [1], [0, 2], [0, 1], _lib.PBN_SCORE_CVLIK)
+        ev_lone = list(s.region_items) + list(s.evaluated)
+        # (2) a batch of LinearGaussian / discrete candidates only: nothing is dealt, no collective is made
+        before = distributed.collective_calls() if hasattr(distributed, "collective_calls") else None
+        light = sharded_batch(s, None, [0, 1, 4], [0, 0, 2], [0, 1, 3, 4], [1, 0, 2, 5], _lib.PBN_SCORE_CVLIK)
+        after = distributed.collective_calls() if hasattr(distributed, "collective_calls") else None
+        queue.put((rank, lone.tolist(), light.tolist(), ev_lone, s.raw_calls, None if before is None else after - before))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_lone_candidate_is_evaluated_once_in_the_job_and_light_batches_make_no_collective(ensure_built):
+    """Round 6: a batch with exactly ONE heavy candidate used to be evaluated by every rank (both dealers wanted at least two); now its terms
+    go round the ranks (term, fold) by (term, fold) like any small batch, every pair evaluated once across the job.  And a batch in which the
+    plan deals nothing (LinearGaussian / discrete candidates, or every term already installed) makes no collective call at all."""
+    from pybnesian_amd import _lib
+
+    world = 3
+    ref = _FakeEngineScore(regions=5)
+    want_lone = ref._batch_raw(None, [2], [1], [0, 2], [0, 1], _lib.PBN_SCORE_CVLIK).tolist()
+    want_light = ref._batch_raw(None, [0, 1, 4], [0, 0, 2], [0, 1, 3, 4], [1, 0, 2, 5], _lib.PBN_SCORE_CVLIK).tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lone_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    evaluated = []
+    for rank, lone, light, ev, raw_calls, ncoll in results:
+        assert lone == want_lone and light == want_light
+        evaluated += ev
+        if ncoll is not None:
+            assert ncoll == 0, "a batch of light candidates made a collective call"
+    k = _lib.PBN_SCORE_CVLIK
+    pairs = {(k, 3, 0, 1, 2, -1, f) for f in range(5)} | {(k, 3, 0, 1, -1, f) for f in range(5)}
+    assert len(evaluated) == 10 and set(evaluated) == pairs          # ten (term, fold) pairs, each on exactly one rank
+    per_rank = [len(ev) for _, _, _, ev, _, _ in results]
+    assert max(per_rank) - min(per_rank) <= 1
