@@ -557,6 +557,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         "cells_scored": hc.last.cells_scored,
         "local_score_evals": hc.last.local_score_evals,
         "iterations": hc.last.iterations,
+        "near_tie_redos": getattr(hc.last, "near_tie_redos", None),
         "arcs_found": res.num_arcs(),
         "estimate_s": dt,
         "score_ctor_s": t_ctor,

@@ -244,6 +244,10 @@ int pbn_lg_cdf(const pbn_table* t, const int* cols, int d, int64_t row0, int64_t
  * evaluate per fold and candidate). */
 int pbn_score_batch(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off,
                     const int* parents, const double* params, int n_params, double* out);
+/* on != 0: the CKDE terms of fp64 tables are evaluated at the accuracy of the per-row path whatever the handle's caches hold, and replace
+ * what they hold (what the search's near-tie check asks for: pbn_hc_config.near_tie_abs; the reference has one precision only,
+ * kde/KDE.hpp:592-640).  Off by default. */
+int pbn_scoredata_set_precise(pbn_scoredata* sd, int on);
 
 /* The two halves of a CKDE likelihood score as functions of a variable SET: local(v | P) = A({v} u P, d) - A(P, d), d = |P| + 1, with
  * A(S, m) = sum over the split's test regions of sum_q log KDE_S(q) under the bandwidth rule for m dimensions on the region's training
@@ -368,6 +372,12 @@ typedef struct {
      * flipped.  node_types then holds n_nodes+n_interface entries, arc sources may be interface ids, the delta
      * matrix of pbn_hc_get is (n_nodes+n_interface) x n_nodes. */
     int n_interface;
+    /* Near ties of likelihood scores (round 6; 0 = off, the reference's behaviour): when the best operator and the runner-up differ by less
+     * than near_tie_abs and one of them rests on a CKDE local score, the local scores behind BOTH deltas are asked for again with bit 1 of
+     * the callback's `validated` argument set (validated | 2 = "at full precision": polynomial 2^f, per-row pruning margin, no fp32 tail, no
+     * moment pass - pbn_scoredata_set_precise) and the operator with the larger precise delta is applied.  The sum-only sweeps carry up to
+     * 3.3e-7 per log-density with a mean bias of -1.3e-9: 4 x 3.3e-7 x test rows is the band in which that could decide. */
+    double near_tie_abs;
 } pbn_hc_config;
 typedef struct {
     int iterations;
@@ -377,6 +387,7 @@ typedef struct {
     int* trace;                /*   kind (0 add, 1 remove, 2 flip, 3 change type), source|node, target|type, 0 */
     double* trace_delta;       /* delta of every applied operator (nullable)                             */
     int trace_len;
+    int64_t near_tie_redos;    /* iterations whose two best operators were re-scored at full precision (near_tie_abs)  */
 } pbn_hc_stats;
 int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn score, void* user, int* out_arcs, int* out_n_arcs,
                     int* out_node_types, pbn_hc_stats* stats);

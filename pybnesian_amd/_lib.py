@@ -70,6 +70,7 @@ SIGNATURES = {
     "pbn_scoredata_create_sharded": (_int, [_vp, _vp, _int, _int, C.c_uint32, C.c_double, _int, _int, C.POINTER(_vp)]),
     "pbn_scoredata_moments": (_int, [_vp, _dp, C.POINTER(_i64), _int]),
     "pbn_scoredata_set_selector": (_int, [_vp, _int]),
+    "pbn_scoredata_set_precise": (_int, [_vp, _int]),
     "pbn_scoredata_cache_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "pbn_scoredata_destroy": (None, [_vp]),
     "pbn_scoredata_set_discrete": (_int, [_vp, _int, C.POINTER(_vp), _ip]),
@@ -156,14 +157,14 @@ class HCConfig(C.Structure):
         ("n_type_blacklist", _int), ("type_blacklist", _ip), ("n_type_whitelist", _int), ("type_whitelist", _ip),
         ("op_arcs", _int), ("op_node_type", _int), ("arcs_first", _int), ("max_indegree", _int), ("max_iters", _int),
         ("epsilon", C.c_double), ("patience", _int), ("validated", _int),
-        ("on_iter", HC_ITER_FN), ("on_iter_user", _vp), ("n_interface", _int),
+        ("on_iter", HC_ITER_FN), ("on_iter_user", _vp), ("n_interface", _int), ("near_tie_abs", C.c_double),
     ]
 
 
 class HCStats(C.Structure):
     _fields_ = [
         ("iterations", _int), ("cells_scored", _i64), ("local_score_evals", _i64), ("trace_capacity", _int),
-        ("trace", _ip), ("trace_delta", _dp), ("trace_len", _int),
+        ("trace", _ip), ("trace_delta", _dp), ("trace_len", _int), ("near_tie_redos", _i64),
     ]
 
 

@@ -403,6 +403,55 @@ struct Engine {
         if (use_types) types_apply(treq, S);
     }
 
+    // ---- near ties (round 6, pbn_hc_config.near_tie_abs; not in the reference) -----------------------------------------------------
+    bool bears_ckde(const Op& o) const {   // does the operator's delta rest on a CKDE local score?
+        if (o.kind == OP_TYPE) return o.new_type == PBN_NODE_CKDE || cur.node_type[o.source] == PBN_NODE_CKDE;
+        if (cur.node_type[o.target] == PBN_NODE_CKDE) return true;
+        return o.kind == OP_FLIP && cur.node_type[o.source] == PBN_NODE_CKDE;
+    }
+    // the runner-up of find_max: the best valid operator other than `best`; the persistent sort order is put back (the second std::sort must
+    // not change which of two EQUAL deltas a later find_max meets first)
+    Op runner_up(const std::vector<Op>* tabu, const Op& best) const {
+        std::vector<Op> tb;
+        if (tabu) tb = *tabu;
+        tb.push_back(best);
+        const std::vector<int> keep = arcs.sorted_idx;
+        Op second = find_max(&tb);
+        arcs.sorted_idx = keep;
+        return second;
+    }
+    // the operator's delta from local scores asked for at full precision (callback flag 2): new local scores of the nodes it changes minus
+    // their current ones, all four / two evaluated in one batch
+    double precise_delta(const Op& o) {
+        Batch b;
+        auto with = [&](int t, int s, bool add) {
+            std::vector<int> p = cur.parents[t];
+            if (add) p.push_back(s); else p.erase(std::remove(p.begin(), p.end(), s), p.end());
+            return p;
+        };
+        std::vector<int> plus, minus;   // indices into the batch
+        if (o.kind == OP_TYPE) {
+            plus.push_back(b.add(o.source, o.new_type, cur.parents[o.source]));
+            minus.push_back(b.add(o.source, cur.node_type[o.source], cur.parents[o.source]));
+        } else if (o.kind == OP_ADD) {
+            plus.push_back(b.add(o.target, cur.node_type[o.target], with(o.target, o.source, true)));
+            minus.push_back(b.add(o.target, cur.node_type[o.target], cur.parents[o.target]));
+        } else if (o.kind == OP_REMOVE) {
+            plus.push_back(b.add(o.target, cur.node_type[o.target], with(o.target, o.source, false)));
+            minus.push_back(b.add(o.target, cur.node_type[o.target], cur.parents[o.target]));
+        } else {   // flip source -> target into target -> source
+            plus.push_back(b.add(o.target, cur.node_type[o.target], with(o.target, o.source, false)));
+            plus.push_back(b.add(o.source, cur.node_type[o.source], with(o.source, o.target, true)));
+            minus.push_back(b.add(o.target, cur.node_type[o.target], cur.parents[o.target]));
+            minus.push_back(b.add(o.source, cur.node_type[o.source], cur.parents[o.source]));
+        }
+        const std::vector<double> S = scorer.run(b, 2);
+        double d = 0.0;
+        for (int i : plus) d += S[(size_t)i];
+        for (int i : minus) d -= S[(size_t)i];
+        return d;
+    }
+
     Op find_max(const std::vector<Op>* tabu) const {
         if (tabu && tabu->empty()) tabu = nullptr;
         double max_delta = LOWEST;
@@ -605,6 +654,7 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
         double accumulated_offset = 0;
         std::vector<Op> tabu;
         int iter = 0;
+        int64_t near_tie_redos = 0;
         std::vector<int> trace;
         auto notify = [&](const Model& mod, const Op* op, int iteration) {  // Callback::call
             if (!cfg->on_iter) return;
@@ -621,6 +671,15 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
         while (iter < cfg->max_iters) {
             ++iter;
             Op best_op = zero_patience ? e.find_max(nullptr) : e.find_max(&tabu);
+            if (cfg->near_tie_abs > 0.0 && best_op.valid()) {
+                const Op second = e.runner_up(zero_patience ? nullptr : &tabu, best_op);
+                if (second.valid() && best_op.delta - second.delta < cfg->near_tie_abs && (e.bears_ckde(best_op) || e.bears_ckde(second))) {
+                    // a gap the sum-only sweeps' error budget could have decided: both deltas again from full-precision local scores
+                    const double d1 = e.precise_delta(best_op), d2 = e.precise_delta(second);
+                    ++near_tie_redos;
+                    if (d2 > d1) { best_op = second; best_op.delta = d2; } else best_op.delta = d1;
+                }
+            }
             if (!best_op.valid() || (best_op.delta - cfg->epsilon) < MACHINE_TOL) break;
             m.apply(best_op);
             std::vector<int> changed = m.nodes_changed(best_op);
@@ -676,6 +735,7 @@ extern "C" int pbn_hc_estimate(const pbn_hc_config* cfg, pbn_hc_score_fn fn, voi
             stats->cells_scored = e.cells_scored;
             stats->local_score_evals = e.scorer.evals;
             stats->trace_len = (int)trace.size() / 4;
+            stats->near_tie_redos = near_tie_redos;
             if (stats->trace && !trace.empty()) std::memcpy(stats->trace, trace.data(), trace.size() * sizeof(int));   // (an empty vector's data() may be null: UB for memcpy even with size 0 - found by the host sanitizer run)
         }
     });

@@ -817,7 +817,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                     out[c] = score_hybrid(sd, kind, cols[0], nt, cols.data() + 1, p, &hp, hybrid_batch(), &sink);
                     continue;
                 }
-                const bool memo = score_memo_on() && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT);   // (discrete factors too: a count over all rows on the host each)
+                const bool memo = score_memo_on() && !sd->force_precise && (kind == PBN_SCORE_CVLIK || kind == PBN_SCORE_HOLDOUT);   // (discrete factors too: a count over all rows on the host each)
                 std::vector<int> key;
                 if (memo) {
                     key.assign(cols.begin() + 1, cols.end());
@@ -929,9 +929,10 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 k.insert(k.begin(), {region, m});
                 return k;
             };
+            const bool precise_all = sd->force_precise && sd->dtype == PBN_F64;
             auto lookup = [&](const std::vector<int>& key, Term& t) {
                 auto it = sd->kde_cache.find(key);
-                if (it != sd->kde_cache.end()) { t.value = it->second; return true; }
+                if (!precise_all && it != sd->kde_cache.end()) { t.value = it->second; return true; }
                 auto is = scheduled.find(key);
                 if (is != scheduled.end()) { t.slot = is->second; return true; }
                 return false;
@@ -945,7 +946,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             struct Unit { int cand; Term joint, marg; bool has_marg; int want; };
             // a term whose total over the regions was installed (pbn_score_terms_put): the total stands for region 0, the others add 0
             auto lookup_total = [&](int m, const int* v, int nv, int region_index, Term& t) {
-                if (sd->term_total.empty() || only_region) return false;   // (one region of a term: never its total)
+                if (sd->term_total.empty() || only_region || precise_all) return false;   // (one region of a term: never its total)
                 std::vector<int> k(v, v + nv);
                 std::sort(k.begin(), k.end());
                 k.insert(k.begin(), {kind, m});   // a validated score asks one handle for both kinds
@@ -1079,7 +1080,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 const int p = par_off[w.cand + 1] - par_off[w.cand];
                 const bool own_term = w.mode == 2 && want && want[w.cand] == 3;   // marginal term over all p + 1 columns, rule for p + 2
                 const int dims = own_term ? p + 1 : (w.mode == 2 ? p : p + 1);
-                if (!kde_group_applies(sd->dtype, dims, min_train, R)) continue;
+                if (precise_all || !kde_group_applies(sd->dtype, dims, min_train, R)) continue;   // (precise: one chain per term, per-row accuracy)
                 Prep pr;
                 prepare(w, pr);
                 std::vector<int> key(pr.use);
@@ -1164,7 +1165,7 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
             for (const Work& w : work) {
                 if (grouped[wi++]) continue;
                 LaneSwitch lane(ctx, (int)(li++ % (size_t)lanes));
-                run_single(w, false);
+                run_single(w, false, precise_all);
             }
             std::vector<double> hs(std::max<size_t>(1, 2 * nslots));
             if (lanes > 1) ctx->sync_lanes(lanes - 1);
@@ -1231,6 +1232,13 @@ static int score_batch_impl(pbn_scoredata* sd, int kind, int n_cand, const int* 
                 out[pd.cand] = wnt >= 2 ? msum[pd.cand] : (wnt == 1 ? jsum[pd.cand] : jsum[pd.cand] - msum[pd.cand]);
             }
         }
+    });
+}
+
+int pbn_scoredata_set_precise(pbn_scoredata* sd, int on) {
+    return guarded(mu_of(sd), [&] {
+        if (!sd) throw invalid_error("pbn_scoredata_set_precise: null handle");
+        sd->force_precise = on != 0;
     });
 }
 
@@ -1369,7 +1377,8 @@ int pbn_score_terms_missing(pbn_scoredata* sd, int kind, int n_terms, const int*
         check_terms(sd, kind, n_terms, off, vars, m, "pbn_score_terms_missing");
         if (n_terms > 0 && !missing) throw invalid_error("pbn_score_terms_missing: null output");
         for (int i = 0; i < n_terms; ++i)
-            missing[i] = sd->term_total.find(term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])) == sd->term_total.end() ? 1 : 0;
+            missing[i] = (sd->force_precise && sd->dtype == PBN_F64) ||   // (precise mode: every term is evaluated again, by the rank it is dealt to)
+                         sd->term_total.find(term_key(kind, vars + off[i], off[i + 1] - off[i], m[i])) == sd->term_total.end() ? 1 : 0;
     });
 }
 

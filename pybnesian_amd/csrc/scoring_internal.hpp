@@ -60,6 +60,10 @@ struct pbn_scoredata {
     std::map<std::vector<int>, double> term_total;
     int64_t kde_sweeps = 0;
     int64_t precise_redos = 0;   // fp64 terms evaluated a second time at per-row accuracy (kde_sum_needs_precision)
+    // pbn_scoredata_set_precise: CKDE terms of fp64 tables are evaluated at the accuracy of the per-row path (polynomial 2^f, per-row pruning
+    // margin, no fp32 tail, no moment pass), whatever the caches hold - their results replace the cached ones.  What the search's near-tie
+    // check asks for (hc.hip); never on by default.
+    bool force_precise = false;
     // hybrid likelihood local scores by [kind, node type, variable, sorted parents...] (see pbn_score_batch)
     std::map<std::vector<int>, double> score_memo;
     int64_t memo_hits = 0;

@@ -9,6 +9,7 @@ ranks and the scores are exchanged with one all_gather per batch (pybnesian_amd/
 then takes the identical, deterministic decision.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -330,6 +331,16 @@ class _EngineBinding:
         cfg.epsilon, cfg.patience = float(epsilon), int(patience)
         cfg.n_interface = len(self.nodes) - self.n_nodes
         cfg.validated = int(isinstance(score, ValidatedScore) or bool(getattr(score, "validated", False)))
+        # near ties of CKDE likelihood scores on fp64 tables (pbn_hc_config.near_tie_abs): 4 x the sum-only sweeps' error budget per
+        # log-density (3.3e-7) x the test rows a local score sums over; PBN_NEAR_TIE=0 switches the check off (the reference has none)
+        cfg.near_tie_abs = 0.0
+        if device_score and os.environ.get("PBN_NEAR_TIE", "1") != "0" and getattr(score, "_kind", None) in (_lib.PBN_SCORE_CVLIK, _lib.PBN_SCORE_HOLDOUT):
+            try:
+                if score._table.dtype == _lib.PBN_F64:
+                    _, _, n_cv, n_hold = score._layout()
+                    cfg.near_tie_abs = 4.0 * 3.3e-7 * float(n_cv if score._kind == _lib.PBN_SCORE_CVLIK else n_hold)
+            except Exception:   # a score without a device layout: no check
+                cfg.near_tie_abs = 0.0
         self.cfg = cfg
         self.errors = []
         self.batch_hook = None
@@ -340,9 +351,16 @@ class _EngineBinding:
                 var_l = [col_of_node[var[i]] for i in range(n_cand)]
                 nt_l = [ntype[i] for i in range(n_cand)]
                 par_l = [col_of_node[par[i]] for i in range(off_l[-1])]
+                precise, validated = bool(validated & 2), validated & 1   # bit 1: "at full precision" (the search's near-tie check)
                 if device_score:
                     kind = _lib.PBN_SCORE_HOLDOUT if validated else score._kind
-                    res = sharded_batch(score, model, var_l, nt_l, off_l, par_l, kind)
+                    if precise:
+                        _lib.check(_lib.load().pbn_scoredata_set_precise(score._handle, 1))
+                    try:
+                        res = sharded_batch(score, model, var_l, nt_l, off_l, par_l, kind)
+                    finally:
+                        if precise:
+                            _lib.check(_lib.load().pbn_scoredata_set_precise(score._handle, 0))
                 else:  # Python-derived Score: one trampoline call per candidate, as the reference does
                     fn = score.vlocal_score_node_type if validated else score.local_score_node_type
                     plain = score.vlocal_score if validated else score.local_score
@@ -633,6 +651,7 @@ class GreedyHillClimbing:
         self.last.iterations = stats.iterations
         self.last.cells_scored = stats.cells_scored
         self.last.local_score_evals = stats.local_score_evals
+        self.last.near_tie_redos = int(stats.near_tie_redos)
         self.last.trace = [binding.make_op(trace[4 * i], trace[4 * i + 1], trace[4 * i + 2], tdelta[i]) for i in range(stats.trace_len)]
         return result
 

@@ -49,6 +49,7 @@ def main():
     from dist_worker_gpu import run as worker_run
 
     out = {"world": 1, "backend": "nccl"}
+    ok = False
     plain = worker_run()                       # no process group yet: the one-process values
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
@@ -74,6 +75,14 @@ def main():
         out["mapped"] = mapped_libraries()
         out["torch"] = torch.__version__
         out["hip_runtime_of_torch"] = torch.version.hip
+        # The SUPPORTED pairing of an N > 1 job under torch (INTEGRATION.md "one HIP runtime per process"): ONE libamdhip64 in the process - the
+        # first one loaded, i.e. torch's - and RCCL from the same distribution; libpbn_hip.so names libamdhip64.so.7 by SONAME, so the loader hands
+        # it the copy torch already mapped (its RUNPATH to /opt/rocm only matters in a process without torch: the plain-C hosts).  Asserted here,
+        # not only recorded: two HIP runtimes in one process, or RCCL from another tree than the HIP runtime, fail the run.
+        hip, rccl = out["mapped"].get("libamdhip64", []), out["mapped"].get("librccl", [])
+        one_runtime = len(hip) == 1 and len(rccl) == 1 and os.path.dirname(hip[0]) == os.path.dirname(rccl[0])
+        out["hip_runtime_pairing"] = ("torch" if one_runtime and "torch" in hip[0] else "rocm" if one_runtime else "MIXED")
+        ok = ok and one_runtime
         dist.destroy_process_group()
     out["seconds"] = time.perf_counter() - t_start
     out["ok"] = bool(ok)
