@@ -73,3 +73,42 @@ def test_kmi_drives_mmpc_and_dynamic_adaptator(pbn):
     assert dyn.static_tests().num_variables() == 2 and dyn.transition_tests().num_variables() == 4
     with pytest.raises(ValueError, match="Wrong data type"):
         pbn.KMutualInformation(pd.DataFrame({"a": [1.0, 2.0, 3.0], "b": pd.Categorical(["x", "y", "x"])}), 1)
+
+
+def test_window_form_gives_the_all_pairs_counts(pbn, monkeypatch):
+    """Round 6: tables of at least 32 768 rows take the sorted-window walk (kmi.hip: kmi_window_kernel) instead of the all-pairs kernels.  Both
+    produce the reference's integer counts (k-th neighbour distance, strictly-inside counts of the subspaces), the host adds the same digammas
+    in the same row order: the estimates are EQUAL, not close - checked on small tables with the window form forced (against the all-pairs form
+    and the oracle, every overload and the permutation p-values) and on a table that takes it by default (against the all-pairs form forced)."""
+    from oracle import oracle
+
+    cases = [("a", "b", []), ("a", "d", []), ("a", "c", ["b"]), ("a", "e", ["d"]), ("b", "c", ["a", "d"]), ("a", "e", ["b", "c", "d"])]
+
+    def values(df, k, **kw):
+        t = pbn.KMutualInformation(df, k, seed=0, **kw)
+        return [t.mi(x, y, z if len(z) != 1 else z[0]) for x, y, z in cases]
+
+    for n, k in ((257, 3), (1200, 10), (5000, 64)):
+        df = table(n, 4)
+        plain = values(df, k)
+        monkeypatch.setenv("PBN_KMI_WINDOW_MIN_ROWS", "0")
+        forced = values(df, k)
+        monkeypatch.delenv("PBN_KMI_WINDOW_MIN_ROWS")
+        assert forced == plain, (n, k)
+        if n <= 1200:
+            for (x, y, z), got in zip(cases, forced):
+                want, _ = oracle.kmi(df[[x, y] + z].to_numpy(dtype=np.float64), k)
+                assert got == pytest.approx(want, rel=1e-10, abs=1e-12)
+    # permutation p-values: the permuted x column goes through the same walk
+    df = table(400, 7)
+    monkeypatch.setenv("PBN_KMI_WINDOW_MIN_ROWS", "0")
+    test = pbn.KMutualInformation(df, 4, seed=3, shuffle_neighbors=5, samples=40)
+    for x, y, z in (("a", "d", []), ("a", "c", ["b"]), ("d", "b", ["a", "c"])):
+        _, want = oracle.kmi(df[[x, y] + z].to_numpy(), 4, 3, 5, 40)
+        assert test.pvalue(x, y, z or None) == want
+    monkeypatch.delenv("PBN_KMI_WINDOW_MIN_ROWS")
+    # a table that takes the window form by default
+    df = table(40_000, 9)
+    window = values(df, 10)
+    monkeypatch.setenv("PBN_KMI_WINDOW_MIN_ROWS", "1000000000")
+    assert values(df, 10) == window
