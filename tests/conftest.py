@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "extra: round-1 surface outside SURVEY.md section 8 (BDe, user-defined network types, discrete-only models) - "
+                                       "runs only when asked for by name: -m extra (add PBN_EXTRA_GPU=1 on a GPU box for the halves that fit factors)")
     # torch first: it ships its own HIP runtime, and a process in which libpbn_hip.so (linked against /opt/rocm) has touched the
     # GPU before torch was imported ends up with torch.cuda.is_available() == False (measured on the GPU box, tools/torch_after.py).
     # bench.py imports torch first for the same reason; the library itself never needs torch.
@@ -32,3 +34,17 @@ def ensure_built():
     import __graft_entry__ as g
 
     g.build()
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `extra` never run in the driver's tiers (`-m "not gpu"`, `-m gpu`): they are deselected unless the marker expression
+    names them.  The GPU tier's time goes to the path."""
+    expr = config.getoption("-m") or ""
+    if "extra" in expr:
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("extra") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep

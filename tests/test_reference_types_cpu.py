@@ -9,6 +9,8 @@ import pickle
 import pyarrow as pa
 import pytest
 
+pytestmark = pytest.mark.extra
+
 import pybnesian_amd as pbn
 from pybnesian_amd import (CKDE, BayesianNetwork, BayesianNetworkType, ConditionalBayesianNetwork, DiscreteBN, DiscreteFactor, Factor,
                            FactorType, GaussianNetwork, KDENetwork, LinearGaussianCPD, SemiparametricBN)

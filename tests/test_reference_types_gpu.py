@@ -10,7 +10,7 @@ import pytest
 from test_reference_types_cpu import (ConditionalNewBN, ConditionalOtherBN, DynamicOtherBN, MyRestrictedGaussianNetworkType, NewBN,
                                       NonHomogeneousType, OtherBN, roundtrip)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.extra]
 ABCD = ["a", "b", "c", "d"]
 
 
