@@ -632,7 +632,9 @@ int split_tiles_for(int ntiles, bool f64) {
 // (tools/r5_probe_m.sh, profiles/r5/moment_pass.txt): 90 000 training rows 2.26 -> 2.99 s, 135 000 4.08 -> 5.28 s, 180 000 6.65 -> 8.07 s,
 // 270 000 12.79 -> 13.56 s; C3 (450 000) 9.04 -> 8.08 s.  Lane utilisation (tools/moment_visits.py): 40-44 of 64 at 57 600 rows with a third
 // of the pairs left to the sweep, 56-62 at 450 000 with 6 % left.
-int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 400000); }
+// (round 5: 400 000; round 6, after the pass got 11 % faster, tools/moment_rows_probe.sh: cv64-shaped searches with the pass forced / off at
+//  90 000 / 180 000 / 270 000 / 360 000 training rows: 2.45 / 2.10 s, 6.40 / 6.19 s, 11.18 / 12.02 s, 16.98 / 19.47 s - it pays from ~220 000)
+int moment_pass_rows() { return knob_int("PBN_MOMENT_MIN_ROWS", 250000); }
 // The training rows the moment-pass rule looks at.  A leave-one-region-out unit (a cross-validation fold: it trains on at least two
 // regions) answers with the size of its pool's SMALLEST training set, T - ceil(T / k) for T = training + test rows - the same number
 // for every fold of the pool, so whether a (term, fold) takes the pass does not depend on which folds of the pool share the call (fold

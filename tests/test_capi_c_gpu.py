@@ -84,7 +84,7 @@ def test_c_host_with_rccl_shards_the_delta_cache(tmp_path):
     vals = dict(line.split() for line in out.stdout.strip().splitlines() if len(line.split()) == 2)
     assert int(vals["rccl_ranks"]) == 1 and int(vals["bit_identical"]) == 1
     assert int(vals["collectives_first_batch"]) == 1            # ONE all-gather per batch
-    assert int(vals["collectives_total"]) == 3                  # moments + two batches
+    assert int(vals["collectives_total"]) == 2                  # moments + the first batch; the second batch finds every term installed and deals nothing: no collective
     assert int(vals["sweeps_sharded"]) == int(vals["sweeps_one"])   # one rank: dealt everything, nothing swept twice
     n = 3000
     u = _xorshift_stream(8 * n).reshape(n, 8)

@@ -2,7 +2,7 @@
 and two variables, where the pass takes the (tile, group) pairs whose order-8 expansion error is proved below the pruning bound and the sweep
 keeps the rest.  What the numbers are held against is the reference's arithmetic (kde/opencl_kernels/KDE.cl.src:115-121,227-233 through
 oracle/): the pass on, off, and the oracle must agree; the pass must really have taken pairs (debug counters), or the test proves nothing.
-The shipped rule switches the pass on from 400 000 training rows (PBN_MOMENT_MIN_ROWS); the small cases lower it to 0."""
+The shipped rule switches the pass on from 250 000 training rows (PBN_MOMENT_MIN_ROWS); the small cases lower it to 0."""
 import ctypes as C
 
 import numpy as np
