@@ -186,7 +186,7 @@ def cpu_arcs_baseline(which, log, cells, host, budget_s=8.0):
     try:
         m_all = int(min(n_rows, which.get("sample_rows_all", 50000)))
         est, used, wall = measure(m_all, cores, budget_s * 0.5)
-        out.update({"value": cells / est, "cores": cores, "cpu_seconds_extrapolated": est,
+        out.update({"value": cells / est, "cores": cores, "cpu_seconds_extrapolated": est, "extrapolated": True,
                     "sample": f"{used} of the run's {len(log.evals)} local-score evaluations on the first {m_all} of {n_rows} rows, {wall:.1f}s wall"})
         m_one = int(min(n_rows, which.get("sample_rows_one", 10000)))
         est1, used1, wall1 = measure(m_one, 1, budget_s * 0.5)
@@ -313,6 +313,9 @@ def bench_c1(pbn):
                                "same_structure": sorted(arcs) == sorted(mine),
                                "same_skeleton": sorted(tuple(sorted(a_)) for a_ in arcs) == sorted(tuple(sorted(a_)) for a_ in mine),
                                "sample": f"the whole search, fit and log-likelihood by the serial restatement: {calls[0]} oracle BIC calls on all 10000 rows"}
+        # 10 000 rows: milliseconds on either side - the device buys nothing at this size (a single CPU thread is within 1.5x of it)
+        out["device_over_cpu"] = dcpu / out["seconds"]
+        out["note"] = "C1 is the reference's own CPU-runnable case: at 10 000 rows the device is launch-bound and buys nothing over one CPU thread"
         out["tie_accounting"] = tie_accounting(pbn, hc, names, sc)
     except Exception as ex:
         out["cpu_baseline"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
@@ -831,7 +834,7 @@ def compact_line(out, full_name):
 
     def search_leg(v):
         o = _pick(v, "value", "unit", "estimate_s", "score_ctor_s", "cells_scored", "local_score_evals", "iterations", "arcs_found", "ranks", "nodes",
-                  "scaling", "mmpc_s", "ci_tests", "cpc_edges", "seconds", "cold_seconds", "near_tie_redos", "error")
+                  "scaling", "mmpc_s", "ci_tests", "cpc_edges", "seconds", "cold_seconds", "near_tie_redos", "device_over_cpu", "error")
         rf = v.get("roofline")
         if isinstance(rf, dict):
             o["roofline"] = _pick(rf, "achieved", "peak", "unit", "frac", "frac_of_measured_copy", "launch_us", "mfma_tflops", "mfma_frac_of_fp64_peak",
