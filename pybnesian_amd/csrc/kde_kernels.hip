@@ -1650,6 +1650,9 @@ __global__ __launch_bounds__(256) void kde_far_fix_kernel(PackArgs a, const hf8*
 #ifndef PBN_F16_FSUM
 #define PBN_F16_FSUM 1
 #endif
+#ifndef PBN_F16_PRUNE_SCHED
+#define PBN_F16_PRUNE_SCHED 1   // pruned blind form: the (tile, 4 groups) stream placed by sched_group_barrier (process_tile)
+#endif
 #ifndef PBN_F16_BLIND_CHUNK
 #define PBN_F16_BLIND_CHUNK 64
 #endif
@@ -1875,6 +1878,24 @@ __device__ __forceinline__ void kde_sweep_f16_body(const SweepArgs& a, const uns
                 else sum[g] += (double)ts;
                 if (COND) sumj[g] += (double)tsj;
             }
+#if PBN_F16_PRUNE_SCHED
+            // Round 6: the blind pruned form's stream placed - M0 M1 [E0] M2 [E1] M3 [E2] [E3], E = the four exponentials and four additions of a
+            // group: no exponential reads an accumulator younger than one group's work, the MFMAs issue between the VALU blocks instead of four
+            // in a row followed by the hazard's s_nops
+            if constexpr (BLIND && !COND && NB == 1 && QG == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+#endif
         } else {
             V acc[QG], accj[QG];
             float ts[QG], tsj[QG];

@@ -17,6 +17,8 @@
 #include <memory>
 #include <numeric>
 #include <random>
+#include <thread>
+#include <exception>
 
 #include "common.hpp"
 
@@ -489,7 +491,26 @@ struct Kmi {
         std::vector<size_t> order((size_t)N), sorted_indices((size_t)N);
         std::iota(order.begin(), order.end(), 0);
         std::vector<bool> used((size_t)N);
+        // Round 6: the RNG-bound part of a sample (the three loops below, serial in the mt19937 stream and kept call for call) and the rest of
+        // it (std::sort of the permuted values into ranks, upload, the device evaluation, the digamma sum) run as a two-stage pipeline: this
+        // thread draws sample s + 1 while a worker finishes sample s.  Same values, same comparisons - only `count_greater` is taken in the worker.
+        std::vector<float> stage[2] = {std::vector<float>((size_t)N), std::vector<float>((size_t)N)};
+        std::thread worker;
+        std::exception_ptr failed;
+        auto finish = [&](int b) {
+            try {
+                HIP_CHECK(hipSetDevice(ctx->device));
+                std::vector<float>& v = stage[b];
+                std::iota(sorted_indices.begin(), sorted_indices.end(), 0);
+                std::sort(sorted_indices.begin(), sorted_indices.end(), IndexLess{v.data()});
+                for (size_t i = 0; i < sorted_indices.size(); ++i) v[sorted_indices[i]] = (float)i;
+                HIP_CHECK(hipMemcpyAsync(h->d_x.p, v.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                if (evaluate(vars, h->d_x.p, v.data()) >= original) ++count_greater;
+            } catch (...) { failed = std::current_exception(); }
+        };
+        const bool pipelined = N >= 65536 && knob_int("PBN_KMI_PIPELINE", 1) != 0;
         for (int s = 0; s < h->samples; ++s) {
+            std::vector<float>& shuffled = stage[s & 1];   // (the worker reads the other one)
             std::shuffle(order.begin(), order.end(), rng);
             // shuffle_dataframe (mutual_information.hpp:128-167)
             for (int64_t i = 0; i < N; ++i) std::shuffle(neighbors.begin() + i * m, neighbors.begin() + (i + 1) * m, rng);
@@ -508,13 +529,14 @@ struct Kmi {
                     used[(size_t)neighbor_index] = true;
                 }
             }
-            std::iota(sorted_indices.begin(), sorted_indices.end(), 0);
-            std::sort(sorted_indices.begin(), sorted_indices.end(), IndexLess{shuffled.data()});
-            for (size_t i = 0; i < sorted_indices.size(); ++i) shuffled[sorted_indices[i]] = (float)i;
-            HIP_CHECK(hipMemcpyAsync(h->d_x.p, shuffled.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-            if (evaluate(vars, h->d_x.p, shuffled.data()) >= original) ++count_greater;
             std::fill(used.begin(), used.end(), false);
+            if (worker.joinable()) worker.join();
+            if (failed) std::rethrow_exception(failed);
+            if (pipelined) worker = std::thread(finish, s & 1);
+            else finish(s & 1);
         }
+        if (worker.joinable()) worker.join();
+        if (failed) std::rethrow_exception(failed);
         return (double)count_greater / h->samples;
     }
 };

@@ -13,7 +13,7 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pybnesian_amd as pbn  # noqa: E402
 
-for n, samples in ((100_000, 100), (1_000_000, 3)):
+for n, samples in ((100_000, 100), (1_000_000, 12)):
     rng = np.random.default_rng(0)
     a = rng.normal(size=n)
     df = pd.DataFrame({"a": a, "b": 0.5 * a + rng.normal(size=n), "c": 0.3 * a + rng.normal(size=n)})
