@@ -322,6 +322,10 @@ typedef struct {
     int (*terms_put)(void* user, int kind, int n_terms, const int* off, const int* vars, const int* m, const double* values);
     int (*batch_parts)(void* user, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents,
                        int part, int n_parts, double* out);
+    /* Optional (NULL: pbn_shard_term_cost on the engine's shape): the engine's own price of one region of a term of `dims` columns - only
+     * ratios matter.  pbn_score_batch's engine prices what ITS kernels cost (profiles/r6/term_prices.txt: on fp64 tables whose folds take the
+     * tile-moment pass a one-variable term is 2.4x cheaper than the list says).  Must be a pure function of replicated state. */
+    double (*term_price)(void* user, int kind, int dims);
 } pbn_shard_engine;
 int pbn_shard_batch(const pbn_shard_engine* engine, const pbn_comm* comm, int kind, int n_cand, const int* var, const int* node_type,
                     const int* par_off, const int* parents, int shard_all, double* out);

@@ -147,6 +147,7 @@ class ShardEngine(C.Structure):   # pbn_shard_engine
         ("term_regions", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _dp)),
         ("terms_put", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _dp)),
         ("batch_parts", C.CFUNCTYPE(_int, _vp, _int, _int, _ip, _ip, _ip, _ip, _int, _int, _dp)),
+        ("term_price", C.CFUNCTYPE(C.c_double, _vp, _int, _int)),
     ]
 
 

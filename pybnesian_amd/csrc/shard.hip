@@ -135,6 +135,7 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
     if (eng->shape) must(eng->shape(eng->user, kind, &regions, &ntr, &nte), "engine shape");
     if (regions < 1) regions = 1;
     if (ntr < 1 || nte < 1) { ntr = 1000000; nte = 100000; }   // an engine that does not say: the shape the per-pair weights were measured on
+    auto price = [&](int dims) { return eng->term_price ? eng->term_price(eng->user, kind, dims) : term_cost(dims, ntr, nte); };
 
     // ---- the plan ------------------------------------------------------------------------------------------------------------------
     std::vector<char> heavy((size_t)n, 0), taken((size_t)n, 0);   // taken: evaluated through the collective (terms assembled later count as light)
@@ -177,10 +178,10 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
         std::vector<int> owner;
         if (by_fold) {
             for (int j = 0; j < (int)todo.size(); ++j)
-                for (int f = 0; f < regions; ++f) { items.emplace_back(j, f); cost.push_back(term_cost((int)todo[j].size() - 1, ntr, nte)); }
+                for (int f = 0; f < regions; ++f) { items.emplace_back(j, f); cost.push_back(price((int)todo[j].size() - 1)); }
             deal(cost, nullptr, world, nullptr, owner);
         } else if (!todo.empty()) {
-            for (const auto& t : todo) { cost.push_back(regions * term_cost((int)t.size() - 1, ntr, nte)); tie.push_back(mix(t.data() + 1, (int)t.size() - 1)); }
+            for (const auto& t : todo) { cost.push_back(regions * price((int)t.size() - 1)); tie.push_back(mix(t.data() + 1, (int)t.size() - 1)); }
             deal(cost, tie.data(), world, nullptr, owner);
         }
         for (size_t i = 0; i < owner.size(); ++i) term_lists[(size_t)owner[i]].push_back((int)i);
@@ -217,7 +218,7 @@ void run(const pbn_shard_engine* eng, const pbn_comm* comm, int kind, int n, con
         std::vector<uint32_t> tie;
         for (size_t s = 0; s < sets.size(); ++s) {   // one joint sweep per set + one marginal sweep per candidate
             const int d = (int)sets[s].size();
-            cost.push_back(regions * (term_cost(d, ntr, nte) + count[s] * term_cost(d - 1, ntr, nte)));
+            cost.push_back(regions * (price(d) + count[s] * price(d - 1)));
             tie.push_back(mix(sets[s].data(), d));
         }
         std::vector<int> owner;
@@ -347,6 +348,18 @@ int b_shape(void* u, int kind, int* regions, int64_t* ntr, int64_t* nte) {
     }
     return PBN_OK;
 }
+// the price list corrected by what THIS engine's kernels cost (tools/term_prices.py, profiles/r6/term_prices.txt: 500 000-row fp64 table,
+// 10 folds - terms of 1 / 2 / 3 / 4 variables 6.0 / 13.0 / 14.1 / 27.7 ms against the list's 1 : 0.81 : 1.00 : 1.63): a one-variable
+// term whose folds take the tile-moment pass costs 0.42 of its list price; the fp32 ratios sit within 25 % of the list
+double b_price(void* u, int kind, int dims) {
+    const pbn_scoredata* sd = ((Bound*)u)->sd;
+    int regions = 1;
+    int64_t ntr = 0, nte = 0;
+    b_shape(u, kind, &regions, &ntr, &nte);
+    double c = term_cost(dims, ntr, nte);
+    if (sd->dtype == PBN_F64 && dims == 1 && ntr >= (int64_t)knob_int("PBN_MOMENT_MIN_ROWS", 250000) && knob_int("PBN_MOMENT_PASS", 1) != 0) c *= 0.42;
+    return c;
+}
 int b_batch(void* u, int kind, int n, const int* var, const int* nt, const int* off, const int* par, double* out) {
     Bound* b = (Bound*)u;
     return pbn::score::score_batch_local(b->sd, kind, n, var, nt, off, par, b->params, b->n_params, out);
@@ -368,7 +381,7 @@ namespace score {
 void score_batch_sharded(pbn_scoredata* sd, int kind, int n_cand, const int* var, const int* node_type, const int* par_off, const int* parents,
                          const double* params, int n_params, double* out) {
     shard::Bound b{sd, params, n_params};
-    pbn_shard_engine eng{&b, sd->n, shard::b_shape, shard::b_batch, shard::b_missing, shard::b_terms, shard::b_regions, shard::b_put, shard::b_parts};
+    pbn_shard_engine eng{&b, sd->n, shard::b_shape, shard::b_batch, shard::b_missing, shard::b_terms, shard::b_regions, shard::b_put, shard::b_parts, shard::b_price};
     shard::run(&eng, &sd->comm, kind, n_cand, var, node_type, par_off, parents, false, out);
 }
 }  // namespace score

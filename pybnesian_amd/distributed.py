@@ -221,7 +221,7 @@ class _PyEngine:
                          terms_put=f["terms_put"](guard(put)) if has_terms else f["terms_put"](),
                          batch_parts=f["batch_parts"](guard(parts)) if has_parts else f["batch_parts"]())
         self.struct = E(None, int(n_cont) if n_cont is not None else 0, *[self._cbs[k] for k in ("shape", "batch", "terms_missing", "terms", "term_regions",
-                                                                                                   "terms_put", "batch_parts")])
+                                                                                                   "terms_put", "batch_parts")], f["term_price"]())
 
 
 def sharded_batch(score, model, var, ntype, off, par, kind, shard_all=False):
