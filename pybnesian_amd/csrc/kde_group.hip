@@ -837,6 +837,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         hipEvent_t le0 = nullptr, le1 = nullptr;
         if (log_chunks) { HIP_CHECK(hipEventCreate(&le0)); HIP_CHECK(hipEventCreate(&le1)); HIP_CHECK(hipEventRecord(le0, st)); }
         sa.moments = moments ? 1 : 0;
+        sa.w32 = (f16 && f16x2_w32p(d0, KS)) ? 1 : 0;
         launch_sweep_grouped(sa, fdt, KS, st);
         if (moments) { KernelTimer km(ctx, PBN_K_MOMENT); launch_moment_grouped(sa, d0, st); }
         if (log_chunks) {

@@ -112,6 +112,7 @@ struct GSweepArgs {
     const int32_t* wg_unit;   // [total flat workgroups / 64] -> unit
     int64_t total_wg;
     int fold, wmul, count_redo, group_masks;
+    int w32;               // fp32 units: paired kept tiles on 32x32x16 MFMAs (kde_sweep_f16_w32p_group_kernel; f16x2_w32p of the chunk's dimension)
     int moments;           // the units carry tile-moment records and the moment pass runs before the sweep (kde_sweep_group_kernel<..., MOM = true>)
     double prune_margin;   // > 0: one margin for every unit of the launch; 0: the units' own
     double far_span;       // SweepArgs::far_span of every unit of the launch

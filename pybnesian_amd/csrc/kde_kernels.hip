@@ -2330,6 +2330,274 @@ __global__ __launch_bounds__(256, PBN_F16_W32_WAVES) void kde_sweep_f16_w32_kern
 }
 
 // ------------------------------------------------------------------------------------------------
+// W32 form of the PRUNED plain fp32 sweeps (round 6; stand-alone handles and the grouped launches of the score engine: C5).  The kept tiles of
+// a split - whatever batch they come from - are taken two at a time as the A operand of v_mfma_f32_32x32x16_f16 (any two 16-row tiles make a
+// 32-row operand: lanes with (lane % 32) < 16 read the first), the wave's four 16-query groups are its two 32-query super-groups: per 2 048
+// pair values 4 MFMAs instead of 8 (4 issue cycles per 256 values instead of 8), the stream software-pipelined by one super-group and placed as
+// in kde_sweep_f16_w32_kernel.  The whole split is ONE blind region (fp32 tile sums: at most a few hundred pair sums per split, <= 3e-5
+// relative, against the fp32 bar of 1e-3; offsets from the prepass bounds: an overflow is rare) - a wave whose sums came out bad walks its kept
+// tiles again through the checked form.  An odd kept tile goes through the checked form too.  Visit masks: one per wave and 64-tile batch, as
+// in kde_sweep_f16_body.
+// ------------------------------------------------------------------------------------------------
+#ifndef PBN_F16_W32P
+#define PBN_F16_W32P 1
+#endif
+template <int NB>
+__device__ __forceinline__ void kde_sweep_f16_w32p_body(const SweepArgs& a, const unsigned bid) {
+    constexpr int NJ = 2 * NB, S = 2, QG = PBN_F16_QG_PRUNE;
+    static_assert(QG == 2 * S, "the wave's query groups are its two 32-query super-groups");
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, col = lane & 31, sub = col >> 4, idx = col & 15;
+    int qx, split;
+    pruned_block(a, QG, bid, qx, split);
+    const int64_t qt0 = (int64_t)qx * QG;
+    if (qt0 >= a.nqtiles) return;
+    const int64_t t0 = (int64_t)split * a.tiles_per_split;
+    const int64_t t1 = (t0 + a.tiles_per_split < a.ntiles) ? t0 + a.tiles_per_split : a.ntiles;
+    const PBN_GLOBAL hf8* __restrict__ Ap = (const PBN_GLOBAL hf8*)a.Apack;
+    const PBN_GLOBAL hf8* __restrict__ Bp = (const PBN_GLOBAL hf8*)a.Bpack;
+    const PBN_GLOBAL float* __restrict__ NYp = (const PBN_GLOBAL float*)a.nypack;
+    const PBN_GLOBAL double* __restrict__ TBp = (const PBN_GLOBAL double*)a.tile_box;
+    const PBN_GLOBAL double* __restrict__ QBp = (const PBN_GLOBAL double*)a.qtile_box;
+    const PBN_GLOBAL double* __restrict__ QTp = (const PBN_GLOBAL double*)a.qtile_thr;
+    const PBN_GLOBAL double* __restrict__ QLp = (const PBN_GLOBAL double*)a.qlb;
+    const int loff = half * 16 + idx;
+
+    hf8 b[S][NJ];
+    float ny[S], m[S];
+    double sum[S];
+    bool lbm[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int64_t qt = qt0 + 2 * s + sub;
+        qt = qt < a.nqtiles ? qt : a.nqtiles - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[s][j] = Bp[(qt * NB + (j >> 1)) * 64 + (j & 1) * 32 + loff];
+        ny[s] = NYp[qt * 16 + idx];
+        m[s] = 0.f;
+        sum[s] = 0.0;
+        lbm[s] = false;
+    }
+    // the wave's query box and threshold (as kde_sweep_f16_body)
+    double wlo[PBN_PRUNE_PD], whi[PBN_PRUNE_PD], wthr = INFINITY;
+    const int pd = a.pdims;
+#pragma unroll
+    for (int k = 0; k < PBN_PRUNE_PD; ++k) { wlo[k] = INFINITY; whi[k] = -INFINITY; }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
+        const double th = QTp[qt];
+        wthr = th < wthr ? th : wthr;
+#pragma unroll
+        for (int k = 0; k < PBN_PRUNE_PD; ++k)
+            if (k < pd) {
+                const double l = QBp[qt * 2 * pd + k], h = QBp[qt * 2 * pd + pd + k];
+                wlo[k] = l < wlo[k] ? l : wlo[k];
+                whi[k] = h > whi[k] ? h : whi[k];
+            }
+    }
+    wthr -= a.prune_margin;
+
+    auto set_off = [&](int s) {   // slots 32 NB - 3 ... of the query side <- split3s(-1/2|z_q|^2 - m_q)
+        hpiece q1, q2, q3;
+        split3s(ny[s] - m[s], q1, q2, q3);
+        if (half == 1) { b[s][NJ - 1][5] = q1; b[s][NJ - 1][6] = q2; b[s][NJ - 1][7] = q3; }
+    };
+    auto load_pair = [&](int64_t ta, int64_t tb, hf8 (&f)[NJ]) {
+        const int64_t t = sub ? tb : ta;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f[j] = Ap[(t * NB + (j >> 1)) * 64 + (j & 1) * 32 + loff];
+    };
+    auto chain = [&](const hf8 (&f)[NJ], int s) {
+        f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[j], b[s][j], c, 0, 0, 0);
+        return c;
+    };
+    auto colmax32 = [&](const f16v& v, int nr) {
+        float mx = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            if (r < nr) mx = v[r] > mx ? v[r] : mx;
+        const float o = __shfl_xor(mx, 32);
+        return mx > o ? mx : o;
+    };
+    // ---- offsets: the first tile pair of the split, then the prepass bounds where they lie above (see kde_sweep_f16_body) ----
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) set_off(s);   // m = 0
+        hf8 f[NJ];
+        load_pair(t0, t0 + 1 < t1 ? t0 + 1 : t0, f);
+#pragma unroll
+        for (int s = 0; s < S; ++s) m[s] = colmax32(chain(f, s), 16);
+        if (a.qlb) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                int64_t qt = qt0 + 2 * s + sub;
+                qt = qt < a.nqtiles ? qt : a.nqtiles - 1;
+                const float lb = (float)QLp[qt * 16 + idx];
+                const bool fin = __builtin_fabsf(lb) < 0x1p22f;   // (a bound fp32 cannot hold to a fraction of a unit is not used)
+                lbm[s] = fin && lb > m[s];
+                if (lbm[s]) m[s] = lb;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) set_off(s);
+    }
+    if (a.count_redo && lane == 0) atomicAdd(&g_sweep_tiles, (unsigned long long)(t1 - t0));
+
+    // ---- the kept tiles of the split, in order: one visit mask per 64-tile batch (uniform control flow: every lane tests its own tile) ----
+    int64_t wtb = t0 - 64;
+    unsigned long long wmask = 0;
+    auto rewind = [&]() { wtb = t0 - 64; wmask = 0; };
+    auto next_tile = [&]() -> int64_t {
+        while (!wmask) {
+            wtb += 64;
+            if (wtb >= t1) return -1;
+            wmask = prune_visit_mask(TBp, pd, wtb, t1, wlo, whi, wthr, lane);
+            if (a.count_redo && lane == 0 && wmask) atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcountll(wmask));
+        }
+        const int bit = __builtin_ctzll(wmask);
+        wmask &= wmask - 1;
+        return wtb + bit;
+    };
+
+    // ---- checked form: ONE tile (rows 0-15 of the pair's accumulator), super-group by super-group ----
+    auto checked_single = [&](int64_t t) {
+        hf8 f[NJ];
+        load_pair(t, t, f);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f16v acc = chain(f, s);
+            auto tile_sum = [&]() {
+                float ts = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) ts += Tr<float>::ex2(acc[r]);
+                return ts;
+            };
+            float ts = tile_sum();
+            if (__builtin_expect(__any(!(ts < Tr<float>::big())), 0)) {
+                const float mx = colmax32(acc, 8);
+                if (mx > 0.f) {
+                    m[s] += mx;
+                    set_off(s);
+                    sum[s] *= exp2(-(double)mx);
+                    acc -= mx;
+                }
+                ts = tile_sum();
+            }
+            sum[s] += (double)ts;
+        }
+    };
+
+    // ---- blind walk: pairs of kept tiles, software-pipelined by one super-group ----
+    float fs[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) fs[s] = 0.f;
+    auto expsum = [&](const f16v& v) {
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float e0 = Tr<float>::ex2(v[4 * k]), e1 = Tr<float>::ex2(v[4 * k + 1]), e2 = Tr<float>::ex2(v[4 * k + 2]), e3 = Tr<float>::ex2(v[4 * k + 3]);
+            q[k] = (e0 + e1) + (e2 + e3);
+        }
+        return ((q[0] + q[1]) + q[2]) + q[3];
+    };
+    auto place = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 16 / NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 16 / NJ, 0);
+        }
+    };
+    int64_t single = -1;
+    {
+        hf8 fA[NJ], fB[NJ];
+        f16v acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = -1000.f;
+        int64_t pa = next_tile(), pb = pa >= 0 ? next_tile() : -1;
+        bool have = pb >= 0;
+        if (!have) single = pa;
+        if (have) load_pair(pa, pb, fA);
+        while (have) {
+            // the next pair (unconditional prefetch: a conditional load costs a vmcnt(0) per pair - see kde_sweep_f16_body)
+            int64_t na = next_tile(), nb = na >= 0 ? next_tile() : -1;
+            const bool more = nb >= 0;
+            if (!more) single = na;
+            load_pair(more ? na : pa, more ? nb : pb, fB);
+            acc0 = chain(fA, 0);
+            fs[1] += expsum(acc1);
+            place();
+            acc1 = chain(fA, 1);
+            fs[0] += expsum(acc0);
+            place();
+            if (!more) break;
+            pa = next_tile();
+            pb = pa >= 0 ? next_tile() : -1;
+            have = pb >= 0;
+            if (!have) single = pa;
+            load_pair(have ? pa : na, have ? pb : nb, fA);
+            acc0 = chain(fB, 0);
+            fs[1] += expsum(acc1);
+            place();
+            acc1 = chain(fB, 1);
+            fs[0] += expsum(acc0);
+            place();
+        }
+        fs[1] += expsum(acc1);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) bad = bad || !(fs[s] < Tr<float>::big());
+    if (__builtin_expect(__any(bad), 0)) {   // the split again, tile by tile, checked (the odd tile included)
+        rewind();
+#pragma unroll 1
+        for (int64_t t = next_tile(); t >= 0; t = next_tile()) checked_single(t);
+    } else {
+#pragma unroll
+        for (int s = 0; s < S; ++s) sum[s] += (double)fs[s];
+        if (single >= 0) checked_single(single);
+    }
+
+    PBN_GLOBAL double* part = (PBN_GLOBAL double*)a.part;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        double v = sum[s];
+        v += __shfl_xor(v, 32);
+        if (v == 0.0 && (m[s] - m[s]) == 0.f && !lbm[s]) v = 1.0;   // (see kde_sweep_f16_body: not when the offset is a prepass bound)
+        const int64_t qt = qt0 + 2 * s + sub;
+        if (half == 0 && qt < a.nqtiles) {
+            PBN_GLOBAL double* o = part + ((int64_t)split * a.nqtiles * 16 + qt * 16 + idx) * 2;
+            o[0] = (double)m[s];
+            o[1] = v;
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(sweep_block_threads(true), PBN_F16_PRUNE_WAVES) void kde_sweep_f16_w32p_kernel(SweepArgs a) {
+    kde_sweep_f16_w32p_body<NB>(a, blockIdx.x);
+}
+template <int NB>
+__global__ __launch_bounds__(sweep_block_threads(true), PBN_F16_PRUNE_WAVES) void kde_sweep_f16_w32p_group_kernel(GSweepArgs g) {
+    const int u = g.wg_unit[blockIdx.x >> 6];
+    const GSweepUnit& su = g.units[u];
+    const unsigned bid = (unsigned)((int64_t)blockIdx.x - su.wg0);
+    if (bid >= (unsigned)su.nwg) return;
+    SweepArgs a;
+    a.Apack = su.Apack; a.nxpack = su.nxpack; a.Axpack = nullptr;
+    a.Bpack = su.Bpack; a.nypack = su.nypack; a.Bxpack = nullptr; a.Bxnorm = nullptr;
+    a.ntiles = su.ntiles; a.nqtiles = su.nqtiles; a.tiles_per_split = su.tps;
+    a.fold = 0; a.count_redo = g.count_redo; a.wmul = 0;
+    a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
+    a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
+    a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = 0;
+    kde_sweep_f16_w32p_body<NB>(a, bid);
+}
+
+// ------------------------------------------------------------------------------------------------
 // kde_cdf: CKDE::cdf.  The reference (CKDE.hpp:560-735 + KDE.cl.src:376-468) materialises, per tile of 64 test rows,
 // the N x 64 weight matrix W (marginal KDE terms), the N x 64 conditional means, their normal cdf, the element-wise
 // product and two column sums.  Here: the weights are the marginal sweep's 2^(s2 - m) (same MFMA + offset machinery),
@@ -2833,6 +3101,11 @@ bool f16x2_w32(int dm, int NB) {
     return knob_int("PBN_F32_W32", 1) != 0 && (NB == 1 || NB == 2) && f16x2_spd(dm) * dm + 6 <= 32 * NB;   // read per call: tests compare the two forms in one process
 }
 
+// ... and of the pruned plain fp32 sweeps (stand-alone handles, grouped launches): one 32-slot block whose last three slots are free
+bool f16x2_w32p(int dm, int NB) {
+    return PBN_F16_W32P != 0 && knob_int("PBN_F32_W32", 1) != 0 && NB == 1 && f16x2_spd(dm) * dm + 6 <= 32;
+}
+
 void launch_pack(const PackArgs& a, int dtype, hipStream_t st) {
     const int64_t npad = a.ntiles * 16;
     if (npad == 0) return;
@@ -3009,6 +3282,14 @@ static void launch_sweep_f16(const SweepArgs& a, int NB, dim3 grid, hipStream_t 
         block = dim3(sweep_block_threads(true));
         constexpr int QGP = PBN_F16_QG_PRUNE;
         grid = dim3((unsigned)(ceil_div(a.nqtiles, QGP) * a.nsplit_grid));   // one wave (QGP query groups) per workgroup, placed by pruned_block
+        if constexpr (!COND) {
+            if (a.w32 && NB == 1) {   // paired kept tiles on 32x32x16 MFMAs (kde_sweep_f16_w32p_body)
+                ++g_w32_launches;
+                hipLaunchKernelGGL((kde_sweep_f16_w32p_kernel<1>), grid, block, 0, st, a);
+                HIP_CHECK(hipGetLastError());
+                return;
+            }
+        }
         if (NB == 1) hipLaunchKernelGGL((kde_sweep_f16_kernel<1, COND, QGP, true>), grid, block, 0, st, a);
         else if (NB == 2) hipLaunchKernelGGL((kde_sweep_f16_kernel<2, COND, QGP, true>), grid, block, 0, st, a);
         else throw invalid_error("KDE: pruned fp32 sweeps cover at most 10 whitened dimensions");
@@ -3067,7 +3348,8 @@ void launch_sweep_grouped(const GSweepArgs& g, int dtype, int KS, hipStream_t st
     if (g.total_wg > 0x7fffffffll) throw invalid_error("grouped sweeps: grid too large");
     const dim3 grid((unsigned)g.total_wg), block(sweep_block_threads(true));
     if (use_f16x2(dtype)) {   // KS carries the number of 32-slot f16 MFMAs
-        if (KS == 1) hipLaunchKernelGGL((kde_sweep_f16_group_kernel<1>), grid, block, 0, st, g);
+        if (KS == 1 && g.w32) { ++g_w32_launches; hipLaunchKernelGGL((kde_sweep_f16_w32p_group_kernel<1>), grid, block, 0, st, g); }
+        else if (KS == 1) hipLaunchKernelGGL((kde_sweep_f16_group_kernel<1>), grid, block, 0, st, g);
         else if (KS == 2) hipLaunchKernelGGL((kde_sweep_f16_group_kernel<2>), grid, block, 0, st, g);
         else throw invalid_error("grouped fp32 sweeps: at most 10 whitened dimensions");
         HIP_CHECK(hipGetLastError());

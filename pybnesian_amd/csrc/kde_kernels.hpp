@@ -275,6 +275,7 @@ void sort_keys(pbn::dev_buf<char>& tmp, const uint32_t* keys_in, uint32_t* keys_
 double prune_margin(int dtype, int64_t n_train, bool sum_only = false);
 bool use_f16x2(int dtype);   // fp32 tables: f16x2 split on the 16-bit matrix cores (default on)
 int f16x2_mfmas(int dm);   // number of v_mfma_f32_16x16x32_f16 per (tile, group) for dm whitened dimensions
+bool f16x2_w32p(int dm, int NB);  // the same for the pruned plain fp32 sweeps (kde_sweep_f16_w32p_body)
 bool f16x2_w32(int dm, int NB);   // the training fragments carry the constants in the last three slots and kde_sweep_f16_w32_kernel applies
 
 // ---- more than 32 whitened dimensions (the reference's kernels loop over any d: kde/KDE.hpp:592-640): a generic, runtime-sized form of

@@ -483,7 +483,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.ntiles = m.ntiles; sa.nqtiles = nqtiles; sa.tiles_per_split = tps;
     sa.fold = fold ? 1 : 0;
     sa.wmul = wmul ? 1 : 0;
-    sa.w32 = (b3 && !m.cond && !m.prune && f16x2_w32(m.dm, m.KS)) ? 1 : 0;
+    sa.w32 = (b3 && !m.cond && (m.prune ? f16x2_w32p(m.dm, m.KS) : f16x2_w32(m.dm, m.KS))) ? 1 : 0;
     sa.far_span = (sum_only && m.prune) ? (double)knob_int("PBN_FAR_SPAN", 17) : 0.0;   // sum-only pruned sweeps: fp32 tail for tiles 26+ bits below the sum bound
     sa.fast = sum_only ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);

@@ -96,7 +96,9 @@ def test_grouped_kernels_keep_their_register_budgets(kde_asm):
         assert vgpr <= 128, (n, vgpr)                     # four waves per SIMD
         assert scratch <= 160, (n, scratch)               # (0-92 bytes today: the unit's argument block, no loop-carried spill)
     c5 = found["_ZN3pbn26kde_sweep_f16_group_kernelILi1EEEvNS_10GSweepArgsE"]
-    assert c5[0] == 0 and c5[1] <= 128, c5                # C5's kernel: four waves per SIMD, nothing in scratch
+    assert c5[0] == 0 and c5[1] <= 128, c5                # C5's kernel (16x16 form): four waves per SIMD, nothing in scratch
+    c5w = found["_ZN3pbn31kde_sweep_f16_w32p_group_kernelILi1EEEvNS_10GSweepArgsE"]
+    assert c5w[0] == 0 and c5w[1] <= 128, c5w             # ... and its paired-tile 32x32x16 form (round 6): the same budget
 
 
 def test_w32_sweep_stream_is_placed(kde_asm):

@@ -135,3 +135,64 @@ def test_queries_beyond_the_f16_range_are_evaluated_in_fp64(pbn, cls):
     assert np.allclose(got[far], want[far], rtol=1e-6 if cls != "CKDE" else 1e-5)
     rest = [i for i in range(100) if i not in far]
     assert np.allclose(got[rest], want[rest], rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 6])
+def test_pruned_w32_form_matches_the_oracle_and_the_16x16_form(pbn, oracle, d):
+    """Pruned fp32 handles (>= 32 768 training rows, <= 6 dimensions) and the grouped launches of the score engine take their kept tiles two at a
+    time on 32x32x16 MFMAs (kde_sweep_f16_w32p_body); PBN_F32_W32=0 brings the 16x16 form back.  Clustered data with far queries: odd numbers of
+    kept tiles per split, splits that are pruned whole, offsets from the prepass bounds."""
+    import ctypes as C
+
+    from pybnesian_amd import _lib
+
+    rng = np.random.default_rng(40 + d)
+    n, m = 50_021, 1501
+    centres = rng.uniform(-20.0, 20.0, size=(3, d))
+    mix = np.tril(rng.uniform(-0.4, 0.4, size=(d, d)), -1) + np.eye(d)
+
+    def draw(k):
+        return centres[rng.integers(0, 3, size=k)] + rng.normal(size=(k, d)) @ mix.T
+
+    names = [f"v{i}" for i in range(d)]
+    train = pd.DataFrame(draw(n), columns=names).astype("float32")
+    q = draw(m)
+    q[:7] += 300.0
+    test = pd.DataFrame(q, columns=names).astype("float32")
+    for cls, fn in ((pbn.KDE, oracle.kde_logl), (pbn.ProductKDE, oracle.product_kde_logl)):
+        k = cls(names)
+        k.fit(train)
+        want = fn(train.to_numpy().astype(np.float64), k.bandwidth, test.to_numpy().astype(np.float64))
+        c = C.c_ulonglong(0)
+        _lib.load().pbn_debug_w32_launches(C.byref(c), 1)
+        w32, w16 = _both(lambda: (k.logl(test), k.slogl(test)))
+        _lib.load().pbn_debug_w32_launches(C.byref(c), 0)
+        assert c.value >= 2, "the pruned W32 form ran (logl and slogl of the first pass)"
+        assert np.all(np.isfinite(w32[0]))
+        assert np.allclose(w32[0], want, atol=5e-4, rtol=1e-4)
+        assert np.allclose(w32[0], w16[0], atol=2e-4, rtol=2e-5)
+        assert abs(w32[1] - want.sum()) <= 1e-4 * abs(want.sum())
+
+
+def test_grouped_fp32_terms_on_paired_tiles(pbn, oracle, monkeypatch):
+    """The score engine's grouped fp32 launches (C5's path in miniature): CV-likelihood local scores of a float table through the paired-tile
+    kernel against the 16x16 form and the oracle."""
+    monkeypatch.setenv("PBN_PRUNE_MIN_ROWS", "256")
+    rng = np.random.default_rng(9)
+    n = 6000
+    a = rng.normal(size=n)
+    b = np.tanh(a) + 0.4 * rng.normal(size=n)
+    c = 0.5 * a - 0.3 * b + 0.5 * rng.normal(size=n)
+    df = pd.DataFrame({"a": a, "b": b, "c": c}).astype("float32")
+    model = pbn.SemiparametricBN(list(df.columns))
+
+    def scores():
+        s = pbn.CVLikelihood(df, 4, 1)
+        return [s.local_score_node_type(model, pbn.CKDEType(), v, ps) for v, ps in (("a", []), ("b", ["a"]), ("c", ["a", "b"]))]
+
+    w32, w16 = _both(scores)
+    data = df.to_numpy().astype(np.float64)
+    wants = [oracle.cv_likelihood(data[:, cols], "ckde", 4, 1) for cols in ([0], [1, 0], [2, 0, 1])]
+    for got32, got16, want in zip(w32, w16, wants):
+        assert abs(got32 - want) <= 1e-4 * abs(want)
+        assert abs(got32 - got16) <= 2e-5 * abs(want)
