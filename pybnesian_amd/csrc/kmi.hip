@@ -517,6 +517,11 @@ struct Kmi {
             std::uniform_real_distribution<float> tiebreaker(-0.5, 0.5);
             for (int64_t i = 0; i < N; ++i) {
                 const size_t index = order[(size_t)i];
+                if (i + 24 < N) {   // the rows are visited in shuffled order: fetch the lines of a later row now (no effect on what is computed)
+                    const size_t ahead = order[(size_t)i + 24];
+                    __builtin_prefetch(&neighbors[ahead * m]);
+                    __builtin_prefetch(&shuffled[ahead], 1);
+                }
                 int neighbor_index = 0;
                 for (int j = 0; j < m; ++j) {
                     neighbor_index = neighbors[index * m + j];
