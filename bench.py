@@ -20,6 +20,7 @@ reference algorithm on the host cores, bounded sample; rank 0, N=1 only).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -601,7 +602,8 @@ def pmc_record(kernel_substr, fname="pmc_per_dispatch.json", src_name="kde_kerne
     except OSError as ex:
         return None, f"kernel source not readable: {ex}"
     reason = f"no profiles/r*/{fname}"
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    rounds = sorted((r for r in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+", r)), key=lambda r: -int(r[1:]))
+    for rnd in rounds:
         path = os.path.join(ROOT, "profiles", rnd, fname)
         try:
             with open(path) as f:
