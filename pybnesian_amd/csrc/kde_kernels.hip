@@ -164,6 +164,52 @@ __device__ __forceinline__ double exp2_f64_fract(double x, double top) {
     return __builtin_ldexp(p, n);
 }
 
+// MAGIC (round 6): the 2^x of sum-only fp64 sweeps without a single DP instruction of range reduction.  The per-query constant that
+// starts the MFMA accumulator carries PBN_MAGIC_C = 1.5 * 2^20 - 1 + 2^-24 on top of the biased exponent, so the MFMA chain itself leaves
+// y = 1.5 * 2^20 + (x - 1 + 2^-24): a double of FIXED exponent whose mantissa is x in fixed point - the low word is the fraction (32
+// bits), the high word is 0x41380000 + floor(x - 1 + 2^-24).  Then
+//   u  = v_alignbit_b32(0x7f, y.lo, 9)      the float 1 + f, f = the fraction's top 23 bits (the 2^-24 in the constant makes the cut
+//                                            a round-to-nearest of x: +-2^-24, no bias);
+//   e  = v_exp_f32(u) in [2, 4]              = 2^(1 + f), 1 ulp;
+//   ed = v_cvt_f64_f32(e);  ed.hi += n << 20 (v_lshl_add_u32; n = y.hi clamped by v_med3_i32 to 0x41380000 - 1024 ... + 1023)
+// = 2^x in 6 instructions / 7 issue slots with the sum's FMA, against 7 / 8 of the v_fract form (fract, cvt_i32, cvt_f32, exp, cvt_f64,
+// ldexp, fma).  The clamp makes the form total: the exponent field of ed (1024 or 1025) + n stays inside [0, 2047] - n = -1024 gives a
+// subnormal or 2^-1022 (a term 2^-1150 below its sum), n = 1023 gives NaN or inf, which the sums' overflow tests catch exactly like the
+// inf of the v_fract form; an accumulator outside [2^20, 2^21) - |x| beyond 2^19, NaN, inf - has a high word beyond the clamp's ends and
+// comes out as ~0 (x -> -inf) or NaN (everything else).  Accuracy per term: x on a 2^-32 grid (the MFMA chain rounds there: <= 1e-9),
+// f to 2^-24 (4.1e-8 relative), v_exp_f32 1 ulp of a value in [2, 4] (<= 1.2e-7): <= 1.65e-7, against 1.4e-7 of the v_fract form.
+// Like that form it is a function of the (row, query) pair alone: the offsets are integers, and an integer added to y moves the high
+// word only (the grid and every rounding of the chain stay where they are while y stays in its binade).
+#ifndef PBN_EXP2_MAGIC
+#define PBN_EXP2_MAGIC 1
+#endif
+#ifndef PBN_MAGIC_CLAMP
+#define PBN_MAGIC_CLAMP 1   // 0: probe builds only (the unclamped 5-instruction form: wraps on exponents beyond +-1023)
+#endif
+#ifndef PBN_MAGIC_PRUNED
+#define PBN_MAGIC_PRUNED 1   // the pruned / grouped sum-only sweeps too (their far tiles pay one v_add_f64 per value to take the constant off)
+#endif
+#ifndef PBN_MAGIC_GUARD
+#define PBN_MAGIC_GUARD 1   // unpruned sweeps: chunks whose exponents are proven inside +-1022 skip the clamp (kde_sweep_body: GUARD)
+#endif
+#define PBN_MAGIC_C (0x1.8p20 - 1.0 + 0x1p-24)
+#define PBN_MAGIC_H0 0x41380000
+template <bool CLAMP = true>
+__device__ __forceinline__ double exp2_magic(double y) {
+    const unsigned lo = (unsigned)__double2loint(y);
+    int t = __double2hiint(y);
+    const float u = __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, lo, 9));
+    const double ed = (double)__builtin_amdgcn_exp2f(u);
+    if constexpr (CLAMP) {
+        t = t < PBN_MAGIC_H0 - 1024 ? PBN_MAGIC_H0 - 1024 : t;
+        t = t > PBN_MAGIC_H0 + 1023 ? PBN_MAGIC_H0 + 1023 : t;   // (v_med3_i32)
+    }
+    unsigned h2;
+    if constexpr (CLAMP) h2 = (unsigned)__double2hiint(ed) + ((unsigned)t << 20);
+    else asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(h2) : "v"(t), "v"(__double2hiint(ed)));   // (left to the compiler this becomes three 64-bit operations)
+    return __hiloint2double((int)h2, __double2loint(ed));
+}
+
 template <int DEG>
 __device__ __forceinline__ double exp2_f64(double x) {
     // x <= ~1000 (larger values are caught by the overflow check of the caller), any negative value.
@@ -192,6 +238,10 @@ struct Tr<double> {
         return PBN_EXP2_DEGREE <= 7 ? exp2_f64_fract<FAST>(x, top) : exp2_f64<GEN_DEG>(x);
     }
     static __device__ __forceinline__ double bias() { return PBN_EXP2_BIAS; }
+    // MAGIC sweeps (exp2_magic): the constant on top of the biased exponents, and 2^x from such an accumulator
+    static __device__ __forceinline__ double magic() { return PBN_MAGIC_C; }
+    template <bool CLAMP = true>
+    static __device__ __forceinline__ double ex2m(double y) { return exp2_magic<CLAMP>(y); }
     static __device__ __forceinline__ double ex2_hi(double x) { return exp2_f64<8>(x); }
     static __device__ __forceinline__ double big() { return 0x1p900; }
     // C/D row held by (lane group lg, register i): cdna_hip_programming.md §3 "f64 MFMA"
@@ -209,6 +259,9 @@ struct Tr<float> {
     template <bool FAST = false>
     static __device__ __forceinline__ float ex2p(float x, float) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float bias() { return 0.0f; }
+    static __device__ __forceinline__ float magic() { return 0.0f; }
+    template <bool CLAMP = true>
+    static __device__ __forceinline__ float ex2m(float y) { return __builtin_amdgcn_exp2f(y); }
     static __device__ __forceinline__ float big() { return 0x1p100f; }
     static __host__ __device__ __forceinline__ int crow(int lg, int i) { return 4 * lg + i; }
 };
@@ -289,6 +342,14 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
         // weights of the WMUL sweep behind the norms: 2^norm; NaN where it would lose bits (the sweep then takes its
         // classic path for that tile), 0 for padding
         if (a.write_w) npack[a.ntiles * 16 + tile * 16 + lg * 4 + i] = !valid ? (T)0 : (nv < -1000.0 ? (T)NAN : (T)exp2(nv));
+        if constexpr (sizeof(T) == 8) {
+            if (a.write_r) {   // the tile's radius: sqrt(max -norm) over its 16 rows (consecutive lanes), +inf with a padding row
+                double rr = valid ? -nv : INFINITY;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { const double v = __shfl_xor(rr, o); rr = v > rr ? v : rr; }
+                if (idx == 0) ((double*)npack)[a.ntiles * 32 + tile] = __builtin_sqrt(rr);
+            }
+        }
     }
     if (a.upack) {  // CKDE::cdf: standardised "x - b.e" of the row, in the norm's layout
         double u = 0.0;
@@ -758,6 +819,15 @@ template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMU
 __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigned bid) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
+    // MAGIC: the accumulators of this sweep carry Tr<T>::magic() and 2^x is exp2_magic - unpruned sum-only fp64 sweeps (round 6)
+    constexpr bool MAGIC = PBN_EXP2_MAGIC && EF32 && PBN_EXP2_F32 && PBN_EXP2_DEGREE <= 7 && sizeof(T) == 8 && !COND && (!PRUNE || PBN_MAGIC_PRUNED);
+    // the per-query constant of the accumulators: norm (+ the magic constant, rounded to ITS grid once per query: what follows - the
+    // integer offset, the bias - is exact), and 2^x of an accumulator
+    auto cbase = [](T nyq) -> T { return MAGIC ? (T)(nyq + Tr<T>::magic()) : nyq; };
+    auto ex2a = [](T v, T top) -> T {
+        if constexpr (MAGIC) { (void)top; return Tr<T>::template ex2m<PBN_MAGIC_CLAMP != 0>(v); }
+        else return Tr<T>::template ex2p<EF32>(v, top);
+    };
     constexpr int WPB = sweep_block_threads(PRUNE) / 64;   // waves per workgroup
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -843,7 +913,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             // rounding (1e-13), not to the polynomial's error bound.  Scaling by 2^integer is exact.
             T mx = __builtin_ceil(colmax<T>(max4<T>(acc)));
             m[g] = mx;
-            cm[g] = ny[g] - mx + Tr<T>::bias();   // main-loop exponents are kept biased (Tr<T>::ex2p)
+            cm[g] = cbase(ny[g]) - mx + Tr<T>::bias();   // main-loop exponents are kept biased (Tr<T>::ex2p)
             if (FOLD || WMUL) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
             if (COND) {
                 V accj = Tr<T>::mfma(ax, bxb[g], acc);
@@ -876,7 +946,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 lbm[g] = fin && lb > m[g];
                 if (lbm[g]) {
                     m[g] = lb;
-                    cm[g] = ny[g] - lb + Tr<T>::bias();
+                    cm[g] = cbase(ny[g]) - lb + Tr<T>::bias();
                 }
                 if (FOLD || WMUL) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
                 if (COND) {
@@ -925,24 +995,24 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             V accj;
             if (COND) accj = Tr<T>::mfma(ax, bx[g], acc);
 
-            T e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop), e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop), e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop), e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
+            T e0 = ex2a(acc[0], ctop), e1 = ex2a(acc[1], ctop), e2 = ex2a(acc[2], ctop), e3 = ex2a(acc[3], ctop);
             T ts;
             if (WMUL) ts = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], e0 * nx[0])));   // nx holds the weights
             else ts = (e0 + e1) + (e2 + e3);
             T tsj = 0;
             bool bad = !(ts < Tr<T>::big());
             if (COND) {
-                T j0 = Tr<T>::template ex2p<EF32>(accj[0], ctop), j1 = Tr<T>::template ex2p<EF32>(accj[1], ctop), j2 = Tr<T>::template ex2p<EF32>(accj[2], ctop), j3 = Tr<T>::template ex2p<EF32>(accj[3], ctop);
+                T j0 = ex2a(accj[0], ctop), j1 = ex2a(accj[1], ctop), j2 = ex2a(accj[2], ctop), j3 = ex2a(accj[3], ctop);
                 tsj = (j0 + j1) + (j2 + j3);
                 bad = bad || !(tsj < Tr<T>::big());
             }
             if (__builtin_expect(__any(bad), 0)) {
                 // Rare wave-uniform slow path: raise the offsets to the tile maximum and redo the tile.
                 if (WMUL) acc += *(const PBN_GLOBAL V*)(Np + t * 16 + lg * 4);   // the classic exponents: norms added
-                T mx = __builtin_ceil(colmax<T>(max4<T>(acc)) - Tr<T>::bias());
+                T mx = __builtin_ceil(colmax<T>(max4<T>(acc)) - (MAGIC ? Tr<T>::magic() : (T)0) - Tr<T>::bias());
                 if (mx > (T)0) {
                     m[g] += mx;
-                    cm[g] = ny[g] - m[g] + Tr<T>::bias();
+                    cm[g] = cbase(ny[g]) - m[g] + Tr<T>::bias();
                     if (FOLD || WMUL) cmv[g] = V{cm[g], cm[g], cm[g], cm[g]};
                     sum[g] *= exp2(-(double)mx);
                     acc -= mx;
@@ -950,7 +1020,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 // the SAME 2^x as the main loop (the exponents are still biased, the offsets integers): a term must come out
                 // identical whichever path evaluates it, or sums taken in another tile order would differ by the polynomial's
                 // error (the Morton-ordered sweeps come through here often, table-ordered ones hardly ever)
-                e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop); e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop); e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop); e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
+                e0 = ex2a(acc[0], ctop); e1 = ex2a(acc[1], ctop); e2 = ex2a(acc[2], ctop); e3 = ex2a(acc[3], ctop);
                 ts = (e0 + e1) + (e2 + e3);
                 if (COND) {
                     T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)) - Tr<T>::bias());
@@ -960,7 +1030,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                         accj -= mxj;
                     }
                     bx[g] = (lg == 2) ? bxb[g] + (m[g] - mj[g]) : bxb[g];
-                    T j0 = Tr<T>::template ex2p<EF32>(accj[0], ctop), j1 = Tr<T>::template ex2p<EF32>(accj[1], ctop), j2 = Tr<T>::template ex2p<EF32>(accj[2], ctop), j3 = Tr<T>::template ex2p<EF32>(accj[3], ctop);
+                    T j0 = ex2a(accj[0], ctop), j1 = ex2a(accj[1], ctop), j2 = ex2a(accj[2], ctop), j3 = ex2a(accj[3], ctop);
                     tsj = (j0 + j1) + (j2 + j3);
                 }
             }
@@ -973,7 +1043,8 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     V nxA, nxB;
     T axA = 0, axB = 0;
     // blind accumulation (see "Unchecked passes" below): no overflow test, no separate add
-    auto process_fast = [&](const T (&af)[KS], const V& nx, const int bit) {
+    auto process_fast = [&](const T (&af)[KS], const V& nx, const int bit, auto clamp) {
+        constexpr bool CLAMPED = decltype(clamp)::value;   // false: exp2_magic without its clamp (the chunk's exponents are proven inside +-1022)
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             if (GMASK && !((gm[g] >> bit) & 1ull)) continue;
@@ -983,13 +1054,19 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
             for (int ks = 0; ks < KS; ++ks) acc = Tr<T>::mfma(af[ks], b[g][ks], acc);
             if constexpr (FARP) {
                 if (!((gn[g] >> bit) & 1ull)) {   // a far tile of this group: the fp32 tail path
+                    if constexpr (MAGIC) acc -= Tr<T>::magic();   // (exact: the accumulator sits on the constant's grid)
                     const float f0 = __builtin_amdgcn_exp2f((float)acc[0]), f1 = __builtin_amdgcn_exp2f((float)acc[1]);
                     const float f2 = __builtin_amdgcn_exp2f((float)acc[2]), f3 = __builtin_amdgcn_exp2f((float)acc[3]);
                     fs[g] += (f0 + f1) + (f2 + f3);
                     continue;
                 }
             }
-            const T e0 = Tr<T>::template ex2p<EF32>(acc[0], ctop), e1 = Tr<T>::template ex2p<EF32>(acc[1], ctop), e2 = Tr<T>::template ex2p<EF32>(acc[2], ctop), e3 = Tr<T>::template ex2p<EF32>(acc[3], ctop);
+            T e0, e1, e2, e3;
+            if constexpr (MAGIC && !CLAMPED) {
+                e0 = Tr<T>::template ex2m<false>(acc[0]); e1 = Tr<T>::template ex2m<false>(acc[1]); e2 = Tr<T>::template ex2m<false>(acc[2]); e3 = Tr<T>::template ex2m<false>(acc[3]);
+            } else {
+                e0 = ex2a(acc[0], ctop); e1 = ex2a(acc[1], ctop); e2 = ex2a(acc[2], ctop); e3 = ex2a(acc[3], ctop);
+            }
             if (WMUL) sum[g] = __builtin_fma(e3, nx[3], __builtin_fma(e2, nx[2], __builtin_fma(e1, nx[1], __builtin_fma(e0, nx[0], sum[g]))));
             else sum[g] += (e0 + e1) + (e2 + e3);
         }
@@ -1009,13 +1086,13 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 const int b2 = more ? __builtin_ctzll(mask) : b;
                 mask &= mask - 1;
                 load_tile(tb + b2, afB, nxB, axB);
-                if constexpr (BLIND) process_fast(afA, nxA, b); else process_tile(tb + b, afA, nxA, axA, b);
+                if constexpr (BLIND) process_fast(afA, nxA, b, std::true_type{}); else process_tile(tb + b, afA, nxA, axA, b);
                 if (!more) break;
                 const bool more2 = mask != 0;
                 const int b3 = more2 ? __builtin_ctzll(mask) : b2;
                 mask &= mask - 1;
                 load_tile(tb + b3, afA, nxA, axA);
-                if constexpr (BLIND) process_fast(afB, nxB, b2); else process_tile(tb + b2, afB, nxB, axB, b2);
+                if constexpr (BLIND) process_fast(afB, nxB, b2, std::true_type{}); else process_tile(tb + b2, afB, nxB, axB, b2);
                 if (!more2) break;
                 b = b3;
             }
@@ -1151,17 +1228,68 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         if constexpr (FAST) {
             constexpr int CH = 32;
             __shared__ double sumsave[QG][256];
+            // GUARD (round 6, MAGIC sweeps): exp2_magic WITHOUT its clamp - 5 instructions per value - for the chunks whose exponents are proven
+            // inside +-1022 before they are computed.  With R = sqrt(max -norm) over the chunk's rows (SweepArgs::tile_r) and, per query, NQ =
+            // -norm and a = the accumulator's constant (norm - offset + bias), Cauchy-Schwarz gives |z_t.z_q| <= 2 R sqrt(NQ) in exponent units:
+            //   WMUL (x = z_t.z_q + a):                      |x| <= 1022  <=  R <= min(1022 - a, 1022 + a) / (2 sqrt(NQ))
+            //   norms in the accumulator (x = a + NQ - d2/2): x <= a + NQ <= 1022 and x >= a + NQ - (R + sqrt(NQ))^2 >= -1022
+            //                                                              <=  R <= sqrt(1022 + a + NQ) - sqrt(NQ)
+            // rlim = the smallest such bound over the wave's queries (recomputed when a checked redo moves the offsets); a chunk is taken
+            // unclamped when every one of its tiles has tile_r <= rlim.  Inside the bound the clamped and the unclamped form are the same
+            // function: which chunks pass changes the time, not a bit of the result.
+            constexpr bool GUARD = MAGIC && PBN_MAGIC_GUARD;
+            const PBN_GLOBAL double* __restrict__ TRp = (const PBN_GLOBAL double*)a.tile_r;
+            double rlim = -1.0;
+            auto set_rlim = [&]() {
+                double lim = INFINITY;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    const double aq = (double)(cm[g] - Tr<T>::magic()), nq = -(double)ny[g];
+                    const double sq = __builtin_sqrt(nq);
+                    double l;
+                    if (WMUL) {
+                        const double h = aq < 0.0 ? 1022.0 + aq : 1022.0 - aq;
+                        l = sq > 0.0 ? 0.5 * h / sq : (h >= 0.0 ? INFINITY : -1.0);
+                    } else {
+                        const double top = aq + nq;
+                        l = top <= 1022.0 ? __builtin_sqrt(1022.0 + top) - sq : -1.0;
+                    }
+                    lim = l < lim ? l : lim;   // (a NaN bound - NaN queries - never lowers the limit: their sums are NaN whatever the path)
+                    if (!(l == l)) lim = -1.0;
+                }
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_xor(lim, o); lim = v < lim ? v : lim; }
+                rlim = lim;
+            };
+            if constexpr (GUARD) { if (TRp) set_rlim(); }
             for (int64_t tc = t0; tc < t1; tc += CH) {
                 const int64_t te = tc + CH < t1 ? tc + CH : t1;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) sumsave[g][threadIdx.x] = sum[g];
+                bool open = false;
+                if constexpr (GUARD) {
+                    if (TRp) {
+                        const int64_t tt = tc + lane < te ? tc + lane : te - 1;
+                        open = __all(lane >= CH || TRp[tt] <= rlim);
+                    }
+                }
                 load_tile(tc, afA, nxA, axA);
-                for (int64_t t = tc; t < te; t += 2) {
-                    const bool second = t + 1 < te;                   // wave-uniform
-                    load_tile(second ? t + 1 : t, afB, nxB, axB);
-                    process_fast(afA, nxA, 0);
-                    load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
-                    if (second) process_fast(afB, nxB, 0);
+                if (open) {
+                    for (int64_t t = tc; t < te; t += 2) {
+                        const bool second = t + 1 < te;                   // wave-uniform
+                        load_tile(second ? t + 1 : t, afB, nxB, axB);
+                        process_fast(afA, nxA, 0, std::false_type{});
+                        load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
+                        if (second) process_fast(afB, nxB, 0, std::false_type{});
+                    }
+                } else {
+                    for (int64_t t = tc; t < te; t += 2) {
+                        const bool second = t + 1 < te;                   // wave-uniform
+                        load_tile(second ? t + 1 : t, afB, nxB, axB);
+                        process_fast(afA, nxA, 0, std::true_type{});
+                        load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
+                        if (second) process_fast(afB, nxB, 0, std::true_type{});
+                    }
                 }
                 bool bad = false;
 #pragma unroll
@@ -1172,6 +1300,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                     for (int g = 0; g < QG; ++g) sum[g] = sumsave[g][threadIdx.x];
                     checked_range(tc, te);
+                    if constexpr (GUARD) { if (TRp) set_rlim(); }   // the offsets may have moved
                 }
             }
         } else {
@@ -1302,6 +1431,9 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
     // still meets its batches in ascending order: the partials are the ones of the group-by-group form, bit for bit.
     // The groups' 16 queries live in lanes 0..15 (copies in the other lanes): coordinates and the exponent offset - the prepass's lower bound of
     // the query's largest exponent, an integer as in the sweep.  A padding row (bound -inf) gets an offset that kills its terms.
+    // (the exponents carry the magic constant of the sweep beside this pass: the same 2^x, exp2_magic - x below is that accumulator form)
+    constexpr bool MOMM = PBN_MOM_EXP_F32 && PBN_EXP2_MAGIC && PBN_MAGIC_PRUNED && PBN_EXP2_F32 && PBN_EXP2_DEGREE <= 7;
+    constexpr double MOMC = MOMM ? PBN_MAGIC_C : 0.0;
     double mqv[QG], cmv[QG], zv[QG][D], thr[QG];
     bool gok[QG], chk[QG];
 #pragma unroll
@@ -1312,11 +1444,11 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
         const double lb = __builtin_ceil(QLp[q]);
         const bool qok = (lb < 0.0 ? -lb : lb) < 0x1p50;
         mqv[gi] = qok ? lb : 0.0;
-        cmv[gi] = qok ? Tr<double>::bias() - lb : -0x1p60;
+        cmv[gi] = qok ? (Tr<double>::bias() + MOMC) - lb : -0x1p60;
         // x = -d2 / 2 + cmv <= cmv: a group none of whose queries can reach 900 exponent units (the prepass bound of its largest exponent lies
         // within ~870 units of 0: every query with a training row within 41 bandwidths) runs its 16 queries without the overflow test - one
         // basic block of 16 independent Horner schemes instead of 16 blocks with a branch between them
-        chk[gi] = __any(cmv[gi] > 900.0) != 0;
+        chk[gi] = __any(cmv[gi] > 900.0 + MOMC) != 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) zv[gi][k] = qok ? ZQp[q * D + k] : 0.0;
 #pragma unroll
@@ -1390,7 +1522,7 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
                         double x = __builtin_fma(-0.5, d2, readlane_f64(cmv[gi], qi));
                         if constexpr (MASK) x = act ? x : -5e19;
                         if constexpr (CHECK) {
-                            while (__builtin_expect(__any(x > 900.0), 0)) {
+                            while (__builtin_expect(__any(x > 900.0 + MOMC), 0)) {
                                 // the offset is a LOWER bound of the query's largest exponent: a far-out query (heavy tails) can sit thousands of
                                 // units below a row its short neighbour scan missed.  Rebase the query (uniform: every lane's sum for it, and the
                                 // offset it lives with from here on) by a fixed integer number of units
@@ -1401,7 +1533,7 @@ __global__ __launch_bounds__(64, D == 2 ? PBN_MOM_WAVES2 : 3) void kde_moment_gr
                         }
                         // 2^x as in the sweep this pass stands in for: 2^f of the fraction on the fp32 unit (<= 1.4e-7 of the pair's contribution,
                         // the budget's first entry); x >= 0 for every pair that matters (the biased offset), a negative x comes out <= 2x too large
-                        const double e = PBN_MOM_EXP_F32 ? exp2_f64_fract<true>(x, 0.0) : Tr<double>::ex2_hi(x);
+                        const double e = MOMM ? exp2_magic<true>(x) : PBN_MOM_EXP_F32 ? exp2_f64_fract<true>(x, 0.0) : Tr<double>::ex2_hi(x);
                         double pv;
                         if constexpr (D == 1) {
                             pv = cf[0];

@@ -38,6 +38,8 @@ struct PackArgs {
     // query pack that leaves the slot 0 (CKDE::cdf, UCV) makes the training side's entry inert.
     int fold_norm;
     int write_w;          // training side, classic pack: also write the weights 2^norm at npack + ntiles * 16 (WMUL sweeps)
+    int write_r;          // ... and per tile sqrt(max -norm) of its rows (+inf with a padding row) as doubles behind the weights (fp64 fragments;
+                          // SweepArgs::tile_r: the guard of the unclamped 2^x of the unpruned sum-only sweeps)
     // source rows: logical row r maps to  l = r < n0 ? row0 + r : row1 + (r - n0)   (two contiguous ranges: a CV training
     // set is "everything before the fold" ++ "everything after it"), and then through the gather list, rows[l], when one is
     // given (hybrid slices: the rows of one discrete configuration, grouped fold by fold - the same two-range trick inside it)
@@ -173,6 +175,9 @@ struct SweepArgs {
     // bound is left to the moment pass (kde_moment_group_kernel) by the sweep; null = off.
     const float* tile_rad2;
     const double* tile_mom;
+    // Unpruned sum-only fp64 sweeps (round 6): tile_r[t] = sqrt(max -norm) over the rows of training tile t (PackArgs::write_r) - a chunk of
+    // tiles whose largest radius proves every exponent of the wave's queries inside +-1022 takes exp2_magic without its clamp; null = clamp always
+    const double* tile_r;
     // Batch boxes (round 5, pruned fp64 plain sweeps): the bounding box of every 64-tile batch of a split - [split * batches_per_split + k][2 * pdims].
     // A wave classifies 64 BATCHES with one ballot (lane = batch) before it loads and tests the tile boxes of the batches in reach; null = off.
     const double* batch_box;

@@ -91,7 +91,8 @@ KdePackBytes kde_pack_bytes(int dtype, int dm, bool cond, int64_t n) {
         return {(size_t)ntiles * f16x2_mfmas(dm) * 64 * 16, 64, cond ? (size_t)ntiles * 64 * 16 : 0};
     const int KS = (dm + 3) / 4;
     // norms [ntiles][16], then the weights 2^norm [ntiles][16] of the WMUL sweep
-    return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es * 2, cond ? (size_t)ntiles * 64 * es : 0};
+    // ... then one double per tile: sqrt(max -norm) of its rows (PackArgs::write_r)
+    return {(size_t)ntiles * KS * 64 * es, (size_t)ntiles * 16 * es * 2 + (size_t)ntiles * 8, cond ? (size_t)ntiles * 64 * es : 0};
 }
 
 void kde_prepare(KdeModel& m, int dtype, int d, int64_t n, const double* bw, int kind, bool cond, const double* center) {
@@ -312,6 +313,8 @@ void kde_pack_train(pbn_ctx* ctx, KdeModel& m, const pbn_table* t, const int* co
     }
     pa.fold_norm = 1;   // harmless for consumers whose query pack leaves the slot 0
     pa.write_w = !use_f16x2(m.fdtype());
+    pa.write_r = pa.write_w && m.fdtype() == PBN_F64;
+    m.tile_r = pa.write_r != 0;
     pa.pack = m.Apack; pa.npack = m.nxpack; pa.xpack = m.cond ? m.Axpack : nullptr;
     KernelTimer kt(ctx, PBN_K_PACK);
     launch_pack(pa, m.fdtype(), ctx->stream);
@@ -485,6 +488,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.wmul = wmul ? 1 : 0;
     sa.w32 = (b3 && !m.cond && (m.prune ? f16x2_w32p(m.dm, m.KS) : f16x2_w32(m.dm, m.KS))) ? 1 : 0;
     sa.far_span = (sum_only && m.prune) ? (double)knob_int("PBN_FAR_SPAN", 17) : 0.0;   // sum-only pruned sweeps: fp32 tail for tiles 26+ bits below the sum bound
+    sa.tile_r = (m.tile_r && !m.prune && sum_only) ? (const double*)((const char*)m.nxpack + (size_t)m.ntiles * 16 * es * 2) : nullptr;
     sa.fast = sum_only ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, sum_only); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;

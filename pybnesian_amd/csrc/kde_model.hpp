@@ -31,7 +31,8 @@ struct KdeModel {
     bool wide = false;
     std::vector<double> W, mu; // d x d row-major lower whitening matrix; d centring offsets (whitening order)
     void* Apack = nullptr;     // device [ntiles][KS][64]
-    void* nxpack = nullptr;    // device [ntiles][16]
+    void* nxpack = nullptr;    // device [ntiles][16] norms, [ntiles][16] weights (classic packs), [ntiles] tile radii as doubles (fp64 fragments)
+    bool tile_r = false;       // the tile radii were written (PackArgs::write_r)
     void* Axpack = nullptr;    // device [ntiles][64] (CKDE only)
     // tile pruning (set by kde_pack_train when asked for and the shape qualifies; see SweepArgs::prune): the packs above
     // hold the training rows in Morton order of their whitened coordinates

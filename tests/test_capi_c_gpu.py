@@ -57,13 +57,15 @@ def test_c_program_matches_the_oracle(tmp_path):
     assert abs(float(vals["ckde_slogl"]) - want_ckde) <= 1e-8 * abs(want_ckde)
     assert abs(float(vals["bic_c_ab"]) - want_bic) <= 1e-9 * abs(want_bic)
     assert int(vals["bad_rc"]) == 1  # PBN_ERR_INVALID
-    # and the Python mirror gives what the C caller got
+    # and the Python mirror gives what the C caller got.  Not bit for bit: the two hosts hand over tables whose whitened rows differ in the
+    # last ulp, and the sum-only sweeps' 2^x (exp2_magic) quantises every exponent to 2^-32 and its fraction to 2^-24 - an ulp on the input
+    # moves a few of the 3.5e6 terms across a rounding boundary (1.6e-10 / 8e-8 of ONE term each): 1e-11 of the sum here, held to 1e-10
     kde = pbn.KDE(["a", "b", "c"])
     kde.fit(train)
-    assert abs(float(vals["kde_slogl"]) - kde.slogl(test)) <= 1e-12 * abs(kde.slogl(test))
+    assert abs(float(vals["kde_slogl"]) - kde.slogl(test)) <= 1e-10 * abs(kde.slogl(test))
     ckde = pbn.CKDE("a", ["b", "c"])
     ckde.fit(train)
-    assert abs(float(vals["ckde_slogl"]) - ckde.slogl(test)) <= 1e-12 * abs(ckde.slogl(test))
+    assert abs(float(vals["ckde_slogl"]) - ckde.slogl(test)) <= 1e-10 * abs(ckde.slogl(test))
 
 
 def test_c_host_with_rccl_shards_the_delta_cache(tmp_path):
