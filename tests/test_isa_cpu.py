@@ -125,3 +125,33 @@ def test_w32_sweep_stream_is_placed(kde_asm):
         assert "scratch_" not in steady[0]
         seen += 1
     assert seen == 2
+
+
+def test_fp64_sum_only_sweeps_take_the_magic_form(kde_asm):
+    """kde_sweep_kernel<double, KS, ..., EF32> (the C2 headline family, sum-only): 2^x comes from the accumulator's own words (exp2_magic) - the
+    blind loops hold, per v_mfma_f64 of a (tile, group) pair's last K step, four values x {v_alignbit_b32, v_exp_f32, v_cvt_f64_f32,
+    v_lshl_add_u32, sum}: no v_fract_f64 / v_cvt_i32_f64 / v_cvt_f32_f64 / v_ldexp_f64 of a range reduction, the clamp (v_med3_i32) in the
+    guard-closed loop only, nothing in scratch, two waves per SIMD."""
+    seen = 0
+    for ks, wmul in ((2, True), (1, True), (2, False), (3, False)):
+        # kde_sweep_kernel<double, KS, COND=false, QG=4, FOLD=!wmul, PRUNE=false, WMUL, EF32=true>
+        pat = r"kde_sweep_kernelIdLi%dELb0ELi4ELb%dELb0ELb%dELb1EE" % (ks, 0 if wmul else 1, 1 if wmul else 0)
+        (name, body), = kernels(kde_asm, pat)
+        hdr = re.search(r"\.amdhsa_kernel %s\n(.*?)\.end_amdhsa_kernel" % re.escape(name), kde_asm, flags=re.S).group(1)
+        assert int(re.search(r"private_segment_fixed_size (\d+)", hdr).group(1)) == 0, name
+        assert int(re.search(r"next_free_vgpr (\d+)", hdr).group(1)) <= 256, name
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        groups = 8                                          # two tiles x four query groups per trip
+        loops = [b for b in blocks if len(re.findall(r"v_mfma_f64", b)) == groups * ks and "Loop" in "\n".join(b.split("\n")[:3])]
+        assert len(loops) == 2, (name, len(loops))          # guard open (no clamp) and guard closed
+        clamps = sorted(len(re.findall(r"\bv_med3_i32", b)) for b in loops)
+        assert clamps == [0, 4 * groups], (name, clamps)
+        for b in loops:
+            for op in ("v_alignbit_b32", "v_exp_f32", "v_cvt_f64_f32", "v_lshl_add_u32"):
+                assert len(re.findall(r"\b%s" % op, b)) == 4 * groups, (name, op)
+            for op in ("v_fract_f64", "v_cvt_i32_f64", "v_cvt_f32_f64", "v_ldexp_f64", "scratch_"):
+                assert op not in b, (name, op)
+            sums = len(re.findall(r"\bv_fmac_f64|\bv_fma_f64", b)) if wmul else len(re.findall(r"\bv_add_f64", b))
+            assert 4 * groups <= sums <= 4 * groups + 2, (name, sums)
+        seen += 1
+    assert seen == 4
