@@ -106,6 +106,7 @@ struct GSweepUnit {
     int32_t nbps;         // 64-tile batches per split (batch_box rows per split)
     const double* batch_box;
     int32_t mom_stride;   // doubles between consecutive values of the tile-moment records (tiles rounded up to 64)
+    int32_t box_full;     // the boxes cover all of the unit's whitened dimensions (pool.kd == pool.d; SweepArgs::box_full)
 };
 struct GSweepArgs {
     const GSweepUnit* units;

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackArgs a) {
         if (a.write_w) npack[a.ntiles * 16 + tile * 16 + lg * 4 + i] = !valid ? (T)0 : (nv < -1000.0 ? (T)NAN : (T)exp2(nv));
         if constexpr (sizeof(T) == 8) {
             if (a.write_r) {   // the tile's radius: sqrt(max -norm) over its 16 rows (consecutive lanes), +inf with a padding row
-                double rr = valid ? -nv : INFINITY;
+                double rr = (valid && nv == nv) ? -nv : INFINITY;   // (a NaN row closes its chunk: the clamped form keeps the NaN)
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { const double v = __shfl_xor(rr, o); rr = v > rr ? v : rr; }
                 if (idx == 0) ((double*)npack)[a.ntiles * 32 + tile] = __builtin_sqrt(rr);
@@ -739,6 +739,23 @@ __device__ __forceinline__ bool batch_in_reach(BP bb, BP qbox, int pd, double th
     return !(-0.5 * d2 < thr);
 }
 
+// GUARD of the pruned sum-only fp64 sweeps (round 6): is the LARGEST squared distance between the batch's box and the group's box at most
+// PBN_OPEN_FAR2?  With boxes over all whitened dimensions every exponent of the batch's rows against the group's queries then lies at most
+// PBN_OPEN_FAR2 / 2 below the offset, and exp2_magic needs no clamp for the batch (false for a box with a NaN or infinite side).
+#define PBN_OPEN_FAR2 2200.0
+template <typename BP>
+__device__ __forceinline__ bool batch_all_near(BP bb, BP qbox, int pd) {
+    double f2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < PBN_PRUNE_PD; ++k)
+        if (k < pd) {
+            const double h1 = bb[pd + k] - qbox[k], h2 = qbox[pd + k] - bb[k];
+            const double h = h1 > h2 ? h1 : h2;
+            f2 = __builtin_fma(h, h, f2);
+        }
+    return f2 <= PBN_OPEN_FAR2;
+}
+
 // ... and with the MOMENT pass (round 5): `mom` = the (tile, group) pairs whose contribution is taken from the tile's moments instead
 // (kde_moment_group_kernel).  The tile's rows are z_t = c + delta_t, |delta_t| <= rho; for a query at u = z_q - c a row's term is
 // 2^(-|u|^2 / 2) 2^(-|delta_t|^2 / 2) e^(s_t), s_t = a u.delta_t, a = ln 2, and e^s is replaced by its Taylor polynomial T_P(s).  By Lagrange's
@@ -984,6 +1001,16 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     float fs[FARP ? QG : 1];
 #pragma unroll
     for (int g = 0; g < (FARP ? QG : 1); ++g) { gn[g] = ~0ull; fs[g] = 0.f; }
+    // GUARDP (round 6): pruned MAGIC sweeps with the norm in a K slot and boxes over all whitened dimensions (d <= 3) - a 64-tile batch whose
+    // box lies within PBN_OPEN_FAR2 of the boxes of the wave's groups runs exp2_magic without its clamp (batch_all_near, one lane-parallel
+    // test per super-batch beside batch_in_reach: nothing per tile); gate_of = the group's side of the proof: offsets inside [-890, 16] (an
+    // exponent is at most bias - offset), no NaN query, not the query tile with the padding rows
+    constexpr bool GUARDP = MAGIC && PRUNE && GMASK && FOLD && KS == 1 && PBN_MAGIC_GUARD;
+    // (taken per super-batch, from the offsets as they stand: a scalar carried around the whole walk - even one computed once before it - pushed
+    // the visit masks out of the SGPRs into vector registers and lane-masked branches: 25 % of the kernel's time)
+    auto gate_of = [&](int g) -> bool {
+        return __builtin_amdgcn_readfirstlane(__all(a.box_full && qt0 + g < a.nqtiles - 1 && ny[g] == ny[g] && m[g] >= (T)-890 && m[g] <= (T)16)) != 0;
+    };
     auto process_tile = [&](const int64_t t, const T (&af)[KS], const V& nx, const T ax, const int bit) {
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
@@ -1044,7 +1071,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     T axA = 0, axB = 0;
     // blind accumulation (see "Unchecked passes" below): no overflow test, no separate add
     auto process_fast = [&](const T (&af)[KS], const V& nx, const int bit, auto clamp) {
-        constexpr bool CLAMPED = decltype(clamp)::value;   // false: exp2_magic without its clamp (the chunk's exponents are proven inside +-1022)
+        constexpr int CLAMPED = decltype(clamp)::value;   // 0: exp2_magic without its clamp (the chunk's / batch's exponents are proven inside +-1022)
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             if (GMASK && !((gm[g] >> bit) & 1ull)) continue;
@@ -1062,7 +1089,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 }
             }
             T e0, e1, e2, e3;
-            if constexpr (MAGIC && !CLAMPED) {
+            if constexpr (MAGIC && CLAMPED == 0) {
                 e0 = Tr<T>::template ex2m<false>(acc[0]); e1 = Tr<T>::template ex2m<false>(acc[1]); e2 = Tr<T>::template ex2m<false>(acc[2]); e3 = Tr<T>::template ex2m<false>(acc[3]);
             } else {
                 e0 = ex2a(acc[0], ctop); e1 = ex2a(acc[1], ctop); e2 = ex2a(acc[2], ctop); e3 = ex2a(acc[3], ctop);
@@ -1074,7 +1101,8 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
     if constexpr (PRUNE) {
         // 64 tiles per visit mask; inside a batch the kept tiles are processed two at a time with ping-pong fragment buffers
         auto run_batch = [&](int64_t tb, unsigned long long mask, auto blind) {
-            constexpr bool BLIND = decltype(blind)::value;
+            constexpr int BMODE = decltype(blind)::value;   // 0: checked, 1: blind, 2: blind and without the clamp of exp2_magic (GUARDP)
+            constexpr bool BLIND = BMODE != 0;
             // The prefetch of the next kept tile is UNCONDITIONAL (after the last one the current tile is simply loaded again):
             // with `if (mask) load` the two paths into the next MFMA differ in their number of loads in flight, and the compiler
             // must wait for ALL of them (s_waitcnt vmcnt(0)) - i.e. for the prefetch it has just issued - before every tile.
@@ -1086,13 +1114,13 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 const int b2 = more ? __builtin_ctzll(mask) : b;
                 mask &= mask - 1;
                 load_tile(tb + b2, afB, nxB, axB);
-                if constexpr (BLIND) process_fast(afA, nxA, b, std::true_type{}); else process_tile(tb + b, afA, nxA, axA, b);
+                if constexpr (BLIND) process_fast(afA, nxA, b, std::integral_constant<int, BMODE == 2 ? 0 : 1>{}); else process_tile(tb + b, afA, nxA, axA, b);
                 if (!more) break;
                 const bool more2 = mask != 0;
                 const int b3 = more2 ? __builtin_ctzll(mask) : b2;
                 mask &= mask - 1;
                 load_tile(tb + b3, afA, nxA, axA);
-                if constexpr (BLIND) process_fast(afB, nxB, b2, std::true_type{}); else process_tile(tb + b2, afB, nxB, axB, b2);
+                if constexpr (BLIND) process_fast(afB, nxB, b2, std::integral_constant<int, BMODE == 2 ? 0 : 1>{}); else process_tile(tb + b2, afB, nxB, axB, b2);
                 if (!more2) break;
                 b = b3;
             }
@@ -1104,7 +1132,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
         // Two levels: a SUPER-BATCH of 64 batches (4096 tiles) is classified first, lane = batch, against the batches' own boxes (grouped
         // sweeps: GSweepUnit::batch_box) - one round trip to L2 for 64 batches instead of one per batch, which is what the walk over a
         // split's tiles costs where most batches hold nothing for the wave (the test below is latency, not arithmetic).
-        auto do_batch = [&](const int64_t tb, const unsigned gsel) {
+        auto do_batch = [&](const int64_t tb, const unsigned gsel, const bool bare) {
             unsigned long long mask;
             if constexpr (GMASK) {
                 mask = 0;
@@ -1121,8 +1149,8 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                             if constexpr (MOM) {   // the moment pass takes the pairs it can expand: this sweep skips them
                                 unsigned long long mx;
                                 gm[g] = prune_group_mask3(TBp, QBp + qt * 2 * pd, (const PBN_GLOBAL float*)a.tile_rad2, pd, tb, t1, QTp[qt] - a.prune_margin,
-                                                          a.far_span > 0.0 ? QTp[qt] - (a.prune_margin - a.far_span) : -INFINITY,
-                                                          QTp[qt] - (a.prune_margin + PBN_MOM_EXTRA), lane, gn[g], mx);
+                                                                  a.far_span > 0.0 ? QTp[qt] - (a.prune_margin - a.far_span) : -INFINITY,
+                                                                  QTp[qt] - (a.prune_margin + PBN_MOM_EXTRA), lane, gn[g], mx);
                                 gm[g] &= ~mx;
                             } else if (a.far_span > 0.0) {
                                 gm[g] = prune_group_mask2(TBp, QBp + qt * 2 * pd, pd, tb, t1, QTp[qt] - a.prune_margin, QTp[qt] - (a.prune_margin - a.far_span), lane, gn[g]);
@@ -1158,28 +1186,33 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 double saved[QG];
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
-                run_batch(tb, mask, std::true_type{});
+                // GUARDP kernels hold ONE blind loop, the bare one: a batch that is not proven goes through the checked loop (2-3 % of the
+                // batches on the bench tables - wide batch boxes, the last tile and the last query tile of a unit, query groups whose offsets
+                // lie beyond -890 - and the same values either way; a third loop, blind WITH the clamp, measured no faster)
+                if constexpr (GUARDP) { if (bare) run_batch(tb, mask, std::integral_constant<int, 2>{}); }
+                else run_batch(tb, mask, std::integral_constant<int, 1>{});
                 if constexpr (FARP) {
 #pragma unroll
                     for (int g = 0; g < QG; ++g) { sum[g] += (double)fs[g]; fs[g] = 0.f; }   // (an overflowed fp32 tail arrives as inf: the batch is redone)
                 }
-                bool bad = false;
+                bool bad = GUARDP && !bare;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
                 const bool redo = __any(bad);
-                if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo) atomicAdd(&g_sweep_redo, 1ull); }
+                if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo && !(GUARDP && !bare)) atomicAdd(&g_sweep_redo, 1ull); }   // (overflows only)
                 if (redo) {
 #pragma unroll
                     for (int g = 0; g < QG; ++g) sum[g] = saved[g];
-                    run_batch(tb, mask, std::false_type{});
+                    run_batch(tb, mask, std::integral_constant<int, 0>{});
                 }
             } else {
-                run_batch(tb, mask, std::false_type{});
+                run_batch(tb, mask, std::integral_constant<int, 0>{});
             }
         };
         for (int64_t sb = t0; sb < t1; sb += 4096) {
             const int64_t bt = sb + 64 * lane;   // my batch's first tile
             unsigned long long bm = __ballot(bt < t1), bmg[QG];
+            unsigned long long bopen = (GUARDP && (MOM || a.group_masks) && a.batch_box) ? ~0ull : 0ull;
 #pragma unroll
             for (int g = 0; g < QG; ++g) bmg[g] = bm;
             if constexpr (GMASK) {
@@ -1191,6 +1224,9 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                         const int64_t qt = qt0 + g < a.nqtiles ? qt0 + g : a.nqtiles - 1;
                         bmg[g] = __ballot(bt < t1 && batch_in_reach(bb, QBp + qt * 2 * pd, pd, QTp[qt] - a.prune_margin));
                         bm |= bmg[g];
+                        // open for the wave = proven for every group that reaches the batch (the batch with the table's last tile - padding
+                        // rows, whose norm slot is not a distance - never)
+                        if constexpr (GUARDP) bopen &= ~bmg[g] | (gate_of(g) ? __ballot(bt + 64 < a.ntiles && batch_all_near(bb, QBp + qt * 2 * pd, pd)) : 0ull);
                     }
                 }
             }
@@ -1200,7 +1236,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 unsigned gsel = 0;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) gsel |= (unsigned)((bmg[g] >> j) & 1ull) << g;
-                do_batch(sb + 64 * (int64_t)j, gsel);
+                do_batch(sb + 64 * (int64_t)j, gsel, GUARDP && ((bopen >> j) & 1ull));
             }
         }
     } else {
@@ -1278,17 +1314,17 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                     for (int64_t t = tc; t < te; t += 2) {
                         const bool second = t + 1 < te;                   // wave-uniform
                         load_tile(second ? t + 1 : t, afB, nxB, axB);
-                        process_fast(afA, nxA, 0, std::false_type{});
+                        process_fast(afA, nxA, 0, std::integral_constant<int, 0>{});
                         load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
-                        if (second) process_fast(afB, nxB, 0, std::false_type{});
+                        if (second) process_fast(afB, nxB, 0, std::integral_constant<int, 0>{});
                     }
                 } else {
                     for (int64_t t = tc; t < te; t += 2) {
                         const bool second = t + 1 < te;                   // wave-uniform
                         load_tile(second ? t + 1 : t, afB, nxB, axB);
-                        process_fast(afA, nxA, 0, std::true_type{});
+                        process_fast(afA, nxA, 0, std::integral_constant<int, 1>{});
                         load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
-                        if (second) process_fast(afB, nxB, 0, std::true_type{});
+                        if (second) process_fast(afB, nxB, 0, std::integral_constant<int, 1>{});
                     }
                 }
                 bool bad = false;
@@ -1359,7 +1395,7 @@ __global__ __launch_bounds__(sweep_block_threads(true), PBN_F64_GROUP_WAVES) voi
     a.Apack = su.Apack; a.nxpack = su.nxpack; a.Axpack = nullptr;
     a.Bpack = su.Bpack; a.nypack = su.nypack; a.Bxpack = nullptr; a.Bxnorm = nullptr;
     a.ntiles = su.ntiles; a.nqtiles = su.nqtiles; a.tiles_per_split = su.tps;
-    a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul;
+    a.fold = g.fold; a.count_redo = g.count_redo; a.wmul = g.wmul; a.box_full = su.box_full; a.tile_r = nullptr;
     a.prune = 1; a.pdims = su.pdims; a.prune_margin = g.prune_margin > 0.0 ? g.prune_margin : (double)su.margin;
     a.tile_box = su.tile_box; a.qtile_box = su.qtile_box; a.qtile_thr = su.qtile_thr; a.qlb = su.qlb;
     a.nsplit_grid = su.nsplit; a.part = su.part; a.group_masks = g.group_masks;

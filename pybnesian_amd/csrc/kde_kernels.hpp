@@ -178,6 +178,7 @@ struct SweepArgs {
     // Unpruned sum-only fp64 sweeps (round 6): tile_r[t] = sqrt(max -norm) over the rows of training tile t (PackArgs::write_r) - a chunk of
     // tiles whose largest radius proves every exponent of the wave's queries inside +-1022 takes exp2_magic without its clamp; null = clamp always
     const double* tile_r;
+    int box_full;              // pruned sweeps: the boxes cover ALL whitened dimensions (pdims == the model's) - the proof behind prune_open_mask
     // Batch boxes (round 5, pruned fp64 plain sweeps): the bounding box of every 64-tile batch of a split - [split * batches_per_split + k][2 * pdims].
     // A wave classifies 64 BATCHES with one ballot (lane = batch) before it loads and tests the tile boxes of the batches in reach; null = off.
     const double* batch_box;

@@ -491,6 +491,7 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.tile_r = (m.tile_r && !m.prune && sum_only) ? (const double*)((const char*)m.nxpack + (size_t)m.ntiles * 16 * es * 2) : nullptr;
     sa.fast = sum_only ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
+    sa.box_full = (m.prune && m.pdims == m.dm) ? 1 : 0;
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, sum_only); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
     sa.group_masks = gmasks;
