@@ -991,7 +991,7 @@ def dp_issue_util():
     if k is None:
         return {"value": None, "reason": why}
     simd_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-    # round 4: the sum-only sweep takes 2^f on the fp32 transcendental unit - one v_exp_f32 per pair value, which holds the issue port
+    # rounds 4-6: the sum-only sweep takes 2^f on the fp32 transcendental unit (round 6: from the accumulator's own words, exp2_magic) - one v_exp_f32 per pair value, which holds the issue port
     # for 8 cycles (a quarter-rate instruction: two slots of 4) - so the slot count is the instruction count plus one per value
     exp32 = 1e11 / 64.0 if k["SQ_INSTS_VALU"] * 64.0 / 1e11 < 9.5 else 0.0
     return {"value": (k["SQ_VALU_MFMA_BUSY_CYCLES"] + 4.0 * (k["SQ_INSTS_VALU"] + exp32)) / simd_cycles,

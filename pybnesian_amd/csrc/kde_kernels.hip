@@ -133,6 +133,8 @@ __device__ __forceinline__ double pin_top_fract() {
 // rounding.  Used by the sweeps whose result is a SUM over the test rows (slogl, the score engine's terms: the north star's bar is
 // 1e-6 relative on slogl); per-row logl outputs keep the polynomial (SweepArgs::fast).  C2 51.5 -> 46.3 ms, cv64 3.42 -> 3.06 s,
 // bounded C3 15.7 -> 14.0 s (profiles/r4/expf32_probe.txt).  -DPBN_EXP2_F32=0 compiles it out.
+// Round 6: the plain sum-only sweeps (every shape but the fused CKDE ones) take exp2_magic below instead - the same v_exp_f32, fed from the
+// accumulator's own words; this form stays for the fused conditional sweeps and for -DPBN_EXP2_MAGIC=0.
 #ifndef PBN_EXP2_F32
 #define PBN_EXP2_F32 1
 #endif
@@ -1309,6 +1311,8 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                         open = __all(lane >= CH || TRp[tt] <= rlim);
                     }
                 }
+                // (measurement aid: chunks taken without the clamp / chunks, through pbn_debug_sweep_visits)
+                if (GUARD && a.count_redo && lane == 0) { atomicAdd(&g_sweep_tiles, 1ull); if (open) atomicAdd(&g_sweep_visit, 1ull); }
                 load_tile(tc, afA, nxA, axA);
                 if (open) {
                     for (int64_t t = tc; t < te; t += 2) {

@@ -1,5 +1,5 @@
 """GPU tier, fp64: adversarial inputs for the error budget of the SUM-ONLY sweeps (slogl, the score engine's terms).  Those sweeps take
-2^f of a term's fractional exponent on the fp32 transcendental unit (<= 1.4e-7 relative per term), prune at the margin whose dropped-mass
+2^f of a term's fractional exponent on the fp32 transcendental unit (<= 1.65e-7 relative per term), prune at the margin whose dropped-mass
 bound is 1.1e-7 of a sum and send far tiles through fp32 (<= 8e-8 of a sum): bounds that ordinary data stays orders of magnitude inside
 because the per-term errors average.  Here they are made NOT to average (kde/opencl_kernels/KDE.cl.src:115-121,227-233 is what the numbers
 are held against, through oracle/pbn_oracle.cpp):
@@ -18,7 +18,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 LOG2E = 1.4426950408889634
-BOUND_EXP, BOUND_DROP, BOUND_FAR = 1.4e-7, 1.1e-7, 8e-8
+BOUND_EXP, BOUND_DROP, BOUND_FAR = 1.65e-7, 1.1e-7, 8e-8   # (2^x: exp2_magic since round 6 - exponent grid 1e-9 + fraction to 2^-24 4.1e-8 + v_exp_f32 1.2e-7)
 
 
 def _oracle():
