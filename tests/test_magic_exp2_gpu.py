@@ -84,3 +84,31 @@ def test_exponents_at_the_clamp(monkeypatch):
     s = k.slogl(tdf)
     assert np.isfinite(s) and abs(s - want.sum()) <= 1e-8 * abs(want.sum())
     assert np.allclose(k.logl(tdf), want, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_pruned_batches_beyond_the_proof(d):
+    """Pruned sweeps (>= 32 768 training rows, d <= 3: the norm in a K slot, boxes over every dimension) drop the clamp per 64-tile batch when
+    the LARGEST distance between the batch's box and the groups' boxes proves every exponent inside +-1022.  A bandwidth of 1/200 of the
+    spread makes most of that fail - batch boxes hundreds of bandwidths wide, queries whose nearest row is dozens of bandwidths away
+    (offsets below -890: the group's gate closes) - so proven and unproven batches, the checked loop and the overflow redo all meet in one
+    sum, which must be the oracle's."""
+    from oracle import oracle
+
+    rng = np.random.default_rng(300 + d)
+    n, m, h = 40_000, 1500, 0.005
+    train = rng.normal(size=(n, d))
+    train[:64] *= 40.0                                   # a sparse halo: tiles whose boxes span thousands of bandwidths
+    test = rng.normal(size=(m, d))
+    test[:96] = rng.normal(size=(96, d)) * 6.0           # queries in empty space
+    k, names = _fit(train, h * h)
+    tdf = pd.DataFrame(test, columns=names)
+    want = oracle.kde_logl(train, np.eye(d) * h * h, test)
+    s = k.slogl(tdf)
+    assert np.isfinite(want).all() and np.isfinite(s)
+    assert abs(s - want.sum()) <= 1e-8 * abs(want.sum())
+    # the per-row path (fp64 polynomial, not this file's subject) as a second witness: Gram-form distances, eps |z|^2 on an exponent
+    z2 = (test ** 2).sum(axis=1) / (h * h)
+    tol = 1e-8 + 32.0 * 2.0 ** -52 * z2
+    rows = k.logl(tdf)
+    assert np.all(np.abs(rows - want) <= tol * np.maximum(1.0, np.abs(want))), np.max(np.abs(rows - want))
