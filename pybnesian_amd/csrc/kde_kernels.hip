@@ -1305,14 +1305,17 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
 #pragma unroll
                 for (int g = 0; g < QG; ++g) sumsave[g][threadIdx.x] = sum[g];
                 bool open = false;
+                unsigned omask = 0;   // bit i: tile tc + i is proven (a chunk with an outlier row keeps its other tiles bare)
                 if constexpr (GUARD) {
                     if (TRp) {
                         const int64_t tt = tc + lane < te ? tc + lane : te - 1;
-                        open = __all(lane >= CH || TRp[tt] <= rlim);
+                        const unsigned long long ob = __ballot(lane < CH && TRp[tt] <= rlim);
+                        omask = (unsigned)ob;
+                        open = omask == 0xffffffffu;
                     }
                 }
-                // (measurement aid: chunks taken without the clamp / chunks, through pbn_debug_sweep_visits)
-                if (GUARD && a.count_redo && lane == 0) { atomicAdd(&g_sweep_tiles, 1ull); if (open) atomicAdd(&g_sweep_visit, 1ull); }
+                // (measurement aid: tiles taken without the clamp / tiles, through pbn_debug_sweep_visits)
+                if (GUARD && a.count_redo && lane == 0) { atomicAdd(&g_sweep_tiles, (unsigned long long)(te - tc)); atomicAdd(&g_sweep_visit, (unsigned long long)__builtin_popcount(omask & (te - tc >= 32 ? ~0u : ((1u << (te - tc)) - 1u)))); }
                 load_tile(tc, afA, nxA, axA);
                 if (open) {
                     for (int64_t t = tc; t < te; t += 2) {
@@ -1325,10 +1328,15 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 } else {
                     for (int64_t t = tc; t < te; t += 2) {
                         const bool second = t + 1 < te;                   // wave-uniform
+                        const unsigned ob = omask >> (unsigned)(t - tc);
                         load_tile(second ? t + 1 : t, afB, nxB, axB);
-                        process_fast(afA, nxA, 0, std::integral_constant<int, 1>{});
+                        if (ob & 1u) process_fast(afA, nxA, 0, std::integral_constant<int, 0>{});
+                        else process_fast(afA, nxA, 0, std::integral_constant<int, 1>{});
                         load_tile(t + 2 < te ? t + 2 : t, afA, nxA, axA);
-                        if (second) process_fast(afB, nxB, 0, std::integral_constant<int, 1>{});
+                        if (second) {
+                            if (ob & 2u) process_fast(afB, nxB, 0, std::integral_constant<int, 0>{});
+                            else process_fast(afB, nxB, 0, std::integral_constant<int, 1>{});
+                        }
                     }
                 }
                 bool bad = false;
