@@ -474,53 +474,58 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
                             **moment_roofline(kt["moment"][0] * 1e-3, kt["moment"][1], mp1.value, mp2.value),
                             "note": "HIP events on the launching stream around the sweep and Gram launches only (issue lanes overlap: device "
                                     "seconds may add up to more than the wall time)"}
-    if log is not None:
-        if host is None:   # device-generated table (n_cols x n_rows): the first m rows, column by column
-            def host(m, t=t, names=names):
-                a = t[:, :m].cpu().numpy().astype(np.float64)
-                return {nm: a[i] for i, nm in enumerate(names)}, None
-        more["cpu_baseline"] = cpu_arcs_baseline(cpu_cfg, log, hc.last.cells_scored, host)
-    if which == "c4" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PBN_BENCH_NO_CPU"):
-        # the CPU side of BGe is the constructor (means + covariance of all columns, one thread in the
-        # reference); timed with the restatement on a row sample and scaled linearly
-        try:
-            from oracle import oracle
+    # The CPU side of the leg (baseline on the leg's own work list, tie accounting): host work of seconds on all cores and gigabytes of host
+    # copies.  Inside the default command it runs AFTER every leg has been timed (DEFERRED_CPU): with it between the legs the searches that
+    # followed measured 7 % (C5) to 18 % (cv_weak) more host time than the same legs without it, device seconds unchanged.
+    def cpu_part(more):
+        nonlocal host
+        if log is not None:
+            if host is None:   # device-generated table (n_cols x n_rows): the first m rows, column by column
+                def host(m, t=t, names=names):
+                    a = t[:, :m].cpu().numpy().astype(np.float64)
+                    return {nm: a[i] for i, nm in enumerate(names)}, None
+            more["cpu_baseline"] = cpu_arcs_baseline(cpu_cfg, log, hc.last.cells_scored, host)
+        if which == "c4" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("PBN_BENCH_NO_CPU"):
+            # the CPU side of BGe is the constructor (means + covariance of all columns, one thread in the
+            # reference); timed with the restatement on a row sample and scaled linearly
+            try:
+                from oracle import oracle
 
-            rows = min(n_rows, 200_000)
-            host = t[:, :rows].T.cpu().numpy()
-            cores = oracle.num_threads()
-            oracle.set_num_threads(1)
-            t0 = time.perf_counter()
-            oracle.cov(host)
-            dcpu = (time.perf_counter() - t0) * (n_rows / rows)
-            oracle.set_num_threads(cores)
-            more["cpu_baseline"] = {"value": hc.last.cells_scored / dcpu, "unit": "arcs/s", "score_ctor_s": dcpu, "kind": "port", "cores": 1,
-                                    "sample": f"covariance of {rows} x {n_cols} rows on one thread (the reference's BGe constructor, bge.hpp:52-72), "
-                                              f"scaled to {n_rows} rows; the per-candidate work is O(p^3) on the cached covariance on both sides and is "
-                                              f"left out of the CPU time (an upper bound of the CPU rate); compare with value_with_ctor"}
-        except Exception as ex:
-            more["cpu_baseline"] = {"score_ctor_s": None, "sample": f"failed: {ex}"}
-        try:
-            # tie accounting on ALL rows: the oracle's whole-table moments once (two-pass, all cores - the sums do not depend on the
-            # thread count), then the reference's BGe arithmetic per local score from them (bge.hpp:52-68 caches exactly these)
-            from oracle import oracle
+                rows = min(n_rows, 200_000)
+                host = t[:, :rows].T.cpu().numpy()
+                cores = oracle.num_threads()
+                oracle.set_num_threads(1)
+                t0 = time.perf_counter()
+                oracle.cov(host)
+                dcpu = (time.perf_counter() - t0) * (n_rows / rows)
+                oracle.set_num_threads(cores)
+                more["cpu_baseline"] = {"value": hc.last.cells_scored / dcpu, "unit": "arcs/s", "score_ctor_s": dcpu, "kind": "port", "cores": 1,
+                                        "sample": f"covariance of {rows} x {n_cols} rows on one thread (the reference's BGe constructor, bge.hpp:52-72), "
+                                                  f"scaled to {n_rows} rows; the per-candidate work is O(p^3) on the cached covariance on both sides and is "
+                                                  f"left out of the CPU time (an upper bound of the CPU rate); compare with value_with_ctor"}
+            except Exception as ex:
+                more["cpu_baseline"] = {"score_ctor_s": None, "sample": f"failed: {ex}"}
+            try:
+                # tie accounting on ALL rows: the oracle's whole-table moments once (two-pass, all cores - the sums do not depend on the
+                # thread count), then the reference's BGe arithmetic per local score from them (bge.hpp:52-68 caches exactly these)
+                from oracle import oracle
 
-            t0 = time.perf_counter()
-            full = np.asfortranarray(t.T.cpu().numpy())
-            cov_all, means_all = oracle.cov(full)
-            del full
-            t_cov = time.perf_counter() - t0
-            memo = {}
+                t0 = time.perf_counter()
+                full = np.asfortranarray(t.T.cpu().numpy())
+                cov_all, means_all = oracle.cov(full)
+                del full
+                t_cov = time.perf_counter() - t0
+                memo = {}
 
-            def sc(v, _nt, par):
-                key = (v, tuple(par))
-                if key not in memo:
-                    memo[key] = oracle.bge_cached(cov_all, means_all, n_rows, [v] + list(par), n_cols)
-                return memo[key]
+                def sc(v, _nt, par):
+                    key = (v, tuple(par))
+                    if key not in memo:
+                        memo[key] = oracle.bge_cached(cov_all, means_all, n_rows, [v] + list(par), n_cols)
+                    return memo[key]
 
-            more["tie_accounting"] = dict(tie_accounting(pbn, hc, names, sc), rows=n_rows, oracle_moments_s=t_cov)
-        except Exception as ex:
-            more["tie_accounting"] = {"error": f"{type(ex).__name__}: {ex}"}
+                more["tie_accounting"] = dict(tie_accounting(pbn, hc, names, sc), rows=n_rows, oracle_moments_s=t_cov)
+            except Exception as ex:
+                more["tie_accounting"] = {"error": f"{type(ex).__name__}: {ex}"}
     if which == "c4":
         # north star: "MFMA utilisation for the covariance batch stated against gfx950 peak".  The BGe constructor's moments are ONE
         # segmented Gram launch over the whole table (scoring.hip: compute_stats_segments -> gram_glds_kernel + the segment reduce):
@@ -551,7 +556,7 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         else:
             roof["mfma_busy"], roof["traffic"], roof["pmc_source"] = None, None, why
         more["roofline"] = roof
-    return {
+    out = {
         **more,
         "metric": "hill-climb candidate-arcs scored/s",
         "which": {"c5mmhc": "c5"}.get(which, which),
@@ -567,6 +572,14 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
         "score_ctor_s": t_ctor,
         "value_with_ctor": hc.last.cells_scored / (dt + t_ctor),
     }
+    if DEFERRED_CPU is not None:
+        DEFERRED_CPU.append(lambda: cpu_part(out))
+    else:
+        cpu_part(out)
+    return out
+
+
+DEFERRED_CPU = None   # a list while the default command collects its legs: the CPU parts of the hill-climb legs, run after the last leg
 
 
 def moment_roofline(moment_s, launches, pairs_d1, pairs_d2):
@@ -1132,6 +1145,8 @@ def main():
 
     if args.no_cpu_baseline:
         os.environ["PBN_BENCH_NO_CPU"] = "1"
+    global DEFERRED_CPU
+    DEFERRED_CPU = []   # the legs' CPU parts run after the last leg has been timed (bench_hill_climb: cpu_part)
     if args.hc != "none":
         # N > 1: the north star's scaling workload in its fixed-work form (64 nodes on every world size: strong scaling of the
         # search) with update batches inside the timed region (max_iters >= 5)
@@ -1300,6 +1315,12 @@ def main():
                 out["e2e_host"] = e2e_host(pbn, kde, names, test_t.T.cpu().numpy(), train_np=train_t.T.cpu().numpy())
             except Exception as ex:
                 out["e2e_host"] = {"value": None, "error": f"{type(ex).__name__}: {ex}"}
+        for fn in DEFERRED_CPU or []:   # every leg is timed: now the CPU sides (baselines on the legs' own work lists, tie accounting)
+            try:
+                fn()
+            except Exception as ex:      # a CPU part must never cost the line
+                print(f"bench.py: a leg's CPU part failed: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+        DEFERRED_CPU = None
         if world == 1 and not args.no_cpu_baseline:
             # the oracle against THIS run (BASELINE size): north star bar 1e-6 relative in fp64, 1e-3 in fp32
             try:
