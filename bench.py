@@ -475,8 +475,9 @@ def bench_hill_climb(torch, pbn, _lib, ctx, device, which, n_rows, max_iters, n_
                             "note": "HIP events on the launching stream around the sweep and Gram launches only (issue lanes overlap: device "
                                     "seconds may add up to more than the wall time)"}
     # The CPU side of the leg (baseline on the leg's own work list, tie accounting): host work of seconds on all cores and gigabytes of host
-    # copies.  Inside the default command it runs AFTER every leg has been timed (DEFERRED_CPU): with it between the legs the searches that
-    # followed measured 7 % (C5) to 18 % (cv_weak) more host time than the same legs without it, device seconds unchanged.
+    # copies.  Inside the default command it runs AFTER every leg has been timed (DEFERRED_CPU), so that none of it stands between two timed
+    # searches.  (Measured: the legs' host time - estimate_s minus device_s - still differs by box and process state, C5 0.9-1.4 s and
+    # cv_weak 0.05-0.2 s, with or without this deferral; the device seconds are the stable part.)
     def cpu_part(more):
         nonlocal host
         if log is not None:
