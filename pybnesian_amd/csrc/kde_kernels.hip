@@ -133,8 +133,8 @@ __device__ __forceinline__ double pin_top_fract() {
 // rounding.  Used by the sweeps whose result is a SUM over the test rows (slogl, the score engine's terms: the north star's bar is
 // 1e-6 relative on slogl); per-row logl outputs keep the polynomial (SweepArgs::fast).  C2 51.5 -> 46.3 ms, cv64 3.42 -> 3.06 s,
 // bounded C3 15.7 -> 14.0 s (profiles/r4/expf32_probe.txt).  -DPBN_EXP2_F32=0 compiles it out.
-// Round 6: the sum-only sweeps take exp2_magic below instead - the same v_exp_f32, fed from the accumulator's own words; this form stays
-// for -DPBN_EXP2_MAGIC=0 (and -DPBN_MAGIC_COND=0: the fused conditional sweeps alone).
+// Round 6: the plain sum-only sweeps (every shape but the fused CKDE ones) take exp2_magic below instead - the same v_exp_f32, fed from the
+// accumulator's own words; this form stays for the fused conditional sweeps and for -DPBN_EXP2_MAGIC=0.
 #ifndef PBN_EXP2_F32
 #define PBN_EXP2_F32 1
 #endif
@@ -190,9 +190,6 @@ __device__ __forceinline__ double exp2_f64_fract(double x, double top) {
 #endif
 #ifndef PBN_MAGIC_PRUNED
 #define PBN_MAGIC_PRUNED 1   // the pruned / grouped sum-only sweeps too (their far tiles pay one v_add_f64 per value to take the constant off)
-#endif
-#ifndef PBN_MAGIC_COND
-#define PBN_MAGIC_COND 1   // the fused conditional (CKDE) sweeps too: both exponents of a pair - marginal and joint - are accumulators of the same form
 #endif
 #ifndef PBN_MAGIC_GUARD
 #define PBN_MAGIC_GUARD 1   // unpruned sweeps: chunks whose exponents are proven inside +-1022 skip the clamp (kde_sweep_body: GUARD)
@@ -841,8 +838,8 @@ template <typename T, int KS, bool COND, int QG, bool FOLD, bool PRUNE, bool WMU
 __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigned bid) {
     static_assert(!WMUL || (!FOLD && !COND), "WMUL: plain sweeps without a free K slot only");
     using V = typename Tr<T>::vec4;
-    // MAGIC: the accumulators of this sweep carry Tr<T>::magic() and 2^x is exp2_magic - the sum-only fp64 sweeps (round 6)
-    constexpr bool MAGIC = PBN_EXP2_MAGIC && EF32 && PBN_EXP2_F32 && PBN_EXP2_DEGREE <= 7 && sizeof(T) == 8 && (!COND || PBN_MAGIC_COND) && (!PRUNE || PBN_MAGIC_PRUNED);
+    // MAGIC: the accumulators of this sweep carry Tr<T>::magic() and 2^x is exp2_magic - unpruned sum-only fp64 sweeps (round 6)
+    constexpr bool MAGIC = PBN_EXP2_MAGIC && EF32 && PBN_EXP2_F32 && PBN_EXP2_DEGREE <= 7 && sizeof(T) == 8 && !COND && (!PRUNE || PBN_MAGIC_PRUNED);
     // the per-query constant of the accumulators: norm (+ the magic constant, rounded to ITS grid once per query: what follows - the
     // integer offset, the bias - is exact), and 2^x of an accumulator
     auto cbase = [](T nyq) -> T { return MAGIC ? (T)(nyq + Tr<T>::magic()) : nyq; };
@@ -1055,7 +1052,7 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 e0 = ex2a(acc[0], ctop); e1 = ex2a(acc[1], ctop); e2 = ex2a(acc[2], ctop); e3 = ex2a(acc[3], ctop);
                 ts = (e0 + e1) + (e2 + e3);
                 if (COND) {
-                    T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)) - (MAGIC ? Tr<T>::magic() : (T)0) - Tr<T>::bias());
+                    T mxj = __builtin_ceil(colmax<T>(max4<T>(accj)) - Tr<T>::bias());
                     if (mxj > (T)0) {
                         mj[g] += mxj;
                         sumj[g] *= exp2(-(double)mxj);
