@@ -163,3 +163,24 @@ def test_fp64_sum_only_sweeps_take_the_magic_form(kde_asm):
             check(b, 4, "v_med3_i32" in b)
         seen += 1
     assert seen == 4
+
+
+def test_pruned_sum_only_sweeps_keep_their_masks_scalar(kde_asm):
+    """kde_sweep_group_kernel<double, KS = 1, QG = 2, norm in a K slot> (cv64's and C3's workhorse) and its stand-alone twin: the blind loop of
+    proven batches takes exp2_magic without the clamp, the checked loop with it - and the 64-bit visit masks of the walk stay in SCALAR
+    registers.  Round 6 measured what happens otherwise: a per-group gate kept as wave state across the walk pushed the masks into vector
+    registers, every (tile, group) test became v_and_b32 / v_cmp_ne_u64 / s_and_saveexec, scratch went from 12 to 144 bytes and the kernel lost
+    25 % - with every test green."""
+    seen = 0
+    for pat in (r"kde_sweep_group_kernelIdLi1ELi2ELb1ELb0ELb0EE", r"kde_sweep_kernelIdLi1ELb0ELi2ELb1ELb1ELb0ELb1EE"):
+        (name, body), = kernels(kde_asm, pat)
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        tails = [b for b in blocks if "v_exp_f32" in b and "v_alignbit_b32" in b]
+        assert len(tails) >= 8, (name, len(tails))
+        bare = [b for b in tails if "v_med3_i32" not in b]
+        clamped = [b for b in tails if "v_med3_i32" in b]
+        assert len(bare) >= 4 and len(clamped) >= 4, (name, len(bare), len(clamped))
+        for b in tails:
+            assert "v_cmp_ne_u64" not in b and "scratch_" not in b, name          # masks tested with s_and_b64 / s_cmp / s_bitcmp, nothing spilled here
+        seen += 1
+    assert seen == 2
