@@ -112,3 +112,22 @@ def test_pruned_batches_beyond_the_proof(d):
     tol = 1e-8 + 32.0 * 2.0 ** -52 * z2
     rows = k.logl(tdf)
     assert np.all(np.abs(rows - want) <= tol * np.maximum(1.0, np.abs(want))), np.max(np.abs(rows - want))
+
+
+@pytest.mark.parametrize("n", [6000, 40_000])            # unpruned (tile-radius guard) and pruned (batch-box guard)
+def test_null_rows_of_the_test_table(n):
+    """The reference's slogl is the sum over the rows WITHOUT nulls (kde/KDE.hpp:451-478, 592-640: the test frame is filtered before the
+    kernel), its logl carries NaN at the null rows: the mirror must do both whichever 2^x its sweeps take - the per-row path marks exactly
+    that row, the sum-only path (exp2_magic) gives the sum of the others."""
+    rng = np.random.default_rng(n)
+    d = 2
+    train = rng.normal(size=(n, d))
+    test = rng.normal(size=(300, d))
+    test[137, 1] = np.nan
+    k, names = _fit(train, 0.04)
+    tdf = pd.DataFrame(test, columns=names)
+    rows = k.logl(tdf)
+    assert np.isnan(rows[137]) and np.isfinite(np.delete(rows, 137)).all()
+    s, clean = k.slogl(tdf), k.slogl(tdf.drop(index=137))
+    assert np.isfinite(s) and abs(s - clean) <= 1e-10 * abs(clean)
+    assert abs(s - np.delete(rows, 137).sum()) <= 1e-8 * abs(s)
