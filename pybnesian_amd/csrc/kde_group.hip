@@ -748,6 +748,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
     std::memcpy(h.data() + o_pools, pools.data(), (size_t)np * sizeof(GPool));
     std::memcpy(h.data() + o_units, units.data(), (size_t)nu * sizeof(GUnit));
     GSweepUnit* hs = (GSweepUnit*)(h.data() + o_sweep);
+    const bool guard = knob_int("PBN_MAGIC_GUARD", 1) != 0;   // 0: exp2_magic keeps its clamp everywhere (kde_model.hip)
     for (int u = 0; u < nu; ++u) {
         const GUnit& U = units[u];
         GSweepUnit& s = hs[u];
@@ -760,7 +761,7 @@ void run_chunk(pbn_ctx* ctx, const pbn_table* t, GroupBatch& b, const std::vecto
         s.tile_mom = moments ? (const double*)(arena + U.mom) : nullptr;
         s.zq = (const double*)(arena + U.zq);
         s.part_mom = moments ? (double*)(arena + U.part) + (size_t)U.nsplit * U.nqtiles * 16 * 2 : nullptr;
-        s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd; s.box_full = pools[U.pool].kd == pools[U.pool].d ? 1 : 0;
+        s.ntiles = U.ntiles; s.nqtiles = U.nqtiles; s.tps = U.tps; s.nsplit = U.nsplit; s.nwg = U.nwg; s.pdims = pools[U.pool].kd; s.box_full = (guard && pools[U.pool].kd == pools[U.pool].d) ? 1 : 0;
         s.margin = (float)prune_margin(fdt, U.N, /*the engine's terms are sums*/ true); s.mom_stride = (U.ntiles + 63) / 64 * 64;
     }
     int32_t* hb = (int32_t*)(h.data() + o_blkpool);

@@ -1188,20 +1188,21 @@ __device__ __forceinline__ void kde_sweep_body(const SweepArgs& a, const unsigne
                 double saved[QG];
 #pragma unroll
                 for (int g = 0; g < QG; ++g) saved[g] = sum[g];
-                // GUARDP kernels hold ONE blind loop, the bare one: a batch that is not proven goes through the checked loop (2-3 % of the
-                // batches on the bench tables - wide batch boxes, the last tile and the last query tile of a unit, query groups whose offsets
-                // lie beyond -890 - and the same values either way; a third loop, blind WITH the clamp, measured no faster)
-                if constexpr (GUARDP) { if (bare) run_batch(tb, mask, std::integral_constant<int, 2>{}); }
+                // a proven batch runs the blind loop without the clamp, any other (2-3 % on the bench tables: wide batch boxes, the last tile and
+                // the last query tile of a unit, query groups whose offsets lie beyond -890) the SAME loop with it: the same instructions but one,
+                // the same order of additions, the far tiles' fp32 tail in both - a batch's sum does not depend on whether it was proven
+                // (PBN_MAGIC_GUARD=0 takes every batch through the second: bit-identical scores, tests/test_magic_exp2_gpu.py)
+                if (GUARDP && bare) run_batch(tb, mask, std::integral_constant<int, 2>{});
                 else run_batch(tb, mask, std::integral_constant<int, 1>{});
                 if constexpr (FARP) {
 #pragma unroll
                     for (int g = 0; g < QG; ++g) { sum[g] += (double)fs[g]; fs[g] = 0.f; }   // (an overflowed fp32 tail arrives as inf: the batch is redone)
                 }
-                bool bad = GUARDP && !bare;
+                bool bad = false;
 #pragma unroll
                 for (int g = 0; g < QG; ++g) bad = bad || !(sum[g] < 0x1p1000);
                 const bool redo = __any(bad);
-                if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo && !(GUARDP && !bare)) atomicAdd(&g_sweep_redo, 1ull); }   // (overflows only)
+                if (a.count_redo && lane == 0) { atomicAdd(&g_sweep_units, 1ull); if (redo) atomicAdd(&g_sweep_redo, 1ull); }
                 if (redo) {
 #pragma unroll
                     for (int g = 0; g < QG; ++g) sum[g] = saved[g];

@@ -488,10 +488,11 @@ void kde_eval_enqueue(pbn_ctx* ctx, const KdeModel& m, const pbn_table* test, co
     sa.wmul = wmul ? 1 : 0;
     sa.w32 = (b3 && !m.cond && (m.prune ? f16x2_w32p(m.dm, m.KS) : f16x2_w32(m.dm, m.KS))) ? 1 : 0;
     sa.far_span = (sum_only && m.prune) ? (double)knob_int("PBN_FAR_SPAN", 17) : 0.0;   // sum-only pruned sweeps: fp32 tail for tiles 26+ bits below the sum bound
-    sa.tile_r = (m.tile_r && !m.prune && sum_only) ? (const double*)((const char*)m.nxpack + (size_t)m.ntiles * 16 * es * 2) : nullptr;
+    const bool guard = knob_int("PBN_MAGIC_GUARD", 1) != 0;   // 0: exp2_magic keeps its clamp everywhere (the same bits, slower: tests/test_magic_exp2_gpu.py)
+    sa.tile_r = (guard && m.tile_r && !m.prune && sum_only) ? (const double*)((const char*)m.nxpack + (size_t)m.ntiles * 16 * es * 2) : nullptr;
     sa.fast = sum_only ? 1 : 0;   // only sums leave this call: 2^f on the fp32 transcendental unit; per-row logl keeps the polynomial
     sa.count_redo = knob_int("PBN_SWEEP_COUNT_REDO", 0);
-    sa.box_full = (m.prune && m.pdims == m.dm) ? 1 : 0;
+    sa.box_full = (guard && m.prune && m.pdims == m.dm) ? 1 : 0;
     sa.prune = m.prune ? 1 : 0; sa.pdims = m.pdims; sa.prune_margin = prune_margin(fdt, m.N, sum_only); sa.tile_box = m.tile_box; sa.qtile_box = qbox; sa.qtile_thr = qthr; sa.qlb = qlb;
     sa.part = (double*)ctx->scratch_part.p;
     sa.group_masks = gmasks;

@@ -131,3 +131,45 @@ def test_null_rows_of_the_test_table(n):
     s, clean = k.slogl(tdf), k.slogl(tdf.drop(index=137))
     assert np.isfinite(s) and abs(s - clean) <= 1e-10 * abs(clean)
     assert abs(s - np.delete(rows, 137).sum()) <= 1e-8 * abs(s)
+
+
+def _cv_score(df, cols, k=3, seed=1):
+    import pybnesian_amd as pbn
+
+    s = pbn.CVLikelihood(df, k, seed)
+    return s.local_score_node_type(pbn.SemiparametricBN(list(df.columns)), pbn.CKDEType(), cols[0], cols[1:])
+
+
+def test_the_guards_change_no_bit(monkeypatch):
+    """PBN_MAGIC_GUARD=0 keeps the clamp of exp2_magic everywhere; with the guards on, chunks / batches whose exponents are proven inside
+    +-1022 run without it.  Inside that range the clamp is a no-op, so the two must agree BIT FOR BIT - unpruned sweeps (norms as weights and
+    in a K slot, ordinary and heavy-tailed tables), pruned stand-alone handles and the grouped CV-likelihood terms of one to three variables."""
+    rng = np.random.default_rng(77)
+
+    def both(fn):
+        monkeypatch.setenv("PBN_MAGIC_GUARD", "1")
+        a = fn()
+        monkeypatch.setenv("PBN_MAGIC_GUARD", "0")
+        b = fn()
+        monkeypatch.delenv("PBN_MAGIC_GUARD")
+        return a, b
+
+    for d, n in ((8, 20_000), (4, 20_000), (3, 20_000), (5, 20_000), (2, 60_000), (3, 60_000), (1, 40_000)):
+        for heavy in (False, True):
+            train = rng.standard_t(2.5, size=(n, d)) if heavy else rng.normal(size=(n, d))
+            test = pd.DataFrame(rng.normal(size=(2000, d)) * (3.0 if heavy else 1.0), columns=[f"v{i}" for i in range(d)])
+
+            def handle(train=train, test=test, d=d):
+                import pybnesian_amd as pbn
+
+                k = pbn.KDE(list(test.columns))
+                k.fit(pd.DataFrame(train, columns=list(test.columns)))
+                return k.slogl(test)
+
+            a, b = both(handle)
+            assert np.isfinite(a) and a == b, (d, n, heavy, a, b)
+    a0 = rng.normal(size=45_000)
+    df = pd.DataFrame({"a": a0, "b": np.tanh(a0) + 0.4 * rng.normal(size=45_000), "c": rng.standard_t(3, size=45_000)})
+    for cols in (["a"], ["b", "a"], ["c", "a", "b"]):
+        a, b = both(lambda cols=cols: _cv_score(df, cols))
+        assert np.isfinite(a) and a == b, (cols, a, b)
